@@ -1,0 +1,308 @@
+#!/usr/bin/env python
+"""
+TEST INFRASTRUCTURE ONLY.  Generates tests/golden/ppo_*.npz by running the
+REFERENCE'S OWN learner code (/root/reference/surreal/learner/ppo.py and the
+model files it imports) under the third-party stand-ins of oracle/ref_shims.py,
+on the seeded synthetic workloads of surreal_amd/synthetic.py with injected
+parameters.  Also cross-checks oracle/ppo_oracle.py (the restatement that
+travels to the GPU box) against the reference run, bit-for-bit.
+
+Run in the build container only (the reference tree does not exist on the GPU
+box):      python oracle/gen_golden.py
+
+For each case the .npz holds the generator arguments (so tests regenerate the
+inputs), the reference outputs (advantages, returns, raw critic values,
+per-epoch loss statistics, final statistics, final parameter checksums), and --
+for the small cases -- the final parameters themselves.
+"""
+import collections
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+from surreal_amd import synthetic  # noqa: E402
+import ppo_oracle  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def build_reference_learner(ref, params, zstate, B, N, D, A, hyper):
+    """object.__new__(PPOLearner) + the attributes PPOLearner.__init__ sets
+    (ppo.py:61-192), bypassing ZMQ / tensorplex / checkpoint construction."""
+    PPOLearner = ref.ppo.PPOLearner
+    PPOModel = ref.ppo_net.PPOModel
+    h = dict(ppo_oracle.DEFAULT_HYPER)
+    h.update(hyper)
+    L = object.__new__(PPOLearner)
+    L.gpu_option = 'cpu'
+    L.use_cuda = False
+    L.gamma, L.lam, L.n_step = h['gamma'], h['lam'], N
+    L.use_z_filter, L.use_r_filter = h['use_z_filter'], h['use_r_filter']
+    L.norm_adv = h['norm_adv']
+    L.batch_size = B
+    L.action_dim = A
+    L.ppo_mode = h['ppo_mode']
+    L.if_rnn_policy = h['if_rnn_policy']
+    L.horizon = h['horizon']
+    L.epoch_policy, L.epoch_baseline = h['epoch_policy'], h['epoch_baseline']
+    L.kl_target = h['kl_target']
+    L.reward_scale = h['reward_scale']
+    if L.ppo_mode == 'adapt':
+        L.beta, L.eta = h['beta_init'], h['kl_cutoff_coeff']
+    else:
+        L.clip_epsilon = h['clip_epsilon_init']
+    obs_spec = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=[D]))
+    hidden = [params['actor.fc1.W'].shape[0], params['actor.fc2.W'].shape[0]]
+    rnn_hidden = params['rnn.weight_hh'].shape[1] if 'rnn.weight_hh' in params else 100
+    model_config = _Cfg(actor_fc_hidden_sizes=hidden, critic_fc_hidden_sizes=hidden,
+                        cnn_feature_dim=256)
+    rnn_config = _Cfg(if_rnn_policy=L.if_rnn_policy, rnn_hidden=rnn_hidden, rnn_layer=1,
+                      horizon=L.horizon)
+
+    def make_model():
+        m = PPOModel(obs_spec=obs_spec, action_dim=A, model_config=model_config,
+                     use_cuda=False, init_log_sig=-1.0, use_z_filter=L.use_z_filter,
+                     if_pixel_input=False, rnn_config=rnn_config)
+        inject_params(m, params, zstate)
+        return m
+    L.model = make_model()
+    L.ref_target_model = make_model()
+    L.ref_target_model.update_target_params(L.model)
+    L.clip_actor_gradient = h['clip_actor_gradient']
+    L.actor_gradient_clip_value = h['actor_gradient_norm_clip']
+    L.clip_critic_gradient = h['clip_critic_gradient']
+    L.critic_gradient_clip_value = h['critic_gradient_norm_clip']
+    L.critic_optim = torch.optim.Adam(L.model.get_critic_params(), lr=h['lr_critic'],
+                                      weight_decay=h['critic_regularization'])
+    L.actor_optim = torch.optim.Adam(L.model.get_actor_params(), lr=h['lr_actor'],
+                                     weight_decay=h['actor_regularization'])
+    hs = sys.modules['torchx.nn.hyper_scheduler']
+    L.actor_lr_scheduler = hs.LinearWithMinLR(L.actor_optim, 1000, update_freq=100, min_lr=5e-5)
+    L.critic_lr_scheduler = hs.LinearWithMinLR(L.critic_optim, 1000, update_freq=100, min_lr=5e-5)
+    L.pd = ref.ppo_net.DiagGauss(A)
+    L.cells = None
+    L.kl_record = []
+    L.exp_counter = 0
+    if L.use_r_filter:
+        from surreal.model.reward_filter import RewardFilter
+        L.reward_filter = RewardFilter()
+    return L
+
+
+def _linears(functional):
+    return [l for l in functional.layers if hasattr(l, 'fc')]
+
+
+def inject_params(m, params, zstate):
+    with torch.no_grad():
+        for net, name in ((m.actor, 'actor'), (m.critic, 'critic')):
+            for i, lin in enumerate(_linears(net.model)):
+                lin.fc.weight.copy_(torch.tensor(params['%s.fc%d.W' % (name, i + 1)]))
+                lin.fc.bias.copy_(torch.tensor(params['%s.fc%d.b' % (name, i + 1)]))
+        m.actor.log_var.copy_(torch.tensor(params['actor.log_var']))
+        if m.rnn_stem is not None:
+            m.rnn_stem.weight_ih_l0.copy_(torch.tensor(params['rnn.weight_ih']))
+            m.rnn_stem.weight_hh_l0.copy_(torch.tensor(params['rnn.weight_hh']))
+            m.rnn_stem.bias_ih_l0.copy_(torch.tensor(params['rnn.bias_ih']))
+            m.rnn_stem.bias_hh_l0.copy_(torch.tensor(params['rnn.bias_hh']))
+        if m.use_z_filter and zstate is not None:
+            m.z_filter.running_sum.copy_(torch.tensor(zstate['running_sum']))
+            m.z_filter.running_sumsq.copy_(torch.tensor(zstate['running_sumsq']))
+            m.z_filter.count.copy_(torch.tensor(zstate['count']))
+
+
+def extract_params(m):
+    out = collections.OrderedDict()
+    if m.rnn_stem is not None:
+        out['rnn.weight_ih'] = m.rnn_stem.weight_ih_l0.detach().numpy().copy()
+        out['rnn.weight_hh'] = m.rnn_stem.weight_hh_l0.detach().numpy().copy()
+        out['rnn.bias_ih'] = m.rnn_stem.bias_ih_l0.detach().numpy().copy()
+        out['rnn.bias_hh'] = m.rnn_stem.bias_hh_l0.detach().numpy().copy()
+    for net, name in ((m.actor, 'actor'), (m.critic, 'critic')):
+        for i, lin in enumerate(_linears(net.model)):
+            out['%s.fc%d.W' % (name, i + 1)] = lin.fc.weight.detach().numpy().copy()
+            out['%s.fc%d.b' % (name, i + 1)] = lin.fc.bias.detach().numpy().copy()
+        if name == 'actor':
+            out['actor.log_var'] = m.actor.log_var.detach().numpy().copy()
+    return out
+
+
+def run_reference(ref, case):
+    """drive the reference's own _preprocess_batch_ppo + _optimize, recording a trace"""
+    shp = case['shape']
+    B, N, D, A = shp['B'], shp['N'], shp['D'], shp['A']
+    hyper = case['hyper']
+    rnn_hidden = case.get('rnn_hidden', 0) if hyper.get('if_rnn_policy') else 0
+    batch = synthetic.make_ppo_batch(B, N, D, A, rnn_hidden=rnn_hidden, **case['batch_args'])
+    params = synthetic.make_ppo_params(D, A, hidden=tuple(case['hidden']), rnn_hidden=rnn_hidden,
+                                       **case['param_args'])
+    zstate = synthetic.make_zfilter_state(D, **case['z_args']) if hyper.get('use_z_filter', True) else None
+    L = build_reference_learner(ref, params, zstate, B, N, D, A, hyper)
+    trace = {'policy': [], 'value': []}
+    PPOLearner = ref.ppo.PPOLearner
+
+    orig_gae = PPOLearner._gae_and_return
+
+    def gae_hook(self, *a):
+        adv, ret = orig_gae(self, *a)
+        trace['advantages'] = adv.detach().numpy().copy()
+        trace['returns'] = ret.detach().numpy().copy()
+        return adv, ret
+    L._gae_and_return = gae_hook.__get__(L)
+    for nm, key in (('_clip_update', 'policy'), ('_adapt_update', 'policy'),
+                    ('_value_update', 'value')):
+        orig = getattr(PPOLearner, nm)
+
+        def hook(self, *a, _orig=orig, _key=key):
+            st = _orig(self, *a)
+            trace[_key].append(st)       # same dict object: '_pol_kl' is patched in later
+            return st
+        setattr(L, nm, hook.__get__(L))
+
+    import copy
+    bd = ref_shims.BeneDict(copy.deepcopy(batch))   # the reference mutates its batch in place
+    bd = L._preprocess_batch_ppo(bd)
+    stats = L._optimize(bd.obs, bd.actions, bd.rewards, bd.obs_next, bd.persistent_infos,
+                        bd.onetime_infos, bd.dones)
+    # the last policy dict is also the dict the reference patches the value / final stats into
+    pol_keys = ('_surr_loss', '_clip_surr_loss', '_kl_loss_adapt', '_entropy', '_clip_epsilon',
+                '_beta', '_pol_kl', 'grad_norm_actor')
+    trace['policy'] = [{k: float(v) for k, v in d.items() if k in pol_keys}
+                       for d in trace['policy']]
+    trace['value'] = [{k: float(v) for k, v in d.items()} for d in trace['value']]
+    stats = {k: float(v) for k, v in stats.items()}
+    final = extract_params(L.model)
+    zfinal = None
+    if L.use_z_filter:
+        zfinal = {'running_sum': L.model.z_filter.running_sum.numpy().copy(),
+                  'running_sumsq': L.model.z_filter.running_sumsq.numpy().copy(),
+                  'count': L.model.z_filter.count.numpy().copy()}
+    return batch, params, zstate, trace, stats, final, zfinal, L
+
+
+def run_oracle(case, batch, params, zstate):
+    shp = case['shape']
+    hyper = dict(case['hyper'])
+    hyper['n_step'] = shp['N']
+    O = ppo_oracle.OraclePPOLearner(params, shp['A'], shp['B'], zstate=zstate, **hyper)
+    stats = O.learn(batch)
+    return O, stats
+
+
+CASES = collections.OrderedDict()
+
+
+def _case(name, shape, hidden, hyper, batch_args=None, param_args=None, z_args=None,
+          keep_params=True, rnn_hidden=0):
+    CASES[name] = dict(name=name, shape=shape, hidden=list(hidden), hyper=hyper,
+                       batch_args=batch_args or dict(seed=0),
+                       param_args=param_args or dict(seed=1),
+                       z_args=z_args or dict(seed=2), keep_params=keep_params,
+                       rnn_hidden=rnn_hidden)
+
+
+S = synthetic.PPO_CONFIGS
+_case('tiny_clip', S['tiny'], (24, 16), dict(ppo_mode='clip', kl_target=1e9))
+_case('tiny_adapt', S['tiny'], (24, 16), dict(ppo_mode='adapt'))
+_case('tiny_adapt_cutoff', S['tiny'], (24, 16),
+      dict(ppo_mode='adapt', kl_target=1e-5, lr_actor=3e-3, epoch_policy=4),
+      batch_args=dict(seed=5))
+_case('ragged_clip', S['ragged'], (40, 24), dict(ppo_mode='clip', kl_target=1e9),
+      batch_args=dict(seed=3, done_prob=0.1))
+_case('ragged_adapt_offpolicy', S['ragged'], (40, 24), dict(ppo_mode='adapt'),
+      batch_args=dict(seed=4, on_policy=False))
+_case('ragged_clip_noz_nonorm', S['ragged'], (40, 24),
+      dict(ppo_mode='clip', use_z_filter=False, norm_adv=False, kl_target=1e9),
+      batch_args=dict(seed=6, done_prob=0.05))
+_case('cfg2_clip', S['cfg2_cheetah64'], (300, 200), dict(ppo_mode='clip', kl_target=1e9),
+      keep_params=False)
+_case('cfg2_adapt', S['cfg2_cheetah64'], (300, 200), dict(ppo_mode='adapt'),
+      keep_params=False)
+_case('cfg5_clip', S['cfg5_synth1024'], (300, 200), dict(ppo_mode='clip', kl_target=1e9),
+      keep_params=False)
+_case('cfg5_adapt', S['cfg5_synth1024'], (300, 200), dict(ppo_mode='adapt', kl_target=1e9),
+      keep_params=False)
+# kl_target chosen so that the KL-cutoff penalty (ppo.py:275-276) switches on around epoch 3
+# and the 4*kl_target early exit (ppo.py:556-557) fires a couple of epochs later
+_case('cfg5_adapt_earlyexit', S['cfg5_synth1024'], (300, 200),
+      dict(ppo_mode='adapt', kl_target=2.0e-4), keep_params=False)
+_case('tiny_adapt_cutoff2', S['tiny'], (24, 16), dict(ppo_mode='adapt', kl_target=4.3e-6))
+# RNN mode (the reference's default config; cfg1 = test_ppo_gym --unit-test shape)
+_case('cfg1_rnn_adapt', S['cfg1_unit'], (300, 200),
+      dict(ppo_mode='adapt', if_rnn_policy=True, horizon=5), keep_params=False, rnn_hidden=100)
+_case('tiny_rnn_clip', S['tiny'], (24, 16),
+      dict(ppo_mode='clip', if_rnn_policy=True, horizon=4, kl_target=1e9), rnn_hidden=12)
+
+
+def checksum(params):
+    return {k: [float(np.sum(v, dtype=np.float64)), float(np.sum(v.astype(np.float64) ** 2))]
+            for k, v in params.items()}
+
+
+def main(only=None):
+    ref = ref_shims.import_reference()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.manual_seed(0)
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        case['hyper'] = dict(case['hyper'])
+        case['hyper']['n_step'] = case['shape']['N']
+        batch, params, zstate, trace, stats, final, zfinal, L = run_reference(ref, case)
+        O, ostats = run_oracle(case, batch, params, zstate)
+        # restatement == reference, bit for bit (same ATen ops, same order)
+        np.testing.assert_array_equal(O.trace['advantages'], trace['advantages'])
+        np.testing.assert_array_equal(O.trace['returns'], trace['returns'])
+        assert len(O.trace['policy']) == len(trace['policy'])
+        for a, b in zip(O.trace['policy'] + O.trace['value'], trace['policy'] + trace['value']):
+            for k in b:
+                assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), (name, k, a[k], b[k])
+        for k in stats:
+            if k == '_lr':
+                continue
+            assert ostats[k] == stats[k] or (np.isnan(stats[k]) and np.isnan(ostats[k])), \
+                (name, k, ostats[k], stats[k])
+        ofinal = O.model.numpy_params()
+        for k in final:
+            np.testing.assert_array_equal(ofinal[k], final[k], err_msg=name + ':' + k)
+        out = {
+            'case_json': np.array(json.dumps(case)),
+            'advantages': trace['advantages'], 'returns': trace['returns'],
+            # raw critic values V(b,t) before the done-mask (ppo.py:385-386); the full
+            # (B, N+1) table for small cases, the first 16 rows for the big ones
+            'values_raw': (O.trace['values_raw'] if O.trace['values_raw'].size <= 10000
+                           else O.trace['values_raw'][:16]),
+            'policy_trace_json': np.array(json.dumps(trace['policy'])),
+            'value_trace_json': np.array(json.dumps(trace['value'])),
+            'stats_json': np.array(json.dumps(stats)),
+            'final_checksum_json': np.array(json.dumps(checksum(final))),
+        }
+        if zfinal is not None:
+            for k, v in zfinal.items():
+                out['zfinal.' + k] = v
+        if case['keep_params']:
+            for k, v in final.items():
+                out['final.' + k] = v
+        path = os.path.join(GOLDEN_DIR, 'ppo_%s.npz' % name)
+        np.savez_compressed(path, **out)
+        print('%-28s epochs=%d/%d  loss0=%s  kl_last=%.3e  -> %s (%d B)' % (
+            name, len(trace['policy']), len(trace['value']),
+            {k: round(v, 6) for k, v in trace['policy'][0].items() if 'loss' in k},
+            stats['_pol_kl'], os.path.relpath(path, ROOT), os.path.getsize(path)))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:] or None)
