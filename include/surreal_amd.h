@@ -1,0 +1,263 @@
+/*
+ * surreal_amd.h -- C ABI of libsurreal_amd.so: the MI355X (gfx950) hot path of
+ * SurrealAI/surreal's Agent -> Replay -> Learner data path.
+ *
+ * The reference is 100 % Python on PyTorch ATen ops: it has NO native layer and
+ * NO FFI for this path.  The entry points below are
+ * therefore exactly the set a maintainer's ctypes binding would call from the
+ * reference's own plugin classes; each one cites the reference interface
+ * (file:line, relative to the reference tree) whose arithmetic it replaces.
+ * INTEGRATION.md shows the reference-side ctypes stubs.
+ *
+ * Conventions
+ *   - extern "C", plain device pointers + sizes, no torch / C++ types.
+ *   - every function returns 0 on success, a negative SMX_E_* argument error, or a
+ *     positive hipError_t from the launch; nothing throws.
+ *   - nothing allocates, nothing synchronises: the caller (PyTorch-ROCm on the
+ *     host side) owns every buffer, including the workspaces whose sizes the
+ *     *_ws_bytes() helpers return.  All launches go to `stream` (a hipStream_t
+ *     passed as void*), so every entry point is legal inside hipGraph capture.
+ *   - all tensors are dense row-major fp32 unless stated.
+ *   - mutable training scalars (learning rates, beta, clip epsilon, Adam step
+ *     counters, the KL early-exit flag) live in DEVICE memory (smx_ppo_ctrl) so
+ *     that a captured graph can be replayed while they change.
+ */
+#ifndef SURREAL_AMD_H
+#define SURREAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* smx_stream_t; /* hipStream_t */
+
+enum {
+    SMX_OK = 0,
+    SMX_E_NULL = -1,      /* required pointer is NULL */
+    SMX_E_SHAPE = -2,     /* non-positive / inconsistent dimension */
+    SMX_E_UNSUPPORTED = -3, /* shape outside what the kernel is built for */
+    SMX_E_WORKSPACE = -4, /* workspace too small */
+    SMX_E_ALIGN = -5      /* pointer not 16-byte aligned where required */
+};
+
+enum { SMX_ACT_NONE = 0, SMX_ACT_RELU = 1, SMX_ACT_TANH = 2 };
+enum { SMX_PPO_CLIP = 0, SMX_PPO_ADAPT = 1 };
+
+int smx_abi_version(void);
+const char* smx_error_string(int code);
+
+/* ---------------------------------------------------------------------------
+ * Three-layer MLP: Linear(D,H1)-ReLU-Linear(H1,H2)-ReLU-Linear(H2,OUT)[-Tanh]
+ * = PPO_ActorNetwork / PPO_CriticNetwork (surreal/model/model_builders/builders.py:86-175).
+ * W* are [out_features, in_features] row-major (torch.nn.Linear layout).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const float* W1; const float* b1; /* [H1,D]  [H1]  */
+    const float* W2; const float* b2; /* [H2,H1] [H2]  */
+    const float* W3; const float* b3; /* [OUT,H2] [OUT] */
+    int32_t D, H1, H2, OUT;
+} smx_mlp3_t;
+
+/* --- z-filter (surreal/model/z_filter.py:44-79) ---------------------------- */
+/* mean = sum/count ; std = clamp(sqrt(sumsq/count - mean^2), min=eps)  (z_filter.py:74-76) */
+int smx_zfilter_stats_f32(const float* running_sum, const float* running_sumsq,
+                          const float* count, int32_t D, float eps,
+                          float* mean_out, float* std_out, smx_stream_t stream);
+/* out[r,:] = clamp((x[r*ldx + :] - mean)/std, -5, 5), r < rows  (z_filter.py:77).
+ * ldx = row stride of x in floats (>= D; e.g. N*D to read step 0 of every sub-trajectory,
+ * ppo.py:537); out is dense [rows, D]. */
+int smx_zfilter_forward_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
+                            const float* mean, const float* std, float* out,
+                            smx_stream_t stream);
+/* sum += sum_rows x ; sumsq += sum_rows x*x ; count += count_rows  (z_filter.py:55-57).
+ * count_rows lets a data-parallel rank add its local column sums while the caller
+ * all-reduces them (pass 0 and add the global count once). */
+int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
+                           float* running_sum, float* running_sumsq, float* count,
+                           float count_rows, smx_stream_t stream);
+
+/* --- fused critic/actor forward over every step of every sub-trajectory ------
+ * Replaces PPOModel.forward_critic / forward_actor on the concatenated
+ * (obs, obs_next) tensor in PPOLearner._gae_and_return (surreal/learner/ppo.py:376-386,
+ * surreal/model/ppo_net.py:253-315): z-filter prologue + three GEMMs on FP32 MFMA
+ * with activations kept in registers.  Logical row r = g*(T0+T1)+t reads
+ * x_main[g, t, :] for t < T0 and x_tail[g, t-T0, :] otherwise, so the reference's
+ * torch.cat([obs, obs_next], dim=1) copy is never materialised.
+ *   x_main [G, T0, D], x_tail [G, T1, D] (T1 may be 0, x_tail NULL)
+ *   zmean/zstd [D] or NULL (no z-filter)
+ *   packed: weights repacked by smx_mlp3_pack_f32 (K-chunked, zero padded)
+ *   out [G*(T0+T1), OUT]; out_act SMX_ACT_NONE (critic) or SMX_ACT_TANH (actor mean)
+ * Supported: H1 <= 320, H2 <= 224, OUT <= 32, any D >= 1. */
+size_t smx_mlp3_packed_bytes(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_mlp3_pack_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
+                      smx_stream_t stream);
+int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_t H1, int32_t H2,
+                               int32_t OUT, const float* x_main, const float* x_tail,
+                               int64_t G, int32_t T0, int32_t T1, const float* zmean,
+                               const float* zstd, float* out, int32_t out_act,
+                               smx_stream_t stream);
+
+/* --- one dense layer on FP32 MFMA (small-batch epochs) ------------------------
+ * C[M,N] = act(A[M,K] . B[N,K]^T + bias[N]); every epoch-loop GEMM of
+ * _clip_update/_adapt_update/_value_update (ppo.py:227-353) is an instance.
+ * a_kcontig: A(m,k) = A[m*lda+k] (1) or A[k*lda+m] (0); same for B.
+ * relu_mask (optional, [M,ldc]): C *= (relu_mask > 0)  -- ReLU backward. */
+int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, const float* B,
+                   int32_t ldb, int32_t b_kcontig, const float* bias, float* C,
+                   int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
+                   const float* relu_mask, const int32_t* stop_flag, smx_stream_t stream);
+
+/* MLP forward keeping the hidden activations (needed by the backward):
+ * h1 [rows,H1], h2 [rows,H2], out [rows,OUT] = act(layer 3). */
+int smx_mlp3_forward_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1,
+                         float* h2, float* out, int32_t out_act,
+                         const int32_t* stop_flag, smx_stream_t stream);
+
+/* MLP backward from dz3 = dLoss/d(pre-activation of layer 3) [rows,OUT]:
+ *   grads  flat [H1*D + H1 + H2*H1 + H2 + OUT*H2 + OUT] in (W1,b1,W2,b2,W3,b3) order
+ *   dz2 [rows,H2], dz1 [rows,H1] scratch; sumsq_partials [smx_mlp3_backward_partials()]
+ *   receives per-tile sums of squares of the gradients (for clip_grad_norm_). */
+int32_t smx_mlp3_backward_partials(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, const float* h1,
+                          const float* h2, const float* dz3, int64_t rows, float* dz2,
+                          float* dz1, float* grads, float* sumsq_partials,
+                          const int32_t* stop_flag, smx_stream_t stream);
+
+/* --- windowed GAE / n-step returns (surreal/learner/ppo.py:387-418) ----------
+ * values [B,N+1] RAW critic outputs; the done-mask values[:,1:] *= 1-dones
+ * (ppo.py:387) is applied inside.  H = N -> non-RNN branch (E = 1);
+ * H = rnn.horizon -> RNN branch, E = N-H+1 sliding windows.
+ * gamma_pow/lam_pow [H] = torch.pow(gamma|lam, arange) as the reference builds
+ * them (ppo.py:372-374); gamma_H = gamma**H.
+ * adv [B,E] (un-normalised), ret [B,E]. */
+int smx_windowed_gae_returns_f32(const float* values, const float* rewards,
+                                 const float* dones, const float* gamma_pow,
+                                 const float* lam_pow, float gamma, float gamma_H,
+                                 int32_t B, int32_t N, int32_t H, float* adv, float* ret,
+                                 smx_stream_t stream);
+/* moments[3] = {n, mean, M2 = sum (x-mean)^2} over n values (two-pass, one workgroup) */
+int smx_moments_f32(const float* x, int64_t n, float* moments, smx_stream_t stream);
+/* Chan-merge k per-rank moment triples [k,3] into out[3] (multi-GPU advantage norm) */
+int smx_moments_merge_f32(const float* parts, int32_t k, float* out, smx_stream_t stream);
+/* x = (x - mean) / max(std_unbiased, min_std)   (ppo.py:402-405, 413-416) */
+int smx_adv_normalize_f32(float* x, int64_t n, const float* moments, float min_std,
+                          smx_stream_t stream);
+
+/* --- PPO device-resident control block ---------------------------------------
+ * Mutable scalars read by the loss / optimiser kernels (see file header). */
+typedef struct {
+    float lr_actor, lr_critic;  /* current learning rates (ppo.py:576) */
+    float beta, eta;            /* adapt mode: KL penalty, cutoff coeff (ppo.py:108-112) */
+    float clip_eps;             /* clip mode (ppo.py:115) */
+    float kl_target;            /* ppo.py:95 */
+    float actor_max_norm, critic_max_norm; /* <=0: no clipping (ppo.py:154-157) */
+    float actor_weight_decay, critic_weight_decay;
+    int32_t adam_step_actor, adam_step_critic; /* torch.optim.Adam 'step' state */
+    int32_t stop_flag;     /* set when KL(ref||curr) > 4*kl_target (ppo.py:556-557) */
+    int32_t epochs_done;   /* policy epochs actually applied this learn() */
+    int32_t reserved[2];
+} smx_ppo_ctrl_t;
+
+/* per-epoch statistics slots (floats) written by the kernels; see ppo.py:219-224,278-284 */
+enum {
+    SMX_PS_SURR = 0,     /* _surr_loss */
+    SMX_PS_LOSS = 1,     /* _clip_surr_loss | _kl_loss_adapt */
+    SMX_PS_ENTROPY = 2,  /* _entropy */
+    SMX_PS_KL = 3,       /* mean KL(ref||learn) at this forward */
+    SMX_PS_GRADNORM = 4, /* grad_norm_actor */
+    SMX_PS_LB = 5,       /* mean behave likelihood */
+    SMX_PS_ISW = 6,      /* mean L_learn/(L_behave+1e-4) */
+    SMX_PS_REFBEH = 7,   /* mean KL(ref||behave) */
+    SMX_PS_STRIDE = 8
+};
+enum { SMX_VS_LOSS = 0, SMX_VS_EXPVAR = 1, SMX_VS_GRADNORM = 2, SMX_VS_STRIDE = 4 };
+
+/* --- DiagGauss surrogate losses, forward + backward to dz3 --------------------
+ * Replaces DiagGauss.loglikelihood/likelihood/kl/entropy (ppo_net.py:29-72) and
+ * _clip_loss / _adapt_loss (ppo.py:194-285) including their autograd backward down to
+ * the pre-tanh output of the actor's last layer and to log_var.
+ *   mean [rows,A] = tanh output of the actor; log_var [A]; actions [rows, lda_act..]
+ *   behave [rows,2A] = [mean|std] (row stride ld_beh), ref [rows,2A] (stride ld_ref)
+ *   adv [rows] (row stride 1)
+ *   row_partials [nblk, SMX_LOSS_PARTIALS(A)], nblk = smx_ppo_loss_blocks(rows)
+ *   g_surr, g_kl [rows,A]: d(sum_r surr_r)/dz3 and d(sum_r KL_r)/dz3, combined by
+ *   smx_ppo_loss_finalize_f32 once the batch means are known.
+ * n_total = global number of rows over all ranks (the mean's denominator). */
+int32_t smx_ppo_loss_blocks(int64_t rows);
+int32_t smx_ppo_loss_partial_stride(int32_t A);
+int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const float* log_var,
+                            const float* actions, int32_t ld_act, const float* behave,
+                            int32_t ld_beh, const float* ref, int32_t ld_ref,
+                            const float* adv, int64_t rows, int32_t A,
+                            const smx_ppo_ctrl_t* ctrl, float* g_surr, float* g_kl,
+                            float* row_partials, smx_stream_t stream);
+/* Reduce the partials (optionally already all-reduced across ranks: pass nblk = 1 and a
+ * summed partial row), write stats[SMX_PS_*], the combined dz3 = (g_surr + c*g_kl)/n_total
+ * and the log_var gradient.  When `check_stop` is non-zero it evaluates the KL early-exit
+ * test of the PREVIOUS update (mean KL(ref||curr) > 4*kl_target, ppo.py:553-557) and raises
+ * ctrl->stop_flag.  When `will_update` is non-zero and the flag stays clear it advances
+ * ctrl->adam_step_actor and ctrl->epochs_done for the optimiser step that follows.
+ * dlogvar_sumsq (optional) receives sum(dlogvar^2), one more clip_grad_norm_ partial.
+ * No-op when ctrl->stop_flag is already set on entry. */
+int smx_ppo_loss_finalize_f32(int32_t mode, const float* row_partials, int32_t nblk,
+                              const float* g_surr, const float* g_kl, const float* log_var,
+                              int64_t rows, int64_t n_total, int32_t A, smx_ppo_ctrl_t* ctrl,
+                              int32_t check_stop, int32_t will_update, float* dz3,
+                              float* dlogvar, float* dlogvar_sumsq, float* stats,
+                              smx_stream_t stream);
+
+/* --- value loss (ppo.py:311-332): loss = mean((V-ret)^2), explained variance ---
+ * dz3[r] = 2 (V_r - ret_r) / n_total ; partials [nblk, 8] = per-block
+ * {n, mean_d, M2_d, mean_ret, M2_ret, sum d^2, 0, 0} with d = ret - V (mergeable moments).
+ * Advances ctrl->adam_step_critic when will_update != 0. */
+int32_t smx_value_loss_blocks(int64_t rows);
+int smx_value_loss_f32(const float* values, const float* returns, int64_t rows,
+                       int64_t n_total, float* dz3, float* partials, smx_ppo_ctrl_t* ctrl,
+                       int32_t will_update, smx_stream_t stream);
+/* stats[e, SMX_VS_*] for e < count from partials [count, nblk, 8] (one launch per learn) */
+int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,
+                                float* stats, int32_t stats_stride, smx_stream_t stream);
+
+/* --- clip_grad_norm_ + Adam (ppo.py:243-247,304-308,348-352; torch.optim.Adam) ----
+ * theta/grads/exp_avg/exp_avg_sq flat [n]; sumsq_partials [npart]: sums of squares of
+ * disjoint pieces of `grads` (per-tile values from smx_mlp3_backward_f32 followed by any
+ * extra entries the caller appended, e.g. log_var's; or smx_sumsq_partials_f32 of the
+ * all-reduced gradient).  which = 0 actor / 1 critic selects lr, max_norm, weight decay and
+ * the (already advanced) step counter in ctrl.  Writes the pre-clip total norm to
+ * *grad_norm_out.  No-op when ctrl->stop_flag is set and honour_stop != 0. */
+int smx_clip_adam_step_f32(float* theta, const float* grads, float* exp_avg,
+                           float* exp_avg_sq, int64_t n, const float* sumsq_partials,
+                           int32_t npart, const smx_ppo_ctrl_t* ctrl, int32_t which,
+                           int32_t honour_stop, float* grad_norm_out, smx_stream_t stream);
+/* partials[b] = sum of squares of block b's slice of x; returns via *nblk_out the count
+ * used (<= max_blocks). */
+int32_t smx_sumsq_blocks(int64_t n);
+int smx_sumsq_partials_f32(const float* x, int64_t n, float* partials, smx_stream_t stream);
+
+/* --- replay buffers (surreal/replay/fifo_replay.py:27-48, uniform_replay.py:36-47) ---
+ * Storage is struct-of-arrays in HBM: one [capacity, width] fp32 table per field.
+ * ring insert: table[(cursor + i) % capacity, :] = src[i, :] for i < n */
+int smx_ring_insert_f32(float* table, int64_t capacity, int32_t width, int64_t cursor,
+                        const float* src, int64_t n, smx_stream_t stream);
+/* gather: dst[i, :] = table[idx[i], :]  (uniform sample with injected / generated idx,
+ * FIFO pop with idx = (head + i) % capacity) */
+int smx_gather_rows_f32(const float* table, int64_t capacity, int32_t width,
+                        const int64_t* idx, int64_t n, float* dst, smx_stream_t stream);
+/* with-replacement uniform indices in [0, len) from a Philox4x32-10 stream
+ * (random.randint(0, len-1) per draw in the reference, uniform_replay.py:44-45) */
+int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
+                        uint64_t offset, smx_stream_t stream);
+
+/* --- sub-trajectory windowing (surreal/env/exp_sender_wrapper.py:209-264) -------
+ * From per-actor rollouts laid out [actors, T, width] emit the n_step windows with the
+ * given stride: dst[(a*W + w), j, :] = src[a, w*stride + j, :], W = (T-n_step)/stride+1. */
+int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, int32_t width,
+                        int32_t n_step, int32_t stride, float* dst, smx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURREAL_AMD_H */

@@ -1,0 +1,133 @@
+"""
+ctypes binding of libsurreal_amd.so (include/surreal_amd.h).  The product path has NO fallback:
+if the HIP library is missing or a symbol does not resolve, importing/using it raises.
+
+PyTorch is plumbing here: device memory (tensor.data_ptr()) and the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsurreal_amd.so')
+
+SMX_ACT_NONE, SMX_ACT_RELU, SMX_ACT_TANH = 0, 1, 2
+SMX_PPO_CLIP, SMX_PPO_ADAPT = 0, 1
+# stats slots (include/surreal_amd.h)
+PS_SURR, PS_LOSS, PS_ENTROPY, PS_KL, PS_GRADNORM, PS_LB, PS_ISW, PS_REFBEH, PS_STRIDE = range(9)
+VS_LOSS, VS_EXPVAR, VS_GRADNORM = 0, 1, 2
+VS_STRIDE = 4
+
+
+class Mlp3(Structure):
+    """smx_mlp3_t"""
+    _fields_ = [('W1', c_void_p), ('b1', c_void_p), ('W2', c_void_p), ('b2', c_void_p),
+                ('W3', c_void_p), ('b3', c_void_p),
+                ('D', c_int32), ('H1', c_int32), ('H2', c_int32), ('OUT', c_int32)]
+
+
+# smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
+CTRL_WORDS = 16
+(C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
+ C_CRITIC_MAX_NORM, C_ACTOR_WD, C_CRITIC_WD, C_STEP_ACTOR, C_STEP_CRITIC, C_STOP,
+ C_EPOCHS_DONE) = range(14)
+
+_P = c_void_p
+_SIGS = {
+    'smx_abi_version': (c_int32, []),
+    'smx_error_string': (c_char_p, [c_int32]),
+    'smx_zfilter_stats_f32': (c_int32, [_P, _P, _P, c_int32, c_float, _P, _P, _P]),
+    'smx_zfilter_forward_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    'smx_zfilter_update_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_float, _P]),
+    'smx_mlp3_packed_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_mlp3_pack_f32': (c_int32, [POINTER(Mlp3), _P, c_size_t, _P]),
+    'smx_mlp3_forward_fused_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                             c_int64, c_int32, c_int32, _P, _P, _P, c_int32, _P]),
+    'smx_linear_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, c_int32, _P, _P, c_int32,
+                                 c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    'smx_mlp3_forward_f32': (c_int32, [POINTER(Mlp3), _P, c_int64, _P, _P, _P, c_int32, _P, _P]),
+    'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_mlp3_backward_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
+                                        _P, _P]),
+    'smx_windowed_gae_returns_f32': (c_int32, [_P, _P, _P, _P, _P, c_float, c_float, c_int32,
+                                               c_int32, c_int32, _P, _P, _P]),
+    'smx_moments_f32': (c_int32, [_P, c_int64, _P, _P]),
+    'smx_moments_merge_f32': (c_int32, [_P, c_int32, _P, _P]),
+    'smx_adv_normalize_f32': (c_int32, [_P, c_int64, _P, c_float, _P]),
+    'smx_ppo_loss_blocks': (c_int32, [c_int64]),
+    'smx_ppo_loss_partial_stride': (c_int32, [c_int32]),
+    'smx_ppo_policy_loss_f32': (c_int32, [c_int32, _P, _P, _P, c_int32, _P, c_int32, _P, c_int32,
+                                          _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
+    'smx_ppo_loss_finalize_f32': (c_int32, [c_int32, _P, c_int32, _P, _P, _P, c_int64, c_int64,
+                                            c_int32, _P, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    'smx_value_loss_blocks': (c_int32, [c_int64]),
+    'smx_value_loss_f32': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P]),
+    'smx_value_loss_finalize_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P]),
+    'smx_clip_adam_step_f32': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, _P, c_int32,
+                                         c_int32, _P, _P]),
+    'smx_sumsq_blocks': (c_int32, [c_int64]),
+    'smx_sumsq_partials_f32': (c_int32, [_P, c_int64, _P, _P]),
+    'smx_ring_insert_f32': (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, _P]),
+    'smx_gather_rows_f32': (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
+    'smx_uniform_indices': (c_int32, [_P, c_int64, c_int64, c_uint64, c_uint64, _P]),
+    'smx_window_emit_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+
+
+class SmxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmxError(
+            'libsurreal_amd.so not found at %s -- build it with `python -m surreal_amd.build` '
+            '(hipcc, gfx950).  There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().smx_error_string(int(rc))
+        raise SmxError('%s failed: rc=%d (%s)' % (what, rc, msg.decode() if msg else '?'))
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    check(rc, name)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise SmxError('surreal_amd needs a ROCm GPU (gfx950): torch.cuda.is_available() is False '
+                       'and there is no CPU fallback')
+    load()

@@ -1,0 +1,464 @@
+// Fused z-filter + Linear-ReLU-Linear-ReLU-Linear[-Tanh] forward over every step of every
+// sub-trajectory: the critic pass of PPOLearner._gae_and_return (surreal/learner/ppo.py:376-386
+// -> surreal/model/ppo_net.py:284-315 -> model_builders/builders.py:159-175), and the actor
+// pass where it runs over all steps.
+//
+// CDNA4 design (not a tiled-GEMM translation):
+//   * everything is computed TRANSPOSED: h^T = W . x^T, so the MFMA "N" axis (lane & 31) is the
+//     data row and the MFMA "M" axis is the output feature.  The C/D fragment of
+//     v_mfma_f32_32x32x2_f32 then holds, per lane, one data row and 16 features -- exactly the
+//     B-operand shape of the NEXT layer's MFMA.  Activations therefore never leave registers:
+//     layer-1 accumulators (after bias+ReLU) are fed straight back as B operands of layer 2, and
+//     layer 2's into layer 3.  One wavefront owns 32 data rows end to end.
+//   * the K index inside a 32-wide chunk is permuted (step 4q+r, half kh -> k = 8q+4kh+r) so
+//     that each lane's four consecutive MFMA steps read ONE 16-byte LDS word (ds_read_b128),
+//     and so that the C-fragment register order IS the k order of the next layer.
+//   * weights stream HBM/L2 -> registers -> LDS in K-chunks of 32 (double buffered, one barrier
+//     per chunk); x is read once from HBM with full 128-byte lines, z-filtered in registers on
+//     the way into LDS.  Rows of 36 floats (144 B) make every ds_read_b128 conflict-free.
+//   * FP32 MFMA (exact fp32, no bf16/xf32): 1e-5 parity with the CPU reference is the contract.
+#include "smx_common.h"
+
+namespace {
+
+constexpr int ROWS_PER_WG = 128;  // 4 waves x 32 data rows
+constexpr int LDS_STRIDE = 36;    // floats per staged row (32 + 4 pad)
+
+struct FusedArgs {
+    const float* packed;
+    const float* x_main;
+    const float* x_tail;
+    const float* zmean;
+    const float* zstd;
+    float* out;
+    long total_rows;
+    int T0, T1, D, OUT, KC1, out_act, xvec;
+};
+
+struct PackLayout {
+    size_t w1, b1, w2, b2, w3, b3, total;  // offsets in floats
+};
+
+__host__ __device__ inline PackLayout pack_layout(int NT1, int NT2, int KC1) {
+    PackLayout L;
+    L.w1 = 0;
+    L.b1 = L.w1 + (size_t)KC1 * NT1 * 32 * 32;
+    L.w2 = L.b1 + (size_t)NT1 * 32;
+    L.b2 = L.w2 + (size_t)NT1 * NT2 * 32 * 32;
+    L.w3 = L.b2 + (size_t)NT2 * 32;
+    L.b3 = L.w3 + (size_t)NT2 * 32 * 32;
+    L.total = L.b3 + 32;
+    return L;
+}
+
+inline bool pick_variant(int H1, int H2, int* nt1, int* nt2) {
+    if (H1 <= 64 && H2 <= 64) { *nt1 = 2; *nt2 = 2; return true; }
+    if (H1 <= 320 && H2 <= 224) { *nt1 = 10; *nt2 = 7; return true; }
+    return false;
+}
+
+__device__ __forceinline__ float zf(float x, float m, float s) {
+    float v = (x - m) / s;                              // z_filter.py:77
+    if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);
+    return v;
+}
+
+__device__ __forceinline__ float relu_f(float v) { return (v < 0.f) ? 0.f : v; }
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+
+// stage NT*32 rows x 32 floats: thread -> rows (srow + 32 i), 16 B at sk8
+template <int NT>
+__device__ __forceinline__ void load_w(float4 (&wreg)[NT], const float* chunk, int srow, int sk8) {
+    const float4* src = reinterpret_cast<const float4*>(chunk);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wreg[i] = src[(srow + 32 * i) * 8 + sk8];
+}
+template <int NT>
+__device__ __forceinline__ void store_w(const float4 (&wreg)[NT], float* Wb, int srow, int sk8) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        *reinterpret_cast<float4*>(Wb + (srow + 32 * i) * LDS_STRIDE + 4 * sk8) = wreg[i];
+}
+
+template <int NT1, int NT2, bool OUT1>
+__global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
+    constexpr int WR = (NT1 > NT2 ? NT1 : NT2) * 32;  // rows of one weight staging buffer
+    extern __shared__ float lds[];
+    float* Wb0 = lds;
+    float* Wb1 = Wb0 + WR * LDS_STRIDE;
+    float* Xb0 = Wb1 + WR * LDS_STRIDE;
+    float* Xb1 = Xb0 + ROWS_PER_WG * LDS_STRIDE;
+    float* b1s = Xb1 + ROWS_PER_WG * LDS_STRIDE;
+    float* b2s = b1s + NT1 * 32;
+    float* w3s = b2s + NT2 * 32;  // OUT1: row 0 of W3 (NT2*32) ; generic: b3 (32)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, kh = lane >> 5;
+    const long row0 = (long)blockIdx.x * ROWS_PER_WG;
+    const PackLayout L = pack_layout(NT1, NT2, A.KC1);
+    const float* W1p = A.packed + L.w1;
+    const float* W2p = A.packed + L.w2;
+    const float* W3p = A.packed + L.w3;
+
+    // ---- staging geometry: thread -> (row srow + 32 i, 4 consecutive k at sk4) ----------
+    const int srow = tid >> 3, sk8 = tid & 7, sk4 = sk8 * 4;
+    const float* xp[4];
+    bool xok[4];
+    {
+        const int T = A.T0 + A.T1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long r = row0 + srow + 32 * i;
+            xok[i] = r < A.total_rows;
+            const long rr = xok[i] ? r : 0;
+            const long g = rr / T;
+            const int tt = (int)(rr - g * T);
+            xp[i] = (tt < A.T0) ? A.x_main + (g * A.T0 + tt) * (long)A.D
+                                : A.x_tail + (g * A.T1 + (tt - A.T0)) * (long)A.D;
+        }
+    }
+    for (int i = tid; i < NT1 * 32; i += 256) b1s[i] = A.packed[L.b1 + i];
+    for (int i = tid; i < NT2 * 32; i += 256) b2s[i] = A.packed[L.b2 + i];
+    if (OUT1) {
+        for (int i = tid; i < NT2 * 32; i += 256) w3s[i] = W3p[(size_t)(i >> 5) * 1024 + (i & 31)];
+    } else {
+        if (tid < 32) w3s[tid] = A.packed[L.b3 + tid];
+    }
+
+    // x staging is split in two so that the HBM latency hides under the MFMA section:
+    // load_x issues the global loads (raw values) before the compute, store_x applies the
+    // z-filter and writes LDS after it.
+    float4 xreg[4], zmreg, zsreg;
+    const bool blk_full = (row0 + ROWS_PER_WG <= A.total_rows);
+    auto load_x = [&](int c) {
+        const int k0 = 32 * c + sk4;
+        if (blk_full && A.xvec && 32 * c + 32 <= A.D) {  // block-uniform fast path
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xreg[i] = *reinterpret_cast<const float4*>(xp[i] + k0);
+            if (A.zmean) {
+                zmreg = *reinterpret_cast<const float4*>(A.zmean + k0);
+                zsreg = *reinterpret_cast<const float4*>(A.zstd + k0);
+            }
+        } else {
+            float zm[4] = {0.f, 0.f, 0.f, 0.f}, zs[4] = {1.f, 1.f, 1.f, 1.f};
+            if (A.zmean) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + e < A.D) { zm[e] = A.zmean[k0 + e]; zs[e] = A.zstd[k0 + e]; }
+            }
+            zmreg = make_float4(zm[0], zm[1], zm[2], zm[3]);
+            zsreg = make_float4(zs[0], zs[1], zs[2], zs[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (xok[i]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + e < A.D) v[e] = xp[i][k0 + e];
+                }
+                xreg[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    auto store_x = [&](float* Xb, int c) {
+        const int k0 = 32 * c + sk4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = xreg[i];
+            if (A.zmean) {
+                // padded k (>= D) and padded rows must stay exactly zero
+                v.x = (xok[i] && k0 + 0 < A.D) ? zf(v.x, zmreg.x, zsreg.x) : 0.f;
+                v.y = (xok[i] && k0 + 1 < A.D) ? zf(v.y, zmreg.y, zsreg.y) : 0.f;
+                v.z = (xok[i] && k0 + 2 < A.D) ? zf(v.z, zmreg.z, zsreg.z) : 0.f;
+                v.w = (xok[i] && k0 + 3 < A.D) ? zf(v.w, zmreg.w, zsreg.w) : 0.f;
+            }
+            *reinterpret_cast<float4*>(Xb + (srow + 32 * i) * LDS_STRIDE + sk4) = v;
+        }
+    };
+
+    // ======================= layer 1: acc1[t] = W1[tile t] . x^T ===========================
+    f32x16 acc1[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc1[t][s] = 0.f;
+
+    float4 w1reg[NT1];
+    load_w<NT1>(w1reg, W1p, srow, sk8);
+    load_x(0);
+    store_w<NT1>(w1reg, Wb0, srow, sk8);
+    store_x(Xb0, 0);
+    __syncthreads();
+
+    for (int c = 0; c < A.KC1; ++c) {
+        const float* Wc = (c & 1) ? Wb1 : Wb0;
+        const float* Xc = (c & 1) ? Xb1 : Xb0;
+        // branch-free prefetch: the last iteration re-stages its own chunk (never read again)
+        const int cn = (c + 1 < A.KC1) ? c + 1 : c;
+        load_w<NT1>(w1reg, W1p + (size_t)cn * NT1 * 1024, srow, sk8);
+        load_x(cn);
+        const float* xrow = Xc + (wv * 32 + j) * LDS_STRIDE + 4 * kh;
+        const float* wrow = Wc + j * LDS_STRIDE + 4 * kh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(xrow + 8 * q);
+            float4 a[NT1];
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+                a[t] = *reinterpret_cast<const float4*>(wrow + t * 32 * LDS_STRIDE + 8 * q);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) acc1[t] = MFMA32(a[t].x, b.x, acc1[t]);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) acc1[t] = MFMA32(a[t].y, b.y, acc1[t]);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) acc1[t] = MFMA32(a[t].z, b.z, acc1[t]);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) acc1[t] = MFMA32(a[t].w, b.w, acc1[t]);
+        }
+        store_w<NT1>(w1reg, (c & 1) ? Wb0 : Wb1, srow, sk8);
+        store_x((c & 1) ? Xb0 : Xb1, cn);
+        __syncthreads();
+    }
+
+    // bias + ReLU in the C-fragment layout: reg s of tile t holds feature 32t + 8(s>>2) + 4kh + (s&3)
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = *reinterpret_cast<const float4*>(b1s + 32 * t + 8 * g + 4 * kh);
+            acc1[t][4 * g + 0] = relu_f(acc1[t][4 * g + 0] + bb.x);
+            acc1[t][4 * g + 1] = relu_f(acc1[t][4 * g + 1] + bb.y);
+            acc1[t][4 * g + 2] = relu_f(acc1[t][4 * g + 2] + bb.z);
+            acc1[t][4 * g + 3] = relu_f(acc1[t][4 * g + 3] + bb.w);
+        }
+
+    // ======================= layer 2: acc2[u] = W2[tile u] . h1^T ==========================
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int u = 0; u < NT2; ++u)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc2[u][s] = 0.f;
+
+    float4 w2reg[NT2];
+    load_w<NT2>(w2reg, W2p, srow, sk8);
+    store_w<NT2>(w2reg, Wb0, srow, sk8);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+        const float* Wc = (t & 1) ? Wb1 : Wb0;
+        load_w<NT2>(w2reg, W2p + (size_t)((t + 1 < NT1) ? t + 1 : t) * NT2 * 1024, srow, sk8);
+        const float* wrow = Wc + j * LDS_STRIDE + 4 * kh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a[NT2];
+#pragma unroll
+            for (int u = 0; u < NT2; ++u)
+                a[u] = *reinterpret_cast<const float4*>(wrow + u * 32 * LDS_STRIDE + 8 * q);
+#pragma unroll
+            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].x, acc1[t][4 * q + 0], acc2[u]);
+#pragma unroll
+            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].y, acc1[t][4 * q + 1], acc2[u]);
+#pragma unroll
+            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].z, acc1[t][4 * q + 2], acc2[u]);
+#pragma unroll
+            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].w, acc1[t][4 * q + 3], acc2[u]);
+        }
+        store_w<NT2>(w2reg, (t & 1) ? Wb0 : Wb1, srow, sk8);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < NT2; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * u + 8 * g + 4 * kh);
+            acc2[u][4 * g + 0] = relu_f(acc2[u][4 * g + 0] + bb.x);
+            acc2[u][4 * g + 1] = relu_f(acc2[u][4 * g + 1] + bb.y);
+            acc2[u][4 * g + 2] = relu_f(acc2[u][4 * g + 2] + bb.z);
+            acc2[u][4 * g + 3] = relu_f(acc2[u][4 * g + 3] + bb.w);
+        }
+
+    // ======================= layer 3 ========================================================
+    const long myrow = row0 + wv * 32 + j;
+    if (OUT1) {
+        // one output: a 2*NT2*16-term dot product per lane pair, on the VALU
+        float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < NT2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 ww = *reinterpret_cast<const float4*>(w3s + 32 * u + 8 * g + 4 * kh);
+                v = fmaf(acc2[u][4 * g + 0], ww.x, v);
+                v = fmaf(acc2[u][4 * g + 1], ww.y, v);
+                v = fmaf(acc2[u][4 * g + 2], ww.z, v);
+                v = fmaf(acc2[u][4 * g + 3], ww.w, v);
+            }
+        v += __shfl_xor(v, 32, 64);
+        v += A.packed[L.b3];
+        if (A.out_act == SMX_ACT_TANH) v = tanhf(v);
+        if (kh == 0 && myrow < A.total_rows) A.out[myrow] = v;
+    } else {
+        // OUT <= 32 outputs: one more MFMA tile; all of W3 (NT2 chunks) fits one staging buffer
+        f32x16 acc3;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc3[s] = 0.f;
+        {
+            const float4* src = reinterpret_cast<const float4*>(W3p);
+#pragma unroll
+            for (int u = 0; u < NT2; ++u) {
+                const float4 t4 = src[(u * 32 + srow) * 8 + sk8];
+                *reinterpret_cast<float4*>(Wb0 + (u * 32 + srow) * LDS_STRIDE + sk4) = t4;
+            }
+        }
+        __syncthreads();
+        const float* wrow = Wb0 + j * LDS_STRIDE + 4 * kh;
+#pragma unroll
+        for (int u = 0; u < NT2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(wrow + u * 32 * LDS_STRIDE + 8 * q);
+                acc3 = MFMA32(a.x, acc2[u][4 * q + 0], acc3);
+                acc3 = MFMA32(a.y, acc2[u][4 * q + 1], acc3);
+                acc3 = MFMA32(a.z, acc2[u][4 * q + 2], acc3);
+                acc3 = MFMA32(a.w, acc2[u][4 * q + 3], acc3);
+            }
+        if (myrow < A.total_rows) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int o = 8 * (s >> 2) + 4 * kh + (s & 3);
+                if (o < A.OUT) {
+                    float v = acc3[s] + w3s[o];
+                    if (A.out_act == SMX_ACT_TANH) v = tanhf(v);
+                    else if (A.out_act == SMX_ACT_RELU) v = relu_f(v);
+                    A.out[myrow * A.OUT + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight repacking: [KC][NT*32][32] K-chunked, zero padded
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp3_pack_kernel(smx_mlp3_t net, float* __restrict__ packed,
+                                                        int NT1, int NT2, int KC1) {
+    const PackLayout L = pack_layout(NT1, NT2, KC1);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < L.total; i += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        if (i < L.b1) {
+            const size_t e = i - L.w1;
+            const int kk = (int)(e & 31);
+            const size_t rc = e >> 5;
+            const int f = (int)(rc % (size_t)(NT1 * 32)), c = (int)(rc / (size_t)(NT1 * 32));
+            const int k = 32 * c + kk;
+            if (f < net.H1 && k < net.D) v = net.W1[(size_t)f * net.D + k];
+        } else if (i < L.w2) {
+            const int f = (int)(i - L.b1);
+            if (f < net.H1) v = net.b1[f];
+        } else if (i < L.b2) {
+            const size_t e = i - L.w2;
+            const int kk = (int)(e & 31);
+            const size_t rc = e >> 5;
+            const int f = (int)(rc % (size_t)(NT2 * 32)), c = (int)(rc / (size_t)(NT2 * 32));
+            const int k = 32 * c + kk;
+            if (f < net.H2 && k < net.H1) v = net.W2[(size_t)f * net.H1 + k];
+        } else if (i < L.w3) {
+            const int f = (int)(i - L.b2);
+            if (f < net.H2) v = net.b2[f];
+        } else if (i < L.b3) {
+            const size_t e = i - L.w3;
+            const int kk = (int)(e & 31);
+            const size_t rc = e >> 5;
+            const int o = (int)(rc & 31), c = (int)(rc >> 5);
+            const int k = 32 * c + kk;
+            if (o < net.OUT && k < net.H2) v = net.W3[(size_t)o * net.H2 + k];
+        } else {
+            const int o = (int)(i - L.b3);
+            if (o < net.OUT) v = net.b3[o];
+        }
+        packed[i] = v;
+    }
+}
+
+template <int NT1, int NT2>
+int launch_fused(const FusedArgs& A, hipStream_t st) {
+    constexpr int WR = (NT1 > NT2 ? NT1 : NT2) * 32;
+    const size_t lds = (size_t)(2 * WR * LDS_STRIDE + 2 * ROWS_PER_WG * LDS_STRIDE + NT1 * 32 +
+                                NT2 * 32 + NT2 * 32) * sizeof(float);
+    const unsigned grid = (unsigned)((A.total_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
+    hipError_t e;
+    if (A.OUT == 1) {
+        auto k = mlp3_fused_kernel<NT1, NT2, true>;
+        e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, A);
+    } else {
+        auto k = mlp3_fused_kernel<NT1, NT2, false>;
+        e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, A);
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? SMX_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" size_t smx_mlp3_packed_bytes(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
+    int nt1, nt2;
+    if (D <= 0 || OUT <= 0 || OUT > 32 || !pick_variant(H1, H2, &nt1, &nt2)) return 0;
+    return pack_layout(nt1, nt2, (D + 31) / 32).total * sizeof(float);
+}
+
+extern "C" int smx_mlp3_pack_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
+                                 smx_stream_t stream) {
+    SMX_REQUIRE(net && packed && net->W1 && net->b1 && net->W2 && net->b2 && net->W3 && net->b3,
+                SMX_E_NULL);
+    SMX_REQUIRE(net->D > 0 && net->H1 > 0 && net->H2 > 0 && net->OUT > 0, SMX_E_SHAPE);
+    int nt1, nt2;
+    SMX_REQUIRE(net->OUT <= 32 && pick_variant(net->H1, net->H2, &nt1, &nt2), SMX_E_UNSUPPORTED);
+    const int KC1 = (net->D + 31) / 32;
+    const PackLayout L = pack_layout(nt1, nt2, KC1);
+    SMX_REQUIRE(packed_bytes >= L.total * sizeof(float), SMX_E_WORKSPACE);
+    SMX_REQUIRE(((uintptr_t)packed & 15) == 0, SMX_E_ALIGN);
+    unsigned blocks = (unsigned)((L.total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mlp3_pack_kernel, dim3(blocks), dim3(256), 0, smx_s(stream), *net, packed, nt1,
+                       nt2, KC1);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_t H1, int32_t H2,
+                                          int32_t OUT, const float* x_main, const float* x_tail,
+                                          int64_t G, int32_t T0, int32_t T1, const float* zmean,
+                                          const float* zstd, float* out, int32_t out_act,
+                                          smx_stream_t stream) {
+    SMX_REQUIRE(packed && x_main && out, SMX_E_NULL);
+    SMX_REQUIRE(T1 == 0 || x_tail, SMX_E_NULL);
+    SMX_REQUIRE((zmean == nullptr) == (zstd == nullptr), SMX_E_NULL);
+    SMX_REQUIRE(G > 0 && T0 > 0 && T1 >= 0 && D > 0 && OUT > 0, SMX_E_SHAPE);
+    int nt1, nt2;
+    SMX_REQUIRE(OUT <= 32 && pick_variant(H1, H2, &nt1, &nt2), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(((uintptr_t)packed & 15) == 0, SMX_E_ALIGN);
+    FusedArgs A;
+    A.packed = packed;
+    A.x_main = x_main;
+    A.x_tail = x_tail ? x_tail : x_main;
+    A.zmean = zmean;
+    A.zstd = zstd;
+    A.out = out;
+    A.total_rows = (long)G * (T0 + T1);
+    A.T0 = T0;
+    A.T1 = T1;
+    A.D = D;
+    A.OUT = OUT;
+    A.KC1 = (D + 31) / 32;
+    A.out_act = out_act;
+    A.xvec = (D % 4 == 0) && (((uintptr_t)x_main & 15) == 0) &&
+             (T1 == 0 || ((uintptr_t)x_tail & 15) == 0) &&
+             (zmean == nullptr || ((((uintptr_t)zmean | (uintptr_t)zstd) & 15) == 0));
+    if (nt1 == 2) return launch_fused<2, 2>(A, smx_s(stream));
+    return launch_fused<10, 7>(A, smx_s(stream));
+}

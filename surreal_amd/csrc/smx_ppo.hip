@@ -1,0 +1,417 @@
+// DiagGauss surrogate losses (forward + analytic backward), value loss, clip_grad_norm_ + Adam.
+// Reference: surreal/model/ppo_net.py:29-72 (DiagGauss), surreal/learner/ppo.py:194-353
+// (_clip_loss/_adapt_loss/_value_loss and their *_update methods), torch.optim.Adam
+// (single-tensor path) and torch.nn.utils.clip_grad_norm_.
+//
+// The reference builds these out of ~40 ATen elementwise ops plus autograd and reads ~6 scalars
+// back to the host per epoch (.item()).  Here each loss is ONE row-parallel kernel (one lane per
+// row, wave-shuffle reductions into per-block partials) and one finalize kernel that turns the
+// batch means into the gradient scale, the statistics and the device-side KL early-exit flag,
+// so an epoch needs no host round trip and the whole learn() can be captured in a hipGraph.
+#include "smx_common.h"
+
+namespace {
+
+constexpr int LOSS_ROWS_PER_BLOCK = 64;  // one wave per block: lane == row
+constexpr int MAX_A = 32;
+
+__device__ __forceinline__ float clamp_min_nan(float x, float lo) {
+    return (x == x) ? fmaxf(x, lo) : x;  // torch.clamp(min=) keeps NaN
+}
+
+__global__ __launch_bounds__(64) void policy_loss_kernel(
+    int mode, const float* __restrict__ mean, const float* __restrict__ log_var,
+    const float* __restrict__ actions, int ld_act, const float* __restrict__ behave, int ld_beh,
+    const float* __restrict__ ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
+    const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
+    float* __restrict__ partials) {
+    if (ctrl->stop_flag) return;
+    const int lane = threadIdx.x;
+    const long r = (long)blockIdx.x * LOSS_ROWS_PER_BLOCK + lane;
+    const bool ok = r < rows;
+    const int stride = 8 + 2 * A;
+    float* P = partials + (size_t)blockIdx.x * stride;
+
+    const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
+    const float half_d = (float)(0.5 * (double)A);
+
+    float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f;       // loglikelihood sums (learn, behave)
+    float kl_a = 0.f, kl_b = 0.f, kb_a = 0.f, kb_b = 0.f;  // KL(ref||learn), KL(ref||behave)
+    if (ok) {
+        for (int a = 0; a < A; ++a) {
+            const float sig = expf(log_var[a]);             // builders.py:127
+            const float mu = mean[r * A + a];
+            const float ac = actions[r * ld_act + a];
+            const float mb = behave[r * ld_beh + a], sb = behave[r * ld_beh + A + a];
+            const float mr = ref[r * ld_ref + a], sr = ref[r * ld_ref + A + a];
+            // ppo_net.py:39-40
+            const float z = (ac - mu) / sig;
+            s1 += z * z;
+            s2 += logf(sig);
+            const float zb = (ac - mb) / sb;
+            sb1 += zb * zb;
+            sb2 += logf(sb);
+            // ppo_net.py:61-62  KL(p0 || p1): p0 = ref, p1 = learn
+            kl_a += logf(sig / sr);
+            kl_b += (sr * sr + (mr - mu) * (mr - mu)) / (2.0f * (sig * sig));
+            kb_a += logf(sb / sr);
+            kb_b += (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
+        }
+    }
+    const float ll = ((-0.5f * s1) - c_ll) - s2;
+    const float llb = ((-0.5f * sb1) - c_ll) - sb2;
+    const float el = expf(ll);
+    const float Ll = clamp_min_nan(el, 1e-5f);       // ppo_net.py:46
+    const float Lb = clamp_min_nan(expf(llb), 1e-5f);
+    const float kl = (kl_a + kl_b) - half_d;
+    const float klb = (kb_a + kb_b) - half_d;
+    const float ad = ok ? adv[r] : 0.f;
+
+    float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
+    if (mode == SMX_PPO_CLIP) {
+        const float eps = ctrl->clip_eps;
+        const float lo = (float)(1.0 - (double)eps), hi = (float)(1.0 + (double)eps);
+        const float ratio = Ll / Lb;                                    // ppo.py:212
+        float cr = ratio;
+        if (cr == cr) cr = fminf(fmaxf(cr, lo), hi);                    // ppo.py:213
+        surr = -ratio * ad;                                             // ppo.py:215
+        const float cs = -cr * ad;                                      // ppo.py:216
+        loss_r = (surr >= cs) ? surr : cs;                              // ppo.py:217
+        // max() routes the gradient to the larger entry; the clamped one has zero slope
+        // outside [lo, hi] and equals the unclamped one inside.
+        dLl = (surr >= cs) ? (-ad / Lb) : 0.f;
+    } else {
+        const float Lbc = clamp_min_nan(Lb, 1e-2f);                     // ppo.py:271
+        surr = -(ad * (Ll / Lbc));
+        loss_r = surr;
+        dLl = -ad / Lbc;
+    }
+    // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
+    const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
+
+    if (ok) {
+        for (int a = 0; a < A; ++a) {
+            const float sig = expf(log_var[a]);
+            const float mu = mean[r * A + a];
+            const float ac = actions[r * ld_act + a];
+            const float mr = ref[r * ld_ref + a];
+            const float dt = 1.0f - mu * mu;                             // tanh'
+            g_surr[r * A + a] = (dll * ((ac - mu) / (sig * sig))) * dt;
+            g_kl[r * A + a] = ((mu - mr) / (sig * sig)) * dt;
+        }
+    }
+    const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
+    const float v0 = smx_wave_sum(ok ? surr : 0.f);
+    const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
+    const float v2 = smx_wave_sum(ok ? kl : 0.f);
+    const float v3 = smx_wave_sum(ok ? Lb : 0.f);
+    const float v4 = smx_wave_sum(ok ? isw : 0.f);
+    const float v5 = smx_wave_sum(ok ? klb : 0.f);
+    if (lane == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
+    // log_var gradient partials: d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
+    for (int a = 0; a < A; ++a) {
+        float gs = 0.f, gk = 0.f;
+        if (ok) {
+            const float sig = expf(log_var[a]);
+            const float mu = mean[r * A + a];
+            const float ac = actions[r * ld_act + a];
+            const float mr = ref[r * ld_ref + a], sr = ref[r * ld_ref + A + a];
+            const float z = (ac - mu) / sig;
+            gs = dll * (z * z - 1.0f);
+            gk = 1.0f - (sr * sr + (mr - mu) * (mr - mu)) / (sig * sig);
+        }
+        gs = smx_wave_sum(gs);
+        gk = smx_wave_sum(gk);
+        if (lane == 0) { P[8 + a] = gs; P[8 + A + a] = gk; }
+    }
+}
+
+__global__ __launch_bounds__(256) void policy_finalize_kernel(
+    int mode, const float* __restrict__ partials, int nblk, const float* __restrict__ g_surr,
+    const float* __restrict__ g_kl, const float* __restrict__ log_var, long rows, long n_total,
+    int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
+    float* __restrict__ dz3, float* __restrict__ dlogvar, float* __restrict__ dlogvar_sumsq,
+    float* __restrict__ stats) {
+    if (ctrl->stop_flag) return;
+    __shared__ float S[8 + 2 * MAX_A];
+    const int stride = 8 + 2 * A;
+    for (int k = threadIdx.x; k < stride; k += 256) {
+        float t = 0.f;
+        for (int b = 0; b < nblk; ++b) t += partials[(size_t)b * stride + k];
+        S[k] = t;
+    }
+    __syncthreads();
+    const float n = (float)n_total;
+    const float surr_mean = S[0] / n;
+    const float kl_mean = S[2] / n;
+    float c_kl = 0.f, loss;
+    if (mode == SMX_PPO_CLIP) {
+        loss = S[1] / n;
+    } else {
+        const float beta = ctrl->beta, eta = ctrl->eta;
+        const double kt2 = 2.0 * (double)ctrl->kl_target;
+        loss = surr_mean + beta * kl_mean;                              // ppo.py:272
+        c_kl = beta;
+        if ((double)kl_mean - kt2 > 0.0) {                              // ppo.py:275-276
+            const float d = kl_mean - (float)kt2;
+            loss += eta * (d * d);
+            c_kl += 2.0f * eta * d;
+        }
+    }
+    const float inv_n = 1.0f / n;
+    const long total = rows * A;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        dz3[i] = (g_surr[i] + c_kl * g_kl[i]) * inv_n;
+    if (blockIdx.x == 0) {
+        for (int a = threadIdx.x; a < A; a += 256)
+            dlogvar[a] = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
+        if (threadIdx.x == 0) {
+            float ls = 0.f, dq = 0.f;
+            for (int a = 0; a < A; ++a) {
+                ls += logf(expf(log_var[a]));
+                const float g = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
+                dq += g * g;
+            }
+            if (dlogvar_sumsq) *dlogvar_sumsq = dq;
+            stats[SMX_PS_SURR] = surr_mean;
+            stats[SMX_PS_LOSS] = loss;
+            // ppo_net.py:72 (sic): 0.5 * sum(log std) + 0.5 * log(2 pi e) * d
+            stats[SMX_PS_ENTROPY] = 0.5f * ls + (float)(0.5 * 2.8378770664093453 * (double)A);
+            stats[SMX_PS_KL] = kl_mean;
+            stats[SMX_PS_LB] = S[3] / n;
+            stats[SMX_PS_ISW] = S[4] / n;
+            stats[SMX_PS_REFBEH] = S[5] / n;
+            int stop = 0;
+            if (check_stop && (double)kl_mean > 4.0 * (double)ctrl->kl_target) stop = 1;  // ppo.py:556
+            if (stop) {
+                ctrl->stop_flag = 1;
+            } else if (will_update) {
+                ctrl->adam_step_actor += 1;
+                ctrl->epochs_done += 1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// value loss: 256 rows per block; per-block mergeable moments of d = ret - V and of ret
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void value_loss_kernel(const float* __restrict__ values,
+                                                         const float* __restrict__ returns,
+                                                         long rows, long n_total,
+                                                         float* __restrict__ dz3,
+                                                         float* __restrict__ partials,
+                                                         smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                         int will_update) {
+    __shared__ float red[16];
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = r < rows;
+    const float v = ok ? values[r] : 0.f, g = ok ? returns[r] : 0.f;
+    const float d = g - v;                                   // returns - values (ppo.py:325)
+    const float e = v - g;                                   // values - returns (ppo.py:326)
+    if (ok) dz3[r] = (2.0f * e) / (float)n_total;
+    long nb = rows - (long)blockIdx.x * 256;
+    if (nb > 256) nb = 256;
+    const float cnt = (float)nb;
+    const float md = smx_block_sum(ok ? d : 0.f, red) / cnt;
+    const float mg = smx_block_sum(ok ? g : 0.f, red) / cnt;
+    const float m2d = smx_block_sum(ok ? (d - md) * (d - md) : 0.f, red);
+    const float m2g = smx_block_sum(ok ? (g - mg) * (g - mg) : 0.f, red);
+    const float sq = smx_block_sum(ok ? e * e : 0.f, red);
+    if (threadIdx.x == 0) {
+        float* P = partials + (size_t)blockIdx.x * 8;
+        P[0] = cnt; P[1] = md; P[2] = m2d; P[3] = mg; P[4] = m2g; P[5] = sq; P[6] = 0.f; P[7] = 0.f;
+        if (blockIdx.x == 0 && will_update) ctrl->adam_step_critic += 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void value_finalize_kernel(const float* __restrict__ partials,
+                                                            int count, int nblk,
+                                                            float* __restrict__ stats,
+                                                            int stats_stride) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= count) return;
+    const float* P = partials + (size_t)e * nblk * 8;
+    double n = 0.0, md = 0.0, qd = 0.0, mg = 0.0, qg = 0.0, sq = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const double nb = P[8 * b];
+        if (nb <= 0.0) continue;
+        const double nt = n + nb;
+        double dl = (double)P[8 * b + 1] - md;
+        qd += (double)P[8 * b + 2] + dl * dl * n * nb / nt;
+        md += dl * nb / nt;
+        dl = (double)P[8 * b + 3] - mg;
+        qg += (double)P[8 * b + 4] + dl * dl * n * nb / nt;
+        mg += dl * nb / nt;
+        sq += (double)P[8 * b + 5];
+        n = nt;
+    }
+    stats[(size_t)e * stats_stride + SMX_VS_LOSS] = (float)(sq / n);          // ppo.py:326
+    // 1 - var(returns - values) / var(returns), unbiased variances (ppo.py:325)
+    stats[(size_t)e * stats_stride + SMX_VS_EXPVAR] =
+        1.0f - (float)(qd / (n - 1.0)) / (float)(qg / (n - 1.0));
+}
+
+// ---------------------------------------------------------------------------
+// clip_grad_norm_ + Adam
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ theta,
+                                                        const float* __restrict__ grads,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        long n, const float* __restrict__ partials,
+                                                        int npart,
+                                                        const smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                        int which, int honour_stop,
+                                                        float* __restrict__ grad_norm_out) {
+    if (honour_stop && ctrl->stop_flag) return;
+    __shared__ float red[16];
+    float t = 0.f;
+    for (int k = threadIdx.x; k < npart; k += 256) t += partials[k];
+    const float total = smx_block_sum(t, red);
+    const float norm = sqrtf(total);
+    const float max_norm = which ? ctrl->critic_max_norm : ctrl->actor_max_norm;
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+        // clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1, always multiplied in
+        coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm_out) *grad_norm_out = norm;
+
+    const double beta1 = 0.9, beta2 = 0.999;
+    const int step = which ? ctrl->adam_step_critic : ctrl->adam_step_actor;
+    const double lr = (double)(which ? ctrl->lr_critic : ctrl->lr_actor);
+    const float wd = which ? ctrl->critic_weight_decay : ctrl->actor_weight_decay;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float neg_step_size = (float)(-(lr / bc1));
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2);
+    const float eps = 1e-8f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float g = grads[i] * coef;
+        const float p = theta[i];
+        if (wd != 0.f) g = g + wd * p;                         // grad.add(param, alpha=wd)
+        float mi = m[i], vi = v[i];
+        mi = mi + w1 * (g - mi);                               // exp_avg.lerp_(grad, 1 - beta1)
+        vi = vi * b2f + w2 * (g * g);                          // mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        theta[i] = p + (neg_step_size * mi) / denom;           // addcdiv_(exp_avg, denom, -step_size)
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n,
+                                                    float* __restrict__ partials) {
+    __shared__ float red[16];
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per;
+    long hi = lo + per;
+    if (hi > n) hi = n;
+    float s = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) s += x[i] * x[i];
+    const float t = smx_block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+}  // namespace
+
+extern "C" int32_t smx_ppo_loss_blocks(int64_t rows) {
+    return (int32_t)((rows + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK);
+}
+extern "C" int32_t smx_ppo_loss_partial_stride(int32_t A) { return 8 + 2 * A; }
+
+extern "C" int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const float* log_var,
+                                       const float* actions, int32_t ld_act, const float* behave,
+                                       int32_t ld_beh, const float* ref, int32_t ld_ref,
+                                       const float* adv, int64_t rows, int32_t A,
+                                       const smx_ppo_ctrl_t* ctrl, float* g_surr, float* g_kl,
+                                       float* row_partials, smx_stream_t stream) {
+    SMX_REQUIRE(mean && log_var && actions && behave && ref && adv && ctrl && g_surr && g_kl &&
+                    row_partials, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && A > 0 && ld_act >= A && ld_beh >= 2 * A && ld_ref >= 2 * A, SMX_E_SHAPE);
+    SMX_REQUIRE(A <= MAX_A && (mode == SMX_PPO_CLIP || mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
+    hipLaunchKernelGGL(policy_loss_kernel, dim3(smx_ppo_loss_blocks(rows)), dim3(64), 0,
+                       smx_s(stream), mode, mean, log_var, actions, ld_act, behave, ld_beh, ref,
+                       ld_ref, adv, (long)rows, A, ctrl, g_surr, g_kl, row_partials);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ppo_loss_finalize_f32(int32_t mode, const float* row_partials, int32_t nblk,
+                                         const float* g_surr, const float* g_kl,
+                                         const float* log_var, int64_t rows, int64_t n_total,
+                                         int32_t A, smx_ppo_ctrl_t* ctrl, int32_t check_stop,
+                                         int32_t will_update, float* dz3, float* dlogvar,
+                                         float* dlogvar_sumsq, float* stats,
+                                         smx_stream_t stream) {
+    SMX_REQUIRE(row_partials && g_surr && g_kl && log_var && ctrl && dz3 && dlogvar && stats,
+                SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && n_total >= rows && A > 0 && nblk > 0, SMX_E_SHAPE);
+    SMX_REQUIRE(A <= MAX_A, SMX_E_UNSUPPORTED);
+    long blocks = (rows * A + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(policy_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream),
+                       mode, row_partials, nblk, g_surr, g_kl, log_var, (long)rows, (long)n_total, A,
+                       ctrl, check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int32_t smx_value_loss_blocks(int64_t rows) { return (int32_t)((rows + 255) / 256); }
+
+extern "C" int smx_value_loss_f32(const float* values, const float* returns, int64_t rows,
+                                  int64_t n_total, float* dz3, float* partials,
+                                  smx_ppo_ctrl_t* ctrl, int32_t will_update, smx_stream_t stream) {
+    SMX_REQUIRE(values && returns && dz3 && partials && ctrl, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && n_total >= rows, SMX_E_SHAPE);
+    hipLaunchKernelGGL(value_loss_kernel, dim3(smx_value_loss_blocks(rows)), dim3(256), 0,
+                       smx_s(stream), values, returns, (long)rows, (long)n_total, dz3, partials, ctrl,
+                       will_update);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,
+                                           float* stats, int32_t stats_stride,
+                                           smx_stream_t stream) {
+    SMX_REQUIRE(partials && stats, SMX_E_NULL);
+    SMX_REQUIRE(count > 0 && nblk > 0 && stats_stride >= 2, SMX_E_SHAPE);
+    hipLaunchKernelGGL(value_finalize_kernel, dim3((count + 63) / 64), dim3(64), 0, smx_s(stream),
+                       partials, count, nblk, stats, stats_stride);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_clip_adam_step_f32(float* theta, const float* grads, float* exp_avg,
+                                      float* exp_avg_sq, int64_t n, const float* sumsq_partials,
+                                      int32_t npart, const smx_ppo_ctrl_t* ctrl, int32_t which,
+                                      int32_t honour_stop, float* grad_norm_out,
+                                      smx_stream_t stream) {
+    SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq && sumsq_partials && ctrl, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && npart > 0, SMX_E_SHAPE);
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), theta,
+                       grads, exp_avg, exp_avg_sq, (long)n, sumsq_partials, npart, ctrl, which,
+                       honour_stop, grad_norm_out);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int32_t smx_sumsq_blocks(int64_t n) {
+    long b = (n + 4095) / 4096;
+    if (b > 256) b = 256;
+    if (b < 1) b = 1;
+    return (int32_t)b;
+}
+
+extern "C" int smx_sumsq_partials_f32(const float* x, int64_t n, float* partials,
+                                      smx_stream_t stream) {
+    SMX_REQUIRE(x && partials, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(smx_sumsq_blocks(n)), dim3(256), 0, smx_s(stream), x,
+                       (long)n, partials);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}

@@ -1,0 +1,153 @@
+// Device-resident replay storage and sub-trajectory windowing (HBM-bound row copies).
+// Reference: surreal/replay/fifo_replay.py:27-48, surreal/replay/uniform_replay.py:36-47,
+// surreal/env/exp_sender_wrapper.py:209-264.  The reference keeps Python lists of experience
+// dicts and pays pyarrow (de)serialisation around every insert/sample; here each experience field
+// is one [capacity, width] fp32 table in HBM and insert/sample are coalesced row copies: one
+// wavefront moves one row with 16-byte lanes when the width allows.
+#include "smx_common.h"
+
+namespace {
+
+// copy `n` rows of `width` floats: dst row i <- src row map(i)
+template <typename SrcRow, typename DstRow>
+__device__ __forceinline__ void copy_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                          long n, int width, bool vec, SrcRow srow, DstRow drow) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long i = wave; i < n; i += nwaves) {
+        const float* s = src + srow(i) * (long)width;
+        float* d = dst + drow(i) * (long)width;
+        if (vec) {
+            const float4* s4 = reinterpret_cast<const float4*>(s);
+            float4* d4 = reinterpret_cast<float4*>(d);
+            for (int k = lane; k < (width >> 2); k += 64) d4[k] = s4[k];
+        } else {
+            for (int k = lane; k < width; k += 64) d[k] = s[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ring_insert_kernel(float* __restrict__ table, long capacity,
+                                                          int width, long cursor,
+                                                          const float* __restrict__ src, long n,
+                                                          int vec) {
+    copy_rows(src, table, n, width, vec != 0, [](long i) { return i; },
+              [=](long i) { return (cursor + i) % capacity; });
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
+                                                          long capacity, int width,
+                                                          const int64_t* __restrict__ idx, long n,
+                                                          float* __restrict__ dst, int vec) {
+    copy_rows(table, dst, n, width, vec != 0,
+              [=](long i) {
+                  long j = (long)idx[i];
+                  j = j < 0 ? 0 : (j >= capacity ? capacity - 1 : j);
+                  return j;
+              },
+              [](long i) { return i; });
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (offset + i, 0), key = seed
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void uniform_indices_kernel(int64_t* __restrict__ idx, long n,
+                                                              uint64_t len, uint64_t seed,
+                                                              uint64_t offset) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ctr = offset + (uint64_t)i;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // 64 random bits -> [0, len) by 128-bit multiply-high (bias < len / 2^64)
+    const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
+    idx[i] = (int64_t)__umul64hi(r64, len);
+}
+
+__global__ __launch_bounds__(256) void window_emit_kernel(const float* __restrict__ src, int actors,
+                                                          int T, int width, int n_step, int stride,
+                                                          int W, float* __restrict__ dst, int vec) {
+    const long n = (long)actors * W * n_step;
+    copy_rows(src, dst, n, width, vec != 0,
+              [=](long i) {
+                  const long jw = i / n_step;
+                  const int j = (int)(i - jw * n_step);
+                  const long a = jw / W;
+                  const int w = (int)(jw - a * W);
+                  return a * T + (long)w * stride + j;
+              },
+              [](long i) { return i; });
+}
+
+inline unsigned row_blocks(long n) {
+    long b = (n + 3) / 4;  // 4 waves (rows) per block
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+inline int can_vec(const void* a, const void* b, int width) {
+    return (width % 4 == 0) && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+}
+
+}  // namespace
+
+extern "C" int smx_ring_insert_f32(float* table, int64_t capacity, int32_t width, int64_t cursor,
+                                   const float* src, int64_t n, smx_stream_t stream) {
+    SMX_REQUIRE(table && src, SMX_E_NULL);
+    SMX_REQUIRE(capacity > 0 && width > 0 && cursor >= 0 && cursor < capacity && n > 0 &&
+                    n <= capacity, SMX_E_SHAPE);
+    hipLaunchKernelGGL(ring_insert_kernel, dim3(row_blocks(n)), dim3(256), 0, smx_s(stream), table,
+                       (long)capacity, width, (long)cursor, src, (long)n, can_vec(table, src, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_gather_rows_f32(const float* table, int64_t capacity, int32_t width,
+                                   const int64_t* idx, int64_t n, float* dst, smx_stream_t stream) {
+    SMX_REQUIRE(table && idx && dst, SMX_E_NULL);
+    SMX_REQUIRE(capacity > 0 && width > 0 && n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(row_blocks(n)), dim3(256), 0, smx_s(stream), table,
+                       (long)capacity, width, idx, (long)n, dst, can_vec(table, dst, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
+                                   uint64_t offset, smx_stream_t stream) {
+    SMX_REQUIRE(idx, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && len > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(uniform_indices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       smx_s(stream), idx, (long)n, (uint64_t)len, seed, offset);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, int32_t width,
+                                   int32_t n_step, int32_t stride, float* dst,
+                                   smx_stream_t stream) {
+    SMX_REQUIRE(src && dst, SMX_E_NULL);
+    SMX_REQUIRE(actors > 0 && T > 0 && width > 0 && n_step > 0 && stride > 0 && n_step <= T,
+                SMX_E_SHAPE);
+    const int W = (T - n_step) / stride + 1;
+    const long n = (long)actors * W * n_step;
+    hipLaunchKernelGGL(window_emit_kernel, dim3(row_blocks(n)), dim3(256), 0, smx_s(stream), src,
+                       actors, T, width, n_step, stride, W, dst, can_vec(src, dst, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}

@@ -1,0 +1,303 @@
+// Windowed GAE / n-step returns, batch moments, advantage normalisation, z-filter.
+// HBM-bound elementwise / reduction kernels: one wavefront per sub-trajectory row,
+// coalesced row loads, LDS-staged masked values, wave-shuffle reductions.
+// Reference: surreal/learner/ppo.py:387-418, surreal/model/z_filter.py:44-79.
+#include "smx_common.h"
+
+// ---------------------------------------------------------------------------
+// One wave per sub-trajectory b.  LDS per wave: Vm[N+1] | r[N] | delta[N]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gae_kernel(
+    const float* __restrict__ values, const float* __restrict__ rewards,
+    const float* __restrict__ dones, const float* __restrict__ gpow,
+    const float* __restrict__ lpow, float gamma, float gamma_H, int B, int N, int H,
+    float* __restrict__ adv, float* __restrict__ ret) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    const int per = 3 * N + 1;
+    float* Vm = lds + (size_t)w * per;
+    float* R = Vm + (N + 1);
+    float* Dl = R + N;
+    if (b < B) {
+        const float* v = values + (size_t)b * (N + 1);
+        const float* r = rewards + (size_t)b * N;
+        const float* d = dones + (size_t)b * N;
+        for (int t = lane; t <= N; t += 64) {
+            float x = v[t];
+            if (t >= 1) x = x * (1.0f - d[t - 1]);  // values[:, 1:] *= 1 - dones   (ppo.py:387)
+            Vm[t] = x;
+            if (t < N) R[t] = r[t];
+        }
+    }
+    __syncthreads();
+    if (b < B) {
+        for (int t = lane; t < N; t += 64) {
+            // tds = rewards + gamma * values[:, 1:] - values[:, :-1]   (ppo.py:390,410)
+            float gv = gamma * Vm[t + 1];
+            float s = R[t] + gv;
+            Dl[t] = s - Vm[t];
+        }
+    }
+    __syncthreads();
+    if (b >= B) return;
+    const int E = N - H + 1;
+    if (E == 1) {
+        // non-RNN: one return / advantage per row, a gamma-lambda weighted reduction
+        float rs = 0.f, as = 0.f;
+        for (int k = lane; k < N; k += 64) {
+            rs += gpow[k] * R[k];
+            as += (Dl[k] * gpow[k]) * lpow[k];
+        }
+        rs = smx_wave_sum(rs);
+        as = smx_wave_sum(as);
+        if (lane == 0) {
+            ret[b] = rs + Vm[N] * gamma_H;  // ppo.py:409
+            adv[b] = as;                    // ppo.py:411
+        }
+    } else {
+        // RNN branch: E sliding windows of H terms  (ppo.py:397-400)
+        for (int s = lane; s < E; s += 64) {
+            float rs = 0.f, as = 0.f;
+            for (int k = 0; k < H; ++k) {
+                rs += gpow[k] * R[s + k];
+                as += (Dl[s + k] * gpow[k]) * lpow[k];
+            }
+            ret[(size_t)b * E + s] = rs + Vm[s + H] * gamma_H;
+            adv[(size_t)b * E + s] = as;
+        }
+    }
+}
+
+extern "C" int smx_windowed_gae_returns_f32(const float* values, const float* rewards,
+                                            const float* dones, const float* gamma_pow,
+                                            const float* lam_pow, float gamma, float gamma_H,
+                                            int32_t B, int32_t N, int32_t H, float* adv,
+                                            float* ret, smx_stream_t stream) {
+    SMX_REQUIRE(values && rewards && dones && gamma_pow && lam_pow && adv && ret, SMX_E_NULL);
+    SMX_REQUIRE(B > 0 && N > 0 && H > 0 && H <= N, SMX_E_SHAPE);
+    const size_t lds = (size_t)4 * (3 * (size_t)N + 1) * sizeof(float);
+    SMX_REQUIRE(lds <= 160 * 1024, SMX_E_UNSUPPORTED);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gae_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(gae_kernel, dim3((B + 3) / 4), dim3(256), lds, smx_s(stream), values,
+                       rewards, dones, gamma_pow, lam_pow, gamma, gamma_H, B, N, H, adv, ret);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// moments: {n, mean, M2}; two passes in fp64 inside one workgroup (n is B*E <= ~1e5)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void moments_kernel(const float* __restrict__ x, long n,
+                                                       float* __restrict__ out) {
+    __shared__ double red[16];
+    __shared__ double bc;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+    s = smx_wave_sum_d(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        bc = t / (double)n;
+    }
+    __syncthreads();
+    const double mean = bc;
+    double q = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        double d = (double)x[i] - mean;
+        q += d * d;
+    }
+    q = smx_wave_sum_d(q);
+    __syncthreads();
+    if (lane == 0) red[w] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[0] = (float)n;
+        out[1] = (float)mean;
+        out[2] = (float)t;
+    }
+}
+
+extern "C" int smx_moments_f32(const float* x, int64_t n, float* moments, smx_stream_t stream) {
+    SMX_REQUIRE(x && moments, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(1024), 0, smx_s(stream), x, (long)n, moments);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+// Chan et al. pairwise merge of per-rank (n, mean, M2)
+__global__ void moments_merge_kernel(const float* __restrict__ parts, int k,
+                                     float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double nb = parts[3 * i], mb = parts[3 * i + 1], qb = parts[3 * i + 2];
+        if (nb <= 0.0) continue;
+        const double nt = n + nb, d = mb - mean;
+        m2 = m2 + qb + d * d * n * nb / nt;
+        mean = mean + d * nb / nt;
+        n = nt;
+    }
+    out[0] = (float)n;
+    out[1] = (float)mean;
+    out[2] = (float)m2;
+}
+
+extern "C" int smx_moments_merge_f32(const float* parts, int32_t k, float* out,
+                                     smx_stream_t stream) {
+    SMX_REQUIRE(parts && out, SMX_E_NULL);
+    SMX_REQUIRE(k > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(moments_merge_kernel, dim3(1), dim3(64), 0, smx_s(stream), parts, k, out);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+__global__ __launch_bounds__(256) void adv_normalize_kernel(float* __restrict__ x, long n,
+                                                            const float* __restrict__ mom,
+                                                            float min_std) {
+    const float cnt = mom[0], mean = mom[1], m2 = mom[2];
+    // advs.std(): unbiased; n == 1 gives 0/0 = NaN exactly as torch does
+    const float stdv = sqrtf(m2 / (cnt - 1.0f));
+    // Python max(std, 1e-4): returns 1e-4 only when 1e-4 > std (NaN std propagates)
+    const float den = (min_std > stdv) ? min_std : stdv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        x[i] = (x[i] - mean) / den;
+}
+
+extern "C" int smx_adv_normalize_f32(float* x, int64_t n, const float* moments, float min_std,
+                                     smx_stream_t stream) {
+    SMX_REQUIRE(x && moments, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adv_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), x,
+                       (long)n, moments, min_std);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// z-filter
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zstats_kernel(const float* __restrict__ rs,
+                                                     const float* __restrict__ rsq,
+                                                     const float* __restrict__ cnt, int D,
+                                                     float eps, float* __restrict__ mean,
+                                                     float* __restrict__ stdv) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= D) return;
+    const float c = cnt[0];
+    const float m = rs[k] / c;                // z_filter.py:74
+    const float var = rsq[k] / c - m * m;     // z_filter.py:75
+    float s = sqrtf(var);                     // .pow(0.5): NaN for var < 0, like torch
+    if (s == s) s = fmaxf(s, eps);            // torch.clamp(min=eps) propagates NaN
+    mean[k] = m;
+    stdv[k] = s;
+}
+
+extern "C" int smx_zfilter_stats_f32(const float* running_sum, const float* running_sumsq,
+                                     const float* count, int32_t D, float eps, float* mean_out,
+                                     float* std_out, smx_stream_t stream) {
+    SMX_REQUIRE(running_sum && running_sumsq && count && mean_out && std_out, SMX_E_NULL);
+    SMX_REQUIRE(D > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(zstats_kernel, dim3((D + 255) / 256), dim3(256), 0, smx_s(stream),
+                       running_sum, running_sumsq, count, D, eps, mean_out, std_out);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+static __device__ __forceinline__ float zclamp(float x, float m, float s) {
+    float v = (x - m) / s;   // z_filter.py:77
+    // torch.clamp(v, -5, 5): NaN stays NaN
+    if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void zforward_kernel(const float* __restrict__ x, long ldx,
+                                                       long total, int D,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ stdv,
+                                                       float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / D;
+        const int k = (int)(i - r * D);
+        out[i] = zclamp(x[r * ldx + k], mean[k], stdv[k]);
+    }
+}
+
+extern "C" int smx_zfilter_forward_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
+                                       const float* mean, const float* stdv, float* out,
+                                       smx_stream_t stream) {
+    SMX_REQUIRE(x && mean && stdv && out, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && D > 0 && ldx >= D, SMX_E_SHAPE);
+    const long total = (long)rows * D;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zforward_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), x,
+                       (long)ldx, total, D, mean, stdv, out);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+// Column sums of x and x*x: block = 64 columns x 4 row-lanes; rows strided by 4.
+__global__ __launch_bounds__(256) void zupdate_kernel(const float* __restrict__ x, long ldx,
+                                                      long rows, int D, float* __restrict__ rs,
+                                                      float* __restrict__ rsq,
+                                                      float* __restrict__ cnt, float count_rows) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float a = 0.f, q = 0.f;
+    if (col < D) {
+        for (long r = g; r < rows; r += 4) {
+            const float v = x[r * ldx + col];
+            a += v;
+            q += v * v;
+        }
+    }
+    s1[g][c] = a;
+    s2[g][c] = q;
+    __syncthreads();
+    if (g == 0 && col < D) {
+        const float ta = ((s1[0][c] + s1[1][c]) + s1[2][c]) + s1[3][c];
+        const float tq = ((s2[0][c] + s2[1][c]) + s2[2][c]) + s2[3][c];
+        rs[col] += ta;    // z_filter.py:55
+        rsq[col] += tq;   // z_filter.py:56
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0] += count_rows;  // z_filter.py:57
+}
+
+extern "C" int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
+                                      float* running_sum, float* running_sumsq, float* count,
+                                      float count_rows, smx_stream_t stream) {
+    SMX_REQUIRE(x && running_sum && running_sumsq && count, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && D > 0 && ldx >= D, SMX_E_SHAPE);
+    hipLaunchKernelGGL(zupdate_kernel, dim3((D + 63) / 64), dim3(256), 0, smx_s(stream), x,
+                       (long)ldx, (long)rows, D, running_sum, running_sumsq, count, count_rows);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_abi_version(void) { return 1; }
+
+extern "C" const char* smx_error_string(int code) {
+    switch (code) {
+        case SMX_OK: return "ok";
+        case SMX_E_NULL: return "required pointer is NULL";
+        case SMX_E_SHAPE: return "non-positive or inconsistent dimension";
+        case SMX_E_UNSUPPORTED: return "shape outside what the kernel is built for";
+        case SMX_E_WORKSPACE: return "workspace too small";
+        case SMX_E_ALIGN: return "pointer not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown smx error";
+    }
+}

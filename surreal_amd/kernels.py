@@ -1,0 +1,185 @@
+"""
+Tensor-level facade over the C ABI (include/surreal_amd.h): every method takes torch device
+tensors (views allowed where a leading stride is part of the C signature), passes raw
+pointers + sizes + the current HIP stream to libsurreal_amd.so, and returns nothing -- outputs
+are written into caller-owned tensors, nothing allocates, nothing synchronises.
+
+The learner / replay / agent classes talk to the GPU only through this object, which is what
+lets the multi-process (gloo, CPU) tests exercise the sharding logic with a test double.
+There is NO fallback in the product: `HipKernels()` raises when the library or a GPU is absent.
+"""
+import ctypes
+
+import torch
+
+from surreal_amd import _lib as L
+
+
+def _row_stride(view, width):
+    """leading stride (floats) of a 2-D view whose rows are `width` contiguous floats"""
+    assert view.dim() == 2 and view.shape[1] == width and (width == 1 or view.stride(1) == 1), \
+        (tuple(view.shape), view.stride())
+    return view.stride(0) if view.shape[0] > 1 else max(view.stride(0), width)
+
+
+class HipKernels(object):
+    name = 'hip'
+
+    def __init__(self):
+        L.require_gpu()
+        self.lib = L.load()
+
+    @staticmethod
+    def _st():
+        return L.current_stream()
+
+    # ---- z-filter -----------------------------------------------------------------------
+    def zfilter_stats(self, rs, rsq, cnt, eps, mean_out, std_out):
+        L.call('smx_zfilter_stats_f32', L.ptr(rs), L.ptr(rsq), L.ptr(cnt), rs.numel(), float(eps),
+               L.ptr(mean_out), L.ptr(std_out), self._st())
+
+    def zfilter_forward(self, x_view, mean, std, out):
+        rows, D = x_view.shape
+        L.call('smx_zfilter_forward_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D,
+               L.ptr(mean), L.ptr(std), L.ptr(out), self._st())
+
+    def zfilter_update(self, x_view, rs, rsq, cnt, count_rows):
+        rows, D = x_view.shape
+        L.call('smx_zfilter_update_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D, L.ptr(rs),
+               L.ptr(rsq), L.ptr(cnt), float(count_rows), self._st())
+
+    # ---- MLP ----------------------------------------------------------------------------
+    def mlp3_packed_numel(self, net):
+        nbytes = self.lib.smx_mlp3_packed_bytes(net.D, net.H1, net.H2, net.OUT)
+        if nbytes == 0:
+            raise L.SmxError('fused MLP kernel does not support D=%d H1=%d H2=%d OUT=%d'
+                             % (net.D, net.H1, net.H2, net.OUT))
+        return nbytes // 4
+
+    def mlp3_pack(self, net, packed):
+        L.call('smx_mlp3_pack_f32', ctypes.byref(net.desc), L.ptr(packed), packed.numel() * 4,
+               self._st())
+
+    def mlp3_forward_fused(self, packed, net, x_main, x_tail, zmean, zstd, out, act):
+        G, T0, D = x_main.shape
+        T1 = 0 if x_tail is None else x_tail.shape[1]
+        assert x_main.is_contiguous() and (x_tail is None or x_tail.is_contiguous())
+        L.call('smx_mlp3_forward_fused_f32', L.ptr(packed), net.D, net.H1, net.H2, net.OUT,
+               L.ptr(x_main), L.ptr(x_tail), G, T0, T1, L.ptr(zmean), L.ptr(zstd), L.ptr(out),
+               act, self._st())
+
+    def mlp3_forward(self, net, x, h1, h2, out, act, stop=None):
+        assert x.is_contiguous()
+        L.call('smx_mlp3_forward_f32', ctypes.byref(net.desc), L.ptr(x), x.shape[0], L.ptr(h1),
+               L.ptr(h2), L.ptr(out), act, L.ptr(stop), self._st())
+
+    def mlp3_backward_partials(self, net):
+        return self.lib.smx_mlp3_backward_partials(net.D, net.H1, net.H2, net.OUT)
+
+    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None):
+        L.call('smx_mlp3_backward_f32', ctypes.byref(net.desc), L.ptr(x), L.ptr(h1), L.ptr(h2),
+               L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1), L.ptr(grads), L.ptr(sumsq),
+               L.ptr(stop), self._st())
+
+    # ---- GAE / normalisation ------------------------------------------------------------
+    def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret):
+        L.call('smx_windowed_gae_returns_f32', L.ptr(values), L.ptr(rewards), L.ptr(dones),
+               L.ptr(gpow), L.ptr(lpow), float(gamma), float(gamma_H), B, N, H, L.ptr(adv),
+               L.ptr(ret), self._st())
+
+    def moments(self, x, out):
+        L.call('smx_moments_f32', L.ptr(x), x.numel(), L.ptr(out), self._st())
+
+    def moments_merge(self, parts, out):
+        L.call('smx_moments_merge_f32', L.ptr(parts), parts.numel() // 3, L.ptr(out), self._st())
+
+    def adv_normalize(self, x, mom, min_std):
+        L.call('smx_adv_normalize_f32', L.ptr(x), x.numel(), L.ptr(mom), float(min_std), self._st())
+
+    # ---- losses -------------------------------------------------------------------------
+    def loss_blocks(self, rows):
+        return self.lib.smx_ppo_loss_blocks(rows)
+
+    def policy_loss(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                    partials):
+        rows, A = mean.shape
+        L.call('smx_ppo_policy_loss_f32', mode, L.ptr(mean), L.ptr(log_var), L.ptr(actions),
+               _row_stride(actions, A), L.ptr(behave), _row_stride(behave, 2 * A), L.ptr(ref),
+               _row_stride(ref, 2 * A), L.ptr(adv), rows, A, L.ptr(ctrl), L.ptr(g_surr),
+               L.ptr(g_kl), L.ptr(partials), self._st())
+
+    def policy_finalize(self, mode, partials, nblk, g_surr, g_kl, log_var, n_total, ctrl,
+                        check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats):
+        rows, A = g_surr.shape
+        L.call('smx_ppo_loss_finalize_f32', mode, L.ptr(partials), nblk, L.ptr(g_surr),
+               L.ptr(g_kl), L.ptr(log_var), rows, n_total, A, L.ptr(ctrl), int(check_stop),
+               int(will_update), L.ptr(dz3), L.ptr(dlogvar), L.ptr(dlogvar_sumsq), L.ptr(stats),
+               self._st())
+
+    def value_loss_blocks(self, rows):
+        return self.lib.smx_value_loss_blocks(rows)
+
+    def value_loss(self, values, returns, n_total, dz3, partials, ctrl, will_update):
+        L.call('smx_value_loss_f32', L.ptr(values), L.ptr(returns), values.numel(), n_total,
+               L.ptr(dz3), L.ptr(partials), L.ptr(ctrl), int(will_update), self._st())
+
+    def value_finalize(self, partials, count, nblk, stats, stride):
+        L.call('smx_value_loss_finalize_f32', L.ptr(partials), count, nblk, L.ptr(stats), stride,
+               self._st())
+
+    # ---- optimiser ----------------------------------------------------------------------
+    def clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out):
+        L.call('smx_clip_adam_step_f32', L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v),
+               theta.numel(), L.ptr(sumsq), npart, L.ptr(ctrl), which, int(honour_stop),
+               L.ptr(grad_norm_out), self._st())
+
+    def sumsq_blocks(self, n):
+        return self.lib.smx_sumsq_blocks(n)
+
+    def sumsq_partials(self, x, partials):
+        L.call('smx_sumsq_partials_f32', L.ptr(x), x.numel(), L.ptr(partials), self._st())
+
+    # ---- replay / windowing ---------------------------------------------------------------
+    def ring_insert(self, table, cursor, src):
+        cap, width = table.shape
+        L.call('smx_ring_insert_f32', L.ptr(table), cap, width, int(cursor), L.ptr(src),
+               src.shape[0], self._st())
+
+    def gather_rows(self, table, idx, dst):
+        cap, width = table.shape
+        L.call('smx_gather_rows_f32', L.ptr(table), cap, width, L.ptr(idx), idx.numel(),
+               L.ptr(dst), self._st())
+
+    def uniform_indices(self, idx, length, seed, offset):
+        L.call('smx_uniform_indices', L.ptr(idx), idx.numel(), int(length), int(seed), int(offset),
+               self._st())
+
+    def window_emit(self, src, n_step, stride, dst):
+        actors, T, width = src.shape
+        L.call('smx_window_emit_f32', L.ptr(src), actors, T, width, n_step, stride, L.ptr(dst),
+               self._st())
+
+
+# ------------------------------------------------------------------------------------------
+# process-wide default.  The product default is HipKernels on 'cuda' and nothing in
+# surreal_amd/ ever installs anything else; tests/ install a CPU test double to exercise
+# the host logic (sharding, epoch control, stats) without a GPU.
+# ------------------------------------------------------------------------------------------
+_default = {'kernels': None, 'device': 'cuda'}
+
+
+def default_kernels():
+    if _default['kernels'] is None:
+        _default['kernels'] = HipKernels()   # raises without the .so or without a GPU
+    return _default['kernels']
+
+
+def default_device():
+    return _default['device']
+
+
+def set_default_kernels(kernels, device):
+    """test hook: returns the previous (kernels, device) so it can be restored"""
+    prev = (_default['kernels'], _default['device'])
+    _default['kernels'], _default['device'] = kernels, device
+    return prev

@@ -1,0 +1,256 @@
+"""
+Learner plugin base class: same constructor, hooks and main loop as the reference's
+``surreal.learner.base.Learner`` (surreal/learner/base.py:21-389), with the ZeroMQ /
+tensorplex process plumbing replaced by in-process hand-off:
+
+  reference                                   here
+  ------------------------------------------  ---------------------------------------------
+  LearnerDataPrefetcher (worker processes     ``attach_replay(replay)`` or
+  REQ -> replay ZmqServer, base.py:102-110)   ``set_data_source(fn)``; ``fetch_batch()`` pulls
+                                              ``batch_size`` experiences, runs
+                                              ``_prefetcher_preprocess`` then ``preprocess``
+  ParameterPublisher (ZMQ PUB -> parameter    ``add_parameter_listener(fn)``: called with
+  servers -> agents, base.py:90-100)          (module_dict(), info) on publish -- agents in the
+                                              same process share device parameters
+  tensorplex / loggerplex clients             ``self.tensorplex`` = in-memory scalar recorder,
+  (base.py:159-175)                           ``self.log`` = std logging
+
+Out of scope: sockets, shards, cluster launchers.
+"""
+import logging
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from surreal_amd.session import Config
+from surreal_amd.utils import AutoInitializeMeta, AttrDict, TimedTracker
+
+
+class ScalarRecorder(object):
+    """stands where the throttled tensorplex client stood (learner/base.py:176-190):
+    keeps the last value and a short history of every scalar group"""
+
+    def __init__(self, keep=1000):
+        self.keep = keep
+        self.history = []
+        self.latest = {}
+
+    def add_scalars(self, scalars, global_step=None):
+        self.latest.update(scalars)
+        self.history.append((global_step, dict(scalars)))
+        if len(self.history) > self.keep:
+            del self.history[:len(self.history) - self.keep]
+
+
+class Learner(metaclass=AutoInitializeMeta):
+    def __init__(self, learner_config, env_config, session_config):
+        self.learner_config = learner_config
+        self.env_config = env_config
+        self.session_config = session_config
+        self.current_iter = 0
+        self._data_source = None
+        self._parameter_listeners = []
+        self._setup_logging()
+        self._setup_checkpoint()
+
+    # ---- abstract (base.py:46-85) ---------------------------------------------------------
+    def learn(self, batch_exp):
+        raise NotImplementedError
+
+    def module_dict(self):
+        raise NotImplementedError
+
+    def checkpoint_attributes(self):
+        return []
+
+    # ---- AutoInitializeMeta hook (base.py:117-128) ----------------------------------------
+    def _initialize(self):
+        if self.session_config.checkpoint.restore:
+            self.restore_checkpoint()
+        self._setup_publish()
+
+    # ---- parameter publish (base.py:90-144) -----------------------------------------------
+    def _setup_publish(self):
+        interval = self.learner_config.parameter_publish.min_publish_interval
+        self._ps_publish_tracker = TimedTracker(interval)
+
+    def add_parameter_listener(self, fn):
+        self._parameter_listeners.append(fn)
+
+    def should_publish_parameter(self):
+        return self._ps_publish_tracker.track_increment()
+
+    def _publish(self, iteration, message=''):
+        info = {'time': time.time(), 'iteration': iteration, 'message': message}
+        for fn in self._parameter_listeners:
+            fn(self.module_dict(), info)
+
+    def publish_parameter(self, iteration, message=''):
+        self._publish(iteration, message)
+
+    # ---- data (base.py:102-115,149-154) ---------------------------------------------------
+    def set_data_source(self, fn):
+        """fn() -> list of `batch_size` experiences (what a replay's sample() returns)"""
+        self._data_source = fn
+
+    def attach_replay(self, replay):
+        bs = self.learner_config.replay.batch_size
+
+        def pull():
+            while not replay.start_sample_condition():
+                time.sleep(0.001)
+            return replay.sample(bs)
+        self._data_source = pull
+
+    def fetch_batch(self):
+        if self._data_source is None:
+            raise RuntimeError('no data source attached: call attach_replay / set_data_source')
+        t0 = time.time()
+        data = self._prefetcher_preprocess(self._data_source())
+        if isinstance(data, dict) and not isinstance(data, AttrDict):
+            data = AttrDict(data)
+        data = self.preprocess(data)
+        self.fetch_time_s = time.time() - t0
+        return data
+
+    def fetch_iterator(self):
+        while True:
+            yield self.fetch_batch()
+
+    def preprocess(self, batch):
+        return batch
+
+    def _prefetcher_preprocess(self, batch):
+        return batch
+
+    # ---- logging / metrics (base.py:159-255) ------------------------------------------------
+    def _setup_logging(self):
+        self.log = logging.getLogger('surreal_amd.learner')
+        self.tensorplex = ScalarRecorder()
+        self.init_time = time.time()
+        self.learn_time_s = 0.0
+        self.fetch_time_s = 0.0
+        self.publish_time_s = 0.0
+        self.iter_time_s = 0.0
+        self.last_time = self.init_time
+        self.last_iter = 0
+
+    def generate_tensorplex_report(self):
+        """the reference's .core/* and .system/* gauges (base.py:201-255); exp_per_s is its own
+        learner-ingest metric (sub-trajectories/s; x n_step = env-steps/s)"""
+        now = time.time()
+        iters = self.current_iter - self.last_iter
+        elapsed = max(now - self.last_time, 1e-9)
+        self.last_iter, self.last_time = self.current_iter, now
+        iter_time = self.iter_time_s + 1e-6
+        iter_per_s = iters / elapsed
+        m = {
+            '.core/learn_time_s': self.learn_time_s + 1e-6,
+            '.core/fetch_time_s': self.fetch_time_s + 1e-6,
+            '.core/publish_time_s': self.publish_time_s + 1e-6,
+            '.core/iter_time_s': iter_time,
+            '.system/iter_per_s': iter_per_s,
+            '.system/exp_per_s': iter_per_s * self.learner_config.replay.batch_size,
+            '.system/compute_load_percent': min(self.learn_time_s / iter_time * 100, 100),
+            '.system/io_fetch_experience_load_percent': min(self.fetch_time_s / iter_time * 100, 100),
+            '.system/io_publish_load_percent': min(self.publish_time_s / iter_time * 100, 100),
+        }
+        self.tensorplex.add_scalars(m)
+        return m
+
+    # ---- checkpoint (base.py:260-313; utils/checkpoint.py:234-314) ----------------------------
+    def _setup_checkpoint(self):
+        ck = self.session_config.checkpoint.learner
+        self._ckpt_folder = os.path.join(self.session_config.folder, 'checkpoint')
+        self._ckpt_period = ck.periodic
+        self._ckpt_min_interval = ck.min_interval
+        self._ckpt_keep = ck.keep_history
+        self._ckpt_calls = 0
+        self._ckpt_last_time = time.time()
+
+    def _checkpoint_payload(self):
+        out = {}
+        for name in self.checkpoint_attributes():
+            obj = getattr(self, name)
+            if hasattr(obj, 'state_dict'):
+                sd = obj.state_dict()
+                obj = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v)
+                       for k, v in sd.items()}
+            out[name] = obj
+        return out
+
+    def save_checkpoint(self, global_steps):
+        os.makedirs(self._ckpt_folder, exist_ok=True)
+        path = os.path.join(self._ckpt_folder, 'learner.%d.ckpt' % global_steps)
+        with open(path, 'wb') as fp:
+            pickle.dump(self._checkpoint_payload(), fp)
+        hist = sorted((f for f in os.listdir(self._ckpt_folder)
+                       if f.startswith('learner.') and f.endswith('.ckpt')),
+                      key=lambda f: int(f.split('.')[1]))
+        for old in hist[:-self._ckpt_keep] if self._ckpt_keep > 0 else []:
+            os.remove(os.path.join(self._ckpt_folder, old))
+        return path
+
+    def periodic_checkpoint(self, global_steps, score=None, **info):
+        self._ckpt_calls += 1
+        if self._ckpt_calls % self._ckpt_period != 0:
+            return False
+        if time.time() - self._ckpt_last_time < self._ckpt_min_interval:
+            return False
+        self._ckpt_last_time = time.time()
+        self.save_checkpoint(global_steps)
+        return True
+
+    def restore_checkpoint(self, path=None):
+        folder = self.session_config.checkpoint.restore_folder or self.session_config.folder
+        if os.path.basename(os.path.normpath(folder)) != 'checkpoint':
+            folder = os.path.join(folder, 'checkpoint')
+        if path is None:
+            hist = sorted((f for f in os.listdir(folder) if f.endswith('.ckpt')),
+                          key=lambda f: int(f.split('.')[1]))
+            if not hist:
+                return False
+            path = os.path.join(folder, hist[-1])
+        with open(path, 'rb') as fp:
+            payload = pickle.load(fp)
+        for name, value in payload.items():
+            obj = getattr(self, name, None)
+            if hasattr(obj, 'load_state_dict'):
+                obj.load_state_dict(value)
+            else:
+                setattr(self, name, value)
+        return True
+
+    # ---- main loop (base.py:348-389) -----------------------------------------------------------
+    def main(self):
+        self.main_setup()
+        while True:
+            self.main_loop()
+
+    def main_setup(self):
+        self.save_config()
+        self._iter_t0 = time.time()
+        self.publish_parameter(0, message='batch ' + str(0))
+
+    def main_loop(self):
+        data = self.fetch_batch()
+        t0 = time.time()
+        self.learn(data)
+        self.learn_time_s = time.time() - t0
+        if self.should_publish_parameter():
+            t1 = time.time()
+            self.publish_parameter(self.current_iter, message='batch ' + str(self.current_iter))
+            self.publish_time_s = time.time() - t1
+        now = time.time()
+        self.iter_time_s = now - getattr(self, '_iter_t0', now)
+        self._iter_t0 = now
+        self.current_iter += 1
+
+    def save_config(self):
+        folder = self.session_config.folder
+        os.makedirs(folder, exist_ok=True)
+        Config(learner_config=self.learner_config, env_config=self.env_config,
+               session_config=self.session_config).dump_file(os.path.join(folder, 'config.yml'))

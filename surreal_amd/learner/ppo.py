@@ -1,0 +1,618 @@
+"""
+PPOLearner for MI355X -- drop-in for ``surreal.learner.ppo.PPOLearner``
+(surreal/learner/ppo.py:12-682): same constructor ``(learner_config, env_config,
+session_config)``, same config keys, same batch contract (``MultistepAggregatorWithInfo``),
+same method names, same statistics keys, and (to 1e-5 fp32) the same advantages, returns,
+per-epoch losses and updated parameters as the reference CPU learner on identical inputs.
+
+What is different is how one ``learn()`` runs (SURVEY.md section 3.1 lists the reference flow):
+
+  * trajectories stay in HBM as struct-of-arrays ``(B, N, .)`` tensors; the reference's
+    ``torch.cat([obs, obs_next])`` copy is never made -- the fused critic kernel addresses
+    both tensors directly;
+  * the critic pass over all B*(N+1) steps is one fused z-filter + 3-layer MLP kernel on FP32
+    MFMA (csrc/smx_mlp3_fused.hip); GAE, normalisation, losses, backward, clip-norm and Adam
+    are HIP kernels chained on the stream with NO host synchronisation: the reference's ~15
+    ``.item()`` reads per learn become one read-back of a small statistics block, and the
+    data-dependent ``break`` of the policy loop (ppo.py:556-557) becomes a device-side flag that
+    turns the remaining policy kernels into no-ops;
+  * the forward pass that the reference repeats after every update just to measure KL
+    (ppo.py:553) is the next epoch's forward pass, so it is computed once;
+  * the value epochs (independent parameters, ppo.py:561-562) run on a second HIP stream next
+    to the policy epochs, and the whole step is captured in a hipGraph and replayed;
+  * with ``torch.distributed`` initialised (one process per GPU, RCCL over xGMI) each rank
+    learns on its shard of the sub-trajectories and the ranks all-reduce the statistics the
+    single reference learner would have seen whole: advantage moments, loss partial sums,
+    gradients, value moments, z-filter sums.
+
+Round-1 scope: MLP policy on low-dimensional observations (``rnn.if_rnn_policy = False``,
+``pixel_input = False``); the LSTM / CNN stems raise NotImplementedError.
+"""
+import types
+
+import numpy as np
+import torch
+
+from surreal_amd import _lib as L
+from surreal_amd import kernels as KN
+from surreal_amd.learner.aggregator import MultistepAggregatorWithInfo
+from surreal_amd.learner.base import Learner
+from surreal_amd.model.ppo_net import DiagGauss, PPOModel
+from surreal_amd.utils import AttrDict
+
+
+class LinearWithMinLR(object):
+    """Learning-rate schedule named by ``algo.network.anneal.lr_scheduler`` (ppo.py:121-125,
+    171-178).  The reference takes it from torchx 0.9 whose source is absent, so the exact
+    formula is unpinned: this one anneals linearly from the initial rate to ``min_lr`` over
+    ``num_updates`` calls of ``step()``, re-evaluated every ``update_freq`` calls."""
+
+    def __init__(self, initial_lr, num_updates, update_freq=1, min_lr=0.0):
+        self.initial_lr = float(initial_lr)
+        self.num_updates = max(int(num_updates), 1)
+        self.update_freq = max(int(update_freq), 1)
+        self.min_lr = float(min_lr)
+        self.n = 0
+        self.lr = float(initial_lr)
+
+    def get_lr(self):
+        return [self.lr]
+
+    def step(self):
+        self.n += 1
+        if self.n % self.update_freq == 0:
+            frac = max(0.0, 1.0 - self.n / self.num_updates)
+            self.lr = max(self.min_lr, self.initial_lr * frac)
+
+    def state_dict(self):
+        return {'n': self.n, 'lr': self.lr}
+
+    def load_state_dict(self, sd):
+        self.n, self.lr = int(sd['n']), float(sd['lr'])
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size(), dist.get_rank()
+    return None, 1, 0
+
+
+class PPOLearner(Learner):
+    def __init__(self, learner_config, env_config, session_config):
+        super().__init__(learner_config, env_config, session_config)
+        self.K = KN.default_kernels()       # raises when the HIP library / GPU is missing
+        self.device = KN.default_device()
+        self._dist, self.world_size, self.rank = _dist_info()
+
+        self.current_iteration = 0
+        self.global_step = 0
+        self.gpu_option = 'cuda:all'
+        self.use_cuda = True
+
+        algo = self.learner_config.algo
+        # RL general parameters (ppo.py:75-85)
+        self.gamma = algo.gamma
+        self.lam = algo.advantage.lam
+        self.n_step = algo.n_step
+        self.use_z_filter = algo.use_z_filter
+        self.use_r_filter = algo.use_r_filter
+        self.norm_adv = algo.advantage.norm_adv
+        self.batch_size = self.learner_config.replay.batch_size
+        self.action_dim = self.env_config.action_spec.dim[0]
+        self.obs_spec = self.env_config.obs_spec
+        self.init_log_sig = algo.consts.init_log_sig
+        # PPO parameters (ppo.py:88-118)
+        self.ppo_mode = algo.ppo_mode
+        self.if_rnn_policy = algo.rnn.if_rnn_policy
+        self.horizon = algo.rnn.horizon
+        self.lr_actor = algo.network.lr_actor
+        self.lr_critic = algo.network.lr_critic
+        self.epoch_policy = algo.consts.epoch_policy
+        self.epoch_baseline = algo.consts.epoch_baseline
+        self.kl_target = algo.consts.kl_target
+        self.adjust_threshold = algo.consts.adjust_threshold
+        self.reward_scale = algo.advantage.reward_scale
+        self.kl_cutoff_coeff = algo.adapt_consts.kl_cutoff_coeff
+        self.beta_init = algo.adapt_consts.beta_init
+        self.beta_range = algo.adapt_consts.beta_range
+        self.clip_range = algo.clip_consts.clip_range
+        self.clip_epsilon_init = algo.clip_consts.clip_epsilon_init
+        if self.ppo_mode == 'adapt':
+            self.beta = self.beta_init
+            self.eta = self.kl_cutoff_coeff
+            self.beta_upper = self.beta_range[1]
+            self.beta_lower = self.beta_range[0]
+            self.beta_adjust_threshold = self.adjust_threshold
+        elif self.ppo_mode == 'clip':
+            self.clip_epsilon = self.clip_epsilon_init
+            self.clip_adjust_threshold = self.adjust_threshold
+            self.clip_upper = self.clip_range[1]
+            self.clip_lower = self.clip_range[0]
+        else:
+            raise ValueError('ppo_mode must be "adapt" or "clip", got %r' % (self.ppo_mode,))
+        # learning-rate annealing (ppo.py:121-125)
+        anneal = algo.network.anneal
+        self.min_lr = anneal.min_lr
+        self.lr_update_frequency = anneal.lr_update_frequency
+        self.frames_to_anneal = anneal.frames_to_anneal
+        num_updates = int(self.frames_to_anneal / self.learner_config.parameter_publish.exp_interval)
+        if anneal.lr_scheduler != 'LinearWithMinLR':
+            raise ValueError('unknown lr_scheduler %r' % (anneal.lr_scheduler,))
+
+        self.exp_counter = 0
+        self.kl_record = []
+
+        mk = dict(obs_spec=self.obs_spec, action_dim=self.action_dim,
+                  model_config=self.learner_config.model, use_cuda=True,
+                  init_log_sig=self.init_log_sig, use_z_filter=self.use_z_filter,
+                  if_pixel_input=self.env_config.get('pixel_input', False),
+                  rnn_config=algo.rnn, device=self.device, kernels=self.K)
+        self.model = PPOModel(**mk)
+        self.ref_target_model = PPOModel(**mk)
+        self.ref_target_model.update_target_params(self.model)          # ppo.py:151
+
+        net = algo.network
+        self.clip_actor_gradient = net.clip_actor_gradient
+        self.actor_gradient_clip_value = net.actor_gradient_norm_clip
+        self.clip_critic_gradient = net.clip_critic_gradient
+        self.critic_gradient_clip_value = net.critic_gradient_norm_clip
+        self.actor_regularization = net.actor_regularization
+        self.critic_regularization = net.critic_regularization
+        # torch.optim.Adam state (ppo.py:159-168), one flat buffer per group
+        self.actor_exp_avg = torch.zeros_like(self.model.actor_flat)
+        self.actor_exp_avg_sq = torch.zeros_like(self.model.actor_flat)
+        self.critic_exp_avg = torch.zeros_like(self.model.critic_flat)
+        self.critic_exp_avg_sq = torch.zeros_like(self.model.critic_flat)
+        self.actor_lr_scheduler = LinearWithMinLR(self.lr_actor, num_updates,
+                                                  self.lr_update_frequency, self.min_lr)
+        self.critic_lr_scheduler = LinearWithMinLR(self.lr_critic, num_updates,
+                                                   self.lr_update_frequency, self.min_lr)
+        self.aggregator = MultistepAggregatorWithInfo(self.env_config.obs_spec,
+                                                      self.env_config.action_spec)
+        self.pd = DiagGauss(self.action_dim)
+        self.cells = None
+        if self.use_r_filter:
+            self._rf_count = torch.tensor(1e-5, device=self.device)
+            self._rf_sum = torch.tensor(0.0, device=self.device)
+            self._rf_sumsq = torch.tensor(0.0, device=self.device)
+
+        lcfg = self.session_config.learner
+        self.use_graph = bool(lcfg.get('use_hip_graph', True)) and self.device != 'cpu' \
+            and self.world_size == 1
+        self.overlap_value_epochs = bool(lcfg.get('overlap_value_epochs', True)) \
+            and self.device != 'cpu'
+        self._ws = None
+        self._graphs = {}
+        self._ctrl_host = None
+        self.trace = None
+
+    # ======================================================================================
+    # device-resident control block (smx_ppo_ctrl_t)
+    # ======================================================================================
+    def _ensure_ctrl(self, ws):
+        vals = [self.actor_lr_scheduler.get_lr()[0], self.critic_lr_scheduler.get_lr()[0],
+                getattr(self, 'beta', 0.0), getattr(self, 'eta', 0.0),
+                getattr(self, 'clip_epsilon', 0.0), self.kl_target,
+                self.actor_gradient_clip_value if self.clip_actor_gradient else 0.0,
+                self.critic_gradient_clip_value if self.clip_critic_gradient else 0.0,
+                self.actor_regularization, self.critic_regularization]
+        if self._ctrl_host != vals:
+            ws.ctrl_f[:10].copy_(torch.tensor(vals, dtype=torch.float32))
+            self._ctrl_host = vals
+
+    # ======================================================================================
+    # workspace
+    # ======================================================================================
+    def _workspace(self, B, N, D, A):
+        key = (B, N, D, A)
+        if self._ws is not None and self._ws.key == key:
+            return self._ws
+        dev, K = self.device, self.K
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        ws = types.SimpleNamespace()
+        ws.key = key
+        act, cri = self.model.actor, self.model.critic
+        E = 1
+        ws.E = E
+        Ep, Ev = self.epoch_policy, self.epoch_baseline
+        # scalars block: ctrl | policy stats | value stats | moments
+        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + Ev * L.VS_STRIDE + 8
+        ws.scal = torch.zeros(n_scal, device=dev, dtype=torch.float32)
+        o = 0
+        ws.ctrl_f = ws.scal[o:o + L.CTRL_WORDS]; o += L.CTRL_WORDS
+        ws.ctrl_i = ws.ctrl_f.view(torch.int32)
+        ws.pstats = ws.scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE); o += (Ep + 1) * L.PS_STRIDE
+        ws.vstats = ws.scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE); o += Ev * L.VS_STRIDE
+        ws.adv_mom = ws.scal[o:o + 3]; o += 3
+        ws.ret_mom = ws.scal[o:o + 3]; o += 3
+        ws.stop = ws.ctrl_i[L.C_STOP:L.C_STOP + 1]
+        # keep the optimiser step counters of a previous workspace
+        if self._ws is not None:
+            ws.ctrl_i[L.C_STEP_ACTOR:L.C_STEP_CRITIC + 1].copy_(
+                self._ws.ctrl_i[L.C_STEP_ACTOR:L.C_STEP_CRITIC + 1])
+        self._ctrl_host = None
+        # critic pass + GAE
+        ws.packed = f(K.mlp3_packed_numel(cri))
+        ws.values = f(B * (N + 1))
+        ws.adv = f(B * E)
+        ws.ret = f(B * E)
+        idx = torch.tensor(range(N), dtype=torch.float32)
+        ws.gpow = torch.pow(self.gamma, idx).to(dev)     # ppo.py:372-374, built as the reference does
+        ws.lpow = torch.pow(self.lam, idx).to(dev)
+        ws.mom_parts = f(self.world_size, 3)
+        # epochs
+        rows = B * E
+        ws.rows = rows
+        ws.xn = f(rows, D)            # z-filtered step-0 observations (model filter)
+        ws.xr = f(rows, D)            # same through the reference-policy filter
+        ws.h1a, ws.h2a, ws.mean = f(rows, act.H1), f(rows, act.H2), f(rows, A)
+        ws.h1r, ws.h2r, ws.ref_mean = f(rows, act.H1), f(rows, act.H2), f(rows, A)
+        ws.ref_pol = f(rows, 2 * A)
+        ws.h1c, ws.h2c, ws.vpred = f(rows, cri.H1), f(rows, cri.H2), f(rows)
+        ws.g_surr, ws.g_kl, ws.dz3a = f(rows, A), f(rows, A), f(rows, A)
+        ws.dz2a, ws.dz1a = f(rows, act.H2), f(rows, act.H1)
+        ws.dz3c, ws.dz2c, ws.dz1c = f(rows), f(rows, cri.H2), f(rows, cri.H1)
+        ws.grads_a = torch.zeros_like(self.model.actor_flat)
+        ws.grads_c = torch.zeros_like(self.model.critic_flat)
+        ws.nblk_p = K.loss_blocks(rows)
+        ws.pstride = 8 + 2 * A
+        ws.ppart = f(ws.nblk_p, ws.pstride)
+        ws.ppart_sum = f(1, ws.pstride)
+        ws.nblk_v = K.value_loss_blocks(rows)
+        ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
+        ws.vpart_local = f(ws.nblk_v, 8)
+        ws.np_a = K.mlp3_backward_partials(act)
+        ws.np_c = K.mlp3_backward_partials(cri)
+        ws.sumsq_a = torch.zeros(max(ws.np_a + 1, K.sumsq_blocks(ws.grads_a.numel())), device=dev)
+        ws.sumsq_c = torch.zeros(max(ws.np_c, K.sumsq_blocks(ws.grads_c.numel())), device=dev)
+        if self.use_z_filter:
+            ws.zdelta = torch.zeros(2 * D + 1, device=dev)
+        self._ws = ws
+        self._graphs = {}
+        return ws
+
+    # ======================================================================================
+    # batch handling
+    # ======================================================================================
+    def _to_dev(self, x):
+        if torch.is_tensor(x):
+            return x.to(self.device, torch.float32)
+        return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.device)
+
+    def _preprocess_batch_ppo(self, batch):
+        """numpy -> device fp32 tensors (ppo.py:420-484); device tensors pass through"""
+        obs, obs_next = batch['obs'], batch['obs_next']
+        for modality in obs:
+            for key in obs[modality]:
+                obs[modality][key] = self._to_dev(obs[modality][key])
+                obs_next[modality][key] = self._to_dev(obs_next[modality][key])
+        batch['actions'] = self._to_dev(batch['actions'])
+        rewards = self._to_dev(batch['rewards'])
+        if self.reward_scale != 1.0:
+            rewards = rewards * self.reward_scale
+        if self.use_r_filter:                                   # reward_filter.py:33-57
+            mean = self._rf_sum / self._rf_count
+            std = torch.clamp((self._rf_sumsq / self._rf_count - mean.pow(2)).pow(0.5), min=1e-5)
+            normed = torch.clamp((rewards - mean) / std, -5.0, 5.0)
+            self._rf_count += float(rewards.numel())
+            self._rf_sum += rewards.sum()
+            self._rf_sumsq = (rewards * rewards).sum()          # overwrite (sic, :42)
+            rewards = normed
+        batch['rewards'] = rewards
+        batch['dones'] = self._to_dev(batch['dones'])
+        if batch.get('persistent_infos') is not None:
+            batch['persistent_infos'] = [self._to_dev(x) for x in batch['persistent_infos']]
+        if batch.get('onetime_infos') is not None:
+            batch['onetime_infos'] = [self._to_dev(x) for x in batch['onetime_infos']]
+        return batch
+
+    def _flat_obs(self, obs):
+        parts = [obs['low_dim'][k] for k in obs['low_dim'].keys()]
+        x = parts[0] if len(parts) == 1 else torch.cat(parts, -1)
+        return x.contiguous()
+
+    # ======================================================================================
+    # pieces of _optimize (each is a short chain of kernel launches, no host sync)
+    # ======================================================================================
+    def _enqueue_gae(self, ws, obs, obs_next, rewards, dones):
+        """critic over all steps + windowed GAE + normalisation (ppo.py:355-418)"""
+        K, m = self.K, self.model
+        B, N, D = obs.shape
+        zm = zs = None
+        if self.use_z_filter:
+            zm, zs = m.z_filter.refresh_stats()
+        K.mlp3_pack(m.critic, ws.packed)
+        K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.values, L.SMX_ACT_NONE)
+        K.gae(ws.values, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N, B, N, N,
+              ws.adv, ws.ret)
+        if self.norm_adv:
+            K.moments(ws.adv, ws.adv_mom)
+            if self.world_size > 1:
+                self._dist.all_gather_into_tensor(ws.mom_parts.view(-1), ws.adv_mom.clone())
+                K.moments_merge(ws.mom_parts, ws.adv_mom)
+            K.adv_normalize(ws.adv, ws.adv_mom, 1e-4)
+
+    def _enqueue_policy_forward(self, ws, e, actions0, behave0):
+        """forward + loss + finalize for epoch slot e (ppo.py:209-225 / 266-285, 553-557)"""
+        K, m = self.K, self.model
+        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
+        K.mlp3_forward(m.actor, ws.xn, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
+        K.policy_loss(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
+                      ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
+        part, nblk = ws.ppart, ws.nblk_p
+        if self.world_size > 1:
+            torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
+            self._dist.all_reduce(ws.ppart_sum)
+            part, nblk = ws.ppart_sum, 1
+        A = self.action_dim
+        K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1),
+                          ws.rows * self.world_size, ws.ctrl_f, e > 0, e < self.epoch_policy,
+                          ws.dz3a, ws.grads_a[m.actor.numel:m.actor.numel + A],
+                          ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
+
+    def _enqueue_policy_update(self, ws, e):
+        """backward + clip_grad_norm_ + Adam (ppo.py:240-248 / 301-309)"""
+        K, m = self.K, self.model
+        K.mlp3_backward(m.actor, ws.xn, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a, ws.grads_a,
+                        ws.sumsq_a, ws.stop)
+        npart = ws.np_a + 1
+        if self.world_size > 1:
+            self._dist.all_reduce(ws.grads_a)
+            K.sumsq_partials(ws.grads_a, ws.sumsq_a)
+            npart = K.sumsq_blocks(ws.grads_a.numel())
+        K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                    ws.sumsq_a, npart, ws.ctrl_f, 0, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
+
+    def _enqueue_value_epoch(self, ws, e):
+        """forward + loss + backward + clip + Adam for the critic (ppo.py:323-353)"""
+        K, m = self.K, self.model
+        K.mlp3_forward(m.critic, ws.xn, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
+        n_total = ws.rows * self.world_size
+        if self.world_size > 1:
+            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
+            self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
+        else:
+            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
+        K.mlp3_backward(m.critic, ws.xn, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
+                        ws.grads_c, ws.sumsq_c, None)
+        npart = ws.np_c
+        if self.world_size > 1:
+            self._dist.all_reduce(ws.grads_c)
+            K.sumsq_partials(ws.grads_c, ws.sumsq_c)
+            npart = K.sumsq_blocks(ws.grads_c.numel())
+        K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                    ws.sumsq_c, npart, ws.ctrl_f, 1, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
+
+    def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds):
+        """the whole of _optimize (ppo.py:487-586) as a launch sequence"""
+        K, m, ref = self.K, self.model, self.ref_target_model
+        B, N, D = obs.shape
+        A = self.action_dim
+        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
+        ws.pstats.zero_()
+        self._enqueue_gae(ws, obs, obs_next, rewards, dones)
+
+        obs0 = obs[:, 0, :]                      # ppo.py:527-537 (views, no copies)
+        actions0 = actions[:, 0, :]
+        behave0 = pds[:, 0, :]
+        if self.use_z_filter:
+            zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed in _enqueue_gae
+            K.zfilter_forward(obs0, zm, zs, ws.xn)
+            rzm, rzs = ref.z_filter.refresh_stats()
+            K.zfilter_forward(obs0, rzm, rzs, ws.xr)
+        else:
+            ws.xn.copy_(obs0)
+            ws.xr.copy_(obs0)
+        # ref_pol = ref_target_model.forward_actor(obs_iter)   (ppo.py:539)
+        K.mlp3_forward(ref.actor, ws.xr, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
+        ws.ref_pol[:, :A].copy_(ws.ref_mean)
+        ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
+
+        def policy_epochs():
+            self._enqueue_policy_forward(ws, 0, actions0, behave0)
+            for e in range(self.epoch_policy):
+                self._enqueue_policy_update(ws, e)
+                self._enqueue_policy_forward(ws, e + 1, actions0, behave0)
+
+        def value_epochs():
+            for e in range(self.epoch_baseline):
+                self._enqueue_value_epoch(ws, e)
+            K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats,
+                             L.VS_STRIDE)
+
+        if self.overlap_value_epochs and self.world_size == 1:
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                value_epochs()
+            policy_epochs()
+            main.wait_stream(side)
+        else:
+            policy_epochs()
+            value_epochs()
+
+        K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
+        if self.use_z_filter:                   # model.z_update(obs_iter)  (ppo.py:578-579)
+            if self.world_size > 1:
+                ws.zdelta.zero_()
+                K.zfilter_update(obs0, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], B)
+                self._dist.all_reduce(ws.zdelta)
+                m.z_filter.running_sum += ws.zdelta[:D]
+                m.z_filter.running_sumsq += ws.zdelta[D:2 * D]
+                m.z_filter.count += ws.zdelta[2 * D:]
+            else:
+                K.zfilter_update(obs0, m.z_filter.running_sum, m.z_filter.running_sumsq,
+                                 m.z_filter.count, B)
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    # ======================================================================================
+    # _optimize / learn  (ppo.py:487-613)
+    # ======================================================================================
+    def _optimize(self, obs, actions, rewards, obs_next, persistent_infos, onetime_infos, dones):
+        if self.if_rnn_policy:
+            raise NotImplementedError('LSTM policy not built yet')
+        x = self._flat_obs(obs)
+        xn = self._flat_obs(obs_next)
+        pds = persistent_infos[-1].contiguous()
+        actions, rewards, dones = actions.contiguous(), rewards.contiguous(), dones.contiguous()
+        B, N, D = x.shape
+        assert B == self.batch_size and N == self.n_step, \
+            'batch is (%d, %d) but config says batch_size=%d n_step=%d' % (B, N, self.batch_size, self.n_step)
+        ws = self._workspace(B, N, D, self.action_dim)
+        self._ensure_ctrl(ws)
+        args = (x, xn, actions, rewards, dones, pds)
+        if self.use_graph:
+            key = tuple(t.data_ptr() for t in args)
+            g = self._graphs.get(key)
+            if g is None:
+                # warm-up run outside capture (lazy module loads, hipFuncSetAttribute), on a
+                # snapshot of the mutable state so that the captured replay is the first real step
+                snap = self._snapshot_state()
+                self._enqueue_optimize(ws, *args)
+                torch.cuda.synchronize()
+                self._restore_state(snap)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_optimize(ws, *args)
+                self._restore_state(snap)
+                self._graphs = {key: g}
+            g.replay()
+        else:
+            self._enqueue_optimize(ws, *args)
+        return self._collect_stats(ws)
+
+    def _snapshot_state(self):
+        m = self.model
+        ws = self._ws
+        st = [m.actor_flat, m.critic_flat, self.actor_exp_avg, self.actor_exp_avg_sq,
+              self.critic_exp_avg, self.critic_exp_avg_sq, ws.scal]
+        if self.use_z_filter:
+            st += [m.z_filter.running_sum, m.z_filter.running_sumsq, m.z_filter.count]
+        return [(t, t.clone()) for t in st]
+
+    def _restore_state(self, snap):
+        for t, c in snap:
+            t.copy_(c)
+        torch.cuda.synchronize()
+
+    def _collect_stats(self, ws):
+        """one device->host read of the statistics block, then the reference's stats dict
+        (ppo.py:219-224, 278-284, 328-331, 559-586)"""
+        scal = ws.scal.cpu()
+        ctrl_i = scal[:L.CTRL_WORDS].view(torch.int32)
+        o = L.CTRL_WORDS
+        Ep, Ev = self.epoch_policy, self.epoch_baseline
+        ps = scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE).numpy(); o += (Ep + 1) * L.PS_STRIDE
+        vs = scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE).numpy(); o += Ev * L.VS_STRIDE
+        ret_mom = scal[o + 3:o + 6].numpy()
+        done = int(ctrl_i[L.C_EPOCHS_DONE])      # policy updates applied
+        # the reference breaks after the update whose KL is too large: `done` updates ran,
+        # slot `done` holds the forward pass after the last one
+        last = done - 1
+        trace = {'policy': [], 'value': []}
+        for e in range(done):
+            d = {'_surr_loss': float(ps[e, L.PS_SURR]), '_entropy': float(ps[e, L.PS_ENTROPY]),
+                 '_pol_kl': float(ps[e + 1, L.PS_KL])}
+            if self.ppo_mode == 'clip':
+                d['_clip_surr_loss'] = float(ps[e, L.PS_LOSS])
+                d['_clip_epsilon'] = self.clip_epsilon
+            else:
+                d['_kl_loss_adapt'] = float(ps[e, L.PS_LOSS])
+                d['_beta'] = self.beta
+            if self.clip_actor_gradient:
+                d['grad_norm_actor'] = float(ps[e, L.PS_GRADNORM])
+            trace['policy'].append(d)
+        for e in range(Ev):
+            d = {'_val_loss': float(vs[e, L.VS_LOSS]), '_val_explained_var': float(vs[e, L.VS_EXPVAR])}
+            if self.clip_critic_gradient:
+                d['grad_norm_critic'] = float(vs[e, L.VS_GRADNORM])
+            trace['value'].append(d)
+        self.trace = trace
+        self.epochs_executed = done
+        stats = dict(trace['policy'][last])
+        self.kl_record.append(stats['_pol_kl'])                          # ppo.py:559
+        stats.update(trace['value'][-1])                                 # ppo.py:565-566
+        stats['_avg_return_targ'] = float(ret_mom[1])
+        stats['_avg_log_sig'] = float(self.model.log_var.mean().item())
+        stats['_avg_behave_likelihood'] = float(ps[done, L.PS_LB])
+        stats['_avg_is_weight'] = float(ps[done, L.PS_ISW])
+        stats['_ref_behave_diff'] = float(ps[done, L.PS_REFBEH])
+        stats['_lr'] = self.actor_lr_scheduler.get_lr()[0]
+        if self.use_z_filter:
+            zf = self.model.z_filter
+            stats['obs_running_mean'] = float(np.mean(zf.running_mean()))
+            stats['obs_running_square'] = float(np.mean(zf.running_square()))
+            stats['obs_running_std'] = float(np.mean(zf.running_std()))
+        if self.use_r_filter:
+            stats['reward_mean'] = float((self._rf_sum / self._rf_count).item())
+        return stats
+
+    def learn(self, batch):
+        self.current_iteration += 1
+        batch = self._preprocess_batch_ppo(batch)
+        tensorplex_update_dict = self._optimize(
+            batch['obs'], batch['actions'], batch['rewards'], batch['obs_next'],
+            batch['persistent_infos'], batch.get('onetime_infos'), batch['dones'])
+        self.periodic_checkpoint(global_steps=self.current_iteration, score=None)
+        self.tensorplex.add_scalars(tensorplex_update_dict, self.global_step)
+        self.exp_counter += self.batch_size * self.world_size
+        self.global_step += 1
+        return tensorplex_update_dict
+
+    # ---- reference-shaped accessors used by the parity tests ---------------------------------
+    def _gae_and_return(self, obs, obs_next, rewards, dones):
+        """-> (advantages (B,1), returns (B,1)) as ppo.py:355-418 returns them"""
+        x, xn = self._flat_obs(obs), self._flat_obs(obs_next)
+        B, N, D = x.shape
+        ws = self._workspace(B, N, D, self.action_dim)
+        self._ensure_ctrl(ws)
+        self._enqueue_gae(ws, x, xn, rewards.contiguous(), dones.contiguous())
+        return ws.adv.view(B, -1).clone(), ws.ret.view(B, -1).clone()
+
+    # ======================================================================================
+    # publish / schedule (ppo.py:615-682)
+    # ======================================================================================
+    def module_dict(self):
+        return {'ppo': self.model}
+
+    def publish_parameter(self, iteration, message=''):
+        if self.exp_counter >= self.learner_config.parameter_publish.exp_interval:
+            self._publish(iteration, message=message)
+            self._post_publish()
+
+    def _post_publish(self):
+        final_kl = np.mean(self.kl_record)
+        scale_c = self.learner_config.algo.clip_consts.scale_constant
+        scale_a = self.learner_config.algo.adapt_consts.scale_constant
+        if self.ppo_mode == 'clip':
+            if final_kl > self.kl_target * self.clip_adjust_threshold[1]:
+                if self.clip_lower < self.clip_epsilon:
+                    self.clip_epsilon = self.clip_epsilon / scale_c
+            elif final_kl < self.kl_target * self.clip_adjust_threshold[0]:
+                if self.clip_upper > self.clip_epsilon:
+                    self.clip_epsilon = self.clip_epsilon * scale_c
+        else:
+            if final_kl > self.kl_target * self.beta_adjust_threshold[1]:
+                if self.beta_upper > self.beta:
+                    self.beta = self.beta * scale_a
+            elif final_kl < self.kl_target * self.beta_adjust_threshold[0]:
+                if self.beta_lower < self.beta:
+                    self.beta = self.beta / scale_a
+        self.ref_target_model.update_target_params(self.model)
+        self.kl_record = []
+        self.exp_counter = 0
+        self.actor_lr_scheduler.step()
+        self.critic_lr_scheduler.step()
+
+    def checkpoint_attributes(self):
+        return ['model', 'ref_target_model', 'actor_lr_scheduler', 'critic_lr_scheduler',
+                'current_iteration']
+
+    def _prefetcher_preprocess(self, batch):
+        return self.aggregator.aggregate(batch)

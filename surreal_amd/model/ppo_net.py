@@ -1,0 +1,270 @@
+"""
+PPO model on MI355X: DiagGauss, ZFilter and PPOModel with the reference's interface
+(surreal/model/ppo_net.py:13-375, surreal/model/z_filter.py:7-107,
+surreal/model/model_builders/builders.py:86-175) over HIP kernels.
+
+Parameters live in HBM as ONE flat fp32 buffer per optimiser group
+(actor: W1|b1|W2|b2|W3|b3|log_var, critic: W1|b1|W2|b2|W3|b3) so that clip_grad_norm_ + Adam
+is a single launch and a data-parallel gradient all-reduce is a single collective.
+"""
+import collections
+import ctypes
+
+import numpy as np
+import torch
+
+from surreal_amd import _lib as L
+from surreal_amd import kernels as KN
+
+
+class DiagGauss(object):
+    """Diagonal Gaussian policy head.  The likelihood / KL / entropy arithmetic of the reference
+    class (ppo_net.py:29-72) runs inside the fused loss kernels (csrc/smx_ppo.hip); the
+    host-side members used by the rollout workers (ppo_net.py:74-91) are kept here."""
+
+    def __init__(self, action_dim):
+        self.d = action_dim
+
+    def sample(self, prob):                      # ppo_net.py:74-83
+        prob = np.asarray(prob)
+        if prob.ndim == 3:
+            prob = prob.reshape(-1, self.d * 2)
+        mean_nd, std_nd = prob[:, :self.d], prob[:, self.d:]
+        return np.random.randn(prob.shape[0], self.d) * std_nd + mean_nd
+
+    def maxprob(self, prob):                     # ppo_net.py:85-91 (3-D branch quirk kept)
+        prob = np.asarray(prob)
+        if prob.ndim == 3:
+            return prob[:, :, self.d]
+        return prob[:, :self.d]
+
+
+class ZFilter(object):
+    """running whitening filter, buffers in HBM (z_filter.py:23-42)"""
+
+    def __init__(self, obs_spec, eps=1e-5, device=None, kernels=None):
+        self.K = kernels or KN.default_kernels()
+        device = device or KN.default_device()
+        self.eps = eps
+        self.obs_spec = obs_spec
+        self.in_size = sum(obs_spec['low_dim'][k][0] for k in obs_spec['low_dim'].keys())
+        d = self.in_size
+        self.running_sum = torch.zeros(d, device=device)
+        self.running_sumsq = eps * torch.ones(d, device=device)
+        self.count = torch.tensor([eps], dtype=torch.float32, device=device)
+        self._mean = torch.empty(d, device=device)
+        self._std = torch.empty(d, device=device)
+
+    def refresh_stats(self):
+        """mean/std used by forward() (z_filter.py:74-76), recomputed on the device"""
+        self.K.zfilter_stats(self.running_sum, self.running_sumsq, self.count, self.eps,
+                             self._mean, self._std)
+        return self._mean, self._std
+
+    def forward(self, inputs):                   # z_filter.py:59-79
+        if inputs is None:
+            return None
+        shape = inputs.shape
+        x = inputs.reshape(-1, shape[-1]).contiguous()
+        self.refresh_stats()
+        out = torch.empty_like(x)
+        self.K.zfilter_forward(x, self._mean, self._std, out)
+        return out.view(shape)
+
+    def z_update(self, x, count_rows=None):      # z_filter.py:44-57
+        """x: [rows, in_size] (a strided 2-D view is fine) or [B, T, in_size]"""
+        if x is None:
+            return
+        if x.dim() == 3:
+            x = x.reshape(-1, self.in_size)
+        self.K.zfilter_update(x, self.running_sum, self.running_sumsq, self.count,
+                              x.shape[0] if count_rows is None else count_rows)
+
+    def running_mean(self):                      # z_filter.py:81-88
+        return (self.running_sum / self.count).cpu().numpy()
+
+    def running_std(self):                       # z_filter.py:90-98
+        return ((self.running_sumsq / self.count)
+                - (self.running_sum / self.count).pow(2)).pow(0.5).cpu().numpy()
+
+    def running_square(self):                    # z_filter.py:100-107
+        return (self.running_sumsq / self.count).cpu().numpy()
+
+    def state_dict(self):
+        return collections.OrderedDict(running_sum=self.running_sum, running_sumsq=self.running_sumsq,
+                                       count=self.count)
+
+    def load_state_dict(self, sd):
+        for k in ('running_sum', 'running_sumsq', 'count'):
+            getattr(self, k).copy_(torch.as_tensor(np.asarray(sd[k].cpu() if torch.is_tensor(sd[k])
+                                                              else sd[k]), dtype=torch.float32))
+
+
+class Mlp3Params(object):
+    """views of one three-layer MLP inside a flat parameter buffer + its C descriptor"""
+
+    def __init__(self, flat, offset, D, H1, H2, OUT):
+        self.D, self.H1, self.H2, self.OUT = D, H1, H2, OUT
+        sizes = [('W1', (H1, D)), ('b1', (H1,)), ('W2', (H2, H1)), ('b2', (H2,)),
+                 ('W3', (OUT, H2)), ('b3', (OUT,))]
+        self.views = collections.OrderedDict()
+        o = offset
+        for name, shp in sizes:
+            n = int(np.prod(shp))
+            self.views[name] = flat[o:o + n].view(*shp)
+            o += n
+        self.numel = o - offset
+        self.offset = offset
+        self.desc = L.Mlp3(*(ctypes.c_void_p(self.views[k].data_ptr())
+                             for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')), D, H1, H2, OUT)
+
+    @staticmethod
+    def count(D, H1, H2, OUT):
+        return H1 * D + H1 + H2 * H1 + H2 + OUT * H2 + OUT
+
+
+class PPOModel(object):
+    """
+    Actor + critic + z-filter with the reference constructor signature (ppo_net.py:110-118).
+    Round-1 scope: low-dimensional observations, MLP policy (if_rnn_policy False,
+    if_pixel_input False); the LSTM / CNN stems raise NotImplementedError.
+    """
+
+    def __init__(self, obs_spec, action_dim, model_config, use_cuda=True, init_log_sig=0,
+                 use_z_filter=False, if_pixel_input=False, rnn_config=None, device=None,
+                 kernels=None):
+        self.K = kernels or KN.default_kernels()     # raises without the HIP library / a GPU
+        device = device or KN.default_device()
+        if if_pixel_input:
+            raise NotImplementedError('pixel (CNN stem) observations are not built yet')
+        if rnn_config is not None and rnn_config.get('if_rnn_policy', False):
+            raise NotImplementedError('LSTM stem (if_rnn_policy=True) is not built yet; set '
+                                      'learner_config.algo.rnn.if_rnn_policy = False')
+        self.obs_spec = obs_spec
+        self.action_dim = action_dim
+        self.model_config = model_config
+        self.use_z_filter = use_z_filter
+        self.init_log_sig = init_log_sig
+        self.if_pixel_input = if_pixel_input
+        self.rnn_config = rnn_config
+        self.device = device
+        self.low_dim = 0
+        if 'low_dim' in obs_spec.keys():
+            for key in obs_spec['low_dim'].keys():
+                self.low_dim += obs_spec['low_dim'][key][0]
+        D, A = self.low_dim, action_dim
+        ah, ch = model_config['actor_fc_hidden_sizes'], model_config['critic_fc_hidden_sizes']
+        n_actor = Mlp3Params.count(D, ah[0], ah[1], A) + A
+        n_critic = Mlp3Params.count(D, ch[0], ch[1], 1)
+        self.actor_flat = torch.empty(n_actor, device=device)
+        self.critic_flat = torch.empty(n_critic, device=device)
+        self.actor = Mlp3Params(self.actor_flat, 0, D, ah[0], ah[1], A)
+        self.critic = Mlp3Params(self.critic_flat, 0, D, ch[0], ch[1], 1)
+        self.log_var = self.actor_flat[self.actor.numel:self.actor.numel + A].view(1, A)
+        self._init_parameters()
+        if use_z_filter:
+            assert self.low_dim > 0, 'No low dimensional input, please turn off z-filter'
+            self.z_filter = ZFilter(obs_spec, device=device, kernels=self.K)
+
+    def _init_parameters(self):
+        # torch.nn.Linear default: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (torchx's own init is
+        # unknown -- source absent; parity tests always inject parameters)
+        for net in (self.actor, self.critic):
+            for name, v in net.views.items():
+                fan_in = net.views['W' + name[1]].shape[1]
+                v.uniform_(-1.0 / np.sqrt(fan_in), 1.0 / np.sqrt(fan_in))
+        self.log_var.fill_(float(self.init_log_sig))
+
+    # ---- canonical parameter dict (names shared with the oracle / synthetic generator) ----
+    def named_parameters(self):
+        out = collections.OrderedDict()
+        for net, pre in ((self.actor, 'actor'), (self.critic, 'critic')):
+            for i in (1, 2, 3):
+                out['%s.fc%d.W' % (pre, i)] = net.views['W%d' % i]
+                out['%s.fc%d.b' % (pre, i)] = net.views['b%d' % i]
+            if pre == 'actor':
+                out['actor.log_var'] = self.log_var
+        return out
+
+    def load_params(self, params):
+        with torch.no_grad():
+            for k, v in self.named_parameters().items():
+                v.copy_(torch.as_tensor(np.asarray(params[k]), dtype=torch.float32).view(v.shape))
+
+    def numpy_params(self):
+        return collections.OrderedDict((k, v.detach().cpu().numpy().copy())
+                                       for k, v in self.named_parameters().items())
+
+    def state_dict(self):
+        sd = collections.OrderedDict(self.named_parameters())
+        if self.use_z_filter:
+            for k, v in self.z_filter.state_dict().items():
+                sd['z_filter.' + k] = v
+        return sd
+
+    def load_state_dict(self, sd):
+        self.load_params({k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in sd.items()
+                          if not k.startswith('z_filter.')})
+        if self.use_z_filter:
+            self.z_filter.load_state_dict({k[len('z_filter.'):]: v for k, v in sd.items()
+                                           if k.startswith('z_filter.')})
+
+    def get_actor_params(self):                  # ppo_net.py:202-212
+        return [self.actor_flat]
+
+    def get_critic_params(self):                 # ppo_net.py:214-224
+        return [self.critic_flat]
+
+    def update_target_params(self, net):         # ppo_net.py:226-242
+        self.actor_flat.copy_(net.actor_flat)
+        self.critic_flat.copy_(net.critic_flat)
+        if self.use_z_filter:
+            self.z_filter.load_state_dict(net.z_filter.state_dict())
+
+    def update_target_z_filter(self, net):       # ppo_net.py:244-251
+        if self.use_z_filter:
+            self.z_filter.load_state_dict(net.z_filter.state_dict())
+
+    def _gather_low_dim_input(self, obs):        # ppo_net.py:168-178
+        if 'low_dim' not in obs.keys():
+            return None
+        parts = [obs['low_dim'][k] for k in obs['low_dim'].keys()]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, -1)
+
+    def _mlp(self, net, x, out_act):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        rows = x2.shape[0]
+        h1 = torch.empty(rows, net.H1, device=x.device)
+        h2 = torch.empty(rows, net.H2, device=x.device)
+        out = torch.empty(rows, net.OUT, device=x.device)
+        self.K.mlp3_forward(net, x2, h1, h2, out, out_act)
+        return out, shape
+
+    def forward_actor(self, obs, cells=None):    # ppo_net.py:253-282, builders.py:114-132
+        x = self._gather_low_dim_input(obs)
+        if self.use_z_filter:
+            x = self.z_filter.forward(x)
+        mean, shape = self._mlp(self.actor, x, L.SMX_ACT_TANH)
+        std = torch.exp(self.log_var) * torch.ones_like(mean)
+        action = torch.cat((mean, std), dim=1)
+        if len(shape) == 3:
+            action = action.view(shape[0], shape[1], -1)
+        return action
+
+    def forward_critic(self, obs, cells=None):   # ppo_net.py:284-315, builders.py:159-175
+        x = self._gather_low_dim_input(obs)
+        if self.use_z_filter:
+            x = self.z_filter.forward(x)
+        v, shape = self._mlp(self.critic, x, L.SMX_ACT_NONE)
+        if len(shape) == 3:
+            v = v.view(shape[0], shape[1], 1)
+        return v
+
+    def forward_actor_expose_cells(self, obs, cells=None):   # ppo_net.py:317-354
+        return self.forward_actor(obs, cells), cells
+
+    def z_update(self, obs):                     # ppo_net.py:356-366
+        if not self.use_z_filter:
+            raise ValueError('Z_update called when network is set to not use z_filter')
+        self.z_filter.z_update(self._gather_low_dim_input(obs))

@@ -1,0 +1,322 @@
+"""
+TEST DOUBLE (tests only): a torch-CPU emulation of every entry point behind
+surreal_amd.kernels.HipKernels, with the same in/out tensor contract as the C ABI
+(include/surreal_amd.h).  It exists so that the host logic of the product -- epoch control,
+the device-side early-exit protocol, statistics slots, sharding + all-reduce across ranks --
+can be exercised without a GPU (``-m "not gpu"`` tier and the world_size-2 gloo tests), and it
+doubles as an executable statement of each kernel's contract for the GPU parity tests.
+
+It is never importable from the product package and the product never selects it.
+"""
+import math
+
+import numpy as np
+import torch
+
+from surreal_amd import _lib as L
+
+
+def _f(x):
+    return torch.as_tensor(x, dtype=torch.float32)
+
+
+class TorchCpuKernels(object):
+    name = 'torch-cpu-double'
+
+    # ---- z-filter -----------------------------------------------------------------------
+    def zfilter_stats(self, rs, rsq, cnt, eps, mean_out, std_out):
+        mean = rs / cnt
+        std = torch.clamp((rsq / cnt - mean.pow(2)).pow(0.5), min=eps)
+        mean_out.copy_(mean)
+        std_out.copy_(std)
+
+    def zfilter_forward(self, x_view, mean, std, out):
+        out.copy_(torch.clamp((x_view - mean) / std, -5.0, 5.0))
+
+    def zfilter_update(self, x_view, rs, rsq, cnt, count_rows):
+        rs += torch.sum(x_view, dim=0)
+        rsq += torch.sum(x_view * x_view, dim=0)
+        cnt += float(count_rows)
+
+    # ---- MLP ----------------------------------------------------------------------------
+    def mlp3_packed_numel(self, net):
+        return net.numel          # opaque to the caller
+
+    def mlp3_pack(self, net, packed):
+        o = 0
+        for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'):
+            n = net.views[k].numel()
+            packed[o:o + n].copy_(net.views[k].reshape(-1))
+            o += n
+
+    @staticmethod
+    def _unpack(packed, net):
+        out, o = {}, 0
+        for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'):
+            n = net.views[k].numel()
+            out[k] = packed[o:o + n].view(net.views[k].shape)
+            o += n
+        return out
+
+    @staticmethod
+    def _act(x, act):
+        if act == L.SMX_ACT_RELU:
+            return torch.relu(x)
+        if act == L.SMX_ACT_TANH:
+            return torch.tanh(x)
+        return x
+
+    def mlp3_forward_fused(self, packed, net, x_main, x_tail, zmean, zstd, out, act):
+        x = x_main if x_tail is None else torch.cat([x_main, x_tail], dim=1)
+        x = x.reshape(-1, x.shape[-1])
+        if zmean is not None:
+            x = torch.clamp((x - zmean) / zstd, -5.0, 5.0)
+        w = self._unpack(packed, net)
+        h = torch.relu(torch.nn.functional.linear(x, w['W1'], w['b1']))
+        h = torch.relu(torch.nn.functional.linear(h, w['W2'], w['b2']))
+        y = self._act(torch.nn.functional.linear(h, w['W3'], w['b3']), act)
+        out.view(-1, net.OUT).copy_(y)
+
+    def mlp3_forward(self, net, x, h1, h2, out, act, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        v = net.views
+        h1.copy_(torch.relu(torch.nn.functional.linear(x, v['W1'], v['b1'])))
+        h2.copy_(torch.relu(torch.nn.functional.linear(h1, v['W2'], v['b2'])))
+        out.copy_(self._act(torch.nn.functional.linear(h2, v['W3'], v['b3']), act))
+
+    def mlp3_backward_partials(self, net):
+        t = lambda a: (a + 31) // 32  # noqa: E731
+        return t(net.H1) * t(net.D) + t(net.H2) * t(net.H1) + t(net.OUT) * t(net.H2)
+
+    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        v = net.views
+        dz2.copy_((dz3 @ v['W3']) * (h2 > 0))
+        dz1.copy_((dz2 @ v['W2']) * (h1 > 0))
+        pieces = [dz1.t() @ x, dz1.sum(0), dz2.t() @ h1, dz2.sum(0), dz3.t() @ h2, dz3.sum(0)]
+        flat = torch.cat([p.reshape(-1) for p in pieces])
+        grads[:flat.numel()].copy_(flat)
+        if sumsq is not None:
+            n = self.mlp3_backward_partials(net)
+            sumsq[:n].zero_()
+            sumsq[0] = float((flat.double() ** 2).sum())
+
+    # ---- GAE / normalisation ------------------------------------------------------------
+    def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret):
+        v = values.view(B, N + 1).clone()
+        v[:, 1:] *= 1 - dones
+        tds = rewards + gamma * v[:, 1:] - v[:, :-1]
+        E = N - H + 1
+        g, l = gpow[:H], lpow[:H]
+        r_out, a_out = torch.zeros(B, E), torch.zeros(B, E)
+        for s in range(E):
+            r_out[:, s] = torch.sum(g * rewards[:, s:s + H], 1) + v[:, s + H] * gamma_H
+            a_out[:, s] = torch.sum(tds[:, s:s + H] * g * l, 1)
+        adv.view(B, E).copy_(a_out)
+        ret.view(B, E).copy_(r_out)
+
+    def moments(self, x, out):
+        xd = x.double().reshape(-1)
+        mean = xd.mean()
+        out.copy_(_f([xd.numel(), float(mean), float(((xd - mean) ** 2).sum())]))
+
+    def moments_merge(self, parts, out):
+        n = mean = m2 = 0.0
+        for nb, mb, qb in parts.view(-1, 3).double().tolist():
+            if nb <= 0:
+                continue
+            nt, d = n + nb, mb - mean
+            m2 += qb + d * d * n * nb / nt
+            mean += d * nb / nt
+            n = nt
+        out.copy_(_f([n, mean, m2]))
+
+    def adv_normalize(self, x, mom, min_std):
+        n, mean, m2 = mom[0], mom[1], mom[2]
+        std = torch.sqrt(m2 / (n - 1.0))
+        den = _f(min_std) if min_std > float(std) else std
+        x.copy_((x - mean) / den)
+
+    # ---- losses -------------------------------------------------------------------------
+    def loss_blocks(self, rows):
+        return (rows + 63) // 64
+
+    def policy_loss(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                    partials):
+        ci = ctrl.view(torch.int32)
+        if int(ci[L.C_STOP]) != 0:
+            return
+        rows, A = mean.shape
+        sig = torch.exp(log_var).view(1, A)
+        mb, sb = behave[:, :A], behave[:, A:]
+        mr, sr = ref[:, :A], ref[:, A:]
+        c = 0.5 * np.log(2.0 * np.pi) * A
+
+        def ll(mu, s):
+            return -0.5 * (((actions - mu) / s) ** 2).sum(1) - c - torch.log(s).expand(rows, A).sum(1)
+
+        el = torch.exp(ll(mean, sig))
+        Ll = torch.clamp(el, min=1e-5)
+        Lb = torch.clamp(torch.exp(ll(mb, sb)), min=1e-5)
+        kl = torch.log(sig / sr).sum(1) + ((sr ** 2 + (mr - mean) ** 2) / (2.0 * sig ** 2)).sum(1) - 0.5 * A
+        klb = torch.log(sb / sr).sum(1) + ((sr ** 2 + (mr - mb) ** 2) / (2.0 * sb ** 2)).sum(1) - 0.5 * A
+        ad = adv.view(-1)
+        if mode == L.SMX_PPO_CLIP:
+            eps = float(ctrl[L.C_CLIP_EPS])
+            ratio = Ll / Lb
+            cr = torch.clamp(ratio, 1 - eps, 1 + eps)
+            surr, cs = -ratio * ad, -cr * ad
+            loss_r = torch.maximum(surr, cs)
+            dLl = torch.where(surr >= cs, -ad / Lb, torch.zeros_like(ad))
+        else:
+            Lbc = torch.clamp(Lb, min=1e-2)
+            surr = -(ad * (Ll / Lbc))
+            loss_r = surr
+            dLl = -ad / Lbc
+        dll = torch.where(el >= 1e-5, dLl * el, torch.zeros_like(el))
+        dt = 1.0 - mean ** 2
+        g_surr.copy_(dll.view(-1, 1) * ((actions - mean) / sig ** 2) * dt)
+        g_kl.copy_(((mean - mr) / sig ** 2) * dt)
+        z2 = ((actions - mean) / sig) ** 2
+        gs = dll.view(-1, 1) * (z2 - 1.0)
+        gk = 1.0 - (sr ** 2 + (mr - mean) ** 2) / sig ** 2
+        isw = Ll / (Lb + 1e-4)
+        nblk = self.loss_blocks(rows)
+        partials.zero_()
+        for b in range(nblk):
+            sl = slice(64 * b, min(64 * (b + 1), rows))
+            partials[b, 0] = surr[sl].sum()
+            partials[b, 1] = loss_r[sl].sum()
+            partials[b, 2] = kl[sl].sum()
+            partials[b, 3] = Lb[sl].sum()
+            partials[b, 4] = isw[sl].sum()
+            partials[b, 5] = klb[sl].sum()
+            partials[b, 8:8 + A] = gs[sl].sum(0)
+            partials[b, 8 + A:8 + 2 * A] = gk[sl].sum(0)
+
+    def policy_finalize(self, mode, partials, nblk, g_surr, g_kl, log_var, n_total, ctrl,
+                        check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats):
+        ci = ctrl.view(torch.int32)
+        if int(ci[L.C_STOP]) != 0:
+            return
+        rows, A = g_surr.shape
+        S = partials[:nblk].sum(0)
+        n = float(n_total)
+        surr_mean, kl_mean = S[0] / n, S[2] / n
+        c_kl = 0.0
+        if mode == L.SMX_PPO_CLIP:
+            loss = S[1] / n
+        else:
+            beta, eta, kt = float(ctrl[L.C_BETA]), float(ctrl[L.C_ETA]), float(ctrl[L.C_KL_TARGET])
+            loss = surr_mean + beta * kl_mean
+            c_kl = beta
+            if float(kl_mean) - 2.0 * kt > 0:
+                d = kl_mean - _f(2.0 * kt)
+                loss = loss + eta * (d * d)
+                c_kl = c_kl + 2.0 * eta * float(d)
+        dz3.copy_((g_surr + c_kl * g_kl) / n)
+        gl = (S[8:8 + A] + c_kl * S[8 + A:8 + 2 * A]) / n
+        dlogvar.copy_(gl)
+        if dlogvar_sumsq is not None:
+            dlogvar_sumsq.copy_((gl * gl).sum().view(1))
+        stats[L.PS_SURR] = surr_mean
+        stats[L.PS_LOSS] = loss
+        stats[L.PS_ENTROPY] = 0.5 * torch.log(torch.exp(log_var)).sum() + .5 * np.log(2 * np.pi * np.e) * A
+        stats[L.PS_KL] = kl_mean
+        stats[L.PS_LB] = S[3] / n
+        stats[L.PS_ISW] = S[4] / n
+        stats[L.PS_REFBEH] = S[5] / n
+        if check_stop and float(kl_mean) > 4.0 * float(ctrl[L.C_KL_TARGET]):
+            ci[L.C_STOP] = 1
+        elif will_update:
+            ci[L.C_STEP_ACTOR] += 1
+            ci[L.C_EPOCHS_DONE] += 1
+
+    def value_loss_blocks(self, rows):
+        return (rows + 255) // 256
+
+    def value_loss(self, values, returns, n_total, dz3, partials, ctrl, will_update):
+        v, g = values.view(-1), returns.view(-1)
+        rows = v.numel()
+        dz3.view(-1).copy_(2.0 * (v - g) / float(n_total))
+        d = g - v
+        for b in range(self.value_loss_blocks(rows)):
+            sl = slice(256 * b, min(256 * (b + 1), rows))
+            db, gb = d[sl].double(), g[sl].double()
+            partials[b] = _f([db.numel(), db.mean(), ((db - db.mean()) ** 2).sum(), gb.mean(),
+                              ((gb - gb.mean()) ** 2).sum(), (db ** 2).sum(), 0, 0])
+        if will_update:
+            ctrl.view(torch.int32)[L.C_STEP_CRITIC] += 1
+
+    def value_finalize(self, partials, count, nblk, stats, stride):
+        for e in range(count):
+            n = md = qd = mg = qg = sq = 0.0
+            for row in partials[e, :nblk].double().tolist():
+                nb = row[0]
+                if nb <= 0:
+                    continue
+                nt = n + nb
+                dl = row[1] - md
+                qd += row[2] + dl * dl * n * nb / nt
+                md += dl * nb / nt
+                dl = row[3] - mg
+                qg += row[4] + dl * dl * n * nb / nt
+                mg += dl * nb / nt
+                sq += row[5]
+                n = nt
+            stats[e, L.VS_LOSS] = sq / n
+            stats[e, L.VS_EXPVAR] = 1.0 - (qd / (n - 1.0)) / (qg / (n - 1.0)) if n > 1 else float('nan')
+
+    # ---- optimiser ----------------------------------------------------------------------
+    def clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out):
+        ci = ctrl.view(torch.int32)
+        if honour_stop and int(ci[L.C_STOP]) != 0:
+            return
+        norm = torch.sqrt(sumsq[:npart].sum())
+        max_norm = float(ctrl[L.C_CRITIC_MAX_NORM if which else L.C_ACTOR_MAX_NORM])
+        coef = 1.0
+        if max_norm > 0:
+            coef = min(max_norm / (float(norm) + 1e-6), 1.0)
+        if grad_norm_out is not None:
+            grad_norm_out.copy_(norm.view(1))
+        step = int(ci[L.C_STEP_CRITIC if which else L.C_STEP_ACTOR])
+        lr = float(ctrl[L.C_LR_CRITIC if which else L.C_LR_ACTOR])
+        wd = float(ctrl[L.C_CRITIC_WD if which else L.C_ACTOR_WD])
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        g = grads * coef
+        if wd != 0:
+            g = g + wd * theta
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        theta.addcdiv_(m, denom, value=-(lr / bc1))
+
+    def sumsq_blocks(self, n):
+        return max(1, min(256, (n + 4095) // 4096))
+
+    def sumsq_partials(self, x, partials):
+        nb = self.sumsq_blocks(x.numel())
+        partials[:nb].zero_()
+        partials[0] = (x.double() ** 2).sum()
+
+    # ---- replay / windowing ---------------------------------------------------------------
+    def ring_insert(self, table, cursor, src):
+        cap = table.shape[0]
+        idx = (int(cursor) + torch.arange(src.shape[0])) % cap
+        table[idx] = src
+
+    def gather_rows(self, table, idx, dst):
+        dst.copy_(table[idx.clamp(0, table.shape[0] - 1)])
+
+    def uniform_indices(self, idx, length, seed, offset):
+        g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2 ** 63))
+        idx.copy_(torch.randint(0, int(length), idx.shape, generator=g))
+
+    def window_emit(self, src, n_step, stride, dst):
+        actors, T, width = src.shape
+        W = (T - n_step) // stride + 1
+        out = torch.stack([src[:, w * stride:w * stride + n_step] for w in range(W)], 1)
+        dst.view(actors, W, n_step, width).copy_(out)
