@@ -1,0 +1,3 @@
+from .base import Learner
+from .aggregator import MultistepAggregatorWithInfo, SSARAggregator
+from .ppo import PPOLearner

@@ -234,7 +234,7 @@ class PPOLearner(Learner):
         self._ctrl_host = None
         # critic pass + GAE
         ws.packed = f(K.mlp3_packed_numel(cri))
-        ws.values = f(B * (N + 1))
+        ws.vals = f(B * (N + 1))
         ws.adv = f(B * E)
         ws.ret = f(B * E)
         idx = torch.tensor(range(N), dtype=torch.float32)
@@ -323,8 +323,8 @@ class PPOLearner(Learner):
         if self.use_z_filter:
             zm, zs = m.z_filter.refresh_stats()
         K.mlp3_pack(m.critic, ws.packed)
-        K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.values, L.SMX_ACT_NONE)
-        K.gae(ws.values, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N, B, N, N,
+        K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.vals, L.SMX_ACT_NONE)
+        K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N, B, N, N,
               ws.adv, ws.ret)
         if self.norm_adv:
             K.moments(ws.adv, ws.adv_mom)

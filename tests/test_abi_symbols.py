@@ -1,0 +1,78 @@
+"""CPU tier: the C-ABI library builds/loads and exports every symbol include/surreal_amd.h
+declares (no compute calls -- there is no GPU here), and the product refuses to run without
+its HIP extension instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'surreal_amd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(smx_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from surreal_amd import build, _lib
+    lib_path = build.build(verbose=False)          # hipcc cross-compiles without a GPU
+    lib = ctypes.CDLL(lib_path)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), 'include/surreal_amd.h declares %s but the .so does not export it' % n
+    # and the ctypes binding covers exactly the header
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    assert _lib.load().smx_abi_version() == 1
+
+
+def test_ctrl_struct_layout_matches_binding():
+    """smx_ppo_ctrl_t is addressed as 16 4-byte words from Python"""
+    src = open(os.path.join(ROOT, 'include', 'surreal_amd.h')).read()
+    end = src.index('} smx_ppo_ctrl_t;')
+    body = src[src.rindex('typedef struct {', 0, end) + len('typedef struct {'):end]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1]
+        for nm in names.split(','):
+            nm = nm.strip()
+            m = re.match(r'(\w+)\[(\d+)\]', nm)
+            fields += [m.group(1)] * int(m.group(2)) if m else [nm]
+    from surreal_amd import _lib as L
+    assert len(fields) == L.CTRL_WORDS
+    assert fields[L.C_LR_ACTOR] == 'lr_actor' and fields[L.C_KL_TARGET] == 'kl_target'
+    assert fields[L.C_STEP_ACTOR] == 'adam_step_actor' and fields[L.C_STOP] == 'stop_flag'
+    assert fields[L.C_EPOCHS_DONE] == 'epochs_done'
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from surreal_amd import _lib, kernels
+    with pytest.raises(_lib.SmxError):
+        kernels.HipKernels()
+    import helpers as H
+    g, case = H.load_golden('tiny_clip')
+    _, params, z = H.case_inputs(case)
+    with pytest.raises(_lib.SmxError):
+        H.make_learner(case, params, z)
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'surreal_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+(oracle|ppo_oracle|ref_shims|cpu_kernels)\b', txt, re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -1,0 +1,343 @@
+"""GPU tier (-m gpu): every HIP entry point, called through the C ABI, against the torch-CPU
+statement of the same contract (tests/cpu_kernels.py) on identical seeded inputs.
+Tolerance: 1e-5 absolute + 1e-5 relative (fp32), the north-star bound."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from surreal_amd import _lib as L
+from cpu_kernels import TorchCpuKernels
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-5, 1e-5
+
+
+@pytest.fixture(scope='module')
+def K():
+    from surreal_amd.kernels import HipKernels
+    return HipKernels()
+
+
+C = TorchCpuKernels()
+
+
+def dev(t):
+    return t.cuda() if torch.is_tensor(t) else t
+
+
+def close(a, b, atol=ATOL, rtol=RTOL, msg=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, err_msg=msg)
+
+
+def make_net(D, H1, H2, OUT, seed, device):
+    from surreal_amd.model.ppo_net import Mlp3Params
+    g = torch.Generator().manual_seed(seed)
+    n = Mlp3Params.count(D, H1, H2, OUT)
+    flat = (torch.rand(n, generator=g) * 2 - 1)
+    net_c = Mlp3Params(flat.clone(), 0, D, H1, H2, OUT)
+    for nm, v in net_c.views.items():
+        fan = net_c.views['W' + nm[1]].shape[1]
+        v.mul_(1.0 / np.sqrt(fan))
+    flat_d = torch.cat([v.reshape(-1) for v in net_c.views.values()]).to(device)
+    net_d = Mlp3Params(flat_d, 0, D, H1, H2, OUT)
+    return net_c, net_d
+
+
+# ------------------------------------------------------------------------------------------
+def test_zfilter(K):
+    g = torch.Generator().manual_seed(0)
+    for D, rows, T in ((17, 64, 5), (376, 1000, 3), (5, 7, 1)):
+        x3 = torch.randn(rows, T, D, generator=g) * 3 + 0.5
+        rs = torch.randn(D, generator=g) * 100
+        rsq = torch.rand(D, generator=g) * 5000 + 300
+        cnt = torch.tensor([1000.0 + 1e-5])
+        mc, sc = torch.empty(D), torch.empty(D)
+        md, sd = torch.empty(D).cuda(), torch.empty(D).cuda()
+        C.zfilter_stats(rs, rsq, cnt, 1e-5, mc, sc)
+        K.zfilter_stats(dev(rs), dev(rsq), dev(cnt), 1e-5, md, sd)
+        close(md, mc), close(sd, sc)
+        xv_c, x3d = x3[:, 0, :], x3.cuda()
+        oc, od = torch.empty(rows, D), torch.empty(rows, D).cuda()
+        C.zfilter_forward(xv_c, mc, sc, oc)
+        K.zfilter_forward(x3d[:, 0, :], md, sd, od)          # strided view: ldx = T*D
+        close(od, oc, msg='zforward D=%d' % D)
+        rs_d, rsq_d, cnt_d = dev(rs.clone()), dev(rsq.clone()), dev(cnt.clone())
+        C.zfilter_update(xv_c, rs, rsq, cnt, rows)
+        K.zfilter_update(x3d[:, 0, :], rs_d, rsq_d, cnt_d, rows)
+        close(rs_d, rs, rtol=1e-5, atol=1e-3), close(rsq_d, rsq, rtol=1e-5, atol=1e-2), close(cnt_d, cnt)
+
+
+@pytest.mark.parametrize('B,N,H', [(8, 12, 12), (37, 19, 19), (1024, 128, 128), (5, 25, 5),
+                                   (64, 128, 5), (3, 200, 1), (2, 1, 1)])
+def test_windowed_gae(K, B, N, H):
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    values = torch.randn(B * (N + 1), generator=g) * 3
+    rewards = torch.randn(B, N, generator=g)
+    dones = (torch.rand(B, N, generator=g) < 0.1).float()
+    idx = torch.tensor(range(N), dtype=torch.float32)
+    gpow, lpow = torch.pow(0.995, idx), torch.pow(0.97, idx)
+    E = N - H + 1
+    ac, rc = torch.empty(B * E), torch.empty(B * E)
+    ad, rd = torch.empty(B * E).cuda(), torch.empty(B * E).cuda()
+    C.gae(values, rewards, dones, gpow, lpow, 0.995, 0.995 ** H, B, N, H, ac, rc)
+    K.gae(dev(values), dev(rewards), dev(dones), dev(gpow), dev(lpow), 0.995, 0.995 ** H, B, N, H, ad, rd)
+    close(ad, ac, msg='adv'), close(rd, rc, msg='ret')
+    # size-independent property: linearity in the rewards (values = 0, no dones) and the
+    # telescoping identity adv = ret - V_0 when lambda = 1
+    one = torch.ones(N)
+    zeros = torch.zeros(B * (N + 1)).cuda()
+    if H == N:
+        K.gae(dev(values), dev(rewards), torch.zeros(B, N).cuda(), dev(gpow), dev(one), 0.995,
+              0.995 ** N, B, N, N, ad, rd)
+        v0 = values.view(B, N + 1)[:, 0]
+        close(ad.cpu(), rd.cpu() - v0, atol=2e-5, rtol=1e-5, msg='lambda=1 telescoping')
+
+
+def test_moments_and_normalize(K):
+    g = torch.Generator().manual_seed(3)
+    for n in (2, 37, 1024, 127000):
+        x = torch.randn(n, generator=g) * 2.5 + 7.0
+        mc, md = torch.empty(3), torch.empty(3).cuda()
+        C.moments(x, mc)
+        K.moments(dev(x), md)
+        close(md, mc, rtol=1e-6)
+        np.testing.assert_allclose(float(torch.sqrt(md[2] / (n - 1))), float(x.std()), rtol=2e-6)
+        xc, xd = x.clone(), dev(x.clone())
+        C.adv_normalize(xc, mc, 1e-4)
+        K.adv_normalize(xd, md, 1e-4)
+        close(xd, xc)
+        close(xd.cpu(), (x - x.mean()) / max(x.std(), 1e-4), atol=2e-5)
+    # tiny spread -> the 1e-4 floor is used (ppo.py:405)
+    x = torch.full((16,), 3.0) + torch.arange(16) * 1e-7
+    md = torch.empty(3).cuda()
+    K.moments(dev(x), md)
+    xd = dev(x.clone())
+    K.adv_normalize(xd, md, 1e-4)
+    close(xd.cpu(), (x - x.mean()) / 1e-4, atol=1e-4)
+    # merge of per-rank moments == moments of the concatenation
+    a, b = torch.randn(300, generator=g), torch.randn(77, generator=g) * 4 + 1
+    parts = torch.empty(2, 3).cuda()
+    K.moments(dev(a), parts[0]), K.moments(dev(b), parts[1])
+    out, full = torch.empty(3).cuda(), torch.empty(3).cuda()
+    K.moments_merge(parts, out)
+    K.moments(dev(torch.cat([a, b])), full)
+    close(out, full, rtol=2e-6)
+
+
+@pytest.mark.parametrize('rows,D,H1,H2,OUT,act', [
+    (8, 11, 24, 16, 3, L.SMX_ACT_TANH), (37, 29, 40, 24, 5, L.SMX_ACT_TANH),
+    (64, 17, 300, 200, 6, L.SMX_ACT_TANH), (1024, 376, 300, 200, 17, L.SMX_ACT_TANH),
+    (1024, 376, 300, 200, 1, L.SMX_ACT_NONE), (33, 100, 300, 200, 1, L.SMX_ACT_NONE)])
+def test_mlp3_forward_backward(K, rows, D, H1, H2, OUT, act):
+    nc, nd = make_net(D, H1, H2, OUT, rows + D, 'cuda')
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g)
+    mk = lambda *s: (torch.empty(*s), torch.empty(*s).cuda())  # noqa: E731
+    (h1c, h1d), (h2c, h2d), (oc, od) = mk(rows, H1), mk(rows, H2), mk(rows, OUT)
+    C.mlp3_forward(nc, x, h1c, h2c, oc, act)
+    K.mlp3_forward(nd, dev(x), h1d, h2d, od, act)
+    close(h1d, h1c, msg='h1'), close(h2d, h2c, msg='h2'), close(od, oc, msg='out')
+    # A = I style transpose detector: out rows must follow x rows, not mix them
+    dz3 = torch.randn(rows, OUT, generator=g) / rows
+    (dz2c, dz2d), (dz1c, dz1d) = mk(rows, H2), mk(rows, H1)
+    n = nc.numel
+    gc, gd = torch.zeros(n), torch.zeros(n).cuda()
+    npart = K.mlp3_backward_partials(nd)
+    assert npart == C.mlp3_backward_partials(nc)
+    sc, sd = torch.zeros(npart), torch.zeros(npart).cuda()
+    C.mlp3_backward(nc, x, h1c, h2c, dz3, dz2c, dz1c, gc, sc)
+    K.mlp3_backward(nd, dev(x), h1d, h2d, dev(dz3), dz2d, dz1d, gd, sd)
+    close(dz2d, dz2c, msg='dz2'), close(dz1d, dz1c, msg='dz1')
+    close(gd, gc, atol=2e-6, rtol=2e-5, msg='grads')
+    np.testing.assert_allclose(float(sd.sum()), float(sc.sum()), rtol=1e-5)
+    # stop flag turns both into no-ops
+    stop = torch.ones(1, dtype=torch.int32).cuda()
+    od.fill_(7.0)
+    K.mlp3_forward(nd, dev(x), h1d, h2d, od, act, stop)
+    assert float(od.min()) == 7.0
+
+
+@pytest.mark.parametrize('G,T0,T1,D,H1,H2,OUT,z', [
+    (8, 12, 1, 11, 24, 16, 1, True), (37, 19, 1, 29, 40, 24, 1, True),
+    (5, 7, 0, 16, 64, 64, 6, False), (64, 128, 1, 17, 300, 200, 1, True),
+    (16, 9, 1, 376, 300, 200, 1, True), (9, 25, 0, 100, 300, 200, 17, False),
+    (1, 1, 1, 3, 5, 4, 2, True), (300, 3, 1, 376, 300, 200, 1, False)])
+def test_mlp3_forward_fused(K, G, T0, T1, D, H1, H2, OUT, z):
+    nc, nd = make_net(D, H1, H2, OUT, G + D, 'cuda')
+    g = torch.Generator().manual_seed(G * 7 + T0)
+    xm = torch.randn(G, T0, D, generator=g) * 2 + 0.3
+    xt = torch.randn(G, T1, D, generator=g) if T1 else None
+    zm = (torch.randn(D, generator=g) * 0.3) if z else None
+    zs = (torch.rand(D, generator=g) + 0.5) if z else None
+    act = L.SMX_ACT_NONE if OUT == 1 else L.SMX_ACT_TANH
+    rows = G * (T0 + T1)
+    pc = torch.empty(C.mlp3_packed_numel(nc))
+    C.mlp3_pack(nc, pc)
+    oc = torch.empty(rows * OUT)
+    C.mlp3_forward_fused(pc, nc, xm, xt, zm, zs, oc, act)
+    pd = torch.empty(K.mlp3_packed_numel(nd)).cuda()
+    K.mlp3_pack(nd, pd)
+    od = torch.full((rows * OUT,), float('nan')).cuda()
+    K.mlp3_forward_fused(pd, nd, dev(xm), dev(xt) if T1 else None, dev(zm) if z else None,
+                         dev(zs) if z else None, od, act)
+    close(od, oc, msg='fused mlp G=%d T0=%d T1=%d D=%d' % (G, T0, T1, D))
+
+
+def test_mlp3_forward_fused_full_size_property(K):
+    """BASELINE full size (1024 x 129 rows x 376): the fused kernel must agree with the layered
+    kernels (independent code path) on every row -- no CPU oracle needed at this size."""
+    B, N, D = 1024, 128, 376
+    nc, nd = make_net(D, 300, 200, 1, 99, 'cuda')
+    g = torch.Generator(device='cuda').manual_seed(5)
+    obs = torch.randn(B, N, D, generator=g, device='cuda')
+    obs_next = torch.randn(B, 1, D, generator=g, device='cuda')
+    pd = torch.empty(K.mlp3_packed_numel(nd)).cuda()
+    K.mlp3_pack(nd, pd)
+    out = torch.empty(B * (N + 1)).cuda()
+    K.mlp3_forward_fused(pd, nd, obs, obs_next, None, None, out, L.SMX_ACT_NONE)
+    x = torch.cat([obs, obs_next], 1).reshape(-1, D).contiguous()
+    h1, h2 = torch.empty(x.shape[0], 300).cuda(), torch.empty(x.shape[0], 200).cuda()
+    ref = torch.empty(x.shape[0], 1).cuda()
+    K.mlp3_forward(nd, x, h1, h2, ref, L.SMX_ACT_NONE)
+    close(out, ref.view(-1), msg='fused vs layered at full size')
+
+
+@pytest.mark.parametrize('mode', [L.SMX_PPO_CLIP, L.SMX_PPO_ADAPT])
+@pytest.mark.parametrize('rows,A,on_policy', [(8, 3, True), (37, 5, False), (1024, 17, True), (130, 17, False)])
+def test_policy_loss_and_finalize(K, mode, rows, A, on_policy):
+    g = torch.Generator().manual_seed(rows + A)
+    N = 4
+    log_var = torch.full((A,), -1.0) + 0.1 * torch.randn(A, generator=g)
+    std = torch.exp(log_var)
+    mean = torch.tanh(0.1 * torch.randn(rows, A, generator=g))
+    if on_policy:
+        mb = mean + 0.05 * torch.randn(rows, A, generator=g)
+        act0 = mb + std * torch.randn(rows, A, generator=g)
+    else:
+        mb = torch.tanh(torch.randn(rows, A, generator=g))
+        act0 = torch.randn(rows, A, generator=g).clamp(-1, 1)
+    actions = torch.randn(rows, N, A, generator=g)
+    actions[:, 0] = act0
+    pds = torch.rand(rows, N, 2 * A, generator=g) + 0.2
+    pds[:, 0, :A], pds[:, 0, A:] = mb, std * 1.1
+    ref = torch.cat([mean + 0.02 * torch.randn(rows, A, generator=g), (std * 0.9).expand(rows, A)], 1)
+    adv = torch.randn(rows, generator=g)
+    ctrl = torch.zeros(L.CTRL_WORDS)
+    ctrl[L.C_BETA], ctrl[L.C_ETA], ctrl[L.C_CLIP_EPS], ctrl[L.C_KL_TARGET] = 1.0, 250.0, 0.2, 1e-3
+    ctrl_d = ctrl.clone().cuda()
+    nblk, stride = C.loss_blocks(rows), 8 + 2 * A
+    assert K.loss_blocks(rows) == nblk
+    outs = {}
+    for name, KK, to in (('cpu', C, lambda t: t), ('hip', K, dev)):
+        gs, gk = to(torch.empty(rows, A)), to(torch.empty(rows, A))
+        part = to(torch.zeros(nblk, stride))
+        c = ctrl if name == 'cpu' else ctrl_d
+        KK.policy_loss(mode, to(mean), to(log_var), to(actions)[:, 0, :], to(pds)[:, 0, :], to(ref),
+                       to(adv), c, gs, gk, part)
+        dz3, dlv, dq = to(torch.empty(rows, A)), to(torch.empty(A)), to(torch.empty(1))
+        st = to(torch.zeros(L.PS_STRIDE))
+        KK.policy_finalize(mode, part, nblk, gs, gk, to(log_var), rows, c, True, True, dz3, dlv, dq, st)
+        outs[name] = (gs, gk, part, dz3, dlv, dq, st, c)
+    for i, nm in enumerate(('g_surr', 'g_kl', 'partials', 'dz3', 'dlogvar', 'dlogvar_sumsq', 'stats')):
+        a, b = outs['hip'][i], outs['cpu'][i]
+        tol = 2e-4 if nm == 'partials' else ATOL     # partial SUMS over 64 rows
+        close(a, b, atol=tol, rtol=1e-4 if nm in ('partials', 'dlogvar_sumsq') else RTOL, msg=nm)
+    ci_d, ci_c = outs['hip'][7].cpu().view(torch.int32), outs['cpu'][7].view(torch.int32)
+    assert ci_d.tolist() == ci_c.tolist()           # stop flag / step counters agree
+
+
+def test_value_loss(K):
+    g = torch.Generator().manual_seed(11)
+    for rows in (8, 37, 1024, 1500):
+        v = torch.randn(rows, generator=g) * 2
+        r = torch.randn(rows, generator=g) * 8 + 3
+        nblk = C.value_loss_blocks(rows)
+        res = {}
+        for name, KK, to in (('cpu', C, lambda t: t), ('hip', K, dev)):
+            dz, part = to(torch.empty(rows)), to(torch.zeros(1, nblk, 8))
+            ctrl = to(torch.zeros(L.CTRL_WORDS))
+            KK.value_loss(to(v), to(r), rows, dz, part[0], ctrl, True)
+            st = to(torch.zeros(1, L.VS_STRIDE))
+            KK.value_finalize(part, 1, nblk, st, L.VS_STRIDE)
+            res[name] = (dz, st, ctrl)
+        close(res['hip'][0], res['cpu'][0]), close(res['hip'][1], res['cpu'][1], rtol=1e-5)
+        # against torch's own formulas (ppo.py:325-326)
+        ev = 1 - torch.var(r - v) / torch.var(r)
+        np.testing.assert_allclose(float(res['hip'][1][0, L.VS_EXPVAR]), float(ev), atol=1e-5)
+        np.testing.assert_allclose(float(res['hip'][1][0, L.VS_LOSS]), float(((v - r) ** 2).mean()), rtol=1e-5)
+        assert int(res['hip'][2].cpu().view(torch.int32)[L.C_STEP_CRITIC]) == 1
+
+
+def test_clip_adam_matches_torch_optim(K):
+    """three consecutive steps against torch.optim.Adam + clip_grad_norm_ on CPU"""
+    g = torch.Generator().manual_seed(21)
+    n = 5000
+    theta0 = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(theta0.clone())
+    opt = torch.optim.Adam([p], lr=1e-3, weight_decay=0.0)
+    th, m, v = dev(theta0.clone()), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    ctrl = torch.zeros(L.CTRL_WORDS)
+    ctrl[L.C_LR_ACTOR], ctrl[L.C_ACTOR_MAX_NORM] = 1e-3, 5.0
+    ctrl = ctrl.cuda()
+    ci = ctrl.view(torch.int32)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (0.2 if step == 2 else 0.01)   # step 2 gets clipped
+        p.grad = grad.clone()
+        tn = torch.nn.utils.clip_grad_norm_([p], 5.0)
+        opt.step()
+        ci[L.C_STEP_ACTOR] = step
+        gd = dev(grad)
+        nb = K.sumsq_blocks(n)
+        part = torch.zeros(nb).cuda()
+        K.sumsq_partials(gd, part)
+        gn = torch.zeros(1).cuda()
+        K.clip_adam(th, gd, m, v, part, nb, ctrl, 0, True, gn)
+        np.testing.assert_allclose(float(gn), float(tn), rtol=1e-5)
+        close(th, p.detach(), atol=1e-6, rtol=1e-6, msg='theta after step %d' % step)
+    ci[L.C_STOP] = 1
+    before = th.clone()
+    K.clip_adam(th, gd, m, v, part, nb, ctrl, 0, True, gn)
+    assert torch.equal(before, th)
+
+
+def test_replay_kernels(K):
+    g = torch.Generator().manual_seed(31)
+    for cap, width in ((5, 7), (96, 44), (1000, 376)):
+        table_c = torch.zeros(cap, width)
+        table_d = table_c.clone().cuda()
+        cursor = 0
+        for n in (3, cap // 2 + 1, 2):
+            src = torch.randn(n, width, generator=g)
+            C.ring_insert(table_c, cursor, src)
+            K.ring_insert(table_d, cursor, dev(src))
+            cursor = (cursor + n) % cap
+        assert torch.equal(table_d.cpu(), table_c)           # bit exact: byte copies
+        idx = torch.randint(0, cap, (64,), generator=g)
+        dc, dd = torch.empty(64, width), torch.empty(64, width).cuda()
+        C.gather_rows(table_c, idx, dc)
+        K.gather_rows(table_d, dev(idx), dd)
+        assert torch.equal(dd.cpu(), dc)
+    # uniform indices: in range, reproducible, roughly uniform (distributional parity with
+    # random.randint -- the Python Mersenne stream itself is not reproducible on a GPU)
+    idx = torch.empty(1 << 16, dtype=torch.int64).cuda()
+    K.uniform_indices(idx, 1000, 1234, 0)
+    a = idx.cpu()
+    assert int(a.min()) >= 0 and int(a.max()) < 1000
+    K.uniform_indices(idx, 1000, 1234, 0)
+    assert torch.equal(idx.cpu(), a)
+    counts = torch.bincount(a, minlength=1000).float()
+    assert float(counts.std()) < 3 * np.sqrt(65.5)
+    K.uniform_indices(idx, 1000, 1234, 1 << 16)
+    assert not torch.equal(idx.cpu(), a)
+    # window emission: n_step/stride moving window (exp_sender_wrapper.py:209-228)
+    src = torch.randn(6, 14, 10, generator=g)
+    W = (14 - 5) // 3 + 1
+    dc, dd = torch.empty(6 * W, 5, 10), torch.empty(6 * W, 5, 10).cuda()
+    C.window_emit(src, 5, 3, dc)
+    K.window_emit(dev(src), 5, 3, dd)
+    assert torch.equal(dd.cpu(), dc) and W == 4

@@ -1,0 +1,95 @@
+"""GPU tier (-m gpu): the product PPOLearner on the HIP path against the golden vectors recorded
+from the reference's own CPU learner (tests/golden/, made by oracle/gen_golden.py): advantages,
+returns, raw critic values, every per-epoch loss statistic, the number of policy epochs executed
+before the KL early exit, final statistics, updated parameters, z-filter state.
+Tolerance 1e-5 (abs + rel), fp32 -- BASELINE.json's bound."""
+import copy
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+NON_RNN = H.golden_cases(rnn=False)
+
+
+def run_case(name, session_overrides=None):
+    g, case = H.load_golden(name)
+    batch, params, zstate = H.case_inputs(case)
+    learner = H.make_learner(case, params, zstate, session_overrides=session_overrides)
+    stats = learner.learn(copy.deepcopy(batch))
+    return g, case, learner, stats
+
+
+def check_case(name, g, case, learner, stats):
+    ws = learner._ws
+    np.testing.assert_allclose(ws.adv.cpu().numpy().reshape(g['advantages'].shape), g['advantages'],
+                               atol=H.ATOL, rtol=H.RTOL, err_msg='advantages')
+    np.testing.assert_allclose(ws.ret.cpu().numpy().reshape(g['returns'].shape), g['returns'],
+                               atol=H.ATOL, rtol=H.RTOL, err_msg='returns')
+    B, N = case['shape']['B'], case['shape']['N']
+    vr = ws.vals.cpu().numpy().reshape(B, N + 1)
+    np.testing.assert_allclose(vr[:g['values_raw'].shape[0]], g['values_raw'], atol=H.ATOL,
+                               rtol=H.RTOL, err_msg='raw critic values')
+    H.assert_trace_close(learner.trace, g, what=name)
+    H.assert_stats_close(stats, g, what=name)
+    H.assert_final_params(learner, g, case, what=name)
+    if 'zfinal.count' in g:
+        sd = learner.model.z_filter.state_dict()
+        for k in ('running_sum', 'running_sumsq', 'count'):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g['zfinal.' + k], rtol=2e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize('name', NON_RNN)
+def test_learner_matches_reference_golden_graph(name):
+    """default product configuration: hipGraph replay + value epochs on a side stream"""
+    check_case(name, *run_case(name))
+
+
+@pytest.mark.parametrize('name', ['tiny_adapt_cutoff2', 'ragged_clip', 'cfg2_adapt', 'cfg5_adapt_earlyexit'])
+def test_learner_matches_reference_golden_eager(name):
+    """same numbers without graph capture and without stream overlap"""
+    check_case(name, *run_case(name, {'use_hip_graph': False, 'overlap_value_epochs': False}))
+
+
+def test_three_learns_match_oracle_and_graph_replays():
+    """consecutive learn() calls on device-resident batches: the captured graph is replayed
+    (pointer-stable inputs) and the optimiser state carries over exactly as torch.optim's"""
+    import ppo_oracle
+    g, case = H.load_golden('cfg2_clip')
+    batch, params, zstate = H.case_inputs(case)
+    hyper = dict(case['hyper'])
+    hyper['n_step'] = case['shape']['N']
+    O = ppo_oracle.OraclePPOLearner(params, case['shape']['A'], case['shape']['B'], zstate=zstate, **hyper)
+    learner = H.make_learner(case, params, zstate)
+    dbatch = learner._preprocess_batch_ppo(copy.deepcopy(batch))      # device-resident once
+    for it in range(3):
+        so = O.learn(copy.deepcopy(batch))
+        sl = learner.learn(dbatch)
+        for k in so:
+            if k != '_lr':
+                np.testing.assert_allclose(sl[k], so[k], atol=H.ATOL, rtol=2e-5,
+                                           err_msg='iteration %d stat %s' % (it, k))
+    assert len(learner._graphs) == 1
+
+
+def test_gae_and_return_accessor():
+    g, case = H.load_golden('ragged_clip')
+    batch, params, zstate = H.case_inputs(case)
+    learner = H.make_learner(case, params, zstate)
+    b = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+    adv, ret = learner._gae_and_return(b['obs'], b['obs_next'], b['rewards'], b['dones'])
+    assert tuple(adv.shape) == g['advantages'].shape == (case['shape']['B'], 1)
+    np.testing.assert_allclose(adv.cpu().numpy(), g['advantages'], atol=H.ATOL, rtol=H.RTOL)
+    np.testing.assert_allclose(ret.cpu().numpy(), g['returns'], atol=H.ATOL, rtol=H.RTOL)
+
+
+def test_rnn_policy_is_refused_loudly():
+    g, case = H.load_golden('cfg1_rnn_adapt')
+    _, params, zstate = H.case_inputs(case)
+    with pytest.raises(NotImplementedError):
+        H.make_learner(case, {k: v for k, v in params.items() if not k.startswith('rnn.')}, zstate)
