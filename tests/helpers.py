@@ -9,9 +9,26 @@ from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
-# fp32 parity tolerance of BASELINE.json's north_star: "within 1e-5 fp32"
+# fp32 parity tolerance of BASELINE.json's north_star ("the same advantages / returns / losses
+# as the reference PyTorch CPU learner ... within 1e-5 fp32"): applied to advantages, returns,
+# critic values and every loss / KL / entropy / likelihood statistic.
 ATOL = 1e-5
 RTOL = 1e-5
+# Gradient norms are diagnostics, not losses, and are NOT reproducible to 1e-5 by the reference
+# itself: the reference's own code (oracle, bit-identical inputs) gives grad_norm_critic =
+# 3.7922561 on the build container's Xeon and 3.7923641 on the GPU box's host CPU for epoch 1
+# of cfg5_clip (2.9e-5 relative; the fp64 value is 3.7922557), because one ReLU pre-activation
+# that lands within fp32 rounding of zero flips its mask and with it that row's contribution
+# to the layer-1/2 gradients (measured with scripts/diag_inputs.py / diag_theta1.py; the HIP
+# path reproduces the GPU-box host value to 1.3e-7).  They get a 2e-4 relative bound.
+LOOSE_KEYS = ('grad_norm_actor', 'grad_norm_critic')
+LOOSE_RTOL = 2e-4
+
+
+def tol_for(key, atol, rtol):
+    if key in LOOSE_KEYS:
+        return atol, max(rtol, LOOSE_RTOL)
+    return atol, rtol
 
 
 def golden_cases(rnn=None):
@@ -86,11 +103,13 @@ def assert_trace_close(trace, g, atol=ATOL, rtol=RTOL, what=''):
     assert len(trace['value']) == len(gv)
     for e, (a, b) in enumerate(zip(trace['policy'], gp)):
         for k in b:
-            np.testing.assert_allclose(a[k], b[k], atol=atol, rtol=rtol,
+            at, rt = tol_for(k, atol, rtol)
+            np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
                                        err_msg='%s policy epoch %d key %s' % (what, e, k))
     for e, (a, b) in enumerate(zip(trace['value'], gv)):
         for k in b:
-            np.testing.assert_allclose(a[k], b[k], atol=atol, rtol=rtol,
+            at, rt = tol_for(k, atol, rtol)
+            np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
                                        err_msg='%s value epoch %d key %s' % (what, e, k))
 
 
@@ -99,7 +118,8 @@ def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):
     for k, v in gs.items():
         if k == '_lr':
             continue
-        np.testing.assert_allclose(stats[k], v, atol=atol, rtol=rtol, err_msg='%s stat %s' % (what, k))
+        at, rt = tol_for(k, atol, rtol)
+        np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg='%s stat %s' % (what, k))
 
 
 def assert_final_params(learner, g, case, atol=2e-5, what=''):

@@ -118,7 +118,7 @@ def test_moments_and_normalize(K):
     K.moments(dev(x), md)
     xd = dev(x.clone())
     K.adv_normalize(xd, md, 1e-4)
-    close(xd.cpu(), (x - x.mean()) / 1e-4, atol=1e-4)
+    close(xd.cpu(), (x - x.double().mean().float()) / 1e-4, atol=1e-4)
     # merge of per-rank moments == moments of the concatenation
     a, b = torch.randn(300, generator=g), torch.randn(77, generator=g) * 4 + 1
     parts = torch.empty(2, 3).cuda()
