@@ -252,10 +252,30 @@ int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
                         uint64_t offset, smx_stream_t stream);
 
 /* --- sub-trajectory windowing (surreal/env/exp_sender_wrapper.py:209-264) -------
- * From per-actor rollouts laid out [actors, T, width] emit the n_step windows with the
- * given stride: dst[(a*W + w), j, :] = src[a, w*stride + j, :], W = (T-n_step)/stride+1. */
+ * From per-actor rollouts laid out [actors, T, width] emit W moving windows of n_step rows:
+ *   dst[(a*W + w), j, :] = src[a, start + w*stride + j, :]     0 <= j < n_step
+ * The reference emits floor((T - n_step)/stride) + 1 windows per episode of T steps
+ * (start = 0); obs_next of window w is the same call with start = n_step, n_step = 1 on a
+ * rollout that holds T+1 observations. */
 int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, int32_t width,
-                        int32_t n_step, int32_t stride, float* dst, smx_stream_t stream);
+                        int32_t start, int32_t n_step, int32_t stride, int32_t W, float* dst,
+                        smx_stream_t stream);
+
+/* --- synthetic vectorised environment step ("batched vectorised env stepping") --------
+ * There is no reference counterpart (the reference steps MuJoCo simulators one process per
+ * agent, surreal/agent/base.py:244-271); this is the synthetic stand-in BASELINE.json names,
+ * stepped for all actors of a GPU in one launch and recorded straight into the device rollout:
+ *   obs_roll[a, slot, :] = state[a, :]; obs_roll[a, slot+1, :] = state'[a, :] (if slot+1 < T);
+ *   act_roll[a, slot, :] = clip(actions[a, :], -1, 1)   (every roll has T rows per actor)
+ *   state'[a, k] = clamp(0.9*state[a,k] + 0.5*act[a, k % A] + 0.01*((37*k) % 17 - 8), -10, 10)
+ *   rew_roll[a, slot] = -0.1 * sum_j act[a,j]^2 + 0.05 * state'[a, 0]
+ *   done_roll[a, slot] = (t + 1 >= episode_len); on done the state resets to
+ *   init_state[a, :] (a fresh episode), mirroring Agent.main_loop's reset.
+ * Rolls may be NULL (pure stepping). */
+int smx_synth_env_step_f32(float* state, const float* init_state, const float* actions,
+                           int32_t n, int32_t D, int32_t A, int32_t t, int32_t episode_len,
+                           int32_t slot, int32_t T, float* obs_roll, float* act_roll,
+                           float* rew_roll, float* done_roll, smx_stream_t stream);
 
 #ifdef __cplusplus
 }

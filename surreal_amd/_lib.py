@@ -71,7 +71,10 @@ _SIGS = {
     'smx_ring_insert_f32': (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, _P]),
     'smx_gather_rows_f32': (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
     'smx_uniform_indices': (c_int32, [_P, c_int64, c_int64, c_uint64, c_uint64, _P]),
-    'smx_window_emit_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'smx_window_emit_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                      c_int32, _P, _P]),
+    'smx_synth_env_step_f32': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_int32, c_int32, _P, _P, _P, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

@@ -1,0 +1,2 @@
+from .base import Agent, AGENT_MODES, PeriodicTracker
+from .ppo_agent import PPOAgent

@@ -1,0 +1,191 @@
+"""
+Agent plugin base class: constructor signature, modes, hooks and the episode loop of the
+reference's ``surreal.agent.base.Agent`` (surreal/agent/base.py:24-377).  The ZeroMQ parameter
+client (REQ 'parameter:<hash>' to a parameter server every ``fetch_parameter_interval`` steps)
+is replaced by an in-process hand-off: ``attach_learner(learner)`` subscribes the agent to the
+learner's publishes, ``fetch_parameter()`` copies the latest published module state, device to
+device -- on one GPU the "parameter server" is a tensor copy.
+"""
+import logging
+
+from surreal_amd.env import MaxStepWrapper
+from surreal_amd.utils import AutoInitializeMeta
+
+AGENT_MODES = ['training', 'eval_deterministic', 'eval_stochastic',
+               'eval_deterministic_local', 'eval_stochastic_local']
+
+
+class PeriodicTracker(object):
+    """True once every `period` increments (surreal/session/tracker.py:10-79)"""
+
+    def __init__(self, period, init_value=0, init_endpoint=0):
+        assert isinstance(period, int) and period > 0
+        self.period = period
+        self.value = init_value
+        self._endpoint = init_endpoint
+
+    def track_increment(self, incr=1):
+        self.value += incr
+        if self.value - self._endpoint >= self.period:
+            self._endpoint += (self.value - self._endpoint) // self.period * self.period
+            return True
+        return False
+
+
+class Agent(object, metaclass=AutoInitializeMeta):
+    def __init__(self, learner_config, env_config, session_config, agent_id, agent_mode,
+                 render=False):
+        self.learner_config = learner_config
+        self.env_config = env_config
+        self.session_config = session_config
+        assert agent_mode in AGENT_MODES
+        self.agent_mode = agent_mode
+        self.agent_id = agent_id
+        self.log = logging.getLogger('surreal_amd.agent.%s' % agent_id)
+        if self.agent_mode not in ['eval_deterministic_local', 'eval_stochastic_local']:
+            self._setup_parameter_pull()
+        self.current_episode = 0
+        self.cumulative_steps = 0
+        self.current_step = 0
+        self.actions_since_param_update = 0
+        self.episodes_since_param_update = 0
+        self.render = render
+        self._published = None       # (module_dict, info) last published by the learner
+        self._fetched_iteration = None
+        self._env_factory = None
+
+    def _initialize(self):
+        self._module_dict = self.module_dict()
+
+    def _setup_parameter_pull(self):
+        self._fetch_parameter_mode = self.session_config.agent.fetch_parameter_mode
+        self._fetch_parameter_interval = self.session_config.agent.fetch_parameter_interval
+        self._fetch_parameter_tracker = PeriodicTracker(self._fetch_parameter_interval)
+
+    # ---- abstract ---------------------------------------------------------------------------
+    def act(self, obs):
+        raise NotImplementedError
+
+    def module_dict(self):
+        raise NotImplementedError
+
+    def reset(self):
+        pass
+
+    # ---- parameter hand-off -------------------------------------------------------------------
+    def attach_learner(self, learner):
+        learner.add_parameter_listener(self._on_publish)
+        self._published = (learner.module_dict(), {'iteration': 0, 'message': 'initial'})
+
+    def _on_publish(self, module_dict, info):
+        self._published = (module_dict, info)
+
+    def on_parameter_fetched(self, params, info):      # agent/base.py:160-180
+        self.actions_since_param_update = 0
+        self.episodes_since_param_update = 0
+        return params
+
+    def fetch_parameter(self):
+        """agent/base.py:355-363; returns True when new parameters were loaded"""
+        if self._published is None:
+            return False
+        params, info = self._published
+        if info.get('iteration') == self._fetched_iteration:
+            return False                      # the reference's "hash unchanged" reply
+        params = self.on_parameter_fetched(params, info)
+        for name, module in self._module_dict.items():
+            module.load_state_dict(params[name].state_dict())
+        self._fetched_iteration = info.get('iteration')
+        return True
+
+    def fetch_parameter_info(self):
+        return None if self._published is None else self._published[1]
+
+    # ---- hooks (agent/base.py:182-222) -----------------------------------------------------------
+    def pre_action(self, obs):
+        if self.agent_mode == 'training':
+            if self._fetch_parameter_mode == 'step' and self._fetch_parameter_tracker.track_increment():
+                self.fetch_parameter()
+
+    def post_action(self, obs, action, obs_next, reward, done, info):
+        self.current_step += 1
+        self.cumulative_steps += 1
+        if self.agent_mode == 'training':
+            self.actions_since_param_update += 1
+            if done:
+                self.episodes_since_param_update += 1
+
+    def pre_episode(self):
+        if self.agent_mode == 'training':
+            if self._fetch_parameter_mode == 'episode' and self._fetch_parameter_tracker.track_increment():
+                self.fetch_parameter()
+
+    def post_episode(self):
+        self.current_episode += 1
+
+    # ---- main loops (agent/base.py:224-271) -----------------------------------------------------
+    def main(self):
+        self.main_setup()
+        while True:
+            self.main_loop()
+
+    def main_setup(self):
+        env = self.get_env()
+        self.env = self.prepare_env(env)
+        if self.agent_mode == 'training':
+            self.fetch_parameter()
+
+    def main_loop(self):
+        """one episode"""
+        env = self.env
+        self.pre_episode()
+        obs, info = env.reset()
+        total_reward = 0.0
+        while True:
+            self.pre_action(obs)
+            action = self.act(obs)
+            obs_next, reward, done, info = env.step(action)
+            total_reward += reward
+            self.post_action(obs, action, obs_next, reward, done, info)
+            obs = obs_next
+            if done:
+                break
+        self.post_episode()
+        return total_reward
+
+    def set_env_factory(self, fn):
+        """fn() -> Env.  (The reference builds simulators through make_env, which needs
+        Gym / MuJoCo and is out of scope.)"""
+        self._env_factory = fn
+
+    def get_env(self):
+        if self._env_factory is None:
+            raise RuntimeError('no environment factory: call set_env_factory(fn)')
+        return self._env_factory()
+
+    def prepare_env(self, env):
+        if self.agent_mode == 'training':
+            return self.prepare_env_agent(env)
+        return self.prepare_env_eval(env)
+
+    def prepare_env_agent(self, env):
+        limit = self.env_config.limit_episode_length
+        if limit > 0:
+            env = MaxStepWrapper(env, limit)
+        return env
+
+    def prepare_env_eval(self, env):
+        limit = self.env_config.limit_episode_length
+        if limit > 0:
+            env = MaxStepWrapper(env, limit)
+        return env
+
+    def main_agent(self):
+        self.main()
+
+    def main_eval(self):
+        self.main()
+
+    def set_agent_mode(self, agent_mode):
+        assert agent_mode in AGENT_MODES
+        self.agent_mode = agent_mode

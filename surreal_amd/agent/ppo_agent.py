@@ -1,0 +1,120 @@
+"""
+PPOAgent -- rollout worker with the reference's interface (surreal/agent/ppo_agent.py:16-190).
+
+``act(obs)`` keeps the batch-1 contract (training mode returns ``(action, [onetime_infos,
+persistent_infos])`` for the windowing wrapper); ``act_batch(obs)`` is the same computation
+for ALL actors of a GPU in one actor forward on the device: mean/std from the policy MLP
+(HIP, FP32 MFMA), per-actor exploration noise ``std *= exp(noise_i)`` with
+``noise_i ~ U(-log_sig_range, +log_sig_range)`` drawn once per actor (ppo_agent.py:57-61,139),
+sample ``a = mean + std * eps``, clip to [-1, 1].
+"""
+import time
+
+import numpy as np
+import torch
+
+from surreal_amd import _lib as L
+from surreal_amd import kernels as KN
+from surreal_amd.env import ExpSenderWrapperMultiStepMovingWindowWithInfo
+from surreal_amd.model.ppo_net import DiagGauss, PPOModel
+from .base import Agent
+
+
+class PPOAgent(Agent):
+    def __init__(self, learner_config, env_config, session_config, agent_id, agent_mode,
+                 render=False):
+        super().__init__(learner_config=learner_config, env_config=env_config,
+                         session_config=session_config, agent_id=agent_id, agent_mode=agent_mode,
+                         render=render)
+        self.action_dim = self.env_config.action_spec.dim[0]
+        self.obs_spec = self.env_config.obs_spec
+        self.use_z_filter = self.learner_config.algo.use_z_filter
+        self.init_log_sig = self.learner_config.algo.consts.init_log_sig
+        self.log_sig_range = self.learner_config.algo.consts.log_sig_range
+        if self.agent_mode != 'training':                        # ppo_agent.py:49-55
+            if self.agent_mode not in ['eval_deterministic_local', 'eval_stochastic_local']:
+                self.agent_mode = 'eval_stochastic' if self.env_config.stochastic_eval \
+                    else 'eval_deterministic'
+        if self.agent_mode != 'training':
+            self.noise = 0
+        else:
+            self.noise = np.random.uniform(low=-self.log_sig_range, high=self.log_sig_range)
+        self.rnn_config = self.learner_config.algo.rnn
+        self.pd = DiagGauss(self.action_dim)
+        self.cells = None
+        self.K = KN.default_kernels()
+        self.device = KN.default_device()
+        self.model = PPOModel(obs_spec=self.obs_spec, action_dim=self.action_dim,
+                              model_config=self.learner_config.model, use_cuda=True,
+                              init_log_sig=self.init_log_sig, use_z_filter=self.use_z_filter,
+                              if_pixel_input=self.env_config.get('pixel_input', False),
+                              rnn_config=self.rnn_config, device=self.device, kernels=self.K)
+        self.sink = None
+        self._batch_noise = None
+
+    # ---- batch-1 reference contract (ppo_agent.py:106-154) ----------------------------------
+    def act(self, obs):
+        action_info = [[], []]
+        obs_tensor = {}
+        for mod in obs.keys():
+            obs_tensor[mod] = {}
+            for k in obs[mod].keys():
+                obs_tensor[mod][k] = torch.as_tensor(np.asarray(obs[mod][k]), dtype=torch.float32) \
+                    .unsqueeze(0).to(self.device)
+        action_pd, self.cells = self.model.forward_actor_expose_cells(obs_tensor, self.cells)
+        action_pd = action_pd.detach().cpu().numpy()
+        action_pd[:, self.action_dim:] *= np.exp(self.noise)
+        if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:
+            action_choice = self.pd.sample(action_pd)
+        else:
+            action_choice = self.pd.maxprob(action_pd).copy()
+        np.clip(action_choice, -1, 1, out=action_choice)
+        action_choice = action_choice.reshape((-1,))
+        action_pd = action_pd.reshape((-1,))
+        action_info[1].append(action_pd)
+        if self.agent_mode != 'training':
+            return action_choice
+        sleep = self.env_config.get('sleep_time', 0)
+        if sleep:
+            time.sleep(sleep)
+        return action_choice, action_info
+
+    # ---- all actors of a GPU in one forward ---------------------------------------------------
+    def act_batch(self, obs, generator=None, eps=None):
+        """obs [n, D] on the device -> (actions [n, A], pds [n, 2A]) on the device.
+        `eps` ([n, A] standard normal) may be injected for exact-parity tests."""
+        n = obs.shape[0]
+        A = self.action_dim
+        if self._batch_noise is None or self._batch_noise.shape[0] != n:
+            if self.agent_mode == 'training':
+                g = torch.Generator().manual_seed(1234 + int(self.agent_id))
+                u = (torch.rand(n, 1, generator=g) * 2 - 1) * self.log_sig_range
+            else:
+                u = torch.zeros(n, 1)
+            self._batch_noise = torch.exp(u).to(self.device)
+        pd = self.model.forward_actor({'low_dim': {'flat_inputs': obs}})
+        pd = pd.clone()
+        pd[:, A:] *= self._batch_noise
+        if self.agent_mode in ['eval_deterministic', 'eval_deterministic_local']:
+            actions = pd[:, :A].clone()
+        else:
+            if eps is None:
+                eps = torch.randn(n, A, device=self.device, generator=generator)
+            actions = eps * pd[:, A:] + pd[:, :A]
+        actions.clamp_(-1.0, 1.0)
+        return actions, pd
+
+    def module_dict(self):
+        return {'ppo': self.model}
+
+    def reset(self):
+        self.cells = None
+
+    def set_experience_sink(self, sink):
+        """where windowed experiences go: normally ``replay._insert_wrapper``"""
+        self.sink = sink
+
+    def prepare_env_agent(self, env):                  # ppo_agent.py:185-190
+        env = super().prepare_env_agent(env)
+        return ExpSenderWrapperMultiStepMovingWindowWithInfo(env, self.learner_config,
+                                                             self.session_config, sink=self.sink)

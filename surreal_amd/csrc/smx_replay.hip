@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256) void uniform_indices_kernel(int64_t* __restric
 }
 
 __global__ __launch_bounds__(256) void window_emit_kernel(const float* __restrict__ src, int actors,
-                                                          int T, int width, int n_step, int stride,
-                                                          int W, float* __restrict__ dst, int vec) {
+                                                          int T, int width, int start, int n_step,
+                                                          int stride, int W, float* __restrict__ dst,
+                                                          int vec) {
     const long n = (long)actors * W * n_step;
     copy_rows(src, dst, n, width, vec != 0,
               [=](long i) {
@@ -89,9 +90,48 @@ __global__ __launch_bounds__(256) void window_emit_kernel(const float* __restric
                   const int j = (int)(i - jw * n_step);
                   const long a = jw / W;
                   const int w = (int)(jw - a * W);
-                  return a * T + (long)w * stride + j;
+                  return a * T + start + (long)w * stride + j;
               },
               [](long i) { return i; });
+}
+
+// one thread per (actor, k); the reward needs the whole action row: lanes k < 1 compute it
+__global__ __launch_bounds__(256) void synth_env_step_kernel(
+    float* __restrict__ state, const float* __restrict__ init_state,
+    const float* __restrict__ actions, int n, int D, int A, int t, int episode_len, int slot, int T,
+    float* __restrict__ obs_roll, float* __restrict__ act_roll, float* __restrict__ rew_roll,
+    float* __restrict__ done_roll) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)n * D) return;
+    const long a = i / D;
+    const int k = (int)(i - a * D);
+    const float s = state[i];
+    float ac = actions[a * A + (k % A)];
+    ac = fminf(fmaxf(ac, -1.0f), 1.0f);
+    const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+    float sn = (0.9f * s + 0.5f * ac) + drift;
+    sn = fminf(fmaxf(sn, -10.0f), 10.0f);
+    const bool done = (t + 1 >= episode_len);
+    if (obs_roll) {
+        obs_roll[(a * T + slot) * D + k] = s;
+        // the observation AFTER this step (the terminal one when done): obs_next of a window
+        // that ends here (exp_sender_wrapper.py:220-221)
+        if (slot + 1 < T) obs_roll[(a * T + slot + 1) * D + k] = sn;
+    }
+    if (k < A && act_roll) {
+        float av = actions[a * A + k];
+        act_roll[(a * T + slot) * A + k] = fminf(fmaxf(av, -1.0f), 1.0f);
+    }
+    if (k == 0) {
+        double q = 0.0;
+        for (int j = 0; j < A; ++j) {
+            float av = fminf(fmaxf(actions[a * A + j], -1.0f), 1.0f);
+            q += (double)av * (double)av;
+        }
+        if (rew_roll) rew_roll[a * T + slot] = (float)(-0.1 * q + 0.05 * (double)sn);
+        if (done_roll) done_roll[a * T + slot] = done ? 1.0f : 0.0f;
+    }
+    state[i] = done ? init_state[i] : sn;
 }
 
 inline unsigned row_blocks(long n) {
@@ -139,15 +179,30 @@ extern "C" int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_
 }
 
 extern "C" int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, int32_t width,
-                                   int32_t n_step, int32_t stride, float* dst,
-                                   smx_stream_t stream) {
+                                   int32_t start, int32_t n_step, int32_t stride, int32_t W,
+                                   float* dst, smx_stream_t stream) {
     SMX_REQUIRE(src && dst, SMX_E_NULL);
-    SMX_REQUIRE(actors > 0 && T > 0 && width > 0 && n_step > 0 && stride > 0 && n_step <= T,
-                SMX_E_SHAPE);
-    const int W = (T - n_step) / stride + 1;
+    SMX_REQUIRE(actors > 0 && T > 0 && width > 0 && n_step > 0 && stride > 0 && W > 0 && start >= 0 &&
+                    start + (long)(W - 1) * stride + n_step <= T, SMX_E_SHAPE);
     const long n = (long)actors * W * n_step;
     hipLaunchKernelGGL(window_emit_kernel, dim3(row_blocks(n)), dim3(256), 0, smx_s(stream), src,
-                       actors, T, width, n_step, stride, W, dst, can_vec(src, dst, width));
+                       actors, T, width, start, n_step, stride, W, dst, can_vec(src, dst, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_synth_env_step_f32(float* state, const float* init_state, const float* actions,
+                                      int32_t n, int32_t D, int32_t A, int32_t t,
+                                      int32_t episode_len, int32_t slot, int32_t T, float* obs_roll,
+                                      float* act_roll, float* rew_roll, float* done_roll,
+                                      smx_stream_t stream) {
+    SMX_REQUIRE(state && init_state && actions, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && D > 0 && A > 0 && A <= D && T > 0 && slot >= 0 && slot < T && episode_len > 0,
+                SMX_E_SHAPE);
+    const long total = (long)n * D;
+    hipLaunchKernelGGL(synth_env_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       smx_s(stream), state, init_state, actions, n, D, A, t, episode_len, slot, T,
+                       obs_roll, act_roll, rew_roll, done_roll);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

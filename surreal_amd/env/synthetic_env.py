@@ -1,0 +1,143 @@
+"""
+Synthetic environments.  The reference has no synthetic env (it steps MuJoCo / Robosuite
+simulators, one OS process per agent: surreal/agent/base.py:244-271, surreal/env/make_env.py);
+BASELINE.json's configs[4] is a synthetic 1024-actor workload, so the dynamics are defined here
+once and implemented twice with bit-identical fp32 results:
+
+  * ``SyntheticEnv``    -- one actor, numpy, the reference ``Env`` protocol (reset/step, nested
+    obs dicts): drives the reference-style Agent + windowing wrappers in tests;
+  * ``SyntheticVecEnv`` -- all actors of a GPU stepped by ONE HIP launch
+    (smx_synth_env_step_f32, csrc/smx_replay.hip) that also records the step straight into the
+    device-resident rollout [actors, T, .]; ``emit_windows`` then cuts the rollout into
+    n_step / stride sub-trajectories (smx_window_emit_f32) exactly as
+    ExpSenderWrapperMultiStepMovingWindowWithInfo would have, without the data ever leaving HBM.
+
+Dynamics (all fp32, no fused multiply-add):
+    a      = clip(action, -1, 1)
+    s'[k]  = clamp(0.9*s[k] + 0.5*a[k % A] + 0.01*((37k) % 17 - 8), -10, 10)
+    reward = -0.1 * sum_j a[j]^2 + 0.05 * s'[0]      (accumulated in fp64, rounded once)
+    done   = (t + 1 >= episode_len)
+"""
+import collections
+
+import numpy as np
+import torch
+
+from surreal_amd import kernels as KN
+from .base import Env
+
+
+def _drift(D):
+    k = np.arange(D)
+    return (np.float32(0.01) * ((37 * k) % 17 - 8).astype(np.float32)).astype(np.float32)
+
+
+class SyntheticEnv(Env):
+    def __init__(self, obs_dim, action_dim, episode_len=200, seed=0):
+        self.D, self.A, self.episode_len = obs_dim, action_dim, episode_len
+        self.rs = np.random.RandomState(seed)
+        self.init_state = self.rs.randn(obs_dim).astype(np.float32)
+        self.state = self.init_state.copy()
+        self.t = 0
+
+    def observation_spec(self):
+        return collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=(self.D,)))
+
+    def action_spec(self):
+        return {'dim': (self.A,), 'type': 'continuous'}
+
+    def _obs(self):
+        return collections.OrderedDict(
+            low_dim=collections.OrderedDict(flat_inputs=self.state.copy()))
+
+    def _reset(self):
+        self.state = self.init_state.copy()
+        self.t = 0
+        return self._obs(), {}
+
+    def _step(self, action):
+        a = np.clip(np.asarray(action, dtype=np.float32).reshape(-1), -1.0, 1.0).astype(np.float32)
+        k = np.arange(self.D)
+        sn = (np.float32(0.9) * self.state + np.float32(0.5) * a[k % self.A]).astype(np.float32)
+        sn = np.clip((sn + _drift(self.D)).astype(np.float32), -10.0, 10.0).astype(np.float32)
+        reward = float(np.float32(-0.1 * np.sum(a.astype(np.float64) ** 2) + 0.05 * float(sn[0])))
+        done = (self.t + 1 >= self.episode_len)
+        self.t += 1
+        self.state = sn
+        return self._obs(), reward, done, {}
+
+
+class SyntheticVecEnv(object):
+    """n actors on one GPU; rollouts of T steps recorded on the device"""
+
+    def __init__(self, n_actors, obs_dim, action_dim, episode_len=200, seeds=None, device=None,
+                 kernels=None):
+        self.K = kernels or KN.default_kernels()
+        self.device = device or KN.default_device()
+        self.n, self.D, self.A, self.episode_len = n_actors, obs_dim, action_dim, episode_len
+        seeds = list(range(n_actors)) if seeds is None else list(seeds)
+        init = np.stack([np.random.RandomState(s).randn(obs_dim).astype(np.float32) for s in seeds])
+        self.init_state = torch.as_tensor(init).to(self.device)
+        self.state = self.init_state.clone()
+        self.t = 0
+        self.rolls = None
+
+    def reset(self):
+        self.state.copy_(self.init_state)
+        self.t = 0
+        return self.state
+
+    def start_rollout(self, T, info_width=0):
+        """allocate a device rollout of T steps.  Every roll has T + 1 rows per actor (the
+        observation roll needs the observation after the last step; the others leave their last
+        row unused) so that one env-step launch records all fields.  A rollout is one episode
+        segment: it starts right after a reset and T <= episode_len, so `done` can only be set
+        on the last recorded step and windows never straddle an episode boundary."""
+        assert self.t == 0 and T <= self.episode_len, 'rollouts start at an episode boundary'
+        f = lambda *s: torch.zeros(*s, device=self.device, dtype=torch.float32)  # noqa: E731
+        self.T = T
+        R = T + 1
+        self.rolls = {'obs': f(self.n, R, self.D), 'actions': f(self.n, R, self.A),
+                      'rewards': f(self.n, R), 'dones': f(self.n, R)}
+        if info_width:
+            self.rolls['pds'] = f(self.n, R, info_width)
+        self.slot = 0
+
+    def step(self, actions, pds=None):
+        """actions [n, A] on the device -> next observation [n, D] (the state tensor)"""
+        r = self.rolls
+        if r is not None and self.slot < self.T:
+            self.K.synth_env_step(self.state, self.init_state, actions, self.t, self.episode_len,
+                                  self.slot, r['obs'], r['actions'], r['rewards'], r['dones'])
+            if pds is not None:
+                r['pds'][:, self.slot] = pds
+            self.slot += 1
+        else:
+            self.K.synth_env_step(self.state, self.init_state, actions, self.t, self.episode_len, 0,
+                                  None, None, None, None)
+        self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
+        return self.state
+
+    def emit_windows(self, n_step, stride):
+        """-> dict of [n*W, n_step, .] sub-trajectories (+ obs_next [n*W, 1, D]) cut from the
+        recorded rollout with the reference's moving-window rule (exp_sender_wrapper.py:209-228):
+        W = floor((T - n_step) / stride) + 1 windows per actor, a partial tail is dropped"""
+        T = self.T
+        assert self.slot == T, 'rollout not complete'
+        W = (T - n_step) // stride + 1
+        r, K, n = self.rolls, self.K, self.n
+        f = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)  # noqa: E731
+        out = {'obs': f(n * W, n_step, self.D), 'obs_next': f(n * W, 1, self.D),
+               'actions': f(n * W, n_step, self.A), 'rewards': f(n * W, n_step, 1),
+               'dones': f(n * W, n_step, 1)}
+        K.window_emit(r['obs'], 0, n_step, stride, W, out['obs'])
+        K.window_emit(r['obs'], n_step, 1, stride, W, out['obs_next'])
+        K.window_emit(r['actions'], 0, n_step, stride, W, out['actions'])
+        K.window_emit(r['rewards'].view(n, T + 1, 1), 0, n_step, stride, W, out['rewards'])
+        K.window_emit(r['dones'].view(n, T + 1, 1), 0, n_step, stride, W, out['dones'])
+        out['rewards'] = out['rewards'].view(n * W, n_step)
+        out['dones'] = out['dones'].view(n * W, n_step)
+        if 'pds' in r:
+            out['pds'] = f(n * W, n_step, r['pds'].shape[2])
+            K.window_emit(r['pds'], 0, n_step, stride, W, out['pds'])
+        return out

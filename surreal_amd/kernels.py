@@ -154,10 +154,21 @@ class HipKernels(object):
         L.call('smx_uniform_indices', L.ptr(idx), idx.numel(), int(length), int(seed), int(offset),
                self._st())
 
-    def window_emit(self, src, n_step, stride, dst):
+    def window_emit(self, src, start, n_step, stride, W, dst):
+        """src [actors, T, width] -> dst [actors*W, n_step, width]"""
         actors, T, width = src.shape
-        L.call('smx_window_emit_f32', L.ptr(src), actors, T, width, n_step, stride, L.ptr(dst),
-               self._st())
+        assert src.is_contiguous() and dst.is_contiguous()
+        L.call('smx_window_emit_f32', L.ptr(src), actors, T, width, start, n_step, stride, W,
+               L.ptr(dst), self._st())
+
+    def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,
+                       rew_roll, done_roll):
+        n, D = state.shape
+        A = actions.shape[1]
+        T = obs_roll.shape[1] if obs_roll is not None else 1
+        L.call('smx_synth_env_step_f32', L.ptr(state), L.ptr(init_state), L.ptr(actions), n, D, A,
+               int(t), int(episode_len), int(slot), T, L.ptr(obs_roll), L.ptr(act_roll),
+               L.ptr(rew_roll), L.ptr(done_roll), self._st())
 
 
 # ------------------------------------------------------------------------------------------

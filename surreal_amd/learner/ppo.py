@@ -358,7 +358,9 @@ class PPOLearner(Learner):
                         ws.sumsq_a, ws.stop)
         npart = ws.np_a + 1
         if self.world_size > 1:
-            self._dist.all_reduce(ws.grads_a)
+            # the MLP gradients are per-rank sums over local rows (already scaled by 1/n_total);
+            # the log_var gradient was built from the all-reduced partials and is global already
+            self._dist.all_reduce(ws.grads_a[:m.actor.numel])
             K.sumsq_partials(ws.grads_a, ws.sumsq_a)
             npart = K.sumsq_blocks(ws.grads_a.numel())
         K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
@@ -434,6 +436,9 @@ class PPOLearner(Learner):
             value_epochs()
 
         K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
+        if self.world_size > 1:
+            self._dist.all_gather_into_tensor(ws.mom_parts.view(-1), ws.ret_mom.clone())
+            K.moments_merge(ws.mom_parts, ws.ret_mom)
         if self.use_z_filter:                   # model.z_update(obs_iter)  (ppo.py:578-579)
             if self.world_size > 1:
                 ws.zdelta.zero_()

@@ -96,8 +96,10 @@ class ZFilter(object):
 
     def load_state_dict(self, sd):
         for k in ('running_sum', 'running_sumsq', 'count'):
-            getattr(self, k).copy_(torch.as_tensor(np.asarray(sd[k].cpu() if torch.is_tensor(sd[k])
-                                                              else sd[k]), dtype=torch.float32))
+            src = sd[k]
+            if not torch.is_tensor(src):
+                src = torch.as_tensor(np.asarray(src), dtype=torch.float32)
+            getattr(self, k).copy_(src.reshape(getattr(self, k).shape))
 
 
 class Mlp3Params(object):
@@ -203,8 +205,13 @@ class PPOModel(object):
         return sd
 
     def load_state_dict(self, sd):
-        self.load_params({k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in sd.items()
-                          if not k.startswith('z_filter.')})
+        with torch.no_grad():
+            for k, v in self.named_parameters().items():
+                src = sd[k]
+                if torch.is_tensor(src):          # device -> device: the in-process "PS"
+                    v.copy_(src.view(v.shape))
+                else:
+                    v.copy_(torch.as_tensor(np.asarray(src), dtype=torch.float32).view(v.shape))
         if self.use_z_filter:
             self.z_filter.load_state_dict({k[len('z_filter.'):]: v for k, v in sd.items()
                                            if k.startswith('z_filter.')})

@@ -1,0 +1,3 @@
+from .base import Replay, DeviceTable
+from .fifo_replay import FIFOReplay
+from .uniform_replay import UniformReplay

@@ -1,0 +1,73 @@
+"""
+UniformReplay (surreal/replay/uniform_replay.py:6-74): a ring buffer with an insert cursor
+``_next_idx``; ``sample`` draws ``batch_size`` indices uniformly WITH replacement
+(``random.randint(0, len - 1)`` each); ready when ``len > sampling_start_size``.
+"""
+import random
+
+import torch
+
+from .base import Replay
+
+
+class UniformReplay(Replay):
+    def __init__(self, learner_config, env_config, session_config, index=0):
+        super().__init__(learner_config=learner_config, env_config=env_config,
+                         session_config=session_config, index=index)
+        self._memory = []
+        self.memory_size = self.learner_config.replay.memory_size
+        self._next_idx = 0
+        # device tier
+        self._dev_len = 0
+        self._dev_next = 0
+        self._draws = 0
+        self.seed = int(self.session_config.replay.get('seed', 0)) + 7919 * int(index)
+
+    # ---- host tier: the reference semantics ---------------------------------------------
+    def insert(self, exp_dict):
+        if self._next_idx >= len(self._memory):
+            self._memory.append(exp_dict)
+        else:
+            self._memory[self._next_idx] = exp_dict
+        self._next_idx = (self._next_idx + 1) % self.memory_size
+
+    def sample(self, batch_size):
+        indices = [random.randint(0, len(self._memory) - 1) for _ in range(batch_size)]
+        return [self._memory[i] for i in indices]
+
+    def evict(self):
+        raise NotImplementedError
+
+    def start_sample_condition(self):
+        return len(self) > self.learner_config.replay.sampling_start_size
+
+    def __len__(self):
+        return len(self._memory) + self._dev_len
+
+    # ---- device tier -----------------------------------------------------------------------
+    def insert_batch(self, fields):
+        tables = self._ensure_tables(self.memory_size, fields)
+        n = next(iter(fields.values())).shape[0]
+        if n > self.memory_size:
+            fields = {k: v[n - self.memory_size:] for k, v in fields.items()}
+            n = self.memory_size
+        for name, t in fields.items():
+            tables[name].insert(self._dev_next, t.to(torch.float32))
+        self._dev_next = (self._dev_next + n) % self.memory_size
+        self._dev_len = min(self.memory_size, self._dev_len + n)
+        self.cumulative_collected_count += n
+
+    def sample_indices(self, batch_size):
+        """with-replacement uniform indices on the device (Philox4x32-10; the reference's
+        Python Mersenne stream cannot be reproduced on a GPU -- distributional parity, and
+        sample_batch(indices=...) takes injected indices for exact-parity tests)"""
+        idx = torch.empty(batch_size, dtype=torch.int64, device=self._dev)
+        self._K.uniform_indices(idx, self._dev_len, self.seed, self._draws)
+        self._draws += batch_size
+        return idx
+
+    def sample_batch(self, batch_size, indices=None):
+        idx = self.sample_indices(batch_size) if indices is None else \
+            torch.as_tensor(indices, dtype=torch.int64).to(self._dev)
+        self.cumulative_sampled_count += batch_size
+        return {name: tab.gather(idx) for name, tab in self._tables.items()}

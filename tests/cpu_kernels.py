@@ -315,8 +315,25 @@ class TorchCpuKernels(object):
         g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2 ** 63))
         idx.copy_(torch.randint(0, int(length), idx.shape, generator=g))
 
-    def window_emit(self, src, n_step, stride, dst):
+    def window_emit(self, src, start, n_step, stride, W, dst):
         actors, T, width = src.shape
-        W = (T - n_step) // stride + 1
-        out = torch.stack([src[:, w * stride:w * stride + n_step] for w in range(W)], 1)
+        out = torch.stack([src[:, start + w * stride:start + w * stride + n_step] for w in range(W)], 1)
         dst.view(actors, W, n_step, width).copy_(out)
+
+    def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,
+                       rew_roll, done_roll):
+        n, D = state.shape
+        A = actions.shape[1]
+        ac = actions.clamp(-1.0, 1.0)
+        k = torch.arange(D)
+        drift = 0.01 * (((37 * k) % 17) - 8).float()
+        sn = ((0.9 * state + 0.5 * ac[:, k % A]) + drift).clamp(-10.0, 10.0)
+        done = (t + 1 >= episode_len)
+        if obs_roll is not None:
+            obs_roll[:, slot] = state
+            if slot + 1 < obs_roll.shape[1]:
+                obs_roll[:, slot + 1] = sn
+            act_roll[:, slot] = ac
+            rew_roll[:, slot] = (-0.1 * (ac.double() ** 2).sum(1) + 0.05 * sn[:, 0].double()).float()
+            done_roll[:, slot] = 1.0 if done else 0.0
+        state.copy_(init_state if done else sn)

@@ -1,0 +1,100 @@
+"""CPU tier, world_size 2 over gloo: the data-parallel path of PPOLearner.  Each rank owns half
+of the sub-trajectories; the ranks all-reduce advantage moments, loss partial sums, gradients,
+value moments and z-filter sums, and must reproduce what the single reference learner computes
+on the whole batch (golden traces) -- on every rank, with identical parameters afterwards."""
+import copy
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import helpers as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, q):
+    try:
+        import torch.distributed as dist
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        from surreal_amd import kernels as KN
+        from cpu_kernels import TorchCpuKernels
+        KN.set_default_kernels(TorchCpuKernels(), 'cpu')
+        g, case = H.load_golden(name)
+        batch, params, zstate = H.case_inputs(case)
+        B = case['shape']['B']
+        lo, hi = rank * B // world, (rank + 1) * B // world
+
+        def shard(x):
+            if isinstance(x, dict):
+                return type(x)((k, shard(v)) for k, v in x.items())
+            if isinstance(x, list):
+                return [shard(v) for v in x]
+            return x[lo:hi] if x is not None else None
+        sb = shard(batch)
+        case_local = copy.deepcopy(case)
+        case_local['shape']['B'] = hi - lo
+        learner = H.make_learner(case_local, params, zstate)
+        assert learner.world_size == world
+        stats = learner.learn(sb)
+        out = {'stats': stats, 'trace': learner.trace,
+               'adv': learner._ws.adv.numpy().copy(), 'ret': learner._ws.ret.numpy().copy(),
+               'actor': learner.model.actor_flat.numpy().copy(),
+               'critic': learner.model.critic_flat.numpy().copy(),
+               'z': {k: v.numpy().copy() for k, v in learner.model.z_filter.state_dict().items()}
+               if zstate is not None else None,
+               'exp_counter': learner.exp_counter, 'lo': lo, 'hi': hi}
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+
+
+@pytest.mark.parametrize('name', ['tiny_clip', 'tiny_adapt_cutoff2', 'cfg2_adapt'])
+def test_two_rank_learner_equals_single_learner(name):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, out = q.get(timeout=600)
+        res[r] = out
+    for p in procs:
+        p.join(60)
+    for r in range(world):
+        assert 'error' not in res[r], res[r].get('error')
+    g, case = H.load_golden(name)
+    adv = np.concatenate([res[r]['adv'] for r in range(world)]).reshape(g['advantages'].shape)
+    ret = np.concatenate([res[r]['ret'] for r in range(world)]).reshape(g['returns'].shape)
+    np.testing.assert_allclose(adv, g['advantages'], atol=H.ATOL, rtol=H.RTOL)   # GLOBAL normalisation
+    np.testing.assert_allclose(ret, g['returns'], atol=H.ATOL, rtol=H.RTOL)
+    for r in range(world):
+        H.assert_trace_close(res[r]['trace'], g, what='%s rank %d' % (name, r))
+        H.assert_stats_close(res[r]['stats'], g, what='%s rank %d' % (name, r))
+        assert res[r]['exp_counter'] == case['shape']['B']
+    # replicas stay bit-identical: same all-reduced gradients -> same Adam step everywhere
+    np.testing.assert_array_equal(res[0]['actor'], res[1]['actor'])
+    np.testing.assert_array_equal(res[0]['critic'], res[1]['critic'])
+    if res[0]['z'] is not None:
+        for k in ('running_sum', 'running_sumsq', 'count'):
+            np.testing.assert_array_equal(res[0]['z'][k], res[1]['z'][k])
+            np.testing.assert_allclose(res[0]['z'][k], g['zfinal.' + k], rtol=1e-6)

@@ -338,6 +338,25 @@ def test_replay_kernels(K):
     src = torch.randn(6, 14, 10, generator=g)
     W = (14 - 5) // 3 + 1
     dc, dd = torch.empty(6 * W, 5, 10), torch.empty(6 * W, 5, 10).cuda()
-    C.window_emit(src, 5, 3, dc)
-    K.window_emit(dev(src), 5, 3, dd)
+    C.window_emit(src, 0, 5, 3, W, dc)
+    K.window_emit(dev(src), 0, 5, 3, W, dd)
     assert torch.equal(dd.cpu(), dc) and W == 4
+    # obs_next of every window: start = n_step, one row
+    nc, nd = torch.empty(6 * 3, 1, 10), torch.empty(6 * 3, 1, 10).cuda()
+    C.window_emit(src, 5, 1, 3, 3, nc)
+    K.window_emit(dev(src), 5, 1, 3, 3, nd)
+    assert torch.equal(nd.cpu(), nc) and torch.equal(nc[1, 0], src[0, 8])
+    # synthetic env step: bit-exact against the CPU statement, incl. episode reset
+    n, D, A, T = 9, 23, 5, 4
+    st = torch.randn(n, D, generator=g)
+    init = torch.randn(n, D, generator=g)
+    rolls_c = [torch.zeros(n, T, D), torch.zeros(n, T, A), torch.zeros(n, T), torch.zeros(n, T)]
+    rolls_d = [r.clone().cuda() for r in rolls_c]
+    sc, sd = st.clone(), st.clone().cuda()
+    for t in range(T):
+        act = torch.randn(n, A, generator=g) * 0.8
+        C.synth_env_step(sc, init, act, t, 3, t, *rolls_c)
+        K.synth_env_step(sd, dev(init), dev(act), t, 3, t, *rolls_d)
+    assert torch.equal(sd.cpu(), sc)
+    for rc, rd in zip(rolls_c, rolls_d):
+        assert torch.equal(rd.cpu(), rc)

@@ -1,0 +1,272 @@
+"""CPU tier: replay buffers, experience windowing, aggregation and the agent loop of the product
+against tests/golden/hostpath.json, recorded from the REFERENCE's own classes
+(oracle/gen_golden_hostpath.py), plus the device tier of the same objects through the CPU
+kernel double, plus the in-process Agent -> Replay -> Learner loop (the reference's only live
+test, test/test_ppo_gym.py -> test_helpers/integration_test.py:42-105, asserts "no exception";
+this one also checks what flowed)."""
+import collections
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+
+GOLD = json.load(open(os.path.join(H.GOLDEN_DIR, 'hostpath.json')))
+
+
+class FakeEnv(object):
+    metadata = {}
+
+    def __init__(self, T):
+        self.T, self.t = T, 0
+
+    def obs(self):
+        return collections.OrderedDict(low_dim=collections.OrderedDict(
+            flat_inputs=np.array([self.t, self.t], dtype=np.float32)))
+
+    def reset(self):
+        self.t = 0
+        return self.obs(), {}
+
+    def step(self, action):
+        self.t += 1
+        return self.obs(), float(self.t), self.t >= self.T, {}
+
+
+def configs(B=2, N=4, stride=2, D=2, A=1, memory=4):
+    lc = ppo_learner_config()
+    lc.algo.n_step, lc.algo.stride = N, stride
+    lc.algo.rnn.if_rnn_policy = False
+    lc.replay.batch_size, lc.replay.memory_size, lc.replay.sampling_start_size = B, memory, B
+    lc.model.actor_fc_hidden_sizes = [24, 16]
+    lc.model.critic_fc_hidden_sizes = [24, 16]
+    return lc, ppo_env_config(D, A), ppo_session_config('/tmp/surreal_amd_test')
+
+
+def test_fifo_replay_matches_reference():
+    from surreal_amd.replay import FIFOReplay
+    lc, ec, sc = configs()
+    f = FIFOReplay(lc, ec, sc)
+    for i in range(10):
+        f.insert(i)
+    assert list(f._memory) == GOLD['fifo_after_insert_0_9']          # maxlen = memory_size + 3
+    assert f.start_sample_condition() == GOLD['fifo_ready']
+    assert f.sample(2) == GOLD['fifo_sample2'] and len(f) == GOLD['fifo_len_after']
+    with pytest.raises(NotImplementedError):
+        f.evict()
+    empty = FIFOReplay(lc, ec, sc)
+    assert not empty.start_sample_condition() and len(empty) == 0
+    assert empty._sample_request_handler(2) is None
+
+
+def test_uniform_replay_matches_reference():
+    from surreal_amd.replay import UniformReplay
+    lc, ec, sc = configs(memory=5)
+    u = UniformReplay(lc, ec, sc)
+    for i in range(8):
+        u.insert(i)
+    assert list(u._memory) == GOLD['uniform_cap5_after_insert_0_7']
+    assert u._next_idx == GOLD['uniform_next_idx'] and u.start_sample_condition()
+    random.seed(123)
+    assert u.sample(6) == GOLD['uniform_sample6_seed123']             # with replacement, same stream
+
+
+@pytest.mark.parametrize('T,n_step,stride', [(14, 5, 3), (10, 4, 4), (7, 3, 1), (5, 6, 2)])
+def test_ppo_window_wrapper_matches_reference(T, n_step, stride):
+    from surreal_amd.env import ExpSenderWrapperMultiStepMovingWindowWithInfo
+    lc, ec, sc = configs(N=n_step, stride=stride)
+    got = []
+    w = ExpSenderWrapperMultiStepMovingWindowWithInfo(FakeEnv(T), lc, sc, sink=got.append)
+    for ep in range(2):
+        w.reset()
+        done = False
+        while not done:
+            _, _, done, _ = w.step((np.zeros(1), [[], [np.array([0.5, 1.0])]]))
+    ref = GOLD['window_T%d_n%d_s%d' % (T, n_step, stride)]
+    assert len(got) == len(ref) == 2 * (max(0, (T - n_step) // stride + 1) if T >= n_step else 0)
+    for e, r in zip(got, ref):
+        assert [int(o['low_dim']['flat_inputs'][0]) for o in e['obs']] == r['obs_t']
+        assert int(e['obs_next']['low_dim']['flat_inputs'][0]) == r['obs_next_t']
+        assert e['rewards'] == r['rewards'] and [bool(d) for d in e['dones']] == r['dones']
+        assert e['n_step'] == r['n_step'] and e['onetime_infos'] == []
+
+
+def test_ddpg_nstep_wrapper_matches_reference_quirks():
+    from surreal_amd.env import ExpSenderWrapperSSARNStepBootstrap
+    lc, ec, sc = configs(N=3)
+    lc.algo.gamma = 0.5
+    got = []
+    w = ExpSenderWrapperSSARNStepBootstrap(FakeEnv(6), lc, sc, sink=got.append)
+    w.reset()
+    done = False
+    while not done:
+        _, _, done, _ = w.step(np.zeros(1))
+    ref = GOLD['ssar_nstep3_gamma0.5_T6']
+    assert len(got) == len(ref)
+    for e, r in zip(got, ref):
+        assert int(e['obs'][0]['low_dim']['flat_inputs'][0]) == r['obs_t']
+        assert int(e['obs'][1]['low_dim']['flat_inputs'][0]) == r['obs_next_t']
+        assert e['reward'] == r['reward'] and bool(e['done']) == r['done']
+
+
+def test_aggregator_matches_reference():
+    from surreal_amd.env import ExpSenderWrapperMultiStepMovingWindowWithInfo
+    from surreal_amd.learner.aggregator import MultistepAggregatorWithInfo
+    lc, ec, sc = configs(N=4, stride=2)
+    got = []
+    w = ExpSenderWrapperMultiStepMovingWindowWithInfo(FakeEnv(9), lc, sc, sink=got.append)
+    w.reset()
+    done = False
+    while not done:
+        _, _, done, _ = w.step((np.array([0.25]), [[], [np.array([0.5, 1.0])]]))
+    b = MultistepAggregatorWithInfo(ec.obs_spec, ec.action_spec).aggregate(got)
+    r = GOLD['aggregate_shapes']
+    assert list(b['obs']['low_dim']['flat_inputs'].shape) == r['obs']
+    assert list(b['obs_next']['low_dim']['flat_inputs'].shape) == r['obs_next']
+    assert list(b['actions'].shape) == r['actions'] and list(b['rewards'].shape) == r['rewards']
+    assert list(b['dones'].shape) == r['dones'] and str(b['dones'].dtype) == r['dones_dtype']
+    assert [list(x.shape) for x in b['persistent_infos']] == r['persistent_infos']
+    assert b['onetime_infos'] is r['onetime_infos'] is None
+    assert b['obs']['low_dim']['flat_inputs'][:, :, 0].tolist() == r['obs_first_col']
+    assert b['rewards'].tolist() == r['rewards_values']
+    with pytest.raises(ValueError):
+        MultistepAggregatorWithInfo(ec.obs_spec, ec.action_spec).aggregate(
+            [got[0], dict(got[1], actions=got[1]['actions'][:2])])      # ragged -> loud
+
+
+def test_maxstep_and_framestack_wrappers():
+    from surreal_amd.env import MaxStepWrapper, FrameStackWrapper
+    from surreal_amd.session import Config
+    env = MaxStepWrapper(FakeEnv(100), 3)
+    env.reset()
+    dones = [env.step(0)[2] for _ in range(3)]
+    assert dones == [False, False, True]
+    with pytest.raises(RuntimeError):
+        MaxStepWrapper(env, 3)                                        # no double wrapping
+
+    class Pix(FakeEnv):
+        def obs(self):
+            return collections.OrderedDict(pixel=collections.OrderedDict(
+                camera0=np.full((1, 2, 2), self.t, dtype=np.uint8)))
+    fs = FrameStackWrapper(Pix(10), Config(frame_stacks=3, frame_stack_concatenate_on_env=True))
+    o, _ = fs.reset()
+    assert o['pixel']['camera0'].shape == (3, 2, 2) and o['pixel']['camera0'][:, 0, 0].tolist() == [0, 0, 0]
+    o = fs.step(0)[0]
+    o = fs.step(0)[0]
+    assert o['pixel']['camera0'][:, 0, 0].tolist() == [0, 1, 2]
+
+
+def test_device_tier_replay_and_vec_env(cpu_double):
+    """SoA tables + ring insert / FIFO pop / uniform gather; vectorised env + window emission
+    against the single-actor numpy env driven through the reference-style wrapper"""
+    from surreal_amd.replay import FIFOReplay, UniformReplay
+    from surreal_amd.env import SyntheticEnv, SyntheticVecEnv, ExpSenderWrapperMultiStepMovingWindowWithInfo
+    n, D, A, T, n_step, stride = 3, 7, 2, 11, 4, 3
+    g = torch.Generator().manual_seed(0)
+    acts = torch.randn(T, n, A, generator=g) * 0.7
+    venv = SyntheticVecEnv(n, D, A, episode_len=T, seeds=[5, 6, 7])
+    venv.start_rollout(T, info_width=2 * A)
+    for t in range(T):
+        venv.step(acts[t], pds=torch.full((n, 2 * A), float(t)))
+    win = venv.emit_windows(n_step, stride)
+    W = (T - n_step) // stride + 1
+    assert win['obs'].shape == (n * W, n_step, D) and win['obs_next'].shape == (n * W, 1, D)
+    lc, ec, sc = configs(N=n_step, stride=stride, D=D, A=A)
+    for a in range(n):                                     # same thing, one actor at a time
+        got = []
+        w = ExpSenderWrapperMultiStepMovingWindowWithInfo(SyntheticEnv(D, A, T, seed=5 + a), lc, sc,
+                                                          sink=got.append)
+        w.reset()
+        for t in range(T):
+            w.step((acts[t, a].numpy(), [[], [np.zeros(2 * A)]]))
+        assert len(got) == W
+        for k, e in enumerate(got):
+            ob = np.stack([o['low_dim']['flat_inputs'] for o in e['obs']])
+            np.testing.assert_array_equal(win['obs'][a * W + k].numpy(), ob)
+            np.testing.assert_array_equal(win['obs_next'][a * W + k, 0].numpy(),
+                                          e['obs_next']['low_dim']['flat_inputs'])
+            np.testing.assert_array_equal(win['rewards'][a * W + k].numpy(),
+                                          np.array(e['rewards'], dtype=np.float32))
+            np.testing.assert_array_equal(win['dones'][a * W + k].numpy(),
+                                          np.array(e['dones'], dtype=np.float32))
+            np.testing.assert_array_equal(win['actions'][a * W + k].numpy(),
+                                          np.clip(np.stack(e['actions']), -1, 1).astype(np.float32))
+    # FIFO device tier: conveyor semantics incl. overflow (capacity memory_size + 3)
+    lc.replay.memory_size, lc.replay.batch_size = 6, 4
+    f = FIFOReplay(lc, ec, sc)
+    fields = {k: v for k, v in win.items()}
+    f.insert_batch(fields)                                 # 9 experiences into capacity 9
+    assert len(f) == n * W and f.start_sample_condition()
+    b = f.sample_batch(4)
+    assert torch.equal(b['obs'], win['obs'][:4]) and len(f) == n * W - 4
+    f.insert_batch({k: v[:6] for k, v in fields.items()})  # 5 + 6 = 11 > 9: two oldest dropped
+    assert len(f) == 9
+    b = f.sample_batch(4)
+    assert torch.equal(b['rewards'], torch.cat([win['rewards'][6:9], win['rewards'][:1]]))
+    # uniform device tier: ring overwrite + injected indices
+    lc.replay.memory_size = 5
+    u = UniformReplay(lc, ec, sc)
+    u.insert_batch({k: v[:8] for k, v in fields.items()})  # capacity 5 <- last 5 of 8... ring
+    assert len(u) == 5
+    u2 = UniformReplay(lc, ec, sc)
+    for i in range(8):
+        u2.insert_batch({k: v[i:i + 1] for k, v in fields.items()})
+    got = u2.sample_batch(5, indices=[0, 1, 2, 3, 4])
+    np.testing.assert_array_equal(got['obs'].numpy(), win['obs'][[5, 6, 7, 3, 4]].numpy())
+    idx = u2.sample_indices(64)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 5
+
+
+def test_agent_replay_learner_loop_in_process(cpu_double):
+    """agents (reference-style, one env each) -> windowing wrapper -> FIFO replay -> learner;
+    then the learner publishes and the agents pick the new parameters up."""
+    from surreal_amd.agent import PPOAgent
+    from surreal_amd.env import SyntheticEnv
+    from surreal_amd.learner import PPOLearner
+    from surreal_amd.replay import FIFOReplay
+    D, A, N = 7, 2, 5
+    lc, ec, sc = configs(B=4, N=N, stride=3, D=D, A=A, memory=8)
+    ec.limit_episode_length = 12
+    lc.parameter_publish.exp_interval = 4
+    lc.parameter_publish.min_publish_interval = 0.0
+    replay = FIFOReplay(lc, ec, sc)
+    learner = PPOLearner(lc, ec, sc)
+    learner.attach_replay(replay)
+    agents = []
+    for i in range(2):
+        ag = PPOAgent(lc, ec, sc, agent_id=i, agent_mode='training')
+        ag.set_experience_sink(replay._insert_wrapper)
+        ag.set_env_factory(lambda i=i: SyntheticEnv(D, A, episode_len=50, seed=i))
+        ag.attach_learner(learner)
+        ag.main_setup()
+        agents.append(ag)
+    learner.main_setup()
+    for it in range(2):
+        for ag in agents:
+            ag.main_loop()
+            ag.main_loop()
+        assert replay.start_sample_condition()
+        learner.main_loop()
+    assert learner.current_iter == 2 and learner.epochs_executed >= 1
+    assert replay.cumulative_collected_count == 2 * 2 * 2 * ((12 - N) // 3 + 1)
+    st = learner.tensorplex.latest
+    for k in ('_surr_loss', '_val_loss', '_pol_kl', '_entropy', '_avg_return_targ', 'obs_running_mean'):
+        assert np.isfinite(st[k]), k
+    # publish happened (exp_interval reached) -> reference policy refreshed, agents can fetch
+    assert learner.exp_counter == 0
+    before = agents[0].model.actor_flat.clone()
+    assert agents[0].fetch_parameter() and not agents[0].fetch_parameter()
+    assert torch.equal(agents[0].model.actor_flat, learner.model.actor_flat)
+    assert not torch.equal(before, agents[0].model.actor_flat)
+    # eval agent: deterministic action = clipped mean
+    ev = PPOAgent(lc, ec, sc, agent_id=9, agent_mode='eval_deterministic_local')
+    o, _ = SyntheticEnv(D, A, seed=3).reset()
+    a1, a2 = ev.act(o), ev.act(o)
+    np.testing.assert_array_equal(a1, a2)
+    acts, pds = agents[0].act_batch(torch.randn(6, D), eps=torch.zeros(6, A))
+    np.testing.assert_allclose(acts.numpy(), np.clip(pds[:, :A].numpy(), -1, 1))
