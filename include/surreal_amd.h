@@ -110,6 +110,13 @@ int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, const float* 
                    int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
                    const float* relu_mask, const int32_t* stop_flag, smx_stream_t stream);
 
+/* Weight gradient of one dense layer: dW[M,N] = dZ^T . X, db[M] = column sums of dZ (db may be
+ * NULL); dZ [rows, .] with row stride ldz, X [rows, .] with row stride ldx (what
+ * loss.backward() produces for nn.Linear, ddpg.py:308,331). */
+int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X, int32_t ldx, float* dW,
+                         int32_t ldw, float* db, int32_t M, int32_t N, int32_t rows,
+                         smx_stream_t stream);
+
 /* MLP forward keeping the hidden activations (needed by the backward):
  * h1 [rows,H1], h2 [rows,H2], out [rows,OUT] = act(layer 3). */
 int smx_mlp3_forward_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1,
@@ -276,6 +283,33 @@ int smx_synth_env_step_f32(float* state, const float* init_state, const float* a
                            int32_t n, int32_t D, int32_t A, int32_t t, int32_t episode_len,
                            int32_t slot, int32_t T, float* obs_roll, float* act_roll,
                            float* rew_roll, float* done_roll, smx_stream_t stream);
+
+/* --- DDPG update pieces (surreal/learner/ddpg.py:244-352, 403-428) --------------------
+ * Dense layers reuse smx_linear_f32 / smx_mlp3_*; the critic's "concat action into layer 2"
+ * (builders.py:58-84) is expressed with row strides: layer 1 writes into the first c1 columns
+ * of a [rows, c1+A] buffer whose last A columns hold the action.
+ *   y = rewards + gamma^n * Q'(s', mu'(s')) * (1 - done)   (ddpg.py:279)
+ *   dz3 = 2 (Q - y) / rows = d MSELoss / dQ                (ddpg.py:307-308) */
+int smx_ddpg_critic_loss_f32(const float* q, const float* q_next_target, const float* rewards,
+                             const float* dones, float gamma_n, int64_t rows, float* y,
+                             float* dz3, smx_stream_t stream);
+/* out = da * (1 - a^2): backward of the actor's final Tanh (builders.py:50) */
+int smx_tanh_backward_f32(const float* da, const float* a, int64_t n, float* out,
+                          smx_stream_t stream);
+int smx_fill_f32(float* x, int64_t n, float value, smx_stream_t stream);
+/* torch.optim.Adam step with optional clip_grad_value_ (Module.clip_grad_value, ddpg.py:309,332);
+ * step = 1-based Adam step count; clip_value <= 0 disables clipping. */
+int smx_adam_step_f32(float* theta, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      int64_t n, double lr, int32_t step, double weight_decay,
+                      double clip_value, smx_stream_t stream);
+/* target = target*(1-tau) + source*tau ; tau >= 1 is hard_update (ddpg.py:410-428) */
+int smx_soft_update_f32(float* target, const float* source, float tau, int64_t n,
+                        smx_stream_t stream);
+/* stats[6] = {actor_loss = -mean q_actor, critic_loss = mean (q-y)^2, action_norm = mean
+ * ||a||_2, mean rewards, Q_target = mean y, Q_policy = mean q}   (ddpg.py:335-342) */
+int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
+                       const float* actions, int32_t ld_act, int32_t A, const float* q_actor,
+                       int64_t rows, float* stats, smx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,140 @@
+"""
+TEST INFRASTRUCTURE ONLY.  CPU restatement (PyTorch fp32) of the reference's DDPG update
+(surreal/learner/ddpg.py:244-352, 403-428; surreal/model/ddpg_net.py:13-95;
+model_builders/builders.py:35-84 with use_layernorm=False), low-dimensional observations,
+single critic, no TD3 action regularisation (the reference defaults, ddpg_configs.py:16-98).
+oracle/gen_golden_ddpg.py pins it bit-for-bit against the reference's own DDPGLearner.
+
+Canonical parameter names: actor.fc{1,2,3}.{W,b} (D->h1->h2->A, tanh);
+critic.fc1.{W,b} (D->c1), critic.fc2.{W,b} (c1+A->c2), critic.fc3.{W,b} (c2->1).
+"""
+import collections
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def make_ddpg_params(D, A, actor_hidden=(300, 200), critic_hidden=(400, 300), seed=3):
+    rs = np.random.RandomState(seed)
+    p = collections.OrderedDict()
+
+    def lin(name, out_f, in_f):
+        b = 1.0 / np.sqrt(in_f)
+        p[name + '.W'] = rs.uniform(-b, b, (out_f, in_f)).astype(np.float32)
+        p[name + '.b'] = rs.uniform(-b, b, (out_f,)).astype(np.float32)
+    lin('actor.fc1', actor_hidden[0], D)
+    lin('actor.fc2', actor_hidden[1], actor_hidden[0])
+    lin('actor.fc3', A, actor_hidden[1])
+    lin('critic.fc1', critic_hidden[0], D)
+    lin('critic.fc2', critic_hidden[1], critic_hidden[0] + A)
+    lin('critic.fc3', 1, critic_hidden[1])
+    return p
+
+
+class OracleDDPGModel(object):
+    def __init__(self, params):
+        self.p = collections.OrderedDict(
+            (k, torch.tensor(np.asarray(v), dtype=torch.float32).clone().requires_grad_(True))
+            for k, v in params.items())
+
+    def actor_params(self):
+        return [v for k, v in self.p.items() if k.startswith('actor.')]
+
+    def critic_params(self):
+        return [v for k, v in self.p.items() if k.startswith('critic.')]
+
+    def forward_actor(self, x):                       # builders.py:35-56
+        p = self.p
+        h = torch.relu(F.linear(x, p['actor.fc1.W'], p['actor.fc1.b']))
+        h = torch.relu(F.linear(h, p['actor.fc2.W'], p['actor.fc2.b']))
+        return torch.tanh(F.linear(h, p['actor.fc3.W'], p['actor.fc3.b']))
+
+    def forward_critic(self, x, a):                   # builders.py:58-84
+        p = self.p
+        h = torch.relu(F.linear(x, p['critic.fc1.W'], p['critic.fc1.b']))
+        h = torch.cat((h, a), 1)
+        h = torch.relu(F.linear(h, p['critic.fc2.W'], p['critic.fc2.b']))
+        return F.linear(h, p['critic.fc3.W'], p['critic.fc3.b'])
+
+    def load_from(self, other, tau=None):
+        with torch.no_grad():
+            for k in self.p:
+                if tau is None:
+                    self.p[k].copy_(other.p[k])                                   # hard_update
+                else:
+                    self.p[k].copy_(self.p[k] * (1.0 - tau) + other.p[k] * tau)   # soft_update
+
+    def numpy_params(self):
+        return collections.OrderedDict((k, v.detach().numpy().copy()) for k, v in self.p.items())
+
+
+class OracleDDPGLearner(object):
+    def __init__(self, params, gamma=0.99, n_step=3, lr_actor=1e-4, lr_critic=1e-3,
+                 clip_actor_gradient=True, actor_gradient_value_clip=1.0,
+                 clip_critic_gradient=False, critic_gradient_value_clip=5.0,
+                 actor_regularization=0.0, critic_regularization=0.0,
+                 target_update_type='hard', target_update_interval=500, tau=1e-3):
+        self.model = OracleDDPGModel(params)
+        self.model_target = OracleDDPGModel(params)
+        self.gamma, self.n_step = gamma, n_step
+        self.clip_actor_gradient, self.actor_clip = clip_actor_gradient, actor_gradient_value_clip
+        self.clip_critic_gradient, self.critic_clip = clip_critic_gradient, critic_gradient_value_clip
+        self.critic_optim = torch.optim.Adam(self.model.critic_params(), lr=lr_critic,
+                                             weight_decay=critic_regularization)
+        self.actor_optim = torch.optim.Adam(self.model.actor_params(), lr=lr_actor,
+                                            weight_decay=actor_regularization)
+        self.target_update_type = target_update_type
+        self.target_update_interval = target_update_interval
+        self.tau = tau
+        self.target_update_counter = 0
+        self.critic_criterion = nn.MSELoss()
+
+    def optimize(self, obs, actions, rewards, obs_next, done):   # ddpg.py:244-352
+        m, mt = self.model, self.model_target
+        assert actions.max().item() <= 1.0 and actions.min().item() >= -1.0
+        model_policy = mt.forward_actor(obs_next)
+        next_Q_target = mt.forward_critic(obs_next, model_policy)
+        y = rewards + pow(self.gamma, self.n_step) * next_Q_target * (1.0 - done)
+        y = y.detach()
+        y_policy = m.forward_critic(obs, actions.detach())
+        for q in m.critic_params():
+            q.grad = None
+        critic_loss = self.critic_criterion(y_policy, y)
+        critic_loss.backward()
+        if self.clip_critic_gradient:
+            nn.utils.clip_grad_value_(m.critic_params(), self.critic_clip)
+        self.critic_optim.step()
+        for q in m.actor_params():
+            q.grad = None
+        actor_loss = -m.forward_critic(obs.detach(), m.forward_actor(obs.detach()))
+        actor_loss = actor_loss.mean()
+        actor_loss.backward()
+        if self.clip_actor_gradient:
+            nn.utils.clip_grad_value_(m.actor_params(), self.actor_clip)
+        self.actor_optim.step()
+        stats = {
+            'actor_loss': actor_loss.item(),
+            'critic_loss': critic_loss.item(),
+            'action_norm': actions.norm(2, 1).mean().item(),
+            'rewards': rewards.mean().item(),
+            'Q_target': y.mean().item(),
+            'Q_policy': y_policy.mean().item(),
+        }
+        self._target_update()
+        return stats
+
+    def _target_update(self):                                    # ddpg.py:403-428
+        if self.target_update_type == 'soft':
+            self.model_target.load_from(self.model, self.tau)
+        else:
+            self.target_update_counter += 1
+            if self.target_update_counter % self.target_update_interval == 0:
+                self.model_target.load_from(self.model)
+
+    def learn(self, batch):
+        t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).clone()  # noqa: E731
+        return self.optimize(t(batch['obs']['low_dim']['flat_inputs']), t(batch['actions']),
+                             t(batch['rewards']), t(batch['obs_next']['low_dim']['flat_inputs']),
+                             t(batch['dones']))

@@ -1,0 +1,148 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE ONLY.  tests/golden/ddpg_*.npz from the REFERENCE's own DDPGLearner
+(surreal/learner/ddpg.py run under oracle/ref_shims.py, build container only), several
+consecutive iterations with injected parameters; cross-checks oracle/ddpg_oracle.py bit-for-bit."""
+import collections
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+ref_shims.install()
+from surreal_amd import synthetic  # noqa: E402
+import ddpg_oracle  # noqa: E402
+import surreal.utils as U  # noqa: E402
+from surreal.learner.ddpg import DDPGLearner  # noqa: E402
+from surreal.model.ddpg_net import DDPGModel  # noqa: E402
+
+
+def lin_layers(net_functional):
+    return [l for l in net_functional.layers if hasattr(l, 'fc')]
+
+
+def inject(m, params):
+    with torch.no_grad():
+        for i, l in enumerate(lin_layers(m.actor.model)):
+            l.fc.weight.copy_(torch.tensor(params['actor.fc%d.W' % (i + 1)]))
+            l.fc.bias.copy_(torch.tensor(params['actor.fc%d.b' % (i + 1)]))
+        c = lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)
+        for i, l in enumerate(c):
+            l.fc.weight.copy_(torch.tensor(params['critic.fc%d.W' % (i + 1)]))
+            l.fc.bias.copy_(torch.tensor(params['critic.fc%d.b' % (i + 1)]))
+
+
+def extract(m):
+    out = collections.OrderedDict()
+    for i, l in enumerate(lin_layers(m.actor.model)):
+        out['actor.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
+        out['actor.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    for i, l in enumerate(lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)):
+        out['critic.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
+        out['critic.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    return out
+
+
+class _Timer(object):
+    avg = 0.0
+
+    def time(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def build_ref(params, D, A, ah, ch, hyper):
+    L = object.__new__(DDPGLearner)
+    L.batch_size = hyper['B']
+    L.discount_factor, L.n_step = hyper['gamma'], hyper['n_step']
+    L.is_pixel_input = False
+    L.use_double_critic = False
+    L.use_action_regularization = False
+    L.gpu_ids, L._num_gpus = 'cpu', 0
+    L.clip_actor_gradient, L.actor_gradient_clip_value = True, 1.0
+    L.clip_critic_gradient, L.critic_gradient_clip_value = hyper.get('clip_critic', False), 5.0
+    L.action_dim = A
+    obs_spec = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=[D]))
+    mk = lambda: DDPGModel(obs_spec=obs_spec, action_dim=A, use_layernorm=False,  # noqa: E731
+                           actor_fc_hidden_sizes=list(ah), critic_fc_hidden_sizes=list(ch),
+                           conv_out_channels=[16, 32], conv_kernel_sizes=[8, 4], conv_strides=[4, 2],
+                           conv_hidden_dim=200)
+    L.model, L.model_target = mk(), mk()
+    inject(L.model, params)
+    inject(L.model_target, params)
+    L.critic_criterion = torch.nn.MSELoss()
+    L.critic_optim = torch.optim.Adam(L.model.get_critic_parameters(), lr=hyper['lr_critic'])
+    L.actor_optim = torch.optim.Adam(L.model.get_actor_parameters(), lr=hyper['lr_actor'])
+    L.target_update_type = hyper['target_update_type']
+    L.target_update_counter = 0
+    L.target_update_interval = hyper['target_update_interval']
+    L.target_update_tau = hyper.get('tau', 1e-3)
+    L.forward_time = L.critic_update_time = L.actor_update_time = _Timer()
+    return L
+
+
+CASES = {
+    'tiny_hard': dict(B=16, D=5, A=2, ah=(24, 16), ch=(32, 24), iters=4,
+                      hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-3, lr_critic=1e-2,
+                                 target_update_type='hard', target_update_interval=2)),
+    'tiny_soft_clipcritic': dict(B=37, D=9, A=3, ah=(40, 24), ch=(48, 40), iters=3,
+                                 hyper=dict(gamma=0.9, n_step=1, lr_actor=1e-3, lr_critic=1e-2,
+                                            target_update_type='soft', target_update_interval=1,
+                                            tau=0.05, clip_critic=True)),
+    'cfg3_cheetah512': dict(B=512, D=17, A=6, ah=(300, 200), ch=(400, 300), iters=3,
+                            hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-4, lr_critic=1e-3,
+                                       target_update_type='hard', target_update_interval=500)),
+}
+
+
+def main():
+    for name, c in CASES.items():
+        hyper = dict(c['hyper'], B=c['B'])
+        params = ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=3)
+        Lr = build_ref(params, c['D'], c['A'], c['ah'], c['ch'], hyper)
+        O = ddpg_oracle.OracleDDPGLearner(
+            params, gamma=hyper['gamma'], n_step=hyper['n_step'], lr_actor=hyper['lr_actor'],
+            lr_critic=hyper['lr_critic'], clip_critic_gradient=hyper.get('clip_critic', False),
+            target_update_type=hyper['target_update_type'],
+            target_update_interval=hyper['target_update_interval'], tau=hyper.get('tau', 1e-3))
+        traces = []
+        for it in range(c['iters']):
+            b = synthetic.make_ddpg_batch(c['B'], c['D'], c['A'], seed=10 + it)
+            t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)  # noqa: E731
+            obs = {'low_dim': {'flat_inputs': t(b['obs']['low_dim']['flat_inputs'])}}
+            obs_next = {'low_dim': {'flat_inputs': t(b['obs_next']['low_dim']['flat_inputs'])}}
+            sr = Lr._optimize(obs, t(b['actions']), t(b['rewards']), obs_next, t(b['dones']))
+            sr = {k: float(v) for k, v in sr.items() if not k.startswith('performance')}
+            so = O.learn(b)
+            for k in sr:
+                assert sr[k] == so[k], (name, it, k, sr[k], so[k])
+            traces.append(sr)
+        fr, fo = extract(Lr.model), O.model.numpy_params()
+        for k in fr:
+            np.testing.assert_array_equal(fr[k], fo[k])
+        ft = extract(Lr.model_target)
+        for k in ft:
+            np.testing.assert_array_equal(ft[k], O.model_target.numpy_params()[k])
+        out = {'case_json': np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v)
+                                                 for k, v in c.items()})),
+               'trace_json': np.array(json.dumps(traces))}
+        if c['B'] <= 64:
+            for k, v in fr.items():
+                out['final.' + k] = v
+            for k, v in ft.items():
+                out['target.' + k] = v
+        out['final_sumsq_json'] = np.array(json.dumps(
+            {k: float(np.sum(v.astype(np.float64) ** 2)) for k, v in fr.items()}))
+        path = os.path.join(ROOT, 'tests', 'golden', 'ddpg_%s.npz' % name)
+        np.savez_compressed(path, **out)
+        print(name, traces[-1], os.path.getsize(path))
+
+
+if __name__ == '__main__':
+    main()

@@ -6,8 +6,8 @@ PyTorch is plumbing here: device memory (tensor.data_ptr()) and the current HIP 
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64,
-                    c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t,
+                    c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsurreal_amd.so')
@@ -46,6 +46,8 @@ _SIGS = {
                                              c_int64, c_int32, c_int32, _P, _P, _P, c_int32, _P]),
     'smx_linear_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, c_int32, _P, _P, c_int32,
                                  c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    'smx_linear_wgrad_f32': (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32,
+                                       c_int32, _P]),
     'smx_mlp3_forward_f32': (c_int32, [POINTER(Mlp3), _P, c_int64, _P, _P, _P, c_int32, _P, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_backward_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
@@ -75,6 +77,13 @@ _SIGS = {
                                       c_int32, _P, _P]),
     'smx_synth_env_step_f32': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_int32, c_int32, _P, _P, _P, _P, _P]),
+    'smx_ddpg_critic_loss_f32': (c_int32, [_P, _P, _P, _P, c_float, c_int64, _P, _P, _P]),
+    'smx_tanh_backward_f32': (c_int32, [_P, _P, c_int64, _P, _P]),
+    'smx_fill_f32': (c_int32, [_P, c_int64, c_float, _P]),
+    'smx_adam_step_f32': (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_int32, c_double, c_double,
+                                    _P]),
+    'smx_soft_update_f32': (c_int32, [_P, _P, c_float, c_int64, _P]),
+    'smx_ddpg_stats_f32': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int64, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

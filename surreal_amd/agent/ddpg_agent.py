@@ -1,0 +1,95 @@
+"""
+DDPGAgent (surreal/agent/ddpg_agent.py:26-200): deterministic actor + exploration noise.
+``act(obs)`` is the batch-1 reference contract; ``act_batch(obs)`` evaluates all actors of a GPU
+in one actor forward (HIP).  Exploration scale follows the reference: sigma_i =
+max_sigma * agent_id / num_agents (max_sigma / 3 for a single agent), ddpg_agent.py:78-84.
+Parameter-space noise (param_noise.py) is not built (raises).
+"""
+import collections
+import time
+
+import numpy as np
+import torch
+
+from surreal_amd import kernels as KN
+from surreal_amd.env import ExpSenderWrapperSSARNStepBootstrap
+from surreal_amd.model.ddpg_net import DDPGModel
+from surreal_amd.session import ConfigError
+from .action_noise import NormalActionNoise, OrnsteinUhlenbeckActionNoise
+from .base import Agent
+
+
+class DDPGAgent(Agent):
+    def __init__(self, learner_config, env_config, session_config, agent_id, agent_mode,
+                 render=False):
+        super().__init__(learner_config=learner_config, env_config=env_config,
+                         session_config=session_config, agent_id=agent_id, agent_mode=agent_mode,
+                         render=render)
+        self.action_dim = self.env_config.action_spec.dim[0]
+        self.obs_spec = self.env_config.obs_spec
+        self.sleep_time = self.env_config.get('sleep_time', 0.0)
+        ex = self.learner_config.algo.exploration
+        if ex.param_noise_type:
+            raise NotImplementedError('parameter-space noise is not built yet')
+        self.noise_type = ex.noise_type
+        n_agents = self.env_config.get('num_agents', 1)
+        if n_agents == 1:
+            self.sigma = ex.max_sigma / 3.0
+        else:
+            self.sigma = ex.max_sigma * (float(agent_id) / n_agents)
+        self.K = KN.default_kernels()
+        self.device = KN.default_device()
+        self.model = DDPGModel(obs_spec=self.obs_spec, action_dim=self.action_dim,
+                               use_layernorm=self.learner_config.model.use_layernorm,
+                               actor_fc_hidden_sizes=self.learner_config.model.actor_fc_hidden_sizes,
+                               critic_fc_hidden_sizes=self.learner_config.model.critic_fc_hidden_sizes,
+                               device=self.device, kernels=self.K)
+        self.sink = None
+        self._init_noise()
+
+    def _init_noise(self):
+        self.noise = None
+        if self.agent_mode in ['eval_deterministic', 'eval_deterministic_local']:
+            return
+        if self.noise_type == 'normal':
+            self.noise = NormalActionNoise(np.zeros(self.action_dim),
+                                           np.ones(self.action_dim) * self.sigma)
+        elif self.noise_type == 'ou_noise':
+            ex = self.learner_config.algo.exploration
+            self.noise = OrnsteinUhlenbeckActionNoise(mu=np.zeros(self.action_dim), sigma=self.sigma,
+                                                      theta=ex.theta, dt=ex.dt)
+        else:
+            raise ConfigError('Noise type {} undefined.'.format(self.noise_type))
+
+    def act(self, obs):                                   # ddpg_agent.py:155-184
+        if self.sleep_time > 0.0:
+            time.sleep(self.sleep_time)
+        x = torch.as_tensor(np.asarray(obs['low_dim']['flat_inputs']), dtype=torch.float32) \
+            .unsqueeze(0).to(self.device)
+        action = self.model.forward_actor(x).cpu().numpy()[0]
+        action = action.clip(-1, 1)
+        if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:
+            action = action + self.noise()
+        return action.clip(-1, 1)
+
+    def act_batch(self, obs, sigmas=None, eps=None, generator=None):
+        """obs [n, D] on the device -> actions [n, A]; sigmas [n] per-actor exploration scale
+        (default: this agent's sigma for all rows)"""
+        a = self.model.forward_actor(obs).clamp_(-1.0, 1.0)
+        if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:
+            if eps is None:
+                eps = torch.randn(a.shape, device=a.device, generator=generator)
+            s = self.sigma if sigmas is None else sigmas.view(-1, 1)
+            a = a + eps * s
+        return a.clamp_(-1.0, 1.0)
+
+    def module_dict(self, model=None):
+        return {'ddpg': self.model if model is None else model}
+
+    def set_experience_sink(self, sink):
+        self.sink = sink
+
+    def prepare_env_agent(self, env):
+        env = super().prepare_env_agent(env)
+        return ExpSenderWrapperSSARNStepBootstrap(env, self.learner_config, self.session_config,
+                                                  sink=self.sink)

@@ -1,0 +1,167 @@
+// DDPG update pieces that are not plain dense layers (surreal/learner/ddpg.py:244-352,403-428):
+// Bellman target + MSE gradient, tanh backward, value-clipped Adam, soft/hard target update,
+// the statistics the reference logs.  All HBM-bound elementwise / small-reduction kernels; the
+// dense layers (actor MLP, critic with the action concatenated into layer 2) reuse the FP32-MFMA
+// smx_linear_f32 / smx_mlp3_* entry points.
+#include "smx_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void ddpg_critic_loss_kernel(
+    const float* __restrict__ q, const float* __restrict__ q_next, const float* __restrict__ rewards,
+    const float* __restrict__ dones, float gamma_n, long rows, float* __restrict__ y,
+    float* __restrict__ dz3) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    // y = rewards + gamma^n * Q'(s', mu'(s')) * (1 - done)        (ddpg.py:279)
+    const float t = (gamma_n * q_next[r]) * (1.0f - dones[r]);
+    const float yy = rewards[r] + t;
+    y[r] = yy;
+    dz3[r] = (2.0f * (q[r] - yy)) / (float)rows;   // d MSELoss / dQ   (ddpg.py:307-308)
+}
+
+__global__ __launch_bounds__(256) void tanh_backward_kernel(const float* __restrict__ da,
+                                                            const float* __restrict__ a, long n,
+                                                            float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = da[i] * (1.0f - a[i] * a[i]);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long n, float v) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
+                                                   const float* __restrict__ grads,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float neg_step_size, float bc2_sqrt, float w1,
+                                                   float b2f, float w2, float eps, float wd,
+                                                   float clip_value) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g = grads[i];
+    if (clip_value > 0.f) g = fminf(fmaxf(g, -clip_value), clip_value);   // clip_grad_value_
+    const float p = theta[i];
+    if (wd != 0.f) g = g + wd * p;
+    float mi = m[i], vi = v[i];
+    mi = mi + w1 * (g - mi);
+    vi = vi * b2f + w2 * (g * g);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    theta[i] = p + (neg_step_size * mi) / denom;
+    m[i] = mi;
+    v[i] = vi;
+}
+
+__global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ tgt,
+                                                          const float* __restrict__ src, float tau,
+                                                          long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // torchx Module.soft_update: target = target * (1 - tau) + source * tau ; tau = 1 -> hard copy
+    tgt[i] = (tau >= 1.0f) ? src[i] : (tgt[i] * (1.0f - tau) + src[i] * tau);
+}
+
+// stats[6] = {actor_loss, critic_loss, action_norm, rewards, Q_target, Q_policy}  (ddpg.py:335-342)
+__global__ __launch_bounds__(1024) void ddpg_stats_kernel(
+    const float* __restrict__ q, const float* __restrict__ y, const float* __restrict__ rewards,
+    const float* __restrict__ actions, int ld_act, int A, const float* __restrict__ q_actor, long rows,
+    float* __restrict__ stats) {
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (long r = threadIdx.x; r < rows; r += 1024) {
+        const float d = q[r] - y[r];
+        float nn = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float a = actions[r * ld_act + j];
+            nn += a * a;
+        }
+        acc[0] += (double)(-q_actor[r]);
+        acc[1] += (double)(d * d);
+        acc[2] += (double)sqrtf(nn);
+        acc[3] += (double)rewards[r];
+        acc[4] += (double)y[r];
+        acc[5] += (double)q[r];
+    }
+    for (int k = 0; k < 6; ++k) {
+        double s = smx_wave_sum_d(acc[k]);
+        __syncthreads();
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += red[i];
+            stats[k] = (float)(t / (double)rows);
+        }
+    }
+}
+
+inline unsigned nb(long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int smx_ddpg_critic_loss_f32(const float* q, const float* q_next_target,
+                                        const float* rewards, const float* dones, float gamma_n,
+                                        int64_t rows, float* y, float* dz3, smx_stream_t stream) {
+    SMX_REQUIRE(q && q_next_target && rewards && dones && y && dz3, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(ddpg_critic_loss_kernel, dim3(nb(rows)), dim3(256), 0, smx_s(stream), q,
+                       q_next_target, rewards, dones, gamma_n, (long)rows, y, dz3);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_tanh_backward_f32(const float* da, const float* a, int64_t n, float* out,
+                                     smx_stream_t stream) {
+    SMX_REQUIRE(da && a && out, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(tanh_backward_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), da, a, (long)n,
+                       out);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_fill_f32(float* x, int64_t n, float value, smx_stream_t stream) {
+    SMX_REQUIRE(x, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(fill_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), x, (long)n, value);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_adam_step_f32(float* theta, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                 int64_t n, double lr, int32_t step, double weight_decay,
+                                 double clip_value, smx_stream_t stream) {
+    SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && step > 0, SMX_E_SHAPE);
+    const double beta1 = 0.9, beta2 = 0.999;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), theta, grads, exp_avg,
+                       exp_avg_sq, (long)n, (float)(-(lr / bc1)), (float)sqrt(bc2), (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), 1e-8f, (float)weight_decay, (float)clip_value);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_soft_update_f32(float* target, const float* source, float tau, int64_t n,
+                                   smx_stream_t stream) {
+    SMX_REQUIRE(target && source, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && tau > 0.f, SMX_E_SHAPE);
+    hipLaunchKernelGGL(soft_update_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), target, source,
+                       tau, (long)n);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
+                                  const float* actions, int32_t ld_act, int32_t A,
+                                  const float* q_actor, int64_t rows, float* stats,
+                                  smx_stream_t stream) {
+    SMX_REQUIRE(q && y && rewards && actions && q_actor && stats, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && A > 0 && ld_act >= A, SMX_E_SHAPE);
+    hipLaunchKernelGGL(ddpg_stats_kernel, dim3(1), dim3(1024), 0, smx_s(stream), q, y, rewards, actions,
+                       ld_act, A, q_actor, (long)rows, stats);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}

@@ -190,6 +190,20 @@ extern "C" int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, co
     return launch_batch(G, smx_s(stream));
 }
 
+// dW[M,N] = dZ^T . X (dZ [rows, >=M] stride ldz, X [rows, >=N] stride ldx), db[M] = column sums of dZ
+extern "C" int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
+                                    float* dW, int32_t ldw, float* db, int32_t M, int32_t N,
+                                    int32_t rows, smx_stream_t stream) {
+    SMX_REQUIRE(dZ && X && dW, SMX_E_NULL);
+    SMX_REQUIRE(M > 0 && N > 0 && rows > 0 && ldz >= M && ldx >= N && ldw >= N, SMX_E_SHAPE);
+    GemmBatch G;
+    G.n = 1;
+    G.stop = nullptr;
+    fill_prob(G.p[0], dZ, ldz, 0, X, ldx, 0, nullptr, nullptr, dW, ldw, M, N, rows, SMX_ACT_NONE, db,
+              nullptr, 0);
+    return launch_batch(G, smx_s(stream));
+}
+
 extern "C" int smx_mlp3_forward_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1,
                                     float* h2, float* out, int32_t out_act,
                                     const int32_t* stop_flag, smx_stream_t stream) {

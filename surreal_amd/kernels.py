@@ -171,6 +171,47 @@ class HipKernels(object):
                L.ptr(rew_roll), L.ptr(done_roll), self._st())
 
 
+    # ---- generic dense layer + DDPG pieces ---------------------------------------------------
+    def linear(self, A, a_kc, B, b_kc, bias, C, M, N, K, act=0, relu_mask=None, lda=None, ldb=None,
+               ldc=None, stop=None):
+        """C[M,N] = act(A . B^T + bias) with explicit leading strides (views into wider buffers)"""
+        lda = lda if lda is not None else A.stride(0)
+        ldb = ldb if ldb is not None else B.stride(0)
+        ldc = ldc if ldc is not None else C.stride(0)
+        L.call('smx_linear_f32', L.ptr(A), lda, int(a_kc), L.ptr(B), ldb, int(b_kc), L.ptr(bias),
+               L.ptr(C), ldc, M, N, K, act, L.ptr(relu_mask), L.ptr(stop), self._st())
+
+    def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None):
+        ldz = ldz if ldz is not None else dZ.stride(0)
+        ldx = ldx if ldx is not None else X.stride(0)
+        ldw = ldw if ldw is not None else dW.stride(0)
+        L.call('smx_linear_wgrad_f32', L.ptr(dZ), ldz, L.ptr(X), ldx, L.ptr(dW), ldw, L.ptr(db), M, N,
+               rows, self._st())
+
+    def ddpg_critic_loss(self, q, q_next, rewards, dones, gamma_n, y, dz3):
+        L.call('smx_ddpg_critic_loss_f32', L.ptr(q), L.ptr(q_next), L.ptr(rewards), L.ptr(dones),
+               float(gamma_n), q.numel(), L.ptr(y), L.ptr(dz3), self._st())
+
+    def tanh_backward(self, da, a, out):
+        L.call('smx_tanh_backward_f32', L.ptr(da), L.ptr(a), a.numel(), L.ptr(out), self._st())
+
+    def fill(self, x, value):
+        L.call('smx_fill_f32', L.ptr(x), x.numel(), float(value), self._st())
+
+    def adam_step(self, theta, grads, m, v, lr, step, weight_decay=0.0, clip_value=0.0):
+        L.call('smx_adam_step_f32', L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(),
+               float(lr), int(step), float(weight_decay), float(clip_value), self._st())
+
+    def soft_update(self, target, source, tau):
+        L.call('smx_soft_update_f32', L.ptr(target), L.ptr(source), float(tau), target.numel(),
+               self._st())
+
+    def ddpg_stats(self, q, y, rewards, actions, q_actor, stats):
+        rows, A = actions.shape
+        L.call('smx_ddpg_stats_f32', L.ptr(q), L.ptr(y), L.ptr(rewards), L.ptr(actions),
+               _row_stride(actions, A), A, L.ptr(q_actor), rows, L.ptr(stats), self._st())
+
+
 # ------------------------------------------------------------------------------------------
 # process-wide default.  The product default is HipKernels on 'cuda' and nothing in
 # surreal_amd/ ever installs anything else; tests/ install a CPU test double to exercise

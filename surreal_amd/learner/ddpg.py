@@ -1,0 +1,214 @@
+"""
+DDPGLearner for MI355X -- drop-in for ``surreal.learner.ddpg.DDPGLearner``
+(surreal/learner/ddpg.py:12-440): same constructor, config keys, SSAR batch contract,
+statistics keys; one iteration = target estimate, critic MSE step (Adam 1e-3), actor step
+through the UPDATED critic (-mean Q, gradient value-clip 1, Adam 1e-4), hard / soft target
+update (ddpg.py:244-352, 403-428), as a chain of HIP launches with no host synchronisation
+until the statistics are read.
+
+Dense layers run on the FP32-MFMA layer kernel (csrc/smx_gemm.hip); the critic's
+"concatenate the action into layer 2" (builders.py:58-84) is done with row strides instead of a
+copy: layer 1 writes into the first c1 columns of a [B, c1+A] buffer whose last A columns hold
+the action.
+
+Scope: low-dimensional observations, single critic, no TD3 action regularisation, no
+LayerNorm (the reference defaults, ddpg_configs.py:16-98); the other switches raise.
+"""
+import types
+
+import numpy as np
+import torch
+
+from surreal_amd import _lib as L
+from surreal_amd import kernels as KN
+from surreal_amd.learner.aggregator import SSARAggregator
+from surreal_amd.learner.base import Learner
+from surreal_amd.model.ddpg_net import DDPGModel
+from surreal_amd.session import ConfigError
+
+
+class DDPGLearner(Learner):
+    def __init__(self, learner_config, env_config, session_config):
+        super().__init__(learner_config, env_config, session_config)
+        self.K = KN.default_kernels()
+        self.device = KN.default_device()
+        self.current_iteration = 0
+        self.batch_size = self.learner_config.replay.batch_size
+        self.discount_factor = self.learner_config.algo.gamma
+        self.n_step = self.learner_config.algo.n_step
+        self.is_pixel_input = self.env_config.get('pixel_input', False)
+        self.use_layernorm = self.learner_config.model.use_layernorm
+        net = self.learner_config.algo.network
+        self.use_double_critic = net.use_double_critic
+        self.use_action_regularization = net.use_action_regularization
+        if self.use_double_critic or self.use_action_regularization:
+            raise NotImplementedError('TD3 options (double critic / action regularisation) are '
+                                      'not built yet')
+        self._target_update_init()
+        self.clip_actor_gradient = net.clip_actor_gradient
+        self.actor_gradient_clip_value = net.actor_gradient_value_clip if self.clip_actor_gradient else 0.0
+        self.clip_critic_gradient = net.clip_critic_gradient
+        self.critic_gradient_clip_value = net.critic_gradient_value_clip if self.clip_critic_gradient else 0.0
+        self.lr_actor, self.lr_critic = net.lr_actor, net.lr_critic
+        self.actor_regularization = net.actor_regularization
+        self.critic_regularization = net.critic_regularization
+        self.action_dim = self.env_config.action_spec.dim[0]
+        mk = dict(obs_spec=self.env_config.obs_spec, action_dim=self.action_dim,
+                  use_layernorm=self.use_layernorm,
+                  actor_fc_hidden_sizes=self.learner_config.model.actor_fc_hidden_sizes,
+                  critic_fc_hidden_sizes=self.learner_config.model.critic_fc_hidden_sizes,
+                  device=self.device, kernels=self.K)
+        self.model = DDPGModel(**mk)
+        self.model_target = DDPGModel(**mk)
+        self.model_target.load_state_dict(self.model.state_dict())       # hard_update (ddpg.py:175-176)
+        z = torch.zeros_like
+        self.actor_exp_avg, self.actor_exp_avg_sq = z(self.model.actor_flat), z(self.model.actor_flat)
+        self.critic_exp_avg, self.critic_exp_avg_sq = z(self.model.critic_flat), z(self.model.critic_flat)
+        self.actor_step = 0
+        self.critic_step = 0
+        self.aggregator = SSARAggregator(self.env_config.obs_spec, self.env_config.action_spec)
+        self._ws = None
+
+    # ---- target update (ddpg.py:389-428) ----------------------------------------------------
+    def _target_update_init(self):
+        cfg = self.learner_config.algo.network.target_update
+        self.target_update_type = cfg.type
+        if self.target_update_type == 'soft':
+            self.target_update_tau = cfg.tau
+        elif self.target_update_type == 'hard':
+            self.target_update_counter = 0
+            self.target_update_interval = cfg.interval
+        else:
+            raise ConfigError('Unsupported ddpg update type: {}'.format(cfg.type))
+
+    def _target_update(self):
+        K, m, t = self.K, self.model, self.model_target
+        if self.target_update_type == 'soft':
+            K.soft_update(t.actor_flat, m.actor_flat, self.target_update_tau)
+            K.soft_update(t.critic_flat, m.critic_flat, self.target_update_tau)
+        else:
+            self.target_update_counter += 1
+            if self.target_update_counter % self.target_update_interval == 0:
+                K.soft_update(t.actor_flat, m.actor_flat, 1.0)
+                K.soft_update(t.critic_flat, m.critic_flat, 1.0)
+
+    # ---- batch (ddpg.py:186-242) ---------------------------------------------------------------
+    def _to_dev(self, x):
+        if torch.is_tensor(x):
+            return x.to(self.device, torch.float32)
+        return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.device)
+
+    def preprocess(self, batch):
+        for key in ('obs', 'obs_next'):
+            for modality in batch[key]:
+                for k in batch[key][modality]:
+                    batch[key][modality][k] = self._to_dev(batch[key][modality][k])
+        for key in ('actions', 'rewards', 'dones'):
+            batch[key] = self._to_dev(batch[key])
+        return batch
+
+    def _workspace(self, B, D):
+        if self._ws is not None and self._ws.key == (B, D):
+            return self._ws
+        m, A = self.model, self.action_dim
+        f = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)  # noqa: E731
+        ws = types.SimpleNamespace(key=(B, D))
+        a, c1, c2 = m.actor, m.c1, m.c2
+        ws.h1a, ws.h2a, ws.act = f(B, a.H1), f(B, a.H2), f(B, A)        # actor forward (s or s')
+        ws.xcat, ws.h2c, ws.q = f(B, c1 + A), f(B, c2), f(B)            # critic forward
+        ws.q_next, ws.y, ws.dz3 = f(B), f(B), f(B)
+        ws.dz2, ws.dxcat = f(B, c2), f(B, c1 + A)
+        ws.q_actor, ws.dz3a, ws.dz2a, ws.dz1a = f(B), f(B, A), f(B, a.H2), f(B, a.H1)
+        ws.grads_c = torch.zeros_like(m.critic_flat)
+        ws.grads_a = torch.zeros_like(m.actor_flat)
+        ws.gc = {}
+        o = 0
+        for name, v in m.critic.items():
+            ws.gc[name] = ws.grads_c[o:o + v.numel()].view(v.shape)
+            o += v.numel()
+        ws.stats = torch.zeros(8, device=self.device)
+        self._ws = ws
+        return ws
+
+    def _critic_backward(self, ws, x, B):
+        """gradients of the critic parameters from ws.dz3 (dLoss/dQ); leaves dLoss/d(xcat) in
+        ws.dxcat (its last A columns are dLoss/d(action))"""
+        K, m, A = self.K, self.model, self.action_dim
+        c, c1, c2, D = m.critic, m.c1, m.c2, x.shape[1]
+        dz3 = ws.dz3.view(B, 1)
+        K.linear(dz3, 1, c['W3'], 0, None, ws.dz2, B, c2, 1, relu_mask=ws.h2c, lda=1, ldb=c2)
+        # d/d(relu(layer1)) masked by relu', into the first c1 columns of dxcat
+        K.linear(ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1, c2, relu_mask=ws.xcat, ldb=c1 + A,
+                 ldc=c1 + A)
+        # d/d(action) into the last A columns (no mask)
+        K.linear(ws.dz2, 1, c['W2'][:, c1:], 0, None, ws.dxcat[:, c1:], B, A, c2, ldb=c1 + A,
+                 ldc=c1 + A)
+        K.linear_wgrad(ws.dxcat, x, ws.gc['W1'], ws.gc['b1'], c1, D, B, ldz=c1 + A)
+        K.linear_wgrad(ws.dz2, ws.xcat, ws.gc['W2'], ws.gc['b2'], c2, c1 + A, B)
+        K.linear_wgrad(dz3, ws.h2c, ws.gc['W3'], ws.gc['b3'], 1, c2, B, ldz=1)
+
+    def _optimize(self, obs, actions, rewards, obs_next, done):       # ddpg.py:244-352
+        K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
+        x = obs['low_dim']['flat_inputs'].contiguous()
+        xn = obs_next['low_dim']['flat_inputs'].contiguous()
+        actions = actions.contiguous()
+        rewards, done = rewards.contiguous().view(-1), done.contiguous().view(-1)
+        B, D = x.shape
+        ws = self._workspace(B, D)
+        # the reference asserts |actions| <= 1 with two .item() syncs (ddpg.py:262-263): checked
+        # lazily together with the statistics read-back instead
+        # ---- target: y = r + gamma^n * Q'(s', mu'(s')) * (1 - done) ----
+        K.mlp3_forward(mt.actor, xn, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
+        mt.critic_forward_into(xn, ws.act, ws.xcat, ws.h2c, ws.q_next)
+        # ---- critic update ----
+        m.critic_forward_into(x, actions, ws.xcat, ws.h2c, ws.q)
+        K.ddpg_critic_loss(ws.q, ws.q_next, rewards, done, pow(self.discount_factor, self.n_step),
+                           ws.y, ws.dz3)
+        self._critic_backward(ws, x, B)
+        self.critic_step += 1
+        K.adam_step(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                    self.lr_critic, self.critic_step, self.critic_regularization,
+                    self.critic_gradient_clip_value)
+        q_policy = ws.q.clone()
+        # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)) ----
+        K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
+        m.critic_forward_into(x, ws.act, ws.xcat, ws.h2c, ws.q_actor)
+        K.fill(ws.dz3, -1.0 / B)
+        c, c1, c2 = m.critic, m.c1, m.c2
+        K.linear(ws.dz3.view(B, 1), 1, c['W3'], 0, None, ws.dz2, B, c2, 1, relu_mask=ws.h2c, lda=1,
+                 ldb=c2)
+        K.linear(ws.dz2, 1, c['W2'][:, c1:], 0, None, ws.dxcat[:, c1:], B, A, c2, ldb=c1 + A,
+                 ldc=c1 + A)
+        da = ws.dxcat[:, c1:]
+        ws.dz3a.copy_(da)                      # dense [B, A]
+        K.tanh_backward(ws.dz3a, ws.act, ws.dz3a)
+        K.mlp3_backward(m.actor, x, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a, ws.grads_a, None)
+        self.actor_step += 1
+        K.adam_step(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                    self.lr_actor, self.actor_step, self.actor_regularization,
+                    self.actor_gradient_clip_value)
+        K.ddpg_stats(q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
+        self._target_update()
+        st = ws.stats.cpu().numpy()
+        amax = float(actions.abs().max())
+        assert amax <= 1.0, 'actions must lie in [-1, 1] (ddpg.py:262-263), got |a| = %g' % amax
+        return {'actor_loss': float(st[0]), 'critic_loss': float(st[1]), 'action_norm': float(st[2]),
+                'rewards': float(st[3]), 'Q_target': float(st[4]), 'Q_policy': float(st[5])}
+
+    def learn(self, batch):
+        self.current_iteration += 1
+        batch = self.preprocess(batch)
+        stats = self._optimize(batch['obs'], batch['actions'], batch['rewards'], batch['obs_next'],
+                               batch['dones'])
+        self.tensorplex.add_scalars(stats, global_step=self.current_iteration)
+        self.periodic_checkpoint(global_steps=self.current_iteration, score=None)
+        return stats
+
+    def module_dict(self):
+        return {'ddpg': self.model}
+
+    def checkpoint_attributes(self):
+        return ['current_iteration', 'model', 'model_target']
+
+    def _prefetcher_preprocess(self, batch):
+        return self.aggregator.aggregate(batch)

@@ -1,1 +1,2 @@
 from .ppo_net import DiagGauss, ZFilter, PPOModel
+from .ddpg_net import DDPGModel

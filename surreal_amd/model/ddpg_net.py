@@ -1,0 +1,137 @@
+"""
+DDPGModel on MI355X (surreal/model/ddpg_net.py:13-95; ActorNetworkX / CriticNetworkX,
+model_builders/builders.py:35-84): low-dimensional observations, use_layernorm=False (the
+reference default, ddpg_configs.py:21); LayerNorm / pixel perception raise NotImplementedError.
+
+  actor : Linear(D,h1)-ReLU-Linear(h1,h2)-ReLU-Linear(h2,A)-Tanh
+  critic: Linear(D,c1)-ReLU ; concat action ; Linear(c1+A,c2)-ReLU ; Linear(c2,1)
+
+One flat fp32 parameter buffer per optimiser group (actor / critic).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from surreal_amd import kernels as KN
+from surreal_amd.model.ppo_net import Mlp3Params
+
+
+class DDPGModel(object):
+    def __init__(self, obs_spec, action_dim, use_layernorm, actor_fc_hidden_sizes,
+                 critic_fc_hidden_sizes, conv_out_channels=None, conv_kernel_sizes=None,
+                 conv_strides=None, conv_hidden_dim=None, critic_only=False, device=None,
+                 kernels=None):
+        self.K = kernels or KN.default_kernels()
+        device = device or KN.default_device()
+        if 'pixel' in obs_spec:
+            raise NotImplementedError('pixel observations (CNN perception) are not built yet')
+        if use_layernorm:
+            raise NotImplementedError('use_layernorm=True is not built yet')
+        self.is_pixel_input = False
+        self.action_dim = A = action_dim
+        self.use_layernorm = use_layernorm
+        self.input_dim = D = obs_spec['low_dim']['flat_inputs'][0]
+        self.device = device
+        ah, ch = list(actor_fc_hidden_sizes), list(critic_fc_hidden_sizes)
+        self.c1, self.c2 = ch
+        self.actor_flat = None
+        if not critic_only:
+            self.actor_flat = torch.empty(Mlp3Params.count(D, ah[0], ah[1], A), device=device)
+            self.actor = Mlp3Params(self.actor_flat, 0, D, ah[0], ah[1], A)
+        else:
+            self.actor = None
+        c1, c2 = ch
+        sizes = [('W1', (c1, D)), ('b1', (c1,)), ('W2', (c2, c1 + A)), ('b2', (c2,)),
+                 ('W3', (1, c2)), ('b3', (1,))]
+        n = sum(int(np.prod(s)) for _, s in sizes)
+        self.critic_flat = torch.empty(n, device=device)
+        self.critic = collections.OrderedDict()
+        o = 0
+        for name, shp in sizes:
+            k = int(np.prod(shp))
+            self.critic[name] = self.critic_flat[o:o + k].view(*shp)
+            o += k
+        self._init()
+
+    def _init(self):
+        nets = [self.critic] + ([self.actor.views] if self.actor is not None else [])
+        for views in nets:
+            for name, v in views.items():
+                fan = views['W' + name[1]].shape[1]
+                v.uniform_(-1.0 / np.sqrt(fan), 1.0 / np.sqrt(fan))
+
+    def named_parameters(self):
+        out = collections.OrderedDict()
+        if self.actor is not None:
+            for i in (1, 2, 3):
+                out['actor.fc%d.W' % i] = self.actor.views['W%d' % i]
+                out['actor.fc%d.b' % i] = self.actor.views['b%d' % i]
+        for i in (1, 2, 3):
+            out['critic.fc%d.W' % i] = self.critic['W%d' % i]
+            out['critic.fc%d.b' % i] = self.critic['b%d' % i]
+        return out
+
+    def load_params(self, params):
+        with torch.no_grad():
+            for k, v in self.named_parameters().items():
+                v.copy_(torch.as_tensor(np.asarray(params[k]), dtype=torch.float32).view(v.shape))
+
+    def numpy_params(self):
+        return collections.OrderedDict((k, v.detach().cpu().numpy().copy())
+                                       for k, v in self.named_parameters().items())
+
+    def state_dict(self):
+        return collections.OrderedDict(self.named_parameters())
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k, v in self.named_parameters().items():
+                src = sd[k]
+                if not torch.is_tensor(src):
+                    src = torch.as_tensor(np.asarray(src), dtype=torch.float32)
+                v.copy_(src.view(v.shape))
+
+    def get_actor_parameters(self):
+        return [self.actor_flat]
+
+    def get_critic_parameters(self):
+        return [self.critic_flat]
+
+    # ---- forward passes (eager helpers; the learner uses its own workspace) -----------------
+    def forward_perception(self, obs):
+        return obs['low_dim']['flat_inputs']
+
+    def forward_actor(self, x):
+        a = self.actor
+        rows = x.shape[0]
+        h1 = torch.empty(rows, a.H1, device=x.device)
+        h2 = torch.empty(rows, a.H2, device=x.device)
+        out = torch.empty(rows, a.OUT, device=x.device)
+        self.K.mlp3_forward(a, x.contiguous(), h1, h2, out, 2)
+        return out
+
+    def critic_forward_into(self, x, action, xcat, h2, q):
+        """xcat [rows, c1+A] receives relu(layer1) | action; h2 [rows, c2]; q [rows]"""
+        K, c = self.K, self.critic
+        rows, D = x.shape
+        A, c1, c2 = self.action_dim, self.c1, self.c2
+        K.linear(x, 1, c['W1'], 1, c['b1'], xcat, rows, c1, D, act=1, ldc=c1 + A)
+        xcat[:, c1:].copy_(action)
+        K.linear(xcat, 1, c['W2'], 1, c['b2'], h2, rows, c2, c1 + A, act=1)
+        K.linear(h2, 1, c['W3'], 1, c['b3'], q.view(rows, 1), rows, 1, c2, act=0)
+
+    def forward_critic(self, x, action):
+        rows = x.shape[0]
+        xcat = torch.empty(rows, self.c1 + self.action_dim, device=x.device)
+        h2 = torch.empty(rows, self.c2, device=x.device)
+        q = torch.empty(rows, device=x.device)
+        self.critic_forward_into(x.contiguous(), action, xcat, h2, q)
+        return q.view(rows, 1)
+
+    def forward(self, obs_in, calculate_value=True, action=None):
+        x = self.forward_perception(obs_in)
+        if action is None:
+            action = self.forward_actor(x)
+        value = self.forward_critic(x, action) if calculate_value else None
+        return action, value

@@ -337,3 +337,68 @@ class TorchCpuKernels(object):
             rew_roll[:, slot] = (-0.1 * (ac.double() ** 2).sum(1) + 0.05 * sn[:, 0].double()).float()
             done_roll[:, slot] = 1.0 if done else 0.0
         state.copy_(init_state if done else sn)
+
+    # ---- generic dense layer + DDPG pieces ---------------------------------------------------
+    def linear(self, A, a_kc, B, b_kc, bias, C, M, N, K, act=0, relu_mask=None, lda=None, ldb=None,
+               ldc=None, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        lda = lda if lda is not None else A.stride(0)
+        ldb = ldb if ldb is not None else B.stride(0)
+        ldc = ldc if ldc is not None else C.stride(0)
+
+        def mat(X, ld, kc, rows):   # -> [rows, K]
+            flat = X.reshape(-1) if X.is_contiguous() else None
+            base = torch.as_strided(X, (rows, K), (ld, 1) if kc else (1, ld))
+            return base
+        a, b = mat(A, lda, a_kc, M), mat(B, ldb, b_kc, N)
+        out = a @ b.t()
+        if bias is not None:
+            out = out + bias[:N]
+        out = self._act(out, act)
+        if relu_mask is not None:
+            out = out * (torch.as_strided(relu_mask, (M, N), (ldc, 1)) > 0)
+        torch.as_strided(C, (M, N), (ldc, 1)).copy_(out)
+
+    def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None):
+        ldz = ldz if ldz is not None else dZ.stride(0)
+        ldx = ldx if ldx is not None else X.stride(0)
+        ldw = ldw if ldw is not None else dW.stride(0)
+        dz = torch.as_strided(dZ, (rows, M), (ldz, 1))
+        x = torch.as_strided(X, (rows, N), (ldx, 1))
+        torch.as_strided(dW, (M, N), (ldw, 1)).copy_(dz.t() @ x)
+        if db is not None:
+            db.view(-1)[:M].copy_(dz.sum(0))
+
+    def ddpg_critic_loss(self, q, q_next, rewards, dones, gamma_n, y, dz3):
+        yy = rewards.view(-1) + gamma_n * q_next.view(-1) * (1.0 - dones.view(-1))
+        y.view(-1).copy_(yy)
+        dz3.view(-1).copy_(2.0 * (q.view(-1) - yy) / q.numel())
+
+    def tanh_backward(self, da, a, out):
+        out.copy_(da * (1.0 - a * a))
+
+    def fill(self, x, value):
+        x.fill_(value)
+
+    def adam_step(self, theta, grads, m, v, lr, step, weight_decay=0.0, clip_value=0.0):
+        g = grads.clamp(-clip_value, clip_value) if clip_value > 0 else grads.clone()
+        if weight_decay != 0:
+            g = g + weight_decay * theta
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        theta.addcdiv_(m, denom, value=-(lr / bc1))
+
+    def soft_update(self, target, source, tau):
+        if tau >= 1.0:
+            target.copy_(source)
+        else:
+            target.copy_(target * (1.0 - tau) + source * tau)
+
+    def ddpg_stats(self, q, y, rewards, actions, q_actor, stats):
+        stats[:6].copy_(_f([float(-q_actor.double().mean()), float(((q - y).double() ** 2).mean()),
+                        float(actions.norm(2, 1).double().mean()), float(rewards.double().mean()),
+                        float(y.double().mean()), float(q.double().mean())]))

@@ -1,0 +1,81 @@
+"""CPU tier: DDPGLearner host logic (update order, target-update schedule, clipping switches,
+Adam step counters) through the CPU kernel double against goldens recorded from the reference's
+own DDPGLearner (oracle/gen_golden_ddpg.py), and the oracle restatement against the same."""
+import json
+
+import numpy as np
+import pytest
+
+import ddpg_helpers as DH
+import ddpg_oracle
+from surreal_amd import synthetic
+
+
+@pytest.mark.parametrize('name', DH.DDPG_CASES)
+def test_ddpg_oracle_matches_reference_golden(name):
+    g, c = DH.load(name)
+    h = c['hyper']
+    params = ddpg_oracle.make_ddpg_params(c['D'], c['A'], tuple(c['ah']), tuple(c['ch']), seed=3)
+    O = ddpg_oracle.OracleDDPGLearner(
+        params, gamma=h['gamma'], n_step=h['n_step'], lr_actor=h['lr_actor'], lr_critic=h['lr_critic'],
+        clip_critic_gradient=h.get('clip_critic', False), target_update_type=h['target_update_type'],
+        target_update_interval=h['target_update_interval'], tau=h.get('tau', 1e-3))
+    ref = json.loads(str(g['trace_json']))
+    for it in range(c['iters']):
+        st = O.learn(synthetic.make_ddpg_batch(c['B'], c['D'], c['A'], seed=10 + it))
+        for k, v in ref[it].items():
+            np.testing.assert_allclose(st[k], v, atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize('name', DH.DDPG_CASES)
+def test_ddpg_learner_host_logic(name, cpu_double):
+    DH.run_and_check(name)
+
+
+def test_ddpg_unsupported_switches_raise(cpu_double):
+    g, c = DH.load('tiny_hard')
+    from surreal_amd.learner.ddpg import DDPGLearner
+    from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
+    lc = ddpg_learner_config()
+    lc.algo.network.use_double_critic = True
+    with pytest.raises(NotImplementedError):
+        DDPGLearner(lc, ddpg_env_config(5, 2), ddpg_session_config())
+    lc = ddpg_learner_config()
+    lc.algo.network.target_update = {'type': 'weird'}
+    from surreal_amd.session import ConfigError
+    with pytest.raises(ConfigError):
+        DDPGLearner(lc, ddpg_env_config(5, 2), ddpg_session_config())
+
+
+def test_ddpg_agent_replay_learner_loop(cpu_double):
+    """DDPG in-process loop: agent -> n-step SSAR wrapper -> uniform replay -> learner"""
+    import torch
+    from surreal_amd.agent import DDPGAgent
+    from surreal_amd.env import SyntheticEnv, MaxStepWrapper
+    from surreal_amd.learner import DDPGLearner
+    from surreal_amd.replay import UniformReplay
+    from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
+    D, A = 7, 2
+    lc = ddpg_learner_config()
+    lc.model.actor_fc_hidden_sizes, lc.model.critic_fc_hidden_sizes = [24, 16], [32, 24]
+    lc.replay.batch_size, lc.replay.memory_size, lc.replay.sampling_start_size = 8, 64, 10
+    ec, sc = ddpg_env_config(D, A, num_agents=2), ddpg_session_config()
+    ec.limit_episode_length = 15
+    replay = UniformReplay(lc, ec, sc)
+    learner = DDPGLearner(lc, ec, sc)
+    learner.attach_replay(replay)
+    ag = DDPGAgent(lc, ec, sc, agent_id=1, agent_mode='training')
+    assert ag.sigma == 0.5
+    ag.set_experience_sink(replay._insert_wrapper)
+    ag.set_env_factory(lambda: SyntheticEnv(D, A, episode_len=100, seed=4))
+    ag.attach_learner(learner)
+    ag.main_setup()
+    ag.main_loop()
+    assert len(replay) == 15 - (lc.algo.n_step - 1)      # the last n_step-1 transitions are never sent
+    assert replay.start_sample_condition()
+    learner.main_setup()
+    learner.main_loop()
+    st = learner.tensorplex.latest
+    assert all(np.isfinite(st[k]) for k in ('actor_loss', 'critic_loss', 'Q_target', 'Q_policy'))
+    acts = ag.act_batch(torch.randn(5, D), eps=torch.zeros(5, A))
+    assert float(acts.abs().max()) <= 1.0
