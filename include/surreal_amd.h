@@ -117,6 +117,30 @@ int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X, int32_t l
                          int32_t ldw, float* db, int32_t M, int32_t N, int32_t rows,
                          smx_stream_t stream);
 
+/* One MLP forward or backward "job" for the multi-network entry points below: PPO's actor and
+ * critic are independent networks updated in lock-step epochs (ppo.py:541-562), so their
+ * layer-l GEMMs share one launch.  Forward uses net/x/rows/h1/h2/out/out_act; backward uses
+ * net/x/rows/h1/h2/dz3 (in) and dz2/dz1/grads/sumsq_partials (out).  stop_flag (device int,
+ * may be NULL): non-zero turns this job's part of every launch into a no-op. */
+typedef struct {
+    const smx_mlp3_t* net;
+    const float* x;
+    int64_t rows;
+    float* h1;
+    float* h2;
+    float* out;
+    int32_t out_act;
+    int32_t reserved;
+    const float* dz3;
+    float* dz2;
+    float* dz1;
+    float* grads;
+    float* sumsq_partials;
+    const int32_t* stop_flag;
+} smx_mlp3_job_t;
+int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
+int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
+
 /* MLP forward keeping the hidden activations (needed by the backward):
  * h1 [rows,H1], h2 [rows,H2], out [rows,OUT] = act(layer 3). */
 int smx_mlp3_forward_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1,
@@ -134,13 +158,15 @@ int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, const float* h1
                           const int32_t* stop_flag, smx_stream_t stream);
 
 /* --- windowed GAE / n-step returns (surreal/learner/ppo.py:387-418) ----------
- * values [B,N+1] RAW critic outputs; the done-mask values[:,1:] *= 1-dones
- * (ppo.py:387) is applied inside.  H = N -> non-RNN branch (E = 1);
+ * values [B,N+1] RAW critic outputs -- or, when values_tail != NULL, values [B,N] for the N
+ * steps and values_tail [B] for obs_next (lets the caller evaluate the two row sets with
+ * different kernels); the done-mask values[:,1:] *= 1-dones (ppo.py:387) is applied inside.  H = N -> non-RNN branch (E = 1);
  * H = rnn.horizon -> RNN branch, E = N-H+1 sliding windows.
  * gamma_pow/lam_pow [H] = torch.pow(gamma|lam, arange) as the reference builds
  * them (ppo.py:372-374); gamma_H = gamma**H.
  * adv [B,E] (un-normalised), ret [B,E]. */
-int smx_windowed_gae_returns_f32(const float* values, const float* rewards,
+int smx_windowed_gae_returns_f32(const float* values, const float* values_tail,
+                                 const float* rewards,
                                  const float* dones, const float* gamma_pow,
                                  const float* lam_pow, float gamma, float gamma_H,
                                  int32_t B, int32_t N, int32_t H, float* adv, float* ret,

@@ -27,6 +27,14 @@ class Mlp3(Structure):
                 ('D', c_int32), ('H1', c_int32), ('H2', c_int32), ('OUT', c_int32)]
 
 
+class Mlp3Job(Structure):
+    """smx_mlp3_job_t"""
+    _fields_ = [('net', POINTER(Mlp3)), ('x', c_void_p), ('rows', c_int64), ('h1', c_void_p),
+                ('h2', c_void_p), ('out', c_void_p), ('out_act', c_int32), ('reserved', c_int32),
+                ('dz3', c_void_p), ('dz2', c_void_p), ('dz1', c_void_p), ('grads', c_void_p),
+                ('sumsq_partials', c_void_p), ('stop_flag', c_void_p)]
+
+
 # smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
 CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
@@ -49,10 +57,12 @@ _SIGS = {
     'smx_linear_wgrad_f32': (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32,
                                        c_int32, _P]),
     'smx_mlp3_forward_f32': (c_int32, [POINTER(Mlp3), _P, c_int64, _P, _P, _P, c_int32, _P, _P]),
+    'smx_mlp3_forward_multi_f32': (c_int32, [POINTER(Mlp3Job), c_int32, _P]),
+    'smx_mlp3_backward_multi_f32': (c_int32, [POINTER(Mlp3Job), c_int32, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_backward_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                         _P, _P]),
-    'smx_windowed_gae_returns_f32': (c_int32, [_P, _P, _P, _P, _P, c_float, c_float, c_int32,
+    'smx_windowed_gae_returns_f32': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int32,
                                                c_int32, c_int32, _P, _P, _P]),
     'smx_moments_f32': (c_int32, [_P, c_int64, _P, _P]),
     'smx_moments_merge_f32': (c_int32, [_P, c_int32, _P, _P]),

@@ -6,8 +6,9 @@
 // (each wave owns every 4th 32-wide K block), operands go HBM/L2 -> registers directly in MFMA
 // fragment order (everything here is L2-resident), partial tiles are combined through LDS in a
 // fixed order (deterministic), and the epilogue (bias / ReLU / tanh / ReLU-mask / bias-gradient /
-// sum-of-squares for clip_grad_norm_) is fused.  Up to 3 problems are grouped into one launch.
+// sum-of-squares for clip_grad_norm_) is fused.  Up to 6 problems are grouped into one launch.
 #include "smx_common.h"
+#include <string.h>
 
 namespace {
 
@@ -22,12 +23,14 @@ struct GemmProb {
     int lda, ldb, ldc, M, N, K;
     int a_kc, b_kc, act;
     int tiles_m, tiles_n, tile_base, a_vec, b_vec;
+    const int* stop;     // device flag: non-zero -> this problem is skipped
 };
 
+constexpr int MAX_PROBS = 6;
+
 struct GemmBatch {
-    GemmProb p[3];
+    GemmProb p[MAX_PROBS];
     int n;
-    const int* stop;
 };
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -63,16 +66,41 @@ __device__ __forceinline__ float act_f(float v, int act) {
     return v;
 }
 
+// load the 8 operand fragments (4 k-groups x {A, B}) of one 32-wide K super-block
+struct Frag8 {
+    float4 a[4], b[4];
+};
+
+__device__ __forceinline__ void load_sb(Frag8& f, const GemmProb& P, int m0, int n0, int i, int kb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f.a[q] = load_frag(P.A, P.lda, P.a_kc, P.a_vec, m0 + i, P.M, kb + 8 * q, P.K);
+        f.b[q] = load_frag(P.B, P.ldb, P.b_kc, P.b_vec, n0 + i, P.N, kb + 8 * q, P.K);
+    }
+}
+
+__device__ __forceinline__ void mma_sb(f32x16& acc, float& asum, const Frag8& f) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc = MFMA32(f.a[q].x, f.b[q].x, acc);
+        acc = MFMA32(f.a[q].y, f.b[q].y, acc);
+        acc = MFMA32(f.a[q].z, f.b[q].z, acc);
+        acc = MFMA32(f.a[q].w, f.b[q].w, acc);
+        asum += (f.a[q].x + f.a[q].y) + (f.a[q].z + f.a[q].w);
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
-    if (G.stop && *G.stop) return;
     __shared__ float red[4][32 * 33];
     __shared__ float dbr[8][32];
     __shared__ float sred[16];
 
     int pi = 0;
-    if (G.n > 1 && (int)blockIdx.x >= G.p[1].tile_base) pi = 1;
-    if (G.n > 2 && (int)blockIdx.x >= G.p[2].tile_base) pi = 2;
+#pragma unroll
+    for (int k = 1; k < MAX_PROBS; ++k)
+        if (k < G.n && (int)blockIdx.x >= G.p[k].tile_base) pi = k;
     const GemmProb& P = G.p[pi];
+    if (P.stop && *P.stop) return;
     const int tile = blockIdx.x - P.tile_base;
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
@@ -85,33 +113,27 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float asum = 0.f;
 
-    const int nsb = (P.K + 31) >> 5;  // 32-wide K super-blocks; wave wv owns sb = wv, wv+4, ...
-    float4 a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
-    {
-        const int kb = wv * 32 + 4 * kh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a_cur[q] = load_frag(P.A, P.lda, P.a_kc, P.a_vec, m0 + i, P.M, kb + 8 * q, P.K);
-            b_cur[q] = load_frag(P.B, P.ldb, P.b_kc, P.b_vec, n0 + i, P.N, kb + 8 * q, P.K);
+    // K is cut into 32-wide super-blocks; wave wv owns sb = wv, wv+4, ...  Three register
+    // buffers form a ring so that up to three super-blocks of operand loads (24 x 16 B per lane)
+    // are in flight ahead of the MFMAs: these GEMMs are latency-bound, not bandwidth-bound.
+    // Loads past K are predicated off and return zeros.
+    const int nsb = (P.K + 31) >> 5;
+    const int kofs = 4 * kh;
+    Frag8 f0, f1, f2;
+    load_sb(f0, P, m0, n0, i, (wv + 0) * 32 + kofs);
+    load_sb(f1, P, m0, n0, i, (wv + 4) * 32 + kofs);
+    load_sb(f2, P, m0, n0, i, (wv + 8) * 32 + kofs);
+    for (int sb = wv; sb < nsb; sb += 12) {
+        mma_sb(acc, asum, f0);
+        if (sb + 12 < nsb) load_sb(f0, P, m0, n0, i, (sb + 12) * 32 + kofs);
+        if (sb + 4 < nsb) {
+            mma_sb(acc, asum, f1);
+            if (sb + 16 < nsb) load_sb(f1, P, m0, n0, i, (sb + 16) * 32 + kofs);
         }
-    }
-    for (int sb = wv; sb < nsb; sb += 4) {
-        const int kn = (sb + 4) * 32 + 4 * kh;  // past K -> guarded loads return zeros
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            a_nxt[q] = load_frag(P.A, P.lda, P.a_kc, P.a_vec, m0 + i, P.M, kn + 8 * q, P.K);
-            b_nxt[q] = load_frag(P.B, P.ldb, P.b_kc, P.b_vec, n0 + i, P.N, kn + 8 * q, P.K);
+        if (sb + 8 < nsb) {
+            mma_sb(acc, asum, f2);
+            if (sb + 20 < nsb) load_sb(f2, P, m0, n0, i, (sb + 20) * 32 + kofs);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc = MFMA32(a_cur[q].x, b_cur[q].x, acc);
-            acc = MFMA32(a_cur[q].y, b_cur[q].y, acc);
-            acc = MFMA32(a_cur[q].z, b_cur[q].z, acc);
-            acc = MFMA32(a_cur[q].w, b_cur[q].w, acc);
-            asum += (a_cur[q].x + a_cur[q].y) + (a_cur[q].z + a_cur[q].w);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { a_cur[q] = a_nxt[q]; b_cur[q] = b_nxt[q]; }
     }
 
     // ---- combine the 4 K-partials through LDS (fixed order => deterministic) -------------
@@ -156,8 +178,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
 
 inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const float* B, int ldb,
                       int b_kc, const float* bias, const float* mask, float* C, int ldc, int M,
-                      int N, int K, int act, float* dbias, float* sumsq, int tile_base) {
+                      int N, int K, int act, float* dbias, float* sumsq, int tile_base,
+                      const int* stop = nullptr) {
     P.A = A; P.B = B; P.bias = bias; P.mask = mask; P.C = C; P.dbias = dbias; P.sumsq = sumsq;
+    P.stop = stop;
     P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
     P.a_kc = a_kc; P.b_kc = b_kc; P.act = act;
     P.tiles_m = (M + 31) / 32; P.tiles_n = (N + 31) / 32; P.tile_base = tile_base;
@@ -184,9 +208,8 @@ extern "C" int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, co
     SMX_REQUIRE(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, SMX_E_SHAPE);
     GemmBatch G;
     G.n = 1;
-    G.stop = stop_flag;
     fill_prob(G.p[0], A, lda, a_kcontig, B, ldb, b_kcontig, bias, relu_mask, C, ldc, M, N, K, act,
-              nullptr, nullptr, 0);
+              nullptr, nullptr, 0, stop_flag);
     return launch_batch(G, smx_s(stream));
 }
 
@@ -198,27 +221,61 @@ extern "C" int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X
     SMX_REQUIRE(M > 0 && N > 0 && rows > 0 && ldz >= M && ldx >= N && ldw >= N, SMX_E_SHAPE);
     GemmBatch G;
     G.n = 1;
-    G.stop = nullptr;
     fill_prob(G.p[0], dZ, ldz, 0, X, ldx, 0, nullptr, nullptr, dW, ldw, M, N, rows, SMX_ACT_NONE, db,
               nullptr, 0);
     return launch_batch(G, smx_s(stream));
 }
 
+// ---------------------------------------------------------------------------
+// multi-job MLP forward / backward: the layer-l GEMMs of up to MAX_JOBS independent networks
+// (PPO: actor + critic, which the reference updates in two separate loops, ppo.py:541-562)
+// share ONE launch per layer -- half the launches, twice the workgroups per launch.
+// ---------------------------------------------------------------------------
+constexpr int MAX_JOBS = 2;
+
+extern "C" int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs,
+                                          smx_stream_t stream) {
+    SMX_REQUIRE(jobs, SMX_E_NULL);
+    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_JOBS, SMX_E_SHAPE);
+    for (int j = 0; j < njobs; ++j) {
+        const smx_mlp3_job_t& J = jobs[j];
+        SMX_REQUIRE(J.net && J.x && J.h1 && J.h2 && J.out, SMX_E_NULL);
+        SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
+    }
+    for (int layer = 0; layer < 3; ++layer) {
+        GemmBatch G;
+        G.n = njobs;
+        int base = 0;
+        for (int j = 0; j < njobs; ++j) {
+            const smx_mlp3_job_t& J = jobs[j];
+            const smx_mlp3_t* n = J.net;
+            const int R = (int)J.rows;
+            if (layer == 0)
+                fill_prob(G.p[j], J.x, n->D, 1, n->W1, n->D, 1, n->b1, nullptr, J.h1, n->H1, R, n->H1,
+                          n->D, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag);
+            else if (layer == 1)
+                fill_prob(G.p[j], J.h1, n->H1, 1, n->W2, n->H1, 1, n->b2, nullptr, J.h2, n->H2, R,
+                          n->H2, n->H1, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag);
+            else
+                fill_prob(G.p[j], J.h2, n->H2, 1, n->W3, n->H2, 1, n->b3, nullptr, J.out, n->OUT, R,
+                          n->OUT, n->H2, J.out_act, nullptr, nullptr, base, J.stop_flag);
+            base += G.p[j].tiles_m * G.p[j].tiles_n;
+        }
+        const int rc = launch_batch(G, smx_s(stream));
+        if (rc) return rc;
+    }
+    return SMX_OK;
+}
+
 extern "C" int smx_mlp3_forward_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1,
                                     float* h2, float* out, int32_t out_act,
                                     const int32_t* stop_flag, smx_stream_t stream) {
-    SMX_REQUIRE(net && x && h1 && h2 && out, SMX_E_NULL);
-    SMX_REQUIRE(rows > 0 && rows < (1 << 30), SMX_E_SHAPE);
-    const int R = (int)rows;
-    int rc;
-    rc = smx_linear_f32(x, net->D, 1, net->W1, net->D, 1, net->b1, h1, net->H1, R, net->H1, net->D,
-                        SMX_ACT_RELU, nullptr, stop_flag, stream);
-    if (rc) return rc;
-    rc = smx_linear_f32(h1, net->H1, 1, net->W2, net->H1, 1, net->b2, h2, net->H2, R, net->H2,
-                        net->H1, SMX_ACT_RELU, nullptr, stop_flag, stream);
-    if (rc) return rc;
-    return smx_linear_f32(h2, net->H2, 1, net->W3, net->H2, 1, net->b3, out, net->OUT, R, net->OUT,
-                          net->H2, out_act, nullptr, stop_flag, stream);
+    smx_mlp3_job_t J;
+    memset(&J, 0, sizeof(J));
+    J.net = net; J.x = x; J.rows = rows; J.h1 = h1; J.h2 = h2; J.out = out; J.out_act = out_act;
+    J.stop_flag = stop_flag;
+    SMX_REQUIRE(net, SMX_E_NULL);
+    return smx_mlp3_forward_multi_f32(&J, 1, stream);
 }
 
 extern "C" int32_t smx_mlp3_backward_partials(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
@@ -226,39 +283,73 @@ extern "C" int32_t smx_mlp3_backward_partials(int32_t D, int32_t H1, int32_t H2,
     return t(H1) * t(D) + t(H2) * t(H1) + t(OUT) * t(H2);
 }
 
+extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs,
+                                           smx_stream_t stream) {
+    SMX_REQUIRE(jobs, SMX_E_NULL);
+    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_JOBS, SMX_E_SHAPE);
+    for (int j = 0; j < njobs; ++j) {
+        const smx_mlp3_job_t& J = jobs[j];
+        SMX_REQUIRE(J.net && J.x && J.h1 && J.h2 && J.dz3 && J.dz2 && J.dz1 && J.grads, SMX_E_NULL);
+        SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
+    }
+    // dz2 = (dz3 . W3) * relu'(h2)   [R, H2], K = OUT ;  dz1 = (dz2 . W2) * relu'(h1)   [R, H1], K = H2
+    for (int stage = 0; stage < 2; ++stage) {
+        GemmBatch G;
+        G.n = njobs;
+        int base = 0;
+        for (int j = 0; j < njobs; ++j) {
+            const smx_mlp3_job_t& J = jobs[j];
+            const smx_mlp3_t* n = J.net;
+            const int R = (int)J.rows;
+            if (stage == 0)
+                fill_prob(G.p[j], J.dz3, n->OUT, 1, n->W3, n->H2, 0, nullptr, J.h2, J.dz2, n->H2, R,
+                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag);
+            else
+                fill_prob(G.p[j], J.dz2, n->H2, 1, n->W2, n->H1, 0, nullptr, J.h1, J.dz1, n->H1, R,
+                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag);
+            base += G.p[j].tiles_m * G.p[j].tiles_n;
+        }
+        const int rc = launch_batch(G, smx_s(stream));
+        if (rc) return rc;
+    }
+    // dW_l = dz_l^T . input_l , db_l = column sums of dz_l : 3 problems per job, one launch
+    GemmBatch G;
+    G.n = 3 * njobs;
+    int base = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const smx_mlp3_job_t& J = jobs[j];
+        const smx_mlp3_t* n = J.net;
+        const int R = (int)J.rows, D = n->D, H1 = n->H1, H2 = n->H2, O = n->OUT;
+        float* gW1 = J.grads;
+        float* gb1 = gW1 + (size_t)H1 * D;
+        float* gW2 = gb1 + H1;
+        float* gb2 = gW2 + (size_t)H2 * H1;
+        float* gW3 = gb2 + H2;
+        float* gb3 = gW3 + (size_t)O * H2;
+        float* sq = J.sumsq_partials;
+        const int job_base = base;
+        fill_prob(G.p[3 * j + 0], J.dz1, H1, 0, J.x, D, 0, nullptr, nullptr, gW1, D, H1, D, R,
+                  SMX_ACT_NONE, gb1, sq, base, J.stop_flag);
+        base += G.p[3 * j + 0].tiles_m * G.p[3 * j + 0].tiles_n;
+        fill_prob(G.p[3 * j + 1], J.dz2, H2, 0, J.h1, H1, 0, nullptr, nullptr, gW2, H1, H2, H1, R,
+                  SMX_ACT_NONE, gb2, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
+        base += G.p[3 * j + 1].tiles_m * G.p[3 * j + 1].tiles_n;
+        fill_prob(G.p[3 * j + 2], J.dz3, O, 0, J.h2, H2, 0, nullptr, nullptr, gW3, H2, O, H2, R,
+                  SMX_ACT_NONE, gb3, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
+        base += G.p[3 * j + 2].tiles_m * G.p[3 * j + 2].tiles_n;
+    }
+    return launch_batch(G, smx_s(stream));
+}
+
 extern "C" int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, const float* h1,
                                      const float* h2, const float* dz3, int64_t rows, float* dz2,
                                      float* dz1, float* grads, float* sumsq_partials,
                                      const int32_t* stop_flag, smx_stream_t stream) {
-    SMX_REQUIRE(net && x && h1 && h2 && dz3 && dz2 && dz1 && grads, SMX_E_NULL);
-    SMX_REQUIRE(rows > 0 && rows < (1 << 30), SMX_E_SHAPE);
-    const int R = (int)rows, D = net->D, H1 = net->H1, H2 = net->H2, O = net->OUT;
-    int rc;
-    // dz2 = (dz3 . W3) * relu'(h2)      [R, H2], K = OUT
-    rc = smx_linear_f32(dz3, O, 1, net->W3, H2, 0, nullptr, dz2, H2, R, H2, O, SMX_ACT_NONE, h2,
-                        stop_flag, stream);
-    if (rc) return rc;
-    // dz1 = (dz2 . W2) * relu'(h1)      [R, H1], K = H2
-    rc = smx_linear_f32(dz2, H2, 1, net->W2, H1, 0, nullptr, dz1, H1, R, H1, H2, SMX_ACT_NONE, h1,
-                        stop_flag, stream);
-    if (rc) return rc;
-    // dW_l = dz_l^T . input_l , db_l = column sums of dz_l : three problems, one launch
-    float* gW1 = grads;
-    float* gb1 = gW1 + (size_t)H1 * D;
-    float* gW2 = gb1 + H1;
-    float* gb2 = gW2 + (size_t)H2 * H1;
-    float* gW3 = gb2 + H2;
-    float* gb3 = gW3 + (size_t)O * H2;
-    GemmBatch G;
-    G.n = 3;
-    G.stop = stop_flag;
-    fill_prob(G.p[0], dz1, H1, 0, x, D, 0, nullptr, nullptr, gW1, D, H1, D, R, SMX_ACT_NONE, gb1,
-              sumsq_partials, 0);
-    int base = G.p[0].tiles_m * G.p[0].tiles_n;
-    fill_prob(G.p[1], dz2, H2, 0, h1, H1, 0, nullptr, nullptr, gW2, H1, H2, H1, R, SMX_ACT_NONE, gb2,
-              sumsq_partials ? sumsq_partials + base : nullptr, base);
-    base += G.p[1].tiles_m * G.p[1].tiles_n;
-    fill_prob(G.p[2], dz3, O, 0, h2, H2, 0, nullptr, nullptr, gW3, H2, O, H2, R, SMX_ACT_NONE, gb3,
-              sumsq_partials ? sumsq_partials + base : nullptr, base);
-    return launch_batch(G, smx_s(stream));
+    smx_mlp3_job_t J;
+    memset(&J, 0, sizeof(J));
+    J.net = net; J.x = x; J.rows = rows; J.h1 = (float*)h1; J.h2 = (float*)h2; J.dz3 = dz3;
+    J.dz2 = dz2; J.dz1 = dz1; J.grads = grads; J.sumsq_partials = sumsq_partials;
+    J.stop_flag = stop_flag;
+    SMX_REQUIRE(net, SMX_E_NULL);
+    return smx_mlp3_backward_multi_f32(&J, 1, stream);
 }

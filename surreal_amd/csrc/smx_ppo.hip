@@ -19,110 +19,144 @@ __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
     return (x == x) ? fmaxf(x, lo) : x;  // torch.clamp(min=) keeps NaN
 }
 
-__global__ __launch_bounds__(64) void policy_loss_kernel(
-    int mode, const float* __restrict__ mean, const float* __restrict__ log_var,
-    const float* __restrict__ actions, int ld_act, const float* __restrict__ behave, int ld_beh,
-    const float* __restrict__ ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
+// 64 rows per block, 256 threads: all four waves move the block's rows of mean / actions /
+// behave / ref HBM -> LDS with coalesced loads (the per-row inputs are short strided rows: read
+// one row per lane they cost ~35 scattered cache lines per instruction), wave 0 then does the
+// row-per-lane arithmetic out of LDS, and all waves write the two gradient tiles back coalesced.
+__global__ __launch_bounds__(256) void policy_loss_kernel(
+    int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
+    const float* __restrict__ g_actions, int ld_act, const float* __restrict__ g_behave, int ld_beh,
+    const float* __restrict__ g_ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
     const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
     float* __restrict__ partials) {
     if (ctrl->stop_flag) return;
-    const int lane = threadIdx.x;
-    const long r = (long)blockIdx.x * LOSS_ROWS_PER_BLOCK + lane;
-    const bool ok = r < rows;
+    extern __shared__ float sm[];
+    const int R = LOSS_ROWS_PER_BLOCK;
+    float* mean = sm;                 // [R, A]
+    float* actions = mean + R * A;    // [R, A]
+    float* behave = actions + R * A;  // [R, 2A]
+    float* ref = behave + R * 2 * A;  // [R, 2A]
+    float* t_gs = ref + R * 2 * A;    // [R, A]
+    float* t_gk = t_gs + R * A;       // [R, A]
+    const long row0 = (long)blockIdx.x * R;
+    long nrows = rows - row0;
+    if (nrows > R) nrows = R;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)nrows * A; i += 256) {
+        const int rr = i / A, a = i - rr * A;
+        mean[i] = g_mean[(row0 + rr) * A + a];
+        actions[i] = g_actions[(row0 + rr) * ld_act + a];
+    }
+    for (int i = tid; i < (int)nrows * 2 * A; i += 256) {
+        const int rr = i / (2 * A), a = i - rr * 2 * A;
+        behave[i] = g_behave[(row0 + rr) * ld_beh + a];
+        ref[i] = g_ref[(row0 + rr) * ld_ref + a];
+    }
+    __syncthreads();
+    const int lane = tid;
     const int stride = 8 + 2 * A;
     float* P = partials + (size_t)blockIdx.x * stride;
+    if (tid < 64) {
+        const int r = lane;                       // row inside the block (LDS index)
+        const bool ok = r < nrows;
+        const int lda = A, ldb = 2 * A;
+        const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
+        const float half_d = (float)(0.5 * (double)A);
 
-    const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
-    const float half_d = (float)(0.5 * (double)A);
-
-    float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f;       // loglikelihood sums (learn, behave)
-    float kl_a = 0.f, kl_b = 0.f, kb_a = 0.f, kb_b = 0.f;  // KL(ref||learn), KL(ref||behave)
-    if (ok) {
-        for (int a = 0; a < A; ++a) {
-            const float sig = expf(log_var[a]);             // builders.py:127
-            const float mu = mean[r * A + a];
-            const float ac = actions[r * ld_act + a];
-            const float mb = behave[r * ld_beh + a], sb = behave[r * ld_beh + A + a];
-            const float mr = ref[r * ld_ref + a], sr = ref[r * ld_ref + A + a];
-            // ppo_net.py:39-40
-            const float z = (ac - mu) / sig;
-            s1 += z * z;
-            s2 += logf(sig);
-            const float zb = (ac - mb) / sb;
-            sb1 += zb * zb;
-            sb2 += logf(sb);
-            // ppo_net.py:61-62  KL(p0 || p1): p0 = ref, p1 = learn
-            kl_a += logf(sig / sr);
-            kl_b += (sr * sr + (mr - mu) * (mr - mu)) / (2.0f * (sig * sig));
-            kb_a += logf(sb / sr);
-            kb_b += (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
-        }
-    }
-    const float ll = ((-0.5f * s1) - c_ll) - s2;
-    const float llb = ((-0.5f * sb1) - c_ll) - sb2;
-    const float el = expf(ll);
-    const float Ll = clamp_min_nan(el, 1e-5f);       // ppo_net.py:46
-    const float Lb = clamp_min_nan(expf(llb), 1e-5f);
-    const float kl = (kl_a + kl_b) - half_d;
-    const float klb = (kb_a + kb_b) - half_d;
-    const float ad = ok ? adv[r] : 0.f;
-
-    float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
-    if (mode == SMX_PPO_CLIP) {
-        const float eps = ctrl->clip_eps;
-        const float lo = (float)(1.0 - (double)eps), hi = (float)(1.0 + (double)eps);
-        const float ratio = Ll / Lb;                                    // ppo.py:212
-        float cr = ratio;
-        if (cr == cr) cr = fminf(fmaxf(cr, lo), hi);                    // ppo.py:213
-        surr = -ratio * ad;                                             // ppo.py:215
-        const float cs = -cr * ad;                                      // ppo.py:216
-        loss_r = (surr >= cs) ? surr : cs;                              // ppo.py:217
-        // max() routes the gradient to the larger entry; the clamped one has zero slope
-        // outside [lo, hi] and equals the unclamped one inside.
-        dLl = (surr >= cs) ? (-ad / Lb) : 0.f;
-    } else {
-        const float Lbc = clamp_min_nan(Lb, 1e-2f);                     // ppo.py:271
-        surr = -(ad * (Ll / Lbc));
-        loss_r = surr;
-        dLl = -ad / Lbc;
-    }
-    // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
-    const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
-
-    if (ok) {
-        for (int a = 0; a < A; ++a) {
-            const float sig = expf(log_var[a]);
-            const float mu = mean[r * A + a];
-            const float ac = actions[r * ld_act + a];
-            const float mr = ref[r * ld_ref + a];
-            const float dt = 1.0f - mu * mu;                             // tanh'
-            g_surr[r * A + a] = (dll * ((ac - mu) / (sig * sig))) * dt;
-            g_kl[r * A + a] = ((mu - mr) / (sig * sig)) * dt;
-        }
-    }
-    const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
-    const float v0 = smx_wave_sum(ok ? surr : 0.f);
-    const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
-    const float v2 = smx_wave_sum(ok ? kl : 0.f);
-    const float v3 = smx_wave_sum(ok ? Lb : 0.f);
-    const float v4 = smx_wave_sum(ok ? isw : 0.f);
-    const float v5 = smx_wave_sum(ok ? klb : 0.f);
-    if (lane == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
-    // log_var gradient partials: d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
-    for (int a = 0; a < A; ++a) {
-        float gs = 0.f, gk = 0.f;
+        float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f;       // loglikelihood sums (learn, behave)
+        float kl_a = 0.f, kl_b = 0.f, kb_a = 0.f, kb_b = 0.f;  // KL(ref||learn), KL(ref||behave)
         if (ok) {
-            const float sig = expf(log_var[a]);
-            const float mu = mean[r * A + a];
-            const float ac = actions[r * ld_act + a];
-            const float mr = ref[r * ld_ref + a], sr = ref[r * ld_ref + A + a];
-            const float z = (ac - mu) / sig;
-            gs = dll * (z * z - 1.0f);
-            gk = 1.0f - (sr * sr + (mr - mu) * (mr - mu)) / (sig * sig);
+            for (int a = 0; a < A; ++a) {
+                const float sig = expf(log_var[a]);             // builders.py:127
+                const float mu = mean[r * lda + a];
+                const float ac = actions[r * lda + a];
+                const float mb = behave[r * ldb + a], sb = behave[r * ldb + A + a];
+                const float mr = ref[r * ldb + a], sr = ref[r * ldb + A + a];
+                // ppo_net.py:39-40
+                const float z = (ac - mu) / sig;
+                s1 += z * z;
+                s2 += logf(sig);
+                const float zb = (ac - mb) / sb;
+                sb1 += zb * zb;
+                sb2 += logf(sb);
+                // ppo_net.py:61-62  KL(p0 || p1): p0 = ref, p1 = learn
+                kl_a += logf(sig / sr);
+                kl_b += (sr * sr + (mr - mu) * (mr - mu)) / (2.0f * (sig * sig));
+                kb_a += logf(sb / sr);
+                kb_b += (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
+            }
         }
-        gs = smx_wave_sum(gs);
-        gk = smx_wave_sum(gk);
-        if (lane == 0) { P[8 + a] = gs; P[8 + A + a] = gk; }
+        const float ll = ((-0.5f * s1) - c_ll) - s2;
+        const float llb = ((-0.5f * sb1) - c_ll) - sb2;
+        const float el = expf(ll);
+        const float Ll = clamp_min_nan(el, 1e-5f);       // ppo_net.py:46
+        const float Lb = clamp_min_nan(expf(llb), 1e-5f);
+        const float kl = (kl_a + kl_b) - half_d;
+        const float klb = (kb_a + kb_b) - half_d;
+        const float ad = ok ? adv[row0 + r] : 0.f;
+
+        float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
+        if (mode == SMX_PPO_CLIP) {
+            const float eps = ctrl->clip_eps;
+            const float lo = (float)(1.0 - (double)eps), hi = (float)(1.0 + (double)eps);
+            const float ratio = Ll / Lb;                                    // ppo.py:212
+            float cr = ratio;
+            if (cr == cr) cr = fminf(fmaxf(cr, lo), hi);                    // ppo.py:213
+            surr = -ratio * ad;                                             // ppo.py:215
+            const float cs = -cr * ad;                                      // ppo.py:216
+            loss_r = (surr >= cs) ? surr : cs;                              // ppo.py:217
+            // max() routes the gradient to the larger entry; the clamped one has zero slope
+            // outside [lo, hi] and equals the unclamped one inside.
+            dLl = (surr >= cs) ? (-ad / Lb) : 0.f;
+        } else {
+            const float Lbc = clamp_min_nan(Lb, 1e-2f);                     // ppo.py:271
+            surr = -(ad * (Ll / Lbc));
+            loss_r = surr;
+            dLl = -ad / Lbc;
+        }
+        // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
+        const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
+
+        if (ok) {
+            for (int a = 0; a < A; ++a) {
+                const float sig = expf(log_var[a]);
+                const float mu = mean[r * lda + a];
+                const float ac = actions[r * lda + a];
+                const float mr = ref[r * ldb + a];
+                const float dt = 1.0f - mu * mu;                             // tanh'
+                t_gs[r * lda + a] = (dll * ((ac - mu) / (sig * sig))) * dt;
+                t_gk[r * lda + a] = ((mu - mr) / (sig * sig)) * dt;
+            }
+        }
+        const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
+        const float v0 = smx_wave_sum(ok ? surr : 0.f);
+        const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
+        const float v2 = smx_wave_sum(ok ? kl : 0.f);
+        const float v3 = smx_wave_sum(ok ? Lb : 0.f);
+        const float v4 = smx_wave_sum(ok ? isw : 0.f);
+        const float v5 = smx_wave_sum(ok ? klb : 0.f);
+        if (lane == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
+        // log_var gradient partials: d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
+        for (int a = 0; a < A; ++a) {
+            float gs = 0.f, gk = 0.f;
+            if (ok) {
+                const float sig = expf(log_var[a]);
+                const float mu = mean[r * lda + a];
+                const float ac = actions[r * lda + a];
+                const float mr = ref[r * ldb + a], sr = ref[r * ldb + A + a];
+                const float z = (ac - mu) / sig;
+                gs = dll * (z * z - 1.0f);
+                gk = 1.0f - (sr * sr + (mr - mu) * (mr - mu)) / (sig * sig);
+            }
+            gs = smx_wave_sum(gs);
+            gk = smx_wave_sum(gk);
+            if (lane == 0) { P[8 + a] = gs; P[8 + A + a] = gk; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)nrows * A; i += 256) {
+        g_surr[row0 * A + i] = t_gs[i];
+        g_kl[row0 * A + i] = t_gk[i];
     }
 }
 
@@ -331,7 +365,8 @@ extern "C" int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const fl
                     row_partials, SMX_E_NULL);
     SMX_REQUIRE(rows > 0 && A > 0 && ld_act >= A && ld_beh >= 2 * A && ld_ref >= 2 * A, SMX_E_SHAPE);
     SMX_REQUIRE(A <= MAX_A && (mode == SMX_PPO_CLIP || mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
-    hipLaunchKernelGGL(policy_loss_kernel, dim3(smx_ppo_loss_blocks(rows)), dim3(64), 0,
+    const size_t lds = (size_t)LOSS_ROWS_PER_BLOCK * 8 * A * sizeof(float);
+    hipLaunchKernelGGL(policy_loss_kernel, dim3(smx_ppo_loss_blocks(rows)), dim3(256), lds,
                        smx_s(stream), mode, mean, log_var, actions, ld_act, behave, ld_beh, ref,
                        ld_ref, adv, (long)rows, A, ctrl, g_surr, g_kl, row_partials);
     SMX_LAUNCH_CHECK();

@@ -8,7 +8,8 @@
 // One wave per sub-trajectory b.  LDS per wave: Vm[N+1] | r[N] | delta[N]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gae_kernel(
-    const float* __restrict__ values, const float* __restrict__ rewards,
+    const float* __restrict__ values, const float* __restrict__ values_tail,
+    const float* __restrict__ rewards,
     const float* __restrict__ dones, const float* __restrict__ gpow,
     const float* __restrict__ lpow, float gamma, float gamma_H, int B, int N, int H,
     float* __restrict__ adv, float* __restrict__ ret) {
@@ -20,11 +21,12 @@ __global__ __launch_bounds__(256) void gae_kernel(
     float* R = Vm + (N + 1);
     float* Dl = R + N;
     if (b < B) {
-        const float* v = values + (size_t)b * (N + 1);
+        // values [B, N+1], or [B, N] + values_tail [B] (bootstrap value of obs_next)
+        const float* v = values + (size_t)b * (values_tail ? N : N + 1);
         const float* r = rewards + (size_t)b * N;
         const float* d = dones + (size_t)b * N;
         for (int t = lane; t <= N; t += 64) {
-            float x = v[t];
+            float x = (values_tail && t == N) ? values_tail[b] : v[t];
             if (t >= 1) x = x * (1.0f - d[t - 1]);  // values[:, 1:] *= 1 - dones   (ppo.py:387)
             Vm[t] = x;
             if (t < N) R[t] = r[t];
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(256) void gae_kernel(
     }
 }
 
-extern "C" int smx_windowed_gae_returns_f32(const float* values, const float* rewards,
+extern "C" int smx_windowed_gae_returns_f32(const float* values, const float* values_tail,
+                                            const float* rewards,
                                             const float* dones, const float* gamma_pow,
                                             const float* lam_pow, float gamma, float gamma_H,
                                             int32_t B, int32_t N, int32_t H, float* adv,
@@ -84,7 +87,7 @@ extern "C" int smx_windowed_gae_returns_f32(const float* values, const float* re
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(gae_kernel, dim3((B + 3) / 4), dim3(256), lds, smx_s(stream), values,
-                       rewards, dones, gamma_pow, lam_pow, gamma, gamma_H, B, N, H, adv, ret);
+                       values_tail, rewards, dones, gamma_pow, lam_pow, gamma, gamma_H, B, N, H, adv, ret);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -249,28 +252,38 @@ extern "C" int smx_zfilter_forward_f32(const float* x, int64_t ldx, int64_t rows
     return SMX_OK;
 }
 
-// Column sums of x and x*x: block = 64 columns x 4 row-lanes; rows strided by 4.
-__global__ __launch_bounds__(256) void zupdate_kernel(const float* __restrict__ x, long ldx,
-                                                      long rows, int D, float* __restrict__ rs,
-                                                      float* __restrict__ rsq,
-                                                      float* __restrict__ cnt, float count_rows) {
-    __shared__ float s1[4][64], s2[4][64];
+// Column sums of x and x*x: block = 64 columns x 16 row-lanes (1024 threads); each thread walks
+// rows r = g, g+16, ... (the rows of obs[:, 0, :] are N*D floats apart: latency-bound, so depth
+// comes from 16 row-lanes x 4 independent loads in flight), then a fixed-order LDS reduction.
+__global__ __launch_bounds__(1024) void zupdate_kernel(const float* __restrict__ x, long ldx,
+                                                       long rows, int D, float* __restrict__ rs,
+                                                       float* __restrict__ rsq,
+                                                       float* __restrict__ cnt, float count_rows) {
+    __shared__ float s1[16][64], s2[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
-    float a = 0.f, q = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
     if (col < D) {
-        for (long r = g; r < rows; r += 4) {
+        long r = g;
+        for (; r + 48 < rows; r += 64) {
+            const float v0 = x[r * ldx + col], v1 = x[(r + 16) * ldx + col];
+            const float v2 = x[(r + 32) * ldx + col], v3 = x[(r + 48) * ldx + col];
+            a0 += v0; q0 += v0 * v0;
+            a1 += v1; q1 += v1 * v1;
+            a2 += v2; q2 += v2 * v2;
+            a3 += v3; q3 += v3 * v3;
+        }
+        for (; r < rows; r += 16) {
             const float v = x[r * ldx + col];
-            a += v;
-            q += v * v;
+            a0 += v; q0 += v * v;
         }
     }
-    s1[g][c] = a;
-    s2[g][c] = q;
+    s1[g][c] = (a0 + a1) + (a2 + a3);
+    s2[g][c] = (q0 + q1) + (q2 + q3);
     __syncthreads();
     if (g == 0 && col < D) {
-        const float ta = ((s1[0][c] + s1[1][c]) + s1[2][c]) + s1[3][c];
-        const float tq = ((s2[0][c] + s2[1][c]) + s2[2][c]) + s2[3][c];
+        float ta = 0.f, tq = 0.f;
+        for (int k = 0; k < 16; ++k) { ta += s1[k][c]; tq += s2[k][c]; }
         rs[col] += ta;    // z_filter.py:55
         rsq[col] += tq;   // z_filter.py:56
     }
@@ -282,7 +295,7 @@ extern "C" int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows,
                                       float count_rows, smx_stream_t stream) {
     SMX_REQUIRE(x && running_sum && running_sumsq && count, SMX_E_NULL);
     SMX_REQUIRE(rows > 0 && D > 0 && ldx >= D, SMX_E_SHAPE);
-    hipLaunchKernelGGL(zupdate_kernel, dim3((D + 63) / 64), dim3(256), 0, smx_s(stream), x,
+    hipLaunchKernelGGL(zupdate_kernel, dim3((D + 63) / 64), dim3(1024), 0, smx_s(stream), x,
                        (long)ldx, (long)rows, D, running_sum, running_sumsq, count, count_rows);
     SMX_LAUNCH_CHECK();
     return SMX_OK;

@@ -73,6 +73,28 @@ class HipKernels(object):
         L.call('smx_mlp3_forward_f32', ctypes.byref(net.desc), L.ptr(x), x.shape[0], L.ptr(h1),
                L.ptr(h2), L.ptr(out), act, L.ptr(stop), self._st())
 
+    def _jobs(self, jobs):
+        arr = (L.Mlp3Job * len(jobs))()
+        for k, j in enumerate(jobs):
+            g = lambda name: L.ptr(j.get(name)) if j.get(name) is not None else None  # noqa: E731
+            arr[k].net = ctypes.pointer(j['net'].desc)
+            arr[k].x = g('x')
+            arr[k].rows = j['x'].shape[0]
+            arr[k].h1, arr[k].h2, arr[k].out = g('h1'), g('h2'), g('out')
+            arr[k].out_act = int(j.get('act', 0))
+            arr[k].dz3, arr[k].dz2, arr[k].dz1 = g('dz3'), g('dz2'), g('dz1')
+            arr[k].grads, arr[k].sumsq_partials = g('grads'), g('sumsq')
+            arr[k].stop_flag = g('stop')
+        return arr
+
+    def mlp3_forward_multi(self, jobs):
+        """jobs: list of dicts(net, x, h1, h2, out, act[, stop]) -- one launch per layer for all"""
+        L.call('smx_mlp3_forward_multi_f32', self._jobs(jobs), len(jobs), self._st())
+
+    def mlp3_backward_multi(self, jobs):
+        """jobs: list of dicts(net, x, h1, h2, dz3, dz2, dz1, grads, sumsq[, stop])"""
+        L.call('smx_mlp3_backward_multi_f32', self._jobs(jobs), len(jobs), self._st())
+
     def mlp3_backward_partials(self, net):
         return self.lib.smx_mlp3_backward_partials(net.D, net.H1, net.H2, net.OUT)
 
@@ -82,8 +104,10 @@ class HipKernels(object):
                L.ptr(stop), self._st())
 
     # ---- GAE / normalisation ------------------------------------------------------------
-    def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret):
-        L.call('smx_windowed_gae_returns_f32', L.ptr(values), L.ptr(rewards), L.ptr(dones),
+    def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret,
+            values_tail=None):
+        L.call('smx_windowed_gae_returns_f32', L.ptr(values), L.ptr(values_tail), L.ptr(rewards),
+               L.ptr(dones),
                L.ptr(gpow), L.ptr(lpow), float(gamma), float(gamma_H), B, N, H, L.ptr(adv),
                L.ptr(ret), self._st())
 

@@ -182,6 +182,8 @@ class PPOLearner(Learner):
             and self.world_size == 1
         self.overlap_value_epochs = bool(lcfg.get('overlap_value_epochs', True)) \
             and self.device != 'cpu'
+        # 'lockstep': actor and critic epochs share launches; 'two_stream': separate chains
+        self.epoch_schedule = lcfg.get('epoch_schedule', 'lockstep')
         self._ws = None
         self._graphs = {}
         self._ctrl_host = None
@@ -235,6 +237,14 @@ class PPOLearner(Learner):
         # critic pass + GAE
         ws.packed = f(K.mlp3_packed_numel(cri))
         ws.vals = f(B * (N + 1))
+        # fused-kernel tail split (see _enqueue_gae): rounds of 128-row workgroups over the CUs
+        n_cu = 256
+        if dev != 'cpu':
+            n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        rounds = lambda rows: -(-(-(-rows // 128)) // n_cu)  # noqa: E731
+        ws.split_tail = bool(self.session_config.learner.get('split_critic_tail', True)) and \
+            rounds(B * (N + 1)) > rounds(B * N)
+        ws.xnext = f(B, D)
         ws.adv = f(B * E)
         ws.ret = f(B * E)
         idx = torch.tensor(range(N), dtype=torch.float32)
@@ -323,9 +333,24 @@ class PPOLearner(Learner):
         if self.use_z_filter:
             zm, zs = m.z_filter.refresh_stats()
         K.mlp3_pack(m.critic, ws.packed)
-        K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.vals, L.SMX_ACT_NONE)
-        K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N, B, N, N,
-              ws.adv, ws.ret)
+        if ws.split_tail:
+            # B*(N+1) rows would need one more (nearly empty) round of workgroups over the chip
+            # than B*N: the fused kernel takes the B*N step rows, the B obs_next rows go through
+            # the layered small-batch kernels (same arithmetic, tests check both against the oracle)
+            K.mlp3_forward_fused(ws.packed, m.critic, obs, None, zm, zs, ws.vals[:B * N],
+                                 L.SMX_ACT_NONE)
+            if self.use_z_filter:
+                K.zfilter_forward(obs_next[:, 0, :], zm, zs, ws.xnext)
+            else:
+                ws.xnext.copy_(obs_next[:, 0, :])
+            K.mlp3_forward(m.critic, ws.xnext, ws.h1c, ws.h2c, ws.vals[B * N:].view(B, 1),
+                           L.SMX_ACT_NONE)
+            K.gae(ws.vals[:B * N], rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N,
+                  B, N, N, ws.adv, ws.ret, values_tail=ws.vals[B * N:])
+        else:
+            K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.vals, L.SMX_ACT_NONE)
+            K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N, B, N, N,
+                  ws.adv, ws.ret)
         if self.norm_adv:
             K.moments(ws.adv, ws.adv_mom)
             if self.world_size > 1:
@@ -386,6 +411,66 @@ class PPOLearner(Learner):
         K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                     ws.sumsq_c, npart, ws.ctrl_f, 1, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
 
+    def _enqueue_lockstep_epochs(self, ws, actions0, behave0):
+        """Policy epoch e and value epoch e advance together: the reference runs the two loops
+        one after the other (ppo.py:541-562) but they touch disjoint parameters, so the layer-l
+        GEMMs of the actor and of the critic share one launch (smx_mlp3_*_multi_f32).  The KL
+        early exit only masks the actor's share (its jobs carry the device stop flag)."""
+        K, m = self.K, self.model
+        Ep, Ev = self.epoch_policy, self.epoch_baseline
+        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
+        A = self.action_dim
+        W = self.world_size
+        n_total = ws.rows * W
+        aj = dict(net=m.actor, x=ws.xn, h1=ws.h1a, h2=ws.h2a, out=ws.mean, act=L.SMX_ACT_TANH,
+                  dz3=ws.dz3a, dz2=ws.dz2a, dz1=ws.dz1a, grads=ws.grads_a, sumsq=ws.sumsq_a,
+                  stop=ws.stop)
+        cj = dict(net=m.critic, x=ws.xn, h1=ws.h1c, h2=ws.h2c, out=ws.vpred.view(-1, 1),
+                  act=L.SMX_ACT_NONE, dz3=ws.dz3c.view(-1, 1), dz2=ws.dz2c, dz1=ws.dz1c,
+                  grads=ws.grads_c, sumsq=ws.sumsq_c)
+        for e in range(max(Ep + 1, Ev)):
+            pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
+            K.mlp3_forward_multi(([aj] if pol_f else []) + ([cj] if val else []))
+            if pol_f:
+                K.policy_loss(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol,
+                              ws.adv, ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
+                part, nblk = ws.ppart, ws.nblk_p
+                if W > 1:
+                    torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
+                    self._dist.all_reduce(ws.ppart_sum)
+                    part, nblk = ws.ppart_sum, 1
+                K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1), n_total,
+                                  ws.ctrl_f, e > 0, pol_u, ws.dz3a,
+                                  ws.grads_a[m.actor.numel:m.actor.numel + A],
+                                  ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
+            if val:
+                if W > 1:
+                    K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
+                    self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
+                else:
+                    K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
+            if pol_u or val:
+                K.mlp3_backward_multi(([aj] if pol_u else []) + ([cj] if val else []))
+            np_a, np_c = ws.np_a + 1, ws.np_c
+            if W > 1:
+                if pol_u:
+                    self._dist.all_reduce(ws.grads_a[:m.actor.numel])
+                    K.sumsq_partials(ws.grads_a, ws.sumsq_a)
+                    np_a = K.sumsq_blocks(ws.grads_a.numel())
+                if val:
+                    self._dist.all_reduce(ws.grads_c)
+                    K.sumsq_partials(ws.grads_c, ws.sumsq_c)
+                    np_c = K.sumsq_blocks(ws.grads_c.numel())
+            if pol_u:
+                K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                            ws.sumsq_a, np_a, ws.ctrl_f, 0, True,
+                            ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
+            if val:
+                K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                            ws.sumsq_c, np_c, ws.ctrl_f, 1, False,
+                            ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
+        K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+
     def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds):
         """the whole of _optimize (ppo.py:487-586) as a launch sequence"""
         K, m, ref = self.K, self.model, self.ref_target_model
@@ -423,7 +508,9 @@ class PPOLearner(Learner):
             K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats,
                              L.VS_STRIDE)
 
-        if self.overlap_value_epochs and self.world_size == 1:
+        if self.epoch_schedule == 'lockstep':
+            self._enqueue_lockstep_epochs(ws, actions0, behave0)
+        elif self.overlap_value_epochs and self.world_size == 1:
             main = torch.cuda.current_stream()
             side = self._side_stream()
             side.wait_stream(main)
@@ -569,6 +656,14 @@ class PPOLearner(Learner):
         self.exp_counter += self.batch_size * self.world_size
         self.global_step += 1
         return tensorplex_update_dict
+
+    def raw_values(self):
+        """critic values of the last learn() as the reference lays them out: (B, N+1)"""
+        ws = self._ws
+        B, N = ws.key[0], ws.key[1]
+        if ws.split_tail:
+            return torch.cat([ws.vals[:B * N].view(B, N), ws.vals[B * N:].view(B, 1)], 1)
+        return ws.vals.view(B, N + 1)
 
     # ---- reference-shaped accessors used by the parity tests ---------------------------------
     def _gae_and_return(self, obs, obs_next, rewards, dones):

@@ -85,6 +85,16 @@ class TorchCpuKernels(object):
         h2.copy_(torch.relu(torch.nn.functional.linear(h1, v['W2'], v['b2'])))
         out.copy_(self._act(torch.nn.functional.linear(h2, v['W3'], v['b3']), act))
 
+    def mlp3_forward_multi(self, jobs):
+        for j in jobs:
+            self.mlp3_forward(j['net'], j['x'], j['h1'], j['h2'], j['out'], j.get('act', 0),
+                              j.get('stop'))
+
+    def mlp3_backward_multi(self, jobs):
+        for j in jobs:
+            self.mlp3_backward(j['net'], j['x'], j['h1'], j['h2'], j['dz3'], j['dz2'], j['dz1'],
+                               j['grads'], j.get('sumsq'), j.get('stop'))
+
     def mlp3_backward_partials(self, net):
         t = lambda a: (a + 31) // 32  # noqa: E731
         return t(net.H1) * t(net.D) + t(net.H2) * t(net.H1) + t(net.OUT) * t(net.H2)
@@ -104,8 +114,12 @@ class TorchCpuKernels(object):
             sumsq[0] = float((flat.double() ** 2).sum())
 
     # ---- GAE / normalisation ------------------------------------------------------------
-    def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret):
-        v = values.view(B, N + 1).clone()
+    def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret,
+            values_tail=None):
+        if values_tail is not None:
+            v = torch.cat([values.view(B, N), values_tail.view(B, 1)], 1)
+        else:
+            v = values.view(B, N + 1).clone()
         v[:, 1:] *= 1 - dones
         tds = rewards + gamma * v[:, 1:] - v[:, :-1]
         E = N - H + 1

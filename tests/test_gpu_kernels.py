@@ -87,6 +87,11 @@ def test_windowed_gae(K, B, N, H):
     C.gae(values, rewards, dones, gpow, lpow, 0.995, 0.995 ** H, B, N, H, ac, rc)
     K.gae(dev(values), dev(rewards), dev(dones), dev(gpow), dev(lpow), 0.995, 0.995 ** H, B, N, H, ad, rd)
     close(ad, ac, msg='adv'), close(rd, rc, msg='ret')
+    # split layout: values [B, N] + values_tail [B]
+    v2 = values.view(B, N + 1)
+    K.gae(dev(v2[:, :N].contiguous()), dev(rewards), dev(dones), dev(gpow), dev(lpow), 0.995,
+          0.995 ** H, B, N, H, ad, rd, values_tail=dev(v2[:, N].contiguous()))
+    close(ad, ac, msg='adv (split values)'), close(rd, rc, msg='ret (split values)')
     # size-independent property: linearity in the rewards (values = 0, no dones) and the
     # telescoping identity adv = ret - V_0 when lambda = 1
     one = torch.ones(N)

@@ -32,7 +32,7 @@ def check_case(name, g, case, learner, stats):
     np.testing.assert_allclose(ws.ret.cpu().numpy().reshape(g['returns'].shape), g['returns'],
                                atol=H.ATOL, rtol=H.RTOL, err_msg='returns')
     B, N = case['shape']['B'], case['shape']['N']
-    vr = ws.vals.cpu().numpy().reshape(B, N + 1)
+    vr = learner.raw_values().cpu().numpy()
     np.testing.assert_allclose(vr[:g['values_raw'].shape[0]], g['values_raw'], atol=H.ATOL,
                                rtol=H.RTOL, err_msg='raw critic values')
     H.assert_trace_close(learner.trace, g, what=name)
@@ -54,6 +54,12 @@ def test_learner_matches_reference_golden_graph(name):
 def test_learner_matches_reference_golden_eager(name):
     """same numbers without graph capture and without stream overlap"""
     check_case(name, *run_case(name, {'use_hip_graph': False, 'overlap_value_epochs': False}))
+
+
+@pytest.mark.parametrize('name', ['tiny_adapt_cutoff2', 'cfg2_clip'])
+def test_learner_two_stream_schedule(name):
+    """the alternative launch schedule (separate policy / value chains on two streams)"""
+    check_case(name, *run_case(name, {'epoch_schedule': 'two_stream'}))
 
 
 def test_three_learns_match_oracle_and_graph_replays():

@@ -32,6 +32,15 @@ def test_learner_host_logic_matches_reference(name, cpu_double):
             np.testing.assert_allclose(sd[k].numpy(), g['zfinal.' + k], rtol=1e-6)
 
 
+def test_two_stream_schedule_host_logic(cpu_double):
+    g, case = H.load_golden('tiny_adapt_cutoff2')
+    batch, params, zstate = H.case_inputs(case)
+    learner = H.make_learner(case, params, zstate, session_overrides={'epoch_schedule': 'two_stream'})
+    stats = learner.learn(copy.deepcopy(batch))
+    H.assert_trace_close(learner.trace, g, what='two_stream')
+    H.assert_stats_close(stats, g, what='two_stream')
+
+
 def test_second_learn_continues_adam_state(cpu_double):
     """Adam moments and step counters persist across learn() calls, as torch.optim does"""
     import ppo_oracle
