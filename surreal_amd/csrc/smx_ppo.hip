@@ -19,10 +19,15 @@ __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
     return (x == x) ? fmaxf(x, lo) : x;  // torch.clamp(min=) keeps NaN
 }
 
-// 64 rows per block, 256 threads: all four waves move the block's rows of mean / actions /
-// behave / ref HBM -> LDS with coalesced loads (the per-row inputs are short strided rows: read
-// one row per lane they cost ~35 scattered cache lines per instruction), wave 0 then does the
-// row-per-lane arithmetic out of LDS, and all waves write the two gradient tiles back coalesced.
+// 64 rows per block, 256 threads, three phases:
+//   1. all waves move the block's rows of mean / actions / behave / ref HBM -> LDS with coalesced
+//      loads and compute the per-ELEMENT terms (one (row, a) pair per thread-iteration): the
+//      transcendentals (log, exp, divisions) are spread over 256 lanes instead of being
+//      serialised 17-deep in one lane per row;
+//   2. one lane per row reduces its A terms, forms the likelihoods / ratio / clip decision and
+//      the per-row gradient scale, and the wave reduces the block partial sums;
+//   3. all waves form the two gradient tiles (element-parallel), write them back coalesced, and
+//      A lanes reduce the log_var gradient partials over the block's rows.
 __global__ __launch_bounds__(256) void policy_loss_kernel(
     int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
     const float* __restrict__ g_actions, int ld_act, const float* __restrict__ g_behave, int ld_beh,
@@ -32,69 +37,72 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
     if (ctrl->stop_flag) return;
     extern __shared__ float sm[];
     const int R = LOSS_ROWS_PER_BLOCK;
-    float* mean = sm;                 // [R, A]
-    float* actions = mean + R * A;    // [R, A]
-    float* behave = actions + R * A;  // [R, 2A]
-    float* ref = behave + R * 2 * A;  // [R, 2A]
-    float* t_gs = ref + R * 2 * A;    // [R, A]
-    float* t_gk = t_gs + R * A;       // [R, A]
+    float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
+    float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
+    float* e_lsb = e_zb2 + R * A;  // log sb
+    float* e_kl = e_lsb + R * A;   // log(sig/sr) + (sr^2+(mr-mu)^2)/(2 sig^2)
+    float* e_klb = e_kl + R * A;   // log(sb/sr) + (sr^2+(mr-mb)^2)/(2 sb^2)
+    float* e_dmu = e_klb + R * A;  // ((a - mu)/sig^2) * (1 - mu^2)        d ll / d z3
+    float* e_dkl = e_dmu + R * A;  // ((mu - mr)/sig^2) * (1 - mu^2)       d KL / d z3
+    float* e_gk = e_dkl + R * A;   // 1 - (sr^2+(mr-mu)^2)/sig^2          d KL / d log_var
+    float* r_dll = e_gk + R * A;   // per-row d(loss_r)/d(ll)             [R]
     const long row0 = (long)blockIdx.x * R;
     long nrows = rows - row0;
     if (nrows > R) nrows = R;
     const int tid = threadIdx.x;
-    for (int i = tid; i < (int)nrows * A; i += 256) {
-        const int rr = i / A, a = i - rr * A;
-        mean[i] = g_mean[(row0 + rr) * A + a];
-        actions[i] = g_actions[(row0 + rr) * ld_act + a];
-    }
-    for (int i = tid; i < (int)nrows * 2 * A; i += 256) {
-        const int rr = i / (2 * A), a = i - rr * 2 * A;
-        behave[i] = g_behave[(row0 + rr) * ld_beh + a];
-        ref[i] = g_ref[(row0 + rr) * ld_ref + a];
-    }
-    __syncthreads();
-    const int lane = tid;
     const int stride = 8 + 2 * A;
     float* P = partials + (size_t)blockIdx.x * stride;
+
+    // ---- phase 1: element-parallel terms ------------------------------------------------
+    for (int i = tid; i < (int)nrows * A; i += 256) {
+        const int rr = i / A, a = i - rr * A;
+        const long gr = row0 + rr;
+        const float sig = expf(log_var[a]);                      // builders.py:127
+        const float mu = g_mean[gr * A + a];
+        const float ac = g_actions[gr * ld_act + a];
+        const float mb = g_behave[gr * ld_beh + a], sb = g_behave[gr * ld_beh + A + a];
+        const float mr = g_ref[gr * ld_ref + a], sr = g_ref[gr * ld_ref + A + a];
+        const float z = (ac - mu) / sig;                         // ppo_net.py:39
+        const float zb = (ac - mb) / sb;
+        const float s2 = sig * sig;
+        const float dt = 1.0f - mu * mu;                         // tanh'
+        const float num = sr * sr + (mr - mu) * (mr - mu);
+        e_z2[i] = z * z;
+        e_zb2[i] = zb * zb;
+        e_lsb[i] = logf(sb);
+        e_kl[i] = logf(sig / sr) + num / (2.0f * s2);            // ppo_net.py:61-62
+        e_klb[i] = logf(sb / sr) + (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
+        e_dmu[i] = ((ac - mu) / s2) * dt;
+        e_dkl[i] = ((mu - mr) / s2) * dt;
+        e_gk[i] = 1.0f - num / s2;
+    }
+    __syncthreads();
+
+    // ---- phase 2: one lane per row ---------------------------------------------------------
     if (tid < 64) {
-        const int r = lane;                       // row inside the block (LDS index)
+        const int r = tid;
         const bool ok = r < nrows;
-        const int lda = A, ldb = 2 * A;
         const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
         const float half_d = (float)(0.5 * (double)A);
-
-        float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f;       // loglikelihood sums (learn, behave)
-        float kl_a = 0.f, kl_b = 0.f, kb_a = 0.f, kb_b = 0.f;  // KL(ref||learn), KL(ref||behave)
+        float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f, klr = 0.f, klbr = 0.f;
         if (ok) {
             for (int a = 0; a < A; ++a) {
-                const float sig = expf(log_var[a]);             // builders.py:127
-                const float mu = mean[r * lda + a];
-                const float ac = actions[r * lda + a];
-                const float mb = behave[r * ldb + a], sb = behave[r * ldb + A + a];
-                const float mr = ref[r * ldb + a], sr = ref[r * ldb + A + a];
-                // ppo_net.py:39-40
-                const float z = (ac - mu) / sig;
-                s1 += z * z;
-                s2 += logf(sig);
-                const float zb = (ac - mb) / sb;
-                sb1 += zb * zb;
-                sb2 += logf(sb);
-                // ppo_net.py:61-62  KL(p0 || p1): p0 = ref, p1 = learn
-                kl_a += logf(sig / sr);
-                kl_b += (sr * sr + (mr - mu) * (mr - mu)) / (2.0f * (sig * sig));
-                kb_a += logf(sb / sr);
-                kb_b += (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
+                s1 += e_z2[r * A + a];
+                s2 += logf(expf(log_var[a]));                    // std0.log()  (ppo_net.py:40)
+                sb1 += e_zb2[r * A + a];
+                sb2 += e_lsb[r * A + a];
+                klr += e_kl[r * A + a];
+                klbr += e_klb[r * A + a];
             }
         }
         const float ll = ((-0.5f * s1) - c_ll) - s2;
         const float llb = ((-0.5f * sb1) - c_ll) - sb2;
         const float el = expf(ll);
-        const float Ll = clamp_min_nan(el, 1e-5f);       // ppo_net.py:46
+        const float Ll = clamp_min_nan(el, 1e-5f);               // ppo_net.py:46
         const float Lb = clamp_min_nan(expf(llb), 1e-5f);
-        const float kl = (kl_a + kl_b) - half_d;
-        const float klb = (kb_a + kb_b) - half_d;
+        const float kl = klr - half_d;
+        const float klb = klbr - half_d;
         const float ad = ok ? adv[row0 + r] : 0.f;
-
         float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
         if (mode == SMX_PPO_CLIP) {
             const float eps = ctrl->clip_eps;
@@ -116,18 +124,7 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
         }
         // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
         const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
-
-        if (ok) {
-            for (int a = 0; a < A; ++a) {
-                const float sig = expf(log_var[a]);
-                const float mu = mean[r * lda + a];
-                const float ac = actions[r * lda + a];
-                const float mr = ref[r * ldb + a];
-                const float dt = 1.0f - mu * mu;                             // tanh'
-                t_gs[r * lda + a] = (dll * ((ac - mu) / (sig * sig))) * dt;
-                t_gk[r * lda + a] = ((mu - mr) / (sig * sig)) * dt;
-            }
-        }
+        r_dll[r] = ok ? dll : 0.f;
         const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
         const float v0 = smx_wave_sum(ok ? surr : 0.f);
         const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
@@ -135,28 +132,25 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
         const float v3 = smx_wave_sum(ok ? Lb : 0.f);
         const float v4 = smx_wave_sum(ok ? isw : 0.f);
         const float v5 = smx_wave_sum(ok ? klb : 0.f);
-        if (lane == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
-        // log_var gradient partials: d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
-        for (int a = 0; a < A; ++a) {
-            float gs = 0.f, gk = 0.f;
-            if (ok) {
-                const float sig = expf(log_var[a]);
-                const float mu = mean[r * lda + a];
-                const float ac = actions[r * lda + a];
-                const float mr = ref[r * ldb + a], sr = ref[r * ldb + A + a];
-                const float z = (ac - mu) / sig;
-                gs = dll * (z * z - 1.0f);
-                gk = 1.0f - (sr * sr + (mr - mu) * (mr - mu)) / (sig * sig);
-            }
-            gs = smx_wave_sum(gs);
-            gk = smx_wave_sum(gk);
-            if (lane == 0) { P[8 + a] = gs; P[8 + A + a] = gk; }
-        }
+        if (tid == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
     }
     __syncthreads();
+
+    // ---- phase 3: gradient tiles + log_var gradient partials -----------------------------
     for (int i = tid; i < (int)nrows * A; i += 256) {
-        g_surr[row0 * A + i] = t_gs[i];
-        g_kl[row0 * A + i] = t_gk[i];
+        const int rr = i / A;
+        g_surr[row0 * A + i] = r_dll[rr] * e_dmu[i];
+        g_kl[row0 * A + i] = e_dkl[i];
+    }
+    if (tid < A) {
+        // d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
+        float gs = 0.f, gk = 0.f;
+        for (int rr = 0; rr < (int)nrows; ++rr) {
+            gs += r_dll[rr] * (e_z2[rr * A + tid] - 1.0f);
+            gk += e_gk[rr * A + tid];
+        }
+        P[8 + tid] = gs;
+        P[8 + A + tid] = gk;
     }
 }
 
@@ -365,7 +359,7 @@ extern "C" int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const fl
                     row_partials, SMX_E_NULL);
     SMX_REQUIRE(rows > 0 && A > 0 && ld_act >= A && ld_beh >= 2 * A && ld_ref >= 2 * A, SMX_E_SHAPE);
     SMX_REQUIRE(A <= MAX_A && (mode == SMX_PPO_CLIP || mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
-    const size_t lds = (size_t)LOSS_ROWS_PER_BLOCK * 8 * A * sizeof(float);
+    const size_t lds = (size_t)LOSS_ROWS_PER_BLOCK * (8 * A + 1) * sizeof(float);
     hipLaunchKernelGGL(policy_loss_kernel, dim3(smx_ppo_loss_blocks(rows)), dim3(256), lds,
                        smx_s(stream), mode, mean, log_var, actions, ld_act, behave, ld_beh, ref,
                        ld_ref, adv, (long)rows, A, ctrl, g_surr, g_kl, row_partials);
