@@ -80,27 +80,45 @@ def device_batch(learner, rank):
     return learner._preprocess_batch_ppo(copy.deepcopy(batch)), batch
 
 
-def time_fused_kernel(learner, dbatch, iters=20):
-    """average duration of the dominant kernel, HIP events on the launch stream"""
+def time_fused_kernel(learner, dbatch, iters=10):
+    """average duration of the dominant kernel: HIP events on the launch stream around ONE launch
+    issued right after a full learn() step (same clocks / cache state as inside the timed steps;
+    back-to-back launches of this MFMA-saturating kernel run ~7 % slower under the power cap)"""
     ws = learner._ws
     obs = dbatch['obs']['low_dim']['flat_inputs']
     obs_next = dbatch['obs_next']['low_dim']['flat_inputs']
     m = learner.model
-    zm, zs = m.z_filter.refresh_stats()
     K = learner.K
-    K.mlp3_pack(m.critic, ws.packed)
     tail = None if ws.split_tail else obs_next       # exactly the launch learn() issues
     out = ws.vals[:B * N] if ws.split_tail else ws.vals
-    for _ in range(3):
-        K.mlp3_forward_fused(ws.packed, m.critic, obs, tail, zm, zs, out, 0)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    total = 0.0
     for _ in range(iters):
+        learner.learn(dbatch)
+        zm, zs = m.z_filter.refresh_stats()
+        K.mlp3_pack(m.critic, ws.packed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         K.mlp3_forward_fused(ws.packed, m.critic, obs, tail, zm, zs, out, 0)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+        e1.record()
+        torch.cuda.synchronize()
+        total += e0.elapsed_time(e1)
+    return total / iters * 1e-3
+
+
+def measured_traffic(rows):
+    """HBM bytes per launch of the fused kernel from the committed PMC pass (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied; profiles/*_pmc_*.json).
+    PMC collection cannot run inside this process, so the figure is read from the profile."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm_traffic.json')), reverse=True):
+        try:
+            fk = json.load(open(path)).get('fused_kernel', {})
+        except Exception:
+            continue
+        for v in fk.values():
+            if v.get('rows_upper_bound') == rows:
+                return v['hbm_read_bytes_corrected'] + v['hbm_write_bytes'], os.path.basename(path)
+    return None, None
 
 
 def cpu_baseline(mode, params, zstate, batch, budget_s=20.0):
@@ -200,7 +218,8 @@ def main():
                 'peak': PEAK_FP32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': flops / kt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                'traffic': None,
+                'traffic': measured_traffic(rows)[0],
+                'traffic_source': measured_traffic(rows)[1],
                 'kernel_ms': kt * 1e3,
                 'flops_per_launch': flops,
                 'algorithmic_bytes_per_launch': bytes_,
