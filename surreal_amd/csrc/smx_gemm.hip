@@ -20,6 +20,8 @@ struct GemmProb {
     float* C;
     float* dbias;        // [M] or null : dbias[m] = sum_k A(m,k)   (bias gradient of a dW GEMM)
     float* sumsq;        // per-tile sum of squares of C (+dbias) or null
+    float* CT;           // optional transposed copy: CT[n * ldct + m] = C[m, n]
+    int ldct;
     int lda, ldb, ldc, M, N, K;
     int a_kc, b_kc, act;
     int tiles_m, tiles_n, tile_base, a_vec, b_vec;
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
             v = act_f(v, P.act);
             if (P.mask) v = (P.mask[(size_t)m * P.ldc + n] > 0.f) ? v : 0.f;
             P.C[(size_t)m * P.ldc + n] = v;
+            if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
             ss += v * v;
         }
     }
@@ -179,8 +182,9 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
 inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const float* B, int ldb,
                       int b_kc, const float* bias, const float* mask, float* C, int ldc, int M,
                       int N, int K, int act, float* dbias, float* sumsq, int tile_base,
-                      const int* stop = nullptr) {
+                      const int* stop = nullptr, float* CT = nullptr, int ldct = 0) {
     P.A = A; P.B = B; P.bias = bias; P.mask = mask; P.C = C; P.dbias = dbias; P.sumsq = sumsq;
+    P.CT = CT; P.ldct = ldct;
     P.stop = stop;
     P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
     P.a_kc = a_kc; P.b_kc = b_kc; P.act = act;
@@ -252,10 +256,10 @@ extern "C" int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t nj
             const int R = (int)J.rows;
             if (layer == 0)
                 fill_prob(G.p[j], J.x, n->D, 1, n->W1, n->D, 1, n->b1, nullptr, J.h1, n->H1, R, n->H1,
-                          n->D, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag);
+                          n->D, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h1T, R);
             else if (layer == 1)
                 fill_prob(G.p[j], J.h1, n->H1, 1, n->W2, n->H1, 1, n->b2, nullptr, J.h2, n->H2, R,
-                          n->H2, n->H1, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag);
+                          n->H2, n->H1, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h2T, R);
             else
                 fill_prob(G.p[j], J.h2, n->H2, 1, n->W3, n->H2, 1, n->b3, nullptr, J.out, n->OUT, R,
                           n->OUT, n->H2, J.out_act, nullptr, nullptr, base, J.stop_flag);
@@ -303,10 +307,10 @@ extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t n
             const int R = (int)J.rows;
             if (stage == 0)
                 fill_prob(G.p[j], J.dz3, n->OUT, 1, n->W3, n->H2, 0, nullptr, J.h2, J.dz2, n->H2, R,
-                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag);
+                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz2T, R);
             else
                 fill_prob(G.p[j], J.dz2, n->H2, 1, n->W2, n->H1, 0, nullptr, J.h1, J.dz1, n->H1, R,
-                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag);
+                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz1T, R);
             base += G.p[j].tiles_m * G.p[j].tiles_n;
         }
         const int rc = launch_batch(G, smx_s(stream));
@@ -328,14 +332,20 @@ extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t n
         float* gb3 = gW3 + (size_t)O * H2;
         float* sq = J.sumsq_partials;
         const int job_base = base;
-        fill_prob(G.p[3 * j + 0], J.dz1, H1, 0, J.x, D, 0, nullptr, nullptr, gW1, D, H1, D, R,
-                  SMX_ACT_NONE, gb1, sq, base, J.stop_flag);
+        // with the transposed copies ([features, rows], written by the producing GEMMs' epilogues)
+        // both operands of dW = dz^T . input are K-contiguous: 16-byte fragment loads, 4 MFMA steps
+        // per load, instead of one 4-byte load per operand per step
+        const bool kc = J.xT && J.h1T && J.h2T && J.dz1T && J.dz2T && J.dz3T;
+        const float *a1 = kc ? J.dz1T : J.dz1, *a2 = kc ? J.dz2T : J.dz2, *a3 = kc ? J.dz3T : J.dz3;
+        const float *b1 = kc ? J.xT : J.x, *b2 = kc ? J.h1T : J.h1, *b3 = kc ? J.h2T : J.h2;
+        fill_prob(G.p[3 * j + 0], a1, kc ? R : H1, kc, b1, kc ? R : D, kc, nullptr, nullptr, gW1, D, H1,
+                  D, R, SMX_ACT_NONE, gb1, sq, base, J.stop_flag);
         base += G.p[3 * j + 0].tiles_m * G.p[3 * j + 0].tiles_n;
-        fill_prob(G.p[3 * j + 1], J.dz2, H2, 0, J.h1, H1, 0, nullptr, nullptr, gW2, H1, H2, H1, R,
-                  SMX_ACT_NONE, gb2, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
+        fill_prob(G.p[3 * j + 1], a2, kc ? R : H2, kc, b2, kc ? R : H1, kc, nullptr, nullptr, gW2, H1,
+                  H2, H1, R, SMX_ACT_NONE, gb2, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
         base += G.p[3 * j + 1].tiles_m * G.p[3 * j + 1].tiles_n;
-        fill_prob(G.p[3 * j + 2], J.dz3, O, 0, J.h2, H2, 0, nullptr, nullptr, gW3, H2, O, H2, R,
-                  SMX_ACT_NONE, gb3, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
+        fill_prob(G.p[3 * j + 2], a3, kc ? R : O, kc, b3, kc ? R : H2, kc, nullptr, nullptr, gW3, H2, O,
+                  H2, R, SMX_ACT_NONE, gb3, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
         base += G.p[3 * j + 2].tiles_m * G.p[3 * j + 2].tiles_n;
     }
     return launch_batch(G, smx_s(stream));

@@ -85,6 +85,8 @@ class HipKernels(object):
             arr[k].dz3, arr[k].dz2, arr[k].dz1 = g('dz3'), g('dz2'), g('dz1')
             arr[k].grads, arr[k].sumsq_partials = g('grads'), g('sumsq')
             arr[k].stop_flag = g('stop')
+            arr[k].h1T, arr[k].h2T, arr[k].xT = g('h1T'), g('h2T'), g('xT')
+            arr[k].dz3T, arr[k].dz2T, arr[k].dz1T = g('dz3T'), g('dz2T'), g('dz1T')
         return arr
 
     def mlp3_forward_multi(self, jobs):
@@ -133,12 +135,12 @@ class HipKernels(object):
                L.ptr(g_kl), L.ptr(partials), self._st())
 
     def policy_finalize(self, mode, partials, nblk, g_surr, g_kl, log_var, n_total, ctrl,
-                        check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats):
+                        check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None):
         rows, A = g_surr.shape
         L.call('smx_ppo_loss_finalize_f32', mode, L.ptr(partials), nblk, L.ptr(g_surr),
                L.ptr(g_kl), L.ptr(log_var), rows, n_total, A, L.ptr(ctrl), int(check_stop),
-               int(will_update), L.ptr(dz3), L.ptr(dlogvar), L.ptr(dlogvar_sumsq), L.ptr(stats),
-               self._st())
+               int(will_update), L.ptr(dz3), L.ptr(dz3_t), L.ptr(dlogvar), L.ptr(dlogvar_sumsq),
+               L.ptr(stats), self._st())
 
     def value_loss_blocks(self, rows):
         return self.lib.smx_value_loss_blocks(rows)

@@ -263,6 +263,12 @@ class PPOLearner(Learner):
         ws.g_surr, ws.g_kl, ws.dz3a = f(rows, A), f(rows, A), f(rows, A)
         ws.dz2a, ws.dz1a = f(rows, act.H2), f(rows, act.H1)
         ws.dz3c, ws.dz2c, ws.dz1c = f(rows), f(rows, cri.H2), f(rows, cri.H1)
+        # transposed copies [features, rows] feeding the weight-gradient GEMMs (K-contiguous)
+        ws.xnT = f(D, rows)
+        ws.h1aT, ws.h2aT, ws.dz3aT = f(act.H1, rows), f(act.H2, rows), f(A, rows)
+        ws.dz2aT, ws.dz1aT = f(act.H2, rows), f(act.H1, rows)
+        ws.h1cT, ws.h2cT = f(cri.H1, rows), f(cri.H2, rows)
+        ws.dz2cT, ws.dz1cT = f(cri.H2, rows), f(cri.H1, rows)
         ws.grads_a = torch.zeros_like(self.model.actor_flat)
         ws.grads_c = torch.zeros_like(self.model.critic_flat)
         ws.nblk_p = K.loss_blocks(rows)
@@ -424,10 +430,12 @@ class PPOLearner(Learner):
         n_total = ws.rows * W
         aj = dict(net=m.actor, x=ws.xn, h1=ws.h1a, h2=ws.h2a, out=ws.mean, act=L.SMX_ACT_TANH,
                   dz3=ws.dz3a, dz2=ws.dz2a, dz1=ws.dz1a, grads=ws.grads_a, sumsq=ws.sumsq_a,
-                  stop=ws.stop)
+                  stop=ws.stop, xT=ws.xnT, h1T=ws.h1aT, h2T=ws.h2aT, dz3T=ws.dz3aT, dz2T=ws.dz2aT,
+                  dz1T=ws.dz1aT)
         cj = dict(net=m.critic, x=ws.xn, h1=ws.h1c, h2=ws.h2c, out=ws.vpred.view(-1, 1),
                   act=L.SMX_ACT_NONE, dz3=ws.dz3c.view(-1, 1), dz2=ws.dz2c, dz1=ws.dz1c,
-                  grads=ws.grads_c, sumsq=ws.sumsq_c)
+                  grads=ws.grads_c, sumsq=ws.sumsq_c, xT=ws.xnT, h1T=ws.h1cT, h2T=ws.h2cT,
+                  dz3T=ws.dz3c, dz2T=ws.dz2cT, dz1T=ws.dz1cT)     # OUT = 1: dz3^T is dz3 itself
         for e in range(max(Ep + 1, Ev)):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
             K.mlp3_forward_multi(([aj] if pol_f else []) + ([cj] if val else []))
@@ -442,7 +450,7 @@ class PPOLearner(Learner):
                 K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1), n_total,
                                   ws.ctrl_f, e > 0, pol_u, ws.dz3a,
                                   ws.grads_a[m.actor.numel:m.actor.numel + A],
-                                  ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
+                                  ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e], dz3_t=ws.dz3aT)
             if val:
                 if W > 1:
                     K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
@@ -491,6 +499,7 @@ class PPOLearner(Learner):
         else:
             ws.xn.copy_(obs0)
             ws.xr.copy_(obs0)
+        ws.xnT.copy_(ws.xn.t())
         # ref_pol = ref_target_model.forward_actor(obs_iter)   (ppo.py:539)
         K.mlp3_forward(ref.actor, ws.xr, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
         ws.ref_pol[:, :A].copy_(ws.ref_mean)

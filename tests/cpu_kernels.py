@@ -87,13 +87,25 @@ class TorchCpuKernels(object):
 
     def mlp3_forward_multi(self, jobs):
         for j in jobs:
-            self.mlp3_forward(j['net'], j['x'], j['h1'], j['h2'], j['out'], j.get('act', 0),
-                              j.get('stop'))
+            if j.get('stop') is not None and int(j['stop'][0]) != 0:
+                continue
+            self.mlp3_forward(j['net'], j['x'], j['h1'], j['h2'], j['out'], j.get('act', 0))
+            if j.get('h1T') is not None:
+                j['h1T'].copy_(j['h1'].t())
+                j['h2T'].copy_(j['h2'].t())
 
     def mlp3_backward_multi(self, jobs):
         for j in jobs:
+            if j.get('dz1T') is not None and j.get('xT') is not None:
+                # the transposed operands must be what the row-major ones say (contract check)
+                assert torch.equal(j['xT'], j['x'].t()) and torch.equal(j['h1T'], j['h1'].t())
+                assert torch.equal(j['h2T'], j['h2'].t())
+                assert torch.equal(j['dz3T'].reshape(j['dz3'].shape[1], -1), j['dz3'].t())
             self.mlp3_backward(j['net'], j['x'], j['h1'], j['h2'], j['dz3'], j['dz2'], j['dz1'],
                                j['grads'], j.get('sumsq'), j.get('stop'))
+            if j.get('dz1T') is not None and not (j.get('stop') is not None and int(j['stop'][0]) != 0):
+                j['dz2T'].copy_(j['dz2'].t())
+                j['dz1T'].copy_(j['dz1'].t())
 
     def mlp3_backward_partials(self, net):
         t = lambda a: (a + 31) // 32  # noqa: E731
@@ -211,7 +223,7 @@ class TorchCpuKernels(object):
             partials[b, 8 + A:8 + 2 * A] = gk[sl].sum(0)
 
     def policy_finalize(self, mode, partials, nblk, g_surr, g_kl, log_var, n_total, ctrl,
-                        check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats):
+                        check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None):
         ci = ctrl.view(torch.int32)
         if int(ci[L.C_STOP]) != 0:
             return
@@ -231,6 +243,8 @@ class TorchCpuKernels(object):
                 loss = loss + eta * (d * d)
                 c_kl = c_kl + 2.0 * eta * float(d)
         dz3.copy_((g_surr + c_kl * g_kl) / n)
+        if dz3_t is not None:
+            dz3_t.copy_(dz3.t())
         gl = (S[8:8 + A] + c_kl * S[8 + A:8 + 2 * A]) / n
         dlogvar.copy_(gl)
         if dlogvar_sumsq is not None:

@@ -365,3 +365,43 @@ def test_replay_kernels(K):
     assert torch.equal(sd.cpu(), sc)
     for rc, rd in zip(rolls_c, rolls_d):
         assert torch.equal(rd.cpu(), rc)
+
+
+@pytest.mark.parametrize('rows,D', [(1024, 376), (96, 20)])
+def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
+    """actor + critic jobs in shared launches; the weight-gradient GEMMs read the transposed
+    (K-contiguous) copies written by the producing epilogues; a raised stop flag masks one job"""
+    g = torch.Generator().manual_seed(rows)
+    specs = [(D, 300, 200, 17, L.SMX_ACT_TANH), (D, 300, 200, 1, L.SMX_ACT_NONE)] if D == 376 else \
+        [(D, 40, 24, 5, L.SMX_ACT_TANH), (D, 40, 24, 1, L.SMX_ACT_NONE)]
+    x = torch.randn(rows, D, generator=g)
+
+    def mk(to, stop_val):
+        jobs = []
+        for k, (d, h1, h2, o, act) in enumerate(specs):
+            nc, nd = make_net(d, h1, h2, o, 77 + k, 'cuda')
+            net = nc if to is None else nd
+            t = (lambda z: z) if to is None else dev
+            f = lambda *s: t(torch.zeros(*s))  # noqa: E731
+            jobs.append(dict(net=net, x=t(x.clone()), h1=f(rows, h1), h2=f(rows, h2), out=f(rows, o), act=act,
+                             dz3=t(torch.randn(rows, o, generator=torch.Generator().manual_seed(5 + k)) / rows),
+                             dz2=f(rows, h2), dz1=f(rows, h1), grads=f(net.numel),
+                             sumsq=f(K.mlp3_backward_partials(nd)), xT=t(x.t().contiguous()),
+                             h1T=f(h1, rows), h2T=f(h2, rows), dz2T=f(h2, rows), dz1T=f(h1, rows)))
+            jobs[-1]['dz3T'] = t(jobs[-1]['dz3'].cpu().t().contiguous())
+        jobs[0]['stop'] = t(torch.tensor([stop_val], dtype=torch.int32))
+        return jobs
+    for stop_val in (0, 1):
+        jc, jd = mk(None, stop_val), mk('cuda', stop_val)
+        C.mlp3_forward_multi(jc)
+        K.mlp3_forward_multi(jd)
+        C.mlp3_backward_multi(jc)
+        K.mlp3_backward_multi(jd)
+        for a, b in zip(jd, jc):
+            for key in ('h1', 'h2', 'out', 'h1T', 'h2T', 'dz2', 'dz1', 'dz2T', 'dz1T'):
+                close(a[key], b[key], msg='%s stop=%d' % (key, stop_val))
+            close(a['grads'], b['grads'], atol=2e-6, rtol=2e-5, msg='grads stop=%d' % stop_val)
+            np.testing.assert_allclose(float(a['sumsq'].sum()), float(b['sumsq'].sum()), rtol=1e-5)
+        if stop_val:
+            assert float(jd[0]['out'].abs().max()) == 0.0 and float(jd[0]['grads'].abs().max()) == 0.0
+            assert float(jd[1]['grads'].abs().max()) > 0.0
