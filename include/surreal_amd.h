@@ -137,7 +137,9 @@ typedef struct {
     float* grads;
     float* sumsq_partials;
     const int32_t* stop_flag;
-    /* optional transposed copies, all [features, rows] (row stride = rows): the forward writes
+    /* optional transposed copies, all [features, rows] with row stride ldT floats (>= rows; 0 means
+     * rows -- pad it, e.g. rows + 16: a power-of-two stride puts all 32 rows of a fragment load
+     * on the same cache set / memory channel): the forward writes
      * h1T / h2T, the backward writes dz2T / dz1T; when xT, dz3T and all four are given the
      * weight-gradient GEMMs read K-contiguous operands (16-byte loads) instead of strided ones */
     float* h1T;
@@ -146,6 +148,7 @@ typedef struct {
     const float* dz3T;
     float* dz2T;
     float* dz1T;
+    int64_t ldT;
 } smx_mlp3_job_t;
 int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
 int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
@@ -243,14 +246,14 @@ int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const float* log_va
  * ctrl->stop_flag.  When `will_update` is non-zero and the flag stays clear it advances
  * ctrl->adam_step_actor and ctrl->epochs_done for the optimiser step that follows.
  * dlogvar_sumsq (optional) receives sum(dlogvar^2), one more clip_grad_norm_ partial.
- * dz3_t (optional) receives the transposed copy dz3_t[a * rows + r] (see smx_mlp3_job_t).
+ * dz3_t (optional) receives the transposed copy dz3_t[a * ld_t + r] (see smx_mlp3_job_t).
  * No-op when ctrl->stop_flag is already set on entry. */
 int smx_ppo_loss_finalize_f32(int32_t mode, const float* row_partials, int32_t nblk,
                               const float* g_surr, const float* g_kl, const float* log_var,
                               int64_t rows, int64_t n_total, int32_t A, smx_ppo_ctrl_t* ctrl,
                               int32_t check_stop, int32_t will_update, float* dz3,
-                              float* dz3_t, float* dlogvar, float* dlogvar_sumsq, float* stats,
-                              smx_stream_t stream);
+                              float* dz3_t, int64_t ld_t, float* dlogvar, float* dlogvar_sumsq,
+                              float* stats, smx_stream_t stream);
 
 /* --- value loss (ppo.py:311-332): loss = mean((V-ret)^2), explained variance ---
  * dz3[r] = 2 (V_r - ret_r) / n_total ; partials [nblk, 8] = per-block

@@ -34,7 +34,7 @@ class Mlp3Job(Structure):
                 ('dz3', c_void_p), ('dz2', c_void_p), ('dz1', c_void_p), ('grads', c_void_p),
                 ('sumsq_partials', c_void_p), ('stop_flag', c_void_p),
                 ('h1T', c_void_p), ('h2T', c_void_p), ('xT', c_void_p), ('dz3T', c_void_p),
-                ('dz2T', c_void_p), ('dz1T', c_void_p)]
+                ('dz2T', c_void_p), ('dz1T', c_void_p), ('ldT', c_int64)]
 
 
 # smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
@@ -74,7 +74,8 @@ _SIGS = {
     'smx_ppo_policy_loss_f32': (c_int32, [c_int32, _P, _P, _P, c_int32, _P, c_int32, _P, c_int32,
                                           _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
     'smx_ppo_loss_finalize_f32': (c_int32, [c_int32, _P, c_int32, _P, _P, _P, c_int64, c_int64,
-                                            c_int32, _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+                                            c_int32, _P, c_int32, c_int32, _P, _P, c_int64, _P, _P,
+                                            _P, _P]),
     'smx_value_loss_blocks': (c_int32, [c_int64]),
     'smx_value_loss_f32': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P]),
     'smx_value_loss_finalize_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P]),

@@ -256,10 +256,10 @@ extern "C" int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t nj
             const int R = (int)J.rows;
             if (layer == 0)
                 fill_prob(G.p[j], J.x, n->D, 1, n->W1, n->D, 1, n->b1, nullptr, J.h1, n->H1, R, n->H1,
-                          n->D, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h1T, R);
+                          n->D, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h1T, (int)(J.ldT ? J.ldT : R));
             else if (layer == 1)
                 fill_prob(G.p[j], J.h1, n->H1, 1, n->W2, n->H1, 1, n->b2, nullptr, J.h2, n->H2, R,
-                          n->H2, n->H1, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h2T, R);
+                          n->H2, n->H1, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h2T, (int)(J.ldT ? J.ldT : R));
             else
                 fill_prob(G.p[j], J.h2, n->H2, 1, n->W3, n->H2, 1, n->b3, nullptr, J.out, n->OUT, R,
                           n->OUT, n->H2, J.out_act, nullptr, nullptr, base, J.stop_flag);
@@ -307,10 +307,10 @@ extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t n
             const int R = (int)J.rows;
             if (stage == 0)
                 fill_prob(G.p[j], J.dz3, n->OUT, 1, n->W3, n->H2, 0, nullptr, J.h2, J.dz2, n->H2, R,
-                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz2T, R);
+                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz2T, (int)(J.ldT ? J.ldT : R));
             else
                 fill_prob(G.p[j], J.dz2, n->H2, 1, n->W2, n->H1, 0, nullptr, J.h1, J.dz1, n->H1, R,
-                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz1T, R);
+                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz1T, (int)(J.ldT ? J.ldT : R));
             base += G.p[j].tiles_m * G.p[j].tiles_n;
         }
         const int rc = launch_batch(G, smx_s(stream));
@@ -336,15 +336,16 @@ extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t n
         // both operands of dW = dz^T . input are K-contiguous: 16-byte fragment loads, 4 MFMA steps
         // per load, instead of one 4-byte load per operand per step
         const bool kc = J.xT && J.h1T && J.h2T && J.dz1T && J.dz2T && J.dz3T;
+        const int LT = (int)(J.ldT ? J.ldT : R);
         const float *a1 = kc ? J.dz1T : J.dz1, *a2 = kc ? J.dz2T : J.dz2, *a3 = kc ? J.dz3T : J.dz3;
         const float *b1 = kc ? J.xT : J.x, *b2 = kc ? J.h1T : J.h1, *b3 = kc ? J.h2T : J.h2;
-        fill_prob(G.p[3 * j + 0], a1, kc ? R : H1, kc, b1, kc ? R : D, kc, nullptr, nullptr, gW1, D, H1,
+        fill_prob(G.p[3 * j + 0], a1, kc ? LT : H1, kc, b1, kc ? LT : D, kc, nullptr, nullptr, gW1, D, H1,
                   D, R, SMX_ACT_NONE, gb1, sq, base, J.stop_flag);
         base += G.p[3 * j + 0].tiles_m * G.p[3 * j + 0].tiles_n;
-        fill_prob(G.p[3 * j + 1], a2, kc ? R : H2, kc, b2, kc ? R : H1, kc, nullptr, nullptr, gW2, H1,
+        fill_prob(G.p[3 * j + 1], a2, kc ? LT : H2, kc, b2, kc ? LT : H1, kc, nullptr, nullptr, gW2, H1,
                   H2, H1, R, SMX_ACT_NONE, gb2, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
         base += G.p[3 * j + 1].tiles_m * G.p[3 * j + 1].tiles_n;
-        fill_prob(G.p[3 * j + 2], a3, kc ? R : O, kc, b3, kc ? R : H2, kc, nullptr, nullptr, gW3, H2, O,
+        fill_prob(G.p[3 * j + 2], a3, kc ? LT : O, kc, b3, kc ? LT : H2, kc, nullptr, nullptr, gW3, H2, O,
                   H2, R, SMX_ACT_NONE, gb3, sq ? sq + (base - job_base) : nullptr, base, J.stop_flag);
         base += G.p[3 * j + 2].tiles_m * G.p[3 * j + 2].tiles_n;
     }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void policy_finalize_kernel(
     int mode, const float* __restrict__ partials, int nblk, const float* __restrict__ g_surr,
     const float* __restrict__ g_kl, const float* __restrict__ log_var, long rows, long n_total,
     int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
-    float* __restrict__ dz3, float* __restrict__ dz3_t, float* __restrict__ dlogvar,
+    float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
     float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
     if (ctrl->stop_flag) return;
     __shared__ float S[8 + 2 * MAX_A];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void policy_finalize_kernel(
         dz3[i] = v;
         if (dz3_t) {
             const long r = i / A;
-            dz3_t[(i - r * A) * rows + r] = v;
+            dz3_t[(i - r * A) * ld_t + r] = v;
         }
     }
     if (blockIdx.x == 0) {
@@ -379,7 +379,7 @@ extern "C" int smx_ppo_loss_finalize_f32(int32_t mode, const float* row_partials
                                          const float* log_var, int64_t rows, int64_t n_total,
                                          int32_t A, smx_ppo_ctrl_t* ctrl, int32_t check_stop,
                                          int32_t will_update, float* dz3, float* dz3_t,
-                                         float* dlogvar, float* dlogvar_sumsq, float* stats,
+                                         int64_t ld_t, float* dlogvar, float* dlogvar_sumsq, float* stats,
                                          smx_stream_t stream) {
     SMX_REQUIRE(row_partials && g_surr && g_kl && log_var && ctrl && dz3 && dlogvar && stats,
                 SMX_E_NULL);
@@ -389,7 +389,8 @@ extern "C" int smx_ppo_loss_finalize_f32(int32_t mode, const float* row_partials
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(policy_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream),
                        mode, row_partials, nblk, g_surr, g_kl, log_var, (long)rows, (long)n_total, A,
-                       ctrl, check_stop, will_update, dz3, dz3_t, dlogvar, dlogvar_sumsq, stats);
+                       ctrl, check_stop, will_update, dz3, dz3_t, (long)(ld_t ? ld_t : rows), dlogvar,
+                       dlogvar_sumsq, stats);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

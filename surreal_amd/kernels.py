@@ -87,6 +87,8 @@ class HipKernels(object):
             arr[k].stop_flag = g('stop')
             arr[k].h1T, arr[k].h2T, arr[k].xT = g('h1T'), g('h2T'), g('xT')
             arr[k].dz3T, arr[k].dz2T, arr[k].dz1T = g('dz3T'), g('dz2T'), g('dz1T')
+            tv = j.get('h1T')      # all transposed views of a job share one row stride
+            arr[k].ldT = 0 if tv is None else (tv.stride(0) if tv.shape[0] > 1 else tv.shape[1])
         return arr
 
     def mlp3_forward_multi(self, jobs):
@@ -139,7 +141,8 @@ class HipKernels(object):
         rows, A = g_surr.shape
         L.call('smx_ppo_loss_finalize_f32', mode, L.ptr(partials), nblk, L.ptr(g_surr),
                L.ptr(g_kl), L.ptr(log_var), rows, n_total, A, L.ptr(ctrl), int(check_stop),
-               int(will_update), L.ptr(dz3), L.ptr(dz3_t), L.ptr(dlogvar), L.ptr(dlogvar_sumsq),
+               int(will_update), L.ptr(dz3), L.ptr(dz3_t),
+               0 if dz3_t is None else dz3_t.stride(0), L.ptr(dlogvar), L.ptr(dlogvar_sumsq),
                L.ptr(stats), self._st())
 
     def value_loss_blocks(self, rows):

@@ -264,11 +264,15 @@ class PPOLearner(Learner):
         ws.dz2a, ws.dz1a = f(rows, act.H2), f(rows, act.H1)
         ws.dz3c, ws.dz2c, ws.dz1c = f(rows), f(rows, cri.H2), f(rows, cri.H1)
         # transposed copies [features, rows] feeding the weight-gradient GEMMs (K-contiguous)
-        ws.xnT = f(D, rows)
-        ws.h1aT, ws.h2aT, ws.dz3aT = f(act.H1, rows), f(act.H2, rows), f(A, rows)
-        ws.dz2aT, ws.dz1aT = f(act.H2, rows), f(act.H1, rows)
-        ws.h1cT, ws.h2cT = f(cri.H1, rows), f(cri.H2, rows)
-        ws.dz2cT, ws.dz1cT = f(cri.H2, rows), f(cri.H1, rows)
+        # (row stride padded off the power of two: all 32 rows of a fragment load would
+        # otherwise land on one cache set / memory channel)
+        ldT = rows + 16
+        ft = lambda n: torch.zeros(n, ldT, device=dev, dtype=torch.float32)[:, :rows]  # noqa: E731
+        ws.xnT = ft(D)
+        ws.h1aT, ws.h2aT, ws.dz3aT = ft(act.H1), ft(act.H2), ft(A)
+        ws.dz2aT, ws.dz1aT = ft(act.H2), ft(act.H1)
+        ws.h1cT, ws.h2cT, ws.dz3cT = ft(cri.H1), ft(cri.H2), ft(1)
+        ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
         ws.grads_a = torch.zeros_like(self.model.actor_flat)
         ws.grads_c = torch.zeros_like(self.model.critic_flat)
         ws.nblk_p = K.loss_blocks(rows)
