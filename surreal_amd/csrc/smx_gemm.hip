@@ -24,7 +24,7 @@ struct GemmProb {
     int ldct;
     int lda, ldb, ldc, M, N, K;
     int a_kc, b_kc, act;
-    int tiles_m, tiles_n, tile_base, a_vec, b_vec;
+    int tiles_m, tiles_n, tile_base, a_mode, b_mode;   // 0 kc-vec, 1 kc-scalar, 2 k-strided
     const int* stop;     // device flag: non-zero -> this problem is skipped
 };
 
@@ -37,27 +37,39 @@ struct GemmBatch {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// operand fragment for one 8-wide k group: lane (i, kh) holds X(row0+i, k0 + 4kh + r), r = 0..3
-__device__ __forceinline__ float4 load_frag(const float* __restrict__ X, int ld, int kc, int vec,
-                                            int row, int nrows, int k0, int K) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row >= nrows) return v;
-    if (kc) {
-        const float* p = X + (size_t)row * ld + k0;
-        if (vec && k0 + 3 < K) {
-            v = *reinterpret_cast<const float4*>(p);
-        } else {
-            if (k0 + 0 < K) v.x = p[0];
-            if (k0 + 1 < K) v.y = p[1];
-            if (k0 + 2 < K) v.z = p[2];
-            if (k0 + 3 < K) v.w = p[3];
-        }
+// Operand fragment for one 8-wide k group: lane (i, kh) holds X(row0+i, k0 + 4kh + r), r = 0..3.
+// Every load is UNCONDITIONAL (clamped address + select): a load guarded by a branch makes hipcc
+// wait for it at the join, which serialises the whole prefetch ring into one L2 round trip per
+// fragment.  MODE 0: K-contiguous, 16-byte load (ld % 4 == 0, K % 4 == 0, aligned base);
+// MODE 1: K-contiguous, four 4-byte loads; MODE 2: K-strided (X(r, k) = X[k*ld + r]).
+template <int MODE>
+__device__ __forceinline__ float4 load_frag(const float* __restrict__ X, int ld, int row, int nrows,
+                                            int k0, int K) {
+    const bool rv = row < nrows;
+    const int rc = rv ? row : 0;
+    float4 v;
+    if (MODE == 0) {
+        const bool ok = rv && (k0 < K);
+        v = *reinterpret_cast<const float4*>(X + (size_t)rc * ld + (ok ? k0 : 0));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (MODE == 1) {
+        const float* p = X + (size_t)rc * ld;
+        const int kl = K - 1;
+        const float x0 = p[min(k0 + 0, kl)], x1 = p[min(k0 + 1, kl)];
+        const float x2 = p[min(k0 + 2, kl)], x3 = p[min(k0 + 3, kl)];
+        v.x = (rv && k0 + 0 < K) ? x0 : 0.f;
+        v.y = (rv && k0 + 1 < K) ? x1 : 0.f;
+        v.z = (rv && k0 + 2 < K) ? x2 : 0.f;
+        v.w = (rv && k0 + 3 < K) ? x3 : 0.f;
     } else {
-        const float* p = X + (size_t)k0 * ld + row;
-        if (k0 + 0 < K) v.x = p[0];
-        if (k0 + 1 < K) v.y = p[(size_t)ld];
-        if (k0 + 2 < K) v.z = p[(size_t)2 * ld];
-        if (k0 + 3 < K) v.w = p[(size_t)3 * ld];
+        const float* p = X + rc;
+        const int kl = K - 1;
+        const float x0 = p[(size_t)min(k0 + 0, kl) * ld], x1 = p[(size_t)min(k0 + 1, kl) * ld];
+        const float x2 = p[(size_t)min(k0 + 2, kl) * ld], x3 = p[(size_t)min(k0 + 3, kl) * ld];
+        v.x = (rv && k0 + 0 < K) ? x0 : 0.f;
+        v.y = (rv && k0 + 1 < K) ? x1 : 0.f;
+        v.z = (rv && k0 + 2 < K) ? x2 : 0.f;
+        v.w = (rv && k0 + 3 < K) ? x3 : 0.f;
     }
     return v;
 }
@@ -73,11 +85,12 @@ struct Frag8 {
     float4 a[4], b[4];
 };
 
+template <int AM, int BM>
 __device__ __forceinline__ void load_sb(Frag8& f, const GemmProb& P, int m0, int n0, int i, int kb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        f.a[q] = load_frag(P.A, P.lda, P.a_kc, P.a_vec, m0 + i, P.M, kb + 8 * q, P.K);
-        f.b[q] = load_frag(P.B, P.ldb, P.b_kc, P.b_vec, n0 + i, P.N, kb + 8 * q, P.K);
+        f.a[q] = load_frag<AM>(P.A, P.lda, m0 + i, P.M, kb + 8 * q, P.K);
+        f.b[q] = load_frag<BM>(P.B, P.ldb, n0 + i, P.N, kb + 8 * q, P.K);
     }
 }
 
@@ -89,6 +102,29 @@ __device__ __forceinline__ void mma_sb(f32x16& acc, float& asum, const Frag8& f)
         acc = MFMA32(f.a[q].z, f.b[q].z, acc);
         acc = MFMA32(f.a[q].w, f.b[q].w, acc);
         asum += (f.a[q].x + f.a[q].y) + (f.a[q].z + f.a[q].w);
+    }
+}
+
+// K is cut into 32-wide super-blocks; wave wv owns sb = wv, wv+4, ...  Three register buffers form
+// a ring so that up to three super-blocks of operand loads (24 x 16 B per lane) are in flight
+// ahead of the MFMAs: these GEMMs are latency-bound, not bandwidth-bound.  Loads past K are
+// clamped and zeroed by select.
+template <int AM, int BM>
+__device__ __forceinline__ void mainloop(const GemmProb& P, int m0, int n0, int i, int kh, int wv,
+                                         f32x16& acc, float& asum) {
+    const int nsb = (P.K + 31) >> 5;
+    const int kofs = 4 * kh;
+    Frag8 f0, f1, f2;
+    load_sb<AM, BM>(f0, P, m0, n0, i, (wv + 0) * 32 + kofs);
+    load_sb<AM, BM>(f1, P, m0, n0, i, (wv + 4) * 32 + kofs);
+    load_sb<AM, BM>(f2, P, m0, n0, i, (wv + 8) * 32 + kofs);
+    for (int sb = wv; sb < nsb; sb += 12) {
+        mma_sb(acc, asum, f0);
+        load_sb<AM, BM>(f0, P, m0, n0, i, (sb + 12) * 32 + kofs);
+        mma_sb(acc, asum, f1);          // all-zero fragments past K: harmless
+        load_sb<AM, BM>(f1, P, m0, n0, i, (sb + 16) * 32 + kofs);
+        mma_sb(acc, asum, f2);
+        load_sb<AM, BM>(f2, P, m0, n0, i, (sb + 20) * 32 + kofs);
     }
 }
 
@@ -115,27 +151,16 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float asum = 0.f;
 
-    // K is cut into 32-wide super-blocks; wave wv owns sb = wv, wv+4, ...  Three register
-    // buffers form a ring so that up to three super-blocks of operand loads (24 x 16 B per lane)
-    // are in flight ahead of the MFMAs: these GEMMs are latency-bound, not bandwidth-bound.
-    // Loads past K are predicated off and return zeros.
-    const int nsb = (P.K + 31) >> 5;
-    const int kofs = 4 * kh;
-    Frag8 f0, f1, f2;
-    load_sb(f0, P, m0, n0, i, (wv + 0) * 32 + kofs);
-    load_sb(f1, P, m0, n0, i, (wv + 4) * 32 + kofs);
-    load_sb(f2, P, m0, n0, i, (wv + 8) * 32 + kofs);
-    for (int sb = wv; sb < nsb; sb += 12) {
-        mma_sb(acc, asum, f0);
-        if (sb + 12 < nsb) load_sb(f0, P, m0, n0, i, (sb + 12) * 32 + kofs);
-        if (sb + 4 < nsb) {
-            mma_sb(acc, asum, f1);
-            if (sb + 16 < nsb) load_sb(f1, P, m0, n0, i, (sb + 16) * 32 + kofs);
-        }
-        if (sb + 8 < nsb) {
-            mma_sb(acc, asum, f2);
-            if (sb + 20 < nsb) load_sb(f2, P, m0, n0, i, (sb + 20) * 32 + kofs);
-        }
+    switch (P.a_mode * 3 + P.b_mode) {   // workgroup-uniform
+        case 0: mainloop<0, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 1: mainloop<0, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 2: mainloop<0, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 3: mainloop<1, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 4: mainloop<1, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 5: mainloop<1, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 6: mainloop<2, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 7: mainloop<2, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
+        default: mainloop<2, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
     }
 
     // ---- combine the 4 K-partials through LDS (fixed order => deterministic) -------------
@@ -189,8 +214,8 @@ inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const floa
     P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
     P.a_kc = a_kc; P.b_kc = b_kc; P.act = act;
     P.tiles_m = (M + 31) / 32; P.tiles_n = (N + 31) / 32; P.tile_base = tile_base;
-    P.a_vec = a_kc && (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
-    P.b_vec = b_kc && (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    P.a_mode = !a_kc ? 2 : ((lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 0 : 1);
+    P.b_mode = !b_kc ? 2 : ((ldb % 4 == 0 && K % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 0 : 1);
 }
 
 inline int launch_batch(GemmBatch& G, hipStream_t st) {
