@@ -25,6 +25,7 @@ struct GemmProb {
     int lda, ldb, ldc, M, N, K;
     int a_kc, b_kc, act;
     int tiles_m, tiles_n, tile_base, a_mode, b_mode;   // 0 kc-vec, 1 kc-scalar, 2 k-strided
+    unsigned a_bytes, b_bytes;   // extent of each operand for the buffer descriptors (< 2 GiB)
     const int* stop;     // device flag: non-zero -> this problem is skipped
 };
 
@@ -38,38 +39,47 @@ struct GemmBatch {
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Operand fragment for one 8-wide k group: lane (i, kh) holds X(row0+i, k0 + 4kh + r), r = 0..3.
-// Every load is UNCONDITIONAL (clamped address + select): a load guarded by a branch makes hipcc
-// wait for it at the join, which serialises the whole prefetch ring into one L2 round trip per
-// fragment.  MODE 0: K-contiguous, 16-byte load (ld % 4 == 0, K % 4 == 0, aligned base);
+// Operands are read with BUFFER loads: the hardware bounds check returns 0 for an offset at or past
+// num_records, so rows >= nrows and k >= K are handled by pointing the lane's byte offset out of
+// range BEFORE the load.  Nothing touches the loaded registers until the MFMA that consumes them,
+// which lets hipcc leave the whole prefetch ring in flight (a select or a branch after the load
+// makes it wait for the data right there).
+// MODE 0: K-contiguous, one 16-byte load (ld % 4 == 0, K % 4 == 0, 16-byte aligned base);
 // MODE 1: K-contiguous, four 4-byte loads; MODE 2: K-strided (X(r, k) = X[k*ld + r]).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;   // extents are < 2 GiB (checked on the host)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    const uintptr_t u = (uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    void* q = (void*)(((uintptr_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// rowbase: byte offset of (row, k = 0), or OOB for a row past the matrix
 template <int MODE>
-__device__ __forceinline__ float4 load_frag(const float* __restrict__ X, int ld, int row, int nrows,
-                                            int k0, int K) {
-    const bool rv = row < nrows;
-    const int rc = rv ? row : 0;
+__device__ __forceinline__ unsigned row_base(int ld, int row, int nrows) {
+    if (row >= nrows) return OOB;
+    return MODE == 2 ? (unsigned)row * 4u : (unsigned)row * (unsigned)ld * 4u;
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 load_frag(rsrc_t R, unsigned rowbase, int ld, int k0, int K) {
     float4 v;
     if (MODE == 0) {
-        const bool ok = rv && (k0 < K);
-        v = *reinterpret_cast<const float4*>(X + (size_t)rc * ld + (ok ? k0 : 0));
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (MODE == 1) {
-        const float* p = X + (size_t)rc * ld;
-        const int kl = K - 1;
-        const float x0 = p[min(k0 + 0, kl)], x1 = p[min(k0 + 1, kl)];
-        const float x2 = p[min(k0 + 2, kl)], x3 = p[min(k0 + 3, kl)];
-        v.x = (rv && k0 + 0 < K) ? x0 : 0.f;
-        v.y = (rv && k0 + 1 < K) ? x1 : 0.f;
-        v.z = (rv && k0 + 2 < K) ? x2 : 0.f;
-        v.w = (rv && k0 + 3 < K) ? x3 : 0.f;
+        const unsigned off = (k0 < K) ? rowbase + (unsigned)k0 * 4u : OOB;
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(R, off, 0, 0);
+        v.x = __uint_as_float(w.x); v.y = __uint_as_float(w.y);
+        v.z = __uint_as_float(w.z); v.w = __uint_as_float(w.w);
     } else {
-        const float* p = X + rc;
-        const int kl = K - 1;
-        const float x0 = p[(size_t)min(k0 + 0, kl) * ld], x1 = p[(size_t)min(k0 + 1, kl) * ld];
-        const float x2 = p[(size_t)min(k0 + 2, kl) * ld], x3 = p[(size_t)min(k0 + 3, kl) * ld];
-        v.x = (rv && k0 + 0 < K) ? x0 : 0.f;
-        v.y = (rv && k0 + 1 < K) ? x1 : 0.f;
-        v.z = (rv && k0 + 2 < K) ? x2 : 0.f;
-        v.w = (rv && k0 + 3 < K) ? x3 : 0.f;
+        const unsigned step = MODE == 1 ? 4u : (unsigned)ld * 4u;
+        const unsigned o0 = rowbase + (unsigned)k0 * step;
+        v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R, (k0 + 0 < K) ? o0 : OOB, 0, 0));
+        v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R, (k0 + 1 < K) ? o0 + step : OOB, 0, 0));
+        v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R, (k0 + 2 < K) ? o0 + 2 * step : OOB, 0, 0));
+        v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R, (k0 + 3 < K) ? o0 + 3 * step : OOB, 0, 0));
     }
     return v;
 }
@@ -80,17 +90,23 @@ __device__ __forceinline__ float act_f(float v, int act) {
     return v;
 }
 
-// load the 8 operand fragments (4 k-groups x {A, B}) of one 32-wide K super-block
+// the 8 operand fragments (4 k-groups x {A, B}) of one 32-wide K super-block
 struct Frag8 {
     float4 a[4], b[4];
 };
 
+struct Operands {
+    rsrc_t ra, rb;
+    unsigned abase, bbase;
+    int lda, ldb, K;
+};
+
 template <int AM, int BM>
-__device__ __forceinline__ void load_sb(Frag8& f, const GemmProb& P, int m0, int n0, int i, int kb) {
+__device__ __forceinline__ void load_sb(Frag8& f, const Operands& O, int kb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        f.a[q] = load_frag<AM>(P.A, P.lda, m0 + i, P.M, kb + 8 * q, P.K);
-        f.b[q] = load_frag<BM>(P.B, P.ldb, n0 + i, P.N, kb + 8 * q, P.K);
+        f.a[q] = load_frag<AM>(O.ra, O.abase, O.lda, kb + 8 * q, O.K);
+        f.b[q] = load_frag<BM>(O.rb, O.bbase, O.ldb, kb + 8 * q, O.K);
     }
 }
 
@@ -108,23 +124,39 @@ __device__ __forceinline__ void mma_sb(f32x16& acc, float& asum, const Frag8& f)
 // K is cut into 32-wide super-blocks; wave wv owns sb = wv, wv+4, ...  Three register buffers form
 // a ring so that up to three super-blocks of operand loads (24 x 16 B per lane) are in flight
 // ahead of the MFMAs: these GEMMs are latency-bound, not bandwidth-bound.  Loads past K are
-// clamped and zeroed by select.
+// out-of-range buffer loads (no memory traffic); MFMAs past K are skipped (wave-uniform).
 template <int AM, int BM>
 __device__ __forceinline__ void mainloop(const GemmProb& P, int m0, int n0, int i, int kh, int wv,
                                          f32x16& acc, float& asum) {
     const int nsb = (P.K + 31) >> 5;
     const int kofs = 4 * kh;
+    Operands O;
+    O.ra = make_rsrc(P.A, P.a_bytes);
+    O.rb = make_rsrc(P.B, P.b_bytes);
+    O.abase = row_base<AM>(P.lda, m0 + i, P.M);
+    O.bbase = row_base<BM>(P.ldb, n0 + i, P.N);
+    O.lda = P.lda; O.ldb = P.ldb; O.K = P.K;
     Frag8 f0, f1, f2;
-    load_sb<AM, BM>(f0, P, m0, n0, i, (wv + 0) * 32 + kofs);
-    load_sb<AM, BM>(f1, P, m0, n0, i, (wv + 4) * 32 + kofs);
-    load_sb<AM, BM>(f2, P, m0, n0, i, (wv + 8) * 32 + kofs);
+    // the barriers pin the issue order f0, f1, f2 (vmcnt is in-order: the wait for f0 must not
+    // cover f1 / f2)
+    load_sb<AM, BM>(f0, O, (wv + 0) * 32 + kofs);
+    __builtin_amdgcn_sched_barrier(0);
+    load_sb<AM, BM>(f1, O, (wv + 4) * 32 + kofs);
+    __builtin_amdgcn_sched_barrier(0);
+    load_sb<AM, BM>(f2, O, (wv + 8) * 32 + kofs);
     for (int sb = wv; sb < nsb; sb += 12) {
+        __builtin_amdgcn_sched_barrier(0);
         mma_sb(acc, asum, f0);
-        load_sb<AM, BM>(f0, P, m0, n0, i, (sb + 12) * 32 + kofs);
-        mma_sb(acc, asum, f1);          // all-zero fragments past K: harmless
-        load_sb<AM, BM>(f1, P, m0, n0, i, (sb + 16) * 32 + kofs);
-        mma_sb(acc, asum, f2);
-        load_sb<AM, BM>(f2, P, m0, n0, i, (sb + 20) * 32 + kofs);
+        __builtin_amdgcn_sched_barrier(0);
+        load_sb<AM, BM>(f0, O, (sb + 12) * 32 + kofs);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sb + 4 < nsb) mma_sb(acc, asum, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_sb<AM, BM>(f1, O, (sb + 16) * 32 + kofs);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sb + 8 < nsb) mma_sb(acc, asum, f2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_sb<AM, BM>(f2, O, (sb + 20) * 32 + kofs);
     }
 }
 
@@ -143,7 +175,8 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and provably so
     const int i = lane & 31, kh = lane >> 5;
 
     f32x16 acc;
@@ -204,6 +237,11 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
     }
 }
 
+inline unsigned long long operand_bytes(int ld, int kc, int nrows, int K) {
+    return kc ? 4ull * ((unsigned long long)(nrows - 1) * ld + K)
+              : 4ull * ((unsigned long long)(K - 1) * ld + nrows);
+}
+
 inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const float* B, int ldb,
                       int b_kc, const float* bias, const float* mask, float* C, int ldc, int M,
                       int N, int K, int act, float* dbias, float* sumsq, int tile_base,
@@ -216,9 +254,19 @@ inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const floa
     P.tiles_m = (M + 31) / 32; P.tiles_n = (N + 31) / 32; P.tile_base = tile_base;
     P.a_mode = !a_kc ? 2 : ((lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 0 : 1);
     P.b_mode = !b_kc ? 2 : ((ldb % 4 == 0 && K % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 0 : 1);
+    P.a_bytes = (unsigned)operand_bytes(lda, a_kc, M, K);
+    P.b_bytes = (unsigned)operand_bytes(ldb, b_kc, N, K);
+}
+
+// every operand must fit a 31-bit byte offset (buffer descriptor addressing)
+inline bool prob_ok(const GemmProb& P) {
+    return operand_bytes(P.lda, P.a_kc, P.M, P.K) < (1ull << 31) &&
+           operand_bytes(P.ldb, P.b_kc, P.N, P.K) < (1ull << 31);
 }
 
 inline int launch_batch(GemmBatch& G, hipStream_t st) {
+    for (int k = 0; k < G.n; ++k)
+        if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
     const GemmProb& L = G.p[G.n - 1];
     const int blocks = L.tile_base + L.tiles_m * L.tiles_n;
     hipLaunchKernelGGL(gemm32_kernel, dim3(blocks), dim3(256), 0, st, G);
