@@ -160,7 +160,10 @@ __device__ __forceinline__ void mainloop(const GemmProb& P, int m0, int n0, int 
     }
 }
 
-__global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
+// ALL_VEC: every problem of the batch is mode (0, 0) -- the host picks this instantiation, which
+// fits 3 workgroups per CU (<= 168 VGPRs); the general one carries the scalar-load variants.
+template <bool ALL_VEC>
+__global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch G) {
     __shared__ float red[4][32 * 33];
     __shared__ float dbr[8][32];
     __shared__ float sred[16];
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmBatch G) {
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float asum = 0.f;
 
-    switch (P.a_mode * 3 + P.b_mode) {   // workgroup-uniform
+    if (ALL_VEC) mainloop<0, 0>(P, m0, n0, i, kh, wv, acc, asum);
+    else switch (P.a_mode * 3 + P.b_mode) {   // workgroup-uniform
         case 0: mainloop<0, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
         case 1: mainloop<0, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
         case 2: mainloop<0, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
@@ -269,7 +273,10 @@ inline int launch_batch(GemmBatch& G, hipStream_t st) {
         if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
     const GemmProb& L = G.p[G.n - 1];
     const int blocks = L.tile_base + L.tiles_m * L.tiles_n;
-    hipLaunchKernelGGL(gemm32_kernel, dim3(blocks), dim3(256), 0, st, G);
+    bool all_vec = true;
+    for (int k = 0; k < G.n; ++k) all_vec = all_vec && G.p[k].a_mode == 0 && G.p[k].b_mode == 0;
+    if (all_vec) hipLaunchKernelGGL(gemm32_kernel<true>, dim3(blocks), dim3(256), 0, st, G);
+    else hipLaunchKernelGGL(gemm32_kernel<false>, dim3(blocks), dim3(256), 0, st, G);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SMX_OK : (int)e;
 }
