@@ -350,6 +350,40 @@ int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
                        const float* actions, int32_t ld_act, int32_t A, const float* q_actor,
                        int64_t rows, float* stats, smx_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LSTM stem (surreal/model/ppo_net.py:143-152: nn.LSTM(in, rnn_hidden, 1, batch_first=True) in
+ * front of the actor / critic MLPs; forward at :277-279, :307-309, single step at :338-349).
+ * torch.nn.LSTM layouts: W_ih [4H, D], W_hh [4H, H], b_ih [4H], b_hh [4H], gate order i, f, g, o.
+ * H must be a multiple of 4 and <= 384; B*T*4H < 2^31.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct smx_lstm {
+    const float* W_ih;
+    const float* W_hh;
+    const float* b_ih;
+    const float* b_hh;
+    int32_t D, H;
+} smx_lstm_t;
+
+/* number of parameters, laid out [W_ih | W_hh | b_ih | b_hh] (also the layout of `grads` below) */
+int64_t smx_lstm_param_count(int32_t D, int32_t H);
+
+/* out[b, t, :] = h_t for x [B, T, D] starting from (h0, c0) [B, H] (NULL = zeros).  Saved for
+ * the backward pass: gates [B, T, 4H] (activated i, f, g, o), cs [B, T, H] (c_t), hprev
+ * [B, T, H] (h_{t-1}, may be NULL for inference).  hN / cN [B, H] (optional) receive the final
+ * state (forward_actor_expose_cells).  A non-zero *stop_flag skips the whole call. */
+int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64_t B, int32_t T,
+                         const float* h0, const float* c0, float* gates, float* out, float* cs,
+                         float* hprev, float* hN, float* cN, const int32_t* stop_flag,
+                         smx_stream_t stream);
+
+/* Back-propagation through time given dout [B, T, H] = dLoss/dh_t from the layers above
+ * (h0, c0 are constants: ppo.py:511-515 detaches them).  dgates [B, T, 4H] is workspace (it may
+ * alias `gates`).  grads receives dW_ih, dW_hh, db_ih, db_hh (overwritten, not accumulated). */
+int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int64_t B, int32_t T,
+                          const float* c0, const float* gates, const float* cs,
+                          const float* hprev, const float* dout, float* dgates, float* grads,
+                          const int32_t* stop_flag, smx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,12 @@ class Mlp3Job(Structure):
                 ('dz2T', c_void_p), ('dz1T', c_void_p), ('ldT', c_int64)]
 
 
+class Lstm(Structure):
+    """smx_lstm_t"""
+    _fields_ = [('W_ih', c_void_p), ('W_hh', c_void_p), ('b_ih', c_void_p), ('b_hh', c_void_p),
+                ('D', c_int32), ('H', c_int32)]
+
+
 # smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
 CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
@@ -97,6 +103,11 @@ _SIGS = {
                                     _P]),
     'smx_soft_update_f32': (c_int32, [_P, _P, c_float, c_int64, _P]),
     'smx_ddpg_stats_f32': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int64, _P, _P]),
+    'smx_lstm_param_count': (c_int64, [c_int32, c_int32]),
+    'smx_lstm_forward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, _P, _P]),
+    'smx_lstm_backward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,
+                                        _P, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

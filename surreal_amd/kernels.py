@@ -241,6 +241,20 @@ class HipKernels(object):
                _row_stride(actions, A), A, L.ptr(q_actor), rows, L.ptr(stats), self._st())
 
 
+    # ---- LSTM stem ----------------------------------------------------------------------------
+    def lstm_forward(self, net, x, B, T, h0, c0, gates, out, cs, hprev=None, hN=None, cN=None,
+                     stop=None):
+        """net: model.ppo_net.LstmParams; x [B*T, D] contiguous; see smx_lstm_forward_f32"""
+        L.call('smx_lstm_forward_f32', ctypes.byref(net.desc), L.ptr(x), B, T, L.ptr(h0), L.ptr(c0),
+               L.ptr(gates), L.ptr(out), L.ptr(cs), L.ptr(hprev), L.ptr(hN), L.ptr(cN), L.ptr(stop),
+               self._st())
+
+    def lstm_backward(self, net, x, B, T, c0, gates, cs, hprev, dout, dgates, grads, stop=None):
+        L.call('smx_lstm_backward_f32', ctypes.byref(net.desc), L.ptr(x), B, T, L.ptr(c0),
+               L.ptr(gates), L.ptr(cs), L.ptr(hprev), L.ptr(dout), L.ptr(dgates), L.ptr(grads),
+               L.ptr(stop), self._st())
+
+
 # ------------------------------------------------------------------------------------------
 # process-wide default.  The product default is HipKernels on 'cuda' and nothing in
 # surreal_amd/ ever installs anything else; tests/ install a CPU test double to exercise
