@@ -25,8 +25,8 @@ What is different is how one ``learn()`` runs (SURVEY.md section 3.1 lists the r
     single reference learner would have seen whole: advantage moments, loss partial sums,
     gradients, value moments, z-filter sums.
 
-Round-1 scope: MLP policy on low-dimensional observations (``rnn.if_rnn_policy = False``,
-``pixel_input = False``); the LSTM / CNN stems raise NotImplementedError.
+Scope: low-dimensional observations, MLP policy or LSTM-stem policy (``rnn.if_rnn_policy``,
+the reference default); the CNN stem (``pixel_input``) raises NotImplementedError.
 """
 import types
 
@@ -215,7 +215,8 @@ class PPOLearner(Learner):
         ws = types.SimpleNamespace()
         ws.key = key
         act, cri = self.model.actor, self.model.critic
-        E = 1
+        rnn = self.if_rnn_policy
+        E = N - self.horizon + 1 if rnn else 1           # ppo.py:398-400, 521-537
         ws.E = E
         Ep, Ev = self.epoch_policy, self.epoch_baseline
         # scalars block: ctrl | policy stats | value stats | moments
@@ -235,7 +236,7 @@ class PPOLearner(Learner):
                 self._ws.ctrl_i[L.C_STEP_ACTOR:L.C_STEP_CRITIC + 1])
         self._ctrl_host = None
         # critic pass + GAE
-        ws.packed = f(K.mlp3_packed_numel(cri))
+        ws.packed = None if rnn else f(K.mlp3_packed_numel(cri))
         ws.vals = f(B * (N + 1))
         # fused-kernel tail split (see _enqueue_gae): rounds of 128-row workgroups over the CUs
         n_cu = 256
@@ -243,7 +244,7 @@ class PPOLearner(Learner):
             n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
         rounds = lambda rows: -(-(-(-rows // 128)) // n_cu)  # noqa: E731
         ws.split_tail = bool(self.session_config.learner.get('split_critic_tail', True)) and \
-            rounds(B * (N + 1)) > rounds(B * N)
+            rounds(B * (N + 1)) > rounds(B * N) and not rnn
         ws.xnext = f(B, D)
         ws.adv = f(B * E)
         ws.ret = f(B * E)
@@ -263,16 +264,29 @@ class PPOLearner(Learner):
         ws.g_surr, ws.g_kl, ws.dz3a = f(rows, A), f(rows, A), f(rows, A)
         ws.dz2a, ws.dz1a = f(rows, act.H2), f(rows, act.H1)
         ws.dz3c, ws.dz2c, ws.dz1c = f(rows), f(rows, cri.H2), f(rows, cri.H1)
-        # transposed copies [features, rows] feeding the weight-gradient GEMMs (K-contiguous)
-        # (row stride padded off the power of two: all 32 rows of a fragment load would
-        # otherwise land on one cache set / memory channel)
-        ldT = rows + 16
-        ft = lambda n: torch.zeros(n, ldT, device=dev, dtype=torch.float32)[:, :rows]  # noqa: E731
-        ws.xnT = ft(D)
-        ws.h1aT, ws.h2aT, ws.dz3aT = ft(act.H1), ft(act.H2), ft(A)
-        ws.dz2aT, ws.dz1aT = ft(act.H2), ft(act.H1)
-        ws.h1cT, ws.h2cT, ws.dz3cT = ft(cri.H1), ft(cri.H2), ft(1)
-        ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
+        if rnn:
+            # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E) ...
+            F = self.model.rnn_hidden
+            ws.h0, ws.c0 = f(B, F), f(B, F)
+            ws.xit = f(B, E, D)                       # obs[:, :E] (raw: also feeds z_update)
+            ws.act_it, ws.beh_it = f(rows, A), f(rows, 2 * A)
+            ws.gates, ws.lo, ws.cs, ws.hp, ws.dlo = f(rows, 4 * F), f(rows, F), f(rows, F), f(rows, F), f(rows, F)
+            # ... and for the critic pass over cat(obs, obs_next) (T = N + 1, ppo.py:376-386)
+            R1 = B * (N + 1)
+            ws.xcat = f(B, N + 1, D)
+            ws.gatesG, ws.loG, ws.csG = f(R1, 4 * F), f(R1, F), f(R1, F)
+            ws.h1G, ws.h2G = f(R1, cri.H1), f(R1, cri.H2)
+        else:
+            # transposed copies [features, rows] feeding the weight-gradient GEMMs (K-contiguous)
+            # (row stride padded off the power of two: all 32 rows of a fragment load would
+            # otherwise land on one cache set / memory channel)
+            ldT = rows + 16
+            ft = lambda n: torch.zeros(n, ldT, device=dev, dtype=torch.float32)[:, :rows]  # noqa: E731
+            ws.xnT = ft(D)
+            ws.h1aT, ws.h2aT, ws.dz3aT = ft(act.H1), ft(act.H2), ft(A)
+            ws.dz2aT, ws.dz1aT = ft(act.H2), ft(act.H1)
+            ws.h1cT, ws.h2cT, ws.dz3cT = ft(cri.H1), ft(cri.H2), ft(1)
+            ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
         ws.grads_a = torch.zeros_like(self.model.actor_flat)
         ws.grads_c = torch.zeros_like(self.model.critic_flat)
         ws.nblk_p = K.loss_blocks(rows)
@@ -485,6 +499,8 @@ class PPOLearner(Learner):
 
     def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds):
         """the whole of _optimize (ppo.py:487-586) as a launch sequence"""
+        if self.if_rnn_policy:
+            return self._enqueue_optimize_rnn(ws, obs, obs_next, actions, rewards, dones, pds)
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
@@ -551,6 +567,148 @@ class PPOLearner(Learner):
                 K.zfilter_update(obs0, m.z_filter.running_sum, m.z_filter.running_sumsq,
                                  m.z_filter.count, B)
 
+    # ======================================================================================
+    # LSTM policy (algo.rnn.if_rnn_policy, the reference default): the stem is shared by the
+    # actor and the critic and belongs to BOTH optimiser groups (ppo_net.py:202-224), so the
+    # value epochs see the stem the policy epochs left behind -- the two loops run one after
+    # the other exactly as ppo.py:541-562 does (no lock-step sharing here).
+    # ======================================================================================
+    def _enqueue_gae_rnn(self, ws, obs, obs_next, rewards, dones):
+        """critic over the whole (B, N+1) sequence from the stored cells + windowed GAE with
+        horizon H (ppo.py:376-418, RNN branch)"""
+        K, m = self.K, self.model
+        B, N, D = obs.shape
+        ws.xcat[:, :N].copy_(obs)                       # torch.cat([obs, obs_next], 1)
+        ws.xcat[:, N:].copy_(obs_next)
+        x2 = ws.xcat.view(B * (N + 1), D)
+        if self.use_z_filter:
+            zm, zs = m.z_filter.refresh_stats()
+            K.zfilter_forward(x2, zm, zs, x2)
+        K.lstm_forward(m.rnn, x2, B, N + 1, ws.h0, ws.c0, ws.gatesG, ws.loG, ws.csG)
+        K.mlp3_forward(m.critic, ws.loG, ws.h1G, ws.h2G, ws.vals.view(-1, 1), L.SMX_ACT_NONE)
+        H = self.horizon
+        K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** H, B, N, H,
+              ws.adv, ws.ret)
+        if self.norm_adv:
+            K.moments(ws.adv, ws.adv_mom)
+            if self.world_size > 1:
+                self._dist.all_gather_into_tensor(ws.mom_parts.view(-1), ws.adv_mom.clone())
+                K.moments_merge(ws.mom_parts, ws.adv_mom)
+            K.adv_normalize(ws.adv, ws.adv_mom, 1e-4)
+
+    def _rnn_policy_forward(self, ws, e):
+        K, m = self.K, self.model
+        B, E, A, W = ws.key[0], ws.E, self.action_dim, self.world_size
+        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
+        K.lstm_forward(m.rnn, ws.xn, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs, ws.hp, stop=ws.stop)
+        K.mlp3_forward(m.actor, ws.lo, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
+        K.policy_loss(mode, ws.mean, m.log_var.view(-1), ws.act_it, ws.beh_it, ws.ref_pol, ws.adv,
+                      ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
+        part, nblk = ws.ppart, ws.nblk_p
+        if W > 1:
+            torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
+            self._dist.all_reduce(ws.ppart_sum)
+            part, nblk = ws.ppart_sum, 1
+        K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1), ws.rows * W,
+                          ws.ctrl_f, e > 0, e < self.epoch_policy, ws.dz3a,
+                          ws.grads_a[m.actor.numel:m.actor.numel + A],
+                          ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
+
+    def _rnn_backward(self, ws, net, h1, h2, dz3, dz2, dz1, g_mlp, g_rnn, stop):
+        """MLP backward, its input gradient, BPTT through the stem"""
+        K, m = self.K, self.model
+        B, E, F = ws.key[0], ws.E, m.rnn_hidden
+        K.mlp3_backward(net, ws.lo, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
+        # d loss / d (LSTM output) = dz1 . W1
+        K.linear(dz1, 1, net.views['W1'], 0, None, ws.dlo, ws.rows, F, net.H1, stop=stop)
+        K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates, g_rnn,
+                        stop)
+
+    def _rnn_policy_update(self, ws, e):
+        K, m = self.K, self.model
+        A = self.action_dim
+        n_mlp, n0 = m.actor.numel, m.actor_flat.numel() - m.n_rnn
+        self._rnn_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a,
+                           ws.grads_a[:n_mlp], ws.grads_a[n0:], ws.stop)
+        if self.world_size > 1:      # log_var's gradient is global already (all-reduced partials)
+            self._dist.all_reduce(ws.grads_a[:n_mlp])
+            self._dist.all_reduce(ws.grads_a[n0:])
+        K.sumsq_partials(ws.grads_a, ws.sumsq_a)
+        K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                    ws.sumsq_a, K.sumsq_blocks(ws.grads_a.numel()), ws.ctrl_f, 0, True,
+                    ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
+
+    def _rnn_value_epoch(self, ws, e):
+        K, m = self.K, self.model
+        B, E = ws.key[0], ws.E
+        K.lstm_forward(m.rnn, ws.xn, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs, ws.hp)
+        K.mlp3_forward(m.critic, ws.lo, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
+        n_total = ws.rows * self.world_size
+        if self.world_size > 1:
+            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
+            self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
+        else:
+            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
+        self._rnn_backward(ws, m.critic, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
+                           ws.grads_c[m.n_rnn:], ws.grads_c[:m.n_rnn], None)
+        if self.world_size > 1:
+            self._dist.all_reduce(ws.grads_c)
+        K.sumsq_partials(ws.grads_c, ws.sumsq_c)
+        K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                    ws.sumsq_c, K.sumsq_blocks(ws.grads_c.numel()), ws.ctrl_f, 1, False,
+                    ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
+
+    def _enqueue_optimize_rnn(self, ws, obs, obs_next, actions, rewards, dones, pds):
+        """_optimize with the LSTM stem (ppo.py:487-586, `if self.if_rnn_policy` branches)"""
+        K, m, ref = self.K, self.model, self.ref_target_model
+        B, N, D = obs.shape
+        A, E = self.action_dim, ws.E
+        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
+        ws.pstats.zero_()
+        self._enqueue_gae_rnn(ws, obs, obs_next, rewards, dones)
+
+        ws.xit.copy_(obs[:, :E])                         # ppo.py:521-537
+        ws.act_it.view(B, E, A).copy_(actions[:, :E])
+        ws.beh_it.view(B, E, 2 * A).copy_(pds[:, :E])
+        x2 = ws.xit.view(B * E, D)
+        if self.use_z_filter:
+            zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed in _enqueue_gae_rnn
+            K.zfilter_forward(x2, zm, zs, ws.xn)
+            rzm, rzs = ref.z_filter.refresh_stats()
+            K.zfilter_forward(x2, rzm, rzs, ws.xr)
+        else:
+            ws.xn.copy_(x2)
+            ws.xr.copy_(x2)
+        # ref_pol = ref_target_model.forward_actor(obs_iter, cells)   (ppo.py:539)
+        K.lstm_forward(ref.rnn, ws.xr, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs)
+        K.mlp3_forward(ref.actor, ws.lo, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
+        ws.ref_pol[:, :A].copy_(ws.ref_mean)
+        ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
+
+        self._rnn_policy_forward(ws, 0)
+        for e in range(self.epoch_policy):
+            self._rnn_policy_update(ws, e)
+            self._rnn_policy_forward(ws, e + 1)
+        for e in range(self.epoch_baseline):
+            self._rnn_value_epoch(ws, e)
+        K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+
+        K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
+        if self.world_size > 1:
+            self._dist.all_gather_into_tensor(ws.mom_parts.view(-1), ws.ret_mom.clone())
+            K.moments_merge(ws.mom_parts, ws.ret_mom)
+        if self.use_z_filter:                   # model.z_update(obs_iter)  (ppo.py:578-579)
+            if self.world_size > 1:
+                ws.zdelta.zero_()
+                K.zfilter_update(x2, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], B * E)
+                self._dist.all_reduce(ws.zdelta)
+                m.z_filter.running_sum += ws.zdelta[:D]
+                m.z_filter.running_sumsq += ws.zdelta[D:2 * D]
+                m.z_filter.count += ws.zdelta[2 * D:]
+            else:
+                K.zfilter_update(x2, m.z_filter.running_sum, m.z_filter.running_sumsq,
+                                 m.z_filter.count, B * E)
+
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream()
@@ -560,8 +718,6 @@ class PPOLearner(Learner):
     # _optimize / learn  (ppo.py:487-613)
     # ======================================================================================
     def _optimize(self, obs, actions, rewards, obs_next, persistent_infos, onetime_infos, dones):
-        if self.if_rnn_policy:
-            raise NotImplementedError('LSTM policy not built yet')
         x = self._flat_obs(obs)
         xn = self._flat_obs(obs_next)
         pds = persistent_infos[-1].contiguous()
@@ -572,6 +728,11 @@ class PPOLearner(Learner):
         ws = self._workspace(B, N, D, self.action_dim)
         self._ensure_ctrl(ws)
         args = (x, xn, actions, rewards, dones, pds)
+        if self.if_rnn_policy:
+            # agent-side LSTM state at the head of every sub-trajectory (ppo.py:511-515):
+            # (B, layers=1, H) -> the kernels' [B, H]
+            ws.h0.copy_(onetime_infos[0].reshape(B, -1))
+            ws.c0.copy_(onetime_infos[1].reshape(B, -1))
         if self.use_graph:
             key = tuple(t.data_ptr() for t in args)
             g = self._graphs.get(key)
@@ -685,7 +846,14 @@ class PPOLearner(Learner):
         B, N, D = x.shape
         ws = self._workspace(B, N, D, self.action_dim)
         self._ensure_ctrl(ws)
-        self._enqueue_gae(ws, x, xn, rewards.contiguous(), dones.contiguous())
+        if self.if_rnn_policy:
+            if self.cells is None:
+                ws.h0.zero_(); ws.c0.zero_()
+            else:
+                ws.h0.copy_(self.cells[0].reshape(B, -1)); ws.c0.copy_(self.cells[1].reshape(B, -1))
+            self._enqueue_gae_rnn(ws, x, xn, rewards.contiguous(), dones.contiguous())
+        else:
+            self._enqueue_gae(ws, x, xn, rewards.contiguous(), dones.contiguous())
         return ws.adv.view(B, -1).clone(), ws.ret.view(B, -1).clone()
 
     # ======================================================================================

@@ -125,11 +125,38 @@ class Mlp3Params(object):
         return H1 * D + H1 + H2 * H1 + H2 + OUT * H2 + OUT
 
 
+class LstmParams(object):
+    """views of torch.nn.LSTM's parameters (1 layer) inside a flat buffer + smx_lstm_t"""
+
+    NAMES = ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')
+
+    def __init__(self, flat, offset, D, H):
+        self.D, self.H = D, H
+        sizes = [('weight_ih', (4 * H, D)), ('weight_hh', (4 * H, H)), ('bias_ih', (4 * H,)),
+                 ('bias_hh', (4 * H,))]
+        self.views = collections.OrderedDict()
+        o = offset
+        for name, shp in sizes:
+            n = int(np.prod(shp))
+            self.views[name] = flat[o:o + n].view(*shp)
+            o += n
+        self.numel = o - offset
+        self.offset = offset
+        self.desc = L.Lstm(*(ctypes.c_void_p(self.views[k].data_ptr()) for k in self.NAMES), D, H)
+
+    @staticmethod
+    def count(D, H):
+        return 4 * H * D + 4 * H * H + 8 * H
+
+
 class PPOModel(object):
     """
-    Actor + critic + z-filter with the reference constructor signature (ppo_net.py:110-118).
-    Round-1 scope: low-dimensional observations, MLP policy (if_rnn_policy False,
-    if_pixel_input False); the LSTM / CNN stems raise NotImplementedError.
+    Actor + critic + z-filter (+ LSTM stem) with the reference constructor signature
+    (ppo_net.py:110-118).  All parameters live in ONE flat buffer laid out
+    ``[actor MLP | log_var | LSTM | critic MLP]`` so that the two optimiser groups of the
+    reference -- actor + shared stem, critic + shared stem (ppo_net.py:202-224) -- are the
+    contiguous slices ``actor_flat`` and ``critic_flat``.  The CNN stem (pixel observations)
+    raises NotImplementedError.
     """
 
     def __init__(self, obs_spec, action_dim, model_config, use_cuda=True, init_log_sig=0,
@@ -139,9 +166,9 @@ class PPOModel(object):
         device = device or KN.default_device()
         if if_pixel_input:
             raise NotImplementedError('pixel (CNN stem) observations are not built yet')
-        if rnn_config is not None and rnn_config.get('if_rnn_policy', False):
-            raise NotImplementedError('LSTM stem (if_rnn_policy=True) is not built yet; set '
-                                      'learner_config.algo.rnn.if_rnn_policy = False')
+        self.if_rnn = bool(rnn_config is not None and rnn_config.get('if_rnn_policy', False))
+        if self.if_rnn and int(rnn_config.get('rnn_layer', 1)) != 1:
+            raise NotImplementedError('only rnn_layer = 1 (the reference default) is built')
         self.obs_spec = obs_spec
         self.action_dim = action_dim
         self.model_config = model_config
@@ -156,13 +183,21 @@ class PPOModel(object):
                 self.low_dim += obs_spec['low_dim'][key][0]
         D, A = self.low_dim, action_dim
         ah, ch = model_config['actor_fc_hidden_sizes'], model_config['critic_fc_hidden_sizes']
-        n_actor = Mlp3Params.count(D, ah[0], ah[1], A) + A
-        n_critic = Mlp3Params.count(D, ch[0], ch[1], 1)
-        self.actor_flat = torch.empty(n_actor, device=device)
-        self.critic_flat = torch.empty(n_critic, device=device)
-        self.actor = Mlp3Params(self.actor_flat, 0, D, ah[0], ah[1], A)
-        self.critic = Mlp3Params(self.critic_flat, 0, D, ch[0], ch[1], 1)
-        self.log_var = self.actor_flat[self.actor.numel:self.actor.numel + A].view(1, A)
+        self.rnn_hidden = int(rnn_config.rnn_hidden) if self.if_rnn else 0
+        F = self.rnn_hidden if self.if_rnn else D        # input width of the MLPs (ppo_net.py:155-156)
+        # the actor block is padded to a 16-byte boundary (the pad has zero gradient, so Adam
+        # leaves it alone): the GEMM kernels take 16-byte operand loads only from aligned bases
+        n_actor = (Mlp3Params.count(F, ah[0], ah[1], A) + A + 3) & ~3
+        n_rnn = LstmParams.count(D, self.rnn_hidden) if self.if_rnn else 0
+        n_critic = Mlp3Params.count(F, ch[0], ch[1], 1)
+        self.flat = torch.zeros(n_actor + n_rnn + n_critic, device=device)
+        self.n_rnn = n_rnn
+        self.actor_flat = self.flat[:n_actor + n_rnn]     # optimiser group: actor (+ shared stem)
+        self.critic_flat = self.flat[n_actor:]            # optimiser group: (shared stem +) critic
+        self.actor = Mlp3Params(self.flat, 0, F, ah[0], ah[1], A)
+        self.rnn = LstmParams(self.flat, n_actor, D, self.rnn_hidden) if self.if_rnn else None
+        self.critic = Mlp3Params(self.flat, n_actor + n_rnn, F, ch[0], ch[1], 1)
+        self.log_var = self.flat[self.actor.numel:self.actor.numel + A].view(1, A)
         self._init_parameters()
         if use_z_filter:
             assert self.low_dim > 0, 'No low dimensional input, please turn off z-filter'
@@ -176,6 +211,10 @@ class PPOModel(object):
                 fan_in = net.views['W' + name[1]].shape[1]
                 v.uniform_(-1.0 / np.sqrt(fan_in), 1.0 / np.sqrt(fan_in))
         self.log_var.fill_(float(self.init_log_sig))
+        if self.if_rnn:                          # torch.nn.LSTM default: U(-1/sqrt(H), 1/sqrt(H))
+            b = 1.0 / np.sqrt(self.rnn_hidden)
+            for v in self.rnn.views.values():
+                v.uniform_(-b, b)
 
     # ---- canonical parameter dict (names shared with the oracle / synthetic generator) ----
     def named_parameters(self):
@@ -186,6 +225,9 @@ class PPOModel(object):
                 out['%s.fc%d.b' % (pre, i)] = net.views['b%d' % i]
             if pre == 'actor':
                 out['actor.log_var'] = self.log_var
+        if self.if_rnn:
+            for k, v in self.rnn.views.items():
+                out['rnn.' + k] = v
         return out
 
     def load_params(self, params):
@@ -223,8 +265,7 @@ class PPOModel(object):
         return [self.critic_flat]
 
     def update_target_params(self, net):         # ppo_net.py:226-242
-        self.actor_flat.copy_(net.actor_flat)
-        self.critic_flat.copy_(net.critic_flat)
+        self.flat.copy_(net.flat)
         if self.use_z_filter:
             self.z_filter.load_state_dict(net.z_filter.state_dict())
 
@@ -248,10 +289,36 @@ class PPOModel(object):
         self.K.mlp3_forward(net, x2, h1, h2, out, out_act)
         return out, shape
 
-    def forward_actor(self, obs, cells=None):    # ppo_net.py:253-282, builders.py:114-132
+    def _stem(self, obs, cells, want_cells=False):
+        """low-dim concat -> z-filter -> [LSTM]  (ppo_net.py:262-279).  With the LSTM stem the
+        input is (B, T, D) and cells = (h0, c0), each (1, B, H), or None for zeros."""
         x = self._gather_low_dim_input(obs)
         if self.use_z_filter:
             x = self.z_filter.forward(x)
+        if not self.if_rnn:
+            return x, cells
+        assert x.dim() == 3, 'the LSTM stem takes (batch, time, features) observations'
+        B, T, D = x.shape
+        H = self.rnn_hidden
+        dev = x.device
+        x2 = x.reshape(B * T, D).contiguous()
+        h0 = c0 = None
+        if cells is not None:
+            h0 = cells[0].reshape(B, H).to(dev, torch.float32).contiguous()
+            c0 = cells[1].reshape(B, H).to(dev, torch.float32).contiguous()
+        gates = torch.empty(B * T, 4 * H, device=dev)
+        out = torch.empty(B, T, H, device=dev)
+        cs = torch.empty(B * T, H, device=dev)
+        hN = cN = None
+        if want_cells:
+            hN, cN = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+        self.K.lstm_forward(self.rnn, x2, B, T, h0, c0, gates, out, cs, None, hN, cN)
+        if want_cells:
+            cells = (hN.view(1, B, H), cN.view(1, B, H))
+        return out, cells
+
+    def forward_actor(self, obs, cells=None):    # ppo_net.py:253-282, builders.py:114-132
+        x, _ = self._stem(obs, cells)
         mean, shape = self._mlp(self.actor, x, L.SMX_ACT_TANH)
         std = torch.exp(self.log_var) * torch.ones_like(mean)
         action = torch.cat((mean, std), dim=1)
@@ -260,16 +327,22 @@ class PPOModel(object):
         return action
 
     def forward_critic(self, obs, cells=None):   # ppo_net.py:284-315, builders.py:159-175
-        x = self._gather_low_dim_input(obs)
-        if self.use_z_filter:
-            x = self.z_filter.forward(x)
+        x, _ = self._stem(obs, cells)
         v, shape = self._mlp(self.critic, x, L.SMX_ACT_NONE)
         if len(shape) == 3:
             v = v.view(shape[0], shape[1], 1)
         return v
 
     def forward_actor_expose_cells(self, obs, cells=None):   # ppo_net.py:317-354
-        return self.forward_actor(obs, cells), cells
+        """one environment step for n actors: obs (n, D), cells (1, n, H) x 2 -> (pd (n, 2A),
+        new cells).  The reference is the n = 1 case (`obs.view(1, 1, -1)`, :338)."""
+        if not self.if_rnn:
+            return self.forward_actor(obs, cells), cells
+        step = {mod: {k: v.unsqueeze(1) for k, v in obs[mod].items()} for mod in obs.keys()}
+        x, cells = self._stem(step, cells, want_cells=True)
+        mean, _ = self._mlp(self.actor, x.reshape(-1, self.rnn_hidden), L.SMX_ACT_TANH)
+        std = torch.exp(self.log_var) * torch.ones_like(mean)
+        return torch.cat((mean, std), dim=1), cells
 
     def z_update(self, obs):                     # ppo_net.py:356-366
         if not self.use_z_filter:

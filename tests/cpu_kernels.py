@@ -398,6 +398,57 @@ class TorchCpuKernels(object):
         if db is not None:
             db.view(-1)[:M].copy_(dz.sum(0))
 
+    # ---- LSTM stem (contract of smx_lstm_forward_f32 / smx_lstm_backward_f32) ------------------
+    def lstm_forward(self, net, x, B, T, h0, c0, gates, out, cs, hprev=None, hN=None, cN=None,
+                     stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        v, H = net.views, net.H
+        xs = x.reshape(B, T, -1)
+        h = h0.reshape(B, H).clone() if h0 is not None else torch.zeros(B, H)
+        c = c0.reshape(B, H).clone() if c0 is not None else torch.zeros(B, H)
+        G, O, C = gates.view(B, T, 4 * H), out.view(B, T, H), cs.view(B, T, H)
+        for t in range(T):
+            g = (xs[:, t] @ v['weight_ih'].t() + v['bias_ih']) + (h @ v['weight_hh'].t() + v['bias_hh'])
+            i, f, gg, o = g.chunk(4, 1)
+            i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+            if hprev is not None:
+                hprev.view(B, T, H)[:, t] = h
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+            G[:, t] = torch.cat([i, f, gg, o], 1)
+            O[:, t] = h
+            C[:, t] = c
+        if hN is not None:
+            hN.copy_(h)
+        if cN is not None:
+            cN.copy_(c)
+
+    def lstm_backward(self, net, x, B, T, c0, gates, cs, hprev, dout, dgates, grads, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        v, H = net.views, net.H
+        G = gates.view(B, T, 4 * H).clone()          # dgates may alias gates
+        C, DO = cs.view(B, T, H), dout.reshape(B, T, H)
+        DG = dgates.view(B, T, 4 * H)
+        dh_rec = torch.zeros(B, H)
+        dc_rec = torch.zeros(B, H)
+        for t in range(T - 1, -1, -1):
+            i, f, gg, o = G[:, t].chunk(4, 1)
+            c = C[:, t]
+            cp = C[:, t - 1] if t > 0 else (c0.reshape(B, H) if c0 is not None else torch.zeros(B, H))
+            dh = DO[:, t] + dh_rec
+            tc = torch.tanh(c)
+            dc = dc_rec + dh * o * (1 - tc * tc)
+            d = torch.cat([dc * gg * i * (1 - i), dc * cp * f * (1 - f), dc * i * (1 - gg * gg),
+                           dh * tc * o * (1 - o)], 1)
+            DG[:, t] = d
+            dc_rec = dc * f
+            dh_rec = d @ v['weight_hh']
+        d2 = DG.reshape(B * T, 4 * H)
+        pieces = [d2.t() @ x.reshape(B * T, -1), d2.t() @ hprev.reshape(B * T, H), d2.sum(0), d2.sum(0)]
+        grads.copy_(torch.cat([p.reshape(-1) for p in pieces]))
+
     def ddpg_critic_loss(self, q, q_next, rewards, dones, gamma_n, y, dz3):
         yy = rewards.view(-1) + gamma_n * q_next.view(-1) * (1.0 - dones.view(-1))
         y.view(-1).copy_(yy)

@@ -15,6 +15,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 NON_RNN = H.golden_cases(rnn=False)
+RNN = H.golden_cases(rnn=True)
 
 
 def run_case(name, session_overrides=None):
@@ -48,6 +49,19 @@ def check_case(name, g, case, learner, stats):
 def test_learner_matches_reference_golden_graph(name):
     """default product configuration: hipGraph replay + value epochs on a side stream"""
     check_case(name, *run_case(name))
+
+
+@pytest.mark.parametrize('name', RNN)
+def test_rnn_learner_matches_reference_golden_graph(name):
+    """LSTM-stem policy (algo.rnn.if_rnn_policy, the reference default; cfg1 is the shape of the
+    reference's own test_ppo_gym --unit-test run): BPTT through the stem in both optimiser
+    groups, horizon-H windowed GAE over the (B, N+1) critic sequence"""
+    check_case(name, *run_case(name))
+
+
+@pytest.mark.parametrize('name', RNN)
+def test_rnn_learner_matches_reference_golden_eager(name):
+    check_case(name, *run_case(name, {'use_hip_graph': False}))
 
 
 @pytest.mark.parametrize('name', ['tiny_adapt_cutoff2', 'ragged_clip', 'cfg2_adapt', 'cfg5_adapt_earlyexit'])
@@ -95,8 +109,34 @@ def test_gae_and_return_accessor():
     np.testing.assert_allclose(ret.cpu().numpy(), g['returns'], atol=H.ATOL, rtol=H.RTOL)
 
 
-def test_rnn_policy_is_refused_loudly():
-    g, case = H.load_golden('cfg1_rnn_adapt')
+def test_rnn_three_learns_match_oracle():
+    """consecutive learn() calls with the LSTM stem: both Adam states of the shared stem carry over"""
+    import ppo_oracle
+    g, case = H.load_golden('tiny_rnn_clip')
+    batch, params, zstate = H.case_inputs(case)
+    hyper = dict(case['hyper'])
+    hyper['n_step'] = case['shape']['N']
+    O = ppo_oracle.OraclePPOLearner(params, case['shape']['A'], case['shape']['B'], zstate=zstate, **hyper)
+    learner = H.make_learner(case, params, zstate)
+    dbatch = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+    for it in range(3):
+        so = O.learn(copy.deepcopy(batch))
+        sl = learner.learn(dbatch)
+        for k in so:
+            if k != '_lr':
+                at, rt = H.tol_for(k, H.ATOL, 2e-5)
+                np.testing.assert_allclose(sl[k], so[k], atol=at, rtol=rt,
+                                           err_msg='iteration %d stat %s' % (it, k))
+    assert len(learner._graphs) == 1
+
+
+def test_pixel_policy_is_refused_loudly():
+    from surreal_amd.main.ppo_configs import ppo_env_config
+    g, case = H.load_golden('tiny_clip')
     _, params, zstate = H.case_inputs(case)
+    import surreal_amd.main.ppo_configs as C
+    env = C.ppo_env_config(case['shape']['D'], case['shape']['A'])
+    env.pixel_input = True
+    from surreal_amd.learner.ppo import PPOLearner
     with pytest.raises(NotImplementedError):
-        H.make_learner(case, {k: v for k, v in params.items() if not k.startswith('rnn.')}, zstate)
+        PPOLearner(C.ppo_learner_config(), env, C.ppo_session_config())

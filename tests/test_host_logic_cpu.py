@@ -9,10 +9,10 @@ import pytest
 
 import helpers as H
 
-NON_RNN = H.golden_cases(rnn=False)
+ALL_CASES = H.golden_cases()        # MLP policy and LSTM-stem policy (the reference default)
 
 
-@pytest.mark.parametrize('name', NON_RNN)
+@pytest.mark.parametrize('name', ALL_CASES)
 def test_learner_host_logic_matches_reference(name, cpu_double):
     g, case = H.load_golden(name)
     batch, params, zstate = H.case_inputs(case)
