@@ -51,6 +51,13 @@ class PPOAgent(Agent):
                               rnn_config=self.rnn_config, device=self.device, kernels=self.K)
         self.sink = None
         self._batch_noise = None
+        self._batch_cells = None
+        self.reset()
+
+    def _zero_cells(self, n):
+        """(h, c), each (rnn_layer, n, rnn_hidden) zeros (ppo_agent.py:83-95)"""
+        shape = (self.rnn_config.rnn_layer, n, self.rnn_config.rnn_hidden)
+        return (torch.zeros(*shape, device=self.device), torch.zeros(*shape, device=self.device))
 
     # ---- batch-1 reference contract (ppo_agent.py:106-154) ----------------------------------
     def act(self, obs):
@@ -61,6 +68,9 @@ class PPOAgent(Agent):
             for k in obs[mod].keys():
                 obs_tensor[mod][k] = torch.as_tensor(np.asarray(obs[mod][k]), dtype=torch.float32) \
                     .unsqueeze(0).to(self.device)
+        if self.rnn_config.if_rnn_policy:                # ppo_agent.py:133-135
+            action_info[0].append(self.cells[0].squeeze(1).cpu().numpy())
+            action_info[0].append(self.cells[1].squeeze(1).cpu().numpy())
         action_pd, self.cells = self.model.forward_actor_expose_cells(obs_tensor, self.cells)
         action_pd = action_pd.detach().cpu().numpy()
         action_pd[:, self.action_dim:] *= np.exp(self.noise)
@@ -92,7 +102,16 @@ class PPOAgent(Agent):
             else:
                 u = torch.zeros(n, 1)
             self._batch_noise = torch.exp(u).to(self.device)
-        pd = self.model.forward_actor({'low_dim': {'flat_inputs': obs}})
+        if self.rnn_config.if_rnn_policy:
+            # one LSTM step for all n actors; `batch_cells_before` is what every actor's
+            # onetime_infos would hold for this step (its state BEFORE acting, :133-135)
+            if self._batch_cells is None or self._batch_cells[0].shape[1] != n:
+                self._batch_cells = self._zero_cells(n)
+            self.batch_cells_before = self._batch_cells
+            pd, self._batch_cells = self.model.forward_actor_expose_cells(
+                {'low_dim': {'flat_inputs': obs}}, self._batch_cells)
+        else:
+            pd = self.model.forward_actor({'low_dim': {'flat_inputs': obs}})
         pd = pd.clone()
         pd[:, A:] *= self._batch_noise
         if self.agent_mode in ['eval_deterministic', 'eval_deterministic_local']:
@@ -107,8 +126,20 @@ class PPOAgent(Agent):
     def module_dict(self):
         return {'ppo': self.model}
 
-    def reset(self):
-        self.cells = None
+    def reset(self):                                   # ppo_agent.py:167-183
+        """zero LSTM hidden and cell state (start of an episode)"""
+        self.cells = self._zero_cells(1) if self.rnn_config.if_rnn_policy else None
+
+    def reset_batch(self, mask=None):
+        """act_batch counterpart of reset(): zero the state of the actors in `mask` ([n] bool on
+        the device; None = all) whose episodes just ended"""
+        if self._batch_cells is None:
+            return
+        if mask is None:
+            self._batch_cells = None
+            return
+        keep = (~mask).to(torch.float32).view(1, -1, 1)
+        self._batch_cells = (self._batch_cells[0] * keep, self._batch_cells[1] * keep)
 
     def set_experience_sink(self, sink):
         """where windowed experiences go: normally ``replay._insert_wrapper``"""

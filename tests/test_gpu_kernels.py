@@ -405,3 +405,67 @@ def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
         if stop_val:
             assert float(jd[0]['out'].abs().max()) == 0.0 and float(jd[0]['grads'].abs().max()) == 0.0
             assert float(jd[1]['grads'].abs().max()) > 0.0
+
+
+# ---- LSTM stem: smx_lstm_forward_f32 / smx_lstm_backward_f32 vs torch.nn.LSTM (ATen CPU fp32,
+# the op the reference calls, ppo_net.py:146-149) and vs the double's statement of the contract
+@pytest.mark.parametrize('B,T,D,H,cells', [
+    (2, 21, 17, 100, True),      # cfg1 epochs: E = 25 - 5 + 1
+    (2, 26, 17, 100, True),      # cfg1 critic pass: N + 1
+    (5, 4, 7, 12, True),         # tiny golden
+    (37, 9, 17, 100, False),     # ragged rows, zero initial state
+    (64, 21, 17, 100, True),     # cfg2-sized batch
+    (3, 5, 9, 128, True),        # H > 112: W_hh fragments re-read every step
+    (20, 6, 11, 256, True),
+])
+def test_lstm_forward_backward_match_aten(K, B, T, D, H, cells):
+    from surreal_amd.model.ppo_net import LstmParams
+    torch.manual_seed(B * 1000 + T)
+    ref = torch.nn.LSTM(D, H, 1, batch_first=True)
+    x = torch.randn(B, T, D)
+    h0, c0 = 0.3 * torch.randn(1, B, H), 0.3 * torch.randn(1, B, H)
+    out, (hN, cN) = ref(x, (h0, c0) if cells else None)
+    dout = torch.randn(B, T, H)
+    (out * dout).sum().backward()
+    plist = (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)
+    flat = torch.cat([p.detach().reshape(-1) for p in plist]).cuda()
+    assert flat.numel() == L.load().smx_lstm_param_count(D, H) == LstmParams.count(D, H)
+    net = LstmParams(flat, 0, D, H)
+    xd = x.cuda().reshape(B * T, D).contiguous()
+    f = lambda *s: torch.empty(*s, device='cuda')  # noqa: E731
+    gates, od, cs, hp, hNd, cNd = f(B * T, 4 * H), f(B, T, H), f(B * T, H), f(B * T, H), f(B, H), f(B, H)
+    h0d = h0[0].cuda().contiguous() if cells else None
+    c0d = c0[0].cuda().contiguous() if cells else None
+    K.lstm_forward(net, xd, B, T, h0d, c0d, gates, od, cs, hp, hNd, cNd)
+    close(od, out, msg='h_t')
+    close(hNd, hN[0], msg='h_N')
+    close(cNd, cN[0], msg='c_N')
+    # the saved tensors are what the contract (test double) says
+    flat_c = flat.cpu()
+    net_c = LstmParams(flat_c, 0, D, H)
+    g2, o2, c2, p2 = torch.empty(B * T, 4 * H), torch.empty(B, T, H), torch.empty(B * T, H), torch.empty(B * T, H)
+    C.lstm_forward(net_c, x.reshape(B * T, D), B, T, h0[0] if cells else None, c0[0] if cells else None,
+                   g2, o2, c2, p2)
+    close(gates, g2, msg='activated gates')
+    close(cs, c2, msg='c_t')
+    close(hp, p2, msg='h_{t-1}')
+    grads = torch.zeros(flat.numel(), device='cuda')
+    K.lstm_backward(net, xd, B, T, c0d, gates, cs, hp, dout.cuda().contiguous(), gates, grads)   # dgates aliases gates
+    gref = torch.cat([p.grad.reshape(-1) for p in plist])
+    scale = float(gref.abs().max())
+    close(grads.cpu() / scale, gref / scale, atol=2e-6, rtol=1e-5, msg='BPTT gradients')
+
+
+def test_lstm_stop_flag_and_limits(K):
+    from surreal_amd.model.ppo_net import LstmParams
+    B, T, D, H = 3, 4, 5, 8
+    flat = torch.randn(LstmParams.count(D, H), device='cuda')
+    net = LstmParams(flat, 0, D, H)
+    x = torch.randn(B * T, D, device='cuda')
+    gates, out, cs = (torch.full((B * T, n), 7.0, device='cuda') for n in (4 * H, H, H))
+    stop = torch.ones(1, dtype=torch.int32, device='cuda')
+    K.lstm_forward(net, x, B, T, None, None, gates, out, cs, None, None, None, stop=stop)
+    assert float(out.min()) == 7.0 and float(gates.min()) == 7.0          # skipped entirely
+    bad = LstmParams(torch.randn(LstmParams.count(D, 6), device='cuda'), 0, D, 6)     # H % 4 != 0
+    with pytest.raises(L.SmxError):
+        K.lstm_forward(bad, x, B, T, None, None, gates, out, cs)

@@ -270,3 +270,64 @@ def test_agent_replay_learner_loop_in_process(cpu_double):
     np.testing.assert_array_equal(a1, a2)
     acts, pds = agents[0].act_batch(torch.randn(6, D), eps=torch.zeros(6, A))
     np.testing.assert_allclose(acts.numpy(), np.clip(pds[:, :A].numpy(), -1, 1))
+
+
+def test_rnn_agent_replay_learner_loop_in_process(cpu_double):
+    """the reference's DEFAULT policy (LSTM stem): the agent carries (h, c) across steps, every
+    window's onetime_infos hold the state before its first step (ppo_agent.py:133-135,
+    exp_sender_wrapper.py:237-252), and the learner's sequence pass from that state reproduces
+    the per-step policies the agent acted with -- the property the whole RNN learner rests on."""
+    from surreal_amd.agent import PPOAgent
+    from surreal_amd.env import SyntheticEnv
+    from surreal_amd.learner import PPOLearner
+    from surreal_amd.replay import FIFOReplay
+    D, A, N, HID = 5, 2, 6, 12
+    lc, ec, sc = configs(B=3, N=N, stride=2, D=D, A=A, memory=16)
+    lc.algo.rnn.if_rnn_policy = True
+    lc.algo.rnn.rnn_hidden = HID
+    lc.algo.rnn.horizon = 3
+    ec.limit_episode_length = 14
+    replay = FIFOReplay(lc, ec, sc)
+    learner = PPOLearner(lc, ec, sc)
+    learner.attach_replay(replay)
+    ag = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='eval_stochastic_local')
+    assert ag.cells[0].shape == (1, 1, HID) and float(ag.cells[0].abs().sum()) == 0.0
+    ag = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
+    ag.noise = 0.0                                   # compare pds without the exploration scale
+    collected = []
+    ag.set_experience_sink(lambda exp: (collected.append(exp), replay._insert_wrapper(exp)))
+    ag.set_env_factory(lambda: SyntheticEnv(D, A, episode_len=50, seed=4))
+    ag.attach_learner(learner)
+    ag.main_setup()
+    learner.main_setup()
+    ag.main_loop()
+    assert len(collected) == (14 - N) // 2 + 1
+    for exp in collected:
+        h, c = exp['onetime_infos']
+        assert h.shape == (1, HID) and c.shape == (1, HID)
+    assert float(np.abs(collected[0]['onetime_infos'][0]).sum()) == 0.0      # episode start
+    assert float(np.abs(collected[1]['onetime_infos'][0]).sum()) > 0.0
+    # sequence pass from the stored state == the step-by-step policies the agent produced
+    exp = collected[1]
+    obs_seq = torch.as_tensor(np.stack([o['low_dim']['flat_inputs'] for o in exp['obs'][:N]]))[None]
+    cells = tuple(torch.as_tensor(x).view(1, 1, HID) for x in exp['onetime_infos'])
+    pd_seq = ag.model.forward_actor({'low_dim': {'flat_inputs': obs_seq}}, cells)[0].numpy()
+    pd_steps = np.stack(exp['persistent_infos'][0]) if isinstance(exp['persistent_infos'], list) \
+        and len(exp['persistent_infos']) == 1 else np.stack([p[-1] for p in exp['persistent_infos']])
+    np.testing.assert_allclose(pd_seq, pd_steps.reshape(pd_seq.shape), atol=1e-6)
+    # learner consumes the windows (onetime_infos -> (1, B, H) cells)
+    ag.main_loop()
+    assert replay.start_sample_condition()
+    learner.main_loop()
+    st = learner.tensorplex.latest
+    for k in ('_surr_loss', '_val_loss', '_pol_kl', 'grad_norm_actor', 'grad_norm_critic'):
+        assert np.isfinite(st[k]), k
+    assert learner._ws.E == N - 3 + 1 and learner._ws.rows == 3 * (N - 3 + 1)
+    # batched acting: per-actor state, reset by mask
+    acts, pds = ag.act_batch(torch.randn(4, D), eps=torch.zeros(4, A))
+    assert float(ag.batch_cells_before[0].abs().sum()) == 0.0
+    acts, pds = ag.act_batch(torch.randn(4, D), eps=torch.zeros(4, A))
+    assert float(ag.batch_cells_before[0].abs().sum()) > 0.0
+    ag.reset_batch(torch.tensor([True, False, False, True]))
+    hb = ag._batch_cells[0][0]
+    assert float(hb[0].abs().sum()) == 0.0 and float(hb[1].abs().sum()) > 0.0
