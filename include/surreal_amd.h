@@ -384,6 +384,29 @@ int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int64_t B, int3
                           const float* hprev, const float* dout, float* dgates, float* grads,
                           const int32_t* stop_flag, smx_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CNN stem data movement (surreal/model/model_builders/builders.py:8-33 CNNStemNetwork;
+ * ppo_net.py:268-273, 368-375 `_scale_image`).  The convolutions themselves are smx_linear_f32 /
+ * smx_linear_wgrad_f32 over patch rows.
+ * ------------------------------------------------------------------------------------------- */
+/* cols[(f*Ho + oy)*Wo + ox, c*kh*kw + i*kw + j] = src(f, c, oy*stride + i, ox*stride + j)
+ * [/ scale_div when scale_div != 0: x / 255.0 of _scale_image].  src: uint8 or fp32 frames
+ * [F, C, Hin, Win] (channel_last = 0), or an fp32 activation [F, Hin*Win, C] (channel_last = 1).
+ * No padding (torch default); Ho = (Hin - kh)/stride + 1.  The k order is torch's
+ * Conv2d.weight.view(out, -1) order. */
+int smx_im2col_f32(const void* src, int32_t src_is_u8, int32_t channel_last, int64_t F, int32_t C,
+                   int32_t Hin, int32_t Win, int32_t kh, int32_t kw, int32_t stride,
+                   float scale_div, float* cols, smx_stream_t stream);
+/* data gradient of the convolution above: dx [F, Hin*Win, C] (channel-last) gathers dcols
+ * [F*Ho*Wo, C*kh*kw]; relu_of (optional, same shape as dx): dx *= (relu_of > 0). */
+int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t kh,
+                   int32_t kw, int32_t stride, const float* relu_of, float* dx,
+                   smx_stream_t stream);
+/* Flatten order of the Linear after the convolutions: to_channel_last != 0:
+ * out[o, p*C + c] = in[o, c*P + p], else the inverse (used for the weight and for its gradient). */
+int smx_flatten_order_f32(const float* in, int32_t O, int32_t C, int32_t P,
+                          int32_t to_channel_last, float* out, smx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

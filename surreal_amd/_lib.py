@@ -108,6 +108,11 @@ _SIGS = {
                                        _P, _P, _P, _P]),
     'smx_lstm_backward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
+    'smx_im2col_f32': (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                 c_int32, c_int32, c_float, _P, _P]),
+    'smx_col2im_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 _P, _P, _P]),
+    'smx_flatten_order_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

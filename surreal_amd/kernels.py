@@ -255,6 +255,21 @@ class HipKernels(object):
                L.ptr(stop), self._st())
 
 
+    # ---- CNN stem data movement ----------------------------------------------------------------
+    def im2col(self, src, F, C, Hin, Win, k, stride, cols, channel_last=False, scale_div=0.0):
+        """src: uint8 / fp32 frames [F, C, Hin, Win] or (channel_last) fp32 [F, Hin*Win, C]"""
+        L.call('smx_im2col_f32', L.ptr(src), int(src.dtype == torch.uint8), int(channel_last), F, C,
+               Hin, Win, k, k, stride, float(scale_div), L.ptr(cols), self._st())
+
+    def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
+        L.call('smx_col2im_f32', L.ptr(dcols), F, C, Hin, Win, k, k, stride, L.ptr(relu_of),
+               L.ptr(dx), self._st())
+
+    def flatten_order(self, src, O, C, P, to_channel_last, out):
+        L.call('smx_flatten_order_f32', L.ptr(src), O, C, P, int(to_channel_last), L.ptr(out),
+               self._st())
+
+
 # ------------------------------------------------------------------------------------------
 # process-wide default.  The product default is HipKernels on 'cuda' and nothing in
 # surreal_amd/ ever installs anything else; tests/ install a CPU test double to exercise

@@ -1,0 +1,123 @@
+"""
+CNN stem of the PPO model (surreal/model/model_builders/builders.py:8-33 ``CNNStemNetwork``):
+Conv2d(16, k8, s4)-ReLU-Conv2d(32, k4, s2)-ReLU-Flatten-Linear(cnn_feature_dim)-ReLU applied to the
+camera frames scaled by 1/255 (ppo_net.py:268-273, 368-375).
+
+Both convolutions are GEMMs over patch rows on the FP32-MFMA layer kernel; activations are kept
+channel-last ``[frame, pixel, channel]`` (what those GEMMs write).  torch flattens channel-first, so
+the Linear runs against a re-indexed copy of its weight (``smx_flatten_order_f32``).
+"""
+import collections
+import types
+
+import numpy as np
+import torch
+
+from surreal_amd import _lib as L
+
+
+class CnnParams(object):
+    """views of the stem's parameters inside a flat buffer, torch layouts:
+    conv1.W [c1, C, k1, k1], conv1.b, conv2.W [c2, c1, k2, k2], conv2.b, fc.W [feat, c2*P2], fc.b"""
+
+    def __init__(self, flat, offset, in_shape, feat_dim, conv_channels=(16, 32),
+                 kernel_sizes=(8, 4), strides=(4, 2)):
+        C, H, W = [int(v) for v in in_shape]
+        self.C, self.H, self.W, self.feat = C, H, W, int(feat_dim)
+        (self.c1, self.c2), (self.k1, self.k2), (self.s1, self.s2) = conv_channels, kernel_sizes, strides
+        self.H1, self.W1 = (H - self.k1) // self.s1 + 1, (W - self.k1) // self.s1 + 1
+        self.H2, self.W2 = (self.H1 - self.k2) // self.s2 + 1, (self.W1 - self.k2) // self.s2 + 1
+        if self.H1 <= 0 or self.W1 <= 0 or self.H2 <= 0 or self.W2 <= 0:
+            raise ValueError('camera frames %r are too small for the CNN stem' % (in_shape,))
+        self.P1, self.P2 = self.H1 * self.W1, self.H2 * self.W2
+        self.K1, self.K2 = C * self.k1 * self.k1, self.c1 * self.k2 * self.k2
+        self.flat_dim = self.c2 * self.P2
+        sizes = [('conv1.W', (self.c1, C, self.k1, self.k1)), ('conv1.b', (self.c1,)),
+                 ('conv2.W', (self.c2, self.c1, self.k2, self.k2)), ('conv2.b', (self.c2,)),
+                 ('fc.W', (self.feat, self.flat_dim)), ('fc.b', (self.feat,))]
+        self.views = collections.OrderedDict()
+        o = offset
+        for name, shp in sizes:
+            n = int(np.prod(shp))
+            self.views[name] = flat[o:o + n].view(*shp)
+            o += n
+        self.numel = o - offset
+        self.offset = offset
+
+    @staticmethod
+    def count(in_shape, feat_dim, conv_channels=(16, 32), kernel_sizes=(8, 4), strides=(4, 2)):
+        C, H, W = [int(v) for v in in_shape]
+        h1, w1 = (H - kernel_sizes[0]) // strides[0] + 1, (W - kernel_sizes[0]) // strides[0] + 1
+        h2, w2 = (h1 - kernel_sizes[1]) // strides[1] + 1, (w1 - kernel_sizes[1]) // strides[1] + 1
+        c1, c2 = conv_channels
+        n = c1 * C * kernel_sizes[0] ** 2 + c1 + c2 * c1 * kernel_sizes[1] ** 2 + c2
+        n += feat_dim * c2 * h2 * w2 + feat_dim
+        return (n + 3) & ~3          # keeps whatever follows 16-byte aligned
+
+    def init_torch_default(self):
+        """torch.nn.Conv2d / Linear default init (kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in)));
+        torchx's own init is unknown (source absent) -- parity tests inject parameters"""
+        for name, v in self.views.items():
+            w = self.views[name.split('.')[0] + '.W']
+            fan_in = int(np.prod(w.shape[1:]))
+            v.uniform_(-1.0 / np.sqrt(fan_in), 1.0 / np.sqrt(fan_in))
+
+
+class CnnStem(object):
+    """forward / backward of the stem over F frames through the kernel facade"""
+
+    def __init__(self, kernels):
+        self.K = kernels
+
+    @staticmethod
+    def workspace(p, F, device, backward=True):
+        f = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)  # noqa: E731
+        ws = types.SimpleNamespace(F=F)
+        ws.cols1, ws.y1 = f(F * p.P1, p.K1), f(F * p.P1, p.c1)
+        ws.cols2, ws.y2 = f(F * p.P2, p.K2), f(F * p.P2, p.c2)
+        ws.wfc = f(p.feat, p.flat_dim)                 # fc.W re-indexed channel-last
+        if backward:
+            ws.dy2, ws.dcols2, ws.dy1 = f(F * p.P2, p.c2), f(F * p.P2, p.K2), f(F * p.P1, p.c1)
+            ws.gwfc = f(p.feat, p.flat_dim)
+        return ws
+
+    def forward(self, p, frames, F, ws, out, stop=None):
+        """frames: uint8 or fp32 [F, C, H, W] (contiguous); out: [F, feat] view (any row stride)"""
+        K, v = self.K, p.views
+        K.im2col(frames, F, p.C, p.H, p.W, p.k1, p.s1, ws.cols1, scale_div=255.0)
+        K.linear(ws.cols1, 1, v['conv1.W'].view(p.c1, p.K1), 1, v['conv1.b'], ws.y1, F * p.P1, p.c1,
+                 p.K1, act=L.SMX_ACT_RELU, stop=stop)
+        K.im2col(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.cols2, channel_last=True)
+        K.linear(ws.cols2, 1, v['conv2.W'].view(p.c2, p.K2), 1, v['conv2.b'], ws.y2, F * p.P2, p.c2,
+                 p.K2, act=L.SMX_ACT_RELU, stop=stop)
+        K.flatten_order(v['fc.W'], p.feat, p.c2, p.P2, True, ws.wfc)
+        K.linear(ws.y2.view(F, p.flat_dim), 1, ws.wfc, 1, v['fc.b'], out, F, p.feat, p.flat_dim,
+                 act=L.SMX_ACT_RELU, ldc=out.stride(0), stop=stop)
+
+    def backward(self, p, F, ws, dfeat, grads, stop=None):
+        """dfeat: [F, feat] view = dLoss/d(stem output), ALREADY multiplied by the output ReLU's
+        mask; ws must still hold this pass's forward activations.  grads: flat, parameter layout."""
+        K, v = self.K, p.views
+        g = CnnParams.__new__(CnnParams)             # same layout over the gradient buffer
+        g.views = collections.OrderedDict()
+        o = 0
+        for name, t in v.items():
+            g.views[name] = grads[o:o + t.numel()].view(t.shape)
+            o += t.numel()
+        gv = g.views
+        ldz = dfeat.stride(0)
+        # Linear: dW (channel-last, then back to torch's order), db, d(flat) * relu'(y2)
+        K.linear_wgrad(dfeat, ws.y2.view(F, p.flat_dim), ws.gwfc, gv['fc.b'], p.feat, p.flat_dim, F,
+                       ldz=ldz)
+        K.flatten_order(ws.gwfc, p.feat, p.c2, p.P2, False, gv['fc.W'])
+        K.linear(dfeat, 1, ws.wfc, 0, None, ws.dy2.view(F, p.flat_dim), F, p.flat_dim, p.feat,
+                 relu_mask=ws.y2.view(F, p.flat_dim), lda=ldz, stop=stop)
+        # conv2: dW, db, data gradient scattered back through the patches * relu'(y1)
+        K.linear_wgrad(ws.dy2, ws.cols2, gv['conv2.W'].view(p.c2, p.K2), gv['conv2.b'], p.c2, p.K2,
+                       F * p.P2)
+        K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
+                 stop=stop)
+        K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)
+        # conv1: dW, db (the frames carry no gradient)
+        K.linear_wgrad(ws.dy1, ws.cols1, gv['conv1.W'].view(p.c1, p.K1), gv['conv1.b'], p.c1, p.K1,
+                       F * p.P1)

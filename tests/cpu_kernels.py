@@ -449,6 +449,32 @@ class TorchCpuKernels(object):
         pieces = [d2.t() @ x.reshape(B * T, -1), d2.t() @ hprev.reshape(B * T, H), d2.sum(0), d2.sum(0)]
         grads.copy_(torch.cat([p.reshape(-1) for p in pieces]))
 
+    # ---- CNN stem data movement (contracts of smx_im2col_f32 / smx_col2im_f32 / flatten_order) ---
+    def im2col(self, src, F, C, Hin, Win, k, stride, cols, channel_last=False, scale_div=0.0):
+        x = src.to(torch.float32)
+        if channel_last:
+            x = x.reshape(F, Hin, Win, C).permute(0, 3, 1, 2)
+        x = x.reshape(F, C, Hin, Win)
+        if scale_div:
+            x = x / scale_div
+        u = torch.nn.functional.unfold(x, k, stride=stride)          # [F, C*k*k, P]
+        cols.copy_(u.transpose(1, 2).reshape(cols.shape))
+
+    def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
+        P = ((Hin - k) // stride + 1) * ((Win - k) // stride + 1)
+        u = dcols.reshape(F, P, C * k * k).transpose(1, 2)
+        x = torch.nn.functional.fold(u, (Hin, Win), k, stride=stride)       # [F, C, Hin, Win]
+        x = x.permute(0, 2, 3, 1).reshape(dx.shape)
+        if relu_of is not None:
+            x = x * (relu_of.reshape(dx.shape) > 0)
+        dx.copy_(x)
+
+    def flatten_order(self, src, O, C, P, to_channel_last, out):
+        if to_channel_last:
+            out.copy_(src.reshape(O, C, P).transpose(1, 2).reshape(out.shape))
+        else:
+            out.copy_(src.reshape(O, P, C).transpose(1, 2).reshape(out.shape))
+
     def ddpg_critic_loss(self, q, q_next, rewards, dones, gamma_n, y, dz3):
         yy = rewards.view(-1) + gamma_n * q_next.view(-1) * (1.0 - dones.view(-1))
         y.view(-1).copy_(yy)
