@@ -39,7 +39,7 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-def build_reference_learner(ref, params, zstate, B, N, D, A, hyper):
+def build_reference_learner(ref, params, zstate, B, N, D, A, hyper, pixel=None):
     """object.__new__(PPOLearner) + the attributes PPOLearner.__init__ sets
     (ppo.py:61-192), bypassing ZMQ / tensorplex / checkpoint construction."""
     PPOLearner = ref.ppo.PPOLearner
@@ -65,17 +65,19 @@ def build_reference_learner(ref, params, zstate, B, N, D, A, hyper):
     else:
         L.clip_epsilon = h['clip_epsilon_init']
     obs_spec = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=[D]))
+    if pixel is not None:
+        obs_spec['pixel'] = collections.OrderedDict(camera0=list(pixel))
     hidden = [params['actor.fc1.W'].shape[0], params['actor.fc2.W'].shape[0]]
     rnn_hidden = params['rnn.weight_hh'].shape[1] if 'rnn.weight_hh' in params else 100
     model_config = _Cfg(actor_fc_hidden_sizes=hidden, critic_fc_hidden_sizes=hidden,
-                        cnn_feature_dim=256)
+                        cnn_feature_dim=params['cnn.fc.W'].shape[0] if pixel is not None else 256)
     rnn_config = _Cfg(if_rnn_policy=L.if_rnn_policy, rnn_hidden=rnn_hidden, rnn_layer=1,
                       horizon=L.horizon)
 
     def make_model():
         m = PPOModel(obs_spec=obs_spec, action_dim=A, model_config=model_config,
                      use_cuda=False, init_log_sig=-1.0, use_z_filter=L.use_z_filter,
-                     if_pixel_input=False, rnn_config=rnn_config)
+                     if_pixel_input=pixel is not None, rnn_config=rnn_config)
         inject_params(m, params, zstate)
         return m
     L.model = make_model()
@@ -106,6 +108,11 @@ def _linears(functional):
     return [l for l in functional.layers if hasattr(l, 'fc')]
 
 
+def _cnn_layers(m):
+    ls = [l for l in m.cnn_stem.model.layers if hasattr(l, 'conv') or hasattr(l, 'fc')]
+    return collections.OrderedDict(zip(('conv1', 'conv2', 'fc'), ls))
+
+
 def inject_params(m, params, zstate):
     with torch.no_grad():
         for net, name in ((m.actor, 'actor'), (m.critic, 'critic')):
@@ -113,6 +120,11 @@ def inject_params(m, params, zstate):
                 lin.fc.weight.copy_(torch.tensor(params['%s.fc%d.W' % (name, i + 1)]))
                 lin.fc.bias.copy_(torch.tensor(params['%s.fc%d.b' % (name, i + 1)]))
         m.actor.log_var.copy_(torch.tensor(params['actor.log_var']))
+        if m.cnn_stem is not None:
+            for nm, layer in _cnn_layers(m).items():
+                mod = layer.conv if hasattr(layer, 'conv') else layer.fc
+                mod.weight.copy_(torch.tensor(params['cnn.%s.W' % nm]))
+                mod.bias.copy_(torch.tensor(params['cnn.%s.b' % nm]))
         if m.rnn_stem is not None:
             m.rnn_stem.weight_ih_l0.copy_(torch.tensor(params['rnn.weight_ih']))
             m.rnn_stem.weight_hh_l0.copy_(torch.tensor(params['rnn.weight_hh']))
@@ -126,6 +138,11 @@ def inject_params(m, params, zstate):
 
 def extract_params(m):
     out = collections.OrderedDict()
+    if m.cnn_stem is not None:
+        for nm, layer in _cnn_layers(m).items():
+            mod = layer.conv if hasattr(layer, 'conv') else layer.fc
+            out['cnn.%s.W' % nm] = mod.weight.detach().numpy().copy()
+            out['cnn.%s.b' % nm] = mod.bias.detach().numpy().copy()
     if m.rnn_stem is not None:
         out['rnn.weight_ih'] = m.rnn_stem.weight_ih_l0.detach().numpy().copy()
         out['rnn.weight_hh'] = m.rnn_stem.weight_hh_l0.detach().numpy().copy()
@@ -146,11 +163,14 @@ def run_reference(ref, case):
     B, N, D, A = shp['B'], shp['N'], shp['D'], shp['A']
     hyper = case['hyper']
     rnn_hidden = case.get('rnn_hidden', 0) if hyper.get('if_rnn_policy') else 0
-    batch = synthetic.make_ppo_batch(B, N, D, A, rnn_hidden=rnn_hidden, **case['batch_args'])
+    pixel = case.get('pixel')
+    pix_kw = dict(pixel=tuple(pixel), cnn_feature_dim=case['cnn_feature_dim']) if pixel else {}
+    batch = synthetic.make_ppo_batch(B, N, D, A, rnn_hidden=rnn_hidden,
+                                     pixel=tuple(pixel) if pixel else None, **case['batch_args'])
     params = synthetic.make_ppo_params(D, A, hidden=tuple(case['hidden']), rnn_hidden=rnn_hidden,
-                                       **case['param_args'])
+                                       **pix_kw, **case['param_args'])
     zstate = synthetic.make_zfilter_state(D, **case['z_args']) if hyper.get('use_z_filter', True) else None
-    L = build_reference_learner(ref, params, zstate, B, N, D, A, hyper)
+    L = build_reference_learner(ref, params, zstate, B, N, D, A, hyper, pixel=pixel)
     trace = {'policy': [], 'value': []}
     PPOLearner = ref.ppo.PPOLearner
 
@@ -206,12 +226,14 @@ CASES = collections.OrderedDict()
 
 
 def _case(name, shape, hidden, hyper, batch_args=None, param_args=None, z_args=None,
-          keep_params=True, rnn_hidden=0):
+          keep_params=True, rnn_hidden=0, pixel=None, cnn_feature_dim=256):
     CASES[name] = dict(name=name, shape=shape, hidden=list(hidden), hyper=hyper,
                        batch_args=batch_args or dict(seed=0),
                        param_args=param_args or dict(seed=1),
                        z_args=z_args or dict(seed=2), keep_params=keep_params,
                        rnn_hidden=rnn_hidden)
+    if pixel is not None:
+        CASES[name].update(pixel=list(pixel), cnn_feature_dim=cnn_feature_dim)
 
 
 S = synthetic.PPO_CONFIGS
@@ -245,6 +267,15 @@ _case('cfg1_rnn_adapt', S['cfg1_unit'], (300, 200),
       dict(ppo_mode='adapt', if_rnn_policy=True, horizon=5), keep_params=False, rnn_hidden=100)
 _case('tiny_rnn_clip', S['tiny'], (24, 16),
       dict(ppo_mode='clip', if_rnn_policy=True, horizon=4, kl_target=1e9), rnn_hidden=12)
+# pixel observations: CNN stem in front of the MLPs / the LSTM (cfg 4 = SawyerLift camera frames,
+# (3, 84, 84) uint8 + robot state, A = 8; golden at 8 actors x 6 steps)
+_case('tiny_pixel_clip', dict(B=6, N=5, D=5, A=2), (24, 16), dict(ppo_mode='clip', kl_target=1e9),
+      pixel=(3, 28, 36), cnn_feature_dim=16)
+_case('tiny_pixel_rnn_adapt', dict(B=5, N=6, D=4, A=2), (24, 16),
+      dict(ppo_mode='adapt', if_rnn_policy=True, horizon=3), rnn_hidden=12, pixel=(2, 20, 24),
+      cnn_feature_dim=8)
+_case('cfg4_pixel_adapt', dict(B=8, N=6, D=32, A=8), (300, 200), dict(ppo_mode='adapt'),
+      keep_params=False, pixel=(3, 84, 84), cnn_feature_dim=256)
 
 
 def checksum(params):

@@ -165,9 +165,27 @@ class OraclePPOModel(object):
             self.p['rnn.weight_hh'] = self._rnn.weight_hh_l0
             self.p['rnn.bias_ih'] = self._rnn.bias_ih_l0
             self.p['rnn.bias_hh'] = self._rnn.bias_hh_l0
+        # optional CNN stem (builders.py:8-33): Conv2d(16,k8,s4)-ReLU-Conv2d(32,k4,s2)-ReLU-Flatten-
+        # Linear(cnn_feature_dim)-ReLU; the same ATen conv2d / linear ops the reference calls
+        self.if_pixel = 'cnn.conv1.W' in self.p
+        feat = 0
+        if self.if_pixel:
+            w1, w2, wf = self.p['cnn.conv1.W'], self.p['cnn.conv2.W'], self.p['cnn.fc.W']
+            feat = wf.shape[0]
+            self._cnn = nn.Sequential(nn.Conv2d(w1.shape[1], w1.shape[0], 8, 4), nn.ReLU(),
+                                      nn.Conv2d(w2.shape[1], w2.shape[0], 4, 2), nn.ReLU(),
+                                      nn.Flatten(), nn.Linear(wf.shape[1], feat), nn.ReLU())
+            mods = {'conv1': self._cnn[0], 'conv2': self._cnn[2], 'fc': self._cnn[5]}
+            with torch.no_grad():
+                for nm, mod in mods.items():
+                    mod.weight.copy_(self.p['cnn.%s.W' % nm])
+                    mod.bias.copy_(self.p['cnn.%s.b' % nm])
+            for nm, mod in mods.items():
+                self.p['cnn.%s.W' % nm] = mod.weight
+                self.p['cnn.%s.b' % nm] = mod.bias
         if use_z_filter:
             d = in_size if in_size is not None else (
-                self.p['rnn.weight_ih'].shape[1] if self.if_rnn else self.p['actor.fc1.W'].shape[1])
+                self.p['rnn.weight_ih'].shape[1] if self.if_rnn else self.p['actor.fc1.W'].shape[1]) - feat
             self.z_filter = ZFilter(d, state=zstate)
 
     # ppo_net.py:202-224 -- shared stems belong to BOTH parameter groups
@@ -176,12 +194,20 @@ class OraclePPOModel(object):
         # builders.py:112) before its children's (self.model.*)
         names = ['actor.log_var'] + [k for k in self.p
                                      if k.startswith('actor.') and k != 'actor.log_var']
+        names += self._cnn_names()
         if self.if_rnn:
             names += [k for k in self.p if k.startswith('rnn.')]
         return [self.p[k] for k in names]
 
+    def _cnn_names(self):
+        # module order of cnn_stem.parameters(): conv1, conv2, fc (weight then bias each)
+        if not self.if_pixel:
+            return []
+        return ['cnn.%s.%s' % (m, q) for m in ('conv1', 'conv2', 'fc') for q in ('W', 'b')]
+
     def critic_params(self):
         names = [k for k in self.p if k.startswith('critic.')]
+        names += self._cnn_names()
         if self.if_rnn:
             names += [k for k in self.p if k.startswith('rnn.')]
         return [self.p[k] for k in names]
@@ -209,6 +235,15 @@ class OraclePPOModel(object):
         x = torch.cat([obs['low_dim'][k] for k in obs['low_dim'].keys()], -1)
         if self.use_z_filter:
             x = self.z_filter.forward(x)
+        if self.if_pixel:                        # ppo_net.py:268-275, 368-375; builders.py:23-33
+            pix = obs['pixel']['camera0'] / 255.0
+            shp = pix.size()
+            if len(shp) == 5:
+                pix = pix.view(-1, *shp[2:])
+            f = self._cnn(pix)
+            if len(shp) == 5:
+                f = f.view(shp[0], shp[1], -1)
+            x = torch.cat([x, f], dim=-1)
         if self.if_rnn:
             x = self._lstm(x, cells)
         return x

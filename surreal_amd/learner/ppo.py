@@ -25,8 +25,8 @@ What is different is how one ``learn()`` runs (SURVEY.md section 3.1 lists the r
     single reference learner would have seen whole: advantage moments, loss partial sums,
     gradients, value moments, z-filter sums.
 
-Scope: low-dimensional observations, MLP policy or LSTM-stem policy (``rnn.if_rnn_policy``,
-the reference default); the CNN stem (``pixel_input``) raises NotImplementedError.
+Scope: MLP policy, LSTM-stem policy (``rnn.if_rnn_policy``, the reference default) and / or CNN
+stem over camera frames (``pixel_input``), one camera.
 """
 import types
 
@@ -206,8 +206,8 @@ class PPOLearner(Learner):
     # ======================================================================================
     # workspace
     # ======================================================================================
-    def _workspace(self, B, N, D, A):
-        key = (B, N, D, A)
+    def _workspace(self, B, N, D, A, pix_dtype=None):
+        key = (B, N, D, A, pix_dtype)
         if self._ws is not None and self._ws.key == key:
             return self._ws
         dev, K = self.device, self.K
@@ -216,6 +216,8 @@ class PPOLearner(Learner):
         ws.key = key
         act, cri = self.model.actor, self.model.critic
         rnn = self.if_rnn_policy
+        pixel = self.model.if_pixel
+        stem = rnn or pixel
         E = N - self.horizon + 1 if rnn else 1           # ppo.py:398-400, 521-537
         ws.E = E
         Ep, Ev = self.epoch_policy, self.epoch_baseline
@@ -236,7 +238,7 @@ class PPOLearner(Learner):
                 self._ws.ctrl_i[L.C_STEP_ACTOR:L.C_STEP_CRITIC + 1])
         self._ctrl_host = None
         # critic pass + GAE
-        ws.packed = None if rnn else f(K.mlp3_packed_numel(cri))
+        ws.packed = None if stem else f(K.mlp3_packed_numel(cri))
         ws.vals = f(B * (N + 1))
         # fused-kernel tail split (see _enqueue_gae): rounds of 128-row workgroups over the CUs
         n_cu = 256
@@ -244,7 +246,7 @@ class PPOLearner(Learner):
             n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
         rounds = lambda rows: -(-(-(-rows // 128)) // n_cu)  # noqa: E731
         ws.split_tail = bool(self.session_config.learner.get('split_critic_tail', True)) and \
-            rounds(B * (N + 1)) > rounds(B * N) and not rnn
+            rounds(B * (N + 1)) > rounds(B * N) and not stem
         ws.xnext = f(B, D)
         ws.adv = f(B * E)
         ws.ret = f(B * E)
@@ -255,8 +257,9 @@ class PPOLearner(Learner):
         # epochs
         rows = B * E
         ws.rows = rows
-        ws.xn = f(rows, D)            # z-filtered step-0 observations (model filter)
-        ws.xr = f(rows, D)            # same through the reference-policy filter
+        Dx = self.model.stem_in       # D, or D + cnn_feature_dim with pixel observations
+        ws.xn = f(rows, Dx)           # z-filtered step-0 observations [| CNN features] (model filter)
+        ws.xr = f(rows, Dx)           # same through the reference-policy filter / stem
         ws.h1a, ws.h2a, ws.mean = f(rows, act.H1), f(rows, act.H2), f(rows, A)
         ws.h1r, ws.h2r, ws.ref_mean = f(rows, act.H1), f(rows, act.H2), f(rows, A)
         ws.ref_pol = f(rows, 2 * A)
@@ -264,18 +267,34 @@ class PPOLearner(Learner):
         ws.g_surr, ws.g_kl, ws.dz3a = f(rows, A), f(rows, A), f(rows, A)
         ws.dz2a, ws.dz1a = f(rows, act.H2), f(rows, act.H1)
         ws.dz3c, ws.dz2c, ws.dz1c = f(rows), f(rows, cri.H2), f(rows, cri.H1)
-        if rnn:
-            # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E) ...
-            F = self.model.rnn_hidden
-            ws.h0, ws.c0 = f(B, F), f(B, F)
-            ws.xit = f(B, E, D)                       # obs[:, :E] (raw: also feeds z_update)
-            ws.act_it, ws.beh_it = f(rows, A), f(rows, 2 * A)
-            ws.gates, ws.lo, ws.cs, ws.hp, ws.dlo = f(rows, 4 * F), f(rows, F), f(rows, F), f(rows, F), f(rows, F)
-            # ... and for the critic pass over cat(obs, obs_next) (T = N + 1, ppo.py:376-386)
+        if stem:
             R1 = B * (N + 1)
-            ws.xcat = f(B, N + 1, D)
-            ws.gatesG, ws.loG, ws.csG = f(R1, 4 * F), f(R1, F), f(R1, F)
+            ws.h0 = ws.c0 = ws.cnn_it = ws.cnn_gae = ws.frames_it = None
+            ws.low_it = f(rows, D)                    # obs[:, :E] (raw: also feeds z_update)
+            ws.act_it, ws.beh_it = f(rows, A), f(rows, 2 * A)
+            ws.ztmp = f(R1, D)
+            ws.lcat, ws.xcat = f(B, N + 1, D), f(R1, Dx)     # critic pass over cat(obs, obs_next)
             ws.h1G, ws.h2G = f(R1, cri.H1), f(R1, cri.H2)
+            if rnn:
+                # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E)
+                # and for the critic pass (T = N + 1, ppo.py:376-386)
+                F = self.model.rnn_hidden
+                ws.h0, ws.c0 = f(B, F), f(B, F)
+                ws.gates, ws.lo, ws.cs, ws.hp, ws.dlo = f(rows, 4 * F), f(rows, F), f(rows, F), f(rows, F), f(rows, F)
+                ws.gatesG, ws.loG, ws.csG = f(R1, 4 * F), f(R1, F), f(R1, F)
+            if pixel:
+                # CNN stem (builders.py:8-33): frames stay in their source dtype (uint8 from the
+                # cameras); the critic pass runs the stem in chunks to bound the patch matrices
+                from surreal_amd.model.cnn_stem import CnnStem
+                cnn = self.model.cnn
+                cam = (cnn.C, cnn.H, cnn.W)
+                ws.frames_it = torch.empty((rows,) + cam, device=dev, dtype=pix_dtype)
+                ws.fcat = torch.empty((B, N + 1) + cam, device=dev, dtype=pix_dtype)
+                ws.dxn = torch.zeros(rows, Dx, device=dev)
+                chunk = int(self.session_config.learner.get('cnn_chunk_frames', 2048))
+                ws.cnn_it = CnnStem.workspace(cnn, rows, dev, backward=True)
+                ws.cnn_gae = ws.cnn_it if rows >= min(chunk, R1) else \
+                    CnnStem.workspace(cnn, min(chunk, R1), dev, backward=False)
         else:
             # transposed copies [features, rows] feeding the weight-gradient GEMMs (K-contiguous)
             # (row stride padded off the power of two: all 32 rows of a fragment load would
@@ -314,13 +333,23 @@ class PPOLearner(Learner):
             return x.to(self.device, torch.float32)
         return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.device)
 
+    def _to_dev_pixels(self, x):
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x))
+        if x.dtype != torch.uint8:
+            x = x.to(torch.float32)
+        return x.to(self.device)
+
     def _preprocess_batch_ppo(self, batch):
         """numpy -> device fp32 tensors (ppo.py:420-484); device tensors pass through"""
         obs, obs_next = batch['obs'], batch['obs_next']
         for modality in obs:
             for key in obs[modality]:
-                obs[modality][key] = self._to_dev(obs[modality][key])
-                obs_next[modality][key] = self._to_dev(obs_next[modality][key])
+                # camera frames stay uint8 (the CNN stem's patch kernel applies x / 255 while it
+                # reads them; the reference converts the whole batch to fp32 first, ppo.py:436-441)
+                conv = self._to_dev_pixels if modality == 'pixel' else self._to_dev
+                obs[modality][key] = conv(obs[modality][key])
+                obs_next[modality][key] = conv(obs_next[modality][key])
         batch['actions'] = self._to_dev(batch['actions'])
         rewards = self._to_dev(batch['rewards'])
         if self.reward_scale != 1.0:
@@ -497,10 +526,12 @@ class PPOLearner(Learner):
                             ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
-    def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds):
+    def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds, pix=None,
+                          pix_next=None):
         """the whole of _optimize (ppo.py:487-586) as a launch sequence"""
-        if self.if_rnn_policy:
-            return self._enqueue_optimize_rnn(ws, obs, obs_next, actions, rewards, dones, pds)
+        if self.if_rnn_policy or self.model.if_pixel:
+            return self._enqueue_optimize_stem(ws, obs, obs_next, actions, rewards, dones, pds, pix,
+                                               pix_next)
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
@@ -568,25 +599,49 @@ class PPOLearner(Learner):
                                  m.z_filter.count, B)
 
     # ======================================================================================
-    # LSTM policy (algo.rnn.if_rnn_policy, the reference default): the stem is shared by the
-    # actor and the critic and belongs to BOTH optimiser groups (ppo_net.py:202-224), so the
-    # value epochs see the stem the policy epochs left behind -- the two loops run one after
-    # the other exactly as ppo.py:541-562 does (no lock-step sharing here).
+    # Policies with a shared stem: the LSTM stem (algo.rnn.if_rnn_policy, the reference
+    # default) and / or the CNN stem (pixel observations).  A stem belongs to BOTH optimiser
+    # groups (ppo_net.py:202-224), so the value epochs see the stem the policy epochs left
+    # behind: the two loops run one after the other exactly as ppo.py:541-562 does (no
+    # lock-step sharing here).  Stem input rows are [z(low_dim) | cnn(camera0 / 255)].
     # ======================================================================================
-    def _enqueue_gae_rnn(self, ws, obs, obs_next, rewards, dones):
-        """critic over the whole (B, N+1) sequence from the stored cells + windowed GAE with
-        horizon H (ppo.py:376-418, RNN branch)"""
+    def _stem_inputs(self, ws, mm, low2d, frames, xin, cnn_ws, zstats, stop=None):
+        """xin[:, :D] = z-filter(low_dim rows) -- skipped when zstats is False (already there);
+        xin[:, D:] = CNN features of `frames` under model `mm` (chunked over cnn_ws.F frames)"""
+        K = self.K
+        D = low2d.shape[1]
+        if zstats is not False:
+            if self.use_z_filter:
+                K.zfilter_forward(low2d, zstats[0], zstats[1], ws.ztmp[:low2d.shape[0]])
+                xin[:, :D].copy_(ws.ztmp[:low2d.shape[0]])
+            else:
+                xin[:, :D].copy_(low2d)
+        if frames is not None:
+            nF = frames.shape[0]
+            for f0 in range(0, nF, cnn_ws.F):
+                f1 = min(nF, f0 + cnn_ws.F)
+                mm._cnn_stem.forward(mm.cnn, frames[f0:f1], f1 - f0, cnn_ws, xin[f0:f1, D:], stop)
+
+    def _enqueue_gae_stem(self, ws, obs, obs_next, pix, pix_next, rewards, dones):
+        """critic over all (B, N+1) steps + windowed GAE with horizon H (ppo.py:376-418)"""
         K, m = self.K, self.model
         B, N, D = obs.shape
-        ws.xcat[:, :N].copy_(obs)                       # torch.cat([obs, obs_next], 1)
-        ws.xcat[:, N:].copy_(obs_next)
-        x2 = ws.xcat.view(B * (N + 1), D)
-        if self.use_z_filter:
-            zm, zs = m.z_filter.refresh_stats()
-            K.zfilter_forward(x2, zm, zs, x2)
-        K.lstm_forward(m.rnn, x2, B, N + 1, ws.h0, ws.c0, ws.gatesG, ws.loG, ws.csG)
-        K.mlp3_forward(m.critic, ws.loG, ws.h1G, ws.h2G, ws.vals.view(-1, 1), L.SMX_ACT_NONE)
-        H = self.horizon
+        rnn = self.if_rnn_policy
+        ws.lcat[:, :N].copy_(obs)                       # torch.cat([obs, obs_next], 1)
+        ws.lcat[:, N:].copy_(obs_next)
+        frames = None
+        if m.if_pixel:
+            ws.fcat[:, :N].copy_(pix)
+            ws.fcat[:, N:].copy_(pix_next)
+            frames = ws.fcat.view((B * (N + 1),) + tuple(ws.fcat.shape[2:]))
+        zst = m.z_filter.refresh_stats() if self.use_z_filter else None
+        self._stem_inputs(ws, m, ws.lcat.view(B * (N + 1), D), frames, ws.xcat, ws.cnn_gae, zst)
+        x = ws.xcat
+        if rnn:
+            K.lstm_forward(m.rnn, ws.xcat, B, N + 1, ws.h0, ws.c0, ws.gatesG, ws.loG, ws.csG)
+            x = ws.loG
+        K.mlp3_forward(m.critic, x, ws.h1G, ws.h2G, ws.vals.view(-1, 1), L.SMX_ACT_NONE)
+        H = self.horizon if rnn else N
         K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** H, B, N, H,
               ws.adv, ws.ret)
         if self.norm_adv:
@@ -596,12 +651,24 @@ class PPOLearner(Learner):
                 K.moments_merge(ws.mom_parts, ws.adv_mom)
             K.adv_normalize(ws.adv, ws.adv_mom, 1e-4)
 
-    def _rnn_policy_forward(self, ws, e):
+    def _stem_forward(self, ws, mm, xin, stop, save=True):
+        """features of the current stem weights -> the MLP input (ws.lo with the LSTM, xin without)"""
+        K = self.K
+        B, E = ws.key[0], ws.E
+        if mm.if_pixel:
+            self._stem_inputs(ws, mm, ws.low_it, ws.frames_it, xin, ws.cnn_it, False, stop)
+        if not mm.if_rnn:
+            return xin
+        K.lstm_forward(mm.rnn, xin, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs,
+                       ws.hp if save else None, stop=stop)
+        return ws.lo
+
+    def _stem_policy_forward(self, ws, e):
         K, m = self.K, self.model
-        B, E, A, W = ws.key[0], ws.E, self.action_dim, self.world_size
+        A, W = self.action_dim, self.world_size
         mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
-        K.lstm_forward(m.rnn, ws.xn, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs, ws.hp, stop=ws.stop)
-        K.mlp3_forward(m.actor, ws.lo, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
+        x = self._stem_forward(ws, m, ws.xn, ws.stop)
+        K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
         K.policy_loss(mode, ws.mean, m.log_var.view(-1), ws.act_it, ws.beh_it, ws.ref_pol, ws.adv,
                       ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
         part, nblk = ws.ppart, ws.nblk_p
@@ -614,22 +681,32 @@ class PPOLearner(Learner):
                           ws.grads_a[m.actor.numel:m.actor.numel + A],
                           ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
 
-    def _rnn_backward(self, ws, net, h1, h2, dz3, dz2, dz1, g_mlp, g_rnn, stop):
-        """MLP backward, its input gradient, BPTT through the stem"""
+    def _stem_backward(self, ws, net, h1, h2, dz3, dz2, dz1, g_mlp, g_cnn, g_rnn, stop):
+        """MLP backward, then back through the stems it sits on"""
         K, m = self.K, self.model
-        B, E, F = ws.key[0], ws.E, m.rnn_hidden
-        K.mlp3_backward(net, ws.lo, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
-        # d loss / d (LSTM output) = dz1 . W1
-        K.linear(dz1, 1, net.views['W1'], 0, None, ws.dlo, ws.rows, F, net.H1, stop=stop)
-        K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates, g_rnn,
-                        stop)
+        B, E, D = ws.key[0], ws.E, ws.key[2]
+        x = ws.lo if m.if_rnn else ws.xn
+        K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
+        if m.if_rnn:
+            # d loss / d (LSTM output) = dz1 . W1, then BPTT (dgates overwrite the saved gates)
+            K.linear(dz1, 1, net.views['W1'], 0, None, ws.dlo, ws.rows, m.rnn_hidden, net.H1, stop=stop)
+            K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates, g_rnn,
+                            stop)
+            up, upW, upK = ws.gates, m.rnn.views['weight_ih'], 4 * m.rnn_hidden
+        else:
+            up, upW, upK = dz1, net.views['W1'], net.H1
+        if m.if_pixel:
+            # d loss / d (CNN features) = upstream . W[:, D:], times the feature ReLU's mask
+            K.linear(up, 1, upW[:, D:], 0, None, ws.dxn[:, D:], ws.rows, m.cnn_feature_dim, upK,
+                     relu_mask=ws.xn[:, D:], stop=stop)
+            m._cnn_stem.backward(m.cnn, ws.rows, ws.cnn_it, ws.dxn[:, D:], g_cnn, stop)
 
-    def _rnn_policy_update(self, ws, e):
+    def _stem_policy_update(self, ws, e):
         K, m = self.K, self.model
-        A = self.action_dim
-        n_mlp, n0 = m.actor.numel, m.actor_flat.numel() - m.n_rnn
-        self._rnn_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a,
-                           ws.grads_a[:n_mlp], ws.grads_a[n0:], ws.stop)
+        n_mlp, n0 = m.actor.numel, m.n_actor_block
+        self._stem_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a,
+                            ws.grads_a[:n_mlp], ws.grads_a[n0:n0 + m.n_cnn],
+                            ws.grads_a[n0 + m.n_cnn:], ws.stop)
         if self.world_size > 1:      # log_var's gradient is global already (all-reduced partials)
             self._dist.all_reduce(ws.grads_a[:n_mlp])
             self._dist.all_reduce(ws.grads_a[n0:])
@@ -638,19 +715,19 @@ class PPOLearner(Learner):
                     ws.sumsq_a, K.sumsq_blocks(ws.grads_a.numel()), ws.ctrl_f, 0, True,
                     ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
 
-    def _rnn_value_epoch(self, ws, e):
+    def _stem_value_epoch(self, ws, e):
         K, m = self.K, self.model
-        B, E = ws.key[0], ws.E
-        K.lstm_forward(m.rnn, ws.xn, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs, ws.hp)
-        K.mlp3_forward(m.critic, ws.lo, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
+        x = self._stem_forward(ws, m, ws.xn, None)
+        K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
         n_total = ws.rows * self.world_size
         if self.world_size > 1:
             K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
             self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
         else:
             K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
-        self._rnn_backward(ws, m.critic, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
-                           ws.grads_c[m.n_rnn:], ws.grads_c[:m.n_rnn], None)
+        self._stem_backward(ws, m.critic, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
+                            ws.grads_c[m.n_stem:], ws.grads_c[:m.n_cnn], ws.grads_c[m.n_cnn:m.n_stem],
+                            None)
         if self.world_size > 1:
             self._dist.all_reduce(ws.grads_c)
         K.sumsq_partials(ws.grads_c, ws.sumsq_c)
@@ -658,39 +735,41 @@ class PPOLearner(Learner):
                     ws.sumsq_c, K.sumsq_blocks(ws.grads_c.numel()), ws.ctrl_f, 1, False,
                     ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
 
-    def _enqueue_optimize_rnn(self, ws, obs, obs_next, actions, rewards, dones, pds):
-        """_optimize with the LSTM stem (ppo.py:487-586, `if self.if_rnn_policy` branches)"""
+    def _enqueue_optimize_stem(self, ws, obs, obs_next, actions, rewards, dones, pds, pix, pix_next):
+        """_optimize with the LSTM and / or CNN stem (ppo.py:487-586)"""
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A, E = self.action_dim, ws.E
         ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
         ws.pstats.zero_()
-        self._enqueue_gae_rnn(ws, obs, obs_next, rewards, dones)
+        self._enqueue_gae_stem(ws, obs, obs_next, pix, pix_next, rewards, dones)
 
-        ws.xit.copy_(obs[:, :E])                         # ppo.py:521-537
+        # obs_iter: the first E steps of every sub-trajectory (E = 1 without the LSTM; ppo.py:521-537)
+        ws.low_it.view(B, E, D).copy_(obs[:, :E])
         ws.act_it.view(B, E, A).copy_(actions[:, :E])
         ws.beh_it.view(B, E, 2 * A).copy_(pds[:, :E])
-        x2 = ws.xit.view(B * E, D)
-        if self.use_z_filter:
-            zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed in _enqueue_gae_rnn
-            K.zfilter_forward(x2, zm, zs, ws.xn)
-            rzm, rzs = ref.z_filter.refresh_stats()
-            K.zfilter_forward(x2, rzm, rzs, ws.xr)
-        else:
-            ws.xn.copy_(x2)
-            ws.xr.copy_(x2)
+        if m.if_pixel:
+            ws.frames_it.view((B, E) + tuple(pix.shape[2:])).copy_(pix[:, :E])
+        zst = (m.z_filter._mean, m.z_filter._std) if self.use_z_filter else None   # refreshed in the GAE pass
+        rzst = ref.z_filter.refresh_stats() if self.use_z_filter else None
+        self._stem_inputs(ws, m, ws.low_it, None, ws.xn, None, zst)     # CNN part: every forward
+        self._stem_inputs(ws, ref, ws.low_it, ws.frames_it if m.if_pixel else None, ws.xr,
+                          ws.cnn_it if m.if_pixel else None, rzst)
         # ref_pol = ref_target_model.forward_actor(obs_iter, cells)   (ppo.py:539)
-        K.lstm_forward(ref.rnn, ws.xr, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs)
-        K.mlp3_forward(ref.actor, ws.lo, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
+        x = ws.xr
+        if ref.if_rnn:
+            K.lstm_forward(ref.rnn, ws.xr, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs)
+            x = ws.lo
+        K.mlp3_forward(ref.actor, x, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
         ws.ref_pol[:, :A].copy_(ws.ref_mean)
         ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
 
-        self._rnn_policy_forward(ws, 0)
+        self._stem_policy_forward(ws, 0)
         for e in range(self.epoch_policy):
-            self._rnn_policy_update(ws, e)
-            self._rnn_policy_forward(ws, e + 1)
+            self._stem_policy_update(ws, e)
+            self._stem_policy_forward(ws, e + 1)
         for e in range(self.epoch_baseline):
-            self._rnn_value_epoch(ws, e)
+            self._stem_value_epoch(ws, e)
         K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
         K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
@@ -700,13 +779,13 @@ class PPOLearner(Learner):
         if self.use_z_filter:                   # model.z_update(obs_iter)  (ppo.py:578-579)
             if self.world_size > 1:
                 ws.zdelta.zero_()
-                K.zfilter_update(x2, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], B * E)
+                K.zfilter_update(ws.low_it, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], B * E)
                 self._dist.all_reduce(ws.zdelta)
                 m.z_filter.running_sum += ws.zdelta[:D]
                 m.z_filter.running_sumsq += ws.zdelta[D:2 * D]
                 m.z_filter.count += ws.zdelta[2 * D:]
             else:
-                K.zfilter_update(x2, m.z_filter.running_sum, m.z_filter.running_sumsq,
+                K.zfilter_update(ws.low_it, m.z_filter.running_sum, m.z_filter.running_sumsq,
                                  m.z_filter.count, B * E)
 
     def _side_stream(self):
@@ -725,9 +804,13 @@ class PPOLearner(Learner):
         B, N, D = x.shape
         assert B == self.batch_size and N == self.n_step, \
             'batch is (%d, %d) but config says batch_size=%d n_step=%d' % (B, N, self.batch_size, self.n_step)
-        ws = self._workspace(B, N, D, self.action_dim)
+        pix = pix_next = None
+        if self.model.if_pixel:                   # one camera (ppo_net.py:269 "assumes only one camera angle")
+            pix = obs['pixel']['camera0'].contiguous()
+            pix_next = obs_next['pixel']['camera0'].contiguous()
+        ws = self._workspace(B, N, D, self.action_dim, pix.dtype if pix is not None else None)
         self._ensure_ctrl(ws)
-        args = (x, xn, actions, rewards, dones, pds)
+        args = (x, xn, actions, rewards, dones, pds) + ((pix, pix_next) if pix is not None else ())
         if self.if_rnn_policy:
             # agent-side LSTM state at the head of every sub-trajectory (ppo.py:511-515):
             # (B, layers=1, H) -> the kernels' [B, H]
@@ -844,14 +927,18 @@ class PPOLearner(Learner):
         """-> (advantages (B,1), returns (B,1)) as ppo.py:355-418 returns them"""
         x, xn = self._flat_obs(obs), self._flat_obs(obs_next)
         B, N, D = x.shape
-        ws = self._workspace(B, N, D, self.action_dim)
+        ws = self._workspace(B, N, D, self.action_dim,
+                             obs['pixel']['camera0'].dtype if self.model.if_pixel else None)
         self._ensure_ctrl(ws)
-        if self.if_rnn_policy:
-            if self.cells is None:
-                ws.h0.zero_(); ws.c0.zero_()
-            else:
-                ws.h0.copy_(self.cells[0].reshape(B, -1)); ws.c0.copy_(self.cells[1].reshape(B, -1))
-            self._enqueue_gae_rnn(ws, x, xn, rewards.contiguous(), dones.contiguous())
+        if self.if_rnn_policy or self.model.if_pixel:
+            if self.if_rnn_policy:
+                if self.cells is None:
+                    ws.h0.zero_(); ws.c0.zero_()
+                else:
+                    ws.h0.copy_(self.cells[0].reshape(B, -1)); ws.c0.copy_(self.cells[1].reshape(B, -1))
+            pix = obs['pixel']['camera0'] if self.model.if_pixel else None
+            pixn = obs_next['pixel']['camera0'] if self.model.if_pixel else None
+            self._enqueue_gae_stem(ws, x, xn, pix, pixn, rewards.contiguous(), dones.contiguous())
         else:
             self._enqueue_gae(ws, x, xn, rewards.contiguous(), dones.contiguous())
         return ws.adv.view(B, -1).clone(), ws.ret.view(B, -1).clone()

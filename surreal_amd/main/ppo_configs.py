@@ -51,9 +51,10 @@ def ppo_learner_config(**algo_overrides):
     return cfg
 
 
-def ppo_env_config(obs_dim, action_dim, env_name='synthetic:flat'):
+def ppo_env_config(obs_dim, action_dim, env_name='synthetic:flat', pixel=None):
     """obs_spec / action_spec in the format make_env_config derives at run time
-    (surreal/env/make_env.py:16-38, docs/env.md:48-77)"""
+    (surreal/env/make_env.py:16-38, docs/env.md:48-77); pixel = (C, H, W) adds the camera0
+    frames and sets pixel_input (ppo_configs.py:100,112)"""
     cfg = Config({
         'env_name': env_name,
         'action_repeat': 1,
@@ -66,6 +67,9 @@ def ppo_env_config(obs_dim, action_dim, env_name='synthetic:flat'):
         'action_spec': {'dim': [action_dim], 'type': 'continuous'},
         'obs_spec': {'low_dim': {'flat_inputs': [obs_dim]}},
     })
+    if pixel is not None:
+        cfg.pixel_input = True
+        cfg.obs_spec['pixel'] = {'camera0': [int(v) for v in pixel]}
     cfg.extend(BASE_ENV_CONFIG)
     return cfg
 

@@ -15,6 +15,7 @@ import torch
 
 from surreal_amd import _lib as L
 from surreal_amd import kernels as KN
+from surreal_amd.model.cnn_stem import CnnParams, CnnStem
 
 
 class DiagGauss(object):
@@ -164,8 +165,7 @@ class PPOModel(object):
                  kernels=None):
         self.K = kernels or KN.default_kernels()     # raises without the HIP library / a GPU
         device = device or KN.default_device()
-        if if_pixel_input:
-            raise NotImplementedError('pixel (CNN stem) observations are not built yet')
+        self.if_pixel = bool(if_pixel_input)
         self.if_rnn = bool(rnn_config is not None and rnn_config.get('if_rnn_policy', False))
         if self.if_rnn and int(rnn_config.get('rnn_layer', 1)) != 1:
             raise NotImplementedError('only rnn_layer = 1 (the reference default) is built')
@@ -184,19 +184,26 @@ class PPOModel(object):
         D, A = self.low_dim, action_dim
         ah, ch = model_config['actor_fc_hidden_sizes'], model_config['critic_fc_hidden_sizes']
         self.rnn_hidden = int(rnn_config.rnn_hidden) if self.if_rnn else 0
-        F = self.rnn_hidden if self.if_rnn else D        # input width of the MLPs (ppo_net.py:155-156)
+        self.cnn_feature_dim = int(model_config['cnn_feature_dim']) if self.if_pixel else 0
+        Dx = D + self.cnn_feature_dim                    # stem input width (ppo_net.py:145)
+        self.stem_in = Dx
+        F = self.rnn_hidden if self.if_rnn else Dx       # input width of the MLPs (ppo_net.py:155-156)
         # the actor block is padded to a 16-byte boundary (the pad has zero gradient, so Adam
         # leaves it alone): the GEMM kernels take 16-byte operand loads only from aligned bases
         n_actor = (Mlp3Params.count(F, ah[0], ah[1], A) + A + 3) & ~3
-        n_rnn = LstmParams.count(D, self.rnn_hidden) if self.if_rnn else 0
+        cam = tuple(obs_spec['pixel']['camera0']) if self.if_pixel else None
+        n_cnn = CnnParams.count(cam, self.cnn_feature_dim) if self.if_pixel else 0
+        n_rnn = LstmParams.count(Dx, self.rnn_hidden) if self.if_rnn else 0
         n_critic = Mlp3Params.count(F, ch[0], ch[1], 1)
-        self.flat = torch.zeros(n_actor + n_rnn + n_critic, device=device)
-        self.n_rnn = n_rnn
-        self.actor_flat = self.flat[:n_actor + n_rnn]     # optimiser group: actor (+ shared stem)
-        self.critic_flat = self.flat[n_actor:]            # optimiser group: (shared stem +) critic
+        self.flat = torch.zeros(n_actor + n_cnn + n_rnn + n_critic, device=device)
+        self.n_actor_block, self.n_cnn, self.n_rnn, self.n_stem = n_actor, n_cnn, n_rnn, n_cnn + n_rnn
+        self.actor_flat = self.flat[:n_actor + self.n_stem]   # optimiser group: actor (+ shared stems)
+        self.critic_flat = self.flat[n_actor:]                # optimiser group: (shared stems +) critic
         self.actor = Mlp3Params(self.flat, 0, F, ah[0], ah[1], A)
-        self.rnn = LstmParams(self.flat, n_actor, D, self.rnn_hidden) if self.if_rnn else None
-        self.critic = Mlp3Params(self.flat, n_actor + n_rnn, F, ch[0], ch[1], 1)
+        self.cnn = CnnParams(self.flat, n_actor, cam, self.cnn_feature_dim) if self.if_pixel else None
+        self.rnn = LstmParams(self.flat, n_actor + n_cnn, Dx, self.rnn_hidden) if self.if_rnn else None
+        self.critic = Mlp3Params(self.flat, n_actor + self.n_stem, F, ch[0], ch[1], 1)
+        self._cnn_stem = CnnStem(self.K) if self.if_pixel else None
         self.log_var = self.flat[self.actor.numel:self.actor.numel + A].view(1, A)
         self._init_parameters()
         if use_z_filter:
@@ -211,6 +218,8 @@ class PPOModel(object):
                 fan_in = net.views['W' + name[1]].shape[1]
                 v.uniform_(-1.0 / np.sqrt(fan_in), 1.0 / np.sqrt(fan_in))
         self.log_var.fill_(float(self.init_log_sig))
+        if self.if_pixel:
+            self.cnn.init_torch_default()
         if self.if_rnn:                          # torch.nn.LSTM default: U(-1/sqrt(H), 1/sqrt(H))
             b = 1.0 / np.sqrt(self.rnn_hidden)
             for v in self.rnn.views.values():
@@ -225,6 +234,9 @@ class PPOModel(object):
                 out['%s.fc%d.b' % (pre, i)] = net.views['b%d' % i]
             if pre == 'actor':
                 out['actor.log_var'] = self.log_var
+        if self.if_pixel:
+            for k, v in self.cnn.views.items():
+                out['cnn.' + k] = v
         if self.if_rnn:
             for k, v in self.rnn.views.items():
                 out['rnn.' + k] = v
@@ -295,6 +307,16 @@ class PPOModel(object):
         x = self._gather_low_dim_input(obs)
         if self.use_z_filter:
             x = self.z_filter.forward(x)
+        if self.if_pixel:                        # ppo_net.py:268-275: cat(z(low_dim), cnn(camera0 / 255))
+            pix = obs['pixel']['camera0']
+            lead = tuple(pix.shape[:-3])
+            frames = pix.reshape((-1,) + tuple(pix.shape[-3:])).contiguous()
+            nF = frames.shape[0]
+            xin = torch.empty(nF, self.stem_in, device=frames.device)
+            xin[:, :self.low_dim].copy_(x.reshape(nF, self.low_dim))
+            cws = CnnStem.workspace(self.cnn, nF, frames.device, backward=False)
+            self._cnn_stem.forward(self.cnn, frames, nF, cws, xin[:, self.low_dim:])
+            x = xin.view(lead + (self.stem_in,))
         if not self.if_rnn:
             return x, cells
         assert x.dim() == 3, 'the LSTM stem takes (batch, time, features) observations'

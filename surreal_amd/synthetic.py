@@ -33,7 +33,9 @@ PPO_CONFIGS = {
 
 
 def make_ppo_batch(B, N, D, A, seed=0, done_prob=0.01, on_policy=True,
-                   init_log_sig=-1.0, rnn_hidden=0, rnn_layers=1):
+                   init_log_sig=-1.0, rnn_hidden=0, rnn_layers=1, pixel=None):
+    """pixel = (C, H, W) adds uint8 camera frames obs['pixel']['camera0'] (B, N, C, H, W) and
+    obs_next (B, 1, C, H, W), drawn after everything else (older cases keep their bits)"""
     rs = np.random.RandomState(seed)
     obs = rs.randn(B, N, D).astype(np.float32)
     obs_next = rs.randn(B, 1, D).astype(np.float32)
@@ -52,11 +54,17 @@ def make_ppo_batch(B, N, D, A, seed=0, done_prob=0.01, on_policy=True,
     if rnn_hidden:
         onetime = [(0.1 * rs.randn(B, rnn_layers, rnn_hidden)).astype(np.float32),
                    (0.1 * rs.randn(B, rnn_layers, rnn_hidden)).astype(np.float32)]
+    obs_d = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=obs))
+    obs_next_d = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=obs_next))
+    if pixel is not None:
+        C, H, W = pixel
+        obs_d['pixel'] = collections.OrderedDict(
+            camera0=rs.randint(0, 256, (B, N, C, H, W)).astype(np.uint8))
+        obs_next_d['pixel'] = collections.OrderedDict(
+            camera0=rs.randint(0, 256, (B, 1, C, H, W)).astype(np.uint8))
     return {
-        'obs': collections.OrderedDict(
-            low_dim=collections.OrderedDict(flat_inputs=obs)),
-        'obs_next': collections.OrderedDict(
-            low_dim=collections.OrderedDict(flat_inputs=obs_next)),
+        'obs': obs_d,
+        'obs_next': obs_next_d,
         'actions': actions,
         'rewards': rewards,
         'dones': dones,
@@ -66,7 +74,7 @@ def make_ppo_batch(B, N, D, A, seed=0, done_prob=0.01, on_policy=True,
 
 
 def make_ppo_params(D, A, hidden=(300, 200), seed=1, init_log_sig=-1.0,
-                    rnn_hidden=0, final_scale=0.05):
+                    rnn_hidden=0, final_scale=0.05, pixel=None, cnn_feature_dim=256):
     """
     Canonical flat parameter dict (numpy fp32), the *injected* initial state
     for both the oracle and the HIP path.  Kaiming-uniform-like fan-in scaling
@@ -83,10 +91,26 @@ def make_ppo_params(D, A, hidden=(300, 200), seed=1, init_log_sig=-1.0,
         p[name + '.W'] = (scale * rs.uniform(-bound, bound, (out_f, in_f))).astype(np.float32)
         p[name + '.b'] = (scale * rs.uniform(-bound, bound, (out_f,))).astype(np.float32)
 
-    in_f = rnn_hidden if rnn_hidden else D
+    Dx = D                                   # width after the optional CNN stem (ppo_net.py:145,155)
+    if pixel is not None:
+        # CNNStemNetwork (builders.py:8-21), drawn from its own stream (older cases keep their bits)
+        rc = np.random.RandomState(seed + 1000)
+        C, H, W = pixel
+        h1_, w1_ = (H - 8) // 4 + 1, (W - 8) // 4 + 1
+        h2_, w2_ = (h1_ - 4) // 2 + 1, (w1_ - 4) // 2 + 1
+
+        def cnn(name, shape):
+            bound = 1.0 / np.sqrt(np.prod(shape[1:]))
+            p['cnn.%s.W' % name] = rc.uniform(-bound, bound, shape).astype(np.float32)
+            p['cnn.%s.b' % name] = rc.uniform(-bound, bound, shape[:1]).astype(np.float32)
+        cnn('conv1', (16, C, 8, 8))
+        cnn('conv2', (32, 16, 4, 4))
+        cnn('fc', (cnn_feature_dim, 32 * h2_ * w2_))
+        Dx = D + cnn_feature_dim
+    in_f = rnn_hidden if rnn_hidden else Dx
     if rnn_hidden:
         bound = 1.0 / np.sqrt(rnn_hidden)
-        p['rnn.weight_ih'] = rs.uniform(-bound, bound, (4 * rnn_hidden, D)).astype(np.float32)
+        p['rnn.weight_ih'] = rs.uniform(-bound, bound, (4 * rnn_hidden, Dx)).astype(np.float32)
         p['rnn.weight_hh'] = rs.uniform(-bound, bound, (4 * rnn_hidden, rnn_hidden)).astype(np.float32)
         p['rnn.bias_ih'] = rs.uniform(-bound, bound, (4 * rnn_hidden,)).astype(np.float32)
         p['rnn.bias_hh'] = rs.uniform(-bound, bound, (4 * rnn_hidden,)).astype(np.float32)

@@ -36,8 +36,10 @@ def golden_cases(rnn=None):
                    if f.startswith('ppo_') and f.endswith('.npz'))
     out = []
     for n in names:
-        is_rnn = 'rnn' in n
-        if rnn is None or rnn == is_rnn:
+        # "rnn" selects the policies with a shared stem (LSTM and / or CNN), which take the
+        # sequential epoch schedule; rnn=False the plain-MLP cases
+        has_stem = 'rnn' in n or 'pixel' in n
+        if rnn is None or rnn == has_stem:
             out.append(n)
     return out
 
@@ -52,10 +54,12 @@ def case_inputs(case):
     """regenerate the seeded inputs / injected parameters of a golden case"""
     shp, hyper = case['shape'], case['hyper']
     rnn_hidden = case.get('rnn_hidden', 0) if hyper.get('if_rnn_policy') else 0
+    pixel = tuple(case['pixel']) if case.get('pixel') else None
+    pix_kw = dict(pixel=pixel, cnn_feature_dim=case['cnn_feature_dim']) if pixel else {}
     batch = synthetic.make_ppo_batch(shp['B'], shp['N'], shp['D'], shp['A'], rnn_hidden=rnn_hidden,
-                                     **case['batch_args'])
+                                     pixel=pixel, **case['batch_args'])
     params = synthetic.make_ppo_params(shp['D'], shp['A'], hidden=tuple(case['hidden']),
-                                       rnn_hidden=rnn_hidden, **case['param_args'])
+                                       rnn_hidden=rnn_hidden, **pix_kw, **case['param_args'])
     zstate = (synthetic.make_zfilter_state(shp['D'], **case['z_args'])
               if hyper.get('use_z_filter', True) else None)
     return batch, params, zstate
@@ -87,7 +91,9 @@ def make_learner(case, params, zstate, cls=None, session_overrides=None):
     sc = ppo_session_config()
     for k, v in (session_overrides or {}).items():
         sc.learner[k] = v
-    learner = cls(lc, ppo_env_config(shp['D'], shp['A']), sc)
+    if case.get('pixel'):
+        lc.model.cnn_feature_dim = case['cnn_feature_dim']
+    learner = cls(lc, ppo_env_config(shp['D'], shp['A'], pixel=case.get('pixel')), sc)
     learner.model.load_params(params)
     learner.ref_target_model.load_params(params)
     if zstate is not None:
@@ -133,7 +139,7 @@ def assert_final_params(learner, g, case, atol=2e-5, what=''):
     lr = max(case['hyper'].get('lr_actor', 1e-4), case['hyper'].get('lr_critic', 1e-4))
     for k, (s, sq) in ck.items():
         # the shared LSTM stem is stepped by both optimisers (10 policy + 10 value epochs)
-        loose = 2 * lr * (20 if k.startswith('rnn.') else 10)
+        loose = 2 * lr * (20 if k.startswith(('rnn.', 'cnn.')) else 10)
         a = got[k].astype(np.float64)
         if 'final.' + k in g:
             ref = g['final.' + k]

@@ -53,9 +53,10 @@ def test_learner_matches_reference_golden_graph(name):
 
 @pytest.mark.parametrize('name', RNN)
 def test_rnn_learner_matches_reference_golden_graph(name):
-    """LSTM-stem policy (algo.rnn.if_rnn_policy, the reference default; cfg1 is the shape of the
-    reference's own test_ppo_gym --unit-test run): BPTT through the stem in both optimiser
-    groups, horizon-H windowed GAE over the (B, N+1) critic sequence"""
+    """policies with a shared stem -- LSTM (algo.rnn.if_rnn_policy, the reference default; cfg1 is
+    the shape of the reference's own test_ppo_gym --unit-test run), CNN over uint8 camera frames
+    (cfg4 = 3x84x84 SawyerLift frames + robot state), and both: back-propagation through the
+    stems in both optimiser groups, horizon-H windowed GAE over the (B, N+1) critic sequence"""
     check_case(name, *run_case(name))
 
 
@@ -128,15 +129,3 @@ def test_rnn_three_learns_match_oracle():
                 np.testing.assert_allclose(sl[k], so[k], atol=at, rtol=rt,
                                            err_msg='iteration %d stat %s' % (it, k))
     assert len(learner._graphs) == 1
-
-
-def test_pixel_policy_is_refused_loudly():
-    from surreal_amd.main.ppo_configs import ppo_env_config
-    g, case = H.load_golden('tiny_clip')
-    _, params, zstate = H.case_inputs(case)
-    import surreal_amd.main.ppo_configs as C
-    env = C.ppo_env_config(case['shape']['D'], case['shape']['A'])
-    env.pixel_input = True
-    from surreal_amd.learner.ppo import PPOLearner
-    with pytest.raises(NotImplementedError):
-        PPOLearner(C.ppo_learner_config(), env, C.ppo_session_config())
