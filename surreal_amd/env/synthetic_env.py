@@ -33,22 +33,37 @@ def _drift(D):
 
 
 class SyntheticEnv(Env):
-    def __init__(self, obs_dim, action_dim, episode_len=200, seed=0):
+    def __init__(self, obs_dim, action_dim, episode_len=200, seed=0, pixel=None):
+        """pixel = (C, H, W): also emit a uint8 camera frame obs['pixel']['camera0'] (a fixed
+        pattern shifted by the step count and the first state component)"""
         self.D, self.A, self.episode_len = obs_dim, action_dim, episode_len
+        self.pixel = tuple(pixel) if pixel is not None else None
         self.rs = np.random.RandomState(seed)
         self.init_state = self.rs.randn(obs_dim).astype(np.float32)
         self.state = self.init_state.copy()
         self.t = 0
 
     def observation_spec(self):
-        return collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=(self.D,)))
+        spec = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=(self.D,)))
+        if self.pixel is not None:
+            spec['pixel'] = collections.OrderedDict(camera0=self.pixel)
+        return spec
+
+    def _frame(self):
+        C, H, W = self.pixel
+        c, y, x = np.meshgrid(np.arange(C), np.arange(H), np.arange(W), indexing='ij')
+        shift = 3 * self.t + int(100 * abs(float(self.state[0])))
+        return ((37 * c + 5 * y + 11 * x + shift) % 256).astype(np.uint8)
 
     def action_spec(self):
         return {'dim': (self.A,), 'type': 'continuous'}
 
     def _obs(self):
-        return collections.OrderedDict(
+        obs = collections.OrderedDict(
             low_dim=collections.OrderedDict(flat_inputs=self.state.copy()))
+        if self.pixel is not None:
+            obs['pixel'] = collections.OrderedDict(camera0=self._frame())
+        return obs
 
     def _reset(self):
         self.state = self.init_state.copy()

@@ -469,3 +469,70 @@ def test_lstm_stop_flag_and_limits(K):
     bad = LstmParams(torch.randn(LstmParams.count(D, 6), device='cuda'), 0, D, 6)     # H % 4 != 0
     with pytest.raises(L.SmxError):
         K.lstm_forward(bad, x, B, T, None, None, gates, out, cs)
+
+
+# ---- CNN stem: data-movement kernels vs the double, whole stem vs torch.nn (ATen conv2d) --------
+@pytest.mark.parametrize('F,C,H,W,k,s,u8,cl', [
+    (3, 3, 20, 20, 8, 4, True, False), (5, 3, 84, 84, 8, 4, True, False),
+    (4, 16, 20, 20, 4, 2, False, True), (2, 2, 13, 17, 4, 2, False, False), (7, 5, 9, 9, 3, 1, False, True),
+])
+def test_im2col_col2im_bit_exact(K, F, C, H, W, k, s, u8, cl):
+    g = torch.Generator().manual_seed(F * 100 + H)
+    Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
+    if u8:
+        src = torch.randint(0, 256, (F, C, H, W), generator=g, dtype=torch.uint8)
+    else:
+        src = torch.randn((F, H * W, C) if cl else (F, C, H, W), generator=g)
+    cols_d, cols_c = torch.empty(F * Ho * Wo, C * k * k, device='cuda'), torch.empty(F * Ho * Wo, C * k * k)
+    div = 255.0 if u8 else 0.0
+    K.im2col(src.cuda(), F, C, H, W, k, s, cols_d, channel_last=cl, scale_div=div)
+    C_ = TorchCpuKernels()
+    C_.im2col(src, F, C, H, W, k, s, cols_c, channel_last=cl, scale_div=div)
+    assert torch.equal(cols_d.cpu(), cols_c)                       # pure data movement (+ x / 255)
+    dcols = torch.randn(F * Ho * Wo, C * k * k, generator=g)
+    act = torch.randn(F * H * W, C, generator=g)
+    dx_d, dx_c = torch.empty(F * H * W, C, device='cuda'), torch.empty(F * H * W, C)
+    K.col2im(dcols.cuda(), F, C, H, W, k, s, act.cuda(), dx_d)
+    C_.col2im(dcols, F, C, H, W, k, s, act, dx_c)
+    close(dx_d, dx_c, atol=1e-6, rtol=1e-6, msg='col2im gather')
+    w = torch.randn(6, C * Ho * Wo, generator=g)
+    a, b = torch.empty(6, C * Ho * Wo, device='cuda'), torch.empty(6, C * Ho * Wo, device='cuda')
+    K.flatten_order(w.cuda(), 6, C, Ho * Wo, True, a)
+    K.flatten_order(a, 6, C, Ho * Wo, False, b)
+    assert torch.equal(b.cpu(), w)
+    assert torch.equal(a.cpu(), w.view(6, C, Ho * Wo).transpose(1, 2).reshape(6, -1))
+
+
+@pytest.mark.parametrize('F,C,H,W,feat', [(3, 3, 20, 20, 8), (5, 2, 36, 28, 24), (16, 3, 84, 84, 256)])
+def test_cnn_stem_forward_backward_match_aten(K, F, C, H, W, feat):
+    import torch.nn as nn
+    from surreal_amd.model.cnn_stem import CnnParams, CnnStem
+    torch.manual_seed(F + H)
+    ref = nn.Sequential(nn.Conv2d(C, 16, 8, 4), nn.ReLU(), nn.Conv2d(16, 32, 4, 2), nn.ReLU(), nn.Flatten())
+    with torch.no_grad():
+        n_flat = ref(torch.zeros(1, C, H, W)).shape[1]
+    fc = nn.Linear(n_flat, feat)
+    frames = torch.randint(0, 256, (F, C, H, W), dtype=torch.uint8)
+    y = torch.relu(fc(ref(frames.float() / 255.0)))
+    dy = torch.randn(F, feat)
+    (y * dy).sum().backward()
+    flat = torch.zeros(CnnParams.count((C, H, W), feat), device='cuda')
+    p = CnnParams(flat, 0, (C, H, W), feat)
+    src = {'conv1.W': ref[0].weight, 'conv1.b': ref[0].bias, 'conv2.W': ref[2].weight,
+           'conv2.b': ref[2].bias, 'fc.W': fc.weight, 'fc.b': fc.bias}
+    for k, v in p.views.items():
+        v.copy_(src[k].detach())
+    stem = CnnStem(K)
+    ws = stem.workspace(p, F, 'cuda')
+    D = 5                                       # features live at a column offset, as in the learner
+    xin = torch.zeros(F, D + feat, device='cuda')
+    stem.forward(p, frames.cuda(), F, ws, xin[:, D:])
+    close(xin[:, D:], y, msg='stem features')
+    dxin = torch.zeros_like(xin)
+    dxin[:, D:] = (dy * (y.detach() > 0)).cuda()
+    grads = torch.zeros_like(flat)
+    stem.backward(p, F, ws, dxin[:, D:], grads)
+    gp = CnnParams(grads, 0, (C, H, W), feat)
+    for k, v in gp.views.items():
+        scale = float(src[k].grad.abs().max())
+        close(v.cpu() / scale, src[k].grad / scale, atol=5e-6, rtol=1e-5, msg='grad ' + k)

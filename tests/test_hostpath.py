@@ -331,3 +331,50 @@ def test_rnn_agent_replay_learner_loop_in_process(cpu_double):
     ag.reset_batch(torch.tensor([True, False, False, True]))
     hb = ag._batch_cells[0][0]
     assert float(hb[0].abs().sum()) == 0.0 and float(hb[1].abs().sum()) > 0.0
+
+
+def test_pixel_agent_replay_learner_loop_in_process(cpu_double):
+    """camera-frame observations (cfg 4's shape of problem): uint8 frames travel agent -> window
+    wrapper -> replay -> aggregator unchanged, the learner keeps them uint8 on the device, and
+    the CNN stem + LSTM stem policy trains on them."""
+    from surreal_amd.agent import PPOAgent
+    from surreal_amd.env import SyntheticEnv
+    from surreal_amd.learner import PPOLearner
+    from surreal_amd.replay import FIFOReplay
+    D, A, N, CAM = 4, 2, 5, (2, 20, 24)
+    lc, _, sc = configs(B=3, N=N, stride=2, D=D, A=A, memory=16)
+    ec = ppo_env_config(D, A, pixel=CAM)
+    ec.limit_episode_length = 11
+    lc.model.cnn_feature_dim = 8
+    lc.algo.rnn.if_rnn_policy = True
+    lc.algo.rnn.rnn_hidden = 12
+    lc.algo.rnn.horizon = 2
+    replay = FIFOReplay(lc, ec, sc)
+    learner = PPOLearner(lc, ec, sc)
+    assert learner.model.if_pixel and learner.model.stem_in == D + 8
+    assert learner.model.actor_flat.numel() + learner.model.critic.numel == learner.model.flat.numel()
+    learner.attach_replay(replay)
+    ag = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
+    collected = []
+    ag.set_experience_sink(lambda exp: (collected.append(exp), replay._insert_wrapper(exp)))
+    ag.set_env_factory(lambda: SyntheticEnv(D, A, episode_len=50, seed=2, pixel=CAM))
+    ag.attach_learner(learner)
+    ag.main_setup()
+    learner.main_setup()
+    ag.main_loop()
+    assert len(collected) == (11 - N) // 2 + 1
+    fr = collected[0]['obs'][0]['pixel']['camera0']
+    assert fr.dtype == np.uint8 and fr.shape == CAM
+    batch = learner.aggregator.aggregate(collected[:3])
+    assert batch['obs']['pixel']['camera0'].shape == (3, N) + CAM
+    assert batch['obs']['pixel']['camera0'].dtype == np.uint8
+    assert batch['obs_next']['pixel']['camera0'].shape == (3, 1) + CAM
+    learner.main_loop()
+    st = learner.tensorplex.latest
+    for k in ('_surr_loss', '_val_loss', '_pol_kl', 'grad_norm_actor', 'grad_norm_critic'):
+        assert np.isfinite(st[k]), k
+    assert learner._ws.frames_it.dtype == torch.uint8          # never widened to fp32
+    # the stems were trained by both optimisers
+    m = learner.model
+    assert float(learner.actor_exp_avg[m.n_actor_block:].abs().sum()) > 0
+    assert float(learner.critic_exp_avg[:m.n_stem].abs().sum()) > 0
