@@ -203,7 +203,8 @@ typedef struct {
     int32_t adam_step_actor, adam_step_critic; /* torch.optim.Adam 'step' state */
     int32_t stop_flag;     /* set when KL(ref||curr) > 4*kl_target (ppo.py:556-557) */
     int32_t epochs_done;   /* policy epochs actually applied this learn() */
-    int32_t reserved[2];
+    int32_t ticket;        /* smx_ppo_epoch_losses_f32's workgroup counter; 0 between launches */
+    int32_t reserved;
 } smx_ppo_ctrl_t;
 
 /* per-epoch statistics slots (floats) written by the kernels; see ppo.py:219-224,278-284 */
@@ -263,6 +264,39 @@ int32_t smx_value_loss_blocks(int64_t rows);
 int smx_value_loss_f32(const float* values, const float* returns, int64_t rows,
                        int64_t n_total, float* dz3, float* partials, smx_ppo_ctrl_t* ctrl,
                        int32_t will_update, smx_stream_t stream);
+/* The three launches above (policy loss, its finalize, value loss) as ONE launch, for a
+ * single-GPU lock-step epoch (n_total == rows; with several ranks the loss partials must be
+ * all-reduced between the loss and its finalize, so the separate entry points are used).  The
+ * last policy workgroup to finish -- a ticket in ctrl -- does the finalize work in a fixed
+ * reduction order.  Field meanings as in the three entry points; values == NULL skips the
+ * value loss. */
+typedef struct smx_ppo_losses {
+    int32_t mode, A;
+    const float* mean;
+    const float* log_var;
+    const float* actions;
+    const float* behave;
+    const float* ref;
+    const float* adv;
+    int32_t ld_act, ld_beh, ld_ref, check_stop;
+    int64_t rows;
+    float* g_surr;
+    float* g_kl;
+    float* row_partials;
+    float* dz3;
+    float* dz3_t;
+    int64_t ld_t;
+    float* dlogvar;
+    float* dlogvar_sumsq;
+    float* stats;
+    const float* values;
+    const float* returns;
+    float* v_dz3;
+    float* v_partials;
+    int32_t will_update, v_will_update;
+} smx_ppo_losses_t;
+int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ctrl_t* ctrl,
+                             smx_stream_t stream);
 /* stats[e, SMX_VS_*] for e < count from partials [count, nblk, 8] (one launch per learn) */
 int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,
                                 float* stats, int32_t stats_stride, smx_stream_t stream);
@@ -278,6 +312,22 @@ int smx_clip_adam_step_f32(float* theta, const float* grads, float* exp_avg,
                            float* exp_avg_sq, int64_t n, const float* sumsq_partials,
                            int32_t npart, const smx_ppo_ctrl_t* ctrl, int32_t which,
                            int32_t honour_stop, float* grad_norm_out, smx_stream_t stream);
+/* The same step for the actor's group AND the critic's group in one launch (a lock-step epoch
+ * updates both: ppo.py:541-562 touches disjoint optimisers).  `which` is implied: actor = 0,
+ * critic = 1. */
+typedef struct smx_adam_group {
+    float* theta;
+    const float* grads;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    const float* sumsq_partials;
+    int32_t npart;
+    int32_t honour_stop;
+    float* grad_norm_out;
+} smx_adam_group_t;
+int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor, const smx_adam_group_t* critic,
+                                const smx_ppo_ctrl_t* ctrl, smx_stream_t stream);
 /* partials[b] = sum of squares of block b's slice of x; returns via *nblk_out the count
  * used (<= max_blocks). */
 int32_t smx_sumsq_blocks(int64_t n);

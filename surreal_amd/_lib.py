@@ -43,11 +43,30 @@ class Lstm(Structure):
                 ('D', c_int32), ('H', c_int32)]
 
 
+class AdamGroup(Structure):
+    """smx_adam_group_t"""
+    _fields_ = [('theta', c_void_p), ('grads', c_void_p), ('exp_avg', c_void_p),
+                ('exp_avg_sq', c_void_p), ('n', c_int64), ('sumsq_partials', c_void_p),
+                ('npart', c_int32), ('honour_stop', c_int32), ('grad_norm_out', c_void_p)]
+
+
+class PpoLosses(Structure):
+    """smx_ppo_losses_t"""
+    _fields_ = [('mode', c_int32), ('A', c_int32), ('mean', c_void_p), ('log_var', c_void_p),
+                ('actions', c_void_p), ('behave', c_void_p), ('ref', c_void_p), ('adv', c_void_p),
+                ('ld_act', c_int32), ('ld_beh', c_int32), ('ld_ref', c_int32), ('check_stop', c_int32),
+                ('rows', c_int64), ('g_surr', c_void_p), ('g_kl', c_void_p),
+                ('row_partials', c_void_p), ('dz3', c_void_p), ('dz3_t', c_void_p), ('ld_t', c_int64),
+                ('dlogvar', c_void_p), ('dlogvar_sumsq', c_void_p), ('stats', c_void_p),
+                ('values', c_void_p), ('returns', c_void_p), ('v_dz3', c_void_p),
+                ('v_partials', c_void_p), ('will_update', c_int32), ('v_will_update', c_int32)]
+
+
 # smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
 CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
  C_CRITIC_MAX_NORM, C_ACTOR_WD, C_CRITIC_WD, C_STEP_ACTOR, C_STEP_CRITIC, C_STOP,
- C_EPOCHS_DONE) = range(14)
+ C_EPOCHS_DONE, C_TICKET) = range(15)
 
 _P = c_void_p
 _SIGS = {
@@ -82,11 +101,13 @@ _SIGS = {
     'smx_ppo_loss_finalize_f32': (c_int32, [c_int32, _P, c_int32, _P, _P, _P, c_int64, c_int64,
                                             c_int32, _P, c_int32, c_int32, _P, _P, c_int64, _P, _P,
                                             _P, _P]),
+    'smx_ppo_epoch_losses_f32': (c_int32, [POINTER(PpoLosses), _P, _P]),
     'smx_value_loss_blocks': (c_int32, [c_int64]),
     'smx_value_loss_f32': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P]),
     'smx_value_loss_finalize_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P]),
     'smx_clip_adam_step_f32': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, _P, c_int32,
                                          c_int32, _P, _P]),
+    'smx_clip_adam_step_pair_f32': (c_int32, [POINTER(AdamGroup), POINTER(AdamGroup), _P, _P]),
     'smx_sumsq_blocks': (c_int32, [c_int64]),
     'smx_sumsq_partials_f32': (c_int32, [_P, c_int64, _P, _P]),
     'smx_ring_insert_f32': (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, _P]),

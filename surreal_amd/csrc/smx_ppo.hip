@@ -28,14 +28,13 @@ __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
 //      the per-row gradient scale, and the wave reduces the block partial sums;
 //   3. all waves form the two gradient tiles (element-parallel), write them back coalesced, and
 //      A lanes reduce the log_var gradient partials over the block's rows.
-__global__ __launch_bounds__(256) void policy_loss_kernel(
+__device__ __forceinline__ void policy_loss_body(
+    const int blk, float* sm,
     int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
     const float* __restrict__ g_actions, int ld_act, const float* __restrict__ g_behave, int ld_beh,
     const float* __restrict__ g_ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
     const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
     float* __restrict__ partials) {
-    if (ctrl->stop_flag) return;
-    extern __shared__ float sm[];
     const int R = LOSS_ROWS_PER_BLOCK;
     float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
     float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
@@ -46,12 +45,12 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
     float* e_dkl = e_dmu + R * A;  // ((mu - mr)/sig^2) * (1 - mu^2)       d KL / d z3
     float* e_gk = e_dkl + R * A;   // 1 - (sr^2+(mr-mu)^2)/sig^2          d KL / d log_var
     float* r_dll = e_gk + R * A;   // per-row d(loss_r)/d(ll)             [R]
-    const long row0 = (long)blockIdx.x * R;
+    const long row0 = (long)blk * R;
     long nrows = rows - row0;
     if (nrows > R) nrows = R;
     const int tid = threadIdx.x;
     const int stride = 8 + 2 * A;
-    float* P = partials + (size_t)blockIdx.x * stride;
+    float* P = partials + (size_t)blk * stride;
 
     // ---- phase 1: element-parallel terms ------------------------------------------------
     for (int i = tid; i < (int)nrows * A; i += 256) {
@@ -154,13 +153,26 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void policy_finalize_kernel(
+__global__ __launch_bounds__(256) void policy_loss_kernel(
+    int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
+    const float* __restrict__ g_actions, int ld_act, const float* __restrict__ g_behave, int ld_beh,
+    const float* __restrict__ g_ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
+    const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
+    float* __restrict__ partials) {
+    if (ctrl->stop_flag) return;
+    extern __shared__ float sm[];
+    policy_loss_body(blockIdx.x, sm, mode, g_mean, log_var, g_actions, ld_act, g_behave, ld_beh, g_ref,
+                     ld_ref, adv, rows, A, ctrl, g_surr, g_kl, partials);
+}
+
+// blk / nblocks: this workgroup's share of the elementwise part (blk 0 also writes the scalars)
+__device__ __forceinline__ void policy_finalize_body(
+    const int blk, const int nblocks,
     int mode, const float* __restrict__ partials, int nblk, const float* __restrict__ g_surr,
     const float* __restrict__ g_kl, const float* __restrict__ log_var, long rows, long n_total,
     int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
     float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
     float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
-    if (ctrl->stop_flag) return;
     __shared__ float S[8 + 2 * MAX_A];
     const int stride = 8 + 2 * A;
     for (int k = threadIdx.x; k < stride; k += 256) {
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void policy_finalize_kernel(
     }
     const float inv_n = 1.0f / n;
     const long total = rows * A;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblocks * 256)
     {
         const float v = (g_surr[i] + c_kl * g_kl[i]) * inv_n;
         dz3[i] = v;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void policy_finalize_kernel(
             dz3_t[(i - r * A) * ld_t + r] = v;
         }
     }
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
         for (int a = threadIdx.x; a < A; a += 256)
             dlogvar[a] = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
         if (threadIdx.x == 0) {
@@ -231,21 +243,32 @@ __global__ __launch_bounds__(256) void policy_finalize_kernel(
 // ---------------------------------------------------------------------------
 // value loss: 256 rows per block; per-block mergeable moments of d = ret - V and of ret
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void value_loss_kernel(const float* __restrict__ values,
-                                                         const float* __restrict__ returns,
-                                                         long rows, long n_total,
-                                                         float* __restrict__ dz3,
-                                                         float* __restrict__ partials,
-                                                         smx_ppo_ctrl_t* __restrict__ ctrl,
-                                                         int will_update) {
+__global__ __launch_bounds__(256) void policy_finalize_kernel(
+    int mode, const float* __restrict__ partials, int nblk, const float* __restrict__ g_surr,
+    const float* __restrict__ g_kl, const float* __restrict__ log_var, long rows, long n_total,
+    int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
+    float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
+    float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
+    if (ctrl->stop_flag) return;
+    policy_finalize_body(blockIdx.x, gridDim.x, mode, partials, nblk, g_surr, g_kl, log_var, rows,
+                         n_total, A, ctrl, check_stop, will_update, dz3, dz3_t, ld_t, dlogvar,
+                         dlogvar_sumsq, stats);
+}
+
+__device__ __forceinline__ void value_loss_body(const int blk, const float* __restrict__ values,
+                                                const float* __restrict__ returns, long rows,
+                                                long n_total, float* __restrict__ dz3,
+                                                float* __restrict__ partials,
+                                                smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                int will_update) {
     __shared__ float red[16];
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    const long r = (long)blk * 256 + threadIdx.x;
     const bool ok = r < rows;
     const float v = ok ? values[r] : 0.f, g = ok ? returns[r] : 0.f;
     const float d = g - v;                                   // returns - values (ppo.py:325)
     const float e = v - g;                                   // values - returns (ppo.py:326)
     if (ok) dz3[r] = (2.0f * e) / (float)n_total;
-    long nb = rows - (long)blockIdx.x * 256;
+    long nb = rows - (long)blk * 256;
     if (nb > 256) nb = 256;
     const float cnt = (float)nb;
     const float md = smx_block_sum(ok ? d : 0.f, red) / cnt;
@@ -254,10 +277,50 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* __restrict
     const float m2g = smx_block_sum(ok ? (g - mg) * (g - mg) : 0.f, red);
     const float sq = smx_block_sum(ok ? e * e : 0.f, red);
     if (threadIdx.x == 0) {
-        float* P = partials + (size_t)blockIdx.x * 8;
+        float* P = partials + (size_t)blk * 8;
         P[0] = cnt; P[1] = md; P[2] = m2d; P[3] = mg; P[4] = m2g; P[5] = sq; P[6] = 0.f; P[7] = 0.f;
-        if (blockIdx.x == 0 && will_update) ctrl->adam_step_critic += 1;
+        if (blk == 0 && will_update) ctrl->adam_step_critic += 1;
     }
+}
+
+__global__ __launch_bounds__(256) void value_loss_kernel(const float* __restrict__ values,
+                                                         const float* __restrict__ returns,
+                                                         long rows, long n_total,
+                                                         float* __restrict__ dz3,
+                                                         float* __restrict__ partials,
+                                                         smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                         int will_update) {
+    value_loss_body(blockIdx.x, values, returns, rows, n_total, dz3, partials, ctrl, will_update);
+}
+
+// One launch for the losses of a lock-step epoch on ONE GPU: workgroups [0, nblk_p) run the policy
+// loss, the last of them to finish (device-scope ticket) turns the block partials into the
+// gradient scale / statistics / early-exit flag (what policy_finalize_kernel does in its own
+// launch), workgroups [nblk_p, ...) run the value loss.  The reduction order is fixed, so the result
+// does not depend on which workgroup happens to be last.
+__global__ __launch_bounds__(256) void ppo_losses_kernel(smx_ppo_losses_t a,
+                                                         smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                         int nblk_p) {
+    extern __shared__ float sm[];
+    __shared__ int is_last;
+    if ((int)blockIdx.x >= nblk_p) {
+        value_loss_body(blockIdx.x - nblk_p, a.values, a.returns, (long)a.rows, (long)a.rows, a.v_dz3,
+                        a.v_partials, ctrl, a.v_will_update);
+        return;
+    }
+    if (ctrl->stop_flag) return;
+    policy_loss_body(blockIdx.x, sm, a.mode, a.mean, a.log_var, a.actions, a.ld_act, a.behave, a.ld_beh,
+                     a.ref, a.ld_ref, a.adv, (long)a.rows, a.A, ctrl, a.g_surr, a.g_kl, a.row_partials);
+    __threadfence();                      // this thread's partials / gradient tiles are visible ...
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (atomicAdd(&ctrl->ticket, 1) == nblk_p - 1);   // ... before the ticket
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) ctrl->ticket = 0;
+    policy_finalize_body(0, 1, a.mode, a.row_partials, nblk_p, a.g_surr, a.g_kl, a.log_var, (long)a.rows,
+                         (long)a.rows, a.A, ctrl, a.check_stop, a.will_update, a.dz3, a.dz3_t,
+                         (long)(a.ld_t ? a.ld_t : a.rows), a.dlogvar, a.dlogvar_sumsq, a.stats);
 }
 
 __global__ __launch_bounds__(64) void value_finalize_kernel(const float* __restrict__ partials,
@@ -290,27 +353,42 @@ __global__ __launch_bounds__(64) void value_finalize_kernel(const float* __restr
 // ---------------------------------------------------------------------------
 // clip_grad_norm_ + Adam
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ theta,
-                                                        const float* __restrict__ grads,
-                                                        float* __restrict__ m, float* __restrict__ v,
-                                                        long n, const float* __restrict__ partials,
-                                                        int npart,
-                                                        const smx_ppo_ctrl_t* __restrict__ ctrl,
-                                                        int which, int honour_stop,
-                                                        float* __restrict__ grad_norm_out) {
-    if (honour_stop && ctrl->stop_flag) return;
+struct AdamGroup {
+    float* theta;
+    const float* grads;
+    float* m;
+    float* v;
+    long n;
+    const float* partials;
+    int npart, which, honour_stop, blocks;
+    float* grad_norm_out;
+};
+
+struct AdamGroups {
+    AdamGroup g[2];
+    int n;
+};
+
+// one launch steps up to two optimiser groups (the actor's and the critic's of a lock-step epoch)
+__global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
+                                                        const smx_ppo_ctrl_t* __restrict__ ctrl) {
+    const int gi = (P.n > 1 && (int)blockIdx.x >= P.g[0].blocks) ? 1 : 0;
+    const AdamGroup& G = P.g[gi];
+    const int blk = blockIdx.x - (gi ? P.g[0].blocks : 0);
+    if (G.honour_stop && ctrl->stop_flag) return;
     __shared__ float red[16];
     float t = 0.f;
-    for (int k = threadIdx.x; k < npart; k += 256) t += partials[k];
+    for (int k = threadIdx.x; k < G.npart; k += 256) t += G.partials[k];
     const float total = smx_block_sum(t, red);
     const float norm = sqrtf(total);
+    const int which = G.which;
     const float max_norm = which ? ctrl->critic_max_norm : ctrl->actor_max_norm;
     float coef = 1.0f;
     if (max_norm > 0.f) {
         // clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1, always multiplied in
         coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm_out) *grad_norm_out = norm;
+    if (blk == 0 && threadIdx.x == 0 && G.grad_norm_out) *G.grad_norm_out = norm;
 
     const double beta1 = 0.9, beta2 = 0.999;
     const int step = which ? ctrl->adam_step_critic : ctrl->adam_step_actor;
@@ -322,7 +400,11 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ thet
     const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2);
     const float eps = 1e-8f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float* __restrict__ theta = G.theta;
+    const float* __restrict__ grads = G.grads;
+    float* __restrict__ m = G.m;
+    float* __restrict__ v = G.v;
+    for (long i = (long)blk * 256 + threadIdx.x; i < G.n; i += (long)G.blocks * 256) {
         float g = grads[i] * coef;
         const float p = theta[i];
         if (wd != 0.f) g = g + wd * p;                         // grad.add(param, alpha=wd)
@@ -409,6 +491,28 @@ extern "C" int smx_value_loss_f32(const float* values, const float* returns, int
     return SMX_OK;
 }
 
+extern "C" int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ctrl_t* ctrl,
+                                        smx_stream_t stream) {
+    SMX_REQUIRE(args && ctrl, SMX_E_NULL);
+    const smx_ppo_losses_t& a = *args;
+    SMX_REQUIRE(a.mean && a.log_var && a.actions && a.behave && a.ref && a.adv && a.g_surr && a.g_kl &&
+                    a.row_partials && a.dz3 && a.dlogvar && a.stats, SMX_E_NULL);
+    SMX_REQUIRE(a.rows > 0 && a.A > 0 && a.ld_act >= a.A && a.ld_beh >= 2 * a.A && a.ld_ref >= 2 * a.A,
+                SMX_E_SHAPE);
+    SMX_REQUIRE(a.A <= MAX_A && (a.mode == SMX_PPO_CLIP || a.mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
+    int nblk_v = 0;
+    if (a.values) {
+        SMX_REQUIRE(a.returns && a.v_dz3 && a.v_partials, SMX_E_NULL);
+        nblk_v = smx_value_loss_blocks(a.rows);
+    }
+    const int nblk_p = smx_ppo_loss_blocks(a.rows);
+    const size_t lds = (size_t)(8 * a.A + 1) * LOSS_ROWS_PER_BLOCK * sizeof(float);
+    hipLaunchKernelGGL(ppo_losses_kernel, dim3(nblk_p + nblk_v), dim3(256), lds, smx_s(stream), a, ctrl,
+                       nblk_p);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
 extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,
                                            float* stats, int32_t stats_stride,
                                            smx_stream_t stream) {
@@ -420,18 +524,53 @@ extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count,
     return SMX_OK;
 }
 
+static int fill_adam_group(AdamGroup& G, float* theta, const float* grads, float* exp_avg,
+                           float* exp_avg_sq, int64_t n, const float* sumsq_partials,
+                           int32_t npart, int32_t which, int32_t honour_stop, float* grad_norm_out) {
+    SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq && sumsq_partials, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && npart > 0, SMX_E_SHAPE);
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    G.theta = theta; G.grads = grads; G.m = exp_avg; G.v = exp_avg_sq; G.n = (long)n;
+    G.partials = sumsq_partials; G.npart = npart; G.which = which; G.honour_stop = honour_stop;
+    G.blocks = (int)blocks; G.grad_norm_out = grad_norm_out;
+    return SMX_OK;
+}
+
 extern "C" int smx_clip_adam_step_f32(float* theta, const float* grads, float* exp_avg,
                                       float* exp_avg_sq, int64_t n, const float* sumsq_partials,
                                       int32_t npart, const smx_ppo_ctrl_t* ctrl, int32_t which,
                                       int32_t honour_stop, float* grad_norm_out,
                                       smx_stream_t stream) {
-    SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq && sumsq_partials && ctrl, SMX_E_NULL);
-    SMX_REQUIRE(n > 0 && npart > 0, SMX_E_SHAPE);
-    long blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), theta,
-                       grads, exp_avg, exp_avg_sq, (long)n, sumsq_partials, npart, ctrl, which,
-                       honour_stop, grad_norm_out);
+    SMX_REQUIRE(ctrl, SMX_E_NULL);
+    AdamGroups P;
+    P.n = 1;
+    const int rc = fill_adam_group(P.g[0], theta, grads, exp_avg, exp_avg_sq, n, sumsq_partials,
+                                   npart, which, honour_stop, grad_norm_out);
+    if (rc) return rc;
+    P.g[1] = P.g[0];
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)P.g[0].blocks), dim3(256), 0,
+                       smx_s(stream), P, ctrl);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor,
+                                           const smx_adam_group_t* critic,
+                                           const smx_ppo_ctrl_t* ctrl, smx_stream_t stream) {
+    SMX_REQUIRE(actor && critic && ctrl, SMX_E_NULL);
+    AdamGroups P;
+    P.n = 2;
+    const smx_adam_group_t* src[2] = {actor, critic};
+    for (int k = 0; k < 2; ++k) {
+        const int rc = fill_adam_group(P.g[k], src[k]->theta, src[k]->grads, src[k]->exp_avg,
+                                       src[k]->exp_avg_sq, src[k]->n, src[k]->sumsq_partials,
+                                       src[k]->npart, k, src[k]->honour_stop,
+                                       src[k]->grad_norm_out);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)(P.g[0].blocks + P.g[1].blocks)),
+                       dim3(256), 0, smx_s(stream), P, ctrl);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

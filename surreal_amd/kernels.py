@@ -145,6 +145,26 @@ class HipKernels(object):
                0 if dz3_t is None else dz3_t.stride(0), L.ptr(dlogvar), L.ptr(dlogvar_sumsq),
                L.ptr(stats), self._st())
 
+    def epoch_losses(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                     partials, check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None,
+                     values=None, returns=None, v_dz3=None, v_partials=None, v_will_update=True):
+        """policy_loss + policy_finalize (+ value_loss) of a single-GPU lock-step epoch, one launch"""
+        rows, A = mean.shape
+        a = L.PpoLosses()
+        a.mode, a.A, a.rows = mode, A, rows
+        a.mean, a.log_var, a.adv = L.ptr(mean), L.ptr(log_var), L.ptr(adv)
+        a.actions, a.ld_act = L.ptr(actions), _row_stride(actions, A)
+        a.behave, a.ld_beh = L.ptr(behave), _row_stride(behave, 2 * A)
+        a.ref, a.ld_ref = L.ptr(ref), _row_stride(ref, 2 * A)
+        a.g_surr, a.g_kl, a.row_partials = L.ptr(g_surr), L.ptr(g_kl), L.ptr(partials)
+        a.check_stop, a.will_update = int(check_stop), int(will_update)
+        a.dz3, a.dz3_t = L.ptr(dz3), L.ptr(dz3_t)
+        a.ld_t = 0 if dz3_t is None else (dz3_t.stride(0) if dz3_t.shape[0] > 1 else dz3_t.shape[1])
+        a.dlogvar, a.dlogvar_sumsq, a.stats = L.ptr(dlogvar), L.ptr(dlogvar_sumsq), L.ptr(stats)
+        a.values, a.returns = L.ptr(values), L.ptr(returns)
+        a.v_dz3, a.v_partials, a.v_will_update = L.ptr(v_dz3), L.ptr(v_partials), int(v_will_update)
+        L.call('smx_ppo_epoch_losses_f32', ctypes.byref(a), L.ptr(ctrl), self._st())
+
     def value_loss_blocks(self, rows):
         return self.lib.smx_value_loss_blocks(rows)
 
@@ -161,6 +181,15 @@ class HipKernels(object):
         L.call('smx_clip_adam_step_f32', L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v),
                theta.numel(), L.ptr(sumsq), npart, L.ptr(ctrl), which, int(honour_stop),
                L.ptr(grad_norm_out), self._st())
+
+    def clip_adam_pair(self, actor, critic, ctrl):
+        """actor / critic: (theta, grads, m, v, sumsq, npart, honour_stop, grad_norm_out)"""
+        gs = []
+        for theta, grads, m, v, sumsq, npart, honour_stop, gno in (actor, critic):
+            gs.append(L.AdamGroup(L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(),
+                                  L.ptr(sumsq), npart, int(honour_stop), L.ptr(gno)))
+        L.call('smx_clip_adam_step_pair_f32', ctypes.byref(gs[0]), ctypes.byref(gs[1]), L.ptr(ctrl),
+               self._st())
 
     def sumsq_blocks(self, n):
         return self.lib.smx_sumsq_blocks(n)

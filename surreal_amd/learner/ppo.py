@@ -306,8 +306,10 @@ class PPOLearner(Learner):
             ws.dz2aT, ws.dz1aT = ft(act.H2), ft(act.H1)
             ws.h1cT, ws.h2cT, ws.dz3cT = ft(cri.H1), ft(cri.H2), ft(1)
             ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
-        ws.grads_a = torch.zeros_like(self.model.actor_flat)
-        ws.grads_c = torch.zeros_like(self.model.critic_flat)
+        # one buffer for both groups' gradients: a data-parallel lock-step epoch all-reduces it once
+        n_a, n_c = self.model.actor_flat.numel(), self.model.critic_flat.numel()
+        ws.grads_all = torch.zeros(n_a + n_c, device=dev)
+        ws.grads_a, ws.grads_c = ws.grads_all[:n_a], ws.grads_all[n_a:]
         ws.nblk_p = K.loss_blocks(rows)
         ws.pstride = 8 + 2 * A
         ws.ppart = f(ws.nblk_p, ws.pstride)
@@ -315,6 +317,8 @@ class PPOLearner(Learner):
         ws.nblk_v = K.value_loss_blocks(rows)
         ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
         ws.vpart_local = f(ws.nblk_v, 8)
+        ws.vpart_loc_all = f(Ev, ws.nblk_v, 8)          # lock-step: gathered once per learn
+        ws.vgather = f(self.world_size, Ev, ws.nblk_v, 8)
         ws.np_a = K.mlp3_backward_partials(act)
         ws.np_c = K.mlp3_backward_partials(cri)
         ws.sumsq_a = torch.zeros(max(ws.np_a + 1, K.sumsq_blocks(ws.grads_a.numel())), device=dev)
@@ -486,7 +490,15 @@ class PPOLearner(Learner):
         for e in range(max(Ep + 1, Ev)):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
             K.mlp3_forward_multi(([aj] if pol_f else []) + ([cj] if val else []))
-            if pol_f:
+            if pol_f and W == 1:
+                # one launch: policy loss, its finalize (last workgroup) and the value loss
+                K.epoch_losses(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
+                               ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart, e > 0, pol_u, ws.dz3a,
+                               ws.grads_a[m.actor.numel:m.actor.numel + A],
+                               ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e], dz3_t=ws.dz3aT,
+                               values=ws.vpred if val else None, returns=ws.ret, v_dz3=ws.dz3c,
+                               v_partials=ws.vpart[e] if val else None)
+            elif pol_f:
                 K.policy_loss(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol,
                               ws.adv, ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
                 part, nblk = ws.ppart, ws.nblk_p
@@ -498,32 +510,49 @@ class PPOLearner(Learner):
                                   ws.ctrl_f, e > 0, pol_u, ws.dz3a,
                                   ws.grads_a[m.actor.numel:m.actor.numel + A],
                                   ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e], dz3_t=ws.dz3aT)
-            if val:
-                if W > 1:
-                    K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
-                    self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
-                else:
-                    K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
+            if val and not (pol_f and W == 1):
+                # the value-loss partial sums only feed statistics: every epoch's stay local and
+                # are gathered once at the end of the learn
+                K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c,
+                             ws.vpart_loc_all[e] if W > 1 else ws.vpart[e], ws.ctrl_f, True)
             if pol_u or val:
                 K.mlp3_backward_multi(([aj] if pol_u else []) + ([cj] if val else []))
             np_a, np_c = ws.np_a + 1, ws.np_c
             if W > 1:
-                if pol_u:
+                if pol_u and val:
+                    # ONE all-reduce for both groups.  log_var's gradient was built from the
+                    # all-reduced loss partials and is global already: exactly one copy may enter
+                    # the sum (exact for any world size)
+                    if self.rank != 0:
+                        ws.grads_a[m.actor.numel:m.actor.numel + A].zero_()
+                    self._dist.all_reduce(ws.grads_all)
+                elif pol_u:
                     self._dist.all_reduce(ws.grads_a[:m.actor.numel])
+                elif val:
+                    self._dist.all_reduce(ws.grads_c)
+                if pol_u:
                     K.sumsq_partials(ws.grads_a, ws.sumsq_a)
                     np_a = K.sumsq_blocks(ws.grads_a.numel())
                 if val:
-                    self._dist.all_reduce(ws.grads_c)
                     K.sumsq_partials(ws.grads_c, ws.sumsq_c)
                     np_c = K.sumsq_blocks(ws.grads_c.numel())
-            if pol_u:
+            if pol_u and val:        # both groups step in one launch
+                K.clip_adam_pair((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                                  ws.sumsq_a, np_a, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1]),
+                                 (m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                                  ws.sumsq_c, np_c, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1]),
+                                 ws.ctrl_f)
+            elif pol_u:
                 K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                             ws.sumsq_a, np_a, ws.ctrl_f, 0, True,
                             ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
-            if val:
+            elif val:
                 K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                             ws.sumsq_c, np_c, ws.ctrl_f, 1, False,
                             ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
+        if W > 1:
+            self._dist.all_gather_into_tensor(ws.vgather.view(-1), ws.vpart_loc_all.view(-1))
+            ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(ws.vgather.permute(1, 0, 2, 3))
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
     def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds, pix=None,
@@ -535,7 +564,7 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
-        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
+        ws.ctrl_i[L.C_STOP:L.C_TICKET + 1].zero_()
         ws.pstats.zero_()
         self._enqueue_gae(ws, obs, obs_next, rewards, dones)
 
@@ -740,7 +769,7 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A, E = self.action_dim, ws.E
-        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
+        ws.ctrl_i[L.C_STOP:L.C_TICKET + 1].zero_()
         ws.pstats.zero_()
         self._enqueue_gae_stem(ws, obs, obs_next, pix, pix_next, rewards, dones)
 

@@ -262,6 +262,18 @@ class TorchCpuKernels(object):
             ci[L.C_STEP_ACTOR] += 1
             ci[L.C_EPOCHS_DONE] += 1
 
+    def epoch_losses(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                     partials, check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None,
+                     values=None, returns=None, v_dz3=None, v_partials=None, v_will_update=True):
+        rows = mean.shape[0]
+        # the value blocks do not look at the stop flag; the policy part is skipped when it is set
+        if values is not None:
+            self.value_loss(values, returns, rows, v_dz3, v_partials, ctrl, v_will_update)
+        self.policy_loss(mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl, partials)
+        self.policy_finalize(mode, partials, self.loss_blocks(rows), g_surr, g_kl, log_var, rows, ctrl,
+                             check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=dz3_t)
+        assert int(ctrl.view(torch.int32)[L.C_TICKET]) == 0
+
     def value_loss_blocks(self, rows):
         return (rows + 255) // 256
 
@@ -321,6 +333,10 @@ class TorchCpuKernels(object):
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
         denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
         theta.addcdiv_(m, denom, value=-(lr / bc1))
+
+    def clip_adam_pair(self, actor, critic, ctrl):
+        for which, (theta, grads, m, v, sumsq, npart, honour_stop, gno) in enumerate((actor, critic)):
+            self.clip_adam(theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, gno)
 
     def sumsq_blocks(self, n):
         return max(1, min(256, (n + 4095) // 4096))

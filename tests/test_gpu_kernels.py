@@ -536,3 +536,67 @@ def test_cnn_stem_forward_backward_match_aten(K, F, C, H, W, feat):
     for k, v in gp.views.items():
         scale = float(src[k].grad.abs().max())
         close(v.cpu() / scale, src[k].grad / scale, atol=5e-6, rtol=1e-5, msg='grad ' + k)
+
+
+# ---- single-launch variants used by the lock-step epoch: they must equal the separate launches
+@pytest.mark.parametrize('mode', [L.SMX_PPO_CLIP, L.SMX_PPO_ADAPT])
+@pytest.mark.parametrize('rows,A', [(8, 3), (130, 5), (1024, 17), (4000, 17)])
+def test_epoch_losses_single_launch_equals_separate_launches(K, mode, rows, A):
+    g = torch.Generator().manual_seed(rows * 7 + A)
+    log_var = (torch.full((A,), -1.0) + 0.1 * torch.randn(A, generator=g)).cuda()
+    mean = torch.tanh(0.1 * torch.randn(rows, A, generator=g)).cuda()
+    std = torch.exp(log_var).cpu()
+    actions = (mean.cpu() + std * torch.randn(rows, A, generator=g)).cuda()
+    behave = torch.cat([mean.cpu() + 0.05 * torch.randn(rows, A, generator=g), (std * 1.1).expand(rows, A)], 1).cuda()
+    ref = torch.cat([mean.cpu() + 0.02 * torch.randn(rows, A, generator=g), (std * 0.9).expand(rows, A)], 1).cuda()
+    adv = torch.randn(rows, generator=g).cuda()
+    vals, rets = (torch.randn(rows, generator=g) * 2).cuda(), (torch.randn(rows, generator=g) * 5).cuda()
+    nblk, nbv, stride = K.loss_blocks(rows), K.value_loss_blocks(rows), 8 + 2 * A
+    ldT = rows + 16
+    res = []
+    for fused in (False, True):
+        ctrl = torch.zeros(L.CTRL_WORDS)
+        ctrl[L.C_BETA], ctrl[L.C_ETA], ctrl[L.C_CLIP_EPS], ctrl[L.C_KL_TARGET] = 1.0, 250.0, 0.2, 1e-3
+        ctrl = ctrl.cuda()
+        f = lambda *s: torch.zeros(*s, device='cuda')  # noqa: E731
+        gs, gk, part, dz3, dlv, dq, st = f(rows, A), f(rows, A), f(nblk, stride), f(rows, A), f(A), f(1), f(L.PS_STRIDE)
+        dz3t = torch.zeros(A, ldT, device='cuda')[:, :rows]
+        vdz, vpart = f(rows), f(nbv, 8)
+        if fused:
+            K.epoch_losses(mode, mean, log_var, actions, behave, ref, adv, ctrl, gs, gk, part, True, True,
+                           dz3, dlv, dq, st, dz3_t=dz3t, values=vals, returns=rets, v_dz3=vdz, v_partials=vpart)
+        else:
+            K.policy_loss(mode, mean, log_var, actions, behave, ref, adv, ctrl, gs, gk, part)
+            K.policy_finalize(mode, part, nblk, gs, gk, log_var, rows, ctrl, True, True, dz3, dlv, dq, st, dz3_t=dz3t)
+            K.value_loss(vals, rets, rows, vdz, vpart, ctrl, True)
+        torch.cuda.synchronize()
+        res.append([t.cpu().clone() for t in (gs, gk, part, dz3, dlv, dq, st, dz3t, vdz, vpart, ctrl.view(torch.int32))])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)                 # same code, same reduction order: bit-identical
+    assert int(res[1][-1][L.C_TICKET]) == 0 and int(res[1][-1][L.C_STEP_CRITIC]) == 1
+
+
+def test_clip_adam_pair_equals_two_launches(K):
+    g = torch.Generator().manual_seed(5)
+    na, nc = 5000, 3333
+    outs = []
+    for pair in (False, True):
+        ctrl = torch.zeros(L.CTRL_WORDS)
+        ctrl[L.C_LR_ACTOR], ctrl[L.C_LR_CRITIC], ctrl[L.C_ACTOR_MAX_NORM], ctrl[L.C_CRITIC_MAX_NORM] = 1e-3, 2e-3, 5.0, 0.5
+        ctrl = ctrl.cuda()
+        ci = ctrl.view(torch.int32)
+        ci[L.C_STEP_ACTOR], ci[L.C_STEP_CRITIC] = 3, 7
+        gg = torch.Generator().manual_seed(9)
+        ta, ga, tc, gc = (torch.randn(n, generator=gg).cuda() for n in (na, na, nc, nc))
+        ma, va, mc, vc = (torch.zeros(n).cuda() for n in (na, na, nc, nc))
+        pa, pc = torch.zeros(K.sumsq_blocks(na)).cuda(), torch.zeros(K.sumsq_blocks(nc)).cuda()
+        K.sumsq_partials(ga, pa); K.sumsq_partials(gc, pc)
+        gna, gnc = torch.zeros(1).cuda(), torch.zeros(1).cuda()
+        if pair:
+            K.clip_adam_pair((ta, ga, ma, va, pa, pa.numel(), True, gna), (tc, gc, mc, vc, pc, pc.numel(), False, gnc), ctrl)
+        else:
+            K.clip_adam(ta, ga, ma, va, pa, pa.numel(), ctrl, 0, True, gna)
+            K.clip_adam(tc, gc, mc, vc, pc, pc.numel(), ctrl, 1, False, gnc)
+        outs.append([t.cpu().clone() for t in (ta, ma, va, tc, mc, vc, gna, gnc)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
