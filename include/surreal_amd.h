@@ -203,8 +203,7 @@ typedef struct {
     int32_t adam_step_actor, adam_step_critic; /* torch.optim.Adam 'step' state */
     int32_t stop_flag;     /* set when KL(ref||curr) > 4*kl_target (ppo.py:556-557) */
     int32_t epochs_done;   /* policy epochs actually applied this learn() */
-    int32_t ticket;        /* smx_ppo_epoch_losses_f32's workgroup counter; 0 between launches */
-    int32_t reserved;
+    int32_t reserved[2];
 } smx_ppo_ctrl_t;
 
 /* per-epoch statistics slots (floats) written by the kernels; see ppo.py:219-224,278-284 */
@@ -264,12 +263,11 @@ int32_t smx_value_loss_blocks(int64_t rows);
 int smx_value_loss_f32(const float* values, const float* returns, int64_t rows,
                        int64_t n_total, float* dz3, float* partials, smx_ppo_ctrl_t* ctrl,
                        int32_t will_update, smx_stream_t stream);
-/* The three launches above (policy loss, its finalize, value loss) as ONE launch, for a
- * single-GPU lock-step epoch (n_total == rows; with several ranks the loss partials must be
- * all-reduced between the loss and its finalize, so the separate entry points are used).  The
- * last policy workgroup to finish -- a ticket in ctrl -- does the finalize work in a fixed
- * reduction order.  Field meanings as in the three entry points; values == NULL skips the
- * value loss. */
+/* The three entry points above in one call, for a single-GPU lock-step epoch (n_total == rows;
+ * with several ranks the loss partials must be all-reduced between the loss and its finalize, so
+ * the separate entry points are used): the policy loss and the value loss share ONE launch
+ * (disjoint workgroup ranges), the policy finalize follows.  Results are bit-identical to the
+ * three separate calls.  Field meanings as there; values == NULL skips the value loss. */
 typedef struct smx_ppo_losses {
     int32_t mode, A;
     const float* mean;

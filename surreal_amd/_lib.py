@@ -66,7 +66,7 @@ class PpoLosses(Structure):
 CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
  C_CRITIC_MAX_NORM, C_ACTOR_WD, C_CRITIC_WD, C_STEP_ACTOR, C_STEP_CRITIC, C_STOP,
- C_EPOCHS_DONE, C_TICKET) = range(15)
+ C_EPOCHS_DONE) = range(14)
 
 _P = c_void_p
 _SIGS = {

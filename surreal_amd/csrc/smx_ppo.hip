@@ -293,16 +293,15 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* __restrict
     value_loss_body(blockIdx.x, values, returns, rows, n_total, dz3, partials, ctrl, will_update);
 }
 
-// One launch for the losses of a lock-step epoch on ONE GPU: workgroups [0, nblk_p) run the policy
-// loss, the last of them to finish (device-scope ticket) turns the block partials into the
-// gradient scale / statistics / early-exit flag (what policy_finalize_kernel does in its own
-// launch), workgroups [nblk_p, ...) run the value loss.  The reduction order is fixed, so the result
-// does not depend on which workgroup happens to be last.
+// The two row-parallel loss kernels of a lock-step epoch in one launch: workgroups [0, nblk_p)
+// run the policy loss, workgroups [nblk_p, ...) the value loss (they share nothing).  The policy
+// finalize stays its own multi-workgroup launch: folding it into the last workgroup to finish
+// (device-scope ticket) was measured at 47 us per launch against 23 us for the three separate
+// kernels -- one workgroup walking all rows x A gradient elements is far slower than a launch.
 __global__ __launch_bounds__(256) void ppo_losses_kernel(smx_ppo_losses_t a,
                                                          smx_ppo_ctrl_t* __restrict__ ctrl,
                                                          int nblk_p) {
     extern __shared__ float sm[];
-    __shared__ int is_last;
     if ((int)blockIdx.x >= nblk_p) {
         value_loss_body(blockIdx.x - nblk_p, a.values, a.returns, (long)a.rows, (long)a.rows, a.v_dz3,
                         a.v_partials, ctrl, a.v_will_update);
@@ -311,16 +310,6 @@ __global__ __launch_bounds__(256) void ppo_losses_kernel(smx_ppo_losses_t a,
     if (ctrl->stop_flag) return;
     policy_loss_body(blockIdx.x, sm, a.mode, a.mean, a.log_var, a.actions, a.ld_act, a.behave, a.ld_beh,
                      a.ref, a.ld_ref, a.adv, (long)a.rows, a.A, ctrl, a.g_surr, a.g_kl, a.row_partials);
-    __threadfence();                      // this thread's partials / gradient tiles are visible ...
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = (atomicAdd(&ctrl->ticket, 1) == nblk_p - 1);   // ... before the ticket
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) ctrl->ticket = 0;
-    policy_finalize_body(0, 1, a.mode, a.row_partials, nblk_p, a.g_surr, a.g_kl, a.log_var, (long)a.rows,
-                         (long)a.rows, a.A, ctrl, a.check_stop, a.will_update, a.dz3, a.dz3_t,
-                         (long)(a.ld_t ? a.ld_t : a.rows), a.dlogvar, a.dlogvar_sumsq, a.stats);
 }
 
 __global__ __launch_bounds__(64) void value_finalize_kernel(const float* __restrict__ partials,
@@ -510,7 +499,9 @@ extern "C" int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ct
     hipLaunchKernelGGL(ppo_losses_kernel, dim3(nblk_p + nblk_v), dim3(256), lds, smx_s(stream), a, ctrl,
                        nblk_p);
     SMX_LAUNCH_CHECK();
-    return SMX_OK;
+    return smx_ppo_loss_finalize_f32(a.mode, a.row_partials, nblk_p, a.g_surr, a.g_kl, a.log_var, a.rows,
+                                     a.rows, a.A, ctrl, a.check_stop, a.will_update, a.dz3, a.dz3_t,
+                                     a.ld_t, a.dlogvar, a.dlogvar_sumsq, a.stats, stream);
 }
 
 extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,

@@ -491,7 +491,7 @@ class PPOLearner(Learner):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
             K.mlp3_forward_multi(([aj] if pol_f else []) + ([cj] if val else []))
             if pol_f and W == 1:
-                # one launch: policy loss, its finalize (last workgroup) and the value loss
+                # one ABI call: policy loss and value loss share a launch, then the policy finalize
                 K.epoch_losses(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
                                ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart, e > 0, pol_u, ws.dz3a,
                                ws.grads_a[m.actor.numel:m.actor.numel + A],
@@ -564,7 +564,7 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
-        ws.ctrl_i[L.C_STOP:L.C_TICKET + 1].zero_()
+        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
         ws.pstats.zero_()
         self._enqueue_gae(ws, obs, obs_next, rewards, dones)
 
@@ -769,7 +769,7 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A, E = self.action_dim, ws.E
-        ws.ctrl_i[L.C_STOP:L.C_TICKET + 1].zero_()
+        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
         ws.pstats.zero_()
         self._enqueue_gae_stem(ws, obs, obs_next, pix, pix_next, rewards, dones)
 

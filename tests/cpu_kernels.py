@@ -272,7 +272,6 @@ class TorchCpuKernels(object):
         self.policy_loss(mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl, partials)
         self.policy_finalize(mode, partials, self.loss_blocks(rows), g_surr, g_kl, log_var, rows, ctrl,
                              check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=dz3_t)
-        assert int(ctrl.view(torch.int32)[L.C_TICKET]) == 0
 
     def value_loss_blocks(self, rows):
         return (rows + 255) // 256

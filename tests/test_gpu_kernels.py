@@ -573,7 +573,7 @@ def test_epoch_losses_single_launch_equals_separate_launches(K, mode, rows, A):
         res.append([t.cpu().clone() for t in (gs, gk, part, dz3, dlv, dq, st, dz3t, vdz, vpart, ctrl.view(torch.int32))])
     for a, b in zip(*res):
         assert torch.equal(a, b)                 # same code, same reduction order: bit-identical
-    assert int(res[1][-1][L.C_TICKET]) == 0 and int(res[1][-1][L.C_STEP_CRITIC]) == 1
+    assert int(res[1][-1][L.C_STEP_CRITIC]) == 1
 
 
 def test_clip_adam_pair_equals_two_launches(K):
