@@ -82,7 +82,65 @@ __device__ __forceinline__ void store_w(const float4 (&wreg)[NT], float* Wb, int
         *reinterpret_cast<float4*>(Wb + (srow + 32 * i) * LDS_STRIDE + 4 * sk8) = wreg[i];
 }
 
-template <int NT1, int NT2, bool OUT1>
+// Vector x staging (D % 4 == 0, 16-byte aligned rows): the loads are UNCONDITIONAL -- a k past D
+// or a row past the batch reads a clamped, valid address and is zeroed when it is written to LDS.
+// A load guarded by a branch (or followed by a select) makes hipcc wait for it on the spot, which
+// put a full HBM round trip at the top of every K chunk.
+template <bool HASZ>
+__device__ __forceinline__ void load_x_vec(float4 (&xreg)[4], float4& zm, float4& zs,
+                                           const float* const (&xp)[4], const float* zmean,
+                                           const float* zstd, int k0, int D) {
+    const int kc = (k0 < D) ? k0 : D - 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xreg[i] = *reinterpret_cast<const float4*>(xp[i] + kc);
+    if (HASZ) {
+        zm = *reinterpret_cast<const float4*>(zmean + kc);
+        zs = *reinterpret_cast<const float4*>(zstd + kc);
+    }
+}
+
+template <bool HASZ>
+__device__ __forceinline__ void store_x_vec(float* Xb, const float4 (&xreg)[4], const float4 zm,
+                                            const float4 zs, const bool (&xok)[4], int k0, int D,
+                                            int srow, int sk4) {
+    const bool kin = k0 < D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 v = xreg[i];
+        const bool ok = xok[i] && kin;          // padded k (>= D) and padded rows stay exactly zero
+        if (HASZ) {
+            v.x = ok ? zf(v.x, zm.x, zs.x) : 0.f;
+            v.y = ok ? zf(v.y, zm.y, zs.y) : 0.f;
+            v.z = ok ? zf(v.z, zm.z, zs.z) : 0.f;
+            v.w = ok ? zf(v.w, zm.w, zs.w) : 0.f;
+        } else if (!ok) {
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *reinterpret_cast<float4*>(Xb + (srow + 32 * i) * LDS_STRIDE + sk4) = v;
+    }
+}
+
+template <bool HASZ>
+__device__ __forceinline__ void stage_x(float* dst, float4 v, const float4 zm, const float4 zs,
+                                        const bool ok) {
+    if (HASZ) {
+        // computed unconditionally, then selected: a conditional division becomes a divergent
+        // branch per element
+        const float a = zf(v.x, zm.x, zs.x), b = zf(v.y, zm.y, zs.y);
+        const float c = zf(v.z, zm.z, zs.z), d = zf(v.w, zm.w, zs.w);
+        v.x = ok ? a : 0.f;
+        v.y = ok ? b : 0.f;
+        v.z = ok ? c : 0.f;
+        v.w = ok ? d : 0.f;
+    } else if (!ok) {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *reinterpret_cast<float4*>(dst) = v;
+}
+
+// XMODE 0: generic x staging (any D / alignment, run-time z-filter switch); 1: vector staging with
+// the z-filter; 2: vector staging without it.
+template <int NT1, int NT2, bool OUT1, int XMODE>
 __global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
     constexpr int WR = (NT1 > NT2 ? NT1 : NT2) * 32;  // rows of one weight staging buffer
     extern __shared__ float lds[];
@@ -187,22 +245,24 @@ __global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
 
     float4 w1reg[NT1];
     load_w<NT1>(w1reg, W1p, srow, sk8);
-    load_x(0);
+    if (XMODE == 0) load_x(0);
+    else load_x_vec<XMODE == 1>(xreg, zmreg, zsreg, xp, A.zmean, A.zstd, sk4, A.D);
     store_w<NT1>(w1reg, Wb0, srow, sk8);
-    store_x(Xb0, 0);
+    if (XMODE == 0) store_x(Xb0, 0);
+    else store_x_vec<XMODE == 1>(Xb0, xreg, zmreg, zsreg, xok, sk4, A.D, srow, sk4);
     __syncthreads();
 
     for (int c = 0; c < A.KC1; ++c) {
         const float* Wc = (c & 1) ? Wb1 : Wb0;
         const float* Xc = (c & 1) ? Xb1 : Xb0;
+        float* Wn = (c & 1) ? Wb0 : Wb1;
+        float* Xn = (c & 1) ? Xb0 : Xb1;
         // branch-free prefetch: the last iteration re-stages its own chunk (never read again)
         const int cn = (c + 1 < A.KC1) ? c + 1 : c;
-        load_w<NT1>(w1reg, W1p + (size_t)cn * NT1 * 1024, srow, sk8);
-        load_x(cn);
         const float* xrow = Xc + (wv * 32 + j) * LDS_STRIDE + 4 * kh;
         const float* wrow = Wc + j * LDS_STRIDE + 4 * kh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        // one 8-wide k group of the chunk: 11 LDS fragment reads, 4 x NT1 MFMAs
+        auto kgroup = [&](int q) {
             const float4 b = *reinterpret_cast<const float4*>(xrow + 8 * q);
             float4 a[NT1];
 #pragma unroll
@@ -216,9 +276,65 @@ __global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
             for (int t = 0; t < NT1; ++t) acc1[t] = MFMA32(a[t].z, b.z, acc1[t]);
 #pragma unroll
             for (int t = 0; t < NT1; ++t) acc1[t] = MFMA32(a[t].w, b.w, acc1[t]);
+        };
+        if (XMODE == 0) {
+            load_w<NT1>(w1reg, W1p + (size_t)cn * NT1 * 1024, srow, sk8);
+            load_x(cn);
+            kgroup(0); kgroup(1); kgroup(2); kgroup(3);
+            store_w<NT1>(w1reg, Wn, srow, sk8);
+            store_x(Xn, cn);
+        } else {
+            // Software pipeline of the next chunk's staging in two batches of 8 x 16 B per lane:
+            //   issue A (x rows, z-filter stats, weight tiles 0-1) | k groups 0, 1 | A -> LDS,
+            //   issue B (weight tiles 2..NT1-1)                    | k groups 2, 3 | B -> LDS.
+            // Each batch has two k groups (~2.4 us of MFMA issue) to land, and only one batch of
+            // staging registers is live at a time.  The sched_barriers pin that order: left
+            // alone, hipcc sinks the loads behind the MFMA block and waits for each in front of
+            // its LDS store.
+            // (named scalars, not arrays: an array that lives across a sched_barrier is left in
+            // scratch memory by hipcc)
+            static_assert(XMODE == 0 || NT1 == 10, "vector staging is written for 10 feature tiles");
+            const float4* wsrc = reinterpret_cast<const float4*>(W1p + (size_t)cn * NT1 * 1024);
+            const int k0n = 32 * cn + sk4;
+            const int kc = (k0n < A.D) ? k0n : A.D - 4;
+            const bool kin = k0n < A.D;
+#define SMX_WLD(i) wsrc[(srow + 32 * (i)) * 8 + sk8]
+#define SMX_WST(i, v) *reinterpret_cast<float4*>(Wn + (srow + 32 * (i)) * LDS_STRIDE + 4 * sk8) = (v)
+            float4 x0 = *reinterpret_cast<const float4*>(xp[0] + kc);
+            float4 x1 = *reinterpret_cast<const float4*>(xp[1] + kc);
+            float4 x2 = *reinterpret_cast<const float4*>(xp[2] + kc);
+            float4 x3 = *reinterpret_cast<const float4*>(xp[3] + kc);
+            float4 zm = make_float4(0.f, 0.f, 0.f, 0.f), zs = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (XMODE == 1) {
+                zm = *reinterpret_cast<const float4*>(A.zmean + kc);
+                zs = *reinterpret_cast<const float4*>(A.zstd + kc);
+            }
+            const float4 wa0 = SMX_WLD(0), wa1 = SMX_WLD(1);
+            __builtin_amdgcn_sched_barrier(0);
+            kgroup(0); kgroup(1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 wb2 = SMX_WLD(2), wb3 = SMX_WLD(3), wb4 = SMX_WLD(4), wb5 = SMX_WLD(5);
+            const float4 wb6 = SMX_WLD(6), wb7 = SMX_WLD(7), wb8 = SMX_WLD(8), wb9 = SMX_WLD(9);
+            __builtin_amdgcn_sched_barrier(0);
+            // batch A (z-filter divisions + LDS stores) is free to interleave with these MFMAs.
+            // The empty asm re-defines the loaded x registers HERE: without it the (pure) z-filter
+            // arithmetic is emitted right behind the loads at the top of the chunk, in front of the
+            // first sched_barrier, and waits for HBM there.
+            asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y),
+                              "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w),
+                              "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w));
+            stage_x<XMODE == 1>(Xn + (srow + 0) * LDS_STRIDE + sk4, x0, zm, zs, xok[0] && kin);
+            stage_x<XMODE == 1>(Xn + (srow + 32) * LDS_STRIDE + sk4, x1, zm, zs, xok[1] && kin);
+            stage_x<XMODE == 1>(Xn + (srow + 64) * LDS_STRIDE + sk4, x2, zm, zs, xok[2] && kin);
+            stage_x<XMODE == 1>(Xn + (srow + 96) * LDS_STRIDE + sk4, x3, zm, zs, xok[3] && kin);
+            SMX_WST(0, wa0); SMX_WST(1, wa1);
+            kgroup(2); kgroup(3);
+            __builtin_amdgcn_sched_barrier(0);
+            SMX_WST(2, wb2); SMX_WST(3, wb3); SMX_WST(4, wb4); SMX_WST(5, wb5);
+            SMX_WST(6, wb6); SMX_WST(7, wb7); SMX_WST(8, wb8); SMX_WST(9, wb9);
+#undef SMX_WLD
+#undef SMX_WST
         }
-        store_w<NT1>(w1reg, (c & 1) ? Wb0 : Wb1, srow, sk8);
-        store_x((c & 1) ? Xb0 : Xb1, cn);
         __syncthreads();
     }
 
@@ -248,24 +364,47 @@ __global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
 #pragma unroll
     for (int t = 0; t < NT1; ++t) {
         const float* Wc = (t & 1) ? Wb1 : Wb0;
-        load_w<NT2>(w2reg, W2p + (size_t)((t + 1 < NT1) ? t + 1 : t) * NT2 * 1024, srow, sk8);
+        float* Wn = (t & 1) ? Wb0 : Wb1;
+        const float* wnext = W2p + (size_t)((t + 1 < NT1) ? t + 1 : t) * NT2 * 1024;
         const float* wrow = Wc + j * LDS_STRIDE + 4 * kh;
+        auto chunk2 = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 a[NT2];
+            for (int q = 0; q < 4; ++q) {
+                float4 a[NT2];
 #pragma unroll
-            for (int u = 0; u < NT2; ++u)
-                a[u] = *reinterpret_cast<const float4*>(wrow + u * 32 * LDS_STRIDE + 8 * q);
+                for (int u = 0; u < NT2; ++u)
+                    a[u] = *reinterpret_cast<const float4*>(wrow + u * 32 * LDS_STRIDE + 8 * q);
 #pragma unroll
-            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].x, acc1[t][4 * q + 0], acc2[u]);
+                for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].x, acc1[t][4 * q + 0], acc2[u]);
 #pragma unroll
-            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].y, acc1[t][4 * q + 1], acc2[u]);
+                for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].y, acc1[t][4 * q + 1], acc2[u]);
 #pragma unroll
-            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].z, acc1[t][4 * q + 2], acc2[u]);
+                for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].z, acc1[t][4 * q + 2], acc2[u]);
 #pragma unroll
-            for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].w, acc1[t][4 * q + 3], acc2[u]);
+                for (int u = 0; u < NT2; ++u) acc2[u] = MFMA32(a[u].w, acc1[t][4 * q + 3], acc2[u]);
+            }
+        };
+        if (XMODE == 0) {
+            load_w<NT2>(w2reg, wnext, srow, sk8);
+            chunk2();
+            store_w<NT2>(w2reg, Wn, srow, sk8);
+        } else {
+            // same pinning as layer 1: the next chunk's weight loads are issued in front of the
+            // MFMAs (named scalars: see above)
+            static_assert(XMODE == 0 || NT2 == 7, "vector staging is written for 7 feature tiles");
+            const float4* wsrc = reinterpret_cast<const float4*>(wnext);
+#define SMX_WLD(i) wsrc[(srow + 32 * (i)) * 8 + sk8]
+#define SMX_WST(i, v) *reinterpret_cast<float4*>(Wn + (srow + 32 * (i)) * LDS_STRIDE + 4 * sk8) = (v)
+            const float4 v0 = SMX_WLD(0), v1 = SMX_WLD(1), v2 = SMX_WLD(2), v3 = SMX_WLD(3);
+            const float4 v4 = SMX_WLD(4), v5 = SMX_WLD(5), v6 = SMX_WLD(6);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk2();
+            __builtin_amdgcn_sched_barrier(0);
+            SMX_WST(0, v0); SMX_WST(1, v1); SMX_WST(2, v2); SMX_WST(3, v3);
+            SMX_WST(4, v4); SMX_WST(5, v5); SMX_WST(6, v6);
+#undef SMX_WLD
+#undef SMX_WST
         }
-        store_w<NT2>(w2reg, (t & 1) ? Wb0 : Wb1, srow, sk8);
         __syncthreads();
     }
 #pragma unroll
@@ -387,18 +526,22 @@ int launch_fused(const FusedArgs& A, hipStream_t st) {
     const size_t lds = (size_t)(2 * WR * LDS_STRIDE + 2 * ROWS_PER_WG * LDS_STRIDE + NT1 * 32 +
                                 NT2 * 32 + NT2 * 32) * sizeof(float);
     const unsigned grid = (unsigned)((A.total_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
-    hipError_t e;
+    // vector x staging only in the large-tile build (the small one is not a throughput path)
+    const int xmode = (NT1 > 2 && A.xvec && A.D >= 4) ? (A.zmean ? 1 : 2) : 0;
+    void (*k)(FusedArgs) = nullptr;
     if (A.OUT == 1) {
-        auto k = mlp3_fused_kernel<NT1, NT2, true>;
-        e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, A);
+        k = xmode == 1 ? mlp3_fused_kernel<NT1, NT2, true, (NT1 > 2 ? 1 : 0)>
+          : xmode == 2 ? mlp3_fused_kernel<NT1, NT2, true, (NT1 > 2 ? 2 : 0)>
+                       : mlp3_fused_kernel<NT1, NT2, true, 0>;
     } else {
-        auto k = mlp3_fused_kernel<NT1, NT2, false>;
-        e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, A);
+        k = xmode == 1 ? mlp3_fused_kernel<NT1, NT2, false, (NT1 > 2 ? 1 : 0)>
+          : xmode == 2 ? mlp3_fused_kernel<NT1, NT2, false, (NT1 > 2 ? 2 : 0)>
+                       : mlp3_fused_kernel<NT1, NT2, false, 0>;
     }
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, A);
     e = hipGetLastError();
     return e == hipSuccess ? SMX_OK : (int)e;
 }
