@@ -108,11 +108,17 @@ __device__ __forceinline__ void store_x_vec(float* Xb, const float4 (&xreg)[4], 
     for (int i = 0; i < 4; ++i) {
         float4 v = xreg[i];
         const bool ok = xok[i] && kin;          // padded k (>= D) and padded rows stay exactly zero
-        if (HASZ) {
-            v.x = ok ? zf(v.x, zm.x, zs.x) : 0.f;
-            v.y = ok ? zf(v.y, zm.y, zs.y) : 0.f;
-            v.z = ok ? zf(v.z, zm.z, zs.z) : 0.f;
-            v.w = ok ? zf(v.w, zm.w, zs.w) : 0.f;
+        if (HASZ) {      // same arithmetic as stage_x below: (x - m) * (1 / s)
+            float a = (v.x - zm.x) * (1.0f / zs.x), b = (v.y - zm.y) * (1.0f / zs.y);
+            float c = (v.z - zm.z) * (1.0f / zs.z), d = (v.w - zm.w) * (1.0f / zs.w);
+            if (a == a) a = fminf(fmaxf(a, -5.0f), 5.0f);
+            if (b == b) b = fminf(fmaxf(b, -5.0f), 5.0f);
+            if (c == c) c = fminf(fmaxf(c, -5.0f), 5.0f);
+            if (d == d) d = fminf(fmaxf(d, -5.0f), 5.0f);
+            v.x = ok ? a : 0.f;
+            v.y = ok ? b : 0.f;
+            v.z = ok ? c : 0.f;
+            v.w = ok ? d : 0.f;
         } else if (!ok) {
             v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -120,14 +126,22 @@ __device__ __forceinline__ void store_x_vec(float* Xb, const float4 (&xreg)[4], 
     }
 }
 
+// (x - m) * (1/s) instead of (x - m) / s: one rounding more than z_filter.py:77 (<= 1 ulp of the
+// filtered input, ~1e-7 relative -- far inside the 1e-5 contract) for a quarter of the vector-ALU
+// work: the reciprocal is formed once per lane and chunk, not once per element.
+__device__ __forceinline__ float zf_mul(float x, float m, float r) {
+    float v = (x - m) * r;
+    if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);
+    return v;
+}
+
 template <bool HASZ>
-__device__ __forceinline__ void stage_x(float* dst, float4 v, const float4 zm, const float4 zs,
+__device__ __forceinline__ void stage_x(float* dst, float4 v, const float4 zm, const float4 rz,
                                         const bool ok) {
     if (HASZ) {
-        // computed unconditionally, then selected: a conditional division becomes a divergent
-        // branch per element
-        const float a = zf(v.x, zm.x, zs.x), b = zf(v.y, zm.y, zs.y);
-        const float c = zf(v.z, zm.z, zs.z), d = zf(v.w, zm.w, zs.w);
+        // computed unconditionally, then selected: a conditional term becomes a divergent branch
+        const float a = zf_mul(v.x, zm.x, rz.x), b = zf_mul(v.y, zm.y, rz.y);
+        const float c = zf_mul(v.z, zm.z, rz.z), d = zf_mul(v.w, zm.w, rz.w);
         v.x = ok ? a : 0.f;
         v.y = ok ? b : 0.f;
         v.z = ok ? c : 0.f;
@@ -316,19 +330,22 @@ __global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
             const float4 wb2 = SMX_WLD(2), wb3 = SMX_WLD(3), wb4 = SMX_WLD(4), wb5 = SMX_WLD(5);
             const float4 wb6 = SMX_WLD(6), wb7 = SMX_WLD(7), wb8 = SMX_WLD(8), wb9 = SMX_WLD(9);
             __builtin_amdgcn_sched_barrier(0);
-            // batch A (z-filter divisions + LDS stores) is free to interleave with these MFMAs.
+            // batch A: the z-filter divisions may run under these MFMAs; its LDS stores follow the
+            // fragment reads in program order (hipcc cannot tell the two staging buffers apart).
             // The empty asm re-defines the loaded x registers HERE: without it the (pure) z-filter
             // arithmetic is emitted right behind the loads at the top of the chunk, in front of the
             // first sched_barrier, and waits for HBM there.
             asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y),
                               "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w),
                               "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w));
-            stage_x<XMODE == 1>(Xn + (srow + 0) * LDS_STRIDE + sk4, x0, zm, zs, xok[0] && kin);
-            stage_x<XMODE == 1>(Xn + (srow + 32) * LDS_STRIDE + sk4, x1, zm, zs, xok[1] && kin);
-            stage_x<XMODE == 1>(Xn + (srow + 64) * LDS_STRIDE + sk4, x2, zm, zs, xok[2] && kin);
-            stage_x<XMODE == 1>(Xn + (srow + 96) * LDS_STRIDE + sk4, x3, zm, zs, xok[3] && kin);
-            SMX_WST(0, wa0); SMX_WST(1, wa1);
+            asm volatile("" : "+v"(zs.x), "+v"(zs.y), "+v"(zs.z), "+v"(zs.w));
+            const float4 rz = make_float4(1.0f / zs.x, 1.0f / zs.y, 1.0f / zs.z, 1.0f / zs.w);
             kgroup(2); kgroup(3);
+            stage_x<XMODE == 1>(Xn + (srow + 0) * LDS_STRIDE + sk4, x0, zm, rz, xok[0] && kin);
+            stage_x<XMODE == 1>(Xn + (srow + 32) * LDS_STRIDE + sk4, x1, zm, rz, xok[1] && kin);
+            stage_x<XMODE == 1>(Xn + (srow + 64) * LDS_STRIDE + sk4, x2, zm, rz, xok[2] && kin);
+            stage_x<XMODE == 1>(Xn + (srow + 96) * LDS_STRIDE + sk4, x3, zm, rz, xok[3] && kin);
+            SMX_WST(0, wa0); SMX_WST(1, wa1);
             __builtin_amdgcn_sched_barrier(0);
             SMX_WST(2, wb2); SMX_WST(3, wb3); SMX_WST(4, wb4); SMX_WST(5, wb5);
             SMX_WST(6, wb6); SMX_WST(7, wb7); SMX_WST(8, wb8); SMX_WST(9, wb9);
