@@ -129,3 +129,28 @@ def test_rnn_three_learns_match_oracle():
                 np.testing.assert_allclose(sl[k], so[k], atol=at, rtol=rt,
                                            err_msg='iteration %d stat %s' % (it, k))
     assert len(learner._graphs) == 1
+
+
+def test_learns_on_moving_batches_use_staging_graph():
+    """batches that arrive at a new address every time (what a sampling replay hands over): the
+    learner captures once on its own staging buffers and replays -- same numbers as the oracle"""
+    import ppo_oracle
+    g, case = H.load_golden('cfg2_adapt')
+    batch, params, zstate = H.case_inputs(case)
+    hyper = dict(case['hyper'])
+    hyper['n_step'] = case['shape']['N']
+    O = ppo_oracle.OraclePPOLearner(params, case['shape']['A'], case['shape']['B'], zstate=zstate, **hyper)
+    learner = H.make_learner(case, params, zstate)
+    captures = []
+    orig = torch.cuda.CUDAGraph
+    for it in range(4):
+        so = O.learn(copy.deepcopy(batch))
+        sl = learner.learn(copy.deepcopy(batch))           # fresh host arrays -> fresh device tensors
+        for k in so:
+            if k != '_lr':
+                at, rt = H.tol_for(k, H.ATOL, 2e-5)
+                np.testing.assert_allclose(sl[k], so[k], atol=at, rtol=rt,
+                                           err_msg='iteration %d stat %s' % (it, k))
+        captures.append(id(next(iter(learner._graphs.values()))))
+    assert learner._ws.staged is not None and len(learner._graphs) == 1
+    assert captures[1] == captures[2] == captures[3]       # one staging-graph capture, then replays
