@@ -378,6 +378,188 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(BwdArgs a) {
     }
 }
 
+// ===========================================================================================
+// 4-row formulation (H <= 112): the same recurrence on v_mfma_f32_4x4x1_16b_f32.  One instruction
+// is 16 independent 4x4 outer products (K = 1): block b of lane l = 4b + j multiplies the 4 batch
+// rows h[i][k] (A operand, lane & 3 = i, the same for every block) with gate column 64w + l of
+// W_hh (B operand, lane = column) -- 4 rows x 64 columns per instruction at the same FLOP rate as
+// the 16x16x4 form, but a workgroup now owns 4 batch rows instead of 16: four times the
+// workgroups (B = 64 -> 16, B = 1024 -> 256 = the whole chip) and a quarter of the serial work
+// per time step.  Wave w keeps W_hh[64w + lane][0..H) in registers for the whole sequence.
+// ===========================================================================================
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+constexpr int RB4 = 4;
+
+// KQ: 4-wide k groups covering H (H <= 4*KQ)
+template <int KQ>
+__global__ __launch_bounds__(NT) void lstm_fwd4_kernel(FwdArgs a) {
+    extern __shared__ float smem[];
+    if (a.stop && *a.stop) return;
+    const int H = a.H, G = 4 * H, T = a.T;
+    constexpr int HS = KQ * 4 + 4;             // h row stride in LDS (columns >= H stay zero)
+    constexpr int GS = NWV * 64 + 4;           // gate row stride (every wave writes its 64 columns)
+    float* hs = smem;                          // [4][HS]
+    float* gh = smem + RB4 * HS;               // [4][GS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * RB4;
+    const int col = wv * 64 + lane;            // gate column of this lane
+
+    float4 wq[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+        wq[q] = (col < G && 4 * q < H)
+                    ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + 4 * q)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bias = (col < G) ? a.b_hh[col] : 0.f;
+
+    for (int idx = tid; idx < RB4 * HS; idx += NT) hs[idx] = 0.f;
+    __syncthreads();
+    // one (row, unit) element per thread
+    const int erow = tid / H, ej = tid - erow * H;
+    const bool ev = tid < RB4 * H;
+    const bool inb = ev && row0 + erow < a.B;
+    const unsigned eoff = inb ? (unsigned)(row0 + erow) * (unsigned)(T * H) + (unsigned)ej : 0u;
+    float creg = (inb && a.c0) ? a.c0[(size_t)(row0 + erow) * H + ej] : 0.f;
+    if (inb && a.h0) hs[erow * HS + ej] = a.h0[(size_t)(row0 + erow) * H + ej];
+    __syncthreads();
+
+    const float* hrow = hs + (lane & 3) * HS;
+    for (int t = 0; t < T; ++t) {
+        float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
+        if (inb) {
+            const unsigned og = (eoff - ej + (unsigned)(t * H)) * 4u + ej;
+            gx0 = a.gates[og]; gx1 = a.gates[og + (unsigned)H];
+            gx2 = a.gates[og + (unsigned)(2 * H)]; gx3 = a.gates[og + (unsigned)(3 * H)];
+        }
+        if (wv * 64 < G) {                     // wave-uniform: waves past the last gate column idle
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float4 hv = *reinterpret_cast<const float4*>(hrow + 4 * q);
+                acc = MFMA4(hv.x, wq[q].x, acc);
+                acc = MFMA4(hv.y, wq[q].y, acc);
+                acc = MFMA4(hv.z, wq[q].z, acc);
+                acc = MFMA4(hv.w, wq[q].w, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gh[r * GS + col] = acc[r] + bias;
+        }
+        __syncthreads();
+        if (ev) {
+            const float* g = gh + erow * GS + ej;
+            const float gi = sigm(gx0 + g[0]);
+            const float gf = sigm(gx1 + g[H]);
+            const float gg = tanhf(gx2 + g[2 * H]);
+            const float go = sigm(gx3 + g[3 * H]);
+            const float c = gf * creg + gi * gg;
+            const float h = go * tanhf(c);
+            if (inb) {
+                const unsigned oh = eoff + (unsigned)(t * H);
+                const unsigned og = (oh - ej) * 4u + ej;
+                a.gates[og] = gi; a.gates[og + (unsigned)H] = gf;
+                a.gates[og + (unsigned)(2 * H)] = gg; a.gates[og + (unsigned)(3 * H)] = go;
+                a.out[oh] = h;
+                a.cs[oh] = c;
+                if (a.hprev) a.hprev[oh] = hs[erow * HS + ej];
+                creg = c;
+                hs[erow * HS + ej] = h;
+            }
+        }
+        __syncthreads();
+    }
+    if (inb) {
+        if (a.hN) a.hN[(size_t)(row0 + erow) * H + ej] = hs[erow * HS + ej];
+        if (a.cN) a.cN[(size_t)(row0 + erow) * H + ej] = creg;
+    }
+}
+
+// Backward: dh_rec[4][H] = dgates_t[4][4H] . W_hh[4H][H].  The K = 4H sum is split over the four
+// gate blocks: wave w handles gate block w & 3 for hidden columns 64 (w >> 2) + lane and keeps its
+// W_hh slice in registers; the four partial sums meet in LDS and are added in a fixed order by the
+// next step's elementwise phase.
+template <int KQ>
+__global__ __launch_bounds__(NT) void lstm_bwd4_kernel(BwdArgs a) {
+    extern __shared__ float smem[];
+    if (a.stop && *a.stop) return;
+    const int H = a.H, G = 4 * H, T = a.T;
+    constexpr int DS = 4 * (KQ * 4) + 4;       // dgates row stride: four gate blocks of KQ*4 (zero padded)
+    constexpr int PS = 128 + 4;                // partial row stride (two 64-column groups)
+    float* dg = smem;                          // [4][DS]   block q at columns [q*KQ*4, q*KQ*4 + H)
+    float* part = smem + RB4 * DS;             // [4 gate blocks][4 rows][PS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * RB4;
+    const int gb = wv & 3, cg = wv >> 2;
+    const int n = cg * 64 + lane;              // hidden column of this lane
+
+    float4 wq[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < H && 4 * q < H) {
+            const float* p = a.W_hh + ((size_t)gb * H + 4 * q) * H + n;
+            w.x = p[0]; w.y = p[H]; w.z = p[2 * (size_t)H]; w.w = p[3 * (size_t)H];
+        }
+        wq[q] = w;
+    }
+    for (int idx = tid; idx < RB4 * DS + 4 * RB4 * PS; idx += NT) smem[idx] = 0.f;
+    const int erow = tid / H, ej = tid - erow * H;
+    const bool ev = tid < RB4 * H;
+    const bool inb = ev && row0 + erow < a.B;
+    const unsigned eoff = inb ? (unsigned)(row0 + erow) * (unsigned)(T * H) + (unsigned)ej : 0u;
+    float dcreg = 0.f;
+    __syncthreads();
+
+    const float* drow = dg + (lane & 3) * DS + gb * (KQ * 4);
+    for (int t = T - 1; t >= 0; --t) {
+        if (inb) {
+            const unsigned oh = eoff + (unsigned)(t * H);
+            const unsigned og = (oh - ej) * 4u + ej;
+            const float gi = a.gates[og], gf = a.gates[og + (unsigned)H];
+            const float gg = a.gates[og + (unsigned)(2 * H)], go = a.gates[og + (unsigned)(3 * H)];
+            const float c = a.cs[oh];
+            const float cp = (t > 0) ? a.cs[oh - (unsigned)H]
+                                     : (a.c0 ? a.c0[(size_t)(row0 + erow) * H + ej] : 0.f);
+            const float* pp = part + erow * PS + ej;
+            const float dhr = ((pp[0] + pp[RB4 * PS]) + pp[2 * RB4 * PS]) + pp[3 * RB4 * PS];
+            const float dh = a.dout[oh] + dhr;
+            const float tc = tanhf(c);
+            const float dc = dcreg + (dh * go) * (1.f - tc * tc);
+            const float dgi = (dc * gg) * (gi * (1.f - gi));
+            const float dgf = (dc * cp) * (gf * (1.f - gf));
+            const float dgg = (dc * gi) * (1.f - gg * gg);
+            const float dgo = (dh * tc) * (go * (1.f - go));
+            dcreg = dc * gf;
+            a.dgates[og] = dgi; a.dgates[og + (unsigned)H] = dgf;
+            a.dgates[og + (unsigned)(2 * H)] = dgg; a.dgates[og + (unsigned)(3 * H)] = dgo;
+            float* gl = dg + erow * DS + ej;
+            gl[0] = dgi; gl[KQ * 4] = dgf; gl[2 * KQ * 4] = dgg; gl[3 * KQ * 4] = dgo;
+        }
+        __syncthreads();
+        if (t > 0 && cg * 64 < H) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float4 dv = *reinterpret_cast<const float4*>(drow + 4 * q);
+                acc = MFMA4(dv.x, wq[q].x, acc);
+                acc = MFMA4(dv.y, wq[q].y, acc);
+                acc = MFMA4(dv.z, wq[q].z, acc);
+                acc = MFMA4(dv.w, wq[q].w, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(gb * RB4 + r) * PS + n] = acc[r];
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
+
+inline size_t lds4_fwd(int kq) { return (size_t)RB4 * ((kq * 4 + 4) + (NWV * 64 + 4)) * sizeof(float); }
+inline size_t lds4_bwd(int kq) { return (size_t)(RB4 * (16 * kq + 4) + 4 * RB4 * (128 + 4)) * sizeof(float); }
+
 constexpr int KG_CACHED = 7;     // H <= 112: W_hh fragments in registers
 constexpr int KG_MAX = 24;       // H <= 384: fragments re-read from L2 every step (LDS-bound)
 
@@ -411,7 +593,13 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     a.cs = cs; a.hprev = hprev; a.hN = hN; a.cN = cN; a.stop = stop_flag;
     a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
-    if (H <= 16 * KG_CACHED) {
+    if (H <= 100) {
+        hipLaunchKernelGGL((lstm_fwd4_kernel<25>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
+                           lds4_fwd(25), smx_s(stream), a);
+    } else if (H <= 4 * KQ4) {
+        hipLaunchKernelGGL((lstm_fwd4_kernel<KQ4>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
+                           lds4_fwd(KQ4), smx_s(stream), a);
+    } else if (H <= 16 * KG_CACHED) {
         hipLaunchKernelGGL((lstm_fwd_kernel<KG_CACHED, true>), dim3(blocks), dim3(NT),
                            lds_bytes(KG_CACHED, H, true), smx_s(stream), a);
     } else {
@@ -443,7 +631,13 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     a.W_hh = net->W_hh; a.c0 = c0; a.gates = gates; a.cs = cs; a.dout = dout; a.dgates = dgates;
     a.stop = stop_flag; a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
-    if (H <= 16 * KG_CACHED) {
+    if (H <= 100) {
+        hipLaunchKernelGGL((lstm_bwd4_kernel<25>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
+                           lds4_bwd(25), smx_s(stream), a);
+    } else if (H <= 4 * KQ4) {
+        hipLaunchKernelGGL((lstm_bwd4_kernel<KQ4>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
+                           lds4_bwd(KQ4), smx_s(stream), a);
+    } else if (H <= 16 * KG_CACHED) {
         hipLaunchKernelGGL((lstm_bwd_kernel<KG_CACHED, true>), dim3(blocks), dim3(NT),
                            lds_bytes_bwd_cached(KG_CACHED), smx_s(stream), a);
     } else {

@@ -415,7 +415,9 @@ def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
     (5, 4, 7, 12, True),         # tiny golden
     (37, 9, 17, 100, False),     # ragged rows, zero initial state
     (64, 21, 17, 100, True),     # cfg2-sized batch
-    (3, 5, 9, 128, True),        # H > 112: W_hh fragments re-read every step
+    (6, 7, 9, 108, True),        # 100 < H <= 112: the wider 4-row instantiation
+    (1024, 3, 17, 100, True),    # one workgroup per 4 rows: 256 workgroups
+    (3, 5, 9, 128, True),        # H > 112: 16-row kernels, W_hh fragments re-read every step
     (20, 6, 11, 256, True),
 ])
 def test_lstm_forward_backward_match_aten(K, B, T, D, H, cells):
