@@ -117,6 +117,15 @@ int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X, int32_t l
                          int32_t ldw, float* db, int32_t M, int32_t N, int32_t rows,
                          smx_stream_t stream);
 
+/* The same with the rows cut into chunks (split-K) when rows >> 1000 -- the weight gradients of
+ * the LSTM / CNN stems run over B*T or B*E*pixels rows.  ws: caller's workspace of at least
+ * smx_linear_wgrad_ws_floats(M, N, rows) floats (0 = the plain entry point is used); partial
+ * tiles are added in a fixed order (deterministic).  ws == NULL falls back to the plain call. */
+int64_t smx_linear_wgrad_ws_floats(int32_t M, int32_t N, int32_t rows);
+int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
+                                float* dW, int32_t ldw, float* db, int32_t M, int32_t N,
+                                int32_t rows, float* ws, int64_t ws_floats, smx_stream_t stream);
+
 /* One MLP forward or backward "job" for the multi-network entry points below: PPO's actor and
  * critic are independent networks updated in lock-step epochs (ppo.py:541-562), so their
  * layer-l GEMMs share one launch.  Forward uses net/x/rows/h1/h2/out/out_act; backward uses
@@ -426,11 +435,15 @@ int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64_t B, int32
 
 /* Back-propagation through time given dout [B, T, H] = dLoss/dh_t from the layers above
  * (h0, c0 are constants: ppo.py:511-515 detaches them).  dgates [B, T, 4H] is workspace (it may
- * alias `gates`).  grads receives dW_ih, dW_hh, db_ih, db_hh (overwritten, not accumulated). */
+ * alias `gates`).  grads receives dW_ih, dW_hh, db_ih, db_hh (overwritten, not accumulated).
+ * ws / ws_floats: optional split-K workspace for the two weight-gradient GEMMs over B*T rows
+ * (smx_lstm_backward_ws_floats; NULL = unsplit). */
+int64_t smx_lstm_backward_ws_floats(int32_t D, int32_t H, int64_t B, int32_t T);
 int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int64_t B, int32_t T,
                           const float* c0, const float* gates, const float* cs,
                           const float* hprev, const float* dout, float* dgates, float* grads,
-                          const int32_t* stop_flag, smx_stream_t stream);
+                          const int32_t* stop_flag, float* ws, int64_t ws_floats,
+                          smx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CNN stem data movement (surreal/model/model_builders/builders.py:8-33 CNNStemNetwork;

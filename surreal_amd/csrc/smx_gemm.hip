@@ -27,6 +27,10 @@ struct GemmProb {
     int tiles_m, tiles_n, tile_base, a_mode, b_mode;   // 0 kc-vec, 1 kc-scalar, 2 k-strided
     unsigned a_bytes, b_bytes;   // extent of each operand for the buffer descriptors (< 2 GiB)
     const int* stop;     // device flag: non-zero -> this problem is skipped
+    // split-K (weight gradients over many rows): `splits` workgroups share an output tile, each
+    // sums k in [s*k_chunk, (s+1)*k_chunk) into its own slice C + s*c_split (dbias + s*M)
+    int splits, k_chunk;
+    long c_split;
 };
 
 constexpr int MAX_PROBS = 6;
@@ -125,17 +129,24 @@ __device__ __forceinline__ void mma_sb(f32x16& acc, float& asum, const Frag8& f)
 // a ring so that up to three super-blocks of operand loads (24 x 16 B per lane) are in flight
 // ahead of the MFMAs: these GEMMs are latency-bound, not bandwidth-bound.  Loads past K are
 // out-of-range buffer loads (no memory traffic); MFMAs past K are skipped (wave-uniform).
+struct KRange {          // the K range this workgroup sums (the whole K unless split)
+    const float* A;
+    const float* B;
+    unsigned a_bytes, b_bytes;
+    int K;
+};
+
 template <int AM, int BM>
-__device__ __forceinline__ void mainloop(const GemmProb& P, int m0, int n0, int i, int kh, int wv,
-                                         f32x16& acc, float& asum) {
-    const int nsb = (P.K + 31) >> 5;
+__device__ __forceinline__ void mainloop(const GemmProb& P, const KRange& R, int m0, int n0, int i,
+                                         int kh, int wv, f32x16& acc, float& asum) {
+    const int nsb = (R.K + 31) >> 5;
     const int kofs = 4 * kh;
     Operands O;
-    O.ra = make_rsrc(P.A, P.a_bytes);
-    O.rb = make_rsrc(P.B, P.b_bytes);
+    O.ra = make_rsrc(R.A, R.a_bytes);
+    O.rb = make_rsrc(R.B, R.b_bytes);
     O.abase = row_base<AM>(P.lda, m0 + i, P.M);
     O.bbase = row_base<BM>(P.ldb, n0 + i, P.N);
-    O.lda = P.lda; O.ldb = P.ldb; O.K = P.K;
+    O.lda = P.lda; O.ldb = P.ldb; O.K = R.K;
     Frag8 f0, f1, f2;
     // the barriers pin the issue order f0, f1, f2 (vmcnt is in-order: the wait for f0 must not
     // cover f1 / f2)
@@ -174,7 +185,20 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
         if (k < G.n && (int)blockIdx.x >= G.p[k].tile_base) pi = k;
     const GemmProb& P = G.p[pi];
     if (P.stop && *P.stop) return;
-    const int tile = blockIdx.x - P.tile_base;
+    int tile = blockIdx.x - P.tile_base;
+    int sp = 0;
+    KRange R;
+    R.A = P.A; R.B = P.B; R.a_bytes = P.a_bytes; R.b_bytes = P.b_bytes; R.K = P.K;
+    if (P.splits > 1) {
+        sp = tile % P.splits;
+        tile /= P.splits;
+        const int k0 = sp * P.k_chunk;
+        R.K = min(P.k_chunk, P.K - k0);
+        R.A = P.A + (P.a_kc ? (size_t)k0 : (size_t)k0 * P.lda);
+        R.B = P.B + (P.b_kc ? (size_t)k0 : (size_t)k0 * P.ldb);
+        R.a_bytes = 4u * (P.a_kc ? (unsigned)(P.M - 1) * P.lda + R.K : (unsigned)(R.K - 1) * P.lda + P.M);
+        R.b_bytes = 4u * (P.b_kc ? (unsigned)(P.N - 1) * P.ldb + R.K : (unsigned)(R.K - 1) * P.ldb + P.N);
+    }
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
 
@@ -187,17 +211,17 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float asum = 0.f;
 
-    if (ALL_VEC) mainloop<0, 0>(P, m0, n0, i, kh, wv, acc, asum);
+    if (ALL_VEC) mainloop<0, 0>(P, R, m0, n0, i, kh, wv, acc, asum);
     else switch (P.a_mode * 3 + P.b_mode) {   // workgroup-uniform
-        case 0: mainloop<0, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 1: mainloop<0, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 2: mainloop<0, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 3: mainloop<1, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 4: mainloop<1, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 5: mainloop<1, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 6: mainloop<2, 0>(P, m0, n0, i, kh, wv, acc, asum); break;
-        case 7: mainloop<2, 1>(P, m0, n0, i, kh, wv, acc, asum); break;
-        default: mainloop<2, 2>(P, m0, n0, i, kh, wv, acc, asum); break;
+        case 0: mainloop<0, 0>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 1: mainloop<0, 1>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 2: mainloop<0, 2>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 3: mainloop<1, 0>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 4: mainloop<1, 1>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 5: mainloop<1, 2>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 6: mainloop<2, 0>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        case 7: mainloop<2, 1>(P, R, m0, n0, i, kh, wv, acc, asum); break;
+        default: mainloop<2, 2>(P, R, m0, n0, i, kh, wv, acc, asum); break;
     }
 
     // ---- combine the 4 K-partials through LDS (fixed order => deterministic) -------------
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
             if (P.bias) v += P.bias[n];
             v = act_f(v, P.act);
             if (P.mask) v = (P.mask[(size_t)m * P.ldc + n] > 0.f) ? v : 0.f;
-            P.C[(size_t)m * P.ldc + n] = v;
+            P.C[(size_t)sp * P.c_split + (size_t)m * P.ldc + n] = v;
             if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
             ss += v * v;
         }
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
 #pragma unroll
         for (int w = 0; w < 8; ++w) d += dbr[w][tid];
         if (m0 + tid < P.M) {
-            P.dbias[m0 + tid] = d;
+            P.dbias[(size_t)sp * P.M + m0 + tid] = d;
             ss += d * d;
         }
     }
@@ -256,6 +280,7 @@ inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const floa
     P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
     P.a_kc = a_kc; P.b_kc = b_kc; P.act = act;
     P.tiles_m = (M + 31) / 32; P.tiles_n = (N + 31) / 32; P.tile_base = tile_base;
+    P.splits = 1; P.k_chunk = K; P.c_split = 0;
     P.a_mode = !a_kc ? 2 : ((lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A & 15) == 0) ? 0 : 1);
     P.b_mode = !b_kc ? 2 : ((ldb % 4 == 0 && K % 4 == 0 && ((uintptr_t)B & 15) == 0) ? 0 : 1);
     P.a_bytes = (unsigned)operand_bytes(lda, a_kc, M, K);
@@ -264,15 +289,16 @@ inline void fill_prob(GemmProb& P, const float* A, int lda, int a_kc, const floa
 
 // every operand must fit a 31-bit byte offset (buffer descriptor addressing)
 inline bool prob_ok(const GemmProb& P) {
-    return operand_bytes(P.lda, P.a_kc, P.M, P.K) < (1ull << 31) &&
-           operand_bytes(P.ldb, P.b_kc, P.N, P.K) < (1ull << 31);
+    const int Kc = P.splits > 1 ? P.k_chunk : P.K;       // what one workgroup addresses
+    return operand_bytes(P.lda, P.a_kc, P.M, Kc) < (1ull << 31) &&
+           operand_bytes(P.ldb, P.b_kc, P.N, Kc) < (1ull << 31);
 }
 
 inline int launch_batch(GemmBatch& G, hipStream_t st) {
     for (int k = 0; k < G.n; ++k)
         if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
     const GemmProb& L = G.p[G.n - 1];
-    const int blocks = L.tile_base + L.tiles_m * L.tiles_n;
+    const int blocks = L.tile_base + L.tiles_m * L.tiles_n * L.splits;
     bool all_vec = true;
     for (int k = 0; k < G.n; ++k) all_vec = all_vec && G.p[k].a_mode == 0 && G.p[k].b_mode == 0;
     if (all_vec) hipLaunchKernelGGL(gemm32_kernel<true>, dim3(blocks), dim3(256), 0, st, G);
@@ -308,6 +334,82 @@ extern "C" int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X
     fill_prob(G.p[0], dZ, ldz, 0, X, ldx, 0, nullptr, nullptr, dW, ldw, M, N, rows, SMX_ACT_NONE, db,
               nullptr, 0);
     return launch_batch(G, smx_s(stream));
+}
+
+// ---------------------------------------------------------------------------
+// split-K weight gradient: with rows >> 10^3 a 32x32 tile of dW would be ONE workgroup walking
+// all rows (LSTM / CNN stems: rows = B*T, B*E*pixels ~ 10^5).  The rows are cut into `splits`
+// chunks, each (tile, chunk) is a workgroup writing a partial tile into the caller's workspace,
+// and a second launch adds the chunks in a fixed order (deterministic).
+// ---------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
+                                                            const float* __restrict__ dbpart,
+                                                            int splits, int M, int N,
+                                                            float* __restrict__ dW, int ldw,
+                                                            float* __restrict__ db) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total + M; i += (long)gridDim.x * 256) {
+        if (i < total) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
+            const long m = i / N;
+            dW[m * ldw + (i - m * N)] = v;
+        } else if (db) {
+            const long m = i - total;
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += dbpart[(size_t)s * M + m];
+            db[m] = v;
+        }
+    }
+}
+
+inline int pick_splits(int M, int N, int rows) {
+    const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    int s = rows / 1024;                    // >= 8 super-blocks per wave and chunk
+    const int cap = (2048 + tiles - 1) / tiles;     // ~8 workgroups per CU at most
+    if (s > cap) s = cap;
+    if (s > 256) s = 256;
+    return s < 2 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" int64_t smx_linear_wgrad_ws_floats(int32_t M, int32_t N, int32_t rows) {
+    const int s = pick_splits(M, N, rows);
+    return s > 1 ? (int64_t)s * ((int64_t)M * N + M) : 0;
+}
+
+extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const float* X,
+                                           int32_t ldx, float* dW, int32_t ldw, float* db,
+                                           int32_t M, int32_t N, int32_t rows, float* ws,
+                                           int64_t ws_floats, smx_stream_t stream) {
+    SMX_REQUIRE(dZ && X && dW, SMX_E_NULL);
+    SMX_REQUIRE(M > 0 && N > 0 && rows > 0 && ldz >= M && ldx >= N && ldw >= N, SMX_E_SHAPE);
+    const int S = pick_splits(M, N, rows);
+    if (S <= 1 || !ws || ws_floats < (int64_t)S * ((int64_t)M * N + M))
+        return smx_linear_wgrad_f32(dZ, ldz, X, ldx, dW, ldw, db, M, N, rows, stream);
+    GemmBatch G;
+    G.n = 1;
+    float* part = ws;
+    float* dbpart = ws + (size_t)S * M * N;
+    fill_prob(G.p[0], dZ, ldz, 0, X, ldx, 0, nullptr, nullptr, part, N, M, N, rows, SMX_ACT_NONE,
+              dbpart, nullptr, 0);
+    G.p[0].splits = S;
+    G.p[0].k_chunk = ((rows + S - 1) / S + 31) & ~31;
+    G.p[0].c_split = (long)M * N;
+    // every chunk must be non-empty
+    while ((long)(G.p[0].splits - 1) * G.p[0].k_chunk >= rows) --G.p[0].splits;
+    const int rc = launch_batch(G, smx_s(stream));
+    if (rc) return rc;
+    const long total = (long)M * N + M;
+    long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), part,
+                       dbpart, G.p[0].splits, M, N, dW, ldw, db);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SMX_OK : (int)e;
 }
 
 // ---------------------------------------------------------------------------

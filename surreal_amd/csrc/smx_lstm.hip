@@ -621,7 +621,8 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
 extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int64_t B, int32_t T,
                                      const float* c0, const float* gates, const float* cs,
                                      const float* hprev, const float* dout, float* dgates,
-                                     float* grads, const int32_t* stop_flag, smx_stream_t stream) {
+                                     float* grads, const int32_t* stop_flag, float* ws,
+                                     int64_t ws_floats, smx_stream_t stream) {
     SMX_REQUIRE(net && x && gates && cs && hprev && dout && dgates && grads, SMX_E_NULL);
     SMX_REQUIRE(net->W_hh, SMX_E_NULL);
     const int H = net->H, D = net->D;
@@ -659,9 +660,17 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     float* gbih = gWhh + (size_t)4 * H * H;
     float* gbhh = gbih + 4 * H;
     const int32_t rows = (int32_t)(B * T);
-    int rc = smx_linear_wgrad_f32(dgates, 4 * H, x, D, gWih, D, gbih, 4 * H, D, rows, stream);
+    int rc = smx_linear_wgrad_splitk_f32(dgates, 4 * H, x, D, gWih, D, gbih, 4 * H, D, rows, ws,
+                                         ws_floats, stream);
     if (rc) return rc;
-    return smx_linear_wgrad_f32(dgates, 4 * H, hprev, H, gWhh, H, gbhh, 4 * H, H, rows, stream);
+    return smx_linear_wgrad_splitk_f32(dgates, 4 * H, hprev, H, gWhh, H, gbhh, 4 * H, H, rows, ws,
+                                       ws_floats, stream);
+}
+
+extern "C" int64_t smx_lstm_backward_ws_floats(int32_t D, int32_t H, int64_t B, int32_t T) {
+    const int64_t a = smx_linear_wgrad_ws_floats(4 * H, D, (int32_t)(B * T));
+    const int64_t b = smx_linear_wgrad_ws_floats(4 * H, H, (int32_t)(B * T));
+    return a > b ? a : b;
 }
 
 extern "C" int64_t smx_lstm_param_count(int32_t D, int32_t H) {

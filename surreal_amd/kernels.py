@@ -239,12 +239,19 @@ class HipKernels(object):
         L.call('smx_linear_f32', L.ptr(A), lda, int(a_kc), L.ptr(B), ldb, int(b_kc), L.ptr(bias),
                L.ptr(C), ldc, M, N, K, act, L.ptr(relu_mask), L.ptr(stop), self._st())
 
-    def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None):
+    def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None, ws=None):
+        """ws: optional split-K workspace (>= linear_wgrad_ws_floats(M, N, rows) floats)"""
         ldz = ldz if ldz is not None else dZ.stride(0)
         ldx = ldx if ldx is not None else X.stride(0)
         ldw = ldw if ldw is not None else dW.stride(0)
-        L.call('smx_linear_wgrad_f32', L.ptr(dZ), ldz, L.ptr(X), ldx, L.ptr(dW), ldw, L.ptr(db), M, N,
-               rows, self._st())
+        L.call('smx_linear_wgrad_splitk_f32', L.ptr(dZ), ldz, L.ptr(X), ldx, L.ptr(dW), ldw, L.ptr(db),
+               M, N, rows, L.ptr(ws), 0 if ws is None else ws.numel(), self._st())
+
+    def linear_wgrad_ws_floats(self, M, N, rows):
+        return int(self.lib.smx_linear_wgrad_ws_floats(M, N, rows))
+
+    def lstm_backward_ws_floats(self, net, B, T):
+        return int(self.lib.smx_lstm_backward_ws_floats(net.D, net.H, B, T))
 
     def ddpg_critic_loss(self, q, q_next, rewards, dones, gamma_n, y, dz3):
         L.call('smx_ddpg_critic_loss_f32', L.ptr(q), L.ptr(q_next), L.ptr(rewards), L.ptr(dones),
@@ -278,10 +285,11 @@ class HipKernels(object):
                L.ptr(gates), L.ptr(out), L.ptr(cs), L.ptr(hprev), L.ptr(hN), L.ptr(cN), L.ptr(stop),
                self._st())
 
-    def lstm_backward(self, net, x, B, T, c0, gates, cs, hprev, dout, dgates, grads, stop=None):
+    def lstm_backward(self, net, x, B, T, c0, gates, cs, hprev, dout, dgates, grads, stop=None,
+                      ws=None):
         L.call('smx_lstm_backward_f32', ctypes.byref(net.desc), L.ptr(x), B, T, L.ptr(c0),
                L.ptr(gates), L.ptr(cs), L.ptr(hprev), L.ptr(dout), L.ptr(dgates), L.ptr(grads),
-               L.ptr(stop), self._st())
+               L.ptr(stop), L.ptr(ws), 0 if ws is None else ws.numel(), self._st())
 
 
     # ---- CNN stem data movement ----------------------------------------------------------------

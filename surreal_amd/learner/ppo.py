@@ -282,6 +282,8 @@ class PPOLearner(Learner):
                 ws.h0, ws.c0 = f(B, F), f(B, F)
                 ws.gates, ws.lo, ws.cs, ws.hp, ws.dlo = f(rows, 4 * F), f(rows, F), f(rows, F), f(rows, F), f(rows, F)
                 ws.gatesG, ws.loG, ws.csG = f(R1, 4 * F), f(R1, F), f(R1, F)
+                n_sk = K.lstm_backward_ws_floats(self.model.rnn, B, E)
+                ws.lstm_sk = f(n_sk) if n_sk else None
             if pixel:
                 # CNN stem (builders.py:8-33): frames stay in their source dtype (uint8 from the
                 # cameras); the critic pass runs the stem in chunks to bound the patch matrices
@@ -293,6 +295,7 @@ class PPOLearner(Learner):
                 ws.dxn = torch.zeros(rows, Dx, device=dev)
                 chunk = int(self.session_config.learner.get('cnn_chunk_frames', 2048))
                 ws.cnn_it = CnnStem.workspace(cnn, rows, dev, backward=True)
+                ws.cnn_it.sk = self.model._cnn_stem.splitk_workspace(cnn, rows, dev)
                 ws.cnn_gae = ws.cnn_it if rows >= min(chunk, R1) else \
                     CnnStem.workspace(cnn, min(chunk, R1), dev, backward=False)
         else:
@@ -720,7 +723,7 @@ class PPOLearner(Learner):
             # d loss / d (LSTM output) = dz1 . W1, then BPTT (dgates overwrite the saved gates)
             K.linear(dz1, 1, net.views['W1'], 0, None, ws.dlo, ws.rows, m.rnn_hidden, net.H1, stop=stop)
             K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates, g_rnn,
-                            stop)
+                            stop, ws=ws.lstm_sk)
             up, upW, upK = ws.gates, m.rnn.views['weight_ih'], 4 * m.rnn_hidden
         else:
             up, upW, upK = dz1, net.views['W1'], net.H1

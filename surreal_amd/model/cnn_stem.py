@@ -76,10 +76,18 @@ class CnnStem(object):
         ws.cols1, ws.y1 = f(F * p.P1, p.K1), f(F * p.P1, p.c1)
         ws.cols2, ws.y2 = f(F * p.P2, p.K2), f(F * p.P2, p.c2)
         ws.wfc = f(p.feat, p.flat_dim)                 # fc.W re-indexed channel-last
+        ws.sk = None
         if backward:
             ws.dy2, ws.dcols2, ws.dy1 = f(F * p.P2, p.c2), f(F * p.P2, p.K2), f(F * p.P1, p.c1)
             ws.gwfc = f(p.feat, p.flat_dim)
         return ws
+
+    def splitk_workspace(self, p, F, device):
+        """split-K workspace of the two convolution weight gradients (their GEMMs sum over
+        F * pixels rows)"""
+        n = max(self.K.linear_wgrad_ws_floats(p.c2, p.K2, F * p.P2),
+                self.K.linear_wgrad_ws_floats(p.c1, p.K1, F * p.P1))
+        return torch.empty(n, device=device, dtype=torch.float32) if n else None
 
     def forward(self, p, frames, F, ws, out, stop=None):
         """frames: uint8 or fp32 [F, C, H, W] (contiguous); out: [F, feat] view (any row stride)"""
@@ -114,10 +122,10 @@ class CnnStem(object):
                  relu_mask=ws.y2.view(F, p.flat_dim), lda=ldz, stop=stop)
         # conv2: dW, db, data gradient scattered back through the patches * relu'(y1)
         K.linear_wgrad(ws.dy2, ws.cols2, gv['conv2.W'].view(p.c2, p.K2), gv['conv2.b'], p.c2, p.K2,
-                       F * p.P2)
+                       F * p.P2, ws=ws.sk)
         K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
                  stop=stop)
         K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)
         # conv1: dW, db (the frames carry no gradient)
         K.linear_wgrad(ws.dy1, ws.cols1, gv['conv1.W'].view(p.c1, p.K1), gv['conv1.b'], p.c1, p.K1,
-                       F * p.P1)
+                       F * p.P1, ws=ws.sk)

@@ -403,7 +403,7 @@ class TorchCpuKernels(object):
             out = out * (torch.as_strided(relu_mask, (M, N), (ldc, 1)) > 0)
         torch.as_strided(C, (M, N), (ldc, 1)).copy_(out)
 
-    def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None):
+    def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None, ws=None):
         ldz = ldz if ldz is not None else dZ.stride(0)
         ldx = ldx if ldx is not None else X.stride(0)
         ldw = ldw if ldw is not None else dW.stride(0)
@@ -439,7 +439,14 @@ class TorchCpuKernels(object):
         if cN is not None:
             cN.copy_(c)
 
-    def lstm_backward(self, net, x, B, T, c0, gates, cs, hprev, dout, dgates, grads, stop=None):
+    def linear_wgrad_ws_floats(self, M, N, rows):
+        return 0
+
+    def lstm_backward_ws_floats(self, net, B, T):
+        return 0
+
+    def lstm_backward(self, net, x, B, T, c0, gates, cs, hprev, dout, dgates, grads, stop=None,
+                      ws=None):
         if stop is not None and int(stop[0]) != 0:
             return
         v, H = net.views, net.H

@@ -602,3 +602,25 @@ def test_clip_adam_pair_equals_two_launches(K):
         outs.append([t.cpu().clone() for t in (ta, ma, va, tc, mc, vc, gna, gnc)])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('M,N,rows', [(400, 17, 7936), (400, 100, 31744), (16, 192, 102400), (33, 70, 5000), (8, 8, 900)])
+def test_linear_wgrad_splitk_matches_fp64(K, M, N, rows):
+    """weight gradients over many rows (LSTM: B*T, CNN: B*E*pixels): split-K partial tiles added in
+    a fixed order; compared with an fp64 reference (both the split and the plain kernel are fp32
+    sums, in different orders)"""
+    g = torch.Generator().manual_seed(M + rows)
+    dz, x = torch.randn(rows, M, generator=g), torch.randn(rows, N, generator=g)
+    ref_w = (dz.double().t() @ x.double())
+    ref_b = dz.double().sum(0)
+    n_ws = K.linear_wgrad_ws_floats(M, N, rows)
+    assert (n_ws > 0) == (rows >= 2048)
+    ws = torch.empty(max(n_ws, 1), device='cuda')
+    dW, db = torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda')
+    K.linear_wgrad(dz.cuda(), x.cuda(), dW, db, M, N, rows, ws=ws if n_ws else None)
+    scale = float(ref_w.abs().max())
+    close(dW.cpu().double() / scale, ref_w / scale, atol=2e-6, rtol=1e-5, msg='dW')
+    close(db.cpu().double() / scale, ref_b / scale, atol=2e-6, rtol=1e-5, msg='db')
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    K.linear_wgrad(dz.cuda(), x.cuda(), dW2, db2, M, N, rows, ws=ws if n_ws else None)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)          # deterministic
