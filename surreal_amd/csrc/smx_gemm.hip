@@ -179,13 +179,23 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     __shared__ float dbr[8][32];
     __shared__ float sred[16];
 
+    // XCD-aware order: consecutive workgroup ids land on the 8 XCDs round-robin, each with its own
+    // L2.  Give XCD x the x-th contiguous eighth of the tile list (tiles are row-major in M, so
+    // that is a band of A rows and all of B) instead of every 8th tile -- otherwise all eight L2s
+    // pull every operand of the launch across the fabric.
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x, q = total >> 3, r = total & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
     int pi = 0;
 #pragma unroll
     for (int k = 1; k < MAX_PROBS; ++k)
-        if (k < G.n && (int)blockIdx.x >= G.p[k].tile_base) pi = k;
+        if (k < G.n && bid >= G.p[k].tile_base) pi = k;
     const GemmProb& P = G.p[pi];
     if (P.stop && *P.stop) return;
-    int tile = blockIdx.x - P.tile_base;
+    int tile = bid - P.tile_base;
     int sp = 0;
     KRange R;
     R.A = P.A; R.B = P.B; R.a_bytes = P.a_bytes; R.b_bytes = P.b_bytes; R.K = P.K;
