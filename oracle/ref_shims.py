@@ -70,6 +70,25 @@ class BeneDict(dict):
         return {k: (v.to_dict() if isinstance(v, BeneDict) else v)
                 for k, v in self.items()}
 
+    # yaml round trip used by surreal/utils/checkpoint.py:94-96, 255-256
+    @classmethod
+    def load_yaml_file(cls, path):
+        import yaml
+        with open(path) as fp:
+            return cls(yaml.safe_load(fp))
+
+    def dump_yaml_file(self, path):
+        import yaml
+
+        def plain(v):
+            if isinstance(v, dict):
+                return {k: plain(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return [plain(x) for x in v]
+            return v
+        with open(path, 'w') as fp:
+            yaml.safe_dump(plain(self), fp, default_flow_style=False)
+
 
 # --------------------------------------------------------------------------
 # torchx

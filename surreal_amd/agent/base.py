@@ -85,8 +85,24 @@ class Agent(object, metaclass=AutoInitializeMeta):
         self.episodes_since_param_update = 0
         return params
 
+    def attach_parameter_client(self, client):
+        """fetch through the reference's parameter protocol (surreal_amd.distributed.ParameterClient:
+        serialised blobs + content-hash "unchanged" replies) instead of the in-process hand-off"""
+        self._param_client = client
+
     def fetch_parameter(self):
         """agent/base.py:355-363; returns True when new parameters were loaded"""
+        client = getattr(self, '_param_client', None)
+        if client is not None:
+            from surreal_amd.distributed import ModuleDict
+            binary, info = client.fetch_parameter_with_info()
+            if binary is None:
+                return False
+            from surreal_amd.utils import serializer
+            params = self.on_parameter_fetched(serializer.deserialize(binary), info)
+            ModuleDict(self._module_dict).load(params)
+            self._fetched_iteration = info.get('iteration')
+            return True
         if self._published is None:
             return False
         params, info = self._published

@@ -83,10 +83,18 @@ class Learner(metaclass=AutoInitializeMeta):
     def should_publish_parameter(self):
         return self._ps_publish_tracker.track_increment()
 
+    def attach_parameter_publisher(self, publish_fn):
+        """also publish serialised parameter blobs (ModuleDict.dumps + info with the content hash)
+        through ``publish_fn((binary, info))`` -- e.g. ``ParameterServer.set_storage`` or a socket"""
+        from surreal_amd.distributed import ParameterPublisher
+        self._ps_publisher = ParameterPublisher(publish_fn, self.module_dict())
+
     def _publish(self, iteration, message=''):
         info = {'time': time.time(), 'iteration': iteration, 'message': message}
         for fn in self._parameter_listeners:
             fn(self.module_dict(), info)
+        if getattr(self, '_ps_publisher', None) is not None:
+            self._ps_publisher.publish(iteration, message)
 
     def publish_parameter(self, iteration, message=''):
         self._publish(iteration, message)
@@ -161,68 +169,37 @@ class Learner(metaclass=AutoInitializeMeta):
         self.tensorplex.add_scalars(m)
         return m
 
-    # ---- checkpoint (base.py:260-313; utils/checkpoint.py:234-314) ----------------------------
+    # ---- checkpoint (base.py:260-313) in the reference's on-disk format (utils/checkpoint.py) ----
     def _setup_checkpoint(self):
+        from surreal_amd.utils.checkpoint import PeriodicCheckpoint
+        tracked_attrs = self.checkpoint_attributes()
+        assert isinstance(tracked_attrs, (list, tuple)), \
+            'checkpoint_attributes must return a list of string attr names'
         ck = self.session_config.checkpoint.learner
-        self._ckpt_folder = os.path.join(self.session_config.folder, 'checkpoint')
-        self._ckpt_period = ck.periodic
-        self._ckpt_min_interval = ck.min_interval
-        self._ckpt_keep = ck.keep_history
-        self._ckpt_calls = 0
-        self._ckpt_last_time = time.time()
+        self._periodic_checkpoint = PeriodicCheckpoint(
+            os.path.join(self.session_config.folder, 'checkpoint'), name='learner',
+            period=ck.periodic, min_interval=ck.min_interval, tracked_obj=self,
+            tracked_attrs=list(tracked_attrs), keep_history=ck.keep_history, keep_best=ck.keep_best)
 
-    def _checkpoint_payload(self):
-        out = {}
-        for name in self.checkpoint_attributes():
-            obj = getattr(self, name)
-            if hasattr(obj, 'state_dict'):
-                sd = obj.state_dict()
-                obj = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v)
-                       for k, v in sd.items()}
-            out[name] = obj
-        return out
-
-    def save_checkpoint(self, global_steps):
-        os.makedirs(self._ckpt_folder, exist_ok=True)
-        path = os.path.join(self._ckpt_folder, 'learner.%d.ckpt' % global_steps)
-        with open(path, 'wb') as fp:
-            pickle.dump(self._checkpoint_payload(), fp)
-        hist = sorted((f for f in os.listdir(self._ckpt_folder)
-                       if f.startswith('learner.') and f.endswith('.ckpt')),
-                      key=lambda f: int(f.split('.')[1]))
-        for old in hist[:-self._ckpt_keep] if self._ckpt_keep > 0 else []:
-            os.remove(os.path.join(self._ckpt_folder, old))
-        return path
+    def save_checkpoint(self, global_steps, score=None, **info):
+        """unconditional save (the reference only exposes the periodic one)"""
+        from surreal_amd.utils.checkpoint import Checkpoint
+        Checkpoint.save(self._periodic_checkpoint, score=score, global_steps=global_steps, **info)
+        return self._periodic_checkpoint.ckpt_path(global_steps)
 
     def periodic_checkpoint(self, global_steps, score=None, **info):
-        self._ckpt_calls += 1
-        if self._ckpt_calls % self._ckpt_period != 0:
-            return False
-        if time.time() - self._ckpt_last_time < self._ckpt_min_interval:
-            return False
-        self._ckpt_last_time = time.time()
-        self.save_checkpoint(global_steps)
-        return True
+        return self._periodic_checkpoint.save(score=score, global_steps=global_steps,
+                                              reload_metadata=False, **info)
 
-    def restore_checkpoint(self, path=None):
-        folder = self.session_config.checkpoint.restore_folder or self.session_config.folder
-        if os.path.basename(os.path.normpath(folder)) != 'checkpoint':
-            folder = os.path.join(folder, 'checkpoint')
-        if path is None:
-            hist = sorted((f for f in os.listdir(folder) if f.endswith('.ckpt')),
-                          key=lambda f: int(f.split('.')[1]))
-            if not hist:
-                return False
-            path = os.path.join(folder, hist[-1])
-        with open(path, 'rb') as fp:
-            payload = pickle.load(fp)
-        for name, value in payload.items():
-            obj = getattr(self, name, None)
-            if hasattr(obj, 'load_state_dict'):
-                obj.load_state_dict(value)
-            else:
-                setattr(self, name, value)
-        return True
+    def restore_checkpoint(self):
+        SC = self.session_config
+        restore_folder = SC.checkpoint.restore_folder
+        if restore_folder and os.path.basename(os.path.normpath(restore_folder)) != 'checkpoint':
+            restore_folder = os.path.join(restore_folder, 'checkpoint')   # base.py:301-304
+        restored = self._periodic_checkpoint.restore(
+            target=SC.checkpoint.learner.restore_target, mode=SC.checkpoint.learner.mode,
+            reload_metadata=True, check_ckpt_exists=True, restore_folder=restore_folder)
+        return bool(restored)
 
     # ---- main loop (base.py:348-389) -----------------------------------------------------------
     def main(self):
