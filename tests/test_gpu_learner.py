@@ -141,11 +141,12 @@ def test_learns_on_moving_batches_use_staging_graph():
     hyper['n_step'] = case['shape']['N']
     O = ppo_oracle.OraclePPOLearner(params, case['shape']['A'], case['shape']['B'], zstate=zstate, **hyper)
     learner = H.make_learner(case, params, zstate)
-    captures = []
-    orig = torch.cuda.CUDAGraph
+    captures, kept = [], []
     for it in range(4):
         so = O.learn(copy.deepcopy(batch))
-        sl = learner.learn(copy.deepcopy(batch))           # fresh host arrays -> fresh device tensors
+        db = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+        kept.append(db)                                    # keep them alive: every batch at a new address
+        sl = learner.learn(db)
         for k in so:
             if k != '_lr':
                 at, rt = H.tol_for(k, H.ATOL, 2e-5)
