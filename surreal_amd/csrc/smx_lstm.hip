@@ -2,16 +2,16 @@
 // nn.LSTM(in, hidden, 1, batch_first=True) in front of the actor / critic MLPs).
 //
 // Batch rows are independent, time steps are not, so the recurrence is ONE launch: a workgroup
-// owns 16 batch rows and walks the whole sequence with h/c resident on chip.
+// owns a few batch rows and walks the whole sequence with h/c resident on chip.
 //   * the input half of the gates, x . W_ih^T + b_ih, has no time dependence: one GEMM over all
 //     B*T rows (smx_linear_f32) before the recurrent kernel;
-//   * per step the recurrent half h_{t-1} . W_hh^T is a [16 x H] x [H x 4H] product on FP32 MFMA
-//     (16x16x4): h_{t-1} is read from LDS, the W_hh fragments of the wave's column tiles stay in
-//     REGISTERS for the whole sequence (H <= 112; larger H re-reads them from L2 every step);
-//   * the cell update is elementwise on a fixed (row, unit) -> thread map, so c_t lives in
-//     registers; h_t goes back to LDS for the next step.
+//   * per step the recurrent half h_{t-1} . W_hh^T runs on FP32 MFMA with h_{t-1} read from LDS:
+//     H <= 112 (the reference default is 100): 4 rows per workgroup on 4x4x1_16b, the W_hh slice of
+//     every lane in REGISTERS for the whole sequence; larger H: 16 rows on 16x16x4, W_hh fragments
+//     re-read from L2 every step;
+//   * the cell update is elementwise on a fixed (row, unit) -> thread map; h_t goes back to LDS.
 // Backward is the mirror image (t = T-1 .. 0, dh_rec = dgates_t . W_hh on MFMA), followed by the
-// weight-gradient GEMMs over all B*T rows (smx_linear_wgrad_f32).
+// weight-gradient GEMMs over all B*T rows (split-K).
 #include "smx_common.h"
 
 namespace {
@@ -39,8 +39,10 @@ struct FwdArgs {
     int B, T, H;
 };
 
-// KG: 16-wide k groups covering H (H <= 16*KG).  CACHE: W_hh fragments live in registers.
-template <int KG, bool CACHE>
+// ---- 16-row workgroups on 16x16x4 MFMA: the large-H variant (112 < H <= 384).  W_hh does not fit
+// the register file, so its fragments are re-read from L2 every step; the cell state lives in LDS.
+// KG: 16-wide k groups covering H (H <= 16*KG).
+template <int KG>
 __global__ __launch_bounds__(NT) void lstm_fwd_kernel(FwdArgs a) {
     extern __shared__ float smem[];
     if (a.stop && *a.stop) return;
@@ -49,158 +51,67 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(FwdArgs a) {
     const int GS = ((G + 15) & ~15) + 4;       // gate row stride in LDS
     float* hs = smem;
     float* gh = smem + RB * HS;
+    float* cl = gh + RB * GS;                  // [RB][H] cell state
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * RB;
     const int nct = (G + 15) >> 4;             // gate column tiles
-    constexpr int TPW = CACHE ? (4 * KG + NWV - 1) / NWV : 1;   // tiles per wave when cached
-    constexpr int EPT = (KG * 16 * RB + NT - 1) / NT;           // (row, unit) elements per thread
+    const int nkg = (H + 15) >> 4;
 
-    float4 wf[TPW][CACHE ? KG : 1];
-    float bh[TPW];
-    if (CACHE) {
-#pragma unroll
-        for (int s = 0; s < TPW; ++s) {
-            const int col = (wv + NWV * s) * 16 + i;
-            bh[s] = (col < G) ? a.b_hh[col] : 0.f;
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int k = 16 * kg + 4 * kq;
-                wf[s][kg] = (col < G && k < H)
-                                ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + k)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
-
-    // ---- initial state ----------------------------------------------------------------
-    // fixed (row, unit) -> thread map: element e of this thread is idx = tid + e*NT.  Offsets
-    // are 32-bit element indices (the host checks B*T*4H < 2^31).
     for (int idx = tid; idx < RB * HS; idx += NT) hs[idx] = 0.f;
     __syncthreads();
-    float* cl = gh + RB * GS;                  // [RB][H] cell state (uncached variant only)
-    float creg[EPT];
-    unsigned eoff[EPT];                        // (row0+row)*T*H + j ; 0xffffffff = no element
-    int lofs[EPT];                             // row*HS + j
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = tid + e * NT;
+    for (int idx = tid; idx < RB * H; idx += NT) {
         const int row = idx / H, j = idx - row * H;
-        const bool inb = idx < RB * H && row0 + row < a.B;
-        eoff[e] = inb ? (unsigned)(row0 + row) * (unsigned)(T * H) + (unsigned)j : 0xffffffffu;
-        lofs[e] = row * HS + j;
-        const float c_init = (inb && a.c0) ? a.c0[(size_t)(row0 + row) * H + j] : 0.f;
-        if (CACHE) creg[e] = c_init;
-        else if (idx < RB * H) cl[row * H + j] = c_init;
-        if (inb && a.h0) hs[lofs[e]] = a.h0[(size_t)(row0 + row) * H + j];
+        const bool inb = row0 + row < a.B;
+        cl[idx] = (inb && a.c0) ? a.c0[(size_t)(row0 + row) * H + j] : 0.f;
+        if (inb && a.h0) hs[row * HS + j] = a.h0[(size_t)(row0 + row) * H + j];
     }
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        // input half of the gates for this step (issued before the MFMAs, used after them)
-        float gx[CACHE ? EPT : 1][4];
-        if (CACHE) {
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const bool inb = eoff[e] != 0xffffffffu;
-                const unsigned j = eoff[e] % (unsigned)H;          // eoff = (b*T)*H + j
-                const unsigned base = (eoff[e] - j + (unsigned)(t * H)) * 4u + j;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gx[e][q] = inb ? a.gates[base + (unsigned)(q * H)] : 0.f;
-            }
-        }
-
         // ---- recurrent half: gh = h_{t-1} . W_hh^T + b_hh ----------------------------
-        if (CACHE) {
-#pragma unroll
-            for (int s = 0; s < TPW; ++s) {
-                const int ct = wv + NWV * s;
-                if (ct < nct) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kg = 0; kg < KG; ++kg) {
-                        const float4 av =
-                            *reinterpret_cast<const float4*>(&hs[i * HS + 16 * kg + 4 * kq]);
-                        acc = MFMA16(av.x, wf[s][kg].x, acc);
-                        acc = MFMA16(av.y, wf[s][kg].y, acc);
-                        acc = MFMA16(av.z, wf[s][kg].z, acc);
-                        acc = MFMA16(av.w, wf[s][kg].w, acc);
-                    }
-                    const int col = ct * 16 + i;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gh[(4 * kq + r) * GS + col] = acc[r] + bh[s];
-                }
+        for (int ct = wv; ct < nct; ct += NWV) {
+            const int col = ct * 16 + i;
+            const float bias = (col < G) ? a.b_hh[col] : 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kg = 0; kg < nkg; ++kg) {
+                const int k = 16 * kg + 4 * kq;
+                const float4 av = *reinterpret_cast<const float4*>(&hs[i * HS + k]);
+                const float4 wv4 =
+                    (col < G && k < H)
+                        ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + k)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = MFMA16(av.x, wv4.x, acc);
+                acc = MFMA16(av.y, wv4.y, acc);
+                acc = MFMA16(av.z, wv4.z, acc);
+                acc = MFMA16(av.w, wv4.w, acc);
             }
-        } else {
-            const int nkg = (H + 15) >> 4;
-            for (int ct = wv; ct < nct; ct += NWV) {
-                const int col = ct * 16 + i;
-                const float bias = (col < G) ? a.b_hh[col] : 0.f;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int kg = 0; kg < nkg; ++kg) {
-                    const int k = 16 * kg + 4 * kq;
-                    const float4 av = *reinterpret_cast<const float4*>(&hs[i * HS + k]);
-                    const float4 wv4 =
-                        (col < G && k < H)
-                            ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + k)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-                    acc = MFMA16(av.x, wv4.x, acc);
-                    acc = MFMA16(av.y, wv4.y, acc);
-                    acc = MFMA16(av.z, wv4.z, acc);
-                    acc = MFMA16(av.w, wv4.w, acc);
-                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gh[(4 * kq + r) * GS + col] = acc[r] + bias;
-            }
+            for (int r = 0; r < 4; ++r) gh[(4 * kq + r) * GS + col] = acc[r] + bias;
         }
         __syncthreads();
 
         // ---- cell update (aten lstm_cell: gates = igates + hgates; i, f, g, o) ---------
-        if (CACHE) {
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                if (eoff[e] != 0xffffffffu) {
-                    const unsigned j = eoff[e] % (unsigned)H;
-                    const unsigned oh = eoff[e] + (unsigned)(t * H);      // (b*T + t)*H + j
-                    const unsigned og = (oh - j) * 4u + j;                // (b*T + t)*4H + j
-                    const float* g = gh + (lofs[e] / HS) * GS + j;
-                    const float gi = sigm(gx[e][0] + g[0]);
-                    const float gf = sigm(gx[e][1] + g[H]);
-                    const float gg = tanhf(gx[e][2] + g[2 * H]);
-                    const float go = sigm(gx[e][3] + g[3 * H]);
-                    const float c = gf * creg[e] + gi * gg;
-                    const float h = go * tanhf(c);
-                    a.gates[og] = gi; a.gates[og + (unsigned)H] = gf;
-                    a.gates[og + (unsigned)(2 * H)] = gg; a.gates[og + (unsigned)(3 * H)] = go;
-                    a.out[oh] = h;
-                    a.cs[oh] = c;
-                    if (a.hprev) a.hprev[oh] = hs[lofs[e]];
-                    creg[e] = c;
-                    hs[lofs[e]] = h;
-                }
-            }
-        } else {
-            for (int idx = tid; idx < RB * H; idx += NT) {
-                const int row = idx / H, j = idx - row * H;
-                if (row0 + row < a.B) {
-                    const unsigned oh = ((unsigned)(row0 + row) * (unsigned)T + (unsigned)t) * (unsigned)H + j;
-                    const unsigned og = (oh - j) * 4u + j;
-                    const float* g = gh + row * GS + j;
-                    const float gi = sigm(a.gates[og] + g[0]);
-                    const float gf = sigm(a.gates[og + (unsigned)H] + g[H]);
-                    const float gg = tanhf(a.gates[og + (unsigned)(2 * H)] + g[2 * H]);
-                    const float go = sigm(a.gates[og + (unsigned)(3 * H)] + g[3 * H]);
-                    const float c = gf * cl[row * H + j] + gi * gg;
-                    const float h = go * tanhf(c);
-                    a.gates[og] = gi; a.gates[og + (unsigned)H] = gf;
-                    a.gates[og + (unsigned)(2 * H)] = gg; a.gates[og + (unsigned)(3 * H)] = go;
-                    a.out[oh] = h;
-                    a.cs[oh] = c;
-                    if (a.hprev) a.hprev[oh] = hs[row * HS + j];
-                    cl[row * H + j] = c;
-                    hs[row * HS + j] = h;
-                }
+        for (int idx = tid; idx < RB * H; idx += NT) {
+            const int row = idx / H, j = idx - row * H;
+            if (row0 + row < a.B) {
+                const unsigned oh = ((unsigned)(row0 + row) * (unsigned)T + (unsigned)t) * (unsigned)H + j;
+                const unsigned og = (oh - j) * 4u + j;
+                const float* g = gh + row * GS + j;
+                const float gi = sigm(a.gates[og] + g[0]);
+                const float gf = sigm(a.gates[og + (unsigned)H] + g[H]);
+                const float gg = tanhf(a.gates[og + (unsigned)(2 * H)] + g[2 * H]);
+                const float go = sigm(a.gates[og + (unsigned)(3 * H)] + g[3 * H]);
+                const float c = gf * cl[idx] + gi * gg;
+                const float h = go * tanhf(c);
+                a.gates[og] = gi; a.gates[og + (unsigned)H] = gf;
+                a.gates[og + (unsigned)(2 * H)] = gg; a.gates[og + (unsigned)(3 * H)] = go;
+                a.out[oh] = h;
+                a.cs[oh] = c;
+                if (a.hprev) a.hprev[oh] = hs[row * HS + j];
+                cl[idx] = c;
+                hs[row * HS + j] = h;
             }
         }
         __syncthreads();
@@ -210,7 +121,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(FwdArgs a) {
         const int row = idx / H, j = idx - row * H;
         if (row0 + row < a.B) {
             if (a.hN) a.hN[(size_t)(row0 + row) * H + j] = hs[row * HS + j];
-            if (a.cN) a.cN[(size_t)(row0 + row) * H + j] = a.cs[((size_t)(row0 + row) * T + (T - 1)) * H + j];
+            if (a.cN) a.cN[(size_t)(row0 + row) * H + j] = cl[idx];
         }
     }
 }
@@ -226,152 +137,73 @@ struct BwdArgs {
     int B, T, H;
 };
 
-// KGB: 16-wide k groups covering 4H.  One output tile (16 hidden units) per wave: H <= 128.
-template <int KG, bool CACHE>
+template <int KG>
 __global__ __launch_bounds__(NT) void lstm_bwd_kernel(BwdArgs a) {
     extern __shared__ float smem[];
     if (a.stop && *a.stop) return;
     const int H = a.H, G = 4 * H, T = a.T;
     constexpr int HS = KG * 16 + 4;
-    constexpr int KGB = 4 * KG;
-    // cached: the unrolled k loop runs over all KGB groups, so the row is padded (zeros) to match
-    const int GS = CACHE ? KGB * 16 + 4 : ((G + 15) & ~15) + 4;
+    const int GS = ((G + 15) & ~15) + 4;
     float* dhr = smem;                 // [RB][HS]  recurrent dh
     float* dg = smem + RB * HS;        // [RB][GS]  dgates of the current step
+    float* dcl = dg + RB * GS;         // [RB][H]   dc carried to step t-1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * RB;
     const int nht = (H + 15) >> 4;     // hidden-unit tiles
-    constexpr int EPT = (KG * 16 * RB + NT - 1) / NT;
+    const int nkg = (G + 15) >> 4;
 
-    // B operand of dh_rec = dgates . W_hh :  B[k][n] = W_hh[k][n]
-    float4 wf[CACHE ? KGB : 1];
-    if (CACHE && wv < nht) {
-        const int n = wv * 16 + i;
-#pragma unroll
-        for (int kg = 0; kg < KGB; ++kg) {
-            const int k = 16 * kg + 4 * kq;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < H && k < G) {   // G % 4 == 0: the four k are in range together
-                w.x = a.W_hh[(size_t)(k + 0) * H + n];
-                w.y = a.W_hh[(size_t)(k + 1) * H + n];
-                w.z = a.W_hh[(size_t)(k + 2) * H + n];
-                w.w = a.W_hh[(size_t)(k + 3) * H + n];
-            }
-            wf[kg] = w;
-        }
-    }
-
-    float* dcl = dg + RB * GS;         // [RB][H] dc carried to step t-1 (uncached variant only)
-    for (int idx = tid; idx < RB * (HS + GS) + (CACHE ? 0 : RB * H); idx += NT) smem[idx] = 0.f;
-    float dcreg[EPT];
-    unsigned eoff[EPT];                // (row0+row)*T*H + j ; 0xffffffff = no element
-    int lofs[EPT];                     // row*HS + j
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = tid + e * NT;
-        const int row = idx / H, j = idx - row * H;
-        const bool inb = idx < RB * H && row0 + row < a.B;
-        eoff[e] = inb ? (unsigned)(row0 + row) * (unsigned)(T * H) + (unsigned)j : 0xffffffffu;
-        lofs[e] = row * HS + j;
-        dcreg[e] = 0.f;
-    }
+    for (int idx = tid; idx < RB * (HS + GS + H); idx += NT) smem[idx] = 0.f;
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
-        if (CACHE) {
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                if (eoff[e] != 0xffffffffu) {
-                    const unsigned j = eoff[e] % (unsigned)H;
-                    const unsigned oh = eoff[e] + (unsigned)(t * H);
-                    const unsigned og = (oh - j) * 4u + j;
-                    const float gi = a.gates[og], gf = a.gates[og + (unsigned)H];
-                    const float gg = a.gates[og + (unsigned)(2 * H)], go = a.gates[og + (unsigned)(3 * H)];
-                    const float c = a.cs[oh];
-                    const float cp = (t > 0) ? a.cs[oh - (unsigned)H]
-                                             : (a.c0 ? a.c0[(eoff[e] - j) / (unsigned)T + j] : 0.f);
-                    const float dh = a.dout[oh] + dhr[lofs[e]];
-                    const float tc = tanhf(c);
-                    const float dc = dcreg[e] + (dh * go) * (1.f - tc * tc);
-                    const float dgi = (dc * gg) * (gi * (1.f - gi));
-                    const float dgf = (dc * cp) * (gf * (1.f - gf));
-                    const float dgg = (dc * gi) * (1.f - gg * gg);
-                    const float dgo = (dh * tc) * (go * (1.f - go));
-                    dcreg[e] = dc * gf;
-                    a.dgates[og] = dgi; a.dgates[og + (unsigned)H] = dgf;
-                    a.dgates[og + (unsigned)(2 * H)] = dgg; a.dgates[og + (unsigned)(3 * H)] = dgo;
-                    float* gl = dg + (lofs[e] / HS) * GS + j;
-                    gl[0] = dgi; gl[H] = dgf; gl[2 * H] = dgg; gl[3 * H] = dgo;
-                }
-            }
-        } else {
-            for (int idx = tid; idx < RB * H; idx += NT) {
-                const int row = idx / H, j = idx - row * H;
-                if (row0 + row < a.B) {
-                    const unsigned oh = ((unsigned)(row0 + row) * (unsigned)T + (unsigned)t) * (unsigned)H + j;
-                    const unsigned og = (oh - j) * 4u + j;
-                    const float gi = a.gates[og], gf = a.gates[og + (unsigned)H];
-                    const float gg = a.gates[og + (unsigned)(2 * H)], go = a.gates[og + (unsigned)(3 * H)];
-                    const float c = a.cs[oh];
-                    const float cp = (t > 0) ? a.cs[oh - (unsigned)H]
-                                             : (a.c0 ? a.c0[(size_t)(row0 + row) * H + j] : 0.f);
-                    const float dh = a.dout[oh] + dhr[row * HS + j];
-                    const float tc = tanhf(c);
-                    const float dc = dcl[row * H + j] + (dh * go) * (1.f - tc * tc);
-                    const float dgi = (dc * gg) * (gi * (1.f - gi));
-                    const float dgf = (dc * cp) * (gf * (1.f - gf));
-                    const float dgg = (dc * gi) * (1.f - gg * gg);
-                    const float dgo = (dh * tc) * (go * (1.f - go));
-                    dcl[row * H + j] = dc * gf;
-                    a.dgates[og] = dgi; a.dgates[og + (unsigned)H] = dgf;
-                    a.dgates[og + (unsigned)(2 * H)] = dgg; a.dgates[og + (unsigned)(3 * H)] = dgo;
-                    float* gl = dg + row * GS + j;
-                    gl[0] = dgi; gl[H] = dgf; gl[2 * H] = dgg; gl[3 * H] = dgo;
-                }
+        for (int idx = tid; idx < RB * H; idx += NT) {
+            const int row = idx / H, j = idx - row * H;
+            if (row0 + row < a.B) {
+                const unsigned oh = ((unsigned)(row0 + row) * (unsigned)T + (unsigned)t) * (unsigned)H + j;
+                const unsigned og = (oh - j) * 4u + j;
+                const float gi = a.gates[og], gf = a.gates[og + (unsigned)H];
+                const float gg = a.gates[og + (unsigned)(2 * H)], go = a.gates[og + (unsigned)(3 * H)];
+                const float c = a.cs[oh];
+                const float cp = (t > 0) ? a.cs[oh - (unsigned)H]
+                                         : (a.c0 ? a.c0[(size_t)(row0 + row) * H + j] : 0.f);
+                const float dh = a.dout[oh] + dhr[row * HS + j];
+                const float tc = tanhf(c);
+                const float dc = dcl[idx] + (dh * go) * (1.f - tc * tc);
+                const float dgi = (dc * gg) * (gi * (1.f - gi));
+                const float dgf = (dc * cp) * (gf * (1.f - gf));
+                const float dgg = (dc * gi) * (1.f - gg * gg);
+                const float dgo = (dh * tc) * (go * (1.f - go));
+                dcl[idx] = dc * gf;
+                a.dgates[og] = dgi; a.dgates[og + (unsigned)H] = dgf;
+                a.dgates[og + (unsigned)(2 * H)] = dgg; a.dgates[og + (unsigned)(3 * H)] = dgo;
+                float* gl = dg + row * GS + j;
+                gl[0] = dgi; gl[H] = dgf; gl[2 * H] = dgg; gl[3 * H] = dgo;
             }
         }
         __syncthreads();
         if (t > 0) {   // dh_rec feeds step t-1 only
-            if (CACHE) {
-                if (wv < nht) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kg = 0; kg < KGB; ++kg) {
-                        const float4 av =
-                            *reinterpret_cast<const float4*>(&dg[i * GS + 16 * kg + 4 * kq]);
-                        acc = MFMA16(av.x, wf[kg].x, acc);
-                        acc = MFMA16(av.y, wf[kg].y, acc);
-                        acc = MFMA16(av.z, wf[kg].z, acc);
-                        acc = MFMA16(av.w, wf[kg].w, acc);
+            for (int ht = wv; ht < nht; ht += NWV) {
+                const int n = ht * 16 + i;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int kg = 0; kg < nkg; ++kg) {
+                    const int k = 16 * kg + 4 * kq;
+                    const float4 av = *reinterpret_cast<const float4*>(&dg[i * GS + k]);
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < H && k < G) {   // G % 4 == 0: the four k are in range together
+                        w.x = a.W_hh[(size_t)(k + 0) * H + n];
+                        w.y = a.W_hh[(size_t)(k + 1) * H + n];
+                        w.z = a.W_hh[(size_t)(k + 2) * H + n];
+                        w.w = a.W_hh[(size_t)(k + 3) * H + n];
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dhr[(4 * kq + r) * HS + wv * 16 + i] = acc[r];
+                    acc = MFMA16(av.x, w.x, acc);
+                    acc = MFMA16(av.y, w.y, acc);
+                    acc = MFMA16(av.z, w.z, acc);
+                    acc = MFMA16(av.w, w.w, acc);
                 }
-            } else {
-                const int nkg = (G + 15) >> 4;
-                for (int ht = wv; ht < nht; ht += NWV) {
-                    const int n = ht * 16 + i;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    for (int kg = 0; kg < nkg; ++kg) {
-                        const int k = 16 * kg + 4 * kq;
-                        const float4 av = *reinterpret_cast<const float4*>(&dg[i * GS + k]);
-                        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (n < H && k < G) {
-                            w.x = a.W_hh[(size_t)(k + 0) * H + n];
-                            w.y = a.W_hh[(size_t)(k + 1) * H + n];
-                            w.z = a.W_hh[(size_t)(k + 2) * H + n];
-                            w.w = a.W_hh[(size_t)(k + 3) * H + n];
-                        }
-                        acc = MFMA16(av.x, w.x, acc);
-                        acc = MFMA16(av.y, w.y, acc);
-                        acc = MFMA16(av.z, w.z, acc);
-                        acc = MFMA16(av.w, w.w, acc);
-                    }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dhr[(4 * kq + r) * HS + n] = acc[r];
-                }
+                for (int r = 0; r < 4; ++r) dhr[(4 * kq + r) * HS + n] = acc[r];
             }
         }
         __syncthreads();
@@ -560,17 +392,11 @@ constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
 inline size_t lds4_fwd(int kq) { return (size_t)RB4 * ((kq * 4 + 4) + (NWV * 64 + 4)) * sizeof(float); }
 inline size_t lds4_bwd(int kq) { return (size_t)(RB4 * (16 * kq + 4) + 4 * RB4 * (128 + 4)) * sizeof(float); }
 
-constexpr int KG_CACHED = 7;     // H <= 112: W_hh fragments in registers
-constexpr int KG_MAX = 24;       // H <= 384: fragments re-read from L2 every step (LDS-bound)
+constexpr int KG_MAX = 24;       // 16-row kernels: H <= 384 (LDS-bound)
 
-// uncached variants also keep the [RB][H] cell state (dc) in LDS
-inline size_t lds_bytes(int kg, int H, bool cached) {
+inline size_t lds_bytes(int kg, int H) {
     const int HS = kg * 16 + 4, GS = ((4 * H + 15) & ~15) + 4;
-    return (size_t)RB * (HS + GS + (cached ? 0 : H)) * sizeof(float);
-}
-
-inline size_t lds_bytes_bwd_cached(int kg) {
-    return (size_t)RB * ((kg * 16 + 4) + (4 * kg * 16 + 4)) * sizeof(float);
+    return (size_t)RB * (HS + GS + H) * sizeof(float);
 }
 
 }  // namespace
@@ -599,20 +425,17 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     } else if (H <= 4 * KQ4) {
         hipLaunchKernelGGL((lstm_fwd4_kernel<KQ4>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_fwd(KQ4), smx_s(stream), a);
-    } else if (H <= 16 * KG_CACHED) {
-        hipLaunchKernelGGL((lstm_fwd_kernel<KG_CACHED, true>), dim3(blocks), dim3(NT),
-                           lds_bytes(KG_CACHED, H, true), smx_s(stream), a);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&lstm_fwd_kernel<KG_MAX, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(KG_MAX, 16 * KG_MAX, false));
+                reinterpret_cast<const void*>(&lstm_fwd_kernel<KG_MAX>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(KG_MAX, 16 * KG_MAX));
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((lstm_fwd_kernel<KG_MAX, false>), dim3(blocks), dim3(NT),
-                           lds_bytes(KG_MAX, H, false), smx_s(stream), a);
+        hipLaunchKernelGGL((lstm_fwd_kernel<KG_MAX>), dim3(blocks), dim3(NT),
+                           lds_bytes(KG_MAX, H), smx_s(stream), a);
     }
     SMX_LAUNCH_CHECK();
     return SMX_OK;
@@ -638,20 +461,17 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     } else if (H <= 4 * KQ4) {
         hipLaunchKernelGGL((lstm_bwd4_kernel<KQ4>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_bwd(KQ4), smx_s(stream), a);
-    } else if (H <= 16 * KG_CACHED) {
-        hipLaunchKernelGGL((lstm_bwd_kernel<KG_CACHED, true>), dim3(blocks), dim3(NT),
-                           lds_bytes_bwd_cached(KG_CACHED), smx_s(stream), a);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&lstm_bwd_kernel<KG_MAX, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(KG_MAX, 16 * KG_MAX, false));
+                reinterpret_cast<const void*>(&lstm_bwd_kernel<KG_MAX>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(KG_MAX, 16 * KG_MAX));
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((lstm_bwd_kernel<KG_MAX, false>), dim3(blocks), dim3(NT),
-                           lds_bytes(KG_MAX, H, false), smx_s(stream), a);
+        hipLaunchKernelGGL((lstm_bwd_kernel<KG_MAX>), dim3(blocks), dim3(NT),
+                           lds_bytes(KG_MAX, H), smx_s(stream), a);
     }
     SMX_LAUNCH_CHECK();
     // grads = [dW_ih (4H x D) | dW_hh (4H x H) | db_ih (4H) | db_hh (4H)]  (nn.LSTM parameter order)
