@@ -304,6 +304,13 @@ typedef struct smx_ppo_losses {
 } smx_ppo_losses_t;
 int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ctrl_t* ctrl,
                              smx_stream_t stream);
+/* The means PPOLearner._optimize reports once per learn, formed on the device so that the whole
+ * statistics block needs one read-back: out4 = {mean(log_var) (ppo.py:572), mean_d(running_sum/
+ * count), mean_d(running_sumsq/count), mean_d(sqrt(running_sumsq/count - (running_sum/count)^2))}
+ * (ppo.py:580-583, z_filter.py:81-107; running_sum == NULL: only out4[0]). */
+int smx_ppo_final_stats_f32(const float* log_var, int32_t A, const float* running_sum,
+                            const float* running_sumsq, const float* count, int32_t D, float* out4,
+                            smx_stream_t stream);
 /* stats[e, SMX_VS_*] for e < count from partials [count, nblk, 8] (one launch per learn) */
 int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,
                                 float* stats, int32_t stats_stride, smx_stream_t stream);

@@ -102,6 +102,7 @@ _SIGS = {
                                             c_int32, _P, c_int32, c_int32, _P, _P, c_int64, _P, _P,
                                             _P, _P]),
     'smx_ppo_epoch_losses_f32': (c_int32, [POINTER(PpoLosses), _P, _P]),
+    'smx_ppo_final_stats_f32': (c_int32, [_P, c_int32, _P, _P, _P, c_int32, _P, _P]),
     'smx_value_loss_blocks': (c_int32, [c_int64]),
     'smx_value_loss_f32': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P]),
     'smx_value_loss_finalize_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P]),

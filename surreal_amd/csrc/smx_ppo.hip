@@ -420,7 +420,47 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// out[0] = mean(log_var); out[1..3] = mean over the D features of running_sum/count,
+// running_sumsq/count and sqrt(running_sumsq/count - (running_sum/count)^2)  (no clamp: z_filter.py:90-98)
+__global__ __launch_bounds__(256) void final_stats_kernel(const float* __restrict__ log_var, int A,
+                                                          const float* __restrict__ rsum,
+                                                          const float* __restrict__ rsumsq,
+                                                          const float* __restrict__ count, int D,
+                                                          float* __restrict__ out) {
+    __shared__ double red[4][4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int a = threadIdx.x; a < A; a += 256) s0 += (double)log_var[a];
+    if (rsum) {
+        const float cnt = count[0];
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float m = rsum[d] / cnt, q = rsumsq[d] / cnt;
+            s1 += (double)m;
+            s2 += (double)q;
+            s3 += (double)sqrtf(q - m * m);
+        }
+    }
+    s0 = smx_wave_sum_d(s0); s1 = smx_wave_sum_d(s1); s2 = smx_wave_sum_d(s2); s3 = smx_wave_sum_d(s3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        out[threadIdx.x] = (float)(t / (double)(threadIdx.x == 0 ? A : (D > 0 ? D : 1)));
+    }
+}
+
 }  // namespace
+
+extern "C" int smx_ppo_final_stats_f32(const float* log_var, int32_t A, const float* running_sum,
+                                       const float* running_sumsq, const float* count, int32_t D,
+                                       float* out4, smx_stream_t stream) {
+    SMX_REQUIRE(log_var && out4, SMX_E_NULL);
+    SMX_REQUIRE(A > 0 && (running_sum == nullptr || (running_sumsq && count && D > 0)), SMX_E_SHAPE);
+    hipLaunchKernelGGL(final_stats_kernel, dim3(1), dim3(256), 0, smx_s(stream), log_var, A,
+                       running_sum, running_sumsq, count, D, out4);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
 
 extern "C" int32_t smx_ppo_loss_blocks(int64_t rows) {
     return (int32_t)((rows + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK);

@@ -165,6 +165,16 @@ class HipKernels(object):
         a.v_dz3, a.v_partials, a.v_will_update = L.ptr(v_dz3), L.ptr(v_partials), int(v_will_update)
         L.call('smx_ppo_epoch_losses_f32', ctypes.byref(a), L.ptr(ctrl), self._st())
 
+    def final_stats(self, log_var, zfilter, out4):
+        """means the learner reports once per learn (ppo.py:572, 580-583), formed on the device so
+        that the statistics need ONE read-back"""
+        zf = zfilter
+        L.call('smx_ppo_final_stats_f32', L.ptr(log_var), log_var.numel(),
+               L.ptr(zf.running_sum) if zf is not None else None,
+               L.ptr(zf.running_sumsq) if zf is not None else None,
+               L.ptr(zf.count) if zf is not None else None,
+               zf.running_sum.numel() if zf is not None else 0, L.ptr(out4), self._st())
+
     def value_loss_blocks(self, rows):
         return self.lib.smx_value_loss_blocks(rows)
 

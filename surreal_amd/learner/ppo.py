@@ -222,7 +222,7 @@ class PPOLearner(Learner):
         ws.E = E
         Ep, Ev = self.epoch_policy, self.epoch_baseline
         # scalars block: ctrl | policy stats | value stats | moments
-        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + Ev * L.VS_STRIDE + 8
+        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + Ev * L.VS_STRIDE + 12
         ws.scal = torch.zeros(n_scal, device=dev, dtype=torch.float32)
         o = 0
         ws.ctrl_f = ws.scal[o:o + L.CTRL_WORDS]; o += L.CTRL_WORDS
@@ -231,6 +231,7 @@ class PPOLearner(Learner):
         ws.vstats = ws.scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE); o += Ev * L.VS_STRIDE
         ws.adv_mom = ws.scal[o:o + 3]; o += 3
         ws.ret_mom = ws.scal[o:o + 3]; o += 3
+        ws.fin = ws.scal[o + 2:o + 6]          # mean log_var, z-filter means (final_stats)
         ws.stop = ws.ctrl_i[L.C_STOP:L.C_STOP + 1]
         # keep the optimiser step counters of a previous workspace
         if self._ws is not None:
@@ -629,6 +630,7 @@ class PPOLearner(Learner):
             else:
                 K.zfilter_update(obs0, m.z_filter.running_sum, m.z_filter.running_sumsq,
                                  m.z_filter.count, B)
+        self._enqueue_final_stats(ws)
 
     # ======================================================================================
     # Policies with a shared stem: the LSTM stem (algo.rnn.if_rnn_policy, the reference
@@ -819,6 +821,11 @@ class PPOLearner(Learner):
             else:
                 K.zfilter_update(ws.low_it, m.z_filter.running_sum, m.z_filter.running_sumsq,
                                  m.z_filter.count, B * E)
+        self._enqueue_final_stats(ws)
+
+    def _enqueue_final_stats(self, ws):
+        self.K.final_stats(self.model.log_var.view(-1),
+                           self.model.z_filter if self.use_z_filter else None, ws.fin)
 
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
@@ -909,6 +916,7 @@ class PPOLearner(Learner):
         ps = scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE).numpy(); o += (Ep + 1) * L.PS_STRIDE
         vs = scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE).numpy(); o += Ev * L.VS_STRIDE
         ret_mom = scal[o + 3:o + 6].numpy()
+        fin = scal[o + 8:o + 12].numpy()
         done = int(ctrl_i[L.C_EPOCHS_DONE])      # policy updates applied
         # the reference breaks after the update whose KL is too large: `done` updates ran,
         # slot `done` holds the forward pass after the last one
@@ -937,16 +945,15 @@ class PPOLearner(Learner):
         self.kl_record.append(stats['_pol_kl'])                          # ppo.py:559
         stats.update(trace['value'][-1])                                 # ppo.py:565-566
         stats['_avg_return_targ'] = float(ret_mom[1])
-        stats['_avg_log_sig'] = float(self.model.log_var.mean().item())
+        stats['_avg_log_sig'] = float(fin[0])
         stats['_avg_behave_likelihood'] = float(ps[done, L.PS_LB])
         stats['_avg_is_weight'] = float(ps[done, L.PS_ISW])
         stats['_ref_behave_diff'] = float(ps[done, L.PS_REFBEH])
         stats['_lr'] = self.actor_lr_scheduler.get_lr()[0]
-        if self.use_z_filter:
-            zf = self.model.z_filter
-            stats['obs_running_mean'] = float(np.mean(zf.running_mean()))
-            stats['obs_running_square'] = float(np.mean(zf.running_square()))
-            stats['obs_running_std'] = float(np.mean(zf.running_std()))
+        if self.use_z_filter:           # ppo.py:580-583, means formed on the device (final_stats)
+            stats['obs_running_mean'] = float(fin[1])
+            stats['obs_running_square'] = float(fin[2])
+            stats['obs_running_std'] = float(fin[3])
         if self.use_r_filter:
             stats['reward_mean'] = float((self._rf_sum / self._rf_count).item())
         return stats

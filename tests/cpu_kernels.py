@@ -273,6 +273,15 @@ class TorchCpuKernels(object):
         self.policy_finalize(mode, partials, self.loss_blocks(rows), g_surr, g_kl, log_var, rows, ctrl,
                              check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=dz3_t)
 
+    def final_stats(self, log_var, zfilter, out4):
+        out4.zero_()
+        out4[0] = log_var.double().mean()
+        if zfilter is not None:
+            m = zfilter.running_sum / zfilter.count
+            q = zfilter.running_sumsq / zfilter.count
+            out4[1], out4[2] = m.double().mean(), q.double().mean()
+            out4[3] = (q - m * m).pow(0.5).double().mean()
+
     def value_loss_blocks(self, rows):
         return (rows + 255) // 256
 
