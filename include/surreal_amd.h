@@ -139,7 +139,7 @@ typedef struct {
     float* h2;
     float* out;
     int32_t out_act;
-    int32_t reserved;
+    int32_t out_ld;      /* row stride of `out` in floats; 0 = OUT (dense) */
     const float* dz3;
     float* dz2;
     float* dz1;
@@ -159,6 +159,9 @@ typedef struct {
     float* dz1T;
     int64_t ldT;
 } smx_mlp3_job_t;
+/* forward: 1 <= njobs <= 4 (one launch per layer for all jobs; jobs may differ in rows and
+ * shapes -- e.g. actor, critic, reference actor and the critic over the obs_next rows at the
+ * start of a learn); backward: 1 <= njobs <= 2 (three launches: dz2, dz1, all weight gradients) */
 int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
 int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
 

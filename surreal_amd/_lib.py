@@ -30,7 +30,7 @@ class Mlp3(Structure):
 class Mlp3Job(Structure):
     """smx_mlp3_job_t"""
     _fields_ = [('net', POINTER(Mlp3)), ('x', c_void_p), ('rows', c_int64), ('h1', c_void_p),
-                ('h2', c_void_p), ('out', c_void_p), ('out_act', c_int32), ('reserved', c_int32),
+                ('h2', c_void_p), ('out', c_void_p), ('out_act', c_int32), ('out_ld', c_int32),
                 ('dz3', c_void_p), ('dz2', c_void_p), ('dz1', c_void_p), ('grads', c_void_p),
                 ('sumsq_partials', c_void_p), ('stop_flag', c_void_p),
                 ('h1T', c_void_p), ('h2T', c_void_p), ('xT', c_void_p), ('dz3T', c_void_p),

@@ -427,15 +427,18 @@ extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const f
 // (PPO: actor + critic, which the reference updates in two separate loops, ppo.py:541-562)
 // share ONE launch per layer -- half the launches, twice the workgroups per launch.
 // ---------------------------------------------------------------------------
-constexpr int MAX_JOBS = 2;
+constexpr int MAX_JOBS = 2;       // backward: 3 GEMM problems per job in one launch
+constexpr int MAX_FWD_JOBS = 4;   // forward: 1 problem per job and layer (e.g. actor, critic,
+                                  // reference actor and the critic's obs_next rows of a learn)
 
 extern "C" int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs,
                                           smx_stream_t stream) {
     SMX_REQUIRE(jobs, SMX_E_NULL);
-    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_JOBS, SMX_E_SHAPE);
+    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_FWD_JOBS, SMX_E_SHAPE);
     for (int j = 0; j < njobs; ++j) {
         const smx_mlp3_job_t& J = jobs[j];
         SMX_REQUIRE(J.net && J.x && J.h1 && J.h2 && J.out, SMX_E_NULL);
+        SMX_REQUIRE(J.out_ld == 0 || J.out_ld >= J.net->OUT, SMX_E_SHAPE);
         SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
     }
     for (int layer = 0; layer < 3; ++layer) {
@@ -453,8 +456,9 @@ extern "C" int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t nj
                 fill_prob(G.p[j], J.h1, n->H1, 1, n->W2, n->H1, 1, n->b2, nullptr, J.h2, n->H2, R,
                           n->H2, n->H1, SMX_ACT_RELU, nullptr, nullptr, base, J.stop_flag, J.h2T, (int)(J.ldT ? J.ldT : R));
             else
-                fill_prob(G.p[j], J.h2, n->H2, 1, n->W3, n->H2, 1, n->b3, nullptr, J.out, n->OUT, R,
-                          n->OUT, n->H2, J.out_act, nullptr, nullptr, base, J.stop_flag);
+                fill_prob(G.p[j], J.h2, n->H2, 1, n->W3, n->H2, 1, n->b3, nullptr, J.out,
+                          J.out_ld ? J.out_ld : n->OUT, R, n->OUT, n->H2, J.out_act, nullptr, nullptr,
+                          base, J.stop_flag);
             base += G.p[j].tiles_m * G.p[j].tiles_n;
         }
         const int rc = launch_batch(G, smx_s(stream));

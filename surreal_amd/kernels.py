@@ -82,6 +82,9 @@ class HipKernels(object):
             arr[k].rows = j['x'].shape[0]
             arr[k].h1, arr[k].h2, arr[k].out = g('h1'), g('h2'), g('out')
             arr[k].out_act = int(j.get('act', 0))
+            out = j.get('out')
+            arr[k].out_ld = 0 if out is None or out.dim() < 2 or out.stride(0) == out.shape[1] \
+                else out.stride(0)
             arr[k].dz3, arr[k].dz2, arr[k].dz1 = g('dz3'), g('dz2'), g('dz1')
             arr[k].grads, arr[k].sumsq_partials = g('grads'), g('sumsq')
             arr[k].stop_flag = g('stop')

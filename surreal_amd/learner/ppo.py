@@ -28,6 +28,7 @@ What is different is how one ``learn()`` runs (SURVEY.md section 3.1 lists the r
 Scope: MLP policy, LSTM-stem policy (``rnn.if_rnn_policy``, the reference default) and / or CNN
 stem over camera frames (``pixel_input``), one camera.
 """
+import gc
 import types
 
 import numpy as np
@@ -233,6 +234,8 @@ class PPOLearner(Learner):
         ws.ret_mom = ws.scal[o:o + 3]; o += 3
         ws.fin = ws.scal[o + 2:o + 6]          # mean log_var, z-filter means (final_stats)
         ws.stop = ws.ctrl_i[L.C_STOP:L.C_STOP + 1]
+        # stop flag + epochs_done + reserved words + the policy statistics rows: one contiguous run
+        ws.zero_block = ws.scal[L.C_STOP:L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE]
         # keep the optimiser step counters of a previous workspace
         if self._ws is not None:
             ws.ctrl_i[L.C_STEP_ACTOR:L.C_STEP_CRITIC + 1].copy_(
@@ -249,6 +252,7 @@ class PPOLearner(Learner):
         ws.split_tail = bool(self.session_config.learner.get('split_critic_tail', True)) and \
             rounds(B * (N + 1)) > rounds(B * N) and not stem
         ws.xnext = f(B, D)
+        ws.h1t, ws.h2t = f(B, cri.H1), f(B, cri.H2)      # critic over the obs_next rows
         ws.adv = f(B * E)
         ws.ret = f(B * E)
         idx = torch.tensor(range(N), dtype=torch.float32)
@@ -388,28 +392,41 @@ class PPOLearner(Learner):
     # ======================================================================================
     def _enqueue_gae(self, ws, obs, obs_next, rewards, dones):
         """critic over all steps + windowed GAE + normalisation (ppo.py:355-418)"""
+        tail = self._enqueue_critic_pass(ws, obs, obs_next)
+        if tail is not None:
+            self.K.mlp3_forward_multi([tail])
+        self._enqueue_gae_from_values(ws, obs, rewards, dones)
+
+    def _enqueue_critic_pass(self, ws, obs, obs_next):
+        """the critic over all steps.  Returns the forward job of the obs_next rows when they are
+        left to the layered kernels (the caller launches it, alone or together with other jobs)."""
         K, m = self.K, self.model
         B, N, D = obs.shape
         zm = zs = None
         if self.use_z_filter:
             zm, zs = m.z_filter.refresh_stats()
         K.mlp3_pack(m.critic, ws.packed)
+        if not ws.split_tail:
+            K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.vals, L.SMX_ACT_NONE)
+            return None
+        # B*(N+1) rows would need one more (nearly empty) round of workgroups over the chip
+        # than B*N: the fused kernel takes the B*N step rows, the B obs_next rows go through
+        # the layered small-batch kernels (same arithmetic, tests check both against the oracle)
+        K.mlp3_forward_fused(ws.packed, m.critic, obs, None, zm, zs, ws.vals[:B * N], L.SMX_ACT_NONE)
+        if self.use_z_filter:
+            K.zfilter_forward(obs_next[:, 0, :], zm, zs, ws.xnext)
+        else:
+            ws.xnext.copy_(obs_next[:, 0, :])
+        return dict(net=m.critic, x=ws.xnext, h1=ws.h1t, h2=ws.h2t, out=ws.vals[B * N:].view(B, 1),
+                    act=L.SMX_ACT_NONE)
+
+    def _enqueue_gae_from_values(self, ws, obs, rewards, dones):
+        K = self.K
+        B, N, D = obs.shape
         if ws.split_tail:
-            # B*(N+1) rows would need one more (nearly empty) round of workgroups over the chip
-            # than B*N: the fused kernel takes the B*N step rows, the B obs_next rows go through
-            # the layered small-batch kernels (same arithmetic, tests check both against the oracle)
-            K.mlp3_forward_fused(ws.packed, m.critic, obs, None, zm, zs, ws.vals[:B * N],
-                                 L.SMX_ACT_NONE)
-            if self.use_z_filter:
-                K.zfilter_forward(obs_next[:, 0, :], zm, zs, ws.xnext)
-            else:
-                ws.xnext.copy_(obs_next[:, 0, :])
-            K.mlp3_forward(m.critic, ws.xnext, ws.h1c, ws.h2c, ws.vals[B * N:].view(B, 1),
-                           L.SMX_ACT_NONE)
             K.gae(ws.vals[:B * N], rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N,
                   B, N, N, ws.adv, ws.ret, values_tail=ws.vals[B * N:])
         else:
-            K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.vals, L.SMX_ACT_NONE)
             K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N, B, N, N,
                   ws.adv, ws.ret)
         if self.norm_adv:
@@ -472,7 +489,7 @@ class PPOLearner(Learner):
         K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                     ws.sumsq_c, npart, ws.ctrl_f, 1, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
 
-    def _enqueue_lockstep_epochs(self, ws, actions0, behave0):
+    def _enqueue_lockstep_epochs(self, ws, actions0, behave0, first_extra=(), after_first=None):
         """Policy epoch e and value epoch e advance together: the reference runs the two loops
         one after the other (ppo.py:541-562) but they touch disjoint parameters, so the layer-l
         GEMMs of the actor and of the critic share one launch (smx_mlp3_*_multi_f32).  The KL
@@ -493,7 +510,10 @@ class PPOLearner(Learner):
                   dz3T=ws.dz3c, dz2T=ws.dz2cT, dz1T=ws.dz1cT)     # OUT = 1: dz3^T is dz3 itself
         for e in range(max(Ep + 1, Ev)):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
-            K.mlp3_forward_multi(([aj] if pol_f else []) + ([cj] if val else []))
+            K.mlp3_forward_multi(([aj] if pol_f else []) + ([cj] if val else []) +
+                                 (list(first_extra) if e == 0 else []))
+            if e == 0 and after_first is not None:
+                after_first()
             if pol_f and W == 1:
                 # one ABI call: policy loss and value loss share a launch, then the policy finalize
                 K.epoch_losses(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
@@ -568,15 +588,19 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
-        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
-        ws.pstats.zero_()
-        self._enqueue_gae(ws, obs, obs_next, rewards, dones)
+        ws.zero_block.zero_()                    # stop flag, epochs done, per-epoch policy statistics
+        lockstep = self.epoch_schedule == 'lockstep'
+        tail = None
+        if lockstep:
+            tail = self._enqueue_critic_pass(ws, obs, obs_next)
+        else:
+            self._enqueue_gae(ws, obs, obs_next, rewards, dones)
 
         obs0 = obs[:, 0, :]                      # ppo.py:527-537 (views, no copies)
         actions0 = actions[:, 0, :]
         behave0 = pds[:, 0, :]
         if self.use_z_filter:
-            zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed in _enqueue_gae
+            zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed by the critic pass
             K.zfilter_forward(obs0, zm, zs, ws.xn)
             rzm, rzs = ref.z_filter.refresh_stats()
             K.zfilter_forward(obs0, rzm, rzs, ws.xr)
@@ -584,10 +608,13 @@ class PPOLearner(Learner):
             ws.xn.copy_(obs0)
             ws.xr.copy_(obs0)
         ws.xnT.copy_(ws.xn.t())
-        # ref_pol = ref_target_model.forward_actor(obs_iter)   (ppo.py:539)
-        K.mlp3_forward(ref.actor, ws.xr, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
-        ws.ref_pol[:, :A].copy_(ws.ref_mean)
+        # ref_pol = ref_target_model.forward_actor(obs_iter)   (ppo.py:539): the mean goes
+        # straight into the left half of ref_pol, the std is exp(log_var) broadcast
+        ref_job = dict(net=ref.actor, x=ws.xr, h1=ws.h1r, h2=ws.h2r, out=ws.ref_pol[:, :A],
+                       act=L.SMX_ACT_TANH)
         ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
+        if not lockstep:
+            K.mlp3_forward_multi([ref_job])
 
         def policy_epochs():
             self._enqueue_policy_forward(ws, 0, actions0, behave0)
@@ -601,8 +628,12 @@ class PPOLearner(Learner):
             K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats,
                              L.VS_STRIDE)
 
-        if self.epoch_schedule == 'lockstep':
-            self._enqueue_lockstep_epochs(ws, actions0, behave0)
+        if lockstep:
+            # the reference policy and the critic's obs_next rows ride in epoch 0's forward
+            # launches (four independent networks, one launch per layer); GAE follows them
+            self._enqueue_lockstep_epochs(
+                ws, actions0, behave0, first_extra=[ref_job] + ([tail] if tail is not None else []),
+                after_first=lambda: self._enqueue_gae_from_values(ws, obs, rewards, dones))
         elif self.overlap_value_epochs and self.world_size == 1:
             main = torch.cuda.current_stream()
             side = self._side_stream()
@@ -774,8 +805,7 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A, E = self.action_dim, ws.E
-        ws.ctrl_i[L.C_STOP:L.C_EPOCHS_DONE + 1].zero_()
-        ws.pstats.zero_()
+        ws.zero_block.zero_()
         self._enqueue_gae_stem(ws, obs, obs_next, pix, pix_next, rewards, dones)
 
         # obs_iter: the first E steps of every sub-trajectory (E = 1 without the LSTM; ppo.py:521-537)
@@ -880,8 +910,18 @@ class PPOLearner(Learner):
                 torch.cuda.synchronize()
                 self._restore_state(snap)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._enqueue_optimize(ws, *args)
+                # no cyclic garbage collection while the stream is capturing: a collection that
+                # frees some earlier learner's graph or device tensors calls hipFree / graph
+                # destructors in the middle of the capture, which aborts the process
+                gc_was_enabled = gc.isenabled()
+                gc.collect()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        self._enqueue_optimize(ws, *args)
+                finally:
+                    if gc_was_enabled:
+                        gc.enable()
                 self._restore_state(snap)
                 if getattr(ws, 'staged', None) is not None and args is ws.staged:
                     self._graphs = {key: g}          # staging mode: the in-place graph is retired
