@@ -150,6 +150,8 @@ def main():
     ap.add_argument('--mode', default='adapt', choices=['adapt', 'clip'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--schedule', default='lockstep', choices=['lockstep', 'two_stream'],
+                    help='epoch launch schedule (session_config.learner.epoch_schedule)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -163,6 +165,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     learner, params, zstate = build_learner(args.mode, local_rank)
+    learner.epoch_schedule = args.schedule
     if args.no_graph:
         learner.use_graph = False
     dbatch, batch = device_batch(learner, rank)
