@@ -136,7 +136,9 @@ struct KRange {          // the K range this workgroup sums (the whole K unless 
     int K;
 };
 
-template <int AM, int BM>
+// `wv` / NW: this wave takes super-blocks wv, wv + NW, ... (NW = 4: the waves of a workgroup split K;
+// NW = 1: the wave walks all of K by itself)
+template <int AM, int BM, int NW = 4>
 __device__ __forceinline__ void mainloop(const GemmProb& P, const KRange& R, int m0, int n0, int i,
                                          int kh, int wv, f32x16& acc, float& asum) {
     const int nsb = (R.K + 31) >> 5;
@@ -150,24 +152,24 @@ __device__ __forceinline__ void mainloop(const GemmProb& P, const KRange& R, int
     Frag8 f0, f1, f2;
     // the barriers pin the issue order f0, f1, f2 (vmcnt is in-order: the wait for f0 must not
     // cover f1 / f2)
-    load_sb<AM, BM>(f0, O, (wv + 0) * 32 + kofs);
+    load_sb<AM, BM>(f0, O, (wv + 0 * NW) * 32 + kofs);
     __builtin_amdgcn_sched_barrier(0);
-    load_sb<AM, BM>(f1, O, (wv + 4) * 32 + kofs);
+    load_sb<AM, BM>(f1, O, (wv + 1 * NW) * 32 + kofs);
     __builtin_amdgcn_sched_barrier(0);
-    load_sb<AM, BM>(f2, O, (wv + 8) * 32 + kofs);
-    for (int sb = wv; sb < nsb; sb += 12) {
+    load_sb<AM, BM>(f2, O, (wv + 2 * NW) * 32 + kofs);
+    for (int sb = wv; sb < nsb; sb += 3 * NW) {
         __builtin_amdgcn_sched_barrier(0);
         mma_sb(acc, asum, f0);
         __builtin_amdgcn_sched_barrier(0);
-        load_sb<AM, BM>(f0, O, (sb + 12) * 32 + kofs);
+        load_sb<AM, BM>(f0, O, (sb + 3 * NW) * 32 + kofs);
         __builtin_amdgcn_sched_barrier(0);
-        if (sb + 4 < nsb) mma_sb(acc, asum, f1);
+        if (sb + NW < nsb) mma_sb(acc, asum, f1);
         __builtin_amdgcn_sched_barrier(0);
-        load_sb<AM, BM>(f1, O, (sb + 16) * 32 + kofs);
+        load_sb<AM, BM>(f1, O, (sb + 4 * NW) * 32 + kofs);
         __builtin_amdgcn_sched_barrier(0);
-        if (sb + 8 < nsb) mma_sb(acc, asum, f2);
+        if (sb + 2 * NW < nsb) mma_sb(acc, asum, f2);
         __builtin_amdgcn_sched_barrier(0);
-        load_sb<AM, BM>(f2, O, (sb + 20) * 32 + kofs);
+        load_sb<AM, BM>(f2, O, (sb + 5 * NW) * 32 + kofs);
     }
 }
 
@@ -275,6 +277,60 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     }
 }
 
+// Many-row variant (M >= 2048: the stem passes over B*T or frames*pixels rows).  A workgroup owns a
+// 128 x 32 output tile and its four waves split the ROWS: each wave walks all of K for its own
+// 32 x 32 tile and stores it straight from the accumulators -- no cross-wave reduction, and the
+// per-workgroup fixed cost is spread over four times the work.  No bias-gradient / sum-of-squares
+// outputs (the weight gradients take the K-split kernel).
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmBatch G) {
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_PROBS; ++k)
+        if (k < G.n && (int)blockIdx.x >= G.p[k].tile_base) pi = k;
+    const GemmProb& P = G.p[pi];
+    if (P.stop && *P.stop) return;
+    const int tile = blockIdx.x - P.tile_base;
+    const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int m0 = (tm * 4 + wv) * 32, n0 = tn * 32;
+    if (m0 >= P.M) return;
+    KRange R;
+    R.A = P.A; R.B = P.B; R.a_bytes = P.a_bytes; R.b_bytes = P.b_bytes; R.K = P.K;
+    f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+    float asum = 0.f;
+    switch (P.a_mode * 3 + P.b_mode) {
+        case 0: mainloop<0, 0, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 1: mainloop<0, 1, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 2: mainloop<0, 2, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 3: mainloop<1, 0, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 4: mainloop<1, 1, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 5: mainloop<1, 2, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 6: mainloop<2, 0, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        case 7: mainloop<2, 1, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+        default: mainloop<2, 2, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
+    }
+    // C fragment: lane holds column n0 + i, reg s holds row (s&3) + 8(s>>2) + 4kh -> each store
+    // instruction writes two rows of 32 consecutive floats
+    const int n = n0 + i;
+    if (n < P.N) {
+        const float bias = P.bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int m = m0 + (s & 3) + 8 * (s >> 2) + 4 * kh;
+            if (m < P.M) {
+                float v = act_f(acc[s] + bias, P.act);
+                if (P.mask) v = (P.mask[(size_t)m * P.ldc + n] > 0.f) ? v : 0.f;
+                P.C[(size_t)m * P.ldc + n] = v;
+                if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
+            }
+        }
+    }
+}
+
 inline unsigned long long operand_bytes(int ld, int kc, int nrows, int K) {
     return kc ? 4ull * ((unsigned long long)(nrows - 1) * ld + K)
               : 4ull * ((unsigned long long)(K - 1) * ld + nrows);
@@ -307,6 +363,21 @@ inline bool prob_ok(const GemmProb& P) {
 inline int launch_batch(GemmBatch& G, hipStream_t st) {
     for (int k = 0; k < G.n; ++k)
         if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
+    bool rows_variant = true;
+    for (int k = 0; k < G.n; ++k)
+        rows_variant = rows_variant && G.p[k].M >= 2048 && !G.p[k].dbias && !G.p[k].sumsq &&
+                       G.p[k].splits == 1;
+    if (rows_variant) {
+        int base = 0;
+        for (int k = 0; k < G.n; ++k) {
+            G.p[k].tiles_m = (G.p[k].M + 127) / 128;        // 128-row workgroup tiles
+            G.p[k].tile_base = base;
+            base += G.p[k].tiles_m * G.p[k].tiles_n;
+        }
+        hipLaunchKernelGGL(gemm_rows_kernel, dim3(base), dim3(256), 0, st, G);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SMX_OK : (int)e;
+    }
     const GemmProb& L = G.p[G.n - 1];
     const int blocks = L.tile_base + L.tiles_m * L.tiles_n * L.splits;
     bool all_vec = true;
