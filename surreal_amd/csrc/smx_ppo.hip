@@ -12,7 +12,9 @@
 
 namespace {
 
-constexpr int LOSS_ROWS_PER_BLOCK = 64;  // one wave per block: lane == row
+// rows per workgroup of the policy loss: 16 -> 64 workgroups for the 1024-row epochs (the kernel is
+// a chain of three short phases; with 64 rows it ran on 16 CUs and took 11 us, most of it waiting)
+constexpr int LOSS_ROWS_PER_BLOCK = 16;
 constexpr int MAX_A = 32;
 
 __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
@@ -78,7 +80,7 @@ __device__ __forceinline__ void policy_loss_body(
     __syncthreads();
 
     // ---- phase 2: one lane per row ---------------------------------------------------------
-    if (tid < 64) {
+    if (tid < 64) {                      // one wave; lanes >= nrows only feed zeros to the sums
         const int r = tid;
         const bool ok = r < nrows;
         const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
@@ -123,7 +125,7 @@ __device__ __forceinline__ void policy_loss_body(
         }
         // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
         const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
-        r_dll[r] = ok ? dll : 0.f;
+        if (r < R) r_dll[r] = ok ? dll : 0.f;
         const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
         const float v0 = smx_wave_sum(ok ? surr : 0.f);
         const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
@@ -174,12 +176,22 @@ __device__ __forceinline__ void policy_finalize_body(
     float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
     float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
     __shared__ float S[8 + 2 * MAX_A];
+    constexpr int CH = 64;                               // partial rows staged per pass
+    __shared__ float buf[CH * (8 + 2 * MAX_A)];
     const int stride = 8 + 2 * A;
-    for (int k = threadIdx.x; k < stride; k += 256) {
-        float t = 0.f;
-        for (int b = 0; b < nblk; ++b) t += partials[(size_t)b * stride + k];
-        S[k] = t;
+    // block partials -> batch sums: the rows are staged through LDS with coalesced loads and
+    // added in row order (the order, hence the result, is the same in every workgroup)
+    float t = 0.f;
+    for (int b0 = 0; b0 < nblk; b0 += CH) {
+        const int nb = min(CH, nblk - b0);
+        for (int idx = threadIdx.x; idx < nb * stride; idx += 256)
+            buf[idx] = partials[(size_t)b0 * stride + idx];
+        __syncthreads();
+        if ((int)threadIdx.x < stride)
+            for (int b = 0; b < nb; ++b) t += buf[b * stride + threadIdx.x];
+        __syncthreads();
     }
+    if ((int)threadIdx.x < stride) S[threadIdx.x] = t;
     __syncthreads();
     const float n = (float)n_total;
     const float surr_mean = S[0] / n;

@@ -166,8 +166,10 @@ class TorchCpuKernels(object):
         x.copy_((x - mean) / den)
 
     # ---- losses -------------------------------------------------------------------------
+    LOSS_ROWS = 16           # rows per workgroup of the policy loss kernel (partial-sum granularity)
+
     def loss_blocks(self, rows):
-        return (rows + 63) // 64
+        return (rows + self.LOSS_ROWS - 1) // self.LOSS_ROWS
 
     def policy_loss(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
                     partials):
@@ -212,7 +214,7 @@ class TorchCpuKernels(object):
         nblk = self.loss_blocks(rows)
         partials.zero_()
         for b in range(nblk):
-            sl = slice(64 * b, min(64 * (b + 1), rows))
+            sl = slice(self.LOSS_ROWS * b, min(self.LOSS_ROWS * (b + 1), rows))
             partials[b, 0] = surr[sl].sum()
             partials[b, 1] = loss_r[sl].sum()
             partials[b, 2] = kl[sl].sum()
