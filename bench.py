@@ -121,6 +121,20 @@ def measured_traffic(rows):
     return None, None
 
 
+def measured_mfma_util(rows):
+    """MFMA-busy share of the fused kernel from the committed PMC pass (profiles/*_pmc_mfma.json)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')), reverse=True):
+        try:
+            ks = json.load(open(path)).get('kernels', {})
+        except Exception:
+            continue
+        for k, v in ks.items():
+            if 'fused' in k and k.endswith('@grid%d' % (rows // 128 * 256)) and 'mfma_util_pct' in v:
+                return v['mfma_util_pct'], os.path.basename(path)
+    return None, None
+
+
 def cpu_baseline(mode, params, zstate, batch, budget_s=20.0):
     """the reference learner's CPU path (oracle restatement, same ATen ops) on this host"""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -158,11 +172,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    # SMX_BENCH_BACKEND=gloo is the single-GPU rehearsal of the N > 1 path (tests/test_gpu_dist.py):
+    # RCCL refuses two ranks on one device, gloo does not, and the ranks then share the GPU
+    backend = os.environ.get('SMX_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     learner, params, zstate = build_learner(args.mode, local_rank)
     learner.epoch_schedule = args.schedule
@@ -223,6 +245,8 @@ def main():
                 'frac': flops / kt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 'traffic': measured_traffic(rows)[0],
                 'traffic_source': measured_traffic(rows)[1],
+                'mfma_busy_pct': measured_mfma_util(rows)[0],
+                'mfma_busy_source': measured_mfma_util(rows)[1],
                 'kernel_ms': kt * 1e3,
                 'flops_per_launch': flops,
                 'algorithmic_bytes_per_launch': bytes_,

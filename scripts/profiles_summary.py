@@ -1,7 +1,8 @@
 """Turn the rocprofv3 CSV outputs under gpurun_out/ into the committed summaries under profiles/:
     <tag>_bench_kernel_stats.csv   per-kernel and per-grid-size durations (--kernel-trace --stats)
     <tag>_pmc_hbm_traffic.json     FETCH_SIZE / WRITE_SIZE per launch (separate --pmc passes)
-usage: python scripts/profiles_summary.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]"""
+    <tag>_pmc_mfma.json            MFMA-busy / issued MFMA flops per launch (its own --pmc pass)
+usage: python scripts/profiles_summary.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir> [<pmc_mfma_dir>]]"""
 import collections
 import csv
 import json
@@ -14,7 +15,43 @@ def short(name):
     return name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].replace(',', ';')
 
 
-def main(tag, stats_dir, fetch_dir=None, write_dir=None):
+N_XCD, N_SIMD = 8, 1024          # MI355X: 8 XCDs, 256 CUs x 4 SIMDs
+
+
+def mfma_summary(tag, mfma_dir):
+    """MfmaUtil as counter_defs.yaml defines it: sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE *
+    SIMD_NUM).  The CSV holds each counter summed over its instances, so GRBM_GUI_ACTIVE (one per
+    XCD) is divided by the 8 XCDs to get the kernel's active cycles."""
+    a = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(mfma_dir + '/bench_counter_collection.csv')):
+        n = short(r['Kernel_Name'])
+        if 'fused' in n or 'gemm' in n or 'lstm' in n:
+            a[(n, int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
+    res = {'note': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES '
+                   'SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (own pass), python bench.py --steps 3 --warmup 1 '
+                   '--no-graph --no-cpu-baseline.  Means per launch.  mfma_util_pct = MFMA_BUSY / '
+                   '(GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) * 100 (the MfmaUtil formula of counter_defs.yaml); '
+                   'mfma_flops = MOPS_F32 * 512; active clock = GRBM_GUI_ACTIVE / 8 / kernel time is what the '
+                   'chip ran at under the profiler (DVFS), so util and the bench roofline.frac (priced at the '
+                   '2.4 GHz peak) differ by that clock ratio.',
+           'kernels': {}}
+    for (n, g), c in sorted(a.items()):
+        m = {k: sum(v) / len(v) for k, v in c.items()}
+        gui = m.get('GRBM_GUI_ACTIVE', 0.0) / N_XCD
+        e = {'launches': len(next(iter(c.values()))), 'counters_mean': m}
+        if gui:
+            e['active_cycles_per_xcd'] = gui
+            e['mfma_util_pct'] = 100.0 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * N_SIMD)
+        e['mfma_flops'] = m.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0) * 512
+        res['kernels']['%s@grid%d' % (n, g)] = e
+    json.dump(res, open('profiles/%s_pmc_mfma.json' % tag, 'w'), indent=1)
+    for k, e in res['kernels'].items():
+        print('%-46s util %5.1f %%  flops %.3e' % (k, e.get('mfma_util_pct', float('nan')), e['mfma_flops']))
+
+
+def main(tag, stats_dir, fetch_dir=None, write_dir=None, mfma_dir=None):
+    if mfma_dir:
+        mfma_summary(tag, mfma_dir)
     rows = list(csv.DictReader(open(stats_dir + '/bench_kernel_stats.csv')))
     out = 'profiles/%s_bench_kernel_stats.csv' % tag
     with open(out, 'w') as f:

@@ -323,9 +323,21 @@ class PPOLearner(Learner):
         ws.ppart = f(ws.nblk_p, ws.pstride)
         ws.ppart_sum = f(1, ws.pstride)
         ws.nblk_v = K.value_loss_blocks(rows)
+        # batch means are over the GLOBAL batch: ranks may hold different numbers of sub-trajectories
+        # (B not divisible by the world size), so the totals are exchanged once per workspace.  A
+        # rank's batch shape may therefore only change in a learn() where every rank's does.
+        ws.n_total, ws.B_total = rows, B
+        if self.world_size > 1:
+            mine = torch.tensor([rows, B], dtype=torch.int64, device=dev)
+            every = torch.empty(2 * self.world_size, dtype=torch.int64, device=dev)
+            self._dist.all_gather_into_tensor(every, mine)
+            every = every.view(-1, 2).tolist()
+            ws.n_total, ws.B_total = sum(r for r, _ in every), sum(b for _, b in every)
+            ws.nblk_v = max(K.value_loss_blocks(r) for r, _ in every)
+        # partial rows a rank does not fill stay zero (count 0: skipped by the merge)
         ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
-        ws.vpart_local = f(ws.nblk_v, 8)
-        ws.vpart_loc_all = f(Ev, ws.nblk_v, 8)          # lock-step: gathered once per learn
+        ws.vpart_local = torch.zeros(ws.nblk_v, 8, device=dev)
+        ws.vpart_loc_all = torch.zeros(Ev, ws.nblk_v, 8, device=dev)   # lock-step: gathered once per learn
         ws.vgather = f(self.world_size, Ev, ws.nblk_v, 8)
         ws.np_a = K.mlp3_backward_partials(act)
         ws.np_c = K.mlp3_backward_partials(cri)
@@ -450,7 +462,7 @@ class PPOLearner(Learner):
             part, nblk = ws.ppart_sum, 1
         A = self.action_dim
         K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1),
-                          ws.rows * self.world_size, ws.ctrl_f, e > 0, e < self.epoch_policy,
+                          ws.n_total, ws.ctrl_f, e > 0, e < self.epoch_policy,
                           ws.dz3a, ws.grads_a[m.actor.numel:m.actor.numel + A],
                           ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
 
@@ -473,7 +485,7 @@ class PPOLearner(Learner):
         """forward + loss + backward + clip + Adam for the critic (ppo.py:323-353)"""
         K, m = self.K, self.model
         K.mlp3_forward(m.critic, ws.xn, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
-        n_total = ws.rows * self.world_size
+        n_total = ws.n_total
         if self.world_size > 1:
             K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
             self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
@@ -499,7 +511,7 @@ class PPOLearner(Learner):
         mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
         A = self.action_dim
         W = self.world_size
-        n_total = ws.rows * W
+        n_total = ws.n_total
         aj = dict(net=m.actor, x=ws.xn, h1=ws.h1a, h2=ws.h2a, out=ws.mean, act=L.SMX_ACT_TANH,
                   dz3=ws.dz3a, dz2=ws.dz2a, dz1=ws.dz1a, grads=ws.grads_a, sumsq=ws.sumsq_a,
                   stop=ws.stop, xT=ws.xnT, h1T=ws.h1aT, h2T=ws.h2aT, dz3T=ws.dz3aT, dz2T=ws.dz2aT,
@@ -741,7 +753,7 @@ class PPOLearner(Learner):
             torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
             self._dist.all_reduce(ws.ppart_sum)
             part, nblk = ws.ppart_sum, 1
-        K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1), ws.rows * W,
+        K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1), ws.n_total,
                           ws.ctrl_f, e > 0, e < self.epoch_policy, ws.dz3a,
                           ws.grads_a[m.actor.numel:m.actor.numel + A],
                           ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
@@ -784,7 +796,7 @@ class PPOLearner(Learner):
         K, m = self.K, self.model
         x = self._stem_forward(ws, m, ws.xn, None)
         K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
-        n_total = ws.rows * self.world_size
+        n_total = ws.n_total
         if self.world_size > 1:
             K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
             self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
@@ -1006,7 +1018,7 @@ class PPOLearner(Learner):
             batch['persistent_infos'], batch.get('onetime_infos'), batch['dones'])
         self.periodic_checkpoint(global_steps=self.current_iteration, score=None)
         self.tensorplex.add_scalars(tensorplex_update_dict, self.global_step)
-        self.exp_counter += self.batch_size * self.world_size
+        self.exp_counter += self._ws.B_total
         self.global_step += 1
         return tensorplex_update_dict
 

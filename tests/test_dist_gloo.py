@@ -65,7 +65,8 @@ def _worker(rank, world, port, name, q):
         q.put((rank, {'error': traceback.format_exc()}))
 
 
-@pytest.mark.parametrize('name', ['tiny_clip', 'tiny_adapt_cutoff2', 'cfg2_adapt', 'tiny_rnn_clip', 'cfg1_rnn_adapt'])
+@pytest.mark.parametrize('name', ['tiny_clip', 'tiny_adapt_cutoff2', 'cfg2_adapt', 'tiny_rnn_clip', 'cfg1_rnn_adapt',
+                                  'tiny_pixel_clip', 'tiny_pixel_rnn_adapt'])
 def test_two_rank_learner_equals_single_learner(name):
     world = 2
     ctx = mp.get_context('spawn')
