@@ -161,7 +161,7 @@ typedef struct {
 } smx_mlp3_job_t;
 /* forward: 1 <= njobs <= 4 (one launch per layer for all jobs; jobs may differ in rows and
  * shapes -- e.g. actor, critic, reference actor and the critic over the obs_next rows at the
- * start of a learn); backward: 1 <= njobs <= 2 (three launches: dz2, dz1, all weight gradients) */
+ * start of a learn); backward: 1 <= njobs <= 3 (three launches: dz2, dz1, all weight gradients) */
 int smx_mlp3_forward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
 int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
 
@@ -307,6 +307,45 @@ typedef struct smx_ppo_losses {
 } smx_ppo_losses_t;
 int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ctrl_t* ctrl,
                              smx_stream_t stream);
+/* Data-parallel lock-step epoch (several ranks): ONE all-reduce per epoch instead
+ * of one for the loss sums and one for the gradients.  The gradient of either loss is linear in
+ * dz3 = (g_surr + c_kl * g_kl) / n_total, and only c_kl needs the GLOBAL mean KL (ppo.py:272-276),
+ * so the backward pass runs on the two right-hand sides separately and the combination happens
+ * after the all-reduce:
+ *   smx_ppo_epoch_losses_dp_f32   the launch of smx_ppo_epoch_losses_f32 WITHOUT its finalize:
+ *                                 args->g_surr / g_kl receive the tiles already divided by
+ *                                 n_total (+ transposed copies [A, ld_t] when g_surr_t != NULL),
+ *                                 args->row_partials the block sums, the value loss uses n_total;
+ *                                 args->dz3 / dz3_t / dlogvar / dlogvar_sumsq / stats are ignored
+ *   (backward on both right-hand sides; all-reduce of [G_surr | G_critic | G_kl | row_partials])
+ *   smx_ppo_epoch_combine_f32     grads_a[i] += c_kl * grads_kl[i] for i < n_mlp (adapt; clip:
+ *                                 grads_kl may be NULL), grads_a[n_mlp + a] = log_var's gradient,
+ *                                 stats / KL early exit / step counters exactly as
+ *                                 smx_ppo_loss_finalize_f32, and the sum-of-squares partials of
+ *                                 both groups for smx_clip_adam_step_pair_f32:
+ *                                 sumsq_a [smx_sumsq_blocks(n_a)], sumsq_c [smx_sumsq_blocks(n_c)]
+ *                                 (grads_c == NULL: actor only). */
+int smx_ppo_epoch_losses_dp_f32(const smx_ppo_losses_t* args, int64_t n_total, float* g_surr_t,
+                                float* g_kl_t, smx_ppo_ctrl_t* ctrl, smx_stream_t stream);
+typedef struct smx_ppo_combine {
+    int32_t mode, A;
+    const float* row_partials; /* [nblk, 8 + 2A], summed over ranks */
+    int32_t nblk;
+    int32_t check_stop;
+    int64_t n_total;
+    const float* log_var;
+    float* stats;
+    float* grads_a;
+    const float* grads_kl;
+    int64_t n_mlp, n_a;
+    float* sumsq_a;
+    const float* grads_c;
+    int64_t n_c;
+    float* sumsq_c;
+    int32_t will_update, reserved;
+} smx_ppo_combine_t;
+int smx_ppo_epoch_combine_f32(const smx_ppo_combine_t* args, smx_ppo_ctrl_t* ctrl,
+                              smx_stream_t stream);
 /* The means PPOLearner._optimize reports once per learn, formed on the device so that the whole
  * statistics block needs one read-back: out4 = {mean(log_var) (ppo.py:572), mean_d(running_sum/
  * count), mean_d(running_sumsq/count), mean_d(sqrt(running_sumsq/count - (running_sum/count)^2))}

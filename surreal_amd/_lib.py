@@ -62,6 +62,16 @@ class PpoLosses(Structure):
                 ('v_partials', c_void_p), ('will_update', c_int32), ('v_will_update', c_int32)]
 
 
+class PpoCombine(Structure):
+    """smx_ppo_combine_t"""
+    _fields_ = [('mode', c_int32), ('A', c_int32), ('row_partials', c_void_p), ('nblk', c_int32),
+                ('check_stop', c_int32), ('n_total', c_int64), ('log_var', c_void_p),
+                ('stats', c_void_p), ('grads_a', c_void_p), ('grads_kl', c_void_p),
+                ('n_mlp', c_int64), ('n_a', c_int64), ('sumsq_a', c_void_p), ('grads_c', c_void_p),
+                ('n_c', c_int64), ('sumsq_c', c_void_p), ('will_update', c_int32),
+                ('reserved', c_int32)]
+
+
 # smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
 CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
@@ -102,6 +112,8 @@ _SIGS = {
                                             c_int32, _P, c_int32, c_int32, _P, _P, c_int64, _P, _P,
                                             _P, _P]),
     'smx_ppo_epoch_losses_f32': (c_int32, [POINTER(PpoLosses), _P, _P]),
+    'smx_ppo_epoch_losses_dp_f32': (c_int32, [POINTER(PpoLosses), c_int64, _P, _P, _P, _P]),
+    'smx_ppo_epoch_combine_f32': (c_int32, [POINTER(PpoCombine), _P, _P]),
     'smx_ppo_final_stats_f32': (c_int32, [_P, c_int32, _P, _P, _P, c_int32, _P, _P]),
     'smx_value_loss_blocks': (c_int32, [c_int64]),
     'smx_value_loss_f32': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P]),

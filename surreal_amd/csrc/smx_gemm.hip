@@ -33,7 +33,7 @@ struct GemmProb {
     long c_split;
 };
 
-constexpr int MAX_PROBS = 6;
+constexpr int MAX_PROBS = 9;
 
 struct GemmBatch {
     GemmProb p[MAX_PROBS];
@@ -498,7 +498,8 @@ extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const f
 // (PPO: actor + critic, which the reference updates in two separate loops, ppo.py:541-562)
 // share ONE launch per layer -- half the launches, twice the workgroups per launch.
 // ---------------------------------------------------------------------------
-constexpr int MAX_JOBS = 2;       // backward: 3 GEMM problems per job in one launch
+constexpr int MAX_JOBS = 3;       // backward: 3 GEMM problems per job in one launch (the third job:
+                                  // the actor's KL right-hand side of a data-parallel epoch)
 constexpr int MAX_FWD_JOBS = 4;   // forward: 1 problem per job and layer (e.g. actor, critic,
                                   // reference actor and the critic's obs_next rows of a learn)
 

@@ -36,7 +36,8 @@ __device__ __forceinline__ void policy_loss_body(
     const float* __restrict__ g_actions, int ld_act, const float* __restrict__ g_behave, int ld_beh,
     const float* __restrict__ g_ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
     const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, const float gscale = 1.0f, const bool scaled = false,
+    float* __restrict__ g_surr_t = nullptr, float* __restrict__ g_kl_t = nullptr, const long ld_t = 0) {
     const int R = LOSS_ROWS_PER_BLOCK;
     float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
     float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
@@ -140,8 +141,15 @@ __device__ __forceinline__ void policy_loss_body(
     // ---- phase 3: gradient tiles + log_var gradient partials -----------------------------
     for (int i = tid; i < (int)nrows * A; i += 256) {
         const int rr = i / A;
-        g_surr[row0 * A + i] = r_dll[rr] * e_dmu[i];
-        g_kl[row0 * A + i] = e_dkl[i];
+        float gs = r_dll[rr] * e_dmu[i], gk = e_dkl[i];
+        if (scaled) { gs *= gscale; gk *= gscale; }       // data-parallel epochs: already / n_total
+        g_surr[row0 * A + i] = gs;
+        g_kl[row0 * A + i] = gk;
+        if (g_surr_t) {
+            const long at = (long)(i - rr * A) * ld_t + row0 + rr;
+            g_surr_t[at] = gs;
+            if (g_kl_t) g_kl_t[at] = gk;
+        }
     }
     if (tid < A) {
         // d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
@@ -167,23 +175,14 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
                      ld_ref, adv, rows, A, ctrl, g_surr, g_kl, partials);
 }
 
-// blk / nblocks: this workgroup's share of the elementwise part (blk 0 also writes the scalars)
-__device__ __forceinline__ void policy_finalize_body(
-    const int blk, const int nblocks,
-    int mode, const float* __restrict__ partials, int nblk, const float* __restrict__ g_surr,
-    const float* __restrict__ g_kl, const float* __restrict__ log_var, long rows, long n_total,
-    int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
-    float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
-    float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
-    __shared__ float S[8 + 2 * MAX_A];
-    constexpr int CH = 64;                               // partial rows staged per pass
-    __shared__ float buf[CH * (8 + 2 * MAX_A)];
-    const int stride = 8 + 2 * A;
-    // block partials -> batch sums: the rows are staged through LDS with coalesced loads and
-    // added in row order (the order, hence the result, is the same in every workgroup)
+// batch sums S[0 .. 8 + 2A) of the block partial rows: staged through LDS with coalesced loads and
+// added in row order (the order, hence the result, is the same in every workgroup)
+constexpr int FIN_CH = 64;                                   // partial rows staged per pass
+__device__ __forceinline__ void reduce_row_partials(const float* __restrict__ partials, int nblk,
+                                                    int stride, float* S, float* buf) {
     float t = 0.f;
-    for (int b0 = 0; b0 < nblk; b0 += CH) {
-        const int nb = min(CH, nblk - b0);
+    for (int b0 = 0; b0 < nblk; b0 += FIN_CH) {
+        const int nb = min(FIN_CH, nblk - b0);
         for (int idx = threadIdx.x; idx < nb * stride; idx += 256)
             buf[idx] = partials[(size_t)b0 * stride + idx];
         __syncthreads();
@@ -193,10 +192,15 @@ __device__ __forceinline__ void policy_finalize_body(
     }
     if ((int)threadIdx.x < stride) S[threadIdx.x] = t;
     __syncthreads();
-    const float n = (float)n_total;
+}
+
+// loss and the coefficient of the KL gradient from the batch sums (ppo.py:217 / 272-276)
+__device__ __forceinline__ void loss_and_kl_coef(int mode, const float* S, float n,
+                                                 const smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                 float& loss, float& c_kl) {
     const float surr_mean = S[0] / n;
     const float kl_mean = S[2] / n;
-    float c_kl = 0.f, loss;
+    c_kl = 0.f;
     if (mode == SMX_PPO_CLIP) {
         loss = S[1] / n;
     } else {
@@ -210,6 +214,56 @@ __device__ __forceinline__ void policy_finalize_body(
             c_kl += 2.0f * eta * d;
         }
     }
+}
+
+// one thread: the epoch's statistics, the KL early exit and the step counters
+__device__ __forceinline__ void write_policy_scalars(const float* S, float n, float loss, float c_kl,
+                                                     const float* __restrict__ log_var, int A,
+                                                     smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                     int check_stop, int will_update,
+                                                     float* __restrict__ dlogvar_sumsq,
+                                                     float* __restrict__ stats) {
+    const float inv_n = 1.0f / n;
+    const float kl_mean = S[2] / n;
+    float ls = 0.f, dq = 0.f;
+    for (int a = 0; a < A; ++a) {
+        ls += logf(expf(log_var[a]));
+        const float g = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
+        dq += g * g;
+    }
+    if (dlogvar_sumsq) *dlogvar_sumsq = dq;
+    stats[SMX_PS_SURR] = S[0] / n;
+    stats[SMX_PS_LOSS] = loss;
+    // ppo_net.py:72 (sic): 0.5 * sum(log std) + 0.5 * log(2 pi e) * d
+    stats[SMX_PS_ENTROPY] = 0.5f * ls + (float)(0.5 * 2.8378770664093453 * (double)A);
+    stats[SMX_PS_KL] = kl_mean;
+    stats[SMX_PS_LB] = S[3] / n;
+    stats[SMX_PS_ISW] = S[4] / n;
+    stats[SMX_PS_REFBEH] = S[5] / n;
+    int stop = 0;
+    if (check_stop && (double)kl_mean > 4.0 * (double)ctrl->kl_target) stop = 1;  // ppo.py:556
+    if (stop) {
+        ctrl->stop_flag = 1;
+    } else if (will_update) {
+        ctrl->adam_step_actor += 1;
+        ctrl->epochs_done += 1;
+    }
+}
+
+// blk / nblocks: this workgroup's share of the elementwise part (blk 0 also writes the scalars)
+__device__ __forceinline__ void policy_finalize_body(
+    const int blk, const int nblocks,
+    int mode, const float* __restrict__ partials, int nblk, const float* __restrict__ g_surr,
+    const float* __restrict__ g_kl, const float* __restrict__ log_var, long rows, long n_total,
+    int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
+    float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
+    float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
+    __shared__ float S[8 + 2 * MAX_A];
+    __shared__ float buf[FIN_CH * (8 + 2 * MAX_A)];
+    reduce_row_partials(partials, nblk, 8 + 2 * A, S, buf);
+    const float n = (float)n_total;
+    float c_kl, loss;
+    loss_and_kl_coef(mode, S, n, ctrl, loss, c_kl);
     const float inv_n = 1.0f / n;
     const long total = rows * A;
     for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblocks * 256)
@@ -224,31 +278,9 @@ __device__ __forceinline__ void policy_finalize_body(
     if (blk == 0) {
         for (int a = threadIdx.x; a < A; a += 256)
             dlogvar[a] = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
-        if (threadIdx.x == 0) {
-            float ls = 0.f, dq = 0.f;
-            for (int a = 0; a < A; ++a) {
-                ls += logf(expf(log_var[a]));
-                const float g = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
-                dq += g * g;
-            }
-            if (dlogvar_sumsq) *dlogvar_sumsq = dq;
-            stats[SMX_PS_SURR] = surr_mean;
-            stats[SMX_PS_LOSS] = loss;
-            // ppo_net.py:72 (sic): 0.5 * sum(log std) + 0.5 * log(2 pi e) * d
-            stats[SMX_PS_ENTROPY] = 0.5f * ls + (float)(0.5 * 2.8378770664093453 * (double)A);
-            stats[SMX_PS_KL] = kl_mean;
-            stats[SMX_PS_LB] = S[3] / n;
-            stats[SMX_PS_ISW] = S[4] / n;
-            stats[SMX_PS_REFBEH] = S[5] / n;
-            int stop = 0;
-            if (check_stop && (double)kl_mean > 4.0 * (double)ctrl->kl_target) stop = 1;  // ppo.py:556
-            if (stop) {
-                ctrl->stop_flag = 1;
-            } else if (will_update) {
-                ctrl->adam_step_actor += 1;
-                ctrl->epochs_done += 1;
-            }
-        }
+        if (threadIdx.x == 0)
+            write_policy_scalars(S, n, loss, c_kl, log_var, A, ctrl, check_stop, will_update,
+                                 dlogvar_sumsq, stats);
     }
 }
 
@@ -312,16 +344,78 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* __restrict
 // kernels -- one workgroup walking all rows x A gradient elements is far slower than a launch.
 __global__ __launch_bounds__(256) void ppo_losses_kernel(smx_ppo_losses_t a,
                                                          smx_ppo_ctrl_t* __restrict__ ctrl,
-                                                         int nblk_p) {
+                                                         int nblk_p, long n_total, int scaled,
+                                                         float* __restrict__ g_surr_t,
+                                                         float* __restrict__ g_kl_t) {
     extern __shared__ float sm[];
     if ((int)blockIdx.x >= nblk_p) {
-        value_loss_body(blockIdx.x - nblk_p, a.values, a.returns, (long)a.rows, (long)a.rows, a.v_dz3,
+        value_loss_body(blockIdx.x - nblk_p, a.values, a.returns, (long)a.rows, n_total, a.v_dz3,
                         a.v_partials, ctrl, a.v_will_update);
         return;
     }
     if (ctrl->stop_flag) return;
     policy_loss_body(blockIdx.x, sm, a.mode, a.mean, a.log_var, a.actions, a.ld_act, a.behave, a.ld_beh,
-                     a.ref, a.ld_ref, a.adv, (long)a.rows, a.A, ctrl, a.g_surr, a.g_kl, a.row_partials);
+                     a.ref, a.ld_ref, a.adv, (long)a.rows, a.A, ctrl, a.g_surr, a.g_kl, a.row_partials,
+                     1.0f / (float)n_total, scaled != 0, g_surr_t, g_kl_t, (long)a.ld_t);
+}
+
+// Data-parallel lock-step epoch, after the all-reduce of [surrogate share | critic gradient | KL
+// share | loss partial rows]: the backward pass ran on the two right-hand sides g_surr / n and
+// g_kl / n (it is linear in dz3), so the gradient of the loss is  G_surr + c_kl * G_kl  with c_kl
+// from the GLOBAL mean KL -- formed here, together with log_var's gradient, the epoch statistics,
+// the KL early exit and the sum-of-squares partials clip_grad_norm_ needs for both groups.
+// Workgroups [0, nb_a): the actor group's elements; [nb_a, nb_a + nb_c): the critic's.
+__global__ __launch_bounds__(256) void epoch_combine_kernel(smx_ppo_combine_t a,
+                                                            smx_ppo_ctrl_t* __restrict__ ctrl,
+                                                            int nb_a, int nb_c) {
+    __shared__ float red[16];
+    if ((int)blockIdx.x >= nb_a) {                       // critic: sum of squares only
+        const int blk = blockIdx.x - nb_a;
+        const long per = (a.n_c + nb_c - 1) / nb_c;
+        const long lo = (long)blk * per;
+        const long hi = min(lo + per, (long)a.n_c);
+        float q = 0.f;
+        for (long i = lo + threadIdx.x; i < hi; i += 256) q += a.grads_c[i] * a.grads_c[i];
+        const float t = smx_block_sum(q, red);
+        if (threadIdx.x == 0) a.sumsq_c[blk] = t;
+        return;
+    }
+    if (ctrl->stop_flag) return;
+    __shared__ float S[8 + 2 * MAX_A];
+    __shared__ float buf[FIN_CH * (8 + 2 * MAX_A)];
+    const int A = a.A;
+    reduce_row_partials(a.row_partials, a.nblk, 8 + 2 * A, S, buf);
+    const float n = (float)a.n_total;
+    float c_kl, loss;
+    loss_and_kl_coef(a.mode, S, n, ctrl, loss, c_kl);
+    const float inv_n = 1.0f / n;
+    const int blk = blockIdx.x;
+    const long per = (a.n_a + nb_a - 1) / nb_a;
+    const long lo = (long)blk * per;
+    // the early exit taken by THIS epoch: workgroup 0 raises the flag below while the others may or
+    // may not have read it yet, so all of them take the decision themselves -- no gradient is formed
+    // (the Adam step is skipped anyway), whichever way the race goes
+    const bool stop_now = a.check_stop && (double)(S[2] / n) > 4.0 * (double)ctrl->kl_target;
+    const long hi = stop_now ? lo : min(lo + per, (long)a.n_a);
+    float q = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        float g = a.grads_a[i];
+        if (i < a.n_mlp) {
+            if (a.grads_kl) { g = g + c_kl * a.grads_kl[i]; a.grads_a[i] = g; }
+        } else if (i < a.n_mlp + A) {
+            const int k = (int)(i - a.n_mlp);
+            g = (S[8 + k] + c_kl * S[8 + A + k]) * inv_n;
+            a.grads_a[i] = g;
+        }
+        q += g * g;
+    }
+    const float t = smx_block_sum(q, red);
+    if (threadIdx.x == 0) {
+        a.sumsq_a[blk] = t;
+        if (blk == 0)
+            write_policy_scalars(S, n, loss, c_kl, a.log_var, A, ctrl, a.check_stop, a.will_update,
+                                 nullptr, a.stats);
+    }
 }
 
 __global__ __launch_bounds__(64) void value_finalize_kernel(const float* __restrict__ partials,
@@ -549,11 +643,56 @@ extern "C" int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ct
     const int nblk_p = smx_ppo_loss_blocks(a.rows);
     const size_t lds = (size_t)(8 * a.A + 1) * LOSS_ROWS_PER_BLOCK * sizeof(float);
     hipLaunchKernelGGL(ppo_losses_kernel, dim3(nblk_p + nblk_v), dim3(256), lds, smx_s(stream), a, ctrl,
-                       nblk_p);
+                       nblk_p, (long)a.rows, 0, (float*)nullptr, (float*)nullptr);
     SMX_LAUNCH_CHECK();
     return smx_ppo_loss_finalize_f32(a.mode, a.row_partials, nblk_p, a.g_surr, a.g_kl, a.log_var, a.rows,
                                      a.rows, a.A, ctrl, a.check_stop, a.will_update, a.dz3, a.dz3_t,
                                      a.ld_t, a.dlogvar, a.dlogvar_sumsq, a.stats, stream);
+}
+
+extern "C" int smx_ppo_epoch_losses_dp_f32(const smx_ppo_losses_t* args, int64_t n_total,
+                                           float* g_surr_t, float* g_kl_t, smx_ppo_ctrl_t* ctrl,
+                                           smx_stream_t stream) {
+    SMX_REQUIRE(args && ctrl, SMX_E_NULL);
+    const smx_ppo_losses_t& a = *args;
+    SMX_REQUIRE(a.mean && a.log_var && a.actions && a.behave && a.ref && a.adv && a.g_surr && a.g_kl &&
+                    a.row_partials, SMX_E_NULL);
+    SMX_REQUIRE(a.rows > 0 && n_total >= a.rows && a.A > 0 && a.ld_act >= a.A && a.ld_beh >= 2 * a.A &&
+                    a.ld_ref >= 2 * a.A, SMX_E_SHAPE);
+    SMX_REQUIRE((g_surr_t == nullptr && g_kl_t == nullptr) || (g_surr_t && a.ld_t >= a.rows), SMX_E_SHAPE);
+    SMX_REQUIRE(a.A <= MAX_A && (a.mode == SMX_PPO_CLIP || a.mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
+    int nblk_v = 0;
+    if (a.values) {
+        SMX_REQUIRE(a.returns && a.v_dz3 && a.v_partials, SMX_E_NULL);
+        nblk_v = smx_value_loss_blocks(a.rows);
+    }
+    const int nblk_p = smx_ppo_loss_blocks(a.rows);
+    const size_t lds = (size_t)(8 * a.A + 1) * LOSS_ROWS_PER_BLOCK * sizeof(float);
+    hipLaunchKernelGGL(ppo_losses_kernel, dim3(nblk_p + nblk_v), dim3(256), lds, smx_s(stream), a, ctrl,
+                       nblk_p, (long)n_total, 1, g_surr_t, g_kl_t);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ppo_epoch_combine_f32(const smx_ppo_combine_t* args, smx_ppo_ctrl_t* ctrl,
+                                         smx_stream_t stream) {
+    SMX_REQUIRE(args && ctrl, SMX_E_NULL);
+    const smx_ppo_combine_t& a = *args;
+    SMX_REQUIRE(a.row_partials && a.log_var && a.stats && a.grads_a && a.sumsq_a, SMX_E_NULL);
+    SMX_REQUIRE(a.A > 0 && a.nblk > 0 && a.n_total > 0 && a.n_mlp >= 0 && a.n_a >= a.n_mlp + a.A,
+                SMX_E_SHAPE);
+    SMX_REQUIRE(a.A <= MAX_A && (a.mode == SMX_PPO_CLIP || a.mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(a.mode == SMX_PPO_CLIP || a.grads_kl, SMX_E_NULL);
+    int nb_c = 0;
+    if (a.grads_c) {
+        SMX_REQUIRE(a.sumsq_c && a.n_c > 0, SMX_E_NULL);
+        nb_c = smx_sumsq_blocks(a.n_c);
+    }
+    const int nb_a = smx_sumsq_blocks(a.n_a);
+    hipLaunchKernelGGL(epoch_combine_kernel, dim3(nb_a + nb_c), dim3(256), 0, smx_s(stream), a, ctrl,
+                       nb_a, nb_c);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
 }
 
 extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count, int32_t nblk,

@@ -148,10 +148,8 @@ class HipKernels(object):
                0 if dz3_t is None else dz3_t.stride(0), L.ptr(dlogvar), L.ptr(dlogvar_sumsq),
                L.ptr(stats), self._st())
 
-    def epoch_losses(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
-                     partials, check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None,
-                     values=None, returns=None, v_dz3=None, v_partials=None, v_will_update=True):
-        """policy_loss + policy_finalize (+ value_loss) of a single-GPU lock-step epoch, one launch"""
+    def _losses_args(self, mode, mean, log_var, actions, behave, ref, adv, g_surr, g_kl, partials,
+                     check_stop, will_update, values, returns, v_dz3, v_partials, v_will_update):
         rows, A = mean.shape
         a = L.PpoLosses()
         a.mode, a.A, a.rows = mode, A, rows
@@ -161,12 +159,46 @@ class HipKernels(object):
         a.ref, a.ld_ref = L.ptr(ref), _row_stride(ref, 2 * A)
         a.g_surr, a.g_kl, a.row_partials = L.ptr(g_surr), L.ptr(g_kl), L.ptr(partials)
         a.check_stop, a.will_update = int(check_stop), int(will_update)
+        a.values, a.returns = L.ptr(values), L.ptr(returns)
+        a.v_dz3, a.v_partials, a.v_will_update = L.ptr(v_dz3), L.ptr(v_partials), int(v_will_update)
+        return a
+
+    def epoch_losses(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                     partials, check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None,
+                     values=None, returns=None, v_dz3=None, v_partials=None, v_will_update=True):
+        """policy_loss + policy_finalize (+ value_loss) of a single-GPU lock-step epoch, one launch"""
+        a = self._losses_args(mode, mean, log_var, actions, behave, ref, adv, g_surr, g_kl, partials,
+                              check_stop, will_update, values, returns, v_dz3, v_partials, v_will_update)
         a.dz3, a.dz3_t = L.ptr(dz3), L.ptr(dz3_t)
         a.ld_t = 0 if dz3_t is None else (dz3_t.stride(0) if dz3_t.shape[0] > 1 else dz3_t.shape[1])
         a.dlogvar, a.dlogvar_sumsq, a.stats = L.ptr(dlogvar), L.ptr(dlogvar_sumsq), L.ptr(stats)
-        a.values, a.returns = L.ptr(values), L.ptr(returns)
-        a.v_dz3, a.v_partials, a.v_will_update = L.ptr(v_dz3), L.ptr(v_partials), int(v_will_update)
         L.call('smx_ppo_epoch_losses_f32', ctypes.byref(a), L.ptr(ctrl), self._st())
+
+    def epoch_losses_dp(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                        partials, n_total, g_surr_t=None, g_kl_t=None, values=None, returns=None,
+                        v_dz3=None, v_partials=None, v_will_update=True):
+        """the loss launch of a data-parallel lock-step epoch: gradient tiles come out divided by
+        n_total (+ transposed copies), no finalize -- see smx_ppo_epoch_combine_f32"""
+        a = self._losses_args(mode, mean, log_var, actions, behave, ref, adv, g_surr, g_kl, partials,
+                              False, False, values, returns, v_dz3, v_partials, v_will_update)
+        t = g_surr_t
+        a.ld_t = 0 if t is None else (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+        L.call('smx_ppo_epoch_losses_dp_f32', ctypes.byref(a), int(n_total), L.ptr(g_surr_t),
+               L.ptr(g_kl_t), L.ptr(ctrl), self._st())
+
+    def epoch_combine(self, mode, partials, nblk, n_total, log_var, ctrl, check_stop, will_update,
+                      stats, grads_a, grads_kl, n_mlp, sumsq_a, grads_c=None, sumsq_c=None):
+        """after the all-reduce of a data-parallel epoch: grads_a += c_kl * grads_kl, log_var's
+        gradient, statistics / early exit, sum-of-squares partials of both groups"""
+        a = L.PpoCombine()
+        a.mode, a.A, a.nblk, a.n_total = mode, log_var.numel(), nblk, int(n_total)
+        a.row_partials, a.log_var, a.stats = L.ptr(partials), L.ptr(log_var), L.ptr(stats)
+        a.check_stop, a.will_update = int(check_stop), int(will_update)
+        a.grads_a, a.grads_kl = L.ptr(grads_a), L.ptr(grads_kl)
+        a.n_mlp, a.n_a, a.sumsq_a = int(n_mlp), grads_a.numel(), L.ptr(sumsq_a)
+        a.grads_c, a.sumsq_c = L.ptr(grads_c), L.ptr(sumsq_c)
+        a.n_c = 0 if grads_c is None else grads_c.numel()
+        L.call('smx_ppo_epoch_combine_f32', ctypes.byref(a), L.ptr(ctrl), self._st())
 
     def final_stats(self, log_var, zfilter, out4):
         """means the learner reports once per learn (ppo.py:572, 580-583), formed on the device so

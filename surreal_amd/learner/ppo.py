@@ -316,17 +316,13 @@ class PPOLearner(Learner):
             ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
         # one buffer for both groups' gradients: a data-parallel lock-step epoch all-reduces it once
         n_a, n_c = self.model.actor_flat.numel(), self.model.critic_flat.numel()
-        ws.grads_all = torch.zeros(n_a + n_c, device=dev)
-        ws.grads_a, ws.grads_c = ws.grads_all[:n_a], ws.grads_all[n_a:]
         ws.nblk_p = K.loss_blocks(rows)
-        ws.pstride = 8 + 2 * A
-        ws.ppart = f(ws.nblk_p, ws.pstride)
-        ws.ppart_sum = f(1, ws.pstride)
         ws.nblk_v = K.value_loss_blocks(rows)
+        ws.pstride = 8 + 2 * A
         # batch means are over the GLOBAL batch: ranks may hold different numbers of sub-trajectories
         # (B not divisible by the world size), so the totals are exchanged once per workspace.  A
         # rank's batch shape may therefore only change in a learn() where every rank's does.
-        ws.n_total, ws.B_total = rows, B
+        ws.n_total, ws.B_total, nblk_p_all = rows, B, ws.nblk_p
         if self.world_size > 1:
             mine = torch.tensor([rows, B], dtype=torch.int64, device=dev)
             every = torch.empty(2 * self.world_size, dtype=torch.int64, device=dev)
@@ -334,6 +330,28 @@ class PPOLearner(Learner):
             every = every.view(-1, 2).tolist()
             ws.n_total, ws.B_total = sum(r for r, _ in every), sum(b for _, b in every)
             ws.nblk_v = max(K.value_loss_blocks(r) for r, _ in every)
+            nblk_p_all = max(K.loss_blocks(r) for r, _ in every)
+        ws.dp_epoch = self.world_size > 1 and not stem
+        if ws.dp_epoch:
+            # [surrogate share of the actor gradient | critic gradient | KL share (adapt) | loss
+            # partial rows]: everything an epoch exchanges, in ONE all-reduce (_enqueue_lockstep_epochs)
+            al = lambda n: (n + 3) & ~3  # noqa: E731
+            adapt = self.ppo_mode != 'clip'
+            off_k = al(n_a + n_c)
+            off_p = off_k + (al(act.numel) if adapt else 0)
+            ws.ar = torch.zeros(off_p + nblk_p_all * ws.pstride, device=dev)
+            ws.grads_all = ws.ar[:n_a + n_c]
+            ws.grads_k = ws.ar[off_k:off_k + act.numel] if adapt else None
+            ws.ppart_ar = ws.ar[off_p:].view(nblk_p_all, ws.pstride)   # rows past this rank's blocks stay 0
+            if adapt:
+                ws.dz3k, ws.dz2k, ws.dz1k = f(rows, A), f(rows, act.H2), f(rows, act.H1)
+                ws.dz3kT, ws.dz2kT, ws.dz1kT = ft(A), ft(act.H2), ft(act.H1)
+                ws.sumsq_k = torch.zeros(K.mlp3_backward_partials(act), device=dev)
+        else:
+            ws.grads_all = torch.zeros(n_a + n_c, device=dev)
+        ws.grads_a, ws.grads_c = ws.grads_all[:n_a], ws.grads_all[n_a:]
+        ws.ppart = f(ws.nblk_p, ws.pstride)
+        ws.ppart_sum = f(1, ws.pstride)
         # partial rows a rank does not fill stay zero (count 0: skipped by the merge)
         ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
         ws.vpart_local = torch.zeros(ws.nblk_v, 8, device=dev)
@@ -526,6 +544,9 @@ class PPOLearner(Learner):
                                  (list(first_extra) if e == 0 else []))
             if e == 0 and after_first is not None:
                 after_first()
+            if ws.dp_epoch and pol_u and val:
+                self._enqueue_dp_epoch(ws, e, mode, aj, cj, actions0, behave0)
+                continue
             if pol_f and W == 1:
                 # one ABI call: policy loss and value loss share a launch, then the policy finalize
                 K.epoch_losses(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
@@ -590,6 +611,35 @@ class PPOLearner(Learner):
             self._dist.all_gather_into_tensor(ws.vgather.view(-1), ws.vpart_loc_all.view(-1))
             ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(ws.vgather.permute(1, 0, 2, 3))
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+
+    def _enqueue_dp_epoch(self, ws, e, mode, aj, cj, actions0, behave0):
+        """One lock-step epoch on several ranks with ONE collective.  The loss
+        gradient is linear in dz3 = (g_surr + c_kl * g_kl) / n and only c_kl needs the global mean
+        KL, so the backward pass runs on both right-hand sides (a third job in the same three
+        launches) and the combination is formed after the all-reduce of
+        [G_surr | G_critic | G_kl | loss partial rows]."""
+        K, m = self.K, self.model
+        adapt = mode == L.SMX_PPO_ADAPT
+        K.epoch_losses_dp(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
+                          ws.ctrl_f, ws.dz3a, ws.dz3k if adapt else ws.g_kl, ws.ppart_ar, ws.n_total,
+                          g_surr_t=ws.dz3aT, g_kl_t=ws.dz3kT if adapt else None, values=ws.vpred,
+                          returns=ws.ret, v_dz3=ws.dz3c, v_partials=ws.vpart_loc_all[e])
+        jobs = [aj]
+        if adapt:
+            jobs.append(dict(aj, dz3=ws.dz3k, dz2=ws.dz2k, dz1=ws.dz1k, grads=ws.grads_k,
+                             sumsq=ws.sumsq_k, dz3T=ws.dz3kT, dz2T=ws.dz2kT, dz1T=ws.dz1kT))
+        K.mlp3_backward_multi(jobs + [cj])
+        self._dist.all_reduce(ws.ar)
+        K.epoch_combine(mode, ws.ppart_ar, ws.ppart_ar.shape[0], ws.n_total, m.log_var.view(-1), ws.ctrl_f,
+                        e > 0, True, ws.pstats[e], ws.grads_a, ws.grads_k if adapt else None,
+                        m.actor.numel, ws.sumsq_a, ws.grads_c, ws.sumsq_c)
+        K.clip_adam_pair((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                          ws.sumsq_a, K.sumsq_blocks(ws.grads_a.numel()), True,
+                          ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1]),
+                         (m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                          ws.sumsq_c, K.sumsq_blocks(ws.grads_c.numel()), False,
+                          ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1]),
+                         ws.ctrl_f)
 
     def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds, pix=None,
                           pix_next=None):

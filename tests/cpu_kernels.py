@@ -275,6 +275,50 @@ class TorchCpuKernels(object):
         self.policy_finalize(mode, partials, self.loss_blocks(rows), g_surr, g_kl, log_var, rows, ctrl,
                              check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=dz3_t)
 
+    def epoch_losses_dp(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
+                        partials, n_total, g_surr_t=None, g_kl_t=None, values=None, returns=None,
+                        v_dz3=None, v_partials=None, v_will_update=True):
+        if values is not None:
+            self.value_loss(values, returns, n_total, v_dz3, v_partials, ctrl, v_will_update)
+        if int(ctrl.view(torch.int32)[L.C_STOP]) != 0:
+            return
+        self.policy_loss(mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl, partials)
+        g_surr.mul_(_f(1.0) / _f(float(n_total)))
+        g_kl.mul_(_f(1.0) / _f(float(n_total)))
+        if g_surr_t is not None:
+            g_surr_t.copy_(g_surr.t())
+            if g_kl_t is not None:
+                g_kl_t.copy_(g_kl.t())
+
+    def epoch_combine(self, mode, partials, nblk, n_total, log_var, ctrl, check_stop, will_update,
+                      stats, grads_a, grads_kl, n_mlp, sumsq_a, grads_c=None, sumsq_c=None):
+        if grads_c is not None:
+            self.sumsq_partials(grads_c, sumsq_c)
+        if int(ctrl.view(torch.int32)[L.C_STOP]) != 0:
+            return
+        A = log_var.numel()
+        # the scalar part of policy_finalize on zero rows of gradient tiles; its c_kl comes back
+        # through log_var's gradient (dlogvar = (S_ll + c_kl * S_kl) / n)
+        empty = torch.zeros(0, A)
+        dlv = torch.zeros(A)
+        beta, eta, kt = float(ctrl[L.C_BETA]), float(ctrl[L.C_ETA]), float(ctrl[L.C_KL_TARGET])
+        S = partials[:nblk].sum(0)
+        kl_mean = S[2] / float(n_total)
+        c_kl = 0.0
+        if mode != L.SMX_PPO_CLIP:
+            c_kl = beta
+            if float(kl_mean) - 2.0 * kt > 0:
+                c_kl = c_kl + 2.0 * eta * float(kl_mean - _f(2.0 * kt))
+        self.policy_finalize(mode, partials, nblk, empty, empty, log_var, n_total, ctrl, check_stop,
+                             will_update, torch.zeros(0, A), dlv, None, stats)
+        if int(ctrl.view(torch.int32)[L.C_STOP]) != 0:
+            sumsq_a.zero_()              # this epoch took the early exit: no gradient is formed
+            return
+        if grads_kl is not None:
+            grads_a[:n_mlp].add_(c_kl * grads_kl[:n_mlp])
+        grads_a[n_mlp:n_mlp + A].copy_(dlv)
+        self.sumsq_partials(grads_a, sumsq_a)
+
     def final_stats(self, log_var, zfilter, out4):
         out4.zero_()
         out4[0] = log_var.double().mean()

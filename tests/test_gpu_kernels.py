@@ -624,3 +624,88 @@ def test_linear_wgrad_splitk_matches_fp64(K, M, N, rows):
     dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
     K.linear_wgrad(dz.cuda(), x.cuda(), dW2, db2, M, N, rows, ws=ws if n_ws else None)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)          # deterministic
+
+
+@pytest.mark.parametrize('mode', [L.SMX_PPO_CLIP, L.SMX_PPO_ADAPT])
+@pytest.mark.parametrize('rows,A,world,kl_target', [(1024, 17, 8, 1e9), (100, 6, 2, 1e9), (100, 6, 2, 1e-4),
+                                                     (5, 2, 1, 1e9)])
+def test_data_parallel_epoch_losses_and_combine(K, mode, rows, A, world, kl_target):
+    """smx_ppo_epoch_losses_dp_f32 + smx_ppo_epoch_combine_f32 (one collective per epoch on several
+    ranks) against the finalize path: with G_surr / G_kl the two right-hand sides pushed through a
+    LINEAR map, combine(G_surr, G_kl) must equal that map applied to finalize's dz3."""
+    from cpu_kernels import TorchCpuKernels
+    C = TorchCpuKernels()
+    g = torch.Generator().manual_seed(rows * 3 + A)
+    n_total = rows * world
+    log_var = torch.full((A,), -1.0) + 0.1 * torch.randn(A, generator=g)
+    mean = torch.tanh(0.1 * torch.randn(rows, A, generator=g))
+    std = torch.exp(log_var)
+    actions = mean + std * torch.randn(rows, A, generator=g)
+    behave = torch.cat([mean + 0.05 * torch.randn(rows, A, generator=g), (std * 1.1).expand(rows, A)], 1).contiguous()
+    ref = torch.cat([mean + 0.2 * torch.randn(rows, A, generator=g), (std * 0.9).expand(rows, A)], 1).contiguous()
+    adv = torch.randn(rows, generator=g)
+    vals, rets = torch.randn(rows, generator=g) * 2, torch.randn(rows, generator=g) * 5
+    n_mlp, n_c = 4100, 9000
+    proj = torch.randn(rows * A, n_mlp, generator=g) / 30.0          # the "backward pass": linear in dz3
+    grads_c0 = torch.randn(n_c, generator=g)
+    nblk, nbv, stride = K.loss_blocks(rows), K.value_loss_blocks(rows), 8 + 2 * A
+    ldT = rows + 16
+
+    def ctrl_():
+        c = torch.zeros(L.CTRL_WORDS)
+        c[L.C_BETA], c[L.C_ETA], c[L.C_CLIP_EPS], c[L.C_KL_TARGET] = 1.0, 250.0, 0.2, kl_target
+        return c
+    outs = {}
+    for name, KK, dev in (('hip', K, 'cuda'), ('cpu', C, 'cpu')):
+        t = lambda x: x.to(dev)  # noqa: E731
+        f = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+        ctrl = t(ctrl_())
+        gs, gk, part = f(rows, A), f(rows, A), f(nblk + 2, stride)       # 2 rows no rank fills
+        gst, gkt = f(A, ldT)[:, :rows], f(A, ldT)[:, :rows]
+        vdz, vpart = f(rows), f(nbv, 8)
+        KK.epoch_losses_dp(mode, t(mean), t(log_var), t(actions), t(behave), t(ref), t(adv), ctrl, gs, gk,
+                           part, n_total, g_surr_t=gst, g_kl_t=gkt, values=t(vals), returns=t(rets),
+                           v_dz3=vdz, v_partials=vpart)
+        if name == 'hip':
+            assert torch.equal(gst.cpu(), gs.cpu().t()) and torch.equal(gkt.cpu(), gk.cpu().t())
+        # "all-reduce" over `world` identical ranks
+        G_s, G_k = (gs.cpu().reshape(-1) @ proj) * world, (gk.cpu().reshape(-1) @ proj) * world
+        part_ar = (part * world).contiguous()
+        n_a = n_mlp + A + 3
+        ga = t(torch.cat([G_s, torch.full((A,), 7.0), torch.zeros(3)]))
+        gkl = t(G_k.clone()) if mode == L.SMX_PPO_ADAPT else None
+        gc = t(grads_c0)
+        sq_a, sq_c, st = f(KK.sumsq_blocks(n_a)), f(KK.sumsq_blocks(n_c)), f(L.PS_STRIDE)
+        KK.epoch_combine(mode, part_ar, nblk + 2, n_total, t(log_var), ctrl, True, True, st, ga, gkl, n_mlp,
+                         sq_a, gc, sq_c)
+        if dev == 'cuda':
+            torch.cuda.synchronize()
+        outs[name] = dict(gs=gs.cpu(), gk=gk.cpu(), part=part.cpu(), vdz=vdz.cpu(), vpart=vpart.cpu(),
+                          ga=ga.cpu(), st=st.cpu(), sq_a=float(sq_a.sum()), sq_c=float(sq_c.sum()),
+                          ci=ctrl.view(torch.int32).cpu().clone())
+    h, c = outs['hip'], outs['cpu']
+    for k in ('gs', 'gk', 'part', 'vdz', 'vpart', 'ga', 'st'):
+        # sums of terms that cancel: the absolute tolerance scales with the largest entry
+        scale = max(1.0, float(c[k].abs().max()))
+        np.testing.assert_allclose(h[k].numpy(), c[k].numpy(), rtol=2e-5, atol=2e-6 * scale, err_msg=k)
+    assert torch.equal(h['ci'], c['ci']) and int(h['ci'][L.C_STEP_CRITIC]) == 1
+    np.testing.assert_allclose(h['sq_c'], c['sq_c'], rtol=1e-5)
+    stopped = int(h['ci'][L.C_STOP]) != 0
+    assert stopped == (kl_target < 1.0)
+    if stopped:          # the early exit: statistics are reported, no gradient is formed
+        return
+    np.testing.assert_allclose(h['sq_a'], c['sq_a'], rtol=1e-5)
+    # and the finalize path pushed through the same linear map gives the same gradient
+    f = lambda *s: torch.zeros(*s, device='cuda')  # noqa: E731
+    ctrl = ctrl_().cuda()
+    gs, gk, part, dz3, dlv, dq, st = f(rows, A), f(rows, A), f(nblk, stride), f(rows, A), f(A), f(1), f(L.PS_STRIDE)
+    K.policy_loss(mode, mean.cuda(), log_var.cuda(), actions.cuda(), behave.cuda(), ref.cuda(), adv.cuda(), ctrl,
+                  gs, gk, part)
+    part_ar = (part * world).contiguous()
+    K.policy_finalize(mode, part_ar, nblk, gs, gk, log_var.cuda(), n_total, ctrl, True, True, dz3, dlv, dq, st)
+    torch.cuda.synchronize()
+    want = (dz3.cpu().reshape(-1).double() @ proj.double()) * world
+    np.testing.assert_allclose(h['ga'][:n_mlp].numpy(), want.numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(h['ga'][n_mlp:n_mlp + A].numpy(), dlv.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(h['ga'][n_mlp + A:], torch.zeros(3))
+    np.testing.assert_allclose(h['st'].numpy(), st.cpu().numpy(), rtol=1e-5, atol=1e-7)
