@@ -72,6 +72,12 @@ int smx_zfilter_stats_f32(const float* running_sum, const float* running_sumsq,
 int smx_zfilter_forward_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
                             const float* mean, const float* std, float* out,
                             smx_stream_t stream);
+/* the two calls above in one launch, straight from the running sums: what an acting agent
+ * needs for its one observation per step (PPOAgent.act -> forward_actor -> ZFilter.forward,
+ * ppo_agent.py:106-154, z_filter.py:59-79).  Bit-identical to stats + forward. */
+int smx_zfilter_forward_sums_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
+                                 const float* running_sum, const float* running_sumsq,
+                                 const float* count, float eps, float* out, smx_stream_t stream);
 /* sum += sum_rows x ; sumsq += sum_rows x*x ; count += count_rows  (z_filter.py:55-57).
  * count_rows lets a data-parallel rank add its local column sums while the caller
  * all-reduces them (pass 0 and add the global count once). */
@@ -346,6 +352,17 @@ typedef struct smx_ppo_combine {
 } smx_ppo_combine_t;
 int smx_ppo_epoch_combine_f32(const smx_ppo_combine_t* args, smx_ppo_ctrl_t* ctrl,
                               smx_stream_t stream);
+/* --- acting head (PPOAgent.act, ppo_agent.py:106-154; DiagGauss.sample/maxprob, ppo_net.py:74-91) ---
+ * pd[r] = [mean[r, :], exp(log_var) * noise_scale[r]]   (builders.py:127; ppo_agent.py:139:
+ *         action_pd[:, A:] *= exp(noise), noise_scale == NULL: 1)
+ * actions[r] = clip(eps[r] * std + mean, -1, 1)         (ppo_net.py:80-82, ppo_agent.py:147),
+ *              eps == NULL: clip(mean) -- the deterministic evaluation modes.
+ * eps is the caller's standard-normal draw (one row per actor); every ld is a row stride in
+ * floats, so pd / actions can be slots of a rollout buffer.  pd may be NULL. */
+int smx_diaggauss_sample_f32(const float* mean, int64_t ld_mean, const float* log_var,
+                             const float* noise_scale, const float* eps, int64_t ld_eps,
+                             int64_t rows, int32_t A, float* actions, int64_t ld_act, float* pd,
+                             int64_t ld_pd, smx_stream_t stream);
 /* The means PPOLearner._optimize reports once per learn, formed on the device so that the whole
  * statistics block needs one read-back: out4 = {mean(log_var) (ppo.py:572), mean_d(running_sum/
  * count), mean_d(running_sumsq/count), mean_d(sqrt(running_sumsq/count - (running_sum/count)^2))}

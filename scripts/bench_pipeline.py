@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""
+Secondary measurement (SURVEY.md 8(d) "secondary", rows a13/a16-a18 of 8(a)): the WHOLE on-device
+loop of one GPU -- n actors stepping the synthetic environment under the current policy
+(PPOAgent.act_batch + SyntheticVecEnv.step, T steps), the moving-window cut
+(exp_sender_wrapper.py:209-228), FIFO insert + pop (fifo_replay.py:6-49, device tier) and
+PPOLearner.learn -- with per-stage timings.  Prints one JSON line.
+
+    python scripts/bench_pipeline.py [--actors 1024] [--steps 128] [--iters 10] [--graph]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--actors', type=int, default=1024)
+    ap.add_argument('--steps', type=int, default=128)
+    ap.add_argument('--obs-dim', type=int, default=376)
+    ap.add_argument('--action-dim', type=int, default=17)
+    ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--graph', action='store_true', help='replay the rollout as one hipGraph')
+    ap.add_argument('--cpu-double', action='store_true', help='dry run on the CPU test double')
+    args = ap.parse_args()
+    from surreal_amd import kernels as KN
+    if args.cpu_double:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from cpu_kernels import TorchCpuKernels
+        KN.set_default_kernels(TorchCpuKernels(), 'cpu')
+    from surreal_amd.agent import PPOAgent
+    from surreal_amd.env import SyntheticVecEnv
+    from surreal_amd.learner import PPOLearner
+    from surreal_amd.replay import FIFOReplay
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    n, T, D, A = args.actors, args.steps, args.obs_dim, args.action_dim
+    lc = ppo_learner_config()
+    lc.algo.n_step, lc.algo.stride = T, T
+    lc.algo.rnn.if_rnn_policy = False
+    lc.algo.consts.kl_target = 1e9                      # no early exit: every learn does 10 + 10 epochs
+    lc.replay.batch_size, lc.replay.memory_size = n, 2 * n
+    ec, sc = ppo_env_config(D, A), ppo_session_config()
+    learner = PPOLearner(lc, ec, sc)
+    agent = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
+    agent.attach_learner(learner)
+    agent.fetch_parameter()
+    replay = FIFOReplay(lc, ec, sc)
+    venv = SyntheticVecEnv(n, D, A, episode_len=T)
+    dev = venv.device
+    sync = torch.cuda.synchronize if str(dev).startswith('cuda') else (lambda: None)
+
+    venv.start_rollout(T, info_width=2 * A)
+
+    act_buf = torch.empty(n, A, device=dev)
+
+    def rollout_body():
+        eps = torch.randn(T, n, A, device=dev)             # the whole rollout's noise in one launch
+        for t in range(T):
+            pd_slot = venv.rolls['pds'][:, t]
+            agent.act_batch(venv.state, eps=eps[t], out_actions=act_buf, out_pd=pd_slot)
+            venv.step(act_buf, pds=pd_slot)
+
+    graph = None
+
+    def rollout():
+        venv.reset()
+        venv.slot = 0
+        if graph is not None:
+            graph.replay()
+            venv.slot, venv.t = T, 0
+        else:
+            rollout_body()
+
+    def to_batch(f):
+        return {'obs': {'low_dim': {'flat_inputs': f['obs']}},
+                'obs_next': {'low_dim': {'flat_inputs': f['obs_next']}},
+                'actions': f['actions'], 'rewards': f['rewards'], 'dones': f['dones'],
+                'persistent_infos': [f['pds']], 'onetime_infos': None}
+
+    def iteration(times=None):
+        t0 = time.perf_counter()
+        rollout()
+        if times is not None:
+            sync()
+        t1 = time.perf_counter()
+        win = venv.emit_windows(T, T)
+        replay.insert_batch(win)
+        batch = replay.sample_batch(n)
+        if times is not None:
+            sync()
+        t2 = time.perf_counter()
+        learner.learn(to_batch(batch))
+        agent.fetch_parameter()
+        if times is not None:
+            sync()
+            t3 = time.perf_counter()
+            times.append((t1 - t0, t2 - t1, t3 - t2))
+
+    iteration()
+    if args.graph and not args.cpu_double:
+        import gc
+        sync()
+        venv.reset()
+        venv.slot = 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            rollout_body()                                # warm every lazily created buffer
+        torch.cuda.current_stream().wait_stream(side)
+        sync()
+        venv.reset()
+        venv.slot = 0
+        gc.collect()
+        gc.disable()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                rollout_body()
+            graph = g
+        finally:
+            gc.enable()
+    for _ in range(args.warmup):
+        iteration()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        iteration()
+    sync()
+    whole = (time.perf_counter() - t0) / args.iters
+    staged = []
+    for _ in range(args.iters):
+        iteration(staged)
+    st = [sum(x[i] for x in staged) / len(staged) for i in range(3)]
+    out = {'metric': 'env-steps/s, whole on-device loop (act + env step + windows + FIFO + learn)',
+           'value': n * T / whole, 'ms_per_iteration': whole * 1e3,
+           'config': {'actors': n, 'steps_per_rollout': T, 'obs_dim': D, 'action_dim': A,
+                      'rollout_graph': graph is not None},
+           'stage_ms_synchronised': {'rollout': st[0] * 1e3, 'windows+fifo': st[1] * 1e3, 'learn': st[2] * 1e3},
+           'rollout_env_steps_per_s': n * T / st[0]}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -84,6 +84,9 @@ _SIGS = {
     'smx_error_string': (c_char_p, [c_int32]),
     'smx_zfilter_stats_f32': (c_int32, [_P, _P, _P, c_int32, c_float, _P, _P, _P]),
     'smx_zfilter_forward_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    'smx_zfilter_forward_sums_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_float, _P, _P]),
+    'smx_diaggauss_sample_f32': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, _P,
+                                           c_int64, _P, c_int64, _P]),
     'smx_zfilter_update_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_float, _P]),
     'smx_mlp3_packed_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_pack_f32': (c_int32, [POINTER(Mlp3), _P, c_size_t, _P]),

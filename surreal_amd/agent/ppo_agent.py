@@ -9,6 +9,7 @@ for ALL actors of a GPU in one actor forward on the device: mean/std from the po
 sample ``a = mean + std * eps``, clip to [-1, 1].
 """
 import time
+import types
 
 import numpy as np
 import torch
@@ -52,6 +53,7 @@ class PPOAgent(Agent):
         self.sink = None
         self._batch_noise = None
         self._batch_cells = None
+        self._act_ws = None
         self.reset()
 
     def _zero_cells(self, n):
@@ -90,11 +92,16 @@ class PPOAgent(Agent):
         return action_choice, action_info
 
     # ---- all actors of a GPU in one forward ---------------------------------------------------
-    def act_batch(self, obs, generator=None, eps=None):
+    def act_batch(self, obs, generator=None, eps=None, out_actions=None, out_pd=None):
         """obs [n, D] on the device -> (actions [n, A], pds [n, 2A]) on the device.
-        `eps` ([n, A] standard normal) may be injected for exact-parity tests."""
+        `eps` ([n, A] standard normal) may be injected: exact-parity tests do, and a rollout driver
+        draws the whole rollout's noise in one launch.  `out_actions` / `out_pd` (row-strided views
+        allowed, e.g. a rollout buffer's slot) receive the results in place.
+        Plain-MLP policies take 5 launches per step: z-filter from the running sums, three layers,
+        the sampling head (the reference's ~15 ATen ops + a host round trip, ppo_agent.py:106-154)."""
         n = obs.shape[0]
         A = self.action_dim
+        K = self.K
         if self._batch_noise is None or self._batch_noise.shape[0] != n:
             if self.agent_mode == 'training':
                 g = torch.Generator().manual_seed(1234 + int(self.agent_id))
@@ -102,25 +109,37 @@ class PPOAgent(Agent):
             else:
                 u = torch.zeros(n, 1)
             self._batch_noise = torch.exp(u).to(self.device)
-        if self.rnn_config.if_rnn_policy:
+        if self.rnn_config.if_rnn_policy or self.model.if_pixel:
             # one LSTM step for all n actors; `batch_cells_before` is what every actor's
             # onetime_infos would hold for this step (its state BEFORE acting, :133-135)
-            if self._batch_cells is None or self._batch_cells[0].shape[1] != n:
-                self._batch_cells = self._zero_cells(n)
-            self.batch_cells_before = self._batch_cells
-            pd, self._batch_cells = self.model.forward_actor_expose_cells(
-                {'low_dim': {'flat_inputs': obs}}, self._batch_cells)
+            if self.rnn_config.if_rnn_policy:
+                if self._batch_cells is None or self._batch_cells[0].shape[1] != n:
+                    self._batch_cells = self._zero_cells(n)
+                self.batch_cells_before = self._batch_cells
+            pd_model, self._batch_cells = self.model.forward_actor_expose_cells(
+                obs if isinstance(obs, dict) else {'low_dim': {'flat_inputs': obs}}, self._batch_cells)
+            mean = pd_model[:, :A]
         else:
-            pd = self.model.forward_actor({'low_dim': {'flat_inputs': obs}})
-        pd = pd.clone()
-        pd[:, A:] *= self._batch_noise
-        if self.agent_mode in ['eval_deterministic', 'eval_deterministic_local']:
-            actions = pd[:, :A].clone()
-        else:
-            if eps is None:
-                eps = torch.randn(n, A, device=self.device, generator=generator)
-            actions = eps * pd[:, A:] + pd[:, :A]
-        actions.clamp_(-1.0, 1.0)
+            ws = self._act_ws
+            if ws is None or ws.n != n:
+                f = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)  # noqa: E731
+                net = self.model.actor
+                ws = self._act_ws = types.SimpleNamespace(n=n, xn=f(n, net.D), h1=f(n, net.H1),
+                                                          h2=f(n, net.H2), mean=f(n, A))
+            if self.use_z_filter:
+                zf = self.model.z_filter
+                K.zfilter_forward_sums(obs, zf.running_sum, zf.running_sumsq, zf.count, zf.eps, ws.xn)
+            else:
+                ws.xn.copy_(obs)
+            K.mlp3_forward(self.model.actor, ws.xn, ws.h1, ws.h2, ws.mean, L.SMX_ACT_TANH)
+            mean = ws.mean
+        deterministic = self.agent_mode in ['eval_deterministic', 'eval_deterministic_local']
+        if not deterministic and eps is None:
+            eps = torch.randn(n, A, device=self.device, generator=generator)
+        actions = out_actions if out_actions is not None else torch.empty(n, A, device=self.device)
+        pd = out_pd if out_pd is not None else torch.empty(n, 2 * A, device=self.device)
+        K.diaggauss_sample(mean, self.model.log_var.view(-1), self._batch_noise.view(-1),
+                           None if deterministic else eps, actions, pd)
         return actions, pd
 
     def module_dict(self):

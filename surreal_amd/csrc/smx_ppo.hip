@@ -555,6 +555,31 @@ __global__ __launch_bounds__(256) void final_stats_kernel(const float* __restric
     }
 }
 
+// acting head of PPOAgent.act (ppo_agent.py:106-154, ppo_net.py:74-91): pd = [mean, exp(log_var) *
+// noise_r], action = clip(eps * std + mean, -1, 1) (training) or clip(mean) (eps == NULL)
+__global__ __launch_bounds__(256) void diaggauss_sample_kernel(const float* __restrict__ mean, long ld_mean,
+                                                               const float* __restrict__ log_var,
+                                                               const float* __restrict__ noise,
+                                                               const float* __restrict__ eps, long ld_eps,
+                                                               long total, int A,
+                                                               float* __restrict__ actions, long ld_act,
+                                                               float* __restrict__ pd, long ld_pd) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / A;
+        const int a = (int)(i - r * A);
+        const float mu = mean[r * ld_mean + a];
+        float sd = expf(log_var[a]);                        // exp(log_var) * ones_like(mean)
+        if (noise) sd = sd * noise[r];                      // action_pd[:, A:] *= exp(noise)
+        float act = eps ? eps[r * ld_eps + a] * sd + mu : mu;
+        if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
+        actions[r * ld_act + a] = act;
+        if (pd) {
+            pd[r * ld_pd + a] = mu;
+            pd[r * ld_pd + A + a] = sd;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int smx_ppo_final_stats_f32(const float* log_var, int32_t A, const float* running_sum,
@@ -564,6 +589,23 @@ extern "C" int smx_ppo_final_stats_f32(const float* log_var, int32_t A, const fl
     SMX_REQUIRE(A > 0 && (running_sum == nullptr || (running_sumsq && count && D > 0)), SMX_E_SHAPE);
     hipLaunchKernelGGL(final_stats_kernel, dim3(1), dim3(256), 0, smx_s(stream), log_var, A,
                        running_sum, running_sumsq, count, D, out4);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_diaggauss_sample_f32(const float* mean, int64_t ld_mean, const float* log_var,
+                                        const float* noise_scale, const float* eps, int64_t ld_eps,
+                                        int64_t rows, int32_t A, float* actions, int64_t ld_act,
+                                        float* pd, int64_t ld_pd, smx_stream_t stream) {
+    SMX_REQUIRE(mean && log_var && actions, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && A > 0 && ld_mean >= A && ld_act >= A && (!eps || ld_eps >= A) &&
+                    (!pd || ld_pd >= 2 * A), SMX_E_SHAPE);
+    const long total = (long)rows * A;
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(diaggauss_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), mean,
+                       (long)ld_mean, log_var, noise_scale, eps, (long)ld_eps, total, A, actions,
+                       (long)ld_act, pd, (long)ld_pd);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

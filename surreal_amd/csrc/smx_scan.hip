@@ -252,6 +252,42 @@ extern "C" int smx_zfilter_forward_f32(const float* x, int64_t ldx, int64_t rows
     return SMX_OK;
 }
 
+// the same straight from the running sums (what ZFilter.forward does on every call,
+// z_filter.py:74-77): an acting agent applies the filter to one observation per step, where a
+// separate statistics launch would double the cost
+__global__ __launch_bounds__(256) void zforward_sums_kernel(const float* __restrict__ x, long ldx,
+                                                            long total, int D,
+                                                            const float* __restrict__ rs,
+                                                            const float* __restrict__ rsq,
+                                                            const float* __restrict__ cnt, float eps,
+                                                            float* __restrict__ out) {
+    const float c = cnt[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / D;
+        const int k = (int)(i - r * D);
+        const float m = rs[k] / c;
+        const float var = rsq[k] / c - m * m;
+        float sd = sqrtf(var);
+        if (sd == sd) sd = fmaxf(sd, eps);
+        out[i] = zclamp(x[r * ldx + k], m, sd);
+    }
+}
+
+extern "C" int smx_zfilter_forward_sums_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
+                                            const float* running_sum, const float* running_sumsq,
+                                            const float* count, float eps, float* out,
+                                            smx_stream_t stream) {
+    SMX_REQUIRE(x && running_sum && running_sumsq && count && out, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && D > 0 && ldx >= D, SMX_E_SHAPE);
+    const long total = (long)rows * D;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zforward_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), x,
+                       (long)ldx, total, D, running_sum, running_sumsq, count, eps, out);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
 // Column sums of x and x*x: block = 64 columns x 16 row-lanes (1024 threads); each thread walks
 // rows r = g, g+16, ... (the rows of obs[:, 0, :] are N*D floats apart: latency-bound, so depth
 // comes from 16 row-lanes x 4 independent loads in flight), then a fixed-order LDS reduction.

@@ -124,8 +124,8 @@ class SyntheticVecEnv(object):
         if r is not None and self.slot < self.T:
             self.K.synth_env_step(self.state, self.init_state, actions, self.t, self.episode_len,
                                   self.slot, r['obs'], r['actions'], r['rewards'], r['dones'])
-            if pds is not None:
-                r['pds'][:, self.slot] = pds
+            if pds is not None and pds.data_ptr() != r['pds'][:, self.slot].data_ptr():
+                r['pds'][:, self.slot] = pds         # (an agent may have written the slot in place)
             self.slot += 1
         else:
             self.K.synth_env_step(self.state, self.init_state, actions, self.t, self.episode_len, 0,

@@ -43,6 +43,21 @@ class HipKernels(object):
         L.call('smx_zfilter_forward_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D,
                L.ptr(mean), L.ptr(std), L.ptr(out), self._st())
 
+    def zfilter_forward_sums(self, x_view, rs, rsq, cnt, eps, out):
+        """stats + forward in one launch (an acting agent's one observation per step)"""
+        rows, D = x_view.shape
+        L.call('smx_zfilter_forward_sums_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D,
+               L.ptr(rs), L.ptr(rsq), L.ptr(cnt), float(eps), L.ptr(out), self._st())
+
+    def diaggauss_sample(self, mean, log_var, noise_scale, eps, actions, pd):
+        """acting head: pd = [mean, exp(log_var) * noise], actions = clip(eps * std + mean, -1, 1);
+        eps None: clip(mean).  actions / pd may be row-strided views (rollout slots)."""
+        rows, A = mean.shape
+        L.call('smx_diaggauss_sample_f32', L.ptr(mean), _row_stride(mean, A), L.ptr(log_var),
+               L.ptr(noise_scale), L.ptr(eps), 0 if eps is None else _row_stride(eps, A), rows, A,
+               L.ptr(actions), _row_stride(actions, A), L.ptr(pd),
+               0 if pd is None else _row_stride(pd, 2 * A), self._st())
+
     def zfilter_update(self, x_view, rs, rsq, cnt, count_rows):
         rows, D = x_view.shape
         L.call('smx_zfilter_update_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D, L.ptr(rs),

@@ -33,6 +33,22 @@ class TorchCpuKernels(object):
     def zfilter_forward(self, x_view, mean, std, out):
         out.copy_(torch.clamp((x_view - mean) / std, -5.0, 5.0))
 
+    def zfilter_forward_sums(self, x_view, rs, rsq, cnt, eps, out):
+        mean = rs / cnt
+        std = torch.clamp((rsq / cnt - mean.pow(2)).pow(0.5), min=eps)
+        out.copy_(torch.clamp((x_view - mean) / std, -5.0, 5.0))
+
+    def diaggauss_sample(self, mean, log_var, noise_scale, eps, actions, pd):
+        A = mean.shape[1]
+        std = torch.exp(log_var) * torch.ones_like(mean)
+        if noise_scale is not None:
+            std = std * noise_scale.view(-1, 1)
+        act = mean if eps is None else eps * std + mean
+        actions.copy_(torch.clamp(act, -1.0, 1.0))
+        if pd is not None:
+            pd[:, :A].copy_(mean)
+            pd[:, A:].copy_(std)
+
     def zfilter_update(self, x_view, rs, rsq, cnt, count_rows):
         rs += torch.sum(x_view, dim=0)
         rsq += torch.sum(x_view * x_view, dim=0)

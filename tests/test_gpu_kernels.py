@@ -709,3 +709,41 @@ def test_data_parallel_epoch_losses_and_combine(K, mode, rows, A, world, kl_targ
     np.testing.assert_allclose(h['ga'][n_mlp:n_mlp + A].numpy(), dlv.cpu().numpy(), rtol=1e-5, atol=1e-7)
     assert torch.equal(h['ga'][n_mlp + A:], torch.zeros(3))
     np.testing.assert_allclose(h['st'].numpy(), st.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_acting_kernels(K):
+    """z-filter straight from the running sums == stats + forward (bit-identical); the sampling head
+    against the ATen expression of PPOAgent.act (ppo_agent.py:137-147), incl. row-strided outputs"""
+    g = torch.Generator().manual_seed(3)
+    n, D, A = 1000, 37, 5
+    x = torch.randn(n, 3, D, generator=g).cuda()
+    rs, rsq = (torch.randn(D, generator=g) * 50).cuda(), (torch.rand(D, generator=g) * 900 + 100).cuda()
+    rsq[3] = 1e-9                                   # var < 0 -> NaN std -> NaN output, like torch
+    rsq[4] = rs[4] * rs[4] / 40.0                   # var == 0 -> std clamps to eps
+    cnt = torch.tensor([40.0]).cuda()
+    mean, std, a, b = (torch.empty(D).cuda(), torch.empty(D).cuda(), torch.empty(n, D).cuda(),
+                       torch.empty(n, D).cuda())
+    K.zfilter_stats(rs, rsq, cnt, 1e-5, mean, std)
+    K.zfilter_forward(x[:, 1], mean, std, a)
+    K.zfilter_forward_sums(x[:, 1], rs, rsq, cnt, 1e-5, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu().nan_to_num(nan=7.0), b.cpu().nan_to_num(nan=7.0))
+    assert bool(torch.isnan(b[:, 3]).all()) and not bool(torch.isnan(b[:, :3]).any())
+
+    mu = torch.tanh(torch.randn(n, 2 * A, generator=g))[:, :A].cuda()        # row stride 2A
+    log_var = (torch.randn(A, generator=g) * 0.3 - 1).cuda()
+    noise = torch.exp(torch.rand(n, generator=g) - 0.5).cuda()
+    eps = torch.randn(n, A, generator=g).cuda() * 2
+    roll = torch.zeros(n, 4, 2 * A).cuda()
+    acts = torch.zeros(n, A).cuda()
+    K.diaggauss_sample(mu, log_var, noise, eps, acts, roll[:, 2])
+    pd = torch.cat([mu, torch.exp(log_var) * torch.ones_like(mu)], 1)
+    pd[:, A:] *= noise.view(-1, 1)
+    want = torch.clamp(eps * pd[:, A:] + pd[:, :A], -1, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(roll[:, 2].cpu().numpy(), pd.cpu().numpy(), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(acts.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    assert float(roll[:, [0, 1, 3]].abs().max()) == 0.0
+    K.diaggauss_sample(mu, log_var, None, None, acts, None)                   # deterministic evaluation
+    torch.cuda.synchronize()
+    assert torch.equal(acts.cpu(), torch.clamp(mu, -1, 1).cpu())
