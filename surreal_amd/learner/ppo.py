@@ -332,6 +332,7 @@ class PPOLearner(Learner):
             ws.nblk_v = max(K.value_loss_blocks(r) for r, _ in every)
             nblk_p_all = max(K.loss_blocks(r) for r, _ in every)
         ws.dp_epoch = self.world_size > 1 and not stem
+        ws.tail_deferred = ws.dp_epoch and self.epoch_policy >= self.epoch_baseline
         if ws.dp_epoch:
             # [surrogate share of the actor gradient | critic gradient | KL share (adapt) | loss
             # partial rows]: everything an epoch exchanges, in ONE all-reduce (_enqueue_lockstep_epochs)
@@ -347,6 +348,18 @@ class PPOLearner(Learner):
                 ws.dz3k, ws.dz2k, ws.dz1k = f(rows, A), f(rows, act.H2), f(rows, act.H1)
                 ws.dz3kT, ws.dz2kT, ws.dz1kT = ft(A), ft(act.H2), ft(act.H1)
                 ws.sumsq_k = torch.zeros(K.mlp3_backward_partials(act), device=dev)
+            # what the end of a learn exchanges, packed into one all-gather (_enqueue_tail_exchange):
+            # [loss sums of the final policy pass | value-loss moments of all epochs | return
+            #  moments | z-filter column sums]
+            nz = 2 * D + 1 if self.use_z_filter else 0
+            cuts = np.cumsum([0, ws.pstride, Ev * ws.nblk_v * 8, 3, nz]).tolist()
+            ws.tail_cuts = cuts
+            ws.tail_pack = torch.zeros(cuts[-1], device=dev)
+            ws.tail_gather = f(self.world_size, cuts[-1])
+            ws.tp_ppart = ws.tail_pack[:cuts[1]].view(1, ws.pstride)
+            ws.vpart_loc_all = ws.tail_pack[cuts[1]:cuts[2]].view(Ev, ws.nblk_v, 8)
+            ws.tp_ret = ws.tail_pack[cuts[2]:cuts[3]]
+            ws.zsum = f(nz) if nz else None
         else:
             ws.grads_all = torch.zeros(n_a + n_c, device=dev)
         ws.grads_a, ws.grads_c = ws.grads_all[:n_a], ws.grads_all[n_a:]
@@ -355,14 +368,15 @@ class PPOLearner(Learner):
         # partial rows a rank does not fill stay zero (count 0: skipped by the merge)
         ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
         ws.vpart_local = torch.zeros(ws.nblk_v, 8, device=dev)
-        ws.vpart_loc_all = torch.zeros(Ev, ws.nblk_v, 8, device=dev)   # lock-step: gathered once per learn
+        if not ws.dp_epoch:
+            ws.vpart_loc_all = torch.zeros(Ev, ws.nblk_v, 8, device=dev)   # lock-step: gathered once per learn
         ws.vgather = f(self.world_size, Ev, ws.nblk_v, 8)
         ws.np_a = K.mlp3_backward_partials(act)
         ws.np_c = K.mlp3_backward_partials(cri)
         ws.sumsq_a = torch.zeros(max(ws.np_a + 1, K.sumsq_blocks(ws.grads_a.numel())), device=dev)
         ws.sumsq_c = torch.zeros(max(ws.np_c, K.sumsq_blocks(ws.grads_c.numel())), device=dev)
         if self.use_z_filter:
-            ws.zdelta = torch.zeros(2 * D + 1, device=dev)
+            ws.zdelta = ws.tail_pack[ws.tail_cuts[3]:] if ws.dp_epoch else torch.zeros(2 * D + 1, device=dev)
         self._ws = ws
         self._graphs = {}
         return ws
@@ -555,6 +569,13 @@ class PPOLearner(Learner):
                                ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e], dz3_t=ws.dz3aT,
                                values=ws.vpred if val else None, returns=ws.ret, v_dz3=ws.dz3c,
                                v_partials=ws.vpart[e] if val else None)
+            elif pol_f and ws.tail_deferred and not pol_u and not val:
+                # the final, forward-only policy pass: its loss sums travel with the end-of-learn
+                # exchange (_enqueue_tail_exchange), which also runs its finalize
+                K.policy_loss(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol,
+                              ws.adv, ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
+                torch.sum(ws.ppart, 0, keepdim=True, out=ws.tp_ppart)
+                continue
             elif pol_f:
                 K.policy_loss(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol,
                               ws.adv, ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
@@ -607,10 +628,42 @@ class PPOLearner(Learner):
                 K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                             ws.sumsq_c, np_c, ws.ctrl_f, 1, False,
                             ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
+        if ws.tail_deferred:
+            return
         if W > 1:
             self._dist.all_gather_into_tensor(ws.vgather.view(-1), ws.vpart_loc_all.view(-1))
             ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(ws.vgather.permute(1, 0, 2, 3))
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+
+    def _enqueue_tail_exchange(self, ws, obs0, actions0, behave0):
+        """end of a data-parallel lock-step learn: ONE all-gather carries the final policy pass's
+        loss sums, the value-loss moments of every epoch, the return moments and the z-filter
+        column sums (four collectives otherwise); every rank then reduces the gathered rows in rank
+        order, so the replicas stay bit-identical"""
+        K, m, W = self.K, self.model, self.world_size
+        Ep, Ev, D = self.epoch_policy, self.epoch_baseline, obs0.shape[1]
+        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
+        c = ws.tail_cuts
+        K.moments(ws.ret, ws.tp_ret)                           # _avg_return_targ (ppo.py:571)
+        if self.use_z_filter:                                  # model.z_update(obs_iter)  (ppo.py:578-579)
+            ws.zdelta.zero_()
+            K.zfilter_update(obs0, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], obs0.shape[0])
+        self._dist.all_gather_into_tensor(ws.tail_gather.view(-1), ws.tail_pack)
+        G = ws.tail_gather
+        torch.sum(G[:, :c[1]], 0, keepdim=True, out=ws.ppart_sum)
+        K.policy_finalize(mode, ws.ppart_sum, 1, ws.g_surr, ws.g_kl, m.log_var.view(-1), ws.n_total,
+                          ws.ctrl_f, Ep > 0, False, ws.dz3a,
+                          ws.grads_a[m.actor.numel:m.actor.numel + self.action_dim],
+                          ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[Ep], dz3_t=ws.dz3aT)
+        ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(G[:, c[1]:c[2]].reshape(W, Ev, ws.nblk_v, 8).permute(1, 0, 2, 3))
+        K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+        ws.mom_parts.copy_(G[:, c[2]:c[3]])
+        K.moments_merge(ws.mom_parts, ws.ret_mom)
+        if self.use_z_filter:
+            torch.sum(G[:, c[3]:], 0, out=ws.zsum)
+            m.z_filter.running_sum += ws.zsum[:D]
+            m.z_filter.running_sumsq += ws.zsum[D:2 * D]
+            m.z_filter.count += ws.zsum[2 * D:]
 
     def _enqueue_dp_epoch(self, ws, e, mode, aj, cj, actions0, behave0):
         """One lock-step epoch on several ranks with ONE collective.  The loss
@@ -708,6 +761,10 @@ class PPOLearner(Learner):
             policy_epochs()
             value_epochs()
 
+        if lockstep and ws.tail_deferred:
+            self._enqueue_tail_exchange(ws, obs0, actions0, behave0)
+            self._enqueue_final_stats(ws)
+            return
         K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
         if self.world_size > 1:
             self._dist.all_gather_into_tensor(ws.mom_parts.view(-1), ws.ret_mom.clone())
