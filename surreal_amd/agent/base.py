@@ -170,30 +170,40 @@ class Agent(object, metaclass=AutoInitializeMeta):
         return total_reward
 
     def set_env_factory(self, fn):
-        """fn() -> Env.  (The reference builds simulators through make_env, which needs
-        Gym / MuJoCo and is out of scope.)"""
+        """fn() -> Env: overrides make_env (scripted / in-process environments)"""
         self._env_factory = fn
 
     def get_env(self):
-        if self._env_factory is None:
-            raise RuntimeError('no environment factory: call set_env_factory(fn)')
-        return self._env_factory()
+        """agent/base.py:272-281: the env named by env_config.env_name, unless a factory is set"""
+        if self._env_factory is not None:
+            return self._env_factory()
+        from surreal_amd.env import make_env
+        mode = 'eval' if self.agent_mode in ('eval_deterministic', 'eval_stochastic') else None
+        return make_env(self.env_config, mode=mode)[0]
 
     def prepare_env(self, env):
         if self.agent_mode == 'training':
             return self.prepare_env_agent(env)
         return self.prepare_env_eval(env)
 
-    def prepare_env_agent(self, env):
-        limit = self.env_config.limit_episode_length
-        if limit > 0:
-            env = MaxStepWrapper(env, limit)
+    def _limit_steps(self, env):
+        limit = self.env_config.limit_episode_length      # first: it alters step()'s `done`
+        return MaxStepWrapper(env, limit) if limit > 0 else env
+
+    def prepare_env_agent(self, env):                      # agent/base.py:296-312
+        from surreal_amd.env import TrainingTensorplexMonitor
+        env = TrainingTensorplexMonitor(self._limit_steps(env), agent_id=self.agent_id,
+                                        session_config=self.session_config, separate_plots=True)
+        self.env_tensorplex = env.tensorplex
         return env
 
-    def prepare_env_eval(self, env):
-        limit = self.env_config.limit_episode_length
-        if limit > 0:
-            env = MaxStepWrapper(env, limit)
+    def prepare_env_eval(self, env):                       # agent/base.py:314-336 (no video recorder)
+        env = self._limit_steps(env)
+        if self.agent_mode not in ('eval_deterministic_local', 'eval_stochastic_local'):
+            from surreal_amd.env import EvalTensorplexMonitor
+            env = EvalTensorplexMonitor(env, eval_id=self.agent_id, fetch_parameter=self.fetch_parameter,
+                                        session_config=self.session_config)
+            self.env_tensorplex = env.tensorplex
         return env
 
     def main_agent(self):

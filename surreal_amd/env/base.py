@@ -2,8 +2,8 @@
 Environment protocol of the reference (surreal/env/base.py:36-140, surreal/env/wrapper.py:18-162):
 ``reset() -> (obs, info)``, ``step(action) -> (obs, reward, done, info)``, observations are
 ``OrderedDict[modality][key] -> np.ndarray`` (docs/env.md:48-77), subclasses override the
-underscored methods.  Simulator adapters (Gym / Robosuite / dm_control) are out of scope: they
-need MuJoCo and run on CPU.
+underscored methods.  The simulators (Gym / Robosuite / dm_control) need MuJoCo and run on CPU; their
+adapters and the observation transforms live in adapters.py, the episode monitors in monitor.py.
 """
 import collections
 from collections import deque

@@ -37,6 +37,10 @@ BASE_SESSION_CONFIG = {
     'learner': {'num_gpus': 0, 'prefetch_processes': 2, 'max_prefetch_queue': 10,
                 'max_preprocess_queue': 2},
     'agent': {'fetch_parameter_mode': 'step', 'fetch_parameter_interval': 100, 'num_gpus': 0},
+    # default_configs.py:183-192: how often (in episodes) the env monitors report, and the
+    # evaluator's throttle; the tensorplex transport itself is replaced by in-process recorders
+    'tensorplex': {'update_schedule': {'training_env': 20, 'eval_env': 20, 'eval_env_sleep': 30,
+                                       'agent': 20, 'learner': 20, 'learner_min_update_interval': 30}},
     'checkpoint': {
         'restore': False,
         'restore_folder': None,
