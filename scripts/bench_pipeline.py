@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--graph', action='store_true', help='replay the rollout as one hipGraph')
+    ap.add_argument('--copies', action='store_true', help='insert / pop through copies (no table views)')
     ap.add_argument('--cpu-double', action='store_true', help='dry run on the CPU test double')
     args = ap.parse_args()
     from surreal_amd import kernels as KN
@@ -91,9 +92,13 @@ def main():
         if times is not None:
             sync()
         t1 = time.perf_counter()
-        win = venv.emit_windows(T, T)
-        replay.insert_batch(win)
-        batch = replay.sample_batch(n)
+        slots = None if args.copies else replay.reserve_batch(n, venv.window_shapes(T))
+        if slots is not None:                  # windows are cut straight into the FIFO table
+            venv.emit_windows(T, T, out=slots)
+            replay.commit_batch(n)
+        else:
+            replay.insert_batch(venv.emit_windows(T, T))
+        batch = replay.sample_batch(n, copy=bool(args.copies))
         if times is not None:
             sync()
         t2 = time.perf_counter()

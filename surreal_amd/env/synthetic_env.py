@@ -133,7 +133,15 @@ class SyntheticVecEnv(object):
         self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
         return self.state
 
-    def emit_windows(self, n_step, stride):
+    def window_shapes(self, n_step):
+        """per-experience shape of every field emit_windows produces (for Replay.reserve_batch)"""
+        shp = {'obs': (n_step, self.D), 'obs_next': (1, self.D), 'actions': (n_step, self.A),
+               'rewards': (n_step,), 'dones': (n_step,)}
+        if self.rolls is not None and 'pds' in self.rolls:
+            shp['pds'] = (n_step, self.rolls['pds'].shape[2])
+        return shp
+
+    def emit_windows(self, n_step, stride, out=None):
         """-> dict of [n*W, n_step, .] sub-trajectories (+ obs_next [n*W, 1, D]) cut from the
         recorded rollout with the reference's moving-window rule (exp_sender_wrapper.py:209-228):
         W = floor((T - n_step) / stride) + 1 windows per actor, a partial tail is dropped"""
@@ -142,9 +150,16 @@ class SyntheticVecEnv(object):
         W = (T - n_step) // stride + 1
         r, K, n = self.rolls, self.K, self.n
         f = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)  # noqa: E731
-        out = {'obs': f(n * W, n_step, self.D), 'obs_next': f(n * W, 1, self.D),
-               'actions': f(n * W, n_step, self.A), 'rewards': f(n * W, n_step, 1),
-               'dones': f(n * W, n_step, 1)}
+        if out is not None:
+            # the caller's buffers (e.g. the replay table's next n*W rows: no copy on insert)
+            out = dict(out)
+            assert out['obs'].shape == (n * W, n_step, self.D) and all(t.is_contiguous() for t in out.values())
+            out['rewards'] = out['rewards'].view(n * W, n_step, 1)
+            out['dones'] = out['dones'].view(n * W, n_step, 1)
+        else:
+            out = {'obs': f(n * W, n_step, self.D), 'obs_next': f(n * W, 1, self.D),
+                   'actions': f(n * W, n_step, self.A), 'rewards': f(n * W, n_step, 1),
+                   'dones': f(n * W, n_step, 1)}
         K.window_emit(r['obs'], 0, n_step, stride, W, out['obs'])
         K.window_emit(r['obs'], n_step, 1, stride, W, out['obs_next'])
         K.window_emit(r['actions'], 0, n_step, stride, W, out['actions'])
@@ -153,6 +168,7 @@ class SyntheticVecEnv(object):
         out['rewards'] = out['rewards'].view(n * W, n_step)
         out['dones'] = out['dones'].view(n * W, n_step)
         if 'pds' in r:
-            out['pds'] = f(n * W, n_step, r['pds'].shape[2])
+            if 'pds' not in out:
+                out['pds'] = f(n * W, n_step, r['pds'].shape[2])
             K.window_emit(r['pds'], 0, n_step, stride, W, out['pds'])
         return out

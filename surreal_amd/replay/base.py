@@ -41,6 +41,10 @@ class DeviceTable(object):
         self.K.gather_rows(self.data, idx, out)
         return out.view((idx.numel(),) + self.shape)
 
+    def rows(self, first, n):
+        """the n consecutive rows from `first` as a VIEW of the table, in the field's shape"""
+        return self.data[first:first + n].view((n,) + self.shape)
+
 
 class Replay(object):
     def __init__(self, learner_config, env_config, session_config, index=0):

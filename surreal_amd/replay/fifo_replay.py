@@ -62,10 +62,38 @@ class FIFOReplay(Replay):
         self._count = min(cap, self._count + n)
         self.cumulative_collected_count += n
 
-    def sample_batch(self, batch_size):
-        """pops the `batch_size` oldest device-tier experiences -> {name: [batch, ...]}"""
+    def reserve_batch(self, n, shapes):
+        """Zero-copy insert, step 1: views of the next `n` table rows per field, for a producer that
+        writes experiences in place (SyntheticVecEnv.emit_windows(out=...)); None when the rows
+        would wrap around the ring or overflow it (fall back to insert_batch).
+        shapes: {name: per-experience shape}.  Follow with commit_batch(n)."""
+        cap = self.memory_size + 3
+        fields = {k: torch.empty((0,) + tuple(shp)) for k, shp in shapes.items()}
+        tables = self._ensure_tables(cap, fields)
+        tail = (self._head + self._count) % cap
+        if n > cap - self._count or tail + n > cap:
+            return None
+        return {name: tables[name].rows(tail, n) for name in shapes}
+
+    def commit_batch(self, n):
+        """zero-copy insert, step 2: the reserved rows now hold experiences"""
+        assert n <= self.memory_size + 3 - self._count
+        self._count += n
+        self.cumulative_collected_count += n
+
+    def sample_batch(self, batch_size, copy=True):
+        """pops the `batch_size` oldest device-tier experiences -> {name: [batch, ...]}.
+        copy=False returns VIEWS of the table when the popped rows are contiguous: valid until the
+        ring wraps over them, i.e. for a consumer that is enqueued before the next inserts (the
+        learner, which stages a moving batch itself)."""
         assert batch_size <= self.memory_size and batch_size <= self._count
         cap = self.memory_size + 3
+        if not copy and self._head + batch_size <= cap:
+            out = {name: tab.rows(self._head, batch_size) for name, tab in self._tables.items()}
+            self._head = (self._head + batch_size) % cap
+            self._count -= batch_size
+            self.cumulative_sampled_count += batch_size
+            return out
         idx = (self._head + torch.arange(batch_size, device=self._dev)) % cap
         out = {name: tab.gather(idx) for name, tab in self._tables.items()}
         self._head = (self._head + batch_size) % cap

@@ -378,3 +378,39 @@ def test_pixel_agent_replay_learner_loop_in_process(cpu_double):
     m = learner.model
     assert float(learner.actor_exp_avg[m.n_actor_block:].abs().sum()) > 0
     assert float(learner.critic_exp_avg[:m.n_stem].abs().sum()) > 0
+
+
+def test_fifo_zero_copy_insert_and_pop_equal_the_copy_path(cpu_double):
+    """reserve_batch / commit_batch (producer writes the table rows in place) and
+    sample_batch(copy=False) (contiguous pops come back as views) hold the same experiences, in the
+    same order, as insert_batch / sample_batch -- including the fall-back when the ring wraps"""
+    from surreal_amd.replay import FIFOReplay
+    from surreal_amd.env import SyntheticVecEnv
+    n, D, A, T = 4, 5, 2, 6
+    lc, ec, sc = configs(B=4, N=T, stride=T, D=D, A=A, memory=9)          # capacity 12
+    a, b = FIFOReplay(lc, ec, sc), FIFOReplay(lc, ec, sc)
+    venv = SyntheticVecEnv(n, D, A, episode_len=T, seeds=[1, 2, 3, 4])
+    g = torch.Generator().manual_seed(0)
+    took_view, took_copy = 0, 0
+    for it in range(7):
+        venv.reset()
+        venv.start_rollout(T, info_width=2 * A)
+        for t in range(T):
+            venv.step(torch.randn(n, A, generator=g), pds=torch.full((n, 2 * A), float(10 * it + t)))
+        ref = venv.emit_windows(T, T)
+        a.insert_batch(ref)
+        slots = b.reserve_batch(n, venv.window_shapes(T))
+        if slots is not None:
+            venv.emit_windows(T, T, out=slots)
+            b.commit_batch(n)
+            took_view += 1
+        else:
+            b.insert_batch(venv.emit_windows(T, T))
+            took_copy += 1
+        assert len(a) == len(b)
+        if it % 2 == 1 or it == 6:
+            pa, pb = a.sample_batch(4), b.sample_batch(4, copy=False)
+            assert set(pa) == set(pb)
+            for k in pa:
+                assert pa[k].shape == pb[k].shape and torch.equal(pa[k], pb[k]), k
+    assert took_view >= 3 and took_copy >= 1 and a.cumulative_collected_count == b.cumulative_collected_count
