@@ -464,11 +464,27 @@ int smx_fill_f32(float* x, int64_t n, float value, smx_stream_t stream);
 int smx_adam_step_f32(float* theta, const float* grads, float* exp_avg, float* exp_avg_sq,
                       int64_t n, double lr, int32_t step, double weight_decay,
                       double clip_value, smx_stream_t stream);
+/* The pieces that let ONE captured hipGraph be replayed for every DDPG iteration: the Adam step
+ * count and the learning rates live in device memory.
+ *   smx_ddpg_critic_loss_step_f32  = smx_ddpg_critic_loss_f32 + (*step_counter += 1): the
+ *                                    iteration's step count, read by both Adam launches after it
+ *   smx_adam_step_dev_f32          = smx_adam_step_f32 with lr / step read from the device
+ *   smx_hard_update_every_f32      target <- source when *step % interval == 0 (the hard target
+ *                                    update of ddpg.py:403-409, decided on the device) */
+int smx_ddpg_critic_loss_step_f32(const float* q, const float* q_next_target, const float* rewards,
+                                  const float* dones, float gamma_n, int64_t rows, float* y,
+                                  float* dz3, int32_t* step_counter, smx_stream_t stream);
+int smx_adam_step_dev_f32(float* theta, const float* grads, float* exp_avg, float* exp_avg_sq,
+                          int64_t n, const float* lr, const int32_t* step, double weight_decay,
+                          double clip_value, smx_stream_t stream);
+int smx_hard_update_every_f32(float* target, const float* source, int64_t n, const int32_t* step,
+                              int32_t interval, smx_stream_t stream);
 /* target = target*(1-tau) + source*tau ; tau >= 1 is hard_update (ddpg.py:410-428) */
 int smx_soft_update_f32(float* target, const float* source, float tau, int64_t n,
                         smx_stream_t stream);
-/* stats[6] = {actor_loss = -mean q_actor, critic_loss = mean (q-y)^2, action_norm = mean
- * ||a||_2, mean rewards, Q_target = mean y, Q_policy = mean q}   (ddpg.py:335-342) */
+/* stats[7] = {actor_loss = -mean q_actor, critic_loss = mean (q-y)^2, action_norm = mean
+ * ||a||_2, mean rewards, Q_target = mean y, Q_policy = mean q   (ddpg.py:335-342),
+ * max |a| (NaN if any action is NaN) for the |actions| <= 1 check of ddpg.py:262-263} */
 int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
                        const float* actions, int32_t ld_act, int32_t A, const float* q_actor,
                        int64_t rows, float* stats, smx_stream_t stream);

@@ -19,6 +19,29 @@ torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
 for i in range(n): st = L.learn(batches[i % 8])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print('DDPG learn (batch resident): %.3f ms/iter  %.3g samples/s  critic_loss %.4f' % (dt * 1e3, B / dt, st['critic_loss']))
+# ---- with the uniform replay in the loop: 1e6 SSAR rows resident in HBM, sample 512 + learn ----
+from surreal_amd.replay import UniformReplay
+lc.replay.memory_size = 1000000
+R = UniformReplay(lc, ddpg_env_config(D, A), ddpg_session_config())
+g = torch.Generator(device='cuda').manual_seed(0)
+for _ in range(10):
+    n = 100000
+    R.insert_batch({'obs': torch.randn(n, D, device='cuda', generator=g), 'obs_next': torch.randn(n, D, device='cuda', generator=g),
+                    'actions': torch.rand(n, A, device='cuda', generator=g) * 2 - 1, 'rewards': torch.randn(n, device='cuda', generator=g),
+                    'dones': (torch.rand(n, device='cuda', generator=g) < 0.01).float()})
+
+
+def sample_and_learn():
+    f = R.sample_batch(B)
+    return L.learn({'obs': {'low_dim': {'flat_inputs': f['obs']}}, 'obs_next': {'low_dim': {'flat_inputs': f['obs_next']}},
+                    'actions': f['actions'], 'rewards': f['rewards'].view(B, 1), 'dones': f['dones'].view(B, 1)})
+
+
+for i in range(20): sample_and_learn()
+torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
+for i in range(n): st = sample_and_learn()
+torch.cuda.synchronize(); ds = (time.perf_counter() - t0) / n
+print('DDPG sample(512 of 1e6) + learn: %.3f ms/iter  %.3g samples/s  (hipGraph %s)' % (ds * 1e3, B / ds, L._ws.graph is not None))
 try:
     import ddpg_oracle
     params = ddpg_oracle.make_ddpg_params(D, A, (300, 200), (400, 300), seed=3)

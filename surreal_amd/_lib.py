@@ -139,6 +139,9 @@ _SIGS = {
     'smx_adam_step_f32': (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_int32, c_double, c_double,
                                     _P]),
     'smx_soft_update_f32': (c_int32, [_P, _P, c_float, c_int64, _P]),
+    'smx_ddpg_critic_loss_step_f32': (c_int32, [_P, _P, _P, _P, c_float, c_int64, _P, _P, _P, _P]),
+    'smx_adam_step_dev_f32': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, c_double, c_double, _P]),
+    'smx_hard_update_every_f32': (c_int32, [_P, _P, c_int64, _P, c_int32, _P]),
     'smx_ddpg_stats_f32': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int64, _P, _P]),
     'smx_lstm_param_count': (c_int64, [c_int32, c_int32]),
     'smx_lstm_forward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,

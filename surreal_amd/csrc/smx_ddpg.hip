@@ -10,8 +10,9 @@ namespace {
 __global__ __launch_bounds__(256) void ddpg_critic_loss_kernel(
     const float* __restrict__ q, const float* __restrict__ q_next, const float* __restrict__ rewards,
     const float* __restrict__ dones, float gamma_n, long rows, float* __restrict__ y,
-    float* __restrict__ dz3) {
+    float* __restrict__ dz3, int* __restrict__ step_counter) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r == 0 && step_counter) *step_counter += 1;      // this iteration's Adam step (both groups)
     if (r >= rows) return;
     // y = rewards + gamma^n * Q'(s', mu'(s')) * (1 - done)        (ddpg.py:279)
     const float t = (gamma_n * q_next[r]) * (1.0f - dones[r]);
@@ -53,6 +54,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta,
     v[i] = vi;
 }
 
+// the same step with the learning rate and the step count read from device memory, so that a
+// captured hipGraph of the whole iteration can be replayed while they change
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ theta,
+                                                       const float* __restrict__ grads,
+                                                       float* __restrict__ m, float* __restrict__ v, long n,
+                                                       const float* __restrict__ lr_ptr,
+                                                       const int* __restrict__ step_ptr, float wd,
+                                                       float clip_value) {
+    __shared__ float coef[2];
+    if (threadIdx.x == 0) {
+        const double beta1 = 0.9, beta2 = 0.999;
+        const double step = (double)*step_ptr;
+        const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+        coef[0] = (float)(-((double)*lr_ptr / bc1));
+        coef[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float neg_step_size = coef[0], bc2_sqrt = coef[1];
+    const float w1 = (float)(1.0 - 0.9), b2f = (float)0.999, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
+    float g = grads[i];
+    if (clip_value > 0.f) g = fminf(fmaxf(g, -clip_value), clip_value);   // clip_grad_value_
+    const float p = theta[i];
+    if (wd != 0.f) g = g + wd * p;
+    float mi = m[i], vi = v[i];
+    mi = mi + w1 * (g - mi);
+    vi = vi * b2f + w2 * (g * g);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    theta[i] = p + (neg_step_size * mi) / denom;
+    m[i] = mi;
+    v[i] = vi;
+}
+
+// hard target update every `interval` iterations (ddpg.py:403-409), decided on the device
+__global__ __launch_bounds__(256) void hard_update_dev_kernel(float* __restrict__ tgt,
+                                                              const float* __restrict__ src, long n,
+                                                              const int* __restrict__ step_ptr,
+                                                              int interval) {
+    if (*step_ptr % interval != 0) return;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tgt[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ tgt,
                                                           const float* __restrict__ src, float tau,
                                                           long n) {
@@ -70,12 +115,14 @@ __global__ __launch_bounds__(1024) void ddpg_stats_kernel(
     __shared__ double red[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc[6] = {0, 0, 0, 0, 0, 0};
+    float amax = 0.f;
     for (long r = threadIdx.x; r < rows; r += 1024) {
         const float d = q[r] - y[r];
         float nn = 0.f;
         for (int j = 0; j < A; ++j) {
             const float a = actions[r * ld_act + j];
             nn += a * a;
+            amax = (a == a) ? fmaxf(amax, fabsf(a)) : a;      // a NaN action must fail the check
         }
         acc[0] += (double)(-q_actor[r]);
         acc[1] += (double)(d * d);
@@ -95,6 +142,15 @@ __global__ __launch_bounds__(1024) void ddpg_stats_kernel(
             stats[k] = (float)(t / (double)rows);
         }
     }
+    // stats[6] = max |action| (the reference asserts |a| <= 1 with two host syncs, ddpg.py:262-263)
+    __shared__ float mx[1024];
+    mx[threadIdx.x] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 1024; ++i) t = (mx[i] == mx[i] && t == t) ? fmaxf(t, mx[i]) : NAN;
+        stats[6] = t;
+    }
 }
 
 inline unsigned nb(long n) { return (unsigned)((n + 255) / 256); }
@@ -107,7 +163,19 @@ extern "C" int smx_ddpg_critic_loss_f32(const float* q, const float* q_next_targ
     SMX_REQUIRE(q && q_next_target && rewards && dones && y && dz3, SMX_E_NULL);
     SMX_REQUIRE(rows > 0, SMX_E_SHAPE);
     hipLaunchKernelGGL(ddpg_critic_loss_kernel, dim3(nb(rows)), dim3(256), 0, smx_s(stream), q,
-                       q_next_target, rewards, dones, gamma_n, (long)rows, y, dz3);
+                       q_next_target, rewards, dones, gamma_n, (long)rows, y, dz3, (int*)nullptr);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ddpg_critic_loss_step_f32(const float* q, const float* q_next_target,
+                                             const float* rewards, const float* dones, float gamma_n,
+                                             int64_t rows, float* y, float* dz3, int32_t* step_counter,
+                                             smx_stream_t stream) {
+    SMX_REQUIRE(q && q_next_target && rewards && dones && y && dz3 && step_counter, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(ddpg_critic_loss_kernel, dim3(nb(rows)), dim3(256), 0, smx_s(stream), q,
+                       q_next_target, rewards, dones, gamma_n, (long)rows, y, dz3, step_counter);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -140,6 +208,28 @@ extern "C" int smx_adam_step_f32(float* theta, const float* grads, float* exp_av
     hipLaunchKernelGGL(adam_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), theta, grads, exp_avg,
                        exp_avg_sq, (long)n, (float)(-(lr / bc1)), (float)sqrt(bc2), (float)(1.0 - beta1),
                        (float)beta2, (float)(1.0 - beta2), 1e-8f, (float)weight_decay, (float)clip_value);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_adam_step_dev_f32(float* theta, const float* grads, float* exp_avg,
+                                     float* exp_avg_sq, int64_t n, const float* lr,
+                                     const int32_t* step, double weight_decay, double clip_value,
+                                     smx_stream_t stream) {
+    SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq && lr && step, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), theta, grads, exp_avg,
+                       exp_avg_sq, (long)n, lr, step, (float)weight_decay, (float)clip_value);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_hard_update_every_f32(float* target, const float* source, int64_t n,
+                                         const int32_t* step, int32_t interval, smx_stream_t stream) {
+    SMX_REQUIRE(target && source && step, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && interval > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(hard_update_dev_kernel, dim3(nb(n)), dim3(256), 0, smx_s(stream), target, source,
+                       (long)n, step, interval);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -331,6 +331,20 @@ class HipKernels(object):
         L.call('smx_soft_update_f32', L.ptr(target), L.ptr(source), float(tau), target.numel(),
                self._st())
 
+    def ddpg_critic_loss_step(self, q, q_next, rewards, dones, gamma_n, y, dz3, step):
+        """ddpg_critic_loss + (step[0] += 1): the iteration's Adam step count, on the device"""
+        L.call('smx_ddpg_critic_loss_step_f32', L.ptr(q), L.ptr(q_next), L.ptr(rewards), L.ptr(dones),
+               float(gamma_n), q.numel(), L.ptr(y), L.ptr(dz3), L.ptr(step), self._st())
+
+    def adam_step_dev(self, theta, grads, m, v, lr, step, weight_decay=0.0, clip_value=0.0):
+        """adam_step with lr ([1] float tensor) and step ([1] int32 tensor) read on the device"""
+        L.call('smx_adam_step_dev_f32', L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(),
+               L.ptr(lr), L.ptr(step), float(weight_decay), float(clip_value), self._st())
+
+    def hard_update_every(self, target, source, step, interval):
+        L.call('smx_hard_update_every_f32', L.ptr(target), L.ptr(source), target.numel(), L.ptr(step),
+               int(interval), self._st())
+
     def ddpg_stats(self, q, y, rewards, actions, q_actor, stats):
         rows, A = actions.shape
         L.call('smx_ddpg_stats_f32', L.ptr(q), L.ptr(y), L.ptr(rewards), L.ptr(actions),

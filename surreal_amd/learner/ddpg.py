@@ -14,6 +14,7 @@ the action.
 Scope: low-dimensional observations, single critic, no TD3 action regularisation, no
 LayerNorm (the reference defaults, ddpg_configs.py:16-98); the other switches raise.
 """
+import gc
 import types
 
 import numpy as np
@@ -45,6 +46,7 @@ class DDPGLearner(Learner):
             raise NotImplementedError('TD3 options (double critic / action regularisation) are '
                                       'not built yet')
         self._target_update_init()
+        self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu'
         self.clip_actor_gradient = net.clip_actor_gradient
         self.actor_gradient_clip_value = net.actor_gradient_value_clip if self.clip_actor_gradient else 0.0
         self.clip_critic_gradient = net.clip_critic_gradient
@@ -81,17 +83,6 @@ class DDPGLearner(Learner):
         else:
             raise ConfigError('Unsupported ddpg update type: {}'.format(cfg.type))
 
-    def _target_update(self):
-        K, m, t = self.K, self.model, self.model_target
-        if self.target_update_type == 'soft':
-            K.soft_update(t.actor_flat, m.actor_flat, self.target_update_tau)
-            K.soft_update(t.critic_flat, m.critic_flat, self.target_update_tau)
-        else:
-            self.target_update_counter += 1
-            if self.target_update_counter % self.target_update_interval == 0:
-                K.soft_update(t.actor_flat, m.actor_flat, 1.0)
-                K.soft_update(t.critic_flat, m.critic_flat, 1.0)
-
     # ---- batch (ddpg.py:186-242) ---------------------------------------------------------------
     def _to_dev(self, x):
         if torch.is_tensor(x):
@@ -127,6 +118,17 @@ class DDPGLearner(Learner):
             ws.gc[name] = ws.grads_c[o:o + v.numel()].view(v.shape)
             o += v.numel()
         ws.stats = torch.zeros(8, device=self.device)
+        # the Adam step count and the learning rates live on the device: one captured hipGraph of
+        # the iteration is replayed while they change (smx_adam_step_dev_f32)
+        ws.step = torch.full((1,), self.critic_step, dtype=torch.int32, device=self.device)
+        ws.dev_step = self.critic_step
+        ws.lr = torch.tensor([self.lr_actor, self.lr_critic], dtype=torch.float32, device=self.device)
+        ws.lr_host = (self.lr_actor, self.lr_critic)
+        ws.q_policy = f(B)
+        # the batch is staged into fixed buffers (5 small copies) so that the graph's pointers hold
+        A = self.action_dim
+        ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done = f(B, D), f(B, D), f(B, A), f(B), f(B)
+        ws.graph = None
         self._ws = ws
         return ws
 
@@ -147,29 +149,21 @@ class DDPGLearner(Learner):
         K.linear_wgrad(ws.dz2, ws.xcat, ws.gc['W2'], ws.gc['b2'], c2, c1 + A, B)
         K.linear_wgrad(dz3, ws.h2c, ws.gc['W3'], ws.gc['b3'], 1, c2, B, ldz=1)
 
-    def _optimize(self, obs, actions, rewards, obs_next, done):       # ddpg.py:244-352
+    def _enqueue_iteration(self, ws, x, xn, actions, rewards, done):
+        """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
         K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
-        x = obs['low_dim']['flat_inputs'].contiguous()
-        xn = obs_next['low_dim']['flat_inputs'].contiguous()
-        actions = actions.contiguous()
-        rewards, done = rewards.contiguous().view(-1), done.contiguous().view(-1)
-        B, D = x.shape
-        ws = self._workspace(B, D)
-        # the reference asserts |actions| <= 1 with two .item() syncs (ddpg.py:262-263): checked
-        # lazily together with the statistics read-back instead
+        B = x.shape[0]
         # ---- target: y = r + gamma^n * Q'(s', mu'(s')) * (1 - done) ----
         K.mlp3_forward(mt.actor, xn, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
         mt.critic_forward_into(xn, ws.act, ws.xcat, ws.h2c, ws.q_next)
         # ---- critic update ----
         m.critic_forward_into(x, actions, ws.xcat, ws.h2c, ws.q)
-        K.ddpg_critic_loss(ws.q, ws.q_next, rewards, done, pow(self.discount_factor, self.n_step),
-                           ws.y, ws.dz3)
+        K.ddpg_critic_loss_step(ws.q, ws.q_next, rewards, done, pow(self.discount_factor, self.n_step),
+                                ws.y, ws.dz3, ws.step)
         self._critic_backward(ws, x, B)
-        self.critic_step += 1
-        K.adam_step(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
-                    self.lr_critic, self.critic_step, self.critic_regularization,
-                    self.critic_gradient_clip_value)
-        q_policy = ws.q.clone()
+        K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                        ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+        ws.q_policy.copy_(ws.q)
         # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)) ----
         K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
         m.critic_forward_into(x, ws.act, ws.xcat, ws.h2c, ws.q_actor)
@@ -179,18 +173,59 @@ class DDPGLearner(Learner):
                  ldb=c2)
         K.linear(ws.dz2, 1, c['W2'][:, c1:], 0, None, ws.dxcat[:, c1:], B, A, c2, ldb=c1 + A,
                  ldc=c1 + A)
-        da = ws.dxcat[:, c1:]
-        ws.dz3a.copy_(da)                      # dense [B, A]
+        ws.dz3a.copy_(ws.dxcat[:, c1:])        # dense [B, A]
         K.tanh_backward(ws.dz3a, ws.act, ws.dz3a)
         K.mlp3_backward(m.actor, x, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a, ws.grads_a, None)
+        K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                        ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
+        K.ddpg_stats(ws.q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
+        # ---- target networks (ddpg.py:389-428) ----
+        if self.target_update_type == 'soft':
+            K.soft_update(mt.actor_flat, m.actor_flat, self.target_update_tau)
+            K.soft_update(mt.critic_flat, m.critic_flat, self.target_update_tau)
+        else:
+            K.hard_update_every(mt.actor_flat, m.actor_flat, ws.step, self.target_update_interval)
+            K.hard_update_every(mt.critic_flat, m.critic_flat, ws.step, self.target_update_interval)
+
+    def _optimize(self, obs, actions, rewards, obs_next, done):       # ddpg.py:244-352
+        x = obs['low_dim']['flat_inputs']
+        xn = obs_next['low_dim']['flat_inputs']
+        B, D = x.shape
+        ws = self._workspace(B, D)
+        if ws.dev_step != self.critic_step:          # restored from a checkpoint
+            ws.step.fill_(self.critic_step)
+        if ws.lr_host != (self.lr_actor, self.lr_critic):
+            ws.lr_host = (self.lr_actor, self.lr_critic)
+            ws.lr.copy_(torch.tensor(ws.lr_host, dtype=torch.float32))
+        ws.s_obs.copy_(x)
+        ws.s_next.copy_(xn)
+        ws.s_act.copy_(actions.reshape(B, -1))
+        ws.s_rew.copy_(rewards.reshape(-1))
+        ws.s_done.copy_(done.reshape(-1))
+        if self.use_graph and ws.graph is None:
+            # capture after one eager iteration (lazy allocations, module load); its effects are
+            # real: the capture itself executes nothing
+            self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
+            gc.collect()
+            gc.disable()               # a collection inside capture may free device memory: illegal
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
+                ws.graph = g
+            finally:
+                gc.enable()
+        elif ws.graph is not None:
+            ws.graph.replay()
+        else:
+            self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
+        self.critic_step += 1
         self.actor_step += 1
-        K.adam_step(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
-                    self.lr_actor, self.actor_step, self.actor_regularization,
-                    self.actor_gradient_clip_value)
-        K.ddpg_stats(q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
-        self._target_update()
-        st = ws.stats.cpu().numpy()
-        amax = float(actions.abs().max())
+        ws.dev_step = self.critic_step
+        if self.target_update_type == 'hard':
+            self.target_update_counter += 1
+        st = ws.stats.cpu().numpy()                  # the iteration's one read-back
+        amax = float(st[6])
         assert amax <= 1.0, 'actions must lie in [-1, 1] (ddpg.py:262-263), got |a| = %g' % amax
         return {'actor_loss': float(st[0]), 'critic_loss': float(st[1]), 'action_norm': float(st[2]),
                 'rewards': float(st[3]), 'Q_target': float(st[4]), 'Q_policy': float(st[5])}

@@ -596,7 +596,19 @@ class TorchCpuKernels(object):
         else:
             target.copy_(target * (1.0 - tau) + source * tau)
 
+    def ddpg_critic_loss_step(self, q, q_next, rewards, dones, gamma_n, y, dz3, step):
+        self.ddpg_critic_loss(q, q_next, rewards, dones, gamma_n, y, dz3)
+        step += 1
+
+    def adam_step_dev(self, theta, grads, m, v, lr, step, weight_decay=0.0, clip_value=0.0):
+        self.adam_step(theta, grads, m, v, float(lr[0]), int(step[0]), weight_decay, clip_value)
+
+    def hard_update_every(self, target, source, step, interval):
+        if int(step[0]) % interval == 0:
+            target.copy_(source)
+
     def ddpg_stats(self, q, y, rewards, actions, q_actor, stats):
         stats[:6].copy_(_f([float(-q_actor.double().mean()), float(((q - y).double() ** 2).mean()),
                         float(actions.norm(2, 1).double().mean()), float(rewards.double().mean()),
                         float(y.double().mean()), float(q.double().mean())]))
+        stats[6] = float('nan') if bool(torch.isnan(actions).any()) else actions.abs().max()
