@@ -446,6 +446,34 @@ int smx_synth_env_step_f32(float* state, const float* init_state, const float* a
                            int32_t slot, int32_t T, float* obs_roll, float* act_roll,
                            float* rew_roll, float* done_roll, smx_stream_t stream);
 
+/* One launch between two policy forwards of a device-resident rollout: the acting head
+ * (smx_diaggauss_sample_f32 on `mean`), the environment step above with the sampled action, and the
+ * z-filter of the NEXT observation (smx_zfilter_forward_sums_f32) into xn_out -- what the next
+ * policy forward reads.  pd_roll [n, T, 2A] receives the action_infos distribution; eps == NULL:
+ * deterministic; zsum == NULL: xn_out = the raw next observation; rolls may be NULL. */
+typedef struct smx_synth_act_step {
+    float* state;
+    const float* init_state;
+    const float* mean;
+    const float* log_var;
+    const float* noise_scale;
+    const float* eps;
+    int64_t ld_mean, ld_eps;
+    int32_t n, D, A, t, episode_len, slot, T, reserved;
+    float* obs_roll;
+    float* act_roll;
+    float* rew_roll;
+    float* done_roll;
+    float* pd_roll;
+    const float* zsum;
+    const float* zsumsq;
+    const float* zcount;
+    float zeps, reserved_f;
+    float* xn_out;
+} smx_synth_act_step_t;
+int smx_synth_act_env_step_f32(const smx_synth_act_step_t* args, smx_stream_t stream);
+
+
 /* --- DDPG update pieces (surreal/learner/ddpg.py:244-352, 403-428) --------------------
  * Dense layers reuse smx_linear_f32 / smx_mlp3_*; the critic's "concat action into layer 2"
  * (builders.py:58-84) is expressed with row strides: layer 1 writes into the first c1 columns

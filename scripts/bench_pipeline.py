@@ -29,6 +29,8 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--graph', action='store_true', help='replay the rollout as one hipGraph')
+    ap.add_argument('--fused-step', action='store_true',
+                    help='sample + env step + next z-filter in one launch (SyntheticVecEnv.rollout)')
     ap.add_argument('--copies', action='store_true', help='insert / pop through copies (no table views)')
     ap.add_argument('--cpu-double', action='store_true', help='dry run on the CPU test double')
     args = ap.parse_args()
@@ -63,6 +65,9 @@ def main():
     act_buf = torch.empty(n, A, device=dev)
 
     def rollout_body():
+        if args.fused_step:                                # 4 launches per env step
+            venv.rollout(agent)
+            return
         eps = torch.randn(T, n, A, device=dev)             # the whole rollout's noise in one launch
         for t in range(T):
             pd_slot = venv.rolls['pds'][:, t]
@@ -147,7 +152,7 @@ def main():
     out = {'metric': 'env-steps/s, whole on-device loop (act + env step + windows + FIFO + learn)',
            'value': n * T / whole, 'ms_per_iteration': whole * 1e3,
            'config': {'actors': n, 'steps_per_rollout': T, 'obs_dim': D, 'action_dim': A,
-                      'rollout_graph': graph is not None},
+                      'rollout_graph': graph is not None, 'fused_step': bool(args.fused_step)},
            'stage_ms_synchronised': {'rollout': st[0] * 1e3, 'windows+fifo': st[1] * 1e3, 'learn': st[2] * 1e3},
            'rollout_env_steps_per_s': n * T / st[0]}
     print(json.dumps(out), flush=True)

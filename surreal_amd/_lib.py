@@ -72,6 +72,17 @@ class PpoCombine(Structure):
                 ('reserved', c_int32)]
 
 
+class SynthActStep(Structure):
+    """smx_synth_act_step_t"""
+    _fields_ = [('state', c_void_p), ('init_state', c_void_p), ('mean', c_void_p), ('log_var', c_void_p),
+                ('noise_scale', c_void_p), ('eps', c_void_p), ('ld_mean', c_int64), ('ld_eps', c_int64),
+                ('n', c_int32), ('D', c_int32), ('A', c_int32), ('t', c_int32), ('episode_len', c_int32),
+                ('slot', c_int32), ('T', c_int32), ('reserved', c_int32),
+                ('obs_roll', c_void_p), ('act_roll', c_void_p), ('rew_roll', c_void_p),
+                ('done_roll', c_void_p), ('pd_roll', c_void_p), ('zsum', c_void_p), ('zsumsq', c_void_p),
+                ('zcount', c_void_p), ('zeps', c_float), ('reserved_f', c_float), ('xn_out', c_void_p)]
+
+
 # smx_ppo_ctrl_t as 16 x 4-byte words: index of each field (floats 0-9, int32 10-15)
 CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
@@ -131,6 +142,7 @@ _SIGS = {
     'smx_uniform_indices': (c_int32, [_P, c_int64, c_int64, c_uint64, c_uint64, _P]),
     'smx_window_emit_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, _P, _P]),
+    'smx_synth_act_env_step_f32': (c_int32, [POINTER(SynthActStep), _P]),
     'smx_synth_env_step_f32': (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_int32, c_int32, _P, _P, _P, _P, _P]),
     'smx_ddpg_critic_loss_f32': (c_int32, [_P, _P, _P, _P, c_float, c_int64, _P, _P, _P]),

@@ -142,6 +142,28 @@ class PPOAgent(Agent):
                            None if deterministic else eps, actions, pd)
         return actions, pd
 
+    def policy_mean(self, xn, out=None):
+        """the policy's mean for observations that are ALREADY z-filtered (plain-MLP policies): the
+        three layer launches alone.  A device-resident rollout filters the next observation and
+        samples in the environment-step launch (SyntheticVecEnv.rollout)."""
+        if self.rnn_config.if_rnn_policy or self.model.if_pixel:
+            raise NotImplementedError('policy_mean: plain MLP policies only; use act_batch')
+        n = xn.shape[0]
+        ws = self._act_ws
+        if ws is None or ws.n != n:
+            self.act_batch(xn, eps=torch.zeros(n, self.action_dim, device=self.device))   # builds the workspace
+            ws = self._act_ws
+        out = ws.mean if out is None else out
+        self.K.mlp3_forward(self.model.actor, xn, ws.h1, ws.h2, out, L.SMX_ACT_TANH)
+        return out
+
+    def batch_noise(self, n):
+        """per-actor exploration scale exp(noise_i) [n, 1] (ppo_agent.py:57-61, 139)"""
+        if self._batch_noise is None or self._batch_noise.shape[0] != n:
+            self.act_batch(torch.zeros(n, self.model.actor.D, device=self.device),
+                           eps=torch.zeros(n, self.action_dim, device=self.device))
+        return self._batch_noise
+
     def module_dict(self):
         return {'ppo': self.model}
 

@@ -8,6 +8,12 @@
 
 namespace {
 
+__device__ __forceinline__ float zclamp(float x, float m, float s) {
+    float v = (x - m) / s;   // z_filter.py:77
+    if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);
+    return v;
+}
+
 // copy `n` rows of `width` floats: dst row i <- src row map(i).  A wavefront moves one SEGMENT of
 // one row (ROW_SEG floats): a learner batch has few, very wide rows (1024 sub-trajectories of
 // 192 KB) and one wave per row left 3/4 of the CUs idle with a single load in flight per lane
@@ -150,6 +156,69 @@ __global__ __launch_bounds__(256) void synth_env_step_kernel(
     state[i] = done ? init_state[i] : sn;
 }
 
+// The acting head, the environment step and the next observation's z-filter in one launch -- the
+// glue between two policy forwards of a device-resident rollout (sampling head as
+// smx_diaggauss_sample_f32, dynamics as synth_env_step_kernel, filter as
+// smx_zfilter_forward_sums_f32: same expressions, same results).
+__global__ __launch_bounds__(256) void synth_act_env_step_kernel(smx_synth_act_step_t p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int D = p.D, A = p.A, T = p.T, slot = p.slot;
+    if (i >= (long)p.n * D) return;
+    const long a = i / D;
+    const int k = (int)(i - a * D);
+    const float nz = p.noise_scale ? p.noise_scale[a] : 1.0f;
+    auto action = [&](int j, float& mu, float& sd) {
+        mu = p.mean[a * p.ld_mean + j];
+        sd = expf(p.log_var[j]);
+        if (p.noise_scale) sd = sd * nz;
+        float act = p.eps ? p.eps[a * p.ld_eps + j] * sd + mu : mu;
+        if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
+        return act;
+    };
+    float mu, sd;
+    const float ac = action(k % A, mu, sd);
+    const float s = p.state[i];
+    const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+    float sn = (0.9f * s + 0.5f * ac) + drift;
+    sn = fminf(fmaxf(sn, -10.0f), 10.0f);
+    const bool done = (p.t + 1 >= p.episode_len);
+    if (p.obs_roll) {
+        p.obs_roll[(a * T + slot) * D + k] = s;
+        if (slot + 1 < T) p.obs_roll[(a * T + slot + 1) * D + k] = sn;
+    }
+    if (k < A) {                                      // here k % A == k
+        if (p.act_roll) p.act_roll[(a * T + slot) * A + k] = ac;
+        if (p.pd_roll) {
+            p.pd_roll[(a * T + slot) * 2 * A + k] = mu;
+            p.pd_roll[(a * T + slot) * 2 * A + A + k] = sd;
+        }
+    }
+    if (k == 0) {
+        double q = 0.0;
+        for (int j = 0; j < A; ++j) {
+            float m2, s2;
+            const float av = action(j, m2, s2);
+            q += (double)av * (double)av;
+        }
+        if (p.rew_roll) p.rew_roll[a * T + slot] = (float)(-0.1 * q + 0.05 * (double)sn);
+        if (p.done_roll) p.done_roll[a * T + slot] = done ? 1.0f : 0.0f;
+    }
+    const float next = done ? p.init_state[i] : sn;
+    p.state[i] = next;
+    if (p.xn_out) {
+        float z = next;
+        if (p.zsum) {
+            const float c = p.zcount[0];
+            const float m = p.zsum[k] / c;
+            const float var = p.zsumsq[k] / c - m * m;
+            float sz = sqrtf(var);
+            if (sz == sz) sz = fmaxf(sz, p.zeps);
+            z = zclamp(next, m, sz);
+        }
+        p.xn_out[i] = z;
+    }
+}
+
 inline unsigned row_blocks(long n, int width) {
     const long items = n * ((width + ROW_SEG - 1) / ROW_SEG);
     long b = (items + 3) / 4;  // 4 waves (row segments) per block
@@ -204,6 +273,20 @@ extern "C" int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, 
     const long n = (long)actors * W * n_step;
     hipLaunchKernelGGL(window_emit_kernel, dim3(row_blocks(n, width)), dim3(256), 0, smx_s(stream), src,
                        actors, T, width, start, n_step, stride, W, dst, can_vec(src, dst, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_synth_act_env_step_f32(const smx_synth_act_step_t* args, smx_stream_t stream) {
+    SMX_REQUIRE(args, SMX_E_NULL);
+    const smx_synth_act_step_t& p = *args;
+    SMX_REQUIRE(p.state && p.init_state && p.mean && p.log_var, SMX_E_NULL);
+    SMX_REQUIRE(p.n > 0 && p.D > 0 && p.A > 0 && p.A <= p.D && p.T > 0 && p.slot >= 0 && p.slot < p.T &&
+                    p.episode_len > 0 && p.ld_mean >= p.A && (!p.eps || p.ld_eps >= p.A), SMX_E_SHAPE);
+    SMX_REQUIRE(!p.zsum || (p.zsumsq && p.zcount && p.xn_out), SMX_E_NULL);
+    const long total = (long)p.n * p.D;
+    hipLaunchKernelGGL(synth_act_env_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       smx_s(stream), p);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

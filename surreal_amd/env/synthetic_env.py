@@ -133,6 +133,35 @@ class SyntheticVecEnv(object):
         self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
         return self.state
 
+    def rollout(self, agent, eps=None):
+        """A whole recorded rollout (start_rollout(T) first) under `agent`'s plain-MLP policy with
+        FOUR launches per environment step: three policy layers, then one launch that samples the
+        action, steps every actor, records the transition and z-filters the next observation.
+        Same numbers as ``for t: agent.act_batch(state) -> step(actions, pds)``.
+        eps: [T, n, A] standard-normal draws (default: drawn here in one launch; None-eps agents in
+        a deterministic mode ignore it)."""
+        T, n, K = self.T, self.n, self.K
+        assert self.slot == 0 and 'pds' in self.rolls, 'start_rollout(T, info_width=2 * A) first'
+        deterministic = agent.agent_mode in ('eval_deterministic', 'eval_deterministic_local')
+        if eps is None and not deterministic:
+            eps = torch.randn(T, n, self.A, device=self.device)
+        noise = agent.batch_noise(n).view(-1)
+        zf = agent.model.z_filter if agent.use_z_filter else None
+        if getattr(self, '_xn', None) is None:
+            self._xn = torch.empty(n, self.D, device=self.device)
+        if zf is not None:
+            K.zfilter_forward_sums(self.state, zf.running_sum, zf.running_sumsq, zf.count, zf.eps, self._xn)
+        else:
+            self._xn.copy_(self.state)
+        log_var = agent.model.log_var.view(-1)
+        for t in range(T):
+            mean = agent.policy_mean(self._xn)
+            K.synth_act_env_step(self.state, self.init_state, mean, log_var, noise,
+                                 None if deterministic else eps[t], self.t, self.episode_len, self.slot,
+                                 self.rolls, zf, self._xn)
+            self.slot += 1
+            self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
+
     def window_shapes(self, n_step):
         """per-experience shape of every field emit_windows produces (for Replay.reserve_batch)"""
         shp = {'obs': (n_step, self.D), 'obs_next': (1, self.D), 'actions': (n_step, self.A),

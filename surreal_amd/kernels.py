@@ -279,6 +279,28 @@ class HipKernels(object):
         L.call('smx_window_emit_f32', L.ptr(src), actors, T, width, start, n_step, stride, W,
                L.ptr(dst), self._st())
 
+    def synth_act_env_step(self, state, init_state, mean, log_var, noise_scale, eps, t, episode_len,
+                           slot, rolls, zfilter, xn_out):
+        """acting head + env step + next observation's z-filter, one launch (see the header);
+        rolls: dict obs / actions / rewards / dones [/ pds] or None; zfilter: ZFilter or None"""
+        n, D = state.shape
+        A = mean.shape[1]
+        p = L.SynthActStep()
+        p.state, p.init_state = L.ptr(state), L.ptr(init_state)
+        p.mean, p.ld_mean, p.log_var = L.ptr(mean), _row_stride(mean, A), L.ptr(log_var)
+        p.noise_scale, p.eps = L.ptr(noise_scale), L.ptr(eps)
+        p.ld_eps = 0 if eps is None else _row_stride(eps, A)
+        p.n, p.D, p.A, p.t, p.episode_len, p.slot = n, D, A, int(t), int(episode_len), int(slot)
+        r = rolls or {}
+        p.T = r['obs'].shape[1] if 'obs' in r else 1
+        p.obs_roll, p.act_roll = L.ptr(r.get('obs')), L.ptr(r.get('actions'))
+        p.rew_roll, p.done_roll, p.pd_roll = L.ptr(r.get('rewards')), L.ptr(r.get('dones')), L.ptr(r.get('pds'))
+        if zfilter is not None:
+            p.zsum, p.zsumsq, p.zcount = L.ptr(zfilter.running_sum), L.ptr(zfilter.running_sumsq), L.ptr(zfilter.count)
+            p.zeps = float(zfilter.eps)
+        p.xn_out = L.ptr(xn_out)
+        L.call('smx_synth_act_env_step_f32', ctypes.byref(p), self._st())
+
     def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,
                        rew_roll, done_roll):
         n, D = state.shape

@@ -452,6 +452,24 @@ class TorchCpuKernels(object):
             done_roll[:, slot] = 1.0 if done else 0.0
         state.copy_(init_state if done else sn)
 
+    def synth_act_env_step(self, state, init_state, mean, log_var, noise_scale, eps, t, episode_len,
+                           slot, rolls, zfilter, xn_out):
+        n, A = mean.shape
+        r = rolls or {}
+        acts = torch.empty(n, A)
+        pd = torch.empty(n, 2 * A)
+        self.diaggauss_sample(mean, log_var, noise_scale, eps, acts, pd)
+        if 'pds' in r:
+            r['pds'][:, slot] = pd
+        self.synth_env_step(state, init_state, acts, t, episode_len, slot, r.get('obs'), r.get('actions'),
+                            r.get('rewards'), r.get('dones'))
+        if xn_out is not None:
+            if zfilter is not None:
+                self.zfilter_forward_sums(state, zfilter.running_sum, zfilter.running_sumsq, zfilter.count,
+                                          zfilter.eps, xn_out)
+            else:
+                xn_out.copy_(state)
+
     # ---- generic dense layer + DDPG pieces ---------------------------------------------------
     def linear(self, A, a_kc, B, b_kc, bias, C, M, N, K, act=0, relu_mask=None, lda=None, ldb=None,
                ldc=None, stop=None):

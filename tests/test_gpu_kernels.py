@@ -747,3 +747,13 @@ def test_acting_kernels(K):
     K.diaggauss_sample(mu, log_var, None, None, acts, None)                   # deterministic evaluation
     torch.cuda.synchronize()
     assert torch.equal(acts.cpu(), torch.clamp(mu, -1, 1).cpu())
+
+
+def test_fused_rollout_equals_act_batch_loop_on_hip(K):
+    """smx_synth_act_env_step_f32 == smx_diaggauss_sample_f32 + smx_synth_env_step_f32 +
+    smx_zfilter_forward_sums_f32, bit for bit, over a whole recorded rollout"""
+    import test_hostpath as TH
+    fused, loop = TH._rollout_pair()
+    for k in fused:
+        assert torch.equal(fused[k], loop[k]), k
+    assert float(fused['pds'].abs().sum()) > 0

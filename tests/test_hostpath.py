@@ -414,3 +414,42 @@ def test_fifo_zero_copy_insert_and_pop_equal_the_copy_path(cpu_double):
             for k in pa:
                 assert pa[k].shape == pb[k].shape and torch.equal(pa[k], pb[k]), k
     assert took_view >= 3 and took_copy >= 1 and a.cumulative_collected_count == b.cumulative_collected_count
+
+
+def _rollout_pair(K_name=None):
+    """(fused rollout, act_batch + step loop) on the same agent / env / noise"""
+    from surreal_amd.agent import PPOAgent
+    from surreal_amd.env import SyntheticVecEnv
+    n, D, A, T = 6, 7, 3, 5
+    lc, ec, sc = configs(B=n, N=T, stride=T, D=D, A=A)
+    agent = PPOAgent(lc, ec, sc, agent_id=2, agent_mode='training')
+    dev = agent.device
+    zf = agent.model.z_filter
+    mean, var = torch.linspace(-3, 3, D), torch.linspace(0.5, 2, D)
+    zf.running_sum.copy_(mean * 40)
+    zf.running_sumsq.copy_((mean * mean + var) * 40)
+    zf.count.fill_(40.0)
+    eps = torch.randn(T, n, A, generator=torch.Generator().manual_seed(4)).to(dev)
+    outs = []
+    for fused in (True, False):
+        venv = SyntheticVecEnv(n, D, A, episode_len=T, seeds=list(range(n)))
+        venv.start_rollout(T, info_width=2 * A)
+        if fused:
+            venv.rollout(agent, eps=eps)
+        else:
+            for t in range(T):
+                a, pd = agent.act_batch(venv.state, eps=eps[t])
+                venv.step(a, pds=pd)
+        assert venv.slot == T and venv.t == 0
+        outs.append({k: v.cpu().clone() for k, v in venv.emit_windows(T, T).items()})
+        outs[-1]['state'] = venv.state.cpu().clone()
+    return outs
+
+
+def test_fused_rollout_equals_act_batch_loop(cpu_double):
+    """SyntheticVecEnv.rollout (4 launches per step) records exactly what the per-step loop records"""
+    fused, loop = _rollout_pair()
+    assert set(fused) == set(loop)
+    for k in fused:
+        assert torch.equal(fused[k], loop[k]), k
+    assert float(fused['pds'].abs().sum()) > 0 and float(fused['dones'][:, -1].min()) == 1.0
