@@ -40,6 +40,51 @@ struct GemmBatch {
     int n;
 };
 
+// Workgroup -> problem descriptor, in TWO batches of scalar loads.  Left to itself the compiler
+// fetches the fields of G.p[pi] one by one where they are first used -- a dozen dependent
+// kernarg round trips (~0.2 us each) in front of the first operand load, a third of the ~6 us a
+// short dependent launch costs.  The empty asm statements "use" every field at once, so all the
+// loads are issued back to back and waited for once.
+struct TileBases {
+    int tb[MAX_PROBS];
+    int n, grid;
+};
+
+// batch 1: every problem's first tile, the problem count and the grid size (static kernarg offsets)
+__device__ __forceinline__ TileBases load_tile_bases(const GemmBatch& G) {
+    static_assert(MAX_PROBS == 9, "the asm operand list below names every entry");
+    TileBases t;
+#pragma unroll
+    for (int k = 0; k < MAX_PROBS; ++k) t.tb[k] = G.p[k].tile_base;
+    t.n = G.n;
+    t.grid = (int)gridDim.x;
+    asm volatile("" :: "s"(t.tb[0]), "s"(t.tb[1]), "s"(t.tb[2]), "s"(t.tb[3]), "s"(t.tb[4]), "s"(t.tb[5]),
+                 "s"(t.tb[6]), "s"(t.tb[7]), "s"(t.tb[8]), "s"(t.n), "s"(t.grid));
+    return t;
+}
+
+// batch 2: the whole descriptor of the problem that owns tile `bid`
+__device__ __forceinline__ GemmProb select_problem(const GemmBatch& G, const TileBases& t, int bid) {
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_PROBS; ++k) pi += (k < t.n && bid >= t.tb[k]) ? 1 : 0;   // tile_base ascends
+    GemmProb P = G.p[pi];
+    asm volatile("" :: "s"(P.A), "s"(P.B), "s"(P.bias), "s"(P.mask), "s"(P.C), "s"(P.dbias), "s"(P.sumsq),
+                 "s"(P.CT), "s"(P.stop), "s"(P.c_split), "s"(P.ldct), "s"(P.lda), "s"(P.ldb), "s"(P.ldc),
+                 "s"(P.M), "s"(P.N), "s"(P.K), "s"(P.a_kc), "s"(P.b_kc), "s"(P.act), "s"(P.tiles_m),
+                 "s"(P.tiles_n), "s"(P.tile_base), "s"(P.a_mode), "s"(P.b_mode), "s"(P.a_bytes),
+                 "s"(P.b_bytes), "s"(P.splits), "s"(P.k_chunk));      // 29 of the 30 operands an asm may have
+    return P;
+}
+
+// the early-exit flag of a problem (the KL stop of the policy epochs): the load is issued here, in
+// front of the operand loads, and consumed with stop_taken() behind the main loop -- a stopped
+// problem does its arithmetic and discards it (rare), every other launch saves a memory round trip
+__device__ __forceinline__ int stop_load(const GemmProb& P) {
+    return P.stop ? __builtin_nontemporal_load(P.stop) : 0;
+}
+__device__ __forceinline__ bool stop_taken(int v) { return __builtin_amdgcn_readfirstlane(v) != 0; }
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Operand fragment for one 8-wide k group: lane (i, kh) holds X(row0+i, k0 + 4kh + r), r = 0..3.
@@ -185,18 +230,15 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     // L2.  Give XCD x the x-th contiguous eighth of the tile list (tiles are row-major in M, so
     // that is a band of A rows and all of B) instead of every 8th tile -- otherwise all eight L2s
     // pull every operand of the launch across the fabric.
+    const TileBases TB = load_tile_bases(G);
     int bid = blockIdx.x;
     {
-        const int total = gridDim.x, q = total >> 3, r = total & 7;
+        const int total = TB.grid, q = total >> 3, r = total & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    int pi = 0;
-#pragma unroll
-    for (int k = 1; k < MAX_PROBS; ++k)
-        if (k < G.n && bid >= G.p[k].tile_base) pi = k;
-    const GemmProb& P = G.p[pi];
-    if (P.stop && *P.stop) return;
+    const GemmProb P = select_problem(G, TB, bid);
+    const int stopv = stop_load(P);
     int tile = bid - P.tile_base;
     int sp = 0;
     KRange R;
@@ -218,6 +260,29 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and provably so
     const int i = lane & 31, kh = lane >> 5;
 
+    // the epilogue's own inputs (4 outputs per thread: bias, ReLU mask) are requested HERE, in front
+    // of the operand loads, instead of behind the last barrier where their latency is exposed
+    // (named scalars: an array live across the main loop's scheduling barriers goes to scratch)
+    const int orow = tid >> 3, oc0 = (tid & 7) * 4;
+    const int m = m0 + orow;
+    float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 0.f, pm0 = 1.f, pm1 = 1.f, pm2 = 1.f, pm3 = 1.f;
+    {
+        const int nb = n0 + oc0;
+        if (P.bias) {
+            if (nb + 0 < P.N) pb0 = P.bias[nb + 0];
+            if (nb + 1 < P.N) pb1 = P.bias[nb + 1];
+            if (nb + 2 < P.N) pb2 = P.bias[nb + 2];
+            if (nb + 3 < P.N) pb3 = P.bias[nb + 3];
+        }
+        if (P.mask && m < P.M) {
+            const float* mk = P.mask + (size_t)m * P.ldc + nb;
+            if (nb + 0 < P.N) pm0 = mk[0];
+            if (nb + 1 < P.N) pm1 = mk[1];
+            if (nb + 2 < P.N) pm2 = mk[2];
+            if (nb + 3 < P.N) pm3 = mk[3];
+        }
+    }
+
     f32x16 acc;
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
@@ -236,6 +301,7 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
         default: mainloop<2, 2>(P, R, m0, n0, i, kh, wv, acc, asum); break;
     }
 
+    if (stop_taken(stopv)) return;
     // ---- combine the 4 K-partials through LDS (fixed order => deterministic) -------------
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -245,18 +311,18 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     dbr[wv * 2 + kh][i] = asum;
     __syncthreads();
 
-    const int orow = tid >> 3, oc0 = (tid & 7) * 4;
-    const int m = m0 + orow;
     float ss = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int n = n0 + oc0 + e;
         float v = ((red[0][orow * 33 + oc0 + e] + red[1][orow * 33 + oc0 + e]) +
                    red[2][orow * 33 + oc0 + e]) + red[3][orow * 33 + oc0 + e];
+        const float pb = e == 0 ? pb0 : e == 1 ? pb1 : e == 2 ? pb2 : pb3;
+        const float pm = e == 0 ? pm0 : e == 1 ? pm1 : e == 2 ? pm2 : pm3;
         if (m < P.M && n < P.N) {
-            if (P.bias) v += P.bias[n];
+            if (P.bias) v += pb;
             v = act_f(v, P.act);
-            if (P.mask) v = (P.mask[(size_t)m * P.ldc + n] > 0.f) ? v : 0.f;
+            if (P.mask) v = (pm > 0.f) ? v : 0.f;
             P.C[(size_t)sp * P.c_split + (size_t)m * P.ldc + n] = v;
             if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
             ss += v * v;
@@ -283,12 +349,9 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
 // per-workgroup fixed cost is spread over four times the work.  No bias-gradient / sum-of-squares
 // outputs (the weight gradients take the K-split kernel).
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmBatch G) {
-    int pi = 0;
-#pragma unroll
-    for (int k = 1; k < MAX_PROBS; ++k)
-        if (k < G.n && (int)blockIdx.x >= G.p[k].tile_base) pi = k;
-    const GemmProb& P = G.p[pi];
-    if (P.stop && *P.stop) return;
+    const TileBases TB = load_tile_bases(G);
+    const GemmProb P = select_problem(G, TB, (int)blockIdx.x);
+    const int stopv = stop_load(P);
     const int tile = blockIdx.x - P.tile_base;
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -313,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmBatch G) {
         case 7: mainloop<2, 1, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
         default: mainloop<2, 2, 1>(P, R, m0, n0, i, kh, 0, acc, asum); break;
     }
+    if (stop_taken(stopv)) return;
     // C fragment: lane holds column n0 + i, reg s holds row (s&3) + 8(s>>2) + 4kh -> each store
     // instruction writes two rows of 32 consecutive floats
     const int n = n0 + i;

@@ -293,6 +293,11 @@ __global__ __launch_bounds__(256) void policy_finalize_kernel(
     int A, smx_ppo_ctrl_t* __restrict__ ctrl, int check_stop, int will_update,
     float* __restrict__ dz3, float* __restrict__ dz3_t, long ld_t, float* __restrict__ dlogvar,
     float* __restrict__ dlogvar_sumsq, float* __restrict__ stats) {
+    // every argument is fetched together with the pointer to the stop flag (one kernarg round trip
+    // in front of the flag's instead of one behind it as well)
+    asm volatile("" :: "s"(mode), "s"(partials), "s"(nblk), "s"(g_surr), "s"(g_kl), "s"(log_var), "s"(rows),
+                 "s"(n_total), "s"(A), "s"(ctrl), "s"(check_stop), "s"(will_update), "s"(dz3), "s"(dz3_t),
+                 "s"(ld_t), "s"(dlogvar), "s"(dlogvar_sumsq), "s"(stats));
     if (ctrl->stop_flag) return;
     policy_finalize_body(blockIdx.x, gridDim.x, mode, partials, nblk, g_surr, g_kl, log_var, rows,
                          n_total, A, ctrl, check_stop, will_update, dz3, dz3_t, ld_t, dlogvar,
@@ -348,6 +353,11 @@ __global__ __launch_bounds__(256) void ppo_losses_kernel(smx_ppo_losses_t a,
                                                          float* __restrict__ g_surr_t,
                                                          float* __restrict__ g_kl_t) {
     extern __shared__ float sm[];
+    asm volatile("" :: "s"(a.mode), "s"(a.A), "s"(a.mean), "s"(a.log_var), "s"(a.actions), "s"(a.behave),
+                 "s"(a.ref), "s"(a.adv), "s"(a.ld_act), "s"(a.ld_beh), "s"(a.ld_ref), "s"(a.rows), "s"(a.g_surr),
+                 "s"(a.g_kl), "s"(a.row_partials), "s"(a.ld_t), "s"(a.values), "s"(a.returns), "s"(a.v_dz3),
+                 "s"(a.v_partials), "s"(a.v_will_update), "s"(ctrl), "s"(nblk_p), "s"(n_total), "s"(scaled),
+                 "s"(g_surr_t), "s"(g_kl_t));             // one kernarg round trip for all of them
     if ((int)blockIdx.x >= nblk_p) {
         value_loss_body(blockIdx.x - nblk_p, a.values, a.returns, (long)a.rows, n_total, a.v_dz3,
                         a.v_partials, ctrl, a.v_will_update);
@@ -468,16 +478,25 @@ struct AdamGroups {
 __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
                                                         const smx_ppo_ctrl_t* __restrict__ ctrl) {
     const int gi = (P.n > 1 && (int)blockIdx.x >= P.g[0].blocks) ? 1 : 0;
-    const AdamGroup& G = P.g[gi];
+    // the group descriptor and the control block in one batch of scalar loads each (fetched field
+    // by field at their first use they form a chain of six dependent round trips, ~1.5 us)
+    const AdamGroup G = P.g[gi];
+    asm volatile("" :: "s"(G.theta), "s"(G.grads), "s"(G.m), "s"(G.v), "s"(G.n), "s"(G.partials), "s"(G.npart),
+                 "s"(G.which), "s"(G.honour_stop), "s"(G.blocks), "s"(G.grad_norm_out));
+    const smx_ppo_ctrl_t C = *ctrl;
+    asm volatile("" :: "s"(C.lr_actor), "s"(C.lr_critic), "s"(C.actor_max_norm), "s"(C.critic_max_norm),
+                 "s"(C.actor_weight_decay), "s"(C.critic_weight_decay), "s"(C.adam_step_actor),
+                 "s"(C.adam_step_critic), "s"(C.stop_flag));
+    const smx_ppo_ctrl_t* ctrl_v = &C;
     const int blk = blockIdx.x - (gi ? P.g[0].blocks : 0);
-    if (G.honour_stop && ctrl->stop_flag) return;
+    if (G.honour_stop && C.stop_flag) return;
     __shared__ float red[16];
     float t = 0.f;
     for (int k = threadIdx.x; k < G.npart; k += 256) t += G.partials[k];
     const float total = smx_block_sum(t, red);
     const float norm = sqrtf(total);
     const int which = G.which;
-    const float max_norm = which ? ctrl->critic_max_norm : ctrl->actor_max_norm;
+    const float max_norm = which ? ctrl_v->critic_max_norm : ctrl_v->actor_max_norm;
     float coef = 1.0f;
     if (max_norm > 0.f) {
         // clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1, always multiplied in
@@ -486,9 +505,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
     if (blk == 0 && threadIdx.x == 0 && G.grad_norm_out) *G.grad_norm_out = norm;
 
     const double beta1 = 0.9, beta2 = 0.999;
-    const int step = which ? ctrl->adam_step_critic : ctrl->adam_step_actor;
-    const double lr = (double)(which ? ctrl->lr_critic : ctrl->lr_actor);
-    const float wd = which ? ctrl->critic_weight_decay : ctrl->actor_weight_decay;
+    const int step = which ? C.adam_step_critic : C.adam_step_actor;
+    const double lr = (double)(which ? C.lr_critic : C.lr_actor);
+    const float wd = which ? C.critic_weight_decay : C.actor_weight_decay;
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     const float neg_step_size = (float)(-(lr / bc1));
