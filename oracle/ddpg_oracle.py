@@ -66,6 +66,17 @@ class OracleDDPGModel(object):
                 else:
                     self.p[k].copy_(self.p[k] * (1.0 - tau) + other.p[k] * tau)   # soft_update
 
+    def load_critic_from(self, other, tau=None):
+        """the second critic's target follows only the critic (ddpg.py:412-415, 422-425)"""
+        with torch.no_grad():
+            for k in self.p:
+                if not k.startswith('critic.'):
+                    continue
+                if tau is None:
+                    self.p[k].copy_(other.p[k])
+                else:
+                    self.p[k].copy_(self.p[k] * (1.0 - tau) + other.p[k] * tau)
+
     def numpy_params(self):
         return collections.OrderedDict((k, v.detach().numpy().copy()) for k, v in self.p.items())
 
@@ -75,9 +86,20 @@ class OracleDDPGLearner(object):
                  clip_actor_gradient=True, actor_gradient_value_clip=1.0,
                  clip_critic_gradient=False, critic_gradient_value_clip=5.0,
                  actor_regularization=0.0, critic_regularization=0.0,
-                 target_update_type='hard', target_update_interval=500, tau=1e-3):
+                 target_update_type='hard', target_update_interval=500, tau=1e-3,
+                 use_double_critic=False, use_action_regularization=False, params2=None,
+                 batch_size=None):
         self.model = OracleDDPGModel(params)
         self.model_target = OracleDDPGModel(params)
+        # TD3 options (ddpg.py:119-147, 162-166): a second critic with its own optimiser and target
+        self.use_double_critic = use_double_critic
+        self.use_action_regularization = use_action_regularization
+        self.batch_size = batch_size
+        if use_double_critic:
+            self.model2 = OracleDDPGModel(params2)
+            self.model_target2 = OracleDDPGModel(params2)
+            self.critic_optim2 = torch.optim.Adam(self.model2.critic_params(), lr=lr_critic,
+                                                  weight_decay=critic_regularization)
         self.gamma, self.n_step = gamma, n_step
         self.clip_actor_gradient, self.actor_clip = clip_actor_gradient, actor_gradient_value_clip
         self.clip_critic_gradient, self.critic_clip = clip_critic_gradient, critic_gradient_value_clip
@@ -96,9 +118,18 @@ class OracleDDPGLearner(object):
         assert actions.max().item() <= 1.0 and actions.min().item() >= -1.0
         model_policy = mt.forward_actor(obs_next)
         next_Q_target = mt.forward_critic(obs_next, model_policy)
+        if self.use_action_regularization:                       # ddpg.py:267-278: AFTER next_Q_target
+            noise = np.clip(np.random.normal(0, 0.2, size=(self.batch_size, model_policy.shape[1])), -0.5, 0.5)
+            model_policy = model_policy + torch.tensor(noise, dtype=torch.float32)
+            model_policy = model_policy.clamp(-1, 1)
         y = rewards + pow(self.gamma, self.n_step) * next_Q_target * (1.0 - done)
+        if self.use_double_critic:                               # ddpg.py:280-283
+            next_Q_target2 = self.model_target2.forward_critic(obs_next, model_policy)
+            y2 = rewards + pow(self.gamma, self.n_step) * next_Q_target2 * (1.0 - done)
+            y = torch.min(y, y2)
         y = y.detach()
         y_policy = m.forward_critic(obs, actions.detach())
+        y_policy2 = self.model2.forward_critic(obs, actions.detach()) if self.use_double_critic else None
         for q in m.critic_params():
             q.grad = None
         critic_loss = self.critic_criterion(y_policy, y)
@@ -106,6 +137,14 @@ class OracleDDPGLearner(object):
         if self.clip_critic_gradient:
             nn.utils.clip_grad_value_(m.critic_params(), self.critic_clip)
         self.critic_optim.step()
+        if self.use_double_critic:                               # ddpg.py:312-319 (critic_loss is overwritten)
+            for q in self.model2.critic_params():
+                q.grad = None
+            critic_loss = self.critic_criterion(y_policy2, y)
+            critic_loss.backward()
+            if self.clip_critic_gradient:
+                nn.utils.clip_grad_value_(self.model2.critic_params(), self.critic_clip)
+            self.critic_optim2.step()
         for q in m.actor_params():
             q.grad = None
         actor_loss = -m.forward_critic(obs.detach(), m.forward_actor(obs.detach()))
@@ -122,16 +161,22 @@ class OracleDDPGLearner(object):
             'Q_target': y.mean().item(),
             'Q_policy': y_policy.mean().item(),
         }
+        if self.use_double_critic:
+            stats['Q_policy2'] = y_policy2.mean().item()
         self._target_update()
         return stats
 
     def _target_update(self):                                    # ddpg.py:403-428
         if self.target_update_type == 'soft':
             self.model_target.load_from(self.model, self.tau)
+            if self.use_double_critic:
+                self.model_target2.load_critic_from(self.model2, self.tau)
         else:
             self.target_update_counter += 1
             if self.target_update_counter % self.target_update_interval == 0:
                 self.model_target.load_from(self.model)
+                if self.use_double_critic:
+                    self.model_target2.load_critic_from(self.model2)
 
     def learn(self, batch):
         t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).clone()  # noqa: E731

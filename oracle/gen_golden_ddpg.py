@@ -49,6 +49,14 @@ def extract(m):
     return out
 
 
+def extract_critic(m):
+    out = collections.OrderedDict()
+    for i, l in enumerate(lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)):
+        out['critic.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
+        out['critic.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    return out
+
+
 class _Timer(object):
     avg = 0.0
 
@@ -57,13 +65,13 @@ class _Timer(object):
         return contextlib.nullcontext()
 
 
-def build_ref(params, D, A, ah, ch, hyper):
+def build_ref(params, D, A, ah, ch, hyper, params2=None):
     L = object.__new__(DDPGLearner)
     L.batch_size = hyper['B']
     L.discount_factor, L.n_step = hyper['gamma'], hyper['n_step']
     L.is_pixel_input = False
-    L.use_double_critic = False
-    L.use_action_regularization = False
+    L.use_double_critic = bool(hyper.get('double_critic', False))
+    L.use_action_regularization = bool(hyper.get('action_reg', False))
     L.gpu_ids, L._num_gpus = 'cpu', 0
     L.clip_actor_gradient, L.actor_gradient_clip_value = True, 1.0
     L.clip_critic_gradient, L.critic_gradient_clip_value = hyper.get('clip_critic', False), 5.0
@@ -78,6 +86,11 @@ def build_ref(params, D, A, ah, ch, hyper):
     inject(L.model_target, params)
     L.critic_criterion = torch.nn.MSELoss()
     L.critic_optim = torch.optim.Adam(L.model.get_critic_parameters(), lr=hyper['lr_critic'])
+    if L.use_double_critic:                                # ddpg.py:119-147, 162-166
+        L.model2, L.model_target2 = mk(), mk()
+        inject(L.model2, params2)
+        inject(L.model_target2, params2)
+        L.critic_optim2 = torch.optim.Adam(L.model2.get_critic_parameters(), lr=hyper['lr_critic'])
     L.actor_optim = torch.optim.Adam(L.model.get_actor_parameters(), lr=hyper['lr_actor'])
     L.target_update_type = hyper['target_update_type']
     L.target_update_counter = 0
@@ -95,6 +108,13 @@ CASES = {
                                  hyper=dict(gamma=0.9, n_step=1, lr_actor=1e-3, lr_critic=1e-2,
                                             target_update_type='soft', target_update_interval=1,
                                             tau=0.05, clip_critic=True)),
+    'tiny_td3_hard': dict(B=16, D=5, A=2, ah=(24, 16), ch=(32, 24), iters=4,
+                          hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-3, lr_critic=1e-2, double_critic=True,
+                                     action_reg=True, target_update_type='hard', target_update_interval=2)),
+    'tiny_double_soft': dict(B=21, D=7, A=3, ah=(24, 16), ch=(32, 24), iters=3,
+                             hyper=dict(gamma=0.95, n_step=2, lr_actor=1e-3, lr_critic=1e-2, double_critic=True,
+                                        target_update_type='soft', target_update_interval=1, tau=0.1,
+                                        clip_critic=True)),
     'cfg3_cheetah512': dict(B=512, D=17, A=6, ah=(300, 200), ch=(400, 300), iters=3,
                             hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-4, lr_critic=1e-3,
                                        target_update_type='hard', target_update_interval=500)),
@@ -105,9 +125,12 @@ def main():
     for name, c in CASES.items():
         hyper = dict(c['hyper'], B=c['B'])
         params = ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=3)
-        Lr = build_ref(params, c['D'], c['A'], c['ah'], c['ch'], hyper)
+        params2 = ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=4)
+        Lr = build_ref(params, c['D'], c['A'], c['ah'], c['ch'], hyper, params2)
         O = ddpg_oracle.OracleDDPGLearner(
-            params, gamma=hyper['gamma'], n_step=hyper['n_step'], lr_actor=hyper['lr_actor'],
+            use_double_critic=hyper.get('double_critic', False),
+            use_action_regularization=hyper.get('action_reg', False), params2=params2, batch_size=c['B'],
+            params=params, gamma=hyper['gamma'], n_step=hyper['n_step'], lr_actor=hyper['lr_actor'],
             lr_critic=hyper['lr_critic'], clip_critic_gradient=hyper.get('clip_critic', False),
             target_update_type=hyper['target_update_type'],
             target_update_interval=hyper['target_update_interval'], tau=hyper.get('tau', 1e-3))
@@ -117,8 +140,10 @@ def main():
             t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)  # noqa: E731
             obs = {'low_dim': {'flat_inputs': t(b['obs']['low_dim']['flat_inputs'])}}
             obs_next = {'low_dim': {'flat_inputs': t(b['obs_next']['low_dim']['flat_inputs'])}}
+            np.random.seed(1000 + it)          # the action-regularisation noise comes from numpy's stream
             sr = Lr._optimize(obs, t(b['actions']), t(b['rewards']), obs_next, t(b['dones']))
             sr = {k: float(v) for k, v in sr.items() if not k.startswith('performance')}
+            np.random.seed(1000 + it)
             so = O.learn(b)
             for k in sr:
                 assert sr[k] == so[k], (name, it, k, sr[k], so[k])
@@ -129,6 +154,13 @@ def main():
         ft = extract(Lr.model_target)
         for k in ft:
             np.testing.assert_array_equal(ft[k], O.model_target.numpy_params()[k])
+        if hyper.get('double_critic'):
+            f2 = {k: v for k, v in extract_critic(Lr.model2).items()}
+            for k, v in f2.items():
+                np.testing.assert_array_equal(v, O.model2.numpy_params()[k])
+            t2 = extract_critic(Lr.model_target2)
+            for k, v in t2.items():
+                np.testing.assert_array_equal(v, O.model_target2.numpy_params()[k])
         out = {'case_json': np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v)
                                                  for k, v in c.items()})),
                'trace_json': np.array(json.dumps(traces))}
@@ -137,6 +169,11 @@ def main():
                 out['final.' + k] = v
             for k, v in ft.items():
                 out['target.' + k] = v
+        if hyper.get('double_critic'):
+            for k, v in f2.items():
+                out['final2.' + k] = v
+            for k, v in t2.items():
+                out['target2.' + k] = v
         out['final_sumsq_json'] = np.array(json.dumps(
             {k: float(np.sum(v.astype(np.float64) ** 2)) for k, v in fr.items()}))
         path = os.path.join(ROOT, 'tests', 'golden', 'ddpg_%s.npz' % name)

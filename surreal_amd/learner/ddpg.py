@@ -11,8 +11,15 @@ Dense layers run on the FP32-MFMA layer kernel (csrc/smx_gemm.hip); the critic's
 copy: layer 1 writes into the first c1 columns of a [B, c1+A] buffer whose last A columns hold
 the action.
 
-Scope: low-dimensional observations, single critic, no TD3 action regularisation, no
-LayerNorm (the reference defaults, ddpg_configs.py:16-98); the other switches raise.
+The TD3 switches are built too (ddpg.py:119-147, 266-283, 312-319): ``use_double_critic`` (a
+second critic with its own optimiser and target, y = min of the two targets, ``Q_policy2`` and
+the second critic's loss reported as the reference does) and ``use_action_regularization``
+(clipped noise on the target policy's action, drawn from numpy's global stream like the
+reference's).  The iteration is captured once in a hipGraph and replayed: the Adam step count,
+the learning rates and the hard-update decision live on the device.
+
+Scope: low-dimensional observations, no LayerNorm (torchx's LayerNorm semantics are unpinned,
+SURVEY.md 8(c)); those switches raise.
 """
 import gc
 import types
@@ -42,9 +49,6 @@ class DDPGLearner(Learner):
         net = self.learner_config.algo.network
         self.use_double_critic = net.use_double_critic
         self.use_action_regularization = net.use_action_regularization
-        if self.use_double_critic or self.use_action_regularization:
-            raise NotImplementedError('TD3 options (double critic / action regularisation) are '
-                                      'not built yet')
         self._target_update_init()
         self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu'
         self.clip_actor_gradient = net.clip_actor_gradient
@@ -64,6 +68,12 @@ class DDPGLearner(Learner):
         self.model_target = DDPGModel(**mk)
         self.model_target.load_state_dict(self.model.state_dict())       # hard_update (ddpg.py:175-176)
         z = torch.zeros_like
+        if self.use_double_critic:
+            # TD3's second critic (ddpg.py:119-147, 162-166, 177-178): own parameters, optimiser, target
+            self.model2 = DDPGModel(critic_only=True, **mk)
+            self.model_target2 = DDPGModel(critic_only=True, **mk)
+            self.model_target2.load_state_dict(self.model2.state_dict())
+            self.critic2_exp_avg, self.critic2_exp_avg_sq = z(self.model2.critic_flat), z(self.model2.critic_flat)
         self.actor_exp_avg, self.actor_exp_avg_sq = z(self.model.actor_flat), z(self.model.actor_flat)
         self.critic_exp_avg, self.critic_exp_avg_sq = z(self.model.critic_flat), z(self.model.critic_flat)
         self.actor_step = 0
@@ -128,26 +138,41 @@ class DDPGLearner(Learner):
         # the batch is staged into fixed buffers (5 small copies) so that the graph's pointers hold
         A = self.action_dim
         ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done = f(B, D), f(B, D), f(B, A), f(B), f(B)
+        if self.use_action_regularization:
+            ws.s_noise, ws.act_n = f(B, A), f(B, A)
+        if self.use_double_critic:
+            ws.xcat2, ws.h2c2, ws.q2, ws.q_next2 = f(B, c1 + A), f(B, c2), f(B), f(B)
+            ws.y2, ws.dz3_2 = f(B), f(B)
+            ws.grads_c2 = torch.zeros_like(self.model2.critic_flat)
+            ws.gc2 = {}
+            o = 0
+            for name, v in self.model2.critic.items():
+                ws.gc2[name] = ws.grads_c2[o:o + v.numel()].view(v.shape)
+                o += v.numel()
+            ws.stats2 = torch.zeros(8, device=self.device)
         ws.graph = None
         self._ws = ws
         return ws
 
-    def _critic_backward(self, ws, x, B):
-        """gradients of the critic parameters from ws.dz3 (dLoss/dQ); leaves dLoss/d(xcat) in
-        ws.dxcat (its last A columns are dLoss/d(action))"""
-        K, m, A = self.K, self.model, self.action_dim
+    def _critic_backward(self, ws, x, B, model=None, dz3=None, xcat=None, h2c=None, gc=None):
+        """gradients of a critic's parameters from dz3 (dLoss/dQ; default: the first critic's
+        buffers); leaves dLoss/d(xcat) in ws.dxcat (its last A columns are dLoss/d(action))"""
+        K, m, A = self.K, model or self.model, self.action_dim
+        xcat = ws.xcat if xcat is None else xcat
+        h2c = ws.h2c if h2c is None else h2c
+        gc = ws.gc if gc is None else gc
         c, c1, c2, D = m.critic, m.c1, m.c2, x.shape[1]
-        dz3 = ws.dz3.view(B, 1)
-        K.linear(dz3, 1, c['W3'], 0, None, ws.dz2, B, c2, 1, relu_mask=ws.h2c, lda=1, ldb=c2)
+        dz3 = (ws.dz3 if dz3 is None else dz3).view(B, 1)
+        K.linear(dz3, 1, c['W3'], 0, None, ws.dz2, B, c2, 1, relu_mask=h2c, lda=1, ldb=c2)
         # d/d(relu(layer1)) masked by relu', into the first c1 columns of dxcat
-        K.linear(ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1, c2, relu_mask=ws.xcat, ldb=c1 + A,
+        K.linear(ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1, c2, relu_mask=xcat, ldb=c1 + A,
                  ldc=c1 + A)
         # d/d(action) into the last A columns (no mask)
         K.linear(ws.dz2, 1, c['W2'][:, c1:], 0, None, ws.dxcat[:, c1:], B, A, c2, ldb=c1 + A,
                  ldc=c1 + A)
-        K.linear_wgrad(ws.dxcat, x, ws.gc['W1'], ws.gc['b1'], c1, D, B, ldz=c1 + A)
-        K.linear_wgrad(ws.dz2, ws.xcat, ws.gc['W2'], ws.gc['b2'], c2, c1 + A, B)
-        K.linear_wgrad(dz3, ws.h2c, ws.gc['W3'], ws.gc['b3'], 1, c2, B, ldz=1)
+        K.linear_wgrad(ws.dxcat, x, gc['W1'], gc['b1'], c1, D, B, ldz=c1 + A)
+        K.linear_wgrad(ws.dz2, xcat, gc['W2'], gc['b2'], c2, c1 + A, B)
+        K.linear_wgrad(dz3, h2c, gc['W3'], gc['b3'], 1, c2, B, ldz=1)
 
     def _enqueue_iteration(self, ws, x, xn, actions, rewards, done):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
@@ -156,14 +181,38 @@ class DDPGLearner(Learner):
         # ---- target: y = r + gamma^n * Q'(s', mu'(s')) * (1 - done) ----
         K.mlp3_forward(mt.actor, xn, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
         mt.critic_forward_into(xn, ws.act, ws.xcat, ws.h2c, ws.q_next)
-        # ---- critic update ----
+        q_next, gamma_n = ws.q_next, pow(self.discount_factor, self.n_step)
+        if self.use_double_critic:
+            # TD3 (ddpg.py:266-283): y = min(y1, y2), the second target critic evaluated at the target
+            # policy's action -- with clipped noise added when action regularisation is on (the
+            # reference adds it AFTER the first critic's target was formed, so only y2 sees it).
+            # r + t is monotone in t: min(r + t1, r + t2) = r + gamma^n (1 - d) min(Q1', Q2')
+            a2 = ws.act
+            if self.use_action_regularization:
+                torch.add(ws.act, ws.s_noise, out=ws.act_n)
+                ws.act_n.clamp_(-1.0, 1.0)
+                a2 = ws.act_n
+            self.model_target2.critic_forward_into(xn, a2, ws.xcat2, ws.h2c2, ws.q_next2)
+            torch.minimum(ws.q_next, ws.q_next2, out=ws.q_next2)
+            q_next = ws.q_next2
+        # ---- critic update(s) ----
         m.critic_forward_into(x, actions, ws.xcat, ws.h2c, ws.q)
-        K.ddpg_critic_loss_step(ws.q, ws.q_next, rewards, done, pow(self.discount_factor, self.n_step),
-                                ws.y, ws.dz3, ws.step)
+        if self.use_double_critic:
+            self.model2.critic_forward_into(x, actions, ws.xcat2, ws.h2c2, ws.q2)
+        K.ddpg_critic_loss_step(ws.q, q_next, rewards, done, gamma_n, ws.y, ws.dz3, ws.step)
         self._critic_backward(ws, x, B)
         K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                         ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
         ws.q_policy.copy_(ws.q)
+        if self.use_double_critic:                       # ddpg.py:312-319
+            m2 = self.model2
+            K.ddpg_critic_loss(ws.q2, q_next, rewards, done, gamma_n, ws.y2, ws.dz3_2)
+            self._critic_backward(ws, x, B, model=m2, dz3=ws.dz3_2, xcat=ws.xcat2, h2c=ws.h2c2, gc=ws.gc2)
+            K.adam_step_dev(m2.critic_flat, ws.grads_c2, self.critic2_exp_avg, self.critic2_exp_avg_sq,
+                            ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+            # the reference reports the SECOND critic's loss as 'critic_loss' (it overwrites the
+            # variable, ddpg.py:313) and adds Q_policy2
+            K.ddpg_stats(ws.q2, ws.y2, rewards, actions, ws.q2, ws.stats2)
         # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)) ----
         K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
         m.critic_forward_into(x, ws.act, ws.xcat, ws.h2c, ws.q_actor)
@@ -180,12 +229,14 @@ class DDPGLearner(Learner):
                         ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
         K.ddpg_stats(ws.q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
         # ---- target networks (ddpg.py:389-428) ----
-        if self.target_update_type == 'soft':
-            K.soft_update(mt.actor_flat, m.actor_flat, self.target_update_tau)
-            K.soft_update(mt.critic_flat, m.critic_flat, self.target_update_tau)
-        else:
-            K.hard_update_every(mt.actor_flat, m.actor_flat, ws.step, self.target_update_interval)
-            K.hard_update_every(mt.critic_flat, m.critic_flat, ws.step, self.target_update_interval)
+        pairs = [(mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat)]
+        if self.use_double_critic:
+            pairs.append((self.model_target2.critic_flat, self.model2.critic_flat))
+        for tgt, src in pairs:
+            if self.target_update_type == 'soft':
+                K.soft_update(tgt, src, self.target_update_tau)
+            else:
+                K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
 
     def _optimize(self, obs, actions, rewards, obs_next, done):       # ddpg.py:244-352
         x = obs['low_dim']['flat_inputs']
@@ -202,6 +253,10 @@ class DDPGLearner(Learner):
         ws.s_act.copy_(actions.reshape(B, -1))
         ws.s_rew.copy_(rewards.reshape(-1))
         ws.s_done.copy_(done.reshape(-1))
+        if self.use_action_regularization:
+            # ddpg.py:268-274: policy_noise 0.2 clipped at 0.5, from numpy's global stream
+            noise = np.clip(np.random.normal(0, 0.2, size=(self.batch_size, self.action_dim)), -0.5, 0.5)
+            ws.s_noise.copy_(torch.as_tensor(noise, dtype=torch.float32))
         if self.use_graph and ws.graph is None:
             # capture after one eager iteration (lazy allocations, module load); its effects are
             # real: the capture itself executes nothing
@@ -227,8 +282,12 @@ class DDPGLearner(Learner):
         st = ws.stats.cpu().numpy()                  # the iteration's one read-back
         amax = float(st[6])
         assert amax <= 1.0, 'actions must lie in [-1, 1] (ddpg.py:262-263), got |a| = %g' % amax
-        return {'actor_loss': float(st[0]), 'critic_loss': float(st[1]), 'action_norm': float(st[2]),
-                'rewards': float(st[3]), 'Q_target': float(st[4]), 'Q_policy': float(st[5])}
+        out = {'actor_loss': float(st[0]), 'critic_loss': float(st[1]), 'action_norm': float(st[2]),
+               'rewards': float(st[3]), 'Q_target': float(st[4]), 'Q_policy': float(st[5])}
+        if self.use_double_critic:
+            st2 = ws.stats2.cpu().numpy()
+            out['critic_loss'], out['Q_policy2'] = float(st2[1]), float(st2[5])
+        return out
 
     def learn(self, batch):
         self.current_iteration += 1

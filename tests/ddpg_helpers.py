@@ -9,7 +9,7 @@ from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, 
 
 import ddpg_oracle
 
-DDPG_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'cfg3_cheetah512']
+DDPG_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'tiny_td3_hard', 'tiny_double_soft', 'cfg3_cheetah512']
 
 
 def load(name):
@@ -28,11 +28,17 @@ def make_learner(case):
     lc.algo.network.clip_critic_gradient = h.get('clip_critic', False)
     lc.algo.network.target_update = {'type': h['target_update_type'],
                                      'interval': h['target_update_interval'], 'tau': h.get('tau', 1e-3)}
+    lc.algo.network.use_double_critic = bool(h.get('double_critic', False))
+    lc.algo.network.use_action_regularization = bool(h.get('action_reg', False))
     lc.replay.batch_size = case['B']
     L = DDPGLearner(lc, ddpg_env_config(case['D'], case['A']), ddpg_session_config())
     params = ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=3)
     L.model.load_params(params)
     L.model_target.load_params(params)
+    if L.use_double_critic:
+        params2 = ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=4)
+        L.model2.load_params(params2)
+        L.model_target2.load_params(params2)
     return L
 
 
@@ -42,7 +48,9 @@ def run_and_check(name, atol=1e-5, rtol=1e-5):
     ref = json.loads(str(g['trace_json']))
     for it in range(case['iters']):
         b = synthetic.make_ddpg_batch(case['B'], case['D'], case['A'], seed=10 + it)
+        np.random.seed(1000 + it)          # TD3's action-regularisation noise (numpy's global stream)
         st = L.learn(b)
+        assert set(st) == set(ref[it]), (sorted(st), sorted(ref[it]))
         for k, v in ref[it].items():
             np.testing.assert_allclose(st[k], v, atol=atol, rtol=rtol,
                                        err_msg='%s iteration %d %s' % (name, it, k))
@@ -60,4 +68,10 @@ def run_and_check(name, atol=1e-5, rtol=1e-5):
         if 'target.' + k in g:
             d = np.abs(tgt[k] - g['target.' + k])
             assert np.mean(d > 2e-5) < 0.03, ('target ' + k, d.max())
+    if L.use_double_critic:
+        got2, tgt2 = L.model2.numpy_params(), L.model_target2.numpy_params()
+        for k in got2:
+            np.testing.assert_allclose(got2[k], g['final2.' + k], atol=2 * lr * case['iters'] + 1e-6, err_msg=k)
+            assert np.mean(np.abs(got2[k] - g['final2.' + k]) > 2e-5) < 0.03, k
+            np.testing.assert_allclose(tgt2[k], g['target2.' + k], atol=2 * lr * case['iters'] + 1e-6, err_msg=k)
     return L

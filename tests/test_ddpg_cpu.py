@@ -16,13 +16,18 @@ def test_ddpg_oracle_matches_reference_golden(name):
     g, c = DH.load(name)
     h = c['hyper']
     params = ddpg_oracle.make_ddpg_params(c['D'], c['A'], tuple(c['ah']), tuple(c['ch']), seed=3)
+    params2 = ddpg_oracle.make_ddpg_params(c['D'], c['A'], tuple(c['ah']), tuple(c['ch']), seed=4)
     O = ddpg_oracle.OracleDDPGLearner(
         params, gamma=h['gamma'], n_step=h['n_step'], lr_actor=h['lr_actor'], lr_critic=h['lr_critic'],
         clip_critic_gradient=h.get('clip_critic', False), target_update_type=h['target_update_type'],
-        target_update_interval=h['target_update_interval'], tau=h.get('tau', 1e-3))
+        target_update_interval=h['target_update_interval'], tau=h.get('tau', 1e-3),
+        use_double_critic=h.get('double_critic', False), use_action_regularization=h.get('action_reg', False),
+        params2=params2, batch_size=c['B'])
     ref = json.loads(str(g['trace_json']))
     for it in range(c['iters']):
+        np.random.seed(1000 + it)
         st = O.learn(synthetic.make_ddpg_batch(c['B'], c['D'], c['A'], seed=10 + it))
+        assert set(st) == set(ref[it])
         for k, v in ref[it].items():
             np.testing.assert_allclose(st[k], v, atol=2e-6, rtol=2e-6)
 
@@ -37,7 +42,7 @@ def test_ddpg_unsupported_switches_raise(cpu_double):
     from surreal_amd.learner.ddpg import DDPGLearner
     from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
     lc = ddpg_learner_config()
-    lc.algo.network.use_double_critic = True
+    lc.model.use_layernorm = True
     with pytest.raises(NotImplementedError):
         DDPGLearner(lc, ddpg_env_config(5, 2), ddpg_session_config())
     lc = ddpg_learner_config()
