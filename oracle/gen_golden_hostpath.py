@@ -136,6 +136,47 @@ def main():
         'obs_first_col': b['obs']['low_dim']['flat_inputs'][:, :, 0].tolist(),
         'rewards_values': b['rewards'].tolist(),
     }
+    # ---- parameter-space noise (agent/param_noise.py) ----------------------------------------
+    import surreal.agent.param_noise as PN
+
+    def params0():
+        return C.OrderedDict(ddpg=C.OrderedDict([('actor.w', np.arange(6, dtype=np.float32).reshape(2, 3)),
+                                                 ('actor.b', np.array([0.5, -0.5], dtype=np.float32)),
+                                                 ('critic.w', np.linspace(-1, 1, 4).astype(np.float32))]))
+    np.random.seed(11)
+    got = PN.NormalParameterNoise(0.25).apply(params0())
+    out['param_noise_normal_seed11'] = {k: np.asarray(v).tolist() for k, v in got['ddpg'].items()}
+
+    class CleanModel(object):
+        """the un-noised copy: its action is a fixed function of what was last loaded"""
+        def __init__(self):
+            self.loaded = None
+
+        def __call__(self, obs, calculate_value=False):
+            return np.asarray(obs, dtype=np.float64) * float(self.loaded['ddpg']['actor.b'][0]), None
+
+    class Loader(object):
+        def __init__(self, m):
+            self.m = m
+
+        def load(self, params):
+            self.m.loaded = params
+    clean = CleanModel()
+    an = PN.AdaptiveNormalParameterNoise(clean, Loader(clean), target_stddev=0.25, compute_dist_interval=3,
+                                         alpha=1.5, sigma=0.1)
+    import io, contextlib
+    trace = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        np.random.seed(12)
+        p = params0()
+        for rnd in range(4):
+            p = an.apply(p)
+            trace.append({'sigma': an.sigma, 'b0': float(p['ddpg']['actor.b'][0]),
+                          'clean_b0': float(clean.loaded['ddpg']['actor.b'][0])})
+            for t in range(5 + rnd):
+                an.compute_action_distance(np.array([1.0, 2.0]), np.array([0.1 * (t + 1) * (rnd + 1), 0.0]))
+            trace[-1].update(i=an.i, dist=float(an.total_action_distance))
+    out['param_noise_adaptive_seed12'] = trace
     path = os.path.join(ROOT, 'tests', 'golden', 'hostpath.json')
     with open(path, 'w') as fp:
         json.dump(out, fp, indent=1, sort_keys=True)

@@ -110,7 +110,8 @@ class Agent(object, metaclass=AutoInitializeMeta):
             return False                      # the reference's "hash unchanged" reply
         params = self.on_parameter_fetched(params, info)
         for name, module in self._module_dict.items():
-            module.load_state_dict(params[name].state_dict())
+            got = params[name]               # a live module, or its wire form after on_parameter_fetched
+            module.load_state_dict(got.state_dict() if hasattr(got, 'state_dict') else got)
         self._fetched_iteration = info.get('iteration')
         return True
 

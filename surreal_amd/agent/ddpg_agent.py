@@ -3,9 +3,11 @@ DDPGAgent (surreal/agent/ddpg_agent.py:26-200): deterministic actor + exploratio
 ``act(obs)`` is the batch-1 reference contract; ``act_batch(obs)`` evaluates all actors of a GPU
 in one actor forward (HIP).  Exploration scale follows the reference: sigma_i =
 max_sigma * agent_id / num_agents (max_sigma / 3 for a single agent), ddpg_agent.py:78-84.
-Parameter-space noise (param_noise.py) is not built (raises).
+Parameter-space noise (param_noise.py: 'normal' / 'adaptive_normal') perturbs the parameters an
+agent fetches, as ddpg_agent.py:136-153, 174-175.
 """
 import collections
+import copy
 import time
 
 import numpy as np
@@ -16,6 +18,7 @@ from surreal_amd.env import ExpSenderWrapperSSARNStepBootstrap
 from surreal_amd.model.ddpg_net import DDPGModel
 from surreal_amd.session import ConfigError
 from .action_noise import NormalActionNoise, OrnsteinUhlenbeckActionNoise
+from .param_noise import NormalParameterNoise, AdaptiveNormalParameterNoise
 from .base import Agent
 
 
@@ -29,8 +32,11 @@ class DDPGAgent(Agent):
         self.obs_spec = self.env_config.obs_spec
         self.sleep_time = self.env_config.get('sleep_time', 0.0)
         ex = self.learner_config.algo.exploration
-        if ex.param_noise_type:
-            raise NotImplementedError('parameter-space noise is not built yet')
+        self.param_noise = None                              # ddpg_agent.py:68-72
+        self.param_noise_type = ex.param_noise_type
+        self.param_noise_sigma = ex.param_noise_sigma
+        self.param_noise_alpha = ex.param_noise_alpha
+        self.param_noise_target_stddev = ex.param_noise_target_stddev
         self.noise_type = ex.noise_type
         n_agents = self.env_config.get('num_agents', 1)
         if n_agents == 1:
@@ -60,13 +66,34 @@ class DDPGAgent(Agent):
                                                       theta=ex.theta, dt=ex.dt)
         else:
             raise ConfigError('Noise type {} undefined.'.format(self.noise_type))
+        if self.param_noise_type == 'normal':                # ddpg_agent.py:136-147
+            self.param_noise = NormalParameterNoise(self.param_noise_sigma)
+        elif self.param_noise_type == 'adaptive_normal':
+            from surreal_amd.distributed import ModuleDict
+            clean = copy.deepcopy(self.model)
+            self.param_noise = AdaptiveNormalParameterNoise(
+                clean, ModuleDict(self.module_dict(clean)), self.param_noise_target_stddev,
+                alpha=self.param_noise_alpha, sigma=self.param_noise_sigma)
+
+    def on_parameter_fetched(self, params, info):         # ddpg_agent.py:149-153
+        params = super().on_parameter_fetched(params, info)
+        if self.param_noise:
+            if any(hasattr(m, 'state_dict') for m in params.values()):
+                # the in-process hand-off passes live modules: noise acts on their wire form
+                from surreal_amd.distributed import ModuleDict
+                params = ModuleDict(dict(params)).numpy_dict()
+            params = self.param_noise.apply(params)
+        return params
 
     def act(self, obs):                                   # ddpg_agent.py:155-184
         if self.sleep_time > 0.0:
             time.sleep(self.sleep_time)
         x = torch.as_tensor(np.asarray(obs['low_dim']['flat_inputs']), dtype=torch.float32) \
             .unsqueeze(0).to(self.device)
-        action = self.model.forward_actor(x).cpu().numpy()[0]
+        action_t = self.model.forward_actor(x)
+        if self.param_noise and self.param_noise_type == 'adaptive_normal':
+            self.param_noise.compute_action_distance({'low_dim': {'flat_inputs': x}}, action_t)
+        action = action_t.cpu().numpy()[0]
         action = action.clip(-1, 1)
         if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:
             action = action + self.noise()

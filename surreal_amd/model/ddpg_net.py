@@ -24,6 +24,10 @@ class DDPGModel(object):
                  kernels=None):
         self.K = kernels or KN.default_kernels()
         device = device or KN.default_device()
+        self._ctor = dict(obs_spec=obs_spec, action_dim=action_dim, use_layernorm=use_layernorm,
+                          actor_fc_hidden_sizes=list(actor_fc_hidden_sizes),
+                          critic_fc_hidden_sizes=list(critic_fc_hidden_sizes), critic_only=critic_only,
+                          device=device, kernels=self.K)
         if 'pixel' in obs_spec:
             raise NotImplementedError('pixel observations (CNN perception) are not built yet')
         if use_layernorm:
@@ -128,6 +132,16 @@ class DDPGModel(object):
         q = torch.empty(rows, device=x.device)
         self.critic_forward_into(x.contiguous(), action, xcat, h2, q)
         return q.view(rows, 1)
+
+    def __deepcopy__(self, memo):
+        """same architecture, own parameter buffers holding the same values (the kernel facade and
+        the device are shared, not copied)"""
+        twin = DDPGModel(**self._ctor)
+        twin.load_state_dict(self.state_dict())
+        return twin
+
+    def __call__(self, obs_in, calculate_value=True, action=None):
+        return self.forward(obs_in, calculate_value=calculate_value, action=action)
 
     def forward(self, obs_in, calculate_value=True, action=None):
         x = self.forward_perception(obs_in)
