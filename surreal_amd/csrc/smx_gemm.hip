@@ -462,9 +462,24 @@ extern "C" int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, co
     SMX_REQUIRE(A && B && C, SMX_E_NULL);
     SMX_REQUIRE(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, SMX_E_SHAPE);
     GemmBatch G;
-    G.n = 1;
-    fill_prob(G.p[0], A, lda, a_kcontig, B, ldb, b_kcontig, bias, relu_mask, C, ldc, M, N, K, act,
-              nullptr, nullptr, 0, stop_flag);
+    // An operand is addressed through a buffer descriptor (31-bit byte offsets).  A row-major A
+    // past 2 GiB -- the patch matrix of a convolution over thousands of frames -- is cut into
+    // row blocks, one problem of the same launch each (rows are independent).
+    const unsigned long long abytes = operand_bytes(lda, a_kcontig, M, K);
+    int parts = 1;
+    if (a_kcontig && abytes >= (1ull << 31)) parts = (int)(abytes / ((1ull << 31) - (1ull << 20))) + 1;
+    SMX_REQUIRE(parts <= MAX_PROBS, SMX_E_UNSUPPORTED);
+    const int rows_per = parts == 1 ? M : ((((M + parts - 1) / parts) + 127) & ~127);
+    G.n = 0;
+    int base = 0;
+    for (int m_off = 0; m_off < M; m_off += rows_per) {
+        const int Mp = M - m_off < rows_per ? M - m_off : rows_per;
+        GemmProb& P = G.p[G.n++];
+        fill_prob(P, A + (size_t)m_off * lda, lda, a_kcontig, B, ldb, b_kcontig, bias,
+                  relu_mask ? relu_mask + (size_t)m_off * ldc : nullptr, C + (size_t)m_off * ldc, ldc, Mp,
+                  N, K, act, nullptr, nullptr, base, stop_flag);
+        base += P.tiles_m * P.tiles_n;
+    }
     return launch_batch(G, smx_s(stream));
 }
 

@@ -99,7 +99,7 @@ class CnnStem(object):
         K.linear(ws.cols2, 1, v['conv2.W'].view(p.c2, p.K2), 1, v['conv2.b'], ws.y2, F * p.P2, p.c2,
                  p.K2, act=L.SMX_ACT_RELU, stop=stop)
         K.flatten_order(v['fc.W'], p.feat, p.c2, p.P2, True, ws.wfc)
-        K.linear(ws.y2.view(F, p.flat_dim), 1, ws.wfc, 1, v['fc.b'], out, F, p.feat, p.flat_dim,
+        K.linear(ws.y2[:F * p.P2].view(F, p.flat_dim), 1, ws.wfc, 1, v['fc.b'], out, F, p.feat, p.flat_dim,
                  act=L.SMX_ACT_RELU, ldc=out.stride(0), stop=stop)
 
     def backward(self, p, F, ws, dfeat, grads, stop=None):
@@ -115,11 +115,11 @@ class CnnStem(object):
         gv = g.views
         ldz = dfeat.stride(0)
         # Linear: dW (channel-last, then back to torch's order), db, d(flat) * relu'(y2)
-        K.linear_wgrad(dfeat, ws.y2.view(F, p.flat_dim), ws.gwfc, gv['fc.b'], p.feat, p.flat_dim, F,
-                       ldz=ldz)
+        y2 = ws.y2[:F * p.P2].view(F, p.flat_dim)         # F may be a tail chunk of the workspace
+        dy2 = ws.dy2[:F * p.P2].view(F, p.flat_dim)
+        K.linear_wgrad(dfeat, y2, ws.gwfc, gv['fc.b'], p.feat, p.flat_dim, F, ldz=ldz)
         K.flatten_order(ws.gwfc, p.feat, p.c2, p.P2, False, gv['fc.W'])
-        K.linear(dfeat, 1, ws.wfc, 0, None, ws.dy2.view(F, p.flat_dim), F, p.flat_dim, p.feat,
-                 relu_mask=ws.y2.view(F, p.flat_dim), lda=ldz, stop=stop)
+        K.linear(dfeat, 1, ws.wfc, 0, None, dy2, F, p.flat_dim, p.feat, relu_mask=y2, lda=ldz, stop=stop)
         # conv2: dW, db, data gradient scattered back through the patches * relu'(y1)
         K.linear_wgrad(ws.dy2, ws.cols2, gv['conv2.W'].view(p.c2, p.K2), gv['conv2.b'], p.c2, p.K2,
                        F * p.P2, ws=ws.sk)

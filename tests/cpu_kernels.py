@@ -562,23 +562,25 @@ class TorchCpuKernels(object):
 
     # ---- CNN stem data movement (contracts of smx_im2col_f32 / smx_col2im_f32 / flatten_order) ---
     def im2col(self, src, F, C, Hin, Win, k, stride, cols, channel_last=False, scale_div=0.0):
-        x = src.to(torch.float32)
+        # buffers may be longer than F frames (a tail chunk of a workspace): only F frames are touched
+        x = src.reshape(-1)[:F * C * Hin * Win].to(torch.float32)
         if channel_last:
             x = x.reshape(F, Hin, Win, C).permute(0, 3, 1, 2)
         x = x.reshape(F, C, Hin, Win)
         if scale_div:
             x = x / scale_div
         u = torch.nn.functional.unfold(x, k, stride=stride)          # [F, C*k*k, P]
-        cols.copy_(u.transpose(1, 2).reshape(cols.shape))
+        P = u.shape[2]
+        cols[:F * P].copy_(u.transpose(1, 2).reshape(F * P, C * k * k))
 
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         P = ((Hin - k) // stride + 1) * ((Win - k) // stride + 1)
-        u = dcols.reshape(F, P, C * k * k).transpose(1, 2)
+        u = dcols[:F * P].reshape(F, P, C * k * k).transpose(1, 2)
         x = torch.nn.functional.fold(u, (Hin, Win), k, stride=stride)       # [F, C, Hin, Win]
-        x = x.permute(0, 2, 3, 1).reshape(dx.shape)
+        x = x.permute(0, 2, 3, 1).reshape(F * Hin * Win, C)
         if relu_of is not None:
-            x = x * (relu_of.reshape(dx.shape) > 0)
-        dx.copy_(x)
+            x = x * (relu_of[:F * Hin * Win].reshape(F * Hin * Win, C) > 0)
+        dx[:F * Hin * Win].copy_(x)
 
     def flatten_order(self, src, O, C, P, to_channel_last, out):
         if to_channel_last:

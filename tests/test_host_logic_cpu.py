@@ -85,3 +85,18 @@ def test_post_publish_adapts_coefficients(cpu_double):
     L.kl_record = [0.0]
     L._post_publish()
     assert L.clip_epsilon == pytest.approx(0.2 * 1.2)
+
+
+@pytest.mark.parametrize('name', ['tiny_pixel_clip', 'tiny_pixel_rnn_adapt'])
+def test_cnn_stem_chunked_critic_pass_with_a_tail(name, cpu_double):
+    """the critic pass runs the CNN stem in chunks of cnn_chunk_frames; a chunk size that does not
+    divide B*(N+1) leaves a shorter tail chunk inside the same workspace"""
+    g, case = H.load_golden(name)
+    batch, params, zstate = H.case_inputs(case)
+    frames = case['shape']['B'] * (case['shape']['N'] + 1)
+    chunk = max(2, frames // 3 + 1)
+    assert frames % chunk != 0
+    learner = H.make_learner(case, params, zstate, session_overrides={'cnn_chunk_frames': chunk})
+    stats = learner.learn(copy.deepcopy(batch))
+    H.assert_trace_close(learner.trace, g, what=name)
+    H.assert_stats_close(stats, g, what=name)
