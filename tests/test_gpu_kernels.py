@@ -757,3 +757,27 @@ def test_fused_rollout_equals_act_batch_loop_on_hip(K):
     for k in fused:
         assert torch.equal(fused[k], loop[k]), k
     assert float(fused['pds'].abs().sum()) > 0
+
+
+def test_linear_cuts_operands_past_2gib_into_row_blocks(K):
+    """smx_linear_f32 addresses operands through 31-bit buffer descriptors; a row-major A past 2 GiB
+    (a convolution's patch matrix over thousands of frames) becomes several problems of one launch.
+    Rows around every cut and at both ends against torch's fp32 GEMM, incl. bias + ReLU + mask."""
+    M, Kd, N = 3_000_000, 192, 16                       # A = 2.3 GB -> two row blocks
+    g = torch.Generator(device='cuda').manual_seed(0)
+    A = torch.randn(M, Kd, device='cuda', generator=g)
+    W = torch.randn(N, Kd, device='cuda', generator=g) / 8
+    b = torch.randn(N, device='cuda', generator=g)
+    C = torch.full((M, N), float('nan'), device='cuda')
+    K.linear(A, 1, W, 1, b, C, M, N, Kd, act=L.SMX_ACT_RELU)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(C).any())
+    idx = torch.cat([torch.arange(0, 300), torch.arange(M // 2 - 4000, M // 2 + 4000), torch.arange(M - 300, M)]).cuda()
+    want = torch.relu(A[idx].double() @ W.double().t() + b.double())
+    np.testing.assert_allclose(C[idx].cpu().numpy(), want.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # the data-gradient form: no bias, ReLU mask
+    mask = (torch.rand(M, N, device='cuda', generator=g) > 0.5).float()
+    K.linear(A, 1, W, 1, None, C, M, N, Kd, relu_mask=mask)
+    torch.cuda.synchronize()
+    want = (A[idx].double() @ W.double().t()) * mask[idx].double()
+    np.testing.assert_allclose(C[idx].cpu().numpy(), want.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
