@@ -781,3 +781,22 @@ def test_linear_cuts_operands_past_2gib_into_row_blocks(K):
     torch.cuda.synchronize()
     want = (A[idx].double() @ W.double().t()) * mask[idx].double()
     np.testing.assert_allclose(C[idx].cpu().numpy(), want.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_linear_wgrad_splitk_over_an_operand_past_2gib(K):
+    """conv1's weight gradient at cfg 4 scale: dW = dZ^T . X over 3e6 patch rows, X = 2.3 GB (each
+    split-K chunk addresses its own slice); fp64 reference on the device"""
+    M, N, rows = 16, 192, 3_000_000
+    g = torch.Generator(device='cuda').manual_seed(1)
+    dz = torch.randn(rows, M, device='cuda', generator=g)
+    x = torch.randn(rows, N, device='cuda', generator=g)
+    ref_w, ref_b = torch.zeros(M, N, dtype=torch.float64, device='cuda'), dz.double().sum(0)
+    for r0 in range(0, rows, 500_000):                     # bounded fp64 temporaries
+        ref_w += dz[r0:r0 + 500_000].double().t() @ x[r0:r0 + 500_000].double()
+    ws = torch.empty(K.linear_wgrad_ws_floats(M, N, rows), device='cuda')
+    dW, db = torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda')
+    K.linear_wgrad(dz, x, dW, db, M, N, rows, ws=ws)
+    torch.cuda.synchronize()
+    scale = float(ref_w.abs().max())
+    close(dW.cpu().double() / scale, ref_w.cpu() / scale, atol=3e-6, rtol=1e-5, msg='dW')
+    close(db.cpu().double() / scale, ref_b.cpu() / scale, atol=3e-6, rtol=1e-5, msg='db')
