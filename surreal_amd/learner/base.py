@@ -17,6 +17,7 @@ tensorplex process plumbing replaced by in-process hand-off:
 
 Out of scope: sockets, shards, cluster launchers.
 """
+import collections.abc
 import logging
 import os
 import pickle
@@ -31,18 +32,57 @@ from surreal_amd.utils import AutoInitializeMeta, AttrDict, TimedTracker
 
 class ScalarRecorder(object):
     """stands where the throttled tensorplex client stood (learner/base.py:176-190):
-    keeps the last value and a short history of every scalar group"""
+    keeps the last value and a short history of every scalar group.  A group may be a mapping that
+    is still being read back from the device (DeferredStats): it is stored untouched and only
+    looked at when somebody asks for ``latest`` / iterates ``history``."""
 
     def __init__(self, keep=1000):
         self.keep = keep
         self.history = []
-        self.latest = {}
+        self._latest = {}
+        self._merged = 0            # history entries already folded into _latest
 
     def add_scalars(self, scalars, global_step=None):
-        self.latest.update(scalars)
-        self.history.append((global_step, dict(scalars)))
+        self.history.append((global_step, scalars if isinstance(scalars, DeferredStats) else dict(scalars)))
         if len(self.history) > self.keep:
-            del self.history[:len(self.history) - self.keep]
+            self.latest                      # fold what is about to be dropped
+            drop = len(self.history) - self.keep
+            del self.history[:drop]
+            self._merged -= drop
+
+    @property
+    def latest(self):
+        for _, scalars in self.history[self._merged:]:
+            self._latest.update(scalars)
+        self._merged = len(self.history)
+        return self._latest
+
+
+class DeferredStats(collections.abc.Mapping):
+    """the statistics of a learn() whose device -> host read-back is still in flight: a read-only
+    mapping that waits for the copy the first time it is looked at.  The learner resolves it at the
+    latest when the next learn() has been enqueued, so the host decodes step k while the GPU runs
+    step k + 1 instead of the GPU idling for the read-back and the Python in between."""
+
+    def __init__(self, resolve):
+        self._resolve, self._value = resolve, None
+
+    def _get(self):
+        if self._value is None:
+            self._resolve()
+        return self._value
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+    def __repr__(self):
+        return 'DeferredStats(%r)' % (self._value if self._value is not None else '<in flight>')
 
 
 class Learner(metaclass=AutoInitializeMeta):

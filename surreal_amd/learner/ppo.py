@@ -37,7 +37,7 @@ import torch
 from surreal_amd import _lib as L
 from surreal_amd import kernels as KN
 from surreal_amd.learner.aggregator import MultistepAggregatorWithInfo
-from surreal_amd.learner.base import Learner
+from surreal_amd.learner.base import Learner, DeferredStats
 from surreal_amd.model.ppo_net import DiagGauss, PPOModel
 from surreal_amd.utils import AttrDict
 
@@ -85,6 +85,9 @@ class PPOLearner(Learner):
         self.K = KN.default_kernels()       # raises when the HIP library / GPU is missing
         self.device = KN.default_device()
         self._dist, self.world_size, self.rank = _dist_info()
+        # statistics are read back asynchronously on a GPU (see _collect_stats)
+        self._pending_stats, self._trace, self._epochs_executed, self._kl_record = None, None, 0, []
+        self.lazy_stats = self.device != 'cpu' and bool(self.session_config.learner.get('lazy_stats', True))
 
         self.current_iteration = 0
         self.global_step = 0
@@ -1065,10 +1068,66 @@ class PPOLearner(Learner):
             t.copy_(c)
         torch.cuda.synchronize()
 
+    # what a learn() leaves behind for the host is read lazily (see _collect_stats)
+    @property
+    def trace(self):
+        self._flush_stats()
+        return self._trace
+
+    @trace.setter
+    def trace(self, v):
+        self._trace = v
+
+    @property
+    def epochs_executed(self):
+        self._flush_stats()
+        return self._epochs_executed
+
+    @epochs_executed.setter
+    def epochs_executed(self, v):
+        self._epochs_executed = v
+
+    @property
+    def kl_record(self):
+        self._flush_stats()
+        return self._kl_record
+
+    @kl_record.setter
+    def kl_record(self, v):
+        self._kl_record = v
+
     def _collect_stats(self, ws):
-        """one device->host read of the statistics block, then the reference's stats dict
+        """The statistics of this learn(): ONE device->host read of the statistics block.  On a GPU
+        the read is asynchronous (pinned buffer + event) and the returned mapping resolves itself
+        when first looked at -- at the latest right after the NEXT learn() has been enqueued -- so
+        the GPU never waits for the read-back and the Python that decodes it."""
+        snap = {'beta': getattr(self, 'beta', None), 'clip_epsilon': getattr(self, 'clip_epsilon', None),
+                'lr': self.actor_lr_scheduler.get_lr()[0]}       # (each mode defines only its own)
+        if self.use_r_filter:
+            snap['reward_mean'] = self._rf_sum / self._rf_count            # 0-d device tensor
+        if not self.lazy_stats:
+            return self._decode_stats(ws.scal.cpu(), snap)
+        self._flush_stats()                        # the previous learn's, now that this one is queued
+        if getattr(ws, 'scal_host', None) is None:
+            ws.scal_host = torch.empty(ws.scal.shape, dtype=ws.scal.dtype, pin_memory=True)
+        ws.scal_host.copy_(ws.scal, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        handle = DeferredStats(self._flush_stats)
+        self._pending_stats = (ev, ws.scal_host, snap, handle)
+        return handle
+
+    def _flush_stats(self):
+        """wait for the read-back in flight (if any) and decode it"""
+        pend, self._pending_stats = self._pending_stats, None
+        if pend is not None:
+            ev, host, snap, handle = pend
+            ev.synchronize()
+            handle._value = self._decode_stats(host, snap)
+
+    def _decode_stats(self, scal, snap):
+        """host copy of the statistics block -> the reference's stats dict
         (ppo.py:219-224, 278-284, 328-331, 559-586)"""
-        scal = ws.scal.cpu()
         ctrl_i = scal[:L.CTRL_WORDS].view(torch.int32)
         o = L.CTRL_WORDS
         Ep, Ev = self.epoch_policy, self.epoch_baseline
@@ -1086,10 +1145,10 @@ class PPOLearner(Learner):
                  '_pol_kl': float(ps[e + 1, L.PS_KL])}
             if self.ppo_mode == 'clip':
                 d['_clip_surr_loss'] = float(ps[e, L.PS_LOSS])
-                d['_clip_epsilon'] = self.clip_epsilon
+                d['_clip_epsilon'] = snap['clip_epsilon']
             else:
                 d['_kl_loss_adapt'] = float(ps[e, L.PS_LOSS])
-                d['_beta'] = self.beta
+                d['_beta'] = snap['beta']
             if self.clip_actor_gradient:
                 d['grad_norm_actor'] = float(ps[e, L.PS_GRADNORM])
             trace['policy'].append(d)
@@ -1098,23 +1157,23 @@ class PPOLearner(Learner):
             if self.clip_critic_gradient:
                 d['grad_norm_critic'] = float(vs[e, L.VS_GRADNORM])
             trace['value'].append(d)
-        self.trace = trace
-        self.epochs_executed = done
+        self._trace = trace
+        self._epochs_executed = done
         stats = dict(trace['policy'][last])
-        self.kl_record.append(stats['_pol_kl'])                          # ppo.py:559
+        self._kl_record.append(stats['_pol_kl'])                         # ppo.py:559
         stats.update(trace['value'][-1])                                 # ppo.py:565-566
         stats['_avg_return_targ'] = float(ret_mom[1])
         stats['_avg_log_sig'] = float(fin[0])
         stats['_avg_behave_likelihood'] = float(ps[done, L.PS_LB])
         stats['_avg_is_weight'] = float(ps[done, L.PS_ISW])
         stats['_ref_behave_diff'] = float(ps[done, L.PS_REFBEH])
-        stats['_lr'] = self.actor_lr_scheduler.get_lr()[0]
+        stats['_lr'] = snap['lr']
         if self.use_z_filter:           # ppo.py:580-583, means formed on the device (final_stats)
             stats['obs_running_mean'] = float(fin[1])
             stats['obs_running_square'] = float(fin[2])
             stats['obs_running_std'] = float(fin[3])
         if self.use_r_filter:
-            stats['reward_mean'] = float((self._rf_sum / self._rf_count).item())
+            stats['reward_mean'] = float(snap['reward_mean'].item())
         return stats
 
     def learn(self, batch):

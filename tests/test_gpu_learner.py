@@ -155,3 +155,25 @@ def test_learns_on_moving_batches_use_staging_graph():
         captures.append(id(next(iter(learner._graphs.values()))))
     assert learner._ws.staged is not None and len(learner._graphs) == 1
     assert captures[1] == captures[2] == captures[3]       # one staging-graph capture, then replays
+
+
+def test_deferred_statistics_equal_the_synchronous_read():
+    """learn() returns a mapping whose device -> host read-back resolves lazily (at the latest when
+    the next learn() has been enqueued): every step's statistics, the trace and the counters must be
+    what the synchronous read gives, in whatever order they are looked at"""
+    from surreal_amd.learner.base import DeferredStats
+    g, case = H.load_golden('cfg2_adapt')
+    batch, params, zstate = H.case_inputs(case)
+    runs = {}
+    for lazy in (False, True):
+        learner = H.make_learner(case, params, zstate, session_overrides={'lazy_stats': lazy})
+        assert learner.lazy_stats == lazy
+        out = [learner.learn(copy.deepcopy(batch)) for _ in range(3)]       # nothing looked at yet
+        assert isinstance(out[0], DeferredStats) == lazy
+        last_trace, done = learner.trace, learner.epochs_executed             # resolves the last one
+        runs[lazy] = ([dict(o) for o in out], last_trace, done, list(learner.kl_record),
+                      dict(learner.tensorplex.latest), learner.model.actor_flat.cpu().clone())
+    a, b = runs[False], runs[True]
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+    assert torch.equal(a[5], b[5])
+    assert a[0][0] != a[0][1]                                                 # three different steps
