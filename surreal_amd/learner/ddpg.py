@@ -30,7 +30,7 @@ import torch
 from surreal_amd import _lib as L
 from surreal_amd import kernels as KN
 from surreal_amd.learner.aggregator import SSARAggregator
-from surreal_amd.learner.base import Learner
+from surreal_amd.learner.base import Learner, DeferredStats
 from surreal_amd.model.ddpg_net import DDPGModel
 from surreal_amd.session import ConfigError
 
@@ -51,6 +51,8 @@ class DDPGLearner(Learner):
         self.use_action_regularization = net.use_action_regularization
         self._target_update_init()
         self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu'
+        self._pending_stats = None
+        self.lazy_stats = self.device != 'cpu' and bool(self.session_config.learner.get('lazy_stats', True))
         self.clip_actor_gradient = net.clip_actor_gradient
         self.actor_gradient_clip_value = net.actor_gradient_value_clip if self.clip_actor_gradient else 0.0
         self.clip_critic_gradient = net.clip_critic_gradient
@@ -279,13 +281,40 @@ class DDPGLearner(Learner):
         ws.dev_step = self.critic_step
         if self.target_update_type == 'hard':
             self.target_update_counter += 1
-        st = ws.stats.cpu().numpy()                  # the iteration's one read-back
+        return self._collect_stats(ws)
+
+    def _collect_stats(self, ws):
+        """the iteration's one read-back; asynchronous on a GPU (resolved when looked at, at the latest
+        after the next iteration has been enqueued -- see learner/base.py DeferredStats)"""
+        if not self.lazy_stats:
+            return self._decode_stats(ws.stats.cpu(), ws.stats2.cpu() if self.use_double_critic else None)
+        self._flush_stats()
+        if getattr(ws, 'stats_host', None) is None:
+            ws.stats_host = torch.empty(2, 8, pin_memory=True)
+        ws.stats_host[0].copy_(ws.stats, non_blocking=True)
+        if self.use_double_critic:
+            ws.stats_host[1].copy_(ws.stats2, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        handle = DeferredStats(self._flush_stats)
+        self._pending_stats = (ev, ws.stats_host, handle)
+        return handle
+
+    def _flush_stats(self):
+        pend, self._pending_stats = self._pending_stats, None
+        if pend is not None:
+            ev, host, handle = pend
+            ev.synchronize()
+            handle._value = self._decode_stats(host[0], host[1] if self.use_double_critic else None)
+
+    def _decode_stats(self, st, st2):
+        st = st.numpy()
         amax = float(st[6])
         assert amax <= 1.0, 'actions must lie in [-1, 1] (ddpg.py:262-263), got |a| = %g' % amax
         out = {'actor_loss': float(st[0]), 'critic_loss': float(st[1]), 'action_norm': float(st[2]),
                'rewards': float(st[3]), 'Q_target': float(st[4]), 'Q_policy': float(st[5])}
-        if self.use_double_critic:
-            st2 = ws.stats2.cpu().numpy()
+        if st2 is not None:
+            st2 = st2.numpy()
             out['critic_loss'], out['Q_policy2'] = float(st2[1]), float(st2[5])
         return out
 
