@@ -84,6 +84,14 @@ class DeferredStats(collections.abc.Mapping):
     def __repr__(self):
         return 'DeferredStats(%r)' % (self._value if self._value is not None else '<in flight>')
 
+    def __reduce__(self):
+        # crossing a process boundary (pickle, multiprocessing queues): the resolved values travel as
+        # a plain dict -- never the learner behind the resolver
+        return (dict, (dict(self._get()),))
+
+    def copy(self):
+        return dict(self._get())
+
 
 class Learner(metaclass=AutoInitializeMeta):
     def __init__(self, learner_config, env_config, session_config):

@@ -720,8 +720,8 @@ class PPOLearner(Learner):
         if self.use_z_filter:
             zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed by the critic pass
             K.zfilter_forward(obs0, zm, zs, ws.xn)
-            rzm, rzs = ref.z_filter.refresh_stats()
-            K.zfilter_forward(obs0, rzm, rzs, ws.xr)
+            rz = ref.z_filter               # statistics + filter in one launch
+            K.zfilter_forward_sums(obs0, rz.running_sum, rz.running_sumsq, rz.count, rz.eps, ws.xr)
         else:
             ws.xn.copy_(obs0)
             ws.xr.copy_(obs0)

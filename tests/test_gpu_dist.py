@@ -53,7 +53,7 @@ def _worker(rank, world, port, name, q):
         assert str(learner.device).startswith('cuda')
         stats = learner.learn(shard(batch))
         cpu = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
-        out = {'stats': stats, 'trace': learner.trace, 'adv': cpu(learner._ws.adv), 'ret': cpu(learner._ws.ret),
+        out = {'stats': dict(stats), 'trace': learner.trace, 'adv': cpu(learner._ws.adv), 'ret': cpu(learner._ws.ret),
                'actor': cpu(learner.model.actor_flat), 'critic': cpu(learner.model.critic_flat),
                'z': {k: cpu(v) for k, v in learner.model.z_filter.state_dict().items()}
                if zstate is not None else None,
@@ -78,7 +78,7 @@ def test_two_rank_hip_learner_equals_single_learner(name):
     res = {}
     try:
         for _ in range(world):
-            r, out = q.get(timeout=600)
+            r, out = q.get(timeout=240)
             res[r] = out
     finally:
         for p in procs:
@@ -116,7 +116,7 @@ def test_bench_two_ranks_share_one_gpu():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]

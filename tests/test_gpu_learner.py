@@ -170,6 +170,8 @@ def test_deferred_statistics_equal_the_synchronous_read():
         assert learner.lazy_stats == lazy
         out = [learner.learn(copy.deepcopy(batch)) for _ in range(3)]       # nothing looked at yet
         assert isinstance(out[0], DeferredStats) == lazy
+        import pickle
+        assert pickle.loads(pickle.dumps(out[0])) == dict(out[0])                 # travels as a plain dict
         last_trace, done = learner.trace, learner.epochs_executed             # resolves the last one
         runs[lazy] = ([dict(o) for o in out], last_trace, done, list(learner.kl_record),
                       dict(learner.tensorplex.latest), learner.model.actor_flat.cpu().clone())
