@@ -50,7 +50,12 @@ class DDPGLearner(Learner):
         self.use_double_critic = net.use_double_critic
         self.use_action_regularization = net.use_action_regularization
         self._target_update_init()
-        self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu'
+        # data-parallel: every rank owns batch_size samples of the global batch (uniform replay shards
+        # per GPU, ddpg_configs.py:89-93 / SURVEY.md 8(e)); gradients are averaged before each Adam step
+        from surreal_amd.learner.ppo import _dist_info
+        self._dist, self.world_size, self.rank = _dist_info()
+        self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu' \
+            and self.world_size == 1
         self._pending_stats = None
         self.lazy_stats = self.device != 'cpu' and bool(self.session_config.learner.get('lazy_stats', True))
         self.clip_actor_gradient = net.clip_actor_gradient
@@ -153,6 +158,12 @@ class DDPGLearner(Learner):
                 o += v.numel()
             ws.stats2 = torch.zeros(8, device=self.device)
         ws.graph = None
+        self._rank_weight = 1.0
+        if self.world_size > 1:            # a rank's share of the global batch: the means are weighted sums
+            mine = torch.tensor([B], dtype=torch.int64, device=self.device)
+            every = torch.empty(self.world_size, dtype=torch.int64, device=self.device)
+            self._dist.all_gather_into_tensor(every, mine)
+            self._rank_weight = float(B) / float(sum(every.tolist()))
         self._ws = ws
         return ws
 
@@ -175,6 +186,13 @@ class DDPGLearner(Learner):
         K.linear_wgrad(ws.dxcat, x, gc['W1'], gc['b1'], c1, D, B, ldz=c1 + A)
         K.linear_wgrad(ws.dz2, xcat, gc['W2'], gc['b2'], c2, c1 + A, B)
         K.linear_wgrad(dz3, h2c, gc['W3'], gc['b3'], 1, c2, B, ldz=1)
+
+    def _average_over_ranks(self, t):
+        """a per-rank mean -> the mean over the global batch: weighted by the rank's share of it, then
+        one all-reduce; a no-op for one rank"""
+        if self.world_size > 1:
+            t.mul_(self._rank_weight)
+            self._dist.all_reduce(t)
 
     def _enqueue_iteration(self, ws, x, xn, actions, rewards, done):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
@@ -203,6 +221,7 @@ class DDPGLearner(Learner):
             self.model2.critic_forward_into(x, actions, ws.xcat2, ws.h2c2, ws.q2)
         K.ddpg_critic_loss_step(ws.q, q_next, rewards, done, gamma_n, ws.y, ws.dz3, ws.step)
         self._critic_backward(ws, x, B)
+        self._average_over_ranks(ws.grads_c)
         K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                         ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
         ws.q_policy.copy_(ws.q)
@@ -210,11 +229,13 @@ class DDPGLearner(Learner):
             m2 = self.model2
             K.ddpg_critic_loss(ws.q2, q_next, rewards, done, gamma_n, ws.y2, ws.dz3_2)
             self._critic_backward(ws, x, B, model=m2, dz3=ws.dz3_2, xcat=ws.xcat2, h2c=ws.h2c2, gc=ws.gc2)
+            self._average_over_ranks(ws.grads_c2)
             K.adam_step_dev(m2.critic_flat, ws.grads_c2, self.critic2_exp_avg, self.critic2_exp_avg_sq,
                             ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
             # the reference reports the SECOND critic's loss as 'critic_loss' (it overwrites the
             # variable, ddpg.py:313) and adds Q_policy2
             K.ddpg_stats(ws.q2, ws.y2, rewards, actions, ws.q2, ws.stats2)
+            self._average_over_ranks(ws.stats2[:6])
         # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)) ----
         K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
         m.critic_forward_into(x, ws.act, ws.xcat, ws.h2c, ws.q_actor)
@@ -227,9 +248,11 @@ class DDPGLearner(Learner):
         ws.dz3a.copy_(ws.dxcat[:, c1:])        # dense [B, A]
         K.tanh_backward(ws.dz3a, ws.act, ws.dz3a)
         K.mlp3_backward(m.actor, x, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a, ws.grads_a, None)
+        self._average_over_ranks(ws.grads_a)
         K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                         ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
         K.ddpg_stats(ws.q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
+        self._average_over_ranks(ws.stats[:6])       # means over the global batch (max |a| stays local)
         # ---- target networks (ddpg.py:389-428) ----
         pairs = [(mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat)]
         if self.use_double_critic:

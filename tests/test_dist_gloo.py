@@ -99,3 +99,76 @@ def test_two_rank_learner_equals_single_learner(name):
         for k in ('running_sum', 'running_sumsq', 'count'):
             np.testing.assert_array_equal(res[0]['z'][k], res[1]['z'][k])
             np.testing.assert_allclose(res[0]['z'][k], g['zfinal.' + k], rtol=1e-6)
+
+
+def _ddpg_worker(rank, world, port, name, q):
+    try:
+        import json
+        import torch.distributed as dist
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+        from surreal_amd import kernels as KN, synthetic
+        from cpu_kernels import TorchCpuKernels
+        KN.set_default_kernels(TorchCpuKernels(), 'cpu')
+        import ddpg_helpers as DH
+        g, case = DH.load(name)
+        B = case['B']
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        local = copy.deepcopy(case)
+        local['B'] = hi - lo
+        L = DH.make_learner(local)
+        assert L.world_size == world
+        trace = []
+        for it in range(case['iters']):
+            b = synthetic.make_ddpg_batch(B, case['D'], case['A'], seed=10 + it)
+
+            def cut(x):
+                if isinstance(x, dict):
+                    return {k: cut(v) for k, v in x.items()}
+                return x[lo:hi]
+            trace.append(dict(L.learn(cut(b))))
+        q.put((rank, {'trace': trace, 'params': L.model.numpy_params(), 'target': L.model_target.numpy_params()}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+
+
+@pytest.mark.parametrize('name', ['tiny_hard', 'tiny_double_soft'])
+def test_two_rank_ddpg_equals_single_learner(name):
+    """data-parallel DDPG: each rank learns on half of every batch, gradients are averaged before
+    each Adam step -> the single reference learner's trace, identical replicas"""
+    import json
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddpg_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, out = q.get(timeout=300)
+        res[r] = out
+    for p in procs:
+        p.join(60)
+    for r in range(world):
+        assert 'error' not in res[r], res[r].get('error')
+    g = np.load(os.path.join(H.GOLDEN_DIR, 'ddpg_%s.npz' % name))
+    ref = json.loads(str(g['trace_json']))
+    for r in range(world):
+        for it, want in enumerate(ref):
+            for k, v in want.items():
+                if k == 'action_norm' or k == 'rewards':       # means over the global batch as well
+                    pass
+                np.testing.assert_allclose(res[r]['trace'][it][k], v, atol=2e-5, rtol=2e-5,
+                                           err_msg='%s rank %d iteration %d %s' % (name, r, it, k))
+    for k in res[0]['params']:
+        np.testing.assert_array_equal(res[0]['params'][k], res[1]['params'][k])
+        np.testing.assert_array_equal(res[0]['target'][k], res[1]['target'][k])
+        if 'final.' + k in g:
+            assert np.mean(np.abs(res[0]['params'][k] - g['final.' + k]) > 2e-5) < 0.03, k
