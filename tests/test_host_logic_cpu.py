@@ -100,3 +100,34 @@ def test_cnn_stem_chunked_critic_pass_with_a_tail(name, cpu_double):
     stats = learner.learn(copy.deepcopy(batch))
     H.assert_trace_close(learner.trace, g, what=name)
     H.assert_stats_close(stats, g, what=name)
+
+
+def test_deferred_stats_and_scalar_recorder():
+    """DeferredStats resolves once, when first looked at; ScalarRecorder stores it untouched and folds
+    it into `latest` on demand (also when old history is trimmed); it pickles as a plain dict"""
+    import pickle
+    from surreal_amd.learner.base import DeferredStats, ScalarRecorder
+    calls = []
+
+    def make(value):
+        box = {}
+
+        def resolve():
+            calls.append(value['k'])
+            box['d']._value = dict(value)
+        box['d'] = DeferredStats(resolve)
+        return box['d']
+    rec = ScalarRecorder(keep=3)
+    a, b = make({'k': 1, 'x': 1.0}), make({'k': 2, 'y': 2.0})
+    rec.add_scalars(a, 1)
+    rec.add_scalars({'k': 0, 'z': 9.0}, 2)
+    rec.add_scalars(b, 3)
+    assert calls == []                                   # nothing has been looked at
+    assert 'x' in a and calls == [1] and a['x'] == 1.0 and len(a) == 2 and calls == [1]
+    assert rec.latest == {'k': 2, 'x': 1.0, 'z': 9.0, 'y': 2.0} and calls == [1, 2]
+    c = make({'k': 3, 'w': 4.0})
+    rec.add_scalars(c, 4)
+    rec.add_scalars({'k': 5}, 5)                         # trims: everything dropped was folded first
+    assert len(rec.history) == 3 and rec.latest['w'] == 4.0 and rec.latest['k'] == 5 and rec.latest['x'] == 1.0
+    assert pickle.loads(pickle.dumps(c)) == {'k': 3, 'w': 4.0} and c.copy() == dict(c)
+    assert 'in flight' in repr(make({'k': 7}))
