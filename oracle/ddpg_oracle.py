@@ -33,6 +33,29 @@ def make_ddpg_params(D, A, actor_hidden=(300, 200), critic_hidden=(400, 300), se
     return p
 
 
+def make_ddpg_pixel_params(low_dim, A, pixel, conv_hidden, actor_hidden, critic_hidden, seed=3,
+                           channels=(16, 32), kernels=(8, 4), strides=(4, 2)):
+    """parameters of the pixel DDPGModel (ddpg_net.py:37-51): CNNStemNetwork perception (builders.py:8-33)
+    whose features are concatenated IN FRONT of the low-dim vector (ddpg_net.py:67-78), then the
+    MLPs over conv_hidden + low_dim inputs.  cnn.* names as in oracle/ppo_oracle.py."""
+    C, H, W = pixel
+    p = make_ddpg_params(conv_hidden + low_dim, A, actor_hidden, critic_hidden, seed=seed)
+    rs = np.random.RandomState(seed + 1000)
+    h1, w1 = (H - kernels[0]) // strides[0] + 1, (W - kernels[0]) // strides[0] + 1
+    h2, w2 = (h1 - kernels[1]) // strides[1] + 1, (w1 - kernels[1]) // strides[1] + 1
+
+    def u(shape, fan):
+        b = 1.0 / np.sqrt(fan)
+        return rs.uniform(-b, b, shape).astype(np.float32)
+    p['cnn.conv1.W'] = u((channels[0], C, kernels[0], kernels[0]), C * kernels[0] ** 2)
+    p['cnn.conv1.b'] = u((channels[0],), C * kernels[0] ** 2)
+    p['cnn.conv2.W'] = u((channels[1], channels[0], kernels[1], kernels[1]), channels[0] * kernels[1] ** 2)
+    p['cnn.conv2.b'] = u((channels[1],), channels[0] * kernels[1] ** 2)
+    p['cnn.fc.W'] = u((conv_hidden, channels[1] * h2 * w2), channels[1] * h2 * w2)
+    p['cnn.fc.b'] = u((conv_hidden,), channels[1] * h2 * w2)
+    return p
+
+
 class OracleDDPGModel(object):
     def __init__(self, params):
         self.p = collections.OrderedDict(
@@ -43,7 +66,25 @@ class OracleDDPGModel(object):
         return [v for k, v in self.p.items() if k.startswith('actor.')]
 
     def critic_params(self):
-        return [v for k, v in self.p.items() if k.startswith('critic.')]
+        # the perception CNN trains with the critic (ddpg_net.py:57-61)
+        return [v for k, v in self.p.items() if k.startswith('critic.') or k.startswith('cnn.')]
+
+    strides = (4, 2)
+
+    def forward_perception(self, obs):                # ddpg_net.py:67-78, builders.py:8-33
+        if not isinstance(obs, dict):
+            return obs
+        parts = []
+        if 'pixel' in obs:
+            p = self.p
+            x = obs['pixel']['camera0'] / 255.0       # scale_image (ddpg_net.py:90-95)
+            x = torch.relu(F.conv2d(x, p['cnn.conv1.W'], p['cnn.conv1.b'], stride=self.strides[0]))
+            x = torch.relu(F.conv2d(x, p['cnn.conv2.W'], p['cnn.conv2.b'], stride=self.strides[1]))
+            x = torch.relu(F.linear(x.reshape(x.shape[0], -1), p['cnn.fc.W'], p['cnn.fc.b']))
+            parts.append(x)
+        if 'low_dim' in obs:
+            parts.append(obs['low_dim']['flat_inputs'])
+        return torch.cat(parts, dim=1)
 
     def forward_actor(self, x):                       # builders.py:35-56
         p = self.p
@@ -70,7 +111,7 @@ class OracleDDPGModel(object):
         """the second critic's target follows only the critic (ddpg.py:412-415, 422-425)"""
         with torch.no_grad():
             for k in self.p:
-                if not k.startswith('critic.'):
+                if not (k.startswith('critic.') or k.startswith('cnn.')):     # + perception (ddpg.py:414-415)
                     continue
                 if tau is None:
                     self.p[k].copy_(other.p[k])
@@ -116,6 +157,8 @@ class OracleDDPGLearner(object):
     def optimize(self, obs, actions, rewards, obs_next, done):   # ddpg.py:244-352
         m, mt = self.model, self.model_target
         assert actions.max().item() <= 1.0 and actions.min().item() >= -1.0
+        obs_next_raw, obs_raw = obs_next, obs
+        obs_next = mt.forward_perception(obs_next)               # ddpg_net.py:80-88
         model_policy = mt.forward_actor(obs_next)
         next_Q_target = mt.forward_critic(obs_next, model_policy)
         if self.use_action_regularization:                       # ddpg.py:267-278: AFTER next_Q_target
@@ -124,12 +167,15 @@ class OracleDDPGLearner(object):
             model_policy = model_policy.clamp(-1, 1)
         y = rewards + pow(self.gamma, self.n_step) * next_Q_target * (1.0 - done)
         if self.use_double_critic:                               # ddpg.py:280-283
-            next_Q_target2 = self.model_target2.forward_critic(obs_next, model_policy)
+            next_Q_target2 = self.model_target2.forward_critic(
+                self.model_target2.forward_perception(obs_next_raw), model_policy)
             y2 = rewards + pow(self.gamma, self.n_step) * next_Q_target2 * (1.0 - done)
             y = torch.min(y, y2)
         y = y.detach()
+        obs = m.forward_perception(obs_raw)                      # ddpg.py:287
         y_policy = m.forward_critic(obs, actions.detach())
-        y_policy2 = self.model2.forward_critic(obs, actions.detach()) if self.use_double_critic else None
+        y_policy2 = self.model2.forward_critic(self.model2.forward_perception(obs_raw), actions.detach()) \
+            if self.use_double_critic else None
         for q in m.critic_params():
             q.grad = None
         critic_loss = self.critic_criterion(y_policy, y)
@@ -180,6 +226,11 @@ class OracleDDPGLearner(object):
 
     def learn(self, batch):
         t = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).clone()  # noqa: E731
+        if 'pixel' in batch['obs']:                              # ddpg.py:207-222: uint8 -> float
+            conv = lambda o: {'pixel': {'camera0': t(o['pixel']['camera0'])},  # noqa: E731
+                              'low_dim': {'flat_inputs': t(o['low_dim']['flat_inputs'])}}
+            return self.optimize(conv(batch['obs']), t(batch['actions']), t(batch['rewards']),
+                                 conv(batch['obs_next']), t(batch['dones']))
         return self.optimize(t(batch['obs']['low_dim']['flat_inputs']), t(batch['actions']),
                              t(batch['rewards']), t(batch['obs_next']['low_dim']['flat_inputs']),
                              t(batch['dones']))

@@ -27,15 +27,35 @@ def lin_layers(net_functional):
     return [l for l in net_functional.layers if hasattr(l, 'fc')]
 
 
+def _perception_layers(m):
+    ls = [l for l in m.perception.model.layers if hasattr(l, 'conv') or hasattr(l, 'fc')]
+    return collections.OrderedDict(zip(('conv1', 'conv2', 'fc'), ls))
+
+
 def inject(m, params):
     with torch.no_grad():
-        for i, l in enumerate(lin_layers(m.actor.model)):
+        if getattr(m, 'is_pixel_input', False):
+            for nm, layer in _perception_layers(m).items():
+                mod = layer.conv if hasattr(layer, 'conv') else layer.fc
+                mod.weight.copy_(torch.tensor(params['cnn.%s.W' % nm]))
+                mod.bias.copy_(torch.tensor(params['cnn.%s.b' % nm]))
+        for i, l in enumerate(lin_layers(m.actor.model) if m.actor is not None else []):
             l.fc.weight.copy_(torch.tensor(params['actor.fc%d.W' % (i + 1)]))
             l.fc.bias.copy_(torch.tensor(params['actor.fc%d.b' % (i + 1)]))
         c = lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)
         for i, l in enumerate(c):
             l.fc.weight.copy_(torch.tensor(params['critic.fc%d.W' % (i + 1)]))
             l.fc.bias.copy_(torch.tensor(params['critic.fc%d.b' % (i + 1)]))
+
+
+def extract_perception(m):
+    out = collections.OrderedDict()
+    if getattr(m, 'is_pixel_input', False):
+        for nm, layer in _perception_layers(m).items():
+            mod = layer.conv if hasattr(layer, 'conv') else layer.fc
+            out['cnn.%s.W' % nm] = mod.weight.detach().numpy().copy()
+            out['cnn.%s.b' % nm] = mod.bias.detach().numpy().copy()
+    return out
 
 
 def extract(m):
@@ -46,6 +66,7 @@ def extract(m):
     for i, l in enumerate(lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)):
         out['critic.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
         out['critic.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    out.update(extract_perception(m))
     return out
 
 
@@ -54,6 +75,7 @@ def extract_critic(m):
     for i, l in enumerate(lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)):
         out['critic.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
         out['critic.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    out.update(extract_perception(m))
     return out
 
 
@@ -65,29 +87,32 @@ class _Timer(object):
         return contextlib.nullcontext()
 
 
-def build_ref(params, D, A, ah, ch, hyper, params2=None):
+def build_ref(params, D, A, ah, ch, hyper, params2=None, pixel=None, conv_hidden=200):
     L = object.__new__(DDPGLearner)
     L.batch_size = hyper['B']
     L.discount_factor, L.n_step = hyper['gamma'], hyper['n_step']
-    L.is_pixel_input = False
+    L.is_pixel_input = pixel is not None
     L.use_double_critic = bool(hyper.get('double_critic', False))
     L.use_action_regularization = bool(hyper.get('action_reg', False))
     L.gpu_ids, L._num_gpus = 'cpu', 0
     L.clip_actor_gradient, L.actor_gradient_clip_value = True, 1.0
     L.clip_critic_gradient, L.critic_gradient_clip_value = hyper.get('clip_critic', False), 5.0
     L.action_dim = A
-    obs_spec = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=[D]))
-    mk = lambda: DDPGModel(obs_spec=obs_spec, action_dim=A, use_layernorm=False,  # noqa: E731
-                           actor_fc_hidden_sizes=list(ah), critic_fc_hidden_sizes=list(ch),
-                           conv_out_channels=[16, 32], conv_kernel_sizes=[8, 4], conv_strides=[4, 2],
-                           conv_hidden_dim=200)
+    obs_spec = collections.OrderedDict()
+    if pixel is not None:                                   # ddpg_net.py:37-44: the CNN perception
+        obs_spec['pixel'] = collections.OrderedDict(camera0=list(pixel))
+    obs_spec['low_dim'] = collections.OrderedDict(flat_inputs=[D])
+    mk = lambda **kw: DDPGModel(obs_spec=obs_spec, action_dim=A, use_layernorm=False,  # noqa: E731
+                                actor_fc_hidden_sizes=list(ah), critic_fc_hidden_sizes=list(ch),
+                                conv_out_channels=[16, 32], conv_kernel_sizes=[8, 4], conv_strides=[4, 2],
+                                conv_hidden_dim=conv_hidden, **kw)
     L.model, L.model_target = mk(), mk()
     inject(L.model, params)
     inject(L.model_target, params)
     L.critic_criterion = torch.nn.MSELoss()
     L.critic_optim = torch.optim.Adam(L.model.get_critic_parameters(), lr=hyper['lr_critic'])
     if L.use_double_critic:                                # ddpg.py:119-147, 162-166
-        L.model2, L.model_target2 = mk(), mk()
+        L.model2, L.model_target2 = mk(critic_only=True), mk(critic_only=True)
         inject(L.model2, params2)
         inject(L.model_target2, params2)
         L.critic_optim2 = torch.optim.Adam(L.model2.get_critic_parameters(), lr=hyper['lr_critic'])
@@ -115,6 +140,13 @@ CASES = {
                              hyper=dict(gamma=0.95, n_step=2, lr_actor=1e-3, lr_critic=1e-2, double_critic=True,
                                         target_update_type='soft', target_update_interval=1, tau=0.1,
                                         clip_critic=True)),
+    'tiny_pixel_hard': dict(B=12, D=4, A=2, ah=(24, 16), ch=(32, 24), iters=4, pixel=(2, 20, 24), conv_hidden=8,
+                            hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-3, lr_critic=1e-2,
+                                       target_update_type='hard', target_update_interval=2)),
+    'tiny_pixel_td3_soft': dict(B=10, D=3, A=2, ah=(24, 16), ch=(32, 24), iters=3, pixel=(3, 28, 36), conv_hidden=16,
+                                hyper=dict(gamma=0.95, n_step=2, lr_actor=1e-3, lr_critic=1e-2, double_critic=True,
+                                           action_reg=True, target_update_type='soft', target_update_interval=1,
+                                           tau=0.1, clip_critic=True)),
     'cfg3_cheetah512': dict(B=512, D=17, A=6, ah=(300, 200), ch=(400, 300), iters=3,
                             hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-4, lr_critic=1e-3,
                                        target_update_type='hard', target_update_interval=500)),
@@ -124,9 +156,15 @@ CASES = {
 def main():
     for name, c in CASES.items():
         hyper = dict(c['hyper'], B=c['B'])
-        params = ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=3)
-        params2 = ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=4)
-        Lr = build_ref(params, c['D'], c['A'], c['ah'], c['ch'], hyper, params2)
+        pixel = tuple(c['pixel']) if c.get('pixel') else None
+        if pixel is not None:
+            mkp = lambda seed: ddpg_oracle.make_ddpg_pixel_params(  # noqa: E731
+                c['D'], c['A'], pixel, c['conv_hidden'], c['ah'], c['ch'], seed=seed)
+        else:
+            mkp = lambda seed: ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=seed)  # noqa: E731
+        params, params2 = mkp(3), mkp(4)
+        Lr = build_ref(params, c['D'], c['A'], c['ah'], c['ch'], hyper, params2, pixel=pixel,
+                       conv_hidden=c.get('conv_hidden', 200))
         O = ddpg_oracle.OracleDDPGLearner(
             use_double_critic=hyper.get('double_critic', False),
             use_action_regularization=hyper.get('action_reg', False), params2=params2, batch_size=c['B'],
@@ -136,10 +174,16 @@ def main():
             target_update_interval=hyper['target_update_interval'], tau=hyper.get('tau', 1e-3))
         traces = []
         for it in range(c['iters']):
-            b = synthetic.make_ddpg_batch(c['B'], c['D'], c['A'], seed=10 + it)
+            b = synthetic.make_ddpg_batch(c['B'], c['D'], c['A'], seed=10 + it, pixel=pixel)
             t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)  # noqa: E731
-            obs = {'low_dim': {'flat_inputs': t(b['obs']['low_dim']['flat_inputs'])}}
-            obs_next = {'low_dim': {'flat_inputs': t(b['obs_next']['low_dim']['flat_inputs'])}}
+
+            def conv(o):                     # what DDPGLearner.preprocess hands over (ddpg.py:207-222)
+                out = collections.OrderedDict()
+                if pixel is not None:
+                    out['pixel'] = {'camera0': torch.tensor(o['pixel']['camera0'], dtype=torch.uint8).float()}
+                out['low_dim'] = {'flat_inputs': t(o['low_dim']['flat_inputs'])}
+                return out
+            obs, obs_next = conv(b['obs']), conv(b['obs_next'])
             np.random.seed(1000 + it)          # the action-regularisation noise comes from numpy's stream
             sr = Lr._optimize(obs, t(b['actions']), t(b['rewards']), obs_next, t(b['dones']))
             sr = {k: float(v) for k, v in sr.items() if not k.startswith('performance')}

@@ -31,6 +31,7 @@ class DDPGAgent(Agent):
         self.action_dim = self.env_config.action_spec.dim[0]
         self.obs_spec = self.env_config.obs_spec
         self.sleep_time = self.env_config.get('sleep_time', 0.0)
+        self.frame_stack_concatenate_on_env = self.env_config.get('frame_stack_concatenate_on_env', True)
         ex = self.learner_config.algo.exploration
         self.param_noise = None                              # ddpg_agent.py:68-72
         self.param_noise_type = ex.param_noise_type
@@ -45,10 +46,14 @@ class DDPGAgent(Agent):
             self.sigma = ex.max_sigma * (float(agent_id) / n_agents)
         self.K = KN.default_kernels()
         self.device = KN.default_device()
+        conv = self.learner_config.model.get('conv_spec', None) or {}
         self.model = DDPGModel(obs_spec=self.obs_spec, action_dim=self.action_dim,
                                use_layernorm=self.learner_config.model.use_layernorm,
                                actor_fc_hidden_sizes=self.learner_config.model.actor_fc_hidden_sizes,
                                critic_fc_hidden_sizes=self.learner_config.model.critic_fc_hidden_sizes,
+                               conv_out_channels=conv.get('out_channels'),
+                               conv_kernel_sizes=conv.get('kernel_sizes'), conv_strides=conv.get('strides'),
+                               conv_hidden_dim=conv.get('hidden_output_dim'),
                                device=self.device, kernels=self.K)
         self.sink = None
         self._init_noise()
@@ -88,11 +93,18 @@ class DDPGAgent(Agent):
     def act(self, obs):                                   # ddpg_agent.py:155-184
         if self.sleep_time > 0.0:
             time.sleep(self.sleep_time)
-        x = torch.as_tensor(np.asarray(obs['low_dim']['flat_inputs']), dtype=torch.float32) \
-            .unsqueeze(0).to(self.device)
-        action_t = self.model.forward_actor(x)
+        obs_t = collections.OrderedDict()                  # ddpg_agent.py:166-172 (frames stay uint8 here)
+        for modality in obs:
+            obs_t[modality] = collections.OrderedDict()
+            for key in obs[modality]:
+                v = np.asarray(obs[modality][key])
+                if modality == 'pixel' and not self.frame_stack_concatenate_on_env and v.ndim == 4:
+                    v = np.concatenate(list(v), axis=0)    # a list of stacked frames (ddpg_agent.py:159-165)
+                t = torch.as_tensor(v) if modality == 'pixel' else torch.as_tensor(v, dtype=torch.float32)
+                obs_t[modality][key] = t.unsqueeze(0).to(self.device)
+        action_t = self.model.forward_actor(self.model.forward_perception(obs_t))
         if self.param_noise and self.param_noise_type == 'adaptive_normal':
-            self.param_noise.compute_action_distance({'low_dim': {'flat_inputs': x}}, action_t)
+            self.param_noise.compute_action_distance(obs_t, action_t)
         action = action_t.cpu().numpy()[0]
         action = action.clip(-1, 1)
         if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:

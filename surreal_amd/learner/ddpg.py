@@ -18,8 +18,12 @@ the second critic's loss reported as the reference does) and ``use_action_regula
 reference's).  The iteration is captured once in a hipGraph and replayed: the Adam step count,
 the learning rates and the hard-update decision live on the device.
 
-Scope: low-dimensional observations, no LayerNorm (torchx's LayerNorm semantics are unpinned,
-SURVEY.md 8(c)); those switches raise.
+Pixel observations (ddpg_net.py:37-88): the perception CNN (model/cnn_stem.py, the PPO stem's
+kernels) runs on camera0 / 255, its features go in front of the low-dim vector, it is trained by
+the critic loss (Adam with the critic's hyper-parameters) and follows the target updates; the actor
+update reuses the features formed before the critic step, as the reference does.
+
+Not built: LayerNorm (torchx's LayerNorm semantics are unpinned); it raises.
 """
 import gc
 import types
@@ -66,21 +70,30 @@ class DDPGLearner(Learner):
         self.actor_regularization = net.actor_regularization
         self.critic_regularization = net.critic_regularization
         self.action_dim = self.env_config.action_spec.dim[0]
+        conv = self.learner_config.model.get('conv_spec', None) or {}
         mk = dict(obs_spec=self.env_config.obs_spec, action_dim=self.action_dim,
                   use_layernorm=self.use_layernorm,
                   actor_fc_hidden_sizes=self.learner_config.model.actor_fc_hidden_sizes,
                   critic_fc_hidden_sizes=self.learner_config.model.critic_fc_hidden_sizes,
+                  conv_out_channels=conv.get('out_channels'), conv_kernel_sizes=conv.get('kernel_sizes'),
+                  conv_strides=conv.get('strides'), conv_hidden_dim=conv.get('hidden_output_dim'),
                   device=self.device, kernels=self.K)
         self.model = DDPGModel(**mk)
         self.model_target = DDPGModel(**mk)
         self.model_target.load_state_dict(self.model.state_dict())       # hard_update (ddpg.py:175-176)
         z = torch.zeros_like
+        self.is_pixel_input = self.model.is_pixel_input
+        if self.is_pixel_input:         # the perception CNN is in the critic's optimiser (ddpg_net.py:57-61)
+            self.perc_exp_avg, self.perc_exp_avg_sq = z(self.model.perception_flat), z(self.model.perception_flat)
         if self.use_double_critic:
             # TD3's second critic (ddpg.py:119-147, 162-166, 177-178): own parameters, optimiser, target
             self.model2 = DDPGModel(critic_only=True, **mk)
             self.model_target2 = DDPGModel(critic_only=True, **mk)
             self.model_target2.load_state_dict(self.model2.state_dict())
             self.critic2_exp_avg, self.critic2_exp_avg_sq = z(self.model2.critic_flat), z(self.model2.critic_flat)
+            if self.is_pixel_input:
+                self.perc2_exp_avg = z(self.model2.perception_flat)
+                self.perc2_exp_avg_sq = z(self.model2.perception_flat)
         self.actor_exp_avg, self.actor_exp_avg_sq = z(self.model.actor_flat), z(self.model.actor_flat)
         self.critic_exp_avg, self.critic_exp_avg_sq = z(self.model.critic_flat), z(self.model.critic_flat)
         self.actor_step = 0
@@ -110,7 +123,12 @@ class DDPGLearner(Learner):
         for key in ('obs', 'obs_next'):
             for modality in batch[key]:
                 for k in batch[key][modality]:
-                    batch[key][modality][k] = self._to_dev(batch[key][modality][k])
+                    v = batch[key][modality][k]
+                    if modality == 'pixel':      # stay uint8: the patch kernel applies / 255 while reading
+                        v = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+                        batch[key][modality][k] = v.to(self.device)
+                    else:
+                        batch[key][modality][k] = self._to_dev(v)
         for key in ('actions', 'rewards', 'dones'):
             batch[key] = self._to_dev(batch[key])
         return batch
@@ -157,6 +175,22 @@ class DDPGLearner(Learner):
                 ws.gc2[name] = ws.grads_c2[o:o + v.numel()].view(v.shape)
                 o += v.numel()
             ws.stats2 = torch.zeros(8, device=self.device)
+        if self.is_pixel_input:
+            from surreal_amd.model.cnn_stem import CnnStem
+            cnn = m.cnn
+            Dx = m.input_dim
+            ws.xf, ws.xnf, ws.dxin = f(B, Dx), f(B, Dx), f(B, Dx)
+            ws.cnn = CnnStem.workspace(cnn, B, self.device, backward=True)
+            ws.cnn.sk = m._cnn_stem.splitk_workspace(cnn, B, self.device)
+            ws.cnn_t = CnnStem.workspace(cnn, B, self.device, backward=False)
+            ws.grads_p = torch.zeros_like(m.perception_flat)
+            if self.use_double_critic:
+                ws.xf2, ws.xnf2 = f(B, Dx), f(B, Dx)
+                ws.cnn2 = CnnStem.workspace(cnn, B, self.device, backward=True)
+                ws.cnn2.sk = ws.cnn.sk
+                ws.cnn_t2 = CnnStem.workspace(cnn, B, self.device, backward=False)
+                ws.grads_p2 = torch.zeros_like(m.perception_flat)
+            ws.s_pix = ws.s_pix_next = None              # staged frames (allocated in their dtype)
         ws.graph = None
         self._rank_weight = 1.0
         if self.world_size > 1:            # a rank's share of the global batch: the means are weighted sums
@@ -187,6 +221,16 @@ class DDPGLearner(Learner):
         K.linear_wgrad(ws.dz2, xcat, gc['W2'], gc['b2'], c2, c1 + A, B)
         K.linear_wgrad(dz3, h2c, gc['W3'], gc['b3'], 1, c2, B, ldz=1)
 
+    def _perception_backward(self, ws, model, xin, cnn_ws, grads_p):
+        """the critic loss's gradient through the perception CNN (ddpg.py:304-308: critic_loss.backward()
+        reaches model.perception): d(critic layer 1 input) = dz1 . W1, masked by the feature ReLU,
+        then the stem's own backward; ws.dxcat must still hold this critic's dz1"""
+        K, A = self.K, self.action_dim
+        c1, Dx = model.c1, model.input_dim
+        K.linear(ws.dxcat, 1, model.critic['W1'], 0, None, ws.dxin, xin.shape[0], Dx, c1, relu_mask=xin,
+                 lda=c1 + A, ldb=Dx)
+        model._cnn_stem.backward(model.cnn, xin.shape[0], cnn_ws, ws.dxin[:, :model.feat_dim], grads_p)
+
     def _average_over_ranks(self, t):
         """a per-rank mean -> the mean over the global batch: weighted by the rank's share of it, then
         one all-reduce; a no-op for one rank"""
@@ -194,10 +238,18 @@ class DDPGLearner(Learner):
             t.mul_(self._rank_weight)
             self._dist.all_reduce(t)
 
-    def _enqueue_iteration(self, ws, x, xn, actions, rewards, done):
+    def _enqueue_iteration(self, ws, x, xn, actions, rewards, done, pix=None, pix_next=None):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
         K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
         B = x.shape[0]
+        low, low_next = x, xn
+        if self.is_pixel_input:
+            # forward_perception (ddpg_net.py:67-78): [CNN(camera0 / 255) | low_dim]; the model's own
+            # features are formed ONCE, before the critic update, and reused by the actor update
+            # (ddpg.py:287, 326-327: perception.detach())
+            mt.perception_into(pix_next, low_next, ws.cnn_t, ws.xnf)
+            m.perception_into(pix, low, ws.cnn, ws.xf)
+            x, xn = ws.xf, ws.xnf
         # ---- target: y = r + gamma^n * Q'(s', mu'(s')) * (1 - done) ----
         K.mlp3_forward(mt.actor, xn, ws.h1a, ws.h2a, ws.act, L.SMX_ACT_TANH)
         mt.critic_forward_into(xn, ws.act, ws.xcat, ws.h2c, ws.q_next)
@@ -212,26 +264,46 @@ class DDPGLearner(Learner):
                 torch.add(ws.act, ws.s_noise, out=ws.act_n)
                 ws.act_n.clamp_(-1.0, 1.0)
                 a2 = ws.act_n
-            self.model_target2.critic_forward_into(xn, a2, ws.xcat2, ws.h2c2, ws.q_next2)
+            xn2 = xn
+            if self.is_pixel_input:                  # the second target has its own perception
+                self.model_target2.perception_into(pix_next, low_next, ws.cnn_t2, ws.xnf2)
+                xn2 = ws.xnf2
+            self.model_target2.critic_forward_into(xn2, a2, ws.xcat2, ws.h2c2, ws.q_next2)
             torch.minimum(ws.q_next, ws.q_next2, out=ws.q_next2)
             q_next = ws.q_next2
         # ---- critic update(s) ----
         m.critic_forward_into(x, actions, ws.xcat, ws.h2c, ws.q)
+        x2 = x
         if self.use_double_critic:
-            self.model2.critic_forward_into(x, actions, ws.xcat2, ws.h2c2, ws.q2)
+            if self.is_pixel_input:
+                self.model2.perception_into(pix, low, ws.cnn2, ws.xf2)
+                x2 = ws.xf2
+            self.model2.critic_forward_into(x2, actions, ws.xcat2, ws.h2c2, ws.q2)
         K.ddpg_critic_loss_step(ws.q, q_next, rewards, done, gamma_n, ws.y, ws.dz3, ws.step)
         self._critic_backward(ws, x, B)
+        if self.is_pixel_input:
+            self._perception_backward(ws, m, x, ws.cnn, ws.grads_p)
+            self._average_over_ranks(ws.grads_p)
         self._average_over_ranks(ws.grads_c)
         K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                         ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+        if self.is_pixel_input:
+            K.adam_step_dev(m.perception_flat, ws.grads_p, self.perc_exp_avg, self.perc_exp_avg_sq,
+                            ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
         ws.q_policy.copy_(ws.q)
         if self.use_double_critic:                       # ddpg.py:312-319
             m2 = self.model2
             K.ddpg_critic_loss(ws.q2, q_next, rewards, done, gamma_n, ws.y2, ws.dz3_2)
-            self._critic_backward(ws, x, B, model=m2, dz3=ws.dz3_2, xcat=ws.xcat2, h2c=ws.h2c2, gc=ws.gc2)
+            self._critic_backward(ws, x2, B, model=m2, dz3=ws.dz3_2, xcat=ws.xcat2, h2c=ws.h2c2, gc=ws.gc2)
+            if self.is_pixel_input:
+                self._perception_backward(ws, m2, x2, ws.cnn2, ws.grads_p2)
+                self._average_over_ranks(ws.grads_p2)
             self._average_over_ranks(ws.grads_c2)
             K.adam_step_dev(m2.critic_flat, ws.grads_c2, self.critic2_exp_avg, self.critic2_exp_avg_sq,
                             ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+            if self.is_pixel_input:
+                K.adam_step_dev(m2.perception_flat, ws.grads_p2, self.perc2_exp_avg, self.perc2_exp_avg_sq,
+                                ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
             # the reference reports the SECOND critic's loss as 'critic_loss' (it overwrites the
             # variable, ddpg.py:313) and adds Q_policy2
             K.ddpg_stats(ws.q2, ws.y2, rewards, actions, ws.q2, ws.stats2)
@@ -255,8 +327,12 @@ class DDPGLearner(Learner):
         self._average_over_ranks(ws.stats[:6])       # means over the global batch (max |a| stays local)
         # ---- target networks (ddpg.py:389-428) ----
         pairs = [(mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat)]
+        if self.is_pixel_input:
+            pairs.append((mt.perception_flat, m.perception_flat))
         if self.use_double_critic:
             pairs.append((self.model_target2.critic_flat, self.model2.critic_flat))
+            if self.is_pixel_input:
+                pairs.append((self.model_target2.perception_flat, self.model2.perception_flat))
         for tgt, src in pairs:
             if self.target_update_type == 'soft':
                 K.soft_update(tgt, src, self.target_update_tau)
@@ -278,6 +354,15 @@ class DDPGLearner(Learner):
         ws.s_act.copy_(actions.reshape(B, -1))
         ws.s_rew.copy_(rewards.reshape(-1))
         ws.s_done.copy_(done.reshape(-1))
+        frames = ()
+        if self.is_pixel_input:
+            pix, pix_next = obs['pixel']['camera0'], obs_next['pixel']['camera0']
+            if ws.s_pix is None or ws.s_pix.dtype != pix.dtype:
+                ws.s_pix, ws.s_pix_next = torch.empty_like(pix), torch.empty_like(pix_next)
+                ws.graph = None
+            ws.s_pix.copy_(pix)
+            ws.s_pix_next.copy_(pix_next)
+            frames = (ws.s_pix, ws.s_pix_next)
         if self.use_action_regularization:
             # ddpg.py:268-274: policy_noise 0.2 clipped at 0.5, from numpy's global stream
             noise = np.clip(np.random.normal(0, 0.2, size=(self.batch_size, self.action_dim)), -0.5, 0.5)
@@ -285,20 +370,20 @@ class DDPGLearner(Learner):
         if self.use_graph and ws.graph is None:
             # capture after one eager iteration (lazy allocations, module load); its effects are
             # real: the capture itself executes nothing
-            self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
+            self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done, *frames)
             gc.collect()
             gc.disable()               # a collection inside capture may free device memory: illegal
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
+                    self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done, *frames)
                 ws.graph = g
             finally:
                 gc.enable()
         elif ws.graph is not None:
             ws.graph.replay()
         else:
-            self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
+            self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done, *frames)
         self.critic_step += 1
         self.actor_step += 1
         ws.dev_step = self.critic_step

@@ -39,12 +39,16 @@ def ddpg_learner_config():
     return cfg
 
 
-def ddpg_env_config(obs_dim, action_dim, num_agents=1, env_name='synthetic:flat'):
+def ddpg_env_config(obs_dim, action_dim, num_agents=1, env_name='synthetic:flat', pixel=None):
+    """pixel = (C, H, W) adds the camera0 frames and sets pixel_input (ddpg_configs.py:100-112)"""
+    obs_spec = {'low_dim': {'flat_inputs': [obs_dim]}}
+    if pixel is not None:
+        obs_spec = {'pixel': {'camera0': list(pixel)}, 'low_dim': {'flat_inputs': [obs_dim]}}
     cfg = Config({
-        'env_name': env_name, 'num_agents': num_agents, 'action_repeat': 1, 'pixel_input': False,
+        'env_name': env_name, 'num_agents': num_agents, 'action_repeat': 1, 'pixel_input': pixel is not None,
         'frame_stacks': 1, 'limit_episode_length': 0, 'stochastic_eval': True,
         'action_spec': {'dim': [action_dim], 'type': 'continuous'},
-        'obs_spec': {'low_dim': {'flat_inputs': [obs_dim]}},
+        'obs_spec': obs_spec,
     })
     cfg.extend(BASE_ENV_CONFIG)
     return cfg

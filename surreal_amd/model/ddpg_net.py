@@ -1,12 +1,15 @@
 """
 DDPGModel on MI355X (surreal/model/ddpg_net.py:13-95; ActorNetworkX / CriticNetworkX,
-model_builders/builders.py:35-84): low-dimensional observations, use_layernorm=False (the
-reference default, ddpg_configs.py:21); LayerNorm / pixel perception raise NotImplementedError.
+model_builders/builders.py:35-84), use_layernorm=False (the reference default, ddpg_configs.py:21;
+LayerNorm raises NotImplementedError).  With camera frames in the observation the "perception" CNN
+(CNNStemNetwork, builders.py:8-33; ddpg_net.py:37-44, 67-78) runs on ``camera0 / 255`` and its
+features are concatenated IN FRONT of the low-dim vector; it trains with the critic
+(ddpg_net.py:57-61).
 
   actor : Linear(D,h1)-ReLU-Linear(h1,h2)-ReLU-Linear(h2,A)-Tanh
   critic: Linear(D,c1)-ReLU ; concat action ; Linear(c1+A,c2)-ReLU ; Linear(c2,1)
 
-One flat fp32 parameter buffer per optimiser group (actor / critic).
+One flat fp32 parameter buffer per network (actor / critic / perception).
 """
 import collections
 
@@ -14,6 +17,7 @@ import numpy as np
 import torch
 
 from surreal_amd import kernels as KN
+from surreal_amd.model.cnn_stem import CnnParams, CnnStem
 from surreal_amd.model.ppo_net import Mlp3Params
 
 
@@ -26,16 +30,29 @@ class DDPGModel(object):
         device = device or KN.default_device()
         self._ctor = dict(obs_spec=obs_spec, action_dim=action_dim, use_layernorm=use_layernorm,
                           actor_fc_hidden_sizes=list(actor_fc_hidden_sizes),
-                          critic_fc_hidden_sizes=list(critic_fc_hidden_sizes), critic_only=critic_only,
-                          device=device, kernels=self.K)
-        if 'pixel' in obs_spec:
-            raise NotImplementedError('pixel observations (CNN perception) are not built yet')
+                          critic_fc_hidden_sizes=list(critic_fc_hidden_sizes),
+                          conv_out_channels=conv_out_channels, conv_kernel_sizes=conv_kernel_sizes,
+                          conv_strides=conv_strides, conv_hidden_dim=conv_hidden_dim,
+                          critic_only=critic_only, device=device, kernels=self.K)
         if use_layernorm:
             raise NotImplementedError('use_layernorm=True is not built yet')
-        self.is_pixel_input = False
+        self.is_pixel_input = 'pixel' in obs_spec
         self.action_dim = A = action_dim
         self.use_layernorm = use_layernorm
-        self.input_dim = D = obs_spec['low_dim']['flat_inputs'][0]
+        self.low_dim = int(obs_spec['low_dim']['flat_inputs'][0]) if 'low_dim' in obs_spec else 0
+        self.cnn = self.perception_flat = self._cnn_stem = None
+        self.feat_dim = 0
+        if self.is_pixel_input:
+            if len(obs_spec['pixel']) != 1 or 'camera0' not in obs_spec['pixel']:
+                raise NotImplementedError('one camera (camera0), as ddpg_net.py:34-35')
+            cam = tuple(int(v) for v in obs_spec['pixel']['camera0'])
+            self.feat_dim = int(conv_hidden_dim)
+            geo = dict(conv_channels=tuple(conv_out_channels or (16, 32)),
+                       kernel_sizes=tuple(conv_kernel_sizes or (8, 4)), strides=tuple(conv_strides or (4, 2)))
+            self.perception_flat = torch.empty(CnnParams.count(cam, self.feat_dim, **geo), device=device)
+            self.cnn = CnnParams(self.perception_flat, 0, cam, self.feat_dim, **geo)
+            self._cnn_stem = CnnStem(self.K)
+        self.input_dim = D = self.feat_dim + self.low_dim          # ddpg_net.py:36-46
         self.device = device
         ah, ch = list(actor_fc_hidden_sizes), list(critic_fc_hidden_sizes)
         self.c1, self.c2 = ch
@@ -59,6 +76,9 @@ class DDPGModel(object):
         self._init()
 
     def _init(self):
+        if self.cnn is not None:
+            self.perception_flat.zero_()
+            self.cnn.init_torch_default()
         nets = [self.critic] + ([self.actor.views] if self.actor is not None else [])
         for views in nets:
             for name, v in views.items():
@@ -74,6 +94,9 @@ class DDPGModel(object):
         for i in (1, 2, 3):
             out['critic.fc%d.W' % i] = self.critic['W%d' % i]
             out['critic.fc%d.b' % i] = self.critic['b%d' % i]
+        if self.cnn is not None:
+            for k, v in self.cnn.views.items():
+                out['cnn.' + k] = v
         return out
 
     def load_params(self, params):
@@ -100,11 +123,26 @@ class DDPGModel(object):
         return [self.actor_flat]
 
     def get_critic_parameters(self):
-        return [self.critic_flat]
+        return [self.critic_flat] + ([self.perception_flat] if self.cnn is not None else [])
 
     # ---- forward passes (eager helpers; the learner uses its own workspace) -----------------
+    def perception_into(self, frames, low, cnn_ws, out):
+        """out [rows, feat + low_dim] = [CNN(frames / 255) | low]; cnn_ws keeps the activations (a
+        backward pass may follow)"""
+        rows = out.shape[0]
+        self._cnn_stem.forward(self.cnn, frames, rows, cnn_ws, out[:, :self.feat_dim])
+        if self.low_dim:
+            out[:, self.feat_dim:].copy_(low)
+
     def forward_perception(self, obs):
-        return obs['low_dim']['flat_inputs']
+        if not self.is_pixel_input:
+            return obs['low_dim']['flat_inputs']
+        frames = obs['pixel']['camera0'].contiguous()
+        rows = frames.shape[0]
+        out = torch.empty(rows, self.input_dim, device=frames.device)
+        cws = CnnStem.workspace(self.cnn, rows, frames.device, backward=False)
+        self.perception_into(frames, obs['low_dim']['flat_inputs'] if self.low_dim else None, cws, out)
+        return out
 
     def forward_actor(self, x):
         a = self.actor

@@ -136,9 +136,19 @@ def make_zfilter_state(D, seed=2, prewarm_rows=4096, eps=1e-5):
             'count': cnt.astype(np.float32)}
 
 
-def make_ddpg_batch(B=512, D=17, A=6, seed=0):
-    """SSARAggregator contract (aggregator.py:97-103)"""
+def make_ddpg_batch(B=512, D=17, A=6, seed=0, pixel=None):
+    """SSARAggregator contract (aggregator.py:97-103); pixel = (C, H, W) adds
+    uint8 camera frames obs['pixel']['camera0'] (B, C, H, W), drawn after everything else"""
     rs = np.random.RandomState(seed)
+    out = _ddpg_low_dim(rs, B, D, A)
+    if pixel is not None:
+        for key in ('obs', 'obs_next'):
+            out[key]['pixel'] = collections.OrderedDict(
+                camera0=rs.randint(0, 256, size=(B,) + tuple(pixel)).astype(np.uint8))
+    return out
+
+
+def _ddpg_low_dim(rs, B, D, A):
     return {
         'obs': collections.OrderedDict(low_dim=collections.OrderedDict(
             flat_inputs=rs.randn(B, D).astype(np.float32))),

@@ -9,7 +9,8 @@ from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, 
 
 import ddpg_oracle
 
-DDPG_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'tiny_td3_hard', 'tiny_double_soft', 'cfg3_cheetah512']
+DDPG_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'tiny_td3_hard', 'tiny_double_soft', 'tiny_pixel_hard',
+              'tiny_pixel_td3_soft', 'cfg3_cheetah512']
 
 
 def load(name):
@@ -31,12 +32,21 @@ def make_learner(case):
     lc.algo.network.use_double_critic = bool(h.get('double_critic', False))
     lc.algo.network.use_action_regularization = bool(h.get('action_reg', False))
     lc.replay.batch_size = case['B']
-    L = DDPGLearner(lc, ddpg_env_config(case['D'], case['A']), ddpg_session_config())
-    params = ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=3)
+    pixel = tuple(case['pixel']) if case.get('pixel') else None
+    if pixel is not None:
+        lc.model.conv_spec.hidden_output_dim = case['conv_hidden']
+    L = DDPGLearner(lc, ddpg_env_config(case['D'], case['A'], pixel=pixel), ddpg_session_config())
+
+    def mkp(seed):
+        if pixel is not None:
+            return ddpg_oracle.make_ddpg_pixel_params(case['D'], case['A'], pixel, case['conv_hidden'],
+                                                      tuple(case['ah']), tuple(case['ch']), seed=seed)
+        return ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=seed)
+    params = mkp(3)
     L.model.load_params(params)
     L.model_target.load_params(params)
     if L.use_double_critic:
-        params2 = ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=4)
+        params2 = mkp(4)
         L.model2.load_params(params2)
         L.model_target2.load_params(params2)
     return L
@@ -47,7 +57,8 @@ def run_and_check(name, atol=1e-5, rtol=1e-5):
     L = make_learner(case)
     ref = json.loads(str(g['trace_json']))
     for it in range(case['iters']):
-        b = synthetic.make_ddpg_batch(case['B'], case['D'], case['A'], seed=10 + it)
+        b = synthetic.make_ddpg_batch(case['B'], case['D'], case['A'], seed=10 + it,
+                                      pixel=tuple(case['pixel']) if case.get('pixel') else None)
         np.random.seed(1000 + it)          # TD3's action-regularisation noise (numpy's global stream)
         st = L.learn(b)
         assert set(st) == set(ref[it]), (sorted(st), sorted(ref[it]))
