@@ -800,3 +800,46 @@ def test_linear_wgrad_splitk_over_an_operand_past_2gib(K):
     scale = float(ref_w.abs().max())
     close(dW.cpu().double() / scale, ref_w.cpu() / scale, atol=3e-6, rtol=1e-5, msg='dW')
     close(db.cpu().double() / scale, ref_b.cpu() / scale, atol=3e-6, rtol=1e-5, msg='db')
+
+
+def test_window_cut_fifo_round_trip_at_baseline_size(K):
+    """BASELINE cfg 5 (1024 actors x 128 steps x 376): the moving-window cut of a whole rollout, the
+    FIFO insert (through the table and zero-copy) and the pop are byte copies -- the popped batch must
+    be the rollout's slices bit for bit; cfg 3: a uniform sample of 512 out of 1e6 rows returns
+    exactly the rows its indices name"""
+    from surreal_amd.env import SyntheticVecEnv
+    from surreal_amd.replay import FIFOReplay, UniformReplay
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    n, T, D, A = 1024, 128, 376, 17
+    venv = SyntheticVecEnv(n, D, A, episode_len=T)
+    venv.start_rollout(T, info_width=2 * A)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for name, r in venv.rolls.items():
+        r.copy_(torch.randn(r.shape, device='cuda', generator=g))
+    venv.slot = T
+    lc = ppo_learner_config()
+    lc.algo.n_step, lc.replay.batch_size, lc.replay.memory_size = T, n, 2 * n
+    ec, sc = ppo_env_config(D, A), ppo_session_config('/tmp/x')
+    for zero_copy in (False, True):
+        f = FIFOReplay(lc, ec, sc)
+        slots = f.reserve_batch(n, venv.window_shapes(T)) if zero_copy else None
+        if zero_copy:
+            assert slots is not None
+            venv.emit_windows(T, T, out=slots)
+            f.commit_batch(n)
+        else:
+            f.insert_batch(venv.emit_windows(T, T))
+        b = f.sample_batch(n, copy=not zero_copy)
+        torch.cuda.synchronize()
+        assert torch.equal(b['obs'], venv.rolls['obs'][:, :T]) and torch.equal(b['obs_next'][:, 0], venv.rolls['obs'][:, T])
+        assert torch.equal(b['actions'], venv.rolls['actions'][:, :T]) and torch.equal(b['pds'], venv.rolls['pds'][:, :T])
+        assert torch.equal(b['rewards'], venv.rolls['rewards'][:, :T]) and torch.equal(b['dones'], venv.rolls['dones'][:, :T])
+        assert len(f) == 0
+    lc.replay.memory_size, lc.replay.batch_size = 1000000, 512
+    u = UniformReplay(lc, ec, sc)
+    rows = torch.randn(1000000, 17, device='cuda', generator=g)
+    u.insert_batch({'obs': rows, 'rewards': rows[:, 0].contiguous()})
+    idx = u.sample_indices(512)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1000000 and len(torch.unique(idx)) > 500
+    got = u.sample_batch(512, indices=idx)
+    assert torch.equal(got['obs'], rows[idx]) and torch.equal(got['rewards'], rows[idx, 0])
