@@ -894,9 +894,12 @@ class PPOLearner(Learner):
         self._stem_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a,
                             ws.grads_a[:n_mlp], ws.grads_a[n0:n0 + m.n_cnn],
                             ws.grads_a[n0 + m.n_cnn:], ws.stop)
-        if self.world_size > 1:      # log_var's gradient is global already (all-reduced partials)
-            self._dist.all_reduce(ws.grads_a[:n_mlp])
-            self._dist.all_reduce(ws.grads_a[n0:])
+        if self.world_size > 1:
+            # ONE all-reduce for the MLP and the stem.  log_var's gradient (between them) was built from
+            # all-reduced loss sums and is global already: exactly one copy may enter the sum
+            if self.rank != 0:
+                ws.grads_a[n_mlp:n0].zero_()
+            self._dist.all_reduce(ws.grads_a)
         K.sumsq_partials(ws.grads_a, ws.sumsq_a)
         K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                     ws.sumsq_a, K.sumsq_blocks(ws.grads_a.numel()), ws.ctrl_f, 0, True,
@@ -907,11 +910,9 @@ class PPOLearner(Learner):
         x = self._stem_forward(ws, m, ws.xn, None)
         K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
         n_total = ws.n_total
-        if self.world_size > 1:
-            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
-            self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
-        else:
-            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
+        # (several ranks: the moments only feed statistics -- gathered once after the last epoch)
+        K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c,
+                     ws.vpart_loc_all[e] if self.world_size > 1 else ws.vpart[e], ws.ctrl_f, True)
         self._stem_backward(ws, m.critic, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
                             ws.grads_c[m.n_stem:], ws.grads_c[:m.n_cnn], ws.grads_c[m.n_cnn:m.n_stem],
                             None)
@@ -956,6 +957,10 @@ class PPOLearner(Learner):
             self._stem_policy_forward(ws, e + 1)
         for e in range(self.epoch_baseline):
             self._stem_value_epoch(ws, e)
+        if self.world_size > 1:
+            Ev, W = self.epoch_baseline, self.world_size
+            self._dist.all_gather_into_tensor(ws.vgather.view(-1), ws.vpart_loc_all.view(-1))
+            ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(ws.vgather.permute(1, 0, 2, 3))
         K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
         K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
