@@ -71,7 +71,8 @@ def build_reference_learner(ref, params, zstate, B, N, D, A, hyper, pixel=None):
     rnn_hidden = params['rnn.weight_hh'].shape[1] if 'rnn.weight_hh' in params else 100
     model_config = _Cfg(actor_fc_hidden_sizes=hidden, critic_fc_hidden_sizes=hidden,
                         cnn_feature_dim=params['cnn.fc.W'].shape[0] if pixel is not None else 256)
-    rnn_config = _Cfg(if_rnn_policy=L.if_rnn_policy, rnn_hidden=rnn_hidden, rnn_layer=1,
+    rnn_layer = 1 + sum(1 for k in params if k.startswith('rnn.weight_ih_l'))
+    rnn_config = _Cfg(if_rnn_policy=L.if_rnn_policy, rnn_hidden=rnn_hidden, rnn_layer=rnn_layer,
                       horizon=L.horizon)
 
     def make_model():
@@ -126,10 +127,10 @@ def inject_params(m, params, zstate):
                 mod.weight.copy_(torch.tensor(params['cnn.%s.W' % nm]))
                 mod.bias.copy_(torch.tensor(params['cnn.%s.b' % nm]))
         if m.rnn_stem is not None:
-            m.rnn_stem.weight_ih_l0.copy_(torch.tensor(params['rnn.weight_ih']))
-            m.rnn_stem.weight_hh_l0.copy_(torch.tensor(params['rnn.weight_hh']))
-            m.rnn_stem.bias_ih_l0.copy_(torch.tensor(params['rnn.bias_ih']))
-            m.rnn_stem.bias_hh_l0.copy_(torch.tensor(params['rnn.bias_hh']))
+            for layer in range(m.rnn_stem.num_layers):
+                sfx = '' if layer == 0 else '_l%d' % layer
+                for nm in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                    getattr(m.rnn_stem, '%s_l%d' % (nm, layer)).copy_(torch.tensor(params['rnn.' + nm + sfx]))
         if m.use_z_filter and zstate is not None:
             m.z_filter.running_sum.copy_(torch.tensor(zstate['running_sum']))
             m.z_filter.running_sumsq.copy_(torch.tensor(zstate['running_sumsq']))
@@ -144,10 +145,10 @@ def extract_params(m):
             out['cnn.%s.W' % nm] = mod.weight.detach().numpy().copy()
             out['cnn.%s.b' % nm] = mod.bias.detach().numpy().copy()
     if m.rnn_stem is not None:
-        out['rnn.weight_ih'] = m.rnn_stem.weight_ih_l0.detach().numpy().copy()
-        out['rnn.weight_hh'] = m.rnn_stem.weight_hh_l0.detach().numpy().copy()
-        out['rnn.bias_ih'] = m.rnn_stem.bias_ih_l0.detach().numpy().copy()
-        out['rnn.bias_hh'] = m.rnn_stem.bias_hh_l0.detach().numpy().copy()
+        for layer in range(m.rnn_stem.num_layers):
+            sfx = '' if layer == 0 else '_l%d' % layer
+            for nm in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                out['rnn.' + nm + sfx] = getattr(m.rnn_stem, '%s_l%d' % (nm, layer)).detach().numpy().copy()
     for net, name in ((m.actor, 'actor'), (m.critic, 'critic')):
         for i, lin in enumerate(_linears(net.model)):
             out['%s.fc%d.W' % (name, i + 1)] = lin.fc.weight.detach().numpy().copy()
@@ -165,10 +166,11 @@ def run_reference(ref, case):
     rnn_hidden = case.get('rnn_hidden', 0) if hyper.get('if_rnn_policy') else 0
     pixel = case.get('pixel')
     pix_kw = dict(pixel=tuple(pixel), cnn_feature_dim=case['cnn_feature_dim']) if pixel else {}
+    layers_kw = dict(rnn_layers=case['rnn_layers']) if case.get('rnn_layers', 1) > 1 else {}
     batch = synthetic.make_ppo_batch(B, N, D, A, rnn_hidden=rnn_hidden,
-                                     pixel=tuple(pixel) if pixel else None, **case['batch_args'])
+                                     pixel=tuple(pixel) if pixel else None, **layers_kw, **case['batch_args'])
     params = synthetic.make_ppo_params(D, A, hidden=tuple(case['hidden']), rnn_hidden=rnn_hidden,
-                                       **pix_kw, **case['param_args'])
+                                       **pix_kw, **layers_kw, **case['param_args'])
     zstate = synthetic.make_zfilter_state(D, **case['z_args']) if hyper.get('use_z_filter', True) else None
     L = build_reference_learner(ref, params, zstate, B, N, D, A, hyper, pixel=pixel)
     trace = {'policy': [], 'value': []}
@@ -226,12 +228,14 @@ CASES = collections.OrderedDict()
 
 
 def _case(name, shape, hidden, hyper, batch_args=None, param_args=None, z_args=None,
-          keep_params=True, rnn_hidden=0, pixel=None, cnn_feature_dim=256):
+          keep_params=True, rnn_hidden=0, pixel=None, cnn_feature_dim=256, rnn_layers=1):
     CASES[name] = dict(name=name, shape=shape, hidden=list(hidden), hyper=hyper,
                        batch_args=batch_args or dict(seed=0),
                        param_args=param_args or dict(seed=1),
                        z_args=z_args or dict(seed=2), keep_params=keep_params,
                        rnn_hidden=rnn_hidden)
+    if rnn_layers > 1:
+        CASES[name].update(rnn_layers=rnn_layers)
     if pixel is not None:
         CASES[name].update(pixel=list(pixel), cnn_feature_dim=cnn_feature_dim)
 
@@ -271,6 +275,8 @@ _case('tiny_rnn_clip', S['tiny'], (24, 16),
 # (3, 84, 84) uint8 + robot state, A = 8; golden at 8 actors x 6 steps)
 _case('tiny_pixel_clip', dict(B=6, N=5, D=5, A=2), (24, 16), dict(ppo_mode='clip', kl_target=1e9),
       pixel=(3, 28, 36), cnn_feature_dim=16)
+_case('tiny_rnn2_adapt', S['tiny'], (24, 16), dict(ppo_mode='adapt', if_rnn_policy=True, horizon=3),
+      rnn_hidden=12, rnn_layers=2)
 _case('tiny_pixel_rnn_adapt', dict(B=5, N=6, D=4, A=2), (24, 16),
       dict(ppo_mode='adapt', if_rnn_policy=True, horizon=3), rnn_hidden=12, pixel=(2, 20, 24),
       cnn_feature_dim=8)

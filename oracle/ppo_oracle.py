@@ -154,17 +154,15 @@ class OraclePPOModel(object):
         self.if_rnn = 'rnn.weight_ih' in self.p
         if self.if_rnn:
             hid, din = self.p['rnn.weight_ih'].shape[0] // 4, self.p['rnn.weight_ih'].shape[1]
-            self._rnn = nn.LSTM(din, hid, 1, batch_first=True)
-            with torch.no_grad():
-                self._rnn.weight_ih_l0.copy_(self.p['rnn.weight_ih'])
-                self._rnn.weight_hh_l0.copy_(self.p['rnn.weight_hh'])
-                self._rnn.bias_ih_l0.copy_(self.p['rnn.bias_ih'])
-                self._rnn.bias_hh_l0.copy_(self.p['rnn.bias_hh'])
-            # the canonical dict aliases the module's own Parameter objects
-            self.p['rnn.weight_ih'] = self._rnn.weight_ih_l0
-            self.p['rnn.weight_hh'] = self._rnn.weight_hh_l0
-            self.p['rnn.bias_ih'] = self._rnn.bias_ih_l0
-            self.p['rnn.bias_hh'] = self._rnn.bias_hh_l0
+            layers = 1 + sum(1 for k in self.p if k.startswith('rnn.weight_ih_l'))   # rnn_layer (ppo_net.py:146)
+            self._rnn = nn.LSTM(din, hid, layers, batch_first=True)
+            for layer in range(layers):
+                sfx = '' if layer == 0 else '_l%d' % layer
+                for nm in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                    mod_p = getattr(self._rnn, '%s_l%d' % (nm, layer))
+                    with torch.no_grad():
+                        mod_p.copy_(self.p['rnn.' + nm + sfx])
+                    self.p['rnn.' + nm + sfx] = mod_p    # the canonical dict aliases the module's Parameters
         # optional CNN stem (builders.py:8-33): Conv2d(16,k8,s4)-ReLU-Conv2d(32,k4,s2)-ReLU-Flatten-
         # Linear(cnn_feature_dim)-ReLU; the same ATen conv2d / linear ops the reference calls
         self.if_pixel = 'cnn.conv1.W' in self.p

@@ -287,10 +287,16 @@ class PPOLearner(Learner):
                 # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E)
                 # and for the critic pass (T = N + 1, ppo.py:376-386)
                 F = self.model.rnn_hidden
-                ws.h0, ws.c0 = f(B, F), f(B, F)
+                nl = self.model.rnn_layers
+                ws.h0L, ws.c0L = f(nl, B, F), f(nl, B, F)          # agent-side state of every layer
+                ws.h0, ws.c0 = ws.h0L[0], ws.c0L[0]
                 ws.gates, ws.lo, ws.cs, ws.hp, ws.dlo = f(rows, 4 * F), f(rows, F), f(rows, F), f(rows, F), f(rows, F)
                 ws.gatesG, ws.loG, ws.csG = f(R1, 4 * F), f(R1, F), f(R1, F)
-                n_sk = K.lstm_backward_ws_floats(self.model.rnn, B, E)
+                # stacked layers above the first: their own sequence buffers (layer l reads layer l-1's lo)
+                ws.upper = [types.SimpleNamespace(gates=f(rows, 4 * F), lo=f(rows, F), cs=f(rows, F),
+                                                  hp=f(rows, F), dlo=f(rows, F)) for _ in range(nl - 1)]
+                ws.loG2 = f(R1, F) if nl > 1 else None
+                n_sk = max(K.lstm_backward_ws_floats(r, B, E) for r in self.model.rnns)
                 ws.lstm_sk = f(n_sk) if n_sk else None
             if pixel:
                 # CNN stem (builders.py:8-33): frames stay in their source dtype (uint8 from the
@@ -825,8 +831,7 @@ class PPOLearner(Learner):
         self._stem_inputs(ws, m, ws.lcat.view(B * (N + 1), D), frames, ws.xcat, ws.cnn_gae, zst)
         x = ws.xcat
         if rnn:
-            K.lstm_forward(m.rnn, ws.xcat, B, N + 1, ws.h0, ws.c0, ws.gatesG, ws.loG, ws.csG)
-            x = ws.loG
+            x = self._lstm_forward_only(ws, m, ws.xcat, B, N + 1, ws.gatesG, ws.csG, ws.loG, ws.loG2)
         K.mlp3_forward(m.critic, x, ws.h1G, ws.h2G, ws.vals.view(-1, 1), L.SMX_ACT_NONE)
         H = self.horizon if rnn else N
         K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** H, B, N, H,
@@ -838,6 +843,15 @@ class PPOLearner(Learner):
                 K.moments_merge(ws.mom_parts, ws.adv_mom)
             K.adv_normalize(ws.adv, ws.adv_mom, 1e-4)
 
+    def _lstm_forward_only(self, ws, mm, xin, B, T, gates, cs, lo_a, lo_b):
+        """the LSTM stack without anything kept for a backward pass (critic pass, reference policy):
+        the layers share gates / cs scratch and ping-pong between two output buffers"""
+        x, out, other = xin, lo_a, lo_b
+        for layer, rnn in enumerate(mm.rnns):
+            self.K.lstm_forward(rnn, x, B, T, ws.h0L[layer], ws.c0L[layer], gates, out, cs)
+            x, out, other = out, other, out
+        return x
+
     def _stem_forward(self, ws, mm, xin, stop, save=True):
         """features of the current stem weights -> the MLP input (ws.lo with the LSTM, xin without)"""
         K = self.K
@@ -848,7 +862,12 @@ class PPOLearner(Learner):
             return xin
         K.lstm_forward(mm.rnn, xin, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs,
                        ws.hp if save else None, stop=stop)
-        return ws.lo
+        x = ws.lo
+        for layer, up in enumerate(ws.upper, 1):       # stacked layers (rnn_layer > 1)
+            K.lstm_forward(mm.rnns[layer], x, B, E, ws.h0L[layer], ws.c0L[layer], up.gates, up.lo, up.cs,
+                           up.hp if save else None, stop=stop)
+            x = up.lo
+        return x
 
     def _stem_policy_forward(self, ws, e):
         K, m = self.K, self.model
@@ -872,13 +891,24 @@ class PPOLearner(Learner):
         """MLP backward, then back through the stems it sits on"""
         K, m = self.K, self.model
         B, E, D = ws.key[0], ws.E, ws.key[2]
-        x = ws.lo if m.if_rnn else ws.xn
+        top = ws.upper[-1] if (m.if_rnn and ws.upper) else ws
+        x = top.lo if m.if_rnn else ws.xn
         K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
         if m.if_rnn:
             # d loss / d (LSTM output) = dz1 . W1, then BPTT (dgates overwrite the saved gates)
-            K.linear(dz1, 1, net.views['W1'], 0, None, ws.dlo, ws.rows, m.rnn_hidden, net.H1, stop=stop)
-            K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates, g_rnn,
-                            stop, ws=ws.lstm_sk)
+            F = m.rnn_hidden
+            K.linear(dz1, 1, net.views['W1'], 0, None, top.dlo, ws.rows, F, net.H1, stop=stop)
+            for layer in range(len(ws.upper), 0, -1):      # stacked layers, top down (rnn_layer > 1)
+                up = ws.upper[layer - 1]
+                below = ws.upper[layer - 2] if layer > 1 else ws
+                o = m.rnn_offsets[layer]
+                K.lstm_backward(m.rnns[layer], below.lo, B, E, ws.c0L[layer], up.gates, up.cs, up.hp, up.dlo,
+                                up.gates, g_rnn[o:o + m.rnn_counts[layer]], stop, ws=ws.lstm_sk)
+                # d loss / d (this layer's input) = dgates . W_ih
+                K.linear(up.gates, 1, m.rnns[layer].views['weight_ih'], 0, None, below.dlo, ws.rows, F, 4 * F,
+                         stop=stop)
+            K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates,
+                            g_rnn[:m.rnn_counts[0]], stop, ws=ws.lstm_sk)
             up, upW, upK = ws.gates, m.rnn.views['weight_ih'], 4 * m.rnn_hidden
         else:
             up, upW, upK = dz1, net.views['W1'], net.H1
@@ -945,8 +975,8 @@ class PPOLearner(Learner):
         # ref_pol = ref_target_model.forward_actor(obs_iter, cells)   (ppo.py:539)
         x = ws.xr
         if ref.if_rnn:
-            K.lstm_forward(ref.rnn, ws.xr, B, E, ws.h0, ws.c0, ws.gates, ws.lo, ws.cs)
-            x = ws.lo
+            x = self._lstm_forward_only(ws, ref, ws.xr, B, E, ws.gates, ws.cs, ws.lo,
+                                        ws.upper[0].lo if ws.upper else None)
         K.mlp3_forward(ref.actor, x, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
         ws.ref_pol[:, :A].copy_(ws.ref_mean)
         ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
@@ -1010,8 +1040,9 @@ class PPOLearner(Learner):
         if self.if_rnn_policy:
             # agent-side LSTM state at the head of every sub-trajectory (ppo.py:511-515):
             # (B, layers=1, H) -> the kernels' [B, H]
-            ws.h0.copy_(onetime_infos[0].reshape(B, -1))
-            ws.c0.copy_(onetime_infos[1].reshape(B, -1))
+            nl, F = self.model.rnn_layers, self.model.rnn_hidden
+            ws.h0L.copy_(onetime_infos[0].reshape(B, nl, F).transpose(0, 1))
+            ws.c0L.copy_(onetime_infos[1].reshape(B, nl, F).transpose(0, 1))
         if self.use_graph:
             # A captured graph is bound to the addresses of its inputs.  The first batch is captured
             # in place (a pointer-stable feed -- device-resident replay, the benchmark -- never pays

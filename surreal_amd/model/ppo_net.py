@@ -157,7 +157,7 @@ class PPOModel(object):
     ``[actor MLP | log_var | LSTM | critic MLP]`` so that the two optimiser groups of the
     reference -- actor + shared stem, critic + shared stem (ppo_net.py:202-224) -- are the
     contiguous slices ``actor_flat`` and ``critic_flat``.  The CNN stem (pixel observations)
-    raises NotImplementedError.
+    raises NotImplementedError.  Stacked LSTM layers (rnn_layer > 1) chain the same kernels.
     """
 
     def __init__(self, obs_spec, action_dim, model_config, use_cuda=True, init_log_sig=0,
@@ -167,8 +167,12 @@ class PPOModel(object):
         device = device or KN.default_device()
         self.if_pixel = bool(if_pixel_input)
         self.if_rnn = bool(rnn_config is not None and rnn_config.get('if_rnn_policy', False))
-        if self.if_rnn and int(rnn_config.get('rnn_layer', 1)) != 1:
-            raise NotImplementedError('only rnn_layer = 1 (the reference default) is built')
+        self.rnn_layers = int(rnn_config.get('rnn_layer', 1)) if self.if_rnn else 0
+        if self.if_rnn and self.rnn_layers < 1:
+            raise ValueError('rnn_layer must be >= 1')
+        if self.if_rnn and int(rnn_config.rnn_hidden) % 4:
+            raise NotImplementedError('rnn_hidden must be a multiple of 4 (the LSTM kernels read W_hh 16 '
+                                      'bytes at a time; the reference default is 100)')
         self.obs_spec = obs_spec
         self.action_dim = action_dim
         self.model_config = model_config
@@ -193,7 +197,10 @@ class PPOModel(object):
         n_actor = (Mlp3Params.count(F, ah[0], ah[1], A) + A + 3) & ~3
         cam = tuple(obs_spec['pixel']['camera0']) if self.if_pixel else None
         n_cnn = CnnParams.count(cam, self.cnn_feature_dim) if self.if_pixel else 0
-        n_rnn = LstmParams.count(Dx, self.rnn_hidden) if self.if_rnn else 0
+        # stacked LSTM layers (nn.LSTM(in, hid, rnn_layer), ppo_net.py:146): layer l > 0 reads layer l-1's output
+        rnn_in = [Dx] + [self.rnn_hidden] * max(0, self.rnn_layers - 1)
+        rnn_n = [LstmParams.count(d, self.rnn_hidden) for d in rnn_in] if self.if_rnn else []
+        n_rnn = sum(rnn_n)
         n_critic = Mlp3Params.count(F, ch[0], ch[1], 1)
         self.flat = torch.zeros(n_actor + n_cnn + n_rnn + n_critic, device=device)
         self.n_actor_block, self.n_cnn, self.n_rnn, self.n_stem = n_actor, n_cnn, n_rnn, n_cnn + n_rnn
@@ -201,7 +208,13 @@ class PPOModel(object):
         self.critic_flat = self.flat[n_actor:]                # optimiser group: (shared stems +) critic
         self.actor = Mlp3Params(self.flat, 0, F, ah[0], ah[1], A)
         self.cnn = CnnParams(self.flat, n_actor, cam, self.cnn_feature_dim) if self.if_pixel else None
-        self.rnn = LstmParams(self.flat, n_actor + n_cnn, Dx, self.rnn_hidden) if self.if_rnn else None
+        self.rnns, o = [], n_actor + n_cnn
+        for d, cnt in zip(rnn_in if self.if_rnn else [], rnn_n):
+            self.rnns.append(LstmParams(self.flat, o, d, self.rnn_hidden))
+            o += cnt
+        self.rnn = self.rnns[0] if self.if_rnn else None        # (the first layer, what sits on the stem input)
+        self.rnn_offsets = np.cumsum([0] + rnn_n[:-1]).tolist() if self.if_rnn else []   # within the LSTM block
+        self.rnn_counts = rnn_n
         self.critic = Mlp3Params(self.flat, n_actor + self.n_stem, F, ch[0], ch[1], 1)
         self._cnn_stem = CnnStem(self.K) if self.if_pixel else None
         self.log_var = self.flat[self.actor.numel:self.actor.numel + A].view(1, A)
@@ -222,8 +235,9 @@ class PPOModel(object):
             self.cnn.init_torch_default()
         if self.if_rnn:                          # torch.nn.LSTM default: U(-1/sqrt(H), 1/sqrt(H))
             b = 1.0 / np.sqrt(self.rnn_hidden)
-            for v in self.rnn.views.values():
-                v.uniform_(-b, b)
+            for r in self.rnns:
+                for v in r.views.values():
+                    v.uniform_(-b, b)
 
     # ---- canonical parameter dict (names shared with the oracle / synthetic generator) ----
     def named_parameters(self):
@@ -238,8 +252,9 @@ class PPOModel(object):
             for k, v in self.cnn.views.items():
                 out['cnn.' + k] = v
         if self.if_rnn:
-            for k, v in self.rnn.views.items():
-                out['rnn.' + k] = v
+            for layer, r in enumerate(self.rnns):            # nn.LSTM's names: *_l0 (kept bare), *_l1, ...
+                for k, v in r.views.items():
+                    out['rnn.' + k + ('' if layer == 0 else '_l%d' % layer)] = v
         return out
 
     def load_params(self, params):
@@ -324,19 +339,24 @@ class PPOModel(object):
         H = self.rnn_hidden
         dev = x.device
         x2 = x.reshape(B * T, D).contiguous()
+        nl = self.rnn_layers
         h0 = c0 = None
-        if cells is not None:
-            h0 = cells[0].reshape(B, H).to(dev, torch.float32).contiguous()
-            c0 = cells[1].reshape(B, H).to(dev, torch.float32).contiguous()
+        if cells is not None:                    # (layers, B, H) each
+            h0 = cells[0].reshape(nl, B, H).to(dev, torch.float32).contiguous()
+            c0 = cells[1].reshape(nl, B, H).to(dev, torch.float32).contiguous()
         gates = torch.empty(B * T, 4 * H, device=dev)
-        out = torch.empty(B, T, H, device=dev)
         cs = torch.empty(B * T, H, device=dev)
         hN = cN = None
         if want_cells:
-            hN, cN = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
-        self.K.lstm_forward(self.rnn, x2, B, T, h0, c0, gates, out, cs, None, hN, cN)
+            hN, cN = torch.empty(nl, B, H, device=dev), torch.empty(nl, B, H, device=dev)
+        for layer, rnn in enumerate(self.rnns):  # layer l reads layer l-1's output sequence
+            out = torch.empty(B, T, H, device=dev)
+            self.K.lstm_forward(rnn, x2, B, T, None if h0 is None else h0[layer],
+                                None if c0 is None else c0[layer], gates, out, cs, None,
+                                hN[layer] if want_cells else None, cN[layer] if want_cells else None)
+            x2 = out.view(B * T, H)
         if want_cells:
-            cells = (hN.view(1, B, H), cN.view(1, B, H))
+            cells = (hN, cN)
         return out, cells
 
     def forward_actor(self, obs, cells=None):    # ppo_net.py:253-282, builders.py:114-132

@@ -74,7 +74,7 @@ def make_ppo_batch(B, N, D, A, seed=0, done_prob=0.01, on_policy=True,
 
 
 def make_ppo_params(D, A, hidden=(300, 200), seed=1, init_log_sig=-1.0,
-                    rnn_hidden=0, final_scale=0.05, pixel=None, cnn_feature_dim=256):
+                    rnn_hidden=0, final_scale=0.05, pixel=None, cnn_feature_dim=256, rnn_layers=1):
     """
     Canonical flat parameter dict (numpy fp32), the *injected* initial state
     for both the oracle and the HIP path.  Kaiming-uniform-like fan-in scaling
@@ -114,6 +114,14 @@ def make_ppo_params(D, A, hidden=(300, 200), seed=1, init_log_sig=-1.0,
         p['rnn.weight_hh'] = rs.uniform(-bound, bound, (4 * rnn_hidden, rnn_hidden)).astype(np.float32)
         p['rnn.bias_ih'] = rs.uniform(-bound, bound, (4 * rnn_hidden,)).astype(np.float32)
         p['rnn.bias_hh'] = rs.uniform(-bound, bound, (4 * rnn_hidden,)).astype(np.float32)
+        if rnn_layers > 1:               # stacked layers (nn.LSTM names them *_l1, *_l2, ...); drawn
+            rl = np.random.RandomState(seed + 2000)          # from their own stream: older cases keep their bits
+            for layer in range(1, rnn_layers):
+                sfx = '_l%d' % layer
+                p['rnn.weight_ih' + sfx] = rl.uniform(-bound, bound, (4 * rnn_hidden, rnn_hidden)).astype(np.float32)
+                p['rnn.weight_hh' + sfx] = rl.uniform(-bound, bound, (4 * rnn_hidden, rnn_hidden)).astype(np.float32)
+                p['rnn.bias_ih' + sfx] = rl.uniform(-bound, bound, (4 * rnn_hidden,)).astype(np.float32)
+                p['rnn.bias_hh' + sfx] = rl.uniform(-bound, bound, (4 * rnn_hidden,)).astype(np.float32)
     lin('actor.fc1', h1, in_f)
     lin('actor.fc2', h2, h1)
     lin('actor.fc3', A, h2, scale=final_scale)

@@ -56,10 +56,11 @@ def case_inputs(case):
     rnn_hidden = case.get('rnn_hidden', 0) if hyper.get('if_rnn_policy') else 0
     pixel = tuple(case['pixel']) if case.get('pixel') else None
     pix_kw = dict(pixel=pixel, cnn_feature_dim=case['cnn_feature_dim']) if pixel else {}
+    layers_kw = dict(rnn_layers=case['rnn_layers']) if case.get('rnn_layers', 1) > 1 else {}
     batch = synthetic.make_ppo_batch(shp['B'], shp['N'], shp['D'], shp['A'], rnn_hidden=rnn_hidden,
-                                     pixel=pixel, **case['batch_args'])
+                                     pixel=pixel, **layers_kw, **case['batch_args'])
     params = synthetic.make_ppo_params(shp['D'], shp['A'], hidden=tuple(case['hidden']),
-                                       rnn_hidden=rnn_hidden, **pix_kw, **case['param_args'])
+                                       rnn_hidden=rnn_hidden, **pix_kw, **layers_kw, **case['param_args'])
     zstate = (synthetic.make_zfilter_state(shp['D'], **case['z_args'])
               if hyper.get('use_z_filter', True) else None)
     return batch, params, zstate
@@ -78,6 +79,7 @@ def make_learner(case, params, zstate, cls=None, session_overrides=None):
     lc.algo.rnn.horizon = hyper.get('horizon', 5)
     if case.get('rnn_hidden'):
         lc.algo.rnn.rnn_hidden = case['rnn_hidden']
+    lc.algo.rnn.rnn_layer = case.get('rnn_layers', 1)
     lc.algo.ppo_mode = hyper.get('ppo_mode', 'adapt')
     lc.algo.use_z_filter = hyper.get('use_z_filter', True)
     lc.algo.advantage.norm_adv = hyper.get('norm_adv', True)

@@ -66,7 +66,7 @@ def _worker(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize('name', ['tiny_clip', 'tiny_adapt_cutoff2', 'cfg2_adapt', 'tiny_rnn_clip', 'cfg1_rnn_adapt',
-                                  'tiny_pixel_clip', 'tiny_pixel_rnn_adapt'])
+                                  'tiny_pixel_clip', 'tiny_pixel_rnn_adapt', 'tiny_rnn2_adapt'])
 def test_two_rank_learner_equals_single_learner(name):
     world = 2
     ctx = mp.get_context('spawn')

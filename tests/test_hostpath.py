@@ -272,8 +272,9 @@ def test_agent_replay_learner_loop_in_process(cpu_double):
     np.testing.assert_allclose(acts.numpy(), np.clip(pds[:, :A].numpy(), -1, 1))
 
 
-def test_rnn_agent_replay_learner_loop_in_process(cpu_double):
-    """the reference's DEFAULT policy (LSTM stem): the agent carries (h, c) across steps, every
+@pytest.mark.parametrize('LAYERS', [1, 2])
+def test_rnn_agent_replay_learner_loop_in_process(cpu_double, LAYERS):
+    """the reference's DEFAULT policy (LSTM stem; also with stacked layers, rnn_layer = 2): the agent carries (h, c) across steps, every
     window's onetime_infos hold the state before its first step (ppo_agent.py:133-135,
     exp_sender_wrapper.py:237-252), and the learner's sequence pass from that state reproduces
     the per-step policies the agent acted with -- the property the whole RNN learner rests on."""
@@ -285,13 +286,14 @@ def test_rnn_agent_replay_learner_loop_in_process(cpu_double):
     lc, ec, sc = configs(B=3, N=N, stride=2, D=D, A=A, memory=16)
     lc.algo.rnn.if_rnn_policy = True
     lc.algo.rnn.rnn_hidden = HID
+    lc.algo.rnn.rnn_layer = LAYERS
     lc.algo.rnn.horizon = 3
     ec.limit_episode_length = 14
     replay = FIFOReplay(lc, ec, sc)
     learner = PPOLearner(lc, ec, sc)
     learner.attach_replay(replay)
     ag = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='eval_stochastic_local')
-    assert ag.cells[0].shape == (1, 1, HID) and float(ag.cells[0].abs().sum()) == 0.0
+    assert ag.cells[0].shape == (LAYERS, 1, HID) and float(ag.cells[0].abs().sum()) == 0.0
     ag = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
     ag.noise = 0.0                                   # compare pds without the exploration scale
     collected = []
@@ -304,13 +306,13 @@ def test_rnn_agent_replay_learner_loop_in_process(cpu_double):
     assert len(collected) == (14 - N) // 2 + 1
     for exp in collected:
         h, c = exp['onetime_infos']
-        assert h.shape == (1, HID) and c.shape == (1, HID)
+        assert h.shape == (LAYERS, HID) and c.shape == (LAYERS, HID)
     assert float(np.abs(collected[0]['onetime_infos'][0]).sum()) == 0.0      # episode start
     assert float(np.abs(collected[1]['onetime_infos'][0]).sum()) > 0.0
     # sequence pass from the stored state == the step-by-step policies the agent produced
     exp = collected[1]
     obs_seq = torch.as_tensor(np.stack([o['low_dim']['flat_inputs'] for o in exp['obs'][:N]]))[None]
-    cells = tuple(torch.as_tensor(x).view(1, 1, HID) for x in exp['onetime_infos'])
+    cells = tuple(torch.as_tensor(x).view(LAYERS, 1, HID) for x in exp['onetime_infos'])
     pd_seq = ag.model.forward_actor({'low_dim': {'flat_inputs': obs_seq}}, cells)[0].numpy()
     pd_steps = np.stack(exp['persistent_infos'][0]) if isinstance(exp['persistent_infos'], list) \
         and len(exp['persistent_infos']) == 1 else np.stack([p[-1] for p in exp['persistent_infos']])
