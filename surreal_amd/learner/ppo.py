@@ -25,8 +25,8 @@ What is different is how one ``learn()`` runs (SURVEY.md section 3.1 lists the r
     single reference learner would have seen whole: advantage moments, loss partial sums,
     gradients, value moments, z-filter sums.
 
-Scope: MLP policy, LSTM-stem policy (``rnn.if_rnn_policy``, the reference default) and / or CNN
-stem over camera frames (``pixel_input``), one camera.
+Scope: MLP policy, LSTM-stem policy (``rnn.if_rnn_policy``, the reference default; stacked layers
+with ``rnn.rnn_layer > 1``) and / or CNN stem over camera frames (``pixel_input``), one camera.
 """
 import gc
 import types

@@ -154,10 +154,10 @@ class PPOModel(object):
     """
     Actor + critic + z-filter (+ LSTM stem) with the reference constructor signature
     (ppo_net.py:110-118).  All parameters live in ONE flat buffer laid out
-    ``[actor MLP | log_var | LSTM | critic MLP]`` so that the two optimiser groups of the
-    reference -- actor + shared stem, critic + shared stem (ppo_net.py:202-224) -- are the
-    contiguous slices ``actor_flat`` and ``critic_flat``.  The CNN stem (pixel observations)
-    raises NotImplementedError.  Stacked LSTM layers (rnn_layer > 1) chain the same kernels.
+    ``[actor MLP | log_var | CNN stem | LSTM layers | critic MLP]`` so that the two optimiser groups
+    of the reference -- actor + shared stems, critic + shared stems (ppo_net.py:202-224) -- are the
+    contiguous slices ``actor_flat`` and ``critic_flat``.  The CNN stem (pixel observations,
+    model/cnn_stem.py) and stacked LSTM layers (rnn_layer > 1) chain the same kernels.
     """
 
     def __init__(self, obs_spec, action_dim, model_config, use_cuda=True, init_log_sig=0,
