@@ -76,3 +76,42 @@ def test_product_never_imports_the_oracle():
                 if re.search(r'^\s*(from|import)\s+(oracle|ppo_oracle|ref_shims|cpu_kernels)\b', txt, re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+STRUCTS = {               # C typedef -> ctypes mirror in surreal_amd/_lib.py
+    'smx_mlp3_t': 'Mlp3', 'smx_mlp3_job_t': 'Mlp3Job', 'smx_lstm_t': 'Lstm', 'smx_adam_group_t': 'AdamGroup',
+    'smx_ppo_losses_t': 'PpoLosses', 'smx_ppo_combine_t': 'PpoCombine', 'smx_synth_act_step_t': 'SynthActStep',
+}
+
+
+def test_struct_layouts_match_the_ctypes_mirrors(tmp_path):
+    """every struct that crosses the C ABI by pointer: sizeof and the offset of every field as the C
+    compiler lays them out (gcc on include/surreal_amd.h) against the ctypes.Structure the product
+    passes -- a silent mismatch would hand the kernels garbage"""
+    import subprocess
+    from surreal_amd import _lib as L
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "surreal_amd.h"', 'int main(void) {']
+    for cname, pyname in STRUCTS.items():
+        cls = getattr(L, pyname)
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {}
+    for ln in out.splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, pyname in STRUCTS.items():
+        cls = getattr(L, pyname)
+        assert got[(cname, 'sizeof')] == ctypes.sizeof(cls), (cname, got[(cname, 'sizeof')], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    # every struct typedef of the header has a mirror (anonymous `typedef struct {` and named ones)
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'surreal_amd.h')).read(), flags=re.S)
+    typedefs = set(re.findall(r'}\s*(smx_\w+_t)\s*;', hdr)) - {'smx_ppo_ctrl_t'}      # (addressed as words)
+    assert typedefs == set(STRUCTS), (sorted(typedefs), sorted(STRUCTS))
