@@ -115,3 +115,38 @@ def test_struct_layouts_match_the_ctypes_mirrors(tmp_path):
     hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'surreal_amd.h')).read(), flags=re.S)
     typedefs = set(re.findall(r'}\s*(smx_\w+_t)\s*;', hdr)) - {'smx_ppo_ctrl_t'}      # (addressed as words)
     assert typedefs == set(STRUCTS), (sorted(typedefs), sorted(STRUCTS))
+
+
+def test_ctypes_signatures_match_the_header():
+    """every entry point: number and kind of parameters (and the return type) the header declares
+    against the argtypes / restype the ctypes binding installs"""
+    from surreal_amd import _lib as L
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'surreal_amd.h')).read(), flags=re.S)
+    decls = re.findall(r'\n\s*([A-Za-z_][\w\s\*]*?)\b(smx_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', hdr)
+    assert len(decls) == len(declared_symbols())
+    kinds = {ctypes.c_int32: 'i32', ctypes.c_int64: 'i64', ctypes.c_float: 'f32', ctypes.c_double: 'f64',
+             ctypes.c_uint64: 'u64', ctypes.c_void_p: 'ptr', ctypes.c_char_p: 'ptr'}
+    kinds[ctypes.c_size_t] = 'u64'                         # (the same 8-byte class as c_uint64 on this ABI)
+
+    def kind_of_c(t):
+        t = t.strip()
+        if '*' in t or re.search(r'\bsmx_stream_t\b', t):
+            return 'ptr'
+        for pat, k in ((r'\bint32_t\b|\bint\b', 'i32'), (r'\buint64_t\b', 'u64'), (r'\bint64_t\b', 'i64'),
+                       (r'\bsize_t\b', 'u64'), (r'\bfloat\b', 'f32'), (r'\bdouble\b', 'f64')):
+            if re.search(pat, t):
+                return k
+        raise AssertionError('unknown C type %r' % t)
+
+    def kind_of_ct(t):
+        if t in kinds:
+            return kinds[t]
+        assert hasattr(t, '_type_') or t is None, t        # POINTER(struct)
+        return 'ptr'
+    for ret, name, params in decls:
+        restype, argtypes = L._SIGS[name]
+        plist = [p for p in (q.strip() for q in params.replace('\n', ' ').split(',')) if p and p != 'void']
+        assert len(plist) == len(argtypes), (name, plist, argtypes)
+        for p, a in zip(plist, argtypes):
+            assert kind_of_c(p) == kind_of_ct(a), (name, p, a)
+        assert kind_of_c(ret) == kind_of_ct(restype), (name, ret, restype)
