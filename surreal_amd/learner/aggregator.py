@@ -10,7 +10,9 @@ the same name (surreal/learner/aggregator.py:106-262, SURVEY.md Appendix B.1 -> 
 
 The reference builds it with nested Python loops over B x N tiny arrays (1.8 s for the
 1024 x 128 batch); here each field is one ``np.asarray`` over the
-already-contiguous per-experience lists.  Experiences that already arrive as one array per
+already-contiguous per-experience lists: 0.16 s for the same batch in steady state (0.87 s the
+first two calls, while the 197 MB result is touched for the first time; one ``np.concatenate`` over
+the flat leaf list measures the same).  Experiences that already arrive as one array per
 field (what the device-resident replay hands over) pass straight through ``np.stack``.
 """
 import collections
