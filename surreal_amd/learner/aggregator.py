@@ -27,6 +27,29 @@ def _stack(seq, dtype=None):
     return a if dtype is None else a.astype(dtype, copy=False)
 
 
+class FrameStackPreprocessor(object):
+    """SSAR experiences whose camera frames were stacked as a LIST (``frame_stack_concatenate_on_env``
+    off: the sender ships every frame once, exp_sender.py dedup) get the frames of each observation
+    joined on the channel axis before aggregation (surreal/learner/aggregator.py:11-30, used by
+    DDPGLearner._prefetcher_preprocess, ddpg.py:430-440).  Works in place, like the reference."""
+
+    def __init__(self, frame_stacks):
+        self.frame_stacks = frame_stacks
+
+    @staticmethod
+    def preprocess_obs(obs):
+        for key in obs.get('pixel', ()):
+            obs['pixel'][key] = np.concatenate(obs['pixel'][key], axis=0)
+            if obs['pixel'][key].ndim != 3:
+                raise AssertionError('stacked camera frames must join to (C, H, W)')
+
+    def preprocess_list(self, exp_list):
+        for exp in exp_list:
+            for obs in (exp['obs'][0], exp['obs'][1]):
+                self.preprocess_obs(obs)
+        return exp_list
+
+
 class MultistepAggregatorWithInfo(object):
     def __init__(self, obs_spec, action_spec):
         if not isinstance(obs_spec, dict) or not isinstance(action_spec, dict):

@@ -118,3 +118,32 @@ def test_ddpg_pixel_agent_acts_on_camera_frames(cpu_double):
     want = O.forward_actor(O.forward_perception({'pixel': {'camera0': t(obs['pixel']['camera0'])},
                                                  'low_dim': {'flat_inputs': t(obs['low_dim']['flat_inputs'])}}))
     np.testing.assert_allclose(a, want.detach().numpy()[0].clip(-1, 1), atol=1e-6)
+
+
+def test_frame_stack_preprocessor_joins_frame_lists(cpu_double):
+    """frame stacks shipped as lists of frames (frame_stack_concatenate_on_env off) are joined on the
+    channel axis before SSAR aggregation (aggregator.py:11-30, ddpg.py:430-440)"""
+    import collections
+    from surreal_amd.learner import DDPGLearner
+    from surreal_amd.learner.aggregator import FrameStackPreprocessor
+    from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
+
+    def obs(t):
+        frames = [np.full((1, 20, 24), t + k, dtype=np.uint8) for k in range(2)]
+        return collections.OrderedDict(pixel={'camera0': frames}, low_dim={'flat_inputs': np.full(3, t, np.float32)})
+    exps = [{'obs': [obs(i), obs(i + 1)], 'action': np.zeros(2, np.float32), 'reward': 1.0, 'done': False}
+            for i in range(4)]
+    lc = ddpg_learner_config()
+    lc.model.actor_fc_hidden_sizes, lc.model.critic_fc_hidden_sizes = [12, 8], [16, 12]
+    lc.model.conv_spec.hidden_output_dim = 8
+    lc.replay.batch_size = 4
+    ec = ddpg_env_config(3, 2, pixel=(2, 20, 24))
+    ec.frame_stack_concatenate_on_env = False
+    L = DDPGLearner(lc, ec, ddpg_session_config())
+    b = L._prefetcher_preprocess(exps)
+    assert b['obs']['pixel']['camera0'].shape == (4, 2, 20, 24) and b['obs']['pixel']['camera0'].dtype == np.uint8
+    assert b['obs_next']['pixel']['camera0'][2, 1, 0, 0] == 4 and b['obs']['low_dim']['flat_inputs'].shape == (4, 3)
+    st = L.learn(b)                                            # and the pixel learner takes it
+    assert np.isfinite(st['critic_loss'])
+    with pytest.raises(AssertionError):
+        FrameStackPreprocessor.preprocess_obs({'pixel': {'camera0': [np.zeros((2, 3))]}})
