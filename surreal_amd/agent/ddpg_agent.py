@@ -108,7 +108,7 @@ class DDPGAgent(Agent):
         action = action_t.cpu().numpy()[0]
         action = action.clip(-1, 1)
         if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:
-            action = action + self.noise()
+            action += self.noise()          # in place: the fp64 draw is rounded into the fp32 action (:180)
         return action.clip(-1, 1)
 
     def act_batch(self, obs, sigmas=None, eps=None, generator=None):
@@ -124,6 +124,11 @@ class DDPGAgent(Agent):
 
     def module_dict(self, model=None):
         return {'ddpg': self.model if model is None else model}
+
+    def pre_episode(self):                                # ddpg_agent.py:205-208
+        super().pre_episode()
+        if self.agent_mode not in ['eval_deterministic', 'eval_deterministic_local']:
+            self.noise.reset()                            # the OU process restarts with every episode
 
     def set_experience_sink(self, sink):
         self.sink = sink

@@ -99,7 +99,10 @@ class PPOAgent(Agent):
         allowed, e.g. a rollout buffer's slot) receive the results in place.
         Plain-MLP policies take 5 launches per step: z-filter from the running sums, three layers,
         the sampling head (the reference's ~15 ATen ops + a host round trip, ppo_agent.py:106-154)."""
-        n = obs.shape[0]
+        if isinstance(obs, dict):                    # {'low_dim': {...}, 'pixel': {...}} of [n, ...] tensors
+            n = next(iter(next(iter(obs.values())).values())).shape[0]
+        else:
+            n = obs.shape[0]
         A = self.action_dim
         K = self.K
         if self._batch_noise is None or self._batch_noise.shape[0] != n:

@@ -74,7 +74,8 @@ def make_ppo_batch(B, N, D, A, seed=0, done_prob=0.01, on_policy=True,
 
 
 def make_ppo_params(D, A, hidden=(300, 200), seed=1, init_log_sig=-1.0,
-                    rnn_hidden=0, final_scale=0.05, pixel=None, cnn_feature_dim=256, rnn_layers=1):
+                    rnn_hidden=0, final_scale=0.05, pixel=None, cnn_feature_dim=256, rnn_layers=1,
+                    log_sig_spread=0.0):
     """
     Canonical flat parameter dict (numpy fp32), the *injected* initial state
     for both the oracle and the HIP path.  Kaiming-uniform-like fan-in scaling
@@ -126,6 +127,8 @@ def make_ppo_params(D, A, hidden=(300, 200), seed=1, init_log_sig=-1.0,
     lin('actor.fc2', h2, h1)
     lin('actor.fc3', A, h2, scale=final_scale)
     p['actor.log_var'] = np.full((1, A), init_log_sig, dtype=np.float32)
+    if log_sig_spread:                   # a different log-sigma per action dimension (agent fixtures)
+        p['actor.log_var'] += (log_sig_spread * np.linspace(-1.0, 1.0, A)).astype(np.float32)[None]
     lin('critic.fc1', h1, in_f)
     lin('critic.fc2', h2, h1)
     lin('critic.fc3', 1, h2)
