@@ -133,6 +133,9 @@ class RewardFilter(object):
                           min=self.eps)
         return torch.clamp((inputs - mean) / std, -5.0, 5.0)
 
+    def reward_mean(self):                       # reward_filter.py:59-63
+        return (self.running_sum / self.count).item()
+
 
 # --------------------------------------------------------------------------
 # PPOModel  (surreal/model/ppo_net.py:94-375; builders.py:86-175)
@@ -537,6 +540,8 @@ class OraclePPOLearner(object):
             stats['obs_running_mean'] = float(np.mean(self.model.z_filter.running_mean()))
             stats['obs_running_square'] = float(np.mean(self.model.z_filter.running_square()))
             stats['obs_running_std'] = float(np.mean(self.model.z_filter.running_std()))
+        if self.use_r_filter:                                    # ppo.py:583-584
+            stats['reward_mean'] = self.reward_filter.reward_mean()
         self.trace = trace
         return stats
 

@@ -75,10 +75,15 @@ class Agent(object, metaclass=AutoInitializeMeta):
     # ---- parameter hand-off -------------------------------------------------------------------
     def attach_learner(self, learner):
         learner.add_parameter_listener(self._on_publish)
-        self._published = (learner.module_dict(), {'iteration': 0, 'message': 'initial'})
+        self._on_publish(learner.module_dict(), {'iteration': 0, 'message': 'initial', 'publish_seq': 0})
 
     def _on_publish(self, module_dict, info):
-        self._published = (module_dict, info)
+        """keeps a SNAPSHOT of what was published (device copies of the state dicts): an agent that
+        fetches later gets the parameters of the publish point -- where PPO synchronised its
+        reference policy and beta -- not whatever the learner holds by then"""
+        snap = {name: {k: (v.clone() if hasattr(v, 'clone') else v) for k, v in m.state_dict().items()}
+                for name, m in module_dict.items()}
+        self._published = (snap, info)
 
     def on_parameter_fetched(self, params, info):      # agent/base.py:160-180
         self.actions_since_param_update = 0
@@ -106,13 +111,13 @@ class Agent(object, metaclass=AutoInitializeMeta):
         if self._published is None:
             return False
         params, info = self._published
-        if info.get('iteration') == self._fetched_iteration:
+        if info.get('publish_seq', info.get('iteration')) == self._fetched_iteration:
             return False                      # the reference's "hash unchanged" reply
         params = self.on_parameter_fetched(params, info)
         for name, module in self._module_dict.items():
             got = params[name]               # a live module, or its wire form after on_parameter_fetched
             module.load_state_dict(got.state_dict() if hasattr(got, 'state_dict') else got)
-        self._fetched_iteration = info.get('iteration')
+        self._fetched_iteration = info.get('publish_seq', info.get('iteration'))
         return True
 
     def fetch_parameter_info(self):

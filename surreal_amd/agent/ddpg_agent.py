@@ -83,10 +83,12 @@ class DDPGAgent(Agent):
     def on_parameter_fetched(self, params, info):         # ddpg_agent.py:149-153
         params = super().on_parameter_fetched(params, info)
         if self.param_noise:
-            if any(hasattr(m, 'state_dict') for m in params.values()):
-                # the in-process hand-off passes live modules: noise acts on their wire form
-                from surreal_amd.distributed import ModuleDict
-                params = ModuleDict(dict(params)).numpy_dict()
+            if any(torch.is_tensor(v) for sd in params.values() for v in sd.values()):
+                # the in-process hand-off passes device snapshots: noise acts on their wire form
+                # ({module: {name: ndarray}}, module_dict.py:34-45)
+                params = {name: collections.OrderedDict(
+                    (k, v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                    for k, v in sd.items()) for name, sd in params.items()}
             params = self.param_noise.apply(params)
         return params
 

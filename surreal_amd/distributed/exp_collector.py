@@ -9,28 +9,30 @@ import weakref
 from surreal_amd.utils import serializer as S
 
 
-class _Box(object):
-    """numpy arrays / lists cannot be weakly referenced directly"""
-    __slots__ = ('value', '__weakref__')
-
-    def __init__(self, value):
-        self.value = value
-
-
 class ExperienceCollector(object):
     def __init__(self, exp_handler):
         """exp_handler(exp): called once per experience, e.g. ``replay._insert_wrapper``"""
         self._exp_handler = exp_handler
+        # hash -> the stored object itself, weakly (as exp_collector.py:40-41): an observation stays
+        # shared across chunks for exactly as long as some experience in the replay still holds it
         self._weakref_map = weakref.WeakValueDictionary()
-        self._alive = {}          # hash -> box, kept while the current chunk is being unpacked
 
     def recv(self, binary):
         exp, storage = S.deserialize(binary)
-        self._alive = {}
         experience_list = self._retrieve_storage(exp, storage)
         for e in experience_list:
             self._exp_handler(e)
         return len(experience_list)
+
+    def _lookup(self, key, storage):
+        obj = self._weakref_map.get(key)
+        if obj is None:
+            obj = storage[key]
+            try:
+                self._weakref_map[key] = obj
+            except TypeError:         # not weakly referenceable (a list of frames, a scalar): shared
+                pass                  # within this chunk through `storage`, not across chunks
+        return obj
 
     def _retrieve_storage(self, exp, storage):
         """exp_collector.py:44-65: recurse through lists / dicts, strip the `_hash` suffix from
@@ -47,12 +49,7 @@ class ExperienceCollector(object):
                 out[new_key] = self._retrieve_storage(value, storage)
             return out
         if isinstance(exp, str):
-            box = self._weakref_map.get(exp)
-            if box is None:
-                if exp not in storage:
-                    return exp
-                box = _Box(storage[exp])
-                self._weakref_map[exp] = box
-            self._alive[exp] = box
-            return box.value
+            if exp not in storage and exp not in self._weakref_map:
+                return exp
+            return self._lookup(exp, storage)
         return exp

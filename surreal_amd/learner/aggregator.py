@@ -31,23 +31,38 @@ class FrameStackPreprocessor(object):
     """SSAR experiences whose camera frames were stacked as a LIST (``frame_stack_concatenate_on_env``
     off: the sender ships every frame once, exp_sender.py dedup) get the frames of each observation
     joined on the channel axis before aggregation (surreal/learner/aggregator.py:11-30, used by
-    DDPGLearner._prefetcher_preprocess, ddpg.py:430-440).  Works in place, like the reference."""
+    DDPGLearner._prefetcher_preprocess, ddpg.py:430-440).
+    The reference rewrites the experiences it is handed, which is safe there only because every
+    batch is a fresh copy off the replay socket.  Here the learner samples the replay's own objects
+    (neighbouring SSAR experiences share one observation dict; uniform sampling repeats experiences),
+    so the joined frames go into NEW experience / observation dicts and the sampled ones stay as the
+    agent sent them."""
 
     def __init__(self, frame_stacks):
         self.frame_stacks = frame_stacks
 
     @staticmethod
     def preprocess_obs(obs):
-        for key in obs.get('pixel', ()):
-            obs['pixel'][key] = np.concatenate(obs['pixel'][key], axis=0)
-            if obs['pixel'][key].ndim != 3:
+        """-> a shallow copy of `obs` whose camera entries are single (C, H, W) arrays"""
+        if 'pixel' not in obs:
+            return obs
+        out = type(obs)(obs)
+        out['pixel'] = type(obs['pixel'])(obs['pixel'])
+        for key, frames in obs['pixel'].items():
+            joined = frames if isinstance(frames, np.ndarray) and frames.ndim == 3 \
+                else np.concatenate(frames, axis=0)
+            if joined.ndim != 3:
                 raise AssertionError('stacked camera frames must join to (C, H, W)')
+            out['pixel'][key] = joined
+        return out
 
     def preprocess_list(self, exp_list):
+        out = []
         for exp in exp_list:
-            for obs in (exp['obs'][0], exp['obs'][1]):
-                self.preprocess_obs(obs)
-        return exp_list
+            exp = dict(exp)
+            exp['obs'] = [self.preprocess_obs(exp['obs'][0]), self.preprocess_obs(exp['obs'][1])]
+            out.append(exp)
+        return out
 
 
 class MultistepAggregatorWithInfo(object):

@@ -44,11 +44,14 @@ class ScalarRecorder(object):
 
     def add_scalars(self, scalars, global_step=None):
         self.history.append((global_step, scalars if isinstance(scalars, DeferredStats) else dict(scalars)))
-        if len(self.history) > self.keep:
-            self.latest                      # fold what is about to be dropped
-            drop = len(self.history) - self.keep
+        drop = len(self.history) - self.keep
+        if drop > 0:
+            # fold ONLY what is about to be dropped: newer entries may be read-backs still in
+            # flight, and looking at them would turn every learn() into a device -> host sync
+            for _, old in self.history[self._merged:drop]:
+                self._latest.update(old)
             del self.history[:drop]
-            self._merged -= drop
+            self._merged = max(self._merged - drop, 0)
 
     @property
     def latest(self):
@@ -138,7 +141,9 @@ class Learner(metaclass=AutoInitializeMeta):
         self._ps_publisher = ParameterPublisher(publish_fn, self.module_dict())
 
     def _publish(self, iteration, message=''):
-        info = {'time': time.time(), 'iteration': iteration, 'message': message}
+        self._publish_seq = getattr(self, '_publish_seq', 0) + 1
+        info = {'time': time.time(), 'iteration': iteration, 'message': message,
+                'publish_seq': self._publish_seq}
         for fn in self._parameter_listeners:
             fn(self.module_dict(), info)
         if getattr(self, '_ps_publisher', None) is not None:

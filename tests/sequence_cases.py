@@ -1,0 +1,93 @@
+"""Shared body of the multi-learn parity tests (tests only): sequences of learn() /
+publish_parameter() on the product PPOLearner against tests/golden/ppo_sequences.json, recorded
+from the REFERENCE's own PPOLearner.learn / publish_parameter / _post_publish
+(oracle/gen_golden_sequence.py): RewardFilter over consecutive learns (incl. its running_sumsq
+overwrite), reward_scale != 1, and the publish boundary -- beta / clip_epsilon adaptation in both
+directions and at the range limits, ref_target_model <- model, kl_record reset -- with the learns
+after a publish running with the adapted coefficient (on the GPU: through hipGraph replay, the
+coefficient travelling in the device control block).  1e-5 on every statistic (fp32)."""
+import copy
+import json
+import os
+
+import numpy as np
+
+import helpers as H
+from surreal_amd import synthetic
+
+DOC = json.load(open(os.path.join(H.GOLDEN_DIR, 'ppo_sequences.json')))
+NAMES = sorted(DOC)
+
+
+def make_learner(case, session_overrides=None):
+    shp = case['shape']
+    hyper = dict(case['hyper'])
+    c = dict(case)
+    c['hyper'] = hyper
+    params = synthetic.make_ppo_params(shp['D'], shp['A'], hidden=tuple(case['hidden']),
+                                       rnn_hidden=case['rnn_hidden'], **case['param_args'])
+    zstate = synthetic.make_zfilter_state(shp['D'], **case['z_args'])
+    # H.make_learner reads the common keys; the sequence-only ones are set on the config it builds
+    from surreal_amd.learner.ppo import PPOLearner
+
+    class Configured(PPOLearner):
+        def __init__(self, lc, ec, sc):
+            lc.algo.use_r_filter = bool(hyper.get('use_r_filter', False))
+            lc.algo.advantage.reward_scale = hyper.get('reward_scale', 1.0)
+            lc.parameter_publish.exp_interval = case['exp_interval']
+            if 'beta_init' in hyper:
+                lc.algo.adapt_consts.beta_init = hyper['beta_init']
+            if 'clip_epsilon_init' in hyper:
+                lc.algo.clip_consts.clip_epsilon_init = hyper['clip_epsilon_init']
+            super().__init__(lc, ec, sc)
+    return H.make_learner(c, params, zstate, cls=Configured, session_overrides=session_overrides)
+
+
+def run_sequence(name, session_overrides=None, atol=H.ATOL, rtol=H.RTOL):
+    case, records = DOC[name]['case'], DOC[name]['records']
+    shp = case['shape']
+    L = make_learner(case, session_overrides)
+    published = []
+    L.add_parameter_listener(lambda md, info: published.append(info))
+    it = 0
+    for r in records:
+        if r['op'] == 'learn':
+            batch = synthetic.make_ppo_batch(shp['B'], shp['N'], shp['D'], shp['A'], rnn_hidden=case['rnn_hidden'],
+                                             seed=r['seed'], **case['batch_args'])
+            stats = L.learn(copy.deepcopy(batch))
+            what = '%s learn #%d' % (name, it)
+            assert set(stats) == set(r['stats']), (what, sorted(set(stats) ^ set(r['stats'])))
+            for k, v in r['stats'].items():
+                if k == '_lr':
+                    continue
+                at, rt = H.tol_for(k, atol, rtol)
+                np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg=what + ' ' + k)
+            tr = L.trace
+            assert len(tr['policy']) == len(r['policy']), (what, 'epochs executed')
+            for e, (a, b) in enumerate(zip(tr['policy'] + tr['value'], r['policy'] + r['value'])):
+                for k in b:
+                    at, rt = H.tol_for(k, atol, rtol)
+                    np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
+                                               err_msg='%s epoch row %d %s' % (what, e, k))
+            adv = L._ws.adv.cpu().numpy().reshape(-1).astype(np.float64)
+            ret = L._ws.ret.cpu().numpy().reshape(-1).astype(np.float64)
+            np.testing.assert_allclose(adv[:8], r['adv_head'], atol=atol, rtol=rtol, err_msg=what + ' adv')
+            np.testing.assert_allclose(ret[:8], r['ret_head'], atol=atol, rtol=rtol, err_msg=what + ' ret')
+            np.testing.assert_allclose(np.abs(adv).sum(), r['adv_abs_sum'], rtol=1e-5, err_msg=what)
+            np.testing.assert_allclose(ret.sum(), r['ret_sum'], rtol=1e-5, atol=1e-4 * len(ret), err_msg=what)
+            assert L.exp_counter == r['exp_counter']
+            np.testing.assert_allclose(L.kl_record, r['kl_record'], atol=atol, rtol=rtol)
+            it += 1
+        else:
+            n0 = len(published)
+            L.publish_parameter(it, message='batch ' + str(it))
+            assert (len(published) > n0) == r['fired'], (name, it, 'publish fired')
+            assert L.exp_counter == r['exp_counter'] and len(L.kl_record) == r['kl_record_len']
+            if r['beta'] is not None:
+                assert L.beta == r['beta'], (name, it, L.beta, r['beta'])       # same fp64 host arithmetic
+            if r['clip_epsilon'] is not None:
+                assert L.clip_epsilon == r['clip_epsilon']
+            if r['fired']:
+                a, b = L.ref_target_model.numpy_params(), L.model.numpy_params()
+                assert all(np.array_equal(a[k], b[k]) for k in a)
+    return L

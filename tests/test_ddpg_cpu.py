@@ -145,5 +145,15 @@ def test_frame_stack_preprocessor_joins_frame_lists(cpu_double):
     assert b['obs_next']['pixel']['camera0'][2, 1, 0, 0] == 4 and b['obs']['low_dim']['flat_inputs'].shape == (4, 3)
     st = L.learn(b)                                            # and the pixel learner takes it
     assert np.isfinite(st['critic_loss'])
+    # the replay's own objects are left as the agent sent them: neighbouring SSAR experiences SHARE
+    # an observation dict (exp_t's obs[1] is exp_{t+1}'s obs[0]) and uniform sampling repeats
+    # experiences, so a second pass over the same objects must see frame lists again
+    shared = [obs(i) for i in range(5)]
+    exps2 = [{'obs': [shared[i], shared[i + 1]], 'action': np.zeros(2, np.float32), 'reward': 1.0, 'done': False}
+             for i in range(4)]
+    b1 = L._prefetcher_preprocess([exps2[0], exps2[1], exps2[1], exps2[3]])
+    b2 = L._prefetcher_preprocess([exps2[0], exps2[1], exps2[1], exps2[3]])
+    np.testing.assert_array_equal(b1['obs']['pixel']['camera0'], b2['obs']['pixel']['camera0'])
+    assert all(isinstance(o['pixel']['camera0'], list) for o in shared)
     with pytest.raises(AssertionError):
         FrameStackPreprocessor.preprocess_obs({'pixel': {'camera0': [np.zeros((2, 3))]}})
