@@ -13,6 +13,7 @@ import os
 import numpy as np
 
 import helpers as H
+import ppo_oracle
 from surreal_amd import synthetic
 
 DOC = json.load(open(os.path.join(H.GOLDEN_DIR, 'ppo_sequences.json')))
@@ -43,10 +44,41 @@ def make_learner(case, session_overrides=None):
     return H.make_learner(c, params, zstate, cls=Configured, session_overrides=session_overrides)
 
 
+# Gradient norms drift ACROSS HOSTS in the reference itself once several learns are chained: the
+# oracle (bit-identical to the reference where the goldens were recorded) run on the GPU box's host
+# CPU gives grad_norm_critic 1.9116889 for the third learn of cfg5_publish_adapt against 1.9129276
+# in the golden (6.5e-4; ReLU masks at the fp32 noise floor + Adam's sign-like first steps), while
+# the HIP path gives 1.9116902 -- 7e-7 from the same-host oracle (scripts/diag_sequence.py).  So the
+# gradient norms are held to LOOSE_RTOL against the oracle run beside the product on the SAME host,
+# and to SEQ_GOLDEN_RTOL against the golden; every loss / KL / likelihood statistic is held to 1e-5
+# against the golden as everywhere else.
+SEQ_GOLDEN_RTOL = 2e-3
+
+
+def make_oracle(case):
+    shp = case['shape']
+    hyper = dict(case['hyper'])
+    hyper['n_step'] = shp['N']
+    params = synthetic.make_ppo_params(shp['D'], shp['A'], hidden=tuple(case['hidden']),
+                                       rnn_hidden=case['rnn_hidden'], **case['param_args'])
+    zstate = synthetic.make_zfilter_state(shp['D'], **case['z_args'])
+    return ppo_oracle.OraclePPOLearner(params, shp['A'], shp['B'], zstate=zstate, **hyper)
+
+
+def _close(key, got, golden, same_host, what, atol, rtol):
+    if key in H.LOOSE_KEYS:
+        np.testing.assert_allclose(got, golden, atol=atol, rtol=SEQ_GOLDEN_RTOL, err_msg=what + ' (golden)')
+        np.testing.assert_allclose(got, same_host, atol=atol, rtol=H.LOOSE_RTOL,
+                                   err_msg=what + ' (oracle on this host)')
+    else:
+        np.testing.assert_allclose(got, golden, atol=atol, rtol=rtol, err_msg=what)
+
+
 def run_sequence(name, session_overrides=None, atol=H.ATOL, rtol=H.RTOL):
     case, records = DOC[name]['case'], DOC[name]['records']
     shp = case['shape']
     L = make_learner(case, session_overrides)
+    O = make_oracle(case)
     published = []
     L.add_parameter_listener(lambda md, info: published.append(info))
     it = 0
@@ -55,20 +87,19 @@ def run_sequence(name, session_overrides=None, atol=H.ATOL, rtol=H.RTOL):
             batch = synthetic.make_ppo_batch(shp['B'], shp['N'], shp['D'], shp['A'], rnn_hidden=case['rnn_hidden'],
                                              seed=r['seed'], **case['batch_args'])
             stats = L.learn(copy.deepcopy(batch))
+            ostats = O.learn(copy.deepcopy(batch))
             what = '%s learn #%d' % (name, it)
             assert set(stats) == set(r['stats']), (what, sorted(set(stats) ^ set(r['stats'])))
             for k, v in r['stats'].items():
                 if k == '_lr':
                     continue
-                at, rt = H.tol_for(k, atol, rtol)
-                np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg=what + ' ' + k)
+                _close(k, stats[k], v, ostats[k], what + ' ' + k, atol, rtol)
             tr = L.trace
             assert len(tr['policy']) == len(r['policy']), (what, 'epochs executed')
+            orows = O.trace['policy'] + O.trace['value']
             for e, (a, b) in enumerate(zip(tr['policy'] + tr['value'], r['policy'] + r['value'])):
                 for k in b:
-                    at, rt = H.tol_for(k, atol, rtol)
-                    np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
-                                               err_msg='%s epoch row %d %s' % (what, e, k))
+                    _close(k, a[k], b[k], orows[e][k], '%s epoch row %d %s' % (what, e, k), atol, rtol)
             adv = L._ws.adv.cpu().numpy().reshape(-1).astype(np.float64)
             ret = L._ws.ret.cpu().numpy().reshape(-1).astype(np.float64)
             np.testing.assert_allclose(adv[:8], r['adv_head'], atol=atol, rtol=rtol, err_msg=what + ' adv')
@@ -81,6 +112,8 @@ def run_sequence(name, session_overrides=None, atol=H.ATOL, rtol=H.RTOL):
         else:
             n0 = len(published)
             L.publish_parameter(it, message='batch ' + str(it))
+            if O.exp_counter >= case['exp_interval']:
+                O._post_publish()
             assert (len(published) > n0) == r['fired'], (name, it, 'publish fired')
             assert L.exp_counter == r['exp_counter'] and len(L.kl_record) == r['kl_record_len']
             if r['beta'] is not None:
