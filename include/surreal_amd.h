@@ -352,6 +352,62 @@ typedef struct smx_ppo_combine {
 } smx_ppo_combine_t;
 int smx_ppo_epoch_combine_f32(const smx_ppo_combine_t* args, smx_ppo_ctrl_t* ctrl,
                               smx_stream_t stream);
+/* the weight-gradient launch of smx_mlp3_backward_multi_f32 alone (all three layers of up to 3 jobs
+ * in ONE launch): dW_l = dz_l^T . input_l, db_l = column sums, per-tile sums of squares.  Needs the
+ * transposed operands (xT, h1T, h2T, dz3T, dz2T, dz1T, ldT) the fused epoch kernels write. */
+int smx_mlp3_wgrad_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream);
+
+/* --- fused row-block epoch kernels -------------------------------------------------------------
+ * One policy / value epoch of PPOLearner._optimize (surreal/learner/ppo.py:541-562; losses
+ * :194-353; forward_actor / forward_critic surreal/model/ppo_net.py:253-315) on a few thousand
+ * rows as FOUR dependent launches instead of nine: a workgroup owns 16 rows of one network and runs
+ *   smx_epoch_forward_f32   layer 1 -> 2 -> 3 (FP32 MFMA 16x16x4, activations through LDS) and the
+ *                           job's loss on those rows: SMX_EPOCH_LOSS_POLICY = DiagGauss likelihoods /
+ *                           KL / surrogate -> loss->g_surr, g_kl [rows, A] and the block partial
+ *                           sums loss->row_partials [smx_epoch_blocks(rows), 8 + 2A];
+ *                           SMX_EPOCH_LOSS_VALUE = loss->v_dz3 [rows] = 2 (V - ret) / n_total and
+ *                           loss->v_partials [smx_epoch_blocks(rows), 8] (mergeable moments, the
+ *                           layout smx_value_loss_finalize_f32 reads).  h1T / h2T ([H, ldT]) receive
+ *                           the hidden activations transposed; out ([rows, OUT], row stride out_ld)
+ *                           the network output (optional).  A job with a raised stop_flag is skipped.
+ *   smx_epoch_backward_f32  policy job: batch means from the partial rows -> KL coefficient
+ *                           (ppo.py:272-276), loss->stats / dlogvar / dlogvar_sumsq, the KL early
+ *                           exit and step counters exactly as smx_ppo_loss_finalize_f32, then
+ *                           dz3 = (g_surr + c_kl g_kl) / n_total; value job: dz3 = job.dz3 [rows].
+ *                           dz2 = (dz3 . W3) * relu'(h2), dz1 = (dz2 . W2) * relu'(h1) written
+ *                           transposed (dz3T [OUT, ldT] policy only, dz2T, dz1T).  With
+ *                           loss->will_update == 0 (the final, forward-only pass) only the
+ *                           statistics / early-exit part runs (one job, one workgroup).
+ * followed by smx_mlp3_wgrad_multi_f32 and smx_clip_adam_step_pair_f32.
+ * Requirements (smx_epoch_supported): D, H1, H2 multiples of 4, OUT <= 32, x dense [rows, D] and the
+ * weights 16-byte aligned.  loss->mean / dz3 / dz3_t / values are not used (the tiles stay on chip). */
+enum { SMX_EPOCH_LOSS_NONE = 0, SMX_EPOCH_LOSS_POLICY = 1, SMX_EPOCH_LOSS_VALUE = 2 };
+typedef struct smx_epoch_job {
+    const smx_mlp3_t* net;
+    const float* x;
+    int64_t rows;
+    float* h1T;
+    float* h2T;
+    int64_t ldT;
+    float* out;
+    int32_t out_ld;   /* 0 = OUT */
+    int32_t out_act;
+    int32_t loss;     /* SMX_EPOCH_LOSS_* */
+    int32_t reserved;
+    const int32_t* stop_flag;
+    const float* dz3; /* backward, value job: [rows] */
+    float* dz3T;
+    float* dz2T;
+    float* dz1T;
+} smx_epoch_job_t;
+struct smx_ppo_losses;
+int32_t smx_epoch_blocks(int64_t rows);
+int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
+                          smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream);
+int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
+                           smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream);
+
 /* --- acting head (PPOAgent.act, ppo_agent.py:106-154; DiagGauss.sample/maxprob, ppo_net.py:74-91) ---
  * pd[r] = [mean[r, :], exp(log_var) * noise_scale[r]]   (builders.py:127; ppo_agent.py:139:
  *         action_pd[:, A:] *= exp(noise), noise_scale == NULL: 1)

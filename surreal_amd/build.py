@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsurreal_amd.so')
 SOURCES = ['smx_scan.hip', 'smx_mlp3_fused.hip', 'smx_gemm.hip', 'smx_ppo.hip', 'smx_replay.hip',
-           'smx_ddpg.hip', 'smx_lstm.hip', 'smx_conv.hip']
+           'smx_ddpg.hip', 'smx_lstm.hip', 'smx_conv.hip', 'smx_epoch.hip']
 # -ffp-contract=off: the reference issues separate ATen mul/add ops; contraction into FMAs would
 # change roundings that the parity tests pin (the MFMA path is unaffected).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
@@ -38,8 +38,8 @@ def _newer(target, deps):
 
 def build(force=False, verbose=True):
     cc = hipcc()
-    headers = [os.path.join(CSRC, 'smx_common.h'),
-               os.path.join(os.path.dirname(HERE), 'include', 'surreal_amd.h')]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'surreal_amd.h')]
     objs = []
     procs = []
     for src in SOURCES:

@@ -634,36 +634,8 @@ extern "C" int32_t smx_mlp3_backward_partials(int32_t D, int32_t H1, int32_t H2,
     return t(H1) * t(D) + t(H2) * t(H1) + t(OUT) * t(H2);
 }
 
-extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs,
-                                           smx_stream_t stream) {
-    SMX_REQUIRE(jobs, SMX_E_NULL);
-    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_JOBS, SMX_E_SHAPE);
-    for (int j = 0; j < njobs; ++j) {
-        const smx_mlp3_job_t& J = jobs[j];
-        SMX_REQUIRE(J.net && J.x && J.h1 && J.h2 && J.dz3 && J.dz2 && J.dz1 && J.grads, SMX_E_NULL);
-        SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
-    }
-    // dz2 = (dz3 . W3) * relu'(h2)   [R, H2], K = OUT ;  dz1 = (dz2 . W2) * relu'(h1)   [R, H1], K = H2
-    for (int stage = 0; stage < 2; ++stage) {
-        GemmBatch G;
-        G.n = njobs;
-        int base = 0;
-        for (int j = 0; j < njobs; ++j) {
-            const smx_mlp3_job_t& J = jobs[j];
-            const smx_mlp3_t* n = J.net;
-            const int R = (int)J.rows;
-            if (stage == 0)
-                fill_prob(G.p[j], J.dz3, n->OUT, 1, n->W3, n->H2, 0, nullptr, J.h2, J.dz2, n->H2, R,
-                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz2T, (int)(J.ldT ? J.ldT : R));
-            else
-                fill_prob(G.p[j], J.dz2, n->H2, 1, n->W2, n->H1, 0, nullptr, J.h1, J.dz1, n->H1, R,
-                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz1T, (int)(J.ldT ? J.ldT : R));
-            base += G.p[j].tiles_m * G.p[j].tiles_n;
-        }
-        const int rc = launch_batch(G, smx_s(stream));
-        if (rc) return rc;
-    }
-    // dW_l = dz_l^T . input_l , db_l = column sums of dz_l : 3 problems per job, one launch
+// dW_l = dz_l^T . input_l , db_l = column sums of dz_l : 3 problems per job, one launch
+static int launch_wgrads(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream) {
     GemmBatch G;
     G.n = 3 * njobs;
     int base = 0;
@@ -697,6 +669,49 @@ extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t n
         base += G.p[3 * j + 2].tiles_m * G.p[3 * j + 2].tiles_n;
     }
     return launch_batch(G, smx_s(stream));
+}
+
+extern "C" int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs,
+                                           smx_stream_t stream) {
+    SMX_REQUIRE(jobs, SMX_E_NULL);
+    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_JOBS, SMX_E_SHAPE);
+    for (int j = 0; j < njobs; ++j) {
+        const smx_mlp3_job_t& J = jobs[j];
+        SMX_REQUIRE(J.net && J.x && J.h1 && J.h2 && J.dz3 && J.dz2 && J.dz1 && J.grads, SMX_E_NULL);
+        SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
+    }
+    // dz2 = (dz3 . W3) * relu'(h2)   [R, H2], K = OUT ;  dz1 = (dz2 . W2) * relu'(h1)   [R, H1], K = H2
+    for (int stage = 0; stage < 2; ++stage) {
+        GemmBatch G;
+        G.n = njobs;
+        int base = 0;
+        for (int j = 0; j < njobs; ++j) {
+            const smx_mlp3_job_t& J = jobs[j];
+            const smx_mlp3_t* n = J.net;
+            const int R = (int)J.rows;
+            if (stage == 0)
+                fill_prob(G.p[j], J.dz3, n->OUT, 1, n->W3, n->H2, 0, nullptr, J.h2, J.dz2, n->H2, R,
+                          n->H2, n->OUT, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz2T, (int)(J.ldT ? J.ldT : R));
+            else
+                fill_prob(G.p[j], J.dz2, n->H2, 1, n->W2, n->H1, 0, nullptr, J.h1, J.dz1, n->H1, R,
+                          n->H1, n->H2, SMX_ACT_NONE, nullptr, nullptr, base, J.stop_flag, J.dz1T, (int)(J.ldT ? J.ldT : R));
+            base += G.p[j].tiles_m * G.p[j].tiles_n;
+        }
+        const int rc = launch_batch(G, smx_s(stream));
+        if (rc) return rc;
+    }
+    return launch_wgrads(jobs, njobs, stream);
+}
+
+extern "C" int smx_mlp3_wgrad_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stream_t stream) {
+    SMX_REQUIRE(jobs, SMX_E_NULL);
+    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_JOBS, SMX_E_SHAPE);
+    for (int j = 0; j < njobs; ++j) {
+        const smx_mlp3_job_t& J = jobs[j];
+        SMX_REQUIRE(J.net && J.grads && J.xT && J.h1T && J.h2T && J.dz1T && J.dz2T && J.dz3T, SMX_E_NULL);
+        SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
+    }
+    return launch_wgrads(jobs, njobs, stream);
 }
 
 extern "C" int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, const float* h1,

@@ -11,157 +11,7 @@
 #include "smx_common.h"
 
 namespace {
-
-// rows per workgroup of the policy loss: 16 -> 64 workgroups for the 1024-row epochs (the kernel is
-// a chain of three short phases; with 64 rows it ran on 16 CUs and took 11 us, most of it waiting)
-constexpr int LOSS_ROWS_PER_BLOCK = 16;
-constexpr int MAX_A = 32;
-
-__device__ __forceinline__ float clamp_min_nan(float x, float lo) {
-    return (x == x) ? fmaxf(x, lo) : x;  // torch.clamp(min=) keeps NaN
-}
-
-// 64 rows per block, 256 threads, three phases:
-//   1. all waves move the block's rows of mean / actions / behave / ref HBM -> LDS with coalesced
-//      loads and compute the per-ELEMENT terms (one (row, a) pair per thread-iteration): the
-//      transcendentals (log, exp, divisions) are spread over 256 lanes instead of being
-//      serialised 17-deep in one lane per row;
-//   2. one lane per row reduces its A terms, forms the likelihoods / ratio / clip decision and
-//      the per-row gradient scale, and the wave reduces the block partial sums;
-//   3. all waves form the two gradient tiles (element-parallel), write them back coalesced, and
-//      A lanes reduce the log_var gradient partials over the block's rows.
-__device__ __forceinline__ void policy_loss_body(
-    const int blk, float* sm,
-    int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
-    const float* __restrict__ g_actions, int ld_act, const float* __restrict__ g_behave, int ld_beh,
-    const float* __restrict__ g_ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
-    const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
-    float* __restrict__ partials, const float gscale = 1.0f, const bool scaled = false,
-    float* __restrict__ g_surr_t = nullptr, float* __restrict__ g_kl_t = nullptr, const long ld_t = 0) {
-    const int R = LOSS_ROWS_PER_BLOCK;
-    float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
-    float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
-    float* e_lsb = e_zb2 + R * A;  // log sb
-    float* e_kl = e_lsb + R * A;   // log(sig/sr) + (sr^2+(mr-mu)^2)/(2 sig^2)
-    float* e_klb = e_kl + R * A;   // log(sb/sr) + (sr^2+(mr-mb)^2)/(2 sb^2)
-    float* e_dmu = e_klb + R * A;  // ((a - mu)/sig^2) * (1 - mu^2)        d ll / d z3
-    float* e_dkl = e_dmu + R * A;  // ((mu - mr)/sig^2) * (1 - mu^2)       d KL / d z3
-    float* e_gk = e_dkl + R * A;   // 1 - (sr^2+(mr-mu)^2)/sig^2          d KL / d log_var
-    float* r_dll = e_gk + R * A;   // per-row d(loss_r)/d(ll)             [R]
-    const long row0 = (long)blk * R;
-    long nrows = rows - row0;
-    if (nrows > R) nrows = R;
-    const int tid = threadIdx.x;
-    const int stride = 8 + 2 * A;
-    float* P = partials + (size_t)blk * stride;
-
-    // ---- phase 1: element-parallel terms ------------------------------------------------
-    for (int i = tid; i < (int)nrows * A; i += 256) {
-        const int rr = i / A, a = i - rr * A;
-        const long gr = row0 + rr;
-        const float sig = expf(log_var[a]);                      // builders.py:127
-        const float mu = g_mean[gr * A + a];
-        const float ac = g_actions[gr * ld_act + a];
-        const float mb = g_behave[gr * ld_beh + a], sb = g_behave[gr * ld_beh + A + a];
-        const float mr = g_ref[gr * ld_ref + a], sr = g_ref[gr * ld_ref + A + a];
-        const float z = (ac - mu) / sig;                         // ppo_net.py:39
-        const float zb = (ac - mb) / sb;
-        const float s2 = sig * sig;
-        const float dt = 1.0f - mu * mu;                         // tanh'
-        const float num = sr * sr + (mr - mu) * (mr - mu);
-        e_z2[i] = z * z;
-        e_zb2[i] = zb * zb;
-        e_lsb[i] = logf(sb);
-        e_kl[i] = logf(sig / sr) + num / (2.0f * s2);            // ppo_net.py:61-62
-        e_klb[i] = logf(sb / sr) + (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
-        e_dmu[i] = ((ac - mu) / s2) * dt;
-        e_dkl[i] = ((mu - mr) / s2) * dt;
-        e_gk[i] = 1.0f - num / s2;
-    }
-    __syncthreads();
-
-    // ---- phase 2: one lane per row ---------------------------------------------------------
-    if (tid < 64) {                      // one wave; lanes >= nrows only feed zeros to the sums
-        const int r = tid;
-        const bool ok = r < nrows;
-        const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
-        const float half_d = (float)(0.5 * (double)A);
-        float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f, klr = 0.f, klbr = 0.f;
-        if (ok) {
-            for (int a = 0; a < A; ++a) {
-                s1 += e_z2[r * A + a];
-                s2 += logf(expf(log_var[a]));                    // std0.log()  (ppo_net.py:40)
-                sb1 += e_zb2[r * A + a];
-                sb2 += e_lsb[r * A + a];
-                klr += e_kl[r * A + a];
-                klbr += e_klb[r * A + a];
-            }
-        }
-        const float ll = ((-0.5f * s1) - c_ll) - s2;
-        const float llb = ((-0.5f * sb1) - c_ll) - sb2;
-        const float el = expf(ll);
-        const float Ll = clamp_min_nan(el, 1e-5f);               // ppo_net.py:46
-        const float Lb = clamp_min_nan(expf(llb), 1e-5f);
-        const float kl = klr - half_d;
-        const float klb = klbr - half_d;
-        const float ad = ok ? adv[row0 + r] : 0.f;
-        float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
-        if (mode == SMX_PPO_CLIP) {
-            const float eps = ctrl->clip_eps;
-            const float lo = (float)(1.0 - (double)eps), hi = (float)(1.0 + (double)eps);
-            const float ratio = Ll / Lb;                                    // ppo.py:212
-            float cr = ratio;
-            if (cr == cr) cr = fminf(fmaxf(cr, lo), hi);                    // ppo.py:213
-            surr = -ratio * ad;                                             // ppo.py:215
-            const float cs = -cr * ad;                                      // ppo.py:216
-            loss_r = (surr >= cs) ? surr : cs;                              // ppo.py:217
-            // max() routes the gradient to the larger entry; the clamped one has zero slope
-            // outside [lo, hi] and equals the unclamped one inside.
-            dLl = (surr >= cs) ? (-ad / Lb) : 0.f;
-        } else {
-            const float Lbc = clamp_min_nan(Lb, 1e-2f);                     // ppo.py:271
-            surr = -(ad * (Ll / Lbc));
-            loss_r = surr;
-            dLl = -ad / Lbc;
-        }
-        // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
-        const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
-        if (r < R) r_dll[r] = ok ? dll : 0.f;
-        const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
-        const float v0 = smx_wave_sum(ok ? surr : 0.f);
-        const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
-        const float v2 = smx_wave_sum(ok ? kl : 0.f);
-        const float v3 = smx_wave_sum(ok ? Lb : 0.f);
-        const float v4 = smx_wave_sum(ok ? isw : 0.f);
-        const float v5 = smx_wave_sum(ok ? klb : 0.f);
-        if (tid == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
-    }
-    __syncthreads();
-
-    // ---- phase 3: gradient tiles + log_var gradient partials -----------------------------
-    for (int i = tid; i < (int)nrows * A; i += 256) {
-        const int rr = i / A;
-        float gs = r_dll[rr] * e_dmu[i], gk = e_dkl[i];
-        if (scaled) { gs *= gscale; gk *= gscale; }       // data-parallel epochs: already / n_total
-        g_surr[row0 * A + i] = gs;
-        g_kl[row0 * A + i] = gk;
-        if (g_surr_t) {
-            const long at = (long)(i - rr * A) * ld_t + row0 + rr;
-            g_surr_t[at] = gs;
-            if (g_kl_t) g_kl_t[at] = gk;
-        }
-    }
-    if (tid < A) {
-        // d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
-        float gs = 0.f, gk = 0.f;
-        for (int rr = 0; rr < (int)nrows; ++rr) {
-            gs += r_dll[rr] * (e_z2[rr * A + tid] - 1.0f);
-            gk += e_gk[rr * A + tid];
-        }
-        P[8 + tid] = gs;
-        P[8 + A + tid] = gk;
-    }
-}
+#include "smx_ppo_loss.inc.h"
 
 __global__ __launch_bounds__(256) void policy_loss_kernel(
     int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
@@ -171,83 +21,8 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(
     float* __restrict__ partials) {
     if (ctrl->stop_flag) return;
     extern __shared__ float sm[];
-    policy_loss_body(blockIdx.x, sm, mode, g_mean, log_var, g_actions, ld_act, g_behave, ld_beh, g_ref,
+    policy_loss_body(blockIdx.x, sm, mode, g_mean + (size_t)blockIdx.x * LOSS_ROWS_PER_BLOCK * A, A, log_var, g_actions, ld_act, g_behave, ld_beh, g_ref,
                      ld_ref, adv, rows, A, ctrl, g_surr, g_kl, partials);
-}
-
-// batch sums S[0 .. 8 + 2A) of the block partial rows: staged through LDS with coalesced loads and
-// added in row order (the order, hence the result, is the same in every workgroup)
-constexpr int FIN_CH = 64;                                   // partial rows staged per pass
-__device__ __forceinline__ void reduce_row_partials(const float* __restrict__ partials, int nblk,
-                                                    int stride, float* S, float* buf) {
-    float t = 0.f;
-    for (int b0 = 0; b0 < nblk; b0 += FIN_CH) {
-        const int nb = min(FIN_CH, nblk - b0);
-        for (int idx = threadIdx.x; idx < nb * stride; idx += 256)
-            buf[idx] = partials[(size_t)b0 * stride + idx];
-        __syncthreads();
-        if ((int)threadIdx.x < stride)
-            for (int b = 0; b < nb; ++b) t += buf[b * stride + threadIdx.x];
-        __syncthreads();
-    }
-    if ((int)threadIdx.x < stride) S[threadIdx.x] = t;
-    __syncthreads();
-}
-
-// loss and the coefficient of the KL gradient from the batch sums (ppo.py:217 / 272-276)
-__device__ __forceinline__ void loss_and_kl_coef(int mode, const float* S, float n,
-                                                 const smx_ppo_ctrl_t* __restrict__ ctrl,
-                                                 float& loss, float& c_kl) {
-    const float surr_mean = S[0] / n;
-    const float kl_mean = S[2] / n;
-    c_kl = 0.f;
-    if (mode == SMX_PPO_CLIP) {
-        loss = S[1] / n;
-    } else {
-        const float beta = ctrl->beta, eta = ctrl->eta;
-        const double kt2 = 2.0 * (double)ctrl->kl_target;
-        loss = surr_mean + beta * kl_mean;                              // ppo.py:272
-        c_kl = beta;
-        if ((double)kl_mean - kt2 > 0.0) {                              // ppo.py:275-276
-            const float d = kl_mean - (float)kt2;
-            loss += eta * (d * d);
-            c_kl += 2.0f * eta * d;
-        }
-    }
-}
-
-// one thread: the epoch's statistics, the KL early exit and the step counters
-__device__ __forceinline__ void write_policy_scalars(const float* S, float n, float loss, float c_kl,
-                                                     const float* __restrict__ log_var, int A,
-                                                     smx_ppo_ctrl_t* __restrict__ ctrl,
-                                                     int check_stop, int will_update,
-                                                     float* __restrict__ dlogvar_sumsq,
-                                                     float* __restrict__ stats) {
-    const float inv_n = 1.0f / n;
-    const float kl_mean = S[2] / n;
-    float ls = 0.f, dq = 0.f;
-    for (int a = 0; a < A; ++a) {
-        ls += logf(expf(log_var[a]));
-        const float g = (S[8 + a] + c_kl * S[8 + A + a]) * inv_n;
-        dq += g * g;
-    }
-    if (dlogvar_sumsq) *dlogvar_sumsq = dq;
-    stats[SMX_PS_SURR] = S[0] / n;
-    stats[SMX_PS_LOSS] = loss;
-    // ppo_net.py:72 (sic): 0.5 * sum(log std) + 0.5 * log(2 pi e) * d
-    stats[SMX_PS_ENTROPY] = 0.5f * ls + (float)(0.5 * 2.8378770664093453 * (double)A);
-    stats[SMX_PS_KL] = kl_mean;
-    stats[SMX_PS_LB] = S[3] / n;
-    stats[SMX_PS_ISW] = S[4] / n;
-    stats[SMX_PS_REFBEH] = S[5] / n;
-    int stop = 0;
-    if (check_stop && (double)kl_mean > 4.0 * (double)ctrl->kl_target) stop = 1;  // ppo.py:556
-    if (stop) {
-        ctrl->stop_flag = 1;
-    } else if (will_update) {
-        ctrl->adam_step_actor += 1;
-        ctrl->epochs_done += 1;
-    }
 }
 
 // blk / nblocks: this workgroup's share of the elementwise part (blk 0 also writes the scalars)
@@ -364,7 +139,7 @@ __global__ __launch_bounds__(256) void ppo_losses_kernel(smx_ppo_losses_t a,
         return;
     }
     if (ctrl->stop_flag) return;
-    policy_loss_body(blockIdx.x, sm, a.mode, a.mean, a.log_var, a.actions, a.ld_act, a.behave, a.ld_beh,
+    policy_loss_body(blockIdx.x, sm, a.mode, a.mean + (size_t)blockIdx.x * LOSS_ROWS_PER_BLOCK * a.A, a.A, a.log_var, a.actions, a.ld_act, a.behave, a.ld_beh,
                      a.ref, a.ld_ref, a.adv, (long)a.rows, a.A, ctrl, a.g_surr, a.g_kl, a.row_partials,
                      1.0f / (float)n_total, scaled != 0, g_surr_t, g_kl_t, (long)a.ld_t);
 }

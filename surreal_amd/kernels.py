@@ -125,6 +125,74 @@ class HipKernels(object):
                L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1), L.ptr(grads), L.ptr(sumsq),
                L.ptr(stop), self._st())
 
+    # ---- fused row-block epoch kernels (csrc/smx_epoch.hip) ------------------------------
+    def epoch_supported(self, net):
+        return bool(self.lib.smx_epoch_supported(net.D, net.H1, net.H2, net.OUT))
+
+    def epoch_blocks(self, rows):
+        return self.lib.smx_epoch_blocks(rows)
+
+    _EPOCH_LOSS = {None: L.EPOCH_LOSS_NONE, 'policy': L.EPOCH_LOSS_POLICY, 'value': L.EPOCH_LOSS_VALUE}
+
+    def _epoch_jobs(self, jobs):
+        arr = (L.EpochJob * len(jobs))()
+        for k, j in enumerate(jobs):
+            g = lambda name: L.ptr(j.get(name)) if j.get(name) is not None else None  # noqa: E731
+            x = j['x']
+            assert x.is_contiguous()
+            arr[k].net = ctypes.pointer(j['net'].desc)
+            arr[k].x, arr[k].rows = L.ptr(x), x.shape[0]
+            arr[k].h1T, arr[k].h2T = g('h1T'), g('h2T')
+            tv = j.get('h1T')
+            arr[k].ldT = 0 if tv is None else (tv.stride(0) if tv.shape[0] > 1 else tv.shape[1])
+            out = j.get('out')
+            arr[k].out = g('out')
+            arr[k].out_ld = 0 if out is None or out.dim() < 2 or out.stride(0) == out.shape[1] else out.stride(0)
+            arr[k].out_act = int(j.get('act', 0))
+            arr[k].loss = self._EPOCH_LOSS[j.get('loss')]
+            arr[k].stop_flag = g('stop')
+            arr[k].dz3, arr[k].dz3T, arr[k].dz2T, arr[k].dz1T = g('dz3'), g('dz3T'), g('dz2T'), g('dz1T')
+        return arr
+
+    @staticmethod
+    def _epoch_loss(loss):
+        if loss is None:
+            return None
+        a = L.PpoLosses()
+        g = lambda name: L.ptr(loss.get(name)) if loss.get(name) is not None else None  # noqa: E731
+        a.mode = int(loss.get('mode', 0))
+        if loss.get('log_var') is not None:
+            A = loss['log_var'].numel()
+            a.A, a.rows = A, int(loss['rows'])
+            a.log_var, a.adv = g('log_var'), g('adv')
+            if loss.get('actions') is not None:
+                a.actions, a.ld_act = g('actions'), _row_stride(loss['actions'], A)
+                a.behave, a.ld_beh = g('behave'), _row_stride(loss['behave'], 2 * A)
+                a.ref, a.ld_ref = g('ref'), _row_stride(loss['ref'], 2 * A)
+            a.g_surr, a.g_kl, a.row_partials = g('g_surr'), g('g_kl'), g('partials')
+            a.check_stop, a.will_update = int(loss.get('check_stop', 0)), int(loss.get('will_update', 0))
+            a.dlogvar, a.dlogvar_sumsq, a.stats = g('dlogvar'), g('dlogvar_sumsq'), g('stats')
+        a.returns, a.v_dz3, a.v_partials = g('returns'), g('v_dz3'), g('v_partials')
+        a.v_will_update = int(loss.get('v_will_update', 0))
+        return ctypes.byref(a)
+
+    def epoch_forward(self, jobs, loss=None, ctrl=None, n_total=0):
+        """jobs: dicts(net, x[, h1T, h2T, out, act, loss='policy'|'value', stop]); loss: dict of the
+        loss tensors (see smx_epoch_forward_f32).  One launch: 16 rows per workgroup through the three
+        layers and the job's loss."""
+        L.call('smx_epoch_forward_f32', self._epoch_jobs(jobs), len(jobs), self._epoch_loss(loss),
+               L.ptr(ctrl), int(n_total), self._st())
+
+    def epoch_backward(self, jobs, loss, ctrl, n_total):
+        """jobs: dicts(net, x, h1T, h2T, loss, dz2T, dz1T[, dz3T (policy), dz3 (value), stop])"""
+        L.call('smx_epoch_backward_f32', self._epoch_jobs(jobs), len(jobs), self._epoch_loss(loss),
+               L.ptr(ctrl), int(n_total), self._st())
+
+    def mlp3_wgrad_multi(self, jobs):
+        """the weight-gradient launch alone: dicts(net, x (for rows), grads, sumsq, xT, h1T, h2T, dz3T,
+        dz2T, dz1T[, stop])"""
+        L.call('smx_mlp3_wgrad_multi_f32', self._jobs(jobs), len(jobs), self._st())
+
     # ---- GAE / normalisation ------------------------------------------------------------
     def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret,
             values_tail=None):

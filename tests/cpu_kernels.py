@@ -141,6 +141,86 @@ class TorchCpuKernels(object):
             sumsq[:n].zero_()
             sumsq[0] = float((flat.double() ** 2).sum())
 
+    # ---- fused row-block epoch kernels ------------------------------------------------------
+    def epoch_supported(self, net):
+        return net.D % 4 == 0 and net.H1 % 4 == 0 and net.H2 % 4 == 0 and net.OUT <= 32
+
+    def epoch_blocks(self, rows):
+        return (rows + 15) // 16
+
+    def epoch_forward(self, jobs, loss=None, ctrl=None, n_total=0):
+        for j in jobs:
+            if j.get('stop') is not None and int(j['stop'][0]) != 0:
+                continue
+            net, x = j['net'], j['x']
+            v = net.views
+            h1 = torch.relu(torch.nn.functional.linear(x, v['W1'], v['b1']))
+            h2 = torch.relu(torch.nn.functional.linear(h1, v['W2'], v['b2']))
+            out = self._act(torch.nn.functional.linear(h2, v['W3'], v['b3']), j.get('act', 0))
+            if j.get('h1T') is not None:
+                j['h1T'].copy_(h1.t())
+                j['h2T'].copy_(h2.t())
+            if j.get('out') is not None:
+                j['out'].copy_(out.view(j['out'].shape))
+            if j.get('loss') == 'policy':
+                self.policy_loss(loss['mode'], out, loss['log_var'], loss['actions'], loss['behave'],
+                                 loss['ref'], loss['adv'], ctrl, loss['g_surr'], loss['g_kl'],
+                                 loss['partials'])
+            elif j.get('loss') == 'value':
+                vv, g = out.view(-1), loss['returns'].view(-1)
+                rows = vv.numel()
+                loss['v_dz3'].view(-1).copy_(2.0 * (vv - g) / float(n_total))
+                d = g - vv
+                for b in range(self.epoch_blocks(rows)):
+                    sl = slice(16 * b, min(16 * (b + 1), rows))
+                    db, gb = d[sl].double(), g[sl].double()
+                    loss['v_partials'][b] = _f([db.numel(), db.mean(), ((db - db.mean()) ** 2).sum(), gb.mean(),
+                                                ((gb - gb.mean()) ** 2).sum(), (db ** 2).sum(), 0, 0])
+                if loss.get('v_will_update'):
+                    ctrl.view(torch.int32)[L.C_STEP_CRITIC] += 1
+
+    def epoch_backward(self, jobs, loss, ctrl, n_total):
+        for j in jobs:
+            net = j['net']
+            v = net.views
+            rows = j['x'].shape[0]
+            if j.get('loss') == 'policy':
+                ci = ctrl.view(torch.int32)
+                if int(ci[L.C_STOP]) != 0:
+                    continue
+                A = net.OUT
+                dz3 = torch.zeros(rows, A)
+                self.policy_finalize(loss['mode'], loss['partials'], self.epoch_blocks(rows), loss['g_surr'],
+                                     loss['g_kl'], loss['log_var'], n_total, ctrl, loss['check_stop'],
+                                     loss['will_update'], dz3, loss['dlogvar'], loss.get('dlogvar_sumsq'),
+                                     loss['stats'])
+                if int(ci[L.C_STOP]) != 0 or not loss['will_update']:
+                    continue
+                j['dz3T'].copy_(dz3.t())
+            else:
+                dz3 = j['dz3'].view(rows, 1)
+            h2, h1 = j['h2T'].t(), j['h1T'].t()
+            dz2 = (dz3 @ v['W3']) * (h2 > 0)
+            dz1 = (dz2 @ v['W2']) * (h1 > 0)
+            j['dz2T'].copy_(dz2.t())
+            j['dz1T'].copy_(dz1.t())
+
+    def mlp3_wgrad_multi(self, jobs):
+        for j in jobs:
+            if j.get('stop') is not None and int(j['stop'][0]) != 0:
+                continue
+            net = j['net']
+            dz1, dz2 = j['dz1T'].t(), j['dz2T'].t()
+            dz3 = j['dz3T'].reshape(net.OUT, -1)[:, :dz1.shape[0]].t()
+            x, h1, h2 = j['xT'].t(), j['h1T'].t(), j['h2T'].t()
+            pieces = [dz1.t() @ x, dz1.sum(0), dz2.t() @ h1, dz2.sum(0), dz3.t() @ h2, dz3.sum(0)]
+            flat = torch.cat([p.reshape(-1) for p in pieces])
+            j['grads'][:flat.numel()].copy_(flat)
+            if j.get('sumsq') is not None:
+                n = self.mlp3_backward_partials(net)
+                j['sumsq'][:n].zero_()
+                j['sumsq'][0] = float((flat.double() ** 2).sum())
+
     # ---- GAE / normalisation ------------------------------------------------------------
     def gae(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret,
             values_tail=None):
