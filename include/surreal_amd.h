@@ -379,8 +379,8 @@ int smx_mlp3_wgrad_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stre
  *                           loss->will_update == 0 (the final, forward-only pass) only the
  *                           statistics / early-exit part runs (one job, one workgroup).
  * followed by smx_mlp3_wgrad_multi_f32 and smx_clip_adam_step_pair_f32.
- * Requirements (smx_epoch_supported): D, H1, H2 multiples of 4, OUT <= 32, x dense [rows, D] and the
- * weights 16-byte aligned.  loss->mean / dz3 / dz3_t / values are not used (the tiles stay on chip). */
+ * Requirements (smx_epoch_supported): H1, H2 multiples of 4, OUT <= 32, x dense [rows, D]; W2, W3,
+ * b1, b2 (and x when D % 4 == 0) 16-byte aligned.  loss->mean / dz3 / dz3_t / values are not used (the tiles stay on chip). */
 enum { SMX_EPOCH_LOSS_NONE = 0, SMX_EPOCH_LOSS_POLICY = 1, SMX_EPOCH_LOSS_VALUE = 2 };
 typedef struct smx_epoch_job {
     const smx_mlp3_t* net;
@@ -399,7 +399,19 @@ typedef struct smx_epoch_job {
     float* dz3T;
     float* dz2T;
     float* dz1T;
+    const float* packed; /* forward: the net's weights as smx_epoch_pack_f32 lays them out */
 } smx_epoch_job_t;
+/* The forward kernel reads the weights in MFMA fragment order: [tile of 16 features][32-wide K chunk]
+ * [half][lane][4], zero padded to whole tiles and an even chunk count, so that every load instruction
+ * reads one contiguous KB (from the row-major matrices a fragment load touches 16 cache lines and the
+ * loop runs at half the MFMA rate).  smx_epoch_pack_f32 writes that copy for up to 4 networks in one
+ * launch; the epoch loop keeps it current by repacking after every optimiser step. */
+typedef struct smx_epoch_pack {
+    const smx_mlp3_t* net;
+    float* packed; /* smx_epoch_packed_floats(D, H1, H2, OUT) floats, 16-byte aligned */
+} smx_epoch_pack_t;
+int64_t smx_epoch_packed_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_stream_t stream);
 struct smx_ppo_losses;
 int32_t smx_epoch_blocks(int64_t rows);
 int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);

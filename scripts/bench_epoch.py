@@ -1,0 +1,65 @@
+"""micro-benchmark of the fused epoch kernels at the benchmark shape (GPU box).
+SMX_EPOCH_DBG bits (timing experiments): 1 no weight traffic, 2 no MFMAs, 4 no hT stores, 8 no loss"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+from surreal_amd import _lib as L
+from surreal_amd.kernels import HipKernels
+import test_gpu_epoch as TE
+K = HipKernels()
+
+
+def timeit(fn, n=100):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+rows, D, H1, H2, A = 1024, 376, 300, 200, 17
+T = TE.build(rows, D, H1, H2, A, seed=1, mode=L.SMX_PPO_ADAPT, device='cuda')
+t = T['d']
+t['ctrl'][L.C_KL_TARGET] = 1e9
+only = os.environ.get('SMX_EPOCH_DBG_ONLY')
+for dbg in ([int(only)] if only is not None else [0] + [int(x) for x in sys.argv[1:]]):
+    os.environ['SMX_EPOCH_DBG'] = str(dbg)
+    f = timeit(lambda: TE.run(K, t, L.SMX_PPO_ADAPT, phase='fwd'))
+    def bwd_only():
+        rows_ = t['x'].shape[0]
+        TE.run(K, t, L.SMX_PPO_ADAPT, phase='bwd')
+    b = timeit(bwd_only)
+    print('dbg=%2d  forward %.2f us   backward+wgrad %.2f us' % (dbg, f, b))
+
+# ---- per-phase timestamps of the forward kernel (thread 0 of every workgroup) ----
+import ctypes
+lib = K.lib
+lib.smx_epoch_debug_tbuf.argtypes = [ctypes.c_void_p]
+lib.smx_epoch_debug_tbuf.restype = None
+tb = torch.zeros(512 * 32, dtype=torch.int64, device='cuda')
+lib.smx_epoch_debug_tbuf(ctypes.c_void_p(tb.data_ptr()))
+for DBG in ('0',):
+  os.environ['SMX_EPOCH_DBG'] = DBG
+  print('--- dbg', DBG)
+  for _ in range(3):
+      TE.run(K, t, L.SMX_PPO_ADAPT, phase='fwd')
+  torch.cuda.synchronize()
+  TT = tb.view(512, 32)[:128].cpu().double()
+  T_ = TT[:, :7]
+  for l in range(3):
+      st = TT[:, 2 + l]
+      print('  layer %d: setup %.0f  main loop %.0f  epilogue %.0f  barrier wait %.0f' % (l + 1, (TT[:, 16 + 4 * l] - st).mean(), (TT[:, 17 + 4 * l] - TT[:, 16 + 4 * l]).mean(), (TT[:, 18 + 4 * l] - TT[:, 17 + 4 * l]).mean(), (TT[:, 3 + l] - TT[:, 18 + 4 * l]).mean()))
+  base = T_[:, 0].min()
+  print('start spread (cycles): max-min of stamp0 = %.0f' % (T_[:, 0].max() - base))
+  # 
+  names = ['prologue loads+LDS', 'barrier', 'layer1', 'layer2', 'layer3', 'loss']
+  for i, nm in enumerate(names):
+      d = T_[:, i + 1] - T_[:, i]
+      print('%-20s mean %7.0f  min %7.0f  max %7.0f cycles   (actor wgs %.0f, critic wgs %.0f)' % (
+          nm, d.mean(), d.min(), d.max(), d[:64].mean(), d[64:].mean()))
+  tot = T_[:, 6] - T_[:, 0]
+  print('total in-kernel: mean %.0f max %.0f ; end-start over all wgs %.0f cycles' % (tot.mean(), tot.max(), T_[:, 6].max() - base))
+lib.smx_epoch_debug_tbuf(None)

@@ -42,7 +42,13 @@ class EpochJob(Structure):
     _fields_ = [('net', POINTER(Mlp3)), ('x', c_void_p), ('rows', c_int64), ('h1T', c_void_p),
                 ('h2T', c_void_p), ('ldT', c_int64), ('out', c_void_p), ('out_ld', c_int32),
                 ('out_act', c_int32), ('loss', c_int32), ('reserved', c_int32), ('stop_flag', c_void_p),
-                ('dz3', c_void_p), ('dz3T', c_void_p), ('dz2T', c_void_p), ('dz1T', c_void_p)]
+                ('dz3', c_void_p), ('dz3T', c_void_p), ('dz2T', c_void_p), ('dz1T', c_void_p),
+                ('packed', c_void_p)]
+
+
+class EpochPack(Structure):
+    """smx_epoch_pack_t"""
+    _fields_ = [('net', POINTER(Mlp3)), ('packed', c_void_p)]
 
 
 EPOCH_LOSS_NONE, EPOCH_LOSS_POLICY, EPOCH_LOSS_VALUE = 0, 1, 2
@@ -124,6 +130,8 @@ _SIGS = {
     'smx_mlp3_wgrad_multi_f32': (c_int32, [POINTER(Mlp3Job), c_int32, _P]),
     'smx_epoch_blocks': (c_int32, [c_int64]),
     'smx_epoch_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_epoch_packed_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_epoch_pack_f32': (c_int32, [POINTER(EpochPack), c_int32, _P]),
     'smx_epoch_forward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
     'smx_epoch_backward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),

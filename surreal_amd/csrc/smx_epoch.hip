@@ -28,6 +28,10 @@
 // one more: 4 dependent launches per epoch instead of 9.
 #include "smx_common.h"
 #include <string.h>
+#include <stdlib.h>
+
+// workgroup barrier for data exchanged through LDS: does NOT wait for the wave's global stores
+#define SMX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 namespace {
 #include "smx_ppo_loss.inc.h"
@@ -35,12 +39,17 @@ namespace {
 constexpr int ER = 16;            // data rows per workgroup (= MFMA N)
 constexpr int NWV = 4;            // waves per workgroup, one per SIMD
 constexpr int NTH = 64 * NWV;
-constexpr int TG = 5;             // feature tiles a wave carries per pass (4 accumulator VGPRs each)
+constexpr int TG = 5;             // feature tiles a wave carries per pass, forward (4 accumulator VGPRs each)
+constexpr int TB = 3;             // the same, backward
 constexpr int MAX_EJOBS = 4;
+constexpr int XV = 7;             // 16-byte words of its x row a thread fetches up front (D <= 448; more: a loop)
+constexpr int LIN = 6;            // loss-input words a thread fetches up front: 16 rows x (5A + 1) <= 6 x 256
+constexpr int EXCLUSIVE_LDS = 84 * 1024;
 constexpr int LDO = 36;           // row stride of the output tile in LDS (<= 32 outputs)
 static_assert(ER == LOSS_ROWS_PER_BLOCK, "a row block is a loss block");
 static_assert(NTH == 256, "the shared loss code strides by 256 threads");
 
+#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -85,6 +94,7 @@ struct EJob {
     // backward
     const float* dz3;
     float *dz3T, *dz2T, *dz1T;
+    const float *P1, *P2, *P3;     // packed weights (smx_epoch_pack_f32) or null
 };
 
 struct PolArgs {       // the DiagGauss losses of the actor job (smx_ppo_losses_t, the parts used here)
@@ -110,6 +120,8 @@ struct EArgs {
     // LDS carve-up (floats), the same for every workgroup of the launch
     int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_red, off_loss;
     int fsplit;
+    long long* tbuf;   // timing experiments only: per-workgroup phase timestamps
+    int dbg;     // timing experiments only (SMX_EPOCH_DBG): 1 = no weight traffic, 2 = no MFMAs
 };
 
 __device__ __forceinline__ EJob select_job(const EArgs& G, int bid) {
@@ -134,124 +146,105 @@ __device__ __forceinline__ EJob select_job(const EArgs& G, int bid) {
 // bytes of its weight row and two 16-byte words of its data row per chunk.  Weight rows >= M and
 // bytes past the matrix are out-of-range buffer loads (0); bytes past K inside the matrix belong to
 // the next row and meet the zero padding of the data tile.
+//
+// CODE SIZE is a first-order cost here: a workgroup runs each instruction stream once or a few
+// times, so every kilobyte of unrolled code is an instruction-cache miss chain (the first version --
+// one inlined copy per layer and per tile count, 56 KB -- spent 10 of its 31 us fetching code).  The
+// three layers therefore share ONE loop body, and the tile count per wave picks among few variants
+// (a missing tile is an out-of-range operand, its MFMAs run on zeros).
 // ---------------------------------------------------------------------------------------------
 template <int NT>
 struct WFrag {
-    float4 a[NT], b[NT];      // k = 8kq + 0..3 and 8kq + 4..7 of the chunk, per tile
+    float4 a[NT], b[NT];      // weights: k = 8kq + 0..3 and 8kq + 4..7 of the chunk, per tile
+    float4 x0, x1;            // the data row's words of the same chunk (LDS)
 };
 
+// Packed weights (smx_epoch_pack_f32): [tile][chunk][half][lane][4 floats], zero padded to whole tiles
+// and an EVEN number of chunks.  A load instruction reads one contiguous KB.  (Read from their
+// row-major home -- adjacent lanes = adjacent ROWS, 16 cache lines per instruction -- the same loop
+// ran at 2500 cycles per chunk against 1280 of MFMA issue; packed: 1540.  scripts/micro/fwd_loop.hip)
 template <int NT>
-__device__ __forceinline__ void ld_wfrag(WFrag<NT>& f, rsrc_t rw, const unsigned (&wo)[TG], int c, int nch) {
+__device__ __forceinline__ void ld_wfrag(WFrag<NT>& f, rsrc_t rw, const unsigned (&wo)[TG], const float* bp, int c) {
 #pragma unroll
     for (int g = 0; g < NT; ++g) {
-        const unsigned o = (c < nch) ? wo[g] + (unsigned)c * 128u : OOB;
+        const unsigned o = wo[g] + (unsigned)c * 2048u;     // past the last chunk: past the buffer (0)
         f.a[g] = ld16(rw, o);
-        f.b[g] = ld16(rw, o + 16u);
+        f.b[g] = ld16(rw, o + 1024u);
     }
+    f.x0 = *(const float4*)(bp + 32 * c);
+    f.x1 = *(const float4*)(bp + 32 * c + 4);
 }
 
 template <int NT>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[TG], const WFrag<NT>& f, const float* bp) {
-    const float4 b0 = *(const float4*)(bp);
-    const float4 b1 = *(const float4*)(bp + 4);
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[TG], const WFrag<NT>& f) {
 #pragma unroll
     for (int g = 0; g < NT; ++g) {
-        acc[g] = MFMA16(f.a[g].x, b0.x, acc[g]);
-        acc[g] = MFMA16(f.a[g].y, b0.y, acc[g]);
-        acc[g] = MFMA16(f.a[g].z, b0.z, acc[g]);
-        acc[g] = MFMA16(f.a[g].w, b0.w, acc[g]);
+        acc[g] = MFMA16(f.a[g].x, f.x0.x, acc[g]);
+        acc[g] = MFMA16(f.a[g].y, f.x0.y, acc[g]);
+        acc[g] = MFMA16(f.a[g].z, f.x0.z, acc[g]);
+        acc[g] = MFMA16(f.a[g].w, f.x0.w, acc[g]);
     }
 #pragma unroll
     for (int g = 0; g < NT; ++g) {
-        acc[g] = MFMA16(f.b[g].x, b1.x, acc[g]);
-        acc[g] = MFMA16(f.b[g].y, b1.y, acc[g]);
-        acc[g] = MFMA16(f.b[g].z, b1.z, acc[g]);
-        acc[g] = MFMA16(f.b[g].w, b1.w, acc[g]);
+        acc[g] = MFMA16(f.b[g].x, f.x1.x, acc[g]);
+        acc[g] = MFMA16(f.b[g].y, f.x1.y, acc[g]);
+        acc[g] = MFMA16(f.b[g].z, f.x1.z, acc[g]);
+        acc[g] = MFMA16(f.b[g].w, f.x1.w, acc[g]);
     }
 }
 
-// tiles t0, t0 + tstep, ... (NT of them) over the K chunks c0, c0 + cstep, ... < nch
+// tiles t0, t0 + NWV, ... (NT of them; tiles >= `tiles` are out-of-range operands) over the C2 (even)
+// K chunks.  Four register stages: while the MFMAs of one chunk issue (NT x 8 x 32 cycles), the next
+// two chunks' 2 NT weight loads and 2 LDS reads each are in flight.  The scheduling barriers pin that order --
+// left alone, hipcc sinks each load to just in front of the MFMA that consumes it and waits for L2
+// there.  Both halves of the loop body are unconditional: a branch around the MFMAs makes hipcc
+// park the accumulators in VGPRs and copy all of them to the MFMA registers and back every chunk.
 template <int NT>
-__device__ __forceinline__ void fwd_tiles(f32x4 (&acc)[TG], rsrc_t rw, int M, int K, const float* in_lds,
-                                          int ldi, int t0, int tstep, int c0, int cstep, int fm, int kq) {
-    const int nch = (K + 31) >> 5;
+__device__ __forceinline__ void fwd_tiles(f32x4 (&acc)[TG], rsrc_t rw, int tiles, int C2, const float* in_lds,
+                                          int ldi, int t0, int lane) {
     unsigned wo[TG];
 #pragma unroll
     for (int g = 0; g < TG; ++g) {
-        const int row = 16 * (t0 + tstep * g) + fm;
-        wo[g] = (g < NT && row < M) ? ((unsigned)row * (unsigned)K + 8u * kq) * 4u : OOB;
+        const int t = t0 + NWV * g;
+        wo[g] = (g < NT && t < tiles) ? ((unsigned)t * (unsigned)C2 * 512u + (unsigned)lane * 4u) * 4u : OOB;
     }
-    const float* bp = in_lds + fm * ldi + 8 * kq;
-    WFrag<NT> P, Q;
-    ld_wfrag<NT>(P, rw, wo, c0, nch);
-    for (int c = c0; c < nch; c += 2 * cstep) {
-        ld_wfrag<NT>(Q, rw, wo, c + cstep, nch);
-        mma_chunk<NT>(acc, P, bp + 32 * c);
-        ld_wfrag<NT>(P, rw, wo, c + 2 * cstep, nch);
-        if (c + cstep < nch) mma_chunk<NT>(acc, Q, bp + 32 * (c + cstep));
+    const float* bp = in_lds + (lane & 15) * ldi + 8 * (lane >> 4);
+    // prefetch distance TWO chunks (the packed weights were just rewritten on other XCDs: a first touch
+    // is a ~1 us trip to the memory-side cache, longer than one chunk's 1280 cycles of MFMA issue)
+    WFrag<NT> P0, P1, Q0, Q1;
+    ld_wfrag<NT>(P0, rw, wo, bp, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ld_wfrag<NT>(P1, rw, wo, bp, 1);
+    int c = 0;
+#pragma unroll 1
+    for (; c + 4 <= C2; c += 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        ld_wfrag<NT>(Q0, rw, wo, bp, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<NT>(acc, P0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_wfrag<NT>(Q1, rw, wo, bp, c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<NT>(acc, P1);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_wfrag<NT>(P0, rw, wo, bp, c + 4);          // (past the last chunk: past the buffer, zeros)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<NT>(acc, Q0);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_wfrag<NT>(P1, rw, wo, bp, c + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<NT>(acc, Q1);
     }
-}
-
-__device__ __forceinline__ void fwd_tiles_n(int nt, f32x4 (&acc)[TG], rsrc_t rw, int M, int K,
-                                            const float* in_lds, int ldi, int t0, int tstep, int c0,
-                                            int cstep, int fm, int kq) {
-    switch (nt) {     // wave-uniform
-        case 1: fwd_tiles<1>(acc, rw, M, K, in_lds, ldi, t0, tstep, c0, cstep, fm, kq); break;
-        case 2: fwd_tiles<2>(acc, rw, M, K, in_lds, ldi, t0, tstep, c0, cstep, fm, kq); break;
-        case 3: fwd_tiles<3>(acc, rw, M, K, in_lds, ldi, t0, tstep, c0, cstep, fm, kq); break;
-        case 4: fwd_tiles<4>(acc, rw, M, K, in_lds, ldi, t0, tstep, c0, cstep, fm, kq); break;
-        case 5: fwd_tiles<5>(acc, rw, M, K, in_lds, ldi, t0, tstep, c0, cstep, fm, kq); break;
-        default: break;
-    }
-}
-
-// one hidden layer: every wave takes the feature tiles wv, wv + NWV, ...; bias + ReLU in the
-// fragment; the tile goes to LDS as [row][feature] (the next layer's B operand) and to HBM as
-// [feature][row] (the weight-gradient GEMM's K-contiguous operand; also the ReLU mask of the
-// backward kernel)
-__device__ __forceinline__ void hidden_layer(const float* W, const float* bias, int H, int K,
-                                             const float* in_lds, int ldi, float* out_lds, int ldo,
-                                             float* hT, long ldT, long row0, int nrows, int wv, int fm,
-                                             int kq) {
-    const int tiles = (H + 15) >> 4;
-    const rsrc_t rw = make_rsrc(W, (unsigned)H * (unsigned)K * 4u);
-    for (int tb = 0; tb < tiles; tb += NWV * TG) {
-        const int t0 = tb + wv;
-        int nt = (tiles - t0 + NWV - 1) / NWV;
-        nt = nt < 0 ? 0 : (nt > TG ? TG : nt);
-        // the epilogue's bias words are requested in front of the main loop
-        float4 bs[TG];
-#pragma unroll
-        for (int g = 0; g < TG; ++g) {
-            const int f0 = 16 * (t0 + NWV * g) + 4 * kq;
-            bs[g] = (g < nt && f0 < H) ? *(const float4*)(bias + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        f32x4 acc[TG];
-#pragma unroll
-        for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        fwd_tiles_n(nt, acc, rw, H, K, in_lds, ldi, t0, NWV, 0, 1, fm, kq);
-#pragma unroll
-        for (int g = 0; g < TG; ++g) {
-            if (g < nt) {
-                const int f0 = 16 * (t0 + NWV * g) + 4 * kq;     // features f0..f0+3 of data row fm
-                float4 v;
-                v.x = act_f(acc[g][0] + bs[g].x, SMX_ACT_RELU);
-                v.y = act_f(acc[g][1] + bs[g].y, SMX_ACT_RELU);
-                v.z = act_f(acc[g][2] + bs[g].z, SMX_ACT_RELU);
-                v.w = act_f(acc[g][3] + bs[g].w, SMX_ACT_RELU);
-                if (f0 >= H) v = make_float4(0.f, 0.f, 0.f, 0.f);      // H % 4 == 0: all four or none
-                *(float4*)(out_lds + fm * ldo + f0) = v;
-                if (hT && f0 < H && fm < nrows) {
-                    float* q = hT + (size_t)f0 * ldT + row0 + fm;
-                    q[0] = v.x; q[ldT] = v.y; q[2 * ldT] = v.z; q[3 * ldT] = v.w;
-                }
-            }
-        }
+    if (c < C2) {                                      // C2 = 4j + 2: the last two chunks are in flight
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk<NT>(acc, P0);
+        mma_chunk<NT>(acc, P1);
     }
 }
 
 __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
     extern __shared__ float sm[];
+    TSTAMP(0);
     const EJob J = select_job(G, (int)blockIdx.x);
     const int stopv = J.stop ? __builtin_nontemporal_load(J.stop) : 0;
     const int blk = blockIdx.x - J.blk_base;
@@ -266,72 +259,179 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
     float* h1s = sm + G.off_h1;
     float* h2s = sm + G.off_h2;
     float* outs = sm + G.off_out;
-    float* red = sm + G.off_red;
     const int ldx = G.ldx, ldh1 = G.ldh1, ldh2 = G.ldh2;
 
-    // ---- x tile -> LDS (rows past the batch and k >= D are zero), hidden tiles cleared -------
-    {
-        const int D4 = J.D >> 2, X4 = ldx >> 2;
-        for (int idx = tid; idx < ER * X4; idx += NTH) {
-            const int n = idx / X4, j = idx - n * X4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < D4 && n < nrows) v = *(const float4*)(J.x + (size_t)(row0 + n) * J.D + 4 * j);
-            *(float4*)(xs + n * ldx + 4 * j) = v;
+    // ---- everything the workgroup reads that does not depend on its own results is requested
+    // HERE, in one batch: the x tile and the loss inputs of its rows (written by earlier launches,
+    // possibly on other XCDs: a first touch is a trip to the memory-side cache, not an L2 hit)
+    const rsrc_t rx = make_rsrc(J.x, (unsigned)J.rows * (unsigned)J.D * 4u);
+    const int xr = tid >> 4, xj = tid & 15;              // 16 threads per row
+    const unsigned xrow = (unsigned)(row0 + xr) * (unsigned)J.D * 4u;
+    const bool xvec = (J.D & 3) == 0;
+    float4 xv[XV];
+    if (xvec) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int k = 4 * (xj + 16 * i);
+            xv[i] = ld16(rx, (k < J.D && xr < nrows) ? xrow + 4u * k : OOB);
         }
-        for (int idx = tid; idx < (G.off_red - G.off_h1) >> 2; idx += NTH)
-            *(float4*)(h1s + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // loss inputs of the 16 rows -> LDS: policy [actions A | behave 2A | ref 2A | adv 1] per row
+    const PolArgs& pa = G.pl;
+    const int LW = 5 * pa.A + 1;
+    float lin[LIN];
+    float vret = 0.f;
+    // (one unconditional load per word from a selected, always valid address: no load under a lane mask)
+    auto loss_input = [&](int idx) -> float {
+        const int A = pa.A;
+        int n = idx / LW;
+        const int c = idx - n * LW;
+        const bool ok = n < nrows;
+        n = ok ? n : 0;
+        const long gr = row0 + n;
+        const float* q = c < A ? pa.actions + gr * pa.ld_act + c
+                       : c < 3 * A ? pa.behave + gr * pa.ld_beh + (c - A)
+                       : c < 5 * A ? pa.ref + gr * pa.ld_ref + (c - 3 * A) : pa.adv + gr;
+        const float v = *q;
+        return ok ? v : 0.f;
+    };
+    if (J.loss == SMX_EPOCH_LOSS_POLICY) {
+#pragma unroll
+        for (int i = 0; i < LIN; ++i) {
+            const int idx = tid + NTH * i;
+            lin[i] = loss_input(idx < ER * LW ? idx : 0);
+        }
+    } else if (J.loss == SMX_EPOCH_LOSS_VALUE && tid < nrows) {
+        vret = G.vl.returns[row0 + tid];
+    }
+    // ---- x tile -> LDS (rows past the batch and k >= D are zero), hidden tiles cleared -------
+    for (int idx = tid; idx < (G.off_red - G.off_h1) >> 2; idx += NTH)
+        *(float4*)(h1s + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xvec) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int k = 4 * (xj + 16 * i);
+            if (k < ldx) *(float4*)(xs + xr * ldx + k) = xv[i];
+        }
+        for (int k = 4 * (xj + 16 * XV); k < ldx; k += 64) {        // D > 64 XV: the rest of the row
+            const float4 v = ld16(rx, (k < J.D && xr < nrows) ? xrow + 4u * k : OOB);
+            *(float4*)(xs + xr * ldx + k) = v;
+        }
+    } else {              // rows of x are only 4-byte aligned (e.g. D = 17)
+        for (int idx = tid; idx < ER * ldx; idx += NTH) {
+            const int n = idx / ldx, j = idx - n * ldx;
+            xs[idx] = (j < J.D && n < nrows) ? J.x[(size_t)(row0 + n) * J.D + j] : 0.f;
+        }
+    }
+    float* lin_s = sm + G.off_loss + loss_scratch_floats(pa.A);      // behind the loss body's own scratch
+    if (J.loss == SMX_EPOCH_LOSS_POLICY) {
+#pragma unroll
+        for (int i = 0; i < LIN; ++i) {
+            const int idx = tid + NTH * i;
+            if (idx < ER * LW) lin_s[idx] = lin[i];
+        }
+        for (int idx = tid + NTH * LIN; idx < ER * LW; idx += NTH) lin_s[idx] = loss_input(idx);    // A > 19
     }
     if (__builtin_amdgcn_readfirstlane(stopv) != 0) return;
-    __syncthreads();
+    TSTAMP(1);
+    SMX_LDS_BARRIER();
+    TSTAMP(2);
 
-    hidden_layer(J.W1, J.b1, J.H1, J.D, xs, ldx, h1s, ldh1, J.h1T, J.ldT, row0, nrows, wv, fm, kq);
-    __syncthreads();
-    hidden_layer(J.W2, J.b2, J.H2, J.H1, h1s, ldh1, h2s, ldh2, J.h2T, J.ldT, row0, nrows, wv, fm, kq);
-    __syncthreads();
-
-    // ---- output layer: <= 2 feature tiles, the four waves split K, partial tiles meet in LDS ----
-    {
-        const int tiles = (J.OUT + 15) >> 4;
-        const rsrc_t rw = make_rsrc(J.W3, (unsigned)J.OUT * (unsigned)J.H2 * 4u);
-        f32x4 acc[TG];
+    // ---- the three layers: one loop body.  Every wave takes the feature tiles wv, wv + NWV, ...;
+    // bias + activation in the fragment; a hidden tile goes to LDS as [row][feature] (the next
+    // layer's B operand) and to HBM as [feature][row] (the weight-gradient GEMM's K-contiguous
+    // operand and the ReLU mask of the backward kernel), the output tile to LDS (the loss reads it)
+    // and to HBM row-major
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        const float* Wp = l == 0 ? J.P1 : (l == 1 ? J.P2 : J.P3);
+        const float* bias = l == 0 ? J.b1 : (l == 1 ? J.b2 : J.b3);
+        const int H = l == 0 ? J.H1 : (l == 1 ? J.H2 : J.OUT);
+        const int K = l == 0 ? J.D : (l == 1 ? J.H1 : J.H2);
+        const float* in_lds = l == 0 ? xs : (l == 1 ? h1s : h2s);
+        const int ldi = l == 0 ? ldx : (l == 1 ? ldh1 : ldh2);
+        float* out_lds = l == 0 ? h1s : (l == 1 ? h2s : outs);
+        const int ldo = l == 0 ? ldh1 : (l == 1 ? ldh2 : LDO);
+        float* hT = l == 0 ? J.h1T : (l == 1 ? J.h2T : nullptr);
+        const int tiles = (H + 15) >> 4;
+        const int C2 = (((K + 31) >> 5) + 1) & ~1;
+        const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
+        const rsrc_t rbias = make_rsrc(bias, (unsigned)H * 4u);
+        float* stp = l == 2 ? J.out : hT;
+        const bool st_ok = stp != nullptr && !(G.dbg & 4);
+        const rsrc_t rst = make_rsrc(stp ? stp : Wp, l == 2 ? (unsigned)J.rows * (unsigned)J.out_ld * 4u
+                                                             : (unsigned)H * (unsigned)J.ldT * 4u);
+#pragma unroll 1
+        for (int tb = 0; tb < tiles; tb += NWV * TG) {
+            const int t0 = tb + wv;
+            int nt = (tiles - t0 + NWV - 1) / NWV;
+            nt = nt < 0 ? 0 : (nt > TG ? TG : nt);
+            // the epilogue's bias words, requested in front of the main loop.  Guards are out-of-range
+            // buffer offsets, never branches: a load under a lane mask makes hipcc wait for it at the
+            // end of the masked region, twenty times in a row
+            float bs[TG][4];
 #pragma unroll
-        for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        fwd_tiles_n(tiles, acc, rw, J.OUT, J.H2, h2s, ldh2, 0, 1, wv, NWV, fm, kq);
+            for (int g = 0; g < TG; ++g) {
+                const int f0 = 16 * (t0 + NWV * g) + 4 * kq;
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-            if (g < tiles) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[((wv * 2 + g) * 16 + 4 * kq + r) * 16 + fm] = acc[g][r];
+                for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rbias, (g < nt) ? (unsigned)(f0 + r) * 4u : OOB);
             }
-        __syncthreads();
-        const int OP = 16 * tiles;
-        for (int idx = tid; idx < ER * OP; idx += NTH) {
-            const int n = idx / OP, f = idx - n * OP;
-            const int e = ((f >> 4) * 16 + (f & 15)) * 16 + n;
-            float v = ((red[e] + red[512 + e]) + red[1024 + e]) + red[1536 + e];
-            if (f < J.OUT) {
-                v = act_f(v + J.b3[f], J.out_act);
-                if (J.out && n < nrows) J.out[(size_t)(row0 + n) * J.out_ld + f] = v;
-            } else {
-                v = 0.f;
+            f32x4 acc[TG];
+#pragma unroll
+            for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            TSTAMP(16 + 4 * l);
+            if (nt > 4) fwd_tiles<5>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
+            else if (nt > 2) fwd_tiles<4>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
+            else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
+            else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
+            TSTAMP(17 + 4 * l);
+            // hidden tiles: [feature][row] in HBM, lane (fm, kq) holds features f0..f0+3 of row fm;
+            // the output tile: row-major.  Stores past the matrix / the batch go to out-of-range offsets.
+            const unsigned sstep = l == 2 ? 4u : (unsigned)J.ldT * 4u;                    // bytes between features
+            const unsigned srow = l == 2 ? (unsigned)(row0 + fm) * (unsigned)J.out_ld * 4u
+                                         : (unsigned)(row0 + fm) * 4u;
+#pragma unroll
+            for (int g = 0; g < TG; ++g) {
+                if (g < nt) {                                            // wave-uniform
+                    const int f0 = 16 * (t0 + NWV * g) + 4 * kq;     // features f0..f0+3 of data row fm
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float z = acc[g][r] + bs[g][r];
+                        // only a wave's FIRST tile can be an output tile (OUT <= 32 < 16 NWV)
+                        if (g == 0 && l == 2) z = act_f(z, J.out_act);
+                        else z = (z < 0.f) ? 0.f : z;
+                        v[r] = (f0 + r < H) ? z : 0.f;
+                    }
+                    *(float4*)(out_lds + fm * ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = st_ok && fm < nrows && f0 + r < H;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rst,
+                                                              ok ? srow + (unsigned)(f0 + r) * sstep : OOB, 0, 0);
+                    }
+                }
             }
-            outs[n * LDO + f] = v;
         }
-        __syncthreads();
+        TSTAMP(18 + 4 * l);
+        SMX_LDS_BARRIER();
+        TSTAMP(3 + l);
     }
 
     // ---- the job's loss on the rows it holds -------------------------------------------------
+    if (G.dbg & 8) return;
     if (J.loss == SMX_EPOCH_LOSS_POLICY) {
         const PolArgs& p = G.pl;
-        policy_loss_body(blk, sm + G.off_loss, p.mode, outs, LDO, p.log_var, p.actions, p.ld_act, p.behave,
-                         p.ld_beh, p.ref, p.ld_ref, p.adv, (long)J.rows, p.A, ctrl, p.g_surr, p.g_kl,
-                         p.row_partials);
+        // inputs staged in LDS: row stride LW, [actions | behave | ref | adv]
+        policy_loss_body(blk, sm + G.off_loss, p.mode, outs, LDO, p.log_var, lin_s, LW, lin_s + p.A, LW,
+                         lin_s + 3 * p.A, LW, lin_s + 5 * p.A, (long)J.rows, p.A, ctrl, p.g_surr, p.g_kl,
+                         p.row_partials, 1.0f, false, nullptr, nullptr, 0, row0, LW);
     } else if (J.loss == SMX_EPOCH_LOSS_VALUE && tid < 64) {
         // squared error of the 16 rows (ppo.py:323-332): dz3 and the block's mergeable moments of
         // d = ret - V and of ret (explained variance), as value_loss_body forms them per 256 rows
         const ValArgs& q = G.vl;
         const bool ok = tid < nrows;
-        const float v = ok ? outs[tid * LDO] : 0.f, g = ok ? q.returns[row0 + tid] : 0.f;
+        const float v = ok ? outs[tid * LDO] : 0.f, g = ok ? vret : 0.f;
         const float d = g - v, e = v - g;
         if (ok) q.v_dz3[row0 + tid] = (2.0f * e) / (float)G.n_total;
         const float cnt = (float)nrows;
@@ -346,6 +446,7 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
             if (blk == 0 && q.will_update) ctrl->adam_step_critic += 1;
         }
     }
+    TSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -354,110 +455,63 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
 // W[(16c + 4kq + r) * M + 16 t + fm] -- four 4-byte loads per chunk and tile, each a 64-byte run per
 // kq group.  k >= K is past the matrix (0); features >= M are pointed out of range.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
 struct TFrag {
-    float a[NT][4];
+    float a[TB][4];
+    float4 x;
 };
 
-template <int NT>
-__device__ __forceinline__ void ld_tfrag(TFrag<NT>& f, rsrc_t rw, const unsigned (&wo)[TG], unsigned kstep,
-                                         int c, int nch) {
+__device__ __forceinline__ void ld_tfrag(TFrag& f, rsrc_t rw, const unsigned (&wo)[TB], unsigned kstep,
+                                         const float* bp, int c, int nch) {
 #pragma unroll
-    for (int g = 0; g < NT; ++g) {
-        const unsigned o = (c < nch) ? wo[g] + (unsigned)c * 16u * kstep : OOB;
+    for (int g = 0; g < TB; ++g) {
+        const unsigned o = wo[g] + (unsigned)c * 16u * kstep;
 #pragma unroll
         for (int r = 0; r < 4; ++r) f.a[g][r] = ld4(rw, (c < nch) ? o + (unsigned)r * kstep : OOB);
     }
+    f.x = *(const float4*)(bp + 16 * (c < nch ? c : 0));
 }
 
-template <int NT>
-__device__ __forceinline__ void mma_tchunk(f32x4 (&acc)[TG], const TFrag<NT>& f, const float* bp) {
-    const float4 b = *(const float4*)(bp);
+__device__ __forceinline__ void mma_tchunk(f32x4 (&acc)[TB], const TFrag& f) {
 #pragma unroll
-    for (int g = 0; g < NT; ++g) {
-        acc[g] = MFMA16(f.a[g][0], b.x, acc[g]);
-        acc[g] = MFMA16(f.a[g][1], b.y, acc[g]);
-        acc[g] = MFMA16(f.a[g][2], b.z, acc[g]);
-        acc[g] = MFMA16(f.a[g][3], b.w, acc[g]);
+    for (int g = 0; g < TB; ++g) {
+        acc[g] = MFMA16(f.a[g][0], f.x.x, acc[g]);
+        acc[g] = MFMA16(f.a[g][1], f.x.y, acc[g]);
+        acc[g] = MFMA16(f.a[g][2], f.x.z, acc[g]);
+        acc[g] = MFMA16(f.a[g][3], f.x.w, acc[g]);
     }
 }
 
-// W row-major [K, M]; tiles t0, t0 + tstep, ... of the M axis
-template <int NT>
-__device__ __forceinline__ void bwd_tiles(f32x4 (&acc)[TG], rsrc_t rw, int M, int K, const float* in_lds,
-                                          int ldi, int t0, int tstep, int fm, int kq) {
+// W row-major [K, M]; tiles t0, t0 + ts, ... of the M axis (TB of them; the ones past `tiles` are
+// out-of-range operands); three register stages (a chunk is only TB x 4 MFMAs here)
+__device__ __forceinline__ void bwd_tiles(f32x4 (&acc)[TB], rsrc_t rw, int M, int K, const float* in_lds, int ldi,
+                                          int t0, int ts, int nt, int fm, int kq) {
     const int nch = (K + 15) >> 4;
     const unsigned kstep = (unsigned)M * 4u;                 // bytes between consecutive k
-    unsigned wo[TG];
+    unsigned wo[TB];
 #pragma unroll
-    for (int g = 0; g < TG; ++g) {
-        const int f = 16 * (t0 + tstep * g) + fm;
-        wo[g] = (g < NT && f < M) ? (unsigned)f * 4u + 4u * kq * kstep : OOB;
+    for (int g = 0; g < TB; ++g) {
+        const int f = 16 * (t0 + ts * g) + fm;
+        wo[g] = (g < nt && f < M) ? (unsigned)f * 4u + 4u * kq * kstep : OOB;
     }
     const float* bp = in_lds + fm * ldi + 4 * kq;
-    TFrag<NT> P, Q;
-    ld_tfrag<NT>(P, rw, wo, kstep, 0, nch);
-    for (int c = 0; c < nch; c += 2) {
-        ld_tfrag<NT>(Q, rw, wo, kstep, c + 1, nch);
-        mma_tchunk<NT>(acc, P, bp + 16 * c);
-        ld_tfrag<NT>(P, rw, wo, kstep, c + 2, nch);
-        if (c + 1 < nch) mma_tchunk<NT>(acc, Q, bp + 16 * (c + 1));
-    }
-}
-
-__device__ __forceinline__ void bwd_tiles_n(int nt, f32x4 (&acc)[TG], rsrc_t rw, int M, int K,
-                                            const float* in_lds, int ldi, int t0, int tstep, int fm, int kq) {
-    switch (nt) {
-        case 1: bwd_tiles<1>(acc, rw, M, K, in_lds, ldi, t0, tstep, fm, kq); break;
-        case 2: bwd_tiles<2>(acc, rw, M, K, in_lds, ldi, t0, tstep, fm, kq); break;
-        case 3: bwd_tiles<3>(acc, rw, M, K, in_lds, ldi, t0, tstep, fm, kq); break;
-        case 4: bwd_tiles<4>(acc, rw, M, K, in_lds, ldi, t0, tstep, fm, kq); break;
-        case 5: bwd_tiles<5>(acc, rw, M, K, in_lds, ldi, t0, tstep, fm, kq); break;
-        default: break;
-    }
-}
-
-// dzT tiles of one layer: (Wt . dz_up) * relu'(h); the tiles first, first + step, ... < tiles go
-// round-robin over the waves.  Results to LDS [row][feature] (when out_lds) and HBM [feature][row]
-// (when outT).
-__device__ __forceinline__ void bwd_layer(const float* W, int M, int K, const float* in_lds, int ldi,
-                                          const float* hT, float* out_lds, int ldo, float* outT, long ldT,
-                                          long row0, int nrows, int first, int step, int wv, int fm, int kq) {
-    const int tiles = (M + 15) >> 4;
-    const rsrc_t rw = make_rsrc(W, (unsigned)K * (unsigned)M * 4u);
-    for (int tb = first; tb < tiles; tb += step * NWV * TG) {
-        const int t0 = tb + step * wv, ts = step * NWV;
-        int nt = (tiles - t0 + ts - 1) / ts;
-        nt = nt < 0 ? 0 : (nt > TG ? TG : nt);
-        float mk[TG][4];            // ReLU masks, requested in front of the main loop
-#pragma unroll
-        for (int g = 0; g < TG; ++g) {
-            const int f0 = 16 * (t0 + ts * g) + 4 * kq;
-            const bool ok = g < nt && f0 < M && fm < nrows;
-            const float* q = hT + (size_t)(ok ? f0 : 0) * ldT + row0 + (ok ? fm : 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mk[g][r] = ok ? q[(size_t)r * ldT] : 0.f;
-        }
-        f32x4 acc[TG];
-#pragma unroll
-        for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bwd_tiles_n(nt, acc, rw, M, K, in_lds, ldi, t0, ts, fm, kq);
-#pragma unroll
-        for (int g = 0; g < TG; ++g) {
-            if (g < nt) {
-                const int f0 = 16 * (t0 + ts * g) + 4 * kq;
-                float4 v;
-                v.x = (mk[g][0] > 0.f) ? acc[g][0] : 0.f;
-                v.y = (mk[g][1] > 0.f) ? acc[g][1] : 0.f;
-                v.z = (mk[g][2] > 0.f) ? acc[g][2] : 0.f;
-                v.w = (mk[g][3] > 0.f) ? acc[g][3] : 0.f;
-                if (out_lds) *(float4*)(out_lds + fm * ldo + f0) = v;
-                if (outT && f0 < M && fm < nrows) {
-                    float* q = outT + (size_t)f0 * ldT + row0 + fm;
-                    q[0] = v.x; q[ldT] = v.y; q[2 * ldT] = v.z; q[3 * ldT] = v.w;
-                }
-            }
-        }
+    TFrag P, Q, R;
+    ld_tfrag(P, rw, wo, kstep, bp, 0, nch);
+    __builtin_amdgcn_sched_barrier(0);
+    ld_tfrag(Q, rw, wo, kstep, bp, 1, nch);
+#pragma unroll 1
+    for (int c = 0; c < nch; c += 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        ld_tfrag(R, rw, wo, kstep, bp, c + 2, nch);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tchunk(acc, P);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_tfrag(P, rw, wo, kstep, bp, c + 3, nch);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nch) mma_tchunk(acc, Q);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_tfrag(Q, rw, wo, kstep, bp, c + 4, nch);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nch) mma_tchunk(acc, R);
     }
 }
 
@@ -467,7 +521,19 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     const EJob J = select_job(G, (int)blockIdx.x);
     const int fs = G.fsplit;
     const int wg = blockIdx.x - J.blk_base;
-    const int blk = wg / fs, half = wg - blk * fs;
+    const int nb = (J.rows + ER - 1) / ER;
+    // workgroup -> (row block, feature split).  Consecutive workgroup ids go round-robin over the 8
+    // XCDs: keep row block b on XCD b % 8, where the forward kernel ran it and left its activations
+    // and loss tiles in that XCD's L2 (when the job's block count allows the bijection)
+    int blk, half;
+    if ((nb & 7) == 0 && (J.blk_base & 7) == 0) {
+        const int s = wg >> 3;
+        half = s % fs;
+        blk = (s / fs) * 8 + (wg & 7);
+    } else {
+        blk = wg / fs;
+        half = wg - blk * fs;
+    }
     const long row0 = (long)blk * ER;
     int nrows = J.rows - (int)row0;
     if (nrows > ER) nrows = ER;
@@ -477,20 +543,35 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     float* dz3s = sm;                       // [16][LDO]
     float* dz2s = sm + G.off_h2;            // [16][ldh2]
     const int ldh2 = G.ldh2;
+    const bool policy = J.loss == SMX_EPOCH_LOSS_POLICY;
+    const PolArgs& p = G.pl;
 
+    // ---- requested up front, in one batch: this workgroup's share of the loss tiles -----------
+    const int A = p.A;
+    float gs0 = 0.f, gk0 = 0.f, gs1 = 0.f, gk1 = 0.f, vd = 0.f;       // <= 2 (row, action) pairs per thread
+    if (policy) {
+        if (tid < ER * A) {
+            const int a = tid / ER, nn = tid - a * ER;
+            if (nn < nrows) { gs0 = p.g_surr[(size_t)(row0 + nn) * A + a]; gk0 = p.g_kl[(size_t)(row0 + nn) * A + a]; }
+        }
+        if (tid + NTH < ER * A) {
+            const int a = (tid + NTH) / ER, nn = tid + NTH - a * ER;
+            if (nn < nrows) { gs1 = p.g_surr[(size_t)(row0 + nn) * A + a]; gk1 = p.g_kl[(size_t)(row0 + nn) * A + a]; }
+        }
+    } else if (tid < nrows) {
+        vd = J.dz3[row0 + tid];
+    }
     for (int idx = tid; idx < (G.off_red >> 2); idx += NTH) *(float4*)(sm + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
     // the early-exit flag may be raised by workgroup 0 of THIS launch while others start: one lane
     // reads it and the workgroup takes one decision
-    if (tid == 0) S[0] = (J.loss == SMX_EPOCH_LOSS_POLICY && ctrl->stop_flag) ? 1.f : 0.f;
-    __syncthreads();
+    if (tid == 0) S[0] = (policy && ctrl->stop_flag) ? 1.f : 0.f;
+    SMX_LDS_BARRIER();
     const bool stopped = S[0] != 0.f;
-    __syncthreads();
+    SMX_LDS_BARRIER();
     if (stopped) return;
 
-    if (J.loss == SMX_EPOCH_LOSS_POLICY) {
-        const PolArgs& p = G.pl;
-        const int A = p.A;
-        const int nblk = (J.rows + ER - 1) / ER;
+    if (policy) {
+        const int nblk = nb;
         reduce_row_partials(p.row_partials, nblk, 8 + 2 * A, S, sm + G.off_loss);   // ends with a barrier
         const float n = (float)G.n_total;
         float c_kl, loss;
@@ -506,38 +587,158 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
                                      p.dlogvar_sumsq, p.stats);
         }
         if (stop_now || !p.will_update) return;
-        for (int idx = tid; idx < ER * A; idx += NTH) {
-            const int a = idx / ER, nn = idx - a * ER;
-            float v = 0.f;
-            if (nn < nrows) {
-                const size_t i = (size_t)(row0 + nn) * A + a;
-                v = (p.g_surr[i] + c_kl * p.g_kl[i]) * inv_n;
-                if (half == 0 && J.dz3T) J.dz3T[(size_t)a * J.ldT + row0 + nn] = v;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTH * i;
+            if (idx < ER * A) {
+                const int a = idx / ER, nn = idx - a * ER;
+                const float v = nn < nrows ? ((i ? gs1 : gs0) + c_kl * (i ? gk1 : gk0)) * inv_n : 0.f;
+                if (nn < nrows && half == 0 && J.dz3T) J.dz3T[(size_t)a * J.ldT + row0 + nn] = v;
+                dz3s[nn * LDO + a] = v;
             }
-            dz3s[nn * LDO + a] = v;
         }
     } else {
-        if (tid < ER) dz3s[tid * LDO] = (tid < nrows) ? J.dz3[row0 + tid] : 0.f;
+        if (tid < ER) dz3s[tid * LDO] = vd;
     }
-    __syncthreads();
-    // dz2 = (dz3 . W3) * relu'(h2): all tiles in every workgroup of the row block (cheap), only
-    // the first one stores the transposed copy
-    bwd_layer(J.W3, J.H2, J.OUT, dz3s, LDO, J.h2T, dz2s, ldh2, half == 0 ? J.dz2T : nullptr, J.ldT, row0,
-              nrows, 0, 1, wv, fm, kq);
-    __syncthreads();
-    // dz1 = (dz2 . W2) * relu'(h1): the feature tiles half, half + fs, ... of this workgroup
-    bwd_layer(J.W2, J.H1, J.H2, dz2s, ldh2, J.h1T, nullptr, 0, J.dz1T, J.ldT, row0, nrows, half, fs, wv, fm,
-              kq);
+    SMX_LDS_BARRIER();
+    // ---- dz2 = (dz3 . W3) * relu'(h2): all tiles in every workgroup of the row block (cheap; only
+    // the first one stores the transposed copy); dz1 = (dz2 . W2) * relu'(h1): the feature tiles
+    // half, half + fs, ... of this workgroup.  One loop body for both (code size, see above).
+#pragma unroll 1
+    for (int l = 0; l < 2; ++l) {
+        const float* W = l == 0 ? J.W3 : J.W2;
+        const int M = l == 0 ? J.H2 : J.H1, K = l == 0 ? J.OUT : J.H2;
+        const float* in_lds = l == 0 ? dz3s : dz2s;
+        const int ldi = l == 0 ? LDO : ldh2;
+        const float* hT = l == 0 ? J.h2T : J.h1T;
+        float* out_lds = l == 0 ? dz2s : nullptr;
+        float* outT = l == 0 ? (half == 0 ? J.dz2T : nullptr) : J.dz1T;
+        const int first = l == 0 ? 0 : half, step = l == 0 ? 1 : fs;
+        const int tiles = (M + 15) >> 4;
+        const rsrc_t rw = make_rsrc(W, (unsigned)K * (unsigned)M * 4u);
+#pragma unroll 1
+        for (int tb = first; tb < tiles; tb += step * NWV * TB) {
+            const int t0 = tb + step * wv, ts = step * NWV;
+            int nt = (tiles - t0 + ts - 1) / ts;
+            nt = nt < 0 ? 0 : (nt > TB ? TB : nt);
+            float mk[TB][4];            // ReLU masks, requested in front of the main loop
+#pragma unroll
+            for (int g = 0; g < TB; ++g) {
+                const int f0 = 16 * (t0 + ts * g) + 4 * kq;
+                const bool ok = g < nt && f0 < M && fm < nrows;
+                const float* q = hT + (size_t)(ok ? f0 : 0) * J.ldT + row0 + (ok ? fm : 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[g][r] = ok ? q[(size_t)r * J.ldT] : 0.f;
+            }
+            f32x4 acc[TB];
+#pragma unroll
+            for (int g = 0; g < TB; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (nt > 0) bwd_tiles(acc, rw, M, K, in_lds, ldi, t0, ts, nt, fm, kq);
+#pragma unroll
+            for (int g = 0; g < TB; ++g) {
+                if (g < nt) {
+                    const int f0 = 16 * (t0 + ts * g) + 4 * kq;
+                    float4 v;
+                    v.x = (mk[g][0] > 0.f) ? acc[g][0] : 0.f;
+                    v.y = (mk[g][1] > 0.f) ? acc[g][1] : 0.f;
+                    v.z = (mk[g][2] > 0.f) ? acc[g][2] : 0.f;
+                    v.w = (mk[g][3] > 0.f) ? acc[g][3] : 0.f;
+                    if (out_lds) *(float4*)(out_lds + fm * ldh2 + f0) = v;
+                    if (outT && f0 < M && fm < nrows) {
+                        float* q = outT + (size_t)f0 * J.ldT + row0 + fm;
+                        q[0] = v.x; q[J.ldT] = v.y; q[2 * J.ldT] = v.z; q[3 * J.ldT] = v.w;
+                    }
+                }
+            }
+        }
+        SMX_LDS_BARRIER();
+    }
 }
 
-inline int r32(int v) { return (v + 31) & ~31; }
+inline int r64(int v) { return (v + 63) & ~63; }
+
+struct PackNet {
+    const float *W1, *W2, *W3;
+    float* packed;
+    int D, H1, H2, OUT;
+    long base;         // first 16-byte word of this net in the launch's index space
+};
+struct PackArgs {
+    PackNet n[MAX_EJOBS];
+    int count;
+    long total;
+};
+
+__host__ __device__ inline long pack_words(int M, int K) {       // 16-byte words of one packed layer
+    return (long)((M + 15) >> 4) * ((((K + 31) >> 5) + 1) & ~1) * 128;
+}
+
+// one thread per 16-byte word of the packed copy: [tile][chunk][half][lane][4] <- W[16 tile + (lane & 15)]
+// [32 chunk + 8 (lane >> 4) + 4 half + 0..3], zero outside the matrix
+__global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.total) return;
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_EJOBS; ++k) pi += (k < P.count && i >= P.n[k].base) ? 1 : 0;
+    const PackNet N = P.n[pi];
+    long w = i - N.base;
+    const long w1 = pack_words(N.H1, N.D), w2 = pack_words(N.H2, N.H1);
+    const float* W; int M, K;
+    if (w < w1) { W = N.W1; M = N.H1; K = N.D; }
+    else if (w < w1 + w2) { W = N.W2; M = N.H2; K = N.H1; w -= w1; }
+    else { W = N.W3; M = N.OUT; K = N.H2; w -= w1 + w2; }
+    const int C2 = (((K + 31) >> 5) + 1) & ~1;
+    const int lane = (int)(w & 63), half = (int)((w >> 6) & 1);
+    const long tc = w >> 7;
+    const int c = (int)(tc % C2), t = (int)(tc / C2);
+    const int m = 16 * t + (lane & 15), k = 32 * c + 8 * (lane >> 4) + 4 * half;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
+        const float* q = W + (size_t)m * K + k;
+        if (k + 0 < K) v.x = q[0];
+        if (k + 1 < K) v.y = q[1];
+        if (k + 2 < K) v.z = q[2];
+        if (k + 3 < K) v.w = q[3];
+    }
+    *(float4*)(N.packed + 4 * (i - N.base)) = v;
+}
+long long* g_tbuf = nullptr;
 
 }  // namespace
+
+extern "C" int64_t smx_epoch_packed_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
+    return 4 * (pack_words(H1, D) + pack_words(H2, H1) + pack_words(OUT, H2));
+}
+
+extern "C" int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_stream_t stream) {
+    SMX_REQUIRE(items, SMX_E_NULL);
+    SMX_REQUIRE(n >= 1 && n <= MAX_EJOBS, SMX_E_SHAPE);
+    PackArgs P;
+    P.count = n;
+    long base = 0;
+    for (int k = 0; k < n; ++k) {
+        SMX_REQUIRE(items[k].net && items[k].packed, SMX_E_NULL);
+        const smx_mlp3_t& m = *items[k].net;
+        SMX_REQUIRE(m.D > 0 && m.H1 > 0 && m.H2 > 0 && m.OUT > 0, SMX_E_SHAPE);
+        SMX_REQUIRE(((uintptr_t)items[k].packed & 15) == 0, SMX_E_ALIGN);
+        P.n[k].W1 = m.W1; P.n[k].W2 = m.W2; P.n[k].W3 = m.W3; P.n[k].packed = items[k].packed;
+        P.n[k].D = m.D; P.n[k].H1 = m.H1; P.n[k].H2 = m.H2; P.n[k].OUT = m.OUT;
+        P.n[k].base = base;
+        base += smx_epoch_packed_floats(m.D, m.H1, m.H2, m.OUT) / 4;
+    }
+    P.total = base;
+    hipLaunchKernelGGL(epoch_pack_kernel, dim3((unsigned)((base + 255) / 256)), dim3(256), 0, smx_s(stream), P);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" void smx_epoch_debug_tbuf(void* p) { g_tbuf = (long long*)p; }
 
 extern "C" int32_t smx_epoch_blocks(int64_t rows) { return (int32_t)((rows + ER - 1) / ER); }
 
 extern "C" int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
-    return D > 0 && H1 > 0 && H2 > 0 && OUT > 0 && D % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0 && OUT <= 32 &&
+    return D > 0 && H1 > 0 && H2 > 0 && OUT > 0 && H1 % 4 == 0 && H2 % 4 == 0 && OUT <= 32 &&
            D <= 2048 && H1 <= 16 * NWV * TG * 2 && H2 <= 16 * NWV * TG * 2;
 }
 
@@ -549,6 +750,7 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
     G.n = njobs;
     G.n_total = n_total;
     G.fsplit = fsplit;
+    { const char* e = getenv("SMX_EPOCH_DBG"); G.dbg = e ? atoi(e) : 0; G.tbuf = g_tbuf; }
     int base = 0, maxD = 0, maxH1 = 0, maxH2 = 0, A = 0;
     for (int k = 0; k < njobs; ++k) {
         const smx_epoch_job_t& s = jobs[k];
@@ -556,8 +758,11 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
         const smx_mlp3_t& n = *s.net;
         SMX_REQUIRE(smx_epoch_supported(n.D, n.H1, n.H2, n.OUT), SMX_E_UNSUPPORTED);
         SMX_REQUIRE(s.rows > 0 && s.rows < (1 << 30), SMX_E_SHAPE);
-        SMX_REQUIRE(((uintptr_t)s.x & 15) == 0 && ((uintptr_t)n.W1 & 15) == 0 && ((uintptr_t)n.W2 & 15) == 0 &&
-                        ((uintptr_t)n.W3 & 15) == 0 && ((uintptr_t)n.b1 & 15) == 0 && ((uintptr_t)n.b2 & 15) == 0,
+        // 16-byte words are read from x rows (when D % 4 == 0), W2 / W3 rows and the hidden biases; W1
+        // rows are D floats apart and their fragment loads only need 4-byte alignment
+        SMX_REQUIRE(((n.D & 3) || ((uintptr_t)s.x & 15) == 0) && ((uintptr_t)n.W1 & 3) == 0 &&
+                        ((uintptr_t)n.W2 & 15) == 0 && ((uintptr_t)n.W3 & 15) == 0 && ((uintptr_t)n.b1 & 15) == 0 &&
+                        ((uintptr_t)n.b2 & 15) == 0,
                     SMX_E_ALIGN);
         SMX_REQUIRE((!s.h1T && !s.h2T) || (s.h1T && s.h2T && s.ldT >= s.rows), SMX_E_SHAPE);
         EJob& J = G.j[k];
@@ -567,6 +772,13 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
         J.out = s.out; J.out_ld = s.out_ld ? s.out_ld : n.OUT; J.out_act = s.out_act; J.loss = s.loss;
         J.stop = s.stop_flag;
         J.dz3 = s.dz3; J.dz3T = s.dz3T; J.dz2T = s.dz2T; J.dz1T = s.dz1T;
+        if (!backward) {
+            SMX_REQUIRE(s.packed, SMX_E_NULL);
+            SMX_REQUIRE(((uintptr_t)s.packed & 15) == 0, SMX_E_ALIGN);
+            J.P1 = s.packed;
+            J.P2 = J.P1 + 4 * pack_words(n.H1, n.D);
+            J.P3 = J.P2 + 4 * pack_words(n.H2, n.H1);
+        }
         J.blk_base = base;
         base += smx_epoch_blocks(s.rows) * fsplit;
         if (s.loss == SMX_EPOCH_LOSS_POLICY) {
@@ -593,15 +805,20 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
         G.vl.will_update = a.v_will_update;
     }
     // LDS carve-up: [x tile | h1 tile | h2 tile | out tile | K-split partials | loss scratch]
-    G.ldx = r32(maxD) + 4; G.ldh1 = r32(maxH1) + 4; G.ldh2 = r32(maxH2) + 4;
+    // (the K loops run over an even number of 32-wide chunks: rows are zero padded to 64 columns)
+    G.ldx = r64(maxD) + 4; G.ldh1 = r64(maxH1) + 4; G.ldh2 = r64(maxH2) + 4;
     if (backward) { G.ldx = 0; G.ldh1 = 0; }     // dz3 tile (at 0, stride LDO) | dz2 tile
     G.off_h1 = backward ? ER * LDO : ER * G.ldx;
     G.off_h2 = G.off_h1 + ER * G.ldh1;
     G.off_out = G.off_h2 + ER * G.ldh2;
     G.off_red = G.off_out + (backward ? 0 : ER * LDO);
     G.off_loss = G.off_red + (backward ? 0 : NWV * 2 * 256);
-    const int loss_floats = backward ? FIN_CH * (8 + 2 * MAX_A) : ER * (8 * (A ? A : 1) + 1);
-    return (G.off_loss + loss_floats) * (int)sizeof(float);
+    const int loss_floats = backward ? FIN_CH * (8 + 2 * MAX_A) : loss_scratch_floats(A) + ER * (5 * A + 1);
+    const int bytes = (G.off_loss + loss_floats) * (int)sizeof(float);
+    // A launch has at most a few hundred workgroups, each keeping the four MFMA pipes of a CU busy
+    // by itself: ask for more than half of the CU's 160 KB of LDS so that the dispatcher cannot put
+    // two of them on one CU while others idle.
+    return bytes > EXCLUSIVE_LDS ? bytes : EXCLUSIVE_LDS;
 }
 
 extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
@@ -617,10 +834,10 @@ extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs,
                             loss->g_kl && loss->row_partials, SMX_E_NULL);
     const EJob& Lj = G.j[njobs - 1];
     const int blocks = Lj.blk_base + smx_epoch_blocks(Lj.rows);
-    SMX_REQUIRE(lds <= 160 * 1024, SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(lds <= 128 * 1024, SMX_E_UNSUPPORTED);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)epoch_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)epoch_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(epoch_fwd_kernel, dim3(blocks), dim3(NTH), lds, smx_s(stream), G, ctrl);
@@ -651,6 +868,11 @@ extern "C" int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs
     if (!update) {
         SMX_REQUIRE(njobs == 1, SMX_E_SHAPE);
         blocks = 1;
+    }
+    static bool attr_set_b = false;
+    if (!attr_set_b) {
+        (void)hipFuncSetAttribute((const void*)epoch_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set_b = true;
     }
     hipLaunchKernelGGL(epoch_bwd_kernel, dim3(blocks), dim3(NTH), lds, smx_s(stream), G, ctrl);
     SMX_LAUNCH_CHECK();

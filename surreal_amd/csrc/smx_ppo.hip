@@ -419,7 +419,7 @@ extern "C" int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const fl
                     row_partials, SMX_E_NULL);
     SMX_REQUIRE(rows > 0 && A > 0 && ld_act >= A && ld_beh >= 2 * A && ld_ref >= 2 * A, SMX_E_SHAPE);
     SMX_REQUIRE(A <= MAX_A && (mode == SMX_PPO_CLIP || mode == SMX_PPO_ADAPT), SMX_E_UNSUPPORTED);
-    const size_t lds = (size_t)LOSS_ROWS_PER_BLOCK * (8 * A + 1) * sizeof(float);
+    const size_t lds = (size_t)loss_scratch_floats(A) * sizeof(float);
     hipLaunchKernelGGL(policy_loss_kernel, dim3(smx_ppo_loss_blocks(rows)), dim3(256), lds,
                        smx_s(stream), mode, mean, log_var, actions, ld_act, behave, ld_beh, ref,
                        ld_ref, adv, (long)rows, A, ctrl, g_surr, g_kl, row_partials);
@@ -477,7 +477,7 @@ extern "C" int smx_ppo_epoch_losses_f32(const smx_ppo_losses_t* args, smx_ppo_ct
         nblk_v = smx_value_loss_blocks(a.rows);
     }
     const int nblk_p = smx_ppo_loss_blocks(a.rows);
-    const size_t lds = (size_t)(8 * a.A + 1) * LOSS_ROWS_PER_BLOCK * sizeof(float);
+    const size_t lds = (size_t)loss_scratch_floats(a.A) * sizeof(float);
     hipLaunchKernelGGL(ppo_losses_kernel, dim3(nblk_p + nblk_v), dim3(256), lds, smx_s(stream), a, ctrl,
                        nblk_p, (long)a.rows, 0, (float*)nullptr, (float*)nullptr);
     SMX_LAUNCH_CHECK();
@@ -503,7 +503,7 @@ extern "C" int smx_ppo_epoch_losses_dp_f32(const smx_ppo_losses_t* args, int64_t
         nblk_v = smx_value_loss_blocks(a.rows);
     }
     const int nblk_p = smx_ppo_loss_blocks(a.rows);
-    const size_t lds = (size_t)(8 * a.A + 1) * LOSS_ROWS_PER_BLOCK * sizeof(float);
+    const size_t lds = (size_t)loss_scratch_floats(a.A) * sizeof(float);
     hipLaunchKernelGGL(ppo_losses_kernel, dim3(nblk_p + nblk_v), dim3(256), lds, smx_s(stream), a, ctrl,
                        nblk_p, (long)n_total, 1, g_surr_t, g_kl_t);
     SMX_LAUNCH_CHECK();

@@ -3,10 +3,20 @@
 // Reference: surreal/model/ppo_net.py:29-72, surreal/learner/ppo.py:194-285, 553-557.
 #pragma once
 
+// barrier between phases that exchange data through LDS only.  The including file may define it as a
+// bare `s_waitcnt lgkmcnt(0); s_barrier`: __syncthreads() also waits for every outstanding GLOBAL
+// store of the wave (vmcnt(0)), a ~1 us round trip the fused epoch kernels pay at each of their phases.
+#ifndef SMX_LDS_BARRIER
+#define SMX_LDS_BARRIER() __syncthreads()
+#endif
+
 // rows per workgroup of the policy loss: 16 -> 64 workgroups for the 1024-row epochs (the kernel is
 // a chain of three short phases; with 64 rows it ran on 16 CUs and took 11 us, most of it waiting)
 constexpr int LOSS_ROWS_PER_BLOCK = 16;
 constexpr int MAX_A = 32;
+
+// LDS scratch (floats) of policy_loss_body for A action dimensions
+__host__ __device__ constexpr int loss_scratch_floats(int A) { return LOSS_ROWS_PER_BLOCK * (8 * A + 1) + 2 * MAX_A; }
 
 __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
     return (x == x) ? fmaxf(x, lo) : x;  // torch.clamp(min=) keeps NaN
@@ -28,7 +38,9 @@ __device__ __forceinline__ void policy_loss_body(
     const float* __restrict__ g_ref, int ld_ref, const float* __restrict__ adv, long rows, int A,
     const smx_ppo_ctrl_t* __restrict__ ctrl, float* __restrict__ g_surr, float* __restrict__ g_kl,
     float* __restrict__ partials, const float gscale = 1.0f, const bool scaled = false,
-    float* __restrict__ g_surr_t = nullptr, float* __restrict__ g_kl_t = nullptr, const long ld_t = 0) {
+    float* __restrict__ g_surr_t = nullptr, float* __restrict__ g_kl_t = nullptr, const long ld_t = 0,
+    const long in_row0 = 0 /* first row held by g_actions / g_behave / g_ref / adv (a staged block: row0) */,
+    const int ld_adv = 1) {
     const int R = LOSS_ROWS_PER_BLOCK;
     float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
     float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
@@ -39,6 +51,8 @@ __device__ __forceinline__ void policy_loss_body(
     float* e_dkl = e_dmu + R * A;  // ((mu - mr)/sig^2) * (1 - mu^2)       d KL / d z3
     float* e_gk = e_dkl + R * A;   // 1 - (sr^2+(mr-mu)^2)/sig^2          d KL / d log_var
     float* r_dll = e_gk + R * A;   // per-row d(loss_r)/d(ll)             [R]
+    float* s_sig = r_dll + R;      // exp(log_var)  (builders.py:127)       [A]
+    float* s_lsig = s_sig + MAX_A; // log(exp(log_var)): std0.log()  (ppo_net.py:40)
     const long row0 = (long)blk * R;
     long nrows = rows - row0;
     if (nrows > R) nrows = R;
@@ -46,11 +60,19 @@ __device__ __forceinline__ void policy_loss_body(
     const int stride = 8 + 2 * A;
     float* P = partials + (size_t)blk * stride;
 
+    // ---- phase 0: the policy's std and its log, once per block (read 17-deep from global memory by
+    // the one-lane-per-row phase they were a chain of dependent cache round trips) --------------------
+    if (tid < A) {
+        const float sg = expf(log_var[tid]);
+        s_sig[tid] = sg;
+        s_lsig[tid] = logf(sg);
+    }
+    SMX_LDS_BARRIER();
     // ---- phase 1: element-parallel terms ------------------------------------------------
     for (int i = tid; i < (int)nrows * A; i += 256) {
         const int rr = i / A, a = i - rr * A;
-        const long gr = row0 + rr;
-        const float sig = expf(log_var[a]);                      // builders.py:127
+        const long gr = row0 + rr - in_row0;
+        const float sig = s_sig[a];
         const float mu = mean_blk[rr * ld_mean + a];      // the block's rows of tanh(z3): global or LDS
         const float ac = g_actions[gr * ld_act + a];
         const float mb = g_behave[gr * ld_beh + a], sb = g_behave[gr * ld_beh + A + a];
@@ -69,7 +91,7 @@ __device__ __forceinline__ void policy_loss_body(
         e_dkl[i] = ((mu - mr) / s2) * dt;
         e_gk[i] = 1.0f - num / s2;
     }
-    __syncthreads();
+    SMX_LDS_BARRIER();
 
     // ---- phase 2: one lane per row ---------------------------------------------------------
     if (tid < 64) {                      // one wave; lanes >= nrows only feed zeros to the sums
@@ -81,7 +103,7 @@ __device__ __forceinline__ void policy_loss_body(
         if (ok) {
             for (int a = 0; a < A; ++a) {
                 s1 += e_z2[r * A + a];
-                s2 += logf(expf(log_var[a]));                    // std0.log()  (ppo_net.py:40)
+                s2 += s_lsig[a];
                 sb1 += e_zb2[r * A + a];
                 sb2 += e_lsb[r * A + a];
                 klr += e_kl[r * A + a];
@@ -95,7 +117,7 @@ __device__ __forceinline__ void policy_loss_body(
         const float Lb = clamp_min_nan(expf(llb), 1e-5f);
         const float kl = klr - half_d;
         const float klb = klbr - half_d;
-        const float ad = ok ? adv[row0 + r] : 0.f;
+        const float ad = ok ? adv[(row0 + r - in_row0) * ld_adv] : 0.f;
         float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
         if (mode == SMX_PPO_CLIP) {
             const float eps = ctrl->clip_eps;
@@ -127,7 +149,7 @@ __device__ __forceinline__ void policy_loss_body(
         const float v5 = smx_wave_sum(ok ? klb : 0.f);
         if (tid == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
     }
-    __syncthreads();
+    SMX_LDS_BARRIER();
 
     // ---- phase 3: gradient tiles + log_var gradient partials -----------------------------
     for (int i = tid; i < (int)nrows * A; i += 256) {
@@ -164,13 +186,13 @@ __device__ __forceinline__ void reduce_row_partials(const float* __restrict__ pa
         const int nb = min(FIN_CH, nblk - b0);
         for (int idx = threadIdx.x; idx < nb * stride; idx += 256)
             buf[idx] = partials[(size_t)b0 * stride + idx];
-        __syncthreads();
+        SMX_LDS_BARRIER();
         if ((int)threadIdx.x < stride)
             for (int b = 0; b < nb; ++b) t += buf[b * stride + threadIdx.x];
-        __syncthreads();
+        SMX_LDS_BARRIER();
     }
     if ((int)threadIdx.x < stride) S[threadIdx.x] = t;
-    __syncthreads();
+    SMX_LDS_BARRIER();
 }
 
 // loss and the coefficient of the KL gradient from the batch sums (ppo.py:217 / 272-276)

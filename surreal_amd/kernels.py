@@ -132,6 +132,17 @@ class HipKernels(object):
     def epoch_blocks(self, rows):
         return self.lib.smx_epoch_blocks(rows)
 
+    def epoch_packed_numel(self, net):
+        return self.lib.smx_epoch_packed_floats(net.D, net.H1, net.H2, net.OUT)
+
+    def epoch_pack(self, items):
+        """items: [(net, packed)], up to 4: the weights in the forward kernel's fragment order, one launch"""
+        arr = (L.EpochPack * len(items))()
+        for k, (net, packed) in enumerate(items):
+            arr[k].net = ctypes.pointer(net.desc)
+            arr[k].packed = L.ptr(packed)
+        L.call('smx_epoch_pack_f32', arr, len(items), self._st())
+
     _EPOCH_LOSS = {None: L.EPOCH_LOSS_NONE, 'policy': L.EPOCH_LOSS_POLICY, 'value': L.EPOCH_LOSS_VALUE}
 
     def _epoch_jobs(self, jobs):
@@ -152,6 +163,7 @@ class HipKernels(object):
             arr[k].loss = self._EPOCH_LOSS[j.get('loss')]
             arr[k].stop_flag = g('stop')
             arr[k].dz3, arr[k].dz3T, arr[k].dz2T, arr[k].dz1T = g('dz3'), g('dz3T'), g('dz2T'), g('dz1T')
+            arr[k].packed = g('packed')
         return arr
 
     @staticmethod

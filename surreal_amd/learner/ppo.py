@@ -186,8 +186,11 @@ class PPOLearner(Learner):
             and self.world_size == 1
         self.overlap_value_epochs = bool(lcfg.get('overlap_value_epochs', True)) \
             and self.device != 'cpu'
-        # 'lockstep': actor and critic epochs share launches; 'two_stream': separate chains
+        # 'lockstep': actor and critic epochs share launches; 'two_stream': separate chains.
+        # 'fused_epochs' (default where the shapes allow): a lock-step epoch is four launches of the
+        # row-block kernels (csrc/smx_epoch.hip) instead of nine layer launches
         self.epoch_schedule = lcfg.get('epoch_schedule', 'lockstep')
+        self.fused_epochs = bool(lcfg.get('fused_epochs', True))
         self._ws = None
         self._graphs = {}
         self._ctrl_host = None
@@ -327,6 +330,16 @@ class PPOLearner(Learner):
         n_a, n_c = self.model.actor_flat.numel(), self.model.critic_flat.numel()
         ws.nblk_p = K.loss_blocks(rows)
         ws.nblk_v = K.value_loss_blocks(rows)
+        # fused row-block epochs: single rank, plain MLP policy, shapes the kernels take
+        ws.fused = (self.fused_epochs and self.epoch_schedule == 'lockstep' and not stem and
+                    self.world_size == 1 and K.epoch_supported(act) and K.epoch_supported(cri))
+        if ws.fused:
+            ws.nblk_v = K.epoch_blocks(rows)         # value-loss moments per 16-row block
+            assert ws.nblk_p == K.epoch_blocks(rows)
+            # the weights in the forward kernel's fragment order (model, critic, reference policy)
+            ws.pk_actor = torch.zeros(K.epoch_packed_numel(act), device=dev)
+            ws.pk_critic = torch.zeros(K.epoch_packed_numel(cri), device=dev)
+            ws.pk_ref = torch.zeros(K.epoch_packed_numel(act), device=dev)
         ws.pstride = 8 + 2 * A
         # batch means are over the GLOBAL batch: ranks may hold different numbers of sub-trajectories
         # (B not divisible by the world size), so the totals are exchanged once per workspace.  A
@@ -644,6 +657,63 @@ class PPOLearner(Learner):
             ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(ws.vgather.permute(1, 0, 2, 3))
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
+    def _enqueue_fused_epochs(self, ws, actions0, behave0, ref_job, tail, gae):
+        """The lock-step epochs on the row-block kernels (csrc/smx_epoch.hip): per epoch
+        [forward + losses] -> [batch means, KL coefficient / early exit, data gradients] ->
+        [all weight gradients] -> [clip-norm + Adam of both groups]: four dependent launches where
+        the layered schedule takes nine.  Same arithmetic contract as _enqueue_lockstep_epochs."""
+        K, m = self.K, self.model
+        Ep, Ev = self.epoch_policy, self.epoch_baseline
+        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
+        A = self.action_dim
+        n_total = ws.n_total
+        # the reference policy and the critic's obs_next rows: one forward-only launch, then GAE
+        K.epoch_pack([(m.actor, ws.pk_actor), (m.critic, ws.pk_critic), (ref_job['net'], ws.pk_ref)])
+        pre = [dict(net=ref_job['net'], packed=ws.pk_ref, x=ref_job['x'], out=ref_job['out'], act=L.SMX_ACT_TANH)]
+        if tail is not None:
+            pre.append(dict(net=tail['net'], packed=ws.pk_critic, x=tail['x'], out=tail['out'], act=L.SMX_ACT_NONE))
+        K.epoch_forward(pre, None, ws.ctrl_f, n_total)
+        gae()
+        aj = dict(net=m.actor, packed=ws.pk_actor, x=ws.xn, act=L.SMX_ACT_TANH, loss='policy', stop=ws.stop, h1T=ws.h1aT,
+                  h2T=ws.h2aT, dz3T=ws.dz3aT, dz2T=ws.dz2aT, dz1T=ws.dz1aT, xT=ws.xnT, grads=ws.grads_a,
+                  sumsq=ws.sumsq_a)
+        cj = dict(net=m.critic, packed=ws.pk_critic, x=ws.xn, act=L.SMX_ACT_NONE, loss='value', h1T=ws.h1cT, h2T=ws.h2cT,
+                  dz3=ws.dz3c, dz3T=ws.dz3c, dz2T=ws.dz2cT, dz1T=ws.dz1cT, xT=ws.xnT, grads=ws.grads_c,
+                  sumsq=ws.sumsq_c)         # OUT = 1: dz3^T is dz3 itself
+        for e in range(max(Ep + 1, Ev)):
+            pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
+            loss = dict(mode=mode, rows=ws.rows, log_var=m.log_var.view(-1), actions=actions0, behave=behave0,
+                        ref=ws.ref_pol, adv=ws.adv, g_surr=ws.g_surr, g_kl=ws.g_kl, partials=ws.ppart,
+                        check_stop=e > 0, will_update=pol_u,
+                        dlogvar=ws.grads_a[m.actor.numel:m.actor.numel + A],
+                        dlogvar_sumsq=ws.sumsq_a[ws.np_a:ws.np_a + 1], stats=ws.pstats[min(e, Ep)],
+                        returns=ws.ret, v_dz3=ws.dz3c, v_partials=ws.vpart[min(e, Ev - 1)], v_will_update=True)
+            K.epoch_forward(([aj] if pol_f else []) + ([cj] if val else []), loss, ws.ctrl_f, n_total)
+            if pol_f and not pol_u:
+                K.epoch_backward([aj], loss, ws.ctrl_f, n_total)       # statistics + early exit only
+            if pol_u or val:
+                bj = ([aj] if pol_u else []) + ([cj] if val else [])
+                K.epoch_backward(bj, loss, ws.ctrl_f, n_total)
+                K.mlp3_wgrad_multi(bj)
+            np_a, np_c = ws.np_a + 1, ws.np_c
+            if pol_u and val:        # both groups step in one launch
+                K.clip_adam_pair((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                                  ws.sumsq_a, np_a, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1]),
+                                 (m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                                  ws.sumsq_c, np_c, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1]),
+                                 ws.ctrl_f)
+            elif pol_u:
+                K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                            ws.sumsq_a, np_a, ws.ctrl_f, 0, True,
+                            ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
+            elif val:
+                K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                            ws.sumsq_c, np_c, ws.ctrl_f, 1, False,
+                            ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
+            if pol_u or val:
+                K.epoch_pack(([(m.actor, ws.pk_actor)] if pol_u else []) + ([(m.critic, ws.pk_critic)] if val else []))
+        K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+
     def _enqueue_tail_exchange(self, ws, obs0, actions0, behave0):
         """end of a data-parallel lock-step learn: ONE all-gather carries the final policy pass's
         loss sums, the value-loss moments of every epoch, the return moments and the z-filter
@@ -752,7 +822,10 @@ class PPOLearner(Learner):
             K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats,
                              L.VS_STRIDE)
 
-        if lockstep:
+        if lockstep and ws.fused:
+            self._enqueue_fused_epochs(ws, actions0, behave0, ref_job, tail,
+                                       lambda: self._enqueue_gae_from_values(ws, obs, rewards, dones))
+        elif lockstep:
             # the reference policy and the critic's obs_next rows ride in epoch 0's forward
             # launches (four independent networks, one launch per layer); GAE follows them
             self._enqueue_lockstep_epochs(

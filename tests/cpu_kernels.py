@@ -143,10 +143,18 @@ class TorchCpuKernels(object):
 
     # ---- fused row-block epoch kernels ------------------------------------------------------
     def epoch_supported(self, net):
-        return net.D % 4 == 0 and net.H1 % 4 == 0 and net.H2 % 4 == 0 and net.OUT <= 32
+        return net.H1 % 4 == 0 and net.H2 % 4 == 0 and net.OUT <= 32
 
     def epoch_blocks(self, rows):
         return (rows + 15) // 16
+
+    def epoch_packed_numel(self, net):
+        return net.numel            # opaque to the caller
+
+    def epoch_pack(self, items):
+        for net, packed in items:      # the double keeps a flat copy: the forward must see THESE values
+            flat = torch.cat([net.views[k].reshape(-1) for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')])
+            packed[:flat.numel()].copy_(flat)
 
     def epoch_forward(self, jobs, loss=None, ctrl=None, n_total=0):
         for j in jobs:
@@ -154,9 +162,15 @@ class TorchCpuKernels(object):
                 continue
             net, x = j['net'], j['x']
             v = net.views
-            h1 = torch.relu(torch.nn.functional.linear(x, v['W1'], v['b1']))
-            h2 = torch.relu(torch.nn.functional.linear(h1, v['W2'], v['b2']))
-            out = self._act(torch.nn.functional.linear(h2, v['W3'], v['b3']), j.get('act', 0))
+            pk, o = j['packed'], 0          # weights from the packed copy, biases from the net (as the kernel)
+            W = {}
+            for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'):
+                n_ = v[k].numel()
+                W[k] = pk[o:o + n_].view(v[k].shape)
+                o += n_
+            h1 = torch.relu(torch.nn.functional.linear(x, W['W1'], v['b1']))
+            h2 = torch.relu(torch.nn.functional.linear(h1, W['W2'], v['b2']))
+            out = self._act(torch.nn.functional.linear(h2, W['W3'], v['b3']), j.get('act', 0))
             if j.get('h1T') is not None:
                 j['h1T'].copy_(h1.t())
                 j['h2T'].copy_(h2.t())

@@ -47,7 +47,7 @@ def build(rows, D, H1, H2, A, seed, mode, device):
     ldT = rows + 16
     T = {}
 
-    def side(dv, act, cri):
+    def side(dv, act, cri, Kx):
         f = lambda *s: torch.zeros(*s, device=dv)  # noqa: E731
         ft = lambda n: torch.zeros(n, ldT, device=dv)[:, :rows]  # noqa: E731
         nblk = (rows + 15) // 16
@@ -57,11 +57,13 @@ def build(rows, D, H1, H2, A, seed, mode, device):
                  v_dz3=f(rows), v_partials=f(nblk, 8), dlogvar=f(A), dlq=f(1), stats=f(L.PS_STRIDE),
                  xT=ft(D), h1aT=ft(H1), h2aT=ft(H2), h1cT=ft(H1), h2cT=ft(H2), dz3aT=ft(A), dz2aT=ft(H2),
                  dz1aT=ft(H1), dz2cT=ft(H2), dz1cT=ft(H1),
-                 grads_a=f(act.numel), grads_c=f(cri.numel), act=act, cri=cri)
+                 grads_a=f(act.numel), grads_c=f(cri.numel), act=act, cri=cri,
+                 pk_a=f(max(Kx.epoch_packed_numel(act), act.numel)), pk_c=f(max(Kx.epoch_packed_numel(cri), cri.numel)))
         t['xT'].copy_(t['x'].t())
         return t
-    T['c'] = side('cpu', act_c, cri_c)
-    T['d'] = side('cuda', act_d, cri_d)
+    from surreal_amd.kernels import HipKernels
+    T['c'] = side('cpu', act_c, cri_c, C)
+    T['d'] = side('cuda', act_d, cri_d, HipKernels())
     return T
 
 
@@ -71,9 +73,11 @@ def run(Kx, t, mode, check_stop=True, will_update=True, stop=None, phase='all'):
                 adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=check_stop,
                 will_update=will_update, dlogvar=t['dlogvar'], dlogvar_sumsq=t['dlq'], stats=t['stats'],
                 returns=t['returns'], v_dz3=t['v_dz3'], v_partials=t['v_partials'], v_will_update=True)
-    aj = dict(net=t['act'], x=t['x'], h1T=t['h1aT'], h2T=t['h2aT'], out=t['mean'], act=L.SMX_ACT_TANH, loss='policy',
+    if phase in ('all', 'fwd'):
+        Kx.epoch_pack([(t['act'], t['pk_a']), (t['cri'], t['pk_c'])])
+    aj = dict(net=t['act'], packed=t['pk_a'], x=t['x'], h1T=t['h1aT'], h2T=t['h2aT'], out=t['mean'], act=L.SMX_ACT_TANH, loss='policy',
               stop=stop, dz3T=t['dz3aT'], dz2T=t['dz2aT'], dz1T=t['dz1aT'], xT=t['xT'], grads=t['grads_a'])
-    cj = dict(net=t['cri'], x=t['x'], h1T=t['h1cT'], h2T=t['h2cT'], out=t['vpred'].view(-1, 1), act=L.SMX_ACT_NONE,
+    cj = dict(net=t['cri'], packed=t['pk_c'], x=t['x'], h1T=t['h1cT'], h2T=t['h2cT'], out=t['vpred'].view(-1, 1), act=L.SMX_ACT_NONE,
               loss='value', dz3=t['v_dz3'], dz3T=t['v_dz3'], dz2T=t['dz2cT'], dz1T=t['dz1cT'], xT=t['xT'],
               grads=t['grads_c'])
     if phase in ('all', 'fwd'):
@@ -87,7 +91,7 @@ def run(Kx, t, mode, check_stop=True, will_update=True, stop=None, phase='all'):
         Kx.epoch_backward([aj], loss, t['ctrl'], rows)
 
 
-SHAPES = [(1024, 376, 300, 200, 17), (64, 16, 300, 200, 6), (37, 28, 40, 24, 5), (16, 12, 24, 16, 3),
+SHAPES = [(1024, 376, 300, 200, 17), (64, 17, 300, 200, 6), (8, 11, 24, 16, 3), (37, 29, 40, 24, 5), (37, 28, 40, 24, 5), (16, 12, 24, 16, 3),
           (100, 64, 332, 212, 32), (5, 8, 16, 12, 1)]
 
 
