@@ -466,6 +466,11 @@ typedef struct smx_adam_group {
     int32_t npart;
     int32_t honour_stop;
     float* grad_norm_out;
+    /* optional (both or neither): the group's MLP and its packed copy (smx_epoch_pack_f32 layout); the
+     * step then writes every updated weight into the packed copy as well, so the next fused epoch
+     * forward needs no separate packing launch */
+    const smx_mlp3_t* pack_net;
+    float* packed;
 } smx_adam_group_t;
 int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor, const smx_adam_group_t* critic,
                                 const smx_ppo_ctrl_t* ctrl, smx_stream_t stream);

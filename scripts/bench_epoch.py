@@ -62,4 +62,21 @@ for DBG in ('0',):
           nm, d.mean(), d.min(), d.max(), d[:64].mean(), d[64:].mean()))
   tot = T_[:, 6] - T_[:, 0]
   print('total in-kernel: mean %.0f max %.0f ; end-start over all wgs %.0f cycles' % (tot.mean(), tot.max(), T_[:, 6].max() - base))
+tb.zero_()
+for _ in range(3):
+    TE.run(K, t, L.SMX_PPO_ADAPT, phase='bwd')
+torch.cuda.synchronize()
+TT = tb.view(512, 32)[:256].cpu().double()
+pol = TT[:, 2] > 0
+for nm, sel in (('actor', pol), ('critic', ~pol)):
+    X = TT[sel]
+    print('bwd %s wgs (%d): entry->flag %.0f | partials+scalars %.0f | dz3 tile+barrier %.0f' % (
+        nm, X.shape[0], (X[:, 1] - X[:, 0]).mean(), ((X[:, 2] - X[:, 1]).mean() if nm == 'actor' else 0),
+        ((X[:, 3] - X[:, 2]).mean() if nm == 'actor' else (X[:, 3] - X[:, 1]).mean())))
+    for l in range(2):
+        st = X[:, 3 + l]
+        print('   layer dz%d: setup %.0f main %.0f epilogue %.0f barrier %.0f' % (2 - l, (X[:, 8 + 4 * l] - st).mean(),
+              (X[:, 9 + 4 * l] - X[:, 8 + 4 * l]).mean(), (X[:, 10 + 4 * l] - X[:, 9 + 4 * l]).mean(),
+              (X[:, 4 + l] - X[:, 10 + 4 * l]).mean()))
+    print('   total %.0f (max %.0f)' % ((X[:, 5] - X[:, 0]).mean(), (X[:, 5] - X[:, 0]).max()))
 lib.smx_epoch_debug_tbuf(None)

@@ -64,7 +64,8 @@ class AdamGroup(Structure):
     """smx_adam_group_t"""
     _fields_ = [('theta', c_void_p), ('grads', c_void_p), ('exp_avg', c_void_p),
                 ('exp_avg_sq', c_void_p), ('n', c_int64), ('sumsq_partials', c_void_p),
-                ('npart', c_int32), ('honour_stop', c_int32), ('grad_norm_out', c_void_p)]
+                ('npart', c_int32), ('honour_stop', c_int32), ('grad_norm_out', c_void_p),
+                ('pack_net', POINTER(Mlp3)), ('packed', c_void_p)]
 
 
 class PpoLosses(Structure):

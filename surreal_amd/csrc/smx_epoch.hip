@@ -35,6 +35,7 @@
 
 namespace {
 #include "smx_ppo_loss.inc.h"
+#include "smx_epoch_pack.inc.h"
 
 constexpr int ER = 16;            // data rows per workgroup (= MFMA N)
 constexpr int NWV = 4;            // waves per workgroup, one per SIMD
@@ -45,6 +46,7 @@ constexpr int MAX_EJOBS = 4;
 constexpr int XV = 7;             // 16-byte words of its x row a thread fetches up front (D <= 448; more: a loop)
 constexpr int LIN = 6;            // loss-input words a thread fetches up front: 16 rows x (5A + 1) <= 6 x 256
 constexpr int EXCLUSIVE_LDS = 84 * 1024;
+constexpr int LDZ = 68;           // row stride of the dz3 tile in LDS (backward: 64 zero-padded columns)
 constexpr int LDO = 36;           // row stride of the output tile in LDS (<= 32 outputs)
 static_assert(ER == LOSS_ROWS_PER_BLOCK, "a row block is a loss block");
 static_assert(NTH == 256, "the shared loss code strides by 256 threads");
@@ -94,7 +96,7 @@ struct EJob {
     // backward
     const float* dz3;
     float *dz3T, *dz2T, *dz1T;
-    const float *P1, *P2, *P3;     // packed weights (smx_epoch_pack_f32) or null
+    const float *P1, *P2, *P3, *P2T, *P3T;     // packed weights (smx_epoch_pack_f32): layers 1-3, transposed 2-3
 };
 
 struct PolArgs {       // the DiagGauss losses of the actor job (smx_ppo_losses_t, the parts used here)
@@ -193,7 +195,7 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[TG], const WFrag<NT>& f) 
     }
 }
 
-// tiles t0, t0 + NWV, ... (NT of them; tiles >= `tiles` are out-of-range operands) over the C2 (even)
+// tiles t0, t0 + tstep, ... (NT of them; tiles >= `tiles` are out-of-range operands) over the C2 (even)
 // K chunks.  Four register stages: while the MFMAs of one chunk issue (NT x 8 x 32 cycles), the next
 // two chunks' 2 NT weight loads and 2 LDS reads each are in flight.  The scheduling barriers pin that order --
 // left alone, hipcc sinks each load to just in front of the MFMA that consumes it and waits for L2
@@ -201,11 +203,11 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[TG], const WFrag<NT>& f) 
 // park the accumulators in VGPRs and copy all of them to the MFMA registers and back every chunk.
 template <int NT>
 __device__ __forceinline__ void fwd_tiles(f32x4 (&acc)[TG], rsrc_t rw, int tiles, int C2, const float* in_lds,
-                                          int ldi, int t0, int lane) {
+                                          int ldi, int t0, int tstep, int lane) {
     unsigned wo[TG];
 #pragma unroll
     for (int g = 0; g < TG; ++g) {
-        const int t = t0 + NWV * g;
+        const int t = t0 + tstep * g;
         wo[g] = (g < NT && t < tiles) ? ((unsigned)t * (unsigned)C2 * 512u + (unsigned)lane * 4u) * 4u : OOB;
     }
     const float* bp = in_lds + (lane & 15) * ldi + 8 * (lane >> 4);
@@ -380,10 +382,10 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
 #pragma unroll
             for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
             TSTAMP(16 + 4 * l);
-            if (nt > 4) fwd_tiles<5>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
-            else if (nt > 2) fwd_tiles<4>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
-            else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
-            else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, lane);
+            if (nt > 4) fwd_tiles<5>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+            else if (nt > 2) fwd_tiles<4>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+            else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+            else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
             TSTAMP(17 + 4 * l);
             // hidden tiles: [feature][row] in HBM, lane (fm, kq) holds features f0..f0+3 of row fm;
             // the output tile: row-major.  Stores past the matrix / the batch go to out-of-range offsets.
@@ -451,73 +453,15 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
 
 // ---------------------------------------------------------------------------------------------
 // backward (data gradients).  accT[g] (16 features x 16 rows) += Wt[16 t_g.., :K] . dzT[:K, 16 rows]
-// with Wt(m, k) = W[k, m] (W row-major [K, M]): the A operand of step r of a 16-wide K chunk c is
-// W[(16c + 4kq + r) * M + 16 t + fm] -- four 4-byte loads per chunk and tile, each a 64-byte run per
-// kq group.  k >= K is past the matrix (0); features >= M are pointed out of range.
+// with Wt(m, k) = W[k, m]: the packed copy holds the TRANSPOSED matrices of layers 2 and 3 in the same
+// fragment order as the forward weights, so this is the forward loop on other operands.  (Read from
+// the row-major matrices -- four 4-byte loads per 4 MFMAs -- the dz1 product ran at half its MFMA rate,
+// bound by the CU's address unit.)
 // ---------------------------------------------------------------------------------------------
-struct TFrag {
-    float a[TB][4];
-    float4 x;
-};
-
-__device__ __forceinline__ void ld_tfrag(TFrag& f, rsrc_t rw, const unsigned (&wo)[TB], unsigned kstep,
-                                         const float* bp, int c, int nch) {
-#pragma unroll
-    for (int g = 0; g < TB; ++g) {
-        const unsigned o = wo[g] + (unsigned)c * 16u * kstep;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f.a[g][r] = ld4(rw, (c < nch) ? o + (unsigned)r * kstep : OOB);
-    }
-    f.x = *(const float4*)(bp + 16 * (c < nch ? c : 0));
-}
-
-__device__ __forceinline__ void mma_tchunk(f32x4 (&acc)[TB], const TFrag& f) {
-#pragma unroll
-    for (int g = 0; g < TB; ++g) {
-        acc[g] = MFMA16(f.a[g][0], f.x.x, acc[g]);
-        acc[g] = MFMA16(f.a[g][1], f.x.y, acc[g]);
-        acc[g] = MFMA16(f.a[g][2], f.x.z, acc[g]);
-        acc[g] = MFMA16(f.a[g][3], f.x.w, acc[g]);
-    }
-}
-
-// W row-major [K, M]; tiles t0, t0 + ts, ... of the M axis (TB of them; the ones past `tiles` are
-// out-of-range operands); three register stages (a chunk is only TB x 4 MFMAs here)
-__device__ __forceinline__ void bwd_tiles(f32x4 (&acc)[TB], rsrc_t rw, int M, int K, const float* in_lds, int ldi,
-                                          int t0, int ts, int nt, int fm, int kq) {
-    const int nch = (K + 15) >> 4;
-    const unsigned kstep = (unsigned)M * 4u;                 // bytes between consecutive k
-    unsigned wo[TB];
-#pragma unroll
-    for (int g = 0; g < TB; ++g) {
-        const int f = 16 * (t0 + ts * g) + fm;
-        wo[g] = (g < nt && f < M) ? (unsigned)f * 4u + 4u * kq * kstep : OOB;
-    }
-    const float* bp = in_lds + fm * ldi + 4 * kq;
-    TFrag P, Q, R;
-    ld_tfrag(P, rw, wo, kstep, bp, 0, nch);
-    __builtin_amdgcn_sched_barrier(0);
-    ld_tfrag(Q, rw, wo, kstep, bp, 1, nch);
-#pragma unroll 1
-    for (int c = 0; c < nch; c += 3) {
-        __builtin_amdgcn_sched_barrier(0);
-        ld_tfrag(R, rw, wo, kstep, bp, c + 2, nch);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tchunk(acc, P);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_tfrag(P, rw, wo, kstep, bp, c + 3, nch);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch) mma_tchunk(acc, Q);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_tfrag(Q, rw, wo, kstep, bp, c + 4, nch);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < nch) mma_tchunk(acc, R);
-    }
-}
-
 __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
     extern __shared__ float sm[];
     __shared__ float S[8 + 2 * MAX_A];
+    TSTAMP(0);
     const EJob J = select_job(G, (int)blockIdx.x);
     const int fs = G.fsplit;
     const int wg = blockIdx.x - J.blk_base;
@@ -540,7 +484,7 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fm = lane & 15, kq = lane >> 4;
-    float* dz3s = sm;                       // [16][LDO]
+    float* dz3s = sm;                       // [16][LDZ]
     float* dz2s = sm + G.off_h2;            // [16][ldh2]
     const int ldh2 = G.ldh2;
     const bool policy = J.loss == SMX_EPOCH_LOSS_POLICY;
@@ -549,17 +493,16 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     // ---- requested up front, in one batch: this workgroup's share of the loss tiles -----------
     const int A = p.A;
     float gs0 = 0.f, gk0 = 0.f, gs1 = 0.f, gk1 = 0.f, vd = 0.f;       // <= 2 (row, action) pairs per thread
-    if (policy) {
-        if (tid < ER * A) {
-            const int a = tid / ER, nn = tid - a * ER;
-            if (nn < nrows) { gs0 = p.g_surr[(size_t)(row0 + nn) * A + a]; gk0 = p.g_kl[(size_t)(row0 + nn) * A + a]; }
-        }
-        if (tid + NTH < ER * A) {
-            const int a = (tid + NTH) / ER, nn = tid + NTH - a * ER;
-            if (nn < nrows) { gs1 = p.g_surr[(size_t)(row0 + nn) * A + a]; gk1 = p.g_kl[(size_t)(row0 + nn) * A + a]; }
-        }
-    } else if (tid < nrows) {
-        vd = J.dz3[row0 + tid];
+    if (policy) {            // (unconditional loads from clamped addresses: no load under a lane mask)
+        const int last = ER * A - 1;
+        const int i0 = tid < last ? tid : last, i1 = tid + NTH < last ? tid + NTH : last;
+        const int a0 = i0 / ER, n0 = i0 - a0 * ER, a1 = i1 / ER, n1 = i1 - a1 * ER;
+        const size_t e0 = (size_t)(row0 + (n0 < nrows ? n0 : 0)) * A + a0;
+        const size_t e1 = (size_t)(row0 + (n1 < nrows ? n1 : 0)) * A + a1;
+        gs0 = p.g_surr[e0]; gk0 = p.g_kl[e0];
+        gs1 = p.g_surr[e1]; gk1 = p.g_kl[e1];
+    } else {
+        vd = J.dz3[row0 + (tid < nrows ? tid : 0)];
     }
     for (int idx = tid; idx < (G.off_red >> 2); idx += NTH) *(float4*)(sm + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
     // the early-exit flag may be raised by workgroup 0 of THIS launch while others start: one lane
@@ -569,6 +512,7 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     const bool stopped = S[0] != 0.f;
     SMX_LDS_BARRIER();
     if (stopped) return;
+    TSTAMP(1);
 
     if (policy) {
         const int nblk = nb;
@@ -586,6 +530,7 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
                 write_policy_scalars(S, n, loss, c_kl, p.log_var, A, ctrl, p.check_stop, p.will_update,
                                      p.dlogvar_sumsq, p.stats);
         }
+        TSTAMP(2);
         if (stop_now || !p.will_update) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -593,47 +538,54 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
             if (idx < ER * A) {
                 const int a = idx / ER, nn = idx - a * ER;
                 const float v = nn < nrows ? ((i ? gs1 : gs0) + c_kl * (i ? gk1 : gk0)) * inv_n : 0.f;
-                if (nn < nrows && half == 0 && J.dz3T) J.dz3T[(size_t)a * J.ldT + row0 + nn] = v;
-                dz3s[nn * LDO + a] = v;
+                if (nn < nrows && half == 0 && J.dz3T) J.dz3T[(size_t)a * J.ldT + row0 + nn] = v;   // (a store: nothing waits for it)
+                dz3s[nn * LDZ + a] = v;
             }
         }
     } else {
-        if (tid < ER) dz3s[tid * LDO] = vd;
+        if (tid < ER) dz3s[tid * LDZ] = tid < nrows ? vd : 0.f;
     }
     SMX_LDS_BARRIER();
+    TSTAMP(3);
     // ---- dz2 = (dz3 . W3) * relu'(h2): all tiles in every workgroup of the row block (cheap; only
     // the first one stores the transposed copy); dz1 = (dz2 . W2) * relu'(h1): the feature tiles
     // half, half + fs, ... of this workgroup.  One loop body for both (code size, see above).
 #pragma unroll 1
     for (int l = 0; l < 2; ++l) {
-        const float* W = l == 0 ? J.W3 : J.W2;
+        const float* Wp = l == 0 ? J.P3T : J.P2T;
         const int M = l == 0 ? J.H2 : J.H1, K = l == 0 ? J.OUT : J.H2;
         const float* in_lds = l == 0 ? dz3s : dz2s;
-        const int ldi = l == 0 ? LDO : ldh2;
+        const int ldi = l == 0 ? LDZ : ldh2;
         const float* hT = l == 0 ? J.h2T : J.h1T;
         float* out_lds = l == 0 ? dz2s : nullptr;
         float* outT = l == 0 ? (half == 0 ? J.dz2T : nullptr) : J.dz1T;
         const int first = l == 0 ? 0 : half, step = l == 0 ? 1 : fs;
         const int tiles = (M + 15) >> 4;
-        const rsrc_t rw = make_rsrc(W, (unsigned)K * (unsigned)M * 4u);
+        const int C2 = (((K + 31) >> 5) + 1) & ~1;
+        const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
+        const rsrc_t rmask = make_rsrc(hT, (unsigned)M * (unsigned)J.ldT * 4u);
+        const rsrc_t rout = make_rsrc(outT ? outT : hT, (unsigned)M * (unsigned)J.ldT * 4u);
 #pragma unroll 1
         for (int tb = first; tb < tiles; tb += step * NWV * TB) {
             const int t0 = tb + step * wv, ts = step * NWV;
             int nt = (tiles - t0 + ts - 1) / ts;
             nt = nt < 0 ? 0 : (nt > TB ? TB : nt);
-            float mk[TB][4];            // ReLU masks, requested in front of the main loop
+            float mk[TB][4];            // ReLU masks, requested in front of the main loop (guards: out-of-range offsets)
 #pragma unroll
             for (int g = 0; g < TB; ++g) {
                 const int f0 = 16 * (t0 + ts * g) + 4 * kq;
                 const bool ok = g < nt && f0 < M && fm < nrows;
-                const float* q = hT + (size_t)(ok ? f0 : 0) * J.ldT + row0 + (ok ? fm : 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mk[g][r] = ok ? q[(size_t)r * J.ldT] : 0.f;
+                for (int r = 0; r < 4; ++r)
+                    mk[g][r] = ld4(rmask, ok ? ((unsigned)(f0 + r) * (unsigned)J.ldT + (unsigned)(row0 + fm)) * 4u : OOB);
             }
-            f32x4 acc[TB];
+            f32x4 acc[TG];
 #pragma unroll
-            for (int g = 0; g < TB; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (nt > 0) bwd_tiles(acc, rw, M, K, in_lds, ldi, t0, ts, nt, fm, kq);
+            for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            TSTAMP(8 + 4 * l);
+            if (nt > 1) fwd_tiles<TB>(acc, rw, tiles, C2, in_lds, ldi, t0, ts, lane);
+            else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, ts, lane);
+            TSTAMP(9 + 4 * l);
 #pragma unroll
             for (int g = 0; g < TB; ++g) {
                 if (g < nt) {
@@ -644,14 +596,18 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
                     v.z = (mk[g][2] > 0.f) ? acc[g][2] : 0.f;
                     v.w = (mk[g][3] > 0.f) ? acc[g][3] : 0.f;
                     if (out_lds) *(float4*)(out_lds + fm * ldh2 + f0) = v;
-                    if (outT && f0 < M && fm < nrows) {
-                        float* q = outT + (size_t)f0 * J.ldT + row0 + fm;
-                        q[0] = v.x; q[J.ldT] = v.y; q[2 * J.ldT] = v.z; q[3 * J.ldT] = v.w;
-                    }
+                    const bool ok = outT != nullptr && f0 < M && fm < nrows;
+                    const unsigned o = ((unsigned)f0 * (unsigned)J.ldT + (unsigned)(row0 + fm)) * 4u, st = (unsigned)J.ldT * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rout, ok ? o : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rout, ok ? o + st : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), rout, ok ? o + 2 * st : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), rout, ok ? o + 3 * st : OOB, 0, 0);
                 }
             }
         }
+        TSTAMP(10 + 4 * l);
         SMX_LDS_BARRIER();
+        TSTAMP(4 + l);
     }
 }
 
@@ -669,12 +625,8 @@ struct PackArgs {
     long total;
 };
 
-__host__ __device__ inline long pack_words(int M, int K) {       // 16-byte words of one packed layer
-    return (long)((M + 15) >> 4) * ((((K + 31) >> 5) + 1) & ~1) * 128;
-}
-
-// one thread per 16-byte word of the packed copy: [tile][chunk][half][lane][4] <- W[16 tile + (lane & 15)]
-// [32 chunk + 8 (lane >> 4) + 4 half + 0..3], zero outside the matrix
+// one thread per 16-byte word of the packed copy: [tile][chunk][half][lane][4] <- X[16 tile + (lane & 15)]
+// [32 chunk + 8 (lane >> 4) + 4 half + 0..3], zero outside the matrix; X = W or W^T
 __global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P.total) return;
@@ -683,32 +635,34 @@ __global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
     for (int k = 1; k < MAX_EJOBS; ++k) pi += (k < P.count && i >= P.n[k].base) ? 1 : 0;
     const PackNet N = P.n[pi];
     long w = i - N.base;
-    const long w1 = pack_words(N.H1, N.D), w2 = pack_words(N.H2, N.H1);
-    const float* W; int M, K;
-    if (w < w1) { W = N.W1; M = N.H1; K = N.D; }
-    else if (w < w1 + w2) { W = N.W2; M = N.H2; K = N.H1; w -= w1; }
-    else { W = N.W3; M = N.OUT; K = N.H2; w -= w1 + w2; }
+    int bn = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) bn += (w >= pack_off(N.D, N.H1, N.H2, N.OUT, k)) ? 1 : 0;
+    w -= pack_off(N.D, N.H1, N.H2, N.OUT, bn);
+    const float* W = bn == 0 ? N.W1 : ((bn == 1 || bn == 3) ? N.W2 : N.W3);
+    const bool tr = bn >= 3;
+    const int M = bn == 0 ? N.H1 : (bn == 1 ? N.H2 : (bn == 2 ? N.OUT : (bn == 3 ? N.H1 : N.H2)));
+    const int K = bn == 0 ? N.D : (bn == 1 ? N.H1 : (bn == 2 ? N.H2 : (bn == 3 ? N.H2 : N.OUT)));
     const int C2 = (((K + 31) >> 5) + 1) & ~1;
     const int lane = (int)(w & 63), half = (int)((w >> 6) & 1);
     const long tc = w >> 7;
     const int c = (int)(tc % C2), t = (int)(tc / C2);
     const int m = 16 * t + (lane & 15), k = 32 * c + 8 * (lane >> 4) + 4 * half;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (m < M) {
-        const float* q = W + (size_t)m * K + k;
-        if (k + 0 < K) v.x = q[0];
-        if (k + 1 < K) v.y = q[1];
-        if (k + 2 < K) v.z = q[2];
-        if (k + 3 < K) v.w = q[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (k + r < K) v[r] = tr ? W[(size_t)(k + r) * M + m] : W[(size_t)m * K + k + r];
     }
-    *(float4*)(N.packed + 4 * (i - N.base)) = v;
+    *(float4*)(N.packed + 4 * (i - N.base)) = make_float4(v[0], v[1], v[2], v[3]);
 }
+
 long long* g_tbuf = nullptr;
 
 }  // namespace
 
 extern "C" int64_t smx_epoch_packed_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
-    return 4 * (pack_words(H1, D) + pack_words(H2, H1) + pack_words(OUT, H2));
+    return 4 * pack_off(D, H1, H2, OUT, 5);
 }
 
 extern "C" int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_stream_t stream) {
@@ -772,12 +726,15 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
         J.out = s.out; J.out_ld = s.out_ld ? s.out_ld : n.OUT; J.out_act = s.out_act; J.loss = s.loss;
         J.stop = s.stop_flag;
         J.dz3 = s.dz3; J.dz3T = s.dz3T; J.dz2T = s.dz2T; J.dz1T = s.dz1T;
-        if (!backward) {
+
+        {
             SMX_REQUIRE(s.packed, SMX_E_NULL);
             SMX_REQUIRE(((uintptr_t)s.packed & 15) == 0, SMX_E_ALIGN);
             J.P1 = s.packed;
-            J.P2 = J.P1 + 4 * pack_words(n.H1, n.D);
-            J.P3 = J.P2 + 4 * pack_words(n.H2, n.H1);
+            J.P2 = s.packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 1);
+            J.P3 = s.packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 2);
+            J.P2T = s.packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 3);
+            J.P3T = s.packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 4);
         }
         J.blk_base = base;
         base += smx_epoch_blocks(s.rows) * fsplit;
@@ -808,7 +765,7 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
     // (the K loops run over an even number of 32-wide chunks: rows are zero padded to 64 columns)
     G.ldx = r64(maxD) + 4; G.ldh1 = r64(maxH1) + 4; G.ldh2 = r64(maxH2) + 4;
     if (backward) { G.ldx = 0; G.ldh1 = 0; }     // dz3 tile (at 0, stride LDO) | dz2 tile
-    G.off_h1 = backward ? ER * LDO : ER * G.ldx;
+    G.off_h1 = backward ? ER * LDZ : ER * G.ldx;
     G.off_h2 = G.off_h1 + ER * G.ldh1;
     G.off_out = G.off_h2 + ER * G.ldh2;
     G.off_red = G.off_out + (backward ? 0 : ER * LDO);

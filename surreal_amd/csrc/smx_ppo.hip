@@ -12,6 +12,7 @@
 
 namespace {
 #include "smx_ppo_loss.inc.h"
+#include "smx_epoch_pack.inc.h"
 
 __global__ __launch_bounds__(256) void policy_loss_kernel(
     int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
@@ -242,6 +243,10 @@ struct AdamGroup {
     const float* partials;
     int npart, which, honour_stop, blocks;
     float* grad_norm_out;
+    // optional: the fused epoch kernels' packed copy of the group's MLP, kept current by this step
+    float* packed;
+    long oW1, oW2, oW3;        // offsets of the three weight matrices inside theta
+    int D, H1, H2, OUT;
 };
 
 struct AdamGroups {
@@ -301,9 +306,25 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
         mi = mi + w1 * (g - mi);                               // exp_avg.lerp_(grad, 1 - beta1)
         vi = vi * b2f + w2 * (g * g);                          // mul_(beta2).addcmul_(g, g, 1-beta2)
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        theta[i] = p + (neg_step_size * mi) / denom;           // addcdiv_(exp_avg, denom, -step_size)
+        const float pn = p + (neg_step_size * mi) / denom;     // addcdiv_(exp_avg, denom, -step_size)
+        theta[i] = pn;
         m[i] = mi;
         v[i] = vi;
+        if (G.packed) {            // the same value into the forward / backward kernels' fragment-order copies
+            float* P = G.packed;
+            if (i >= G.oW1 && i < G.oW1 + (long)G.H1 * G.D) {
+                const int mm = (int)((i - G.oW1) / G.D), kk = (int)((i - G.oW1) - (long)mm * G.D);
+                P[pack_pos(G.D, mm, kk)] = pn;
+            } else if (i >= G.oW2 && i < G.oW2 + (long)G.H2 * G.H1) {
+                const int mm = (int)((i - G.oW2) / G.H1), kk = (int)((i - G.oW2) - (long)mm * G.H1);
+                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 1) + pack_pos(G.H1, mm, kk)] = pn;
+                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 3) + pack_pos(G.H2, kk, mm)] = pn;
+            } else if (i >= G.oW3 && i < G.oW3 + (long)G.OUT * G.H2) {
+                const int mm = (int)((i - G.oW3) / G.H2), kk = (int)((i - G.oW3) - (long)mm * G.H2);
+                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 2) + pack_pos(G.H2, mm, kk)] = pn;
+                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 4) + pack_pos(G.OUT, kk, mm)] = pn;
+            }
+        }
     }
 }
 
@@ -544,7 +565,19 @@ extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count,
 
 static int fill_adam_group(AdamGroup& G, float* theta, const float* grads, float* exp_avg,
                            float* exp_avg_sq, int64_t n, const float* sumsq_partials,
-                           int32_t npart, int32_t which, int32_t honour_stop, float* grad_norm_out) {
+                           int32_t npart, int32_t which, int32_t honour_stop, float* grad_norm_out,
+                           const smx_mlp3_t* pack_net = nullptr, float* packed = nullptr) {
+    G.packed = nullptr;
+    G.oW1 = G.oW2 = G.oW3 = 0;
+    G.D = G.H1 = G.H2 = G.OUT = 0;
+    if (packed) {
+        SMX_REQUIRE(pack_net && theta, SMX_E_NULL);
+        const smx_mlp3_t& N = *pack_net;
+        G.packed = packed;
+        G.oW1 = N.W1 - theta; G.oW2 = N.W2 - theta; G.oW3 = N.W3 - theta;
+        G.D = N.D; G.H1 = N.H1; G.H2 = N.H2; G.OUT = N.OUT;
+        SMX_REQUIRE(G.oW1 >= 0 && G.oW3 + (long)N.OUT * N.H2 <= n, SMX_E_SHAPE);   // the MLP lies inside theta
+    }
     SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq && sumsq_partials, SMX_E_NULL);
     SMX_REQUIRE(n > 0 && npart > 0, SMX_E_SHAPE);
     long blocks = (n + 255) / 256;
@@ -584,7 +617,7 @@ extern "C" int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor,
         const int rc = fill_adam_group(P.g[k], src[k]->theta, src[k]->grads, src[k]->exp_avg,
                                        src[k]->exp_avg_sq, src[k]->n, src[k]->sumsq_partials,
                                        src[k]->npart, k, src[k]->honour_stop,
-                                       src[k]->grad_norm_out);
+                                       src[k]->grad_norm_out, src[k]->pack_net, src[k]->packed);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)(P.g[0].blocks + P.g[1].blocks)),

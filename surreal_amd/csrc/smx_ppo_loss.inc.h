@@ -184,8 +184,18 @@ __device__ __forceinline__ void reduce_row_partials(const float* __restrict__ pa
     float t = 0.f;
     for (int b0 = 0; b0 < nblk; b0 += FIN_CH) {
         const int nb = min(FIN_CH, nblk - b0);
-        for (int idx = threadIdx.x; idx < nb * stride; idx += 256)
-            buf[idx] = partials[(size_t)b0 * stride + idx];
+        const int cnt = nb * stride;
+        const float* src = partials + (size_t)b0 * stride;
+        // the chunk's words are requested in batches of eight per thread (a load -> LDS store loop
+        // with a run-time trip count is a chain of dependent round trips)
+        for (int i0 = threadIdx.x; i0 < cnt; i0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + 256 * u, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 256 * u < cnt) buf[i0 + 256 * u] = v[u];
+        }
         SMX_LDS_BARRIER();
         if ((int)threadIdx.x < stride)
             for (int b = 0; b < nb; ++b) t += buf[b * stride + threadIdx.x];

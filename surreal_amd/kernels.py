@@ -322,12 +322,17 @@ class HipKernels(object):
                theta.numel(), L.ptr(sumsq), npart, L.ptr(ctrl), which, int(honour_stop),
                L.ptr(grad_norm_out), self._st())
 
-    def clip_adam_pair(self, actor, critic, ctrl):
-        """actor / critic: (theta, grads, m, v, sumsq, npart, honour_stop, grad_norm_out)"""
+    def clip_adam_pair(self, actor, critic, ctrl, pack=None):
+        """actor / critic: (theta, grads, m, v, sumsq, npart, honour_stop, grad_norm_out);
+        pack: ((actor net, packed), (critic net, packed)) -- the step also refreshes the fused epoch
+        kernels' packed weight copies"""
         gs = []
-        for theta, grads, m, v, sumsq, npart, honour_stop, gno in (actor, critic):
-            gs.append(L.AdamGroup(L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(),
-                                  L.ptr(sumsq), npart, int(honour_stop), L.ptr(gno)))
+        for k, (theta, grads, m, v, sumsq, npart, honour_stop, gno) in enumerate((actor, critic)):
+            g = L.AdamGroup(L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(),
+                            L.ptr(sumsq), npart, int(honour_stop), L.ptr(gno))
+            if pack is not None:
+                g.pack_net, g.packed = ctypes.pointer(pack[k][0].desc), L.ptr(pack[k][1])
+            gs.append(g)
         L.call('smx_clip_adam_step_pair_f32', ctypes.byref(gs[0]), ctypes.byref(gs[1]), L.ptr(ctrl),
                self._st())
 

@@ -701,7 +701,7 @@ class PPOLearner(Learner):
                                   ws.sumsq_a, np_a, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1]),
                                  (m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                                   ws.sumsq_c, np_c, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1]),
-                                 ws.ctrl_f)
+                                 ws.ctrl_f, pack=((m.actor, ws.pk_actor), (m.critic, ws.pk_critic)))
             elif pol_u:
                 K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                             ws.sumsq_a, np_a, ws.ctrl_f, 0, True,
@@ -710,8 +710,8 @@ class PPOLearner(Learner):
                 K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                             ws.sumsq_c, np_c, ws.ctrl_f, 1, False,
                             ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
-            if pol_u or val:
-                K.epoch_pack(([(m.actor, ws.pk_actor)] if pol_u else []) + ([(m.critic, ws.pk_critic)] if val else []))
+            if pol_u != val:         # (an unpaired step -- epoch_policy != epoch_baseline -- repacks separately)
+                K.epoch_pack([(m.actor, ws.pk_actor)] if pol_u else [(m.critic, ws.pk_critic)])
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
     def _enqueue_tail_exchange(self, ws, obs0, actions0, behave0):

@@ -156,18 +156,22 @@ class TorchCpuKernels(object):
             flat = torch.cat([net.views[k].reshape(-1) for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')])
             packed[:flat.numel()].copy_(flat)
 
+    @staticmethod
+    def _packed_views(pk, net):
+        W, o = {}, 0
+        for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'):
+            n_ = net.views[k].numel()
+            W[k] = pk[o:o + n_].view(net.views[k].shape)
+            o += n_
+        return W
+
     def epoch_forward(self, jobs, loss=None, ctrl=None, n_total=0):
         for j in jobs:
             if j.get('stop') is not None and int(j['stop'][0]) != 0:
                 continue
             net, x = j['net'], j['x']
             v = net.views
-            pk, o = j['packed'], 0          # weights from the packed copy, biases from the net (as the kernel)
-            W = {}
-            for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'):
-                n_ = v[k].numel()
-                W[k] = pk[o:o + n_].view(v[k].shape)
-                o += n_
+            W = self._packed_views(j['packed'], net)   # weights from the packed copy, biases from the net
             h1 = torch.relu(torch.nn.functional.linear(x, W['W1'], v['b1']))
             h2 = torch.relu(torch.nn.functional.linear(h1, W['W2'], v['b2']))
             out = self._act(torch.nn.functional.linear(h2, W['W3'], v['b3']), j.get('act', 0))
@@ -214,8 +218,9 @@ class TorchCpuKernels(object):
             else:
                 dz3 = j['dz3'].view(rows, 1)
             h2, h1 = j['h2T'].t(), j['h1T'].t()
-            dz2 = (dz3 @ v['W3']) * (h2 > 0)
-            dz1 = (dz2 @ v['W2']) * (h1 > 0)
+            W = self._packed_views(j['packed'], net)
+            dz2 = (dz3 @ W['W3']) * (h2 > 0)
+            dz1 = (dz2 @ W['W2']) * (h1 > 0)
             j['dz2T'].copy_(dz2.t())
             j['dz1T'].copy_(dz1.t())
 
@@ -498,9 +503,11 @@ class TorchCpuKernels(object):
         denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
         theta.addcdiv_(m, denom, value=-(lr / bc1))
 
-    def clip_adam_pair(self, actor, critic, ctrl):
+    def clip_adam_pair(self, actor, critic, ctrl, pack=None):
         for which, (theta, grads, m, v, sumsq, npart, honour_stop, gno) in enumerate((actor, critic)):
             self.clip_adam(theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, gno)
+        if pack is not None:
+            self.epoch_pack(list(pack))
 
     def sumsq_blocks(self, n):
         return max(1, min(256, (n + 4095) // 4096))
