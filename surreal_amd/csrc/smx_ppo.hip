@@ -204,31 +204,62 @@ __global__ __launch_bounds__(256) void epoch_combine_kernel(smx_ppo_combine_t a,
     }
 }
 
+// mergeable moments (count, mean, M2) of two disjoint sets (Chan et al.)
+struct Mom { double n, mean, m2; };
+__device__ __forceinline__ Mom mom_merge(const Mom& a, const Mom& b) {
+    if (b.n <= 0.0) return a;
+    if (a.n <= 0.0) return b;
+    Mom r;
+    r.n = a.n + b.n;
+    const double d = b.mean - a.mean;
+    r.m2 = a.m2 + b.m2 + d * d * a.n * b.n / r.n;
+    r.mean = a.mean + d * b.n / r.n;
+    return r;
+}
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// one wave per epoch: lane l folds the partial rows l, l + 64, ... in order, then the 64 lanes are
+// merged pairwise in a fixed tree (lane l with l + 32, 16, ...: the same order on every run)
 __global__ __launch_bounds__(64) void value_finalize_kernel(const float* __restrict__ partials,
                                                             int count, int nblk,
                                                             float* __restrict__ stats,
                                                             int stats_stride) {
-    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int e = blockIdx.x, lane = threadIdx.x;
     if (e >= count) return;
     const float* P = partials + (size_t)e * nblk * 8;
-    double n = 0.0, md = 0.0, qd = 0.0, mg = 0.0, qg = 0.0, sq = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const double nb = P[8 * b];
-        if (nb <= 0.0) continue;
-        const double nt = n + nb;
-        double dl = (double)P[8 * b + 1] - md;
-        qd += (double)P[8 * b + 2] + dl * dl * n * nb / nt;
-        md += dl * nb / nt;
-        dl = (double)P[8 * b + 3] - mg;
-        qg += (double)P[8 * b + 4] + dl * dl * n * nb / nt;
-        mg += dl * nb / nt;
-        sq += (double)P[8 * b + 5];
-        n = nt;
+    Mom d = {0.0, 0.0, 0.0}, g = {0.0, 0.0, 0.0};
+    double sq = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        const float4 lo = *(const float4*)(P + 8 * b);
+        const float4 hi = *(const float4*)(P + 8 * b + 4);
+        const Mom db = {(double)lo.x, (double)lo.y, (double)lo.z}, gb = {(double)lo.x, (double)lo.w, (double)hi.x};
+        d = mom_merge(d, db);
+        g = mom_merge(g, gb);
+        if (lo.x > 0.f) sq += (double)hi.y;
     }
-    stats[(size_t)e * stats_stride + SMX_VS_LOSS] = (float)(sq / n);          // ppo.py:326
-    // 1 - var(returns - values) / var(returns), unbiased variances (ppo.py:325)
-    stats[(size_t)e * stats_stride + SMX_VS_EXPVAR] =
-        1.0f - (float)(qd / (n - 1.0)) / (float)(qg / (n - 1.0));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Mom od, og;
+        od.n = shfl_d(d.n, lane + off); od.mean = shfl_d(d.mean, lane + off); od.m2 = shfl_d(d.m2, lane + off);
+        og.n = od.n; og.mean = shfl_d(g.mean, lane + off); og.m2 = shfl_d(g.m2, lane + off);
+        const double osq = shfl_d(sq, lane + off);
+        if (lane < off) {
+            d = mom_merge(d, od);
+            g = mom_merge(g, og);
+            sq += osq;
+        }
+    }
+    if (lane == 0) {
+        const double n = d.n;
+        stats[(size_t)e * stats_stride + SMX_VS_LOSS] = (float)(sq / n);          // ppo.py:326
+        // 1 - var(returns - values) / var(returns), unbiased variances (ppo.py:325)
+        stats[(size_t)e * stats_stride + SMX_VS_EXPVAR] =
+            1.0f - (float)(d.m2 / (n - 1.0)) / (float)(g.m2 / (n - 1.0));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -271,6 +302,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
     const int blk = blockIdx.x - (gi ? P.g[0].blocks : 0);
     if (G.honour_stop && C.stop_flag) return;
     __shared__ float red[16];
+    float* __restrict__ theta = G.theta;
+    const float* __restrict__ grads = G.grads;
+    float* __restrict__ m = G.m;
+    float* __restrict__ v = G.v;
+    // this thread's first two elements are requested in front of the norm reduction (independent of
+    // it): one memory round trip for the step instead of two back to back
+    const long stride = (long)G.blocks * 256;
+    const long i0 = (long)blk * 256 + threadIdx.x, i1 = i0 + stride;
+    const long c0 = i0 < G.n ? i0 : G.n - 1, c1 = i1 < G.n ? i1 : G.n - 1;
+    const float g0 = grads[c0], p0 = theta[c0], m0 = m[c0], v0 = v[c0];
+    const float g1 = grads[c1], p1 = theta[c1], m1 = m[c1], v1 = v[c1];
     float t = 0.f;
     for (int k = threadIdx.x; k < G.npart; k += 256) t += G.partials[k];
     const float total = smx_block_sum(t, red);
@@ -294,15 +336,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
     const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2);
     const float eps = 1e-8f;
-    float* __restrict__ theta = G.theta;
-    const float* __restrict__ grads = G.grads;
-    float* __restrict__ m = G.m;
-    float* __restrict__ v = G.v;
-    for (long i = (long)blk * 256 + threadIdx.x; i < G.n; i += (long)G.blocks * 256) {
-        float g = grads[i] * coef;
-        const float p = theta[i];
+    auto step_one = [&](long i, float g, float p, float mi, float vi) {
+        g = g * coef;
         if (wd != 0.f) g = g + wd * p;                         // grad.add(param, alpha=wd)
-        float mi = m[i], vi = v[i];
         mi = mi + w1 * (g - mi);                               // exp_avg.lerp_(grad, 1 - beta1)
         vi = vi * b2f + w2 * (g * g);                          // mul_(beta2).addcmul_(g, g, 1-beta2)
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -311,21 +347,24 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
         m[i] = mi;
         v[i] = vi;
         if (G.packed) {            // the same value into the forward / backward kernels' fragment-order copies
-            float* P = G.packed;
+            float* Pk = G.packed;
             if (i >= G.oW1 && i < G.oW1 + (long)G.H1 * G.D) {
                 const int mm = (int)((i - G.oW1) / G.D), kk = (int)((i - G.oW1) - (long)mm * G.D);
-                P[pack_pos(G.D, mm, kk)] = pn;
+                Pk[pack_pos(G.D, mm, kk)] = pn;
             } else if (i >= G.oW2 && i < G.oW2 + (long)G.H2 * G.H1) {
                 const int mm = (int)((i - G.oW2) / G.H1), kk = (int)((i - G.oW2) - (long)mm * G.H1);
-                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 1) + pack_pos(G.H1, mm, kk)] = pn;
-                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 3) + pack_pos(G.H2, kk, mm)] = pn;
+                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 1) + pack_pos(G.H1, mm, kk)] = pn;
+                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 3) + pack_pos(G.H2, kk, mm)] = pn;
             } else if (i >= G.oW3 && i < G.oW3 + (long)G.OUT * G.H2) {
                 const int mm = (int)((i - G.oW3) / G.H2), kk = (int)((i - G.oW3) - (long)mm * G.H2);
-                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 2) + pack_pos(G.H2, mm, kk)] = pn;
-                P[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 4) + pack_pos(G.OUT, kk, mm)] = pn;
+                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 2) + pack_pos(G.H2, mm, kk)] = pn;
+                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 4) + pack_pos(G.OUT, kk, mm)] = pn;
             }
         }
-    }
+    };
+    if (i0 < G.n) step_one(i0, g0, p0, m0, v0);
+    if (i1 < G.n) step_one(i1, g1, p1, m1, v1);
+    for (long i = i1 + stride; i < G.n; i += stride) step_one(i, grads[i], theta[i], m[i], v[i]);
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n,
@@ -557,7 +596,7 @@ extern "C" int smx_value_loss_finalize_f32(const float* partials, int32_t count,
                                            smx_stream_t stream) {
     SMX_REQUIRE(partials && stats, SMX_E_NULL);
     SMX_REQUIRE(count > 0 && nblk > 0 && stats_stride >= 2, SMX_E_SHAPE);
-    hipLaunchKernelGGL(value_finalize_kernel, dim3((count + 63) / 64), dim3(64), 0, smx_s(stream),
+    hipLaunchKernelGGL(value_finalize_kernel, dim3(count), dim3(64), 0, smx_s(stream),
                        partials, count, nblk, stats, stats_stride);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
@@ -580,7 +619,7 @@ static int fill_adam_group(AdamGroup& G, float* theta, const float* grads, float
     }
     SMX_REQUIRE(theta && grads && exp_avg && exp_avg_sq && sumsq_partials, SMX_E_NULL);
     SMX_REQUIRE(n > 0 && npart > 0, SMX_E_SHAPE);
-    long blocks = (n + 255) / 256;
+    long blocks = (n + 511) / 512;          // two elements per thread
     if (blocks > 1024) blocks = 1024;
     G.theta = theta; G.grads = grads; G.m = exp_avg; G.v = exp_avg_sq; G.n = (long)n;
     G.partials = sumsq_partials; G.npart = npart; G.which = which; G.honour_stop = honour_stop;
