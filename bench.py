@@ -164,6 +164,7 @@ def main():
     ap.add_argument('--mode', default='adapt', choices=['adapt', 'clip'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--split-chains', action='store_true', help='policy and value epochs on two streams')
     ap.add_argument('--schedule', default='lockstep', choices=['lockstep', 'two_stream'],
                     help='epoch launch schedule (session_config.learner.epoch_schedule)')
     args = ap.parse_args()

@@ -472,6 +472,9 @@ typedef struct smx_adam_group {
     const smx_mlp3_t* pack_net;
     float* packed;
 } smx_adam_group_t;
+/* one group (which: 0 = actor's scalars of the control block, 1 = critic's), with the optional packed copy */
+int smx_clip_adam_step_group_f32(const smx_adam_group_t* group, int32_t which, const smx_ppo_ctrl_t* ctrl,
+                                 smx_stream_t stream);
 int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor, const smx_adam_group_t* critic,
                                 const smx_ppo_ctrl_t* ctrl, smx_stream_t stream);
 /* partials[b] = sum of squares of block b's slice of x; returns via *nblk_out the count

@@ -1,5 +1,6 @@
-"""micro-benchmark of the fused epoch kernels at the benchmark shape (GPU box).
-SMX_EPOCH_DBG bits (timing experiments): 1 no weight traffic, 2 no MFMAs, 4 no hT stores, 8 no loss"""
+"""micro-benchmark of the fused epoch kernels at the benchmark shape (GPU box): host-side launch times and,
+with a timing build (SMX_EXTRA_FLAGS=-DSMX_EPOCH_TIMING python -m surreal_amd.build --force), the per-phase
+cycle counts of every workgroup (thread 0) of the forward and the backward kernel."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -24,15 +25,9 @@ rows, D, H1, H2, A = 1024, 376, 300, 200, 17
 T = TE.build(rows, D, H1, H2, A, seed=1, mode=L.SMX_PPO_ADAPT, device='cuda')
 t = T['d']
 t['ctrl'][L.C_KL_TARGET] = 1e9
-only = os.environ.get('SMX_EPOCH_DBG_ONLY')
-for dbg in ([int(only)] if only is not None else [0] + [int(x) for x in sys.argv[1:]]):
-    os.environ['SMX_EPOCH_DBG'] = str(dbg)
-    f = timeit(lambda: TE.run(K, t, L.SMX_PPO_ADAPT, phase='fwd'))
-    def bwd_only():
-        rows_ = t['x'].shape[0]
-        TE.run(K, t, L.SMX_PPO_ADAPT, phase='bwd')
-    b = timeit(bwd_only)
-    print('dbg=%2d  forward %.2f us   backward+wgrad %.2f us' % (dbg, f, b))
+f = timeit(lambda: TE.run(K, t, L.SMX_PPO_ADAPT, phase='fwd'))
+b = timeit(lambda: TE.run(K, t, L.SMX_PPO_ADAPT, phase='bwd'))
+print('eager launches (host-bound): pack + forward %.2f us   backward + wgrad %.2f us' % (f, b))
 
 # ---- per-phase timestamps of the forward kernel (thread 0 of every workgroup) ----
 import ctypes
@@ -41,9 +36,7 @@ lib.smx_epoch_debug_tbuf.argtypes = [ctypes.c_void_p]
 lib.smx_epoch_debug_tbuf.restype = None
 tb = torch.zeros(512 * 32, dtype=torch.int64, device='cuda')
 lib.smx_epoch_debug_tbuf(ctypes.c_void_p(tb.data_ptr()))
-for DBG in ('0',):
-  os.environ['SMX_EPOCH_DBG'] = DBG
-  print('--- dbg', DBG)
+for _once in (0,):
   for _ in range(3):
       TE.run(K, t, L.SMX_PPO_ADAPT, phase='fwd')
   torch.cuda.synchronize()

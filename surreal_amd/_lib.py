@@ -159,6 +159,7 @@ _SIGS = {
     'smx_value_loss_finalize_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P]),
     'smx_clip_adam_step_f32': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, _P, c_int32,
                                          c_int32, _P, _P]),
+    'smx_clip_adam_step_group_f32': (c_int32, [POINTER(AdamGroup), c_int32, _P, _P]),
     'smx_clip_adam_step_pair_f32': (c_int32, [POINTER(AdamGroup), POINTER(AdamGroup), _P, _P]),
     'smx_sumsq_blocks': (c_int32, [c_int64]),
     'smx_sumsq_partials_f32': (c_int32, [_P, c_int64, _P, _P]),

@@ -22,6 +22,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
          '-Wno-unused-result']
 
 
+# e.g. SMX_EXTRA_FLAGS=-DSMX_EPOCH_TIMING python -m surreal_amd.build --force  (scripts/bench_epoch.py)
+FLAGS += [f for f in os.environ.get('SMX_EXTRA_FLAGS', '').split() if f]
+
+
 def hipcc():
     exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(exe):

@@ -10,9 +10,8 @@
 //   epoch_fwd_kernel   x tile -> LDS; layer 1 -> layer 2 -> layer 3 on v_mfma_f32_16x16x4_f32 in
 //                      TRANSPOSED form (h^T = W . x^T: the MFMA M axis is the output feature, the
 //                      N axis the data row), the four waves split the feature tiles, weights go
-//                      L2 -> registers in fragment order straight from their row-major home (no
-//                      packing: a lane reads 32 contiguous bytes of its weight row per 32-wide K
-//                      chunk, a full 128-byte line per row across the wave), activations go
+//                      L2 -> registers from a copy PACKED in fragment order (one contiguous KB per
+//                      load instruction; the optimiser step keeps the copy current), activations go
 //                      wave -> LDS -> all waves between layers and to HBM once, transposed
 //                      ([features, rows]: what the weight-gradient GEMMs read K-contiguously);
 //                      then the loss of the job on the rows it holds: DiagGauss likelihoods / KL /
@@ -24,11 +23,16 @@
 //                      16 rows per workgroup, two workgroups per row block splitting the dz1
 //                      feature tiles (the dz2 product is cheap and recomputed by both).
 //
+// What shaped the code (all measured, scripts/bench_epoch.py + scripts/micro/): guards are out-of-range
+// buffer offsets, never branches (a load under a lane mask is waited for at the end of the masked
+// region -- twenty bias words one after the other cost 3000 cycles per layer); nothing conditional
+// sits between MFMAs on live accumulators (hipcc then copies them out of and into the MFMA registers
+// every chunk); a phase's inputs are requested in one batch at kernel start.
+//
 // The weight gradients (sums over ALL rows) stay a GEMM launch (smx_gemm.hip), clip-norm + Adam
 // one more: 4 dependent launches per epoch instead of 9.
 #include "smx_common.h"
 #include <string.h>
-#include <stdlib.h>
 
 // workgroup barrier for data exchanged through LDS: does NOT wait for the wave's global stores
 #define SMX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -51,7 +55,13 @@ constexpr int LDO = 36;           // row stride of the output tile in LDS (<= 32
 static_assert(ER == LOSS_ROWS_PER_BLOCK, "a row block is a loss block");
 static_assert(NTH == 256, "the shared loss code strides by 256 threads");
 
+// Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer) exist
+// only in a build with -DSMX_EPOCH_TIMING (scripts/bench_epoch.py); the product build has none.
+#ifdef SMX_EPOCH_TIMING
 #define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -122,8 +132,7 @@ struct EArgs {
     // LDS carve-up (floats), the same for every workgroup of the launch
     int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_red, off_loss;
     int fsplit;
-    long long* tbuf;   // timing experiments only: per-workgroup phase timestamps
-    int dbg;     // timing experiments only (SMX_EPOCH_DBG): 1 = no weight traffic, 2 = no MFMAs
+    long long* tbuf;   // SMX_EPOCH_TIMING builds: per-workgroup phase timestamps (else null)
 };
 
 __device__ __forceinline__ EJob select_job(const EArgs& G, int bid) {
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
         const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
         const rsrc_t rbias = make_rsrc(bias, (unsigned)H * 4u);
         float* stp = l == 2 ? J.out : hT;
-        const bool st_ok = stp != nullptr && !(G.dbg & 4);
+        const bool st_ok = stp != nullptr;
         const rsrc_t rst = make_rsrc(stp ? stp : Wp, l == 2 ? (unsigned)J.rows * (unsigned)J.out_ld * 4u
                                                              : (unsigned)H * (unsigned)J.ldT * 4u);
 #pragma unroll 1
@@ -421,7 +430,6 @@ __global__ __launch_bounds__(NTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t*
     }
 
     // ---- the job's loss on the rows it holds -------------------------------------------------
-    if (G.dbg & 8) return;
     if (J.loss == SMX_EPOCH_LOSS_POLICY) {
         const PolArgs& p = G.pl;
         // inputs staged in LDS: row stride LW, [actions | behave | ref | adv]
@@ -687,6 +695,7 @@ extern "C" int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_
     return SMX_OK;
 }
 
+// SMX_EPOCH_TIMING builds only (not declared in include/surreal_amd.h): where the timestamps go
 extern "C" void smx_epoch_debug_tbuf(void* p) { g_tbuf = (long long*)p; }
 
 extern "C" int32_t smx_epoch_blocks(int64_t rows) { return (int32_t)((rows + ER - 1) / ER); }
@@ -704,7 +713,7 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
     G.n = njobs;
     G.n_total = n_total;
     G.fsplit = fsplit;
-    { const char* e = getenv("SMX_EPOCH_DBG"); G.dbg = e ? atoi(e) : 0; G.tbuf = g_tbuf; }
+    G.tbuf = g_tbuf;
     int base = 0, maxD = 0, maxH1 = 0, maxH2 = 0, A = 0;
     for (int k = 0; k < njobs; ++k) {
         const smx_epoch_job_t& s = jobs[k];

@@ -218,11 +218,103 @@ __device__ __forceinline__ void mainloop(const GemmProb& P, const KRange& R, int
     }
 }
 
+// Coalesced operand path (both operands K-contiguous, 16-byte aligned).  In fragment order a load
+// instruction touches 32 different rows -- 32 cache lines, 32 bytes of each -- and the CU's address
+// unit, not the MFMA pipe, bounds the loop (scripts/micro/fwd_loop.hip: 2500 vs 1280 cycles per chunk
+// on the same pattern).  Here a wave fetches its 32 x 32 block of each operand as whole 128-byte row
+// segments (lane -> row (l >> 3) + 8 j, bytes 16 (l & 7)), passes it through a wave-private LDS tile and
+// reads the fragments back with ds_read_b128 (rows of 36 floats: conflict-free).  LDS operations of a
+// wave complete in order, so the tile needs no barrier and no double buffering: the fragments of
+// super-block s are in registers before the data of s + 1 overwrites the tile.
+struct CoBlk {
+    float4 a[4], b[4];
+};
+
+struct CoOperands {
+    rsrc_t ra, rb;
+    unsigned arow[4], brow[4];      // byte offset of (row, k = 0) per instruction, or OOB
+    int K;
+};
+
+__device__ __forceinline__ void load_co(CoBlk& g, const CoOperands& O, int kb, int kseg) {
+    const int k = kb + kseg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(O.ra, (k < O.K) ? O.arow[j] + (unsigned)k * 4u : OOB, 0, 0);
+        const u32x4 wb = __builtin_amdgcn_raw_buffer_load_b128(O.rb, (k < O.K) ? O.brow[j] + (unsigned)k * 4u : OOB, 0, 0);
+        g.a[j] = make_float4(__uint_as_float(wa.x), __uint_as_float(wa.y), __uint_as_float(wa.z), __uint_as_float(wa.w));
+        g.b[j] = make_float4(__uint_as_float(wb.x), __uint_as_float(wb.y), __uint_as_float(wb.z), __uint_as_float(wb.w));
+    }
+}
+
+__device__ __forceinline__ void stage_co(const CoBlk& g, float* sA, float* sB, int wofs) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *(float4*)(sA + wofs + j * 8 * 36) = g.a[j];
+        *(float4*)(sB + wofs + j * 8 * 36) = g.b[j];
+    }
+}
+
+__device__ __forceinline__ void frags_co(Frag8& f, const float* sA, const float* sB, int rofs) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f.a[q] = *(const float4*)(sA + rofs + 8 * q);
+        f.b[q] = *(const float4*)(sB + rofs + 8 * q);
+    }
+}
+
+__device__ __forceinline__ void mainloop_co(const GemmProb& P, const KRange& R, int m0, int n0, int lane,
+                                            int wv, float* stage, f32x16& acc, float& asum) {
+    const int nsb = (R.K + 31) >> 5;
+    CoOperands O;
+    O.ra = make_rsrc(R.A, R.a_bytes);
+    O.rb = make_rsrc(R.B, R.b_bytes);
+    O.K = R.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        O.arow[j] = row_base<0>(P.lda, m0 + (lane >> 3) + 8 * j, P.M);
+        O.brow[j] = row_base<0>(P.ldb, n0 + (lane >> 3) + 8 * j, P.N);
+    }
+    const int kseg = 4 * (lane & 7);
+    float* sA = stage + wv * 2 * 32 * 36;
+    float* sB = sA + 32 * 36;
+    const int wofs = (lane >> 3) * 36 + kseg;                    // where this lane's words of a block go
+    const int rofs = (lane & 31) * 36 + 4 * (lane >> 5);         // fragment (i = lane & 31, kh = lane >> 5)
+    CoBlk ga, gb;
+    Frag8 f0, f1;
+    load_co(ga, O, (wv + 0) * 32, kseg);
+    __builtin_amdgcn_sched_barrier(0);
+    load_co(gb, O, (wv + 4) * 32, kseg);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_co(ga, sA, sB, wofs);
+    frags_co(f0, sA, sB, rofs);
+    __builtin_amdgcn_sched_barrier(0);
+    load_co(ga, O, (wv + 8) * 32, kseg);
+    // two super-blocks per trip; blocks past K are zeros (their MFMAs run: at most one idle block)
+    for (int sb = wv; sb < nsb; sb += 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_co(gb, sA, sB, wofs);               // data of sb + 4 (in flight since the previous trip)
+        frags_co(f1, sA, sB, rofs);
+        __builtin_amdgcn_sched_barrier(0);
+        load_co(gb, O, (sb + 12) * 32, kseg);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_sb(acc, asum, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_co(ga, sA, sB, wofs);               // data of sb + 8
+        frags_co(f0, sA, sB, rofs);
+        __builtin_amdgcn_sched_barrier(0);
+        load_co(ga, O, (sb + 16) * 32, kseg);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_sb(acc, asum, f1);
+    }
+}
+
 // ALL_VEC: every problem of the batch is mode (0, 0) -- the host picks this instantiation, which
 // fits 3 workgroups per CU (<= 168 VGPRs); the general one carries the scalar-load variants.
 template <bool ALL_VEC>
-__global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch G) {
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmBatch G) {
     __shared__ float red[4][32 * 33];
+    __shared__ float stage[ALL_VEC ? 4 * 2 * 32 * 36 : 4];      // wave-private operand tiles (coalesced path)
     __shared__ float dbr[8][32];
     __shared__ float sred[16];
 
@@ -288,7 +380,7 @@ __global__ __launch_bounds__(256, ALL_VEC ? 3 : 2) void gemm32_kernel(GemmBatch 
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float asum = 0.f;
 
-    if (ALL_VEC) mainloop<0, 0>(P, R, m0, n0, i, kh, wv, acc, asum);
+    if (ALL_VEC) mainloop_co(P, R, m0, n0, lane, wv, stage, acc, asum);
     else switch (P.a_mode * 3 + P.b_mode) {   // workgroup-uniform
         case 0: mainloop<0, 0>(P, R, m0, n0, i, kh, wv, acc, asum); break;
         case 1: mainloop<0, 1>(P, R, m0, n0, i, kh, wv, acc, asum); break;

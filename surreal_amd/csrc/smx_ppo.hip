@@ -645,6 +645,22 @@ extern "C" int smx_clip_adam_step_f32(float* theta, const float* grads, float* e
     return SMX_OK;
 }
 
+extern "C" int smx_clip_adam_step_group_f32(const smx_adam_group_t* group, int32_t which,
+                                            const smx_ppo_ctrl_t* ctrl, smx_stream_t stream) {
+    SMX_REQUIRE(group && ctrl, SMX_E_NULL);
+    SMX_REQUIRE(which == 0 || which == 1, SMX_E_SHAPE);
+    AdamGroups P;
+    P.n = 1;
+    const int rc = fill_adam_group(P.g[0], group->theta, group->grads, group->exp_avg, group->exp_avg_sq,
+                                   group->n, group->sumsq_partials, group->npart, which, group->honour_stop,
+                                   group->grad_norm_out, group->pack_net, group->packed);
+    if (rc) return rc;
+    P.g[1] = P.g[0];
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)P.g[0].blocks), dim3(256), 0, smx_s(stream), P, ctrl);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
 extern "C" int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor,
                                            const smx_adam_group_t* critic,
                                            const smx_ppo_ctrl_t* ctrl, smx_stream_t stream) {

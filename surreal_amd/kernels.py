@@ -317,7 +317,13 @@ class HipKernels(object):
                self._st())
 
     # ---- optimiser ----------------------------------------------------------------------
-    def clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out):
+    def clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out, pack=None):
+        if pack is not None:
+            g = L.AdamGroup(L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(), L.ptr(sumsq), npart,
+                            int(honour_stop), L.ptr(grad_norm_out))
+            g.pack_net, g.packed = ctypes.pointer(pack[0].desc), L.ptr(pack[1])
+            L.call('smx_clip_adam_step_group_f32', ctypes.byref(g), which, L.ptr(ctrl), self._st())
+            return
         L.call('smx_clip_adam_step_f32', L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v),
                theta.numel(), L.ptr(sumsq), npart, L.ptr(ctrl), which, int(honour_stop),
                L.ptr(grad_norm_out), self._st())

@@ -191,6 +191,7 @@ class PPOLearner(Learner):
         # row-block kernels (csrc/smx_epoch.hip) instead of nine layer launches
         self.epoch_schedule = lcfg.get('epoch_schedule', 'lockstep')
         self.fused_epochs = bool(lcfg.get('fused_epochs', True))
+        self.split_chains = bool(lcfg.get('split_chains', False))
         self._ws = None
         self._graphs = {}
         self._ctrl_host = None
@@ -680,14 +681,45 @@ class PPOLearner(Learner):
         cj = dict(net=m.critic, packed=ws.pk_critic, x=ws.xn, act=L.SMX_ACT_NONE, loss='value', h1T=ws.h1cT, h2T=ws.h2cT,
                   dz3=ws.dz3c, dz3T=ws.dz3c, dz2T=ws.dz2cT, dz1T=ws.dz1cT, xT=ws.xnT, grads=ws.grads_c,
                   sumsq=ws.sumsq_c)         # OUT = 1: dz3^T is dz3 itself
-        for e in range(max(Ep + 1, Ev)):
-            pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
-            loss = dict(mode=mode, rows=ws.rows, log_var=m.log_var.view(-1), actions=actions0, behave=behave0,
+        def loss_args(e):
+            return dict(mode=mode, rows=ws.rows, log_var=m.log_var.view(-1), actions=actions0, behave=behave0,
                         ref=ws.ref_pol, adv=ws.adv, g_surr=ws.g_surr, g_kl=ws.g_kl, partials=ws.ppart,
-                        check_stop=e > 0, will_update=pol_u,
+                        check_stop=e > 0, will_update=e < Ep,
                         dlogvar=ws.grads_a[m.actor.numel:m.actor.numel + A],
                         dlogvar_sumsq=ws.sumsq_a[ws.np_a:ws.np_a + 1], stats=ws.pstats[min(e, Ep)],
                         returns=ws.ret, v_dz3=ws.dz3c, v_partials=ws.vpart[min(e, Ev - 1)], v_will_update=True)
+
+        if self.split_chains and self.device != 'cpu':
+            # The policy and the value epochs touch disjoint parameters (ppo.py:541-562) and each of
+            # their launches fills at most half of the chip: the two chains run on two streams, so a
+            # chain's launch gaps and latency-bound phases overlap with the other chain's kernels
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for e in range(Ev):
+                    loss = loss_args(e)
+                    K.epoch_forward([cj], loss, ws.ctrl_f, n_total)
+                    K.epoch_backward([cj], loss, ws.ctrl_f, n_total)
+                    K.mlp3_wgrad_multi([cj])
+                    K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                                ws.sumsq_c, ws.np_c, ws.ctrl_f, 1, False,
+                                ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1], pack=(m.critic, ws.pk_critic))
+            for e in range(Ep + 1):
+                loss = loss_args(e)
+                K.epoch_forward([aj], loss, ws.ctrl_f, n_total)
+                K.epoch_backward([aj], loss, ws.ctrl_f, n_total)
+                if e < Ep:
+                    K.mlp3_wgrad_multi([aj])
+                    K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                                ws.sumsq_a, ws.np_a + 1, ws.ctrl_f, 0, True,
+                                ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1], pack=(m.actor, ws.pk_actor))
+            main.wait_stream(side)
+            K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+            return
+        for e in range(max(Ep + 1, Ev)):
+            pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
+            loss = loss_args(e)
             K.epoch_forward(([aj] if pol_f else []) + ([cj] if val else []), loss, ws.ctrl_f, n_total)
             if pol_f and not pol_u:
                 K.epoch_backward([aj], loss, ws.ctrl_f, n_total)       # statistics + early exit only

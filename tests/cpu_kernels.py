@@ -479,7 +479,12 @@ class TorchCpuKernels(object):
             stats[e, L.VS_EXPVAR] = 1.0 - (qd / (n - 1.0)) / (qg / (n - 1.0)) if n > 1 else float('nan')
 
     # ---- optimiser ----------------------------------------------------------------------
-    def clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out):
+    def clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out, pack=None):
+        self._clip_adam(theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out)
+        if pack is not None:
+            self.epoch_pack([pack])
+
+    def _clip_adam(self, theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, grad_norm_out):
         ci = ctrl.view(torch.int32)
         if honour_stop and int(ci[L.C_STOP]) != 0:
             return
