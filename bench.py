@@ -16,9 +16,15 @@ to the CPU baseline.  Weak scaling: each rank owns its 
 sub-trajectories (actors shard across GPUs); gradients / loss sums / moments are all-reduced.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description), with
-`roofline` for the dominant kernel (the fused FP32-MFMA critic pass) and `cpu_baseline`
-(oracle/ppo_oracle.py -- the CPU restatement of the reference learner, pinned bit-for-bit
-against the reference's own code -- timed on this host's cores).
+`roofline` for the dominant kernel (the fused FP32-MFMA critic pass), `step_roofline` for the whole
+learn() (71 GFLOP and 200.5 MB algorithmic per learn), `cpu_baseline`
+(oracle/ppo_oracle.py -- the CPU restatement of the reference learner, pinned bit-for-bit against
+the reference's own code -- timed on this host over a sweep of thread counts: the best and the
+single-thread figure), at N > 1 a `strong` entry (the SAME global batch of 1024 sub-trajectories
+split over the ranks) next to the weak-scaling headline, and at N = 1 `secondary` entries for the
+other BASELINE configurations (PPO 64 x 128 HalfCheetah shapes with the MLP and with the reference's
+default LSTM policy, DDPG batch 512 off a 1e6-row uniform replay, PPO on 256 actors of 3x84x84 camera
+frames).
 """
 import argparse
 import copy
@@ -41,6 +47,9 @@ HIDDEN = (300, 200)
 METRIC = 'env-steps/sec (learner ingest) PPO 1024 actors×128 steps, 1/2/4/8 MI355X'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense FP32 MFMA)
 PEAK_HBM_GBPS = 8000.0
+# algorithmic work of one learn() at this configuration
+STEP_FLOPS = 2.0 * B * (N + 1) * (D * 300 + 300 * 200 + 200) + 10 * (3 * 2.0 * B * (D * 300 + 60000 + 200 * A) + 2.0 * B * (D * 300 + 60000 + 200 * A)) + 10 * 3 * 2.0 * B * (D * 300 + 60000 + 200) + 2.0 * B * (D * 300 + 60000 + 200 * A)
+STEP_BYTES = 200466432.0
 
 
 def algorithmic_costs(split_tail):
@@ -53,7 +62,7 @@ def algorithmic_costs(split_tail):
     return rows, flops, bytes_
 
 
-def build_learner(mode, device_index):
+def build_learner(mode, device_index, B=B, split_chains=False, use_graph=True):
     from surreal_amd.learner.ppo import PPOLearner
     lc = ppo_learner_config()
     lc.model.actor_fc_hidden_sizes = list(HIDDEN)
@@ -64,7 +73,10 @@ def build_learner(mode, device_index):
     lc.algo.ppo_mode = mode
     lc.algo.consts.kl_target = 1e9          # no data-dependent early exit: full 10 + 10 epochs
     lc.replay.batch_size = B
-    learner = PPOLearner(lc, ppo_env_config(D, A), ppo_session_config('/tmp/surreal_amd_bench'))
+    sc = ppo_session_config('/tmp/surreal_amd_bench')
+    sc.learner.split_chains = bool(split_chains)
+    sc.learner.use_hip_graph = bool(use_graph)
+    learner = PPOLearner(lc, ppo_env_config(D, A), sc)
     params = synthetic.make_ppo_params(D, A, hidden=HIDDEN, seed=1)
     zstate = synthetic.make_zfilter_state(D, seed=2)
     learner.model.load_params(params)
@@ -74,10 +86,23 @@ def build_learner(mode, device_index):
     return learner, params, zstate
 
 
-def device_batch(learner, rank):
-    """synthetic batch of the BASELINE shape, generated once and left resident in HBM"""
-    batch = synthetic.make_ppo_batch(B, N, D, A, seed=100 + rank)
+def device_batch(learner, rank, B=B, lo=0):
+    """synthetic batch of the BASELINE shape, generated once and left resident in HBM (B rows starting
+    at row `lo` of the seed's 1024: a strong-scaling rank's share of the one global batch)"""
+    batch = synthetic.make_ppo_batch(1024 if lo or B < 1024 else B, N, D, A, seed=100 + (0 if lo or B < 1024 else rank))
+    if lo or B < 1024:
+        batch = slice_batch(batch, lo, lo + B)
     return learner._preprocess_batch_ppo(copy.deepcopy(batch)), batch
+
+
+def slice_batch(batch, lo, hi):
+    def cut(x):
+        if isinstance(x, dict):
+            return type(x)((k, cut(v)) for k, v in x.items())
+        if isinstance(x, list):
+            return [cut(v) for v in x]
+        return None if x is None else x[lo:hi]
+    return cut(batch)
 
 
 def time_fused_kernel(learner, dbatch, iters=10):
@@ -135,25 +160,139 @@ def measured_mfma_util(rows):
     return None, None
 
 
-def cpu_baseline(mode, params, zstate, batch, budget_s=20.0):
-    """the reference learner's CPU path (oracle restatement, same ATen ops) on this host"""
+def host_cpu():
+    """model name, sockets x cores (physical) and logical CPUs of this host, from lscpu"""
+    import subprocess
+    info = {}
+    try:
+        for ln in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if ':' in ln:
+                k, v = ln.split(':', 1)
+                info[k.strip()] = v.strip()
+    except Exception:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        physical = int(info.get('Socket(s)', '1')) * int(info.get('Core(s) per socket', str(logical)))
+    except ValueError:
+        physical = logical
+    return {'model': info.get('Model name', 'unknown'), 'physical_cores': min(physical, logical),
+            'logical_cpus': logical}
+
+
+def cpu_baseline(mode, params, zstate, batch, budget_s=24.0):
+    """the reference learner's CPU path (oracle restatement, same ATen ops) on this host, swept over
+    torch.set_num_threads (n = physical cores AND n = 1; more threads than the GEMMs
+    of a 1024-row epoch can use make it slower, so the best of the sweep is the baseline)"""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import ppo_oracle
-    cores = torch.get_num_threads()
-    O = ppo_oracle.OraclePPOLearner(params, A, B, zstate=zstate, n_step=N, ppo_mode=mode,
-                                    kl_target=1e9)
-    O.learn(copy.deepcopy(batch))        # warm-up
-    t0 = time.time()
-    n = 0
-    while n < 3 or (time.time() - t0 < budget_s and n < 50):
-        O.learn(copy.deepcopy(batch))
-        n += 1
-        if time.time() - t0 > budget_s:
-            break
-    dt = (time.time() - t0) / n
-    return {'value': B * N / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d learn() calls of the full 1024x128x376 batch (10+10 epochs, %s mode), '
-                      '%.3f s each, torch %s CPU' % (n, mode, dt, torch.__version__)}
+    cpu = host_cpu()
+    prev = torch.get_num_threads()
+    counts = sorted({n for n in (1, 8, 16, 32, 64, cpu['physical_cores']) if 1 <= n <= cpu['logical_cpus']})
+    O = ppo_oracle.OraclePPOLearner(params, A, B, zstate=zstate, n_step=N, ppo_mode=mode, kl_target=1e9)
+    sweep = []
+    per = budget_s / len(counts)
+    for n in counts:
+        torch.set_num_threads(n)
+        O.learn(copy.deepcopy(batch))        # warm-up at this thread count
+        t0, k = time.time(), 0
+        while k < 1 or (time.time() - t0 < per and k < 20):
+            O.learn(copy.deepcopy(batch))
+            k += 1
+        dt = (time.time() - t0) / k
+        sweep.append({'threads': n, 's_per_learn': dt, 'env_steps_per_s': B * N / dt, 'learns': k})
+    torch.set_num_threads(prev)
+    best = max(sweep, key=lambda r: r['env_steps_per_s'])
+    one = [r for r in sweep if r['threads'] == 1][0]
+    return {'value': best['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': best['threads'], 'kind': 'port',
+            'sample': 'learn() on the full 1024x128x376 batch (10+10 epochs, %s mode), torch %s CPU, one warm-up + '
+                      '>= 1 timed call per thread count, best of the sweep (%.3f s per learn at %d threads)'
+                      % (mode, torch.__version__, best['s_per_learn'], best['threads']),
+            'single_thread': one['env_steps_per_s'], 'sweep': sweep, 'cpu_model': cpu['model'],
+            'physical_cores': cpu['physical_cores'], 'logical_cpus': cpu['logical_cpus']}
+
+
+# ---- the other BASELINE configurations (N = 1 only; a few steps each) -----------------------------
+def _time_learn(L, db, steps, warm=2):
+    for _ in range(warm):
+        L.learn(db)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        L.learn(db)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5):
+    from surreal_amd.learner.ppo import PPOLearner
+    lc = ppo_learner_config()
+    lc.algo.n_step = Ns
+    lc.algo.stride = Ns
+    lc.algo.rnn.if_rnn_policy = rnn
+    lc.algo.consts.kl_target = 1e9
+    lc.replay.batch_size = Bs
+    L = PPOLearner(lc, ppo_env_config(Ds, As, pixel=pixel), ppo_session_config('/tmp/surreal_amd_bench2'))
+    batch = synthetic.make_ppo_batch(Bs, Ns, Ds, As, seed=1, rnn_hidden=lc.algo.rnn.rnn_hidden if rnn else 0,
+                                     pixel=pixel)
+    dt = _time_learn(L, L._preprocess_batch_ppo(copy.deepcopy(batch)), steps)
+    return {'ms_per_learn': dt * 1e3, 'env_steps_per_s': Bs * Ns / dt, 'B': Bs, 'n_step': Ns, 'obs_dim': Ds,
+            'action_dim': As, 'policy': ('cnn+' if pixel else '') + ('lstm100(H=5)+mlp' if rnn else 'mlp'),
+            'epochs': '10+10, KL early exit disabled'}
+
+
+def secondary_ddpg(steps=200):
+    from surreal_amd.learner.ddpg import DDPGLearner
+    from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
+    from surreal_amd.replay import UniformReplay
+    Bd, Dd, Ad = 512, 17, 6
+    lc = ddpg_learner_config()
+    lc.replay.batch_size = Bd
+    lc.replay.memory_size = 1000000
+    L = DDPGLearner(lc, ddpg_env_config(Dd, Ad), ddpg_session_config())
+    R = UniformReplay(lc, ddpg_env_config(Dd, Ad), ddpg_session_config())
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for _ in range(10):
+        n = 100000
+        R.insert_batch({'obs': torch.randn(n, Dd, device='cuda', generator=g),
+                        'obs_next': torch.randn(n, Dd, device='cuda', generator=g),
+                        'actions': torch.rand(n, Ad, device='cuda', generator=g) * 2 - 1,
+                        'rewards': torch.randn(n, device='cuda', generator=g),
+                        'dones': (torch.rand(n, device='cuda', generator=g) < 0.01).float()})
+
+    def sample_and_learn():
+        f = R.sample_batch(Bd)
+        return L.learn({'obs': {'low_dim': {'flat_inputs': f['obs']}},
+                        'obs_next': {'low_dim': {'flat_inputs': f['obs_next']}}, 'actions': f['actions'],
+                        'rewards': f['rewards'].view(Bd, 1), 'dones': f['dones'].view(Bd, 1)})
+    for _ in range(20):
+        sample_and_learn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sample_and_learn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'ms_per_iteration': dt * 1e3, 'samples_per_s': Bd / dt, 'batch': Bd, 'replay_rows': 1000000,
+            'what': 'uniform sample of 512 out of 1e6 device-resident rows + DDPGLearner.learn'}
+
+
+def secondaries():
+    out = {}
+    for key, fn in (
+            ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda: secondary_ppo(64, 128, 17, 6, False)),
+            ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
+             lambda: secondary_ppo(64, 128, 17, 6, True)),
+            ('configs[2] DDPG HalfCheetah shapes, uniform replay 1e6, batch 512', secondary_ddpg),
+            ('configs[3] PPO 256 actors x 32 steps, 3x84x84 uint8 frames + 32-d state, CNN + LSTM policy',
+             lambda: secondary_ppo(256, 32, 32, 8, True, pixel=(3, 84, 84), steps=3))):
+        try:
+            out[key] = fn()
+        except Exception as e:       # a secondary must never take the headline line down
+            out[key] = {'error': repr(e)}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -165,6 +304,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--split-chains', action='store_true', help='policy and value epochs on two streams')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: 1024 sub-trajectories per GPU (the headline); strong: 1024 in total')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the other BASELINE configurations')
     ap.add_argument('--schedule', default='lockstep', choices=['lockstep', 'two_stream'],
                     help='epoch launch schedule (session_config.learner.epoch_schedule)')
     args = ap.parse_args()
@@ -187,79 +329,120 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    learner, params, zstate = build_learner(args.mode, local_rank)
-    learner.epoch_schedule = args.schedule
-    if args.no_graph:
-        learner.use_graph = False
-    dbatch, batch = device_batch(learner, rank)
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        learner.learn(dbatch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats = learner.learn(dbatch)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert learner.epochs_executed == learner.epoch_policy, 'work was skipped inside the timed region'
+    def timed_run(Bl, lo):
+        """W warm-up steps, then exactly K steps between barriers + device syncs; max over ranks"""
+        learner, params, zstate = build_learner(args.mode, local_rank, B=Bl, split_chains=args.split_chains,
+                                                use_graph=not args.no_graph)
+        learner.epoch_schedule = args.schedule
+        dbatch, batch = device_batch(learner, rank, B=Bl, lo=lo)
+        for _ in range(args.warmup):
+            learner.learn(dbatch)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats = learner.learn(dbatch)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert learner.epochs_executed == learner.epoch_policy, 'work was skipped inside the timed region'
+        return learner, params, zstate, dbatch, batch, dict(stats), dt
 
-    kt = time_fused_kernel(learner, dbatch)
+    strong_lo, strong_hi = rank * B // world, (rank + 1) * B // world
+    strong = None
+    if args.scaling == 'strong':
+        learner, params, zstate, dbatch, batch, stats, dt = timed_run(strong_hi - strong_lo, strong_lo)
+        total_rows = B
+    else:
+        learner, params, zstate, dbatch, batch, stats, dt = timed_run(B, 0)
+        total_rows = world * B
+        if world > 1:       # the same global batch of 1024 sub-trajectories split over the ranks
+            sl, _, _, _, _, sstats, sdt = timed_run(strong_hi - strong_lo, strong_lo)
+            strong = {'value': B * N * args.steps / sdt, 'unit': 'env-steps/s', 'ms_per_step': sdt / args.steps * 1e3,
+                      'global_batch': B, 'B_per_gpu': strong_hi - strong_lo, 'hip_graph': bool(sl.use_graph),
+                      'final_stats': {k: sstats[k] for k in ('_surr_loss', '_val_loss', '_pol_kl') if k in sstats}}
+            del sl
+
+    ws = learner._ws
+    kt = time_fused_kernel(learner, dbatch) if ws.key[0] == B and not (learner.if_rnn_policy or learner.model.if_pixel) else None
     out = None
     if rank == 0:
-        rows, flops, bytes_ = algorithmic_costs(learner._ws.split_tail)
+        step_s = dt / args.steps
         out = {
             'metric': METRIC,
-            'value': world * B * N * args.steps / dt,
+            'value': total_rows * N * args.steps / dt,
             'unit': 'env-steps/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step': step_s * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
                 'workload': 'BASELINE configs[4]: PPO synthetic 1024 actors x 128 steps x 376-dim '
-                            'obs per GPU, A=17, MLP [300,200], z-filter, %s mode, 10 policy + 10 '
-                            'value epochs (KL early exit disabled), batch resident in HBM' % args.mode,
-                'B_per_gpu': B, 'n_step': N, 'obs_dim': D, 'action_dim': A,
+                            'obs %s, A=17, MLP [300,200], z-filter, %s mode, 10 policy + 10 '
+                            'value epochs (KL early exit disabled), batch resident in HBM' % (
+                                'per GPU' if args.scaling == 'weak' else 'in total, split over the GPUs', args.mode),
+                'B_per_gpu': ws.key[0], 'n_step': N, 'obs_dim': D, 'action_dim': A,
                 'hip_graph': bool(learner.use_graph), 'parallelism': 'dp%d' % world,
+                'epoch_kernels': 'fused row-block' if getattr(ws, 'fused', False) else 'layered',
+                'collectives_per_step': getattr(learner, 'collectives_per_step', 0 if world == 1 else None),
             },
-            'roofline': {
+            'final_stats': {k: stats[k] for k in ('_surr_loss', '_val_loss', '_pol_kl') if k in stats},
+        }
+        if kt is not None:
+            rows, flops, bytes_ = algorithmic_costs(ws.split_tail)
+            traffic, tsrc = measured_traffic(rows)
+            busy, bsrc = measured_mfma_util(rows)
+            out['roofline'] = {
                 'kernel': 'mlp3_fused_kernel<10,7,true> (z-filter + critic MLP over %d rows)' % rows,
                 'bound': 'mfma',
                 'achieved': flops / kt / 1e12,
                 'peak': PEAK_FP32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': flops / kt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                'traffic': measured_traffic(rows)[0],
-                'traffic_source': measured_traffic(rows)[1],
-                'mfma_busy_pct': measured_mfma_util(rows)[0],
-                'mfma_busy_source': measured_mfma_util(rows)[1],
-                'kernel_ms': kt * 1e3,
+                # PMC counters cannot be collected inside this process: these two come from the committed
+                # rocprofv3 --pmc passes of the same command (profiles/), NOT from this run
+                'traffic': traffic, 'traffic_source': tsrc, 'traffic_measured_in_run': False,
+                'mfma_busy_pct': busy, 'mfma_busy_source': bsrc, 'mfma_busy_measured_in_run': False,
+                'kernel_ms': kt * 1e3,          # measured in this run (HIP events on the launch stream)
                 'flops_per_launch': flops,
                 'algorithmic_bytes_per_launch': bytes_,
                 'hbm_GBps': bytes_ / kt / 1e9,
                 'hbm_frac': bytes_ / kt / 1e9 / PEAK_HBM_GBPS,
-                'share_of_step': kt / (dt / args.steps),
-            },
-            'final_stats': {k: stats[k] for k in ('_surr_loss', '_val_loss', '_pol_kl') if k in stats},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(args.mode, params, zstate, batch)
-            out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+                'share_of_step': kt / step_s,
+            }
+        if args.scaling == 'weak':
+            # the whole learn() against both roofs (SURVEY.md 8(d): 71 GFLOP and 200 466 432 B per learn and GPU)
+            out['step_roofline'] = {
+                'algorithmic_flops_per_learn': STEP_FLOPS, 'algorithmic_bytes_per_learn': STEP_BYTES,
+                'achieved_mfma_TFLOPs': STEP_FLOPS / step_s / 1e12,
+                'mfma_frac': STEP_FLOPS / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'achieved_hbm_GBps': STEP_BYTES / step_s / 1e9,
+                'hbm_frac': STEP_BYTES / step_s / 1e9 / PEAK_HBM_GBPS,
+            }
+        if strong is not None:
+            out['strong'] = strong
+        if world == 1 and args.scaling == 'weak':
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(args.mode, params, zstate, batch)
+                out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+                out['gpu_over_cpu_single_thread'] = out['value'] / out['cpu_baseline']['single_thread']
+            if not args.no_secondary:
+                del learner, dbatch
+                torch.cuda.empty_cache()
+                out['secondary'] = secondaries()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
