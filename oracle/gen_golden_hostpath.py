@@ -89,7 +89,7 @@ def main():
     random.seed(123)
     out['uniform_sample6_seed123'] = u.sample(6)
     # ---- PPO window wrapper --------------------------------------------------------------
-    for T, n_step, stride in ((14, 5, 3), (10, 4, 4), (7, 3, 1), (5, 6, 2)):
+    for T, n_step, stride in ((14, 5, 3), (10, 4, 4), (7, 3, 1), (5, 6, 2), (12, 3, 5)):
         cap = Capture()
         w = bare(esw.ExpSenderWrapperMultiStepMovingWindowWithInfo, env=FakeEnv(T), sender=cap,
                  _ob=None, n_step=n_step, stride=stride, last_n=C.deque())

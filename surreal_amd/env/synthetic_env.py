@@ -172,11 +172,14 @@ class SyntheticVecEnv(object):
 
     def emit_windows(self, n_step, stride, out=None):
         """-> dict of [n*W, n_step, .] sub-trajectories (+ obs_next [n*W, 1, D]) cut from the
-        recorded rollout with the reference's moving-window rule (exp_sender_wrapper.py:209-228):
-        W = floor((T - n_step) / stride) + 1 windows per actor, a partial tail is dropped"""
+        recorded rollout with the reference's moving-window rule (exp_sender_wrapper.py:209-228), the
+        same index arithmetic as the host wrapper (env/exp_sender_wrapper.py): window w = steps
+        [w * advance, w * advance + n_step), W = windows_per_episode(T, n_step, stride) per actor"""
+        from surreal_amd.env.exp_sender_wrapper import window_advance, windows_per_episode
         T = self.T
         assert self.slot == T, 'rollout not complete'
-        W = (T - n_step) // stride + 1
+        W = windows_per_episode(T, n_step, stride)
+        stride = window_advance(n_step, stride)
         r, K, n = self.rolls, self.K, self.n
         f = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)  # noqa: E731
         if out is not None:

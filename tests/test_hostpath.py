@@ -76,7 +76,7 @@ def test_uniform_replay_matches_reference():
     assert u.sample(6) == GOLD['uniform_sample6_seed123']             # with replacement, same stream
 
 
-@pytest.mark.parametrize('T,n_step,stride', [(14, 5, 3), (10, 4, 4), (7, 3, 1), (5, 6, 2)])
+@pytest.mark.parametrize('T,n_step,stride', [(14, 5, 3), (10, 4, 4), (7, 3, 1), (5, 6, 2), (12, 3, 5)])
 def test_ppo_window_wrapper_matches_reference(T, n_step, stride):
     from surreal_amd.env import ExpSenderWrapperMultiStepMovingWindowWithInfo
     lc, ec, sc = configs(N=n_step, stride=stride)
@@ -88,7 +88,10 @@ def test_ppo_window_wrapper_matches_reference(T, n_step, stride):
         while not done:
             _, _, done, _ = w.step((np.zeros(1), [[], [np.array([0.5, 1.0])]]))
     ref = GOLD['window_T%d_n%d_s%d' % (T, n_step, stride)]
-    assert len(got) == len(ref) == 2 * (max(0, (T - n_step) // stride + 1) if T >= n_step else 0)
+    from surreal_amd.env.exp_sender_wrapper import windows_per_episode
+    # (12, 3, 5): a stride past the window length advances by n_step -- the reference pops `stride`
+    # entries off a queue that holds only n_step
+    assert len(got) == len(ref) == 2 * windows_per_episode(T, n_step, stride)
     for e, r in zip(got, ref):
         assert [int(o['low_dim']['flat_inputs'][0]) for o in e['obs']] == r['obs_t']
         assert int(e['obs_next']['low_dim']['flat_inputs'][0]) == r['obs_next_t']
