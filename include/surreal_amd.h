@@ -381,7 +381,12 @@ int smx_mlp3_wgrad_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stre
  * followed by smx_mlp3_wgrad_multi_f32 and smx_clip_adam_step_pair_f32.
  * Requirements (smx_epoch_supported): H1, H2 multiples of 4, OUT <= 32, x dense [rows, D]; W2, W3,
  * b1, b2 (and x when D % 4 == 0) 16-byte aligned.  loss->mean / dz3 / dz3_t / values are not used (the tiles stay on chip). */
-enum { SMX_EPOCH_LOSS_NONE = 0, SMX_EPOCH_LOSS_POLICY = 1, SMX_EPOCH_LOSS_VALUE = 2 };
+/* backward only, data-parallel epochs (several ranks): SMX_EPOCH_RHS_SURR / _KL run the actor's data
+ * gradients on ONE right-hand side each, dz3 = g_surr / n_total or g_kl / n_total, with no batch means
+ * and no statistics (the loss gradient is linear in dz3; smx_ppo_epoch_combine_f32 forms G_surr + c_kl
+ * G_kl after the all-reduce) */
+enum { SMX_EPOCH_LOSS_NONE = 0, SMX_EPOCH_LOSS_POLICY = 1, SMX_EPOCH_LOSS_VALUE = 2, SMX_EPOCH_RHS_SURR = 3,
+       SMX_EPOCH_RHS_KL = 4 };
 typedef struct smx_epoch_job {
     const smx_mlp3_t* net;
     const float* x;

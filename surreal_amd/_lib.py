@@ -51,7 +51,7 @@ class EpochPack(Structure):
     _fields_ = [('net', POINTER(Mlp3)), ('packed', c_void_p)]
 
 
-EPOCH_LOSS_NONE, EPOCH_LOSS_POLICY, EPOCH_LOSS_VALUE = 0, 1, 2
+EPOCH_LOSS_NONE, EPOCH_LOSS_POLICY, EPOCH_LOSS_VALUE, EPOCH_RHS_SURR, EPOCH_RHS_KL = 0, 1, 2, 3, 4
 
 
 class Lstm(Structure):

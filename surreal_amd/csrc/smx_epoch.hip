@@ -496,12 +496,17 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     float* dz2s = sm + G.off_h2;            // [16][ldh2]
     const int ldh2 = G.ldh2;
     const bool policy = J.loss == SMX_EPOCH_LOSS_POLICY;
+    // data-parallel epochs: the backward pass runs on the two right-hand sides g_surr / n and g_kl / n
+    // separately (the loss gradient is linear in dz3; the KL coefficient needs the GLOBAL mean KL and is
+    // applied after the all-reduce, smx_ppo_epoch_combine_f32): no batch means, no statistics here
+    const bool dp_surr = J.loss == SMX_EPOCH_RHS_SURR, dp_kl = J.loss == SMX_EPOCH_RHS_KL;
+    const bool actor = policy || dp_surr || dp_kl;
     const PolArgs& p = G.pl;
 
     // ---- requested up front, in one batch: this workgroup's share of the loss tiles -----------
     const int A = p.A;
     float gs0 = 0.f, gk0 = 0.f, gs1 = 0.f, gk1 = 0.f, vd = 0.f;       // <= 2 (row, action) pairs per thread
-    if (policy) {            // (unconditional loads from clamped addresses: no load under a lane mask)
+    if (actor) {             // (unconditional loads from clamped addresses: no load under a lane mask)
         const int last = ER * A - 1;
         const int i0 = tid < last ? tid : last, i1 = tid + NTH < last ? tid + NTH : last;
         const int a0 = i0 / ER, n0 = i0 - a0 * ER, a1 = i1 / ER, n1 = i1 - a1 * ER;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     for (int idx = tid; idx < (G.off_red >> 2); idx += NTH) *(float4*)(sm + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
     // the early-exit flag may be raised by workgroup 0 of THIS launch while others start: one lane
     // reads it and the workgroup takes one decision
-    if (tid == 0) S[0] = (policy && ctrl->stop_flag) ? 1.f : 0.f;
+    if (tid == 0) S[0] = (actor && ctrl->stop_flag) ? 1.f : 0.f;
     SMX_LDS_BARRIER();
     const bool stopped = S[0] != 0.f;
     SMX_LDS_BARRIER();
@@ -547,6 +552,18 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
                 const int a = idx / ER, nn = idx - a * ER;
                 const float v = nn < nrows ? ((i ? gs1 : gs0) + c_kl * (i ? gk1 : gk0)) * inv_n : 0.f;
                 if (nn < nrows && half == 0 && J.dz3T) J.dz3T[(size_t)a * J.ldT + row0 + nn] = v;   // (a store: nothing waits for it)
+                dz3s[nn * LDZ + a] = v;
+            }
+        }
+    } else if (actor) {
+        const float inv_n = 1.0f / (float)G.n_total;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTH * i;
+            if (idx < ER * A) {
+                const int a = idx / ER, nn = idx - a * ER;
+                const float v = nn < nrows ? (dp_surr ? (i ? gs1 : gs0) : (i ? gk1 : gk0)) * inv_n : 0.f;
+                if (nn < nrows && half == 0 && J.dz3T) J.dz3T[(size_t)a * J.ldT + row0 + nn] = v;
                 dz3s[nn * LDZ + a] = v;
             }
         }
@@ -747,7 +764,11 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
         }
         J.blk_base = base;
         base += smx_epoch_blocks(s.rows) * fsplit;
-        if (s.loss == SMX_EPOCH_LOSS_POLICY) {
+        if (s.loss == SMX_EPOCH_RHS_SURR || s.loss == SMX_EPOCH_RHS_KL) {
+            SMX_REQUIRE(backward, SMX_E_UNSUPPORTED);
+            SMX_REQUIRE(loss && loss->g_surr && loss->g_kl && s.dz3T, SMX_E_NULL);
+        }
+        if (s.loss == SMX_EPOCH_LOSS_POLICY || s.loss == SMX_EPOCH_RHS_SURR || s.loss == SMX_EPOCH_RHS_KL) {
             SMX_REQUIRE(loss, SMX_E_NULL);
             SMX_REQUIRE(loss->A == n.OUT && loss->A <= MAX_A, SMX_E_SHAPE);
             SMX_REQUIRE(loss->rows == s.rows, SMX_E_SHAPE);

@@ -143,7 +143,8 @@ class HipKernels(object):
             arr[k].packed = L.ptr(packed)
         L.call('smx_epoch_pack_f32', arr, len(items), self._st())
 
-    _EPOCH_LOSS = {None: L.EPOCH_LOSS_NONE, 'policy': L.EPOCH_LOSS_POLICY, 'value': L.EPOCH_LOSS_VALUE}
+    _EPOCH_LOSS = {None: L.EPOCH_LOSS_NONE, 'policy': L.EPOCH_LOSS_POLICY, 'value': L.EPOCH_LOSS_VALUE,
+                   'rhs_surr': L.EPOCH_RHS_SURR, 'rhs_kl': L.EPOCH_RHS_KL}
 
     def _epoch_jobs(self, jobs):
         arr = (L.EpochJob * len(jobs))()

@@ -72,10 +72,29 @@ class LinearWithMinLR(object):
         self.n, self.lr = int(sd['n']), float(sd['lr'])
 
 
+class _CountingDist(object):
+    """torch.distributed with a counter on the collectives a learn() issues (reported by bench.py)"""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.count = 0
+
+    def all_reduce(self, *a, **k):
+        self.count += 1
+        return self._d.all_reduce(*a, **k)
+
+    def all_gather_into_tensor(self, *a, **k):
+        self.count += 1
+        return self._d.all_gather_into_tensor(*a, **k)
+
+    def __getattr__(self, name):
+        return getattr(self._d, name)
+
+
 def _dist_info():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        return dist, dist.get_world_size(), dist.get_rank()
+        return _CountingDist(dist), dist.get_world_size(), dist.get_rank()
     return None, 1, 0
 
 
@@ -330,12 +349,14 @@ class PPOLearner(Learner):
         # one buffer for both groups' gradients: a data-parallel lock-step epoch all-reduces it once
         n_a, n_c = self.model.actor_flat.numel(), self.model.critic_flat.numel()
         ws.nblk_p = K.loss_blocks(rows)
-        ws.nblk_v = K.value_loss_blocks(rows)
-        # fused row-block epochs: single rank, plain MLP policy, shapes the kernels take
+        # fused row-block epochs: plain MLP policy, shapes the kernels take; on several ranks the
+        # paired-epoch schedule with one collective per epoch (epoch_policy == epoch_baseline)
         ws.fused = (self.fused_epochs and self.epoch_schedule == 'lockstep' and not stem and
-                    self.world_size == 1 and K.epoch_supported(act) and K.epoch_supported(cri))
+                    (self.world_size == 1 or self.epoch_policy == self.epoch_baseline) and
+                    K.epoch_supported(act) and K.epoch_supported(cri))
+        vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
+        ws.nblk_v = vblocks(rows)
         if ws.fused:
-            ws.nblk_v = K.epoch_blocks(rows)         # value-loss moments per 16-row block
             assert ws.nblk_p == K.epoch_blocks(rows)
             # the weights in the forward kernel's fragment order (model, critic, reference policy)
             ws.pk_actor = torch.zeros(K.epoch_packed_numel(act), device=dev)
@@ -352,7 +373,7 @@ class PPOLearner(Learner):
             self._dist.all_gather_into_tensor(every, mine)
             every = every.view(-1, 2).tolist()
             ws.n_total, ws.B_total = sum(r for r, _ in every), sum(b for _, b in every)
-            ws.nblk_v = max(K.value_loss_blocks(r) for r, _ in every)
+            ws.nblk_v = max(vblocks(r) for r, _ in every)
             nblk_p_all = max(K.loss_blocks(r) for r, _ in every)
         ws.dp_epoch = self.world_size > 1 and not stem
         ws.tail_deferred = ws.dp_epoch and self.epoch_policy >= self.epoch_baseline
@@ -681,13 +702,48 @@ class PPOLearner(Learner):
         cj = dict(net=m.critic, packed=ws.pk_critic, x=ws.xn, act=L.SMX_ACT_NONE, loss='value', h1T=ws.h1cT, h2T=ws.h2cT,
                   dz3=ws.dz3c, dz3T=ws.dz3c, dz2T=ws.dz2cT, dz1T=ws.dz1cT, xT=ws.xnT, grads=ws.grads_c,
                   sumsq=ws.sumsq_c)         # OUT = 1: dz3^T is dz3 itself
+        dp = ws.dp_epoch                     # several ranks: one all-reduce per epoch (see _enqueue_dp_epoch)
+        adapt = mode == L.SMX_PPO_ADAPT
+
         def loss_args(e):
             return dict(mode=mode, rows=ws.rows, log_var=m.log_var.view(-1), actions=actions0, behave=behave0,
-                        ref=ws.ref_pol, adv=ws.adv, g_surr=ws.g_surr, g_kl=ws.g_kl, partials=ws.ppart,
+                        ref=ws.ref_pol, adv=ws.adv, g_surr=ws.g_surr, g_kl=ws.g_kl,
+                        partials=ws.ppart_ar if dp and e < Ep else ws.ppart,
                         check_stop=e > 0, will_update=e < Ep,
                         dlogvar=ws.grads_a[m.actor.numel:m.actor.numel + A],
                         dlogvar_sumsq=ws.sumsq_a[ws.np_a:ws.np_a + 1], stats=ws.pstats[min(e, Ep)],
-                        returns=ws.ret, v_dz3=ws.dz3c, v_partials=ws.vpart[min(e, Ev - 1)], v_will_update=True)
+                        returns=ws.ret, v_dz3=ws.dz3c,
+                        v_partials=(ws.vpart_loc_all if dp else ws.vpart)[min(e, Ev - 1)], v_will_update=True)
+
+        if dp:
+            assert Ep == Ev and ws.tail_deferred
+            rhs = [dict(aj, loss='rhs_surr')]
+            if adapt:
+                rhs.append(dict(aj, loss='rhs_kl', dz3T=ws.dz3kT, dz2T=ws.dz2kT, dz1T=ws.dz1kT, grads=ws.grads_k,
+                                sumsq=ws.sumsq_k))
+            for e in range(Ep + 1):
+                loss = loss_args(e)
+                if e == Ep:
+                    # the final, forward-only policy pass: its loss sums travel with the end-of-learn
+                    # exchange (_enqueue_tail_exchange), which also runs its finalize
+                    K.epoch_forward([aj], loss, ws.ctrl_f, n_total)
+                    torch.sum(ws.ppart, 0, keepdim=True, out=ws.tp_ppart)
+                    break
+                K.epoch_forward([aj, cj], loss, ws.ctrl_f, n_total)
+                K.epoch_backward(rhs + [cj], loss, ws.ctrl_f, n_total)
+                K.mlp3_wgrad_multi(rhs + [cj])
+                self._dist.all_reduce(ws.ar)
+                K.epoch_combine(mode, ws.ppart_ar, ws.ppart_ar.shape[0], n_total, m.log_var.view(-1), ws.ctrl_f,
+                                e > 0, True, ws.pstats[e], ws.grads_a, ws.grads_k if adapt else None,
+                                m.actor.numel, ws.sumsq_a, ws.grads_c, ws.sumsq_c)
+                K.clip_adam_pair((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                                  ws.sumsq_a, K.sumsq_blocks(ws.grads_a.numel()), True,
+                                  ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1]),
+                                 (m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                                  ws.sumsq_c, K.sumsq_blocks(ws.grads_c.numel()), False,
+                                  ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1]),
+                                 ws.ctrl_f, pack=((m.actor, ws.pk_actor), (m.critic, ws.pk_critic)))
+            return
 
         if self.split_chains and self.device != 'cpu':
             # The policy and the value epochs touch disjoint parameters (ppo.py:541-562) and each of
@@ -1319,6 +1375,7 @@ class PPOLearner(Learner):
 
     def learn(self, batch):
         self.current_iteration += 1
+        c0 = self._dist.count if self._dist is not None else 0
         batch = self._preprocess_batch_ppo(batch)
         tensorplex_update_dict = self._optimize(
             batch['obs'], batch['actions'], batch['rewards'], batch['obs_next'],
@@ -1327,6 +1384,7 @@ class PPOLearner(Learner):
         self.tensorplex.add_scalars(tensorplex_update_dict, self.global_step)
         self.exp_counter += self._ws.B_total
         self.global_step += 1
+        self.collectives_per_step = (self._dist.count - c0) if self._dist is not None else 0
         return tensorplex_update_dict
 
     def raw_values(self):

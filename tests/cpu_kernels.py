@@ -215,6 +215,11 @@ class TorchCpuKernels(object):
                 if int(ci[L.C_STOP]) != 0 or not loss['will_update']:
                     continue
                 j['dz3T'].copy_(dz3.t())
+            elif j.get('loss') in ('rhs_surr', 'rhs_kl'):
+                if int(ctrl.view(torch.int32)[L.C_STOP]) != 0:
+                    continue
+                dz3 = (loss['g_surr'] if j['loss'] == 'rhs_surr' else loss['g_kl']) / float(n_total)
+                j['dz3T'].copy_(dz3.t())
             else:
                 dz3 = j['dz3'].view(rows, 1)
             h2, h1 = j['h2T'].t(), j['h1T'].t()

@@ -57,7 +57,8 @@ def _worker(rank, world, port, name, q):
                'actor': cpu(learner.model.actor_flat), 'critic': cpu(learner.model.critic_flat),
                'z': {k: cpu(v) for k, v in learner.model.z_filter.state_dict().items()}
                if zstate is not None else None,
-               'exp_counter': learner.exp_counter}
+               'exp_counter': learner.exp_counter, 'collectives': learner.collectives_per_step,
+               'fused': bool(getattr(learner._ws, 'fused', False))}
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
@@ -66,7 +67,10 @@ def _worker(rank, world, port, name, q):
         q.put((rank, {'error': traceback.format_exc()}))
 
 
-@pytest.mark.parametrize('name', ['tiny_clip', 'cfg2_adapt', 'cfg1_rnn_adapt', 'tiny_pixel_rnn_adapt'])
+# (cfg5_*: a 512-row shard of the benchmark shape per rank -- the fused row-block epoch kernels with the
+# data-parallel right-hand sides, smx_ppo_epoch_combine_f32 after the all-reduce, the deferred tail exchange)
+@pytest.mark.parametrize('name', ['tiny_clip', 'cfg2_adapt', 'cfg1_rnn_adapt', 'tiny_pixel_rnn_adapt', 'cfg5_clip',
+                                  'cfg5_adapt', 'cfg5_adapt_earlyexit'])
 def test_two_rank_hip_learner_equals_single_learner(name):
     world = 2
     ctx = mp.get_context('spawn')
@@ -96,6 +100,10 @@ def test_two_rank_hip_learner_equals_single_learner(name):
         H.assert_trace_close(res[r]['trace'], g, what='%s rank %d' % (name, r))
         H.assert_stats_close(res[r]['stats'], g, what='%s rank %d' % (name, r))
         assert res[r]['exp_counter'] == case['shape']['B']
+    if name.startswith('cfg5'):
+        # one all-reduce per paired epoch (+ the workspace's batch-size exchange, the advantage moments and
+        # the end-of-learn gather): epochs executed + 3
+        assert res[0]['fused'] and res[0]['collectives'] <= case['hyper'].get('epoch_policy', 10) + 3, res[0]['collectives']
     # replicas stay bit-identical: same all-reduced gradients -> same Adam step everywhere
     np.testing.assert_array_equal(res[0]['actor'], res[1]['actor'])
     np.testing.assert_array_equal(res[0]['critic'], res[1]['critic'])
@@ -123,5 +131,7 @@ def test_bench_two_ranks_share_one_gpu():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
     assert out['config']['parallelism'] == 'dp2' and out['value'] > 0
+    assert out['strong']['global_batch'] == 1024 and out['strong']['B_per_gpu'] == 512 and out['strong']['value'] > 0
+    assert out['config']['collectives_per_step'] == 12 and out['config']['epoch_kernels'] == 'fused row-block'
     assert 'cpu_baseline' not in out and out['roofline']['frac'] > 0
     assert all(np.isfinite(v) for v in out['final_stats'].values())
