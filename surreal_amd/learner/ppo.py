@@ -72,20 +72,79 @@ class LinearWithMinLR(object):
         self.n, self.lr = int(sd['n']), float(sd['lr'])
 
 
+class _SegmentedGraph(object):
+    """A learn() on several ranks as hipGraph SEGMENTS with the collectives issued between them: the
+    kernels (and the few torch ops) between two collectives are captured once and replayed, RCCL is
+    called eagerly on the same stream.  One learn of the benchmark is ~70 launches; issued one by
+    one from Python they cost more host time than the GPU needs to run them, which a single-rank
+    learner never pays (its whole step is one graph)."""
+
+    def __init__(self):
+        self.items = []
+        self.pool = torch.cuda.graph_pool_handle()      # one pool: a segment's temporaries outlive it
+        self._cur = None
+
+    def _open(self):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog thread queries events while we capture; under the
+        # default (global) mode a HIP call from ANY thread invalidates the capture
+        ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode='thread_local')
+        ctx.__enter__()
+        self._cur = (g, ctx)
+
+    def _close(self):
+        g, ctx = self._cur
+        ctx.__exit__(None, None, None)
+        self.items.append(g)
+        self._cur = None
+
+    def capture(self, fn, dist_proxy):
+        dist_proxy.recorder = self
+        self._open()
+        try:
+            fn()
+        finally:
+            self._close()
+            dist_proxy.recorder = None
+
+    def collective(self, thunk):
+        """called by the distributed proxy while capturing: cut the graph here (the collective is NOT
+        executed during the capture pass -- the kernels around it are not either)"""
+        self._close()
+        self.items.append(thunk)
+        self._open()
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class _CountingDist(object):
-    """torch.distributed with a counter on the collectives a learn() issues (reported by bench.py)"""
+    """torch.distributed with a counter on the collectives a learn() issues (reported by bench.py) and
+    a hook for _SegmentedGraph"""
 
     def __init__(self, dist):
         self._d = dist
         self.count = 0
+        self.recorder = None
+
+    def _run(self, name, a, k):
+        def thunk():
+            self.count += 1
+            return getattr(self._d, name)(*a, **k)
+        if self.recorder is not None:
+            self.recorder.collective(thunk)
+            return None
+        return thunk()
 
     def all_reduce(self, *a, **k):
-        self.count += 1
-        return self._d.all_reduce(*a, **k)
+        return self._run('all_reduce', a, k)
 
     def all_gather_into_tensor(self, *a, **k):
-        self.count += 1
-        return self._d.all_gather_into_tensor(*a, **k)
+        return self._run('all_gather_into_tensor', a, k)
 
     def __getattr__(self, name):
         return getattr(self._d, name)
@@ -201,8 +260,10 @@ class PPOLearner(Learner):
             self._rf_sumsq = torch.tensor(0.0, device=self.device)
 
         lcfg = self.session_config.learner
+        # one rank: the whole step is ONE hipGraph; several ranks: graph segments between the
+        # collectives (_SegmentedGraph), unless session_config.learner.graph_segments is off
         self.use_graph = bool(lcfg.get('use_hip_graph', True)) and self.device != 'cpu' \
-            and self.world_size == 1
+            and (self.world_size == 1 or bool(lcfg.get('graph_segments', True)))
         self.overlap_value_epochs = bool(lcfg.get('overlap_value_epochs', True)) \
             and self.device != 'cpu'
         # 'lockstep': actor and critic epochs share launches; 'two_stream': separate chains.
@@ -1228,7 +1289,7 @@ class PPOLearner(Learner):
                 self._enqueue_optimize(ws, *args)
                 torch.cuda.synchronize()
                 self._restore_state(snap)
-                g = torch.cuda.CUDAGraph()
+                g = torch.cuda.CUDAGraph() if self.world_size == 1 else _SegmentedGraph()
                 # no cyclic garbage collection while the stream is capturing: a collection that
                 # frees some earlier learner's graph or device tensors calls hipFree / graph
                 # destructors in the middle of the capture, which aborts the process
@@ -1236,8 +1297,11 @@ class PPOLearner(Learner):
                 gc.collect()
                 gc.disable()
                 try:
-                    with torch.cuda.graph(g):
-                        self._enqueue_optimize(ws, *args)
+                    if self.world_size == 1:
+                        with torch.cuda.graph(g):
+                            self._enqueue_optimize(ws, *args)
+                    else:
+                        g.capture(lambda: self._enqueue_optimize(ws, *args), self._dist)
                 finally:
                     if gc_was_enabled:
                         gc.enable()
