@@ -1,7 +1,7 @@
 # quick per-kernel time table of one bench.py run (rocprofv3 --kernel-trace --stats); args are passed to bench.py
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out && rm -rf gpurun_out/prof_q
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_q -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/prof_q.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_q -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary "$@" > gpurun_out/prof_q.log 2>&1
 tail -1 gpurun_out/prof_q.log | cut -c1-330
 python - <<'PY'
 import csv, glob, collections

@@ -1301,11 +1301,19 @@ class PPOLearner(Learner):
                         with torch.cuda.graph(g):
                             self._enqueue_optimize(ws, *args)
                     else:
-                        g.capture(lambda: self._enqueue_optimize(ws, *args), self._dist)
+                        try:
+                            g.capture(lambda: self._enqueue_optimize(ws, *args), self._dist)
+                        except Exception as e:      # e.g. a runtime that refuses to capture next to RCCL
+                            self.log.warning('graph segments unavailable (%r): eager launches from here on', e)
+                            g = None
+                            self.use_graph = False
                 finally:
                     if gc_was_enabled:
                         gc.enable()
                 self._restore_state(snap)
+                if g is None:
+                    self._enqueue_optimize(ws, *args)
+                    return self._collect_stats(ws)
                 if getattr(ws, 'staged', None) is not None and args is ws.staged:
                     self._graphs = {key: g}          # staging mode: the in-place graph is retired
                 else:
