@@ -100,6 +100,11 @@ int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
 size_t smx_mlp3_packed_bytes(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
 int smx_mlp3_pack_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
                       smx_stream_t stream);
+/* the same launch also refreshing the z-filter statistics the pass that follows reads (exactly
+ * smx_zfilter_stats_f32: mean_out / std_out [D] from the running sums) */
+int smx_mlp3_pack_zstats_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
+                             const float* running_sum, const float* running_sumsq, const float* count,
+                             int32_t D, float eps, float* mean_out, float* std_out, smx_stream_t stream);
 int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_t H1, int32_t H2,
                                int32_t OUT, const float* x_main, const float* x_tail,
                                int64_t G, int32_t T0, int32_t T1, const float* zmean,
@@ -201,6 +206,28 @@ int smx_windowed_gae_returns_f32(const float* values, const float* values_tail,
                                  const float* lam_pow, float gamma, float gamma_H,
                                  int32_t B, int32_t N, int32_t H, float* adv, float* ret,
                                  smx_stream_t stream);
+/* smx_windowed_gae_returns_f32 + smx_moments_f32 + smx_adv_normalize_f32 in ONE launch (single rank):
+ * the last workgroup to finish forms the batch moments of adv (adv_moments[3]) and normalises adv in
+ * place with max(std_unbiased, min_std).  ticket: one int32 in device memory, zero before the first
+ * call (the kernel leaves it zero). */
+int smx_windowed_gae_norm_f32(const float* values, const float* values_tail, const float* rewards,
+                              const float* dones, const float* gamma_pow, const float* lam_pow,
+                              float gamma, float gamma_H, int32_t B, int32_t N, int32_t H, float* adv,
+                              float* ret, float* adv_moments, float min_std, int32_t* ticket,
+                              smx_stream_t stream);
+/* What PPOLearner._optimize does after its epoch loops (ppo.py:565-584) in ONE launch (single rank):
+ *   smx_value_loss_finalize_f32 (v_partials [n_epochs, nblk, 8] -> v_stats rows; n_epochs may be 0),
+ *   smx_moments_f32 over the return targets (ret_moments[3]), smx_zfilter_update_f32 on x [rows, D]
+ *   (x == NULL: no z-filter), then -- by the last workgroup to finish, so it reads the updated sums --
+ *   smx_ppo_final_stats_f32 (out4).  ticket as above. */
+typedef struct smx_learn_epilogue {
+    const float* x; int64_t ldx; int64_t rows; int32_t D; int32_t A;
+    float* running_sum; float* running_sumsq; float* count; float count_rows; int32_t n_epochs;
+    const float* ret; int64_t n_ret; float* ret_moments;
+    const float* v_partials; int32_t nblk; int32_t stats_stride; float* v_stats;
+    const float* log_var; float* out4; int32_t* ticket;
+} smx_learn_epilogue_t;
+int smx_ppo_learn_epilogue_f32(const smx_learn_epilogue_t* args, smx_stream_t stream);
 /* moments[3] = {n, mean, M2 = sum (x-mean)^2} over n values (two-pass, one workgroup) */
 int smx_moments_f32(const float* x, int64_t n, float* moments, smx_stream_t stream);
 /* Chan-merge k per-rank moment triples [k,3] into out[3] (multi-GPU advantage norm) */
@@ -417,6 +444,28 @@ typedef struct smx_epoch_pack {
 } smx_epoch_pack_t;
 int64_t smx_epoch_packed_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
 int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_stream_t stream);
+/* What PPOLearner._optimize prepares once per learn for its epoch loops (ppo.py:527-539), in ONE launch:
+ *   xn  [rows, D] = ZFilter.forward(obs0) with the model's statistics (zmean / zstd from
+ *        smx_zfilter_stats_f32; NULL: plain copy), xnT [D, ldT] its transposed copy (optional);
+ *   xr  [rows, D] = the same through the REFERENCE policy's filter, straight from its running sums
+ *        (ref_filter != 0; else plain copy)  -- ref_target_model.forward_actor's input (ppo.py:539);
+ *   xnext [rows, D] = ZFilter.forward(obs_next rows) (optional: the critic's tail rows, ppo.py:380);
+ *   ref_std [rows, A] (row stride ld_ref) = exp(ref_log_var): the std columns of ref_pol (builders.py:126-129);
+ *   the packed weight copies of n_pack networks (smx_epoch_pack_f32);
+ *   zero_words[0 .. n_zero) = 0 (the control block's stop flag / epoch counter / statistics rows).
+ * obs0 / obs_next are row-strided views (ld in floats, e.g. N * D: step 0 of every sub-trajectory). */
+typedef struct smx_epoch_prep {
+    const float* obs0; int64_t ld_obs0; int64_t rows; int32_t D; int32_t A;
+    const float* zmean; const float* zstd;
+    float* xn; float* xnT; int64_t ldT;
+    const float* ref_sum; const float* ref_sumsq; const float* ref_count; float ref_eps; int32_t ref_filter;
+    float* xr;
+    const float* obs_next; int64_t ld_next; float* xnext;
+    const float* ref_log_var; float* ref_std; int64_t ld_ref;
+    int32_t* zero_words; int32_t n_zero; int32_t n_pack;
+    smx_epoch_pack_t pack[4];
+} smx_epoch_prep_t;
+int smx_epoch_prepare_f32(const smx_epoch_prep_t* args, smx_stream_t stream);
 struct smx_ppo_losses;
 int32_t smx_epoch_blocks(int64_t rows);
 int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);

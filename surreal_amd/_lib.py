@@ -51,6 +51,25 @@ class EpochPack(Structure):
     _fields_ = [('net', POINTER(Mlp3)), ('packed', c_void_p)]
 
 
+class LearnEpilogue(Structure):
+    """smx_learn_epilogue_t"""
+    _fields_ = [('x', c_void_p), ('ldx', c_int64), ('rows', c_int64), ('D', c_int32), ('A', c_int32),
+                ('running_sum', c_void_p), ('running_sumsq', c_void_p), ('count', c_void_p), ('count_rows', c_float),
+                ('n_epochs', c_int32), ('ret', c_void_p), ('n_ret', c_int64), ('ret_moments', c_void_p),
+                ('v_partials', c_void_p), ('nblk', c_int32), ('stats_stride', c_int32), ('v_stats', c_void_p),
+                ('log_var', c_void_p), ('out4', c_void_p), ('ticket', c_void_p)]
+
+
+class EpochPrep(Structure):
+    """smx_epoch_prep_t"""
+    _fields_ = [('obs0', c_void_p), ('ld_obs0', c_int64), ('rows', c_int64), ('D', c_int32), ('A', c_int32),
+                ('zmean', c_void_p), ('zstd', c_void_p), ('xn', c_void_p), ('xnT', c_void_p), ('ldT', c_int64),
+                ('ref_sum', c_void_p), ('ref_sumsq', c_void_p), ('ref_count', c_void_p), ('ref_eps', c_float),
+                ('ref_filter', c_int32), ('xr', c_void_p), ('obs_next', c_void_p), ('ld_next', c_int64),
+                ('xnext', c_void_p), ('ref_log_var', c_void_p), ('ref_std', c_void_p), ('ld_ref', c_int64),
+                ('zero_words', c_void_p), ('n_zero', c_int32), ('n_pack', c_int32), ('pack', EpochPack * 4)]
+
+
 EPOCH_LOSS_NONE, EPOCH_LOSS_POLICY, EPOCH_LOSS_VALUE, EPOCH_RHS_SURR, EPOCH_RHS_KL = 0, 1, 2, 3, 4
 
 
@@ -119,6 +138,7 @@ _SIGS = {
     'smx_zfilter_update_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_float, _P]),
     'smx_mlp3_packed_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_pack_f32': (c_int32, [POINTER(Mlp3), _P, c_size_t, _P]),
+    'smx_mlp3_pack_zstats_f32': (c_int32, [POINTER(Mlp3), _P, c_size_t, _P, _P, _P, c_int32, c_float, _P, _P, _P]),
     'smx_mlp3_forward_fused_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                              c_int64, c_int32, c_int32, _P, _P, _P, c_int32, _P]),
     'smx_linear_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, c_int32, _P, _P, c_int32,
@@ -133,6 +153,7 @@ _SIGS = {
     'smx_epoch_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_packed_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_pack_f32': (c_int32, [POINTER(EpochPack), c_int32, _P]),
+    'smx_epoch_prepare_f32': (c_int32, [POINTER(EpochPrep), _P]),
     'smx_epoch_forward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
     'smx_epoch_backward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
@@ -140,6 +161,9 @@ _SIGS = {
                                         _P, _P]),
     'smx_windowed_gae_returns_f32': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int32,
                                                c_int32, c_int32, _P, _P, _P]),
+    'smx_windowed_gae_norm_f32': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int32, c_int32, c_int32, _P, _P, _P,
+                                            c_float, _P, _P]),
+    'smx_ppo_learn_epilogue_f32': (c_int32, [POINTER(LearnEpilogue), _P]),
     'smx_moments_f32': (c_int32, [_P, c_int64, _P, _P]),
     'smx_moments_merge_f32': (c_int32, [_P, c_int32, _P, _P]),
     'smx_adv_normalize_f32': (c_int32, [_P, c_int64, _P, c_float, _P]),

@@ -652,9 +652,7 @@ struct PackArgs {
 
 // one thread per 16-byte word of the packed copy: [tile][chunk][half][lane][4] <- X[16 tile + (lane & 15)]
 // [32 chunk + 8 (lane >> 4) + 4 half + 0..3], zero outside the matrix; X = W or W^T
-__global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= P.total) return;
+__device__ __forceinline__ void pack_word(const PackArgs& P, long i) {
     int pi = 0;
 #pragma unroll
     for (int k = 1; k < MAX_EJOBS; ++k) pi += (k < P.count && i >= P.n[k].base) ? 1 : 0;
@@ -668,7 +666,7 @@ __global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
     const bool tr = bn >= 3;
     const int M = bn == 0 ? N.H1 : (bn == 1 ? N.H2 : (bn == 2 ? N.OUT : (bn == 3 ? N.H1 : N.H2)));
     const int K = bn == 0 ? N.D : (bn == 1 ? N.H1 : (bn == 2 ? N.H2 : (bn == 3 ? N.H2 : N.OUT)));
-    const int C2 = (((K + 31) >> 5) + 1) & ~1;
+    const int C2 = pack_chunks(K);
     const int lane = (int)(w & 63), half = (int)((w >> 6) & 1);
     const long tc = w >> 7;
     const int c = (int)(tc % C2), t = (int)(tc / C2);
@@ -682,6 +680,81 @@ __global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
     *(float4*)(N.packed + 4 * (i - N.base)) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+__global__ __launch_bounds__(256) void epoch_pack_kernel(PackArgs P) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < P.total) pack_word(P, i);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Everything the epoch loop needs prepared once per learn, in ONE launch instead of seven: the
+// z-filtered step-0 observations through the model's filter (+ their transposed copy, the weight-
+// gradient GEMMs' K-contiguous operand) and through the reference policy's filter, the z-filtered
+// obs_next rows (the critic's tail rows), the reference policy's std columns, and the packed weight
+// copies of up to four networks.  Arithmetic as smx_zfilter_forward_f32 / _forward_sums_f32 /
+// smx_epoch_pack_f32 (bit-identical; z_filter.py:74-77, builders.py:126-129).
+// ---------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float* obs0; long ld_obs0; long rows; int D;
+    const float *zmean, *zstd;
+    float *xn, *xnT; long ldT;
+    const float *rsum, *rsumsq, *rcount; float reps; int ref_filter;
+    float* xr;
+    const float* obs_next; long ld_next; float* xnext;
+    const float* ref_log_var; int A; float* ref_std; long ld_ref;
+    int* zero_words; int n_zero;
+    PackArgs pack;
+    long n_x, n_std;            // rows * D, rows * A
+};
+
+__device__ __forceinline__ float zclamp_e(float x, float m, float sdev) {
+    float v = (x - m) / sdev;   // z_filter.py:77
+    if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);       // torch.clamp keeps NaN
+    return v;
+}
+
+__global__ __launch_bounds__(256) void epoch_prepare_kernel(PrepArgs P) {
+    const long tid0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    if (tid0 < P.n_zero) P.zero_words[tid0] = 0;
+    const long nx = P.n_x, n_next = P.xnext ? nx : 0;
+    const long total = 2 * nx + n_next + P.n_std + P.pack.total;
+    for (long i = tid0; i < total; i += stride) {
+        if (i < 2 * nx + n_next) {
+            const int which = i < nx ? 0 : (i < 2 * nx ? 1 : 2);      // xn | xr | xnext
+            const long e = i - (which == 0 ? 0 : (which == 1 ? nx : 2 * nx));
+            const long r = e / P.D;
+            const int k = (int)(e - r * P.D);
+            const float x = which == 2 ? P.obs_next[r * P.ld_next + k] : P.obs0[r * P.ld_obs0 + k];
+            float v = x;
+            if (which == 1) {
+                if (P.ref_filter) {
+                    const float c = P.rcount[0];
+                    const float m = P.rsum[k] / c;
+                    const float var = P.rsumsq[k] / c - m * m;
+                    float sd = sqrtf(var);
+                    if (sd == sd) sd = fmaxf(sd, P.reps);
+                    v = zclamp_e(x, m, sd);
+                }
+                P.xr[e] = v;
+            } else {
+                if (P.zmean) v = zclamp_e(x, P.zmean[k], P.zstd[k]);
+                if (which == 0) {
+                    P.xn[e] = v;
+                    if (P.xnT) P.xnT[(size_t)k * P.ldT + r] = v;
+                } else {
+                    P.xnext[e] = v;
+                }
+            }
+        } else if (i < 2 * nx + n_next + P.n_std) {
+            const long e = i - (2 * nx + n_next);
+            const long r = e / P.A;
+            const int a = (int)(e - r * P.A);
+            P.ref_std[r * P.ld_ref + a] = expf(P.ref_log_var[a]);      // exp(log_var) * ones_like(mean)
+        } else {
+            pack_word(P.pack, i - (2 * nx + n_next + P.n_std));
+        }
+    }
+}
+
 long long* g_tbuf = nullptr;
 
 }  // namespace
@@ -690,10 +763,9 @@ extern "C" int64_t smx_epoch_packed_floats(int32_t D, int32_t H1, int32_t H2, in
     return 4 * pack_off(D, H1, H2, OUT, 5);
 }
 
-extern "C" int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_stream_t stream) {
+static int fill_pack(PackArgs& P, const smx_epoch_pack_t* items, int32_t n) {
     SMX_REQUIRE(items, SMX_E_NULL);
     SMX_REQUIRE(n >= 1 && n <= MAX_EJOBS, SMX_E_SHAPE);
-    PackArgs P;
     P.count = n;
     long base = 0;
     for (int k = 0; k < n; ++k) {
@@ -707,7 +779,47 @@ extern "C" int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_
         base += smx_epoch_packed_floats(m.D, m.H1, m.H2, m.OUT) / 4;
     }
     P.total = base;
-    hipLaunchKernelGGL(epoch_pack_kernel, dim3((unsigned)((base + 255) / 256)), dim3(256), 0, smx_s(stream), P);
+    return SMX_OK;
+}
+
+extern "C" int smx_epoch_pack_f32(const smx_epoch_pack_t* items, int32_t n, smx_stream_t stream) {
+    PackArgs P;
+    const int rc = fill_pack(P, items, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(epoch_pack_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, smx_s(stream), P);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_epoch_prepare_f32(const smx_epoch_prep_t* a, smx_stream_t stream) {
+    SMX_REQUIRE(a && a->obs0 && a->xn && a->xr, SMX_E_NULL);
+    SMX_REQUIRE(a->rows > 0 && a->D > 0 && a->ld_obs0 >= a->D, SMX_E_SHAPE);
+    SMX_REQUIRE((a->zmean == nullptr) == (a->zstd == nullptr), SMX_E_NULL);
+    SMX_REQUIRE(!a->xnT || a->ldT >= a->rows, SMX_E_SHAPE);
+    SMX_REQUIRE(!a->ref_filter || (a->ref_sum && a->ref_sumsq && a->ref_count), SMX_E_NULL);
+    SMX_REQUIRE(!a->xnext || (a->obs_next && a->ld_next >= a->D), SMX_E_SHAPE);
+    SMX_REQUIRE(!a->ref_std || (a->ref_log_var && a->A > 0 && a->ld_ref >= a->A), SMX_E_SHAPE);
+    SMX_REQUIRE(a->n_zero >= 0 && a->n_zero <= 256 && (a->n_zero == 0 || a->zero_words), SMX_E_SHAPE);
+    PrepArgs P;
+    memset(&P, 0, sizeof(P));
+    P.obs0 = a->obs0; P.ld_obs0 = (long)a->ld_obs0; P.rows = (long)a->rows; P.D = a->D;
+    P.zmean = a->zmean; P.zstd = a->zstd; P.xn = a->xn; P.xnT = a->xnT; P.ldT = (long)a->ldT;
+    P.rsum = a->ref_sum; P.rsumsq = a->ref_sumsq; P.rcount = a->ref_count; P.reps = a->ref_eps;
+    P.ref_filter = a->ref_filter; P.xr = a->xr;
+    P.obs_next = a->obs_next; P.ld_next = (long)a->ld_next; P.xnext = a->xnext;
+    P.ref_log_var = a->ref_log_var; P.A = a->A; P.ref_std = a->ref_std; P.ld_ref = (long)a->ld_ref;
+    P.zero_words = a->zero_words; P.n_zero = a->n_zero;
+    P.n_x = P.rows * P.D;
+    P.n_std = a->ref_std ? P.rows * a->A : 0;
+    P.pack.count = 0; P.pack.total = 0;
+    if (a->n_pack > 0) {
+        const int rc = fill_pack(P.pack, a->pack, a->n_pack);
+        if (rc) return rc;
+    }
+    const long total = 2 * P.n_x + (P.xnext ? P.n_x : 0) + P.n_std + P.pack.total;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(epoch_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), P);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -18,6 +18,7 @@
 //     the way into LDS.  Rows of 36 floats (144 B) make every ds_read_b128 conflict-free.
 //   * FP32 MFMA (exact fp32, no bf16/xf32): 1e-5 parity with the CPU reference is the contract.
 #include "smx_common.h"
+#include <string.h>
 
 namespace {
 
@@ -497,8 +498,28 @@ __global__ __launch_bounds__(256, 1) void mlp3_fused_kernel(FusedArgs A) {
 // ---------------------------------------------------------------------------
 // weight repacking: [KC][NT*32][32] K-chunked, zero padded
 // ---------------------------------------------------------------------------
+// optional rider: the z-filter statistics of the pass that follows (smx_zfilter_stats_f32's arithmetic,
+// z_filter.py:74-76) -- the repack and the statistics are the two launches in front of every critic pass
+struct ZStatsRider {
+    const float *rs, *rsq, *cnt;
+    float *mean, *stdv;
+    int D;
+    float eps;
+};
+
 __global__ __launch_bounds__(256) void mlp3_pack_kernel(smx_mlp3_t net, float* __restrict__ packed,
-                                                        int NT1, int NT2, int KC1) {
+                                                        int NT1, int NT2, int KC1, ZStatsRider Z) {
+    if (Z.rs) {
+        for (int k = blockIdx.x * 256 + threadIdx.x; k < Z.D; k += gridDim.x * 256) {
+            const float c = Z.cnt[0];
+            const float m = Z.rs[k] / c;                // z_filter.py:74
+            const float var = Z.rsq[k] / c - m * m;     // z_filter.py:75
+            float sd = sqrtf(var);                      // .pow(0.5): NaN for var < 0, like torch
+            if (sd == sd) sd = fmaxf(sd, Z.eps);        // torch.clamp(min=eps) propagates NaN
+            Z.mean[k] = m;
+            Z.stdv[k] = sd;
+        }
+    }
     const PackLayout L = pack_layout(NT1, NT2, KC1);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < L.total; i += (size_t)gridDim.x * 256) {
         float v = 0.f;
@@ -571,8 +592,8 @@ extern "C" size_t smx_mlp3_packed_bytes(int32_t D, int32_t H1, int32_t H2, int32
     return pack_layout(nt1, nt2, (D + 31) / 32).total * sizeof(float);
 }
 
-extern "C" int smx_mlp3_pack_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
-                                 smx_stream_t stream) {
+static int pack_launch(const smx_mlp3_t* net, float* packed, size_t packed_bytes, const ZStatsRider& Z,
+                       smx_stream_t stream) {
     SMX_REQUIRE(net && packed && net->W1 && net->b1 && net->W2 && net->b2 && net->W3 && net->b3,
                 SMX_E_NULL);
     SMX_REQUIRE(net->D > 0 && net->H1 > 0 && net->H2 > 0 && net->OUT > 0, SMX_E_SHAPE);
@@ -585,9 +606,28 @@ extern "C" int smx_mlp3_pack_f32(const smx_mlp3_t* net, float* packed, size_t pa
     unsigned blocks = (unsigned)((L.total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(mlp3_pack_kernel, dim3(blocks), dim3(256), 0, smx_s(stream), *net, packed, nt1,
-                       nt2, KC1);
+                       nt2, KC1, Z);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
+}
+
+extern "C" int smx_mlp3_pack_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
+                                 smx_stream_t stream) {
+    ZStatsRider Z;
+    memset(&Z, 0, sizeof(Z));
+    return pack_launch(net, packed, packed_bytes, Z, stream);
+}
+
+extern "C" int smx_mlp3_pack_zstats_f32(const smx_mlp3_t* net, float* packed, size_t packed_bytes,
+                                        const float* running_sum, const float* running_sumsq,
+                                        const float* count, int32_t D, float eps, float* mean_out,
+                                        float* std_out, smx_stream_t stream) {
+    SMX_REQUIRE(running_sum && running_sumsq && count && mean_out && std_out, SMX_E_NULL);
+    SMX_REQUIRE(D > 0, SMX_E_SHAPE);
+    ZStatsRider Z;
+    Z.rs = running_sum; Z.rsq = running_sumsq; Z.cnt = count; Z.mean = mean_out; Z.stdv = std_out;
+    Z.D = D; Z.eps = eps;
+    return pack_launch(net, packed, packed_bytes, Z, stream);
 }
 
 extern "C" int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_t H1, int32_t H2,

@@ -3,11 +3,12 @@
 // coalesced row loads, LDS-staged masked values, wave-shuffle reductions.
 // Reference: surreal/learner/ppo.py:387-418, surreal/model/z_filter.py:44-79.
 #include "smx_common.h"
+#include "smx_moments.inc.h"
 
 // ---------------------------------------------------------------------------
 // One wave per sub-trajectory b.  LDS per wave: Vm[N+1] | r[N] | delta[N]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gae_kernel(
+__device__ __forceinline__ void gae_body(
     const float* __restrict__ values, const float* __restrict__ values_tail,
     const float* __restrict__ rewards,
     const float* __restrict__ dones, const float* __restrict__ gpow,
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void gae_kernel(
         }
     }
     __syncthreads();
-    if (b >= B) return;
+    if (b < B) {
     const int E = N - H + 1;
     if (E == 1) {
         // non-RNN: one return / advantage per row, a gamma-lambda weighted reduction
@@ -69,6 +70,86 @@ __global__ __launch_bounds__(256) void gae_kernel(
             adv[(size_t)b * E + s] = as;
         }
     }
+    }
+}
+
+__global__ __launch_bounds__(256) void gae_kernel(
+    const float* __restrict__ values, const float* __restrict__ values_tail,
+    const float* __restrict__ rewards, const float* __restrict__ dones, const float* __restrict__ gpow,
+    const float* __restrict__ lpow, float gamma, float gamma_H, int B, int N, int H,
+    float* __restrict__ adv, float* __restrict__ ret) {
+    gae_body(values, values_tail, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret);
+}
+
+// the LAST workgroup of a launch to get here returns true (device-scope release / acquire around a
+// ticket counter, which it resets for the next launch): the place for a launch's global epilogue
+__device__ __forceinline__ bool last_block_done(int* ticket) {
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(ticket, 1);
+        is_last = (t == (int)gridDim.x - 1);
+        if (is_last) *ticket = 0;
+        __threadfence();
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+
+// batch moments {n, mean, M2} of x[0, n) in fp64 (two passes) by ONE workgroup of blockDim.x <= 1024 threads
+__device__ __forceinline__ void block_moments(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ double red[16];
+    __shared__ double bc;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += (double)__builtin_nontemporal_load(x + i);
+    s = smx_wave_sum_d(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < nw; ++i) t += red[i];
+        bc = t / (double)n;
+    }
+    __syncthreads();
+    const double mean = bc;
+    double q = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const double d = (double)__builtin_nontemporal_load(x + i) - mean;
+        q += d * d;
+    }
+    q = smx_wave_sum_d(q);
+    __syncthreads();
+    if (lane == 0) red[w] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < nw; ++i) t += red[i];
+        out[0] = (float)n;
+        out[1] = (float)mean;
+        out[2] = (float)t;
+        bc = t;
+    }
+    __syncthreads();
+}
+
+// GAE + (optionally) the batch normalisation of the advantages (ppo.py:402-405, 413-416) in the same
+// launch: the last workgroup to finish forms the moments and normalises in place
+__global__ __launch_bounds__(256) void gae_norm_kernel(
+    const float* __restrict__ values, const float* __restrict__ values_tail,
+    const float* __restrict__ rewards, const float* __restrict__ dones, const float* __restrict__ gpow,
+    const float* __restrict__ lpow, float gamma, float gamma_H, int B, int N, int H,
+    float* __restrict__ adv, float* __restrict__ ret, float* __restrict__ norm_mom, float min_std,
+    int* __restrict__ ticket) {
+    gae_body(values, values_tail, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret);
+    if (!last_block_done(ticket)) return;
+    const long n = (long)B * (N - H + 1);
+    block_moments(adv, n, norm_mom);
+    const float cnt = (float)n, mean = norm_mom[1], m2 = norm_mom[2];
+    const float stdv = sqrtf(m2 / (cnt - 1.0f));             // advs.std(): unbiased
+    const float den = (min_std > stdv) ? min_std : stdv;     // Python max(std, 1e-4)
+    for (long i = threadIdx.x; i < n; i += blockDim.x) adv[i] = (__builtin_nontemporal_load(adv + i) - mean) / den;
 }
 
 extern "C" int smx_windowed_gae_returns_f32(const float* values, const float* values_tail,
@@ -88,6 +169,27 @@ extern "C" int smx_windowed_gae_returns_f32(const float* values, const float* va
     }
     hipLaunchKernelGGL(gae_kernel, dim3((B + 3) / 4), dim3(256), lds, smx_s(stream), values,
                        values_tail, rewards, dones, gamma_pow, lam_pow, gamma, gamma_H, B, N, H, adv, ret);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_windowed_gae_norm_f32(const float* values, const float* values_tail, const float* rewards,
+                                         const float* dones, const float* gamma_pow, const float* lam_pow,
+                                         float gamma, float gamma_H, int32_t B, int32_t N, int32_t H, float* adv,
+                                         float* ret, float* adv_moments, float min_std, int32_t* ticket,
+                                         smx_stream_t stream) {
+    SMX_REQUIRE(values && rewards && dones && gamma_pow && lam_pow && adv && ret && adv_moments && ticket, SMX_E_NULL);
+    SMX_REQUIRE(B > 0 && N > 0 && H > 0 && H <= N, SMX_E_SHAPE);
+    const size_t lds = (size_t)4 * (3 * (size_t)N + 1) * sizeof(float);
+    SMX_REQUIRE(lds <= 128 * 1024, SMX_E_UNSUPPORTED);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gae_norm_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(gae_norm_kernel, dim3((B + 3) / 4), dim3(256), lds, smx_s(stream), values, values_tail,
+                       rewards, dones, gamma_pow, lam_pow, gamma, gamma_H, B, N, H, adv, ret, adv_moments, min_std,
+                       (int*)ticket);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -333,6 +435,95 @@ extern "C" int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows,
     SMX_REQUIRE(rows > 0 && D > 0 && ldx >= D, SMX_E_SHAPE);
     hipLaunchKernelGGL(zupdate_kernel, dim3((D + 63) / 64), dim3(1024), 0, smx_s(stream), x,
                        (long)ldx, (long)rows, D, running_sum, running_sumsq, count, count_rows);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// What PPOLearner._optimize does after its epoch loops (ppo.py:565-584), in ONE launch instead of
+// four: the explained variance / value loss of every value epoch from their block moments, the
+// moments of the return targets, the z-filter update on the step-0 observations -- independent
+// pieces, one per group of workgroups -- and, by the last workgroup to finish, the means the learner
+// reports (they read the UPDATED z-filter sums).
+//   blocks [0, nz)            column sums of 64 observation features each (zupdate_kernel's scheme)
+//   block  nz                 moments of `ret`
+//   blocks (nz, nz + nv]      value-loss finalize, 16 epochs (waves) per block
+// ---------------------------------------------------------------------------
+struct EpilogueArgs {
+    const float* x; long ldx; long rows; int D;
+    float *rs, *rsq, *cnt; float count_rows;
+    const float* ret; long n_ret; float* ret_mom;
+    const float* vpartials; int n_epochs, nblk; float* vstats; int vstride;
+    const float* log_var; int A; float* out4;
+    int* ticket;
+    int nz;
+};
+
+__global__ __launch_bounds__(1024) void learn_epilogue_kernel(EpilogueArgs P) {
+    __shared__ float s1[16][64], s2[16][64];
+    __shared__ double red4[16][4];
+    const int blk = blockIdx.x;
+    if (blk < P.nz) {
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int col = blk * 64 + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        if (col < P.D) {
+            const float* x = P.x;
+            const long ldx = P.ldx, rows = P.rows;
+            long r = g;
+            for (; r + 48 < rows; r += 64) {
+                const float v0 = x[r * ldx + col], v1 = x[(r + 16) * ldx + col];
+                const float v2 = x[(r + 32) * ldx + col], v3 = x[(r + 48) * ldx + col];
+                a0 += v0; q0 += v0 * v0;
+                a1 += v1; q1 += v1 * v1;
+                a2 += v2; q2 += v2 * v2;
+                a3 += v3; q3 += v3 * v3;
+            }
+            for (; r < rows; r += 16) {
+                const float v = x[r * ldx + col];
+                a0 += v; q0 += v * v;
+            }
+        }
+        s1[g][c] = (a0 + a1) + (a2 + a3);
+        s2[g][c] = (q0 + q1) + (q2 + q3);
+        __syncthreads();
+        if (g == 0 && col < P.D) {
+            float ta = 0.f, tq = 0.f;
+            for (int k = 0; k < 16; ++k) { ta += s1[k][c]; tq += s2[k][c]; }
+            P.rs[col] += ta;    // z_filter.py:55
+            P.rsq[col] += tq;   // z_filter.py:56
+        }
+        if (blk == 0 && threadIdx.x == 0) P.cnt[0] += P.count_rows;  // z_filter.py:57
+    } else if (blk == P.nz) {
+        block_moments(P.ret, P.n_ret, P.ret_mom);
+    } else {
+        const int e = (blk - P.nz - 1) * 16 + (threadIdx.x >> 6);
+        if (e < P.n_epochs)
+            value_finalize_wave(P.vpartials + (size_t)e * P.nblk * 8, P.nblk, P.vstats + (size_t)e * P.vstride,
+                                threadIdx.x & 63);
+    }
+    if (!last_block_done(P.ticket)) return;
+    final_stats_block(P.log_var, P.A, P.nz ? P.rs : nullptr, P.rsq, P.cnt, P.D, P.out4, red4);
+}
+
+extern "C" int smx_ppo_learn_epilogue_f32(const smx_learn_epilogue_t* a, smx_stream_t stream) {
+    SMX_REQUIRE(a && a->ret && a->ret_moments && a->log_var && a->out4 && a->ticket, SMX_E_NULL);
+    SMX_REQUIRE(a->n_ret > 0 && a->A > 0, SMX_E_SHAPE);
+    SMX_REQUIRE(!a->x || (a->running_sum && a->running_sumsq && a->count && a->rows > 0 && a->D > 0 && a->ldx >= a->D),
+                SMX_E_SHAPE);
+    SMX_REQUIRE(a->n_epochs == 0 || (a->v_partials && a->v_stats && a->nblk > 0 && a->stats_stride >= 2), SMX_E_SHAPE);
+    SMX_REQUIRE(a->n_epochs == 0 || ((uintptr_t)a->v_partials & 15) == 0, SMX_E_ALIGN);
+    EpilogueArgs P;
+    P.x = a->x; P.ldx = (long)a->ldx; P.rows = (long)a->rows; P.D = a->D;
+    P.rs = a->running_sum; P.rsq = a->running_sumsq; P.cnt = a->count; P.count_rows = a->count_rows;
+    P.ret = a->ret; P.n_ret = (long)a->n_ret; P.ret_mom = a->ret_moments;
+    P.vpartials = a->v_partials; P.n_epochs = a->n_epochs; P.nblk = a->nblk; P.vstats = a->v_stats;
+    P.vstride = a->stats_stride;
+    P.log_var = a->log_var; P.A = a->A; P.out4 = a->out4; P.ticket = (int*)a->ticket;
+    P.nz = a->x ? (a->D + 63) / 64 : 0;
+    const int nv = (a->n_epochs + 15) / 16;
+    hipLaunchKernelGGL(learn_epilogue_kernel, dim3(P.nz + 1 + nv), dim3(1024), 0, smx_s(stream), P);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

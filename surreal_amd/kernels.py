@@ -75,6 +75,12 @@ class HipKernels(object):
         L.call('smx_mlp3_pack_f32', ctypes.byref(net.desc), L.ptr(packed), packed.numel() * 4,
                self._st())
 
+    def mlp3_pack_zstats(self, net, packed, zf):
+        """mlp3_pack + the statistics of ZFilter `zf` (its _mean / _std buffers) in one launch"""
+        L.call('smx_mlp3_pack_zstats_f32', ctypes.byref(net.desc), L.ptr(packed), packed.numel() * 4,
+               L.ptr(zf.running_sum), L.ptr(zf.running_sumsq), L.ptr(zf.count), zf.running_sum.numel(),
+               float(zf.eps), L.ptr(zf._mean), L.ptr(zf._std), self._st())
+
     def mlp3_forward_fused(self, packed, net, x_main, x_tail, zmean, zstd, out, act):
         G, T0, D = x_main.shape
         T1 = 0 if x_tail is None else x_tail.shape[1]
@@ -142,6 +148,35 @@ class HipKernels(object):
             arr[k].net = ctypes.pointer(net.desc)
             arr[k].packed = L.ptr(packed)
         L.call('smx_epoch_pack_f32', arr, len(items), self._st())
+
+    def epoch_prepare(self, obs0, xn, xnT, xr, zmean=None, zstd=None, ref_filter=None, obs_next=None, xnext=None,
+                      ref_log_var=None, ref_std=None, pack=(), zero_words=None):
+        """the per-learn preparation of the epoch loops in one launch (smx_epoch_prepare_f32): obs0 /
+        obs_next are row-strided [rows, D] views, ref_filter the reference policy's ZFilter (or None),
+        ref_std the [rows, A] std columns of ref_pol (a column-slice view), pack [(net, packed)]"""
+        rows, D = obs0.shape
+        a = L.EpochPrep()
+        a.obs0, a.ld_obs0, a.rows, a.D = L.ptr(obs0), _row_stride(obs0, D), rows, D
+        a.zmean, a.zstd = L.ptr(zmean), L.ptr(zstd)
+        a.xn, a.xnT = L.ptr(xn), L.ptr(xnT)
+        a.ldT = 0 if xnT is None else (xnT.stride(0) if xnT.shape[0] > 1 else xnT.shape[1])
+        if ref_filter is not None:
+            a.ref_sum, a.ref_sumsq, a.ref_count = L.ptr(ref_filter.running_sum), L.ptr(ref_filter.running_sumsq), \
+                L.ptr(ref_filter.count)
+            a.ref_eps, a.ref_filter = float(ref_filter.eps), 1
+        a.xr = L.ptr(xr)
+        if xnext is not None:
+            a.obs_next, a.ld_next, a.xnext = L.ptr(obs_next), _row_stride(obs_next, D), L.ptr(xnext)
+        if ref_std is not None:
+            A = ref_std.shape[1]
+            a.A, a.ref_log_var, a.ref_std, a.ld_ref = A, L.ptr(ref_log_var), L.ptr(ref_std), _row_stride(ref_std, A)
+        if zero_words is not None:
+            a.zero_words, a.n_zero = L.ptr(zero_words), zero_words.numel()
+        a.n_pack = len(pack)
+        for k, (net, packed) in enumerate(pack):
+            a.pack[k].net = ctypes.pointer(net.desc)
+            a.pack[k].packed = L.ptr(packed)
+        L.call('smx_epoch_prepare_f32', ctypes.byref(a), self._st())
 
     _EPOCH_LOSS = {None: L.EPOCH_LOSS_NONE, 'policy': L.EPOCH_LOSS_POLICY, 'value': L.EPOCH_LOSS_VALUE,
                    'rhs_surr': L.EPOCH_RHS_SURR, 'rhs_kl': L.EPOCH_RHS_KL}
@@ -213,6 +248,30 @@ class HipKernels(object):
                L.ptr(dones),
                L.ptr(gpow), L.ptr(lpow), float(gamma), float(gamma_H), B, N, H, L.ptr(adv),
                L.ptr(ret), self._st())
+
+    def gae_norm(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret, adv_mom, min_std, ticket,
+                 values_tail=None):
+        """gae + moments + adv_normalize in one launch (single rank)"""
+        L.call('smx_windowed_gae_norm_f32', L.ptr(values), L.ptr(values_tail), L.ptr(rewards), L.ptr(dones),
+               L.ptr(gpow), L.ptr(lpow), float(gamma), float(gamma_H), B, N, H, L.ptr(adv), L.ptr(ret), L.ptr(adv_mom),
+               float(min_std), L.ptr(ticket), self._st())
+
+    def learn_epilogue(self, ret, ret_mom, log_var, out4, ticket, zfilter=None, x=None, count_rows=0, v_partials=None,
+                       n_epochs=0, nblk=0, v_stats=None, stats_stride=0):
+        """value_finalize + moments(ret) + zfilter_update(x) + final_stats in one launch (single rank)"""
+        a = L.LearnEpilogue()
+        if zfilter is not None:
+            rows, D = x.shape
+            a.x, a.ldx, a.rows, a.D = L.ptr(x), _row_stride(x, D), rows, D
+            a.running_sum, a.running_sumsq, a.count = L.ptr(zfilter.running_sum), L.ptr(zfilter.running_sumsq), \
+                L.ptr(zfilter.count)
+            a.count_rows = float(count_rows)
+        a.A = log_var.numel()
+        a.ret, a.n_ret, a.ret_moments = L.ptr(ret), ret.numel(), L.ptr(ret_mom)
+        a.v_partials, a.n_epochs, a.nblk, a.v_stats, a.stats_stride = L.ptr(v_partials), n_epochs, nblk, L.ptr(v_stats), \
+            stats_stride
+        a.log_var, a.out4, a.ticket = L.ptr(log_var), L.ptr(out4), L.ptr(ticket)
+        L.call('smx_ppo_learn_epilogue_f32', ctypes.byref(a), self._st())
 
     def moments(self, x, out):
         L.call('smx_moments_f32', L.ptr(x), x.numel(), L.ptr(out), self._st())

@@ -417,6 +417,9 @@ class PPOLearner(Learner):
                     K.epoch_supported(act) and K.epoch_supported(cri))
         vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
         ws.nblk_v = vblocks(rows)
+        # single rank: GAE + normalisation and the end-of-learn statistics are one launch each
+        ws.merged_tail = ws.fused and self.world_size == 1
+        ws.ticket = torch.zeros(2, dtype=torch.int32, device=dev)
         if ws.fused:
             assert ws.nblk_p == K.epoch_blocks(rows)
             # the weights in the forward kernel's fragment order (model, critic, reference policy)
@@ -546,15 +549,18 @@ class PPOLearner(Learner):
             self.K.mlp3_forward_multi([tail])
         self._enqueue_gae_from_values(ws, obs, rewards, dones)
 
-    def _enqueue_critic_pass(self, ws, obs, obs_next):
+    def _enqueue_critic_pass(self, ws, obs, obs_next, filter_tail=True):
         """the critic over all steps.  Returns the forward job of the obs_next rows when they are
-        left to the layered kernels (the caller launches it, alone or together with other jobs)."""
+        left to the layered kernels (the caller launches it, alone or together with other jobs;
+        filter_tail=False: the caller also z-filters those rows into ws.xnext)."""
         K, m = self.K, self.model
         B, N, D = obs.shape
         zm = zs = None
-        if self.use_z_filter:
-            zm, zs = m.z_filter.refresh_stats()
-        K.mlp3_pack(m.critic, ws.packed)
+        if self.use_z_filter:            # repack + z-filter statistics: one launch
+            K.mlp3_pack_zstats(m.critic, ws.packed, m.z_filter)
+            zm, zs = m.z_filter._mean, m.z_filter._std
+        else:
+            K.mlp3_pack(m.critic, ws.packed)
         if not ws.split_tail:
             K.mlp3_forward_fused(ws.packed, m.critic, obs, obs_next, zm, zs, ws.vals, L.SMX_ACT_NONE)
             return None
@@ -562,7 +568,9 @@ class PPOLearner(Learner):
         # than B*N: the fused kernel takes the B*N step rows, the B obs_next rows go through
         # the layered small-batch kernels (same arithmetic, tests check both against the oracle)
         K.mlp3_forward_fused(ws.packed, m.critic, obs, None, zm, zs, ws.vals[:B * N], L.SMX_ACT_NONE)
-        if self.use_z_filter:
+        if not filter_tail:
+            pass
+        elif self.use_z_filter:
             K.zfilter_forward(obs_next[:, 0, :], zm, zs, ws.xnext)
         else:
             ws.xnext.copy_(obs_next[:, 0, :])
@@ -572,6 +580,11 @@ class PPOLearner(Learner):
     def _enqueue_gae_from_values(self, ws, obs, rewards, dones):
         K = self.K
         B, N, D = obs.shape
+        if ws.merged_tail and self.norm_adv:
+            K.gae_norm(ws.vals[:B * N] if ws.split_tail else ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma,
+                       self.gamma ** N, B, N, N, ws.adv, ws.ret, ws.adv_mom, 1e-4, ws.ticket[0:1],
+                       values_tail=ws.vals[B * N:] if ws.split_tail else None)
+            return
         if ws.split_tail:
             K.gae(ws.vals[:B * N], rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** N,
                   B, N, N, ws.adv, ws.ret, values_tail=ws.vals[B * N:])
@@ -751,7 +764,6 @@ class PPOLearner(Learner):
         A = self.action_dim
         n_total = ws.n_total
         # the reference policy and the critic's obs_next rows: one forward-only launch, then GAE
-        K.epoch_pack([(m.actor, ws.pk_actor), (m.critic, ws.pk_critic), (ref_job['net'], ws.pk_ref)])
         pre = [dict(net=ref_job['net'], packed=ws.pk_ref, x=ref_job['x'], out=ref_job['out'], act=L.SMX_ACT_TANH)]
         if tail is not None:
             pre.append(dict(net=tail['net'], packed=ws.pk_critic, x=tail['x'], out=tail['out'], act=L.SMX_ACT_NONE))
@@ -832,7 +844,8 @@ class PPOLearner(Learner):
                                 ws.sumsq_a, ws.np_a + 1, ws.ctrl_f, 0, True,
                                 ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1], pack=(m.actor, ws.pk_actor))
             main.wait_stream(side)
-            K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+            if not ws.merged_tail:
+                K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
             return
         for e in range(max(Ep + 1, Ev)):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
@@ -861,7 +874,8 @@ class PPOLearner(Learner):
                             ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
             if pol_u != val:         # (an unpaired step -- epoch_policy != epoch_baseline -- repacks separately)
                 K.epoch_pack([(m.actor, ws.pk_actor)] if pol_u else [(m.critic, ws.pk_critic)])
-        K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
+        if not ws.merged_tail:
+            K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
     def _enqueue_tail_exchange(self, ws, obs0, actions0, behave0):
         """end of a data-parallel lock-step learn: ONE all-gather carries the final policy pass's
@@ -931,18 +945,32 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
-        ws.zero_block.zero_()                    # stop flag, epochs done, per-epoch policy statistics
         lockstep = self.epoch_schedule == 'lockstep'
+        fused = lockstep and ws.fused
+        if not fused:
+            ws.zero_block.zero_()                # stop flag, epochs done, per-epoch policy statistics
         tail = None
         if lockstep:
-            tail = self._enqueue_critic_pass(ws, obs, obs_next)
+            tail = self._enqueue_critic_pass(ws, obs, obs_next, filter_tail=not fused)
         else:
             self._enqueue_gae(ws, obs, obs_next, rewards, dones)
 
         obs0 = obs[:, 0, :]                      # ppo.py:527-537 (views, no copies)
         actions0 = actions[:, 0, :]
         behave0 = pds[:, 0, :]
-        if self.use_z_filter:
+        if fused:
+            # ONE launch: both z-filtered copies of the step-0 observations (+ the transposed one), the
+            # critic's obs_next rows, the reference policy's std columns, the packed weights of the
+            # three networks, and the zeroing of the control block's per-learn words
+            zf = m.z_filter if self.use_z_filter else None
+            K.epoch_prepare(obs0, ws.xn, ws.xnT, ws.xr, zmean=zf._mean if zf else None, zstd=zf._std if zf else None,
+                            ref_filter=ref.z_filter if self.use_z_filter else None,
+                            obs_next=obs_next[:, 0, :] if tail is not None else None,
+                            xnext=ws.xnext if tail is not None else None,
+                            ref_log_var=ref.log_var.view(-1), ref_std=ws.ref_pol[:, A:],
+                            pack=[(m.actor, ws.pk_actor), (m.critic, ws.pk_critic), (ref.actor, ws.pk_ref)],
+                            zero_words=ws.zero_block.view(torch.int32))
+        elif self.use_z_filter:
             zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed by the critic pass
             K.zfilter_forward(obs0, zm, zs, ws.xn)
             rz = ref.z_filter               # statistics + filter in one launch
@@ -950,12 +978,13 @@ class PPOLearner(Learner):
         else:
             ws.xn.copy_(obs0)
             ws.xr.copy_(obs0)
-        ws.xnT.copy_(ws.xn.t())
         # ref_pol = ref_target_model.forward_actor(obs_iter)   (ppo.py:539): the mean goes
         # straight into the left half of ref_pol, the std is exp(log_var) broadcast
         ref_job = dict(net=ref.actor, x=ws.xr, h1=ws.h1r, h2=ws.h2r, out=ws.ref_pol[:, :A],
                        act=L.SMX_ACT_TANH)
-        ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
+        if not fused:
+            ws.xnT.copy_(ws.xn.t())
+            ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
         if not lockstep:
             K.mlp3_forward_multi([ref_job])
 
@@ -995,6 +1024,14 @@ class PPOLearner(Learner):
         if lockstep and ws.tail_deferred:
             self._enqueue_tail_exchange(ws, obs0, actions0, behave0)
             self._enqueue_final_stats(ws)
+            return
+        if fused and ws.merged_tail:
+            # value-loss finalize, _avg_return_targ (ppo.py:571), model.z_update(obs_iter) (:578-579) and the
+            # reported means: one launch
+            K.learn_epilogue(ws.ret, ws.ret_mom, m.log_var.view(-1), ws.fin, ws.ticket[1:2],
+                             zfilter=m.z_filter if self.use_z_filter else None, x=obs0, count_rows=B,
+                             v_partials=ws.vpart, n_epochs=self.epoch_baseline, nblk=ws.vpart.shape[1],
+                             v_stats=ws.vstats, stats_stride=L.VS_STRIDE)
             return
         K.moments(ws.ret, ws.ret_mom)           # _avg_return_targ (ppo.py:571)
         if self.world_size > 1:

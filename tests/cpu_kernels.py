@@ -65,6 +65,10 @@ class TorchCpuKernels(object):
             packed[o:o + n].copy_(net.views[k].reshape(-1))
             o += n
 
+    def mlp3_pack_zstats(self, net, packed, zf):
+        self.mlp3_pack(net, packed)
+        self.zfilter_stats(zf.running_sum, zf.running_sumsq, zf.count, zf.eps, zf._mean, zf._std)
+
     @staticmethod
     def _unpack(packed, net):
         out, o = {}, 0
@@ -155,6 +159,31 @@ class TorchCpuKernels(object):
         for net, packed in items:      # the double keeps a flat copy: the forward must see THESE values
             flat = torch.cat([net.views[k].reshape(-1) for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')])
             packed[:flat.numel()].copy_(flat)
+
+    def epoch_prepare(self, obs0, xn, xnT, xr, zmean=None, zstd=None, ref_filter=None, obs_next=None, xnext=None,
+                      ref_log_var=None, ref_std=None, pack=(), zero_words=None):
+        if zmean is not None:
+            self.zfilter_forward(obs0, zmean, zstd, xn)
+        else:
+            xn.copy_(obs0)
+        if xnT is not None:
+            xnT.copy_(xn.t())
+        if ref_filter is not None:
+            self.zfilter_forward_sums(obs0, ref_filter.running_sum, ref_filter.running_sumsq, ref_filter.count,
+                                      ref_filter.eps, xr)
+        else:
+            xr.copy_(obs0)
+        if xnext is not None:
+            if zmean is not None:
+                self.zfilter_forward(obs_next, zmean, zstd, xnext)
+            else:
+                xnext.copy_(obs_next)
+        if ref_std is not None:
+            ref_std.copy_(torch.exp(ref_log_var).view(1, -1).expand(ref_std.shape))
+        if zero_words is not None:
+            zero_words.zero_()
+        if pack:
+            self.epoch_pack(list(pack))
 
     @staticmethod
     def _packed_views(pk, net):
@@ -262,6 +291,21 @@ class TorchCpuKernels(object):
             a_out[:, s] = torch.sum(tds[:, s:s + H] * g * l, 1)
         adv.view(B, E).copy_(a_out)
         ret.view(B, E).copy_(r_out)
+
+    def gae_norm(self, values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret, adv_mom, min_std, ticket,
+                 values_tail=None):
+        self.gae(values, rewards, dones, gpow, lpow, gamma, gamma_H, B, N, H, adv, ret, values_tail=values_tail)
+        self.moments(adv, adv_mom)
+        self.adv_normalize(adv, adv_mom, min_std)
+
+    def learn_epilogue(self, ret, ret_mom, log_var, out4, ticket, zfilter=None, x=None, count_rows=0, v_partials=None,
+                       n_epochs=0, nblk=0, v_stats=None, stats_stride=0):
+        if n_epochs:
+            self.value_finalize(v_partials, n_epochs, nblk, v_stats, stats_stride)
+        self.moments(ret, ret_mom)
+        if zfilter is not None:
+            self.zfilter_update(x, zfilter.running_sum, zfilter.running_sumsq, zfilter.count, count_rows)
+        self.final_stats(log_var, zfilter, out4)
 
     def moments(self, x, out):
         xd = x.double().reshape(-1)

@@ -157,3 +157,116 @@ def test_epoch_early_exit_and_final_pass(K):
     close(T['d']['stats'], T['c']['stats'], atol=1e-5, rtol=2e-5)
     assert int(T['d']['ctrl'].cpu().view(torch.int32)[L.C_EPOCHS_DONE]) == 0
     assert float(T['d']['dz1aT'].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('rows,N,D,A,use_z,tail', [(1024, 3, 376, 17, True, True), (37, 2, 29, 5, True, False),
+                                                  (16, 1, 12, 3, False, True)])
+def test_epoch_prepare_equals_the_separate_launches(K, rows, N, D, A, use_z, tail):
+    """smx_epoch_prepare_f32 (one launch) against the z-filter / copy / exp / pack steps it replaces"""
+    import types
+    g = torch.Generator().manual_seed(rows + D)
+    obs = torch.randn(rows, N, D, generator=g) * 2 + 0.3
+    obs_next = torch.randn(rows, 1, D, generator=g)
+    zmean, zstd = torch.randn(D, generator=g) * 0.2, torch.rand(D, generator=g) + 0.5
+    ref = types.SimpleNamespace(running_sum=torch.randn(D, generator=g) * 50, running_sumsq=torch.rand(D, generator=g) * 4000 + 500,
+                                count=torch.tensor([1000.0]), eps=1e-5)
+    log_var = -1.0 + 0.3 * torch.randn(A, generator=g)
+    act_c, act_d = make_net(D, 24, 16, A, 5, 'cuda')
+    cri_c, cri_d = make_net(D, 24, 16, 1, 6, 'cuda')
+
+    def side(dv, Kx, act, cri):
+        t = lambda x: x.to(dv)  # noqa: E731
+        f = lambda *s: torch.full(s, 7.0, device=dv)  # noqa: E731
+        o, on = t(obs), t(obs_next)
+        out = dict(xn=f(rows, D), xnT=torch.full((D, rows + 16), 7.0, device=dv)[:, :rows], xr=f(rows, D), xnext=f(rows, D),
+                   ref_pol=f(rows, 2 * A), zero=torch.full((20,), 3, dtype=torch.int32, device=dv),
+                   pa=f(max(Kx.epoch_packed_numel(act), act.numel)), pc=f(max(Kx.epoch_packed_numel(cri), cri.numel)))
+        rf = types.SimpleNamespace(running_sum=t(ref.running_sum), running_sumsq=t(ref.running_sumsq), count=t(ref.count),
+                                   eps=ref.eps)
+        Kx.epoch_prepare(o[:, 0, :], out['xn'], out['xnT'], out['xr'], zmean=t(zmean) if use_z else None,
+                         zstd=t(zstd) if use_z else None, ref_filter=rf if use_z else None,
+                         obs_next=on[:, 0, :] if tail else None, xnext=out['xnext'] if tail else None,
+                         ref_log_var=t(log_var), ref_std=out['ref_pol'][:, A:], pack=[(act, out['pa']), (cri, out['pc'])],
+                         zero_words=out['zero'][4:15])
+        return out
+    c = side('cpu', C, act_c, cri_c)
+    d = side('cuda', K, act_d, cri_d)
+    torch.cuda.synchronize()
+    for k in ('xn', 'xnT', 'xr', 'xnext', 'ref_pol'):
+        close(d[k], c[k], atol=1e-6, rtol=1e-6, msg=k)
+    # ... and bit for bit what the separate HIP launches give
+    o = obs.cuda()
+    if use_z:
+        ref_d = types.SimpleNamespace(**{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in vars(ref).items()})
+        x1, x2 = torch.empty(rows, D).cuda(), torch.empty(rows, D).cuda()
+        K.zfilter_forward(o[:, 0, :], zmean.cuda(), zstd.cuda(), x1)
+        K.zfilter_forward_sums(o[:, 0, :], ref_d.running_sum, ref_d.running_sumsq, ref_d.count, ref_d.eps, x2)
+        assert torch.equal(x1, d['xn']) and torch.equal(x1.t(), d['xnT']) and torch.equal(x2, d['xr'])
+        if tail:
+            K.zfilter_forward(obs_next.cuda()[:, 0, :], zmean.cuda(), zstd.cuda(), x1)
+            assert torch.equal(x1, d['xnext'])
+    else:
+        assert torch.equal(o[:, 0, :], d['xn']) and torch.equal(o[:, 0, :], d['xr'])
+    assert float(d['ref_pol'][:, :A].min()) == 7.0                          # the mean columns are not touched
+    assert d['zero'].cpu().tolist() == [3] * 4 + [0] * 11 + [3] * 5
+    if not tail:
+        assert float(d['xnext'].min()) == 7.0
+    # the packed copies: the forward kernel must see the same weights as through smx_epoch_pack_f32
+    pa2 = torch.zeros_like(d['pa'])
+    K.epoch_pack([(act_d, pa2)])
+    assert torch.equal(pa2, d['pa'])
+
+
+@pytest.mark.parametrize('B,N', [(1024, 128), (37, 19), (5, 3)])
+def test_gae_norm_equals_the_three_launches(K, B, N):
+    g = torch.Generator().manual_seed(B + N)
+    values = torch.randn(B * N, generator=g) * 3
+    tail = torch.randn(B, generator=g)
+    rewards = torch.randn(B, N, generator=g)
+    dones = (torch.rand(B, N, generator=g) < 0.1).float()
+    idx = torch.tensor(range(N), dtype=torch.float32)
+    gpow, lpow = torch.pow(0.995, idx), torch.pow(0.97, idx)
+    ac, rc, mc = torch.empty(B), torch.empty(B), torch.empty(3)
+    C.gae_norm(values, rewards, dones, gpow, lpow, 0.995, 0.995 ** N, B, N, N, ac, rc, mc, 1e-4, None, values_tail=tail)
+    ad, rd, md = torch.empty(B).cuda(), torch.empty(B).cuda(), torch.empty(3).cuda()
+    ticket = torch.zeros(1, dtype=torch.int32).cuda()
+    for _ in range(2):                 # twice: the ticket counter must come back to zero
+        K.gae_norm(dev(values), dev(rewards), dev(dones), dev(gpow), dev(lpow), 0.995, 0.995 ** N, B, N, N, ad, rd, md,
+                   1e-4, ticket, values_tail=dev(tail))
+    close(rd, rc, msg='ret'), close(md, mc, atol=1e-5, rtol=1e-5, msg='moments'), close(ad, ac, msg='normalised adv')
+    assert int(ticket[0]) == 0
+
+
+@pytest.mark.parametrize('rows,D,A,Ev,nblk,use_z', [(1024, 376, 17, 10, 64, True), (37, 29, 5, 3, 3, True),
+                                                   (64, 17, 6, 20, 4, False)])
+def test_learn_epilogue_equals_the_four_launches(K, rows, D, A, Ev, nblk, use_z):
+    import types
+    g = torch.Generator().manual_seed(rows + Ev)
+    x3 = torch.randn(rows, 2, D, generator=g) * 2 + 0.5
+    ret = torch.randn(rows, generator=g) * 3 + 1
+    part = torch.zeros(Ev, nblk, 8)
+    part[:, :, 0] = 16.0
+    part[:, :, 1:6] = torch.rand(Ev, nblk, 5, generator=g) + 0.1
+    log_var = -1.0 + 0.3 * torch.randn(A, generator=g)
+    zf0 = dict(running_sum=torch.randn(D, generator=g) * 100, running_sumsq=torch.rand(D, generator=g) * 5000 + 2000,
+               count=torch.tensor([1000.0]), eps=1e-5)
+
+    def side(dv, Kx):
+        t = lambda v: v.to(dv).clone() if torch.is_tensor(v) else v  # noqa: E731
+        zf = types.SimpleNamespace(**{k: t(v) for k, v in zf0.items()}) if use_z else None
+        out = dict(ret_mom=torch.zeros(3, device=dv), vstats=torch.zeros(Ev, L.VS_STRIDE, device=dv),
+                   out4=torch.zeros(4, device=dv), zf=zf, ticket=torch.zeros(1, dtype=torch.int32, device=dv))
+        Kx.learn_epilogue(t(ret), out['ret_mom'], t(log_var), out['out4'], out['ticket'], zfilter=zf,
+                          x=t(x3)[:, 0, :] if use_z else None, count_rows=rows, v_partials=t(part), n_epochs=Ev,
+                          nblk=nblk, v_stats=out['vstats'], stats_stride=L.VS_STRIDE)
+        return out
+    c, d = side('cpu', C), side('cuda', K)
+    torch.cuda.synchronize()
+    close(d['ret_mom'], c['ret_mom'], atol=1e-5, rtol=1e-5)
+    close(d['vstats'][:, :2], c['vstats'][:, :2], atol=1e-5, rtol=1e-5)
+    close(d['out4'], c['out4'], atol=1e-5, rtol=2e-5, msg='reported means (after the z-filter update)')
+    if use_z:
+        close(d['zf'].running_sum, c['zf'].running_sum, rtol=1e-5, atol=1e-3)
+        close(d['zf'].running_sumsq, c['zf'].running_sumsq, rtol=1e-5, atol=1e-2)
+        close(d['zf'].count, c['zf'].count)
+    assert int(d['ticket'][0]) == 0
