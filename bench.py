@@ -155,7 +155,8 @@ def measured_mfma_util(rows):
         except Exception:
             continue
         for k, v in ks.items():
-            if 'fused' in k and k.endswith('@grid%d' % (rows // 128 * 256)) and 'mfma_util_pct' in v:
+            if (('fused' in k and k.endswith('@grid%d' % (rows // 128 * 256))) or
+                    ('rows16' in k and k.endswith('@grid%d' % (rows // 128 * 512)))) and 'mfma_util_pct' in v:
                 return v['mfma_util_pct'], os.path.basename(path)
     return None, None
 
@@ -406,7 +407,7 @@ def main():
             traffic, tsrc = measured_traffic(rows)
             busy, bsrc = measured_mfma_util(rows)
             out['roofline'] = {
-                'kernel': 'mlp3_fused_kernel<10,7,true> (z-filter + critic MLP over %d rows)' % rows,
+                'kernel': 'mlp3_rows16_kernel<19,13,true> (z-filter + critic MLP over %d rows, smx_mlp3_rows16.hip)' % rows,
                 'bound': 'mfma',
                 'achieved': flops / kt / 1e12,
                 'peak': PEAK_FP32_MFMA_TFLOPS,

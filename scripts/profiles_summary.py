@@ -25,7 +25,7 @@ def mfma_summary(tag, mfma_dir):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(mfma_dir + '/bench_counter_collection.csv')):
         n = short(r['Kernel_Name'])
-        if 'fused' in n or 'gemm' in n or 'lstm' in n or 'epoch' in n or 'adam' in n:
+        if 'fused' in n or 'rows16' in n or 'gemm' in n or 'lstm' in n or 'epoch' in n or 'adam' in n:
             a[(n, int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
     res = {'note': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES '
                    'SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (own pass), python bench.py --steps 3 --warmup 1 '
@@ -65,7 +65,7 @@ def main(tag, stats_dir, fetch_dir=None, write_dir=None, mfma_dir=None):
         agg = collections.defaultdict(list)
         for r in tr:
             n = short(r['Kernel_Name'])
-            if 'gemm' in n or 'fused' in n or 'epoch' in n or 'adam' in n:
+            if 'gemm' in n or 'fused' in n or 'rows16' in n or 'epoch' in n or 'adam' in n:
                 agg[(n, int(r['Grid_Size_X']))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         f.write('\n# per grid size (threads): kernel,grid_x,calls,avg_ns,min_ns\n')
         for (n, g), v in sorted(agg.items()):
@@ -80,7 +80,7 @@ def main(tag, stats_dir, fetch_dir=None, write_dir=None, mfma_dir=None):
             if r['Counter_Name'] == c:
                 a[(short(r['Kernel_Name']), int(r['Grid_Size']))].append(float(r['Counter_Value']))
         pmc[c] = {'%s@grid%d' % k: {'launches': len(v), 'mean_kib': sum(v) / len(v)} for k, v in a.items()
-                  if 'fused' in k[0] or 'gemm' in k[0] or 'adam' in k[0] or 'epoch' in k[0]}
+                  if 'fused' in k[0] or 'rows16' in k[0] or 'gemm' in k[0] or 'adam' in k[0] or 'epoch' in k[0]}
     res = {'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (--kernel-trace only), '
                    'python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline.  Counter means per launch in KiB '
                    'as reported.  On gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced '
@@ -88,9 +88,10 @@ def main(tag, stats_dir, fetch_dir=None, write_dir=None, mfma_dir=None):
                    'WRITE_SIZE is taken as reported (it equals the 4 B x rows the kernel writes).',
            'counters': pmc, 'fused_kernel': {}}
     for k in pmc['FETCH_SIZE']:
-        if 'fused' not in k:
+        if 'fused' not in k and 'rows16' not in k:
             continue
-        nrows = int(k.split('grid')[1]) // 256 * 128
+        # 128 rows per workgroup: 256 threads (32-row wavefronts) or 512 (16-row wavefronts, smx_mlp3_rows16.hip)
+        nrows = int(k.split('grid')[1]) // (512 if 'rows16' in k else 256) * 128
         fetch = pmc['FETCH_SIZE'][k]['mean_kib'] * 1024 * 2
         wr = pmc['WRITE_SIZE'].get(k, {'mean_kib': 0})['mean_kib'] * 1024
         alg = nrows * 377 * 4.0

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsurreal_amd.so')
+LIB_PATH = os.environ.get('SMX_LIB_PATH') or os.path.join(_HERE, 'libsurreal_amd.so')
 
 SMX_ACT_NONE, SMX_ACT_RELU, SMX_ACT_TANH = 0, 1, 2
 SMX_PPO_CLIP, SMX_PPO_ADAPT = 0, 1

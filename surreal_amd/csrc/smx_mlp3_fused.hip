@@ -18,39 +18,14 @@
 //     the way into LDS.  Rows of 36 floats (144 B) make every ds_read_b128 conflict-free.
 //   * FP32 MFMA (exact fp32, no bf16/xf32): 1e-5 parity with the CPU reference is the contract.
 #include "smx_common.h"
+#include "smx_mlp3_fused.inc.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
 
 constexpr int ROWS_PER_WG = 128;  // 4 waves x 32 data rows
 constexpr int LDS_STRIDE = 36;    // floats per staged row (32 + 4 pad)
-
-struct FusedArgs {
-    const float* packed;
-    const float* x_main;
-    const float* x_tail;
-    const float* zmean;
-    const float* zstd;
-    float* out;
-    long total_rows;
-    int T0, T1, D, OUT, KC1, out_act, xvec;
-};
-
-struct PackLayout {
-    size_t w1, b1, w2, b2, w3, b3, total;  // offsets in floats
-};
-
-__host__ __device__ inline PackLayout pack_layout(int NT1, int NT2, int KC1) {
-    PackLayout L;
-    L.w1 = 0;
-    L.b1 = L.w1 + (size_t)KC1 * NT1 * 32 * 32;
-    L.w2 = L.b1 + (size_t)NT1 * 32;
-    L.b2 = L.w2 + (size_t)NT1 * NT2 * 32 * 32;
-    L.w3 = L.b2 + (size_t)NT2 * 32;
-    L.b3 = L.w3 + (size_t)NT2 * 32 * 32;
-    L.total = L.b3 + 32;
-    return L;
-}
 
 inline bool pick_variant(int H1, int H2, int* nt1, int* nt2) {
     if (H1 <= 64 && H2 <= 64) { *nt1 = 2; *nt2 = 2; return true; }
@@ -586,6 +561,10 @@ int launch_fused(const FusedArgs& A, hipStream_t st) {
 
 }  // namespace
 
+static long long* g_fused_tbuf = nullptr;
+// timing builds (-DSMX_FUSED_TIMING, scripts/bench_fused.py): where the 16-row kernel writes its phase timestamps
+extern "C" void smx_mlp3_fused_debug_tbuf(void* p) { g_fused_tbuf = (long long*)p; }
+
 extern "C" size_t smx_mlp3_packed_bytes(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
     int nt1, nt2;
     if (D <= 0 || OUT <= 0 || OUT > 32 || !pick_variant(H1, H2, &nt1, &nt2)) return 0;
@@ -656,9 +635,18 @@ extern "C" int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_
     A.OUT = OUT;
     A.KC1 = (D + 31) / 32;
     A.out_act = out_act;
+    A.tbuf = g_fused_tbuf;
+    A.exp = 0;
     A.xvec = (D % 4 == 0) && (((uintptr_t)x_main & 15) == 0) &&
              (T1 == 0 || ((uintptr_t)x_tail & 15) == 0) &&
              (zmean == nullptr || ((((uintptr_t)zmean | (uintptr_t)zstd) & 15) == 0));
     if (nt1 == 2) return launch_fused<2, 2>(A, smx_s(stream));
+    // 16-row wavefronts (smx_mlp3_rows16.hip) where the shape allows; SMX_FUSED32=1 keeps the 32-row
+    // kernel for A/B measurements (scripts/bench_gemm.py)
+    static const bool force32 = getenv("SMX_FUSED32") != nullptr;
+    if (!force32) {
+        const int rc = smx_rows16_launch(A, H1, H2, smx_s(stream));
+        if (rc != SMX_E_UNSUPPORTED) return rc;
+    }
     return launch_fused<10, 7>(A, smx_s(stream));
 }
