@@ -85,6 +85,11 @@ int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
                            float* running_sum, float* running_sumsq, float* count,
                            float count_rows, smx_stream_t stream);
 
+/* Process-wide switch of smx_mlp3_forward_fused_f32's z-filter arithmetic.  0 (default): (x - m) * (1 / s), one rounding
+ * more than surreal/model/z_filter.py:77 (<= 1 ulp of the filtered input); 1: the reference's division, on the
+ * generic (slower) staging path.  tests/test_gpu_kernels.py::test_fused_exact_zfilter_switch pins both. */
+int smx_mlp3_fused_exact_zfilter(int32_t on);
+
 /* --- fused critic/actor forward over every step of every sub-trajectory ------
  * Replaces PPOModel.forward_critic / forward_actor on the concatenated
  * (obs, obs_next) tensor in PPOLearner._gae_and_return (surreal/learner/ppo.py:376-386,

@@ -139,6 +139,7 @@ _SIGS = {
     'smx_mlp3_packed_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_pack_f32': (c_int32, [POINTER(Mlp3), _P, c_size_t, _P]),
     'smx_mlp3_pack_zstats_f32': (c_int32, [POINTER(Mlp3), _P, c_size_t, _P, _P, _P, c_int32, c_float, _P, _P, _P]),
+    'smx_mlp3_fused_exact_zfilter': (c_int32, [c_int32]),
     'smx_mlp3_forward_fused_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                              c_int64, c_int32, c_int32, _P, _P, _P, c_int32, _P]),
     'smx_linear_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, c_int32, _P, _P, c_int32,

@@ -561,6 +561,14 @@ int launch_fused(const FusedArgs& A, hipStream_t st) {
 
 }  // namespace
 
+static int g_exact_zfilter = 0;
+// 1: z-filter with the reference's division (z_filter.py:77) instead of (x - m) * (1 / s): the generic staging
+// path of the 32-row kernel.  Process-wide; the goldens run with 0.
+extern "C" int smx_mlp3_fused_exact_zfilter(int32_t on) {
+    g_exact_zfilter = on ? 1 : 0;
+    return SMX_OK;
+}
+
 static long long* g_fused_tbuf = nullptr;
 // timing builds (-DSMX_FUSED_TIMING, scripts/bench_fused.py): where the 16-row kernel writes its phase timestamps
 extern "C" void smx_mlp3_fused_debug_tbuf(void* p) { g_fused_tbuf = (long long*)p; }
@@ -644,7 +652,8 @@ extern "C" int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_
     // 16-row wavefronts (smx_mlp3_rows16.hip) where the shape allows; SMX_FUSED32=1 keeps the 32-row
     // kernel for A/B measurements (scripts/bench_gemm.py)
     static const bool force32 = getenv("SMX_FUSED32") != nullptr;
-    if (!force32) {
+    if (g_exact_zfilter && zmean) A.xvec = 0;
+    if (!force32 && A.xvec) {
         const int rc = smx_rows16_launch(A, H1, H2, smx_s(stream));
         if (rc != SMX_E_UNSUPPORTED) return rc;
     }

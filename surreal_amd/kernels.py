@@ -81,6 +81,11 @@ class HipKernels(object):
                L.ptr(zf.running_sum), L.ptr(zf.running_sumsq), L.ptr(zf.count), zf.running_sum.numel(),
                float(zf.eps), L.ptr(zf._mean), L.ptr(zf._std), self._st())
 
+    def fused_exact_zfilter(self, on):
+        """process-wide: the fused critic pass z-filters with the reference's division (z_filter.py:77) instead of
+        (x - m) * (1 / s); the goldens run with the default (off), DESIGN.md 1"""
+        L.call('smx_mlp3_fused_exact_zfilter', 1 if on else 0)
+
     def mlp3_forward_fused(self, packed, net, x_main, x_tail, zmean, zstd, out, act):
         G, T0, D = x_main.shape
         T1 = 0 if x_tail is None else x_tail.shape[1]

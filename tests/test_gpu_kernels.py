@@ -193,6 +193,34 @@ def test_mlp3_forward_fused(K, G, T0, T1, D, H1, H2, OUT, z):
     close(od, oc, msg='fused mlp G=%d T0=%d T1=%d D=%d' % (G, T0, T1, D))
 
 
+def test_fused_exact_zfilter_switch(K):
+    """the two z-filter arithmetics of the fused critic pass: the default multiplies by a
+    reciprocal, the switch selects the reference's division; both within the contract, and within a few ulp of the
+    filtered input of each other"""
+    G, T0, D, H1, H2 = 16, 9, 376, 300, 200
+    nc, nd = make_net(D, H1, H2, 1, 11, 'cuda')
+    g = torch.Generator().manual_seed(2)
+    xm = torch.randn(G, T0, D, generator=g) * 2 + 0.3
+    zm, zs = torch.randn(D, generator=g) * 0.3, torch.rand(D, generator=g) + 0.5
+    pc = torch.empty(C.mlp3_packed_numel(nc))
+    C.mlp3_pack(nc, pc)
+    oc = torch.empty(G * T0)
+    C.mlp3_forward_fused(pc, nc, xm, None, zm, zs, oc, L.SMX_ACT_NONE)
+    pd = torch.empty(K.mlp3_packed_numel(nd)).cuda()
+    K.mlp3_pack(nd, pd)
+    outs = []
+    try:
+        for exact in (False, True):
+            K.fused_exact_zfilter(exact)
+            od = torch.full((G * T0,), float('nan')).cuda()
+            K.mlp3_forward_fused(pd, nd, dev(xm), None, dev(zm), dev(zs), od, L.SMX_ACT_NONE)
+            close(od, oc, msg='fused, exact z-filter %s' % exact)
+            outs.append(od.cpu())
+    finally:
+        K.fused_exact_zfilter(False)
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-6
+
+
 def test_mlp3_forward_fused_full_size_property(K):
     """BASELINE full size (1024 x 129 rows x 376): the fused kernel must agree with the layered
     kernels (independent code path) on every row -- no CPU oracle needed at this size."""
