@@ -555,6 +555,14 @@ int smx_gather_rows_f32(const float* table, int64_t capacity, int32_t width,
 int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
                         uint64_t offset, smx_stream_t stream);
 
+/* The same two copies for fields of any element width: a row is `row_bytes` opaque bytes (uint8 camera frames --
+ * `pixel_input`, surreal/env/wrapper.py observation specs -- stay uint8 in HBM: a quarter of the table and copy
+ * bytes of an fp32 widening).  Moves 16-byte lanes when pitch and addresses allow, else dwords, else bytes. */
+int smx_ring_insert_bytes(void* table, int64_t capacity, int64_t row_bytes, int64_t cursor,
+                          const void* src, int64_t n, smx_stream_t stream);
+int smx_gather_rows_bytes(const void* table, int64_t capacity, int64_t row_bytes, const int64_t* idx,
+                          int64_t n, void* dst, smx_stream_t stream);
+
 /* --- sub-trajectory windowing (surreal/env/exp_sender_wrapper.py:209-264) -------
  * From per-actor rollouts laid out [actors, T, width] emit W moving windows of n_step rows:
  *   dst[(a*W + w), j, :] = src[a, start + w*stride + j, :]     0 <= j < n_step
@@ -564,6 +572,9 @@ int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
 int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, int32_t width,
                         int32_t start, int32_t n_step, int32_t stride, int32_t W, float* dst,
                         smx_stream_t stream);
+/* byte-width variant (uint8 frames): rows of `row_bytes` bytes, same index arithmetic */
+int smx_window_emit_bytes(const void* src, int32_t actors, int32_t T, int64_t row_bytes, int32_t start,
+                          int32_t n_step, int32_t stride, int32_t W, void* dst, smx_stream_t stream);
 
 /* --- synthetic vectorised environment step ("batched vectorised env stepping") --------
  * There is no reference counterpart (the reference steps MuJoCo simulators one process per

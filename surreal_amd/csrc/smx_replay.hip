@@ -18,36 +18,52 @@ __device__ __forceinline__ float zclamp(float x, float m, float s) {
 // one row (ROW_SEG floats): a learner batch has few, very wide rows (1024 sub-trajectories of
 // 192 KB) and one wave per row left 3/4 of the CUs idle with a single load in flight per lane
 // (2.9 TB/s; 5.3 TB/s = the device's copy rate with segments and four loads in flight).
-constexpr int ROW_SEG = 2048;
+constexpr int ROW_SEG = 2048;             // floats = 8 KB per segment
+constexpr int ROW_SEG_BYTES = ROW_SEG * 4;
 
+// Rows are opaque byte strings: `gran` is the widest unit both row pitch and base addresses allow
+// (16: float4 lanes, 4: dwords, 1: bytes) -- fp32 fields are rows of 4-byte units, uint8 camera frames
+// (3 x 84 x 84 = 21 168 B = 1323 float4) move as what they are instead of being widened to fp32.
 template <typename SrcRow, typename DstRow>
-__device__ __forceinline__ void copy_rows(const float* __restrict__ src, float* __restrict__ dst,
-                                          long n, int width, bool vec, SrcRow srow, DstRow drow) {
+__device__ __forceinline__ void copy_rows_bytes(const unsigned char* __restrict__ src,
+                                                unsigned char* __restrict__ dst, long n, long row_bytes,
+                                                int gran, SrcRow srow, DstRow drow) {
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    const int nseg = (width + ROW_SEG - 1) / ROW_SEG;
+    const int nseg = (int)((row_bytes + ROW_SEG_BYTES - 1) / ROW_SEG_BYTES);
     const long items = n * nseg;
     for (long it = wave; it < items; it += nwaves) {
         const long i = it / nseg;
-        const int k0 = (int)(it - i * nseg) * ROW_SEG;
-        const int len = min(ROW_SEG, width - k0);
-        const float* s = src + srow(i) * (long)width + k0;
-        float* d = dst + drow(i) * (long)width + k0;
-        if (vec) {
+        const long k0 = (it - i * nseg) * (long)ROW_SEG_BYTES;
+        const int len = (int)min((long)ROW_SEG_BYTES, row_bytes - k0);
+        const unsigned char* s = src + srow(i) * row_bytes + k0;
+        unsigned char* d = dst + drow(i) * row_bytes + k0;
+        if (gran == 16) {
             const float4* s4 = reinterpret_cast<const float4*>(s);
             float4* d4 = reinterpret_cast<float4*>(d);
-            const int n4 = len >> 2;
+            const int n4 = len >> 4;
             int k = lane;
             for (; k + 192 < n4; k += 256) {            // four independent 16-byte loads per lane
                 const float4 a = s4[k], b = s4[k + 64], c = s4[k + 128], e = s4[k + 192];
                 d4[k] = a; d4[k + 64] = b; d4[k + 128] = c; d4[k + 192] = e;
             }
             for (; k < n4; k += 64) d4[k] = s4[k];
+        } else if (gran == 4) {
+            const uint32_t* s1 = reinterpret_cast<const uint32_t*>(s);
+            uint32_t* d1 = reinterpret_cast<uint32_t*>(d);
+            for (int k = lane; k < (len >> 2); k += 64) d1[k] = s1[k];
         } else {
             for (int k = lane; k < len; k += 64) d[k] = s[k];
         }
     }
+}
+
+template <typename SrcRow, typename DstRow>
+__device__ __forceinline__ void copy_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                          long n, int width, bool vec, SrcRow srow, DstRow drow) {
+    copy_rows_bytes(reinterpret_cast<const unsigned char*>(src), reinterpret_cast<unsigned char*>(dst), n,
+                    (long)width * 4, vec ? 16 : 4, srow, drow);
 }
 
 __global__ __launch_bounds__(256) void ring_insert_kernel(float* __restrict__ table, long capacity,
@@ -115,6 +131,43 @@ __global__ __launch_bounds__(256) void window_emit_kernel(const float* __restric
                   return a * T + start + (long)w * stride + j;
               },
               [](long i) { return i; });
+}
+
+__global__ __launch_bounds__(256) void ring_insert_bytes_kernel(unsigned char* __restrict__ table, long capacity,
+                                                                long row_bytes, long cursor,
+                                                                const unsigned char* __restrict__ src, long n,
+                                                                int gran) {
+    copy_rows_bytes(src, table, n, row_bytes, gran, [](long i) { return i; },
+                    [=](long i) { return (cursor + i) % capacity; });
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const unsigned char* __restrict__ table,
+                                                                long capacity, long row_bytes,
+                                                                const int64_t* __restrict__ idx, long n,
+                                                                unsigned char* __restrict__ dst, int gran) {
+    copy_rows_bytes(table, dst, n, row_bytes, gran,
+                    [=](long i) {
+                        long j = (long)idx[i];
+                        j = j < 0 ? 0 : (j >= capacity ? capacity - 1 : j);
+                        return j;
+                    },
+                    [](long i) { return i; });
+}
+
+__global__ __launch_bounds__(256) void window_emit_bytes_kernel(const unsigned char* __restrict__ src, int actors,
+                                                                int T, long row_bytes, int start, int n_step,
+                                                                int stride, int W, unsigned char* __restrict__ dst,
+                                                                int gran) {
+    const long n = (long)actors * W * n_step;
+    copy_rows_bytes(src, dst, n, row_bytes, gran,
+                    [=](long i) {
+                        const long jw = i / n_step;
+                        const int j = (int)(i - jw * n_step);
+                        const long a = jw / W;
+                        const int w = (int)(jw - a * W);
+                        return a * T + start + (long)w * stride + j;
+                    },
+                    [](long i) { return i; });
 }
 
 // one thread per (actor, k); the reward needs the whole action row: lanes k < 1 compute it
@@ -231,6 +284,19 @@ inline int can_vec(const void* a, const void* b, int width) {
     return (width % 4 == 0) && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
 }
 
+inline unsigned row_blocks_bytes(long n, long row_bytes) {
+    const long items = n * ((row_bytes + ROW_SEG_BYTES - 1) / ROW_SEG_BYTES);
+    long b = (items + 3) / 4;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+inline int byte_gran(const void* a, const void* b, long row_bytes) {
+    const uintptr_t u = (uintptr_t)a | (uintptr_t)b | (uintptr_t)row_bytes;
+    return (u & 15) == 0 ? 16 : ((u & 3) == 0 ? 4 : 1);
+}
+
 }  // namespace
 
 extern "C" int smx_ring_insert_f32(float* table, int64_t capacity, int32_t width, int64_t cursor,
@@ -273,6 +339,42 @@ extern "C" int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, 
     const long n = (long)actors * W * n_step;
     hipLaunchKernelGGL(window_emit_kernel, dim3(row_blocks(n, width)), dim3(256), 0, smx_s(stream), src,
                        actors, T, width, start, n_step, stride, W, dst, can_vec(src, dst, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ring_insert_bytes(void* table, int64_t capacity, int64_t row_bytes, int64_t cursor,
+                                     const void* src, int64_t n, smx_stream_t stream) {
+    SMX_REQUIRE(table && src, SMX_E_NULL);
+    SMX_REQUIRE(capacity > 0 && row_bytes > 0 && cursor >= 0 && cursor < capacity && n > 0 && n <= capacity,
+                SMX_E_SHAPE);
+    hipLaunchKernelGGL(ring_insert_bytes_kernel, dim3(row_blocks_bytes(n, row_bytes)), dim3(256), 0, smx_s(stream),
+                       (unsigned char*)table, (long)capacity, (long)row_bytes, (long)cursor,
+                       (const unsigned char*)src, (long)n, byte_gran(table, src, row_bytes));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_gather_rows_bytes(const void* table, int64_t capacity, int64_t row_bytes, const int64_t* idx,
+                                     int64_t n, void* dst, smx_stream_t stream) {
+    SMX_REQUIRE(table && idx && dst, SMX_E_NULL);
+    SMX_REQUIRE(capacity > 0 && row_bytes > 0 && n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3(row_blocks_bytes(n, row_bytes)), dim3(256), 0, smx_s(stream),
+                       (const unsigned char*)table, (long)capacity, (long)row_bytes, idx, (long)n,
+                       (unsigned char*)dst, byte_gran(table, dst, row_bytes));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_window_emit_bytes(const void* src, int32_t actors, int32_t T, int64_t row_bytes, int32_t start,
+                                     int32_t n_step, int32_t stride, int32_t W, void* dst, smx_stream_t stream) {
+    SMX_REQUIRE(src && dst, SMX_E_NULL);
+    SMX_REQUIRE(actors > 0 && T > 0 && row_bytes > 0 && n_step > 0 && stride > 0 && W > 0 && start >= 0 &&
+                    start + (long)(W - 1) * stride + n_step <= T, SMX_E_SHAPE);
+    const long n = (long)actors * W * n_step;
+    hipLaunchKernelGGL(window_emit_bytes_kernel, dim3(row_blocks_bytes(n, row_bytes)), dim3(256), 0, smx_s(stream),
+                       (const unsigned char*)src, actors, T, (long)row_bytes, start, n_step, stride, W,
+                       (unsigned char*)dst, byte_gran(src, dst, row_bytes));
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

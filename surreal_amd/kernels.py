@@ -415,14 +415,26 @@ class HipKernels(object):
 
     # ---- replay / windowing ---------------------------------------------------------------
     def ring_insert(self, table, cursor, src):
+        """table [capacity, width] <- src [n, width] at ring position `cursor`; fp32 or any other element type
+        (uint8 frames), as long as both agree"""
         cap, width = table.shape
-        L.call('smx_ring_insert_f32', L.ptr(table), cap, width, int(cursor), L.ptr(src),
-               src.shape[0], self._st())
+        assert table.dtype == src.dtype and src.is_contiguous(), (table.dtype, src.dtype)
+        if table.dtype == torch.float32:
+            L.call('smx_ring_insert_f32', L.ptr(table), cap, width, int(cursor), L.ptr(src),
+                   src.shape[0], self._st())
+        else:
+            L.call('smx_ring_insert_bytes', L.ptr(table), cap, width * table.element_size(), int(cursor),
+                   L.ptr(src), src.shape[0], self._st())
 
     def gather_rows(self, table, idx, dst):
         cap, width = table.shape
-        L.call('smx_gather_rows_f32', L.ptr(table), cap, width, L.ptr(idx), idx.numel(),
-               L.ptr(dst), self._st())
+        assert table.dtype == dst.dtype and dst.is_contiguous(), (table.dtype, dst.dtype)
+        if table.dtype == torch.float32:
+            L.call('smx_gather_rows_f32', L.ptr(table), cap, width, L.ptr(idx), idx.numel(),
+                   L.ptr(dst), self._st())
+        else:
+            L.call('smx_gather_rows_bytes', L.ptr(table), cap, width * table.element_size(), L.ptr(idx),
+                   idx.numel(), L.ptr(dst), self._st())
 
     def uniform_indices(self, idx, length, seed, offset):
         L.call('smx_uniform_indices', L.ptr(idx), idx.numel(), int(length), int(seed), int(offset),
@@ -431,9 +443,13 @@ class HipKernels(object):
     def window_emit(self, src, start, n_step, stride, W, dst):
         """src [actors, T, width] -> dst [actors*W, n_step, width]"""
         actors, T, width = src.shape
-        assert src.is_contiguous() and dst.is_contiguous()
-        L.call('smx_window_emit_f32', L.ptr(src), actors, T, width, start, n_step, stride, W,
-               L.ptr(dst), self._st())
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype
+        if src.dtype == torch.float32:
+            L.call('smx_window_emit_f32', L.ptr(src), actors, T, width, start, n_step, stride, W,
+                   L.ptr(dst), self._st())
+        else:
+            L.call('smx_window_emit_bytes', L.ptr(src), actors, T, width * src.element_size(), start, n_step,
+                   stride, W, L.ptr(dst), self._st())
 
     def synth_act_env_step(self, state, init_state, mean, log_var, noise_scale, eps, t, episode_len,
                            slot, rolls, zfilter, xn_out):

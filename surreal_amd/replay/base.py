@@ -21,23 +21,31 @@ import torch
 from surreal_amd import kernels as KN
 
 
-class DeviceTable(object):
-    """one experience field: [capacity, width] fp32 rows in HBM"""
+def table_dtype(dtype):
+    """element type a field is stored with: uint8 (camera frames, `pixel_input`) stays uint8 -- a quarter of the
+    HBM and copy bytes of an fp32 widening, and what the CNN stem's im2col reads anyway; every other field
+    (observations, actions, rewards, dones, policy infos) is fp32 like the learner's batch contract"""
+    return torch.uint8 if dtype == torch.uint8 else torch.float32
 
-    def __init__(self, capacity, shape, device, kernels):
+
+class DeviceTable(object):
+    """one experience field: [capacity, width] rows in HBM, fp32 or uint8 (``table_dtype``)"""
+
+    def __init__(self, capacity, shape, device, kernels, dtype=torch.float32):
         self.shape = tuple(shape)
         width = 1
         for s in self.shape:
             width *= int(s)
         self.width = width
-        self.data = torch.zeros(capacity, width, device=device, dtype=torch.float32)
+        self.dtype = table_dtype(dtype)
+        self.data = torch.zeros(capacity, width, device=device, dtype=self.dtype)
         self.K = kernels
 
     def insert(self, cursor, rows):
-        self.K.ring_insert(self.data, cursor, rows.reshape(rows.shape[0], -1).contiguous())
+        self.K.ring_insert(self.data, cursor, rows.reshape(rows.shape[0], -1).to(self.dtype).contiguous())
 
     def gather(self, idx):
-        out = torch.empty(idx.numel(), self.width, device=self.data.device, dtype=torch.float32)
+        out = torch.empty(idx.numel(), self.width, device=self.data.device, dtype=self.dtype)
         self.K.gather_rows(self.data, idx, out)
         return out.view((idx.numel(),) + self.shape)
 
@@ -120,7 +128,7 @@ class Replay(object):
     def _ensure_tables(self, capacity, fields):
         if self._tables is None:
             K, dev = KN.default_kernels(), KN.default_device()
-            self._tables = {name: DeviceTable(capacity, t.shape[1:], dev, K)
+            self._tables = {name: DeviceTable(capacity, t.shape[1:], dev, K, t.dtype)
                             for name, t in fields.items()}
             self._dev_capacity = capacity
             self._K, self._dev = K, dev

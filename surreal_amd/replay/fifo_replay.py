@@ -56,19 +56,21 @@ class FIFOReplay(Replay):
             n = cap
         tail = (self._head + self._count) % cap
         for name, t in fields.items():
-            tables[name].insert(tail, t.to(torch.float32))
+            tables[name].insert(tail, t)
         overflow = max(0, self._count + n - cap)
         self._head = (self._head + overflow) % cap
         self._count = min(cap, self._count + n)
         self.cumulative_collected_count += n
 
-    def reserve_batch(self, n, shapes):
+    def reserve_batch(self, n, shapes, dtypes=None):
         """Zero-copy insert, step 1: views of the next `n` table rows per field, for a producer that
         writes experiences in place (SyntheticVecEnv.emit_windows(out=...)); None when the rows
         would wrap around the ring or overflow it (fall back to insert_batch).
-        shapes: {name: per-experience shape}.  Follow with commit_batch(n)."""
+        shapes: {name: per-experience shape}; dtypes: {name: torch dtype} for the fields that are not fp32 (uint8
+        frames).  Follow with commit_batch(n)."""
         cap = self.memory_size + 3
-        fields = {k: torch.empty((0,) + tuple(shp)) for k, shp in shapes.items()}
+        dtypes = dtypes or {}
+        fields = {k: torch.empty((0,) + tuple(shp), dtype=dtypes.get(k, torch.float32)) for k, shp in shapes.items()}
         tables = self._ensure_tables(cap, fields)
         tail = (self._head + self._count) % cap
         if n > cap - self._count or tail + n > cap:

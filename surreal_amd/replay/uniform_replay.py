@@ -52,7 +52,7 @@ class UniformReplay(Replay):
             fields = {k: v[n - self.memory_size:] for k, v in fields.items()}
             n = self.memory_size
         for name, t in fields.items():
-            tables[name].insert(self._dev_next, t.to(torch.float32))
+            tables[name].insert(self._dev_next, t)
         self._dev_next = (self._dev_next + n) % self.memory_size
         self._dev_len = min(self.memory_size, self._dev_len + n)
         self.cumulative_collected_count += n

@@ -338,6 +338,62 @@ def test_clip_adam_matches_torch_optim(K):
     assert torch.equal(before, th)
 
 
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.int16])
+def test_replay_kernels_byte_rows(K, dtype):
+    """ring insert / gather / window emission of non-fp32 rows (uint8 camera frames): bit-exact against index
+    arithmetic, for row pitches that move as 16-byte lanes (3 x 84 x 84 B), dwords and single bytes, rows longer
+    than one 8 KB segment, and unaligned sub-views"""
+    g = torch.Generator().manual_seed(7)
+    hi = 255 if dtype == torch.uint8 else 30000
+    for cap, width in ((5, 7), (9, 12), (40, 3 * 84 * 84), (33, 8192 * 2 + 16), (17, 1001)):
+        table_c = torch.zeros(cap, width, dtype=dtype)
+        table_d = table_c.clone().cuda()
+        cursor = 0
+        for n in (3, cap // 2 + 1, 2):
+            src = torch.randint(0, hi, (n, width), generator=g).to(dtype)
+            C.ring_insert(table_c, cursor, src)
+            K.ring_insert(table_d, cursor, dev(src))
+            cursor = (cursor + n) % cap
+        assert torch.equal(table_d.cpu(), table_c)
+        idx = torch.randint(0, cap, (19,), generator=g)
+        dc, dd = torch.empty(19, width, dtype=dtype), torch.empty(19, width, dtype=dtype).cuda()
+        C.gather_rows(table_c, idx, dc)
+        K.gather_rows(table_d, dev(idx), dd)
+        assert torch.equal(dd.cpu(), dc)
+    for width in (3 * 8 * 8, 7):
+        src = torch.randint(0, hi, (4, 14, width), generator=g).to(dtype)
+        W = (14 - 5) // 3 + 1
+        dc, dd = torch.empty(4 * W, 5, width, dtype=dtype), torch.empty(4 * W, 5, width, dtype=dtype).cuda()
+        C.window_emit(src, 0, 5, 3, W, dc)
+        K.window_emit(dev(src), 0, 5, 3, W, dd)
+        assert torch.equal(dd.cpu(), dc)
+
+
+def test_uint8_frames_stay_uint8_in_the_device_replay(K):
+    """pixel observations in the replay's device tier: uint8 tables (a quarter of the fp32 bytes), FIFO pop and
+    uniform gather return the frames bit-exact and still uint8 -- what the CNN stem's im2col reads"""
+    from surreal_amd.replay import FIFOReplay, UniformReplay
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    lc, ec, sc = ppo_learner_config(), ppo_env_config(6, 2), ppo_session_config('/tmp/surreal_amd_test')
+    lc.replay.memory_size, lc.replay.batch_size = 13, 4
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 255, (10, 4, 3, 12, 12), generator=g).to(torch.uint8).cuda()
+    low = torch.randn(10, 4, 6, generator=g).cuda()
+    f = FIFOReplay(lc, ec, sc)
+    f.insert_batch({'frames': frames, 'low': low})
+    assert f._tables['frames'].data.dtype == torch.uint8 and f._tables['low'].data.dtype == torch.float32
+    assert f._tables['frames'].data.numel() * 1 == (13 + 3) * 4 * 3 * 12 * 12
+    b = f.sample_batch(4)
+    assert b['frames'].dtype == torch.uint8 and torch.equal(b['frames'], frames[:4]) and torch.equal(b['low'], low[:4])
+    f.insert_batch({'frames': frames[:9], 'low': low[:9]})         # wraps the ring
+    b = f.sample_batch(8)
+    assert torch.equal(b['frames'], torch.cat([frames[4:], frames[:2]]))
+    u = UniformReplay(lc, ec, sc)
+    u.insert_batch({'frames': frames, 'low': low})
+    got = u.sample_batch(5, indices=[9, 0, 3, 3, 7])
+    assert got['frames'].dtype == torch.uint8 and torch.equal(got['frames'], frames[[9, 0, 3, 3, 7]])
+
+
 def test_replay_kernels(K):
     g = torch.Generator().manual_seed(31)
     for cap, width in ((5, 7), (96, 44), (1000, 376)):

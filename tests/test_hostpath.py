@@ -225,6 +225,30 @@ def test_device_tier_replay_and_vec_env(cpu_double):
     assert int(idx.min()) >= 0 and int(idx.max()) < 5
 
 
+def test_device_tier_keeps_uint8_frames(cpu_double):
+    """host logic of the per-field table dtype: uint8 fields get uint8 tables, everything
+    else is widened to fp32; reserve_batch hands out views of the right dtype"""
+    from surreal_amd.replay import FIFOReplay, UniformReplay
+    from surreal_amd.replay.base import table_dtype
+    assert table_dtype(torch.uint8) == torch.uint8 and table_dtype(torch.float64) == torch.float32
+    lc, ec, sc = configs(N=4, D=6, A=2)
+    lc.replay.memory_size, lc.replay.batch_size = 6, 2
+    g = torch.Generator().manual_seed(1)
+    frames = torch.randint(0, 255, (5, 4, 3, 6, 6), generator=g).to(torch.uint8)
+    dones = torch.randint(0, 2, (5, 4), generator=g)                 # int64 -> fp32 like the batch contract
+    f = FIFOReplay(lc, ec, sc)
+    f.insert_batch({'frames': frames, 'dones': dones})
+    assert f._tables['frames'].data.dtype == torch.uint8 and f._tables['dones'].data.dtype == torch.float32
+    b = f.sample_batch(3)
+    assert b['frames'].dtype == torch.uint8 and torch.equal(b['frames'], frames[:3])
+    assert torch.equal(b['dones'], dones[:3].float())
+    views = f.reserve_batch(2, {'frames': (4, 3, 6, 6), 'dones': (4,)}, dtypes={'frames': torch.uint8})
+    assert views['frames'].dtype == torch.uint8 and views['frames'].shape == (2, 4, 3, 6, 6)
+    u = UniformReplay(lc, ec, sc)
+    u.insert_batch({'frames': frames})
+    assert torch.equal(u.sample_batch(2, indices=[4, 1])['frames'], frames[[4, 1]])
+
+
 def test_agent_replay_learner_loop_in_process(cpu_double):
     """agents (reference-style, one env each) -> windowing wrapper -> FIFO replay -> learner;
     then the learner publishes and the agents pick the new parameters up."""
