@@ -278,9 +278,25 @@ def secondary_ddpg(steps=200):
             'what': 'uniform sample of 512 out of 1e6 device-resident rows + DDPGLearner.learn'}
 
 
+def secondary_pipeline(actors):
+    """the whole on-device loop of one GPU (scripts/bench_pipeline.py): actors acting under the current policy on the
+    synthetic environment -> window cut -> FIFO -> learn, 1024 sub-trajectories per learn"""
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import bench_pipeline
+    r = bench_pipeline.run_pipeline(actors=actors, iters=5, warmup=2, graph=True, fused_step=True)
+    return {'env_steps_per_s': r['value'], 'ms_per_iteration': r['ms_per_iteration'],
+            'rollout_env_steps_per_s': r['rollout_env_steps_per_s'], 'stage_ms': r['stage_ms_synchronised'],
+            'actors': actors, 'n_step': 128, 'learns_per_rollout': r['config']['learns_per_rollout'],
+            'what': 'act (3 policy layers + sample / env step / record / z-filter launch per env step, rollout replayed '
+                    'as one hipGraph) + moving-window cut into the FIFO table + pop + PPOLearner.learn'}
+
+
 def secondaries():
     out = {}
     for key, fn in (
+            ('on-device loop, 1024 actors x 128 steps (act + env step + windows + FIFO + learn)',
+             lambda: secondary_pipeline(1024)),
+            ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout', lambda: secondary_pipeline(4096)),
             ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda: secondary_ppo(64, 128, 17, 6, False)),
             ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
              lambda: secondary_ppo(64, 128, 17, 6, True)),

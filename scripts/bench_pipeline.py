@@ -6,7 +6,12 @@ loop of one GPU -- n actors stepping the synthetic environment under the current
 (exp_sender_wrapper.py:209-228), FIFO insert + pop (fifo_replay.py:6-49, device tier) and
 PPOLearner.learn -- with per-stage timings.  Prints one JSON line.
 
-    python scripts/bench_pipeline.py [--actors 1024] [--steps 128] [--iters 10] [--graph]
+    python scripts/bench_pipeline.py [--actors 1024] [--steps 128] [--iters 10] [--graph] [--fused-step]
+
+--actors may exceed --learn-batch (1024 sub-trajectories per learn, the benchmark configuration): one rollout then
+feeds actors / learn-batch learner iterations through the FIFO.  Acting is a chain of dependent launches per
+environment step whose cost barely depends on the number of actors, so more actors per GPU amortise it -- the
+reference's deployment knob too (agents per learner).
 """
 import argparse
 import json
@@ -18,6 +23,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def run_pipeline(actors=1024, steps=128, obs_dim=376, action_dim=17, iters=10, warmup=3, graph=True, fused_step=True,
+                 copies=False, cpu_double=False, learn_batch=1024):
+    """-> the result dict main() prints (also called by bench.py for its `secondary` entry)"""
+    args = argparse.Namespace(actors=actors, steps=steps, obs_dim=obs_dim, action_dim=action_dim, iters=iters,
+                              warmup=warmup, graph=graph, fused_step=fused_step, copies=copies,
+                              cpu_double=cpu_double, learn_batch=learn_batch)
+    return _run(args)
 
 
 def main():
@@ -33,7 +47,12 @@ def main():
                     help='sample + env step + next z-filter in one launch (SyntheticVecEnv.rollout)')
     ap.add_argument('--copies', action='store_true', help='insert / pop through copies (no table views)')
     ap.add_argument('--cpu-double', action='store_true', help='dry run on the CPU test double')
+    ap.add_argument('--learn-batch', type=int, default=1024, help='sub-trajectories per learner iteration')
     args = ap.parse_args()
+    print(json.dumps(_run(args)), flush=True)
+
+
+def _run(args):
     from surreal_amd import kernels as KN
     if args.cpu_double:
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -45,11 +64,13 @@ def main():
     from surreal_amd.replay import FIFOReplay
     from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
     n, T, D, A = args.actors, args.steps, args.obs_dim, args.action_dim
+    LB = min(args.learn_batch, n)
+    assert n % LB == 0, 'actors must be a multiple of the learner batch'
     lc = ppo_learner_config()
     lc.algo.n_step, lc.algo.stride = T, T
     lc.algo.rnn.if_rnn_policy = False
     lc.algo.consts.kl_target = 1e9                      # no early exit: every learn does 10 + 10 epochs
-    lc.replay.batch_size, lc.replay.memory_size = n, 2 * n
+    lc.replay.batch_size, lc.replay.memory_size = LB, 2 * n
     ec, sc = ppo_env_config(D, A), ppo_session_config()
     learner = PPOLearner(lc, ec, sc)
     agent = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
@@ -103,16 +124,23 @@ def main():
             replay.commit_batch(n)
         else:
             replay.insert_batch(venv.emit_windows(T, T))
-        batch = replay.sample_batch(n, copy=bool(args.copies))
         if times is not None:
             sync()
         t2 = time.perf_counter()
-        learner.learn(to_batch(batch))
+        for _ in range(n // LB):               # the FIFO hands the rollout over one learner batch at a time
+            if times is not None:
+                sync()
+            tb = time.perf_counter()
+            batch = replay.sample_batch(LB, copy=bool(args.copies))
+            if times is not None:
+                sync()
+            t2 += time.perf_counter() - tb          # (t2 - t1 = window cut + FIFO hand-over)
+            learner.learn(to_batch(batch))
         agent.fetch_parameter()
         if times is not None:
             sync()
             t3 = time.perf_counter()
-            times.append((t1 - t0, t2 - t1, t3 - t2))
+            times.append((t1 - t0, t2 - t1, t3 - t0 - (t1 - t0) - (t2 - t1)))
 
     iteration()
     if args.graph and not args.cpu_double:
@@ -151,11 +179,12 @@ def main():
     st = [sum(x[i] for x in staged) / len(staged) for i in range(3)]
     out = {'metric': 'env-steps/s, whole on-device loop (act + env step + windows + FIFO + learn)',
            'value': n * T / whole, 'ms_per_iteration': whole * 1e3,
-           'config': {'actors': n, 'steps_per_rollout': T, 'obs_dim': D, 'action_dim': A,
-                      'rollout_graph': graph is not None, 'fused_step': bool(args.fused_step)},
+           'config': {'actors': n, 'steps_per_rollout': T, 'obs_dim': D, 'action_dim': A, 'learn_batch': LB,
+                      'learns_per_rollout': n // LB, 'rollout_graph': graph is not None,
+                      'fused_step': bool(args.fused_step)},
            'stage_ms_synchronised': {'rollout': st[0] * 1e3, 'windows+fifo': st[1] * 1e3, 'learn': st[2] * 1e3},
            'rollout_env_steps_per_s': n * T / st[0]}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 if __name__ == '__main__':
