@@ -132,22 +132,23 @@ def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):
         np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg='%s stat %s' % (what, k))
 
 
-def assert_final_params(learner, g, case, atol=2e-5, what=''):
-    """updated parameters: full tensors for the small cases, checksums for the big ones.
-    Adam's first steps move every weight by ~lr*sign(g), so an element whose gradient is at the
-    fp32 noise floor can differ by up to 2*lr per step: the bound is epochs*2*lr, not 1e-5."""
+FINAL_PARAM_REPORT = {}      # 'case tensor' -> (fraction of elements off by > atol, max diff, elements)
+
+
+def assert_final_params(learner, g, case, atol=1e-5, what=''):
+    """updated parameters after the 10 + 10 Adam steps: EVERY element of every stored tensor within 1e-5 of the
+    reference's (measured on the MI355X path: 171 tensors, 55 581 elements, largest difference 1.4e-7; round 1
+    allowed epochs * 2 * lr on 2 % of the elements -- Adam's first steps move a weight by ~lr * sign(g), so an
+    element whose gradient sat at the fp32 noise floor COULD differ by that much, but none does); squared-sum
+    checksums for the big cases whose tensors are not stored.  tests/conftest.py prints the tightness summary."""
     got = learner.model.numpy_params()
     ck = json.loads(str(g['final_checksum_json']))
-    lr = max(case['hyper'].get('lr_actor', 1e-4), case['hyper'].get('lr_critic', 1e-4))
     for k, (s, sq) in ck.items():
-        # the shared LSTM stem is stepped by both optimisers (10 policy + 10 value epochs)
-        loose = 2 * lr * (20 if k.startswith(('rnn.', 'cnn.')) else 10)
         a = got[k].astype(np.float64)
         if 'final.' + k in g:
             ref = g['final.' + k]
             diff = np.abs(got[k] - ref)
-            assert diff.max() <= loose + 1e-7, '%s %s max diff %g' % (what, k, diff.max())
-            # the bulk must agree tightly; only noise-floor-gradient elements may sit at ~lr
-            assert np.mean(diff > atol) < 0.02, '%s %s: %.3f%% of elements off by > %g' % (
-                what, k, 100 * np.mean(diff > atol), atol)
+            FINAL_PARAM_REPORT['%s %s' % (what, k)] = (float(np.mean(diff > atol)), float(diff.max()), int(diff.size))
+            assert diff.max() <= atol, '%s %s: max diff %g, %.3f%% of elements off by > %g' % (
+                what, k, diff.max(), 100 * np.mean(diff > atol), atol)
         np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=1e-4, err_msg=what + ' sumsq ' + k)
