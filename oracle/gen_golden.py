@@ -282,6 +282,12 @@ _case('tiny_pixel_rnn_adapt', dict(B=5, N=6, D=4, A=2), (24, 16),
       cnn_feature_dim=8)
 _case('cfg4_pixel_adapt', dict(B=8, N=6, D=32, A=8), (300, 200), dict(ppo_mode='adapt'),
       keep_params=False, pixel=(3, 84, 84), cnn_feature_dim=256)
+# BASELINE configs[3] at its stated size: 256 actors x 32 steps of 3 x 84 x 84 uint8 frames + 32-d robot state, A = 8,
+# the reference's default policy with pixels (CNN stem -> LSTM 100, horizon 5 -> MLPs).  ~1 minute of CPU per run here;
+# the CPU test tier skips it (tests/helpers.py BIG_CASES), the GPU tier runs it.
+_case('cfg4_pixel_rnn_256x32', dict(B=256, N=32, D=32, A=8), (300, 200),
+      dict(ppo_mode='adapt', if_rnn_policy=True, horizon=5), keep_params=False, rnn_hidden=100, pixel=(3, 84, 84),
+      cnn_feature_dim=256)
 
 
 def checksum(params):

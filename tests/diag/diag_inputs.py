@@ -1,6 +1,6 @@
 """diagnostic: are the regenerated inputs bit-identical across hosts; fp32 vs fp64 oracle"""
 import copy, json, sys, os, hashlib, types
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import numpy as np, torch

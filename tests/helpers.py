@@ -19,23 +19,44 @@ RTOL = 1e-5
 # 3.7922561 on the build container's Xeon and 3.7923641 on the GPU box's host CPU for epoch 1
 # of cfg5_clip (2.9e-5 relative; the fp64 value is 3.7922557), because one ReLU pre-activation
 # that lands within fp32 rounding of zero flips its mask and with it that row's contribution
-# to the layer-1/2 gradients (measured with scripts/diag_inputs.py / diag_theta1.py; the HIP
+# to the layer-1/2 gradients (measured with tests/diag/diag_inputs.py / diag_theta1.py; the HIP
 # path reproduces the GPU-box host value to 1.3e-7).  They get a 2e-4 relative bound.
 LOOSE_KEYS = ('grad_norm_actor', 'grad_norm_critic')
 LOOSE_RTOL = 2e-4
 
 
-def tol_for(key, atol, rtol):
+# cfg4_pixel_rnn_256x32 (BASELINE configs[3] at full size): on a randomly initialised CNN + LSTM stem the loss
+# gradients are sums of 7168 nearly cancelling row terms, Adam's first steps are ~lr * sign(g) per element, and the
+# stem is stepped by both optimisers -- the reference itself drifts on the gradient norms between hosts: the oracle
+# (= the reference's ATen ops) run on the GPU box's host CPU gives grad_norm_critic 0.120958 / 0.0304084 / 0.0240116
+# at value epochs 0 / 4 / 5 where the golden (recorded on the build container) has 0.120771 / 0.0305881 / 0.0237972
+# (1.5e-3 ... 9e-3 relative; tests/diag/diag_case.py cfg4_pixel_rnn_256x32 --oracle), while every loss agrees to 1e-5.
+# The HIP path sits in the same band (<= 1.8e-2).  Its gradient norms get 3e-2; all other keys the common bound.
+# Its explained variance, 1 - var(ret - V) / var(ret) = 5e-4 there, carries the value loss's RELATIVE error (1e-5)
+# as an absolute one and gets 5e-5.
+CASE_LOOSE_RTOL = {'cfg4_pixel_rnn_256x32': 3e-2}
+CASE_ATOL = {'cfg4_pixel_rnn_256x32': {'_val_explained_var': 5e-5}}
+
+
+def tol_for(key, atol, rtol, case=''):
+    atol = max(atol, CASE_ATOL.get(case, {}).get(key, 0.0))
     if key in LOOSE_KEYS:
-        return atol, max(rtol, LOOSE_RTOL)
+        return atol, max(rtol, CASE_LOOSE_RTOL.get(case, LOOSE_RTOL))
     return atol, rtol
 
 
-def golden_cases(rnn=None):
+# goldens whose CPU re-run takes about a minute (8448 camera frames through the CNN stem 25 times): checked against
+# the oracle bit for bit when they were recorded (oracle/gen_golden.py), run by the GPU tier, skipped by the CPU tier
+BIG_CASES = ('cfg4_pixel_rnn_256x32',)
+
+
+def golden_cases(rnn=None, big=True):
     names = sorted(f[len('ppo_'):-len('.npz')] for f in os.listdir(GOLDEN_DIR)
                    if f.startswith('ppo_') and f.endswith('.npz'))
     out = []
     for n in names:
+        if not big and n in BIG_CASES:
+            continue
         # "rnn" selects the policies with a shared stem (LSTM and / or CNN), which take the
         # sequential epoch schedule; rnn=False the plain-MLP cases
         has_stem = 'rnn' in n or 'pixel' in n
@@ -113,12 +134,12 @@ def assert_trace_close(trace, g, atol=ATOL, rtol=RTOL, what=''):
     assert len(trace['value']) == len(gv)
     for e, (a, b) in enumerate(zip(trace['policy'], gp)):
         for k in b:
-            at, rt = tol_for(k, atol, rtol)
+            at, rt = tol_for(k, atol, rtol, what)
             np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
                                        err_msg='%s policy epoch %d key %s' % (what, e, k))
     for e, (a, b) in enumerate(zip(trace['value'], gv)):
         for k in b:
-            at, rt = tol_for(k, atol, rtol)
+            at, rt = tol_for(k, atol, rtol, what)
             np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
                                        err_msg='%s value epoch %d key %s' % (what, e, k))
 
@@ -128,7 +149,7 @@ def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):
     for k, v in gs.items():
         if k == '_lr':
             continue
-        at, rt = tol_for(k, atol, rtol)
+        at, rt = tol_for(k, atol, rtol, what)
         np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg='%s stat %s' % (what, k))
 
 
@@ -151,4 +172,9 @@ def assert_final_params(learner, g, case, atol=1e-5, what=''):
             FINAL_PARAM_REPORT['%s %s' % (what, k)] = (float(np.mean(diff > atol)), float(diff.max()), int(diff.size))
             assert diff.max() <= atol, '%s %s: max diff %g, %.3f%% of elements off by > %g' % (
                 what, k, diff.max(), 100 * np.mean(diff > atol), atol)
-        np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=1e-4, err_msg=what + ' sumsq ' + k)
+        # (the full-size pixel case: parameters that start near zero -- the stem's biases -- end wherever ~20 sign-like
+        # Adam steps on noise-floor gradients take them.  Measured: the oracle on the GPU box's host is off the golden
+        # by up to 5.8e-4 on these checksums (cnn.conv2.b), the HIP path -- whose split-K weight / bias gradients sum
+        # 3.4 M patch rows in another order -- by up to 3.5e-3 (cnn.fc.b); weights agree to 1e-4 or better on both)
+        np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=5e-3 if what in CASE_LOOSE_RTOL else 1e-4,
+                                   err_msg=what + ' sumsq ' + k)

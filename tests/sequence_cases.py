@@ -48,7 +48,7 @@ def make_learner(case, session_overrides=None):
 # oracle (bit-identical to the reference where the goldens were recorded) run on the GPU box's host
 # CPU gives grad_norm_critic 1.9116889 for the third learn of cfg5_publish_adapt against 1.9129276
 # in the golden (6.5e-4; ReLU masks at the fp32 noise floor + Adam's sign-like first steps), while
-# the HIP path gives 1.9116902 -- 7e-7 from the same-host oracle (scripts/diag_sequence.py).  So the
+# the HIP path gives 1.9116902 -- 7e-7 from the same-host oracle (tests/diag/diag_sequence.py).  So the
 # gradient norms are held to LOOSE_RTOL against the golden OR the oracle run beside the product on the
 # SAME host (the fused epoch kernels land on the golden's side: 1.9129289), and to SEQ_GOLDEN_RTOL
 # against the golden; every loss / KL / likelihood statistic is held to 1e-5

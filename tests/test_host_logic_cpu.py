@@ -9,7 +9,7 @@ import pytest
 
 import helpers as H
 
-ALL_CASES = H.golden_cases()        # MLP policy and LSTM-stem policy (the reference default)
+ALL_CASES = H.golden_cases(big=False)        # MLP policy and LSTM-stem policy (the reference default)
 
 
 @pytest.mark.parametrize('name', ALL_CASES)

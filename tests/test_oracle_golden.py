@@ -10,7 +10,7 @@ import helpers as H
 import ppo_oracle
 
 
-@pytest.mark.parametrize('name', H.golden_cases())
+@pytest.mark.parametrize('name', H.golden_cases(big=False))
 def test_oracle_reproduces_reference_golden(name):
     g, case = H.load_golden(name)
     batch, params, zstate = H.case_inputs(case)
