@@ -618,6 +618,12 @@ typedef struct smx_synth_act_step {
     float* xn_out;
 } smx_synth_act_step_t;
 int smx_synth_act_env_step_f32(const smx_synth_act_step_t* args, smx_stream_t stream);
+/* The same launch with the policy's output layer folded in (PPOAgent.act's last Linear + Tanh, surreal/model/
+ * model_builders/builders.py:126-135): mean = act(h2 . W3^T + b3) is formed per actor inside (A <= 32; args->mean is
+ * ignored), so an acting step of a device-resident rollout is three dependent launches instead of four. */
+int smx_synth_act_env_step_head_f32(const smx_synth_act_step_t* args, const float* W3, const float* b3,
+                                    const float* h2, int64_t ld_h2, int32_t H2, int32_t out_act,
+                                    smx_stream_t stream);
 
 
 /* --- DDPG update pieces (surreal/learner/ddpg.py:244-352, 403-428) --------------------

@@ -272,6 +272,81 @@ __global__ __launch_bounds__(256) void synth_act_env_step_kernel(smx_synth_act_s
     }
 }
 
+// The same step with the policy's OUTPUT LAYER folded in: one workgroup per actor forms mean = act(h2 . W3^T + b3)
+// itself (A <= 32 outputs, eight lanes per output, a fixed-order tree) and goes on as synth_act_env_step_kernel does --
+// an acting step is then three dependent launches (hidden layer 1, hidden layer 2, this) instead of four.
+__global__ __launch_bounds__(256) void synth_act_head_step_kernel(smx_synth_act_step_t p, const float* __restrict__ W3,
+                                                                  const float* __restrict__ b3,
+                                                                  const float* __restrict__ h2, long ld_h2, int H2,
+                                                                  int out_act) {
+    __shared__ float s_act[32];
+    const int tid = threadIdx.x;
+    const long a = blockIdx.x;
+    const int D = p.D, A = p.A, T = p.T, slot = p.slot;
+    {
+        const int j = tid >> 3, l = tid & 7;
+        float acc = 0.f;
+        if (j < A) {
+            const float* hr = h2 + a * ld_h2;
+            const float* wr = W3 + (size_t)j * H2;
+            for (int k = l; k < H2; k += 8) acc = fmaf(hr[k], wr[k], acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (j < A && l == 0) {
+            float mu = acc + b3[j];
+            if (out_act == SMX_ACT_TANH) mu = tanhf(mu);
+            else if (out_act == SMX_ACT_RELU) mu = mu < 0.f ? 0.f : mu;
+            const float nz = p.noise_scale ? p.noise_scale[a] : 1.0f;
+            float sd = expf(p.log_var[j]);
+            if (p.noise_scale) sd = sd * nz;
+            float act = p.eps ? p.eps[a * p.ld_eps + j] * sd + mu : mu;
+            if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
+            s_act[j] = act;
+            if (p.act_roll) p.act_roll[(a * T + slot) * A + j] = act;
+            if (p.pd_roll) {
+                p.pd_roll[(a * T + slot) * 2 * A + j] = mu;
+                p.pd_roll[(a * T + slot) * 2 * A + A + j] = sd;
+            }
+        }
+    }
+    __syncthreads();
+    const bool done = (p.t + 1 >= p.episode_len);
+    for (int k = tid; k < D; k += 256) {
+        const long i = a * D + k;
+        const float ac = s_act[k % A];
+        const float s = p.state[i];
+        const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+        float sn = (0.9f * s + 0.5f * ac) + drift;
+        sn = fminf(fmaxf(sn, -10.0f), 10.0f);
+        if (p.obs_roll) {
+            p.obs_roll[(a * T + slot) * D + k] = s;
+            if (slot + 1 < T) p.obs_roll[(a * T + slot + 1) * D + k] = sn;
+        }
+        if (k == 0) {
+            double q = 0.0;
+            for (int j = 0; j < A; ++j) q += (double)s_act[j] * (double)s_act[j];
+            if (p.rew_roll) p.rew_roll[a * T + slot] = (float)(-0.1 * q + 0.05 * (double)sn);
+            if (p.done_roll) p.done_roll[a * T + slot] = done ? 1.0f : 0.0f;
+        }
+        const float next = done ? p.init_state[i] : sn;
+        p.state[i] = next;
+        if (p.xn_out) {
+            float z = next;
+            if (p.zsum) {
+                const float c = p.zcount[0];
+                const float m = p.zsum[k] / c;
+                const float var = p.zsumsq[k] / c - m * m;
+                float sz = sqrtf(var);
+                if (sz == sz) sz = fmaxf(sz, p.zeps);
+                z = zclamp(next, m, sz);
+            }
+            p.xn_out[i] = z;
+        }
+    }
+}
+
 inline unsigned row_blocks(long n, int width) {
     const long items = n * ((width + ROW_SEG - 1) / ROW_SEG);
     long b = (items + 3) / 4;  // 4 waves (row segments) per block
@@ -389,6 +464,21 @@ extern "C" int smx_synth_act_env_step_f32(const smx_synth_act_step_t* args, smx_
     const long total = (long)p.n * p.D;
     hipLaunchKernelGGL(synth_act_env_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        smx_s(stream), p);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_synth_act_env_step_head_f32(const smx_synth_act_step_t* args, const float* W3, const float* b3,
+                                               const float* h2, int64_t ld_h2, int32_t H2, int32_t out_act,
+                                               smx_stream_t stream) {
+    SMX_REQUIRE(args && W3 && b3 && h2, SMX_E_NULL);
+    const smx_synth_act_step_t& p = *args;
+    SMX_REQUIRE(p.state && p.init_state && p.log_var, SMX_E_NULL);
+    SMX_REQUIRE(p.n > 0 && p.D > 0 && p.A > 0 && p.A <= 32 && p.A <= p.D && p.T > 0 && p.slot >= 0 && p.slot < p.T &&
+                    p.episode_len > 0 && H2 > 0 && ld_h2 >= H2 && (!p.eps || p.ld_eps >= p.A), SMX_E_SHAPE);
+    SMX_REQUIRE(!p.zsum || (p.zsumsq && p.zcount && p.xn_out), SMX_E_NULL);
+    hipLaunchKernelGGL(synth_act_head_step_kernel, dim3((unsigned)p.n), dim3(256), 0, smx_s(stream), p, W3, b3, h2,
+                       (long)ld_h2, H2, out_act);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

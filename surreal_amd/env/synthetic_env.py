@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from surreal_amd import kernels as KN
+from surreal_amd import _lib as L
 from .base import Env
 
 
@@ -135,8 +136,8 @@ class SyntheticVecEnv(object):
 
     def rollout(self, agent, eps=None):
         """A whole recorded rollout (start_rollout(T) first) under `agent`'s plain-MLP policy with
-        FOUR launches per environment step: three policy layers, then one launch that samples the
-        action, steps every actor, records the transition and z-filters the next observation.
+        THREE launches per environment step: the two hidden layers, then one launch that forms the policy mean,
+        samples the action, steps every actor, records the transition and z-filters the next observation.
         Same numbers as ``for t: agent.act_batch(state) -> step(actions, pds)``.
         eps: [T, n, A] standard-normal draws (default: drawn here in one launch; None-eps agents in
         a deterministic mode ignore it)."""
@@ -154,7 +155,24 @@ class SyntheticVecEnv(object):
         else:
             self._xn.copy_(self.state)
         log_var = agent.model.log_var.view(-1)
-        for t in range(T):
+        actor = agent.model.actor
+        if not (agent.rnn_config.if_rnn_policy or agent.model.if_pixel) and actor.OUT <= 32:
+            # THREE launches per environment step: the two hidden layers, then one launch that forms the policy
+            # mean (output layer + tanh) per actor, samples, steps, records and z-filters the next observation
+            if getattr(self, '_h1', None) is None or self._h1.shape != (n, actor.H1):
+                self._h1 = torch.empty(n, actor.H1, device=self.device)
+                self._h2 = torch.empty(n, actor.H2, device=self.device)
+            v = actor.views
+            for t in range(T):
+                K.linear(self._xn, 1, v['W1'], 1, v['b1'], self._h1, n, actor.H1, actor.D, act=L.SMX_ACT_RELU)
+                K.linear(self._h1, 1, v['W2'], 1, v['b2'], self._h2, n, actor.H2, actor.H1, act=L.SMX_ACT_RELU)
+                K.synth_act_env_step_head(v['W3'], v['b3'], self._h2, L.SMX_ACT_TANH, self.state, self.init_state,
+                                          log_var, noise, None if deterministic else eps[t], self.t,
+                                          self.episode_len, self.slot, self.rolls, zf, self._xn)
+                self.slot += 1
+                self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
+            return
+        for t in range(T):                     # four launches per step: three policy layers + the step launch
             mean = agent.policy_mean(self._xn)
             K.synth_act_env_step(self.state, self.init_state, mean, log_var, noise,
                                  None if deterministic else eps[t], self.t, self.episode_len, self.slot,

@@ -451,15 +451,13 @@ class HipKernels(object):
             L.call('smx_window_emit_bytes', L.ptr(src), actors, T, width * src.element_size(), start, n_step,
                    stride, W, L.ptr(dst), self._st())
 
-    def synth_act_env_step(self, state, init_state, mean, log_var, noise_scale, eps, t, episode_len,
-                           slot, rolls, zfilter, xn_out):
-        """acting head + env step + next observation's z-filter, one launch (see the header);
-        rolls: dict obs / actions / rewards / dones [/ pds] or None; zfilter: ZFilter or None"""
+    @staticmethod
+    def _synth_act_step(state, init_state, mean, A, log_var, noise_scale, eps, t, episode_len, slot, rolls, zfilter,
+                        xn_out):
         n, D = state.shape
-        A = mean.shape[1]
         p = L.SynthActStep()
         p.state, p.init_state = L.ptr(state), L.ptr(init_state)
-        p.mean, p.ld_mean, p.log_var = L.ptr(mean), _row_stride(mean, A), L.ptr(log_var)
+        p.mean, p.ld_mean, p.log_var = L.ptr(mean), (0 if mean is None else _row_stride(mean, A)), L.ptr(log_var)
         p.noise_scale, p.eps = L.ptr(noise_scale), L.ptr(eps)
         p.ld_eps = 0 if eps is None else _row_stride(eps, A)
         p.n, p.D, p.A, p.t, p.episode_len, p.slot = n, D, A, int(t), int(episode_len), int(slot)
@@ -471,7 +469,24 @@ class HipKernels(object):
             p.zsum, p.zsumsq, p.zcount = L.ptr(zfilter.running_sum), L.ptr(zfilter.running_sumsq), L.ptr(zfilter.count)
             p.zeps = float(zfilter.eps)
         p.xn_out = L.ptr(xn_out)
+        return p
+
+    def synth_act_env_step(self, state, init_state, mean, log_var, noise_scale, eps, t, episode_len,
+                           slot, rolls, zfilter, xn_out):
+        """acting head + env step + next observation's z-filter, one launch (see the header);
+        rolls: dict obs / actions / rewards / dones [/ pds] or None; zfilter: ZFilter or None"""
+        p = self._synth_act_step(state, init_state, mean, mean.shape[1], log_var, noise_scale, eps, t, episode_len,
+                                 slot, rolls, zfilter, xn_out)
         L.call('smx_synth_act_env_step_f32', ctypes.byref(p), self._st())
+
+    def synth_act_env_step_head(self, W3, b3, h2, out_act, state, init_state, log_var, noise_scale, eps, t,
+                                episode_len, slot, rolls, zfilter, xn_out):
+        """the same launch with the policy's output layer folded in: mean = act(h2 . W3^T + b3) formed per actor"""
+        A, H2 = W3.shape
+        p = self._synth_act_step(state, init_state, None, A, log_var, noise_scale, eps, t, episode_len, slot, rolls,
+                                 zfilter, xn_out)
+        L.call('smx_synth_act_env_step_head_f32', ctypes.byref(p), L.ptr(W3), L.ptr(b3), L.ptr(h2),
+               _row_stride(h2, H2), H2, int(out_act), self._st())
 
     def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,
                        rew_roll, done_roll):

@@ -592,6 +592,12 @@ class TorchCpuKernels(object):
         out = torch.stack([src[:, start + w * stride:start + w * stride + n_step] for w in range(W)], 1)
         dst.view(actors, W, n_step, width).copy_(out)
 
+    def synth_act_env_step_head(self, W3, b3, h2, out_act, state, init_state, log_var, noise_scale, eps, t,
+                                episode_len, slot, rolls, zfilter, xn_out):
+        mean = self._act(torch.nn.functional.linear(h2, W3, b3), out_act)
+        self.synth_act_env_step(state, init_state, mean, log_var, noise_scale, eps, t, episode_len, slot, rolls,
+                                zfilter, xn_out)
+
     def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,
                        rew_roll, done_roll):
         n, D = state.shape
