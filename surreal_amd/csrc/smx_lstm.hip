@@ -220,10 +220,6 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(BwdArgs a) {
 // per time step.  Wave w keeps W_hh[64w + lane][0..H) in registers for the whole sequence.
 // ===========================================================================================
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
-// barrier between phases that exchange data through LDS only: __syncthreads() also drains every outstanding
-// GLOBAL store of the wave (vmcnt(0)), which put two HBM round trips into every time step of the 4-row kernels
-// (measured: 11 us per step for 100 dependent MFMAs)
-#define LSTM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 constexpr int RB4 = 4;
 
@@ -239,6 +235,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd4_kernel(FwdArgs a) {
     float* gh = smem + RB4 * HS;               // [4][GS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * RB4;
     const int col = wv * 64 + lane;            // gate column of this lane
 
     float4 wq[KQ];
@@ -249,56 +246,39 @@ __global__ __launch_bounds__(NT) void lstm_fwd4_kernel(FwdArgs a) {
                     : make_float4(0.f, 0.f, 0.f, 0.f);
     const float bias = (col < G) ? a.b_hh[col] : 0.f;
 
-    // PERSISTENT over groups of 4 batch rows: the training path runs B (N - horizon + 1) windows of only
-    // `horizon` (5) steps each, so a workgroup that fetched its 160 KB of W_hh for ONE group spent most of its
-    // time on that fetch (1984 groups x 160 KB = 317 MB of L2 reads per launch at 64 x 128); now the register
-    // copy serves every group the workgroup walks.
+    for (int idx = tid; idx < RB4 * HS; idx += NT) hs[idx] = 0.f;
+    __syncthreads();
     // one (row, unit) element per thread
     const int erow = tid / H, ej = tid - erow * H;
     const bool ev = tid < RB4 * H;
-    const float* hrow = hs + (lane & 3) * HS;
-    const int ngroups = (a.B + RB4 - 1) / RB4;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int row0 = grp * RB4;
-    __syncthreads();                           // the previous group's last reads of hs / gh
-    for (int idx = tid; idx < RB4 * HS; idx += NT) hs[idx] = 0.f;
-    __syncthreads();
     const bool inb = ev && row0 + erow < a.B;
     const unsigned eoff = inb ? (unsigned)(row0 + erow) * (unsigned)(T * H) + (unsigned)ej : 0u;
     float creg = (inb && a.c0) ? a.c0[(size_t)(row0 + erow) * H + ej] : 0.f;
     if (inb && a.h0) hs[erow * HS + ej] = a.h0[(size_t)(row0 + erow) * H + ej];
     __syncthreads();
 
-    // the gate inputs of step t are requested during step t - 1 (software pipeline: no load latency in the chain)
-    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
-    if (inb) {
-        const unsigned og = (eoff - ej) * 4u + ej;
-        gx0 = a.gates[og]; gx1 = a.gates[og + (unsigned)H];
-        gx2 = a.gates[og + (unsigned)(2 * H)]; gx3 = a.gates[og + (unsigned)(3 * H)];
-    }
+    const float* hrow = hs + (lane & 3) * HS;
     for (int t = 0; t < T; ++t) {
+        float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gx3 = 0.f;
+        if (inb) {
+            const unsigned og = (eoff - ej + (unsigned)(t * H)) * 4u + ej;
+            gx0 = a.gates[og]; gx1 = a.gates[og + (unsigned)H];
+            gx2 = a.gates[og + (unsigned)(2 * H)]; gx3 = a.gates[og + (unsigned)(3 * H)];
+        }
         if (wv * 64 < G) {                     // wave-uniform: waves past the last gate column idle
-            // four independent accumulator chains (a dependent v_mfma_f32_4x4x1 waits ~4 issue slots for its
-            // predecessor: one chain of H MFMAs was the longest piece of a time step), summed in a fixed order
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, ac1 = acc, ac2 = acc, ac3 = acc;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const float4 hv = *reinterpret_cast<const float4*>(hrow + 4 * q);
                 acc = MFMA4(hv.x, wq[q].x, acc);
-                ac1 = MFMA4(hv.y, wq[q].y, ac1);
-                ac2 = MFMA4(hv.z, wq[q].z, ac2);
-                ac3 = MFMA4(hv.w, wq[q].w, ac3);
+                acc = MFMA4(hv.y, wq[q].y, acc);
+                acc = MFMA4(hv.z, wq[q].z, acc);
+                acc = MFMA4(hv.w, wq[q].w, acc);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gh[r * GS + col] = ((acc[r] + ac1[r]) + (ac2[r] + ac3[r])) + bias;
+            for (int r = 0; r < 4; ++r) gh[r * GS + col] = acc[r] + bias;
         }
-        float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, nx3 = 0.f;
-        if (inb && t + 1 < T) {
-            const unsigned og = (eoff - ej + (unsigned)((t + 1) * H)) * 4u + ej;
-            nx0 = a.gates[og]; nx1 = a.gates[og + (unsigned)H];
-            nx2 = a.gates[og + (unsigned)(2 * H)]; nx3 = a.gates[og + (unsigned)(3 * H)];
-        }
-        LSTM_LDS_BARRIER();
+        __syncthreads();
         if (ev) {
             const float* g = gh + erow * GS + ej;
             const float gi = sigm(gx0 + g[0]);
@@ -319,14 +299,12 @@ __global__ __launch_bounds__(NT) void lstm_fwd4_kernel(FwdArgs a) {
                 hs[erow * HS + ej] = h;
             }
         }
-        gx0 = nx0; gx1 = nx1; gx2 = nx2; gx3 = nx3;
-        LSTM_LDS_BARRIER();
+        __syncthreads();
     }
     if (inb) {
         if (a.hN) a.hN[(size_t)(row0 + erow) * H + ej] = hs[erow * HS + ej];
         if (a.cN) a.cN[(size_t)(row0 + erow) * H + ej] = creg;
     }
-    }   // groups
 }
 
 // Backward: dh_rec[4][H] = dgates_t[4][4H] . W_hh[4H][H].  The K = 4H sum is split over the four
@@ -344,6 +322,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd4_kernel(BwdArgs a) {
     float* part = smem + RB4 * DS;             // [4 gate blocks][4 rows][PS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * RB4;
     const int gb = wv & 3, cg = wv >> 2;
     const int n = cg * 64 + lane;              // hidden column of this lane
 
@@ -357,42 +336,27 @@ __global__ __launch_bounds__(NT) void lstm_bwd4_kernel(BwdArgs a) {
         }
         wq[q] = w;
     }
+    for (int idx = tid; idx < RB4 * DS + 4 * RB4 * PS; idx += NT) smem[idx] = 0.f;
     const int erow = tid / H, ej = tid - erow * H;
     const bool ev = tid < RB4 * H;
-    const float* drow = dg + (lane & 3) * DS + gb * (KQ * 4);
-    const int ngroups = (a.B + RB4 - 1) / RB4;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {      // persistent: see lstm_fwd4_kernel
-    const int row0 = grp * RB4;
-    __syncthreads();
-    for (int idx = tid; idx < RB4 * DS + 4 * RB4 * PS; idx += NT) smem[idx] = 0.f;
     const bool inb = ev && row0 + erow < a.B;
     const unsigned eoff = inb ? (unsigned)(row0 + erow) * (unsigned)(T * H) + (unsigned)ej : 0u;
     float dcreg = 0.f;
     __syncthreads();
 
-    // the inputs of step t - 1 are requested during step t (software pipeline)
-    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cp = 0.f, dout = 0.f;
-    auto fetch = [&](int t, float& xi, float& xf, float& xg, float& xo, float& xcp, float& xd) {
-        const unsigned oh = eoff + (unsigned)(t * H);
-        const unsigned og = (oh - ej) * 4u + ej;
-        xi = a.gates[og]; xf = a.gates[og + (unsigned)H];
-        xg = a.gates[og + (unsigned)(2 * H)]; xo = a.gates[og + (unsigned)(3 * H)];
-        xcp = (t > 0) ? a.cs[oh - (unsigned)H] : (a.c0 ? a.c0[(size_t)(row0 + erow) * H + ej] : 0.f);
-        xd = a.dout[oh];
-    };
-    if (inb) {
-        fetch(T - 1, gi, gf, gg, go, cp, dout);
-        c = a.cs[eoff + (unsigned)((T - 1) * H)];
-    }
+    const float* drow = dg + (lane & 3) * DS + gb * (KQ * 4);
     for (int t = T - 1; t >= 0; --t) {
-        float ni = 0.f, nf = 0.f, ng = 0.f, no = 0.f, ncp = 0.f, nd = 0.f;
-        if (inb && t > 0) fetch(t - 1, ni, nf, ng, no, ncp, nd);
         if (inb) {
             const unsigned oh = eoff + (unsigned)(t * H);
             const unsigned og = (oh - ej) * 4u + ej;
+            const float gi = a.gates[og], gf = a.gates[og + (unsigned)H];
+            const float gg = a.gates[og + (unsigned)(2 * H)], go = a.gates[og + (unsigned)(3 * H)];
+            const float c = a.cs[oh];
+            const float cp = (t > 0) ? a.cs[oh - (unsigned)H]
+                                     : (a.c0 ? a.c0[(size_t)(row0 + erow) * H + ej] : 0.f);
             const float* pp = part + erow * PS + ej;
             const float dhr = ((pp[0] + pp[RB4 * PS]) + pp[2 * RB4 * PS]) + pp[3 * RB4 * PS];
-            const float dh = dout + dhr;
+            const float dh = a.dout[oh] + dhr;
             const float tc = tanhf(c);
             const float dc = dcreg + (dh * go) * (1.f - tc * tc);
             const float dgi = (dc * gg) * (gi * (1.f - gi));
@@ -405,34 +369,25 @@ __global__ __launch_bounds__(NT) void lstm_bwd4_kernel(BwdArgs a) {
             float* gl = dg + erow * DS + ej;
             gl[0] = dgi; gl[KQ * 4] = dgf; gl[2 * KQ * 4] = dgg; gl[3 * KQ * 4] = dgo;
         }
-        LSTM_LDS_BARRIER();
+        __syncthreads();
         if (t > 0 && cg * 64 < H) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, ac1 = acc, ac2 = acc, ac3 = acc;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
                 const float4 dv = *reinterpret_cast<const float4*>(drow + 4 * q);
                 acc = MFMA4(dv.x, wq[q].x, acc);
-                ac1 = MFMA4(dv.y, wq[q].y, ac1);
-                ac2 = MFMA4(dv.z, wq[q].z, ac2);
-                ac3 = MFMA4(dv.w, wq[q].w, ac3);
+                acc = MFMA4(dv.y, wq[q].y, acc);
+                acc = MFMA4(dv.z, wq[q].z, acc);
+                acc = MFMA4(dv.w, wq[q].w, acc);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(gb * RB4 + r) * PS + n] = (acc[r] + ac1[r]) + (ac2[r] + ac3[r]);
+            for (int r = 0; r < 4; ++r) part[(gb * RB4 + r) * PS + n] = acc[r];
         }
-        c = cp;                                 // c_{t-1}: the cell state of the step that runs next
-        gi = ni; gf = nf; gg = ng; go = no; cp = ncp; dout = nd;
-        LSTM_LDS_BARRIER();
+        __syncthreads();
     }
-    }   // groups
 }
 
 constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
-
-// persistent 4-row kernels: at most 3 workgroups (of 8 wavefronts) per CU walk the groups of 4 batch rows
-inline unsigned grid4(int64_t B) {
-    const int64_t g = (B + RB4 - 1) / RB4;
-    return (unsigned)(g < 768 ? g : 768);
-}
 
 inline size_t lds4_fwd(int kq) { return (size_t)RB4 * ((kq * 4 + 4) + (NWV * 64 + 4)) * sizeof(float); }
 inline size_t lds4_bwd(int kq) { return (size_t)(RB4 * (16 * kq + 4) + 4 * RB4 * (128 + 4)) * sizeof(float); }
@@ -465,10 +420,10 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
     if (H <= 100) {
-        hipLaunchKernelGGL((lstm_fwd4_kernel<25>), dim3(grid4(B)), dim3(NT),
+        hipLaunchKernelGGL((lstm_fwd4_kernel<25>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_fwd(25), smx_s(stream), a);
     } else if (H <= 4 * KQ4) {
-        hipLaunchKernelGGL((lstm_fwd4_kernel<KQ4>), dim3(grid4(B)), dim3(NT),
+        hipLaunchKernelGGL((lstm_fwd4_kernel<KQ4>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_fwd(KQ4), smx_s(stream), a);
     } else {
         static bool attr_set = false;
@@ -501,10 +456,10 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     a.stop = stop_flag; a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
     if (H <= 100) {
-        hipLaunchKernelGGL((lstm_bwd4_kernel<25>), dim3(grid4(B)), dim3(NT),
+        hipLaunchKernelGGL((lstm_bwd4_kernel<25>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_bwd(25), smx_s(stream), a);
     } else if (H <= 4 * KQ4) {
-        hipLaunchKernelGGL((lstm_bwd4_kernel<KQ4>), dim3(grid4(B)), dim3(NT),
+        hipLaunchKernelGGL((lstm_bwd4_kernel<KQ4>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_bwd(KQ4), smx_s(stream), a);
     } else {
         static bool attr_set = false;
