@@ -77,6 +77,16 @@ def test_learner_two_stream_schedule(name):
     check_case(name, *run_case(name, {'epoch_schedule': 'two_stream'}))
 
 
+@pytest.mark.parametrize('name,opts', [
+    ('cfg5_adapt', {'split_chains': True}),                      # actor / critic chains on two streams in the graph
+    ('cfg5_clip', {'fused_epochs': False}),                      # the layered (one launch per layer) epoch schedule
+    ('cfg2_adapt', {'fused_epochs': False, 'split_chains': True}),
+    ('cfg5_adapt_earlyexit', {'split_chains': True})])
+def test_learner_session_options_keep_the_numbers(name, opts):
+    """every schedule option of the fused-epoch learner (session_config.learner.*) reproduces the same goldens"""
+    check_case(name, *run_case(name, opts))
+
+
 def test_three_learns_match_oracle_and_graph_replays():
     """consecutive learn() calls on device-resident batches: the captured graph is replayed
     (pointer-stable inputs) and the optimiser state carries over exactly as torch.optim's"""
