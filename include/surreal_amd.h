@@ -720,6 +720,15 @@ int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int64_t B, int3
 int smx_im2col_f32(const void* src, int32_t src_is_u8, int32_t channel_last, int64_t F, int32_t C,
                    int32_t Hin, int32_t Win, int32_t kh, int32_t kw, int32_t stride,
                    float scale_div, float* cols, smx_stream_t stream);
+/* First convolution over uint8 frames as an implicit GEMM (no patch matrix): y[(f, oy, ox), o] = relu(b[o] +
+ * sum_{c,i,j} W[o][c][i][j] * float(frames[f][c][oy*stride + i][ox*stride + j]) / 255) -- Conv2d + ReLU of
+ * surreal/model/model_builders/builders.py:8-33 on `x / 255` (ppo_net.py:268-275), the same numbers as
+ * smx_im2col_f32 (scale_div 255) + smx_linear_f32 (ReLU).  y is channel-last [F*Ho*Wo, cout].
+ * SMX_E_UNSUPPORTED unless cout <= 16, k % 4 == 0, Win % 4 == 0, stride % 4 == 0, C*k*k in {64, 128, 192, 256}.
+ * stop_flag (device, may be NULL): non-zero turns the launch into a no-op (the KL early exit). */
+int smx_conv_u8_forward_f32(const void* frames, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                            int32_t stride, const float* W, const float* bias, int32_t cout, float* y,
+                            const int32_t* stop_flag, smx_stream_t stream);
 /* data gradient of the convolution above: dx [F, Hin*Win, C] (channel-last) gathers dcols
  * [F*Ho*Wo, C*kh*kw]; relu_of (optional, same shape as dx): dx *= (relu_of > 0). */
 int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t kh,

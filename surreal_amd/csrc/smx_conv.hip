@@ -98,6 +98,98 @@ inline int grid_for(long long total) {
     return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
+// ---------------------------------------------------------------------------------------------
+// The first convolution over uint8 camera frames as an IMPLICIT GEMM: y[(f, oy, ox), o] =
+// relu(b[o] + sum_k W[o][k] * frame[f][c][oy s + i][ox s + j] / 255), k = (c, i, j).  The materialised
+// patch matrix of that layer is 2.2 GB at 7168 frames (1.7 ms to write, and the GEMM over it reads it
+// back at the HBM rate); here a lane gathers its share of a patch straight from the frame.
+//   * v_mfma_f32_16x16x4: M = 16 consecutive patches (A operand), N = the <= 16 output channels (B);
+//   * lane (i = lane & 15, kq = lane >> 4) fetches, per group g of 16 k's, ONE dword = the four bytes
+//     k = 16 g + 4 kq + s, s = 0..3 (the same (c, row) of the patch: kw % 4 == 0; aligned: W, stride % 4
+//     == 0) -- the k's of four consecutive MFMA steps; its weight registers hold W[lane & 15][the same k's];
+//   * u8 / 255.0f exactly: q = x r, q' = fma(fma(-q, 255, x), r, q) with r = fl(1 / 255) is the correctly
+//     rounded quotient for every byte (all 256 checked), a multiply alone is wrong for 126 of them;
+//   * the weights stay in registers: a wavefront walks many 16-patch tiles (persistent), the next tile's
+//     dwords are requested before the current tile's MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define MFMA16C(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float u8_div255(unsigned x, int byte) {
+    const float v = (float)((x >> (8 * byte)) & 0xffu);
+    const float r = 1.0f / 255.0f;                      // compile-time constant, correctly rounded
+    const float q = v * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, v), r, q);
+}
+
+template <int NG>      // K = 16 NG
+__global__ __launch_bounds__(256) void conv_u8_fwd_kernel(const unsigned char* __restrict__ frames, ConvGeom g,
+                                                          long long rows, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int cout,
+                                                          float* __restrict__ y, const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int K = 16 * NG;
+    // weights of output channel i (zero past cout) and the byte offset of each group's dword inside a frame
+    float4 w[NG];
+    int koff[NG];
+#pragma unroll
+    for (int gidx = 0; gidx < NG; ++gidx) {
+        const int k = 16 * gidx + 4 * kq;
+        w[gidx] = (i < cout) ? *reinterpret_cast<const float4*>(W + (size_t)i * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = k / (g.kh * g.kw), ij = k - c * (g.kh * g.kw);
+        const int ki = ij / g.kw, kj = ij - ki * g.kw;
+        koff[gidx] = (c * g.Hin + ki) * g.Win + kj;
+    }
+    const float bv = (i < cout) ? bias[i] : 0.f;
+    const int P = g.Ho * g.Wo;
+    const long long ntiles = (rows + 15) >> 4;
+    auto base_of = [&](long long tile) -> long long {
+        long long row = tile * 16 + i;
+        if (row >= rows) row = rows - 1;                 // clamped: loaded, never stored
+        const long long f = row / P;
+        const int p = (int)(row - f * P);
+        const int oy = p / g.Wo, ox = p - oy * g.Wo;
+        return (f * g.C * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride;
+    };
+    unsigned cur[NG], nxt[NG];
+    long long tile = wave;
+    if (tile < ntiles) {
+        const unsigned char* b = frames + base_of(tile);
+#pragma unroll
+        for (int gidx = 0; gidx < NG; ++gidx) cur[gidx] = *reinterpret_cast<const unsigned*>(b + koff[gidx]);
+    }
+    for (; tile < ntiles; tile += nwaves) {
+        const long long tn = tile + nwaves;
+        {
+            const unsigned char* b = frames + base_of(tn < ntiles ? tn : tile);
+#pragma unroll
+            for (int gidx = 0; gidx < NG; ++gidx) nxt[gidx] = *reinterpret_cast<const unsigned*>(b + koff[gidx]);
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gidx = 0; gidx < NG; ++gidx) {
+            const unsigned x = cur[gidx];
+            acc = MFMA16C(u8_div255(x, 0), w[gidx].x, acc);
+            acc = MFMA16C(u8_div255(x, 1), w[gidx].y, acc);
+            acc = MFMA16C(u8_div255(x, 2), w[gidx].z, acc);
+            acc = MFMA16C(u8_div255(x, 3), w[gidx].w, acc);
+        }
+        // C fragment: lane holds patches 4 kq + r (r = 0..3) of output channel i
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long row = tile * 16 + 4 * kq + r;
+            float v = acc[r] + bv;
+            v = v < 0.f ? 0.f : v;
+            if (row < rows && i < cout) y[row * cout + i] = v;
+        }
+#pragma unroll
+        for (int gidx = 0; gidx < NG; ++gidx) cur[gidx] = nxt[gidx];
+    }
+}
+
 inline bool geom_ok(const ConvGeom& g) {
     return g.C > 0 && g.Hin > 0 && g.Win > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 &&
            g.Ho == (g.Hin - g.kh) / g.stride + 1 && g.Wo == (g.Win - g.kw) / g.stride + 1 &&
@@ -124,6 +216,37 @@ extern "C" int smx_im2col_f32(const void* src, int32_t src_is_u8, int32_t channe
     else
         hipLaunchKernelGGL((im2col_kernel<false, false>), dim3(blocks), dim3(256), 0,
                            smx_s(stream), src, g, total, scale_div, cols);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_conv_u8_forward_f32(const void* frames, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                                       int32_t stride, const float* W, const float* bias, int32_t cout, float* y,
+                                       const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(frames && W && bias && y, SMX_E_NULL);
+    ConvGeom g{C, Hin, Win, k, k, stride, (Hin - k) / stride + 1, (Win - k) / stride + 1};
+    SMX_REQUIRE(F > 0 && geom_ok(g) && cout > 0, SMX_E_SHAPE);
+    const int K = C * k * k;
+    // dword gathers: four consecutive k's share a frame row and are 4-byte aligned
+    if (cout > 16 || k % 4 || Win % 4 || stride % 4 || K % 16 || K > 256 || ((uintptr_t)frames & 3) ||
+        ((uintptr_t)W & 15))
+        return SMX_E_UNSUPPORTED;
+    const long long rows = (long long)F * g.Ho * g.Wo;
+    const long long ntiles = (rows + 15) >> 4;
+    long long blocks = (ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;                   // 8 workgroups of 4 wavefronts per CU at most
+    const unsigned char* fr = static_cast<const unsigned char*>(frames);
+    void (*kern)(const unsigned char*, ConvGeom, long long, const float*, const float*, int, float*, const int*) =
+        nullptr;
+    switch (K / 16) {
+        case 4: kern = conv_u8_fwd_kernel<4>; break;
+        case 8: kern = conv_u8_fwd_kernel<8>; break;
+        case 12: kern = conv_u8_fwd_kernel<12>; break;
+        case 16: kern = conv_u8_fwd_kernel<16>; break;
+        default: return SMX_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), fr, g, rows, W, bias, cout, y,
+                       stop_flag);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -581,6 +581,18 @@ class HipKernels(object):
         L.call('smx_im2col_f32', L.ptr(src), int(src.dtype == torch.uint8), int(channel_last), F, C,
                Hin, Win, k, k, stride, float(scale_div), L.ptr(cols), self._st())
 
+    @staticmethod
+    def conv_u8_supported(frames, C, Hin, Win, k, stride, cout):
+        """shapes smx_conv_u8_forward_f32 takes (the implicit-GEMM first convolution over uint8 frames)"""
+        K = C * k * k
+        return frames.dtype == torch.uint8 and cout <= 16 and k % 4 == 0 and Win % 4 == 0 and stride % 4 == 0 \
+            and K % 64 == 0 and K <= 256 and frames.data_ptr() % 4 == 0
+
+    def conv_u8_forward(self, frames, F, C, Hin, Win, k, stride, W, bias, cout, y, stop=None):
+        """y [F*Ho*Wo, cout] = relu(conv(frames / 255, W) + bias), no patch matrix (see the header)"""
+        L.call('smx_conv_u8_forward_f32', L.ptr(frames), F, C, Hin, Win, k, stride, L.ptr(W), L.ptr(bias), cout,
+               L.ptr(y), L.ptr(stop), self._st())
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         L.call('smx_col2im_f32', L.ptr(dcols), F, C, Hin, Win, k, k, stride, L.ptr(relu_of),
                L.ptr(dx), self._st())

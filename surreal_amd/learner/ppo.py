@@ -1070,9 +1070,13 @@ class PPOLearner(Learner):
                 xin[:, :D].copy_(low2d)
         if frames is not None:
             nF = frames.shape[0]
+            # one chunk: the patch matrix of the first convolution survives until the frames change (the caller
+            # bumps ws.frames_epoch when it refills them) -- every later forward of this learn, under either model,
+            # and the backward passes reuse it
+            tag = (getattr(ws, 'frames_epoch', 0), frames.data_ptr(), nF) if nF <= cnn_ws.F else None
             for f0 in range(0, nF, cnn_ws.F):
                 f1 = min(nF, f0 + cnn_ws.F)
-                mm._cnn_stem.forward(mm.cnn, frames[f0:f1], f1 - f0, cnn_ws, xin[f0:f1, D:], stop)
+                mm._cnn_stem.forward(mm.cnn, frames[f0:f1], f1 - f0, cnn_ws, xin[f0:f1, D:], stop, cols1_tag=tag)
 
     def _enqueue_gae_stem(self, ws, obs, obs_next, pix, pix_next, rewards, dones):
         """critic over all (B, N+1) steps + windowed GAE with horizon H (ppo.py:376-418)"""
@@ -1226,6 +1230,7 @@ class PPOLearner(Learner):
         ws.beh_it.view(B, E, 2 * A).copy_(pds[:, :E])
         if m.if_pixel:
             ws.frames_it.view((B, E) + tuple(pix.shape[2:])).copy_(pix[:, :E])
+            ws.frames_epoch = getattr(ws, 'frames_epoch', 0) + 1      # new frames: the cached patch matrix is stale
         zst = (m.z_filter._mean, m.z_filter._std) if self.use_z_filter else None   # refreshed in the GAE pass
         rzst = ref.z_filter.refresh_stats() if self.use_z_filter else None
         self._stem_inputs(ws, m, ws.low_it, None, ws.xn, None, zst)     # CNN part: every forward

@@ -89,12 +89,25 @@ class CnnStem(object):
                 self.K.linear_wgrad_ws_floats(p.c1, p.K1, F * p.P1))
         return torch.empty(n, device=device, dtype=torch.float32) if n else None
 
-    def forward(self, p, frames, F, ws, out, stop=None):
-        """frames: uint8 or fp32 [F, C, H, W] (contiguous); out: [F, feat] view (any row stride)"""
+    def forward(self, p, frames, F, ws, out, stop=None, cols1_tag=None):
+        """frames: uint8 or fp32 [F, C, H, W] (contiguous); out: [F, feat] view (any row stride).
+        cols1_tag: identifies the CONTENT of `frames` (the caller's choice, e.g. (learn counter, pointer, F)); when it
+        equals the tag of the patch matrix ws.cols1 already holds, the first convolution's im2col is skipped -- the
+        patches do not depend on the weights, and a learn runs ~22 forwards over the same frames."""
         K, v = self.K, p.views
-        K.im2col(frames, F, p.C, p.H, p.W, p.k1, p.s1, ws.cols1, scale_div=255.0)
-        K.linear(ws.cols1, 1, v['conv1.W'].view(p.c1, p.K1), 1, v['conv1.b'], ws.y1, F * p.P1, p.c1,
-                 p.K1, act=L.SMX_ACT_RELU, stop=stop)
+        if K.conv_u8_supported(frames, p.C, p.H, p.W, p.k1, p.s1, p.c1):
+            # implicit GEMM straight from the uint8 frames: no patch matrix on the forward path.  The weight
+            # gradient of this layer still reads one (backward() builds it on first use, once per set of frames)
+            K.conv_u8_forward(frames, F, p.C, p.H, p.W, p.k1, p.s1, v['conv1.W'], v['conv1.b'], p.c1, ws.y1,
+                              stop=stop)
+            ws.cols1_src = (frames, F, cols1_tag)
+        else:
+            if cols1_tag is None or getattr(ws, 'cols1_tag', None) != cols1_tag:
+                K.im2col(frames, F, p.C, p.H, p.W, p.k1, p.s1, ws.cols1, scale_div=255.0)
+                ws.cols1_tag = cols1_tag
+            ws.cols1_src = None
+            K.linear(ws.cols1, 1, v['conv1.W'].view(p.c1, p.K1), 1, v['conv1.b'], ws.y1, F * p.P1, p.c1,
+                     p.K1, act=L.SMX_ACT_RELU, stop=stop)
         K.im2col(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.cols2, channel_last=True)
         K.linear(ws.cols2, 1, v['conv2.W'].view(p.c2, p.K2), 1, v['conv2.b'], ws.y2, F * p.P2, p.c2,
                  p.K2, act=L.SMX_ACT_RELU, stop=stop)
@@ -126,6 +139,13 @@ class CnnStem(object):
         K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
                  stop=stop)
         K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)
-        # conv1: dW, db (the frames carry no gradient)
+        # conv1: dW, db (the frames carry no gradient); the patch matrix is built here when the forward pass went
+        # through the implicit GEMM and the cached one belongs to other frames
+        src = getattr(ws, 'cols1_src', None)
+        if src is not None:
+            frames, Fs, tag = src
+            if tag is None or getattr(ws, 'cols1_tag', None) != tag:
+                K.im2col(frames, Fs, p.C, p.H, p.W, p.k1, p.s1, ws.cols1, scale_div=255.0)
+                ws.cols1_tag = tag
         K.linear_wgrad(ws.dy1, ws.cols1, gv['conv1.W'].view(p.c1, p.K1), gv['conv1.b'], p.c1, p.K1,
                        F * p.P1, ws=ws.sk)

@@ -737,6 +737,20 @@ class TorchCpuKernels(object):
         P = u.shape[2]
         cols[:F * P].copy_(u.transpose(1, 2).reshape(F * P, C * k * k))
 
+    @staticmethod
+    def conv_u8_supported(frames, C, Hin, Win, k, stride, cout):
+        K = C * k * k
+        return frames.dtype == torch.uint8 and cout <= 16 and k % 4 == 0 and Win % 4 == 0 and stride % 4 == 0 \
+            and K % 64 == 0 and K <= 256
+
+    def conv_u8_forward(self, frames, F, C, Hin, Win, k, stride, W, bias, cout, y, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        Ho, Wo = (Hin - k) // stride + 1, (Win - k) // stride + 1
+        cols = torch.empty(F * Ho * Wo, C * k * k)
+        self.im2col(frames, F, C, Hin, Win, k, stride, cols, scale_div=255.0)
+        y[:F * Ho * Wo].copy_(torch.relu(torch.nn.functional.linear(cols, W.reshape(cout, -1), bias)))
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         P = ((Hin - k) // stride + 1) * ((Win - k) // stride + 1)
         u = dcols[:F * P].reshape(F, P, C * k * k).transpose(1, 2)

@@ -394,6 +394,39 @@ def test_uint8_frames_stay_uint8_in_the_device_replay(K):
     assert got['frames'].dtype == torch.uint8 and torch.equal(got['frames'], frames[[9, 0, 3, 3, 7]])
 
 
+@pytest.mark.parametrize('F,C,H,W,k,st,cout', [(5, 3, 84, 84, 8, 4, 16), (3, 2, 20, 24, 8, 4, 16), (7, 1, 28, 36, 8, 4, 9),
+                                                (2, 4, 84, 84, 8, 4, 16), (1, 4, 12, 12, 4, 4, 5)])
+def test_conv_u8_forward_is_im2col_plus_gemm(K, F, C, H, W, k, st, cout):
+    """the implicit-GEMM first convolution over uint8 frames (smx_conv_u8_forward_f32) against the materialised
+    route (smx_im2col_f32 with /255 + smx_linear_f32 with ReLU) and the CPU double; every byte value occurs, a
+    row count that is not a multiple of 16, fewer than 16 output channels, and the stop flag"""
+    g = torch.Generator().manual_seed(F * 7 + C)
+    frames = torch.randint(0, 256, (F, C, H, W), generator=g).to(torch.uint8)
+    frames.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
+    Kc = C * k * k
+    Wt = torch.randn(cout, C, k, k, generator=g) / Kc ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
+    rows = F * Ho * Wo
+    assert K.conv_u8_supported(dev(frames), C, H, W, k, st, cout)
+    yc = torch.empty(rows, cout)
+    C_ = C
+    from cpu_kernels import TorchCpuKernels
+    TorchCpuKernels().conv_u8_forward(frames, F, C_, H, W, k, st, Wt, b, cout, yc)
+    yd = torch.full((rows, cout), float('nan')).cuda()
+    K.conv_u8_forward(dev(frames), F, C, H, W, k, st, dev(Wt), dev(b), cout, yd)
+    close(yd, yc, msg='implicit conv vs double')
+    cols = torch.empty(rows, Kc).cuda()
+    K.im2col(dev(frames), F, C, H, W, k, st, cols, scale_div=255.0)
+    ym = torch.empty(rows, cout).cuda()
+    K.linear(cols, 1, dev(Wt).view(cout, Kc), 1, dev(b), ym, rows, cout, Kc, act=L.SMX_ACT_RELU)
+    close(yd, ym.cpu(), atol=2e-6, rtol=2e-6, msg='implicit conv vs im2col + GEMM')
+    stop = torch.ones(1, dtype=torch.int32).cuda()
+    yd.fill_(3.0)
+    K.conv_u8_forward(dev(frames), F, C, H, W, k, st, dev(Wt), dev(b), cout, yd, stop=stop)
+    assert float(yd.min()) == 3.0
+
+
 def test_replay_kernels(K):
     g = torch.Generator().manual_seed(31)
     for cap, width in ((5, 7), (96, 44), (1000, 376)):
