@@ -390,6 +390,21 @@ def main():
             del sl
 
     ws = learner._ws
+    # what one per-epoch exchange costs on this node: the all-reduce of the epoch payload, timed alone
+    collective_us = collective_bytes = None
+    if world > 1 and getattr(ws, 'ar', None) is not None:
+        for _ in range(5):
+            dist.all_reduce(ws.ar)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(ws.ar)
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        collective_us, collective_bytes = float(t.item()), ws.ar.numel() * 4
     kt = time_fused_kernel(learner, dbatch) if ws.key[0] == B and not (learner.if_rnn_policy or learner.model.if_pixel) else None
     out = None
     if rank == 0:
@@ -416,6 +431,8 @@ def main():
                 'hip_graph': bool(learner.use_graph), 'parallelism': 'dp%d' % world,
                 'epoch_kernels': 'fused row-block' if getattr(ws, 'fused', False) else 'layered',
                 'collectives_per_step': getattr(learner, 'collectives_per_step', 0 if world == 1 else None),
+                'epoch_all_reduce_us': collective_us, 'epoch_all_reduce_bytes': collective_bytes,
+                'graph_segments': bool(getattr(learner, 'graph_segments_active', world > 1 and learner.use_graph)),
             },
             'final_stats': {k: stats[k] for k in ('_surr_loss', '_val_loss', '_pol_kl') if k in stats},
         }

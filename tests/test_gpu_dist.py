@@ -136,5 +136,6 @@ def test_bench_two_ranks_share_one_gpu():
     assert out['config']['parallelism'] == 'dp2' and out['value'] > 0
     assert out['strong']['global_batch'] == 1024 and out['strong']['B_per_gpu'] == 512 and out['strong']['value'] > 0
     assert out['config']['collectives_per_step'] == 12 and out['config']['epoch_kernels'] == 'fused row-block'
+    assert out['config']['epoch_all_reduce_us'] > 0 and out['config']['epoch_all_reduce_bytes'] > 1e6
     assert 'cpu_baseline' not in out and out['roofline']['frac'] > 0
     assert all(np.isfinite(v) for v in out['final_stats'].values())
