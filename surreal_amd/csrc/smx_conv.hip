@@ -20,24 +20,27 @@ struct ConvGeom {
 
 // SRC_U8: src is uint8 NCHW frames, value = float(u8) / 255.0f; else fp32.
 // CHANNEL_LAST: src is [F, Hin*Win, C] (an activation of ours); else [F, C, Hin, Win].
-template <bool SRC_U8, bool CHANNEL_LAST>
+// IDX: unsigned (32-bit index arithmetic) whenever the patch matrix and the source have fewer than 2^31 elements --
+// the element -> (row, c, i, j) decomposition is five integer divisions, and 64-bit ones (software sequences of ~60
+// instructions each on this ISA) made these pure data-movement kernels ALU-bound at 1.2 TB/s.
+template <bool SRC_U8, bool CHANNEL_LAST, typename IDX>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ src, ConvGeom g,
-                                                     long long total, float scale_div,
+                                                     long long total_, float scale_div,
                                                      float* __restrict__ cols) {
-    const int K = g.C * g.kh * g.kw;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * 256) {
-        const long long row = idx / K;
+    const IDX K = (IDX)(g.C * g.kh * g.kw), total = (IDX)total_;
+    const IDX P = (IDX)(g.Ho * g.Wo);
+    for (IDX idx = (IDX)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (IDX)gridDim.x * 256) {
+        const IDX row = idx / K;
         const int k = (int)(idx - row * K);
         const int c = k / (g.kh * g.kw), ij = k - c * (g.kh * g.kw);
         const int i = ij / g.kw, j = ij - i * g.kw;
-        const long long f = row / (g.Ho * g.Wo);
-        const int p = (int)(row - f * (g.Ho * g.Wo));
+        const IDX f = row / P;
+        const int p = (int)(row - f * P);
         const int oy = p / g.Wo, ox = p - oy * g.Wo;
         const int y = oy * g.stride + i, x = ox * g.stride + j;
-        const long long s = CHANNEL_LAST
-                                ? ((f * g.Hin + y) * g.Win + x) * g.C + c
-                                : ((f * g.C + c) * g.Hin + y) * (long long)g.Win + x;
+        const IDX s = CHANNEL_LAST
+                          ? ((f * g.Hin + y) * g.Win + x) * g.C + c
+                          : ((f * g.C + c) * g.Hin + y) * (IDX)g.Win + x;
         float v = SRC_U8 ? (float)static_cast<const unsigned char*>(src)[s]
                          : static_cast<const float*>(src)[s];
         if (scale_div != 0.f) v = v / scale_div;
@@ -47,17 +50,17 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ sr
 
 // dX[f, y, x, c] = mask * sum over (i, j) with oy*stride + i == y, ox*stride + j == x of
 //                  dcols[(f, oy, ox), c*kh*kw + i*kw + j]          (channel-last dX)
+template <typename IDX>
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, ConvGeom g,
-                                                     long long total,
+                                                     long long total_,
                                                      const float* __restrict__ relu_of,
                                                      float* __restrict__ dx) {
-    const int K = g.C * g.kh * g.kw;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * 256) {
-        const int c = (int)(idx % g.C);
-        const long long pix = idx / g.C;
-        const long long f = pix / (g.Hin * g.Win);
-        const int yx = (int)(pix - f * (g.Hin * g.Win));
+    const IDX K = (IDX)(g.C * g.kh * g.kw), total = (IDX)total_;
+    for (IDX idx = (IDX)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (IDX)gridDim.x * 256) {
+        const int c = (int)(idx % (IDX)g.C);
+        const IDX pix = idx / (IDX)g.C;
+        const IDX f = pix / (IDX)(g.Hin * g.Win);
+        const int yx = (int)(pix - f * (IDX)(g.Hin * g.Win));
         const int y = yx / g.Win, x = yx - y * g.Win;
         float acc = 0.f;
         for (int i = y % g.stride; i < g.kh; i += g.stride) {
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
             for (int j = x % g.stride; j < g.kw; j += g.stride) {
                 const int ox = (x - j) / g.stride;
                 if (x - j < 0 || ox >= g.Wo) continue;
-                acc += dcols[((f * g.Ho + oy) * g.Wo + ox) * K + c * (g.kh * g.kw) + i * g.kw + j];
+                acc += dcols[((f * g.Ho + oy) * g.Wo + ox) * K + (IDX)(c * (g.kh * g.kw) + i * g.kw + j)];
             }
         }
         if (relu_of) acc = (relu_of[idx] > 0.f) ? acc : 0.f;
@@ -207,15 +210,20 @@ extern "C" int smx_im2col_f32(const void* src, int32_t src_is_u8, int32_t channe
     SMX_REQUIRE(!(src_is_u8 && channel_last), SMX_E_UNSUPPORTED);
     const long long total = (long long)F * g.Ho * g.Wo * C * kh * kw;
     const int blocks = grid_for(total);
-    if (src_is_u8)
-        hipLaunchKernelGGL((im2col_kernel<true, false>), dim3(blocks), dim3(256), 0, smx_s(stream),
-                           src, g, total, scale_div, cols);
-    else if (channel_last)
-        hipLaunchKernelGGL((im2col_kernel<false, true>), dim3(blocks), dim3(256), 0, smx_s(stream),
-                           src, g, total, scale_div, cols);
-    else
-        hipLaunchKernelGGL((im2col_kernel<false, false>), dim3(blocks), dim3(256), 0,
-                           smx_s(stream), src, g, total, scale_div, cols);
+    const bool small = total < (1ll << 31) && (long long)F * C * Hin * Win < (1ll << 31);
+#define SMX_IM2COL(U8, CL)                                                                                    \
+    do {                                                                                                      \
+        if (small)                                                                                            \
+            hipLaunchKernelGGL((im2col_kernel<U8, CL, unsigned>), dim3(blocks), dim3(256), 0, smx_s(stream),  \
+                               src, g, total, scale_div, cols);                                               \
+        else                                                                                                  \
+            hipLaunchKernelGGL((im2col_kernel<U8, CL, long long>), dim3(blocks), dim3(256), 0, smx_s(stream), \
+                               src, g, total, scale_div, cols);                                               \
+    } while (0)
+    if (src_is_u8) SMX_IM2COL(true, false);
+    else if (channel_last) SMX_IM2COL(false, true);
+    else SMX_IM2COL(false, false);
+#undef SMX_IM2COL
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -258,8 +266,12 @@ extern "C" int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t 
     ConvGeom g{C, Hin, Win, kh, kw, stride, (Hin - kh) / stride + 1, (Win - kw) / stride + 1};
     SMX_REQUIRE(F > 0 && geom_ok(g), SMX_E_SHAPE);
     const long long total = (long long)F * Hin * Win * C;
-    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, smx_s(stream), dcols, g,
-                       total, relu_of, dx);
+    if ((long long)F * g.Ho * g.Wo * C * kh * kw < (1ll << 31) && total < (1ll << 31))
+        hipLaunchKernelGGL(col2im_kernel<unsigned>, dim3(grid_for(total)), dim3(256), 0, smx_s(stream), dcols, g,
+                           total, relu_of, dx);
+    else
+        hipLaunchKernelGGL(col2im_kernel<long long>, dim3(grid_for(total)), dim3(256), 0, smx_s(stream), dcols, g,
+                           total, relu_of, dx);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
