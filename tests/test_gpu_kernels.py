@@ -193,6 +193,35 @@ def test_mlp3_forward_fused(K, G, T0, T1, D, H1, H2, OUT, z):
     close(od, oc, msg='fused mlp G=%d T0=%d T1=%d D=%d' % (G, T0, T1, D))
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_mlp3_forward_fused_random_shapes_agree_with_the_32_row_kernel(K, seed):
+    """the 16-row kernel (smx_mlp3_rows16.hip) over random shapes inside its fast path -- hidden sizes that end in a
+    partial 16-feature tile, D = 4 .. 400 in steps of 4, 1 .. 16 outputs, ragged row counts, with and without the
+    obs_next tail and the z-filter -- against the CPU double"""
+    g = torch.Generator().manual_seed(100 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    D, H1, H2 = 4 * ri(1, 100), ri(65, 320), ri(65, 224)
+    OUT = 1 if seed % 2 == 0 else ri(2, 16)
+    G, T0, T1 = ri(1, 40), ri(1, 23), ri(0, 1)
+    z = bool(seed % 3)
+    nc, nd = make_net(D, H1, H2, OUT, 7 + seed, 'cuda')
+    xm = torch.randn(G, T0, D, generator=g) * 2 + 0.3
+    xt = torch.randn(G, T1, D, generator=g) if T1 else None
+    zm = (torch.randn(D, generator=g) * 0.3) if z else None
+    zs = (torch.rand(D, generator=g) + 0.5) if z else None
+    act = L.SMX_ACT_NONE if OUT == 1 else L.SMX_ACT_TANH
+    rows = G * (T0 + T1)
+    pc = torch.empty(C.mlp3_packed_numel(nc))
+    C.mlp3_pack(nc, pc)
+    oc = torch.empty(rows * OUT)
+    C.mlp3_forward_fused(pc, nc, xm, xt, zm, zs, oc, act)
+    pd = torch.empty(K.mlp3_packed_numel(nd)).cuda()
+    K.mlp3_pack(nd, pd)
+    od = torch.full((rows * OUT,), float('nan')).cuda()
+    K.mlp3_forward_fused(pd, nd, dev(xm), dev(xt) if T1 else None, dev(zm) if z else None, dev(zs) if z else None, od, act)
+    close(od, oc, msg='fused mlp D=%d H1=%d H2=%d OUT=%d rows=%d z=%s' % (D, H1, H2, OUT, rows, z))
+
+
 def test_fused_exact_zfilter_switch(K):
     """the two z-filter arithmetics of the fused critic pass: the default multiplies by a
     reciprocal, the switch selects the reference's division; both within the contract, and within a few ulp of the
