@@ -729,6 +729,16 @@ int smx_im2col_f32(const void* src, int32_t src_is_u8, int32_t channel_last, int
 int smx_conv_u8_forward_f32(const void* frames, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
                             int32_t stride, const float* W, const float* bias, int32_t cout, float* y,
                             const int32_t* stop_flag, smx_stream_t stream);
+/* The same layer's weight gradient, again from the uint8 frames (no patch matrix): dW[o][(c, i, j)] = sum over
+ * (f, oy, ox) of dy[(f, oy, ox), o] * float(frames[f][c][oy*stride + i][ox*stride + j]) / 255, db[o] = the column
+ * sums of dy -- what autograd gives Conv2d.weight / .bias (ppo.py:243-247 backward through builders.py:8-33); equal
+ * to smx_im2col_f32 + smx_linear_wgrad_splitk_f32 up to summation order.  dy is [F*Ho*Wo, cout] row-major; ws holds
+ * smx_conv_u8_wgrad_ws_floats(cout, C*k*k) floats (per-workgroup partials, added in a fixed order by a second launch).
+ * Same shape limits as smx_conv_u8_forward_f32. */
+int64_t smx_conv_u8_wgrad_ws_floats(int32_t cout, int32_t K);
+int smx_conv_u8_wgrad_f32(const void* frames, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                          int32_t stride, const float* dy, int32_t cout, float* dW, float* db, float* ws,
+                          int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream);
 /* data gradient of the convolution above: dx [F, Hin*Win, C] (channel-last) gathers dcols
  * [F*Ho*Wo, C*kh*kw]; relu_of (optional, same shape as dx): dx *= (relu_of > 0). */
 int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t kh,

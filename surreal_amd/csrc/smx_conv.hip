@@ -193,6 +193,140 @@ __global__ __launch_bounds__(256) void conv_u8_fwd_kernel(const unsigned char* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The first convolution's WEIGHT GRADIENT from the uint8 frames (no patch matrix): dW[o][k] = sum over patch rows of
+// dy[row][o] * patch[row][k], db[o] = sum of dy[row][o].  v_mfma_f32_16x16x4 with M = output channel, N = 16 of the K
+// patch columns, the MFMA k dimension = four patch rows per step:
+//   * a wavefront takes 16 patch rows at a time: lane (i = row, kq) fetches the row's bytes as dwords exactly like the
+//     forward kernel and drops them RAW into a 16 x K byte tile in LDS; the B fragments are then byte reads,
+//     tile[4 kq + s][16 t + i], converted with the exact u8 / 255;
+//   * the A fragments are dy[r0 + 4 kq + s][i] (64-byte runs);
+//   * NG accumulators (16 x 16 each) stay in registers over all the groups a wavefront walks; the four wavefronts of a
+//     workgroup are summed through LDS and a workgroup writes ONE partial [cout][K] (+ [cout] for the bias); a second
+//     launch adds the partials in a fixed order (smx_gemm.hip's split-K reduce contract: deterministic).
+// ---------------------------------------------------------------------------------------------
+template <int NG>
+__global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char* __restrict__ frames, ConvGeom g,
+                                                            long long rows, const float* __restrict__ dy, int cout,
+                                                            float* __restrict__ part, float* __restrict__ dbpart,
+                                                            const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    constexpr int K = 16 * NG;
+    constexpr int RS = K + 16;                          // byte row stride of the LDS tile (bank spread)
+    __shared__ unsigned char tile[4][16 * RS];
+    __shared__ float comb[4][16 * K];                   // the four wavefronts' accumulators, then their sum
+    __shared__ float dbs[4][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    const long long nwaves = (long long)gridDim.x * 4;
+    int koff[NG];
+#pragma unroll
+    for (int gidx = 0; gidx < NG; ++gidx) {
+        const int k = 16 * gidx + 4 * kq;
+        const int c = k / (g.kh * g.kw), ij = k - c * (g.kh * g.kw);
+        const int ki = ij / g.kw, kj = ij - ki * g.kw;
+        koff[gidx] = (c * g.Hin + ki) * g.Win + kj;
+    }
+    const int P = g.Ho * g.Wo;
+    const long long ngroups = (rows + 15) >> 4;
+    auto base_of = [&](long long grp) -> long long {
+        long long row = grp * 16 + i;
+        if (row >= rows) row = rows - 1;                // clamped: its dy is taken as zero
+        const long long f = row / P;
+        const int p = (int)(row - f * P);
+        const int oy = p / g.Wo, ox = p - oy * g.Wo;
+        return (f * g.C * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride;
+    };
+    f32x4 acc[NG];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc = 0.f;
+    unsigned char* mytile = tile[wv];
+    unsigned cur[NG], nxt[NG];
+    long long grp = wave;
+    if (grp < ngroups) {
+        const unsigned char* b = frames + base_of(grp);
+#pragma unroll
+        for (int gidx = 0; gidx < NG; ++gidx) cur[gidx] = *reinterpret_cast<const unsigned*>(b + koff[gidx]);
+    }
+    for (; grp < ngroups; grp += nwaves) {
+        const long long gn = grp + nwaves;
+        {
+            const unsigned char* b = frames + base_of(gn < ngroups ? gn : grp);
+#pragma unroll
+            for (int gidx = 0; gidx < NG; ++gidx) nxt[gidx] = *reinterpret_cast<const unsigned*>(b + koff[gidx]);
+        }
+        // dy of the group's rows 4 kq + s, channel i
+        float a[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const long long row = grp * 16 + 4 * kq + s4;
+            a[s4] = (row < rows && i < cout) ? dy[row * cout + i] : 0.f;
+            dbacc += a[s4];
+        }
+        // raw bytes of patch row i, columns 16 g + 4 kq .. + 3  -> the wavefront's LDS tile
+#pragma unroll
+        for (int gidx = 0; gidx < NG; ++gidx)
+            *reinterpret_cast<unsigned*>(mytile + i * RS + 16 * gidx + 4 * kq) = cur[gidx];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS is in order per wavefront; the tile is private
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const unsigned bt = mytile[(4 * kq + s4) * RS + 16 * t + i];
+                acc[t] = MFMA16C(a[s4], u8_div255(bt, 0), acc[t]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int gidx = 0; gidx < NG; ++gidx) cur[gidx] = nxt[gidx];
+    }
+    // lane (i, kq) holds dW[o = 4 kq + r][k = 16 t + i]; the bias partial: sum over the four kq lane groups
+    dbacc += __shfl_xor(dbacc, 16, 64);
+    dbacc += __shfl_xor(dbacc, 32, 64);
+    if (kq == 0) dbs[wv][i] = dbacc;
+#pragma unroll
+    for (int t = 0; t < NG; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) comb[wv][(4 * kq + r) * K + 16 * t + i] = acc[t][r];
+    __syncthreads();
+    float* out = part + (size_t)blockIdx.x * cout * K;
+    for (int idx = threadIdx.x; idx < cout * K; idx += 256)
+        out[idx] = ((comb[0][idx] + comb[1][idx]) + comb[2][idx]) + comb[3][idx];
+    if (threadIdx.x < cout)
+        dbpart[(size_t)blockIdx.x * cout + threadIdx.x] =
+            ((dbs[0][threadIdx.x] + dbs[1][threadIdx.x]) + dbs[2][threadIdx.x]) + dbs[3][threadIdx.x];
+}
+
+// out[e] = sum over s of part[s][e], fixed order
+__global__ __launch_bounds__(256) void conv_partial_reduce_kernel(const float* __restrict__ part,
+                                                                  const float* __restrict__ dbpart, int splits,
+                                                                  int nW, int nB, float* __restrict__ dW,
+                                                                  float* __restrict__ db,
+                                                                  const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nW + nB) return;
+    const float* src = e < nW ? part + e : dbpart + (e - nW);
+    const int stride = e < nW ? nW : nB;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;          // four interleaved chains, combined in a fixed order
+    int sidx = 0;
+    for (; sidx + 3 < splits; sidx += 4) {
+        v0 += src[(size_t)sidx * stride];
+        v1 += src[(size_t)(sidx + 1) * stride];
+        v2 += src[(size_t)(sidx + 2) * stride];
+        v3 += src[(size_t)(sidx + 3) * stride];
+    }
+    for (; sidx < splits; ++sidx) v0 += src[(size_t)sidx * stride];
+    const float v = (v0 + v1) + (v2 + v3);
+    if (e < nW) dW[e] = v;
+    else if (db) db[e - nW] = v;
+}
+
+constexpr int CONV_WGRAD_BLOCKS = 256;      // one workgroup per CU: 256 partials
+
 inline bool geom_ok(const ConvGeom& g) {
     return g.C > 0 && g.Hin > 0 && g.Win > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 &&
            g.Ho == (g.Hin - g.kh) / g.stride + 1 && g.Wo == (g.Win - g.kw) / g.stride + 1 &&
@@ -255,6 +389,45 @@ extern "C" int smx_conv_u8_forward_f32(const void* frames, int64_t F, int32_t C,
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), fr, g, rows, W, bias, cout, y,
                        stop_flag);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int64_t smx_conv_u8_wgrad_ws_floats(int32_t cout, int32_t K) {
+    return (int64_t)CONV_WGRAD_BLOCKS * ((int64_t)cout * K + cout);
+}
+
+extern "C" int smx_conv_u8_wgrad_f32(const void* frames, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                                     int32_t stride, const float* dy, int32_t cout, float* dW, float* db, float* ws,
+                                     int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(frames && dy && dW && ws, SMX_E_NULL);
+    ConvGeom g{C, Hin, Win, k, k, stride, (Hin - k) / stride + 1, (Win - k) / stride + 1};
+    SMX_REQUIRE(F > 0 && geom_ok(g) && cout > 0, SMX_E_SHAPE);
+    const int K = C * k * k;
+    if (cout > 16 || k % 4 || Win % 4 || stride % 4 || K % 64 || K > 256 || ((uintptr_t)frames & 3))
+        return SMX_E_UNSUPPORTED;
+    SMX_REQUIRE(ws_floats >= smx_conv_u8_wgrad_ws_floats(cout, K), SMX_E_WORKSPACE);
+    const long long rows = (long long)F * g.Ho * g.Wo;
+    const long long ngroups = (rows + 15) >> 4;
+    int blocks = (int)((ngroups + 3) / 4);
+    if (blocks > CONV_WGRAD_BLOCKS) blocks = CONV_WGRAD_BLOCKS;
+    float* part = ws;
+    float* dbpart = ws + (size_t)CONV_WGRAD_BLOCKS * cout * K;
+    const unsigned char* fr = static_cast<const unsigned char*>(frames);
+    void (*kern)(const unsigned char*, ConvGeom, long long, const float*, int, float*, float*, const int*) = nullptr;
+    switch (K / 16) {
+        case 4: kern = conv_u8_wgrad_kernel<4>; break;
+        case 8: kern = conv_u8_wgrad_kernel<8>; break;
+        case 12: kern = conv_u8_wgrad_kernel<12>; break;
+        case 16: kern = conv_u8_wgrad_kernel<16>; break;
+        default: return SMX_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), fr, g, rows, dy, cout, part, dbpart,
+                       stop_flag);
+    SMX_LAUNCH_CHECK();
+    const int n = cout * K + cout;
+    hipLaunchKernelGGL(conv_partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream),
+                       part, dbpart, blocks, cout * K, cout, dW, db, stop_flag);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -593,6 +593,14 @@ class HipKernels(object):
         L.call('smx_conv_u8_forward_f32', L.ptr(frames), F, C, Hin, Win, k, stride, L.ptr(W), L.ptr(bias), cout,
                L.ptr(y), L.ptr(stop), self._st())
 
+    def conv_u8_wgrad_ws_floats(self, cout, K):
+        return int(self.lib.smx_conv_u8_wgrad_ws_floats(cout, K))
+
+    def conv_u8_wgrad(self, frames, F, C, Hin, Win, k, stride, dy, cout, dW, db, ws, stop=None):
+        """dW [cout, C*k*k] (torch's Conv2d.weight order), db [cout] from dy [F*Ho*Wo, cout] and the uint8 frames"""
+        L.call('smx_conv_u8_wgrad_f32', L.ptr(frames), F, C, Hin, Win, k, stride, L.ptr(dy), cout, L.ptr(dW), L.ptr(db),
+               L.ptr(ws), ws.numel(), L.ptr(stop), self._st())
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         L.call('smx_col2im_f32', L.ptr(dcols), F, C, Hin, Win, k, k, stride, L.ptr(relu_of),
                L.ptr(dx), self._st())

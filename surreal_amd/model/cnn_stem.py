@@ -86,7 +86,8 @@ class CnnStem(object):
         """split-K workspace of the two convolution weight gradients (their GEMMs sum over
         F * pixels rows)"""
         n = max(self.K.linear_wgrad_ws_floats(p.c2, p.K2, F * p.P2),
-                self.K.linear_wgrad_ws_floats(p.c1, p.K1, F * p.P1))
+                self.K.linear_wgrad_ws_floats(p.c1, p.K1, F * p.P1),
+                self.K.conv_u8_wgrad_ws_floats(p.c1, p.K1))
         return torch.empty(n, device=device, dtype=torch.float32) if n else None
 
     def forward(self, p, frames, F, ws, out, stop=None, cols1_tag=None):
@@ -139,9 +140,14 @@ class CnnStem(object):
         K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
                  stop=stop)
         K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)
-        # conv1: dW, db (the frames carry no gradient); the patch matrix is built here when the forward pass went
-        # through the implicit GEMM and the cached one belongs to other frames
+        # conv1: dW, db (the frames carry no gradient).  Frames that went through the implicit-GEMM forward also give
+        # their weight gradient without a patch matrix; otherwise it is the GEMM over the materialised patches
         src = getattr(ws, 'cols1_src', None)
+        if src is not None and ws.sk is not None:
+            frames, Fs, _ = src
+            K.conv_u8_wgrad(frames, Fs, p.C, p.H, p.W, p.k1, p.s1, ws.dy1, p.c1, gv['conv1.W'].view(p.c1, p.K1),
+                            gv['conv1.b'], ws.sk, stop=stop)
+            return
         if src is not None:
             frames, Fs, tag = src
             if tag is None or getattr(ws, 'cols1_tag', None) != tag:

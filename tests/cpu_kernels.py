@@ -751,6 +751,20 @@ class TorchCpuKernels(object):
         self.im2col(frames, F, C, Hin, Win, k, stride, cols, scale_div=255.0)
         y[:F * Ho * Wo].copy_(torch.relu(torch.nn.functional.linear(cols, W.reshape(cout, -1), bias)))
 
+    def conv_u8_wgrad_ws_floats(self, cout, K):
+        return 1
+
+    def conv_u8_wgrad(self, frames, F, C, Hin, Win, k, stride, dy, cout, dW, db, ws, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        Ho, Wo = (Hin - k) // stride + 1, (Win - k) // stride + 1
+        rows = F * Ho * Wo
+        cols = torch.empty(rows, C * k * k)
+        self.im2col(frames, F, C, Hin, Win, k, stride, cols, scale_div=255.0)
+        dW.view(cout, -1).copy_(dy[:rows].reshape(rows, cout).t() @ cols)
+        if db is not None:
+            db.view(-1)[:cout].copy_(dy[:rows].reshape(rows, cout).sum(0))
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         P = ((Hin - k) // stride + 1) * ((Win - k) // stride + 1)
         u = dcols[:F * P].reshape(F, P, C * k * k).transpose(1, 2)

@@ -456,6 +456,37 @@ def test_conv_u8_forward_is_im2col_plus_gemm(K, F, C, H, W, k, st, cout):
     assert float(yd.min()) == 3.0
 
 
+@pytest.mark.parametrize('F,C,H,W,k,st,cout', [(5, 3, 84, 84, 8, 4, 16), (3, 2, 20, 24, 8, 4, 16), (7, 1, 28, 36, 8, 4, 9),
+                                                (40, 3, 84, 84, 8, 4, 16), (1, 4, 12, 12, 4, 4, 5)])
+def test_conv_u8_wgrad_is_im2col_plus_wgrad_gemm(K, F, C, H, W, k, st, cout):
+    """the implicit first-convolution weight gradient (smx_conv_u8_wgrad_f32) against the CPU double (patch matrix,
+    dy^T . patches in fp32) and against the materialised HIP route; fp32 tolerance on sums of F*Ho*Wo terms"""
+    g = torch.Generator().manual_seed(F * 3 + C)
+    frames = torch.randint(0, 256, (F, C, H, W), generator=g).to(torch.uint8)
+    Kc = C * k * k
+    Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
+    rows = F * Ho * Wo
+    dy = torch.randn(rows, cout, generator=g) / rows ** 0.5
+    dy[torch.rand(rows, cout, generator=g) < 0.4] = 0.0          # a ReLU mask's zeros
+    from cpu_kernels import TorchCpuKernels
+    Wc, bc = torch.empty(cout, Kc), torch.empty(cout)
+    TorchCpuKernels().conv_u8_wgrad(frames, F, C, H, W, k, st, dy, cout, Wc, bc, None)
+    ws = torch.empty(K.conv_u8_wgrad_ws_floats(cout, Kc)).cuda()
+    Wd, bd = torch.full((cout, Kc), float('nan')).cuda(), torch.full((cout,), float('nan')).cuda()
+    K.conv_u8_wgrad(dev(frames), F, C, H, W, k, st, dev(dy), cout, Wd, bd, ws)
+    close(Wd, Wc, atol=2e-5, rtol=2e-5, msg='implicit conv wgrad vs double')
+    close(bd, bc, atol=2e-5, rtol=2e-5, msg='bias gradient')
+    cols = torch.empty(rows, Kc).cuda()
+    K.im2col(dev(frames), F, C, H, W, k, st, cols, scale_div=255.0)
+    Wm, bm = torch.empty(cout, Kc).cuda(), torch.empty(cout).cuda()
+    K.linear_wgrad(dev(dy), cols, Wm, bm, cout, Kc, rows)
+    close(Wd, Wm.cpu(), atol=2e-5, rtol=2e-5, msg='implicit vs materialised wgrad')
+    stop = torch.ones(1, dtype=torch.int32).cuda()
+    Wd.fill_(3.0)
+    K.conv_u8_wgrad(dev(frames), F, C, H, W, k, st, dev(dy), cout, Wd, bd, ws, stop=stop)
+    assert float(Wd.min()) == 3.0
+
+
 def test_replay_kernels(K):
     g = torch.Generator().manual_seed(31)
     for cap, width in ((5, 7), (96, 44), (1000, 376)):
