@@ -73,7 +73,10 @@ class CnnStem(object):
     def workspace(p, F, device, backward=True):
         f = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)  # noqa: E731
         ws = types.SimpleNamespace(F=F)
-        ws.cols1, ws.y1 = f(F * p.P1, p.K1), f(F * p.P1, p.c1)
+        # the first convolution's patch matrix (2.2 GB at 7168 camera frames) is only allocated if something asks for
+        # it: uint8 frames inside the implicit-GEMM kernels' limits never do (_cols1)
+        ws.cols1, ws.y1 = None, f(F * p.P1, p.c1)
+        ws.cols1_shape, ws.device = (F * p.P1, p.K1), device
         ws.cols2, ws.y2 = f(F * p.P2, p.K2), f(F * p.P2, p.c2)
         ws.wfc = f(p.feat, p.flat_dim)                 # fc.W re-indexed channel-last
         ws.sk = None
@@ -81,6 +84,12 @@ class CnnStem(object):
             ws.dy2, ws.dcols2, ws.dy1 = f(F * p.P2, p.c2), f(F * p.P2, p.K2), f(F * p.P1, p.c1)
             ws.gwfc = f(p.feat, p.flat_dim)
         return ws
+
+    @staticmethod
+    def _cols1(ws):
+        if ws.cols1 is None:
+            ws.cols1 = torch.empty(*ws.cols1_shape, device=ws.device, dtype=torch.float32)
+        return ws.cols1
 
     def splitk_workspace(self, p, F, device):
         """split-K workspace of the two convolution weight gradients (their GEMMs sum over
@@ -104,7 +113,7 @@ class CnnStem(object):
             ws.cols1_src = (frames, F, cols1_tag)
         else:
             if cols1_tag is None or getattr(ws, 'cols1_tag', None) != cols1_tag:
-                K.im2col(frames, F, p.C, p.H, p.W, p.k1, p.s1, ws.cols1, scale_div=255.0)
+                K.im2col(frames, F, p.C, p.H, p.W, p.k1, p.s1, self._cols1(ws), scale_div=255.0)
                 ws.cols1_tag = cols1_tag
             ws.cols1_src = None
             K.linear(ws.cols1, 1, v['conv1.W'].view(p.c1, p.K1), 1, v['conv1.b'], ws.y1, F * p.P1, p.c1,
@@ -151,7 +160,7 @@ class CnnStem(object):
         if src is not None:
             frames, Fs, tag = src
             if tag is None or getattr(ws, 'cols1_tag', None) != tag:
-                K.im2col(frames, Fs, p.C, p.H, p.W, p.k1, p.s1, ws.cols1, scale_div=255.0)
+                K.im2col(frames, Fs, p.C, p.H, p.W, p.k1, p.s1, self._cols1(ws), scale_div=255.0)
                 ws.cols1_tag = tag
         K.linear_wgrad(ws.dy1, ws.cols1, gv['conv1.W'].view(p.c1, p.K1), gv['conv1.b'], p.c1, p.K1,
                        F * p.P1, ws=ws.sk)
