@@ -739,6 +739,18 @@ int64_t smx_conv_u8_wgrad_ws_floats(int32_t cout, int32_t K);
 int smx_conv_u8_wgrad_f32(const void* frames, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
                           int32_t stride, const float* dy, int32_t cout, float* dW, float* db, float* ws,
                           int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream);
+/* A convolution over an fp32 CHANNEL-LAST source of 16 channels ([F, Hin*Win, 16]: the first convolution's output) as
+ * implicit GEMMs, forward (+ bias + ReLU) and weight gradient -- the second Conv2d of builders.py:8-33 and what autograd
+ * gives its weight / bias; W and dW in torch's [cout][16][k][k] order; y / dy are [F*Ho*Wo, cout].  Equal to
+ * smx_im2col_f32 (channel_last = 1) + smx_linear_f32 / smx_linear_wgrad_splitk_f32 up to summation order.
+ * SMX_E_UNSUPPORTED unless C == 16, cout <= 32, k in {2, 3, 4}.  ws: smx_conv_cl_wgrad_ws_floats(cout, k) floats. */
+int smx_conv_cl_forward_f32(const float* src, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                            int32_t stride, const float* W, const float* bias, int32_t cout, float* y,
+                            const int32_t* stop_flag, smx_stream_t stream);
+int64_t smx_conv_cl_wgrad_ws_floats(int32_t cout, int32_t k);
+int smx_conv_cl_wgrad_f32(const float* src, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                          int32_t stride, const float* dy, int32_t cout, float* dW, float* db, float* ws,
+                          int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream);
 /* data gradient of the convolution above: dx [F, Hin*Win, C] (channel-last) gathers dcols
  * [F*Ho*Wo, C*kh*kw]; relu_of (optional, same shape as dx): dx *= (relu_of > 0). */
 int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t kh,

@@ -327,6 +327,192 @@ __global__ __launch_bounds__(256) void conv_partial_reduce_kernel(const float* _
 
 constexpr int CONV_WGRAD_BLOCKS = 256;      // one workgroup per CU: 256 partials
 
+// ---------------------------------------------------------------------------------------------
+// The SECOND convolution (fp32 channel-last source [F, Hin*Win, 16], e.g. the first one's output) as implicit GEMMs.
+// A patch is kh*kw positions of 16 contiguous channels: lane (i = patch, kq) fetches, per position p, the float4 of
+// channels 4 kq .. 4 kq + 3 -- the k's of four consecutive MFMA steps -- so the column order inside the kernels is
+// (p, c) while the weight stays in torch's [o][c][p] order (each lane picks its W[o][4 kq + s][p] once, into registers).
+// No patch matrix (594 MB at 7168 frames), no im2col launch (0.5 ms), and the GEMM no longer streams that matrix.
+// ---------------------------------------------------------------------------------------------
+template <int NP, int NT>      // NP = kh*kw positions (<= 16), NT = 16-channel output tiles (cout <= 16 NT)
+__global__ __launch_bounds__(256) void conv_cl_fwd_kernel(const float* __restrict__ src, ConvGeom g, long long rows,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          int cout, float* __restrict__ y, const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float4 w[NT][NP];
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int o = 16 * nt + i;
+        bv[nt] = o < cout ? bias[o] : 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < cout) {
+                const float* q = W + ((size_t)o * 16 + 4 * kq) * NP + p;       // W[o][c][p], c = 4 kq + s
+                v = make_float4(q[0], q[NP], q[2 * NP], q[3 * NP]);
+            }
+            w[nt][p] = v;
+        }
+    }
+    int poff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) poff[p] = ((p / g.kw) * g.Win + (p % g.kw)) * 16 + 4 * kq;
+    const int P = g.Ho * g.Wo;
+    const long long ntiles = (rows + 15) >> 4;
+    for (long long tile = wave; tile < ntiles; tile += nwaves) {
+        long long row = tile * 16 + i;
+        if (row >= rows) row = rows - 1;
+        const long long f = row / P;
+        const int pp = (int)(row - f * P);
+        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+        const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
+        float4 a[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const float4*>(b + poff[p]);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = MFMA16C(a[p].x, w[nt][p].x, acc[nt]);
+                acc[nt] = MFMA16C(a[p].y, w[nt][p].y, acc[nt]);
+                acc[nt] = MFMA16C(a[p].z, w[nt][p].z, acc[nt]);
+                acc[nt] = MFMA16C(a[p].w, w[nt][p].w, acc[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int o = 16 * nt + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long orow = tile * 16 + 4 * kq + r;
+                float v = acc[nt][r] + bv[nt];
+                v = v < 0.f ? 0.f : v;
+                if (orow < rows && o < cout) y[orow * cout + o] = v;
+            }
+        }
+    }
+}
+
+// weight gradient of the same layer: per-WAVEFRONT partials dW[o][(p, c)] (+ db), summed and re-ordered to torch's
+// [o][c][p] by conv_cl_wgrad_reduce_kernel.  The 16 x (16 NP) float tile of a group's patches goes through LDS (the
+// forward kernel's float4 gathers in, the B fragments' single floats out), as in conv_u8_wgrad_kernel.
+template <int NP, int NT>
+__global__ __launch_bounds__(256) void conv_cl_wgrad_kernel(const float* __restrict__ src, ConvGeom g, long long rows,
+                                                            const float* __restrict__ dy, int cout,
+                                                            float* __restrict__ part, float* __restrict__ dbpart,
+                                                            const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    constexpr int K = 16 * NP;
+    constexpr int RS = K + 4;                            // float row stride of the LDS tile
+    extern __shared__ float cl_tile[];                   // [4 wavefronts][16][RS]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    const long long nwaves = (long long)gridDim.x * 4;
+    float* mytile = cl_tile + (size_t)wv * 16 * RS;
+    int poff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) poff[p] = ((p / g.kw) * g.Win + (p % g.kw)) * 16 + 4 * kq;
+    const int P = g.Ho * g.Wo;
+    const long long ngroups = (rows + 15) >> 4;
+    f32x4 acc[NT][NP];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[nt][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dbacc[nt] = 0.f;
+    for (long long grp = wave; grp < ngroups; grp += nwaves) {
+        long long row = grp * 16 + i;
+        if (row >= rows) row = rows - 1;                 // clamped: its dy is taken as zero
+        const long long f = row / P;
+        const int pp = (int)(row - f * P);
+        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+        const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            *reinterpret_cast<float4*>(mytile + i * RS + 16 * p + 4 * kq) = *reinterpret_cast<const float4*>(b + poff[p]);
+        float a[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const long long r = grp * 16 + 4 * kq + s4;
+                const int o = 16 * nt + i;
+                a[nt][s4] = (r < rows && o < cout) ? dy[r * cout + o] : 0.f;
+                dbacc[nt] += a[nt][s4];
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float bval = mytile[(4 * kq + s4) * RS + 16 * p + i];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][p] = MFMA16C(a[nt][s4], bval, acc[nt][p]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // lane (i, kq): dW[o = 16 nt + 4 kq + r][(p, c = i)]
+    float* out = part + (size_t)wave * (16 * NT) * K;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float d = dbacc[nt];
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        if (kq == 0) dbpart[(size_t)wave * (16 * NT) + 16 * nt + i] = d;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(16 * nt + 4 * kq + r) * K + 16 * p + i] = acc[nt][p][r];
+    }
+}
+
+// dW[o][c][p] = sum over the wavefront partials of part[s][o][(p, c)]; db likewise.  Fixed order.
+__global__ __launch_bounds__(256) void conv_cl_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                   const float* __restrict__ dbpart, int splits,
+                                                                   int OP /* 16 NT */, int NP, int cout,
+                                                                   float* __restrict__ dW, float* __restrict__ db,
+                                                                   const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int K = 16 * NP;
+    const int nW = OP * K;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nW + OP) return;
+    const float* srcp = e < nW ? part + e : dbpart + (e - nW);
+    const int stride = e < nW ? nW : OP;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int sidx = 0;
+    for (; sidx + 3 < splits; sidx += 4) {
+        v0 += srcp[(size_t)sidx * stride];
+        v1 += srcp[(size_t)(sidx + 1) * stride];
+        v2 += srcp[(size_t)(sidx + 2) * stride];
+        v3 += srcp[(size_t)(sidx + 3) * stride];
+    }
+    for (; sidx < splits; ++sidx) v0 += srcp[(size_t)sidx * stride];
+    const float v = (v0 + v1) + (v2 + v3);
+    if (e < nW) {
+        const int o = e / K, pc = e - o * K;
+        const int p = pc >> 4, c = pc & 15;
+        if (o < cout) dW[((size_t)o * 16 + c) * NP + p] = v;
+    } else if (db && e - nW < cout) {
+        db[e - nW] = v;
+    }
+}
+
+constexpr int CONV_CL_WGRAD_BLOCKS = 256;   // x 4 wavefronts = 1024 partials
+
 inline bool geom_ok(const ConvGeom& g) {
     return g.C > 0 && g.Hin > 0 && g.Win > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 &&
            g.Ho == (g.Hin - g.kh) / g.stride + 1 && g.Wo == (g.Win - g.kw) / g.stride + 1 &&
@@ -409,8 +595,9 @@ extern "C" int smx_conv_u8_wgrad_f32(const void* frames, int64_t F, int32_t C, i
     SMX_REQUIRE(ws_floats >= smx_conv_u8_wgrad_ws_floats(cout, K), SMX_E_WORKSPACE);
     const long long rows = (long long)F * g.Ho * g.Wo;
     const long long ngroups = (rows + 15) >> 4;
-    int blocks = (int)((ngroups + 3) / 4);
+    int blocks = (int)((ngroups + 31) / 32);             // >= 8 groups per wavefront: few partials for few rows
     if (blocks > CONV_WGRAD_BLOCKS) blocks = CONV_WGRAD_BLOCKS;
+    if (blocks < 1) blocks = 1;
     float* part = ws;
     float* dbpart = ws + (size_t)CONV_WGRAD_BLOCKS * cout * K;
     const unsigned char* fr = static_cast<const unsigned char*>(frames);
@@ -428,6 +615,70 @@ extern "C" int smx_conv_u8_wgrad_f32(const void* frames, int64_t F, int32_t C, i
     const int n = cout * K + cout;
     hipLaunchKernelGGL(conv_partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream),
                        part, dbpart, blocks, cout * K, cout, dW, db, stop_flag);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+static bool conv_cl_ok(const ConvGeom& g, int cout, const void* src) {
+    const int NP = g.kh * g.kw;
+    return g.C == 16 && cout <= 32 && (NP == 16 || NP == 9 || NP == 4) && (((uintptr_t)src) & 15) == 0;
+}
+
+extern "C" int smx_conv_cl_forward_f32(const float* src, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                                       int32_t stride, const float* W, const float* bias, int32_t cout, float* y,
+                                       const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(src && W && bias && y, SMX_E_NULL);
+    ConvGeom g{C, Hin, Win, k, k, stride, (Hin - k) / stride + 1, (Win - k) / stride + 1};
+    SMX_REQUIRE(F > 0 && geom_ok(g) && cout > 0, SMX_E_SHAPE);
+    if (!conv_cl_ok(g, cout, src)) return SMX_E_UNSUPPORTED;
+    const long long rows = (long long)F * g.Ho * g.Wo;
+    long long blocks = (((rows + 15) >> 4) + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const int NP = k * k, NT = (cout + 15) / 16;
+    void (*kern)(const float*, ConvGeom, long long, const float*, const float*, int, float*, const int*) = nullptr;
+    if (NP == 16) kern = NT == 1 ? conv_cl_fwd_kernel<16, 1> : conv_cl_fwd_kernel<16, 2>;
+    else if (NP == 9) kern = NT == 1 ? conv_cl_fwd_kernel<9, 1> : conv_cl_fwd_kernel<9, 2>;
+    else kern = NT == 1 ? conv_cl_fwd_kernel<4, 1> : conv_cl_fwd_kernel<4, 2>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), src, g, rows, W, bias, cout, y,
+                       stop_flag);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int64_t smx_conv_cl_wgrad_ws_floats(int32_t cout, int32_t k) {
+    const int64_t OP = 16 * ((cout + 15) / 16);
+    return (int64_t)CONV_CL_WGRAD_BLOCKS * 4 * (OP * 16 * k * k + OP);
+}
+
+extern "C" int smx_conv_cl_wgrad_f32(const float* src, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                                     int32_t stride, const float* dy, int32_t cout, float* dW, float* db, float* ws,
+                                     int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(src && dy && dW && ws, SMX_E_NULL);
+    ConvGeom g{C, Hin, Win, k, k, stride, (Hin - k) / stride + 1, (Win - k) / stride + 1};
+    SMX_REQUIRE(F > 0 && geom_ok(g) && cout > 0, SMX_E_SHAPE);
+    if (!conv_cl_ok(g, cout, src)) return SMX_E_UNSUPPORTED;
+    SMX_REQUIRE(ws_floats >= smx_conv_cl_wgrad_ws_floats(cout, k), SMX_E_WORKSPACE);
+    const long long rows = (long long)F * g.Ho * g.Wo;
+    const long long ngroups = (rows + 15) >> 4;
+    int blocks = (int)((ngroups + 31) / 32);
+    if (blocks > CONV_CL_WGRAD_BLOCKS) blocks = CONV_CL_WGRAD_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const int NP = k * k, NT = (cout + 15) / 16, OP = 16 * NT;
+    float* part = ws;
+    float* dbpart = ws + (size_t)CONV_CL_WGRAD_BLOCKS * 4 * OP * 16 * NP;
+    void (*kern)(const float*, ConvGeom, long long, const float*, int, float*, float*, const int*) = nullptr;
+    if (NP == 16) kern = NT == 1 ? conv_cl_wgrad_kernel<16, 1> : conv_cl_wgrad_kernel<16, 2>;
+    else if (NP == 9) kern = NT == 1 ? conv_cl_wgrad_kernel<9, 1> : conv_cl_wgrad_kernel<9, 2>;
+    else kern = NT == 1 ? conv_cl_wgrad_kernel<4, 1> : conv_cl_wgrad_kernel<4, 2>;
+    const size_t lds = (size_t)4 * 16 * (16 * NP + 4) * sizeof(float);
+    hipError_t er = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return (int)er;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, smx_s(stream), src, g, rows, dy, cout, part,
+                       dbpart, stop_flag);
+    SMX_LAUNCH_CHECK();
+    const int n = OP * 16 * NP + OP;
+    hipLaunchKernelGGL(conv_cl_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream),
+                       part, dbpart, blocks * 4, OP, NP, cout, dW, db, stop_flag);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

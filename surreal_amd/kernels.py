@@ -601,6 +601,22 @@ class HipKernels(object):
         L.call('smx_conv_u8_wgrad_f32', L.ptr(frames), F, C, Hin, Win, k, stride, L.ptr(dy), cout, L.ptr(dW), L.ptr(db),
                L.ptr(ws), ws.numel(), L.ptr(stop), self._st())
 
+    @staticmethod
+    def conv_cl_supported(src, C, k, cout):
+        """shapes smx_conv_cl_forward_f32 / _wgrad_f32 take (implicit GEMMs over a 16-channel channel-last source)"""
+        return src.dtype == torch.float32 and C == 16 and cout <= 32 and k in (2, 3, 4) and src.data_ptr() % 16 == 0
+
+    def conv_cl_forward(self, src, F, C, Hin, Win, k, stride, W, bias, cout, y, stop=None):
+        L.call('smx_conv_cl_forward_f32', L.ptr(src), F, C, Hin, Win, k, stride, L.ptr(W), L.ptr(bias), cout, L.ptr(y),
+               L.ptr(stop), self._st())
+
+    def conv_cl_wgrad_ws_floats(self, cout, k):
+        return int(self.lib.smx_conv_cl_wgrad_ws_floats(cout, k))
+
+    def conv_cl_wgrad(self, src, F, C, Hin, Win, k, stride, dy, cout, dW, db, ws, stop=None):
+        L.call('smx_conv_cl_wgrad_f32', L.ptr(src), F, C, Hin, Win, k, stride, L.ptr(dy), cout, L.ptr(dW), L.ptr(db),
+               L.ptr(ws), ws.numel(), L.ptr(stop), self._st())
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         L.call('smx_col2im_f32', L.ptr(dcols), F, C, Hin, Win, k, k, stride, L.ptr(relu_of),
                L.ptr(dx), self._st())

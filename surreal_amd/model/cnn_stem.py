@@ -77,7 +77,8 @@ class CnnStem(object):
         # it: uint8 frames inside the implicit-GEMM kernels' limits never do (_cols1)
         ws.cols1, ws.y1 = None, f(F * p.P1, p.c1)
         ws.cols1_shape, ws.device = (F * p.P1, p.K1), device
-        ws.cols2, ws.y2 = f(F * p.P2, p.K2), f(F * p.P2, p.c2)
+        ws.cols2, ws.y2 = None, f(F * p.P2, p.c2)
+        ws.cols2_shape = (F * p.P2, p.K2)
         ws.wfc = f(p.feat, p.flat_dim)                 # fc.W re-indexed channel-last
         ws.sk = None
         if backward:
@@ -91,12 +92,18 @@ class CnnStem(object):
             ws.cols1 = torch.empty(*ws.cols1_shape, device=ws.device, dtype=torch.float32)
         return ws.cols1
 
+    @staticmethod
+    def _cols2(ws):
+        if ws.cols2 is None:
+            ws.cols2 = torch.empty(*ws.cols2_shape, device=ws.device, dtype=torch.float32)
+        return ws.cols2
+
     def splitk_workspace(self, p, F, device):
         """split-K workspace of the two convolution weight gradients (their GEMMs sum over
         F * pixels rows)"""
         n = max(self.K.linear_wgrad_ws_floats(p.c2, p.K2, F * p.P2),
                 self.K.linear_wgrad_ws_floats(p.c1, p.K1, F * p.P1),
-                self.K.conv_u8_wgrad_ws_floats(p.c1, p.K1))
+                self.K.conv_u8_wgrad_ws_floats(p.c1, p.K1), self.K.conv_cl_wgrad_ws_floats(p.c2, p.k2))
         return torch.empty(n, device=device, dtype=torch.float32) if n else None
 
     def forward(self, p, frames, F, ws, out, stop=None, cols1_tag=None):
@@ -118,9 +125,13 @@ class CnnStem(object):
             ws.cols1_src = None
             K.linear(ws.cols1, 1, v['conv1.W'].view(p.c1, p.K1), 1, v['conv1.b'], ws.y1, F * p.P1, p.c1,
                      p.K1, act=L.SMX_ACT_RELU, stop=stop)
-        K.im2col(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.cols2, channel_last=True)
-        K.linear(ws.cols2, 1, v['conv2.W'].view(p.c2, p.K2), 1, v['conv2.b'], ws.y2, F * p.P2, p.c2,
-                 p.K2, act=L.SMX_ACT_RELU, stop=stop)
+        ws.conv2_implicit = K.conv_cl_supported(ws.y1, p.c1, p.k2, p.c2)
+        if ws.conv2_implicit:          # gathers from the channel-last y1: no patch matrix for this layer either
+            K.conv_cl_forward(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, v['conv2.W'], v['conv2.b'], p.c2, ws.y2, stop=stop)
+        else:
+            K.im2col(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, self._cols2(ws), channel_last=True)
+            K.linear(ws.cols2, 1, v['conv2.W'].view(p.c2, p.K2), 1, v['conv2.b'], ws.y2, F * p.P2, p.c2,
+                     p.K2, act=L.SMX_ACT_RELU, stop=stop)
         K.flatten_order(v['fc.W'], p.feat, p.c2, p.P2, True, ws.wfc)
         K.linear(ws.y2[:F * p.P2].view(F, p.flat_dim), 1, ws.wfc, 1, v['fc.b'], out, F, p.feat, p.flat_dim,
                  act=L.SMX_ACT_RELU, ldc=out.stride(0), stop=stop)
@@ -144,8 +155,14 @@ class CnnStem(object):
         K.flatten_order(ws.gwfc, p.feat, p.c2, p.P2, False, gv['fc.W'])
         K.linear(dfeat, 1, ws.wfc, 0, None, dy2, F, p.flat_dim, p.feat, relu_mask=y2, lda=ldz, stop=stop)
         # conv2: dW, db, data gradient scattered back through the patches * relu'(y1)
-        K.linear_wgrad(ws.dy2, ws.cols2, gv['conv2.W'].view(p.c2, p.K2), gv['conv2.b'], p.c2, p.K2,
-                       F * p.P2, ws=ws.sk)
+        if getattr(ws, 'conv2_implicit', False) and ws.sk is not None:
+            K.conv_cl_wgrad(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.dy2, p.c2, gv['conv2.W'].view(p.c2, p.K2),
+                            gv['conv2.b'], ws.sk, stop=stop)
+        else:
+            if getattr(ws, 'conv2_implicit', False):        # (no split-K workspace: the materialised route)
+                K.im2col(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, self._cols2(ws), channel_last=True)
+            K.linear_wgrad(ws.dy2, ws.cols2, gv['conv2.W'].view(p.c2, p.K2), gv['conv2.b'], p.c2, p.K2,
+                           F * p.P2, ws=ws.sk)
         K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
                  stop=stop)
         K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)

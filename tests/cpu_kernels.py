@@ -765,6 +765,32 @@ class TorchCpuKernels(object):
         if db is not None:
             db.view(-1)[:cout].copy_(dy[:rows].reshape(rows, cout).sum(0))
 
+    @staticmethod
+    def conv_cl_supported(src, C, k, cout):
+        return src.dtype == torch.float32 and C == 16 and cout <= 32 and k in (2, 3, 4)
+
+    def conv_cl_forward(self, src, F, C, Hin, Win, k, stride, W, bias, cout, y, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        Ho, Wo = (Hin - k) // stride + 1, (Win - k) // stride + 1
+        cols = torch.empty(F * Ho * Wo, C * k * k)
+        self.im2col(src, F, C, Hin, Win, k, stride, cols, channel_last=True)
+        y[:F * Ho * Wo].copy_(torch.relu(torch.nn.functional.linear(cols, W.reshape(cout, -1), bias)))
+
+    def conv_cl_wgrad_ws_floats(self, cout, k):
+        return 1
+
+    def conv_cl_wgrad(self, src, F, C, Hin, Win, k, stride, dy, cout, dW, db, ws, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        Ho, Wo = (Hin - k) // stride + 1, (Win - k) // stride + 1
+        rows = F * Ho * Wo
+        cols = torch.empty(rows, C * k * k)
+        self.im2col(src, F, C, Hin, Win, k, stride, cols, channel_last=True)
+        dW.view(cout, -1).copy_(dy[:rows].reshape(rows, cout).t() @ cols)
+        if db is not None:
+            db.view(-1)[:cout].copy_(dy[:rows].reshape(rows, cout).sum(0))
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         P = ((Hin - k) // stride + 1) * ((Win - k) // stride + 1)
         u = dcols[:F * P].reshape(F, P, C * k * k).transpose(1, 2)

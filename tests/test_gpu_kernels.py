@@ -487,6 +487,48 @@ def test_conv_u8_wgrad_is_im2col_plus_wgrad_gemm(K, F, C, H, W, k, st, cout):
     assert float(Wd.min()) == 3.0
 
 
+@pytest.mark.parametrize('F,H,W,k,st,cout', [(5, 20, 20, 4, 2, 32), (3, 9, 11, 3, 1, 20), (40, 20, 20, 4, 2, 32),
+                                              (2, 6, 5, 2, 1, 7), (1, 20, 20, 4, 2, 16)])
+def test_conv_cl_forward_and_wgrad_are_im2col_plus_gemm(K, F, H, W, k, st, cout):
+    """the implicit second convolution (fp32 channel-last source of 16 channels): forward + bias + ReLU and the weight /
+    bias gradients against the CPU double (materialised patches) and the materialised HIP route"""
+    C = 16
+    g = torch.Generator().manual_seed(F * 5 + k)
+    src = torch.relu(torch.randn(F, H * W, C, generator=g))
+    Kc = C * k * k
+    Wt = torch.randn(cout, C, k, k, generator=g) / Kc ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
+    rows = F * Ho * Wo
+    from cpu_kernels import TorchCpuKernels
+    Cd = TorchCpuKernels()
+    assert K.conv_cl_supported(dev(src), C, k, cout)
+    yc = torch.empty(rows, cout)
+    Cd.conv_cl_forward(src, F, C, H, W, k, st, Wt, b, cout, yc)
+    yd = torch.full((rows, cout), float('nan')).cuda()
+    K.conv_cl_forward(dev(src), F, C, H, W, k, st, dev(Wt), dev(b), cout, yd)
+    close(yd, yc, msg='implicit conv2 forward vs double')
+    cols = torch.empty(rows, Kc).cuda()
+    K.im2col(dev(src), F, C, H, W, k, st, cols, channel_last=True)
+    ym = torch.empty(rows, cout).cuda()
+    K.linear(cols, 1, dev(Wt).view(cout, Kc), 1, dev(b), ym, rows, cout, Kc, act=L.SMX_ACT_RELU)
+    close(yd, ym.cpu(), atol=2e-6, rtol=2e-6, msg='implicit vs im2col + GEMM')
+    dy = torch.randn(rows, cout, generator=g) / rows ** 0.5
+    dy[torch.rand(rows, cout, generator=g) < 0.4] = 0.0
+    Wc, bc = torch.empty(cout, Kc), torch.empty(cout)
+    Cd.conv_cl_wgrad(src, F, C, H, W, k, st, dy, cout, Wc, bc, None)
+    ws = torch.empty(K.conv_cl_wgrad_ws_floats(cout, k)).cuda()
+    Wd, bd = torch.full((cout, Kc), float('nan')).cuda(), torch.full((cout,), float('nan')).cuda()
+    K.conv_cl_wgrad(dev(src), F, C, H, W, k, st, dev(dy), cout, Wd, bd, ws)
+    close(Wd, Wc, atol=2e-5, rtol=2e-5, msg='implicit conv2 wgrad vs double')
+    close(bd, bc, atol=2e-5, rtol=2e-5, msg='bias gradient')
+    stop = torch.ones(1, dtype=torch.int32).cuda()
+    yd.fill_(3.0); Wd.fill_(3.0)
+    K.conv_cl_forward(dev(src), F, C, H, W, k, st, dev(Wt), dev(b), cout, yd, stop=stop)
+    K.conv_cl_wgrad(dev(src), F, C, H, W, k, st, dev(dy), cout, Wd, bd, ws, stop=stop)
+    assert float(yd.min()) == 3.0 and float(Wd.min()) == 3.0
+
+
 def test_replay_kernels(K):
     g = torch.Generator().manual_seed(31)
     for cap, width in ((5, 7), (96, 44), (1000, 376)):
