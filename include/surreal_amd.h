@@ -751,6 +751,12 @@ int64_t smx_conv_cl_wgrad_ws_floats(int32_t cout, int32_t k);
 int smx_conv_cl_wgrad_f32(const float* src, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
                           int32_t stride, const float* dy, int32_t cout, float* dW, float* db, float* ws,
                           int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream);
+/* ... and its data gradient, dx [F, Hin*Win, 16] (channel-last) = relu'(relu_of) * conv_transpose(dy, W), without the
+ * intermediate dcols matrix: what smx_linear_f32 (dy . W) + smx_col2im_f32 give, up to summation order.
+ * SMX_E_UNSUPPORTED unless C == 16, cout <= 32 and k == 2 * stride. */
+int smx_conv_cl_dgrad_f32(const float* dy, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                          int32_t stride, const float* W, int32_t cout, const float* relu_of, float* dx,
+                          const int32_t* stop_flag, smx_stream_t stream);
 /* data gradient of the convolution above: dx [F, Hin*Win, C] (channel-last) gathers dcols
  * [F*Ho*Wo, C*kh*kw]; relu_of (optional, same shape as dx): dx *= (relu_of > 0). */
 int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t kh,

@@ -199,6 +199,8 @@ _SIGS = {
     'smx_conv_cl_wgrad_ws_floats': (c_int64, [c_int32, c_int32]),
     'smx_conv_cl_wgrad_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int32, _P, _P, _P,
                                         c_int64, _P, _P]),
+    'smx_conv_cl_dgrad_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int32, _P, _P,
+                                        _P, _P]),
     'smx_ring_insert_bytes': (c_int32, [_P, c_int64, c_int64, c_int64, _P, c_int64, _P]),
     'smx_gather_rows_bytes': (c_int32, [_P, c_int64, c_int64, _P, c_int64, _P, _P]),
     'smx_window_emit_bytes': (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),

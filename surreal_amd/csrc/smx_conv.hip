@@ -513,6 +513,99 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_reduce_kernel(const float* 
 
 constexpr int CONV_CL_WGRAD_BLOCKS = 256;   // x 4 wavefronts = 1024 partials
 
+// ---------------------------------------------------------------------------------------------
+// The second convolution's DATA GRADIENT as an implicit GEMM (k == 2 stride: every input pixel is seen by exactly
+// 2 x 2 kernel positions): dx[(f, y, x), c] = relu'(x_act) * sum over u, v in {0, 1} and o of
+//   dy[(f, (y - ki) / s, (x - kj) / s), o] * W[o][c][ki][kj],   ki = y % s + u s,  kj = x % s + v s
+// (terms whose output position falls outside the map are absent).  M = 16 input pixels of ONE parity class
+// (y % s, x % s) -- they share the four kernel positions, hence the B operand --, N = the 16 input channels,
+// K = 4 positions x cout.  The materialised route wrote dcols = dy . W (594 MB at 7168 frames) and gathered it back.
+// ---------------------------------------------------------------------------------------------
+template <int NH>          // cout <= 16 NH
+__global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restrict__ dy, ConvGeom g, long long F,
+                                                            const float* __restrict__ W, int cout,
+                                                            const float* __restrict__ relu_of, float* __restrict__ dx,
+                                                            const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int st = g.stride, NPK = g.kh * g.kw;
+    const int na = (g.Hin + st - 1) / st, nb = (g.Win + st - 1) / st;       // class pixels per frame: na x nb (max)
+    for (int cls = 0; cls < st * st; ++cls) {
+        const int py = cls / st, px = cls - py * st;
+        const int ca = (g.Hin - py + st - 1) / st, cb = (g.Win - px + st - 1) / st;   // rows / columns of this class
+        if (ca <= 0 || cb <= 0) continue;
+        // B operand: lane (c = i, kq) holds W[o = 16 h + 4 kq + s][c][ki][kj] for the class's four positions
+        float4 w[4][NH];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ki = py + (q >> 1) * st, kj = px + (q & 1) * st;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float v[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int o = 16 * h + 4 * kq + s4;
+                    v[s4] = (o < cout && ki < g.kh && kj < g.kw) ? W[((size_t)o * 16 + i) * NPK + ki * g.kw + kj] : 0.f;
+                }
+                w[q][h] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        const long long per = (long long)ca * cb;
+        const long long npix = F * per;
+        const long long ntiles = (npix + 15) >> 4;
+        for (long long tile = wave; tile < ntiles; tile += nwaves) {
+            long long n = tile * 16 + i;
+            const bool inr = n < npix;
+            if (!inr) n = npix - 1;
+            const long long f = n / per;
+            const int ab = (int)(n - f * per);
+            const int a = ab / cb, b = ab - a * cb;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oy = a - (q >> 1), ox = b - (q & 1);
+                const bool ok = inr && oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+                const long long prow = (f * g.Ho + (ok ? oy : 0)) * g.Wo + (ok ? ox : 0);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const int o0 = 16 * h + 4 * kq;
+                    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (o0 + 3 < cout) av = *reinterpret_cast<const float4*>(dy + prow * cout + o0);
+                    else if (o0 < cout) {
+                        const float* q4 = dy + prow * cout + o0;
+                        av.x = q4[0];
+                        if (o0 + 1 < cout) av.y = q4[1];
+                        if (o0 + 2 < cout) av.z = q4[2];
+                    }
+                    if (!ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc = MFMA16C(av.x, w[q][h].x, acc);
+                    acc = MFMA16C(av.y, w[q][h].y, acc);
+                    acc = MFMA16C(av.z, w[q][h].z, acc);
+                    acc = MFMA16C(av.w, w[q][h].w, acc);
+                }
+            }
+            // C fragment: lane (c = i, kq) holds the class pixels 16 tile + 4 kq + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = tile * 16 + 4 * kq + r;
+                if (m < npix) {
+                    const long long f2 = m / per;
+                    const int ab2 = (int)(m - f2 * per);
+                    const int a2 = ab2 / cb, b2 = ab2 - a2 * cb;
+                    const long long pix = (f2 * g.Hin + (long long)(a2 * st + py)) * g.Win + (b2 * st + px);
+                    float v = acc[r];
+                    if (relu_of) v = (relu_of[pix * 16 + i] > 0.f) ? v : 0.f;
+                    dx[pix * 16 + i] = v;
+                }
+            }
+        }
+    }
+    (void)na; (void)nb;
+}
+
 inline bool geom_ok(const ConvGeom& g) {
     return g.C > 0 && g.Hin > 0 && g.Win > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 &&
            g.Ho == (g.Hin - g.kh) / g.stride + 1 && g.Wo == (g.Win - g.kw) / g.stride + 1 &&
@@ -679,6 +772,25 @@ extern "C" int smx_conv_cl_wgrad_f32(const float* src, int64_t F, int32_t C, int
     const int n = OP * 16 * NP + OP;
     hipLaunchKernelGGL(conv_cl_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream),
                        part, dbpart, blocks * 4, OP, NP, cout, dW, db, stop_flag);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_conv_cl_dgrad_f32(const float* dy, int64_t F, int32_t C, int32_t Hin, int32_t Win, int32_t k,
+                                     int32_t stride, const float* W, int32_t cout, const float* relu_of, float* dx,
+                                     const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(dy && W && dx, SMX_E_NULL);
+    ConvGeom g{C, Hin, Win, k, k, stride, (Hin - k) / stride + 1, (Win - k) / stride + 1};
+    SMX_REQUIRE(F > 0 && geom_ok(g) && cout > 0, SMX_E_SHAPE);
+    if (C != 16 || cout > 32 || k != 2 * stride || (cout % 4 == 0 && (((uintptr_t)dy) & 15))) return SMX_E_UNSUPPORTED;
+    const long long tiles = ((long long)F * Hin * Win / (stride * stride) + 15) >> 4;
+    long long blocks = (tiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    void (*kern)(const float*, ConvGeom, long long, const float*, int, const float*, float*, const int*) =
+        cout <= 16 ? conv_cl_dgrad_kernel<1> : conv_cl_dgrad_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), dy, g, (long long)F, W, cout, relu_of,
+                       dx, stop_flag);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -617,6 +617,15 @@ class HipKernels(object):
         L.call('smx_conv_cl_wgrad_f32', L.ptr(src), F, C, Hin, Win, k, stride, L.ptr(dy), cout, L.ptr(dW), L.ptr(db),
                L.ptr(ws), ws.numel(), L.ptr(stop), self._st())
 
+    @staticmethod
+    def conv_cl_dgrad_supported(dy, C, k, stride, cout):
+        return C == 16 and cout <= 32 and k == 2 * stride and dy.data_ptr() % 16 == 0
+
+    def conv_cl_dgrad(self, dy, F, C, Hin, Win, k, stride, W, cout, relu_of, dx, stop=None):
+        """dx [F*Hin*Win, 16] = relu'(relu_of) * conv_transpose(dy [F*Ho*Wo, cout], W [cout, 16, k, k])"""
+        L.call('smx_conv_cl_dgrad_f32', L.ptr(dy), F, C, Hin, Win, k, stride, L.ptr(W), cout, L.ptr(relu_of), L.ptr(dx),
+               L.ptr(stop), self._st())
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         L.call('smx_col2im_f32', L.ptr(dcols), F, C, Hin, Win, k, k, stride, L.ptr(relu_of),
                L.ptr(dx), self._st())

@@ -82,7 +82,7 @@ class CnnStem(object):
         ws.wfc = f(p.feat, p.flat_dim)                 # fc.W re-indexed channel-last
         ws.sk = None
         if backward:
-            ws.dy2, ws.dcols2, ws.dy1 = f(F * p.P2, p.c2), f(F * p.P2, p.K2), f(F * p.P1, p.c1)
+            ws.dy2, ws.dcols2, ws.dy1 = f(F * p.P2, p.c2), None, f(F * p.P1, p.c1)
             ws.gwfc = f(p.feat, p.flat_dim)
         return ws
 
@@ -163,9 +163,15 @@ class CnnStem(object):
                 K.im2col(ws.y1, F, p.c1, p.H1, p.W1, p.k2, p.s2, self._cols2(ws), channel_last=True)
             K.linear_wgrad(ws.dy2, ws.cols2, gv['conv2.W'].view(p.c2, p.K2), gv['conv2.b'], p.c2, p.K2,
                            F * p.P2, ws=ws.sk)
-        K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
-                 stop=stop)
-        K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)
+        if K.conv_cl_dgrad_supported(ws.dy2, p.c1, p.k2, p.s2, p.c2):
+            # d(y1) * relu'(y1) straight from dy2 and the weight: no dcols matrix, no col2im pass
+            K.conv_cl_dgrad(ws.dy2, F, p.c1, p.H1, p.W1, p.k2, p.s2, v['conv2.W'], p.c2, ws.y1, ws.dy1, stop=stop)
+        else:
+            if ws.dcols2 is None:
+                ws.dcols2 = torch.empty(*ws.cols2_shape, device=ws.device, dtype=torch.float32)
+            K.linear(ws.dy2, 1, v['conv2.W'].view(p.c2, p.K2), 0, None, ws.dcols2, F * p.P2, p.K2, p.c2,
+                     stop=stop)
+            K.col2im(ws.dcols2, F, p.c1, p.H1, p.W1, p.k2, p.s2, ws.y1, ws.dy1)
         # conv1: dW, db (the frames carry no gradient).  Frames that went through the implicit-GEMM forward also give
         # their weight gradient without a patch matrix; otherwise it is the GEMM over the materialised patches
         src = getattr(ws, 'cols1_src', None)

@@ -791,6 +791,18 @@ class TorchCpuKernels(object):
         if db is not None:
             db.view(-1)[:cout].copy_(dy[:rows].reshape(rows, cout).sum(0))
 
+    @staticmethod
+    def conv_cl_dgrad_supported(dy, C, k, stride, cout):
+        return C == 16 and cout <= 32 and k == 2 * stride
+
+    def conv_cl_dgrad(self, dy, F, C, Hin, Win, k, stride, W, cout, relu_of, dx, stop=None):
+        if stop is not None and int(stop[0]) != 0:
+            return
+        Ho, Wo = (Hin - k) // stride + 1, (Win - k) // stride + 1
+        rows = F * Ho * Wo
+        dcols = dy[:rows].reshape(rows, cout) @ W.reshape(cout, -1)
+        self.col2im(dcols, F, C, Hin, Win, k, stride, relu_of, dx)
+
     def col2im(self, dcols, F, C, Hin, Win, k, stride, relu_of, dx):
         P = ((Hin - k) // stride + 1) * ((Win - k) // stride + 1)
         u = dcols[:F * P].reshape(F, P, C * k * k).transpose(1, 2)

@@ -529,6 +529,38 @@ def test_conv_cl_forward_and_wgrad_are_im2col_plus_gemm(K, F, H, W, k, st, cout)
     assert float(yd.min()) == 3.0 and float(Wd.min()) == 3.0
 
 
+@pytest.mark.parametrize('F,H,W,k,st,cout', [(5, 20, 20, 4, 2, 32), (3, 9, 11, 2, 1, 20), (40, 20, 20, 4, 2, 32),
+                                              (2, 7, 6, 2, 1, 7), (1, 21, 20, 4, 2, 16), (3, 13, 9, 6, 3, 12)])
+def test_conv_cl_dgrad_is_gemm_plus_col2im(K, F, H, W, k, st, cout):
+    """the implicit data gradient of the second convolution against dy . W + the col2im gather (CPU double and the
+    materialised HIP route): odd map sizes, pixels no output position sees, fewer than 16 / 32 output channels, the
+    ReLU mask, the stop flag"""
+    C = 16
+    g = torch.Generator().manual_seed(F * 11 + k)
+    Wt = torch.randn(cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+    Ho, Wo = (H - k) // st + 1, (W - k) // st + 1
+    rows = F * Ho * Wo
+    dy = torch.randn(rows, cout, generator=g)
+    act = torch.randn(F * H * W, C, generator=g)
+    from cpu_kernels import TorchCpuKernels
+    Cd = TorchCpuKernels()
+    assert K.conv_cl_dgrad_supported(dev(dy), C, k, st, cout)
+    dxc = torch.empty(F * H * W, C)
+    Cd.conv_cl_dgrad(dy, F, C, H, W, k, st, Wt, cout, act, dxc)
+    dxd = torch.full((F * H * W, C), float('nan')).cuda()
+    K.conv_cl_dgrad(dev(dy), F, C, H, W, k, st, dev(Wt), cout, dev(act), dxd)
+    close(dxd, dxc, atol=2e-5, rtol=2e-5, msg='implicit conv2 dgrad vs double')
+    dcols = torch.empty(rows, C * k * k).cuda()
+    K.linear(dev(dy), 1, dev(Wt).view(cout, -1), 0, None, dcols, rows, C * k * k, cout)
+    dxm = torch.empty(F * H * W, C).cuda()
+    K.col2im(dcols, F, C, H, W, k, st, dev(act), dxm)
+    close(dxd, dxm.cpu(), atol=2e-5, rtol=2e-5, msg='implicit vs GEMM + col2im')
+    stop = torch.ones(1, dtype=torch.int32).cuda()
+    dxd.fill_(3.0)
+    K.conv_cl_dgrad(dev(dy), F, C, H, W, k, st, dev(Wt), cout, dev(act), dxd, stop=stop)
+    assert float(dxd.min()) == 3.0
+
+
 def test_replay_kernels(K):
     g = torch.Generator().manual_seed(31)
     for cap, width in ((5, 7), (96, 44), (1000, 376)):
