@@ -117,6 +117,19 @@ inline int grid_for(long long total) {
 // ---------------------------------------------------------------------------------------------
 #define MFMA16C(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// q = n / d, r = n % d; 32-bit when the caller knows n < 2^31 (`small`, launch-uniform): a 64-bit division is a
+// ~60-instruction software sequence and the implicit-GEMM kernels decompose a row index per lane and tile
+__device__ __forceinline__ void divmod_idx(long long n, int d, bool small, long long& q, int& r) {
+    if (small) {
+        const unsigned uq = (unsigned)n / (unsigned)d;
+        q = uq;
+        r = (int)((unsigned)n - uq * (unsigned)d);
+    } else {
+        q = n / d;
+        r = (int)(n - q * d);
+    }
+}
+
 __device__ __forceinline__ float u8_div255(unsigned x, int byte) {
     const float v = (float)((x >> (8 * byte)) & 0xffu);
     const float r = 1.0f / 255.0f;                      // compile-time constant, correctly rounded
@@ -152,8 +165,9 @@ __global__ __launch_bounds__(256) void conv_u8_fwd_kernel(const unsigned char* _
     auto base_of = [&](long long tile) -> long long {
         long long row = tile * 16 + i;
         if (row >= rows) row = rows - 1;                 // clamped: loaded, never stored
-        const long long f = row / P;
-        const int p = (int)(row - f * P);
+        long long f;
+        int p;
+        divmod_idx(row, P, rows < (1ll << 31), f, p);
         const int oy = p / g.Wo, ox = p - oy * g.Wo;
         return (f * g.C * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride;
     };
@@ -233,8 +247,9 @@ __global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char*
     auto base_of = [&](long long grp) -> long long {
         long long row = grp * 16 + i;
         if (row >= rows) row = rows - 1;                // clamped: its dy is taken as zero
-        const long long f = row / P;
-        const int p = (int)(row - f * P);
+        long long f;
+        int p;
+        divmod_idx(row, P, rows < (1ll << 31), f, p);
         const int oy = p / g.Wo, ox = p - oy * g.Wo;
         return (f * g.C * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride;
     };
@@ -367,8 +382,9 @@ __global__ __launch_bounds__(256) void conv_cl_fwd_kernel(const float* __restric
     for (long long tile = wave; tile < ntiles; tile += nwaves) {
         long long row = tile * 16 + i;
         if (row >= rows) row = rows - 1;
-        const long long f = row / P;
-        const int pp = (int)(row - f * P);
+        long long f;
+        int pp;
+        divmod_idx(row, P, rows < (1ll << 31), f, pp);
         const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
         const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
         float4 a[NP];
@@ -434,8 +450,9 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_kernel(const float* __restr
     for (long long grp = wave; grp < ngroups; grp += nwaves) {
         long long row = grp * 16 + i;
         if (row >= rows) row = rows - 1;                 // clamped: its dy is taken as zero
-        const long long f = row / P;
-        const int pp = (int)(row - f * P);
+        long long f;
+        int pp;
+        divmod_idx(row, P, rows < (1ll << 31), f, pp);
         const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
         const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
 #pragma unroll
@@ -555,13 +572,15 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restr
         }
         const long long per = (long long)ca * cb;
         const long long npix = F * per;
+        const bool small = npix < (1ll << 31);
         const long long ntiles = (npix + 15) >> 4;
         for (long long tile = wave; tile < ntiles; tile += nwaves) {
             long long n = tile * 16 + i;
             const bool inr = n < npix;
             if (!inr) n = npix - 1;
-            const long long f = n / per;
-            const int ab = (int)(n - f * per);
+            long long f;
+            int ab;
+            divmod_idx(n, (int)per, small, f, ab);
             const int a = ab / cb, b = ab - a * cb;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -592,8 +611,9 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restr
             for (int r = 0; r < 4; ++r) {
                 const long long m = tile * 16 + 4 * kq + r;
                 if (m < npix) {
-                    const long long f2 = m / per;
-                    const int ab2 = (int)(m - f2 * per);
+                    long long f2;
+                    int ab2;
+                    divmod_idx(m, (int)per, small, f2, ab2);
                     const int a2 = ab2 / cb, b2 = ab2 - a2 * cb;
                     const long long pix = (f2 * g.Hin + (long long)(a2 * st + py)) * g.Win + (b2 * st + px);
                     float v = acc[r];
