@@ -13,6 +13,7 @@
 // Backward is the mirror image (t = T-1 .. 0, dh_rec = dgates_t . W_hh on MFMA), followed by the
 // weight-gradient GEMMs over all B*T rows (split-K).
 #include "smx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -220,6 +221,8 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(BwdArgs a) {
 // per time step.  Wave w keeps W_hh[64w + lane][0..H) in registers for the whole sequence.
 // ===========================================================================================
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+// barrier between phases that exchange data through LDS only (__syncthreads() also drains the global stores)
+#define LSTM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 constexpr int RB4 = 4;
 
@@ -387,6 +390,154 @@ __global__ __launch_bounds__(NT) void lstm_bwd4_kernel(BwdArgs a) {
     }
 }
 
+// ===========================================================================================
+// ONE batch row per workgroup, on the vector ALU (H <= 128).  Training runs B sequences of N - horizon + 1 (124)
+// steps 43 times per learn: at B = 64 the 4-row MFMA kernels keep 16 CUs busy for ~2.1 us per step, of which the
+// matrix pipe needs ~0.9 (a v_mfma_f32_4x4x1 pass computes 4 rows whether it has them or not) and the five
+// transcendentals per (row, unit) thread ~0.8.  Here thread `col` owns gate column col with W_hh[col][0..H) in
+// registers: H fused multiply-adds against h_{t-1} broadcast from LDS, then ITS gate's one activation; the H unit
+// threads then form c_t, h_t.  Per step: ~100 FMAs + 1 transcendental + 2 short barriers + 2 transcendentals on the
+// unit threads -- and B workgroups instead of B / 4.  Same FLOP rate per row as the MFMA form (H = 100: 40 k MACs per
+// row-step = 312 cycles of a CU's FP32 lanes vs 350 of its matrix pipes per row).  Measured: 14.7 -> 11.1 ms per
+// learn at 64 x 128, 26.5 -> 22.8 at 256 x 128 (SMX_LSTM_MFMA4=1 selects the 4-row kernels for comparison).
+// ===========================================================================================
+template <int HQ>          // H <= 4 HQ
+__global__ __launch_bounds__(NT) void lstm_fwd1_kernel(FwdArgs a) {
+    if (a.stop && *a.stop) return;
+    __shared__ float4 hs4[HQ];                 // h_{t-1}, zero padded
+    __shared__ float gact[4 * 4 * HQ];         // activated gates of the step
+    float* hs = reinterpret_cast<float*>(hs4);
+    const int H = a.H, G = 4 * H, T = a.T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool colv = tid < G, unit = tid < H;
+    float4 w[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q)
+        w[q] = (colv && 4 * q < H) ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)tid * H + 4 * q)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bias = colv ? a.b_hh[tid] : 0.f;
+    const bool is_g = tid >= 2 * H && tid < 3 * H;     // the cell candidate: tanh; the other gates: sigmoid
+    if (tid < 4 * HQ) hs[tid] = (unit && a.h0) ? a.h0[(size_t)b * H + tid] : 0.f;
+    float creg = (unit && a.c0) ? a.c0[(size_t)b * H + tid] : 0.f;
+    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    float gx = colv ? a.gates[gbase + tid] : 0.f;      // the input half of step 0 (smx_linear_f32)
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const float4 hv = hs4[q];
+            acc0 = __builtin_fmaf(hv.x, w[q].x, acc0);
+            acc1 = __builtin_fmaf(hv.y, w[q].y, acc1);
+            acc0 = __builtin_fmaf(hv.z, w[q].z, acc0);
+            acc1 = __builtin_fmaf(hv.w, w[q].w, acc1);
+        }
+        const float pre = gx + ((acc0 + acc1) + bias);
+        const float act = is_g ? tanhf(pre) : sigm(pre);
+        if (colv) {
+            gact[tid] = act;
+            a.gates[gbase + (size_t)t * G + tid] = act;
+        }
+        gx = (colv && t + 1 < T) ? a.gates[gbase + (size_t)(t + 1) * G + tid] : 0.f;
+        LSTM_LDS_BARRIER();
+        if (unit) {
+            const float gi = gact[tid], gf = gact[H + tid], gg = gact[2 * H + tid], go = gact[3 * H + tid];
+            const float c = gf * creg + gi * gg;
+            const float h = go * tanhf(c);
+            const size_t oh = hbase + (size_t)t * H + tid;
+            a.out[oh] = h;
+            a.cs[oh] = c;
+            if (a.hprev) a.hprev[oh] = hs[tid];
+            creg = c;
+            hs[tid] = h;
+        }
+        LSTM_LDS_BARRIER();
+    }
+    if (unit) {
+        if (a.hN) a.hN[(size_t)b * H + tid] = hs[tid];
+        if (a.cN) a.cN[(size_t)b * H + tid] = creg;
+    }
+}
+
+// backward of the same: thread (gb = tid / H, n = tid % H) keeps W_hh[gb H + k][n], k < H, in registers and forms gate
+// block gb's share of dh_rec[n]; the four shares are added in a fixed order by the unit threads of the next step
+template <int HQ>
+__global__ __launch_bounds__(NT) void lstm_bwd1_kernel(BwdArgs a) {
+    if (a.stop && *a.stop) return;
+    __shared__ float4 dg4[4][HQ];              // dgates of the step, gate block gb at dg4[gb] (zero padded)
+    __shared__ float part[4][4 * HQ];
+    const int H = a.H, G = 4 * H, T = a.T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool colv = tid < G, unit = tid < H;
+    const int gb = colv ? tid / H : 0, n = colv ? tid - gb * H : 0;
+    float4 w[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (colv && 4 * q < H) {
+            const float* p = a.W_hh + ((size_t)gb * H + 4 * q) * H + n;
+            v = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
+        }
+        w[q] = v;
+    }
+    for (int idx = tid; idx < 4 * 4 * HQ; idx += NT) {
+        reinterpret_cast<float*>(dg4)[idx] = 0.f;
+        reinterpret_cast<float*>(part)[idx] = 0.f;
+    }
+    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    float dcreg = 0.f;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cp = 0.f, dout = 0.f;
+    auto fetch = [&](int t, float& xi, float& xf, float& xg, float& xo, float& xcp, float& xd) {
+        const size_t og = gbase + (size_t)t * G + tid, oh = hbase + (size_t)t * H + tid;
+        xi = a.gates[og]; xf = a.gates[og + H]; xg = a.gates[og + 2 * (size_t)H]; xo = a.gates[og + 3 * (size_t)H];
+        xcp = (t > 0) ? a.cs[oh - H] : (a.c0 ? a.c0[(size_t)b * H + tid] : 0.f);
+        xd = a.dout[oh];
+    };
+    if (unit) {
+        fetch(T - 1, gi, gf, gg, go, cp, dout);
+        c = a.cs[hbase + (size_t)(T - 1) * H + tid];
+    }
+    __syncthreads();
+    float* dg = reinterpret_cast<float*>(dg4);
+    for (int t = T - 1; t >= 0; --t) {
+        float ni = 0.f, nf = 0.f, ng = 0.f, no = 0.f, ncp = 0.f, nd = 0.f;
+        if (unit && t > 0) fetch(t - 1, ni, nf, ng, no, ncp, nd);      // the next step's inputs: requested early
+        if (unit) {
+            const float dhr = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+            const float dh = dout + dhr;
+            const float tc = tanhf(c);
+            const float dc = dcreg + (dh * go) * (1.f - tc * tc);
+            const float dgi = (dc * gg) * (gi * (1.f - gi));
+            const float dgf = (dc * cp) * (gf * (1.f - gf));
+            const float dgg = (dc * gi) * (1.f - gg * gg);
+            const float dgo = (dh * tc) * (go * (1.f - go));
+            dcreg = dc * gf;
+            const size_t og = gbase + (size_t)t * G + tid;
+            a.dgates[og] = dgi; a.dgates[og + H] = dgf;
+            a.dgates[og + 2 * (size_t)H] = dgg; a.dgates[og + 3 * (size_t)H] = dgo;
+            dg[tid] = dgi; dg[4 * HQ + tid] = dgf; dg[8 * HQ + tid] = dgg; dg[12 * HQ + tid] = dgo;
+        }
+        LSTM_LDS_BARRIER();
+        if (t > 0 && colv) {
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const float4 dv = dg4[gb][q];
+                acc0 = __builtin_fmaf(dv.x, w[q].x, acc0);
+                acc1 = __builtin_fmaf(dv.y, w[q].y, acc1);
+                acc0 = __builtin_fmaf(dv.z, w[q].z, acc0);
+                acc1 = __builtin_fmaf(dv.w, w[q].w, acc1);
+            }
+            part[gb][n] = acc0 + acc1;
+        }
+        c = cp;
+        gi = ni; gf = nf; gg = ng; go = no; cp = ncp; dout = nd;
+        LSTM_LDS_BARRIER();
+    }
+}
+
 constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
 
 inline size_t lds4_fwd(int kq) { return (size_t)RB4 * ((kq * 4 + 4) + (NWV * 64 + 4)) * sizeof(float); }
@@ -419,7 +570,13 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     a.cs = cs; a.hprev = hprev; a.hN = hN; a.cN = cN; a.stop = stop_flag;
     a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
-    if (H <= 100) {
+    // H <= 128: one row per workgroup on the vector ALU (SMX_LSTM_MFMA4=1 keeps the 4-row MFMA kernels for A/B runs)
+    static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
+    if (!mfma4 && H <= 100) {
+        hipLaunchKernelGGL((lstm_fwd1_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && H <= 128) {
+        hipLaunchKernelGGL((lstm_fwd1_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (H <= 100) {
         hipLaunchKernelGGL((lstm_fwd4_kernel<25>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_fwd(25), smx_s(stream), a);
     } else if (H <= 4 * KQ4) {
@@ -455,7 +612,12 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     a.W_hh = net->W_hh; a.c0 = c0; a.gates = gates; a.cs = cs; a.dout = dout; a.dgates = dgates;
     a.stop = stop_flag; a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
-    if (H <= 100) {
+    static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
+    if (!mfma4 && H <= 100) {
+        hipLaunchKernelGGL((lstm_bwd1_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && H <= 128) {
+        hipLaunchKernelGGL((lstm_bwd1_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (H <= 100) {
         hipLaunchKernelGGL((lstm_bwd4_kernel<25>), dim3((unsigned)((B + RB4 - 1) / RB4)), dim3(NT),
                            lds4_bwd(25), smx_s(stream), a);
     } else if (H <= 4 * KQ4) {
