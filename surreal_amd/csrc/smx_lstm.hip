@@ -5,10 +5,11 @@
 // owns a few batch rows and walks the whole sequence with h/c resident on chip.
 //   * the input half of the gates, x . W_ih^T + b_ih, has no time dependence: one GEMM over all
 //     B*T rows (smx_linear_f32) before the recurrent kernel;
-//   * per step the recurrent half h_{t-1} . W_hh^T runs on FP32 MFMA with h_{t-1} read from LDS:
-//     H <= 112 (the reference default is 100): 4 rows per workgroup on 4x4x1_16b, the W_hh slice of
-//     every lane in REGISTERS for the whole sequence; larger H: 16 rows on 16x16x4, W_hh fragments
-//     re-read from L2 every step;
+//   * per step the recurrent half h_{t-1} . W_hh^T with h_{t-1} read from LDS:
+//     H <= 128 (the reference default is 100): ONE row per workgroup on the vector ALU, thread = gate column with its
+//     W_hh row in REGISTERS for the whole sequence (lstm_fwd1 / lstm_bwd1_kernel; the 4-row v_mfma_f32_4x4x1 kernels
+//     it replaced remain behind SMX_LSTM_MFMA4=1); larger H: 16 rows on FP32 MFMA 16x16x4, W_hh fragments re-read
+//     from L2 every step;
 //   * the cell update is elementwise on a fixed (row, unit) -> thread map; h_t goes back to LDS.
 // Backward is the mirror image (t = T-1 .. 0, dh_rec = dgates_t . W_hh on MFMA), followed by the
 // weight-gradient GEMMs over all B*T rows (split-K).
