@@ -109,6 +109,30 @@ def test_three_learns_match_oracle_and_graph_replays():
     assert len(learner._graphs) == 1
 
 
+@pytest.mark.parametrize('name', ['cfg5_adapt', 'tiny_rnn_clip', 'tiny_pixel_clip'])
+def test_learns_are_bit_reproducible_run_to_run(name):
+    """no atomics, fixed reduction orders, tickets reset by their last block: two independent learners fed the same
+    batches end at bit-identical parameters and statistics after several graph replays; a longer run stays finite"""
+    g, case = H.load_golden(name)
+    batch, params, zstate = H.case_inputs(case)
+    finals, stats = [], []
+    for _ in range(2):
+        learner = H.make_learner(case, params, zstate)
+        dbatch = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+        for it in range(4):
+            st = dict(learner.learn(dbatch))
+        finals.append({k: v.copy() for k, v in learner.model.numpy_params().items()})
+        stats.append(st)
+    for k in finals[0]:
+        assert np.array_equal(finals[0][k], finals[1][k]), 'parameters differ run to run: ' + k
+    for k in stats[0]:
+        a, b = stats[0][k], stats[1][k]
+        assert a == b or (np.isnan(a) and np.isnan(b)), 'statistic %s differs run to run: %r %r' % (k, a, b)
+    for it in range(40):                                    # the last learner keeps going: counters, tickets, graphs
+        st = learner.learn(dbatch)
+    assert all(np.isfinite(v) for k, v in dict(st).items() if k != '_lr')
+
+
 def test_gae_and_return_accessor():
     g, case = H.load_golden('ragged_clip')
     batch, params, zstate = H.case_inputs(case)
