@@ -8,8 +8,10 @@ import collections
 import json
 import os
 import random
+import sys
 
 import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 import torch
 
@@ -482,6 +484,18 @@ def test_fused_rollout_equals_act_batch_loop(cpu_double):
     for k in fused:
         assert torch.equal(fused[k], loop[k]), k
     assert float(fused['pds'].abs().sum()) > 0 and float(fused['dones'][:, -1].min()) == 1.0
+
+
+def test_pipeline_bench_feeds_several_learns_per_rollout(cpu_double):
+    """scripts/bench_pipeline.py (bench.py's on-device-loop secondary) on the CPU double: more actors than one learner
+    batch -> the FIFO hands the rollout over in learner batches; every stage is exercised and the counters add up"""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    bp = importlib.import_module('bench_pipeline')
+    r = bp.run_pipeline(actors=8, steps=6, obs_dim=8, action_dim=2, iters=1, warmup=0, graph=False, fused_step=True,
+                        cpu_double=True, learn_batch=4)
+    assert r['config']['learns_per_rollout'] == 2 and r['config']['learn_batch'] == 4
+    assert r['value'] > 0 and set(r['stage_ms_synchronised']) == {'rollout', 'windows+fifo', 'learn'}
 
 
 def test_parameter_noise_matches_reference():
