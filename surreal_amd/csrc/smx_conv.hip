@@ -275,9 +275,11 @@ __global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char*
         // dy of the group's rows 4 kq + s, channel i
         float a[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const long long row = grp * 16 + 4 * kq + s4;
-            a[s4] = (row < rows && i < cout) ? dy[row * cout + i] : 0.f;
+        for (int s4 = 0; s4 < 4; ++s4) {       // unconditional loads from clamped addresses, zeroed by a select: a
+            const long long row = grp * 16 + 4 * kq + s4;        // load under a lane mask is waited for on the spot
+            const bool ok = row < rows && i < cout;
+            const float v = dy[(ok ? row : 0) * cout + (i < cout ? i : 0)];
+            a[s4] = ok ? v : 0.f;
             dbacc += a[s4];
         }
         // raw bytes of patch row i, columns 16 g + 4 kq .. + 3  -> the wavefront's LDS tile
@@ -465,7 +467,9 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_kernel(const float* __restr
             for (int s4 = 0; s4 < 4; ++s4) {
                 const long long r = grp * 16 + 4 * kq + s4;
                 const int o = 16 * nt + i;
-                a[nt][s4] = (r < rows && o < cout) ? dy[r * cout + o] : 0.f;
+                const bool ok = r < rows && o < cout;
+                const float v = dy[(ok ? r : 0) * cout + (o < cout ? o : 0)];      // unconditional, clamped
+                a[nt][s4] = ok ? v : 0.f;
                 dbacc[nt] += a[nt][s4];
             }
         __builtin_amdgcn_wave_barrier();
@@ -538,7 +542,7 @@ constexpr int CONV_CL_WGRAD_BLOCKS = 256;   // x 4 wavefronts = 1024 partials
 // (y % s, x % s) -- they share the four kernel positions, hence the B operand --, N = the 16 input channels,
 // K = 4 positions x cout.  The materialised route wrote dcols = dy . W (594 MB at 7168 frames) and gathered it back.
 // ---------------------------------------------------------------------------------------------
-template <int NH>          // cout <= 16 NH
+template <int NH, bool VEC4>          // cout <= 16 NH; VEC4: cout % 4 == 0
 __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restrict__ dy, ConvGeom g, long long F,
                                                             const float* __restrict__ W, int cout,
                                                             const float* __restrict__ relu_of, float* __restrict__ dx,
@@ -591,15 +595,19 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restr
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     const int o0 = 16 * h + 4 * kq;
-                    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (o0 + 3 < cout) av = *reinterpret_cast<const float4*>(dy + prow * cout + o0);
-                    else if (o0 < cout) {
-                        const float* q4 = dy + prow * cout + o0;
-                        av.x = q4[0];
-                        if (o0 + 1 < cout) av.y = q4[1];
-                        if (o0 + 2 < cout) av.z = q4[2];
+                    // unconditional loads from clamped addresses, zeroed by selects (a load under a lane mask is
+                    // waited for on the spot: eight serial L2 round trips per tile)
+                    float4 av;
+                    if (VEC4) {                          // cout % 4 == 0: rows are 16-byte aligned
+                        av = *reinterpret_cast<const float4*>(dy + prow * cout + (o0 + 3 < cout ? o0 : 0));
+                        if (!(ok && o0 + 3 < cout)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        const float* q4 = dy + prow * cout;
+                        const float x0 = q4[o0 < cout ? o0 : 0], x1 = q4[o0 + 1 < cout ? o0 + 1 : 0];
+                        const float x2 = q4[o0 + 2 < cout ? o0 + 2 : 0], x3 = q4[o0 + 3 < cout ? o0 + 3 : 0];
+                        av = make_float4((ok && o0 < cout) ? x0 : 0.f, (ok && o0 + 1 < cout) ? x1 : 0.f,
+                                         (ok && o0 + 2 < cout) ? x2 : 0.f, (ok && o0 + 3 < cout) ? x3 : 0.f);
                     }
-                    if (!ok) av = make_float4(0.f, 0.f, 0.f, 0.f);
                     acc = MFMA16C(av.x, w[q][h].x, acc);
                     acc = MFMA16C(av.y, w[q][h].y, acc);
                     acc = MFMA16C(av.z, w[q][h].z, acc);
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restr
                     const int a2 = ab2 / cb, b2 = ab2 - a2 * cb;
                     const long long pix = (f2 * g.Hin + (long long)(a2 * st + py)) * g.Win + (b2 * st + px);
                     float v = acc[r];
-                    if (relu_of) v = (relu_of[pix * 16 + i] > 0.f) ? v : 0.f;
+                    if (relu_of) v = (relu_of[pix * 16 + i] > 0.f) ? v : 0.f;      // (uniform branch)
                     dx[pix * 16 + i] = v;
                 }
             }
@@ -808,7 +816,8 @@ extern "C" int smx_conv_cl_dgrad_f32(const float* dy, int64_t F, int32_t C, int3
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     void (*kern)(const float*, ConvGeom, long long, const float*, int, const float*, float*, const int*) =
-        cout <= 16 ? conv_cl_dgrad_kernel<1> : conv_cl_dgrad_kernel<2>;
+        cout <= 16 ? (cout % 4 == 0 ? conv_cl_dgrad_kernel<1, true> : conv_cl_dgrad_kernel<1, false>)
+                   : (cout % 4 == 0 ? conv_cl_dgrad_kernel<2, true> : conv_cl_dgrad_kernel<2, false>);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), dy, g, (long long)F, W, cout, relu_of,
                        dx, stop_flag);
     SMX_LAUNCH_CHECK();
