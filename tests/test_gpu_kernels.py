@@ -756,8 +756,12 @@ def test_im2col_col2im_bit_exact(K, F, C, H, W, k, s, u8, cl):
     assert torch.equal(a.cpu(), w.view(6, C, Ho * Wo).transpose(1, 2).reshape(6, -1))
 
 
+@pytest.mark.parametrize('implicit_wgrad', [True, False])
 @pytest.mark.parametrize('F,C,H,W,feat', [(3, 3, 20, 20, 8), (5, 2, 36, 28, 24), (16, 3, 84, 84, 256)])
-def test_cnn_stem_forward_backward_match_aten(K, F, C, H, W, feat):
+def test_cnn_stem_forward_backward_match_aten(K, F, C, H, W, feat, implicit_wgrad):
+    """the whole stem against ATen's conv2d + autograd.  implicit_wgrad: with the split-K / partial workspace the two
+    convolutions' weight gradients come from the implicit-GEMM kernels, without it from the materialised patch
+    matrices; the forward passes and conv2's data gradient are implicit either way (uint8 frames, k = 2 stride)"""
     import torch.nn as nn
     from surreal_amd.model.cnn_stem import CnnParams, CnnStem
     torch.manual_seed(F + H)
@@ -777,6 +781,8 @@ def test_cnn_stem_forward_backward_match_aten(K, F, C, H, W, feat):
         v.copy_(src[k].detach())
     stem = CnnStem(K)
     ws = stem.workspace(p, F, 'cuda')
+    if implicit_wgrad:
+        ws.sk = stem.splitk_workspace(p, F, 'cuda')
     D = 5                                       # features live at a column offset, as in the learner
     xin = torch.zeros(F, D + feat, device='cuda')
     stem.forward(p, frames.cuda(), F, ws, xin[:, D:])
