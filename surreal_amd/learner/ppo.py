@@ -396,20 +396,6 @@ class PPOLearner(Learner):
                 ws.cnn_it.sk = self.model._cnn_stem.splitk_workspace(cnn, rows, dev)
                 ws.cnn_gae = ws.cnn_it if rows >= min(chunk, R1) else \
                     CnnStem.workspace(cnn, min(chunk, R1), dev, backward=False)
-            # the MLPs on top of the stem on the fused row-block kernels (single rank): forward + loss, finalize + data
-            # gradients, one weight-gradient launch -- instead of ~11 layer launches per epoch
-            ws.stem_fused = (self.fused_epochs and self.world_size == 1 and K.epoch_supported(act) and
-                             K.epoch_supported(cri) and act.D % 4 == 0)
-            if ws.stem_fused:
-                ldT = rows + 16
-                ft = lambda n: torch.zeros(n, ldT, device=dev, dtype=torch.float32)[:, :rows]  # noqa: E731
-                ws.xT = ft(act.D)                                  # the MLP input (stem output), transposed
-                ws.h1aT, ws.h2aT, ws.dz3aT = ft(act.H1), ft(act.H2), ft(A)
-                ws.dz2aT, ws.dz1aT = ft(act.H2), ft(act.H1)
-                ws.h1cT, ws.h2cT = ft(cri.H1), ft(cri.H2)
-                ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
-                ws.pk_actor = torch.zeros(K.epoch_packed_numel(act), device=dev)
-                ws.pk_critic = torch.zeros(K.epoch_packed_numel(cri), device=dev)
         else:
             # transposed copies [features, rows] feeding the weight-gradient GEMMs (K-contiguous)
             # (row stride padded off the power of two: all 32 rows of a fragment load would
@@ -429,8 +415,7 @@ class PPOLearner(Learner):
         ws.fused = (self.fused_epochs and self.epoch_schedule == 'lockstep' and not stem and
                     (self.world_size == 1 or self.epoch_policy == self.epoch_baseline) and
                     K.epoch_supported(act) and K.epoch_supported(cri))
-        ws.stem_fused = stem and getattr(ws, 'stem_fused', False)
-        vblocks = K.epoch_blocks if (ws.fused or ws.stem_fused) else K.value_loss_blocks   # moments per 16 / 256 rows
+        vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
         ws.nblk_v = vblocks(rows)
         # single rank: GAE + normalisation and the end-of-learn statistics are one launch each
         ws.merged_tail = ws.fused and self.world_size == 1
@@ -1147,43 +1132,11 @@ class PPOLearner(Learner):
             x = up.lo
         return x
 
-    def _stem_fused_jobs(self, ws, x):
-        """the actor / critic jobs of the fused row-block kernels on the stem output x [rows, Dx]"""
-        m = self.model
-        n_mlp = m.actor.numel
-        aj = dict(net=m.actor, packed=ws.pk_actor, x=x, act=L.SMX_ACT_TANH, loss='policy', stop=ws.stop, h1T=ws.h1aT,
-                  h2T=ws.h2aT, dz3T=ws.dz3aT, dz2T=ws.dz2aT, dz1T=ws.dz1aT, xT=ws.xT, grads=ws.grads_a[:n_mlp],
-                  sumsq=ws.sumsq_a)
-        cj = dict(net=m.critic, packed=ws.pk_critic, x=x, act=L.SMX_ACT_NONE, loss='value', h1T=ws.h1cT, h2T=ws.h2cT,
-                  dz3=ws.dz3c, dz3T=ws.dz3c, dz2T=ws.dz2cT, dz1T=ws.dz1cT, xT=ws.xT, grads=ws.grads_c[m.n_stem:],
-                  sumsq=ws.sumsq_c)
-        return aj, cj
-
-    def _stem_fused_loss_args(self, ws, e):
-        m, A = self.model, self.action_dim
-        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
-        Ep, Ev = self.epoch_policy, self.epoch_baseline
-        return dict(mode=mode, rows=ws.rows, log_var=m.log_var.view(-1), actions=ws.act_it, behave=ws.beh_it,
-                    ref=ws.ref_pol, adv=ws.adv, g_surr=ws.g_surr, g_kl=ws.g_kl, partials=ws.ppart,
-                    check_stop=e > 0, will_update=e < Ep,
-                    dlogvar=ws.grads_a[m.actor.numel:m.actor.numel + A],
-                    dlogvar_sumsq=ws.sumsq_a[ws.np_a:ws.np_a + 1], stats=ws.pstats[min(e, Ep)],
-                    returns=ws.ret, v_dz3=ws.dz3c, v_partials=ws.vpart[min(e, Ev - 1)], v_will_update=True)
-
     def _stem_policy_forward(self, ws, e):
         K, m = self.K, self.model
         A, W = self.action_dim, self.world_size
         mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
         x = self._stem_forward(ws, m, ws.xn, ws.stop)
-        if ws.stem_fused:
-            # forward of the MLP + policy loss in one launch; the finalize (batch means, KL coefficient, early
-            # exit) and the data gradients in the next (also on the final, forward-only pass: statistics)
-            aj, _ = self._stem_fused_jobs(ws, x)
-            loss = self._stem_fused_loss_args(ws, e)
-            ws.xT.copy_(x.t())
-            K.epoch_forward([aj], loss, ws.ctrl_f, ws.n_total)
-            K.epoch_backward([aj], loss, ws.ctrl_f, ws.n_total)
-            return
         K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
         K.policy_loss(mode, ws.mean, m.log_var.view(-1), ws.act_it, ws.beh_it, ws.ref_pol, ws.adv,
                       ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
@@ -1197,23 +1150,17 @@ class PPOLearner(Learner):
                           ws.grads_a[m.actor.numel:m.actor.numel + A],
                           ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
 
-    def _stem_backward(self, ws, net, h1, h2, dz3, dz2, dz1, g_mlp, g_cnn, g_rnn, stop, fused_job=None):
-        """MLP backward, then back through the stems it sits on.  fused_job: the MLP's data gradients are already
-        there, TRANSPOSED (dz1 is [H1, rows]: epoch_backward); only its weight gradients remain"""
+    def _stem_backward(self, ws, net, h1, h2, dz3, dz2, dz1, g_mlp, g_cnn, g_rnn, stop):
+        """MLP backward, then back through the stems it sits on"""
         K, m = self.K, self.model
         B, E, D = ws.key[0], ws.E, ws.key[2]
         top = ws.upper[-1] if (m.if_rnn and ws.upper) else ws
         x = top.lo if m.if_rnn else ws.xn
-        dz1_kc = 1
-        if fused_job is not None:
-            K.mlp3_wgrad_multi([fused_job])
-            dz1_kc = 0                       # A operand given as [K = H1][M = rows]
-        else:
-            K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
+        K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
         if m.if_rnn:
             # d loss / d (LSTM output) = dz1 . W1, then BPTT (dgates overwrite the saved gates)
             F = m.rnn_hidden
-            K.linear(dz1, dz1_kc, net.views['W1'], 0, None, top.dlo, ws.rows, F, net.H1, stop=stop)
+            K.linear(dz1, 1, net.views['W1'], 0, None, top.dlo, ws.rows, F, net.H1, stop=stop)
             for layer in range(len(ws.upper), 0, -1):      # stacked layers, top down (rnn_layer > 1)
                 up = ws.upper[layer - 1]
                 below = ws.upper[layer - 2] if layer > 1 else ws
@@ -1226,25 +1173,20 @@ class PPOLearner(Learner):
             K.lstm_backward(m.rnn, ws.xn, B, E, ws.c0, ws.gates, ws.cs, ws.hp, ws.dlo, ws.gates,
                             g_rnn[:m.rnn_counts[0]], stop, ws=ws.lstm_sk)
             up, upW, upK = ws.gates, m.rnn.views['weight_ih'], 4 * m.rnn_hidden
-            up_kc = 1
         else:
-            up, upW, upK, up_kc = dz1, net.views['W1'], net.H1, dz1_kc
+            up, upW, upK = dz1, net.views['W1'], net.H1
         if m.if_pixel:
             # d loss / d (CNN features) = upstream . W[:, D:], times the feature ReLU's mask
-            K.linear(up, up_kc, upW[:, D:], 0, None, ws.dxn[:, D:], ws.rows, m.cnn_feature_dim, upK,
+            K.linear(up, 1, upW[:, D:], 0, None, ws.dxn[:, D:], ws.rows, m.cnn_feature_dim, upK,
                      relu_mask=ws.xn[:, D:], stop=stop)
             m._cnn_stem.backward(m.cnn, ws.rows, ws.cnn_it, ws.dxn[:, D:], g_cnn, stop)
 
     def _stem_policy_update(self, ws, e):
         K, m = self.K, self.model
         n_mlp, n0 = m.actor.numel, m.n_actor_block
-        fj = None
-        if ws.stem_fused:
-            top = ws.upper[-1] if (m.if_rnn and ws.upper) else ws
-            fj, _ = self._stem_fused_jobs(ws, top.lo if m.if_rnn else ws.xn)
-        self._stem_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1aT if fj else ws.dz1a,
+        self._stem_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a,
                             ws.grads_a[:n_mlp], ws.grads_a[n0:n0 + m.n_cnn],
-                            ws.grads_a[n0 + m.n_cnn:], ws.stop, fused_job=fj)
+                            ws.grads_a[n0 + m.n_cnn:], ws.stop)
         if self.world_size > 1:
             # ONE all-reduce for the MLP and the stem.  log_var's gradient (between them) was built from
             # all-reduced loss sums and is global already: exactly one copy may enter the sum
@@ -1254,35 +1196,25 @@ class PPOLearner(Learner):
         K.sumsq_partials(ws.grads_a, ws.sumsq_a)
         K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                     ws.sumsq_a, K.sumsq_blocks(ws.grads_a.numel()), ws.ctrl_f, 0, True,
-                    ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1],
-                    pack=(m.actor, ws.pk_actor) if ws.stem_fused else None)
+                    ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
 
     def _stem_value_epoch(self, ws, e):
         K, m = self.K, self.model
         x = self._stem_forward(ws, m, ws.xn, None)
+        K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
         n_total = ws.n_total
-        fj = None
-        if ws.stem_fused:
-            _, fj = self._stem_fused_jobs(ws, x)
-            loss = self._stem_fused_loss_args(ws, e)
-            ws.xT.copy_(x.t())
-            K.epoch_forward([fj], loss, ws.ctrl_f, n_total)
-            K.epoch_backward([fj], loss, ws.ctrl_f, n_total)
-        else:
-            K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
-            # (several ranks: the moments only feed statistics -- gathered once after the last epoch)
-            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c,
-                         ws.vpart_loc_all[e] if self.world_size > 1 else ws.vpart[e], ws.ctrl_f, True)
-        self._stem_backward(ws, m.critic, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1cT if fj else ws.dz1c,
+        # (several ranks: the moments only feed statistics -- gathered once after the last epoch)
+        K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c,
+                     ws.vpart_loc_all[e] if self.world_size > 1 else ws.vpart[e], ws.ctrl_f, True)
+        self._stem_backward(ws, m.critic, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
                             ws.grads_c[m.n_stem:], ws.grads_c[:m.n_cnn], ws.grads_c[m.n_cnn:m.n_stem],
-                            None, fused_job=fj)
+                            None)
         if self.world_size > 1:
             self._dist.all_reduce(ws.grads_c)
         K.sumsq_partials(ws.grads_c, ws.sumsq_c)
         K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                     ws.sumsq_c, K.sumsq_blocks(ws.grads_c.numel()), ws.ctrl_f, 1, False,
-                    ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1],
-                    pack=(m.critic, ws.pk_critic) if ws.stem_fused else None)
+                    ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
 
     def _enqueue_optimize_stem(self, ws, obs, obs_next, actions, rewards, dones, pds, pix, pix_next):
         """_optimize with the LSTM and / or CNN stem (ppo.py:487-586)"""
@@ -1290,8 +1222,6 @@ class PPOLearner(Learner):
         B, N, D = obs.shape
         A, E = self.action_dim, ws.E
         ws.zero_block.zero_()
-        if ws.stem_fused:              # the MLP weights in the fused kernels' fragment order (kept fresh by the Adam steps)
-            K.epoch_pack([(m.actor, ws.pk_actor), (m.critic, ws.pk_critic)])
         self._enqueue_gae_stem(ws, obs, obs_next, pix, pix_next, rewards, dones)
 
         # obs_iter: the first E steps of every sub-trajectory (E = 1 without the LSTM; ppo.py:521-537)
