@@ -6,6 +6,7 @@ import copy
 
 import numpy as np
 import pytest
+import torch
 
 import helpers as H
 
@@ -131,3 +132,52 @@ def test_deferred_stats_and_scalar_recorder():
     assert len(rec.history) == 3 and rec.latest['w'] == 4.0 and rec.latest['k'] == 5 and rec.latest['x'] == 1.0
     assert pickle.loads(pickle.dumps(c)) == {'k': 3, 'w': 4.0} and c.copy() == dict(c)
     assert 'in flight' in repr(make({'k': 7}))
+
+
+@pytest.mark.parametrize('sk', [True, False])
+@pytest.mark.parametrize('u8,C,H,W,feat', [(True, 3, 20, 20, 8), (False, 2, 36, 28, 24), (True, 3, 21, 22, 12)])
+def test_cnn_stem_host_logic_matches_aten_autograd(cpu_double, u8, C, H, W, feat, sk):
+    """CnnStem.forward / backward on the kernel double against torch.nn's Conv2d-ReLU-Conv2d-ReLU-Flatten-Linear-ReLU and
+    autograd: the path selection (implicit-GEMM entry points for uint8 frames inside their limits -- with and without
+    the partial-sum workspace --, materialised patches for fp32 frames or a width that is not a multiple of 4), the
+    channel-last flatten order of the Linear and the parameter / gradient layout"""
+    import torch.nn as nn
+    from surreal_amd import kernels as KN
+    from surreal_amd.model.cnn_stem import CnnParams, CnnStem
+    torch.manual_seed(H + C)
+    F = 4
+    ref = nn.Sequential(nn.Conv2d(C, 16, 8, 4), nn.ReLU(), nn.Conv2d(16, 32, 4, 2), nn.ReLU(), nn.Flatten())
+    with torch.no_grad():
+        n_flat = ref(torch.zeros(1, C, H, W)).shape[1]
+    fc = nn.Linear(n_flat, feat)
+    frames = torch.randint(0, 256, (F, C, H, W), dtype=torch.uint8)
+    if not u8:
+        frames = frames.float()
+    y = torch.relu(fc(ref(frames.float() / 255.0)))
+    dy = torch.randn(F, feat)
+    (y * dy).sum().backward()
+    flat = torch.zeros(CnnParams.count((C, H, W), feat))
+    p = CnnParams(flat, 0, (C, H, W), feat)
+    src = {'conv1.W': ref[0].weight, 'conv1.b': ref[0].bias, 'conv2.W': ref[2].weight,
+           'conv2.b': ref[2].bias, 'fc.W': fc.weight, 'fc.b': fc.bias}
+    for k, v in p.views.items():
+        v.copy_(src[k].detach())
+    K = KN.default_kernels()
+    stem = CnnStem(K)
+    ws = stem.workspace(p, F, 'cpu')
+    if sk:
+        ws.sk = torch.empty(max(1, K.conv_u8_wgrad_ws_floats(p.c1, p.K1), K.conv_cl_wgrad_ws_floats(p.c2, p.k2)))
+    xin = torch.zeros(F, 3 + feat)
+    stem.forward(p, frames, F, ws, xin[:, 3:])
+    implicit = u8 and W % 4 == 0
+    assert (ws.cols1 is None) == implicit          # no patch matrix on the implicit forward path
+    np.testing.assert_allclose(xin[:, 3:].numpy(), y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    dxin = torch.zeros_like(xin)
+    dxin[:, 3:] = dy * (y.detach() > 0)
+    grads = torch.zeros_like(flat)
+    stem.backward(p, F, ws, dxin[:, 3:], grads)
+    assert (ws.cols1 is None) == (implicit and sk)
+    gp = CnnParams(grads, 0, (C, H, W), feat)
+    for k, v in gp.views.items():
+        scale = float(src[k].grad.abs().max())
+        np.testing.assert_allclose(v.numpy() / scale, src[k].grad.numpy() / scale, rtol=1e-4, atol=1e-5, err_msg=k)
