@@ -7,9 +7,10 @@ learner's publishes, ``fetch_parameter()`` copies the latest published module st
 device -- on one GPU the "parameter server" is a tensor copy.
 """
 import logging
+import time
 
 from surreal_amd.env import MaxStepWrapper
-from surreal_amd.utils import AutoInitializeMeta
+from surreal_amd.utils import AutoInitializeMeta, MovingAverageRecorder, PeriodicScalars
 
 AGENT_MODES = ['training', 'eval_deterministic', 'eval_stochastic',
                'eval_deterministic_local', 'eval_stochastic_local']
@@ -44,6 +45,7 @@ class Agent(object, metaclass=AutoInitializeMeta):
         self.log = logging.getLogger('surreal_amd.agent.%s' % agent_id)
         if self.agent_mode not in ['eval_deterministic_local', 'eval_stochastic_local']:
             self._setup_parameter_pull()
+            self._setup_logging()
         self.current_episode = 0
         self.cumulative_steps = 0
         self.current_step = 0
@@ -62,6 +64,18 @@ class Agent(object, metaclass=AutoInitializeMeta):
         self._fetch_parameter_interval = self.session_config.agent.fetch_parameter_interval
         self._fetch_parameter_tracker = PeriodicTracker(self._fetch_parameter_interval)
 
+    def _setup_logging(self):
+        """agent/base.py:87-108: the throttled scalar sink ('agent/<id>' or 'eval/<id>') and the
+        how-long-was-a-parameter-set-used bookkeeping (weighted over ~100 parameter updates)"""
+        from surreal_amd.learner.base import ScalarRecorder
+        self.tensorplex_name = '{}/{}'.format('agent' if self.agent_mode == 'training' else 'eval', self.agent_id)
+        self.tensorplex = PeriodicScalars(ScalarRecorder(),
+                                          self.session_config.tensorplex.update_schedule.agent)
+        self.actions_since_param_update = 0
+        self.episodes_since_param_update = 0
+        self.actions_per_param_update = MovingAverageRecorder(decay=0.99)
+        self.episodes_per_param_update = MovingAverageRecorder(decay=0.99)
+
     # ---- abstract ---------------------------------------------------------------------------
     def act(self, obs):
         raise NotImplementedError
@@ -75,19 +89,33 @@ class Agent(object, metaclass=AutoInitializeMeta):
     # ---- parameter hand-off -------------------------------------------------------------------
     def attach_learner(self, learner):
         learner.add_parameter_listener(self._on_publish)
-        self._on_publish(learner.module_dict(), {'iteration': 0, 'message': 'initial', 'publish_seq': 0})
+        self._on_publish(learner.module_dict(), {'time': time.time(), 'iteration': 0, 'message': 'initial',
+                                                 'publish_seq': 0})
 
     def _on_publish(self, module_dict, info):
         """keeps a SNAPSHOT of what was published (device copies of the state dicts): an agent that
         fetches later gets the parameters of the publish point -- where PPO synchronised its
-        reference policy and beta -- not whatever the learner holds by then"""
-        snap = {name: {k: (v.clone() if hasattr(v, 'clone') else v) for k, v in m.state_dict().items()}
-                for name, m in module_dict.items()}
+        reference policy and beta -- not whatever the learner holds by then.  The snapshot is taken
+        once per publish and shared by every agent attached to the learner (Learner._publish hands
+        all listeners the same `info`; the copy rides in it)."""
+        snap = info.get('_snapshot')
+        if snap is None:
+            snap = {name: {k: (v.clone() if hasattr(v, 'clone') else v) for k, v in m.state_dict().items()}
+                    for name, m in module_dict.items()}
+            info['_snapshot'] = snap
         self._published = (snap, info)
 
     def on_parameter_fetched(self, params, info):      # agent/base.py:160-180
-        self.actions_since_param_update = 0
-        self.episodes_since_param_update = 0
+        if self.agent_mode == 'training':
+            delay = time.time() - info['time']         # learner -> agent
+            self.actions_per_param_update.add_value(self.actions_since_param_update)
+            self.episodes_per_param_update.add_value(self.episodes_since_param_update)
+            self.tensorplex.add_scalars({
+                '.core/parameter_publish_delay_s': delay,
+                '.core/actions_per_param_update': self.actions_per_param_update.cur_value(),
+                '.core/episodes_per_param_update': self.episodes_per_param_update.cur_value()})
+            self.actions_since_param_update = 0
+            self.episodes_since_param_update = 0
         return params
 
     def attach_parameter_client(self, client):

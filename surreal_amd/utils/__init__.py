@@ -1,1 +1,1 @@
-from .common import AutoInitializeMeta, AttrDict, TimedTracker
+from .common import AutoInitializeMeta, AttrDict, TimedTracker, MovingAverageRecorder, PeriodicScalars

@@ -157,3 +157,52 @@ def make_fake_dm(base=object):
         def close(self):
             self.closed = True
     return FakeDMControl
+
+
+# ---- scripted env for the agent main loop (oracle/gen_golden_agentloop.py, tests/agent_loop_cases.py) ----
+def make_scripted_loop_env(base=object):
+    """An environment in the reference's protocol (``reset() -> (obs, info)``, ``step(a) -> (obs, r,
+    done, info)``) whose observations come from a seeded stream that does NOT depend on the actions
+    (so that a 1e-5 difference in an action cannot fork the script), with scripted episode lengths.
+    `base` is the Env class of the side under test (the reference's or ours)."""
+    class ScriptedLoopEnv(base):
+        metadata = {}
+
+        def __init__(self, D, A, episode_lens, seed=0):
+            self.D, self.A = D, A
+            self.episode_lens = list(episode_lens)
+            self.rs = np.random.RandomState(seed)
+            self.episode = -1
+            self.t = 0
+            self.total_steps = 0
+            self.actions = []
+
+        def _obs(self):
+            return collections.OrderedDict(low_dim=collections.OrderedDict(
+                flat_inputs=self.rs.randn(self.D).astype(np.float32)))
+
+        def _reset(self):
+            self.episode += 1
+            self.t = 0
+            return self._obs(), {}
+
+        def _step(self, action):
+            self.t += 1
+            self.total_steps += 1
+            self.actions.append(np.array(action, dtype=np.float64))
+            done = self.t >= self.episode_lens[self.episode % len(self.episode_lens)]
+            return self._obs(), 0.5 * self.t - 0.125 * self.episode, done, {'t': self.t}
+
+        # (a base without the reset/step -> _reset/_step indirection)
+        def reset(self):
+            return self._reset()
+
+        def step(self, action):
+            return self._step(action)
+
+        def action_spec(self):
+            return {'dim': [self.A], 'type': 'continuous'}
+
+        def observation_spec(self):
+            return collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=[self.D]))
+    return ScriptedLoopEnv

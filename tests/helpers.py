@@ -180,3 +180,23 @@ def assert_final_params(learner, g, case, atol=1e-5, what=''):
         # 3.4 M patch rows in another order -- by up to 3.5e-3 (cnn.fc.b); weights agree to 1e-4 or better on both)
         np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=5e-3 if what in CASE_LOOSE_RTOL else 1e-4,
                                    err_msg=what + ' sumsq ' + k)
+
+
+def assert_plain_close(got, want, atol, rtol, what=''):
+    """two env_fakes.to_plain() structures: same keys / order / dtypes / shapes, numbers within tolerance"""
+    if isinstance(want, dict) and set(want) == {'dtype', 'shape', 'data'}:
+        assert isinstance(got, dict) and got['dtype'] == want['dtype'] and got['shape'] == want['shape'], what
+        np.testing.assert_allclose(np.asarray(got['data'], dtype=np.float64), np.asarray(want['data'], dtype=np.float64),
+                                   atol=atol, rtol=rtol, err_msg=what)
+    elif isinstance(want, (list, tuple)):
+        assert isinstance(got, (list, tuple)) and len(got) == len(want), '%s: %r vs %r' % (what, got, want)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert_plain_close(a, b, atol, rtol, '%s[%d]' % (what, i))
+    elif isinstance(want, dict):
+        assert isinstance(got, dict) and list(got) == list(want), what
+        for k in want:
+            assert_plain_close(got[k], want[k], atol, rtol, '%s.%s' % (what, k))
+    elif isinstance(want, float) or isinstance(got, float):
+        np.testing.assert_allclose(got, want, atol=atol, rtol=rtol, err_msg=what)
+    else:
+        assert got == want, '%s: %r vs %r' % (what, got, want)

@@ -5,6 +5,7 @@ at 1e-5."""
 import pytest
 
 import agent_cases as AC
+import agent_loop_cases as AL
 
 pytestmark = pytest.mark.gpu
 
@@ -17,3 +18,10 @@ def test_ppo_agent_matches_reference_agent_hip(name):
 @pytest.mark.parametrize('name', AC.DDPG_CASES)
 def test_ddpg_agent_matches_reference_agent_hip(name):
     AC.check_ddpg_case(name)
+
+
+@pytest.mark.parametrize('name', AL.CASES)
+def test_agent_main_loop_matches_reference_loop_hip(name, monkeypatch):
+    """the reference's own Agent.main_setup / main_loop recording (hook order, fetch cadence, counters,
+    per-step actions and distributions, experience windows) replayed with the policy on the HIP path"""
+    AL.check_case(name, monkeypatch)
