@@ -220,6 +220,19 @@ int smx_windowed_gae_norm_f32(const float* values, const float* values_tail, con
                               float gamma, float gamma_H, int32_t B, int32_t N, int32_t H, float* adv,
                               float* ret, float* adv_moments, float min_std, int32_t* ticket,
                               smx_stream_t stream);
+/* rewards * reward_scale and RewardFilter.forward + RewardFilter.update (surreal/learner/ppo.py:452-455,
+ * surreal/model/reward_filter.py:33-57) in ONE launch, legal under graph capture:
+ *   x = rewards[i] * scale;  out[i] = use_filter ? clamp((x - mean) / std, -5, 5) : x   with
+ *   mean = state[1] / state[0], std = max(sqrt(state[2] / state[0] - mean^2), eps) taken BEFORE the update;
+ *   update_state: state[0] += n, state[1] += sum(x), state[2] = sum(x*x)  (assigned, reward_filter.py:42).
+ * state = {count, running_sum, running_sumsq} (3 floats in device memory); sums (nullable): {n, sum(x),
+ * sum(x*x)} of this call (what several ranks exchange before they update the state themselves);
+ * partials: smx_reward_filter_partials() doubles of scratch; ticket: one int32, zero before the first call
+ * (left zero).  out may alias rewards. */
+int smx_reward_filter_f32(const float* rewards, int64_t n, float scale, int32_t use_filter, float* state,
+                          float eps, int32_t update_state, float* out, float* sums, double* partials,
+                          int32_t* ticket, smx_stream_t stream);
+int32_t smx_reward_filter_partials(void);
 /* What PPOLearner._optimize does after its epoch loops (ppo.py:565-584) in ONE launch (single rank):
  *   smx_value_loss_finalize_f32 (v_partials [n_epochs, nblk, 8] -> v_stats rows; n_epochs may be 0),
  *   smx_moments_f32 over the return targets (ret_moments[3]), smx_zfilter_update_f32 on x [rows, D]

@@ -165,6 +165,8 @@ _SIGS = {
     'smx_windowed_gae_norm_f32': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int32, c_int32, c_int32, _P, _P, _P,
                                             c_float, _P, _P]),
     'smx_ppo_learn_epilogue_f32': (c_int32, [POINTER(LearnEpilogue), _P]),
+    'smx_reward_filter_f32': (c_int32, [_P, c_int64, c_float, c_int32, _P, c_float, c_int32, _P, _P, _P, _P, _P]),
+    'smx_reward_filter_partials': (c_int32, []),
     'smx_moments_f32': (c_int32, [_P, c_int64, _P, _P]),
     'smx_moments_merge_f32': (c_int32, [_P, c_int32, _P, _P]),
     'smx_adv_normalize_f32': (c_int32, [_P, c_int64, _P, c_float, _P]),

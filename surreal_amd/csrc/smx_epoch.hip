@@ -829,9 +829,21 @@ extern "C" void smx_epoch_debug_tbuf(void* p) { g_tbuf = (long long*)p; }
 
 extern "C" int32_t smx_epoch_blocks(int64_t rows) { return (int32_t)((rows + ER - 1) / ER); }
 
+// LDS bytes of a forward launch whose widest job is (D, H1, H2) with A-dimensional policy losses: the same
+// carve-up fill_args() makes ([x tile | h1 tile | h2 tile | out tile | K-split partials | loss scratch + inputs])
+static int fwd_lds_bytes(int D, int H1, int H2, int A) {
+    const int floats = ER * (r64(D) + 4) + ER * (r64(H1) + 4) + ER * (r64(H2) + 4) + ER * LDO + NWV * 2 * 256 +
+                       loss_scratch_floats(A) + ER * (5 * A + 1);
+    return floats * (int)sizeof(float);
+}
+constexpr int MAX_LDS = 128 * 1024;
+
 extern "C" int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
+    // (the LDS bound is taken for the widest loss a job of this network can carry: A = OUT; a launch pairs
+    // networks that share D and the hidden sizes, so what this accepts fill_args() can place)
     return D > 0 && H1 > 0 && H2 > 0 && OUT > 0 && H1 % 4 == 0 && H2 % 4 == 0 && OUT <= 32 &&
-           D <= 2048 && H1 <= 16 * NWV * TG * 2 && H2 <= 16 * NWV * TG * 2;
+           D <= 2048 && H1 <= 16 * NWV * TG * 2 && H2 <= 16 * NWV * TG * 2 &&
+           fwd_lds_bytes(D, H1, H2, OUT) <= MAX_LDS;
 }
 
 static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
@@ -933,7 +945,7 @@ extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs,
                             loss->g_kl && loss->row_partials, SMX_E_NULL);
     const EJob& Lj = G.j[njobs - 1];
     const int blocks = Lj.blk_base + smx_epoch_blocks(Lj.rows);
-    SMX_REQUIRE(lds <= 128 * 1024, SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(lds <= MAX_LDS, SMX_E_UNSUPPORTED);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)epoch_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);

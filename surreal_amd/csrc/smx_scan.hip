@@ -195,6 +195,81 @@ extern "C" int smx_windowed_gae_norm_f32(const float* values, const float* value
 }
 
 // ---------------------------------------------------------------------------
+// Reward scale + RewardFilter (ppo.py:452-455, reward_filter.py:33-57) in ONE launch: x = r * scale;
+// out = clamp((x - mean) / std, -5, 5) with mean / std from the statistics BEFORE this batch; then the
+// statistics take the batch in: count += n, running_sum += sum(x), running_sumsq = sum(x * x) (assigned,
+// not accumulated: reward_filter.py:42).  Block partial sums in fp64, added in block order by the last
+// workgroup to finish (no floating-point atomics: the result does not depend on the schedule).
+// ---------------------------------------------------------------------------
+constexpr int RF_MAX_BLOCKS = 64;
+
+__global__ __launch_bounds__(256) void reward_filter_kernel(const float* __restrict__ r, long n, float scale, int filter,
+                                                            float* __restrict__ state, float eps, int update,
+                                                            float* __restrict__ out, float* __restrict__ sums,
+                                                            double* __restrict__ partials, int* __restrict__ ticket) {
+    __shared__ double red[8];
+    float mean = 0.f, sd = 1.f;
+    if (filter) {
+        const float cnt = state[0];
+        mean = state[1] / cnt;
+        sd = sqrtf(state[2] / cnt - mean * mean);          // pow(0.5): NaN for a negative argument
+        if (sd == sd) sd = fmaxf(sd, eps);                   // torch.clamp keeps NaN
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = r[i] * scale;
+        float v = x;
+        if (filter) {
+            v = (x - mean) / sd;
+            if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);
+        }
+        out[i] = v;
+        s1 += (double)x;
+        s2 += (double)x * (double)x;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    s1 = smx_wave_sum_d(s1);
+    s2 = smx_wave_sum_d(s2);
+    if (lane == 0) { red[w] = s1; red[4 + w] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        partials[2 * blockIdx.x + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+    if (!last_block_done(ticket)) return;
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) {
+            t1 += __builtin_nontemporal_load(partials + 2 * b);
+            t2 += __builtin_nontemporal_load(partials + 2 * b + 1);
+        }
+        if (sums) { sums[0] = (float)n; sums[1] = (float)t1; sums[2] = (float)t2; }
+        if (update) {
+            state[0] += (float)n;
+            state[1] += (float)t1;
+            state[2] = (float)t2;
+        }
+    }
+}
+
+extern "C" int smx_reward_filter_f32(const float* rewards, int64_t n, float scale, int32_t use_filter, float* state,
+                                     float eps, int32_t update_state, float* out, float* sums, double* partials,
+                                     int32_t* ticket, smx_stream_t stream) {
+    SMX_REQUIRE(rewards && out && partials && ticket, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    SMX_REQUIRE(!(use_filter || update_state) || state, SMX_E_NULL);
+    SMX_REQUIRE(((uintptr_t)partials & 7) == 0, SMX_E_ALIGN);
+    long blocks = (n + 1023) / 1024;
+    if (blocks > RF_MAX_BLOCKS) blocks = RF_MAX_BLOCKS;
+    hipLaunchKernelGGL(reward_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), rewards, (long)n, scale,
+                       use_filter, state, eps, update_state, out, sums, partials, (int*)ticket);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int32_t smx_reward_filter_partials(void) { return 2 * RF_MAX_BLOCKS; }
+
+// ---------------------------------------------------------------------------
 // moments: {n, mean, M2}; two passes in fp64 inside one workgroup (n is B*E <= ~1e5)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void moments_kernel(const float* __restrict__ x, long n,

@@ -137,8 +137,12 @@ class HipKernels(object):
                L.ptr(stop), self._st())
 
     # ---- fused row-block epoch kernels (csrc/smx_epoch.hip) ------------------------------
-    def epoch_supported(self, net):
-        return bool(self.lib.smx_epoch_supported(net.D, net.H1, net.H2, net.OUT))
+    def epoch_supported(self, *nets):
+        """every network by itself, and the launch that carries all of them (its LDS tiles are sized for
+        the widest layer of any job)"""
+        ok = all(self.lib.smx_epoch_supported(n.D, n.H1, n.H2, n.OUT) for n in nets)
+        return bool(ok and self.lib.smx_epoch_supported(max(n.D for n in nets), max(n.H1 for n in nets),
+                                                        max(n.H2 for n in nets), max(n.OUT for n in nets)))
 
     def epoch_blocks(self, rows):
         return self.lib.smx_epoch_blocks(rows)
@@ -260,6 +264,15 @@ class HipKernels(object):
         L.call('smx_windowed_gae_norm_f32', L.ptr(values), L.ptr(values_tail), L.ptr(rewards), L.ptr(dones),
                L.ptr(gpow), L.ptr(lpow), float(gamma), float(gamma_H), B, N, H, L.ptr(adv), L.ptr(ret), L.ptr(adv_mom),
                float(min_std), L.ptr(ticket), self._st())
+
+    def reward_filter_partials(self):
+        return int(self.lib.smx_reward_filter_partials())
+
+    def reward_filter(self, rewards, scale, state, eps, out, partials, ticket, use_filter=True, update=True, sums=None):
+        """out = clamp((rewards * scale - mean) / std, -5, 5) from `state` = [count, sum, sumsq] as it was BEFORE
+        the call, then state <- batch (reward_filter.py:33-57); use_filter=False: the scale alone"""
+        L.call('smx_reward_filter_f32', L.ptr(rewards), rewards.numel(), float(scale), int(use_filter), L.ptr(state),
+               float(eps), int(update), L.ptr(out), L.ptr(sums), L.ptr(partials), L.ptr(ticket), self._st())
 
     def learn_epilogue(self, ret, ret_mom, log_var, out4, ticket, zfilter=None, x=None, count_rows=0, v_partials=None,
                        n_epochs=0, nblk=0, v_stats=None, stats_stride=0):
@@ -582,11 +595,12 @@ class HipKernels(object):
                Hin, Win, k, k, stride, float(scale_div), L.ptr(cols), self._st())
 
     @staticmethod
-    def conv_u8_supported(frames, C, Hin, Win, k, stride, cout):
-        """shapes smx_conv_u8_forward_f32 takes (the implicit-GEMM first convolution over uint8 frames)"""
+    def conv_u8_supported(frames, C, Hin, Win, k, stride, cout, W=None):
+        """shapes smx_conv_u8_forward_f32 takes (the implicit-GEMM first convolution over uint8 frames); `W`:
+        the layer's weight, a view into the flat parameter buffer whose 16-byte alignment depends on its offset"""
         K = C * k * k
         return frames.dtype == torch.uint8 and cout <= 16 and k % 4 == 0 and Win % 4 == 0 and stride % 4 == 0 \
-            and K % 64 == 0 and K <= 256 and frames.data_ptr() % 4 == 0
+            and K % 64 == 0 and K <= 256 and frames.data_ptr() % 4 == 0 and (W is None or W.data_ptr() % 16 == 0)
 
     def conv_u8_forward(self, frames, F, C, Hin, Win, k, stride, W, bias, cout, y, stop=None):
         """y [F*Ho*Wo, cout] = relu(conv(frames / 255, W) + bias), no patch matrix (see the header)"""

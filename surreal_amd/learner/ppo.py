@@ -254,10 +254,8 @@ class PPOLearner(Learner):
                                                       self.env_config.action_spec)
         self.pd = DiagGauss(self.action_dim)
         self.cells = None
-        if self.use_r_filter:
-            self._rf_count = torch.tensor(1e-5, device=self.device)
-            self._rf_sum = torch.tensor(0.0, device=self.device)
-            self._rf_sumsq = torch.tensor(0.0, device=self.device)
+        # reward scale / RewardFilter (ppo.py:452-455) run inside the step: one launch (smx_reward_filter_f32)
+        self.filter_rewards = bool(self.use_r_filter) or self.reward_scale != 1.0
 
         lcfg = self.session_config.learner
         # one rank: the whole step is ONE hipGraph; several ranks: graph segments between the
@@ -310,7 +308,7 @@ class PPOLearner(Learner):
         ws.E = E
         Ep, Ev = self.epoch_policy, self.epoch_baseline
         # scalars block: ctrl | policy stats | value stats | moments
-        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + Ev * L.VS_STRIDE + 12
+        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + Ev * L.VS_STRIDE + 12 + 4
         ws.scal = torch.zeros(n_scal, device=dev, dtype=torch.float32)
         o = 0
         ws.ctrl_f = ws.scal[o:o + L.CTRL_WORDS]; o += L.CTRL_WORDS
@@ -320,6 +318,18 @@ class PPOLearner(Learner):
         ws.adv_mom = ws.scal[o:o + 3]; o += 3
         ws.ret_mom = ws.scal[o:o + 3]; o += 3
         ws.fin = ws.scal[o + 2:o + 6]          # mean log_var, z-filter means (final_stats)
+        # RewardFilter's {count, running_sum, running_sumsq} (reward_filter.py:28-31): in the statistics block,
+        # so the reported reward mean needs no read-back of its own; survives a change of workspace
+        ws.rf_state = ws.scal[o + 6:o + 9]
+        if self._ws is not None:
+            ws.rf_state.copy_(self._ws.rf_state)
+        else:
+            ws.rf_state.copy_(torch.tensor([1e-5, 0.0, 0.0]))
+        if self.filter_rewards:
+            ws.rew = torch.empty(B, N, device=dev, dtype=torch.float32)
+            ws.rf_part = torch.zeros(K.reward_filter_partials(), device=dev, dtype=torch.float64)
+            ws.rf_ticket = torch.zeros(1, device=dev, dtype=torch.int32)
+            ws.rf_sums = torch.zeros(3, device=dev, dtype=torch.float32)
         ws.stop = ws.ctrl_i[L.C_STOP:L.C_STOP + 1]
         # stop flag + epochs_done + reserved words + the policy statistics rows: one contiguous run
         ws.zero_block = ws.scal[L.C_STOP:L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE]
@@ -414,7 +424,7 @@ class PPOLearner(Learner):
         # paired-epoch schedule with one collective per epoch (epoch_policy == epoch_baseline)
         ws.fused = (self.fused_epochs and self.epoch_schedule == 'lockstep' and not stem and
                     (self.world_size == 1 or self.epoch_policy == self.epoch_baseline) and
-                    K.epoch_supported(act) and K.epoch_supported(cri))
+                    K.epoch_supported(act, cri))
         vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
         ws.nblk_v = vblocks(rows)
         # single rank: GAE + normalisation and the end-of-learn statistics are one launch each
@@ -451,7 +461,8 @@ class PPOLearner(Learner):
             ws.ar = torch.zeros(off_p + nblk_p_all * ws.pstride, device=dev)
             ws.grads_all = ws.ar[:n_a + n_c]
             ws.grads_k = ws.ar[off_k:off_k + act.numel] if adapt else None
-            ws.ppart_ar = ws.ar[off_p:].view(nblk_p_all, ws.pstride)   # rows past this rank's blocks stay 0
+            # (rows past this rank's own blocks must be 0 when the all-reduce reads them: see _clear_foreign_partials)
+            ws.ppart_ar = ws.ar[off_p:].view(nblk_p_all, ws.pstride)
             if adapt:
                 ws.dz3k, ws.dz2k, ws.dz1k = f(rows, A), f(rows, act.H2), f(rows, act.H1)
                 ws.dz3kT, ws.dz2kT, ws.dz1kT = ft(A), ft(act.H2), ft(act.H1)
@@ -515,18 +526,9 @@ class PPOLearner(Learner):
                 obs[modality][key] = conv(obs[modality][key])
                 obs_next[modality][key] = conv(obs_next[modality][key])
         batch['actions'] = self._to_dev(batch['actions'])
-        rewards = self._to_dev(batch['rewards'])
-        if self.reward_scale != 1.0:
-            rewards = rewards * self.reward_scale
-        if self.use_r_filter:                                   # reward_filter.py:33-57
-            mean = self._rf_sum / self._rf_count
-            std = torch.clamp((self._rf_sumsq / self._rf_count - mean.pow(2)).pow(0.5), min=1e-5)
-            normed = torch.clamp((rewards - mean) / std, -5.0, 5.0)
-            self._rf_count += float(rewards.numel())
-            self._rf_sum += rewards.sum()
-            self._rf_sumsq = (rewards * rewards).sum()          # overwrite (sic, :42)
-            rewards = normed
-        batch['rewards'] = rewards
+        # (reward_scale and the RewardFilter of ppo.py:452-455 are applied by the step itself:
+        # _enqueue_reward_filter, one launch inside the captured graph)
+        batch['rewards'] = self._to_dev(batch['rewards'])
         batch['dones'] = self._to_dev(batch['dones'])
         if batch.get('persistent_infos') is not None:
             batch['persistent_infos'] = [self._to_dev(x) for x in batch['persistent_infos']]
@@ -753,6 +755,14 @@ class PPOLearner(Learner):
             ws.vpart.view(Ev, W, ws.nblk_v, 8).copy_(ws.vgather.permute(1, 0, 2, 3))
         K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
 
+    def _clear_foreign_partials(self, ws):
+        """The all-reduce sums ws.ar in place, so afterwards EVERY loss-partial row holds the global sum --
+        also the rows past this rank's own blocks, which its loss launch never rewrites (ranks may hold
+        different numbers of sixteen-row blocks).  Those rows go back to zero before the next epoch's
+        exchange, or the previous epoch's sums would be added again."""
+        if ws.nblk_p < ws.ppart_ar.shape[0]:
+            ws.ppart_ar[ws.nblk_p:].zero_()
+
     def _enqueue_fused_epochs(self, ws, actions0, behave0, ref_job, tail, gae):
         """The lock-step epochs on the row-block kernels (csrc/smx_epoch.hip): per epoch
         [forward + losses] -> [batch means, KL coefficient / early exit, data gradients] ->
@@ -802,6 +812,7 @@ class PPOLearner(Learner):
                     K.epoch_forward([aj], loss, ws.ctrl_f, n_total)
                     torch.sum(ws.ppart, 0, keepdim=True, out=ws.tp_ppart)
                     break
+                self._clear_foreign_partials(ws)
                 K.epoch_forward([aj, cj], loss, ws.ctrl_f, n_total)
                 K.epoch_backward(rhs + [cj], loss, ws.ctrl_f, n_total)
                 K.mlp3_wgrad_multi(rhs + [cj])
@@ -915,6 +926,7 @@ class PPOLearner(Learner):
         [G_surr | G_critic | G_kl | loss partial rows]."""
         K, m = self.K, self.model
         adapt = mode == L.SMX_PPO_ADAPT
+        self._clear_foreign_partials(ws)
         K.epoch_losses_dp(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
                           ws.ctrl_f, ws.dz3a, ws.dz3k if adapt else ws.g_kl, ws.ppart_ar, ws.n_total,
                           g_surr_t=ws.dz3aT, g_kl_t=ws.dz3kT if adapt else None, values=ws.vpred,
@@ -936,9 +948,28 @@ class PPOLearner(Learner):
                           ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1]),
                          ws.ctrl_f)
 
+    def _enqueue_reward_filter(self, ws, rewards):
+        """rewards * reward_scale, then RewardFilter.forward and .update (ppo.py:452-455,
+        reward_filter.py:33-57): one launch into ws.rew.  Several ranks: the filter's statistics are those of
+        the GLOBAL batch -- every rank normalises with the same state, the batch sums are all-reduced, and
+        the state takes them in on every rank alike."""
+        K = self.K
+        if self.world_size == 1 or not self.use_r_filter:
+            K.reward_filter(rewards, self.reward_scale, ws.rf_state, 1e-5, ws.rew, ws.rf_part, ws.rf_ticket,
+                            use_filter=self.use_r_filter, update=self.use_r_filter)
+            return ws.rew
+        K.reward_filter(rewards, self.reward_scale, ws.rf_state, 1e-5, ws.rew, ws.rf_part, ws.rf_ticket,
+                        use_filter=True, update=False, sums=ws.rf_sums)
+        self._dist.all_reduce(ws.rf_sums)
+        ws.rf_state[:2] += ws.rf_sums[:2]
+        ws.rf_state[2:] = ws.rf_sums[2:]
+        return ws.rew
+
     def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds, pix=None,
                           pix_next=None):
         """the whole of _optimize (ppo.py:487-586) as a launch sequence"""
+        if self.filter_rewards:
+            rewards = self._enqueue_reward_filter(ws, rewards)
         if self.if_rnn_policy or self.model.if_pixel:
             return self._enqueue_optimize_stem(ws, obs, obs_next, actions, rewards, dones, pds, pix,
                                                pix_next)
@@ -1414,8 +1445,6 @@ class PPOLearner(Learner):
         the GPU never waits for the read-back and the Python that decodes it."""
         snap = {'beta': getattr(self, 'beta', None), 'clip_epsilon': getattr(self, 'clip_epsilon', None),
                 'lr': self.actor_lr_scheduler.get_lr()[0]}       # (each mode defines only its own)
-        if self.use_r_filter:
-            snap['reward_mean'] = self._rf_sum / self._rf_count            # 0-d device tensor
         if not self.lazy_stats:
             return self._decode_stats(ws.scal.cpu(), snap)
         self._flush_stats()                        # the previous learn's, now that this one is queued
@@ -1446,6 +1475,7 @@ class PPOLearner(Learner):
         vs = scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE).numpy(); o += Ev * L.VS_STRIDE
         ret_mom = scal[o + 3:o + 6].numpy()
         fin = scal[o + 8:o + 12].numpy()
+        rf = scal[o + 12:o + 15].numpy()
         done = int(ctrl_i[L.C_EPOCHS_DONE])      # policy updates applied
         # the reference breaks after the update whose KL is too large: `done` updates ran,
         # slot `done` holds the forward pass after the last one
@@ -1484,7 +1514,7 @@ class PPOLearner(Learner):
             stats['obs_running_square'] = float(fin[2])
             stats['obs_running_std'] = float(fin[3])
         if self.use_r_filter:
-            stats['reward_mean'] = float(snap['reward_mean'].item())
+            stats['reward_mean'] = float(rf[1] / rf[0])                  # reward_filter.py:59-63
         return stats
 
     def learn(self, batch):

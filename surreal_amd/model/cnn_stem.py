@@ -112,7 +112,7 @@ class CnnStem(object):
         equals the tag of the patch matrix ws.cols1 already holds, the first convolution's im2col is skipped -- the
         patches do not depend on the weights, and a learn runs ~22 forwards over the same frames."""
         K, v = self.K, p.views
-        if K.conv_u8_supported(frames, p.C, p.H, p.W, p.k1, p.s1, p.c1):
+        if K.conv_u8_supported(frames, p.C, p.H, p.W, p.k1, p.s1, p.c1, v['conv1.W']):
             # implicit GEMM straight from the uint8 frames: no patch matrix on the forward path.  The weight
             # gradient of this layer still reads one (backward() builds it on first use, once per set of frames)
             K.conv_u8_forward(frames, F, p.C, p.H, p.W, p.k1, p.s1, v['conv1.W'], v['conv1.b'], p.c1, ws.y1,

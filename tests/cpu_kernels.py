@@ -149,8 +149,8 @@ class TorchCpuKernels(object):
             sumsq[0] = float((flat.double() ** 2).sum())
 
     # ---- fused row-block epoch kernels ------------------------------------------------------
-    def epoch_supported(self, net):
-        return net.H1 % 4 == 0 and net.H2 % 4 == 0 and net.OUT <= 32
+    def epoch_supported(self, *nets):
+        return all(net.H1 % 4 == 0 and net.H2 % 4 == 0 and net.OUT <= 32 for net in nets)
 
     def epoch_blocks(self, rows):
         return (rows + 15) // 16
@@ -301,6 +301,25 @@ class TorchCpuKernels(object):
         self.moments(adv, adv_mom)
         self.adv_normalize(adv, adv_mom, min_std)
 
+    def reward_filter_partials(self):
+        return 128
+
+    def reward_filter(self, rewards, scale, state, eps, out, partials, ticket, use_filter=True, update=True, sums=None):
+        x = rewards * _f(scale)
+        if use_filter:
+            mean = state[1] / state[0]
+            std = torch.clamp((state[2] / state[0] - mean.pow(2)).pow(0.5), min=eps)
+            out.copy_(torch.clamp((x - mean) / std, -5.0, 5.0))
+        else:
+            out.copy_(x)
+        s1, s2 = x.double().sum(), (x.double() * x.double()).sum()
+        if sums is not None:
+            sums.copy_(torch.stack([torch.tensor(float(x.numel())), s1.float(), s2.float()]))
+        if update:
+            state[0] += float(x.numel())
+            state[1] += s1.float()
+            state[2] = s2.float()
+
     def learn_epilogue(self, ret, ret_mom, log_var, out4, ticket, zfilter=None, x=None, count_rows=0, v_partials=None,
                        n_epochs=0, nblk=0, v_stats=None, stats_stride=0):
         if n_epochs:
@@ -379,7 +398,7 @@ class TorchCpuKernels(object):
         gk = 1.0 - (sr ** 2 + (mr - mean) ** 2) / sig ** 2
         isw = Ll / (Lb + 1e-4)
         nblk = self.loss_blocks(rows)
-        partials.zero_()
+        partials[:nblk].zero_()       # like the kernels: a launch rewrites the rows of ITS blocks, nothing else
         for b in range(nblk):
             sl = slice(self.LOSS_ROWS * b, min(self.LOSS_ROWS * (b + 1), rows))
             partials[b, 0] = surr[sl].sum()
@@ -738,7 +757,7 @@ class TorchCpuKernels(object):
         cols[:F * P].copy_(u.transpose(1, 2).reshape(F * P, C * k * k))
 
     @staticmethod
-    def conv_u8_supported(frames, C, Hin, Win, k, stride, cout):
+    def conv_u8_supported(frames, C, Hin, Win, k, stride, cout, W=None):
         K = C * k * k
         return frames.dtype == torch.uint8 and cout <= 16 and k % 4 == 0 and Win % 4 == 0 and stride % 4 == 0 \
             and K % 64 == 0 and K <= 256

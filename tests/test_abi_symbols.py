@@ -151,3 +151,19 @@ def test_ctypes_signatures_match_the_header():
         for p, a in zip(plist, argtypes):
             assert kind_of_c(p) == kind_of_ct(a), (name, p, a)
         assert kind_of_c(ret) == kind_of_ct(restype), (name, ret, restype)
+
+
+def test_epoch_supported_mirrors_the_launch_lds_budget():
+    """smx_epoch_supported() is what makes the learner choose the fused row-block epochs; it must refuse what
+    smx_epoch_forward_f32 cannot place in 128 KB of LDS (x, h1 and h2 tiles of 16 rows), or such configs
+    raise at launch instead of taking the layered schedule (host-side arithmetic: no GPU needed)"""
+    from surreal_amd import _lib as L
+    lib = L.load()
+    assert lib.smx_epoch_supported(376, 300, 200, 17) == 1          # the benchmark shape
+    assert lib.smx_epoch_supported(17, 300, 200, 6) == 1
+    assert lib.smx_epoch_supported(1200, 300, 200, 17) == 0         # ~133 KB: was accepted, failed at launch
+    assert lib.smx_epoch_supported(1024, 640, 640, 17) == 0
+    assert lib.smx_epoch_supported(376, 302, 200, 17) == 0          # hidden sizes must be multiples of 4
+    # the largest observation the default hidden sizes leave room for is accepted and one 64-column step more is not
+    ok = [d for d in range(64, 2049, 64) if lib.smx_epoch_supported(d, 300, 200, 17)]
+    assert ok and ok == list(range(64, ok[-1] + 1, 64)) and ok[-1] < 1200

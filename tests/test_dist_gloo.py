@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, cuts=None):
     try:
         import torch.distributed as dist
         os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -37,6 +37,8 @@ def _worker(rank, world, port, name, q):
         batch, params, zstate = H.case_inputs(case)
         B = case['shape']['B']
         lo, hi = rank * B // world, (rank + 1) * B // world
+        if cuts is not None:
+            lo, hi = cuts[rank], cuts[rank + 1]
 
         def shard(x):
             if isinstance(x, dict):
@@ -83,11 +85,19 @@ def test_eight_rank_learner_equals_single_learner():
     _ranks_equal_single_learner('cfg2_adapt', 8)
 
 
-def _ranks_equal_single_learner(name, world):
+@pytest.mark.parametrize('name', ['ragged_adapt_offpolicy', 'ragged_clip'])
+def test_three_ranks_with_different_block_counts(name):
+    """37 sub-trajectories cut 5 | 20 | 12: the ranks hold 1, 2 and 1 sixteen-row loss blocks, so the
+    all-reduced loss-partial rows are longer than what ranks 0 and 2 rewrite every epoch -- the rows
+    they do not own must not carry the previous epoch's sums into the next all-reduce"""
+    _ranks_equal_single_learner(name, 3, cuts=[0, 5, 25, 37])
+
+
+def _ranks_equal_single_learner(name, world, cuts=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, cuts)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

@@ -1140,3 +1140,42 @@ def test_window_cut_fifo_round_trip_at_baseline_size(K):
     assert int(idx.min()) >= 0 and int(idx.max()) < 1000000 and len(torch.unique(idx)) > 500
     got = u.sample_batch(512, indices=idx)
     assert torch.equal(got['obs'], rows[idx]) and torch.equal(got['rewards'], rows[idx, 0])
+
+
+@pytest.mark.parametrize('n', [7, 1024 * 128, 70001])
+def test_reward_filter_scale_forward_update(K, n):
+    """smx_reward_filter_f32 against RewardFilter.forward / .update written with the reference's own torch ops
+    (surreal/model/reward_filter.py:33-57): three consecutive batches (the second call filters with the state
+    the first left behind, incl. the running_sumsq ASSIGNMENT), scale-only mode, the sums-only mode several
+    ranks use, and in-place output"""
+    g = torch.Generator().manual_seed(n)
+    state = torch.tensor([1e-5, 0.0, 0.0])
+    dstate = state.clone().cuda()
+    part = torch.zeros(K.reward_filter_partials(), dtype=torch.float64, device='cuda')
+    ticket = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for it in range(3):
+        r = torch.randn(n, generator=g) * (1.0 + it) + 0.3 * it
+        x = r * 0.25
+        mean = state[1] / state[0]
+        std = torch.clamp((state[2] / state[0] - mean.pow(2)).pow(0.5), min=1e-5)
+        want = torch.clamp((x - mean) / std, -5.0, 5.0)
+        state = torch.stack([state[0] + float(n), state[1] + x.sum(), (x * x).sum()])
+        out = torch.empty(n, device='cuda')
+        K.reward_filter(r.cuda(), 0.25, dstate, 1e-5, out, part, ticket)
+        close(out, want, msg='filtered rewards, batch %d' % it)
+        close(dstate, state, rtol=2e-6, atol=1e-3, msg='filter state after batch %d' % it)
+        assert int(ticket.item()) == 0
+    # scale only: no filter, state untouched; in place
+    r = torch.randn(n, generator=g)
+    buf = r.clone().cuda()
+    before = dstate.clone()
+    K.reward_filter(buf, 3.0, dstate, 1e-5, buf, part, ticket, use_filter=False, update=False)
+    close(buf, r * 3.0, atol=0, rtol=0)
+    assert torch.equal(before, dstate)
+    # what several ranks run: filter with the current state, report the batch sums, leave the state alone
+    sums = torch.zeros(3, device='cuda')
+    out = torch.empty(n, device='cuda')
+    K.reward_filter(r.cuda(), 0.5, dstate, 1e-5, out, part, ticket, use_filter=True, update=False, sums=sums)
+    x = r * 0.5
+    close(sums, torch.stack([torch.tensor(float(n)), x.sum(), (x * x).sum()]), rtol=2e-6, atol=1e-3)
+    assert torch.equal(before, dstate)
