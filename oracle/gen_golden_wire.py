@@ -97,6 +97,16 @@ def main():
         pickle.dump({'chunk': chunk, 'unpacked': unpacked, 'n_storage': n_storage,
                      'chunk_hash': U.binary_hash(chunk)}, fp)
 
+    # ---- the batch the reference's learner would see of that chunk (aggregator.py:106-262) ------------
+    from surreal.learner.aggregator import MultistepAggregatorWithInfo
+    agg = MultistepAggregatorWithInfo(
+        collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=[4])), {'dim': [2], 'type': 'continuous'})
+    bt = agg.aggregate(copy.deepcopy(unpacked))
+    assert bt['onetime_infos'] is None and len(bt['persistent_infos']) == 1
+    np.savez(os.path.join(OUT, 'exp_chunk_aggregated.npz'), obs=bt['obs']['low_dim']['flat_inputs'],
+             obs_next=bt['obs_next']['low_dim']['flat_inputs'], actions=bt['actions'], rewards=bt['rewards'],
+             dones=bt['dones'], persistent_infos0=bt['persistent_infos'][0])
+
     # ---- parameter protocol -------------------------------------------------------------------
     ps = object.__new__(ParameterServer)
     ps.parameters, ps.param_info = None, None

@@ -71,14 +71,14 @@ class ZFilter(object):
         # z_filter.py:40-42
         self.running_sum = torch.zeros(in_size)
         self.running_sumsq = eps * torch.ones(in_size)
-        self.count = torch.tensor([eps], dtype=torch.float32)
+        self.count = torch.tensor([eps], dtype=torch.get_default_dtype())
         if state is not None:
             self.load(state)
 
     def load(self, state):
-        self.running_sum = torch.tensor(np.asarray(state['running_sum']), dtype=torch.float32).clone()
-        self.running_sumsq = torch.tensor(np.asarray(state['running_sumsq']), dtype=torch.float32).clone()
-        self.count = torch.tensor(np.asarray(state['count']), dtype=torch.float32).clone()
+        self.running_sum = torch.tensor(np.asarray(state['running_sum']), dtype=torch.get_default_dtype()).clone()
+        self.running_sumsq = torch.tensor(np.asarray(state['running_sumsq']), dtype=torch.get_default_dtype()).clone()
+        self.count = torch.tensor(np.asarray(state['count']), dtype=torch.get_default_dtype()).clone()
 
     def state(self):
         return {'running_sum': self.running_sum.numpy().copy(),
@@ -118,9 +118,9 @@ class ZFilter(object):
 class RewardFilter(object):
     def __init__(self, eps=1e-5):
         self.eps = eps
-        self.count = torch.tensor(eps, dtype=torch.float32)
-        self.running_sum = torch.tensor(0.0, dtype=torch.float32)
-        self.running_sumsq = torch.tensor(0.0, dtype=torch.float32)
+        self.count = torch.tensor(eps, dtype=torch.get_default_dtype())
+        self.running_sum = torch.tensor(0.0, dtype=torch.get_default_dtype())
+        self.running_sumsq = torch.tensor(0.0, dtype=torch.get_default_dtype())
 
     def update(self, x):                         # reward_filter.py:33-42
         self.count += float(np.prod(x.size()))
@@ -150,7 +150,7 @@ class OraclePPOModel(object):
 
     def __init__(self, params, action_dim, use_z_filter=True, zstate=None, in_size=None):
         self.p = collections.OrderedDict(
-            (k, torch.tensor(np.asarray(v), dtype=torch.float32).clone().requires_grad_(True))
+            (k, torch.tensor(np.asarray(v), dtype=torch.get_default_dtype()).clone().requires_grad_(True))
             for k, v in params.items())
         self.action_dim = action_dim
         self.use_z_filter = use_z_filter
@@ -407,7 +407,7 @@ class OraclePPOLearner(object):
 
     # ------------------------------------------------------------- GAE
     def _gae_and_return(self, obs, obs_next, rewards, dones):    # ppo.py:355-418
-        index_set = torch.tensor(range(self.n_step), dtype=torch.float32)
+        index_set = torch.tensor(range(self.n_step), dtype=torch.get_default_dtype())
         gamma = torch.pow(self.gamma, index_set)
         lam = torch.pow(self.lam, index_set)
         oc = {}
@@ -428,7 +428,7 @@ class OraclePPOLearner(object):
     def gae_from_values(self, values, rewards, gamma=None, lam=None):
         """ppo.py:389-418 given the already-masked values (B, N+1)"""
         if gamma is None:
-            index_set = torch.tensor(range(self.n_step), dtype=torch.float32)
+            index_set = torch.tensor(range(self.n_step), dtype=torch.get_default_dtype())
             gamma = torch.pow(self.gamma, index_set)
             lam = torch.pow(self.lam, index_set)
         if self.if_rnn_policy:
@@ -465,22 +465,22 @@ class OraclePPOLearner(object):
         for m in batch['obs']:
             obs[m], obs_next[m] = {}, {}
             for k in batch['obs'][m]:
-                obs[m][k] = torch.as_tensor(np.asarray(batch['obs'][m][k]), dtype=torch.float32).clone()
-                obs_next[m][k] = torch.as_tensor(np.asarray(batch['obs_next'][m][k]), dtype=torch.float32).clone()
+                obs[m][k] = torch.as_tensor(np.asarray(batch['obs'][m][k]), dtype=torch.get_default_dtype()).clone()
+                obs_next[m][k] = torch.as_tensor(np.asarray(batch['obs_next'][m][k]), dtype=torch.get_default_dtype()).clone()
         out['obs'], out['obs_next'] = obs, obs_next
-        out['actions'] = torch.as_tensor(np.asarray(batch['actions']), dtype=torch.float32).clone()
-        rewards = torch.as_tensor(np.asarray(batch['rewards']), dtype=torch.float32) * self.reward_scale
+        out['actions'] = torch.as_tensor(np.asarray(batch['actions']), dtype=torch.get_default_dtype()).clone()
+        rewards = torch.as_tensor(np.asarray(batch['rewards']), dtype=torch.get_default_dtype()) * self.reward_scale
         if self.use_r_filter:
             normed = self.reward_filter.forward(rewards)
             self.reward_filter.update(rewards)
             rewards = normed
         out['rewards'] = rewards
-        out['dones'] = torch.as_tensor(np.asarray(batch['dones']), dtype=torch.float32).clone()
+        out['dones'] = torch.as_tensor(np.asarray(batch['dones']), dtype=torch.get_default_dtype()).clone()
         if batch.get('persistent_infos') is not None:
-            out['persistent_infos'] = [torch.as_tensor(np.asarray(x), dtype=torch.float32).clone()
+            out['persistent_infos'] = [torch.as_tensor(np.asarray(x), dtype=torch.get_default_dtype()).clone()
                                        for x in batch['persistent_infos']]
         if batch.get('onetime_infos') is not None:
-            out['onetime_infos'] = [torch.as_tensor(np.asarray(x), dtype=torch.float32).clone()
+            out['onetime_infos'] = [torch.as_tensor(np.asarray(x), dtype=torch.get_default_dtype()).clone()
                                     for x in batch['onetime_infos']]
         return out
 

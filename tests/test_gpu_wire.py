@@ -5,7 +5,9 @@ learner -- the flat parameter buffers the HIP kernels update in place:
       policy then runs on the GPU: the blob is the reference's wire form (numpy fp32 state dict), the
       hash / "unchanged" protocol holds, the agent acts with exactly the learner's parameters
   f2  experience chunks (hash-deduplicated observations) from agents acting on the GPU into the replay
-      and on into learn()
+      and on into learn(); and the chunk RECORDED FROM THE REFERENCE's own ExpBuffer (tests/golden/wire)
+      through collector -> FIFO replay -> aggregator -> learn on the GPU: the device batch equals the
+      reference aggregator's batch of the same chunk bit for bit, the learn() statistics equal the oracle's
   f3  checkpoint round trip in the reference's folder layout: a learner that learned on the GPU is saved
       and restored into a fresh one; the restored learner's next learn() equals the oracle continuing
       from the same parameters (the reference checkpoints the models and schedulers, NOT the optimiser
@@ -167,3 +169,9 @@ def test_experience_chunks_from_gpu_agents_feed_the_learner():
     st = learner.tensorplex.latest
     assert all(np.isfinite(st[k]) for k in ('_surr_loss', '_val_loss', '_pol_kl'))
     assert ag.fetch_parameter() and torch.equal(ag.model.flat, learner.model.flat)
+
+
+def test_reference_chunk_to_device_learn_equals_reference_batch_and_oracle():
+    """f2 against the oracle, on the HIP path (body and what it checks: tests/wire_cases.py)"""
+    import wire_cases
+    wire_cases.check_reference_chunk_to_learn(expect_cuda=True)

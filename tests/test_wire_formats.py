@@ -299,3 +299,9 @@ def test_agent_replay_learner_loop_over_the_wire_formats(cpu_double):
     before = ag.model.flat.clone()
     assert ag.fetch_parameter() and not ag.fetch_parameter()
     assert torch.equal(ag.model.flat, learner.model.flat) and not torch.equal(before, ag.model.flat)
+
+
+def test_reference_chunk_to_learn_equals_reference_batch_and_oracle(cpu_double):
+    """f2 end to end on the host tier: reference chunk -> collector -> FIFO -> aggregator -> learn"""
+    import wire_cases
+    wire_cases.check_reference_chunk_to_learn(expect_cuda=False)
