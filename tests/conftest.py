@@ -31,6 +31,16 @@ def pytest_sessionfinish(session, exitstatus):
         import helpers
     except Exception:
         return
+    arb = getattr(helpers, 'FP64_REPORT', {})
+    if arb:
+        worst = max(arb.items(), key=lambda kv: kv[1][0] / kv[1][2])
+        print('\nfp64 arbiter: %d gradient-norm traces; closest to its bound: %s -- %.3g from float64, the reference %.3g, '
+              'bound %.3g' % (len(arb), worst[0], worst[1][0], worst[1][1], worst[1][2]))
+        out = os.path.join(ROOT, 'gpurun_out')
+        if os.path.isdir(out):
+            import json
+            json.dump({k: {'path_vs_fp64': v[0], 'reference_vs_fp64': v[1], 'bound': v[2]} for k, v in arb.items()},
+                      open(os.path.join(out, 'fp64_arbiter_report.json'), 'w'), indent=0)
     rep = helpers.FINAL_PARAM_REPORT
     if not rep:
         return

@@ -25,19 +25,58 @@ LOOSE_KEYS = ('grad_norm_actor', 'grad_norm_critic')
 LOOSE_RTOL = 2e-4
 
 
-# cfg4_pixel_rnn_256x32 (BASELINE configs[3] at full size): on a randomly initialised CNN + LSTM stem the loss
-# gradients are sums of 7168 nearly cancelling row terms, Adam's first steps are ~lr * sign(g) per element, and the
-# stem is stepped by both optimisers -- the reference itself drifts on the gradient norms between hosts: the oracle
-# (= the reference's ATen ops) run on the GPU box's host CPU gives grad_norm_critic 0.120958 / 0.0304084 / 0.0240116
-# at value epochs 0 / 4 / 5 where the golden (recorded on the build container) has 0.120771 / 0.0305881 / 0.0237972
-# (1.5e-3 ... 9e-3 relative; tests/diag/diag_case.py cfg4_pixel_rnn_256x32 --oracle), while every loss agrees to 1e-5.
-# The HIP path -- other summation orders again (implicit-GEMM convolution gradients, split-K) -- stays within 4e-2,
-# the largest deviation where the critic's gradient norm passes through its minimum (value epochs 4-5, a fifth of its
-# initial value).  Its gradient norms get 6e-2; all other keys the common bound.
+# ---- the fp64 arbiter (oracle/gen_golden_fp64.py -> tests/golden/fp64_arbiter.json) ------------------------------
+# cfg4_pixel_rnn_256x32 (BASELINE configs[3] at full size): on a randomly initialised CNN + LSTM stem the loss gradients
+# are sums of 7168 nearly cancelling row terms, Adam's first steps are ~lr * sign(g) per element, and the stem is stepped
+# by both optimisers.  The reference's OWN fp32 path is not close to exact arithmetic there: against the float64 run of
+# the same learner its grad_norm_critic is off by 1.9e-3 / 8e-3 / 2.0e-2 at value epochs 0 / 5 / 6 (and moves by
+# 1.5e-3 ... 9e-3 between two x86 hosts), while every loss agrees to ~1e-5.  So for the gradient norms of the cases the
+# arbiter file holds, the bar is not "equal to the golden" but "no further from exact arithmetic than the reference is":
+#     max_e |HIP_e - fp64_e| / |fp64_e|  <=  2 * max_e |ATen_e - fp64_e| / |fp64_e|  +  LOOSE_RTOL
+# (assert_fp64_arbiter, per trace and key), and the direct comparison with the golden is DERIVED from it -- a path that
+# meets the arbiter is within 3x the reference's own distance of the golden -- instead of a hand-picked constant.
 # Its explained variance, 1 - var(ret - V) / var(ret) = 5e-4 there, carries the value loss's RELATIVE error (1e-5)
 # as an absolute one and gets 5e-5.
-CASE_LOOSE_RTOL = {'cfg4_pixel_rnn_256x32': 6e-2}
+FP64 = json.load(open(os.path.join(GOLDEN_DIR, 'fp64_arbiter.json')))
+FP64_REPORT = {}             # 'case key' -> (HIP-vs-fp64, reference-vs-fp64, bound): printed / written by conftest.py
+
+
+def _max_rel(rows, ref_rows, key):
+    return max(abs(a[key] - b[key]) / abs(b[key]) for a, b in zip(rows, ref_rows) if key in b)
+
+
+def reference_fp64_distance(name, key):
+    """how far the REFERENCE's fp32 trace (the golden) is from the float64 run, max over the epochs"""
+    g, _ = load_golden(name)
+    which = 'policy' if key == 'grad_norm_actor' else 'value'
+    return _max_rel(json.loads(str(g[which + '_trace_json'])), FP64['golden'][name][which], key)
+
+
+def _derived_loose_rtol():
+    out = {}
+    for name in FP64['golden']:
+        if not os.path.exists(os.path.join(GOLDEN_DIR, 'ppo_%s.npz' % name)):
+            continue
+        d = max(reference_fp64_distance(name, k) for k in LOOSE_KEYS)
+        if d > 5.0 * LOOSE_RTOL:          # (cases the reference itself reproduces to ~LOOSE_RTOL keep the common bound)
+            out[name] = 3.0 * d + LOOSE_RTOL
+    return out
+
+
+CASE_LOOSE_RTOL = None       # filled below (needs load_golden)
 CASE_ATOL = {'cfg4_pixel_rnn_256x32': {'_val_explained_var': 5e-5}}
+
+
+def assert_fp64_arbiter(rows, golden_rows, f64_rows, what, floor=LOOSE_RTOL):
+    """gradient norms of one trace (policy or value rows): no further from float64 than twice the reference's fp32"""
+    for key in LOOSE_KEYS:
+        if not f64_rows or key not in f64_rows[0]:
+            continue
+        ours, ref = _max_rel(rows, f64_rows, key), _max_rel(golden_rows, f64_rows, key)
+        bound = 2.0 * ref + floor
+        FP64_REPORT['%s %s' % (what, key)] = (ours, ref, bound)
+        assert ours <= bound, '%s %s: %.3g from the float64 value, the reference is %.3g from it (bound %.3g)' % (
+            what, key, ours, ref, bound)
 
 
 def tol_for(key, atol, rtol, case=''):
@@ -71,6 +110,9 @@ def load_golden(name):
     g = np.load(os.path.join(GOLDEN_DIR, 'ppo_%s.npz' % name))
     case = json.loads(str(g['case_json']))
     return g, case
+
+
+CASE_LOOSE_RTOL = _derived_loose_rtol()
 
 
 def case_inputs(case):
@@ -144,6 +186,10 @@ def assert_trace_close(trace, g, atol=ATOL, rtol=RTOL, what=''):
             at, rt = tol_for(k, atol, rtol, what)
             np.testing.assert_allclose(a[k], b[k], atol=at, rtol=rt,
                                        err_msg='%s value epoch %d key %s' % (what, e, k))
+    case = what.split(' ')[0]
+    if case in FP64['golden']:
+        assert_fp64_arbiter(trace['policy'], gp, FP64['golden'][case]['policy'], what + ' policy')
+        assert_fp64_arbiter(trace['value'], gv, FP64['golden'][case]['value'], what + ' value')
 
 
 def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):

@@ -104,6 +104,12 @@ def run_sequence(name, session_overrides=None, atol=H.ATOL, rtol=H.RTOL):
             for e, (a, b) in enumerate(zip(tr['policy'] + tr['value'], r['policy'] + r['value'])):
                 for k in b:
                     _close(k, a[k], b[k], orows[e][k], '%s epoch row %d %s' % (what, e, k), atol, rtol)
+            f64 = H.FP64['sequences'].get(name)
+            if f64 is not None:
+                # the float64 run of the same sequence settles which fp32 answer is "right": the path may sit as far
+                # from it as the band in which the reference itself moves between hosts (SEQ_GOLDEN_RTOL), never further
+                H.assert_fp64_arbiter(tr['policy'], r['policy'], f64[it]['policy'], what + ' policy', floor=SEQ_GOLDEN_RTOL)
+                H.assert_fp64_arbiter(tr['value'], r['value'], f64[it]['value'], what + ' value', floor=SEQ_GOLDEN_RTOL)
             adv = L._ws.adv.cpu().numpy().reshape(-1).astype(np.float64)
             ret = L._ws.ret.cpu().numpy().reshape(-1).astype(np.float64)
             np.testing.assert_allclose(adv[:8], r['adv_head'], atol=atol, rtol=rtol, err_msg=what + ' adv')
