@@ -387,24 +387,34 @@ def main():
             strong = {'value': B * N * args.steps / sdt, 'unit': 'env-steps/s', 'ms_per_step': sdt / args.steps * 1e3,
                       'global_batch': B, 'B_per_gpu': strong_hi - strong_lo, 'hip_graph': bool(sl.use_graph),
                       'final_stats': {k: sstats[k] for k in ('_surr_loss', '_val_loss', '_pol_kl') if k in sstats}}
+            if sl._dist.exchange is not None:
+                barrier()
+                sl._dist.exchange.close()
             del sl
 
     ws = learner._ws
-    # what one per-epoch exchange costs on this node: the all-reduce of the epoch payload, timed alone
-    collective_us = collective_bytes = None
+    # what one per-epoch exchange costs on this node: the all-reduce of the epoch payload, timed alone -- through the
+    # path the learner used (PeerExchange kernels over IPC-mapped peer buffers when its self-check passed, else the
+    # process group) and through the process group (RCCL) for comparison
+    collective_us = collective_bytes = pg_us = None
+    exchange_kind = getattr(learner, 'exchange_kind', None)
     if world > 1 and getattr(ws, 'ar', None) is not None:
-        for _ in range(5):
-            dist.all_reduce(ws.ar)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            dist.all_reduce(ws.ar)
-        e1.record()
-        torch.cuda.synchronize()
-        t = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        collective_us, collective_bytes = float(t.item()), ws.ar.numel() * 4
+        def time_all_reduce(fn):
+            for _ in range(5):
+                fn(ws.ar)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn(ws.ar)
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        pg_us = time_all_reduce(dist.all_reduce)
+        collective_us = time_all_reduce(learner._dist.all_reduce) if learner._dist.exchange is not None else pg_us
+        collective_bytes = ws.ar.numel() * 4
     kt = time_fused_kernel(learner, dbatch) if ws.key[0] == B and not (learner.if_rnn_policy or learner.model.if_pixel) else None
     out = None
     if rank == 0:
@@ -431,8 +441,11 @@ def main():
                 'hip_graph': bool(learner.use_graph), 'parallelism': 'dp%d' % world,
                 'epoch_kernels': 'fused row-block' if getattr(ws, 'fused', False) else 'layered',
                 'collectives_per_step': getattr(learner, 'collectives_per_step', 0 if world == 1 else None),
+                'exchange': exchange_kind,
                 'epoch_all_reduce_us': collective_us, 'epoch_all_reduce_bytes': collective_bytes,
-                'graph_segments': bool(getattr(learner, 'graph_segments_active', world > 1 and learner.use_graph)),
+                'epoch_all_reduce_us_process_group': pg_us,
+                'graph_segments': bool(world > 1 and learner.use_graph and getattr(learner._dist, 'exchange', None) is None),
+                'zfilter': 'reciprocal (<= 1 ulp from z_filter.py:77; the exact division is selectable, DESIGN.md 1)',
             },
             'final_stats': {k: stats[k] for k in ('_surr_loss', '_val_loss', '_pol_kl') if k in stats},
         }
@@ -467,6 +480,16 @@ def main():
                 'achieved_hbm_GBps': STEP_BYTES / step_s / 1e9,
                 'hbm_frac': STEP_BYTES / step_s / 1e9 / PEAK_HBM_GBPS,
             }
+        if world > 1 and collective_us is not None:
+            # the serial share of the exchanges in a step, if none of them overlapped with compute (the two large
+            # ones per epoch do not: the next launch needs their result), and the weak-scaling efficiency that
+            # leaves: t_1 / t_N with t_1 = t_N - exchanges
+            per_step = out['config']['collectives_per_step'] or 0
+            ex_ms = per_step * collective_us / 1e3
+            out['exchange_model'] = {'exchange_ms_per_step': ex_ms, 'share_of_step': ex_ms / (step_s * 1e3),
+                                     'predicted_efficiency': max(0.0, 1.0 - ex_ms / (step_s * 1e3)),
+                                     'note': 'collectives_per_step x epoch_all_reduce_us (the small exchanges are '
+                                             'priced like the large one: an upper bound)'}
         if strong is not None:
             out['strong'] = strong
         if world == 1 and args.scaling == 'weak':
@@ -481,6 +504,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if getattr(learner, '_dist', None) is not None and learner._dist.exchange is not None:
+            learner._dist.exchange.close()
         dist.destroy_process_group()
 
 

@@ -780,6 +780,46 @@ int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_
 int smx_flatten_order_f32(const float* in, int32_t O, int32_t C, int32_t P,
                           int32_t to_channel_last, float* out, smx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Data-parallel exchange between the learner ranks of one node over IPC-mapped peer buffers (xGMI loads): the
+ * collectives N sharded learners need to equal the single reference learner -- the per-epoch
+ * [gradients | loss partial rows] sum of surreal/learner/ppo.py:541-562 run on shards, the advantage moments
+ * (ppo.py:413-416), the end-of-learn statistics -- as ONE kernel each inside the learner's hipGraph instead of an
+ * eager RCCL call between graph segments (csrc/smx_xchg.hip has the protocol).  The reference has no counterpart (one
+ * learner process); the host-side fallback is torch.distributed (RCCL).
+ *
+ * Set-up, once per learner workspace: every rank  smx_xchg_alloc()s a buffer of smx_xchg_bytes(capacity, world),
+ * smx_xchg_export()s its 64-byte handle, the handles travel through the process group, every rank smx_xchg_open()s
+ * its peers' handles and fills smx_xchg_t.peer[] (peer[rank] = its own buffer), then a barrier.  These are the only
+ * entry points of the library that allocate or synchronise.
+ * Exchanges: issued by every rank in the same order on ONE stream per exchange context; the sequence number lives in
+ * the buffer, so a captured graph replays.  err (nullable): a device int32 into which a timed-out wait ORs
+ * 0x100 | phase << 4 | peer (the caller reads it back with its statistics); after an error no wait blocks any more.
+ * Results are bit-identical on all ranks (rank c alone reduces chunk c, summing the ranks in rank order). */
+#define SMX_XCHG_MAX_RANKS 8
+#define SMX_XCHG_HANDLE_BYTES 64
+typedef struct {
+    int32_t world, rank;
+    int64_t capacity;                      /* floats one exchange may carry */
+    void* peer[SMX_XCHG_MAX_RANKS];        /* every rank's buffer as mapped in THIS process */
+} smx_xchg_t;
+int64_t smx_xchg_bytes(int64_t capacity_floats, int32_t world);
+/* kind (nullable) <- 0 uncached, 1 fine-grained, 2 plain device memory (what the runtime granted); timeout_s: bound of
+ * every in-kernel wait (<= 0: 2 s).  Zero-fills and synchronises `stream`. */
+int smx_xchg_alloc(int64_t bytes, double timeout_s, void** ptr, int32_t* kind, smx_stream_t stream);
+int smx_xchg_free(void* ptr);
+int smx_xchg_export(void* ptr, void* handle64);
+int smx_xchg_open(const void* handle64, void** ptr);
+int smx_xchg_close(void* ptr);
+/* out[0, n) = sum over ranks of in[0, n); in == out allowed; 16-byte aligned; n <= capacity */
+int smx_xchg_allreduce_f32(const smx_xchg_t* x, const float* in, float* out, int64_t n, int32_t* err,
+                           smx_stream_t stream);
+/* out [world, n_per_rank] <- every rank's in[0, n_per_rank); world * n_per_rank <= capacity */
+int smx_xchg_allgather_f32(const smx_xchg_t* x, const float* in, int64_t n_per_rank, float* out, int32_t* err,
+                           smx_stream_t stream);
+/* seq_err_dev[2] (device) <- {exchanges completed, error word} of this rank's buffer */
+int smx_xchg_status(const smx_xchg_t* x, uint32_t* seq_err_dev, smx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,11 @@ class PpoCombine(Structure):
                 ('reserved', c_int32)]
 
 
+class Xchg(Structure):
+    """smx_xchg_t"""
+    _fields_ = [('world', c_int32), ('rank', c_int32), ('capacity', c_int64), ('peer', c_void_p * 8)]
+
+
 class SynthActStep(Structure):
     """smx_synth_act_step_t"""
     _fields_ = [('state', c_void_p), ('init_state', c_void_p), ('mean', c_void_p), ('log_var', c_void_p),
@@ -125,6 +130,7 @@ CTRL_WORDS = 16
 (C_LR_ACTOR, C_LR_CRITIC, C_BETA, C_ETA, C_CLIP_EPS, C_KL_TARGET, C_ACTOR_MAX_NORM,
  C_CRITIC_MAX_NORM, C_ACTOR_WD, C_CRITIC_WD, C_STEP_ACTOR, C_STEP_CRITIC, C_STOP,
  C_EPOCHS_DONE) = range(14)
+C_XCHG_ERR = 14          # reserved[0]: raised by a peer exchange that timed out (zeroed with the per-learn words)
 
 _P = c_void_p
 _SIGS = {
@@ -238,6 +244,15 @@ _SIGS = {
     'smx_col2im_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  _P, _P, _P]),
     'smx_flatten_order_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'smx_xchg_bytes': (c_int64, [c_int64, c_int32]),
+    'smx_xchg_alloc': (c_int32, [c_int64, c_double, POINTER(c_void_p), POINTER(c_int32), _P]),
+    'smx_xchg_free': (c_int32, [_P]),
+    'smx_xchg_export': (c_int32, [_P, _P]),
+    'smx_xchg_open': (c_int32, [_P, POINTER(c_void_p)]),
+    'smx_xchg_close': (c_int32, [_P]),
+    'smx_xchg_allreduce_f32': (c_int32, [POINTER(Xchg), _P, _P, c_int64, _P, _P]),
+    'smx_xchg_allgather_f32': (c_int32, [POINTER(Xchg), _P, c_int64, _P, _P, _P]),
+    'smx_xchg_status': (c_int32, [POINTER(Xchg), _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))

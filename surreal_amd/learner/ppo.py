@@ -123,13 +123,17 @@ class _SegmentedGraph(object):
 
 
 class _CountingDist(object):
-    """torch.distributed with a counter on the collectives a learn() issues (reported by bench.py) and
-    a hook for _SegmentedGraph"""
+    """torch.distributed with a counter on the collectives a learn() issues (reported by bench.py), a hook
+    for _SegmentedGraph, and -- when the ranks share a node -- the fp32 exchanges routed through
+    surreal_amd.distributed.PeerExchange (one kernel on the learner's stream, part of its graph) instead of
+    the process group (an eager RCCL call that cuts the graph)."""
 
     def __init__(self, dist):
         self._d = dist
         self.count = 0
         self.recorder = None
+        self.exchange = None         # PeerExchange, once a workspace has set it up and checked it
+        self.err_word = None         # device int32 a timed-out exchange raises (the learner's control block)
 
     def _run(self, name, a, k):
         def thunk():
@@ -140,11 +144,22 @@ class _CountingDist(object):
             return None
         return thunk()
 
-    def all_reduce(self, *a, **k):
-        return self._run('all_reduce', a, k)
+    def _peer_ok(self, *tensors):
+        ex = self.exchange
+        return ex is not None and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and
+                                      t.numel() <= ex.capacity and t.data_ptr() % 16 == 0 for t in tensors)
 
-    def all_gather_into_tensor(self, *a, **k):
-        return self._run('all_gather_into_tensor', a, k)
+    def all_reduce(self, t, *a, **k):
+        if not a and not k and self._peer_ok(t):
+            self.count += 1
+            return self.exchange.all_reduce(t, err=self.err_word)
+        return self._run('all_reduce', (t,) + a, k)
+
+    def all_gather_into_tensor(self, out, t, *a, **k):
+        if not a and not k and self._peer_ok(out, t):
+            self.count += 1
+            return self.exchange.all_gather_into_tensor(out, t, err=self.err_word)
+        return self._run('all_gather_into_tensor', (out, t) + a, k)
 
     def __getattr__(self, name):
         return getattr(self._d, name)
@@ -496,9 +511,35 @@ class PPOLearner(Learner):
         ws.sumsq_c = torch.zeros(max(ws.np_c, K.sumsq_blocks(ws.grads_c.numel())), device=dev)
         if self.use_z_filter:
             ws.zdelta = ws.tail_pack[ws.tail_cuts[3]:] if ws.dp_epoch else torch.zeros(2 * D + 1, device=dev)
+        ws.xerr = ws.ctrl_i[L.C_XCHG_ERR:L.C_XCHG_ERR + 1]
+        if self.world_size > 1:
+            self._setup_peer_exchange(ws, n_a + n_c)
         self._ws = ws
         self._graphs = {}
         return ws
+
+    def _setup_peer_exchange(self, ws, n_grads):
+        """several ranks on one node: the fp32 exchanges of a learn() as kernels over IPC-mapped peer buffers
+        (surreal_amd.distributed.PeerExchange) -- set up and SELF-CHECKED once, collectively; any failure leaves
+        the process group (RCCL) in place.  session_config.learner.peer_exchange = False keeps RCCL."""
+        d = self._dist
+        d.err_word = ws.xerr
+        want = bool(self.session_config.learner.get('peer_exchange', True)) and self.device != 'cpu'
+        need = max(ws.ar.numel() if ws.dp_epoch else n_grads, 64)
+        if getattr(ws, 'tail_gather', None) is not None:
+            need = max(need, ws.tail_gather.numel())
+        if not want:
+            return
+        if d.exchange is not None and d.exchange.capacity >= need:
+            return
+        if d.exchange is not None:
+            d._d.barrier()
+            d.exchange.close()
+            d.exchange = None
+        from surreal_amd.distributed.peer_exchange import PeerExchange
+        d.exchange = PeerExchange.create(d._d, need, timeout_s=float(self.session_config.learner.get(
+            'peer_exchange_timeout_s', 2.0)))
+        self.exchange_kind = 'peer buffers (%s)' % d.exchange.check_message if d.exchange is not None else 'process group'
 
     # ======================================================================================
     # batch handling
@@ -1369,6 +1410,7 @@ class PPOLearner(Learner):
                 gc_was_enabled = gc.isenabled()
                 gc.collect()
                 gc.disable()
+                c_cap = self._dist.count if self._dist is not None else 0
                 try:
                     if self.world_size == 1:
                         with torch.cuda.graph(g):
@@ -1387,11 +1429,18 @@ class PPOLearner(Learner):
                 if g is None:
                     self._enqueue_optimize(ws, *args)
                     return self._collect_stats(ws)
+                # exchanges that run as kernels INSIDE the graph (PeerExchange) were counted while they were captured,
+                # not executed: a replay re-runs them, so it re-counts them (the process group's calls count themselves)
+                if self._dist is not None:
+                    g.in_graph_collectives = self._dist.count - c_cap
+                    self._dist.count = c_cap
                 if getattr(ws, 'staged', None) is not None and args is ws.staged:
                     self._graphs = {key: g}          # staging mode: the in-place graph is retired
                 else:
                     self._graphs[key] = g
             g.replay()
+            if self._dist is not None:
+                self._dist.count += getattr(g, 'in_graph_collectives', 0)
         else:
             self._enqueue_optimize(ws, *args)
         return self._collect_stats(ws)
@@ -1476,6 +1525,9 @@ class PPOLearner(Learner):
         ret_mom = scal[o + 3:o + 6].numpy()
         fin = scal[o + 8:o + 12].numpy()
         rf = scal[o + 12:o + 15].numpy()
+        if int(ctrl_i[L.C_XCHG_ERR]) != 0:
+            raise RuntimeError('a peer exchange timed out in the last learn(): error word 0x%x (0x100 | phase << 4 | peer) '
+                               '-- a rank died or fell behind by more than the timeout' % (int(ctrl_i[L.C_XCHG_ERR]) & 0xffff))
         done = int(ctrl_i[L.C_EPOCHS_DONE])      # policy updates applied
         # the reference breaks after the update whose KL is too large: `done` updates ran,
         # slot `done` holds the forward pass after the last one
