@@ -287,9 +287,9 @@ def secondary_pipeline(actors):
     return {'env_steps_per_s': r['value'], 'ms_per_iteration': r['ms_per_iteration'],
             'rollout_env_steps_per_s': r['rollout_env_steps_per_s'], 'stage_ms': r['stage_ms_synchronised'],
             'actors': actors, 'n_step': 128, 'learns_per_rollout': r['config']['learns_per_rollout'],
-            'what': 'act (3 dependent launches per env step: two hidden layers, then output layer + sample + env step + '
-                    'record + z-filter; rollout replayed as one hipGraph) + moving-window cut into the FIFO table + pop '
-                    '+ PPOLearner.learn'}
+            'what': 'act: ONE launch per rollout (smx_synth_rollout_f32: a workgroup owns 16 actors through all 128 steps '
+                    '-- z-filter, the three policy layers on FP32 MFMA, sample, env step, record) + moving-window cut into '
+                    'the FIFO table + pop + PPOLearner.learn'}
 
 
 def secondaries():

@@ -780,6 +780,38 @@ int smx_col2im_f32(const float* dcols, int64_t F, int32_t C, int32_t Hin, int32_
 int smx_flatten_order_f32(const float* in, int32_t O, int32_t C, int32_t P,
                           int32_t to_channel_last, float* out, smx_stream_t stream);
 
+/* A whole device-resident rollout in ONE launch: `steps` iterations of [z-filter -> policy MLP -> DiagGauss sample ->
+ * clip -> synthetic env step -> record] for all n actors (the per-step loop of surreal/agent/base.py:244-271 with
+ * PPOAgent.act, surreal/agent/ppo_agent.py:106-154, and the recording of env/exp_sender_wrapper.py:153-264).  A
+ * workgroup owns 16 actors for the whole rollout; the policy layers run on FP32 MFMA from `packed`
+ * (smx_epoch_pack_f32 of `net`), with the operations of smx_epoch_forward_f32 in the same order (bit-identical means);
+ * sampling, dynamics, recording and the z-filter use the expressions of smx_synth_act_env_step_f32.
+ * eps [steps, n, A] standard normals (NULL: deterministic); zsum/zsumsq/zcount: the z-filter's running sums (NULL:
+ * raw observations); rolls [n, rows_per_actor, .] (any may be NULL); state [n, D] is read at the start and left at
+ * the state after the last step; t: the episode clock at the first step. */
+typedef struct smx_synth_rollout {
+    const smx_mlp3_t* net;
+    const float* packed;
+    int32_t out_act, n;
+    const float* log_var;
+    const float* noise_scale;
+    const float* eps;
+    const float* zsum;
+    const float* zsumsq;
+    const float* zcount;
+    float zeps;
+    int32_t t, episode_len, steps, rows_per_actor, slot;
+    float* state;
+    const float* init_state;
+    float* obs_roll;
+    float* act_roll;
+    float* rew_roll;
+    float* done_roll;
+    float* pd_roll;
+} smx_synth_rollout_t;
+int32_t smx_synth_rollout_supported(int32_t D, int32_t H1, int32_t H2, int32_t A);
+int smx_synth_rollout_f32(const smx_synth_rollout_t* args, smx_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Data-parallel exchange between the learner ranks of one node over IPC-mapped peer buffers (xGMI loads): the
  * collectives N sharded learners need to equal the single reference learner -- the per-epoch

@@ -109,6 +109,16 @@ class PpoCombine(Structure):
                 ('reserved', c_int32)]
 
 
+class SynthRollout(Structure):
+    """smx_synth_rollout_t"""
+    _fields_ = [('net', POINTER(Mlp3)), ('packed', c_void_p), ('out_act', c_int32), ('n', c_int32),
+                ('log_var', c_void_p), ('noise_scale', c_void_p), ('eps', c_void_p), ('zsum', c_void_p),
+                ('zsumsq', c_void_p), ('zcount', c_void_p), ('zeps', c_float), ('t', c_int32),
+                ('episode_len', c_int32), ('steps', c_int32), ('rows_per_actor', c_int32), ('slot', c_int32),
+                ('state', c_void_p), ('init_state', c_void_p), ('obs_roll', c_void_p), ('act_roll', c_void_p),
+                ('rew_roll', c_void_p), ('done_roll', c_void_p), ('pd_roll', c_void_p)]
+
+
 class Xchg(Structure):
     """smx_xchg_t"""
     _fields_ = [('world', c_int32), ('rank', c_int32), ('capacity', c_int64), ('peer', c_void_p * 8)]
@@ -244,6 +254,8 @@ _SIGS = {
     'smx_col2im_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  _P, _P, _P]),
     'smx_flatten_order_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'smx_synth_rollout_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_synth_rollout_f32': (c_int32, [POINTER(SynthRollout), _P]),
     'smx_xchg_bytes': (c_int64, [c_int64, c_int32]),
     'smx_xchg_alloc': (c_int32, [c_int64, c_double, POINTER(c_void_p), POINTER(c_int32), _P]),
     'smx_xchg_free': (c_int32, [_P]),

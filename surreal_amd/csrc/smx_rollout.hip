@@ -1,0 +1,269 @@
+// A whole device-resident rollout in ONE launch (surreal/agent/base.py:244-271 the per-step loop of a rollout
+// worker, surreal/agent/ppo_agent.py:106-154 act: z-filter -> policy MLP -> DiagGauss sample -> clip; the environment
+// step and the recording that surreal/env/exp_sender_wrapper.py:153-264 does on the host).
+//
+// Actors are independent of each other, time steps are not: so a workgroup OWNS 16 actors and walks them through all
+// T steps by itself -- no per-step launch, no grid-wide synchronisation.  Per step:
+//   x tile (z-filtered observations of its 16 actors, LDS)  ->  the three policy layers on v_mfma_f32_16x16x4_f32 with
+//   the fragment-order packed weights streamed from L2 (the row-block loop of smx_epoch_mma.inc.h, the same operations
+//   in the same order as smx_epoch_forward_f32: bit-identical means)  ->  the sampling head (mean, std * exp(noise),
+//   a = clip(mean + std * eps))  ->  the synthetic environment's step for the 16 actors (state kept in LDS for the
+//   whole rollout)  ->  the transition recorded into the rollout tables [actors, T + 1, .]  ->  the next observation
+//   z-filtered straight into the x tile.
+// The per-step launches it replaces were 3 dependent launches of ~9.5 us each (two hidden layers as GEMM launches, then
+// head + step), 384 launches for T = 128; here a step is the MFMA issue time of one CU for 16 rows (~12 us at
+// D = 376, [300, 200]) and the chip runs 256 such workgroups side by side (4096 actors cost what 1024 do).
+#include "smx_common.h"
+#include <string.h>
+
+namespace {
+#include "smx_epoch_pack.inc.h"
+#include "smx_epoch_mma.inc.h"
+
+constexpr int RLDO = 36;          // row stride of the mean tile in LDS (<= 32 actions)
+constexpr int RMAX_A = 32;
+
+struct RollArgs {
+    const float *P1, *P2, *P3;                  // packed weights (smx_epoch_pack_f32)
+    const float *b1, *b2, *b3;
+    int D, H1, H2, A, out_act;
+    const float *log_var, *noise_scale, *eps;   // eps [T, n, A] or null (deterministic)
+    const float *zsum, *zsumsq, *zcount;        // z-filter running sums or null
+    float zeps;
+    float* state;                               // [n, D] in / out
+    const float* init_state;
+    int n, t0, episode_len, steps, R, slot0;    // R = rows per actor in the rollout tables
+    float *obs_roll, *act_roll, *rew_roll, *done_roll, *pd_roll;
+    int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_state, off_z, off_act, lds_floats;
+};
+
+__device__ __forceinline__ float zclamp_r(float x, float m, float sd) {
+    float v = (x - m) / sd;                     // z_filter.py:77
+    if (v == v) v = fminf(fmaxf(v, -5.0f), 5.0f);
+    return v;
+}
+
+__global__ __launch_bounds__(NTH) void rollout_kernel(RollArgs G) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fm = lane & 15, kq = lane >> 4;
+    const long row0 = (long)blockIdx.x * ER;
+    int nrows = G.n - (int)row0;
+    if (nrows > ER) nrows = ER;
+    const int D = G.D, A = G.A, R = G.R;
+    float* xs = sm;
+    float* h1s = sm + G.off_h1;
+    float* h2s = sm + G.off_h2;
+    float* outs = sm + G.off_out;
+    float* st = sm + G.off_state;               // [16][D] raw states
+    float* zm = sm + G.off_z;                   // [D] z-filter mean | [D] std
+    float* zs = zm + D;
+    float* s_act = sm + G.off_act;              // [16][RMAX_A] clipped actions
+    const int ldx = G.ldx, ldh1 = G.ldh1, ldh2 = G.ldh2;
+    const int xr = tid >> 4, xj = tid & 15;     // 16 threads per actor row
+
+    // ---- once: clear the tiles, z-filter statistics, the 16 states ------------------------------------
+    for (int i = tid; i < G.off_state; i += NTH) sm[i] = 0.f;
+    if (G.zsum) {
+        for (int k = tid; k < D; k += NTH) {
+            const float c = G.zcount[0];
+            const float m = G.zsum[k] / c;
+            const float var = G.zsumsq[k] / c - m * m;
+            float sz = sqrtf(var);
+            if (sz == sz) sz = fmaxf(sz, G.zeps);
+            zm[k] = m; zs[k] = sz;
+        }
+    }
+    for (int k = xj; k < D; k += 16)
+        st[xr * D + k] = xr < nrows ? G.state[(row0 + xr) * D + k] : 0.f;
+    SMX_LDS_BARRIER();
+    for (int k = xj; k < D; k += 16) {
+        const float s = st[xr * D + k];
+        xs[xr * ldx + k] = xr < nrows ? (G.zsum ? zclamp_r(s, zm[k], zs[k]) : s) : 0.f;
+    }
+    SMX_LDS_BARRIER();
+
+    int t = G.t0;
+#pragma unroll 1
+    for (int step = 0; step < G.steps; ++step) {
+        const int slot = G.slot0 + step;
+        // this step's normal draws, requested before the layers (consumed behind them)
+        float ev[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTH * i;               // (row, action) pairs: 16 x A <= 512
+            const int r = idx / A, j = idx - r * A;
+            if (G.eps && r < nrows) ev[i] = G.eps[((size_t)step * G.n + row0 + r) * A + j];
+        }
+        // ---- the three layers: the loop of epoch_fwd_kernel without its global stores ---------------------
+#pragma unroll 1
+        for (int l = 0; l < 3; ++l) {
+            const float* Wp = l == 0 ? G.P1 : (l == 1 ? G.P2 : G.P3);
+            const float* bias = l == 0 ? G.b1 : (l == 1 ? G.b2 : G.b3);
+            const int H = l == 0 ? G.H1 : (l == 1 ? G.H2 : A);
+            const int K = l == 0 ? D : (l == 1 ? G.H1 : G.H2);
+            const float* in_lds = l == 0 ? xs : (l == 1 ? h1s : h2s);
+            const int ldi = l == 0 ? ldx : (l == 1 ? ldh1 : ldh2);
+            float* out_lds = l == 0 ? h1s : (l == 1 ? h2s : outs);
+            const int ldo = l == 0 ? ldh1 : (l == 1 ? ldh2 : RLDO);
+            const int tiles = (H + 15) >> 4;
+            const int C2 = pack_chunks(K);
+            const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
+            const rsrc_t rbias = make_rsrc(bias, (unsigned)H * 4u);
+#pragma unroll 1
+            for (int tb = 0; tb < tiles; tb += NWV * TG) {
+                const int t0 = tb + wv;
+                int nt = (tiles - t0 + NWV - 1) / NWV;
+                nt = nt < 0 ? 0 : (nt > TG ? TG : nt);
+                float bs[TG][4];
+#pragma unroll
+                for (int g = 0; g < TG; ++g) {
+                    const int f0 = 16 * (t0 + NWV * g) + 4 * kq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rbias, (g < nt) ? (unsigned)(f0 + r) * 4u : OOB);
+                }
+                f32x4 acc[TG];
+#pragma unroll
+                for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (nt > 4) fwd_tiles<5>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+                else if (nt > 2) fwd_tiles<4>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+                else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+                else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+#pragma unroll
+                for (int g = 0; g < TG; ++g) {
+                    if (g < nt) {
+                        const int f0 = 16 * (t0 + NWV * g) + 4 * kq;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float z = acc[g][r] + bs[g][r];
+                            if (g == 0 && l == 2) z = act_f(z, G.out_act);
+                            else z = (z < 0.f) ? 0.f : z;
+                            v[r] = (f0 + r < H) ? z : 0.f;
+                        }
+                        *(float4*)(out_lds + fm * ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+            SMX_LDS_BARRIER();
+        }
+        // ---- sampling head (smx_diaggauss_sample_f32's expressions): one (actor, action) pair per lane -------
+        const bool done = (t + 1 >= G.episode_len);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTH * i;
+            const int r = idx / A, j = idx - r * A;
+            if (r < nrows) {
+                const long a = row0 + r;
+                const float mu = outs[r * RLDO + j];
+                float sd = expf(G.log_var[j]);
+                if (G.noise_scale) sd = sd * G.noise_scale[a];
+                float act = G.eps ? ev[i] * sd + mu : mu;
+                if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
+                s_act[r * RMAX_A + j] = act;
+                if (G.act_roll) G.act_roll[(a * R + slot) * A + j] = act;
+                if (G.pd_roll) {
+                    G.pd_roll[(a * R + slot) * 2 * A + j] = mu;
+                    G.pd_roll[(a * R + slot) * 2 * A + A + j] = sd;
+                }
+            }
+        }
+        SMX_LDS_BARRIER();
+        // ---- environment step of the 16 actors (smx_synth_env_step_f32's expressions), recording, next x tile ---
+        if (xr < nrows) {
+            const long a = row0 + xr;
+            for (int k = xj; k < D; k += 16) {
+                const float ac = s_act[xr * RMAX_A + (k % A)];
+                const float s = st[xr * D + k];
+                const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+                float sn = (0.9f * s + 0.5f * ac) + drift;
+                sn = fminf(fmaxf(sn, -10.0f), 10.0f);
+                if (G.obs_roll) {
+                    G.obs_roll[(a * R + slot) * D + k] = s;
+                    if (slot + 1 < R) G.obs_roll[(a * R + slot + 1) * D + k] = sn;
+                }
+                if (k == 0) {
+                    double q = 0.0;
+                    for (int j = 0; j < A; ++j) {
+                        const float av = s_act[xr * RMAX_A + j];
+                        q += (double)av * (double)av;
+                    }
+                    if (G.rew_roll) G.rew_roll[a * R + slot] = (float)(-0.1 * q + 0.05 * (double)sn);
+                    if (G.done_roll) G.done_roll[a * R + slot] = done ? 1.0f : 0.0f;
+                }
+                const float next = done ? G.init_state[a * D + k] : sn;
+                st[xr * D + k] = next;
+                xs[xr * ldx + k] = G.zsum ? zclamp_r(next, zm[k], zs[k]) : next;
+            }
+        }
+        t = done ? 0 : t + 1;
+        SMX_LDS_BARRIER();
+    }
+    // ---- the states the actors are left in ---------------------------------------------------------------
+    if (xr < nrows)
+        for (int k = xj; k < D; k += 16) G.state[(row0 + xr) * D + k] = st[xr * D + k];
+}
+
+inline int rr64(int v) { return (v + 63) & ~63; }
+
+int carve(RollArgs& G) {
+    G.ldx = rr64(G.D) + 4; G.ldh1 = rr64(G.H1) + 4; G.ldh2 = rr64(G.H2) + 4;
+    G.off_h1 = ER * G.ldx;
+    G.off_h2 = G.off_h1 + ER * G.ldh1;
+    G.off_out = G.off_h2 + ER * G.ldh2;
+    G.off_state = G.off_out + ER * RLDO;
+    G.off_z = G.off_state + ER * G.D;
+    G.off_act = G.off_z + 2 * G.D;
+    G.lds_floats = G.off_act + ER * RMAX_A;
+    return G.lds_floats * (int)sizeof(float);
+}
+
+constexpr int ROLL_MAX_LDS = 150 * 1024;
+constexpr int ROLL_EXCLUSIVE_LDS = 84 * 1024;
+
+}  // namespace
+
+extern "C" int32_t smx_synth_rollout_supported(int32_t D, int32_t H1, int32_t H2, int32_t A) {
+    if (!(D > 0 && H1 > 0 && H2 > 0 && A > 0 && A <= RMAX_A && H1 % 4 == 0 && H2 % 4 == 0)) return 0;
+    if (!(H1 <= 16 * NWV * TG * 2 && H2 <= 16 * NWV * TG * 2)) return 0;
+    RollArgs G;
+    memset(&G, 0, sizeof(G));
+    G.D = D; G.H1 = H1; G.H2 = H2; G.A = A;
+    return carve(G) <= ROLL_MAX_LDS;
+}
+
+extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t stream) {
+    SMX_REQUIRE(a && a->net && a->packed && a->log_var && a->state && a->init_state, SMX_E_NULL);
+    const smx_mlp3_t& n = *a->net;
+    SMX_REQUIRE(smx_synth_rollout_supported(n.D, n.H1, n.H2, n.OUT), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(a->n > 0 && a->steps > 0 && a->episode_len > 0 && a->rows_per_actor > 0, SMX_E_SHAPE);
+    SMX_REQUIRE(a->slot >= 0 && (!a->obs_roll || a->slot + a->steps <= a->rows_per_actor), SMX_E_SHAPE);
+    SMX_REQUIRE(((uintptr_t)a->packed & 15) == 0 && ((uintptr_t)n.b1 & 3) == 0, SMX_E_ALIGN);
+    SMX_REQUIRE((a->zsum == nullptr) == (a->zsumsq == nullptr) && (a->zsum == nullptr) == (a->zcount == nullptr), SMX_E_NULL);
+    RollArgs G;
+    memset(&G, 0, sizeof(G));
+    G.P1 = a->packed;
+    G.P2 = a->packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 1);
+    G.P3 = a->packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 2);
+    G.b1 = n.b1; G.b2 = n.b2; G.b3 = n.b3;
+    G.D = n.D; G.H1 = n.H1; G.H2 = n.H2; G.A = n.OUT; G.out_act = a->out_act;
+    G.log_var = a->log_var; G.noise_scale = a->noise_scale; G.eps = a->eps;
+    G.zsum = a->zsum; G.zsumsq = a->zsumsq; G.zcount = a->zcount; G.zeps = a->zeps;
+    G.state = a->state; G.init_state = a->init_state;
+    G.n = a->n; G.t0 = a->t; G.episode_len = a->episode_len; G.steps = a->steps; G.R = a->rows_per_actor; G.slot0 = a->slot;
+    G.obs_roll = a->obs_roll; G.act_roll = a->act_roll; G.rew_roll = a->rew_roll; G.done_roll = a->done_roll;
+    G.pd_roll = a->pd_roll;
+    int lds = carve(G);
+    // one workgroup per CU: each keeps the four matrix pipes of a CU busy by itself
+    if (lds < ROLL_EXCLUSIVE_LDS) lds = ROLL_EXCLUSIVE_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
+        attr_set = true;
+    }
+    const int blocks = (a->n + ER - 1) / ER;
+    hipLaunchKernelGGL(rollout_kernel, dim3(blocks), dim3(NTH), lds, smx_s(stream), G);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}

@@ -97,6 +97,7 @@ class SyntheticVecEnv(object):
         self.state = self.init_state.clone()
         self.t = 0
         self.rolls = None
+        self.persistent = True        # rollout(): the one-launch kernel where the policy's shapes allow it
 
     def reset(self):
         self.state.copy_(self.init_state)
@@ -135,10 +136,12 @@ class SyntheticVecEnv(object):
         return self.state
 
     def rollout(self, agent, eps=None):
-        """A whole recorded rollout (start_rollout(T) first) under `agent`'s plain-MLP policy with
-        THREE launches per environment step: the two hidden layers, then one launch that forms the policy mean,
-        samples the action, steps every actor, records the transition and z-filters the next observation.
-        Same numbers as ``for t: agent.act_batch(state) -> step(actions, pds)``.
+        """A whole recorded rollout (start_rollout(T) first) under `agent`'s plain-MLP policy: ONE launch
+        (smx_synth_rollout_f32: 16 actors per workgroup through all T steps) where the shapes allow it, else
+        THREE launches per environment step (the two hidden layers, then one launch that forms the policy mean,
+        samples the action, steps every actor, records the transition and z-filters the next observation).
+        Same numbers (1e-6: the layers' fp32 summation order differs between the two) as
+        ``for t: agent.act_batch(state) -> step(actions, pds)``.
         eps: [T, n, A] standard-normal draws (default: drawn here in one launch; None-eps agents in
         a deterministic mode ignore it)."""
         T, n, K = self.T, self.n, self.K
@@ -148,15 +151,30 @@ class SyntheticVecEnv(object):
             eps = torch.randn(T, n, self.A, device=self.device)
         noise = agent.batch_noise(n).view(-1)
         zf = agent.model.z_filter if agent.use_z_filter else None
+        log_var = agent.model.log_var.view(-1)
+        actor = agent.model.actor
+        plain_mlp = not (agent.rnn_config.if_rnn_policy or agent.model.if_pixel)
+        if plain_mlp and self.persistent and K.synth_rollout_supported(actor):
+            # ONE launch for the whole rollout: a workgroup owns 16 actors and walks them through all T steps
+            # (csrc/smx_rollout.hip).  The packed weight copy is refreshed here: the agent's parameters only change
+            # between rollouts (fetch_parameter)
+            if getattr(self, '_pk', None) is None or self._pk.numel() != K.epoch_packed_numel(actor):
+                self._pk = torch.zeros(K.epoch_packed_numel(actor), device=self.device)
+            K.epoch_pack([(actor, self._pk)])
+            K.synth_rollout(actor, self._pk, L.SMX_ACT_TANH, self.state, self.init_state, log_var, noise,
+                            None if deterministic else eps.contiguous(), self.t, self.episode_len, T, self.slot,
+                            self.rolls, zf)
+            self.slot += T
+            for _ in range(T):
+                self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
+            return
         if getattr(self, '_xn', None) is None:
             self._xn = torch.empty(n, self.D, device=self.device)
         if zf is not None:
             K.zfilter_forward_sums(self.state, zf.running_sum, zf.running_sumsq, zf.count, zf.eps, self._xn)
         else:
             self._xn.copy_(self.state)
-        log_var = agent.model.log_var.view(-1)
-        actor = agent.model.actor
-        if not (agent.rnn_config.if_rnn_policy or agent.model.if_pixel) and actor.OUT <= 32:
+        if plain_mlp and actor.OUT <= 32:
             # THREE launches per environment step: the two hidden layers, then one launch that forms the policy
             # mean (output layer + tanh) per actor, samples, steps, records and z-filters the next observation
             if getattr(self, '_h1', None) is None or self._h1.shape != (n, actor.H1):
@@ -177,6 +195,30 @@ class SyntheticVecEnv(object):
             K.synth_act_env_step(self.state, self.init_state, mean, log_var, noise,
                                  None if deterministic else eps[t], self.t, self.episode_len, self.slot,
                                  self.rolls, zf, self._xn)
+            self.slot += 1
+            self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
+
+    def rollout_reference(self, agent, eps):
+        """the same rollout with TWO launches per step out of the kernels the persistent one is built from: the
+        row-block forward (smx_epoch_forward_f32: the means) and the head + step launch.  Bit-identical to
+        ``rollout`` on the persistent kernel -- the parity test's reference; not used by the product loop."""
+        T, n, K = self.T, self.n, self.K
+        actor = agent.model.actor
+        noise = agent.batch_noise(n).view(-1)
+        zf = agent.model.z_filter if agent.use_z_filter else None
+        xn = torch.empty(n, self.D, device=self.device)
+        mean = torch.empty(n, actor.OUT, device=self.device)
+        pk = torch.zeros(K.epoch_packed_numel(actor), device=self.device)
+        K.epoch_pack([(actor, pk)])
+        if zf is not None:
+            K.zfilter_forward_sums(self.state, zf.running_sum, zf.running_sumsq, zf.count, zf.eps, xn)
+        else:
+            xn.copy_(self.state)
+        ctrl = torch.zeros(L.CTRL_WORDS, device=self.device)
+        for t in range(T):
+            K.epoch_forward([dict(net=actor, packed=pk, x=xn, out=mean, act=L.SMX_ACT_TANH)], None, ctrl, n)
+            K.synth_act_env_step(self.state, self.init_state, mean, agent.model.log_var.view(-1), noise,
+                                 None if eps is None else eps[t], self.t, self.episode_len, self.slot, self.rolls, zf, xn)
             self.slot += 1
             self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
 

@@ -501,6 +501,31 @@ class HipKernels(object):
         L.call('smx_synth_act_env_step_head_f32', ctypes.byref(p), L.ptr(W3), L.ptr(b3), L.ptr(h2),
                _row_stride(h2, H2), H2, int(out_act), self._st())
 
+    def synth_rollout_supported(self, net):
+        return bool(self.lib.smx_synth_rollout_supported(net.D, net.H1, net.H2, net.OUT))
+
+    def synth_rollout(self, net, packed, out_act, state, init_state, log_var, noise_scale, eps, t, episode_len,
+                      steps, slot, rolls, zfilter):
+        """`steps` acting + environment steps of all actors in ONE launch (csrc/smx_rollout.hip): a workgroup owns
+        16 actors for the whole rollout.  packed: epoch_pack of `net`; eps [steps, n, A] or None; rolls as in
+        synth_act_env_step ([n, T + 1, .] tables)."""
+        n, D = state.shape
+        p = L.SynthRollout()
+        p.net, p.packed, p.out_act, p.n = ctypes.pointer(net.desc), L.ptr(packed), int(out_act), n
+        p.log_var, p.noise_scale, p.eps = L.ptr(log_var), L.ptr(noise_scale), L.ptr(eps)
+        if eps is not None:
+            assert eps.is_contiguous() and tuple(eps.shape) == (steps, n, net.OUT)
+        if zfilter is not None:
+            p.zsum, p.zsumsq, p.zcount = L.ptr(zfilter.running_sum), L.ptr(zfilter.running_sumsq), L.ptr(zfilter.count)
+            p.zeps = float(zfilter.eps)
+        r = rolls or {}
+        p.t, p.episode_len, p.steps, p.slot = int(t), int(episode_len), int(steps), int(slot)
+        p.rows_per_actor = r['obs'].shape[1] if 'obs' in r else 1
+        p.state, p.init_state = L.ptr(state), L.ptr(init_state)
+        p.obs_roll, p.act_roll = L.ptr(r.get('obs')), L.ptr(r.get('actions'))
+        p.rew_roll, p.done_roll, p.pd_roll = L.ptr(r.get('rewards')), L.ptr(r.get('dones')), L.ptr(r.get('pds'))
+        L.call('smx_synth_rollout_f32', ctypes.byref(p), self._st())
+
     def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,
                        rew_roll, done_roll):
         n, D = state.shape

@@ -304,6 +304,9 @@ class TorchCpuKernels(object):
     def reward_filter_partials(self):
         return 128
 
+    def synth_rollout_supported(self, net):
+        return False                 # the double walks the rollout step by step (SyntheticVecEnv's layered path)
+
     def reward_filter(self, rewards, scale, state, eps, out, partials, ticket, use_filter=True, update=True, sums=None):
         x = rewards * _f(scale)
         if use_filter:

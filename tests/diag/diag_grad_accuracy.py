@@ -85,3 +85,25 @@ for which, key in (('policy', 'grad_norm_actor'), ('value', 'grad_norm_critic'))
 d = os.path.join(ROOT, 'gpurun_out')
 if os.path.isdir(d):
     json.dump(out, open(os.path.join(d, 'grad_accuracy_%s.json' % name), 'w'), indent=0)
+
+# ---- ReLU-mask lottery: how many of the CNN stem's output activations have a different sign in each fp32 path than
+# in float64 (a unit within fp32 rounding of zero lands on either side; its whole gradient contribution flips) -----
+if m.if_pixel:
+    E, B = ws.E, ws.key[0]
+    pix = np.asarray(batch['obs']['pixel']['camera0'])[:, :E]
+    pix = pix.reshape((-1,) + pix.shape[2:])
+    feats = {}
+    for nm, dt in (('f64', torch.float64), ('f32', torch.float32)):
+        torch.set_default_dtype(dt)
+        M = ppo_oracle.OraclePPOModel(params, case['shape']['A'], True, zstate, in_size=case['shape']['D'])
+        with torch.no_grad():
+            feats[nm] = torch.cat([M._cnn(torch.as_tensor(pix[i:i + 512], dtype=dt) / 255.0) for i in range(0, len(pix), 512)]).double().numpy()
+    torch.set_default_dtype(torch.float32)
+    D = ws.key[2]
+    feats['hip'] = ws.xn[:, D:].detach().cpu().double().numpy()
+    for nm in ('hip', 'f32'):
+        flips = np.argwhere((feats[nm] > 0) != (feats['f64'] > 0))
+        print('CNN feature units whose ReLU mask differs from float64: %-4s %d of %d; max |feature - f64| %.2e' % (
+            nm, len(flips), feats['f64'].size, np.abs(feats[nm] - feats['f64']).max()))
+        for r, c in flips[:5]:
+            print('    row %d unit %d: %s %.3e  f64 %.3e' % (r, c, nm, feats[nm][r, c], feats['f64'][r, c]))

@@ -1179,3 +1179,70 @@ def test_reward_filter_scale_forward_update(K, n):
     x = r * 0.5
     close(sums, torch.stack([torch.tensor(float(n)), x.sum(), (x * x).sum()]), rtol=2e-6, atol=1e-3)
     assert torch.equal(before, dstate)
+
+
+def _rollout_setup(n, D, A, hidden, T, episode_len, use_z, deterministic, seed):
+    from surreal_amd.agent import PPOAgent
+    from surreal_amd.env import SyntheticVecEnv
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    from surreal_amd import synthetic
+    lc = ppo_learner_config()
+    lc.algo.rnn.if_rnn_policy = False
+    lc.algo.use_z_filter = use_z
+    lc.model.actor_fc_hidden_sizes = lc.model.critic_fc_hidden_sizes = list(hidden)
+    ec, sc = ppo_env_config(D, A), ppo_session_config('/tmp/surreal_amd_test_rollout')
+    agent = PPOAgent(lc, ec, sc, agent_id=1, agent_mode='eval_deterministic_local' if deterministic else 'training')
+    agent.model.load_params(synthetic.make_ppo_params(D, A, hidden=tuple(hidden), seed=seed, final_scale=2.0,
+                                                      log_sig_spread=0.4))
+    if use_z:
+        agent.model.z_filter.load_state_dict(synthetic.make_zfilter_state(D, seed=seed + 1))
+    eps = None if deterministic else torch.randn(T, n, A, generator=torch.Generator().manual_seed(seed)).cuda()
+
+    def run(how):
+        venv = SyntheticVecEnv(n, D, A, episode_len=episode_len, seeds=list(range(n)))
+        # (an episode may end inside the recorded span here: the kernels' reset path is exercised on purpose)
+        venv.T, venv.slot = T, 0
+        f = lambda *s: torch.zeros(*s, device='cuda')  # noqa: E731
+        venv.rolls = {'obs': f(n, T + 1, D), 'actions': f(n, T + 1, A), 'rewards': f(n, T + 1), 'dones': f(n, T + 1),
+                      'pds': f(n, T + 1, 2 * A)}
+        if how == 'persistent':
+            venv.persistent = True
+            venv.rollout(agent, eps=eps)
+        elif how == 'reference':
+            venv.rollout_reference(agent, eps)
+        else:
+            venv.persistent = False
+            venv.rollout(agent, eps=eps)
+        torch.cuda.synchronize()
+        assert venv.slot == T
+        out = {k: v.cpu() for k, v in venv.rolls.items()}
+        out['state'], out['t'] = venv.state.cpu(), venv.t
+        return out
+    return agent, run
+
+
+@pytest.mark.parametrize('n,D,A,hidden,T,ep,use_z,det', [
+    (37, 11, 3, (24, 16), 9, 9, True, False),          # a partial last workgroup (37 = 2 x 16 + 5)
+    (16, 376, 17, (300, 200), 6, 50, True, False),     # the benchmark's policy shape
+    (48, 17, 6, (300, 200), 7, 4, True, False),        # the episode ends (and resets) inside the rollout
+    (20, 29, 5, (40, 24), 5, 5, False, False),         # no z-filter
+    (33, 12, 2, (16, 12), 4, 9, True, True),           # deterministic mode: no draws
+])
+def test_persistent_rollout_kernel(K, n, D, A, hidden, T, ep, use_z, det):
+    """smx_synth_rollout_f32 (one launch, 16 actors per workgroup through all T steps) records bit for bit what the
+    two-launches-per-step loop built from the same operations records (smx_epoch_forward_f32 for the means, then
+    smx_synth_act_env_step_f32), and -- to fp32 rounding of the layer sums -- what the layered per-step path
+    (GEMM launches per layer) records"""
+    agent, run = _rollout_setup(n, D, A, hidden, T, ep, use_z, det, seed=11)
+    assert K.synth_rollout_supported(agent.model.actor)
+    one, ref, layered = run('persistent'), run('reference'), run('layered')
+    for k in ref:
+        if k == 't':
+            assert one[k] == ref[k] == layered[k]
+            continue
+        assert torch.equal(one[k], ref[k]), '%s differs from the two-launch reference (max %g)' % (
+            k, float((one[k] - ref[k]).abs().max()))
+        np.testing.assert_allclose(one[k].numpy(), layered[k].numpy(), rtol=1e-5, atol=1e-5, err_msg=k)
+    assert float(one['pds'].abs().sum()) > 0 and float(one['obs'][:, T].abs().sum()) > 0
+    if ep < T:
+        assert float(one['dones'][:, :T].sum()) == n * (T // ep)
