@@ -7,8 +7,8 @@
 //   x tile (z-filtered observations of its 16 actors, LDS)  ->  the three policy layers on v_mfma_f32_16x16x4_f32 with
 //   the fragment-order packed weights streamed from L2 (the row-block loop of smx_epoch_mma.inc.h, the same operations
 //   in the same order as smx_epoch_forward_f32: bit-identical means)  ->  the sampling head (mean, std * exp(noise),
-//   a = clip(mean + std * eps))  ->  the synthetic environment's step for the 16 actors (state kept in LDS for the
-//   whole rollout)  ->  the transition recorded into the rollout tables [actors, T + 1, .]  ->  the next observation
+//   a = clip(mean + std * eps))  ->  the synthetic environment's step for the 16 actors (state kept in registers for
+//   the whole rollout)  ->  the transition recorded into the rollout tables [actors, T + 1, .]  ->  the next observation
 //   z-filtered straight into the x tile.
 // The per-step launches it replaces were 3 dependent launches of ~9.5 us each (two hidden layers as GEMM launches, then
 // head + step), 384 launches for T = 128; here a step is the MFMA issue time of one CU for 16 rows (~12 us at
@@ -19,6 +19,18 @@
 namespace {
 #include "smx_epoch_pack.inc.h"
 #include "smx_epoch_mma.inc.h"
+
+// Phase timestamps exist only in a build with -DSMX_ROLLOUT_TIMING (scripts/bench_rollout.py); the product build has none.
+#ifdef SMX_ROLLOUT_TIMING
+#define RSTAMP(i) do { if (g_rtbuf_dev && threadIdx.x == 0 && step == G.steps / 2) g_rtbuf_dev[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RWALL(i) do { if (g_rtbuf_dev && threadIdx.x == 0) g_rtbuf_dev[(size_t)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#define RCYC(i) do { if (g_rtbuf_dev && threadIdx.x == 0) g_rtbuf_dev[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+__device__ long long* g_rtbuf_dev = nullptr;
+#else
+#define RSTAMP(i) do { } while (0)
+#define RWALL(i) do { } while (0)
+#define RCYC(i) do { } while (0)
+#endif
 
 constexpr int RLDO = 36;          // row stride of the mean tile in LDS (<= 32 actions)
 constexpr int RMAX_A = 32;
@@ -34,7 +46,7 @@ struct RollArgs {
     const float* init_state;
     int n, t0, episode_len, steps, R, slot0;    // R = rows per actor in the rollout tables
     float *obs_roll, *act_roll, *rew_roll, *done_roll, *pd_roll;
-    int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_state, off_z, off_act, lds_floats;
+    int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_act, off_z, lds_floats;
 };
 
 __device__ __forceinline__ float zclamp_r(float x, float m, float sd) {
@@ -43,7 +55,14 @@ __device__ __forceinline__ float zclamp_r(float x, float m, float sd) {
     return v;
 }
 
-__global__ __launch_bounds__(NTH) void rollout_kernel(RollArgs G) {
+constexpr int RNWV = 8;           // two wavefronts per SIMD: the K loops have no barrier inside, so one wave's loads
+constexpr int RNTH = 64 * RNWV;   // and epilogue hide under the other's MFMAs (a tile's arithmetic does not depend on
+                                  // which wave carries it: same bits as the four-wave epoch kernels)
+constexpr int RROWS = ER / RNWV;  // actor rows a wavefront steps in the environment phase
+constexpr int RKV = 8;            // observation elements a lane owns per row (D <= 64 RKV)
+constexpr int RTG = 3;            // feature tiles a wave carries per pass (register budget of two waves per SIMD)
+
+__global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
     extern __shared__ float sm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,46 +75,60 @@ __global__ __launch_bounds__(NTH) void rollout_kernel(RollArgs G) {
     float* h1s = sm + G.off_h1;
     float* h2s = sm + G.off_h2;
     float* outs = sm + G.off_out;
-    float* st = sm + G.off_state;               // [16][D] raw states
-    float* zm = sm + G.off_z;                   // [D] z-filter mean | [D] std
-    float* zs = zm + D;
     float* s_act = sm + G.off_act;              // [16][RMAX_A] clipped actions
     const int ldx = G.ldx, ldh1 = G.ldh1, ldh2 = G.ldh2;
-    const int xr = tid >> 4, xj = tid & 15;     // 16 threads per actor row
 
-    // ---- once: clear the tiles, z-filter statistics, the 16 states ------------------------------------
-    for (int i = tid; i < G.off_state; i += NTH) sm[i] = 0.f;
-    if (G.zsum) {
-        for (int k = tid; k < D; k += NTH) {
+    // ---- once: clear the tiles; the z-filter's mean / std and k % A (an integer division per element and step
+    // otherwise) go to LDS tables; a lane owns elements k = lane + 64 i of the actor rows 2 wv and 2 wv + 1 and keeps
+    // their raw state in registers for the whole rollout
+    for (int i = tid; i < G.off_z; i += RNTH) sm[i] = 0.f;          // (incl. the action tile: its unused columns stay 0)
+    float* zm = sm + G.off_z;                   // [D] z-filter mean | [D] std | [D] k % A (as int)
+    float* zs = zm + D;
+    int* kmod = (int*)(zs + D);
+    for (int k = tid; k < D; k += RNTH) {
+        kmod[k] = k % A;
+        float m = 0.f, sz = 1.f;
+        if (G.zsum) {
             const float c = G.zcount[0];
-            const float m = G.zsum[k] / c;
+            m = G.zsum[k] / c;
             const float var = G.zsumsq[k] / c - m * m;
-            float sz = sqrtf(var);
+            sz = sqrtf(var);
             if (sz == sz) sz = fmaxf(sz, G.zeps);
-            zm[k] = m; zs[k] = sz;
+        }
+        zm[k] = m; zs[k] = sz;
+    }
+    float st[RROWS][RKV];
+#pragma unroll
+    for (int i = 0; i < RKV; ++i) {
+        const int k = lane + 64 * i;
+#pragma unroll
+        for (int rr = 0; rr < RROWS; ++rr) {
+            const int r = RROWS * wv + rr;
+            st[rr][i] = (k < D && r < nrows) ? G.state[(row0 + r) * D + k] : 0.f;
         }
     }
-    for (int k = xj; k < D; k += 16)
-        st[xr * D + k] = xr < nrows ? G.state[(row0 + xr) * D + k] : 0.f;
     SMX_LDS_BARRIER();
-    for (int k = xj; k < D; k += 16) {
-        const float s = st[xr * D + k];
-        xs[xr * ldx + k] = xr < nrows ? (G.zsum ? zclamp_r(s, zm[k], zs[k]) : s) : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RROWS; ++rr) {
+        const int r = RROWS * wv + rr;
+#pragma unroll
+        for (int i = 0; i < RKV; ++i) {
+            const int k = lane + 64 * i;
+            if (k < D && r < nrows) xs[r * ldx + k] = G.zsum ? zclamp_r(st[rr][i], zm[k], zs[k]) : st[rr][i];
+        }
     }
     SMX_LDS_BARRIER();
 
     int t = G.t0;
+    RWALL(12); RCYC(13);
 #pragma unroll 1
     for (int step = 0; step < G.steps; ++step) {
         const int slot = G.slot0 + step;
-        // this step's normal draws, requested before the layers (consumed behind them)
-        float ev[2] = {0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + NTH * i;               // (row, action) pairs: 16 x A <= 512
-            const int r = idx / A, j = idx - r * A;
-            if (G.eps && r < nrows) ev[i] = G.eps[((size_t)step * G.n + row0 + r) * A + j];
-        }
+        RSTAMP(0);
+        // this step's normal draw of the lane's (row, action) pair, requested before the layers (consumed behind them)
+        const int hr = tid / A, hj = tid - hr * A;        // 16 x A <= 512 pairs
+        float ev = 0.f;
+        if (G.eps && hr < nrows) ev = G.eps[((size_t)step * G.n + row0 + hr) * A + hj];
         // ---- the three layers: the loop of epoch_fwd_kernel without its global stores ---------------------
 #pragma unroll 1
         for (int l = 0; l < 3; ++l) {
@@ -112,33 +145,32 @@ __global__ __launch_bounds__(NTH) void rollout_kernel(RollArgs G) {
             const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
             const rsrc_t rbias = make_rsrc(bias, (unsigned)H * 4u);
 #pragma unroll 1
-            for (int tb = 0; tb < tiles; tb += NWV * TG) {
+            for (int tb = 0; tb < tiles; tb += RNWV * RTG) {
                 const int t0 = tb + wv;
-                int nt = (tiles - t0 + NWV - 1) / NWV;
-                nt = nt < 0 ? 0 : (nt > TG ? TG : nt);
-                float bs[TG][4];
+                int nt = (tiles - t0 + RNWV - 1) / RNWV;
+                nt = nt < 0 ? 0 : (nt > RTG ? RTG : nt);
+                float bs[RTG][4];
 #pragma unroll
-                for (int g = 0; g < TG; ++g) {
-                    const int f0 = 16 * (t0 + NWV * g) + 4 * kq;
+                for (int g = 0; g < RTG; ++g) {
+                    const int f0 = 16 * (t0 + RNWV * g) + 4 * kq;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rbias, (g < nt) ? (unsigned)(f0 + r) * 4u : OOB);
                 }
                 f32x4 acc[TG];
 #pragma unroll
                 for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (nt > 4) fwd_tiles<5>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
-                else if (nt > 2) fwd_tiles<4>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
-                else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
-                else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, NWV, lane);
+                if (nt > 2) fwd_tiles<3>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
 #pragma unroll
-                for (int g = 0; g < TG; ++g) {
+                for (int g = 0; g < RTG; ++g) {
                     if (g < nt) {
-                        const int f0 = 16 * (t0 + NWV * g) + 4 * kq;
+                        const int f0 = 16 * (t0 + RNWV * g) + 4 * kq;
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float z = acc[g][r] + bs[g][r];
-                            if (g == 0 && l == 2) z = act_f(z, G.out_act);
+                            if (l == 2) z = act_f(z, G.out_act);
                             else z = (z < 0.f) ? 0.f : z;
                             v[r] = (f0 + r < H) ? z : 0.f;
                         }
@@ -147,62 +179,82 @@ __global__ __launch_bounds__(NTH) void rollout_kernel(RollArgs G) {
                 }
             }
             SMX_LDS_BARRIER();
+            RSTAMP(1 + l);
         }
         // ---- sampling head (smx_diaggauss_sample_f32's expressions): one (actor, action) pair per lane -------
         const bool done = (t + 1 >= G.episode_len);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + NTH * i;
-            const int r = idx / A, j = idx - r * A;
-            if (r < nrows) {
-                const long a = row0 + r;
-                const float mu = outs[r * RLDO + j];
-                float sd = expf(G.log_var[j]);
-                if (G.noise_scale) sd = sd * G.noise_scale[a];
-                float act = G.eps ? ev[i] * sd + mu : mu;
-                if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
-                s_act[r * RMAX_A + j] = act;
-                if (G.act_roll) G.act_roll[(a * R + slot) * A + j] = act;
-                if (G.pd_roll) {
-                    G.pd_roll[(a * R + slot) * 2 * A + j] = mu;
-                    G.pd_roll[(a * R + slot) * 2 * A + A + j] = sd;
-                }
+        if (hr < nrows) {
+            const long a = row0 + hr;
+            const float mu = outs[hr * RLDO + hj];
+            float sd = expf(G.log_var[hj]);
+            if (G.noise_scale) sd = sd * G.noise_scale[a];
+            float act = G.eps ? ev * sd + mu : mu;
+            if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
+            s_act[hr * RMAX_A + hj] = act;
+            if (G.act_roll) G.act_roll[(a * R + slot) * A + hj] = act;
+            if (G.pd_roll) {
+                G.pd_roll[(a * R + slot) * 2 * A + hj] = mu;
+                G.pd_roll[(a * R + slot) * 2 * A + A + hj] = sd;
             }
         }
         SMX_LDS_BARRIER();
+        RSTAMP(4);
         // ---- environment step of the 16 actors (smx_synth_env_step_f32's expressions), recording, next x tile ---
-        if (xr < nrows) {
-            const long a = row0 + xr;
-            for (int k = xj; k < D; k += 16) {
-                const float ac = s_act[xr * RMAX_A + (k % A)];
-                const float s = st[xr * D + k];
-                const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
-                float sn = (0.9f * s + 0.5f * ac) + drift;
-                sn = fminf(fmaxf(sn, -10.0f), 10.0f);
-                if (G.obs_roll) {
-                    G.obs_roll[(a * R + slot) * D + k] = s;
-                    if (slot + 1 < R) G.obs_roll[(a * R + slot + 1) * D + k] = sn;
-                }
-                if (k == 0) {
-                    double q = 0.0;
-                    for (int j = 0; j < A; ++j) {
-                        const float av = s_act[xr * RMAX_A + j];
-                        q += (double)av * (double)av;
+#pragma unroll
+        for (int rr = 0; rr < RROWS; ++rr) {
+            const int r = RROWS * wv + rr;                 // wave-uniform
+            if (r < nrows) {
+                const long a = row0 + r;
+                float* orow = G.obs_roll ? G.obs_roll + (a * R + slot) * D : nullptr;
+                float sn0 = 0.f;
+#pragma unroll
+                for (int i = 0; i < RKV; ++i) {
+                    const int k = lane + 64 * i;
+                    if (k < D) {
+                        const float ac = s_act[r * RMAX_A + kmod[k]];
+                        const float s = st[rr][i];
+                        const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+                        float sn = (0.9f * s + 0.5f * ac) + drift;
+                        sn = fminf(fmaxf(sn, -10.0f), 10.0f);
+                        if (orow) {
+                            orow[k] = s;
+                            if (slot + 1 < R) orow[D + k] = sn;
+                        }
+                        if (i == 0) sn0 = sn;
+                        const float next = done ? G.init_state[a * D + k] : sn;
+                        st[rr][i] = next;
+                        xs[r * ldx + k] = G.zsum ? zclamp_r(next, zm[k], zs[k]) : next;
                     }
-                    if (G.rew_roll) G.rew_roll[a * R + slot] = (float)(-0.1 * q + 0.05 * (double)sn);
+                }
+                if (lane == 0) {                            // (k == 0 lives in lane 0, i == 0)
+                    // sum_j a_j^2 in fp64, j ascending (the order of smx_synth_env_step_f32).  All RMAX_A reads are
+                    // issued up front (unused columns of the tile are zero and add +0.0): one LDS round trip, not A
+                    float av[RMAX_A];
+#pragma unroll
+                    for (int j = 0; j < RMAX_A; ++j) av[j] = s_act[r * RMAX_A + j];
+                    double q = 0.0;
+#pragma unroll
+                    for (int j = 0; j < RMAX_A; ++j) q += (double)av[j] * (double)av[j];
+                    if (G.rew_roll) G.rew_roll[a * R + slot] = (float)(-0.1 * q + 0.05 * (double)sn0);
                     if (G.done_roll) G.done_roll[a * R + slot] = done ? 1.0f : 0.0f;
                 }
-                const float next = done ? G.init_state[a * D + k] : sn;
-                st[xr * D + k] = next;
-                xs[xr * ldx + k] = G.zsum ? zclamp_r(next, zm[k], zs[k]) : next;
             }
         }
         t = done ? 0 : t + 1;
         SMX_LDS_BARRIER();
+        RSTAMP(5);
     }
+    RWALL(14); RCYC(15);
     // ---- the states the actors are left in ---------------------------------------------------------------
-    if (xr < nrows)
-        for (int k = xj; k < D; k += 16) G.state[(row0 + xr) * D + k] = st[xr * D + k];
+#pragma unroll
+    for (int rr = 0; rr < RROWS; ++rr) {
+        const int r = RROWS * wv + rr;
+#pragma unroll
+        for (int i = 0; i < RKV; ++i) {
+            const int k = lane + 64 * i;
+            if (k < D && r < nrows) G.state[(row0 + r) * D + k] = st[rr][i];
+        }
+    }
 }
 
 inline int rr64(int v) { return (v + 63) & ~63; }
@@ -212,10 +264,9 @@ int carve(RollArgs& G) {
     G.off_h1 = ER * G.ldx;
     G.off_h2 = G.off_h1 + ER * G.ldh1;
     G.off_out = G.off_h2 + ER * G.ldh2;
-    G.off_state = G.off_out + ER * RLDO;
-    G.off_z = G.off_state + ER * G.D;
-    G.off_act = G.off_z + 2 * G.D;
-    G.lds_floats = G.off_act + ER * RMAX_A;
+    G.off_act = G.off_out + ER * RLDO;
+    G.off_z = G.off_act + ER * RMAX_A;
+    G.lds_floats = G.off_z + 3 * G.D;
     return G.lds_floats * (int)sizeof(float);
 }
 
@@ -224,9 +275,14 @@ constexpr int ROLL_EXCLUSIVE_LDS = 84 * 1024;
 
 }  // namespace
 
+#ifdef SMX_ROLLOUT_TIMING
+// timing builds only (not declared in include/surreal_amd.h): where the timestamps go ([workgroups][16] int64)
+extern "C" void smx_rollout_debug_tbuf(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rtbuf_dev), &p, sizeof(p)); }
+#endif
+
 extern "C" int32_t smx_synth_rollout_supported(int32_t D, int32_t H1, int32_t H2, int32_t A) {
     if (!(D > 0 && H1 > 0 && H2 > 0 && A > 0 && A <= RMAX_A && H1 % 4 == 0 && H2 % 4 == 0)) return 0;
-    if (!(H1 <= 16 * NWV * TG * 2 && H2 <= 16 * NWV * TG * 2)) return 0;
+    if (!(H1 <= 640 && H2 <= 640 && D <= 64 * RKV)) return 0;
     RollArgs G;
     memset(&G, 0, sizeof(G));
     G.D = D; G.H1 = H1; G.H2 = H2; G.A = A;
@@ -263,7 +319,7 @@ extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t 
         attr_set = true;
     }
     const int blocks = (a->n + ER - 1) / ER;
-    hipLaunchKernelGGL(rollout_kernel, dim3(blocks), dim3(NTH), lds, smx_s(stream), G);
+    hipLaunchKernelGGL(rollout_kernel, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
