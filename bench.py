@@ -278,18 +278,39 @@ def secondary_ddpg(steps=200):
             'what': 'uniform sample of 512 out of 1e6 device-resident rows + DDPGLearner.learn'}
 
 
-def secondary_pipeline(actors):
+def secondary_pipeline(actors, overlap=False):
     """the whole on-device loop of one GPU (scripts/bench_pipeline.py): actors acting under the current policy on the
     synthetic environment -> window cut -> FIFO -> learn, 1024 sub-trajectories per learn"""
     sys.path.insert(0, os.path.join(ROOT, 'scripts'))
     import bench_pipeline
-    r = bench_pipeline.run_pipeline(actors=actors, iters=5, warmup=2, graph=True, fused_step=True)
+    r = bench_pipeline.run_pipeline(actors=actors, iters=5, warmup=2, graph=True, fused_step=True, overlap=overlap)
+    out = {'env_steps_per_s': r['value'], 'ms_per_iteration': r['ms_per_iteration'],
+           'actors': actors, 'n_step': 128, 'learns_per_rollout': r['config']['learns_per_rollout'],
+           'what': 'act: ONE launch per rollout (smx_synth_rollout_f32: a workgroup owns 16 actors through all 128 steps '
+                   '-- z-filter, the three policy layers on FP32 MFMA, sample, env step, record) + moving-window cut into '
+                   'the FIFO table + pop + PPOLearner.learn'}
+    if overlap:
+        out['what'] += '; rollout k + 1 runs on a second stream while learn k runs (actors one rollout ahead, as ' \
+                       'surreal\'s asynchronous agents are)'
+    else:
+        out.update(rollout_env_steps_per_s=r['rollout_env_steps_per_s'], stage_ms=r['stage_ms_synchronised'])
+    return out
+
+
+def secondary_pixel_pipeline():
+    """configs[3]'s shapes as an on-device loop: 256 actors x 32 steps, every actor with a 3 x 84 x 84 uint8 camera
+    rendered and stored once per step on the device, the CNN + LSTM policy acting on it (one batched act per step),
+    windows (+ the LSTM state at their first step) cut on the device, FIFO, PPOLearner.learn"""
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import bench_pipeline
+    r = bench_pipeline.run_pipeline(actors=256, steps=32, obs_dim=32, action_dim=8, iters=3, warmup=1, graph=False,
+                                    fused_step=True, learn_batch=256, pixel=(3, 84, 84), frame_stacks=1, rnn=True)
     return {'env_steps_per_s': r['value'], 'ms_per_iteration': r['ms_per_iteration'],
             'rollout_env_steps_per_s': r['rollout_env_steps_per_s'], 'stage_ms': r['stage_ms_synchronised'],
-            'actors': actors, 'n_step': 128, 'learns_per_rollout': r['config']['learns_per_rollout'],
-            'what': 'act: ONE launch per rollout (smx_synth_rollout_f32: a workgroup owns 16 actors through all 128 steps '
-                    '-- z-filter, the three policy layers on FP32 MFMA, sample, env step, record) + moving-window cut into '
-                    'the FIFO table + pop + PPOLearner.learn'}
+            'actors': 256, 'n_step': 32, 'policy': 'cnn+lstm100(H=5)+mlp',
+            'what': 'device camera (smx_synth_frame_u8) + frame stacking gather (smx_frame_stack_u8) + batched CNN + LSTM '
+                    'act per step + env step launch; window cut incl. uint8 frames and the LSTM state at each window\'s '
+                    'first step; FIFO (uint8 tables); PPOLearner.learn'}
 
 
 def secondaries():
@@ -298,6 +319,10 @@ def secondaries():
             ('on-device loop, 1024 actors x 128 steps (act + env step + windows + FIFO + learn)',
              lambda: secondary_pipeline(1024)),
             ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout', lambda: secondary_pipeline(4096)),
+            ('on-device loop, 1024 actors x 128 steps, actors one rollout ahead of the learner (two streams)',
+             lambda: secondary_pipeline(1024, overlap=True)),
+            ('configs[3] on-device loop: 256 actors x 32 steps, 3x84x84 uint8 camera + 32-d state, CNN + LSTM policy',
+             secondary_pixel_pipeline),
             ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda: secondary_ppo(64, 128, 17, 6, False)),
             ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
              lambda: secondary_ppo(64, 128, 17, 6, True)),

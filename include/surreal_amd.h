@@ -589,6 +589,23 @@ int smx_window_emit_f32(const float* src, int32_t actors, int32_t T, int32_t wid
 int smx_window_emit_bytes(const void* src, int32_t actors, int32_t T, int64_t row_bytes, int32_t start,
                           int32_t n_step, int32_t stride, int32_t W, void* dst, smx_stream_t stream);
 
+/* --- "obs stacking" (FrameStackWrapper, surreal/env/wrapper.py:407-472) over a device-resident rollout -----------
+ * frames [actors, R, frame_bytes] holds ONE raw camera frame per step (row 0: the frame after reset).  The stacked
+ * observation of row s is the last n_stack frames on the channel axis, oldest first; a reset fills the history with
+ * the first frame:   stacked(a, s)[i] = frames[a, max(s - (n_stack - 1) + i, first(a, s))],   0 <= i < n_stack,
+ * first(a, s) = episode_first ? episode_first[a*R + s] : 0 (the row at which the episode that row s belongs to began).
+ * Emitted as W moving windows of n_step rows (smx_window_emit_bytes' arithmetic) in the same gather:
+ *   dst[(a*W + w), j, i, :] = stacked(a, start + w*stride + j)[i]      dst: [actors*W, n_step, n_stack, frame_bytes]
+ * (W = 1, n_step = 1, start = t: what every actor's policy sees at step t.)  The raw frames are stored once; the
+ * n_stack-fold copy of every frame that stacking on the host keeps per step is never made. */
+int smx_frame_stack_u8(const void* frames, int32_t actors, int32_t R, int64_t frame_bytes, int32_t n_stack,
+                       const int32_t* episode_first, int32_t start, int32_t n_step, int32_t stride, int32_t W,
+                       void* dst, smx_stream_t stream);
+/* the synthetic environment's camera (no reference counterpart: the reference renders MuJoCo): for every actor a,
+ * dst[a*ld_dst + (c, y, x)] = (37 c + 5 y + 11 x + 3 t + (int)(100 |s0[a*ld_s0]|)) % 256, uint8 [C, H, W]. */
+int smx_synth_frame_u8(const float* s0, int64_t ld_s0, int32_t n, int32_t C, int32_t H, int32_t W, int32_t t,
+                       void* dst, int64_t ld_dst, smx_stream_t stream);
+
 /* --- synthetic vectorised environment step ("batched vectorised env stepping") --------
  * There is no reference counterpart (the reference steps MuJoCo simulators one process per
  * agent, surreal/agent/base.py:244-271); this is the synthetic stand-in BASELINE.json names,

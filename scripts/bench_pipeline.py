@@ -26,11 +26,12 @@ sys.path.insert(0, ROOT)
 
 
 def run_pipeline(actors=1024, steps=128, obs_dim=376, action_dim=17, iters=10, warmup=3, graph=True, fused_step=True,
-                 copies=False, cpu_double=False, learn_batch=1024):
+                 copies=False, cpu_double=False, learn_batch=1024, pixel=None, frame_stacks=1, rnn=False, overlap=False):
     """-> the result dict main() prints (also called by bench.py for its `secondary` entry)"""
     args = argparse.Namespace(actors=actors, steps=steps, obs_dim=obs_dim, action_dim=action_dim, iters=iters,
                               warmup=warmup, graph=graph, fused_step=fused_step, copies=copies,
-                              cpu_double=cpu_double, learn_batch=learn_batch)
+                              cpu_double=cpu_double, learn_batch=learn_batch, pixel=pixel, frame_stacks=frame_stacks,
+                              rnn=rnn, overlap=overlap)
     return _run(args)
 
 
@@ -48,6 +49,13 @@ def main():
     ap.add_argument('--copies', action='store_true', help='insert / pop through copies (no table views)')
     ap.add_argument('--cpu-double', action='store_true', help='dry run on the CPU test double')
     ap.add_argument('--learn-batch', type=int, default=1024, help='sub-trajectories per learner iteration')
+    ap.add_argument('--pixel', type=int, nargs=3, default=None, metavar=('C', 'H', 'W'),
+                    help='camera frames (uint8) next to the low-dim state: the CNN-stem policy (configs[3]: 3 84 84)')
+    ap.add_argument('--frame-stacks', type=int, default=1, help='frames the policy sees, stacked on the channel axis')
+    ap.add_argument('--rnn', action='store_true', help='LSTM-stem policy (the reference default)')
+    ap.add_argument('--overlap', action='store_true',
+                    help='actors one rollout ahead of the learner: rollout k + 1 on a second stream while learn k runs '
+                         '(how the reference runs: agents keep acting on the parameters they last fetched)')
     args = ap.parse_args()
     print(json.dumps(_run(args)), flush=True)
 
@@ -68,16 +76,19 @@ def _run(args):
     assert n % LB == 0, 'actors must be a multiple of the learner batch'
     lc = ppo_learner_config()
     lc.algo.n_step, lc.algo.stride = T, T
-    lc.algo.rnn.if_rnn_policy = False
+    lc.algo.rnn.if_rnn_policy = bool(args.rnn)
+    stem = bool(args.rnn) or args.pixel is not None
     lc.algo.consts.kl_target = 1e9                      # no early exit: every learn does 10 + 10 epochs
     lc.replay.batch_size, lc.replay.memory_size = LB, 2 * n
-    ec, sc = ppo_env_config(D, A), ppo_session_config()
+    cam = (args.frame_stacks * args.pixel[0], args.pixel[1], args.pixel[2]) if args.pixel else None   # what the policy sees
+    ec, sc = ppo_env_config(D, A, pixel=cam), ppo_session_config()
     learner = PPOLearner(lc, ec, sc)
     agent = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
     agent.attach_learner(learner)
     agent.fetch_parameter()
     replay = FIFOReplay(lc, ec, sc)
-    venv = SyntheticVecEnv(n, D, A, episode_len=T)
+    venv = SyntheticVecEnv(n, D, A, episode_len=T, pixel=tuple(args.pixel) if args.pixel else None,
+                           frame_stacks=args.frame_stacks)
     dev = venv.device
     sync = torch.cuda.synchronize if str(dev).startswith('cuda') else (lambda: None)
 
@@ -106,11 +117,8 @@ def _run(args):
         else:
             rollout_body()
 
-    def to_batch(f):
-        return {'obs': {'low_dim': {'flat_inputs': f['obs']}},
-                'obs_next': {'low_dim': {'flat_inputs': f['obs_next']}},
-                'actions': f['actions'], 'rewards': f['rewards'], 'dones': f['dones'],
-                'persistent_infos': [f['pds']], 'onetime_infos': None}
+    to_batch = venv.to_batch
+    use_graph = bool(args.graph) and not stem        # (the stem path allocates per step: eager launches)
 
     def iteration(times=None):
         t0 = time.perf_counter()
@@ -118,7 +126,7 @@ def _run(args):
         if times is not None:
             sync()
         t1 = time.perf_counter()
-        slots = None if args.copies else replay.reserve_batch(n, venv.window_shapes(T))
+        slots = None if (args.copies or stem) else replay.reserve_batch(n, venv.window_shapes(T))
         if slots is not None:                  # windows are cut straight into the FIFO table
             venv.emit_windows(T, T, out=slots)
             replay.commit_batch(n)
@@ -143,7 +151,7 @@ def _run(args):
             times.append((t1 - t0, t2 - t1, t3 - t0 - (t1 - t0) - (t2 - t1)))
 
     iteration()
-    if args.graph and not args.cpu_double:
+    if use_graph and not args.cpu_double:
         import gc
         sync()
         venv.reset()
@@ -165,6 +173,32 @@ def _run(args):
             graph = g
         finally:
             gc.enable()
+    if args.overlap and not args.cpu_double:
+        # actors one rollout ahead of the learner: while learn(k) runs on the main stream, rollout k + 1 runs on a
+        # second one under the parameters the agent fetched last (surreal's agents act asynchronously in the same way,
+        # agent/base.py:182-198); the window cut of rollout k sits between the two (it reads the rollout tables)
+        side = torch.cuda.Stream()
+        sequential = iteration
+
+        def iteration(times=None):                  # noqa: F811
+            main_s = torch.cuda.current_stream()
+            slots = None if (args.copies or stem) else replay.reserve_batch(n, venv.window_shapes(T))
+            if slots is not None:
+                venv.emit_windows(T, T, out=slots)
+                replay.commit_batch(n)
+            else:
+                replay.insert_batch(venv.emit_windows(T, T))
+            side.wait_stream(main_s)
+            with torch.cuda.stream(side):
+                rollout()
+            for _ in range(n // LB):
+                learner.learn(to_batch(replay.sample_batch(LB, copy=bool(args.copies))))
+            main_s.wait_stream(side)
+            agent.fetch_parameter()
+            if times is not None:
+                sync()
+                times.append((0.0, 0.0, 0.0))
+        rollout()                                   # rollout 0: the pipeline's fill
     for _ in range(args.warmup):
         iteration()
     sync()
@@ -181,7 +215,8 @@ def _run(args):
            'value': n * T / whole, 'ms_per_iteration': whole * 1e3,
            'config': {'actors': n, 'steps_per_rollout': T, 'obs_dim': D, 'action_dim': A, 'learn_batch': LB,
                       'learns_per_rollout': n // LB, 'rollout_graph': graph is not None,
-                      'fused_step': bool(args.fused_step)},
+                      'fused_step': bool(args.fused_step), 'overlap': bool(args.overlap), 'rnn': bool(args.rnn),
+                      'pixel': list(args.pixel) if args.pixel else None, 'frame_stacks': args.frame_stacks},
            'stage_ms_synchronised': {'rollout': st[0] * 1e3, 'windows+fifo': st[1] * 1e3, 'learn': st[2] * 1e3},
            'rollout_env_steps_per_s': n * T / st[0]}
     return out

@@ -254,6 +254,8 @@ _SIGS = {
     'smx_col2im_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  _P, _P, _P]),
     'smx_flatten_order_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'smx_frame_stack_u8': (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'smx_synth_frame_u8': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     'smx_synth_rollout_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_synth_rollout_f32': (c_int32, [POINTER(SynthRollout), _P]),
     'smx_xchg_bytes': (c_int64, [c_int64, c_int32]),

@@ -170,6 +170,47 @@ __global__ __launch_bounds__(256) void window_emit_bytes_kernel(const unsigned c
                     [](long i) { return i; });
 }
 
+// "obs stacking" (FrameStackWrapper, surreal/env/wrapper.py:407-472) as index arithmetic over the raw frames of a
+// device-resident rollout (one frame per step, row 0 = the frame after reset): the observation of row s is the last
+// n_stack frames on the channel axis, oldest first, and a reset fills the history with the first frame --
+//   stacked(s)[i] = frames[max(s - (n_stack - 1) + i, first(s))]
+// -- cut into W moving windows of n_step rows in the same gather (window_emit's arithmetic).
+__global__ __launch_bounds__(256) void frame_stack_kernel(const unsigned char* __restrict__ src, int actors, int R,
+                                                          long frame_bytes, int n_stack,
+                                                          const int* __restrict__ first, int start, int n_step,
+                                                          int stride, int W, unsigned char* __restrict__ dst, int gran) {
+    const long n = (long)actors * W * n_step * n_stack;
+    copy_rows_bytes(src, dst, n, frame_bytes, gran,
+                    [=](long i) {
+                        const long q = i / n_stack;
+                        const int ii = (int)(i - q * n_stack);
+                        const long jw = q / n_step;
+                        const int j = (int)(q - jw * n_step);
+                        const long a = jw / W;
+                        const int w = (int)(jw - a * W);
+                        const int sidx = start + w * stride + j;
+                        const int lo = first ? first[a * R + sidx] : 0;
+                        int f = sidx - (n_stack - 1) + ii;
+                        f = f < lo ? lo : f;
+                        return a * R + f;
+                    },
+                    [](long i) { return i; });
+}
+
+// the synthetic camera (surreal_amd.env.SyntheticEnv._frame): frame[c, y, x] = (37 c + 5 y + 11 x + 3 t +
+// int(100 |s0|)) % 256 for every actor, s0 = the first state component the frame belongs to
+__global__ __launch_bounds__(256) void synth_frame_kernel(const float* __restrict__ s0, long ld_s0, int n, int C, int H,
+                                                          int Wd, int t, unsigned char* __restrict__ dst, long ld_dst) {
+    const long per = (long)C * H * Wd;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)n * per) return;
+    const long a = i / per;
+    const int e = (int)(i - a * per);
+    const int c = e / (H * Wd), yx = e - c * (H * Wd), y = yx / Wd, x = yx - y * Wd;
+    const int shift = 3 * t + (int)(100.0 * (double)fabsf(s0[a * ld_s0]));
+    dst[a * ld_dst + e] = (unsigned char)((37 * c + 5 * y + 11 * x + shift) % 256);
+}
+
 // one thread per (actor, k); the reward needs the whole action row: lanes k < 1 compute it
 __global__ __launch_bounds__(256) void synth_env_step_kernel(
     float* __restrict__ state, const float* __restrict__ init_state,
@@ -450,6 +491,31 @@ extern "C" int smx_window_emit_bytes(const void* src, int32_t actors, int32_t T,
     hipLaunchKernelGGL(window_emit_bytes_kernel, dim3(row_blocks_bytes(n, row_bytes)), dim3(256), 0, smx_s(stream),
                        (const unsigned char*)src, actors, T, (long)row_bytes, start, n_step, stride, W,
                        (unsigned char*)dst, byte_gran(src, dst, row_bytes));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_frame_stack_u8(const void* frames, int32_t actors, int32_t R, int64_t frame_bytes, int32_t n_stack,
+                                  const int32_t* episode_first, int32_t start, int32_t n_step, int32_t stride, int32_t W,
+                                  void* dst, smx_stream_t stream) {
+    SMX_REQUIRE(frames && dst, SMX_E_NULL);
+    SMX_REQUIRE(actors > 0 && R > 0 && frame_bytes > 0 && n_stack > 0 && n_step > 0 && stride > 0 && W > 0 && start >= 0 &&
+                    start + (long)(W - 1) * stride + n_step <= R, SMX_E_SHAPE);
+    const long n = (long)actors * W * n_step * n_stack;
+    hipLaunchKernelGGL(frame_stack_kernel, dim3(row_blocks_bytes(n, frame_bytes)), dim3(256), 0, smx_s(stream),
+                       (const unsigned char*)frames, actors, R, (long)frame_bytes, n_stack, (const int*)episode_first, start,
+                       n_step, stride, W, (unsigned char*)dst, byte_gran(frames, dst, frame_bytes));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_synth_frame_u8(const float* s0, int64_t ld_s0, int32_t n, int32_t C, int32_t H, int32_t W, int32_t t,
+                                  void* dst, int64_t ld_dst, smx_stream_t stream) {
+    SMX_REQUIRE(s0 && dst, SMX_E_NULL);
+    SMX_REQUIRE(n > 0 && C > 0 && H > 0 && W > 0 && t >= 0 && ld_s0 > 0 && ld_dst >= (int64_t)C * H * W, SMX_E_SHAPE);
+    const long total = (long)n * C * H * W;
+    hipLaunchKernelGGL(synth_frame_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, smx_s(stream), s0,
+                       (long)ld_s0, n, C, H, W, t, (unsigned char*)dst, (long)ld_dst);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -1,4 +1,4 @@
-from .base import Env, Wrapper, MaxStepWrapper, FrameStackWrapper
+from .base import Env, Wrapper, MaxStepWrapper, FrameStackWrapper, stack_sources
 from .exp_sender_wrapper import (ExpSenderWrapperBase, ExpSenderWrapperSSAR,
                                  ExpSenderWrapperSSARNStepBootstrap,
                                  ExpSenderWrapperMultiStepMovingWindowWithInfo)

@@ -6,7 +6,6 @@ underscored methods.  The simulators (Gym / Robosuite / dm_control) need MuJoCo 
 adapters and the observation transforms live in adapters.py, the episode monitors in monitor.py.
 """
 import collections
-from collections import deque
 
 import numpy as np
 
@@ -83,64 +82,76 @@ class Wrapper(Env):
         return self.env.unwrapped
 
 
+def stack_sources(step, n_stack, first=0):
+    """Which raw frames make up the stacked observation of `step` (FrameStackWrapper, surreal/env/wrapper.py:407-472):
+    the last `n_stack` frames, oldest first, where the frames "before" the episode's first one are that first frame
+    (a reset fills the history with it).  The single statement of the rule: the host wrapper below and the device
+    gather (smx_frame_stack_u8 over a rollout's raw frames) both evaluate it."""
+    return [max(step - (n_stack - 1) + i, first) for i in range(n_stack)]
+
+
 class MaxStepWrapper(Wrapper):
-    """forces done after `max_steps` steps (wrapper.py:142-162)"""
+    """an episode ends after at most `max_steps` steps (wrapper.py:142-162): a budget that reset() refills and
+    every step() draws on; `done` is forced once it is spent"""
 
     def __init__(self, env, max_steps):
         super().__init__(env)
         if max_steps <= 0:
             raise ValueError('MaxStepWrapper received max_steps')
         self.max_steps = max_steps
-        self.current_step = 0
+        self._left = max_steps
+
+    @property
+    def current_step(self):
+        return self.max_steps - self._left
 
     def _reset(self):
-        self.current_step = 0
+        self._left = self.max_steps
         return self.env.reset()
 
     def _step(self, action):
-        self.current_step += 1
+        self._left -= 1
         observation, reward, done, info = self.env.step(action)
-        if self.current_step >= self.max_steps:
-            done = True
-        return observation, reward, done, info
+        return observation, reward, bool(done) or self._left <= 0, info
 
 
 class FrameStackWrapper(Wrapper):
-    """"obs stacking" for pixel observations (wrapper.py:407-472): the last `frame_stacks`
-    frames concatenated on the channel axis; reset fills the history with the first frame."""
+    """"obs stacking" for pixel observations (wrapper.py:407-472): the observation carries the last
+    `frame_stacks` camera frames -- concatenated on the channel axis, or as a list when
+    ``frame_stack_concatenate_on_env`` is off.  Stated as index arithmetic: the episode's raw observations
+    are kept by step number (only the last `n` are retained) and the stacked observation of step j is
+    frames ``stack_sources(j, n)``; the device tier runs the same rule as a gather over the rollout's raw
+    frames (SyntheticVecEnv, smx_frame_stack_u8)."""
 
     def __init__(self, env, env_config):
         super().__init__(env)
         self.n = env_config.frame_stacks
         self.frame_stack_concatenate_on_env = env_config.frame_stack_concatenate_on_env
-        self._history = deque(maxlen=self.n)
+        self._raw = {}               # step number within the episode -> raw observation (last n kept)
+        self._j = 0
 
-    def _stacked_observation(self, obs):
+    def _observe(self, obs):
+        self._raw[self._j] = obs
+        self._raw.pop(self._j - self.n, None)
+        picked = [self._raw[f] for f in stack_sources(self._j, self.n)]
         pixels = collections.OrderedDict()
         for key in obs['pixel']:
-            frames = [h['pixel'][key] for h in self._history]
-            pixels[key] = np.concatenate(frames, axis=0) if self.frame_stack_concatenate_on_env \
-                else frames
-        out = collections.OrderedDict()
-        for key in obs:
-            out[key] = pixels if key == 'pixel' else obs[key]
-        return out
+            frames = [h['pixel'][key] for h in picked]
+            pixels[key] = np.concatenate(frames, axis=0) if self.frame_stack_concatenate_on_env else frames
+        return collections.OrderedDict((k, pixels if k == 'pixel' else v) for k, v in obs.items())
 
     def _step(self, action):
         obs_next, reward, done, info = self.env.step(action)
-        self._history.append(obs_next)
-        return self._stacked_observation(obs_next), reward, done, info
+        self._j += 1
+        return self._observe(obs_next), reward, done, info
 
     def _reset(self):
         obs, info = self.env.reset()
-        for _ in range(self.n):
-            self._history.append(obs)
-        return self._stacked_observation(obs), info
+        self._raw, self._j = {}, 0
+        return self._observe(obs), info
 
     def observation_spec(self):
         spec = self.env.observation_spec()
-        if 'pixel' in spec:
-            for key in spec['pixel']:
-                C, H, W = spec['pixel'][key]
-                spec['pixel'][key] = (C * self.n, H, W)
+        for key, (C, H, W) in list(spec.get('pixel', {}).items()):
+            spec['pixel'][key] = (C * self.n, H, W)
         return spec

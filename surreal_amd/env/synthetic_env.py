@@ -87,10 +87,16 @@ class SyntheticVecEnv(object):
     """n actors on one GPU; rollouts of T steps recorded on the device"""
 
     def __init__(self, n_actors, obs_dim, action_dim, episode_len=200, seeds=None, device=None,
-                 kernels=None):
+                 kernels=None, pixel=None, frame_stacks=1):
+        """pixel = (C, H, W): every actor also has a camera (SyntheticEnv's frame: a pattern shifted by the step
+        count and the first state component), rendered on the device; frame_stacks = n: the policy observes the
+        last n frames on the channel axis (FrameStackWrapper's rule, surreal/env/wrapper.py:407-472) -- the rollout
+        stores ONE raw uint8 frame per step and the stacking is a gather (smx_frame_stack_u8)."""
         self.K = kernels or KN.default_kernels()
         self.device = device or KN.default_device()
         self.n, self.D, self.A, self.episode_len = n_actors, obs_dim, action_dim, episode_len
+        self.pixel = tuple(pixel) if pixel is not None else None
+        self.frame_stacks = int(frame_stacks) if pixel is not None else 1
         seeds = list(range(n_actors)) if seeds is None else list(seeds)
         init = np.stack([np.random.RandomState(s).randn(obs_dim).astype(np.float32) for s in seeds])
         self.init_state = torch.as_tensor(init).to(self.device)
@@ -119,6 +125,21 @@ class SyntheticVecEnv(object):
         if info_width:
             self.rolls['pds'] = f(self.n, R, info_width)
         self.slot = 0
+        if self.pixel is not None:
+            # raw camera frames, one per step, uint8 [actors, T + 1, C, H, W]; row 0 = the frame after reset
+            self.frames = torch.zeros((self.n, R) + self.pixel, device=self.device, dtype=torch.uint8)
+            self.K.synth_frames(self.state[:, 0], self.t, self.frames[:, 0])
+
+    def observation(self):
+        """what the policies see now: the state [n, D], or with a camera the nested observation
+        {'pixel': {'camera0': uint8 [n, frame_stacks * C, H, W]}, 'low_dim': {'flat_inputs': state}}"""
+        if self.pixel is None:
+            return self.state
+        C, H, W = self.pixel
+        stacked = torch.empty(self.n, self.frame_stacks * C, H, W, device=self.device, dtype=torch.uint8)
+        self.K.frame_stack(self.frames, self.frame_stacks, self.slot, 1, 1, 1, stacked)
+        return collections.OrderedDict(pixel=collections.OrderedDict(camera0=stacked),
+                                       low_dim=collections.OrderedDict(flat_inputs=self.state))
 
     def step(self, actions, pds=None):
         """actions [n, A] on the device -> next observation [n, D] (the state tensor)"""
@@ -129,6 +150,10 @@ class SyntheticVecEnv(object):
             if pds is not None and pds.data_ptr() != r['pds'][:, self.slot].data_ptr():
                 r['pds'][:, self.slot] = pds         # (an agent may have written the slot in place)
             self.slot += 1
+            if self.pixel is not None:
+                # the camera frame of the observation AFTER this step (the terminal one when the episode ends here):
+                # rendered from the recorded next observation, at the step count it belongs to
+                self.K.synth_frames(r['obs'][:, self.slot, 0], self.t + 1, self.frames[:, self.slot])
         else:
             self.K.synth_env_step(self.state, self.init_state, actions, self.t, self.episode_len, 0,
                                   None, None, None, None)
@@ -149,6 +174,8 @@ class SyntheticVecEnv(object):
         deterministic = agent.agent_mode in ('eval_deterministic', 'eval_deterministic_local')
         if eps is None and not deterministic:
             eps = torch.randn(T, n, self.A, device=self.device)
+        if agent.rnn_config.if_rnn_policy or agent.model.if_pixel:
+            return self._rollout_stem(agent, None if deterministic else eps)
         noise = agent.batch_noise(n).view(-1)
         zf = agent.model.z_filter if agent.use_z_filter else None
         log_var = agent.model.log_var.view(-1)
@@ -198,6 +225,26 @@ class SyntheticVecEnv(object):
             self.slot += 1
             self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
 
+    def _rollout_stem(self, agent, eps):
+        """policies with an LSTM and / or CNN stem: one batched act per step (PPOAgent.act_batch: the stem and the
+        MLP for all actors at once) on the stacked observation, then the step launch; the LSTM state every actor
+        held BEFORE each step is recorded (what the window that starts there carries as onetime_infos,
+        ppo_agent.py:133-135)"""
+        T, n = self.T, self.n
+        rnn = agent.rnn_config.if_rnn_policy
+        agent.reset_batch()                      # a rollout starts at an episode boundary: zero state
+        if rnn and 'cells' not in self.rolls:
+            nl, F = agent.rnn_config.rnn_layer, agent.rnn_config.rnn_hidden
+            self.rolls['cells'] = torch.zeros(n, T + 1, 2, nl, F, device=self.device)
+        for t in range(T):
+            a, pd = agent.act_batch(self.observation(), eps=None if eps is None else eps[t],
+                                    out_pd=self.rolls['pds'][:, self.slot])
+            if rnn:
+                h, c = agent.batch_cells_before                   # (layers, n, hidden) each
+                self.rolls['cells'][:, self.slot, 0].copy_(h.permute(1, 0, 2))
+                self.rolls['cells'][:, self.slot, 1].copy_(c.permute(1, 0, 2))
+            self.step(a, pds=pd)
+
     def rollout_reference(self, agent, eps):
         """the same rollout with TWO launches per step out of the kernels the persistent one is built from: the
         row-block forward (smx_epoch_forward_f32: the means) and the head + step launch.  Bit-identical to
@@ -228,6 +275,10 @@ class SyntheticVecEnv(object):
                'rewards': (n_step,), 'dones': (n_step,)}
         if self.rolls is not None and 'pds' in self.rolls:
             shp['pds'] = (n_step, self.rolls['pds'].shape[2])
+        if self.pixel is not None:
+            C, H, Wd = self.pixel
+            shp['pixel'] = (n_step, self.frame_stacks * C, H, Wd)
+            shp['pixel_next'] = (1, self.frame_stacks * C, H, Wd)
         return shp
 
     def emit_windows(self, n_step, stride, out=None):
@@ -263,4 +314,30 @@ class SyntheticVecEnv(object):
             if 'pds' not in out:
                 out['pds'] = f(n * W, n_step, r['pds'].shape[2])
             K.window_emit(r['pds'], 0, n_step, stride, W, out['pds'])
+        if self.pixel is not None:
+            # the windows' camera observations: window cut and frame stacking in one gather over the raw frames
+            C, H, Wd = self.pixel
+            ns = self.frame_stacks
+            u8 = lambda *s: torch.empty(*s, device=self.device, dtype=torch.uint8)  # noqa: E731
+            if 'pixel' not in out:
+                out['pixel'], out['pixel_next'] = u8(n * W, n_step, ns * C, H, Wd), u8(n * W, 1, ns * C, H, Wd)
+            K.frame_stack(self.frames, ns, 0, n_step, stride, W, out['pixel'])
+            K.frame_stack(self.frames, ns, n_step, 1, stride, W, out['pixel_next'])
+        if 'cells' in r:
+            # onetime_infos: the LSTM state at the FIRST step of every window (exp_sender_wrapper.py:236-242)
+            cw = r['cells'][0, 0].numel()
+            cells = f(n * W, 1, cw)
+            K.window_emit(r['cells'].view(n, T + 1, cw), 0, 1, stride, W, cells)
+            out['cells'] = cells.view((n * W,) + tuple(r['cells'].shape[2:]))
         return out
+
+    def to_batch(self, f):
+        """emit_windows' fields -> the learner's batch contract (MultistepAggregatorWithInfo, aggregator.py:106-262)"""
+        obs = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=f['obs']))
+        nxt = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=f['obs_next']))
+        if 'pixel' in f:
+            obs['pixel'] = collections.OrderedDict(camera0=f['pixel'])
+            nxt['pixel'] = collections.OrderedDict(camera0=f['pixel_next'])
+        once = [f['cells'][:, 0], f['cells'][:, 1]] if 'cells' in f else None
+        return {'obs': obs, 'obs_next': nxt, 'actions': f['actions'], 'rewards': f['rewards'], 'dones': f['dones'],
+                'persistent_infos': [f['pds']], 'onetime_infos': once}

@@ -464,6 +464,23 @@ class HipKernels(object):
             L.call('smx_window_emit_bytes', L.ptr(src), actors, T, width * src.element_size(), start, n_step,
                    stride, W, L.ptr(dst), self._st())
 
+    def frame_stack(self, frames, n_stack, start, n_step, stride, W, dst, episode_first=None):
+        """frames [actors, R, C, H, W] uint8 (one raw frame per step) -> dst [actors*W, n_step, n_stack*C, H, W]: the
+        last n_stack frames on the channel axis, oldest first, history filled with the first frame after a reset"""
+        actors, R = frames.shape[:2]
+        fb = frames[0, 0].numel() * frames.element_size()
+        assert frames.is_contiguous() and dst.is_contiguous() and frames.dtype == dst.dtype
+        assert dst.numel() == actors * W * n_step * n_stack * frames[0, 0].numel()
+        L.call('smx_frame_stack_u8', L.ptr(frames), actors, R, fb, int(n_stack), L.ptr(episode_first), int(start),
+               int(n_step), int(stride), int(W), L.ptr(dst), self._st())
+
+    def synth_frames(self, s0, t, dst):
+        """the synthetic camera for all actors: s0 [n] (strided view allowed), dst [n, C, H, W] uint8 (row-strided
+        view allowed: a rollout slot)"""
+        n, C, H, W = dst.shape
+        assert dst.dtype == torch.uint8 and dst[0].is_contiguous() and s0.dim() == 1
+        L.call('smx_synth_frame_u8', L.ptr(s0), s0.stride(0), n, C, H, W, int(t), L.ptr(dst), dst.stride(0), self._st())
+
     @staticmethod
     def _synth_act_step(state, init_state, mean, A, log_var, noise_scale, eps, t, episode_len, slot, rolls, zfilter,
                         xn_out):

@@ -304,6 +304,26 @@ class TorchCpuKernels(object):
     def reward_filter_partials(self):
         return 128
 
+    def frame_stack(self, frames, n_stack, start, n_step, stride, W, dst, episode_first=None):
+        actors, R = frames.shape[:2]
+        fr = frames.reshape(actors, R, -1)
+        out = dst.view(actors * W, n_step, n_stack, -1)
+        for a in range(actors):
+            for w in range(W):
+                for j in range(n_step):
+                    s_ = start + w * stride + j
+                    lo = int(episode_first[a, s_]) if episode_first is not None else 0
+                    for i in range(n_stack):
+                        out[a * W + w, j, i] = fr[a, max(s_ - (n_stack - 1) + i, lo)]
+
+    def synth_frames(self, s0, t, dst):
+        n, C, H, W = dst.shape
+        c, y, x = np.meshgrid(np.arange(C), np.arange(H), np.arange(W), indexing='ij')
+        base = torch.as_tensor(37 * c + 5 * y + 11 * x)
+        for a in range(n):
+            shift = 3 * int(t) + int(100 * abs(float(s0[a])))
+            dst[a] = ((base + shift) % 256).to(torch.uint8)
+
     def synth_rollout_supported(self, net):
         return False                 # the double walks the rollout step by step (SyntheticVecEnv's layered path)
 

@@ -152,3 +152,16 @@ def test_gpu_agent_through_the_pixel_robosuite_stack_cnn_policy_equals_oracle():
     # the stack really moves: the newest frame of step t is the oldest of step t + 2
     np.testing.assert_array_equal(seen[1][0]['pixel']['camera0'][2], seen[3][0]['pixel']['camera0'][0])
     assert windows and windows[0]['obs'][0]['pixel']['camera0'].dtype == np.uint8
+
+
+def test_device_camera_and_frame_stacking_match_host_wrapper_hip():
+    """"obs stacking" on the device (smx_synth_frame_u8 + smx_frame_stack_u8): raw uint8 frames rendered and stored once
+    per step, the policy's stacked observation and the stacked windows by one gather -- bit-exact against SyntheticEnv
+    under the host FrameStackWrapper (which tests/test_env_adapters.py pins to the reference's), incl. frames as wide as
+    configs[3]'s 3 x 84 x 84 and an odd row pitch (dword / byte lanes)"""
+    import pixel_env_cases as PC
+    from surreal_amd import kernels as KN
+    PC.check_device_camera_matches_host_framestack()
+    PC.check_device_camera_matches_host_framestack(n=3, D=5, A=2, pixel=(3, 84, 84), stacks=2, T=4, n_step=2, stride=1)
+    PC.check_device_camera_matches_host_framestack(n=2, D=5, A=2, pixel=(1, 9, 7), stacks=4, T=5, n_step=2, stride=2)
+    PC.check_frame_stack_with_resets_inside(KN.default_kernels(), 'cuda')

@@ -574,3 +574,11 @@ def test_ddpg_agent_parameter_noise_in_the_fetch_path(cpu_double):
     assert ag.fetch_parameter() and ag.param_noise.sigma != sigma0 and ag.param_noise.i == 0
     plain = DDPGAgent(ddpg_learner_config(), ec, sc, agent_id=1, agent_mode='training')
     assert plain.param_noise is None
+
+
+def test_device_camera_and_frame_stacking_match_host_wrapper(cpu_double):
+    """SyntheticVecEnv(pixel, frame_stacks) on the torch-CPU double == SyntheticEnv under FrameStackWrapper"""
+    import pixel_env_cases as PC
+    PC.check_device_camera_matches_host_framestack()
+    from surreal_amd import kernels as KN
+    PC.check_frame_stack_with_resets_inside(KN.default_kernels(), 'cpu')
