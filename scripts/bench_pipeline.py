@@ -218,7 +218,7 @@ def _run(args):
                       'fused_step': bool(args.fused_step), 'overlap': bool(args.overlap), 'rnn': bool(args.rnn),
                       'pixel': list(args.pixel) if args.pixel else None, 'frame_stacks': args.frame_stacks},
            'stage_ms_synchronised': {'rollout': st[0] * 1e3, 'windows+fifo': st[1] * 1e3, 'learn': st[2] * 1e3},
-           'rollout_env_steps_per_s': n * T / st[0]}
+           'rollout_env_steps_per_s': n * T / st[0] if st[0] > 0 else None}
     return out
 
 

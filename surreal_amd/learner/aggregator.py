@@ -20,7 +20,16 @@ import collections
 import numpy as np
 
 
-def _stack(seq, dtype=None):
+def _stack(seq, dtype=None, out=None):
+    """`out`: a preallocated array of the result's shape (e.g. a pinned staging buffer: PinnedBatchStager.host_views)
+    that receives the values in place -- the batch is then never materialised anywhere else on the host"""
+    if out is not None:
+        if len(seq) and isinstance(seq[0], (list, tuple)):          # [B][N] leaves -> one flat list
+            flat = [leaf for row in seq for leaf in row]
+            np.stack(flat, out=out.reshape((len(flat),) + out.shape[2:]), casting='unsafe')
+        else:
+            np.stack([np.asarray(x) for x in seq], out=out, casting='unsafe')
+        return out
     a = np.asarray(seq)
     if a.dtype == object:      # ragged input is a contract violation, not something to paper over
         raise ValueError('experiences have inconsistent shapes')
@@ -73,43 +82,51 @@ class MultistepAggregatorWithInfo(object):
         self.action_spec = action_spec
         self.obs_spec = obs_spec
 
-    def _batch_obs(self, per_exp_steps):
+    def _batch_obs(self, per_exp_steps, into=None):
         """per_exp_steps: list (B) of list (steps) of nested obs dicts -> dict of (B, steps, ...)"""
         out = collections.OrderedDict()
         for modality in self.obs_spec.keys():
             out[modality] = collections.OrderedDict()
             for key in self.obs_spec[modality].keys():
                 out[modality][key] = _stack(
-                    [[step[modality][key] for step in steps] for steps in per_exp_steps])
+                    [[step[modality][key] for step in steps] for steps in per_exp_steps],
+                    out=None if into is None else into[modality][key])
         return out
 
-    def _gather_action_infos(self, exp_list):
+    def _gather_action_infos(self, exp_list, into=None):
         """aggregator.py:223-262"""
         first = exp_list[0]
         onetime = persistent = None
+        o = (lambda name, i: None) if into is None else (lambda name, i: into[name][i])
         if len(first['onetime_infos']) > 0:
-            onetime = [_stack([exp['onetime_infos'][i] for exp in exp_list])
+            onetime = [_stack([exp['onetime_infos'][i] for exp in exp_list], out=o('onetime_infos', i))
                        for i in range(len(first['onetime_infos']))]
         if len(first['persistent_infos'][0]) > 0:
-            persistent = [_stack([[step[i] for step in exp['persistent_infos']] for exp in exp_list])
+            persistent = [_stack([[step[i] for step in exp['persistent_infos']] for exp in exp_list],
+                                 out=o('persistent_infos', i))
                           for i in range(len(first['persistent_infos'][0]))]
         return onetime, persistent
 
-    def aggregate(self, exp_list):
+    def aggregate(self, exp_list, out=None):
+        """out: a batch-shaped tree of preallocated arrays (PinnedBatchStager.host_views(slot)) that receives every
+        field in place -- experiences unpacked from the collector's chunks go straight into the pinned
+        struct-of-arrays staging the host-to-device copy reads (no intermediate batch on the host)"""
         if self.action_type != 'continuous':
             # the reference's discrete branch is broken (aggregator.py:172-173) -- continuous only
             raise NotImplementedError('action_spec unsupported ' + str(self.action_spec))
-        observations = self._batch_obs([exp['obs'] for exp in exp_list])
-        next_obs = self._batch_obs([[exp['obs_next']] for exp in exp_list])
-        onetime, persistent = self._gather_action_infos(exp_list)
+        g = (lambda k: None) if out is None else (lambda k: out[k])
+        observations = self._batch_obs([exp['obs'] for exp in exp_list], g('obs'))
+        next_obs = self._batch_obs([[exp['obs_next']] for exp in exp_list], g('obs_next'))
+        onetime, persistent = self._gather_action_infos(exp_list, out)
+        dones = _stack([exp['dones'] for exp in exp_list], out=g('dones'))
         return {
             'obs': observations,
             'obs_next': next_obs,
-            'actions': _stack([exp['actions'] for exp in exp_list]),
-            'rewards': _stack([exp['rewards'] for exp in exp_list]),
+            'actions': _stack([exp['actions'] for exp in exp_list], out=g('actions')),
+            'rewards': _stack([exp['rewards'] for exp in exp_list], out=g('rewards')),
             'persistent_infos': persistent,
             'onetime_infos': onetime,
-            'dones': _stack([exp['dones'] for exp in exp_list]).astype('float32'),
+            'dones': dones if out is not None else dones.astype('float32'),
         }
 
 

@@ -166,7 +166,40 @@ class Learner(metaclass=AutoInitializeMeta):
             return replay.sample(bs)
         self._data_source = pull
 
+    def start_prefetching(self, depth=2):
+        """Host-fed learners (experiences arriving in host memory): a background thread pulls and aggregates the next
+        batch into pinned struct-of-arrays staging and its host-to-device copy runs on a second stream UNDER the
+        current learn() (surreal_amd.distributed.LearnerDataPrefetcher + PinnedBatchStager; the reference's
+        LearnerDataPrefetcher, learner/base.py:102-110, data_fetcher.py:9-73).  fetch_batch() then hands out
+        device-resident batches from `depth` fixed address sets (one captured graph each)."""
+        from surreal_amd.distributed.data_fetcher import LearnerDataPrefetcher, PinnedBatchStager
+        if self._data_source is None:
+            raise RuntimeError('no data source attached: call attach_replay / set_data_source')
+        first = self.preprocess(self._as_attr(self._prefetcher_preprocess(self._data_source())))
+        device = getattr(self, 'device', 'cpu')
+        stager = PinnedBatchStager(first, depth=depth, device=device)
+        self.graph_input_sets = max(getattr(self, 'graph_input_sets', 1), depth)
+        src = self._data_source
+        self._prefetch_queue = LearnerDataPrefetcher(self.session_config, self.learner_config.replay.batch_size,
+                                                     worker_preprocess=self._prefetcher_preprocess,
+                                                     main_preprocess=lambda b: self.preprocess(self._as_attr(b)),
+                                                     source=lambda bs: src(), stager=stager)
+        # the batch that sized the staging is not lost: it goes through slot 0 first
+        stager.stage(first)
+        self._prefetch_queue.preprocess_queue.put(('slot', 0))
+        self._prefetch_queue.start()
+        return self._prefetch_queue
+
+    @staticmethod
+    def _as_attr(data):
+        return AttrDict(data) if isinstance(data, dict) and not isinstance(data, AttrDict) else data
+
     def fetch_batch(self):
+        if getattr(self, '_prefetch_queue', None) is not None:
+            t0 = time.time()
+            data = self._prefetch_queue.get()
+            self.fetch_time_s = time.time() - t0
+            return data
         if self._data_source is None:
             raise RuntimeError('no data source attached: call attach_replay / set_data_source')
         t0 = time.time()

@@ -1388,7 +1388,7 @@ class PPOLearner(Learner):
             # instead of re-capturing ~130 launches for every new address.
             key = tuple(t.data_ptr() for t in args)
             g = self._graphs.get(key)
-            if g is None and self._graphs:
+            if g is None and len(self._graphs) >= getattr(self, 'graph_input_sets', 1):
                 if getattr(ws, 'staged', None) is None:
                     ws.staged = tuple(torch.empty_like(t) for t in args)
                 for dst, src in zip(ws.staged, args):
@@ -1651,5 +1651,6 @@ class PPOLearner(Learner):
         return ['model', 'ref_target_model', 'actor_lr_scheduler', 'critic_lr_scheduler',
                 'current_iteration']
 
-    def _prefetcher_preprocess(self, batch):
-        return self.aggregator.aggregate(batch)
+    def _prefetcher_preprocess(self, batch, out=None):
+        return self.aggregator.aggregate(batch, out=out)
+    _prefetcher_preprocess.accepts_out = True       # (LearnerDataPrefetcher: aggregate straight into pinned staging)

@@ -175,3 +175,11 @@ def test_reference_chunk_to_device_learn_equals_reference_batch_and_oracle():
     """f2 against the oracle, on the HIP path (body and what it checks: tests/wire_cases.py)"""
     import wire_cases
     wire_cases.check_reference_chunk_to_learn(expect_cuda=True)
+
+
+def test_host_fed_learner_pinned_double_buffered_ingest():
+    """batches from host memory: aggregated in place into PINNED staging by the prefetch thread, copied to the device
+    on a second stream while the previous learn() runs, consumed from two fixed address sets (two captured graphs) --
+    bit-identical to feeding the same batches synchronously"""
+    import wire_cases
+    wire_cases.check_host_fed_learner(expect_cuda=True)

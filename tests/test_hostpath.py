@@ -582,3 +582,10 @@ def test_device_camera_and_frame_stacking_match_host_wrapper(cpu_double):
     PC.check_device_camera_matches_host_framestack()
     from surreal_amd import kernels as KN
     PC.check_frame_stack_with_resets_inside(KN.default_kernels(), 'cpu')
+
+
+def test_host_fed_learner_through_the_prefetcher(cpu_double):
+    """LearnerDataPrefetcher + PinnedBatchStager (host tier: plain memory, no copy stream): in-place aggregation into
+    the staging slots, slot hand-over, same results as synchronous feeding"""
+    import wire_cases
+    wire_cases.check_host_fed_learner(expect_cuda=False)
