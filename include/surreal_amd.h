@@ -126,6 +126,20 @@ int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, const float* 
                    int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
                    const float* relu_mask, const int32_t* stop_flag, smx_stream_t stream);
 
+/* Up to 9 INDEPENDENT dense problems in ONE launch -- the layers (or weight gradients) of one dependency level of an
+ * update, e.g. DDPG's target-actor, critic and actor first layers (surreal/learner/ddpg.py:244-352 issues them as
+ * separate ATen calls).  kind 0: C [M,N] = act(A . B^T + bias) (* (relu_mask > 0)), arguments as smx_linear_f32;
+ * kind 1: C = dW [M,N] = A^T . B with A = dZ [K rows, >= M] (stride lda), B = X [K rows, >= N] (stride ldb),
+ * dbias [M] = column sums of dZ (nullable), arguments as smx_linear_wgrad_f32. */
+typedef struct smx_linear_job {
+    int32_t kind, act;
+    const float* A; const float* B; const float* bias; const float* relu_mask;
+    float* C; float* dbias;
+    int32_t lda, ldb, ldc, a_kcontig, b_kcontig, M, N, K;
+    const int32_t* stop_flag;
+} smx_linear_job_t;
+int smx_linear_multi_f32(const smx_linear_job_t* jobs, int32_t njobs, smx_stream_t stream);
+
 /* Weight gradient of one dense layer: dW[M,N] = dZ^T . X, db[M] = column sums of dZ (db may be
  * NULL); dZ [rows, .] with row stride ldz, X [rows, .] with row stride ldx (what
  * loss.backward() produces for nn.Linear, ddpg.py:308,331). */

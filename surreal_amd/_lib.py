@@ -109,6 +109,14 @@ class PpoCombine(Structure):
                 ('reserved', c_int32)]
 
 
+class LinearJob(Structure):
+    """smx_linear_job_t"""
+    _fields_ = [('kind', c_int32), ('act', c_int32), ('A', c_void_p), ('B', c_void_p), ('bias', c_void_p),
+                ('relu_mask', c_void_p), ('C', c_void_p), ('dbias', c_void_p), ('lda', c_int32), ('ldb', c_int32),
+                ('ldc', c_int32), ('a_kcontig', c_int32), ('b_kcontig', c_int32), ('M', c_int32), ('N', c_int32),
+                ('K', c_int32), ('stop_flag', c_void_p)]
+
+
 class SynthRollout(Structure):
     """smx_synth_rollout_t"""
     _fields_ = [('net', POINTER(Mlp3)), ('packed', c_void_p), ('out_act', c_int32), ('n', c_int32),
@@ -254,6 +262,7 @@ _SIGS = {
     'smx_col2im_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  _P, _P, _P]),
     'smx_flatten_order_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'smx_linear_multi_f32': (c_int32, [POINTER(LinearJob), c_int32, _P]),
     'smx_frame_stack_u8': (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'smx_synth_frame_u8': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     'smx_synth_rollout_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),

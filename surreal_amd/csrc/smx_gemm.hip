@@ -575,6 +575,34 @@ extern "C" int smx_linear_f32(const float* A, int32_t lda, int32_t a_kcontig, co
     return launch_batch(G, smx_s(stream));
 }
 
+// Up to 9 INDEPENDENT dense problems in one launch (the latency of a short launch is paid once per dependency level
+// instead of once per layer): each job is either a layer  C = act(A . B^T + bias) [* (mask > 0)]  (kind 0, the
+// arguments of smx_linear_f32) or a weight gradient  dW = dZ^T . X, db = column sums of dZ  (kind 1, the arguments of
+// smx_linear_wgrad_f32: A = dZ, B = X, C = dW, dbias = db, M x N = dW's shape, K = rows).
+extern "C" int smx_linear_multi_f32(const smx_linear_job_t* jobs, int32_t njobs, smx_stream_t stream) {
+    SMX_REQUIRE(jobs, SMX_E_NULL);
+    SMX_REQUIRE(njobs >= 1 && njobs <= MAX_PROBS, SMX_E_SHAPE);
+    GemmBatch G;
+    G.n = njobs;
+    int base = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const smx_linear_job_t& j = jobs[k];
+        SMX_REQUIRE(j.A && j.B && j.C, SMX_E_NULL);
+        SMX_REQUIRE(j.M > 0 && j.N > 0 && j.K > 0 && j.lda > 0 && j.ldb > 0 && j.ldc >= j.N, SMX_E_SHAPE);
+        if (j.kind == 1) {
+            SMX_REQUIRE(j.lda >= j.M && j.ldb >= j.N, SMX_E_SHAPE);
+            fill_prob(G.p[k], j.A, j.lda, 0, j.B, j.ldb, 0, nullptr, nullptr, j.C, j.ldc, j.M, j.N, j.K, SMX_ACT_NONE,
+                      j.dbias, nullptr, base, j.stop_flag);
+        } else {
+            SMX_REQUIRE(j.kind == 0, SMX_E_UNSUPPORTED);
+            fill_prob(G.p[k], j.A, j.lda, j.a_kcontig, j.B, j.ldb, j.b_kcontig, j.bias, j.relu_mask, j.C, j.ldc, j.M, j.N,
+                      j.K, j.act, nullptr, nullptr, base, j.stop_flag);
+        }
+        base += G.p[k].tiles_m * G.p[k].tiles_n;
+    }
+    return launch_batch(G, smx_s(stream));
+}
+
 // dW[M,N] = dZ^T . X (dZ [rows, >=M] stride ldz, X [rows, >=N] stride ldx), db[M] = column sums of dZ
 extern "C" int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
                                     float* dW, int32_t ldw, float* db, int32_t M, int32_t N,

@@ -563,6 +563,28 @@ class HipKernels(object):
         L.call('smx_linear_f32', L.ptr(A), lda, int(a_kc), L.ptr(B), ldb, int(b_kc), L.ptr(bias),
                L.ptr(C), ldc, M, N, K, act, L.ptr(relu_mask), L.ptr(stop), self._st())
 
+    def linear_multi(self, jobs):
+        """independent dense problems in ONE launch (<= 9).  Each job is the argument tuple of ``linear``
+        (``('linear', A, a_kc, B, b_kc, bias, C, M, N, K, {act, relu_mask, lda, ldb, ldc, stop})``) or of
+        ``linear_wgrad`` (``('wgrad', dZ, X, dW, db, M, N, rows, {ldz, ldx, ldw})``)."""
+        arr = (L.LinearJob * len(jobs))()
+        for k, j in enumerate(jobs):
+            kw = j[-1] if isinstance(j[-1], dict) else {}
+            a = arr[k]
+            if j[0] == 'wgrad':
+                _, dZ, X, dW, db, M, N, rows = j[:8]
+                a.kind, a.A, a.B, a.C, a.dbias = 1, L.ptr(dZ), L.ptr(X), L.ptr(dW), L.ptr(db)
+                a.lda, a.ldb, a.ldc = kw.get('ldz') or dZ.stride(0), kw.get('ldx') or X.stride(0), kw.get('ldw') or dW.stride(0)
+                a.M, a.N, a.K = M, N, rows
+            else:
+                _, A, a_kc, B, b_kc, bias, C, M, N, K = j[:10]
+                a.kind, a.act = 0, int(kw.get('act', 0))
+                a.A, a.B, a.bias, a.C, a.relu_mask = L.ptr(A), L.ptr(B), L.ptr(bias), L.ptr(C), L.ptr(kw.get('relu_mask'))
+                a.lda, a.ldb, a.ldc = kw.get('lda') or A.stride(0), kw.get('ldb') or B.stride(0), kw.get('ldc') or C.stride(0)
+                a.a_kcontig, a.b_kcontig, a.M, a.N, a.K = int(a_kc), int(b_kc), M, N, K
+                a.stop_flag = L.ptr(kw.get('stop'))
+        L.call('smx_linear_multi_f32', arr, len(jobs), self._st())
+
     def linear_wgrad(self, dZ, X, dW, db, M, N, rows, ldz=None, ldx=None, ldw=None, ws=None):
         """ws: optional split-K workspace (>= linear_wgrad_ws_floats(M, N, rows) floats)"""
         ldz = ldz if ldz is not None else dZ.stride(0)

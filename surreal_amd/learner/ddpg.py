@@ -102,6 +102,8 @@ class DDPGLearner(Learner):
         self.frame_stack_preprocess = FrameStackPreprocessor(self.env_config.get('frame_stacks', 1))
         self.aggregator = SSARAggregator(self.env_config.obs_spec, self.env_config.action_spec)
         self._ws = None
+        # independent layers of an iteration share launches (_enqueue_iteration_levels); off: one launch per layer
+        self.level_schedule = bool(self.session_config.learner.get('ddpg_level_schedule', True))
 
     # ---- target update (ddpg.py:389-428) ----------------------------------------------------
     def _target_update_init(self):
@@ -162,6 +164,12 @@ class DDPGLearner(Learner):
         ws.lr = torch.tensor([self.lr_actor, self.lr_critic], dtype=torch.float32, device=self.device)
         ws.lr_host = (self.lr_actor, self.lr_critic)
         ws.q_policy = f(B)
+        # the levelled schedule (_enqueue_iteration_levels) keeps the four forward chains of an iteration apart: target
+        # actor, target critic, critic, actor each have their own activations, so independent layers share a launch
+        ws.h1a_t, ws.h2a_t = f(B, a.H1), f(B, a.H2)
+        ws.xcat_t, ws.h2c_t = f(B, c1 + A), f(B, c2)
+        ws.xcat_a, ws.h2c_a = f(B, c1 + A), f(B, c2)
+        ws.dz3_actor = torch.full((B,), -1.0 / B, device=self.device)       # d(-mean Q) / dQ  (ddpg.py:331)
         # the batch is staged into fixed buffers (5 small copies) so that the graph's pointers hold
         A = self.action_dim
         ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done = f(B, D), f(B, D), f(B, A), f(B), f(B)
@@ -240,8 +248,78 @@ class DDPGLearner(Learner):
             t.mul_(self._rank_weight)
             self._dist.all_reduce(t)
 
+    def _enqueue_iteration_levels(self, ws, x, xn, actions, rewards, done):
+        """One DDPG iteration (ddpg.py:244-352; low-dimensional observations, one critic, one rank) scheduled by
+        DEPENDENCY LEVEL: the layers of the target actor, the target critic, the critic and the actor that do not
+        depend on each other share a launch (smx_linear_multi_f32), and so do a level's weight gradients --
+        22 dependent launches where the layer-by-layer schedule takes ~40 (each ~6 us at batch 512: the
+        iteration is launch-latency bound).  The arithmetic of every layer is the same kernel with the same
+        operands as in _enqueue_iteration: identical results.
+        The actor's forward pass for ITS update (ddpg.py:326-329) only reads the actor's parameters, which the
+        critic update does not touch, so it rides in levels 1-3."""
+        K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
+        B, D = x.shape
+        a, ta, c, tc = m.actor.views, mt.actor.views, m.critic, mt.critic
+        c1, c2, ld = m.c1, m.c2, m.c1 + A
+        H1, H2 = m.actor.H1, m.actor.H2
+        R, T = L.SMX_ACT_RELU, L.SMX_ACT_TANH
+        ws.xcat[:, c1:].copy_(actions)
+        # 1: first layers of all four chains (none depends on another)
+        K.linear_multi([('linear', xn, 1, ta['W1'], 1, ta['b1'], ws.h1a_t, B, H1, D, dict(act=R)),
+                        ('linear', xn, 1, tc['W1'], 1, tc['b1'], ws.xcat_t, B, c1, D, dict(act=R, ldc=ld)),
+                        ('linear', x, 1, c['W1'], 1, c['b1'], ws.xcat, B, c1, D, dict(act=R, ldc=ld)),
+                        ('linear', x, 1, a['W1'], 1, a['b1'], ws.h1a, B, H1, D, dict(act=R))])
+        # 2
+        K.linear_multi([('linear', ws.h1a_t, 1, ta['W2'], 1, ta['b2'], ws.h2a_t, B, H2, H1, dict(act=R)),
+                        ('linear', ws.xcat, 1, c['W2'], 1, c['b2'], ws.h2c, B, c2, ld, dict(act=R)),
+                        ('linear', ws.h1a, 1, a['W2'], 1, a['b2'], ws.h2a, B, H2, H1, dict(act=R))])
+        # 3: the target policy's action lands in the target critic's concat buffer, the policy's own action in the
+        # concat buffer of the actor update's critic pass
+        K.linear_multi([('linear', ws.h2a_t, 1, ta['W3'], 1, ta['b3'], ws.xcat_t[:, c1:], B, A, H2, dict(act=T, ldc=ld)),
+                        ('linear', ws.h2c, 1, c['W3'], 1, c['b3'], ws.q.view(B, 1), B, 1, c2, dict(act=0)),
+                        ('linear', ws.h2a, 1, a['W3'], 1, a['b3'], ws.xcat_a[:, c1:], B, A, H2, dict(act=T, ldc=ld)),
+                        ('linear', ws.h2a, 1, a['W3'], 1, a['b3'], ws.act, B, A, H2, dict(act=T))])   # (dense copy: tanh')
+        # 4, 5: Q'(s', mu'(s'))
+        K.linear(ws.xcat_t, 1, tc['W2'], 1, tc['b2'], ws.h2c_t, B, c2, ld, act=R)
+        K.linear(ws.h2c_t, 1, tc['W3'], 1, tc['b3'], ws.q_next.view(B, 1), B, 1, c2, act=0)
+        # 6: y, critic loss gradient, the iteration's Adam step count
+        K.ddpg_critic_loss_step(ws.q, ws.q_next, rewards, done, pow(self.discount_factor, self.n_step), ws.y, ws.dz3,
+                                ws.step)
+        # 7-9: critic backward; a layer's weight gradient shares the launch of the next data gradient
+        dz3 = ws.dz3.view(B, 1)
+        K.linear_multi([('linear', dz3, 1, c['W3'], 0, None, ws.dz2, B, c2, 1, dict(relu_mask=ws.h2c, lda=1, ldb=c2)),
+                        ('wgrad', dz3, ws.h2c, ws.gc['W3'], ws.gc['b3'], 1, c2, B, dict(ldz=1))])
+        K.linear_multi([('linear', ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1, c2,
+                         dict(relu_mask=ws.xcat, ldb=ld, ldc=ld)),
+                        ('wgrad', ws.dz2, ws.xcat, ws.gc['W2'], ws.gc['b2'], c2, ld, B, {})])
+        K.linear_wgrad(ws.dxcat, x, ws.gc['W1'], ws.gc['b1'], c1, D, B, ldz=ld)
+        # 10
+        K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                        ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+        # 11-13: Q(s, mu(s)) through the UPDATED critic; d(-mean Q)/d(layer 2) needs only that pass's ReLU mask
+        K.linear(x, 1, c['W1'], 1, c['b1'], ws.xcat_a, B, c1, D, act=R, ldc=ld)
+        K.linear(ws.xcat_a, 1, c['W2'], 1, c['b2'], ws.h2c_a, B, c2, ld, act=R)
+        K.linear_multi([('linear', ws.h2c_a, 1, c['W3'], 1, c['b3'], ws.q_actor.view(B, 1), B, 1, c2, dict(act=0)),
+                        ('linear', ws.dz3_actor.view(B, 1), 1, c['W3'], 0, None, ws.dz2, B, c2, 1,
+                         dict(relu_mask=ws.h2c_a, lda=1, ldb=c2))])
+        # 14, 15: d/d(action), through tanh
+        K.linear(ws.dz2, 1, c['W2'][:, c1:], 0, None, ws.dz3a, B, A, c2, ldb=ld)
+        K.tanh_backward(ws.dz3a, ws.act, ws.dz3a)
+        # 16-18: actor backward (data gradients, weight gradients), 19: its Adam step
+        K.mlp3_backward(m.actor, x, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a, ws.grads_a, None)
+        K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                        ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
+        K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
+        for tgt, src in ((mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat)):
+            if self.target_update_type == 'soft':
+                K.soft_update(tgt, src, self.target_update_tau)
+            else:
+                K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
+
     def _enqueue_iteration(self, ws, x, xn, actions, rewards, done, pix=None, pix_next=None):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
+        if self.level_schedule and not (self.is_pixel_input or self.use_double_critic or self.world_size > 1):
+            return self._enqueue_iteration_levels(ws, x, xn, actions, rewards, done)
         K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
         B = x.shape[0]
         low, low_next = x, xn

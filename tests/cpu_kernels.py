@@ -304,6 +304,14 @@ class TorchCpuKernels(object):
     def reward_filter_partials(self):
         return 128
 
+    def linear_multi(self, jobs):
+        for j in jobs:
+            kw = j[-1] if isinstance(j[-1], dict) else {}
+            if j[0] == 'wgrad':
+                self.linear_wgrad(*j[1:8], **kw)
+            else:
+                self.linear(*j[1:10], **kw)
+
     def frame_stack(self, frames, n_stack, start, n_step, stride, W, dst, episode_first=None):
         actors, R = frames.shape[:2]
         fr = frames.reshape(actors, R, -1)
@@ -866,6 +874,7 @@ class TorchCpuKernels(object):
         dz3.view(-1).copy_(2.0 * (q.view(-1) - yy) / q.numel())
 
     def tanh_backward(self, da, a, out):
+        assert da.is_contiguous() and a.is_contiguous() and out.is_contiguous()     # the kernel indexes linearly
         out.copy_(da * (1.0 - a * a))
 
     def fill(self, x, value):
