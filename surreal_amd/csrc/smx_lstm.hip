@@ -539,6 +539,156 @@ __global__ __launch_bounds__(NT) void lstm_bwd1_kernel(BwdArgs a) {
     }
 }
 
+// ===========================================================================================
+// The same one-row-per-workgroup recurrence with the four gates of a hidden unit in ADJACENT LANES (thread 4 n + g:
+// unit n, gate g).  What that buys per time step:
+//   * the gates of a unit meet through DPP quad broadcasts -- no LDS round trip and no barrier between the gate
+//     activations and the cell update, which all four lanes of a quad now form redundantly (on all eight waves instead
+//     of two waves working while six wait);
+//   * h_t (forward) / the step's dgates (backward) ping-pong between two LDS buffers, so ONE barrier per step is
+//     enough (a buffer is rewritten two steps later, behind the barrier of the step in between);
+//   * backward: a quad's four partial sums of dh_rec stay in registers and are added by DPP in the fixed order
+//     ((p0 + p1) + p2) + p3 -- the LDS exchange and its barrier are gone;
+//   * the H multiply-adds per lane are packed two to an instruction (v_pk_fma_f32), same two accumulation chains.
+// Every value is formed by the same operations in the same order as in lstm_fwd1 / lstm_bwd1_kernel (bit-identical
+// results); SMX_LSTM_V1=1 selects those for A/B runs.
+// ===========================================================================================
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int G>
+__device__ __forceinline__ float quad_bcast(float v) {      // lane G of every quad -> all four lanes
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), G * 0x55, 0xf, 0xf, true));
+}
+
+template <int HQ>          // H <= 4 HQ
+__global__ __launch_bounds__(NT) void lstm_fwdq_kernel(FwdArgs a) {
+    if (a.stop && *a.stop) return;
+    __shared__ float4 hs4[2][HQ];              // h_{t-1} / h_t, zero padded
+    const int H = a.H, G = 4 * H, T = a.T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool colv = tid < G;
+    const int n = tid >> 2, g = tid & 3;
+    const int col = colv ? g * H + n : 0;
+    float4 w[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q)
+        w[q] = (colv && 4 * q < H) ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + 4 * q)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bias = colv ? a.b_hh[col] : 0.f;
+    const bool is_g = g == 2;                  // the cell candidate: tanh; the other gates: sigmoid
+    float* hs = reinterpret_cast<float*>(hs4);
+    for (int i = tid; i < 2 * 4 * HQ; i += NT) hs[i] = 0.f;
+    __syncthreads();
+    if (colv && g == 0 && a.h0) hs[n] = a.h0[(size_t)b * H + n];
+    float creg = (colv && a.c0) ? a.c0[(size_t)b * H + n] : 0.f;
+    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    float gx = colv ? a.gates[gbase + col] : 0.f;      // the input half of step 0 (smx_linear_f32)
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int p = t & 1;
+        v2f acc = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const float4 hv = hs4[p][q];
+            acc = __builtin_elementwise_fma((v2f){hv.x, hv.y}, (v2f){w[q].x, w[q].y}, acc);
+            acc = __builtin_elementwise_fma((v2f){hv.z, hv.w}, (v2f){w[q].z, w[q].w}, acc);
+        }
+        const float pre = gx + ((acc.x + acc.y) + bias);
+        const float act = is_g ? tanhf(pre) : sigm(pre);
+        if (colv) a.gates[gbase + (size_t)t * G + col] = act;
+        gx = (colv && t + 1 < T) ? a.gates[gbase + (size_t)(t + 1) * G + col] : 0.f;
+        const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+        const float c = gf * creg + gi * gg;
+        const float h = go * tanhf(c);
+        creg = c;
+        if (colv && g == 0) {
+            const size_t oh = hbase + (size_t)t * H + n;
+            a.out[oh] = h;
+            a.cs[oh] = c;
+            if (a.hprev) a.hprev[oh] = hs[p * 4 * HQ + n];
+            hs[(1 - p) * 4 * HQ + n] = h;
+        }
+        LSTM_LDS_BARRIER();
+    }
+    if (colv && g == 0) {
+        if (a.hN) a.hN[(size_t)b * H + n] = hs[(T & 1) * 4 * HQ + n];
+        if (a.cN) a.cN[(size_t)b * H + n] = creg;
+    }
+}
+
+template <int HQ>
+__global__ __launch_bounds__(NT) void lstm_bwdq_kernel(BwdArgs a) {
+    if (a.stop && *a.stop) return;
+    __shared__ float4 dg4[2][4][HQ];           // the step's dgates, gate block gb at dg4[p][gb] (zero padded)
+    const int H = a.H, G = 4 * H, T = a.T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool colv = tid < G;
+    const int n = colv ? tid >> 2 : 0, gb = tid & 3;
+    float4 w[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (colv && 4 * q < H) {
+            const float* p = a.W_hh + ((size_t)gb * H + 4 * q) * H + n;
+            v = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
+        }
+        w[q] = v;
+    }
+    float* dg = reinterpret_cast<float*>(dg4);
+    for (int idx = tid; idx < 2 * 4 * 4 * HQ; idx += NT) dg[idx] = 0.f;
+    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    float dcreg = 0.f, share = 0.f;            // share: this lane's gate block's part of dh_rec[n] (previous step)
+    float gmine = 0.f, c = 0.f, cp = 0.f, dout = 0.f;
+    auto fetch = [&](int t, float& xg, float& xcp, float& xd) {
+        const size_t oh = hbase + (size_t)t * H + n;
+        xg = a.gates[gbase + (size_t)t * G + (size_t)gb * H + n];      // this lane's own gate of unit n
+        xcp = (t > 0) ? a.cs[oh - H] : (a.c0 ? a.c0[(size_t)b * H + n] : 0.f);
+        xd = a.dout[oh];
+    };
+    if (colv) {
+        fetch(T - 1, gmine, cp, dout);
+        c = a.cs[hbase + (size_t)(T - 1) * H + n];
+    }
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const int p = t & 1;
+        float ng = 0.f, ncp = 0.f, nd = 0.f;
+        if (colv && t > 0) fetch(t - 1, ng, ncp, nd);              // the next step's inputs: requested early
+        const float gi = quad_bcast<0>(gmine), gf = quad_bcast<1>(gmine), gg = quad_bcast<2>(gmine),
+                    go = quad_bcast<3>(gmine);
+        const float dhr = ((quad_bcast<0>(share) + quad_bcast<1>(share)) + quad_bcast<2>(share)) + quad_bcast<3>(share);
+        const float dh = dout + dhr;
+        const float tc = tanhf(c);
+        const float dc = dcreg + (dh * go) * (1.f - tc * tc);
+        const float dgi = (dc * gg) * (gi * (1.f - gi));
+        const float dgf = (dc * cp) * (gf * (1.f - gf));
+        const float dgg = (dc * gi) * (1.f - gg * gg);
+        const float dgo = (dh * tc) * (go * (1.f - go));
+        dcreg = dc * gf;
+        const float mine = gb == 0 ? dgi : (gb == 1 ? dgf : (gb == 2 ? dgg : dgo));
+        if (colv) {
+            a.dgates[gbase + (size_t)t * G + (size_t)gb * H + n] = mine;
+            dg[((p * 4 + gb) * 4 * HQ) + n] = mine;
+        }
+        LSTM_LDS_BARRIER();
+        share = 0.f;
+        if (t > 0 && colv) {
+            v2f acc = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const float4 dv = dg4[p][gb][q];
+                acc = __builtin_elementwise_fma((v2f){dv.x, dv.y}, (v2f){w[q].x, w[q].y}, acc);
+                acc = __builtin_elementwise_fma((v2f){dv.z, dv.w}, (v2f){w[q].z, w[q].w}, acc);
+            }
+            share = acc.x + acc.y;
+        }
+        c = cp;
+        gmine = ng; cp = ncp; dout = nd;
+    }
+}
+
 constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
 
 inline size_t lds4_fwd(int kq) { return (size_t)RB4 * ((kq * 4 + 4) + (NWV * 64 + 4)) * sizeof(float); }
@@ -573,7 +723,12 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     const int blocks = (int)((B + RB - 1) / RB);
     // H <= 128: one row per workgroup on the vector ALU (SMX_LSTM_MFMA4=1 keeps the 4-row MFMA kernels for A/B runs)
     static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
-    if (!mfma4 && H <= 100) {
+    static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;       // the LDS-exchange one-row kernels, for A/B runs
+    if (!mfma4 && !v1 && H <= 100) {
+        hipLaunchKernelGGL((lstm_fwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && H <= 128) {
+        hipLaunchKernelGGL((lstm_fwdq_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && H <= 100) {
         hipLaunchKernelGGL((lstm_fwd1_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && H <= 128) {
         hipLaunchKernelGGL((lstm_fwd1_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
@@ -614,7 +769,12 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     a.stop = stop_flag; a.B = (int)B; a.T = T; a.H = H;
     const int blocks = (int)((B + RB - 1) / RB);
     static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
-    if (!mfma4 && H <= 100) {
+    static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;
+    if (!mfma4 && !v1 && H <= 100) {
+        hipLaunchKernelGGL((lstm_bwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && H <= 128) {
+        hipLaunchKernelGGL((lstm_bwdq_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && H <= 100) {
         hipLaunchKernelGGL((lstm_bwd1_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && H <= 128) {
         hipLaunchKernelGGL((lstm_bwd1_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);

@@ -49,8 +49,7 @@ class PinnedBatchStager(object):
     stay uint8, everything else travels as float32 -- what the learners' preprocess would make of it)."""
 
     def __init__(self, example, depth=2, device=None):
-        self.device = torch.device(device if device is not None else 'cuda')
-        self.on_gpu = self.device.type == 'cuda'
+XX
         self.depth = depth
         self.template = example
         self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
