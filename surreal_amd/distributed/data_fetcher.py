@@ -49,7 +49,10 @@ class PinnedBatchStager(object):
     stay uint8, everything else travels as float32 -- what the learners' preprocess would make of it)."""
 
     def __init__(self, example, depth=2, device=None):
-XX
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.on_gpu = self.device.type == 'cuda'
+        if self.on_gpu and self.device.index is None:       # (threads set their current device from it)
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.depth = depth
         self.template = example
         self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
