@@ -11,6 +11,7 @@
 //     a GEMM over patch rows writes), torch flattens channel-first, so the Linear's weight is
 //     re-indexed [out, c*P + p] <-> [out, p*C + c].
 #include "smx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -634,6 +635,130 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restr
     (void)na; (void)nb;
 }
 
+// The same data gradient tiled over CELLS instead of parity classes (stride 2, kernel 4, even Hin / Win -- the
+// reference's second convolution): a cell (a, b) is the 2 x 2 block of input pixels (2a + py, 2b + px), and all four of
+// them read the SAME four output positions (a - u, b - v), u, v in {0, 1} -- only the kernel taps differ.  A wavefront
+// therefore gathers the dy rows of 16 cells ONCE (8 x 16-byte loads per lane) and runs all four classes on them
+// (4 x 32 MFMAs against four register-resident weight sets) where the class-major kernel above gathered them four
+// times, once per pass over the whole tensor; and the two classes that share a 128-byte line of dx / of the ReLU mask
+// (px = 0, 1) now write / read it back to back instead of a whole tensor pass apart.  The next tile's gather is in
+// flight under the current tile's MFMAs.  Same sums in the same order per output element: bit-identical results.
+template <int NH, bool VEC4>
+__global__ __launch_bounds__(256) void conv_cl_dgrad_cells_kernel(const float* __restrict__ dy, ConvGeom g, long long F,
+                                                                  const float* __restrict__ W, int cout,
+                                                                  const float* __restrict__ relu_of,
+                                                                  float* __restrict__ dx, const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int NPK = g.kh * g.kw;
+    const int ca = g.Hin >> 1, cb = g.Win >> 1;
+    // B operands of the four classes: lane (c = i, kq) holds W[o = 16 h + 4 kq + s][c][ki][kj], ki = py + 2 u, kj = px + 2 v
+    float4 w[4][4][NH];
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ki = (cls >> 1) + (q >> 1) * 2, kj = (cls & 1) + (q & 1) * 2;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float v[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int o = 16 * h + 4 * kq + s4;
+                    v[s4] = o < cout ? W[((size_t)o * 16 + i) * NPK + ki * g.kw + kj] : 0.f;
+                }
+                w[cls][q][h] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    const long long per = (long long)ca * cb;
+    const long long ncell = F * per;
+    const bool small = ncell < (1ll << 31);
+    const long long ntiles = (ncell + 15) >> 4;
+    // the A operands of a tile: lane (cell = i, kq) holds dy[(f, a - u, b - v), o = 16 h + 4 kq + 0..3] (zero outside)
+    auto gather = [&](long long tile, float4 (&av)[4][NH]) {
+        long long n = tile * 16 + i;
+        const bool inr = n < ncell;
+        if (!inr) n = ncell - 1;
+        long long f;
+        int ab;
+        divmod_idx(n, (int)per, small, f, ab);
+        const int a = ab / cb, b = ab - a * cb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = a - (q >> 1), ox = b - (q & 1);
+            const bool ok = inr && oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+            const long long prow = (f * g.Ho + (ok ? oy : 0)) * g.Wo + (ok ? ox : 0);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int o0 = 16 * h + 4 * kq;
+                float4 v;
+                if (VEC4) {
+                    v = *reinterpret_cast<const float4*>(dy + prow * cout + (o0 + 3 < cout ? o0 : 0));
+                    if (!(ok && o0 + 3 < cout)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    const float* q4 = dy + prow * cout;
+                    const float x0 = q4[o0 < cout ? o0 : 0], x1 = q4[o0 + 1 < cout ? o0 + 1 : 0];
+                    const float x2 = q4[o0 + 2 < cout ? o0 + 2 : 0], x3 = q4[o0 + 3 < cout ? o0 + 3 : 0];
+                    v = make_float4((ok && o0 < cout) ? x0 : 0.f, (ok && o0 + 1 < cout) ? x1 : 0.f,
+                                    (ok && o0 + 2 < cout) ? x2 : 0.f, (ok && o0 + 3 < cout) ? x3 : 0.f);
+                }
+                av[q][h] = v;
+            }
+        }
+    };
+    float4 cur[4][NH], nxt[4][NH];
+    long long tile = wave;
+    if (tile < ntiles) gather(tile, cur);
+    for (; tile < ntiles; tile += nwaves) {
+        const long long tn = tile + nwaves;
+        if (tn < ntiles) gather(tn, nxt);
+        // the C fragment's cells: lane (c = i, kq) holds cells 16 tile + 4 kq + r
+        long long pix0[4];
+        bool okm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long m = tile * 16 + 4 * kq + r;
+            okm[r] = m < ncell;
+            long long f2;
+            int ab2;
+            divmod_idx(okm[r] ? m : 0, (int)per, small, f2, ab2);
+            const int a2 = ab2 / cb, b2 = ab2 - a2 * cb;
+            pix0[r] = (f2 * g.Hin + 2ll * a2) * g.Win + 2 * b2;          // the cell's pixel (py, px) = (0, 0)
+        }
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    acc = MFMA16C(cur[q][h].x, w[cls][q][h].x, acc);
+                    acc = MFMA16C(cur[q][h].y, w[cls][q][h].y, acc);
+                    acc = MFMA16C(cur[q][h].z, w[cls][q][h].z, acc);
+                    acc = MFMA16C(cur[q][h].w, w[cls][q][h].w, acc);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (okm[r]) {
+                    const long long pix = pix0[r] + (long long)(cls >> 1) * g.Win + (cls & 1);
+                    float v = acc[r];
+                    if (relu_of) v = (relu_of[pix * 16 + i] > 0.f) ? v : 0.f;
+                    dx[pix * 16 + i] = v;
+                }
+            }
+        }
+        if (tn < ntiles) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) cur[q][h] = nxt[q][h];
+        }
+    }
+}
+
 inline bool geom_ok(const ConvGeom& g) {
     return g.C > 0 && g.Hin > 0 && g.Win > 0 && g.kh > 0 && g.kw > 0 && g.stride > 0 &&
            g.Ho == (g.Hin - g.kh) / g.stride + 1 && g.Wo == (g.Win - g.kw) / g.stride + 1 &&
@@ -818,6 +943,12 @@ extern "C" int smx_conv_cl_dgrad_f32(const float* dy, int64_t F, int32_t C, int3
     void (*kern)(const float*, ConvGeom, long long, const float*, int, const float*, float*, const int*) =
         cout <= 16 ? (cout % 4 == 0 ? conv_cl_dgrad_kernel<1, true> : conv_cl_dgrad_kernel<1, false>)
                    : (cout % 4 == 0 ? conv_cl_dgrad_kernel<2, true> : conv_cl_dgrad_kernel<2, false>);
+    // stride 2, even maps (the reference's geometry): tiles of 2 x 2 cells, one gather for the four parity classes
+    // (SMX_CONV_DGRAD_CLASSES=1 keeps the class-major kernel for A/B runs)
+    static const bool classes = getenv("SMX_CONV_DGRAD_CLASSES") != nullptr;
+    if (!classes && stride == 2 && Hin % 2 == 0 && Win % 2 == 0)
+        kern = cout <= 16 ? (cout % 4 == 0 ? conv_cl_dgrad_cells_kernel<1, true> : conv_cl_dgrad_cells_kernel<1, false>)
+                          : (cout % 4 == 0 ? conv_cl_dgrad_cells_kernel<2, true> : conv_cl_dgrad_cells_kernel<2, false>);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), dy, g, (long long)F, W, cout, relu_of,
                        dx, stop_flag);
     SMX_LAUNCH_CHECK();
