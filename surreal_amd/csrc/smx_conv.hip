@@ -644,41 +644,46 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_kernel(const float* __restr
 // (px = 0, 1) now write / read it back to back instead of a whole tensor pass apart.  The next tile's gather is in
 // flight under the current tile's MFMAs.  Same sums in the same order per output element: bit-identical results.
 template <int NH, bool VEC4>
-__global__ __launch_bounds__(256) void conv_cl_dgrad_cells_kernel(const float* __restrict__ dy, ConvGeom g, long long F,
+__global__ __launch_bounds__(256, 3) void conv_cl_dgrad_cells_kernel(const float* __restrict__ dy, ConvGeom g, long long F,
                                                                   const float* __restrict__ W, int cout,
                                                                   const float* __restrict__ relu_of,
                                                                   float* __restrict__ dx, const int* __restrict__ stop) {
     if (stop && *stop) return;
+    // B operands of the four classes in LDS, fragment order (one ds_read_b128 per four MFMAs): [cls][q][h][lane].
+    // (In registers they cost 128 VGPRs and left two wavefronts per SIMD to hide the HBM latency of the mask reads.)
+    __shared__ float4 ws[4 * 4 * NH * 64];
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kq = lane >> 4;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const int NPK = g.kh * g.kw;
     const int ca = g.Hin >> 1, cb = g.Win >> 1;
-    // B operands of the four classes: lane (c = i, kq) holds W[o = 16 h + 4 kq + s][c][ki][kj], ki = py + 2 u, kj = px + 2 v
-    float4 w[4][4][NH];
+    for (int e = threadIdx.x; e < 4 * 4 * NH * 64; e += 256) {
+        // entry (cls, q, h, l): lane l = (c = l & 15, kq = l >> 4) holds W[o = 16 h + 4 kq + s][c][ki][kj]
+        const int l = e & 63, h = (e >> 6) % NH, q = ((e >> 6) / NH) & 3, cls = (e >> 6) / NH / 4;
+        const int ki = (cls >> 1) + (q >> 1) * 2, kj = (cls & 1) + (q & 1) * 2;
+        float v[4];
 #pragma unroll
-    for (int cls = 0; cls < 4; ++cls)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ki = (cls >> 1) + (q >> 1) * 2, kj = (cls & 1) + (q & 1) * 2;
-#pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                float v[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int o = 16 * h + 4 * kq + s4;
-                    v[s4] = o < cout ? W[((size_t)o * 16 + i) * NPK + ki * g.kw + kj] : 0.f;
-                }
-                w[cls][q][h] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int o = 16 * h + 4 * (l >> 4) + s4;
+            v[s4] = o < cout ? W[((size_t)o * 16 + (l & 15)) * NPK + ki * g.kw + kj] : 0.f;
         }
+        ws[e] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
     const long long per = (long long)ca * cb;
     const long long ncell = F * per;
     const bool small = ncell < (1ll << 31);
     const long long ntiles = (ncell + 15) >> 4;
-    // the A operands of a tile: lane (cell = i, kq) holds dy[(f, a - u, b - v), o = 16 h + 4 kq + 0..3] (zero outside)
-    auto gather = [&](long long tile, float4 (&av)[4][NH]) {
+    // what a tile reads, requested one tile ahead: its A operands -- lane (cell = i, kq) holds dy[(f, a - u, b - v),
+    // o = 16 h + 4 kq + 0..3] (zero outside the map) -- and, for the C fragment's cells (16 tile + 4 kq + r), the
+    // 2 x 2 pixels' ReLU-mask values and addresses
+    struct Tile {
+        float4 av[4][NH];
+        float mk[4][4];          // [cls][r]
+        long long pix0[4];       // pixel (py, px) = (0, 0) of cell r; < 0: past the end
+    };
+    auto fetch = [&](long long tile, Tile& T) {
         long long n = tile * 16 + i;
         const bool inr = n < ncell;
         if (!inr) n = ncell - 1;
@@ -705,29 +710,33 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_cells_kernel(const float* _
                     v = make_float4((ok && o0 < cout) ? x0 : 0.f, (ok && o0 + 1 < cout) ? x1 : 0.f,
                                     (ok && o0 + 2 < cout) ? x2 : 0.f, (ok && o0 + 3 < cout) ? x3 : 0.f);
                 }
-                av[q][h] = v;
+                T.av[q][h] = v;
             }
         }
-    };
-    float4 cur[4][NH], nxt[4][NH];
-    long long tile = wave;
-    if (tile < ntiles) gather(tile, cur);
-    for (; tile < ntiles; tile += nwaves) {
-        const long long tn = tile + nwaves;
-        if (tn < ntiles) gather(tn, nxt);
-        // the C fragment's cells: lane (c = i, kq) holds cells 16 tile + 4 kq + r
-        long long pix0[4];
-        bool okm[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long long m = tile * 16 + 4 * kq + r;
-            okm[r] = m < ncell;
+            const bool okm = m < ncell;
             long long f2;
             int ab2;
-            divmod_idx(okm[r] ? m : 0, (int)per, small, f2, ab2);
+            divmod_idx(okm ? m : 0, (int)per, small, f2, ab2);
             const int a2 = ab2 / cb, b2 = ab2 - a2 * cb;
-            pix0[r] = (f2 * g.Hin + 2ll * a2) * g.Win + 2 * b2;          // the cell's pixel (py, px) = (0, 0)
+            const long long p0 = (f2 * g.Hin + 2ll * a2) * g.Win + 2 * b2;
+            T.pix0[r] = okm ? p0 : -1;
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls)       // (unconditional loads from valid addresses: cell 0 when past the end)
+                T.mk[cls][r] = relu_of ? relu_of[(p0 + (long long)(cls >> 1) * g.Win + (cls & 1)) * 16 + i] : 1.f;
         }
+    };
+    Tile cur, nxt;
+    long long tile = wave;
+    if (tile < ntiles) fetch(tile, cur);
+    for (; tile < ntiles; tile += nwaves) {
+        const long long tn = tile + nwaves;
+        if (tn < ntiles) fetch(tn, nxt);
+        // (always 0, but not to the compiler: the weight reads below must stay LDS reads inside the loop -- hoisted out
+        // of it they would be 128 registers again)
+        const int z = __builtin_amdgcn_readfirstlane((int)((unsigned long long)tile >> 62));
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -735,27 +744,21 @@ __global__ __launch_bounds__(256) void conv_cl_dgrad_cells_kernel(const float* _
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    acc = MFMA16C(cur[q][h].x, w[cls][q][h].x, acc);
-                    acc = MFMA16C(cur[q][h].y, w[cls][q][h].y, acc);
-                    acc = MFMA16C(cur[q][h].z, w[cls][q][h].z, acc);
-                    acc = MFMA16C(cur[q][h].w, w[cls][q][h].w, acc);
+                    const float4 wv = ws[((cls * 4 + q) * NH + h) * 64 + lane + z];
+                    acc = MFMA16C(cur.av[q][h].x, wv.x, acc);
+                    acc = MFMA16C(cur.av[q][h].y, wv.y, acc);
+                    acc = MFMA16C(cur.av[q][h].z, wv.z, acc);
+                    acc = MFMA16C(cur.av[q][h].w, wv.w, acc);
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (okm[r]) {
-                    const long long pix = pix0[r] + (long long)(cls >> 1) * g.Win + (cls & 1);
-                    float v = acc[r];
-                    if (relu_of) v = (relu_of[pix * 16 + i] > 0.f) ? v : 0.f;
-                    dx[pix * 16 + i] = v;
+                if (cur.pix0[r] >= 0) {
+                    const long long pix = cur.pix0[r] + (long long)(cls >> 1) * g.Win + (cls & 1);
+                    dx[pix * 16 + i] = (cur.mk[cls][r] > 0.f) ? acc[r] : 0.f;
                 }
             }
         }
-        if (tn < ntiles) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) cur[q][h] = nxt[q][h];
-        }
+        if (tn < ntiles) cur = nxt;
     }
 }
 
