@@ -450,18 +450,27 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_kernel(const float* __restr
     float dbacc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) dbacc[nt] = 0.f;
-    for (long long grp = wave; grp < ngroups; grp += nwaves) {
-        long long row = grp * 16 + i;
-        if (row >= rows) row = rows - 1;                 // clamped: its dy is taken as zero
+    // a group's operands are requested one group AHEAD (a wavefront has its SIMD to itself here -- 128 accumulator
+    // registers -- so nothing else hides the gather's latency): the patch words and the dy words of group g + 1 are in
+    // flight while group g's 128 MFMAs issue
+    // (written out twice, unconditionally: behind a lambda or a branch hipcc leaves the arrays in scratch memory)
+    // (named scalars: a loop-carried ARRAY of prefetched words is left in scratch memory by hipcc)
+#define PW_ALL(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define PW_DECL(k) float4 pw##k = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PW_LOAD(k) if (k < NP) pw##k = *reinterpret_cast<const float4*>(b + poff[k < NP ? k : 0]);
+#define PW_STORE(k) if (k < NP) *reinterpret_cast<float4*>(mytile + i * RS + 16 * k + 4 * kq) = pw##k;
+    PW_ALL(PW_DECL)
+    float a[NT][4];
+    long long grp = wave;
+    {
+        long long row = (grp < ngroups ? grp : 0) * 16 + i;
+        if (row >= rows) row = rows - 1;
         long long f;
         int pp;
         divmod_idx(row, P, rows < (1ll << 31), f, pp);
         const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
         const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-            *reinterpret_cast<float4*>(mytile + i * RS + 16 * p + 4 * kq) = *reinterpret_cast<const float4*>(b + poff[p]);
-        float a[NT][4];
+        PW_ALL(PW_LOAD)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -471,21 +480,60 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_kernel(const float* __restr
                 const bool ok = r < rows && o < cout;
                 const float v = dy[(ok ? r : 0) * cout + (o < cout ? o : 0)];      // unconditional, clamped
                 a[nt][s4] = ok ? v : 0.f;
-                dbacc[nt] += a[nt][s4];
             }
+    }
+    for (; grp < ngroups; grp += nwaves) {
+        PW_ALL(PW_STORE)
+        float ac[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                ac[nt][s4] = a[nt][s4];
+                dbacc[nt] += ac[nt][s4];
+            }
+        {
+            // the next group (the last iteration re-requests its own: cache hits, results unused)
+            const long long gn = grp + nwaves < ngroups ? grp + nwaves : grp;
+            long long row = gn * 16 + i;
+            if (row >= rows) row = rows - 1;             // clamped: its dy is taken as zero
+            long long f;
+            int pp;
+            divmod_idx(row, P, rows < (1ll << 31), f, pp);
+            const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+            const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
+            PW_ALL(PW_LOAD)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const long long r = gn * 16 + 4 * kq + s4;
+                    const int o = 16 * nt + i;
+                    const bool ok = r < rows && o < cout;
+                    const float v = dy[(ok ? r : 0) * cout + (o < cout ? o : 0)];
+                    a[nt][s4] = ok ? v : 0.f;
+                }
+        }
+        // (LDS operations of one wavefront execute in order; a fence without a memory-clobbering asm statement: an
+        // array that is live across one is left in scratch memory by hipcc)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float bval = mytile[(4 * kq + s4) * RS + 16 * p + i];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][p] = MFMA16C(a[nt][s4], bval, acc[nt][p]);
+                for (int nt = 0; nt < NT; ++nt) acc[nt][p] = MFMA16C(ac[nt][s4], bval, acc[nt][p]);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
+#undef PW_ALL
+#undef PW_DECL
+#undef PW_LOAD
+#undef PW_STORE
     // lane (i, kq): dW[o = 16 nt + 4 kq + r][(p, c = i)]
     float* out = part + (size_t)wave * (16 * NT) * K;
 #pragma unroll
