@@ -261,10 +261,20 @@ __global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char*
     unsigned char* mytile = tile[wv];
     unsigned cur[NG], nxt[NG];
     long long grp = wave;
+    // (unconditional loads from clamped addresses, zeroed by a select: a load under a lane mask is waited for on the spot)
+#define DY_REQUEST(G, DST, S4)                                                        \
+    do {                                                                              \
+        const long long row_ = (G) * 16 + 4 * kq + (S4);                              \
+        const bool ok_ = row_ < rows && i < cout;                                     \
+        const float v_ = dy[(ok_ ? row_ : 0) * cout + (i < cout ? i : 0)];            \
+        DST = ok_ ? v_ : 0.f;                                                         \
+    } while (0)
+    float na0 = 0.f, na1 = 0.f, na2 = 0.f, na3 = 0.f;
     if (grp < ngroups) {
         const unsigned char* b = frames + base_of(grp);
 #pragma unroll
         for (int gidx = 0; gidx < NG; ++gidx) cur[gidx] = *reinterpret_cast<const unsigned*>(b + koff[gidx]);
+        DY_REQUEST(grp, na0, 0); DY_REQUEST(grp, na1, 1); DY_REQUEST(grp, na2, 2); DY_REQUEST(grp, na3, 3);
     }
     for (; grp < ngroups; grp += nwaves) {
         const long long gn = grp + nwaves;
@@ -273,15 +283,14 @@ __global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char*
 #pragma unroll
             for (int gidx = 0; gidx < NG; ++gidx) nxt[gidx] = *reinterpret_cast<const unsigned*>(b + koff[gidx]);
         }
-        // dy of the group's rows 4 kq + s, channel i
-        float a[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {       // unconditional loads from clamped addresses, zeroed by a select: a
-            const long long row = grp * 16 + 4 * kq + s4;        // load under a lane mask is waited for on the spot
-            const bool ok = row < rows && i < cout;
-            const float v = dy[(ok ? row : 0) * cout + (i < cout ? i : 0)];
-            a[s4] = ok ? v : 0.f;
-            dbacc += a[s4];
+        // dy of the group's rows 4 kq + s, channel i: requested ONE GROUP AHEAD like the frame bytes (the wavefront has
+        // its SIMD to itself -- one partial per wavefront bounds the grid -- so an exposed L2 / HBM round trip per group
+        // was half of the group's time).  Named scalars: a loop-carried array is left in scratch memory by hipcc.
+        float a[4] = {na0, na1, na2, na3};
+        dbacc += a[0]; dbacc += a[1]; dbacc += a[2]; dbacc += a[3];
+        {
+            const long long g2 = gn < ngroups ? gn : grp;
+            DY_REQUEST(g2, na0, 0); DY_REQUEST(g2, na1, 1); DY_REQUEST(g2, na2, 2); DY_REQUEST(g2, na3, 3);
         }
         // raw bytes of patch row i, columns 16 g + 4 kq .. + 3  -> the wavefront's LDS tile
 #pragma unroll
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char*
 #pragma unroll
         for (int gidx = 0; gidx < NG; ++gidx) cur[gidx] = nxt[gidx];
     }
+#undef DY_REQUEST
     // lane (i, kq) holds dW[o = 4 kq + r][k = 16 t + i]; the bias partial: sum over the four kq lane groups
     dbacc += __shfl_xor(dbacc, 16, 64);
     dbacc += __shfl_xor(dbacc, 32, 64);
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_partial_reduce_kernel(const float* _
     else if (db) db[e - nW] = v;
 }
 
-constexpr int CONV_WGRAD_BLOCKS = 256;      // one workgroup per CU: 256 partials
+constexpr int CONV_WGRAD_BLOCKS = 512;      // two workgroups per CU (a wavefront's byte unpacking hides under its SIMD partner's MFMAs): 512 partials
 
 // ---------------------------------------------------------------------------------------------
 // The SECOND convolution (fp32 channel-last source [F, Hin*Win, 16], e.g. the first one's output) as implicit GEMMs.
@@ -357,42 +367,61 @@ __global__ __launch_bounds__(256) void conv_cl_fwd_kernel(const float* __restric
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           int cout, float* __restrict__ y, const int* __restrict__ stop) {
     if (stop && *stop) return;
+    // the weight fragments in LDS, fragment order [nt][p][lane] (one ds_read_b128 per four MFMAs; in registers they are
+    // 128 VGPRs at cout = 32 and left two wavefronts per SIMD to hide the patch gather's latency), and the next tile's
+    // patch words requested one tile ahead
+    __shared__ float4 ws[NT * NP * 64];
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kq = lane >> 4;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    float4 w[NT][NP];
+    for (int e = threadIdx.x; e < NT * NP * 64; e += 256) {
+        const int l = e & 63, p = (e >> 6) % NP, nt = (e >> 6) / NP;
+        const int o = 16 * nt + (l & 15);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < cout) {
+            const float* q = W + ((size_t)o * 16 + 4 * (l >> 4)) * NP + p;       // W[o][c][p], c = 4 kq + s
+            v = make_float4(q[0], q[NP], q[2 * NP], q[3 * NP]);
+        }
+        ws[e] = v;
+    }
     float bv[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int o = 16 * nt + i;
-        bv[nt] = o < cout ? bias[o] : 0.f;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o < cout) {
-                const float* q = W + ((size_t)o * 16 + 4 * kq) * NP + p;       // W[o][c][p], c = 4 kq + s
-                v = make_float4(q[0], q[NP], q[2 * NP], q[3 * NP]);
-            }
-            w[nt][p] = v;
-        }
-    }
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = 16 * nt + i < cout ? bias[16 * nt + i] : 0.f;
+    __syncthreads();
     int poff[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) poff[p] = ((p / g.kw) * g.Win + (p % g.kw)) * 16 + 4 * kq;
     const int P = g.Ho * g.Wo;
     const long long ntiles = (rows + 15) >> 4;
-    for (long long tile = wave; tile < ntiles; tile += nwaves) {
-        long long row = tile * 16 + i;
-        if (row >= rows) row = rows - 1;
-        long long f;
-        int pp;
-        divmod_idx(row, P, rows < (1ll << 31), f, pp);
-        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
-        const float* b = src + ((f * g.Hin + (long long)oy * g.stride) * g.Win + ox * g.stride) * 16;
+    // (named scalars: a loop-carried ARRAY of prefetched words is left in scratch memory by hipcc)
+#define PA_ALL(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define PA_DECL(k) float4 pa##k = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PA_LOAD(k) if (k < NP) pa##k = *reinterpret_cast<const float4*>(b_ + poff[k < NP ? k : 0]);
+#define PA_TAKE(k) if (k < NP) a[k < NP ? k : 0] = pa##k;
+#define PA_REQUEST(T)                                                                                       \
+    do {                                                                                                    \
+        long long row_ = (T) * 16 + i;                                                                      \
+        if (row_ >= rows) row_ = rows - 1;                                                                  \
+        long long f_;                                                                                       \
+        int pp_;                                                                                            \
+        divmod_idx(row_, P, rows < (1ll << 31), f_, pp_);                                                   \
+        const int oy_ = pp_ / g.Wo, ox_ = pp_ - oy_ * g.Wo;                                                 \
+        const float* b_ = src + ((f_ * g.Hin + (long long)oy_ * g.stride) * g.Win + ox_ * g.stride) * 16;  \
+        PA_ALL(PA_LOAD)                                                                                     \
+    } while (0)
+    PA_ALL(PA_DECL)
+    long long tile = wave;
+    if (tile < ntiles) PA_REQUEST(tile);
+    for (; tile < ntiles; tile += nwaves) {
         float4 a[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const float4*>(b + poff[p]);
+        PA_ALL(PA_TAKE)
+        {
+            const long long tn = tile + nwaves < ntiles ? tile + nwaves : tile;
+            PA_REQUEST(tn);
+        }
+        // (always 0, but not to the compiler: the weight reads must stay LDS reads inside the loop)
+        const int z = __builtin_amdgcn_readfirstlane((int)((unsigned long long)tile >> 62));
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -400,10 +429,11 @@ __global__ __launch_bounds__(256) void conv_cl_fwd_kernel(const float* __restric
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                acc[nt] = MFMA16C(a[p].x, w[nt][p].x, acc[nt]);
-                acc[nt] = MFMA16C(a[p].y, w[nt][p].y, acc[nt]);
-                acc[nt] = MFMA16C(a[p].z, w[nt][p].z, acc[nt]);
-                acc[nt] = MFMA16C(a[p].w, w[nt][p].w, acc[nt]);
+                const float4 wv = ws[(nt * NP + p) * 64 + lane + z];
+                acc[nt] = MFMA16C(a[p].x, wv.x, acc[nt]);
+                acc[nt] = MFMA16C(a[p].y, wv.y, acc[nt]);
+                acc[nt] = MFMA16C(a[p].z, wv.z, acc[nt]);
+                acc[nt] = MFMA16C(a[p].w, wv.w, acc[nt]);
             }
         }
 #pragma unroll
@@ -418,6 +448,11 @@ __global__ __launch_bounds__(256) void conv_cl_fwd_kernel(const float* __restric
             }
         }
     }
+#undef PA_ALL
+#undef PA_DECL
+#undef PA_LOAD
+#undef PA_TAKE
+#undef PA_REQUEST
 }
 
 // weight gradient of the same layer: per-WAVEFRONT partials dW[o][(p, c)] (+ db), summed and re-ordered to torch's
