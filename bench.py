@@ -181,7 +181,7 @@ def host_cpu():
             'logical_cpus': logical}
 
 
-def cpu_baseline(mode, params, zstate, batch, budget_s=24.0):
+def cpu_baseline(mode, params, zstate, batch, budget_s=30.0):
     """the reference learner's CPU path (oracle restatement, same ATen ops) on this host, swept over
     torch.set_num_threads (n = physical cores AND n = 1; more threads than the GEMMs
     of a 1024-row epoch can use make it slower, so the best of the sweep is the baseline)"""
@@ -196,18 +196,21 @@ def cpu_baseline(mode, params, zstate, batch, budget_s=24.0):
     for n in counts:
         torch.set_num_threads(n)
         O.learn(copy.deepcopy(batch))        # warm-up at this thread count
-        t0, k = time.time(), 0
-        while k < 1 or (time.time() - t0 < per and k < 20):
+        t0, k, times = time.time(), 0, []
+        while k < 3 or (time.time() - t0 < per and k < 20):      # at least three timed learns per thread count
+            t1 = time.time()
             O.learn(copy.deepcopy(batch))
+            times.append(time.time() - t1)
             k += 1
         dt = (time.time() - t0) / k
-        sweep.append({'threads': n, 's_per_learn': dt, 'env_steps_per_s': B * N / dt, 'learns': k})
+        sweep.append({'threads': n, 's_per_learn': dt, 'env_steps_per_s': B * N / dt, 'learns': k,
+                      's_per_learn_min': min(times), 's_per_learn_max': max(times)})
     torch.set_num_threads(prev)
     best = max(sweep, key=lambda r: r['env_steps_per_s'])
     one = [r for r in sweep if r['threads'] == 1][0]
     return {'value': best['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': best['threads'], 'kind': 'port',
             'sample': 'learn() on the full 1024x128x376 batch (10+10 epochs, %s mode), torch %s CPU, one warm-up + '
-                      '>= 1 timed call per thread count, best of the sweep (%.3f s per learn at %d threads)'
+                      '>= 3 timed calls per thread count, best mean of the sweep (%.3f s per learn at %d threads)'
                       % (mode, torch.__version__, best['s_per_learn'], best['threads']),
             'single_thread': one['env_steps_per_s'], 'sweep': sweep, 'cpu_model': cpu['model'],
             'physical_cores': cpu['physical_cores'], 'logical_cpus': cpu['logical_cpus']}
@@ -372,6 +375,8 @@ def secondaries():
             ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda: secondary_ppo(64, 128, 17, 6, False)),
             ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
              lambda: secondary_ppo(64, 128, 17, 6, True)),
+            ('PPO 1024x128, D=17, A=6, LSTM policy (the reference default at the benchmark batch)',
+             lambda: secondary_ppo(1024, 128, 17, 6, True, steps=3)),
             ('configs[2] DDPG HalfCheetah shapes, uniform replay 1e6, batch 512', secondary_ddpg),
             ('configs[3] PPO 256 actors x 32 steps, 3x84x84 uint8 frames + 32-d state, CNN + LSTM policy',
              lambda: secondary_ppo(256, 32, 32, 8, True, pixel=(3, 84, 84), steps=3))):
