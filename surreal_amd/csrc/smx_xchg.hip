@@ -52,12 +52,19 @@ struct Ctrl {
     long long timeout;   // wall-clock ticks (100 MHz) a wait may take
 };
 
-__host__ __device__ inline long chunk_cap(long capacity, int world) {
-    const long c = (capacity + world - 1) / world;
-    return (c + 3) & ~3L;
-}
+// Layout.  A vector of n floats is cut into W chunks of `chunk` = ceil(n / W) rounded UP to XAL floats; element e of the
+// vector sits at S[e], so the staging must hold W * chunk floats -- up to W * XAL - 1 more than n (zero padding that step
+// 0 really writes).  Sizing S by the capacity alone let that padding run into the head of R[0] (12 floats at 4 ranks, 28
+// at 8): harmless unless a late step-0 workgroup's padding landed after a sibling's step-1 result -- a wrong sum once
+// in many runs under contention.  Chunks, workgroup slices, S and both halves of R are whole 256-byte lines, so no line
+// is ever shared by two writers or two phases.
+constexpr long XAL = 64;
+__host__ __device__ inline long round_up(long v, long a) { return (v + a - 1) / a * a; }
+__host__ __device__ inline long chunk_of(long n, int world) { return round_up((n + world - 1) / world, XAL); }
+__host__ __device__ inline long chunk_cap(long capacity, int world) { return chunk_of(capacity, world); }
+__host__ __device__ inline long staging_floats(long capacity, int world) { return world * chunk_cap(capacity, world); }
 __host__ __device__ inline long total_bytes(long capacity, int world) {
-    return HDR_BYTES + 4L * (((capacity + 3) & ~3L) + 2 * chunk_cap(capacity, world));
+    return HDR_BYTES + 4L * (staging_floats(capacity, world) + 2 * chunk_cap(capacity, world));
 }
 
 struct View {
@@ -72,7 +79,7 @@ __device__ __forceinline__ View view(void* base, long capacity, int world) {
     v.ctrl = (Ctrl*)p;
     v.flags = (unsigned*)(p + CTRL_BYTES);
     v.S = (float*)(p + HDR_BYTES);
-    v.R = v.S + ((capacity + 3) & ~3L);
+    v.R = v.S + staging_floats(capacity, world);
     return v;
 }
 __device__ __forceinline__ unsigned* flag_of(const View& v, int phase, int w) {
@@ -115,9 +122,12 @@ __device__ __forceinline__ bool wait_peers(const smx_xchg_t& X, const View& own,
 }
 
 __device__ __forceinline__ void release_flag(const View& own, int phase, int w, unsigned seq) {
-    __syncthreads();                                  // every lane's stores are issued and acknowledged (vmcnt(0))
+    // barrier (workgroup-scope release/acquire of every lane's stores), then lane 0's SYSTEM-scope release: write back
+    // the L2 + s_waitcnt vmcnt(0) behind the workgroup's stores (a CU's vector memory operations reach the L2 in order;
+    // the fence is cumulative), then the flag
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: write back what the L2 holds
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // "" = system scope
         __hip_atomic_store(flag_of(own, phase, w), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -143,10 +153,8 @@ __global__ __launch_bounds__(XTH) void xchg_allreduce_kernel(smx_xchg_t X, const
     const View own = view(X.peer[X.rank], X.capacity, X.world);
     const unsigned seq = own.ctrl->seq + 1u;
     const int W = X.world, w = blockIdx.x, NB = gridDim.x;
-    long chunk = (n + W - 1) / W;
-    chunk = (chunk + 3) & ~3L;
-    long sub = (chunk + NB - 1) / NB;
-    sub = (sub + 3) & ~3L;
+    const long chunk = chunk_of(n, W);
+    const long sub = round_up((chunk + NB - 1) / NB, XAL);
     const long s0 = (long)w * sub, s1 = s0 + sub < chunk ? s0 + sub : chunk;       // this workgroup's slice of a chunk
     // ---- 0: own input -> S ------------------------------------------------------------------------
     for (int c = 0; c < W; ++c) {
@@ -326,7 +334,7 @@ extern "C" int smx_xchg_allreduce_f32(const smx_xchg_t* x, const float* in, floa
     SMX_REQUIRE(in && out, SMX_E_NULL);
     SMX_REQUIRE(n > 0 && n <= x->capacity, SMX_E_SHAPE);
     SMX_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, SMX_E_ALIGN);
-    const long chunk = ((n + x->world - 1) / x->world + 3) & ~3L;
+    const long chunk = chunk_of(n, x->world);
     hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(blocks_for(chunk)), dim3(XTH), 0, smx_s(stream), *x, in, out, (long)n,
                        (int*)err);
     SMX_LAUNCH_CHECK();

@@ -168,3 +168,19 @@ def test_epoch_supported_mirrors_the_launch_lds_budget():
     # the largest observation the default hidden sizes leave room for is accepted and one 64-column step more is not
     ok = [d for d in range(64, 2049, 64) if lib.smx_epoch_supported(d, 300, 200, 17)]
     assert ok and ok == list(range(64, ok[-1] + 1, 64)) and ok[-1] < 1200
+
+
+def test_peer_exchange_buffer_holds_the_padded_chunks():
+    """smx_xchg_bytes(): the staging holds the vector cut into `world` chunks of ceil(n / world) rounded up to whole
+    256-byte lines -- INCLUDING the padding of the last chunk, which the all-reduce's first step really writes -- plus
+    the two halves of the reduced-chunk buffer behind a 16 KB header.  (Sized by the capacity alone the padding ran
+    into the first reduced chunk: 28 floats at 8 ranks; host-side arithmetic, no GPU needed.)"""
+    from surreal_amd import _lib as L
+    lib = L.load()
+    line = 64                                          # floats
+    for world in range(2, 9):
+        for cap in (1, 3, 63, 64, 65, 4096, 540001, 536278, 10 ** 7 + 1):
+            chunk = -(-(-(-cap // world)) // line) * line
+            assert chunk * world >= cap and chunk % line == 0
+            assert lib.smx_xchg_bytes(cap, world) == 16384 + 4 * (world * chunk + 2 * chunk), (cap, world)
+    assert lib.smx_xchg_bytes(0, 2) == 0 and lib.smx_xchg_bytes(10, 1) == 0 and lib.smx_xchg_bytes(10, 9) == 0

@@ -227,12 +227,18 @@ def _xchg_worker(rank, world, port, q, mode):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
                     step()
-                tot = sum(range(1, world + 1))
-                for _ in range(5):
+                for it in range(24):
+                    # new values every replay: a peer that read the staging before the owner's stores landed would
+                    # see the previous exchange's numbers
+                    src.fill_(float(rank + 1 + it))
+                    src3.fill_(float(rank + 1 + it))
                     g.replay()
                     torch.cuda.synchronize()
-                    assert float(a[0]) == 0.5 * tot * world and float(a[-1]) == 0.5 * tot * world
-                    assert b.cpu().tolist() == [float(r + 1) for r in range(world) for _ in range(3)]
+                    tot = sum(r + 1 + it for r in range(world))
+                    bad = (a != 0.5 * tot * world).nonzero().flatten()
+                    assert bad.numel() == 0, 'replay %d: %d of %d elements wrong, first at %d: %r (want %r), err %#x' % (
+                        it, bad.numel(), n, int(bad[0]), float(a[bad[0]]), 0.5 * tot * world, int(err.item()))
+                    assert b.cpu().tolist() == [float(r + 1 + it) for r in range(world) for _ in range(3)]
                 # how long one 2.1 MB all-reduce takes when the peers arrive together (one GPU: protocol cost only)
                 dist.barrier()
                 t0 = time.perf_counter()
@@ -294,7 +300,7 @@ def _run_xchg(world, mode):
     return res
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_peer_exchange_is_the_rank_ordered_sum_and_replays_in_a_graph(world):
     res = _run_xchg(world, 'protocol')
     print('\\npeer exchange, %d ranks on one GPU: memory %s, %.1f us per captured graph of 3 exchanges (2.1 MB all-reduce x 2 '
