@@ -328,6 +328,38 @@ __global__ __launch_bounds__(256) void conv_u8_wgrad_kernel(const unsigned char*
             ((dbs[0][threadIdx.x] + dbs[1][threadIdx.x]) + dbs[2][threadIdx.x]) + dbs[3][threadIdx.x];
 }
 
+// The split partials of a weight gradient summed in a fixed order on a 2-D grid: a workgroup owns RED_EL consecutive
+// elements, its 256 threads are RED_EL elements x RED_SL slices of the partial index; a thread sums its slice on four
+// interleaved chains, the slices are combined through LDS in slice order.  (One thread per element walking all 512 - 1024
+// partials was 13 - 33 workgroups on 256 CUs: 41 / 66 us per launch, 2 ms per learn at configs[3].)
+constexpr int RED_EL = 16, RED_SL = 256 / RED_EL;
+__device__ __forceinline__ float reduce_slices(const float* __restrict__ src, size_t stride, int splits, bool valid) {
+    __shared__ float red[RED_SL][RED_EL];
+    const int el = threadIdx.x % RED_EL, sl = threadIdx.x / RED_EL;
+    const int per = (splits + RED_SL - 1) / RED_SL;
+    const int s0 = sl * per, s1 = s0 + per < splits ? s0 + per : splits;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (valid) {
+        int sidx = s0;
+        for (; sidx + 3 < s1; sidx += 4) {
+            v0 += src[(size_t)sidx * stride];
+            v1 += src[(size_t)(sidx + 1) * stride];
+            v2 += src[(size_t)(sidx + 2) * stride];
+            v3 += src[(size_t)(sidx + 3) * stride];
+        }
+        for (; sidx < s1; ++sidx) v0 += src[(size_t)sidx * stride];
+    }
+    red[sl][el] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    float v = 0.f;
+    if (sl == 0) {
+        v = red[0][el];
+#pragma unroll
+        for (int j = 1; j < RED_SL; ++j) v += red[j][el];
+    }
+    return v;
+}
+
 // out[e] = sum over s of part[s][e], fixed order
 __global__ __launch_bounds__(256) void conv_partial_reduce_kernel(const float* __restrict__ part,
                                                                   const float* __restrict__ dbpart, int splits,
@@ -335,20 +367,12 @@ __global__ __launch_bounds__(256) void conv_partial_reduce_kernel(const float* _
                                                                   float* __restrict__ db,
                                                                   const int* __restrict__ stop) {
     if (stop && *stop) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nW + nB) return;
+    const int e = blockIdx.x * RED_EL + threadIdx.x % RED_EL;
+    const bool valid = e < nW + nB;
     const float* src = e < nW ? part + e : dbpart + (e - nW);
     const int stride = e < nW ? nW : nB;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;          // four interleaved chains, combined in a fixed order
-    int sidx = 0;
-    for (; sidx + 3 < splits; sidx += 4) {
-        v0 += src[(size_t)sidx * stride];
-        v1 += src[(size_t)(sidx + 1) * stride];
-        v2 += src[(size_t)(sidx + 2) * stride];
-        v3 += src[(size_t)(sidx + 3) * stride];
-    }
-    for (; sidx < splits; ++sidx) v0 += src[(size_t)sidx * stride];
-    const float v = (v0 + v1) + (v2 + v3);
+    const float v = reduce_slices(src, (size_t)stride, splits, valid);
+    if (threadIdx.x >= RED_EL || !valid) return;
     if (e < nW) dW[e] = v;
     else if (db) db[e - nW] = v;
 }
@@ -584,7 +608,7 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_kernel(const float* __restr
     }
 }
 
-// dW[o][c][p] = sum over the wavefront partials of part[s][o][(p, c)]; db likewise.  Fixed order.
+// dW[o][c][p] = sum over the wavefront partials of part[s][o][(p, c)]; db likewise.  Fixed order (reduce_slices).
 __global__ __launch_bounds__(256) void conv_cl_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                    const float* __restrict__ dbpart, int splits,
                                                                    int OP /* 16 NT */, int NP, int cout,
@@ -593,20 +617,12 @@ __global__ __launch_bounds__(256) void conv_cl_wgrad_reduce_kernel(const float* 
     if (stop && *stop) return;
     const int K = 16 * NP;
     const int nW = OP * K;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nW + OP) return;
+    const int e = blockIdx.x * RED_EL + threadIdx.x % RED_EL;
+    const bool valid = e < nW + OP;
     const float* srcp = e < nW ? part + e : dbpart + (e - nW);
     const int stride = e < nW ? nW : OP;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    int sidx = 0;
-    for (; sidx + 3 < splits; sidx += 4) {
-        v0 += srcp[(size_t)sidx * stride];
-        v1 += srcp[(size_t)(sidx + 1) * stride];
-        v2 += srcp[(size_t)(sidx + 2) * stride];
-        v3 += srcp[(size_t)(sidx + 3) * stride];
-    }
-    for (; sidx < splits; ++sidx) v0 += srcp[(size_t)sidx * stride];
-    const float v = (v0 + v1) + (v2 + v3);
+    const float v = reduce_slices(srcp, (size_t)stride, splits, valid);
+    if (threadIdx.x >= RED_EL || !valid) return;
     if (e < nW) {
         const int o = e / K, pc = e - o * K;
         const int p = pc >> 4, c = pc & 15;
@@ -945,7 +961,7 @@ extern "C" int smx_conv_u8_wgrad_f32(const void* frames, int64_t F, int32_t C, i
                        stop_flag);
     SMX_LAUNCH_CHECK();
     const int n = cout * K + cout;
-    hipLaunchKernelGGL(conv_partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream),
+    hipLaunchKernelGGL(conv_partial_reduce_kernel, dim3((unsigned)((n + RED_EL - 1) / RED_EL)), dim3(256), 0, smx_s(stream),
                        part, dbpart, blocks, cout * K, cout, dW, db, stop_flag);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
@@ -1009,7 +1025,7 @@ extern "C" int smx_conv_cl_wgrad_f32(const float* src, int64_t F, int32_t C, int
                        dbpart, stop_flag);
     SMX_LAUNCH_CHECK();
     const int n = OP * 16 * NP + OP;
-    hipLaunchKernelGGL(conv_cl_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream),
+    hipLaunchKernelGGL(conv_cl_wgrad_reduce_kernel, dim3((unsigned)((n + RED_EL - 1) / RED_EL)), dim3(256), 0, smx_s(stream),
                        part, dbpart, blocks * 4, OP, NP, cout, dW, db, stop_flag);
     SMX_LAUNCH_CHECK();
     return SMX_OK;

@@ -9,6 +9,7 @@
 // sum-of-squares for clip_grad_norm_) is fused.  Up to 6 problems are grouped into one launch.
 #include "smx_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -487,6 +488,162 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmBatch G) {
     }
 }
 
+// Throughput variant for the stems' big layers (M >= 2048 rows AND N >= 64: the Linear behind the convolutions,
+// 7168 x 2592 x 256, the LSTM's input projection and the MLP on top of it over B*T rows).  gemm_rows_kernel reads both
+// operands of every 32 x 32 wave tile straight from L2 in fragment order -- 64 operand words per 1024 MACs, 32 cache
+// lines per load instruction -- and sits at 30 - 50 TFLOP/s there.  Here a workgroup owns a (64 TM) x (64 TN) tile, its
+// 2 x 2 wavefronts a (32 TM) x (32 TN) quarter each; a 32-wide K block of both operands is fetched as whole 128-byte
+// segments (coalesced), staged in LDS (double-buffered: the global loads of block k + 1 are in flight under the MFMAs
+// of block k, one barrier per block) and read back as fragments.  The fragment mapping and the K order are those of
+// gemm_rows_kernel (pairs (k, k + 4) inside 8-wide groups, blocks ascending), so every output is the SAME sum in the
+// same order: the two kernels are bit-identical and the host may pick either by shape.
+// Operand storage: MODE 0 (K-contiguous, 16-byte aligned) -> LDS rows of 36 floats, fragments by ds_read_b128;
+// MODE 2 (K-strided: X(r, k) = X[k ld + r], ld % 4 == 0, aligned) -> LDS [k][rows + 4], fragments by four ds_read_b32.
+template <int MODE, int R>            // R rows of the operand per workgroup tile
+struct TileStage {
+    static constexpr int NV = R * 32 / 4 / 256;                        // 16-byte words per thread and K block
+    static constexpr int LDS_FLOATS = MODE == 0 ? R * 36 : 32 * (R + 4);
+    unsigned off[NV];                                                   // byte offset of the word at K block 0, or OOB
+    int kk[NV];                                                         // its k inside the block
+    int wofs[NV];                                                       // where it goes in the LDS tile (floats)
+    unsigned kstep;                                                     // bytes per k
+    __device__ __forceinline__ void init(int ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (MODE == 0) {
+                const int r = (tid >> 3) + 32 * j, ks = 4 * (tid & 7);
+                off[j] = row0 + r < nrows ? ((unsigned)(row0 + r) * (unsigned)ld + (unsigned)ks) * 4u : OOB;
+                kk[j] = ks;
+                wofs[j] = r * 36 + ks;
+            } else {
+                constexpr int TPR = R / 4;                              // threads per k row
+                const int rs = 4 * (tid % TPR), k = tid / TPR + (256 / TPR) * j;
+                off[j] = row0 + rs < nrows ? ((unsigned)k * (unsigned)ld + (unsigned)(row0 + rs)) * 4u : OOB;
+                kk[j] = k;
+                wofs[j] = k * (R + 4) + rs;
+            }
+        }
+        kstep = MODE == 0 ? 4u : (unsigned)ld * 4u;
+    }
+    __device__ __forceinline__ void load(u32x4 (&w)[NV], rsrc_t rs, int kb, int K) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool in = kb + kk[j] < K && off[j] != OOB;
+            w[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, in ? off[j] + (unsigned)kb * kstep : OOB, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(const u32x4 (&w)[NV], float* tile) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) *(u32x4*)(tile + wofs[j]) = w[j];
+    }
+    // fragment of the 8-wide k group q for the 32 rows at `r0` of the tile: lane (i, kh) <- X(r0 + i, 8 q + 4 kh + 0..3)
+    static __device__ __forceinline__ float4 frag(const float* tile, int r0, int i, int kh, int q) {
+        if (MODE == 0) return *(const float4*)(tile + (r0 + i) * 36 + 8 * q + 4 * kh);
+        const float* t = tile + (8 * q + 4 * kh) * (R + 4) + r0 + i;
+        return make_float4(t[0], t[R + 4], t[2 * (R + 4)], t[3 * (R + 4)]);
+    }
+};
+
+template <int AM, int BM, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
+    constexpr int RM = 64 * TM, RN = 64 * TN;
+    typedef TileStage<AM, RM> SA;
+    typedef TileStage<BM, RN> SB;
+    extern __shared__ float lds_tile[];
+    constexpr int BUF = SA::LDS_FLOATS + SB::LDS_FLOATS;                 // one buffer: [A tile | B tile]
+    const TileBases TB = load_tile_bases(G);
+    // XCD-aware order: consecutive workgroup ids go round the 8 XCDs; give each XCD a contiguous run of tiles so that
+    // the tiles sharing an operand block meet in ONE L2
+    const int grid = TB.grid, per = grid >> 3, rem = grid & 7;
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    const GemmProb P = select_problem(G, TB, bid);
+    const int stopv = stop_load(P);
+    const int tile = bid - P.tile_base;
+    const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int m0 = tm * RM, n0 = tn * RN;
+    const int wm0 = (wv >> 1) * 32 * TM, wn0 = (wv & 1) * 32 * TN;       // this wave's quarter inside the tile
+    const rsrc_t ra = make_rsrc(P.A, P.a_bytes), rb = make_rsrc(P.B, P.b_bytes);
+    SA sa;
+    SB sb;
+    sa.init(P.lda, m0, P.M, tid);
+    sb.init(P.ldb, n0, P.N, tid);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nkb = (P.K + 31) >> 5;
+    u32x4 wa[SA::NV], wb[SB::NV];
+    sa.load(wa, ra, 0, P.K);
+    sb.load(wb, rb, 0, P.K);
+    sa.store(wa, lds_tile);
+    sb.store(wb, lds_tile + SA::LDS_FLOATS);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const float* tA = lds_tile + (kb & 1) * BUF;
+        const float* tB = tA + SA::LDS_FLOATS;
+        if (kb + 1 < nkb) {                                              // wave-uniform
+            sa.load(wa, ra, (kb + 1) * 32, P.K);
+            sb.load(wb, rb, (kb + 1) * 32, P.K);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = SA::frag(tA, wm0 + 32 * a, i, kh, q);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = SB::frag(tB, wn0 + 32 * b, i, kh, q);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(fa[a].x, fb[b].x, acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(fa[a].y, fb[b].y, acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(fa[a].z, fb[b].z, acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = MFMA32(fa[a].w, fb[b].w, acc[a][b]);
+        }
+        if (kb + 1 < nkb) {
+            float* nA = lds_tile + ((kb + 1) & 1) * BUF;
+            sa.store(wa, nA);
+            sb.store(wb, nA + SA::LDS_FLOATS);
+        }
+        __syncthreads();
+    }
+    if (stop_taken(stopv)) return;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn0 + 32 * b + i;
+        if (n >= P.N) continue;
+        const float bias = P.bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < P.M) {
+                    float v = act_f(acc[a][b][r] + bias, P.act);
+                    if (P.mask) v = (P.mask[(size_t)m * P.ldc + n] > 0.f) ? v : 0.f;
+                    P.C[(size_t)m * P.ldc + n] = v;
+                    if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
+                }
+            }
+    }
+}
+
 inline unsigned long long operand_bytes(int ld, int kc, int nrows, int K) {
     return kc ? 4ull * ((unsigned long long)(nrows - 1) * ld + K)
               : 4ull * ((unsigned long long)(K - 1) * ld + nrows);
@@ -516,13 +673,74 @@ inline bool prob_ok(const GemmProb& P) {
            operand_bytes(P.ldb, P.b_kc, P.N, Kc) < (1ull << 31);
 }
 
+// gemm_tile_kernel: eligible when every problem of the batch has the same operand storage out of {K-contiguous aligned,
+// K-strided with ld % 4 == 0 and an aligned base}, N >= 64 and K >= 32.
+template <int AM, int BM, int TM, int TN>
+inline int launch_tile_variant(GemmBatch& G, hipStream_t st) {
+    int base = 0;
+    for (int k = 0; k < G.n; ++k) {
+        G.p[k].tiles_m = (G.p[k].M + 64 * TM - 1) / (64 * TM);
+        G.p[k].tiles_n = (G.p[k].N + 64 * TN - 1) / (64 * TN);
+        G.p[k].tile_base = base;
+        base += G.p[k].tiles_m * G.p[k].tiles_n;
+    }
+    const size_t lds = 2 * sizeof(float) * (size_t)(TileStage<AM, 64 * TM>::LDS_FLOATS + TileStage<BM, 64 * TN>::LDS_FLOATS);
+    auto kern = gemm_tile_kernel<AM, BM, TM, TN>;
+    static bool attr_done = false;                        // per instantiation
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(base), dim3(256), lds, st, G);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SMX_OK : (int)e;
+}
+
+// Tile shape: 64 x 64 (TM = TN = 1, 32 x 32 per wavefront).  Measured on the stems' shapes (scripts/bench_gemm_tile.py):
+// 7168 x 256 x 2592: 85 TFLOP/s against 81 (128 x 64) and 48 (128 x 128); 7168 x 2592 x 256: 75 / 54 / 52; 131072 x 300 x
+// 100: 57 / 48 / 42 -- with one K block of look-ahead the bigger tiles' 2 - 3 workgroups per CU cannot cover a workgroup's
+// load -> LDS -> barrier bubble, the small tile's 6 - 7 can.  (gemm_rows_kernel on the same three: 59 / 47 / 35.)
+template <int AM, int BM>
+inline int launch_tile_modes(GemmBatch& G, hipStream_t st) {
+    return launch_tile_variant<AM, BM, 1, 1>(G, st);
+}
+
+inline bool tile_mode_of(const float* X, int ld, int kc, int mode, int& out) {
+    if (kc) { out = 0; return mode == 0; }
+    out = 2;
+    return ld % 4 == 0 && ((uintptr_t)X & 15) == 0;
+}
+
+// -> true when the batch was taken (rc = the launch's result)
+inline bool launch_tiles(GemmBatch& G, hipStream_t st, int& rc) {
+    static const bool off = getenv("SMX_GEMM_ROWS_ONLY") != nullptr;     // A/B switch for measurements
+    if (off) return false;
+    int am = -1, bm = -1;
+    for (int k = 0; k < G.n; ++k) {
+        const GemmProb& P = G.p[k];
+        int a, b;
+        if (!tile_mode_of(P.A, P.lda, P.a_kc, P.a_mode, a) || !tile_mode_of(P.B, P.ldb, P.b_kc, P.b_mode, b)) return false;
+        if (P.N < 64 || P.K < 32) return false;
+        if (k && (a != am || b != bm)) return false;
+        am = a; bm = b;
+    }
+    if (am == 0 && bm == 0) rc = launch_tile_modes<0, 0>(G, st);
+    else if (am == 0 && bm == 2) rc = launch_tile_modes<0, 2>(G, st);
+    else if (am == 2 && bm == 0) rc = launch_tile_modes<2, 0>(G, st);
+    else rc = launch_tile_modes<2, 2>(G, st);
+    return true;
+}
+
 inline int launch_batch(GemmBatch& G, hipStream_t st) {
     for (int k = 0; k < G.n; ++k)
         if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
     bool rows_variant = true;
+    int rc_tiles = SMX_OK;
     for (int k = 0; k < G.n; ++k)
         rows_variant = rows_variant && G.p[k].M >= 2048 && !G.p[k].dbias && !G.p[k].sumsq &&
                        G.p[k].splits == 1;
+    if (rows_variant && launch_tiles(G, st, rc_tiles)) return rc_tiles;
     if (rows_variant) {
         int base = 0;
         for (int k = 0; k < G.n; ++k) {

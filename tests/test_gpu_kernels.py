@@ -1,6 +1,7 @@
 """GPU tier (-m gpu): every HIP entry point, called through the C ABI, against the torch-CPU
 statement of the same contract (tests/cpu_kernels.py) on identical seeded inputs.
 Tolerance: 1e-5 absolute + 1e-5 relative (fp32), the north-star bound."""
+import os
 import types
 
 import numpy as np
@@ -1054,6 +1055,37 @@ def test_act_env_step_head_equals_separate_launches(K):
         for k in outs[0]:
             np.testing.assert_allclose(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy(), rtol=1e-5, atol=1e-6,
                                        err_msg=k)
+
+
+def test_linear_tile_kernel_matches_fp64_and_the_rows_kernel_bit_for_bit(K, tmp_path):
+    """the LDS-tiled throughput GEMM (gemm_tile_kernel: M >= 2048 rows, N >= 64, K >= 32; all four operand storage
+    combinations, three tile shapes, ragged M / N / K, bias + ReLU / tanh / ReLU-mask epilogues) against a float64 GEMM,
+    and against gemm_rows_kernel run in a subprocess (SMX_GEMM_ROWS_ONLY=1): same fragment mapping and K order, so the
+    SAME BITS -- the host picks either by shape without moving a golden"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'diag'))
+    import gemm_tile_cases as GC
+    outs = GC.run_cases(K)
+    for (M, N, Kd, akc, bkc, bias, act, mask), (A, B, b, mk, C) in zip(GC.CASES, outs):
+        assert not bool(torch.isnan(C).any()), (M, N, Kd)
+        rows = torch.cat([torch.arange(0, 160), torch.arange(M // 2, M // 2 + 160), torch.arange(M - 160, M)]).cuda()
+        Ad = (A[rows] if akc else A[:, rows].t()).double()
+        Bd = (B if bkc else B.t()).double()
+        want = Ad @ Bd.t()
+        if b is not None:
+            want = want + b.double()
+        want = torch.relu(want) if act == 1 else torch.tanh(want) if act == 2 else want
+        if mk is not None:
+            want = want * mk[rows].double()
+        np.testing.assert_allclose(C[rows].cpu().numpy(), want.float().cpu().numpy(), rtol=2e-5, atol=2e-5,
+                                   err_msg=str((M, N, Kd, akc, bkc)))
+    ref = str(tmp_path / 'rows_kernel.npz')
+    env = dict(os.environ, SMX_GEMM_ROWS_ONLY='1')
+    subprocess.run([sys.executable, GC.__file__, ref], check=True, env=env, timeout=600)
+    got = np.load(ref)
+    for ci, o in enumerate(outs):
+        assert np.array_equal(o[-1].cpu().numpy(), got['c%d' % ci]), 'case %d: tile and rows kernels differ' % ci
 
 
 def test_linear_cuts_operands_past_2gib_into_row_blocks(K):
