@@ -210,6 +210,15 @@ int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, const float* h1
                           const float* h2, const float* dz3, int64_t rows, float* dz2,
                           float* dz1, float* grads, float* sumsq_partials,
                           const int32_t* stop_flag, smx_stream_t stream);
+/* The same for MANY rows (the MLP on top of an LSTM / CNN stem runs over B x T rows, loss.backward() of
+ * surreal/learner/ppo.py:227-353 with surreal/model/ppo_net.py:143-152 in front): the rows of every weight gradient are cut
+ * into chunks (one workgroup per (tile, chunk), partial tiles in ws), one segmented reduce forms the six gradients in a
+ * fixed order.  ws: smx_mlp3_backward_ws_floats() floats (0: few rows, no split); with ws == NULL or too small this IS
+ * smx_mlp3_backward_f32 without sum-of-squares partials. */
+int64_t smx_mlp3_backward_ws_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT, int64_t rows);
+int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
+                                 const float* dz3, int64_t rows, float* dz2, float* dz1, float* grads, float* ws,
+                                 int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream);
 
 /* --- windowed GAE / n-step returns (surreal/learner/ppo.py:387-418) ----------
  * values [B,N+1] RAW critic outputs -- or, when values_tail != NULL, values [B,N] for the N

@@ -842,6 +842,50 @@ extern "C" int smx_linear_wgrad_f32(const float* dZ, int32_t ldz, const float* X
 // ---------------------------------------------------------------------------
 namespace {
 
+// Partial sums of SEVERAL split-K problems reduced in one launch: segment g is `count` consecutive elements whose
+// partial s sits at src + s * stride; 16 elements x 16 slices of the split index per workgroup, slices combined through
+// LDS in slice order (deterministic).
+struct RedSeg {
+    const float* src;
+    float* dst;
+    int base, stride;
+};
+struct RedSegs {
+    RedSeg g[6];
+    int n, total;
+};
+__global__ __launch_bounds__(256) void segmented_reduce_kernel(RedSegs L, int splits, const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    __shared__ float red[16][16];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const bool valid = e < L.total;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) gi += (k < L.n && e >= L.g[k].base) ? 1 : 0;
+    const RedSeg G = L.g[gi];
+    const float* src = G.src + (e - G.base);
+    const int per = (splits + 15) >> 4;
+    const int s0 = sl * per, s1 = s0 + per < splits ? s0 + per : splits;
+    float v0 = 0.f, v1 = 0.f;
+    if (valid) {
+        int sidx = s0;
+        for (; sidx + 1 < s1; sidx += 2) {
+            v0 += src[(size_t)sidx * G.stride];
+            v1 += src[(size_t)(sidx + 1) * G.stride];
+        }
+        if (sidx < s1) v0 += src[(size_t)sidx * G.stride];
+    }
+    red[sl][el] = v0 + v1;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        float v = red[0][el];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) v += red[j][el];
+        G.dst[e - G.base] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part,
                                                             const float* __restrict__ dbpart,
                                                             int splits, int M, int N,
@@ -1063,4 +1107,93 @@ extern "C" int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, cons
     J.stop_flag = stop_flag;
     SMX_REQUIRE(net, SMX_E_NULL);
     return smx_mlp3_backward_multi_f32(&J, 1, stream);
+}
+
+// The same over MANY rows (the stems' MLPs: rows = B x T ~ 10^4 - 10^5).  smx_mlp3_backward_f32 gives each 32 x 32 tile
+// of a weight gradient to ONE workgroup that walks every row -- 117 workgroups at [300, 200] hidden sizes, 58 us at
+// 7936 rows, 0.9 ms at 127 k.  Here the rows are cut into S chunks ((tile, chunk) -> a workgroup, partial tiles in the
+// caller's workspace) and ONE segmented reduce forms the six gradients.  No sum-of-squares partials (the stem path takes
+// the norm of the whole parameter group afterwards).
+static int mlp3_splits(const smx_mlp3_t* n, int64_t rows) {
+    const int t = ((n->H1 + 31) / 32) * ((n->D + 31) / 32) + ((n->H2 + 31) / 32) * ((n->H1 + 31) / 32) +
+                  ((n->OUT + 31) / 32) * ((n->H2 + 31) / 32);
+    long s = rows / 1024;
+    const long cap = 4096 / t > 1 ? 4096 / t : 1;
+    if (s > cap) s = cap;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : (int)s;
+}
+static int64_t mlp3_numel(const smx_mlp3_t* n) {
+    return (int64_t)n->H1 * n->D + n->H1 + (int64_t)n->H2 * n->H1 + n->H2 + (int64_t)n->OUT * n->H2 + n->OUT;
+}
+
+extern "C" int64_t smx_mlp3_backward_ws_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT, int64_t rows) {
+    smx_mlp3_t n;
+    memset(&n, 0, sizeof(n));
+    n.D = D; n.H1 = H1; n.H2 = H2; n.OUT = OUT;
+    if (D <= 0 || H1 <= 0 || H2 <= 0 || OUT <= 0 || rows <= 0) return 0;
+    const int S = mlp3_splits(&n, rows);
+    return S > 1 ? (int64_t)S * mlp3_numel(&n) : 0;
+}
+
+extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
+                                            const float* dz3, int64_t rows, float* dz2, float* dz1, float* grads,
+                                            float* ws, int64_t ws_floats, const int32_t* stop_flag,
+                                            smx_stream_t stream) {
+    SMX_REQUIRE(net && x && h1 && h2 && dz3 && dz2 && dz1 && grads, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && rows < (1 << 30), SMX_E_SHAPE);
+    int S = mlp3_splits(net, rows);
+    if (S <= 1 || !ws || ws_floats < (int64_t)S * mlp3_numel(net))
+        return smx_mlp3_backward_f32(net, x, h1, h2, dz3, rows, dz2, dz1, grads, nullptr, stop_flag, stream);
+    const int R = (int)rows, D = net->D, H1 = net->H1, H2 = net->H2, O = net->OUT;
+    // dz2 = (dz3 . W3) * relu'(h2), dz1 = (dz2 . W2) * relu'(h1): as smx_mlp3_backward_multi_f32
+    for (int stage = 0; stage < 2; ++stage) {
+        GemmBatch G;
+        G.n = 1;
+        if (stage == 0)
+            fill_prob(G.p[0], dz3, O, 1, net->W3, H2, 0, nullptr, h2, dz2, H2, R, H2, O, SMX_ACT_NONE, nullptr, nullptr, 0,
+                      stop_flag);
+        else
+            fill_prob(G.p[0], dz2, H2, 1, net->W2, H1, 0, nullptr, h1, dz1, H1, R, H1, H2, SMX_ACT_NONE, nullptr, nullptr,
+                      0, stop_flag);
+        const int rc = launch_batch(G, smx_s(stream));
+        if (rc) return rc;
+    }
+    int k_chunk = ((R + S - 1) / S + 31) & ~31;
+    while ((long)(S - 1) * k_chunk >= R) --S;                 // every chunk non-empty
+    const float* dz[3] = {dz1, dz2, dz3};
+    const float* in[3] = {x, h1, h2};
+    const int Ms[3] = {H1, H2, O}, Ns[3] = {D, H1, H2};
+    float* gdst = grads;
+    float* wsp = ws;
+    GemmBatch G;
+    G.n = 3;
+    RedSegs L;
+    L.n = 6;
+    int base = 0, ebase = 0;
+    for (int l = 0; l < 3; ++l) {
+        const int M = Ms[l], N = Ns[l];
+        float* wpart = wsp;
+        float* bpart = wsp + (size_t)S * M * N;
+        wsp = bpart + (size_t)S * M;
+        fill_prob(G.p[l], dz[l], M, 0, in[l], N, 0, nullptr, nullptr, wpart, N, M, N, R, SMX_ACT_NONE, bpart, nullptr, base,
+                  stop_flag);
+        G.p[l].splits = S;
+        G.p[l].k_chunk = k_chunk;
+        G.p[l].c_split = (long)M * N;
+        base += G.p[l].tiles_m * G.p[l].tiles_n * S;
+        L.g[2 * l] = RedSeg{wpart, gdst, ebase, M * N};
+        ebase += M * N;
+        gdst += (size_t)M * N;
+        L.g[2 * l + 1] = RedSeg{bpart, gdst, ebase, M};
+        ebase += M;
+        gdst += M;
+    }
+    L.total = ebase;
+    const int rc = launch_batch(G, smx_s(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(segmented_reduce_kernel, dim3((unsigned)((L.total + 15) / 16)), dim3(256), 0, smx_s(stream), L, S,
+                       stop_flag);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
 }

@@ -131,10 +131,20 @@ class HipKernels(object):
     def mlp3_backward_partials(self, net):
         return self.lib.smx_mlp3_backward_partials(net.D, net.H1, net.H2, net.OUT)
 
-    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None):
+    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None, ws=None):
+        """ws: optional split-K workspace (>= mlp3_backward_ws_floats(net, rows) floats) for many-row calls that do
+        not need the sum-of-squares partials: the weight gradients' rows are cut into chunks"""
+        if ws is not None and sumsq is None:
+            L.call('smx_mlp3_backward_splitk_f32', ctypes.byref(net.desc), L.ptr(x), L.ptr(h1), L.ptr(h2),
+                   L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1), L.ptr(grads), L.ptr(ws), ws.numel(),
+                   L.ptr(stop), self._st())
+            return
         L.call('smx_mlp3_backward_f32', ctypes.byref(net.desc), L.ptr(x), L.ptr(h1), L.ptr(h2),
                L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1), L.ptr(grads), L.ptr(sumsq),
                L.ptr(stop), self._st())
+
+    def mlp3_backward_ws_floats(self, net, rows):
+        return int(self.lib.smx_mlp3_backward_ws_floats(net.D, net.H1, net.H2, net.OUT, int(rows)))
 
     # ---- fused row-block epoch kernels (csrc/smx_epoch.hip) ------------------------------
     def epoch_supported(self, *nets):

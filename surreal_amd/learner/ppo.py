@@ -392,6 +392,8 @@ class PPOLearner(Learner):
             ws.ztmp = f(R1, D)
             ws.lcat, ws.xcat = f(B, N + 1, D), f(R1, Dx)     # critic pass over cat(obs, obs_next)
             ws.h1G, ws.h2G = f(R1, cri.H1), f(R1, cri.H2)
+            n_sk = max(K.mlp3_backward_ws_floats(n, rows) for n in (act, cri))
+            ws.mlp_sk = f(n_sk) if n_sk else None          # split-K partials of the MLP weight gradients over B x T rows
             if rnn:
                 # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E)
                 # and for the critic pass (T = N + 1, ppo.py:376-386)
@@ -1228,7 +1230,7 @@ class PPOLearner(Learner):
         B, E, D = ws.key[0], ws.E, ws.key[2]
         top = ws.upper[-1] if (m.if_rnn and ws.upper) else ws
         x = top.lo if m.if_rnn else ws.xn
-        K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop)
+        K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop, ws=ws.mlp_sk)
         if m.if_rnn:
             # d loss / d (LSTM output) = dz1 . W1, then BPTT (dgates overwrite the saved gates)
             F = m.rnn_hidden

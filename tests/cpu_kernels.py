@@ -134,7 +134,10 @@ class TorchCpuKernels(object):
         t = lambda a: (a + 31) // 32  # noqa: E731
         return t(net.H1) * t(net.D) + t(net.H2) * t(net.H1) + t(net.OUT) * t(net.H2)
 
-    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None):
+    def mlp3_backward_ws_floats(self, net, rows):
+        return 0
+
+    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None, ws=None):
         if stop is not None and int(stop[0]) != 0:
             return
         v = net.views

@@ -168,6 +168,45 @@ def test_mlp3_forward_backward(K, rows, D, H1, H2, OUT, act):
     assert float(od.min()) == 7.0
 
 
+@pytest.mark.parametrize('rows,D,H1,H2,OUT', [(7936, 100, 300, 200, 6), (2100, 17, 64, 40, 1), (40000, 132, 300, 200, 12),
+                                              (1500, 100, 300, 200, 6)])
+def test_mlp3_backward_splitk_over_many_rows(K, rows, D, H1, H2, OUT):
+    """the stems' MLP backward over B x T rows: weight-gradient rows cut into chunks + ONE segmented reduce
+    (smx_mlp3_backward_splitk_f32) against a float64 statement of loss.backward() and against the unsplit entry point;
+    few rows (no workspace needed) take the unsplit path and must equal it bit for bit; a raised stop flag leaves the
+    gradients untouched"""
+    _, nd = make_net(D, H1, H2, OUT, rows + D, 'cuda')
+    g = torch.Generator(device='cuda').manual_seed(rows)
+    x = torch.randn(rows, D, device='cuda', generator=g)
+    f = lambda *s: torch.empty(*s, device='cuda')  # noqa: E731
+    h1, h2, out = f(rows, H1), f(rows, H2), f(rows, OUT)
+    K.mlp3_forward(nd, x, h1, h2, out, L.SMX_ACT_NONE)
+    dz3 = torch.randn(rows, OUT, device='cuda', generator=g) / rows
+    n = nd.numel
+    nws = K.mlp3_backward_ws_floats(nd, rows)
+    assert (nws > 0) == (rows >= 2048) and nws % n == 0
+    ws = f(max(nws, 1))
+    g_split, g_plain = torch.full((n,), float('nan'), device='cuda'), torch.zeros(n, device='cuda')
+    dz2a, dz1a, dz2b, dz1b = f(rows, H2), f(rows, H1), f(rows, H2), f(rows, H1)
+    K.mlp3_backward(nd, x, h1, h2, dz3, dz2a, dz1a, g_split, None, ws=ws)
+    K.mlp3_backward(nd, x, h1, h2, dz3, dz2b, dz1b, g_plain, None)
+    assert torch.equal(dz2a, dz2b) and torch.equal(dz1a, dz1b)
+    v = nd.views
+    d3 = dz3.double()
+    d2 = (d3 @ v['W3'].double()) * (h2 > 0)
+    d1 = (d2 @ v['W2'].double()) * (h1 > 0)
+    want = torch.cat([t.reshape(-1) for t in (d1.t() @ x.double(), d1.sum(0), d2.t() @ h1.double(), d2.sum(0),
+                                              d3.t() @ h2.double(), d3.sum(0))]).float()
+    close(g_split, want, atol=2e-6, rtol=2e-5, msg='split-K grads vs float64')
+    close(g_plain, want, atol=2e-6, rtol=2e-5, msg='unsplit grads vs float64')
+    if nws == 0:
+        assert torch.equal(g_split, g_plain)
+    stop = torch.ones(1, dtype=torch.int32, device='cuda')
+    g_split.fill_(3.0)
+    K.mlp3_backward(nd, x, h1, h2, dz3, dz2a, dz1a, g_split, None, stop, ws=ws)
+    assert float(g_split.min()) == 3.0 and float(g_split.max()) == 3.0
+
+
 @pytest.mark.parametrize('G,T0,T1,D,H1,H2,OUT,z', [
     (8, 12, 1, 11, 24, 16, 1, True), (37, 19, 1, 29, 40, 24, 1, True),
     (5, 7, 0, 16, 64, 64, 6, False), (64, 128, 1, 17, 300, 200, 1, True),
