@@ -559,18 +559,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
     const int bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
     const GemmProb P = select_problem(G, TB, bid);
     const int stopv = stop_load(P);
-    const int tile = bid - P.tile_base;
+    int tile = bid - P.tile_base;
+    // split-K (weight gradients over 10^4 - 10^5 rows): `splits` workgroups share an output tile, each sums its own K
+    // chunk into its own slice of C (and of dbias), as in gemm32_kernel
+    int sp = 0;
+    KRange R;
+    R.A = P.A; R.B = P.B; R.a_bytes = P.a_bytes; R.b_bytes = P.b_bytes; R.K = P.K;
+    if (P.splits > 1) {
+        sp = tile % P.splits;
+        tile /= P.splits;
+        const int k0 = sp * P.k_chunk;
+        R.K = min(P.k_chunk, P.K - k0);
+        R.A = P.A + (P.a_kc ? (size_t)k0 : (size_t)k0 * P.lda);
+        R.B = P.B + (P.b_kc ? (size_t)k0 : (size_t)k0 * P.ldb);
+        R.a_bytes = 4u * (P.a_kc ? (unsigned)(P.M - 1) * P.lda + R.K : (unsigned)(R.K - 1) * P.lda + P.M);
+        R.b_bytes = 4u * (P.b_kc ? (unsigned)(P.N - 1) * P.ldb + R.K : (unsigned)(R.K - 1) * P.ldb + P.N);
+    }
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const int m0 = tm * RM, n0 = tn * RN;
     const int wm0 = (wv >> 1) * 32 * TM, wn0 = (wv & 1) * 32 * TN;       // this wave's quarter inside the tile
-    const rsrc_t ra = make_rsrc(P.A, P.a_bytes), rb = make_rsrc(P.B, P.b_bytes);
+    const rsrc_t ra = make_rsrc(R.A, R.a_bytes), rb = make_rsrc(R.B, R.b_bytes);
     SA sa;
     SB sb;
     sa.init(P.lda, m0, P.M, tid);
     sb.init(P.ldb, n0, P.N, tid);
+    float asum[TM];                                                       // row sums of A (the bias gradient)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) asum[a] = 0.f;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -578,10 +596,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int nkb = (P.K + 31) >> 5;
+    const int nkb = (R.K + 31) >> 5;
+    // One K block of look-ahead: the global loads of block k + 1 are in flight under the MFMAs of block k.  (A three-block
+    // register ring was measured and dropped: 118 instead of 70 VGPRs, 4 instead of 7 wavefronts per SIMD, 3 % slower on
+    // the many-workgroup shapes and no faster on the few-workgroup ones -- with one wavefront per SIMD the block time,
+    // 2400 cycles against 1090 of MFMA issue, is LDS round trips, the dependent accumulator chain and the barrier.)
     u32x4 wa[SA::NV], wb[SB::NV];
-    sa.load(wa, ra, 0, P.K);
-    sb.load(wb, rb, 0, P.K);
+    sa.load(wa, ra, 0, R.K);
+    sb.load(wb, rb, 0, R.K);
     sa.store(wa, lds_tile);
     sb.store(wb, lds_tile + SA::LDS_FLOATS);
     __syncthreads();
@@ -589,8 +611,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
         const float* tA = lds_tile + (kb & 1) * BUF;
         const float* tB = tA + SA::LDS_FLOATS;
         if (kb + 1 < nkb) {                                              // wave-uniform
-            sa.load(wa, ra, (kb + 1) * 32, P.K);
-            sb.load(wb, rb, (kb + 1) * 32, P.K);
+            sa.load(wa, ra, (kb + 1) * 32, R.K);
+            sb.load(wb, rb, (kb + 1) * 32, R.K);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -599,6 +621,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
             for (int a = 0; a < TM; ++a) fa[a] = SA::frag(tA, wm0 + 32 * a, i, kh, q);
 #pragma unroll
             for (int b = 0; b < TN; ++b) fb[b] = SB::frag(tB, wn0 + 32 * b, i, kh, q);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) asum[a] += (fa[a].x + fa[a].y) + (fa[a].z + fa[a].w);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -624,6 +648,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
         __syncthreads();
     }
     if (stop_taken(stopv)) return;
+    if (P.dbias && tn == 0 && wn0 == 0) {                                // wave-uniform
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const float d = asum[a] + __shfl_xor(asum[a], 32, 64);        // the two k halves of a row
+            const int m = m0 + wm0 + 32 * a + i;
+            if (kh == 0 && m < P.M) P.dbias[(size_t)sp * P.M + m] = d;
+        }
+    }
+    float* const Cs = P.C + (size_t)sp * P.c_split;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn0 + 32 * b + i;
@@ -637,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmBatch G) {
                 if (m < P.M) {
                     float v = act_f(acc[a][b][r] + bias, P.act);
                     if (P.mask) v = (P.mask[(size_t)m * P.ldc + n] > 0.f) ? v : 0.f;
-                    P.C[(size_t)m * P.ldc + n] = v;
+                    Cs[(size_t)m * P.ldc + n] = v;
                     if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
                 }
             }
@@ -682,7 +715,7 @@ inline int launch_tile_variant(GemmBatch& G, hipStream_t st) {
         G.p[k].tiles_m = (G.p[k].M + 64 * TM - 1) / (64 * TM);
         G.p[k].tiles_n = (G.p[k].N + 64 * TN - 1) / (64 * TN);
         G.p[k].tile_base = base;
-        base += G.p[k].tiles_m * G.p[k].tiles_n;
+        base += G.p[k].tiles_m * G.p[k].tiles_n * G.p[k].splits;
     }
     const size_t lds = 2 * sizeof(float) * (size_t)(TileStage<AM, 64 * TM>::LDS_FLOATS + TileStage<BM, 64 * TN>::LDS_FLOATS);
     auto kern = gemm_tile_kernel<AM, BM, TM, TN>;
@@ -721,7 +754,7 @@ inline bool launch_tiles(GemmBatch& G, hipStream_t st, int& rc) {
         const GemmProb& P = G.p[k];
         int a, b;
         if (!tile_mode_of(P.A, P.lda, P.a_kc, P.a_mode, a) || !tile_mode_of(P.B, P.ldb, P.b_kc, P.b_mode, b)) return false;
-        if (P.N < 64 || P.K < 32) return false;
+        if (P.N < 64 || (P.splits > 1 ? P.k_chunk : P.K) < 32 || P.sumsq) return false;
         if (k && (a != am || b != bm)) return false;
         am = a; bm = b;
     }
@@ -741,6 +774,20 @@ inline int launch_batch(GemmBatch& G, hipStream_t st) {
         rows_variant = rows_variant && G.p[k].M >= 2048 && !G.p[k].dbias && !G.p[k].sumsq &&
                        G.p[k].splits == 1;
     if (rows_variant && launch_tiles(G, st, rc_tiles)) return rc_tiles;
+    // weight gradients over many rows (M x N = the weight's shape, K = rows >= 2048, split or not): 64 x 64 tiles read
+    // each operand word for 64 outputs instead of 32 -- at 10^5 rows the 32 x 32 kernel is bound by L2 -> CU traffic
+    {
+        bool wide = true;
+        long wgs = 0;
+        for (int k = 0; k < G.n; ++k) {
+            wide = wide && G.p[k].K >= 2048 && G.p[k].M >= 48 && !G.p[k].sumsq;
+            wgs += (long)((G.p[k].M + 63) / 64) * ((G.p[k].N + 63) / 64) * G.p[k].splits;
+        }
+        // ... when there are enough of them: a workgroup alone on its CU runs a K block in 2400 cycles (1090 of MFMA
+        // issue); below ~2 workgroups per CU the 32 x 32 kernel's four-way K split inside the workgroup is faster
+        // (measured: 7936 rows, dW_hh 98 workgroups 36 us against 20 us; 127 k rows, 896: 0.19 against 0.38 ms)
+        if (wide && wgs >= 512 && launch_tiles(G, st, rc_tiles)) return rc_tiles;
+    }
     if (rows_variant) {
         int base = 0;
         for (int k = 0; k < G.n; ++k) {
@@ -1166,22 +1213,28 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
     const int Ms[3] = {H1, H2, O}, Ns[3] = {D, H1, H2};
     float* gdst = grads;
     float* wsp = ws;
-    GemmBatch G;
-    G.n = 3;
+    // two launches: the layers wide enough for the 64 x 64 tile kernel, and the rest (the output layer: 1 - 17 rows of
+    // dW3) on 32 x 32 tiles -- launch_batch() takes a batch to one kernel as a whole
+    GemmBatch Gw, Gr;
+    Gw.n = Gr.n = 0;
     RedSegs L;
     L.n = 6;
-    int base = 0, ebase = 0;
+    int base_w = 0, base_r = 0, ebase = 0;
     for (int l = 0; l < 3; ++l) {
         const int M = Ms[l], N = Ns[l];
         float* wpart = wsp;
         float* bpart = wsp + (size_t)S * M * N;
         wsp = bpart + (size_t)S * M;
-        fill_prob(G.p[l], dz[l], M, 0, in[l], N, 0, nullptr, nullptr, wpart, N, M, N, R, SMX_ACT_NONE, bpart, nullptr, base,
+        const bool wide = M >= 48 && N >= 64 && M % 4 == 0 && N % 4 == 0;
+        GemmBatch& G = wide ? Gw : Gr;
+        int& base = wide ? base_w : base_r;
+        GemmProb& P = G.p[G.n++];
+        fill_prob(P, dz[l], M, 0, in[l], N, 0, nullptr, nullptr, wpart, N, M, N, R, SMX_ACT_NONE, bpart, nullptr, base,
                   stop_flag);
-        G.p[l].splits = S;
-        G.p[l].k_chunk = k_chunk;
-        G.p[l].c_split = (long)M * N;
-        base += G.p[l].tiles_m * G.p[l].tiles_n * S;
+        P.splits = S;
+        P.k_chunk = k_chunk;
+        P.c_split = (long)M * N;
+        base += P.tiles_m * P.tiles_n * S;
         L.g[2 * l] = RedSeg{wpart, gdst, ebase, M * N};
         ebase += M * N;
         gdst += (size_t)M * N;
@@ -1190,8 +1243,11 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
         gdst += M;
     }
     L.total = ebase;
-    const int rc = launch_batch(G, smx_s(stream));
-    if (rc) return rc;
+    for (GemmBatch* G : {&Gw, &Gr}) {
+        if (!G->n) continue;
+        const int rc = launch_batch(*G, smx_s(stream));
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(segmented_reduce_kernel, dim3((unsigned)((L.total + 15) / 16)), dim3(256), 0, smx_s(stream), L, S,
                        stop_flag);
     SMX_LAUNCH_CHECK();

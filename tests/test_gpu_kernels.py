@@ -169,7 +169,7 @@ def test_mlp3_forward_backward(K, rows, D, H1, H2, OUT, act):
 
 
 @pytest.mark.parametrize('rows,D,H1,H2,OUT', [(7936, 100, 300, 200, 6), (2100, 17, 64, 40, 1), (40000, 132, 300, 200, 12),
-                                              (1500, 100, 300, 200, 6)])
+                                              (900, 100, 300, 200, 6), (131072, 100, 300, 200, 17)])
 def test_mlp3_backward_splitk_over_many_rows(K, rows, D, H1, H2, OUT):
     """the stems' MLP backward over B x T rows: weight-gradient rows cut into chunks + ONE segmented reduce
     (smx_mlp3_backward_splitk_f32) against a float64 statement of loss.backward() and against the unsplit entry point;
