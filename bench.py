@@ -369,6 +369,8 @@ def secondaries():
             ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout', lambda: secondary_pipeline(4096)),
             ('on-device loop, 1024 actors x 128 steps, actors one rollout ahead of the learner (two streams)',
              lambda: secondary_pipeline(1024, overlap=True)),
+            ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout, actors one rollout ahead (two streams)',
+             lambda: secondary_pipeline(4096, overlap=True)),
             ('configs[3] on-device loop: 256 actors x 32 steps, 3x84x84 uint8 camera + 32-d state, CNN + LSTM policy',
              secondary_pixel_pipeline),
             ('host-fed learner: 1024 x 128 x 376 batches from host memory (pinned double-buffered ingest)', secondary_host_fed),

@@ -617,6 +617,131 @@ __global__ __launch_bounds__(NT) void lstm_fwdq_kernel(FwdArgs a) {
     }
 }
 
+// ===========================================================================================
+// Forward recurrence with the K SUM of a hidden unit split over its quad (thread 4 n + kq: unit n, k-quarter kq, all
+// four gates).  In lstm_fwdq_kernel every lane reads ALL of h_{t-1} from LDS each step: 25 ds_read_b128 per lane whose
+// data return -- 64 lanes x 16 bytes per instruction, broadcast or not -- is 8 cycles of the CU's one LDS pipe each:
+// 8 wavefronts x 25 x 8 = 1600 cycles of a 2100-cycle step.  Here a lane reads only ITS quarter of h (7 reads, 450
+// cycles per step and CU), multiplies it with the four gates' weights (the same 4 H / 4 = 100 weights per lane, in
+// registers), and the quad's partial sums meet by a DPP reduce-scatter: lane kq ends with gate kq's sum in the fixed
+// order (q0 + q1) + (q2 + q3), activates it, and the cell update proceeds as in lstm_fwdq_kernel.
+// ===========================================================================================
+// Gate non-linearities on the hardware exp2 / rcp units.  A step of the one-row recurrence is VALU-issue bound (8
+// wavefronts x ~200 instructions on 4 SIMDs = 1600 of its 2040 cycles), and more than half of those instructions were
+// the libm expf / tanhf / IEEE division of sigmoid and tanh -- executed on BOTH sides of the tanh-or-sigmoid branch,
+// since the four gates of a unit sit in one quad.  sigmoid(z) = rcp(1 + exp2(-z log2 e)) is 5 instructions; tanh(x) =
+// 2 sigmoid(2 x) - 1 shares them, so a lane's gate is ONE branch-free sequence.  Absolute error <= 1.5e-7 (v_exp_f32 and
+// v_rcp_f32 are 1 ulp; the argument scaling adds |z| 2^-24 relative to an exponent whose sensitivity s (1 - s) |z| peaks
+// at 0.22) against the 1e-5 parity bound.
+__device__ __forceinline__ float fast_sigm(float z) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z));
+}
+__device__ __forceinline__ float fast_tanh(float x) { return 2.f * fast_sigm(2.f * x) - 1.f; }
+
+__device__ __forceinline__ float quad_xor1(float v) {       // lane ^ 1 inside the quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {       // lane ^ 2 inside the quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+}
+
+template <int Q4>          // float4 words per k-quarter: H <= 16 Q4
+__global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
+    if (a.stop && *a.stop) return;
+    __shared__ float4 hs4[2][4][Q4];           // h_{t-1} / h_t by k-quarter, zero padded
+    const int H = a.H, G = 4 * H, T = a.T, QS = H >> 2;     // (H % 4 == 0)
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool colv = tid < G;
+    const int n = tid >> 2, kq = tid & 3;
+    float4 w[4][Q4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < Q4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (colv) {
+                const float* p = a.W_hh + (size_t)(g * H + n) * H + kq * QS + 4 * q;
+                if (4 * q + 0 < QS) v.x = p[0];
+                if (4 * q + 1 < QS) v.y = p[1];
+                if (4 * q + 2 < QS) v.z = p[2];
+                if (4 * q + 3 < QS) v.w = p[3];
+            }
+            w[g][q] = v;
+        }
+    const int col = colv ? kq * H + n : 0;     // the gate column this lane activates: gate kq of unit n
+    const float bias = colv ? a.b_hh[col] : 0.f;
+    const bool is_g = kq == 2;                 // the cell candidate: tanh; the other gates: sigmoid
+    float* hs = reinterpret_cast<float*>(hs4);
+    for (int i = tid; i < 2 * 4 * 4 * Q4; i += NT) hs[i] = 0.f;
+    __syncthreads();
+    const int pos = colv ? (n / QS) * 4 * Q4 + (n % QS) : 0;       // unit n inside the quartered layout
+    if (colv && kq == 0 && a.h0) hs[pos] = a.h0[(size_t)b * H + n];
+    float creg = (colv && a.c0) ? a.c0[(size_t)b * H + n] : 0.f;
+    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    // the input half of the gates (smx_linear_f32 wrote it) is requested FOUR steps ahead: the [B, T, 4H] buffer does not
+    // stay in L2 between the GEMM and this kernel, and a request made one step ahead -- as in lstm_fwdq_kernel -- makes
+    // every 0.9 us step wait for a memory round trip of about that length.  Four named registers rotated by unrolling.
+    float gx0 = colv ? a.gates[gbase + col] : 0.f;
+    float gx1 = (colv && 1 < T) ? a.gates[gbase + (size_t)1 * G + col] : 0.f;
+    float gx2 = (colv && 2 < T) ? a.gates[gbase + (size_t)2 * G + col] : 0.f;
+    float gx3 = (colv && 3 < T) ? a.gates[gbase + (size_t)3 * G + col] : 0.f;
+    const bool odd = (kq & 1) != 0, hi = (kq & 2) != 0;
+    __syncthreads();
+#define SMX_FWDK_STEP(GX, TT)                                                                                          \
+    if ((TT) < T) {                                                                                                    \
+        const int t = (TT);                                                                                            \
+        const int p = t & 1;                                                                                           \
+        v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};                                        \
+        _Pragma("unroll") for (int q = 0; q < Q4; ++q) {                                                               \
+            const float4 hv = hs4[p][kq][q];                                                                           \
+            const v2f lo = {hv.x, hv.y}, up = {hv.z, hv.w};                                                            \
+            a0 = __builtin_elementwise_fma(lo, (v2f){w[0][q].x, w[0][q].y}, a0);                                       \
+            a1 = __builtin_elementwise_fma(lo, (v2f){w[1][q].x, w[1][q].y}, a1);                                       \
+            a2 = __builtin_elementwise_fma(lo, (v2f){w[2][q].x, w[2][q].y}, a2);                                       \
+            a3 = __builtin_elementwise_fma(lo, (v2f){w[3][q].x, w[3][q].y}, a3);                                       \
+            a0 = __builtin_elementwise_fma(up, (v2f){w[0][q].z, w[0][q].w}, a0);                                       \
+            a1 = __builtin_elementwise_fma(up, (v2f){w[1][q].z, w[1][q].w}, a1);                                       \
+            a2 = __builtin_elementwise_fma(up, (v2f){w[2][q].z, w[2][q].w}, a2);                                       \
+            a3 = __builtin_elementwise_fma(up, (v2f){w[3][q].z, w[3][q].w}, a3);                                       \
+        }                                                                                                              \
+        const float p0 = a0.x + a0.y, p1 = a1.x + a1.y, p2 = a2.x + a2.y, p3 = a3.x + a3.y;                            \
+        /* reduce-scatter over the quad.  Step 1 (partner lane ^ 1): even lanes collect gates 0 and 2, odd lanes 1, 3 */ \
+        const float s_lo = (odd ? p1 : p0) + quad_xor1(odd ? p0 : p1);                                                 \
+        const float s_up = (odd ? p3 : p2) + quad_xor1(odd ? p2 : p3);                                                 \
+        /* step 2 (partner lane ^ 2): lanes 0, 1 keep gates 0, 1; lanes 2, 3 keep gates 2, 3 */                        \
+        const float tot = (hi ? s_up : s_lo) + quad_xor2(hi ? s_lo : s_up);                                            \
+        const float pre = GX + (tot + bias);                                                                           \
+        const float sg = fast_sigm(is_g ? 2.f * pre : pre);                                                          \
+        const float act = is_g ? 2.f * sg - 1.f : sg;            /* tanh for the cell candidate, sigmoid otherwise */   \
+        if (colv) a.gates[gbase + (size_t)t * G + col] = act;                                                          \
+        GX = (colv && t + 4 < T) ? a.gates[gbase + (size_t)(t + 4) * G + col] : 0.f;                                   \
+        const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act); \
+        const float c = gf * creg + gi * gg;                                                                           \
+        const float h = go * fast_tanh(c);                                                                             \
+        creg = c;                                                                                                      \
+        if (colv && kq == 0) {                                                                                         \
+            const size_t oh = hbase + (size_t)t * H + n;                                                               \
+            a.out[oh] = h;                                                                                             \
+            a.cs[oh] = c;                                                                                              \
+            if (a.hprev) a.hprev[oh] = hs[p * 16 * Q4 + pos];                                                          \
+            hs[(1 - p) * 16 * Q4 + pos] = h;                                                                           \
+        }                                                                                                              \
+        LSTM_LDS_BARRIER();                                                                                            \
+    }
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        SMX_FWDK_STEP(gx0, t0)
+        SMX_FWDK_STEP(gx1, t0 + 1)
+        SMX_FWDK_STEP(gx2, t0 + 2)
+        SMX_FWDK_STEP(gx3, t0 + 3)
+    }
+#undef SMX_FWDK_STEP
+    if (colv && kq == 0) {
+        if (a.hN) a.hN[(size_t)b * H + n] = hs[(T & 1) * 16 * Q4 + pos];
+        if (a.cN) a.cN[(size_t)b * H + n] = creg;
+    }
+}
+
 template <int HQ>
 __global__ __launch_bounds__(NT) void lstm_bwdq_kernel(BwdArgs a) {
     if (a.stop && *a.stop) return;
@@ -660,7 +785,7 @@ __global__ __launch_bounds__(NT) void lstm_bwdq_kernel(BwdArgs a) {
                     go = quad_bcast<3>(gmine);
         const float dhr = ((quad_bcast<0>(share) + quad_bcast<1>(share)) + quad_bcast<2>(share)) + quad_bcast<3>(share);
         const float dh = dout + dhr;
-        const float tc = tanhf(c);
+        const float tc = fast_tanh(c);             // (the forward pass formed h with the same function)
         const float dc = dcreg + (dh * go) * (1.f - tc * tc);
         const float dgi = (dc * gg) * (gi * (1.f - gi));
         const float dgf = (dc * cp) * (gf * (1.f - gf));
@@ -683,6 +808,110 @@ __global__ __launch_bounds__(NT) void lstm_bwdq_kernel(BwdArgs a) {
                 acc = __builtin_elementwise_fma((v2f){dv.z, dv.w}, (v2f){w[q].z, w[q].w}, acc);
             }
             share = acc.x + acc.y;
+        }
+        c = cp;
+        gmine = ng; cp = ncp; dout = nd;
+    }
+}
+
+// ===========================================================================================
+// Backward recurrence with TWO hidden units per 8 lanes in the dh_rec product.  In lstm_bwdq_kernel lane (n, gb) reads
+// the 100 dgates of gate block gb -- 25 ds_read_b128 whose data return (64 lanes x 16 bytes = 8 cycles of the CU's LDS
+// pipe each, x 8 wavefronts = 1600 cycles) bounds the 2470-cycle step.  Here the eight lanes of two adjacent quads
+// (units 2 p and 2 p + 1) split the K = 4 H sum eight ways -- lane e takes half (e & 1) of gate block e >> 1 -- and
+// each forms the partial sums of BOTH units from the words it reads: 13 reads per lane, the same 100 weights in
+// registers.  The partials meet by DPP: the two quads swap the other unit's partial (row_shl / row_shr 4), then each
+// quad adds its four in the fixed order (l0 + l1) + (l2 + l3).  The element-wise half of the step is that of
+// lstm_bwdq_kernel (thread 4 n + gb).
+// ===========================================================================================
+__device__ __forceinline__ float row_from_plus4(float v) {   // lane i <- lane i + 4 (inside a 16-lane row)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_from_minus4(float v) {  // lane i <- lane i - 4
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+}
+
+template <int HH>          // float4 words per half gate block: H <= 8 HH
+__global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
+    if (a.stop && *a.stop) return;
+    __shared__ float4 dg4[2][4][2 * HH];       // the step's dgates, gate block gb at dg4[p][gb] (zero padded)
+    const int H = a.H, G = 4 * H, T = a.T;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const bool colv = tid < G;
+    const int n = colv ? tid >> 2 : 0, gb = tid & 3;                   // element-wise role: gate gb of unit n
+    const int e = tid & 7, uA = 2 * (tid >> 3), kgb = e >> 1;          // product role: k-eighth e of units uA, uA + 1
+    const int nq = H >> 2, half0 = (nq + 1) >> 1;                      // float4 words per gate block / in its first half
+    const int q0 = (e & 1) ? half0 : 0, qn = (e & 1) ? nq - half0 : half0;
+    float4 wA[HH], wB[HH];
+#pragma unroll
+    for (int q = 0; q < HH; ++q) {
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (colv && q < qn) {
+            const float* p = a.W_hh + ((size_t)kgb * H + 4 * (q0 + q)) * H + uA;
+            va = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
+            vb = make_float4(p[1], p[H + 1], p[2 * (size_t)H + 1], p[3 * (size_t)H + 1]);
+        }
+        wA[q] = va;
+        wB[q] = vb;
+    }
+    float* dg = reinterpret_cast<float*>(dg4);
+    for (int idx = tid; idx < 2 * 4 * 8 * HH; idx += NT) dg[idx] = 0.f;
+    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    float dcreg = 0.f, dhr = 0.f;              // dhr: dh_rec[n] from the previous step's product
+    float gmine = 0.f, c = 0.f, cp = 0.f, dout = 0.f;
+    auto fetch = [&](int t, float& xg, float& xcp, float& xd) {
+        const size_t oh = hbase + (size_t)t * H + n;
+        xg = a.gates[gbase + (size_t)t * G + (size_t)gb * H + n];      // this lane's own gate of unit n
+        xcp = (t > 0) ? a.cs[oh - H] : (a.c0 ? a.c0[(size_t)b * H + n] : 0.f);
+        xd = a.dout[oh];
+    };
+    if (colv) {
+        fetch(T - 1, gmine, cp, dout);
+        c = a.cs[hbase + (size_t)(T - 1) * H + n];
+    }
+    const bool upper = (tid & 4) != 0;         // the quad of unit uA + 1
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const int p = t & 1;
+        float ng = 0.f, ncp = 0.f, nd = 0.f;
+        if (colv && t > 0) fetch(t - 1, ng, ncp, nd);              // the next step's inputs: requested early
+        const float gi = quad_bcast<0>(gmine), gf = quad_bcast<1>(gmine), gg = quad_bcast<2>(gmine),
+                    go = quad_bcast<3>(gmine);
+        const float dh = dout + dhr;
+        const float tc = fast_tanh(c);             // (the forward pass formed h with the same function)
+        const float dc = dcreg + (dh * go) * (1.f - tc * tc);
+        const float dgi = (dc * gg) * (gi * (1.f - gi));
+        const float dgf = (dc * cp) * (gf * (1.f - gf));
+        const float dgg = (dc * gi) * (1.f - gg * gg);
+        const float dgo = (dh * tc) * (go * (1.f - go));
+        dcreg = dc * gf;
+        const float mine = gb == 0 ? dgi : (gb == 1 ? dgf : (gb == 2 ? dgg : dgo));
+        if (colv) {
+            a.dgates[gbase + (size_t)t * G + (size_t)gb * H + n] = mine;
+            dg[((p * 4 + gb) * 8 * HH) + n] = mine;
+        }
+        LSTM_LDS_BARRIER();
+        if (t > 0) {                               // (every lane: lanes past 4 H hold zero weights)
+            v2f accA = {0.f, 0.f}, accB = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < HH; ++q) {
+                const float4 dv = dg4[p][kgb][q0 + q];
+                const v2f lo = {dv.x, dv.y}, up = {dv.z, dv.w};
+                accA = __builtin_elementwise_fma(lo, (v2f){wA[q].x, wA[q].y}, accA);
+                accB = __builtin_elementwise_fma(lo, (v2f){wB[q].x, wB[q].y}, accB);
+                accA = __builtin_elementwise_fma(up, (v2f){wA[q].z, wA[q].w}, accA);
+                accB = __builtin_elementwise_fma(up, (v2f){wB[q].z, wB[q].w}, accB);
+            }
+            const float pA = accA.x + accA.y, pB = accB.x + accB.y;
+            // the two quads swap the partial of the unit the OTHER one owns
+            const float give = upper ? pA : pB;
+            // (both DPP moves run with every lane enabled: under a divergent branch a disabled source lane reads as 0)
+            const float from_lo = row_from_minus4(give), from_up = row_from_plus4(give);
+            const float got = upper ? from_lo : from_up;
+            const float s1 = (upper ? pB : pA) + got;
+            const float s2 = s1 + quad_xor1(s1);
+            dhr = s2 + quad_xor2(s2);
         }
         c = cp;
         gmine = ng; cp = ncp; dout = nd;
@@ -724,7 +953,12 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     // H <= 128: one row per workgroup on the vector ALU (SMX_LSTM_MFMA4=1 keeps the 4-row MFMA kernels for A/B runs)
     static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
     static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;       // the LDS-exchange one-row kernels, for A/B runs
-    if (!mfma4 && !v1 && H <= 100) {
+    static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;   // every lane reads all of h (the round-3 first form)
+    if (!mfma4 && !v1 && !quad && H <= 112) {
+        hipLaunchKernelGGL((lstm_fwdk_kernel<7>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && !quad && H <= 128) {
+        hipLaunchKernelGGL((lstm_fwdk_kernel<8>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && H <= 100) {
         hipLaunchKernelGGL((lstm_fwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 128) {
         hipLaunchKernelGGL((lstm_fwdq_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
@@ -770,7 +1004,12 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     const int blocks = (int)((B + RB - 1) / RB);
     static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
     static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;
-    if (!mfma4 && !v1 && H <= 100) {
+    static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;
+    if (!mfma4 && !v1 && !quad && H <= 104) {
+        hipLaunchKernelGGL((lstm_bwdk_kernel<13>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && !quad && H <= 128) {
+        hipLaunchKernelGGL((lstm_bwdk_kernel<16>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && H <= 100) {
         hipLaunchKernelGGL((lstm_bwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 128) {
         hipLaunchKernelGGL((lstm_bwdq_kernel<32>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
