@@ -306,7 +306,7 @@ def secondary_pixel_pipeline():
     windows (+ the LSTM state at their first step) cut on the device, FIFO, PPOLearner.learn"""
     sys.path.insert(0, os.path.join(ROOT, 'scripts'))
     import bench_pipeline
-    r = bench_pipeline.run_pipeline(actors=256, steps=32, obs_dim=32, action_dim=8, iters=3, warmup=1, graph=False,
+    r = bench_pipeline.run_pipeline(actors=256, steps=32, obs_dim=32, action_dim=8, iters=5, warmup=3, graph=False,
                                     fused_step=True, learn_batch=256, pixel=(3, 84, 84), frame_stacks=1, rnn=True)
     return {'env_steps_per_s': r['value'], 'ms_per_iteration': r['ms_per_iteration'],
             'rollout_env_steps_per_s': r['rollout_env_steps_per_s'], 'stage_ms': r['stage_ms_synchronised'],
@@ -369,8 +369,6 @@ def secondaries():
             ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout', lambda: secondary_pipeline(4096)),
             ('on-device loop, 1024 actors x 128 steps, actors one rollout ahead of the learner (two streams)',
              lambda: secondary_pipeline(1024, overlap=True)),
-            ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout, actors one rollout ahead (two streams)',
-             lambda: secondary_pipeline(4096, overlap=True)),
             ('configs[3] on-device loop: 256 actors x 32 steps, 3x84x84 uint8 camera + 32-d state, CNN + LSTM policy',
              secondary_pixel_pipeline),
             ('host-fed learner: 1024 x 128 x 376 batches from host memory (pinned double-buffered ingest)', secondary_host_fed),
