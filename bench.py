@@ -353,11 +353,58 @@ def secondary_host_fed(iters=12):
                      'host_to_device_GBps': stager.bytes_per_batch / dt / 1e9}
         del learner, stager, pf
         torch.cuda.empty_cache()
+    # the whole host path: 1024 experiences as the Python objects a collector hands over (lists of per-step arrays,
+    # floats, bools) -> MultistepAggregatorWithInfo.aggregate writing straight into the pinned staging (the CPython
+    # extension csrc/host/smx_host.c) in the prefetch thread -> H2D under learn(k) -> learn
+    try:
+        from surreal_amd.learner import aggregator as AG
+        pi = batch['persistent_infos'][0]
+        ob, obn = batch['obs']['low_dim']['flat_inputs'], batch['obs_next']['low_dim']['flat_inputs']
+        exps = [{'obs': [{'low_dim': {'flat_inputs': ob[b, s]}} for s in range(N)],
+                 'obs_next': {'low_dim': {'flat_inputs': obn[b, 0]}},
+                 'actions': [batch['actions'][b, s] for s in range(N)],
+                 'rewards': [float(x) for x in batch['rewards'][b]], 'dones': [bool(x) for x in batch['dones'][b]],
+                 'persistent_infos': [[pi[b, s]] for s in range(N)], 'onetime_infos': [], 'n_step': N} for b in range(B)]
+        learner, _, _ = build_learner('adapt', torch.cuda.current_device())
+        learner.graph_input_sets = 2
+        stager = PinnedBatchStager(batch, depth=2, device=learner.device)
+        agg_ms = {}
+        for label, native in (('extension', True), ('numpy', False)):
+            saved = list(AG._NATIVE)
+            if not native:
+                AG._NATIVE[:] = [True, None]
+            views = stager.host_views(0)
+            learner.aggregator.aggregate(exps, out=views)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                learner.aggregator.aggregate(exps, out=views)
+            agg_ms[label] = (time.perf_counter() - t0) / 3 * 1e3
+            AG._NATIVE[:] = saved
+        pf = LearnerDataPrefetcher(learner.session_config, B, worker_preprocess=learner._prefetcher_preprocess,
+                                   source=lambda bs: exps, stager=stager)
+        pf.start()
+        for _ in range(3):
+            learner.learn(pf.get())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            learner.learn(pf.get())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 8
+        pf.stop()
+        out['experience dicts from CPU agents, aggregated in place by the prefetch thread'] = {
+            'ms_per_batch': dt * 1e3, 'env_steps_per_s': B * N / dt, 'aggregate_ms': agg_ms,
+            'native_extension': AG.native_fill() is not None}
+        del learner, stager, pf
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out['experience dicts from CPU agents, aggregated in place by the prefetch thread'] = {'error': repr(e)}
     out['batch_bytes'] = 4 * (B * N * D + B * D + B * N * A + 2 * B * N + B * N * 2 * A)
     out['pcie_roof'] = {'GBps': 63.0, 'env_steps_per_s': B * N / (out['batch_bytes'] / 63e9)}
     out['what'] = 'pinned double-buffered staging; H2D of batch k + 1 on a copy stream under learn(k); two captured graphs ' \
-                  '(one per staging slot).  The host-tier aggregator (Python dicts -> arrays, 0.16 s per batch) is not in ' \
-                  'this number: it bounds a deployment fed by remote CPU agents at ~8e5 env-steps/s per aggregating process'
+                  '(one per staging slot).  The first two entries start from arrays; the third includes the host-tier ' \
+                  'aggregation of 131 072 per-step Python objects per batch, which is what bounds a deployment fed by ' \
+                  'remote CPU agents (per aggregating process)'
     return out
 
 

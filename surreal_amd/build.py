@@ -69,6 +69,30 @@ def build(force=False, verbose=True):
     return LIB
 
 
+HOST_SRC = os.path.join(CSRC, 'host', 'smx_host.c')
+HOST_LIB = os.path.join(HERE, '_smx_host.so')
+
+
+def build_host(force=False, verbose=True):
+    """surreal_amd/_smx_host.so: the CPython extension that assembles host-fed batches in place (csrc/host/smx_host.c;
+    gcc + OpenMP, CPython and numpy headers -- no device code)"""
+    if not (force or _newer(HOST_LIB, [HOST_SRC])):
+        return HOST_LIB
+    import sysconfig
+    import numpy
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        raise RuntimeError('gcc not found: cannot build _smx_host.so')
+    cmd = [cc, '-O3', '-fPIC', '-shared', '-fopenmp', '-Wall', '-I' + sysconfig.get_paths()['include'],
+           '-I' + numpy.get_include(), HOST_SRC, '-o', HOST_LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    build_host(force='--force' in sys.argv)
     print(LIB)
+    print(HOST_LIB)

@@ -16,8 +16,28 @@ the flat leaf list measures the same).  Experiences that already arrive as one a
 field (what the device-resident replay hands over) pass straight through ``np.stack``.
 """
 import collections
+import os
 
 import numpy as np
+
+_NATIVE = [False, None]          # [looked for, the extension's fill() or None]
+
+
+def native_fill():
+    """``_smx_host.fill`` (surreal_amd/csrc/host/smx_host.c, built by ``surreal_amd.build.build_host``) or None when the
+    extension has not been built.  It writes one field of a batch into a preallocated array: leaf pointers collected with
+    the GIL held, the copies done without it on a few threads.  SMX_HOST_NUMPY=1 forces the numpy path (A/B runs)."""
+    if not _NATIVE[0]:
+        _NATIVE[0] = True
+        if not os.environ.get('SMX_HOST_NUMPY'):
+            try:
+                from surreal_amd import _smx_host
+                _NATIVE[1] = _smx_host.fill
+            except ImportError:
+                import warnings
+                warnings.warn('surreal_amd/_smx_host.so is not built (python -m surreal_amd.build): host-fed batches are '
+                              'assembled by numpy, ~5x slower')
+    return _NATIVE[1]
 
 
 def _stack(seq, dtype=None, out=None):
@@ -81,17 +101,32 @@ class MultistepAggregatorWithInfo(object):
         self.action_type = action_spec['type']
         self.action_spec = action_spec
         self.obs_spec = obs_spec
+        # copy threads of the in-place path.  One by default: the leaf walk (GIL held) is half the time, and on hosts with
+        # a CPU quota below their core count extra OpenMP threads spin instead of copying (measured 43 -> 105 ms at 8)
+        self.threads = max(1, int(os.environ.get('SMX_HOST_THREADS', '1')))
 
-    def _batch_obs(self, per_exp_steps, into=None):
-        """per_exp_steps: list (B) of list (steps) of nested obs dicts -> dict of (B, steps, ...)"""
+    def _batch_obs(self, per_exp_steps, into=None, native=None):
+        """per_exp_steps: list (B) of list (steps) of nested obs dicts (or a callable that builds it) -> dict of
+        (B, steps, ...).  native = (exp_list, field, per_step): try the C extension first (in-place staging only)"""
         out = collections.OrderedDict()
+        fill = native_fill() if (native is not None and into is not None) else None
         for modality in self.obs_spec.keys():
             out[modality] = collections.OrderedDict()
             for key in self.obs_spec[modality].keys():
+                dst = None if into is None else into[modality][key]
+                if fill is not None and fill(dst, native[0], native[1], (modality, key), native[2], self.threads) >= 0:
+                    out[modality][key] = dst
+                    continue
+                if callable(per_exp_steps):          # (built only when some field needs the numpy path)
+                    per_exp_steps = per_exp_steps()
                 out[modality][key] = _stack(
-                    [[step[modality][key] for step in steps] for steps in per_exp_steps],
-                    out=None if into is None else into[modality][key])
+                    [[step[modality][key] for step in steps] for steps in per_exp_steps], out=dst)
         return out
+
+    def _field(self, exp_list, name, dst, path=(), per_step=1):
+        """one plain field (actions / rewards / dones / an info slot) into `dst` through the extension; False: not taken"""
+        fill = native_fill() if dst is not None else None
+        return fill is not None and fill(dst, exp_list, name, path, per_step, self.threads) >= 0
 
     def _gather_action_infos(self, exp_list, into=None):
         """aggregator.py:223-262"""
@@ -99,11 +134,14 @@ class MultistepAggregatorWithInfo(object):
         onetime = persistent = None
         o = (lambda name, i: None) if into is None else (lambda name, i: into[name][i])
         if len(first['onetime_infos']) > 0:
-            onetime = [_stack([exp['onetime_infos'][i] for exp in exp_list], out=o('onetime_infos', i))
+            onetime = [o('onetime_infos', i) if self._field(exp_list, 'onetime_infos', o('onetime_infos', i), (i,), 0)
+                       else _stack([exp['onetime_infos'][i] for exp in exp_list], out=o('onetime_infos', i))
                        for i in range(len(first['onetime_infos']))]
         if len(first['persistent_infos'][0]) > 0:
-            persistent = [_stack([[step[i] for step in exp['persistent_infos']] for exp in exp_list],
-                                 out=o('persistent_infos', i))
+            persistent = [o('persistent_infos', i)
+                          if self._field(exp_list, 'persistent_infos', o('persistent_infos', i), (i,), 1)
+                          else _stack([[step[i] for step in exp['persistent_infos']] for exp in exp_list],
+                                      out=o('persistent_infos', i))
                           for i in range(len(first['persistent_infos'][0]))]
         return onetime, persistent
 
@@ -115,15 +153,20 @@ class MultistepAggregatorWithInfo(object):
             # the reference's discrete branch is broken (aggregator.py:172-173) -- continuous only
             raise NotImplementedError('action_spec unsupported ' + str(self.action_spec))
         g = (lambda k: None) if out is None else (lambda k: out[k])
-        observations = self._batch_obs([exp['obs'] for exp in exp_list], g('obs'))
-        next_obs = self._batch_obs([[exp['obs_next']] for exp in exp_list], g('obs_next'))
+        observations = self._batch_obs(lambda: [exp['obs'] for exp in exp_list], g('obs'), (exp_list, 'obs', 1))
+        next_obs = self._batch_obs(lambda: [[exp['obs_next']] for exp in exp_list], g('obs_next'),
+                                   (exp_list, 'obs_next', 0))
         onetime, persistent = self._gather_action_infos(exp_list, out)
-        dones = _stack([exp['dones'] for exp in exp_list], out=g('dones'))
+
+        def plain(name):
+            dst = g(name)
+            return dst if self._field(exp_list, name, dst) else _stack([exp[name] for exp in exp_list], out=dst)
+        dones = plain('dones')
         return {
             'obs': observations,
             'obs_next': next_obs,
-            'actions': _stack([exp['actions'] for exp in exp_list], out=g('actions')),
-            'rewards': _stack([exp['rewards'] for exp in exp_list], out=g('rewards')),
+            'actions': plain('actions'),
+            'rewards': plain('rewards'),
             'persistent_infos': persistent,
             'onetime_infos': onetime,
             'dones': dones if out is not None else dones.astype('float32'),

@@ -658,10 +658,11 @@ def test_replay_kernels(K):
         assert torch.equal(rd.cpu(), rc)
 
 
-@pytest.mark.parametrize('rows,D', [(1024, 376), (96, 20)])
+@pytest.mark.parametrize('rows,D', [(1024, 376), (96, 20), (4100, 376)])
 def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
     """actor + critic jobs in shared launches; the weight-gradient GEMMs read the transposed
-    (K-contiguous) copies written by the producing epilogues; a raised stop flag masks one job"""
+    (K-contiguous) copies written by the producing epilogues; a raised stop flag masks one job.  4100 rows: the
+    layers and data gradients take the LDS-tiled kernel (its transposed-copy epilogue, its stop flag, ragged rows)"""
     g = torch.Generator().manual_seed(rows)
     specs = [(D, 300, 200, 17, L.SMX_ACT_TANH), (D, 300, 200, 1, L.SMX_ACT_NONE)] if D == 376 else \
         [(D, 40, 24, 5, L.SMX_ACT_TANH), (D, 40, 24, 1, L.SMX_ACT_NONE)]

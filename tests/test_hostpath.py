@@ -144,6 +144,96 @@ def test_aggregator_matches_reference():
             [got[0], dict(got[1], actions=got[1]['actions'][:2])])      # ragged -> loud
 
 
+def _host_batch_out(B, N, D, A, pixel=None, hid=None):
+    out = {'obs': {'low_dim': {'flat_inputs': np.full((B, N, D), np.nan, np.float32)}},
+           'obs_next': {'low_dim': {'flat_inputs': np.full((B, 1, D), np.nan, np.float32)}},
+           'actions': np.full((B, N, A), np.nan, np.float32), 'rewards': np.full((B, N), np.nan, np.float32),
+           'dones': np.full((B, N), np.nan, np.float32), 'persistent_infos': [np.full((B, N, 2 * A), np.nan, np.float32)],
+           'onetime_infos': None if hid is None else [np.full((B, 1, hid), np.nan, np.float32) for _ in range(2)]}
+    if pixel:
+        out['obs']['pixel'] = {'camera0': np.zeros((B, N) + pixel, np.uint8)}
+        out['obs_next']['pixel'] = {'camera0': np.zeros((B, 1) + pixel, np.uint8)}
+    return out
+
+
+@pytest.mark.parametrize('layout', ['float32', 'float64_obs', 'pixel_rnn', 'array_fields', 'unsupported_leaf'])
+def test_native_batch_assembly_equals_the_numpy_path(layout, monkeypatch):
+    """MultistepAggregatorWithInfo.aggregate(out=pinned staging views): the CPython extension (csrc/host/smx_host.c --
+    leaf pointers collected under the GIL, copies / float64 -> float32 / bool -> float32 conversions done without it)
+    writes the same bytes as the numpy path for what the agents send (lists of per-step arrays, Python floats and
+    bools, uint8 camera frames, LSTM states as one-time infos, whole (N, ...) arrays per field), and hands a field
+    with a leaf it does not know (float16) to numpy instead of guessing"""
+    from surreal_amd.learner import aggregator as AG
+    assert AG.native_fill() is not None, 'build it: python -m surreal_amd.build'
+    B, N, D, A = 6, 5, 7, 3
+    pixel = (2, 6, 4) if layout == 'pixel_rnn' else None
+    hid = 4 if layout == 'pixel_rnn' else None
+    rs = np.random.RandomState(5)
+    odt = np.float64 if layout == 'float64_obs' else (np.float16 if layout == 'unsupported_leaf' else np.float32)
+
+    def ob():
+        o = collections.OrderedDict(low_dim=collections.OrderedDict(flat_inputs=rs.randn(D).astype(odt)))
+        if pixel:
+            o['pixel'] = collections.OrderedDict(camera0=rs.randint(0, 256, pixel).astype(np.uint8))
+        return o
+    exps = []
+    for _ in range(B):
+        e = {'obs': [ob() for _ in range(N)], 'obs_next': ob(),
+             'actions': [rs.randn(A).astype(np.float32) for _ in range(N)],
+             'rewards': [float(rs.randn()) for _ in range(N)], 'dones': [bool(rs.rand() < 0.3) for _ in range(N)],
+             'persistent_infos': [[rs.randn(2 * A).astype(np.float32)] for _ in range(N)],
+             'onetime_infos': [] if hid is None else [rs.randn(1, hid).astype(np.float32), rs.randn(1, hid).astype(np.float32)]}
+        if layout == 'array_fields':                 # one array per field (what a device-tier replay hands over)
+            e['actions'] = np.stack(e['actions'])
+            e['rewards'] = np.asarray(e['rewards'], np.float64)
+            e['dones'] = np.asarray(e['dones'])
+        exps.append(e)
+    spec = {'low_dim': {'flat_inputs': [D]}}
+    if pixel:
+        spec['pixel'] = {'camera0': list(pixel)}
+    agg = AG.MultistepAggregatorWithInfo(spec, {'type': 'continuous', 'dim': [A]})
+    native = agg.aggregate(exps, out=_host_batch_out(B, N, D, A, pixel, hid))
+    calls = []
+    real = AG.native_fill()
+    monkeypatch.setattr(AG, '_NATIVE', [True, lambda *a: calls.append(a[2]) or real(*a)])
+    agg.aggregate(exps, out=_host_batch_out(B, N, D, A, pixel, hid))
+    assert 'obs' in calls and 'rewards' in calls and 'persistent_infos' in calls      # the extension is what ran
+    monkeypatch.setattr(AG, '_NATIVE', [True, None])
+    plain = agg.aggregate(exps, out=_host_batch_out(B, N, D, A, pixel, hid))
+
+    def same(a, b, where=''):
+        if isinstance(a, dict):
+            assert list(a) == list(b)
+            for k in a:
+                same(a[k], b[k], where + '/' + str(k))
+        elif isinstance(a, list):
+            assert len(a) == len(b)
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, where + '[%d]' % i)
+        elif a is None:
+            assert b is None, where
+        else:
+            assert a.dtype == b.dtype and not np.isnan(a.astype(np.float64)).any(), where
+            assert np.array_equal(a, b), where
+    same(native, plain)
+
+
+def test_native_batch_assembly_refuses_what_it_cannot_place():
+    from surreal_amd.learner import aggregator as AG
+    fill = AG.native_fill()
+    exps = [{'x': [np.zeros(3, np.float32), np.zeros(3, np.float32)]} for _ in range(2)]
+    assert fill(np.zeros((2, 2, 3), np.float32), exps, 'x', ()) == 4
+    assert fill(np.zeros((2, 2, 4), np.float32), exps, 'x', ()) == -1           # slot size
+    assert fill(np.zeros((3, 2, 3), np.float32), exps, 'x', ()) == -1           # batch size
+    assert fill(np.zeros((2, 3, 3), np.float32), exps, 'x', ()) == -1           # steps
+    assert fill(np.zeros((2, 2, 3), np.float64), exps, 'x', ()) == -1           # staging is float32 / uint8
+    assert fill(np.zeros((2, 2, 3), np.float32)[:, :, ::1].transpose(1, 0, 2), exps, 'x', ()) == -1   # not contiguous
+    assert fill(np.zeros((2, 2, 3), np.float32), exps, 'y', ()) == -1           # no such field
+    out = np.full((2, 2, 3), 7.0, np.float32)
+    assert fill(out, [exps[0], {'x': [np.zeros(3, np.float32), np.zeros(3, np.float16)]}], 'x', ()) == -1
+    assert float(out.min()) == 7.0                                               # nothing written on refusal
+
+
 def test_maxstep_and_framestack_wrappers():
     from surreal_amd.env import MaxStepWrapper, FrameStackWrapper
     from surreal_amd.session import Config
