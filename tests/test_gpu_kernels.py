@@ -692,7 +692,8 @@ def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
         for a, b in zip(jd, jc):
             for key in ('h1', 'h2', 'out', 'h1T', 'h2T', 'dz2', 'dz1', 'dz2T', 'dz1T'):
                 close(a[key], b[key], msg='%s stop=%d' % (key, stop_val))
-            close(a['grads'], b['grads'], atol=2e-6, rtol=2e-5, msg='grads stop=%d' % stop_val)
+            # (two fp32 sums over `rows` terms in different orders: the absolute bound grows with the row count)
+            close(a['grads'], b['grads'], atol=2e-6 if rows <= 1024 else 1e-5, rtol=2e-5, msg='grads stop=%d' % stop_val)
             np.testing.assert_allclose(float(a['sumsq'].sum()), float(b['sumsq'].sum()), rtol=1e-5)
         if stop_val:
             assert float(jd[0]['out'].abs().max()) == 0.0 and float(jd[0]['grads'].abs().max()) == 0.0
