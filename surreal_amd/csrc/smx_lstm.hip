@@ -678,14 +678,20 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     const int pos = colv ? (n / QS) * 4 * Q4 + (n % QS) : 0;       // unit n inside the quartered layout
     if (colv && kq == 0 && a.h0) hs[pos] = a.h0[(size_t)b * H + n];
     float creg = (colv && a.c0) ? a.c0[(size_t)b * H + n] : 0.f;
-    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    // addressing: a UNIFORM row / step base (scalar registers) + a 32-bit lane offset, so that a step's loads and stores
+    // carry no 64-bit vector address arithmetic (it was a fifth of the step's VALU instructions)
+    float* const grow = a.gates + (size_t)b * T * G;          // this row's gates [T][4H]
+    float* const orow = a.out + (size_t)b * T * H;
+    float* const crow = a.cs + (size_t)b * T * H;
+    float* const prow = a.hprev ? a.hprev + (size_t)b * T * H : nullptr;
+    const unsigned ucol = (unsigned)col, un = (unsigned)n;
     // the input half of the gates (smx_linear_f32 wrote it) is requested FOUR steps ahead: the [B, T, 4H] buffer does not
     // stay in L2 between the GEMM and this kernel, and a request made one step ahead -- as in lstm_fwdq_kernel -- makes
     // every 0.9 us step wait for a memory round trip of about that length.  Four named registers rotated by unrolling.
-    float gx0 = colv ? a.gates[gbase + col] : 0.f;
-    float gx1 = (colv && 1 < T) ? a.gates[gbase + (size_t)1 * G + col] : 0.f;
-    float gx2 = (colv && 2 < T) ? a.gates[gbase + (size_t)2 * G + col] : 0.f;
-    float gx3 = (colv && 3 < T) ? a.gates[gbase + (size_t)3 * G + col] : 0.f;
+    float gx0 = colv ? grow[ucol] : 0.f;
+    float gx1 = (colv && 1 < T) ? (grow + G)[ucol] : 0.f;
+    float gx2 = (colv && 2 < T) ? (grow + 2 * G)[ucol] : 0.f;
+    float gx3 = (colv && 3 < T) ? (grow + 3 * G)[ucol] : 0.f;
     const bool odd = (kq & 1) != 0, hi = (kq & 2) != 0;
     __syncthreads();
 #define SMX_FWDK_STEP(GX, TT)                                                                                          \
@@ -714,17 +720,17 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
         const float pre = GX + (tot + bias);                                                                           \
         const float sg = fast_sigm(is_g ? 2.f * pre : pre);                                                          \
         const float act = is_g ? 2.f * sg - 1.f : sg;            /* tanh for the cell candidate, sigmoid otherwise */   \
-        if (colv) a.gates[gbase + (size_t)t * G + col] = act;                                                          \
-        GX = (colv && t + 4 < T) ? a.gates[gbase + (size_t)(t + 4) * G + col] : 0.f;                                   \
+        float* const gstep = grow + (size_t)t * G;                   /* uniform */                                      \
+        if (colv) gstep[ucol] = act;                                                                                   \
+        GX = (colv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                                                \
         const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act); \
         const float c = gf * creg + gi * gg;                                                                           \
         const float h = go * fast_tanh(c);                                                                             \
         creg = c;                                                                                                      \
         if (colv && kq == 0) {                                                                                         \
-            const size_t oh = hbase + (size_t)t * H + n;                                                               \
-            a.out[oh] = h;                                                                                             \
-            a.cs[oh] = c;                                                                                              \
-            if (a.hprev) a.hprev[oh] = hs[p * 16 * Q4 + pos];                                                          \
+            (orow + (size_t)t * H)[un] = h;                                                                            \
+            (crow + (size_t)t * H)[un] = c;                                                                            \
+            if (prow) (prow + (size_t)t * H)[un] = hs[p * 16 * Q4 + pos];                                              \
             hs[(1 - p) * 16 * Q4 + pos] = h;                                                                           \
         }                                                                                                              \
         LSTM_LDS_BARRIER();                                                                                            \
@@ -857,18 +863,23 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
     }
     float* dg = reinterpret_cast<float*>(dg4);
     for (int idx = tid; idx < 2 * 4 * 8 * HH; idx += NT) dg[idx] = 0.f;
-    const size_t gbase = (size_t)b * T * G, hbase = (size_t)b * T * H;
+    // addressing: uniform row / step bases + 32-bit lane offsets (no 64-bit vector address arithmetic inside the step)
+    const float* const grow = a.gates + (size_t)b * T * G;
+    float* const dgrow = a.dgates + (size_t)b * T * G;
+    const float* const crow = a.cs + (size_t)b * T * H;
+    const float* const drow = a.dout + (size_t)b * T * H;
+    const float* const c0row = a.c0 ? a.c0 + (size_t)b * H : nullptr;
+    const unsigned ug = (unsigned)(gb * H + n), un = (unsigned)n;
     float dcreg = 0.f, dhr = 0.f;              // dhr: dh_rec[n] from the previous step's product
     float gmine = 0.f, c = 0.f, cp = 0.f, dout = 0.f;
     auto fetch = [&](int t, float& xg, float& xcp, float& xd) {
-        const size_t oh = hbase + (size_t)t * H + n;
-        xg = a.gates[gbase + (size_t)t * G + (size_t)gb * H + n];      // this lane's own gate of unit n
-        xcp = (t > 0) ? a.cs[oh - H] : (a.c0 ? a.c0[(size_t)b * H + n] : 0.f);
-        xd = a.dout[oh];
+        xg = (grow + (size_t)t * G)[ug];                                 // this lane's own gate of unit n
+        xcp = (t > 0) ? (crow + (size_t)(t - 1) * H)[un] : (c0row ? c0row[un] : 0.f);
+        xd = (drow + (size_t)t * H)[un];
     };
     if (colv) {
         fetch(T - 1, gmine, cp, dout);
-        c = a.cs[hbase + (size_t)(T - 1) * H + n];
+        c = (crow + (size_t)(T - 1) * H)[un];
     }
     const bool upper = (tid & 4) != 0;         // the quad of unit uA + 1
     __syncthreads();
@@ -888,7 +899,7 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
         dcreg = dc * gf;
         const float mine = gb == 0 ? dgi : (gb == 1 ? dgf : (gb == 2 ? dgg : dgo));
         if (colv) {
-            a.dgates[gbase + (size_t)t * G + (size_t)gb * H + n] = mine;
+            (dgrow + (size_t)t * G)[ug] = mine;
             dg[((p * 4 + gb) * 8 * HH) + n] = mine;
         }
         LSTM_LDS_BARRIER();
