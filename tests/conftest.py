@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.dirname(os.path.abspath(__
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the host-side CPython extension (csrc/host/smx_host.c -> surreal_amd/_smx_host.so): built here, incrementally, so
+    # that a fresh checkout's first test run has it (gcc, two seconds; test_abi_symbols does the same for the HIP library)
+    try:
+        from surreal_amd import build
+        build.build_host(verbose=False)
+    except Exception as e:                     # the tests that need it say so themselves
+        import warnings
+        warnings.warn('could not build surreal_amd/_smx_host.so: %r' % (e,))
 
 
 @pytest.fixture
