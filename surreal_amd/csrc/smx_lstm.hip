@@ -626,13 +626,13 @@ __global__ __launch_bounds__(NT) void lstm_fwdq_kernel(FwdArgs a) {
 // registers), and the quad's partial sums meet by a DPP reduce-scatter: lane kq ends with gate kq's sum in the fixed
 // order (q0 + q1) + (q2 + q3), activates it, and the cell update proceeds as in lstm_fwdq_kernel.
 // ===========================================================================================
-// Gate non-linearities on the hardware exp2 / rcp units.  A step of the one-row recurrence is VALU-issue bound (8
-// wavefronts x ~200 instructions on 4 SIMDs = 1600 of its 2040 cycles), and more than half of those instructions were
-// the libm expf / tanhf / IEEE division of sigmoid and tanh -- executed on BOTH sides of the tanh-or-sigmoid branch,
-// since the four gates of a unit sit in one quad.  sigmoid(z) = rcp(1 + exp2(-z log2 e)) is 5 instructions; tanh(x) =
-// 2 sigmoid(2 x) - 1 shares them, so a lane's gate is ONE branch-free sequence.  Absolute error <= 1.5e-7 (v_exp_f32 and
-// v_rcp_f32 are 1 ulp; the argument scaling adds |z| 2^-24 relative to an exponent whose sensitivity s (1 - s) |z| peaks
-// at 0.22) against the 1e-5 parity bound.
+// Gate non-linearities on the hardware exp2 / rcp units.  A step of the one-row recurrence lasts as long as ONE wavefront
+// needs for its own in-order instruction stream (profiles/r03_pmc_lstm.json: vector ALUs 24 % busy, LDS 2 % -- nothing is
+// saturated), and more than half of that stream was the libm expf / tanhf / IEEE division of sigmoid and tanh -- on
+// BOTH sides of the tanh-or-sigmoid branch, since the four gates of a unit sit in one quad.  sigmoid(z) = rcp(1 +
+// exp2(-z log2 e)) is 5 instructions; tanh(x) = 2 sigmoid(2 x) - 1 shares them, so a lane's gate is ONE branch-free
+// sequence.  Absolute error <= 1.5e-7 (v_exp_f32 and v_rcp_f32 are 1 ulp; the argument scaling adds |z| 2^-24 relative
+// to an exponent whose sensitivity s (1 - s) |z| peaks at 0.22) against the 1e-5 parity bound.
 __device__ __forceinline__ float fast_sigm(float z) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z));
 }
