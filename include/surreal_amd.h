@@ -590,6 +590,17 @@ int smx_gather_rows_f32(const float* table, int64_t capacity, int32_t width,
  * (random.randint(0, len-1) per draw in the reference, uniform_replay.py:44-45) */
 int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
                         uint64_t offset, smx_stream_t stream);
+/* UniformReplay.sample (surreal/replay/uniform_replay.py:36-47) over a device-resident replay in ONE launch: the rows
+ * idx[i] (or, idx == NULL, the rows smx_uniform_indices(len, seed, offset) would draw -- the same Philox counters) of up
+ * to 8 field tables [capacity, row_bytes] -> dst [rows, row_bytes] each.  idx_out (nullable) receives the indices. */
+typedef struct {
+    const void* table;
+    void* dst;
+    int64_t row_bytes;
+} smx_gather_job_t;
+int smx_uniform_gather_multi(const smx_gather_job_t* jobs, int32_t njobs, int64_t capacity, int64_t rows,
+                             const int64_t* idx, int64_t len, uint64_t seed, uint64_t offset, int64_t* idx_out,
+                             smx_stream_t stream);
 
 /* The same two copies for fields of any element width: a row is `row_bytes` opaque bytes (uint8 camera frames --
  * `pixel_input`, surreal/env/wrapper.py observation specs -- stay uint8 in HBM: a quarter of the table and copy

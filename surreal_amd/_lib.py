@@ -117,6 +117,11 @@ class LinearJob(Structure):
                 ('K', c_int32), ('stop_flag', c_void_p)]
 
 
+class GatherJob(Structure):
+    """smx_gather_job_t"""
+    _fields_ = [('table', c_void_p), ('dst', c_void_p), ('row_bytes', c_int64)]
+
+
 class SynthRollout(Structure):
     """smx_synth_rollout_t"""
     _fields_ = [('net', POINTER(Mlp3)), ('packed', c_void_p), ('out_act', c_int32), ('n', c_int32),
@@ -235,6 +240,8 @@ _SIGS = {
     'smx_ring_insert_f32': (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, _P]),
     'smx_gather_rows_f32': (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
     'smx_uniform_indices': (c_int32, [_P, c_int64, c_int64, c_uint64, c_uint64, _P]),
+    'smx_uniform_gather_multi': (c_int32, [POINTER(GatherJob), c_int32, c_int64, c_int64, _P, c_int64, c_uint64, c_uint64,
+                                           _P, _P]),
     'smx_window_emit_f32': (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, _P, _P]),
     'smx_synth_act_env_step_f32': (c_int32, [POINTER(SynthActStep), _P]),

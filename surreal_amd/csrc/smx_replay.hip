@@ -25,12 +25,24 @@ constexpr int ROW_SEG_BYTES = ROW_SEG * 4;
 // (16: float4 lanes, 4: dwords, 1: bytes) -- fp32 fields are rows of 4-byte units, uint8 camera frames
 // (3 x 84 x 84 = 21 168 B = 1323 float4) move as what they are instead of being widened to fp32.
 template <typename SrcRow, typename DstRow>
+__device__ __forceinline__ void copy_rows_bytes_part(const unsigned char* __restrict__ src,
+                                                     unsigned char* __restrict__ dst, long n, long row_bytes,
+                                                     int gran, SrcRow srow, DstRow drow, long wave, long nwaves);
+
+template <typename SrcRow, typename DstRow>
 __device__ __forceinline__ void copy_rows_bytes(const unsigned char* __restrict__ src,
                                                 unsigned char* __restrict__ dst, long n, long row_bytes,
                                                 int gran, SrcRow srow, DstRow drow) {
+    copy_rows_bytes_part(src, dst, n, row_bytes, gran, srow, drow, ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6,
+                         ((long)gridDim.x * blockDim.x) >> 6);
+}
+
+// the same for the waves [wave, wave + nwaves, ...) of a PART of the grid (several tables gathered by one launch)
+template <typename SrcRow, typename DstRow>
+__device__ __forceinline__ void copy_rows_bytes_part(const unsigned char* __restrict__ src,
+                                                     unsigned char* __restrict__ dst, long n, long row_bytes,
+                                                     int gran, SrcRow srow, DstRow drow, long wave, long nwaves) {
     const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const int nseg = (int)((row_bytes + ROW_SEG_BYTES - 1) / ROW_SEG_BYTES);
     const long items = n * nseg;
     for (long it = wave; it < items; it += nwaves) {
@@ -115,6 +127,51 @@ __global__ __launch_bounds__(256) void uniform_indices_kernel(int64_t* __restric
     // 64 random bits -> [0, len) by 128-bit multiply-high (bias < len / 2^64)
     const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
     idx[i] = (int64_t)__umul64hi(r64, len);
+}
+
+__device__ __forceinline__ long philox_index(uint64_t ctr, uint64_t len, uint64_t seed) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const uint64_t r64 = ((uint64_t)c[0] << 32) | c[1];
+    return (long)__umul64hi(r64, len);
+}
+
+// A whole uniform sample in ONE launch (UniformReplay.sample, surreal/replay/uniform_replay.py:36-47): every field's
+// table is gathered by its own part of the grid; the row indices are the ones smx_uniform_indices would write (the same
+// Philox counters), formed where they are used -- or read from `idx` when the caller injects them.
+struct GatherJobs {
+    const unsigned char* table[8];
+    unsigned char* dst[8];
+    long row_bytes[8];
+    int gran[8];
+    int block0[9];          // first workgroup of each job, [n] = grid size
+    int n;
+};
+__global__ __launch_bounds__(256) void uniform_gather_multi_kernel(GatherJobs J, long capacity, long rows,
+                                                                   const int64_t* __restrict__ idx, uint64_t len,
+                                                                   uint64_t seed, uint64_t offset,
+                                                                   int64_t* __restrict__ idx_out) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) j += (k < J.n && (int)blockIdx.x >= J.block0[k]) ? 1 : 0;
+    const long wave = ((long)((int)blockIdx.x - J.block0[j]) * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)(J.block0[j + 1] - J.block0[j]) * blockDim.x) >> 6;
+    if (idx_out && j == 0)
+        for (long i = (long)((int)blockIdx.x - J.block0[0]) * blockDim.x + threadIdx.x; i < rows;
+             i += (long)(J.block0[1] - J.block0[0]) * blockDim.x)
+            idx_out[i] = idx ? idx[i] : (int64_t)philox_index(offset + (uint64_t)i, len, seed);
+    copy_rows_bytes_part(J.table[j], J.dst[j], rows, J.row_bytes[j], J.gran[j],
+                         [=](long i) {
+                             long r = idx ? (long)idx[i] : philox_index(offset + (uint64_t)i, len, seed);
+                             return r < 0 ? 0 : (r >= capacity ? capacity - 1 : r);
+                         },
+                         [](long i) { return i; }, wave, nwaves);
 }
 
 __global__ __launch_bounds__(256) void window_emit_kernel(const float* __restrict__ src, int actors,
@@ -442,6 +499,31 @@ extern "C" int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_
     SMX_REQUIRE(n > 0 && len > 0, SMX_E_SHAPE);
     hipLaunchKernelGGL(uniform_indices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        smx_s(stream), idx, (long)n, (uint64_t)len, seed, offset);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_uniform_gather_multi(const smx_gather_job_t* jobs, int32_t njobs, int64_t capacity, int64_t rows,
+                                        const int64_t* idx, int64_t len, uint64_t seed, uint64_t offset,
+                                        int64_t* idx_out, smx_stream_t stream) {
+    SMX_REQUIRE(jobs, SMX_E_NULL);
+    SMX_REQUIRE(njobs >= 1 && njobs <= 8 && capacity > 0 && rows > 0 && (idx || (len > 0 && len <= capacity)), SMX_E_SHAPE);
+    GatherJobs J;
+    J.n = njobs;
+    int base = 0;
+    for (int k = 0; k < njobs; ++k) {
+        SMX_REQUIRE(jobs[k].table && jobs[k].dst, SMX_E_NULL);
+        SMX_REQUIRE(jobs[k].row_bytes > 0, SMX_E_SHAPE);
+        J.table[k] = (const unsigned char*)jobs[k].table;
+        J.dst[k] = (unsigned char*)jobs[k].dst;
+        J.row_bytes[k] = (long)jobs[k].row_bytes;
+        J.gran[k] = byte_gran(jobs[k].table, jobs[k].dst, (long)jobs[k].row_bytes);
+        J.block0[k] = base;
+        base += (int)row_blocks_bytes((long)rows, (long)jobs[k].row_bytes);
+    }
+    for (int k = njobs; k <= 8; ++k) J.block0[k] = base;
+    hipLaunchKernelGGL(uniform_gather_multi_kernel, dim3((unsigned)base), dim3(256), 0, smx_s(stream), J, (long)capacity,
+                       (long)rows, idx, (uint64_t)len, seed, offset, idx_out);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -459,6 +459,17 @@ class HipKernels(object):
             L.call('smx_gather_rows_bytes', L.ptr(table), cap, width * table.element_size(), L.ptr(idx),
                    idx.numel(), L.ptr(dst), self._st())
 
+    def uniform_gather_multi(self, tables, outs, length, seed, offset, idx=None, idx_out=None):
+        """a whole uniform sample in one launch: row idx[i] -- or, idx None, the row smx_uniform_indices(length, seed,
+        offset) would draw -- of every table [capacity, width] -> outs[k] [rows, width] (<= 8 tables, fp32 or uint8)"""
+        arr = (L.GatherJob * len(tables))()
+        cap, rows = tables[0].shape[0], outs[0].shape[0]
+        for k, (t, o) in enumerate(zip(tables, outs)):
+            assert t.dtype == o.dtype and o.is_contiguous() and t.shape[0] == cap and o.shape[0] == rows
+            arr[k].table, arr[k].dst, arr[k].row_bytes = L.ptr(t), L.ptr(o), t.shape[1] * t.element_size()
+        L.call('smx_uniform_gather_multi', arr, len(tables), cap, rows, L.ptr(idx), int(length), int(seed), int(offset),
+               L.ptr(idx_out), self._st())
+
     def uniform_indices(self, idx, length, seed, offset):
         L.call('smx_uniform_indices', L.ptr(idx), idx.numel(), int(length), int(seed), int(offset),
                self._st())

@@ -310,11 +310,19 @@ class DDPGLearner(Learner):
         K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                         ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
         K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
-        for tgt, src in ((mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat)):
+        for tgt, src in self._target_pairs(mt, m):
             if self.target_update_type == 'soft':
                 K.soft_update(tgt, src, self.target_update_tau)
             else:
                 K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
+
+    @staticmethod
+    def _target_pairs(mt, m):
+        """(target, source) buffers of the target-network update (ddpg.py:344-352): actor + critic as the one buffer they
+        share when both models have it"""
+        if getattr(mt, 'ac_flat', None) is not None and getattr(m, 'ac_flat', None) is not None:
+            return ((mt.ac_flat, m.ac_flat),)
+        return ((mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat))
 
     def _enqueue_iteration(self, ws, x, xn, actions, rewards, done, pix=None, pix_next=None):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
@@ -406,7 +414,7 @@ class DDPGLearner(Learner):
         K.ddpg_stats(ws.q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
         self._average_over_ranks(ws.stats[:6])       # means over the global batch (max |a| stays local)
         # ---- target networks (ddpg.py:389-428) ----
-        pairs = [(mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat)]
+        pairs = list(self._target_pairs(mt, m))
         if self.is_pixel_input:
             pairs.append((mt.perception_flat, m.perception_flat))
         if self.use_double_critic:

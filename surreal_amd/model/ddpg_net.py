@@ -56,17 +56,23 @@ class DDPGModel(object):
         self.device = device
         ah, ch = list(actor_fc_hidden_sizes), list(critic_fc_hidden_sizes)
         self.c1, self.c2 = ch
-        self.actor_flat = None
-        if not critic_only:
-            self.actor_flat = torch.empty(Mlp3Params.count(D, ah[0], ah[1], A), device=device)
-            self.actor = Mlp3Params(self.actor_flat, 0, D, ah[0], ah[1], A)
-        else:
-            self.actor = None
         c1, c2 = ch
         sizes = [('W1', (c1, D)), ('b1', (c1,)), ('W2', (c2, c1 + A)), ('b2', (c2,)),
                  ('W3', (1, c2)), ('b3', (1,))]
         n = sum(int(np.prod(s)) for _, s in sizes)
-        self.critic_flat = torch.empty(n, device=device)
+        self.actor_flat = self.ac_flat = None
+        if not critic_only:
+            # actor and critic parameters live in ONE buffer (each on a 256-byte boundary, the gap zero): the target
+            # network's soft / hard update is then one launch over `ac_flat` instead of one per network
+            na = Mlp3Params.count(D, ah[0], ah[1], A)
+            na_pad = (na + 63) // 64 * 64
+            self.ac_flat = torch.zeros(na_pad + n, device=device)
+            self.actor_flat = self.ac_flat[:na]
+            self.actor = Mlp3Params(self.actor_flat, 0, D, ah[0], ah[1], A)
+            self.critic_flat = self.ac_flat[na_pad:na_pad + n]
+        else:
+            self.actor = None
+            self.critic_flat = torch.empty(n, device=device)
         self.critic = collections.OrderedDict()
         o = 0
         for name, shp in sizes:

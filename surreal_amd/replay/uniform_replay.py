@@ -67,7 +67,17 @@ class UniformReplay(Replay):
         return idx
 
     def sample_batch(self, batch_size, indices=None):
-        idx = self.sample_indices(batch_size) if indices is None else \
-            torch.as_tensor(indices, dtype=torch.int64).to(self._dev)
+        """one launch for the whole sample (smx_uniform_gather_multi): every field's rows, the indices drawn where they
+        are used -- the same Philox counters as sample_indices(), so the two agree row for row"""
+        idx = None if indices is None else torch.as_tensor(indices, dtype=torch.int64).to(self._dev)
         self.cumulative_sampled_count += batch_size
-        return {name: tab.gather(idx) for name, tab in self._tables.items()}
+        names = list(self._tables)
+        if len(names) > 8:                       # (more fields than one launch carries: field by field)
+            idx = self.sample_indices(batch_size) if idx is None else idx
+            return {name: tab.gather(idx) for name, tab in self._tables.items()}
+        tabs = [self._tables[k] for k in names]
+        outs = [torch.empty(batch_size, t.width, device=self._dev, dtype=t.dtype) for t in tabs]
+        self._K.uniform_gather_multi([t.data for t in tabs], outs, self._dev_len, self.seed, self._draws, idx=idx)
+        if idx is None:
+            self._draws += batch_size
+        return {k: o.view((batch_size,) + t.shape) for k, o, t in zip(names, outs, tabs)}

@@ -640,6 +640,16 @@ class TorchCpuKernels(object):
         g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2 ** 63))
         idx.copy_(torch.randint(0, int(length), idx.shape, generator=g))
 
+    def uniform_gather_multi(self, tables, outs, length, seed, offset, idx=None, idx_out=None):
+        if idx is None:
+            idx = torch.empty(outs[0].shape[0], dtype=torch.int64)
+            self.uniform_indices(idx, length, seed, offset)
+        if idx_out is not None:
+            idx_out.copy_(idx)
+        j = idx.clamp(0, tables[0].shape[0] - 1)
+        for t, o in zip(tables, outs):
+            o.copy_(t[j])
+
     def window_emit(self, src, start, n_step, stride, W, dst):
         actors, T, width = src.shape
         out = torch.stack([src[:, start + w * stride:start + w * stride + n_step] for w in range(W)], 1)

@@ -375,6 +375,34 @@ def test_value_loss(K):
         assert int(res['hip'][2].cpu().view(torch.int32)[L.C_STEP_CRITIC]) == 1
 
 
+def test_uniform_gather_multi_is_uniform_indices_plus_gather_rows(K):
+    """UniformReplay.sample in one launch (smx_uniform_gather_multi): the rows it draws are the ones smx_uniform_indices
+    draws with the same (length, seed, offset) -- same Philox counters -- and every field (fp32 rows of odd and wide
+    widths, uint8 camera frames, one-float rows) equals smx_gather_rows over those indices; injected indices (incl. out
+    of range: clamped like smx_gather_rows) take precedence"""
+    cap, rows = 5000, 777
+    g = torch.Generator(device='cuda').manual_seed(3)
+    tabs = [torch.randn(cap, 17, device='cuda', generator=g), torch.randn(cap, 4100, device='cuda', generator=g),
+            torch.randn(cap, 1, device='cuda', generator=g), torch.randn(cap, 6, device='cuda', generator=g),
+            torch.randint(0, 256, (cap, 3 * 20 * 20), device='cuda', dtype=torch.uint8, generator=g)]
+    for length, seed, offset in ((cap, 12345, 0), (1234, 2 ** 40 + 7, 10 ** 9 + 3)):
+        outs = [torch.full((rows, t.shape[1]), 0, device='cuda', dtype=t.dtype) for t in tabs]
+        got_idx = torch.full((rows,), -1, dtype=torch.int64, device='cuda')
+        K.uniform_gather_multi(tabs, outs, length, seed, offset, idx_out=got_idx)
+        idx = torch.empty(rows, dtype=torch.int64, device='cuda')
+        K.uniform_indices(idx, length, seed, offset)
+        assert torch.equal(got_idx, idx) and int(idx.max()) < length and int(idx.min()) >= 0
+        for t, o in zip(tabs, outs):
+            ref = torch.empty_like(o)
+            K.gather_rows(t, idx, ref)
+            assert torch.equal(o, ref) and torch.equal(o, t[idx])
+    inj = torch.randint(-3, cap + 3, (rows,), device='cuda', generator=g)
+    outs = [torch.empty(rows, t.shape[1], device='cuda', dtype=t.dtype) for t in tabs]
+    K.uniform_gather_multi(tabs, outs, cap, 1, 0, idx=inj)
+    for t, o in zip(tabs, outs):
+        assert torch.equal(o, t[inj.clamp(0, cap - 1)])
+
+
 def test_clip_adam_matches_torch_optim(K):
     """three consecutive steps against torch.optim.Adam + clip_grad_norm_ on CPU"""
     g = torch.Generator().manual_seed(21)
