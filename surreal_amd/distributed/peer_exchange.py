@@ -37,34 +37,59 @@ class PeerExchange(object):
         self.lib = L.load()
         self.device = torch.device('cuda', torch.cuda.current_device())
         nbytes = self.lib.smx_xchg_bytes(self.capacity, self.world)
-        own, kind = ctypes.c_void_p(), ctypes.c_int32()
-        L.call('smx_xchg_alloc', nbytes, float(timeout_s), ctypes.byref(own), ctypes.byref(kind), L.current_stream())
-        self._own, self.memory_kind = own, ('uncached', 'fine-grained', 'device')[kind.value]
-        self._opened = []
-        handle = (ctypes.c_uint8 * 64)()
-        L.call('smx_xchg_export', own, handle)
-        # the handles through the process group (64 bytes per rank; a CPU tensor for gloo, a device one for RCCL)
+        # Set-up is collective, and so are its failures: a rank whose allocation / export / mapping fails still takes part
+        # in the handle gather and in the final agreement, so that EVERY rank raises (and PeerExchange.create falls back
+        # on every rank) instead of one rank leaving its peers inside a collective.
         backend = dist.get_backend()
         where = self.device if backend == 'nccl' else 'cpu'
-        mine = torch.tensor(list(bytes(handle)), dtype=torch.uint8, device=where)
-        every = torch.empty(self.world * 64, dtype=torch.uint8, device=where)
+        self._own, self._opened, self.memory_kind = None, [], '?'
+        problem = None
+        handle = (ctypes.c_uint8 * 64)()
+        try:
+            own, kind = ctypes.c_void_p(), ctypes.c_int32()
+            L.call('smx_xchg_alloc', nbytes, float(timeout_s), ctypes.byref(own), ctypes.byref(kind), L.current_stream())
+            self._own, self.memory_kind = own, ('uncached', 'fine-grained', 'device')[kind.value]
+            L.call('smx_xchg_export', own, handle)
+        except Exception as e:
+            problem = 'allocation / export: %r' % (e,)
+        # the handles through the process group (64 bytes + an ok byte per rank; a CPU tensor for gloo, a device one for RCCL)
+        mine = torch.tensor(list(bytes(handle)) + [0 if problem else 1], dtype=torch.uint8, device=where)
+        every = torch.empty(self.world * 65, dtype=torch.uint8, device=where)
         dist.all_gather_into_tensor(every, mine)
-        every = every.cpu().numpy().reshape(self.world, 64)
+        every = every.cpu().numpy().reshape(self.world, 65)
+        if problem is None and not every[:, 64].all():
+            problem = 'rank(s) %s could not allocate / export' % [int(r) for r in range(self.world) if not every[r, 64]]
         self.x = L.Xchg()
         self.x.world, self.x.rank, self.x.capacity = self.world, self.rank, self.capacity
-        for p in range(self.world):
-            if p == self.rank:
-                self.x.peer[p] = own.value
-                continue
-            h = (ctypes.c_uint8 * 64)(*every[p].tolist())
-            mapped = ctypes.c_void_p()
-            L.call('smx_xchg_open', h, ctypes.byref(mapped))
-            self._opened.append(mapped)
-            self.x.peer[p] = mapped.value
+        if problem is None:
+            try:
+                for p in range(self.world):
+                    if p == self.rank:
+                        self.x.peer[p] = self._own.value
+                        continue
+                    h = (ctypes.c_uint8 * 64)(*every[p, :64].tolist())
+                    mapped = ctypes.c_void_p()
+                    L.call('smx_xchg_open', h, ctypes.byref(mapped))
+                    self._opened.append(mapped)
+                    self.x.peer[p] = mapped.value
+            except Exception as e:
+                problem = 'mapping a peer buffer: %r' % (e,)
         self._status = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.exchanges = 0
         torch.cuda.synchronize()
-        dist.barrier()                       # nobody polls a buffer that is not mapped and zeroed yet
+        ok = torch.tensor([0.0 if problem else 1.0], device=where)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # (also the barrier: nobody polls a buffer that is not mapped yet)
+        if float(ok) < 1.0:
+            self._release()
+            raise RuntimeError('peer exchange set-up failed: %s' % (problem or 'on another rank'))
+
+    def _release(self):
+        for m in self._opened:
+            self.lib.smx_xchg_close(m)
+        self._opened = []
+        if self._own is not None:
+            self.lib.smx_xchg_free(self._own)
+            self._own = None
 
     # ---- the two collectives ---------------------------------------------------------------------
     def all_reduce(self, t, err=None):
@@ -91,9 +116,12 @@ class PeerExchange(object):
     # ---- validation before use ---------------------------------------------------------------------
     def self_check(self, rounds=16):
         """`rounds` all-reduces and all-gathers of changing vectors against the process group's results,
-        plus bit-equality across ranks.  Collective; returns (ok, message)."""
+        plus bit-equality across ranks.  Collective; returns (ok, message).  Every rank runs EVERY round whatever it
+        has seen so far: a rank that left early would issue a different sequence of process-group collectives than its
+        peers (after a device error the exchange's own waits return at once, so a broken exchange costs no time)."""
         g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
         sizes = [self.capacity, max(4, self.capacity // 3 + 1), 3, 1031][:max(2, min(4, rounds))]
+        fail = None
         for r in range(rounds):
             n = min(self.capacity, sizes[r % len(sizes)])
             a = (torch.rand(n, generator=g) - 0.5).to(self.device)
@@ -101,27 +129,29 @@ class PeerExchange(object):
             self.dist.all_reduce(want)
             got = a.clone()
             self.all_reduce(got)
-            if not torch.allclose(got, want, rtol=1e-5, atol=1e-6):
-                return False, 'all-reduce round %d (n = %d): max diff %g' % (r, n, float((got - want).abs().max()))
+            if fail is None and not torch.allclose(got, want, rtol=1e-5, atol=1e-6):
+                fail = 'all-reduce round %d (n = %d): max diff %g' % (r, n, float((got - want).abs().max()))
             # replicas must be bit-identical: compare a checksum of the raw bits through the group
             bits = got.view(torch.int32).to(torch.int64)
             ck = torch.stack([bits.sum(), (bits * torch.arange(1, n + 1, device=self.device) % 1000003).sum()]).double()
             lo, hi = ck.clone(), ck.clone()
             self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
             self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
-            if not torch.equal(lo, hi):
-                return False, 'all-reduce round %d: ranks hold different bits' % r
+            if fail is None and not torch.equal(lo, hi):
+                fail = 'all-reduce round %d: ranks hold different bits' % r
             m = min(n, self.capacity // self.world)
             part = a[:m].contiguous()
             want_g = torch.empty(self.world * m, device=self.device)
             self.dist.all_gather_into_tensor(want_g, part)
             got_g = torch.empty(self.world * m, device=self.device)
             self.all_gather_into_tensor(got_g, part)
-            if not torch.equal(got_g, want_g):
-                return False, 'all-gather round %d (n = %d) differs' % (r, m)
+            if fail is None and not torch.equal(got_g, want_g):
+                fail = 'all-gather round %d (n = %d) differs' % (r, m)
         done, err = self.status()
         if err:
-            return False, 'device error word 0x%x (timeout | phase << 4 | peer)' % err
+            return False, 'device error word 0x%x (timeout | phase << 4 | peer)%s' % (err, '; ' + fail if fail else '')
+        if fail is not None:
+            return False, fail
         return True, '%d rounds, memory %s' % (rounds, self.memory_kind)
 
     @classmethod
@@ -156,9 +186,4 @@ class PeerExchange(object):
 
     def close(self):
         torch.cuda.synchronize()
-        for m in self._opened:
-            self.lib.smx_xchg_close(m)
-        self._opened = []
-        if self._own is not None:
-            self.lib.smx_xchg_free(self._own)
-            self._own = None
+        self._release()

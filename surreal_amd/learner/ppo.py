@@ -540,7 +540,7 @@ class PPOLearner(Learner):
             d.exchange = None
         from surreal_amd.distributed.peer_exchange import PeerExchange
         d.exchange = PeerExchange.create(d._d, need, timeout_s=float(self.session_config.learner.get(
-            'peer_exchange_timeout_s', 2.0)))
+            'peer_exchange_timeout_s', 5.0)))
         self.exchange_kind = 'peer buffers (%s)' % d.exchange.check_message if d.exchange is not None else 'process group'
 
     # ======================================================================================

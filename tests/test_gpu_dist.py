@@ -251,6 +251,25 @@ def _xchg_worker(rank, world, port, q, mode):
             out['exchanges'] = done
             dist.barrier()
             ex.close()
+        elif mode == 'setup_failure':
+            # one rank cannot allocate its buffer: EVERY rank must come back from create() with None (the process-group
+            # fallback), none may be left inside a collective
+            from surreal_amd import _lib as LL
+            if rank == 1:
+                real = LL.call
+
+                def failing(name, *a):
+                    if name == 'smx_xchg_alloc':
+                        raise LL.SmxError('injected allocation failure')
+                    return real(name, *a)
+                LL.call = failing
+                import surreal_amd.distributed.peer_exchange as PX
+                PX.L.call = failing
+            t0 = time.perf_counter()
+            ex = PeerExchange.create(dist, 4096, timeout_s=1.0, rounds=4)
+            out['none'] = ex is None
+            out['s'] = time.perf_counter() - t0
+            dist.barrier()
         else:
             # a peer that never shows up: the wait is bounded, the error words say who was missing, later waits
             # return at once, nothing hangs
@@ -309,6 +328,12 @@ def test_peer_exchange_is_the_rank_ordered_sum_and_replays_in_a_graph(world):
     if os.path.isdir(d):
         import json
         json.dump(res[0], open(os.path.join(d, 'peer_exchange_w%d.json' % world), 'w'))
+
+
+def test_peer_exchange_setup_failure_on_one_rank_falls_back_on_all():
+    res = _run_xchg(2, 'setup_failure')
+    assert res[0]['none'] and res[1]['none'], res
+    assert res[0]['s'] < 20 and res[1]['s'] < 20, res
 
 
 def test_peer_exchange_wait_is_bounded_and_reports_the_missing_peer():
