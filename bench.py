@@ -23,8 +23,10 @@ the reference's own code -- timed on this host over a sweep of thread counts: th
 single-thread figure), at N > 1 a `strong` entry (the SAME global batch of 1024 sub-trajectories
 split over the ranks) next to the weak-scaling headline, and at N = 1 `secondary` entries for the
 other BASELINE configurations (PPO 64 x 128 HalfCheetah shapes with the MLP and with the reference's
-default LSTM policy, DDPG batch 512 off a 1e6-row uniform replay, PPO on 256 actors of 3x84x84 camera
-frames).
+default LSTM policy -- the latter also at 1024 x 128 --, DDPG batch 512 off a 1e6-row uniform replay, PPO
+on 256 actors of 3x84x84 camera frames), the whole on-device loops (rollout -> windows -> FIFO -> learn,
+low-dim and pixel) and the host-fed learner (batches from host memory through the pinned double-buffered
+ingest, incl. the path that starts from the collector's per-step Python objects).
 """
 import argparse
 import copy
