@@ -289,7 +289,8 @@ typedef struct {
     int32_t adam_step_actor, adam_step_critic; /* torch.optim.Adam 'step' state */
     int32_t stop_flag;     /* set when KL(ref||curr) > 4*kl_target (ppo.py:556-557) */
     int32_t epochs_done;   /* policy epochs actually applied this learn() */
-    int32_t reserved[2];
+    int32_t reserved[2];   /* [0]: error word of a peer exchange (smx_xchg_*: pass its address as `err`); non-zero
+                              makes smx_clip_adam* skip the step.  [1]: unused */
 } smx_ppo_ctrl_t;
 
 /* per-epoch statistics slots (floats) written by the kernels; see ppo.py:219-224,278-284 */

@@ -294,7 +294,9 @@ extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t 
     const smx_mlp3_t& n = *a->net;
     SMX_REQUIRE(smx_synth_rollout_supported(n.D, n.H1, n.H2, n.OUT), SMX_E_UNSUPPORTED);
     SMX_REQUIRE(a->n > 0 && a->steps > 0 && a->episode_len > 0 && a->rows_per_actor > 0, SMX_E_SHAPE);
-    SMX_REQUIRE(a->slot >= 0 && (!a->obs_roll || a->slot + a->steps <= a->rows_per_actor), SMX_E_SHAPE);
+    // (every roll table is indexed by slot + step: the bound holds whichever of them is recorded)
+    const bool records = a->obs_roll || a->act_roll || a->rew_roll || a->done_roll || a->pd_roll;
+    SMX_REQUIRE(a->slot >= 0 && (!records || a->slot + a->steps <= a->rows_per_actor), SMX_E_SHAPE);
     SMX_REQUIRE(((uintptr_t)a->packed & 15) == 0 && ((uintptr_t)n.b1 & 3) == 0, SMX_E_ALIGN);
     SMX_REQUIRE((a->zsum == nullptr) == (a->zsumsq == nullptr) && (a->zsum == nullptr) == (a->zcount == nullptr), SMX_E_NULL);
     RollArgs G;

@@ -122,18 +122,21 @@ __device__ __forceinline__ bool wait_peers(const smx_xchg_t& X, const View& own,
 }
 
 __device__ __forceinline__ void release_flag(const View& own, int phase, int w, unsigned seq) {
-    // barrier (workgroup-scope release/acquire of every lane's stores), then lane 0's SYSTEM-scope release: write back
-    // the L2 + s_waitcnt vmcnt(0) behind the workgroup's stores (a CU's vector memory operations reach the L2 in order;
-    // the fence is cumulative), then the flag
+    // EVERY wavefront takes a SYSTEM-scope release behind its own stores (s_waitcnt vmcnt(0) + write-back: a wavefront's
+    // fence only covers that wavefront's stores, and the workgroup barrier does not wait on vmcnt -- with lane 0 alone
+    // fencing, the other seven wavefronts' stores to S / R were not formally ordered in front of the flag), then the
+    // barrier, then lane 0 publishes the flag with a system-scope release store
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // "" = system scope
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // "" = system scope
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __hip_atomic_store(flag_of(own, phase, w), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 // the exchange's last workgroup publishes the new sequence number (the next launch reads it at its start)
 __device__ __forceinline__ void finish(const View& own, unsigned seq) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // every wavefront's stores to `out` are out before the ticket
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -173,14 +176,17 @@ __global__ __launch_bounds__(XTH) void xchg_allreduce_kernel(smx_xchg_t X, const
     }
     release_flag(own, 0, w, seq);
     // ---- 1: reduce chunk `rank` over the ranks, in rank order ---------------------------------------
-    wait_peers(X, own, 0, w, seq, err_out);
+    // a wait that timed out leaves `out` alone from here on (what it would sum is not what the peers meant to send);
+    // the flags are still published so that a peer which is merely late is not held up as well, and the optimiser
+    // launch that follows skips its step when the error word is up (clip_adam_kernel)
+    const bool ok0 = wait_peers(X, own, 0, w, seq, err_out);
     const float* Sp[XW];
 #pragma unroll
     for (int p = 0; p < XW; ++p) Sp[p] = view(X.peer[p < W ? p : 0], X.capacity, X.world).S;
     float* Rmine = own.R + (size_t)(seq & 1u) * chunk_cap(X.capacity, W);
     {
         const long base = (long)X.rank * chunk;
-        for (long i = s0 + 4L * threadIdx.x; i < s1; i += 4L * XTH) {
+        for (long i = s0 + 4L * threadIdx.x; ok0 && i < s1; i += 4L * XTH) {
             float4 v[XW];
 #pragma unroll
             for (int p = 0; p < XW; ++p)
@@ -201,12 +207,12 @@ __global__ __launch_bounds__(XTH) void xchg_allreduce_kernel(smx_xchg_t X, const
     }
     release_flag(own, 1, w, seq);
     // ---- 2: pull the other ranks' reduced chunks ------------------------------------------------------
-    wait_peers(X, own, 1, w, seq, err_out);
+    const bool ok1 = wait_peers(X, own, 1, w, seq, err_out) && ok0;
     const float* Rp[XW];
 #pragma unroll
     for (int p = 0; p < XW; ++p)
         Rp[p] = view(X.peer[p < W ? p : 0], X.capacity, X.world).R + (size_t)(seq & 1u) * chunk_cap(X.capacity, W);
-    for (long i = s0 + 4L * threadIdx.x; i < s1; i += 4L * XTH) {
+    for (long i = s0 + 4L * threadIdx.x; ok1 && i < s1; i += 4L * XTH) {
         float4 v[XW];
 #pragma unroll
         for (int p = 0; p < XW; ++p)
@@ -236,8 +242,8 @@ __global__ __launch_bounds__(XTH) void xchg_allgather_kernel(smx_xchg_t X, const
     const size_t roff = (size_t)(seq & 1u) * chunk_cap(X.capacity, W);
     for (long i = s0 + threadIdx.x; i < s1; i += XTH) own.R[roff + i] = in[i];
     release_flag(own, 0, w, seq);
-    wait_peers(X, own, 0, w, seq, err_out);
-    for (int p = 0; p < W; ++p) {
+    const bool ok = wait_peers(X, own, 0, w, seq, err_out);
+    for (int p = 0; ok && p < W; ++p) {
         const float* src = view(X.peer[p], X.capacity, X.world).R + roff;
         for (long i = s0 + threadIdx.x; i < s1; i += XTH) out[(long)p * n_per + i] = src[i];
     }

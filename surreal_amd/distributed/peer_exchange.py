@@ -128,7 +128,10 @@ class PeerExchange(object):
             want = a.clone()
             self.dist.all_reduce(want)
             got = a.clone()
-            self.all_reduce(got)
+            try:                  # a launch failure on THIS rank must not take it out of the rounds' process-group calls
+                self.all_reduce(got)
+            except Exception as e:
+                fail = fail or 'all-reduce round %d raised %r' % (r, e)
             if fail is None and not torch.allclose(got, want, rtol=1e-5, atol=1e-6):
                 fail = 'all-reduce round %d (n = %d): max diff %g' % (r, n, float((got - want).abs().max()))
             # replicas must be bit-identical: compare a checksum of the raw bits through the group
@@ -144,7 +147,10 @@ class PeerExchange(object):
             want_g = torch.empty(self.world * m, device=self.device)
             self.dist.all_gather_into_tensor(want_g, part)
             got_g = torch.empty(self.world * m, device=self.device)
-            self.all_gather_into_tensor(got_g, part)
+            try:
+                self.all_gather_into_tensor(got_g, part)
+            except Exception as e:
+                fail = fail or 'all-gather round %d raised %r' % (r, e)
             if fail is None and not torch.equal(got_g, want_g):
                 fail = 'all-gather round %d (n = %d) differs' % (r, m)
         done, err = self.status()
@@ -172,7 +178,10 @@ class PeerExchange(object):
                 ex.close()
             log.warning('peer exchange unavailable on some rank (%s): using the process group', why or 'a peer failed')
             return None
-        good, msg = ex.self_check(rounds)
+        try:
+            good, msg = ex.self_check(rounds)
+        except Exception as e:               # a launch failure / SmxError on THIS rank: still take part in the agreement
+            good, msg = False, 'self-check raised %r' % (e,)
         ok = torch.tensor([1.0 if good else 0.0])
         if dist.get_backend() == 'nccl':
             ok = ok.cuda()

@@ -175,14 +175,18 @@ class Learner(metaclass=AutoInitializeMeta):
         from surreal_amd.distributed.data_fetcher import LearnerDataPrefetcher, PinnedBatchStager
         if self._data_source is None:
             raise RuntimeError('no data source attached: call attach_replay / set_data_source')
-        first = self.preprocess(self._as_attr(self._prefetcher_preprocess(self._data_source())))
+        # The staging is sized from the HOST batch and the learner's device-moving preprocess() is NOT run in the worker:
+        # the stager's device twins (fp32, uint8 for camera frames) are what preprocess() would make of the batch.
+        # (Run there, a preprocess that moves the batch to the device -- DDPG's -- cost H->D->H->D, and its allocator /
+        # synchronous copy calls came from the worker thread while the main thread may be capturing a hipGraph.)
+        first = self._as_attr(self._prefetcher_preprocess(self._data_source()))
         device = getattr(self, 'device', 'cpu')
         stager = PinnedBatchStager(first, depth=depth, device=device)
         self.graph_input_sets = max(getattr(self, 'graph_input_sets', 1), depth)
         src = self._data_source
         self._prefetch_queue = LearnerDataPrefetcher(self.session_config, self.learner_config.replay.batch_size,
                                                      worker_preprocess=self._prefetcher_preprocess,
-                                                     main_preprocess=lambda b: self.preprocess(self._as_attr(b)),
+                                                     main_preprocess=None,
                                                      source=lambda bs: src(), stager=stager)
         # the batch that sized the staging is not lost: it goes through slot 0 first
         stager.stage(first)

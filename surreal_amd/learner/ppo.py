@@ -1011,17 +1011,23 @@ class PPOLearner(Learner):
     def _enqueue_optimize(self, ws, obs, obs_next, actions, rewards, dones, pds, pix=None,
                           pix_next=None):
         """the whole of _optimize (ppo.py:487-586) as a launch sequence"""
+        # The reward statistics of several ranks are exchanged BEFORE everything else; the exchange's error word
+        # (C_XCHG_ERR) is one of the control block's per-learn words, so those are zeroed in front of it -- zeroed
+        # behind it (as the first launches of the step used to do) a timeout of this exchange would be erased.
+        pre_zeroed = self.filter_rewards and self.use_r_filter and self.world_size > 1
+        if pre_zeroed:
+            ws.zero_block.zero_()
         if self.filter_rewards:
             rewards = self._enqueue_reward_filter(ws, rewards)
         if self.if_rnn_policy or self.model.if_pixel:
             return self._enqueue_optimize_stem(ws, obs, obs_next, actions, rewards, dones, pds, pix,
-                                               pix_next)
+                                               pix_next, pre_zeroed)
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
         lockstep = self.epoch_schedule == 'lockstep'
         fused = lockstep and ws.fused
-        if not fused:
+        if not fused and not pre_zeroed:
             ws.zero_block.zero_()                # stop flag, epochs done, per-epoch policy statistics
         tail = None
         if lockstep:
@@ -1043,7 +1049,7 @@ class PPOLearner(Learner):
                             xnext=ws.xnext if tail is not None else None,
                             ref_log_var=ref.log_var.view(-1), ref_std=ws.ref_pol[:, A:],
                             pack=[(m.actor, ws.pk_actor), (m.critic, ws.pk_critic), (ref.actor, ws.pk_ref)],
-                            zero_words=ws.zero_block.view(torch.int32))
+                            zero_words=None if pre_zeroed else ws.zero_block.view(torch.int32))
         elif self.use_z_filter:
             zm, zs = m.z_filter._mean, m.z_filter._std          # refreshed by the critic pass
             K.zfilter_forward(obs0, zm, zs, ws.xn)
@@ -1290,12 +1296,14 @@ class PPOLearner(Learner):
                     ws.sumsq_c, K.sumsq_blocks(ws.grads_c.numel()), ws.ctrl_f, 1, False,
                     ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
 
-    def _enqueue_optimize_stem(self, ws, obs, obs_next, actions, rewards, dones, pds, pix, pix_next):
+    def _enqueue_optimize_stem(self, ws, obs, obs_next, actions, rewards, dones, pds, pix, pix_next,
+                               pre_zeroed=False):
         """_optimize with the LSTM and / or CNN stem (ppo.py:487-586)"""
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A, E = self.action_dim, ws.E
-        ws.zero_block.zero_()
+        if not pre_zeroed:
+            ws.zero_block.zero_()
         self._enqueue_gae_stem(ws, obs, obs_next, pix, pix_next, rewards, dones)
 
         # obs_iter: the first E steps of every sub-trajectory (E = 1 without the LSTM; ppo.py:521-537)
