@@ -289,8 +289,9 @@ typedef struct {
     int32_t adam_step_actor, adam_step_critic; /* torch.optim.Adam 'step' state */
     int32_t stop_flag;     /* set when KL(ref||curr) > 4*kl_target (ppo.py:556-557) */
     int32_t epochs_done;   /* policy epochs actually applied this learn() */
-    int32_t reserved[2];   /* [0]: error word of a peer exchange (smx_xchg_*: pass its address as `err`); non-zero
-                              makes smx_clip_adam* skip the step.  [1]: unused */
+    int32_t reserved[2];   /* [0]: error word of a peer exchange (smx_xchg_*: pass its address as `err`); [1]: raised by
+                              smx_epoch_fwdbwd_f32 when its in-launch wait timed out.  Either makes smx_clip_adam* skip
+                              the step. */
 } smx_ppo_ctrl_t;
 
 /* per-epoch statistics slots (floats) written by the kernels; see ppo.py:219-224,278-284 */
@@ -515,6 +516,28 @@ int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const stru
                           smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream);
 int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
                            smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream);
+/* smx_epoch_forward_f32 + smx_epoch_backward_f32 of an UPDATING epoch (loss->will_update != 0; surreal/learner/
+ * ppo.py:209-248 / 266-309 / 323-353 up to the data gradients) in ONE launch: a workgroup carries its 16 rows through
+ * the three layers, the loss and back to dz2 / dz1 while the activations (the ReLU masks) and the loss's gradient
+ * terms are still in LDS.  The batch means the adapt loss needs (c_kl = beta + 2 eta max(0, KL - 2 kl_target),
+ * ppo.py:272-276) travel INSIDE the launch: every actor workgroup stores its block's KL sum together with a "there"
+ * bit as ONE 8-byte device-scope word (kl_slots[block]), multiplies both right-hand sides (g_surr / n, g_kl / n)
+ * through the output layer meanwhile, then reads the slots of all blocks (bounded wait: 2 s, then ctrl->reserved[1]
+ * is raised and the optimiser launch skips its step), adds them in a fixed order and continues with
+ * dz2 = (W3^T g_surr + c_kl W3^T g_kl) * relu'(h2) -- the combination is formed one layer later than
+ * smx_epoch_backward_f32 forms it (rounding differs in the last bit, the contract is the same).  Clip mode: no
+ * gradient depends on the batch, nobody waits.  The epoch's scalars (statistics, log_var's gradient, early-exit flag,
+ * step counters) are formed once, by the last workgroup of the grid after its own rows, from the partial rows
+ * (device-scope stores; *sync_word counts the actor workgroups whose row is complete).  loss->g_surr / g_kl are not
+ * written (the tiles stay in LDS).
+ * Jobs: SMX_EPOCH_LOSS_POLICY (at most one) and / or SMX_EPOCH_LOSS_VALUE, fields as for the two calls it
+ * replaces.  sync_word: one int32 per launch; kl_slots: smx_epoch_blocks(rows of the policy job) 8-byte words per
+ * launch; both zero on entry (the caller clears them once per learn).
+ * smx_epoch_fwdbwd_supported: smx_epoch_supported and H2 <= 384 and the larger LDS carve-up fits. */
+int32_t smx_epoch_fwdbwd_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
+                         smx_ppo_ctrl_t* ctrl, int64_t n_total, int32_t* sync_word, uint64_t* kl_slots,
+                         smx_stream_t stream);
 
 /* --- acting head (PPOAgent.act, ppo_agent.py:106-154; DiagGauss.sample/maxprob, ppo_net.py:74-91) ---
  * pd[r] = [mean[r, :], exp(log_var) * noise_scale[r]]   (builders.py:127; ppo_agent.py:139:

@@ -154,6 +154,7 @@ CTRL_WORDS = 16
  C_CRITIC_MAX_NORM, C_ACTOR_WD, C_CRITIC_WD, C_STEP_ACTOR, C_STEP_CRITIC, C_STOP,
  C_EPOCHS_DONE) = range(14)
 C_XCHG_ERR = 14          # reserved[0]: raised by a peer exchange that timed out (zeroed with the per-learn words)
+C_SYNC_ERR = 15          # reserved[1]: raised by smx_epoch_fwdbwd_f32 when its in-launch wait timed out
 
 _P = c_void_p
 _SIGS = {
@@ -186,6 +187,8 @@ _SIGS = {
     'smx_epoch_prepare_f32': (c_int32, [POINTER(EpochPrep), _P]),
     'smx_epoch_forward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
     'smx_epoch_backward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
+    'smx_epoch_fwdbwd_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_epoch_fwdbwd_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P, _P, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_backward_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                         _P, _P]),

@@ -97,6 +97,11 @@ struct EArgs {
     long n_total;
     // LDS carve-up (floats), the same for every workgroup of the launch
     int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_red, off_loss;
+    int off_g;         // forward + backward in one launch: [dz3 tile (surrogate) | dz3 tile (KL) | dz2 tile]
+    int* sync;         // ... and the counter its actor workgroups publish their loss partial rows through
+    int nb_pol;        // ... row blocks of its policy job (0: none)
+    const int* pol_stop;   // ... and that job's early-exit flag (its workgroups return at once when it is up)
+    unsigned long long* kl_slots;   // ... [nb_pol]: a row block's KL sum | 1 << 32, zero on entry
     int fsplit;
     long long* tbuf;   // SMX_EPOCH_TIMING builds: per-workgroup phase timestamps (else null)
 };
@@ -124,7 +129,47 @@ constexpr int FNWV = 8;
 constexpr int FNTH = 64 * FNWV;
 constexpr int FTG = 3;            // feature tiles a wave carries per pass (the register budget of two waves per SIMD)
 
-__global__ __launch_bounds__(FNTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
+// batch sums S[0 .. stride) of the loss partial rows, 512 threads: staged through LDS with coalesced DEVICE-SCOPE loads
+// (the rows were written by other workgroups of this launch, see partial_store), four independent chains per column
+// added in a fixed order (the same in every workgroup, whatever the schedule)
+__device__ __forceinline__ void fb_reduce_partials(const float* __restrict__ partials, int nblk, int stride, float* S,
+                                                   float* buf) {
+    const int tid = threadIdx.x;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int b0 = 0; b0 < nblk; b0 += FIN_CH) {
+        const int nb = min(FIN_CH, nblk - b0);
+        const int cnt = nb * stride;
+        const float* src = partials + (size_t)b0 * stride;
+        for (int i0 = tid; i0 < cnt; i0 += 8 * FNTH) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = __hip_atomic_load(src + min(i0 + FNTH * u, cnt - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + FNTH * u < cnt) buf[i0 + FNTH * u] = v[u];
+        }
+        SMX_LDS_BARRIER();
+        if (tid < stride) {
+            int b = 0;
+            for (; b + 4 <= nb; b += 4) {
+                t0 += buf[b * stride + tid];
+                t1 += buf[(b + 1) * stride + tid];
+                t2 += buf[(b + 2) * stride + tid];
+                t3 += buf[(b + 3) * stride + tid];
+            }
+            for (; b < nb; ++b) t0 += buf[b * stride + tid];
+        }
+        SMX_LDS_BARRIER();
+    }
+    if (tid < stride) S[tid] = (t0 + t1) + (t2 + t3);
+    SMX_LDS_BARRIER();
+}
+
+// Forward of up to four jobs' row blocks (FB = false: epoch_fwd_kernel), or forward + loss + data gradients of the
+// same rows in ONE launch (FB = true: epoch_fb_kernel, see there).
+template <bool FB>
+__device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* __restrict__ ctrl) {
     extern __shared__ float sm[];
     TSTAMP(0);
     const EJob J = select_job(G, (int)blockIdx.x);
@@ -301,6 +346,7 @@ __global__ __launch_bounds__(FNTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t
     }
 
     // ---- the job's loss on the rows it holds (four waves: the other four retire here) ---------
+    if constexpr (!FB) {
     if (!lo) return;
     if (J.loss == SMX_EPOCH_LOSS_POLICY) {
         const PolArgs& p = G.pl;
@@ -329,6 +375,285 @@ __global__ __launch_bounds__(FNTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t
         }
     }
     TSTAMP(6);
+    } else {
+    // =========================================================================================
+    // FB: the loss, then the data gradients of the SAME rows without leaving the workgroup -- the
+    // hidden activations (ReLU masks) and the loss's per-element gradient terms are still in LDS.
+    //   dz3 = (g_surr + c_kl g_kl) / n needs the batch mean KL (adapt mode: c_kl = beta + 2 eta max(0, KL - 2 kl_target),
+    //   ppo.py:272-276), i.e. every actor workgroup's KL sum.  The actor workgroups publish their partial row
+    //   (device-scope write-through stores, then one counter increment), and while the others arrive they multiply BOTH
+    //   right-hand sides through the output layer (dz2 is linear in dz3: W3^T g_surr / n and W3^T g_kl / n, a K <= 32
+    //   product each); only then do they look at the counter, add up the KL column of the partial rows (device-scope
+    //   loads; one value per lane + a butterfly: the same bits in every workgroup), combine under the ReLU mask and
+    //   carry on with the one expensive product, dz1.  (The first version used agent-scope fences around the counter:
+    //   on gfx950 those write back / invalidate the whole L2 -- 4 us per side, and every workgroup of the XCD ran cold
+    //   afterwards.)  The critic's workgroups never wait.  In clip mode nothing in the gradient depends on the batch.
+    //   The epoch's scalars -- all column sums, statistics, log_var's gradient, the early-exit flag, the step counters
+    //   -- are formed ONCE, by the last workgroup of the grid after its own work (a critic workgroup when the launch
+    //   carries both jobs: those finish ~8 us ahead of the actor's); the optimiser launch that follows honours the flag.
+    // All eight wavefronts stay: the four that do not run the loss execute its barriers.
+    // =========================================================================================
+    __shared__ float S[8 + 2 * MAX_A];
+    __shared__ float s_kl;
+    __shared__ int wait_ok;
+    const PolArgs& p = G.pl;
+    const bool policy = J.loss == SMX_EPOCH_LOSS_POLICY;
+    const bool adapt = policy && p.mode == SMX_PPO_ADAPT;
+    const int A = p.A;
+    const int pstride = 8 + 2 * A;
+    float* gss = sm + G.off_g;                 // [16][LDZ]: dz3 right-hand side (surrogate share / the critic's dz3)
+    float* gks = gss + ER * LDZ;               // [16][LDZ]: the KL share (adapt)
+    float* dz2s = gks + ER * LDZ;              // [16][ldh2]
+    const float nf = (float)G.n_total;
+    const float inv_n = 1.0f / nf;
+    // was the actor's early-exit flag up when the launch started?  (its workgroups have returned then; read by the
+    // workgroup that forms the epoch's scalars, long before it could raise the flag itself)
+    const int pol_stopped = (G.pol_stop && blockIdx.x == gridDim.x - 1) ? __builtin_nontemporal_load(G.pol_stop) : 0;
+    // the output layer's transposed weights for this wave's dz2 tiles (chunk 0: K = OUT <= 32), requested BEFORE the
+    // loss: the optimiser launch has just rewritten them on other XCDs, a first touch is a trip to the memory-side cache
+    const int tiles2 = (J.H2 + 15) >> 4;
+    float4 wa[FTG], wb[FTG];
+    {
+        const rsrc_t rw3 = make_rsrc(J.P3T, (unsigned)tiles2 * (unsigned)pack_chunks(J.OUT) * 2048u);
+#pragma unroll
+        for (int g = 0; g < FTG; ++g) {
+            const int t = wv + FNWV * g;
+            const unsigned o = t < tiles2 ? ((unsigned)t * (unsigned)pack_chunks(J.OUT) * 512u + (unsigned)lane * 4u) * 4u : OOB;
+            wa[g] = ld16(rw3, o);
+            wb[g] = ld16(rw3, t < tiles2 ? o + 1024u : OOB);
+        }
+    }
+    if (policy) {
+        if (lo) {
+            policy_loss_body<true>(blk, sm + G.off_loss, p.mode, outs, LDO, p.log_var, lin_s, LW, lin_s + p.A, LW,
+                                   lin_s + 3 * p.A, LW, lin_s + 5 * p.A, (long)J.rows, p.A, ctrl, nullptr, nullptr,
+                                   p.row_partials, 1.0f, false, nullptr, nullptr, 0, row0, LW, G.kl_slots);
+        } else {
+#pragma unroll
+            for (int i = 0; i < POLICY_LOSS_BARRIERS; ++i) SMX_LDS_BARRIER();
+        }
+    } else if (tid < 64) {
+        const ValArgs& q = G.vl;
+        const bool ok = tid < nrows;
+        const float v = ok ? outs[tid * LDO] : 0.f, g = ok ? vret : 0.f;
+        const float d = g - v, e = v - g;
+        const float dz = (2.0f * e) / nf;
+        if (ok) q.v_dz3[row0 + tid] = dz;
+        if (tid < ER) gss[tid * LDZ] = ok ? dz : 0.f;
+        const float cnt = (float)nrows;
+        const float md = smx_wave_sum(ok ? d : 0.f) / cnt;
+        const float mg = smx_wave_sum(ok ? g : 0.f) / cnt;
+        const float m2d = smx_wave_sum(ok ? (d - md) * (d - md) : 0.f);
+        const float m2g = smx_wave_sum(ok ? (g - mg) * (g - mg) : 0.f);
+        const float sq = smx_wave_sum(ok ? e * e : 0.f);
+        if (tid == 0) {
+            float* P = q.v_partials + (size_t)blk * 8;
+            P[0] = cnt; P[1] = md; P[2] = m2d; P[3] = mg; P[4] = m2g; P[5] = sq; P[6] = 0.f; P[7] = 0.f;
+            if (blk == 0 && q.will_update) ctrl->adam_step_critic += 1;
+        }
+    }
+    SMX_LDS_BARRIER();
+    TSTAMP(6);
+    if (policy) {
+        // right-hand side tiles from the loss's scratch, zero padded to the 32 columns the K loop reads
+        const float* sc = sm + G.off_loss;
+        const float* e_dmu = loss_elem_dmu(sc, A);
+        const float* e_dkl = loss_elem_dkl(sc, A);
+        const float* r_dll = loss_row_dll(sc, A);
+        for (int idx = tid; idx < ER * 32; idx += FNTH) {
+            const int n = idx >> 5, a = idx & 31;
+            const bool ok = n < nrows && a < A;
+            const int i = ok ? n * A + a : 0;
+            const float gs = r_dll[ok ? n : 0] * e_dmu[i];
+            gss[n * LDZ + a] = ok ? gs * inv_n : 0.f;
+            if (adapt) gks[n * LDZ + a] = ok ? e_dkl[i] * inv_n : 0.f;
+        }
+    }
+    SMX_LDS_BARRIER();
+    // ---- dz2 (before the mask) for both right-hand sides: every wave's tiles wv, wv + 8, ... (one chunk, K <= 32;
+    // the weight fragments are shared by the two right-hand sides) ------------------------------------------
+    f32x4 aS[FTG], aK[FTG];
+#pragma unroll
+    for (int g = 0; g < FTG; ++g) { aS[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; aK[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    {
+        const float* bs = gss + (lane & 15) * LDZ + 8 * (lane >> 4);
+        const float4 s0 = *(const float4*)bs, s1 = *(const float4*)(bs + 4);
+        float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
+        if (adapt) {
+            const float* bk = gks + (lane & 15) * LDZ + 8 * (lane >> 4);
+            k0 = *(const float4*)bk; k1 = *(const float4*)(bk + 4);
+        }
+#pragma unroll
+        for (int g = 0; g < FTG; ++g) {
+            if (wv + FNWV * g < tiles2) {                       // wave-uniform; each tile has its own accumulators
+                aS[g] = MFMA16(wa[g].x, s0.x, aS[g]); aS[g] = MFMA16(wa[g].y, s0.y, aS[g]);
+                aS[g] = MFMA16(wa[g].z, s0.z, aS[g]); aS[g] = MFMA16(wa[g].w, s0.w, aS[g]);
+                aS[g] = MFMA16(wb[g].x, s1.x, aS[g]); aS[g] = MFMA16(wb[g].y, s1.y, aS[g]);
+                aS[g] = MFMA16(wb[g].z, s1.z, aS[g]); aS[g] = MFMA16(wb[g].w, s1.w, aS[g]);
+                if (adapt) {
+                    aK[g] = MFMA16(wa[g].x, k0.x, aK[g]); aK[g] = MFMA16(wa[g].y, k0.y, aK[g]);
+                    aK[g] = MFMA16(wa[g].z, k0.z, aK[g]); aK[g] = MFMA16(wa[g].w, k0.w, aK[g]);
+                    aK[g] = MFMA16(wb[g].x, k1.x, aK[g]); aK[g] = MFMA16(wb[g].y, k1.y, aK[g]);
+                    aK[g] = MFMA16(wb[g].z, k1.z, aK[g]); aK[g] = MFMA16(wb[g].w, k1.w, aK[g]);
+                }
+            }
+        }
+    }
+    TSTAMP(7);
+    // ---- the batch KL (adapt: every actor workgroup needs it now) ---------------------------------------
+    const int nbp = G.nb_pol;
+    auto wait_count = [&]() {        // every actor workgroup of the launch has published its partial row
+        if (tid == 0) {
+            const long long t0 = (long long)wall_clock64();
+            int okw = 1;
+            while (__hip_atomic_load(G.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbp) {
+                if ((long long)wall_clock64() - t0 > 200000000LL) { okw = 0; break; }     // 2 s (100 MHz): a lost workgroup
+                __builtin_amdgcn_s_sleep(1);
+            }
+            wait_ok = okw;
+            if (!okw) atomicOr(&ctrl->reserved[1], 1);
+        }
+        __syncthreads();
+    };
+    // The batch KL: lane l of wavefront 0 takes row blocks l, l + 64, ... -- it polls the block's slot (ONE device-scope
+    // 8-byte load: the sum and its "there" bit were stored together, so there is no separate flag round trip and the
+    // producer never waits for its own store) -- then a butterfly: the same bits in every workgroup.
+    auto kl_total = [&]() -> float {
+        if (tid < 64) {
+            float t = 0.f;
+            int okw = 1;
+            const long long t0 = (long long)wall_clock64();
+            for (int b = tid; b < nbp; b += 64) {
+                unsigned long long w;
+                while (((w = __hip_atomic_load(G.kl_slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0ull) {
+                    if ((long long)wall_clock64() - t0 > 200000000LL) { okw = 0; break; }    // 2 s (100 MHz): a lost workgroup
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                t += __uint_as_float((unsigned)w);
+            }
+            t = smx_wave_sum(t);
+            okw = __all(okw);
+            if (tid == 0) {
+                s_kl = t;
+                wait_ok = okw;
+                if (!okw) atomicOr(&ctrl->reserved[1], 1);
+            }
+        }
+        SMX_LDS_BARRIER();
+        return s_kl;
+    };
+    auto kl_coef = [&](float klsum, float& ck, bool& stop) {
+        float S3[3] = {0.f, 0.f, klsum}, ls;
+        loss_and_kl_coef(p.mode, S3, nf, ctrl, ls, ck);
+        stop = (p.check_stop && (double)(klsum / nf) > 4.0 * (double)ctrl->kl_target) || wait_ok == 0;
+    };
+    float c_kl = 0.f;
+    bool stop_now = false;
+    if (adapt) kl_coef(kl_total(), c_kl, stop_now);
+    else if (tid == 0) wait_ok = 1;
+    // the partial ROW (all column sums: the finalizing workgroup's input) went out with device-scope stores during the
+    // loss, several microseconds ago: wavefronts 0 and 1 make sure they have completed, then the counter moves
+    if (policy && tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SMX_LDS_BARRIER();
+    if (policy && tid == 0) __hip_atomic_fetch_add(G.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TSTAMP(8);
+    if (!stop_now) {
+        // ---- dz2 = (W3^T dz3) * relu'(h2): LDS tile (dz1's B operand) + transposed copy (weight gradients) ----
+        {
+            const rsrc_t rout = make_rsrc(J.dz2T, (unsigned)J.H2 * (unsigned)J.ldT * 4u);
+#pragma unroll
+            for (int g = 0; g < FTG; ++g) {
+                const int t = wv + FNWV * g;
+                if (t < tiles2) {                                   // wave-uniform
+                    const int f0 = 16 * t + 4 * kq;
+                    const float4 m = *(const float4*)(h2s + fm * ldh2 + f0);
+                    float4 v;
+                    v.x = (m.x > 0.f) ? aS[g][0] + c_kl * aK[g][0] : 0.f;
+                    v.y = (m.y > 0.f) ? aS[g][1] + c_kl * aK[g][1] : 0.f;
+                    v.z = (m.z > 0.f) ? aS[g][2] + c_kl * aK[g][2] : 0.f;
+                    v.w = (m.w > 0.f) ? aS[g][3] + c_kl * aK[g][3] : 0.f;
+                    *(float4*)(dz2s + fm * ldh2 + f0) = v;
+                    const bool ok = fm < nrows;
+                    const unsigned o = ((unsigned)f0 * (unsigned)J.ldT + (unsigned)(row0 + fm)) * 4u, st = (unsigned)J.ldT * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rout, ok && f0 < J.H2 ? o : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rout, ok && f0 + 1 < J.H2 ? o + st : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), rout, ok && f0 + 2 < J.H2 ? o + 2 * st : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), rout, ok && f0 + 3 < J.H2 ? o + 3 * st : OOB, 0, 0);
+                }
+            }
+        }
+        if (policy) {       // dz3^T for the output layer's weight gradient
+            for (int idx = tid; idx < ER * A; idx += FNTH) {
+                const int a = idx / ER, n = idx - a * ER;
+                const float v = gss[n * LDZ + a] + c_kl * gks[n * LDZ + a];
+                if (n < nrows) J.dz3T[(size_t)a * J.ldT + row0 + n] = v;
+            }
+        }
+        SMX_LDS_BARRIER();
+        TSTAMP(9);
+        // ---- dz1 = (W2^T dz2) * relu'(h1) -----------------------------------------------------------
+        {
+            const int tiles1 = (J.H1 + 15) >> 4;
+            const int C2h = pack_chunks(J.H2);
+            const rsrc_t rw2 = make_rsrc(J.P2T, (unsigned)tiles1 * (unsigned)C2h * 2048u);
+            const rsrc_t rout = make_rsrc(J.dz1T, (unsigned)J.H1 * (unsigned)J.ldT * 4u);
+#pragma unroll 1
+            for (int tb = 0; tb < tiles1; tb += FNWV * FTG) {
+                const int t0 = tb + wv;
+                int nt = (tiles1 - t0 + FNWV - 1) / FNWV;
+                nt = nt < 0 ? 0 : (nt > FTG ? FTG : nt);
+                f32x4 acc[TG];
+#pragma unroll
+                for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (nt > 2) fwd_tiles<3>(acc, rw2, tiles1, C2h, dz2s, ldh2, t0, FNWV, lane);
+                else fwd_tiles<2>(acc, rw2, tiles1, C2h, dz2s, ldh2, t0, FNWV, lane);
+#pragma unroll
+                for (int g = 0; g < FTG; ++g) {
+                    if (g < nt) {
+                        const int f0 = 16 * (t0 + FNWV * g) + 4 * kq;
+                        const float4 m = *(const float4*)(h1s + fm * ldh1 + f0);
+                        const float vx = (m.x > 0.f) ? acc[g][0] : 0.f, vy = (m.y > 0.f) ? acc[g][1] : 0.f;
+                        const float vz = (m.z > 0.f) ? acc[g][2] : 0.f, vw = (m.w > 0.f) ? acc[g][3] : 0.f;
+                        const bool ok = fm < nrows;
+                        const unsigned o = ((unsigned)f0 * (unsigned)J.ldT + (unsigned)(row0 + fm)) * 4u, st = (unsigned)J.ldT * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vx), rout, ok && f0 < J.H1 ? o : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vy), rout, ok && f0 + 1 < J.H1 ? o + st : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vz), rout, ok && f0 + 2 < J.H1 ? o + 2 * st : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vw), rout, ok && f0 + 3 < J.H1 ? o + 3 * st : OOB, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    TSTAMP(10);
+    // ---- the epoch's scalars: the last workgroup of the grid, once its own rows are done -------------------
+    if (nbp > 0 && blockIdx.x == gridDim.x - 1 && pol_stopped == 0) {
+        wait_count();
+        fb_reduce_partials(p.row_partials, nbp, pstride, S, sm + G.off_loss);
+        const float klsum = kl_total();                    // the KL sum every actor workgroup used: the same bits
+        float loss = 0.f, ck = 0.f;
+        if (tid == 0) S[2] = klsum;
+        SMX_LDS_BARRIER();
+        loss_and_kl_coef(p.mode, S, nf, ctrl, loss, ck);
+        for (int a = tid; a < A; a += FNTH) p.dlogvar[a] = (S[8 + a] + ck * S[8 + A + a]) * inv_n;
+        if (tid == 0 && wait_ok)
+            write_policy_scalars(S, nf, loss, ck, p.log_var, A, ctrl, p.check_stop, p.will_update, p.dlogvar_sumsq,
+                                 p.stats);
+    }
+    TSTAMP(11);
+    }
+}
+
+__global__ __launch_bounds__(FNTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
+    epoch_fwd_body<false>(G, ctrl);
+}
+
+// One launch per epoch for [forward + loss + data gradients] of the row blocks of both networks: what
+// epoch_fwd_kernel + epoch_bwd_kernel do in two (the batch means travel through a counter inside the launch,
+// see the FB part of epoch_fwd_body).  The actor workgroups of a launch must be co-resident (<= one per CU,
+// dispatched before anything that could wait on them: they are); a wait is bounded all the same.
+__global__ __launch_bounds__(FNTH) void epoch_fb_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
+    epoch_fwd_body<true>(G, ctrl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,7 +911,7 @@ __device__ __forceinline__ float zclamp_e(float x, float m, float sdev) {
 
 __global__ __launch_bounds__(256) void epoch_prepare_kernel(PrepArgs P) {
     const long tid0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-    if (tid0 < P.n_zero) P.zero_words[tid0] = 0;
+    for (long i = tid0; i < P.n_zero; i += stride) P.zero_words[i] = 0;
     const long nx = P.n_x, n_next = P.xnext ? nx : 0;
     const long total = 2 * nx + n_next + P.n_std + P.pack.total;
     for (long i = tid0; i < total; i += stride) {
@@ -671,7 +996,7 @@ extern "C" int smx_epoch_prepare_f32(const smx_epoch_prep_t* a, smx_stream_t str
     SMX_REQUIRE(!a->ref_filter || (a->ref_sum && a->ref_sumsq && a->ref_count), SMX_E_NULL);
     SMX_REQUIRE(!a->xnext || (a->obs_next && a->ld_next >= a->D), SMX_E_SHAPE);
     SMX_REQUIRE(!a->ref_std || (a->ref_log_var && a->A > 0 && a->ld_ref >= a->A), SMX_E_SHAPE);
-    SMX_REQUIRE(a->n_zero >= 0 && a->n_zero <= 256 && (a->n_zero == 0 || a->zero_words), SMX_E_SHAPE);
+    SMX_REQUIRE(a->n_zero >= 0 && a->n_zero <= 65536 && (a->n_zero == 0 || a->zero_words), SMX_E_SHAPE);
     PrepArgs P;
     memset(&P, 0, sizeof(P));
     P.obs0 = a->obs0; P.ld_obs0 = (long)a->ld_obs0; P.rows = (long)a->rows; P.D = a->D;
@@ -708,6 +1033,17 @@ static int fwd_lds_bytes(int D, int H1, int H2, int A) {
                        loss_scratch_floats(A) + ER * (5 * A + 1);
     return floats * (int)sizeof(float);
 }
+// ... of a forward + backward launch: two dz3 tiles and the dz2 tile more, and the loss scratch doubles as the
+// staging buffer of the partial-row reduction
+static int fb_loss_floats(int A) {
+    const int a = loss_scratch_floats(A) + ER * (5 * A + 1), b = FIN_CH * (8 + 2 * A);
+    return a > b ? a : b;
+}
+static int fb_lds_bytes(int D, int H1, int H2, int A) {
+    const int floats = ER * (r64(D) + 4) + ER * (r64(H1) + 4) + ER * (r64(H2) + 4) + ER * LDO + 2 * ER * LDZ +
+                       ER * (r64(H2) + 4) + NWV * 2 * 256 + fb_loss_floats(A);
+    return floats * (int)sizeof(float);
+}
 constexpr int MAX_LDS = 128 * 1024;
 
 extern "C" int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
@@ -718,8 +1054,16 @@ extern "C" int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_
            fwd_lds_bytes(D, H1, H2, OUT) <= MAX_LDS;
 }
 
+extern "C" int32_t smx_epoch_fwdbwd_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
+    // (the dz2 accumulators of both right-hand sides live in registers across the wait: one pass of FTG tiles per wave)
+    return smx_epoch_supported(D, H1, H2, OUT) && H2 <= 16 * FNWV * FTG && fb_lds_bytes(D, H1, H2, OUT) <= MAX_LDS;
+}
+
+enum { KIND_FWD = 0, KIND_BWD = 1, KIND_FB = 2 };
+
 static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
-                     int64_t n_total, int fsplit, bool backward) {
+                     int64_t n_total, int fsplit, int kind) {
+    const bool backward = kind == KIND_BWD;
     SMX_REQUIRE(jobs, SMX_E_NULL);
     SMX_REQUIRE(njobs >= 1 && njobs <= MAX_EJOBS, SMX_E_SHAPE);
     memset(&G, 0, sizeof(G));
@@ -774,7 +1118,12 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
             SMX_REQUIRE(loss && n.OUT == 1, SMX_E_SHAPE);
             SMX_REQUIRE(backward ? s.dz3 != nullptr : (loss->returns && loss->v_dz3 && loss->v_partials), SMX_E_NULL);
         }
-        if (backward) SMX_REQUIRE(s.h1T && s.h2T && s.dz2T && s.dz1T, SMX_E_NULL);
+        if (backward || kind == KIND_FB) SMX_REQUIRE(s.h1T && s.h2T && s.dz2T && s.dz1T, SMX_E_NULL);
+        if (kind == KIND_FB) {
+            SMX_REQUIRE(s.loss == SMX_EPOCH_LOSS_POLICY || s.loss == SMX_EPOCH_LOSS_VALUE, SMX_E_UNSUPPORTED);
+            SMX_REQUIRE(smx_epoch_fwdbwd_supported(n.D, n.H1, n.H2, n.OUT), SMX_E_UNSUPPORTED);
+            SMX_REQUIRE(s.loss != SMX_EPOCH_LOSS_POLICY || s.dz3T, SMX_E_NULL);
+        }
         maxD = n.D > maxD ? n.D : maxD; maxH1 = n.H1 > maxH1 ? n.H1 : maxH1; maxH2 = n.H2 > maxH2 ? n.H2 : maxH2;
     }
     if (loss) {
@@ -794,9 +1143,12 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
     G.off_h1 = backward ? ER * LDZ : ER * G.ldx;
     G.off_h2 = G.off_h1 + ER * G.ldh1;
     G.off_out = G.off_h2 + ER * G.ldh2;
-    G.off_red = G.off_out + (backward ? 0 : ER * LDO);
+    // (forward + backward: the dz3 / dz2 tiles sit in front of off_red, inside the range the prologue clears)
+    G.off_g = G.off_out + ER * LDO;
+    G.off_red = G.off_out + (backward ? 0 : ER * LDO) + (kind == KIND_FB ? 2 * ER * LDZ + ER * G.ldh2 : 0);
     G.off_loss = G.off_red + (backward ? 0 : NWV * 2 * 256);
-    const int loss_floats = backward ? FIN_CH * (8 + 2 * MAX_A) : loss_scratch_floats(A) + ER * (5 * A + 1);
+    const int loss_floats = backward ? FIN_CH * (8 + 2 * MAX_A)
+                                     : (kind == KIND_FB ? fb_loss_floats(A) : loss_scratch_floats(A) + ER * (5 * A + 1));
     const int bytes = (G.off_loss + loss_floats) * (int)sizeof(float);
     // A launch has at most a few hundred workgroups, each keeping the four MFMA pipes of a CU busy
     // by itself: ask for more than half of the CU's 160 KB of LDS so that the dispatcher cannot put
@@ -807,7 +1159,7 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
 extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
                                      smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream) {
     EArgs G;
-    const int lds = fill_args(G, jobs, njobs, loss, n_total, 1, false);
+    const int lds = fill_args(G, jobs, njobs, loss, n_total, 1, KIND_FWD);
     if (lds < 0) return lds;
     SMX_REQUIRE(ctrl, SMX_E_NULL);
     if (loss && loss->mode != SMX_PPO_CLIP && loss->mode != SMX_PPO_ADAPT) return SMX_E_UNSUPPORTED;
@@ -828,6 +1180,46 @@ extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs,
     return SMX_OK;
 }
 
+extern "C" int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
+                                    smx_ppo_ctrl_t* ctrl, int64_t n_total, int32_t* sync_word, uint64_t* kl_slots,
+                                    smx_stream_t stream) {
+    EArgs G;
+    SMX_REQUIRE(loss && ctrl, SMX_E_NULL);
+    const int lds = fill_args(G, jobs, njobs, loss, n_total, 1, KIND_FB);
+    if (lds < 0) return lds;
+    if (loss->mode != SMX_PPO_CLIP && loss->mode != SMX_PPO_ADAPT) return SMX_E_UNSUPPORTED;
+    int n_policy = 0;
+    for (int k = 0; k < njobs; ++k)
+        if (jobs[k].loss == SMX_EPOCH_LOSS_POLICY) {
+            // an updating epoch: the forward-only final pass stays on smx_epoch_forward_f32 + _backward_f32
+            SMX_REQUIRE(loss->will_update, SMX_E_UNSUPPORTED);
+            SMX_REQUIRE(loss->log_var && loss->actions && loss->behave && loss->ref && loss->adv && loss->g_surr &&
+                            loss->g_kl && loss->row_partials && loss->dlogvar && loss->stats && sync_word && kl_slots,
+                        SMX_E_NULL);
+            SMX_REQUIRE(((uintptr_t)kl_slots & 7) == 0, SMX_E_ALIGN);
+            ++n_policy;
+        }
+    SMX_REQUIRE(n_policy <= 1, SMX_E_SHAPE);       // one counter, one set of partial rows
+    G.sync = (int*)sync_word;
+    G.kl_slots = (unsigned long long*)kl_slots;
+    for (int k = 0; k < njobs; ++k)
+        if (jobs[k].loss == SMX_EPOCH_LOSS_POLICY) {
+            G.nb_pol = smx_epoch_blocks(jobs[k].rows);
+            G.pol_stop = jobs[k].stop_flag;
+        }
+    const EJob& Lj = G.j[njobs - 1];
+    const int blocks = Lj.blk_base + smx_epoch_blocks(Lj.rows);
+    SMX_REQUIRE(lds <= MAX_LDS, SMX_E_UNSUPPORTED);
+    static bool attr_set_fb = false;
+    if (!attr_set_fb) {
+        (void)hipFuncSetAttribute((const void*)epoch_fb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set_fb = true;
+    }
+    hipLaunchKernelGGL(epoch_fb_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
 extern "C" int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
                                       smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream) {
     EArgs G;
@@ -837,7 +1229,7 @@ extern "C" int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs
     for (int k = 0; k < njobs && jobs; ++k)
         if (jobs[k].loss == SMX_EPOCH_LOSS_POLICY && loss && !loss->will_update) update = false;
     const int fs = 2;
-    const int lds = fill_args(G, jobs, njobs, loss, n_total, fs, true);
+    const int lds = fill_args(G, jobs, njobs, loss, n_total, fs, KIND_BWD);
     if (lds < 0) return lds;
     SMX_REQUIRE(ctrl, SMX_E_NULL);
     for (int k = 0; k < njobs; ++k)

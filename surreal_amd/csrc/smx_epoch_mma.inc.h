@@ -150,3 +150,22 @@ __device__ __forceinline__ void fwd_tiles(f32x4 (&acc)[TG], rsrc_t rw, int tiles
     }
 }
 
+
+// the same for a K of at most 32 (ONE chunk: the products against the output layer's transposed weights, K = OUT <= 32;
+// the packed copy pads to an even number of chunks, the second one is all zeros and is not read): no loop
+template <int NT>
+__device__ __forceinline__ void fwd_tiles_k32(f32x4 (&acc)[TG], rsrc_t rw, int tiles, const float* in_lds, int ldi,
+                                              int t0, int tstep, int lane) {
+    unsigned wo[TG];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+        const int t = t0 + tstep * g;
+        wo[g] = (g < NT && t < tiles) ? ((unsigned)t * 2u * 512u + (unsigned)lane * 4u) * 4u : OOB;
+    }
+    const float* bp = in_lds + (lane & 15) * ldi + 8 * (lane >> 4);
+    WFrag<NT> P0;
+    ld_wfrag<NT>(P0, rw, wo, bp, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk<NT>(acc, P0);
+}
+

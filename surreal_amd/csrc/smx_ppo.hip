@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
     const smx_ppo_ctrl_t* ctrl_v = &C;
     const int blk = blockIdx.x - (gi ? P.g[0].blocks : 0);
     if (G.honour_stop && C.stop_flag) return;
-    // reserved[0]: raised by a peer exchange of this learn() that timed out (smx_xchg.hip) -- the gradients may
-    // then be anything: no step for either group; the learner raises when it reads the word back
-    if (C.reserved[0] != 0) return;
+    // reserved[0]: raised by a peer exchange of this learn() that timed out (smx_xchg.hip); reserved[1]: by the fused
+    // forward + backward epoch launch whose in-launch wait timed out -- the gradients may then be anything: no step
+    // for either group; the learner raises when it reads the words back
+    if ((C.reserved[0] | C.reserved[1]) != 0) return;
     __shared__ float red[16];
     float* __restrict__ theta = G.theta;
     const float* __restrict__ grads = G.grads;

@@ -17,9 +17,27 @@ constexpr int MAX_A = 32;
 
 // LDS scratch (floats) of policy_loss_body for A action dimensions
 __host__ __device__ constexpr int loss_scratch_floats(int A) { return LOSS_ROWS_PER_BLOCK * (8 * A + 1) + 2 * MAX_A; }
+// What policy_loss_body leaves in its scratch for a caller that carries on in the same workgroup (the fused
+// forward + backward epoch kernel): per-element d ll / d z3 and d KL / d z3 [R, A], per-row d loss / d ll [R] --
+// g_surr[r][a] = row_dll[r] * elem_dmu[r * A + a], g_kl[r][a] = elem_dkl[r * A + a].
+__device__ __forceinline__ const float* loss_elem_dmu(const float* sm, int A) { return sm + 5 * LOSS_ROWS_PER_BLOCK * A; }
+__device__ __forceinline__ const float* loss_elem_dkl(const float* sm, int A) { return sm + 6 * LOSS_ROWS_PER_BLOCK * A; }
+__device__ __forceinline__ const float* loss_row_dll(const float* sm, int A) { return sm + 8 * LOSS_ROWS_PER_BLOCK * A; }
+// SMX_LDS_BARRIER()s inside policy_loss_body: wavefronts of the workgroup that do not run the body must execute as many
+constexpr int POLICY_LOSS_BARRIERS = 3;
 
 __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
     return (x == x) ? fmaxf(x, lo) : x;  // torch.clamp(min=) keeps NaN
+}
+
+// a block's partial sums: plain stores, or (COH) device-scope write-through stores -- for a consumer in ANOTHER workgroup
+// of the SAME launch (the fused forward + backward epoch kernel), which reads them with device-scope loads: no
+// cache-wide write-back / invalidate (an agent-scope fence on gfx950 is buffer_wbl2 / buffer_inv of the whole L2,
+// measured at ~4 us per side with the launch's activations dirty in it)
+template <bool COH>
+__device__ __forceinline__ void partial_store(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 
 // 64 rows per block, 256 threads, three phases:
@@ -31,6 +49,7 @@ __device__ __forceinline__ float clamp_min_nan(float x, float lo) {
 //      the per-row gradient scale, and the wave reduces the block partial sums;
 //   3. all waves form the two gradient tiles (element-parallel), write them back coalesced, and
 //      A lanes reduce the log_var gradient partials over the block's rows.
+template <bool COH = false>
 __device__ __forceinline__ void policy_loss_body(
     const int blk, float* sm,
     int mode, const float* __restrict__ mean_blk, const int ld_mean, const float* __restrict__ log_var,
@@ -40,7 +59,9 @@ __device__ __forceinline__ void policy_loss_body(
     float* __restrict__ partials, const float gscale = 1.0f, const bool scaled = false,
     float* __restrict__ g_surr_t = nullptr, float* __restrict__ g_kl_t = nullptr, const long ld_t = 0,
     const long in_row0 = 0 /* first row held by g_actions / g_behave / g_ref / adv (a staged block: row0) */,
-    const int ld_adv = 1) {
+    const int ld_adv = 1,
+    unsigned long long* __restrict__ kl_slot = nullptr /* (COH) the block's KL sum | 1 << 32, ONE 8-byte device-scope
+    store as soon as it is known: value and "it is there" travel together (see epoch_fb_kernel) */) {
     const int R = LOSS_ROWS_PER_BLOCK;
     float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
     float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
@@ -68,40 +89,58 @@ __device__ __forceinline__ void policy_loss_body(
         s_lsig[tid] = logf(sg);
     }
     SMX_LDS_BARRIER();
-    // ---- phase 1: element-parallel terms ------------------------------------------------
-    for (int i = tid; i < (int)nrows * A; i += 256) {
-        const int rr = i / A, a = i - rr * A;
-        const long gr = row0 + rr - in_row0;
-        const float sig = s_sig[a];
-        const float mu = mean_blk[rr * ld_mean + a];      // the block's rows of tanh(z3): global or LDS
-        const float ac = g_actions[gr * ld_act + a];
-        const float mb = g_behave[gr * ld_beh + a], sb = g_behave[gr * ld_beh + A + a];
-        const float mr = g_ref[gr * ld_ref + a], sr = g_ref[gr * ld_ref + A + a];
-        const float z = (ac - mu) / sig;                         // ppo_net.py:39
-        const float zb = (ac - mb) / sb;
-        const float s2 = sig * sig;
-        const float dt = 1.0f - mu * mu;                         // tanh'
-        const float num = sr * sr + (mr - mu) * (mr - mu);
-        e_z2[i] = z * z;
-        e_zb2[i] = zb * zb;
-        e_lsb[i] = logf(sb);
-        e_kl[i] = logf(sig / sr) + num / (2.0f * s2);            // ppo_net.py:61-62
-        e_klb[i] = logf(sb / sr) + (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
-        e_dmu[i] = ((ac - mu) / s2) * dt;
-        e_dkl[i] = ((mu - mr) / s2) * dt;
-        e_gk[i] = 1.0f - num / s2;
+    // ---- phase 1: element-parallel terms; a thread's elements i and i + 256 go through the chain of LDS reads,
+    // divisions and logarithms TOGETHER (16 x 17 = 272 elements on 256 threads: run one after the other, the sixteen
+    // elements of the second pass cost as much as the first 256) ------------------------------------------------
+    const int n_el = (int)nrows * A;
+    for (int i0 = tid; i0 < n_el; i0 += 512) {
+        float o_z2[2], o_zb2[2], o_lsb[2], o_kl[2], o_klb[2], o_dmu[2], o_dkl[2], o_gk[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = min(i0 + 256 * u, n_el - 1);
+            const int rr = i / A, a = i - rr * A;
+            const long gr = row0 + rr - in_row0;
+            const float sig = s_sig[a];
+            const float mu = mean_blk[rr * ld_mean + a];      // the block's rows of tanh(z3): global or LDS
+            const float ac = g_actions[gr * ld_act + a];
+            const float mb = g_behave[gr * ld_beh + a], sb = g_behave[gr * ld_beh + A + a];
+            const float mr = g_ref[gr * ld_ref + a], sr = g_ref[gr * ld_ref + A + a];
+            const float z = (ac - mu) / sig;                         // ppo_net.py:39
+            const float zb = (ac - mb) / sb;
+            const float s2 = sig * sig;
+            const float dt = 1.0f - mu * mu;                         // tanh'
+            const float num = sr * sr + (mr - mu) * (mr - mu);
+            o_z2[u] = z * z;
+            o_zb2[u] = zb * zb;
+            o_lsb[u] = logf(sb);
+            o_kl[u] = logf(sig / sr) + num / (2.0f * s2);            // ppo_net.py:61-62
+            o_klb[u] = logf(sb / sr) + (sr * sr + (mr - mb) * (mr - mb)) / (2.0f * (sb * sb));
+            o_dmu[u] = ((ac - mu) / s2) * dt;
+            o_dkl[u] = ((mu - mr) / s2) * dt;
+            o_gk[u] = 1.0f - num / s2;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n_el) {
+                e_z2[i] = o_z2[u]; e_zb2[i] = o_zb2[u]; e_lsb[i] = o_lsb[u]; e_kl[i] = o_kl[u];
+                e_klb[i] = o_klb[u]; e_dmu[i] = o_dmu[u]; e_dkl[i] = o_dkl[u]; e_gk[i] = o_gk[u];
+            }
+        }
     }
     SMX_LDS_BARRIER();
 
-    // ---- phase 2: one lane per row ---------------------------------------------------------
-    if (tid < 64) {                      // one wave; lanes >= nrows only feed zeros to the sums
-        const int r = tid;
+    // ---- phase 2: FOUR lanes per row (lane 4 r + q takes a = q, q + 4, ...; the quad's partial sums meet in the
+    // fixed order (q0 + q1) + (q2 + q3) through two butterfly steps, the same bits in all four lanes): the A-deep
+    // chain of dependent LDS reads of one lane per row was the longest single piece of the loss -------------------
+    if (tid < 64) {                      // one wave = 16 rows; rows >= nrows only feed zeros to the sums
+        const int r = tid >> 2, q = tid & 3;
         const bool ok = r < nrows;
         const float c_ll = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
         const float half_d = (float)(0.5 * (double)A);
         float s1 = 0.f, s2 = 0.f, sb1 = 0.f, sb2 = 0.f, klr = 0.f, klbr = 0.f;
         if (ok) {
-            for (int a = 0; a < A; ++a) {
+            for (int a = q; a < A; a += 4) {
                 s1 += e_z2[r * A + a];
                 s2 += s_lsig[a];
                 sb1 += e_zb2[r * A + a];
@@ -110,6 +149,15 @@ __device__ __forceinline__ void policy_loss_body(
                 klbr += e_klb[r * A + a];
             }
         }
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+            sb1 += __shfl_xor(sb1, off, 64);
+            sb2 += __shfl_xor(sb2, off, 64);
+            klr += __shfl_xor(klr, off, 64);
+            klbr += __shfl_xor(klbr, off, 64);
+        }
         const float ll = ((-0.5f * s1) - c_ll) - s2;
         const float llb = ((-0.5f * sb1) - c_ll) - sb2;
         const float el = expf(ll);
@@ -117,7 +165,7 @@ __device__ __forceinline__ void policy_loss_body(
         const float Lb = clamp_min_nan(expf(llb), 1e-5f);
         const float kl = klr - half_d;
         const float klb = klbr - half_d;
-        const float ad = ok ? adv[(row0 + r - in_row0) * ld_adv] : 0.f;
+        const float ad = ok ? adv[(row0 + r - in_row0) * ld_adv] : 0.f;        // (R = 16 rows: r = tid >> 2 < R)
         float surr, loss_r, dLl;  // dLl = d(loss_r)/d(L_learn)
         if (mode == SMX_PPO_CLIP) {
             const float eps = ctrl->clip_eps;
@@ -139,40 +187,60 @@ __device__ __forceinline__ void policy_loss_body(
         }
         // d(loss_r)/d(ll): clamp(min=1e-5) passes the gradient where exp(ll) >= 1e-5
         const float dll = (el >= 1e-5f) ? dLl * el : 0.f;
-        if (r < R) r_dll[r] = ok ? dll : 0.f;
+        if (q == 0) r_dll[r] = ok ? dll : 0.f;
         const float isw = Ll / (Lb + 1e-4f);                                // ppo.py:574
-        const float v0 = smx_wave_sum(ok ? surr : 0.f);
-        const float v1 = smx_wave_sum(ok ? loss_r : 0.f);
-        const float v2 = smx_wave_sum(ok ? kl : 0.f);
-        const float v3 = smx_wave_sum(ok ? Lb : 0.f);
-        const float v4 = smx_wave_sum(ok ? isw : 0.f);
-        const float v5 = smx_wave_sum(ok ? klb : 0.f);
-        if (tid == 0) { P[0] = v0; P[1] = v1; P[2] = v2; P[3] = v3; P[4] = v4; P[5] = v5; P[6] = 0.f; P[7] = 0.f; }
+        const bool one = ok && q == 0;                                      // a row enters the block sums once
+        const float v0 = smx_wave_sum(one ? surr : 0.f);
+        const float v1 = smx_wave_sum(one ? loss_r : 0.f);
+        const float v2 = smx_wave_sum(one ? kl : 0.f);
+        const float v3 = smx_wave_sum(one ? Lb : 0.f);
+        const float v4 = smx_wave_sum(one ? isw : 0.f);
+        const float v5 = smx_wave_sum(one ? klb : 0.f);
+        if (tid == 0) {
+            if (COH && kl_slot)
+                __hip_atomic_store(kl_slot + blk, (unsigned long long)__float_as_uint(v2) | (1ull << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            partial_store<COH>(P + 0, v0); partial_store<COH>(P + 1, v1); partial_store<COH>(P + 2, v2);
+            partial_store<COH>(P + 3, v3); partial_store<COH>(P + 4, v4); partial_store<COH>(P + 5, v5);
+            partial_store<COH>(P + 6, 0.f); partial_store<COH>(P + 7, 0.f);
+        }
     }
     SMX_LDS_BARRIER();
 
     // ---- phase 3: gradient tiles + log_var gradient partials -----------------------------
-    for (int i = tid; i < (int)nrows * A; i += 256) {
-        const int rr = i / A;
-        float gs = r_dll[rr] * e_dmu[i], gk = e_dkl[i];
-        if (scaled) { gs *= gscale; gk *= gscale; }       // data-parallel epochs: already / n_total
-        g_surr[row0 * A + i] = gs;
-        g_kl[row0 * A + i] = gk;
-        if (g_surr_t) {
-            const long at = (long)(i - rr * A) * ld_t + row0 + rr;
-            g_surr_t[at] = gs;
-            if (g_kl_t) g_kl_t[at] = gk;
+    // (g_surr == nullptr: the caller takes the tiles from the scratch -- loss_elem_dmu / _dkl / loss_row_dll)
+    if (g_surr) {
+        for (int i = tid; i < (int)nrows * A; i += 256) {
+            const int rr = i / A;
+            float gs = r_dll[rr] * e_dmu[i], gk = e_dkl[i];
+            if (scaled) { gs *= gscale; gk *= gscale; }       // data-parallel epochs: already / n_total
+            g_surr[row0 * A + i] = gs;
+            g_kl[row0 * A + i] = gk;
+            if (g_surr_t) {
+                const long at = (long)(i - rr * A) * ld_t + row0 + rr;
+                g_surr_t[at] = gs;
+                if (g_kl_t) g_kl_t[at] = gk;
+            }
         }
     }
-    if (tid < A) {
-        // d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2
+    if (tid < 4 * A) {
+        // d ll/d log_var_a = z^2 - 1 ; d KL/d log_var_a = 1 - (sr^2+(mr-mu)^2)/sig^2.  Four lanes per column (lane
+        // 4 a + q takes rows q, q + 4, ...), the quad's partial sums meet in the order (q0 + q1) + (q2 + q3)
+        const int a = tid >> 2, q = tid & 3;
         float gs = 0.f, gk = 0.f;
-        for (int rr = 0; rr < (int)nrows; ++rr) {
-            gs += r_dll[rr] * (e_z2[rr * A + tid] - 1.0f);
-            gk += e_gk[rr * A + tid];
+        for (int rr = q; rr < (int)nrows; rr += 4) {
+            gs += r_dll[rr] * (e_z2[rr * A + a] - 1.0f);
+            gk += e_gk[rr * A + a];
         }
-        P[8 + tid] = gs;
-        P[8 + A + tid] = gk;
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {
+            gs += __shfl_xor(gs, off, 64);
+            gk += __shfl_xor(gk, off, 64);
+        }
+        if (q == 0) {
+            partial_store<COH>(P + 8 + a, gs);
+            partial_store<COH>(P + 8 + A + a, gk);
+        }
     }
 }
 

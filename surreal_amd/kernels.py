@@ -255,6 +255,17 @@ class HipKernels(object):
         L.call('smx_epoch_backward_f32', self._epoch_jobs(jobs), len(jobs), self._epoch_loss(loss),
                L.ptr(ctrl), int(n_total), self._st())
 
+    def epoch_fwdbwd_supported(self, *nets):
+        return bool(all(self.lib.smx_epoch_fwdbwd_supported(n.D, n.H1, n.H2, n.OUT) for n in nets) and
+                    self.lib.smx_epoch_fwdbwd_supported(max(n.D for n in nets), max(n.H1 for n in nets),
+                                                        max(n.H2 for n in nets), max(n.OUT for n in nets)))
+
+    def epoch_fwdbwd(self, jobs, loss, ctrl, n_total, sync_word, kl_slots):
+        """epoch_forward + epoch_backward of an updating epoch in ONE launch (smx_epoch_fwdbwd_f32); sync_word: one
+        int32, kl_slots: 2 * epoch_blocks(rows) 4-byte words (8-byte aligned) per launch, zero on entry"""
+        L.call('smx_epoch_fwdbwd_f32', self._epoch_jobs(jobs), len(jobs), self._epoch_loss(loss),
+               L.ptr(ctrl), int(n_total), L.ptr(sync_word), L.ptr(kl_slots), self._st())
+
     def mlp3_wgrad_multi(self, jobs):
         """the weight-gradient launch alone: dicts(net, x (for rows), grads, sumsq, xT, h1T, h2T, dz3T,
         dz2T, dz1T[, stop])"""

@@ -304,6 +304,9 @@ class PPOLearner(Learner):
             ws.ctrl_f[:10].copy_(torch.tensor(vals, dtype=torch.float32))
             self._ctrl_host = vals
 
+    def _sync_words(self):
+        return (max(self.epoch_policy, self.epoch_baseline) + 1 + 3) & ~3
+
     # ======================================================================================
     # workspace
     # ======================================================================================
@@ -323,12 +326,20 @@ class PPOLearner(Learner):
         ws.E = E
         Ep, Ev = self.epoch_policy, self.epoch_baseline
         # scalars block: ctrl | policy stats | value stats | moments
-        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + Ev * L.VS_STRIDE + 12 + 4
+        # scalars block: ctrl | policy stats | in-launch counters of the fused forward + backward epochs | value stats | moments
+        # (+ per launch and row block of the fused forward + backward epochs: an 8-byte slot)
+        n_slots = 0 if (self.if_rnn_policy or self.model.if_pixel or self.world_size > 1) else \
+            2 * (max(Ep, Ev) + 1) * ((B + 15) // 16)
+        n_sync = self._sync_words() + n_slots
+        n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + n_sync + Ev * L.VS_STRIDE + 12 + 4
         ws.scal = torch.zeros(n_scal, device=dev, dtype=torch.float32)
         o = 0
         ws.ctrl_f = ws.scal[o:o + L.CTRL_WORDS]; o += L.CTRL_WORDS
         ws.ctrl_i = ws.ctrl_f.view(torch.int32)
         ws.pstats = ws.scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE); o += (Ep + 1) * L.PS_STRIDE
+        ws.sync = ws.scal[o:o + n_sync].view(torch.int32); o += n_sync       # one word per epoch launch, zeroed per learn
+        ws.kl_slots = ws.sync[self._sync_words():].view(-1, 2 * ((B + 15) // 16)) if n_slots else None
+        ws.n_sync = n_sync
         ws.vstats = ws.scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE); o += Ev * L.VS_STRIDE
         ws.adv_mom = ws.scal[o:o + 3]; o += 3
         ws.ret_mom = ws.scal[o:o + 3]; o += 3
@@ -347,7 +358,7 @@ class PPOLearner(Learner):
             ws.rf_sums = torch.zeros(3, device=dev, dtype=torch.float32)
         ws.stop = ws.ctrl_i[L.C_STOP:L.C_STOP + 1]
         # stop flag + epochs_done + reserved words + the policy statistics rows: one contiguous run
-        ws.zero_block = ws.scal[L.C_STOP:L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE]
+        ws.zero_block = ws.scal[L.C_STOP:L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + n_sync]
         # keep the optimiser step counters of a previous workspace
         if self._ws is not None:
             ws.ctrl_i[L.C_STEP_ACTOR:L.C_STEP_CRITIC + 1].copy_(
@@ -442,6 +453,10 @@ class PPOLearner(Learner):
         ws.fused = (self.fused_epochs and self.epoch_schedule == 'lockstep' and not stem and
                     (self.world_size == 1 or self.epoch_policy == self.epoch_baseline) and
                     K.epoch_supported(act, cri))
+        # ... and an updating epoch's forward + loss + data gradients as ONE launch (single rank; several ranks need the
+        # all-reduce between them)
+        ws.fb = (ws.fused and self.world_size == 1 and bool(self.session_config.learner.get('fused_fwdbwd', True)) and
+                 n_slots > 0 and K.epoch_fwdbwd_supported(act, cri))
         vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
         ws.nblk_v = vblocks(rows)
         # single rank: GAE + normalisation and the end-of-learn statistics are one launch each
@@ -904,13 +919,19 @@ class PPOLearner(Learner):
         for e in range(max(Ep + 1, Ev)):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
             loss = loss_args(e)
-            K.epoch_forward(([aj] if pol_f else []) + ([cj] if val else []), loss, ws.ctrl_f, n_total)
-            if pol_f and not pol_u:
-                K.epoch_backward([aj], loss, ws.ctrl_f, n_total)       # statistics + early exit only
-            if pol_u or val:
+            if ws.fb and (pol_u or not pol_f) and (pol_u or val):
+                # forward + loss + data gradients of every job of the epoch in ONE launch (smx_epoch_fwdbwd_f32)
                 bj = ([aj] if pol_u else []) + ([cj] if val else [])
-                K.epoch_backward(bj, loss, ws.ctrl_f, n_total)
+                K.epoch_fwdbwd(bj, loss, ws.ctrl_f, n_total, ws.sync[e:e + 1], ws.kl_slots[e])
                 K.mlp3_wgrad_multi(bj)
+            else:
+                K.epoch_forward(([aj] if pol_f else []) + ([cj] if val else []), loss, ws.ctrl_f, n_total)
+                if pol_f and not pol_u:
+                    K.epoch_backward([aj], loss, ws.ctrl_f, n_total)       # statistics + early exit only
+                if pol_u or val:
+                    bj = ([aj] if pol_u else []) + ([cj] if val else [])
+                    K.epoch_backward(bj, loss, ws.ctrl_f, n_total)
+                    K.mlp3_wgrad_multi(bj)
             np_a, np_c = ws.np_a + 1, ws.np_c
             if pol_u and val:        # both groups step in one launch
                 K.clip_adam_pair((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
@@ -1503,7 +1524,8 @@ class PPOLearner(Learner):
         when first looked at -- at the latest right after the NEXT learn() has been enqueued -- so
         the GPU never waits for the read-back and the Python that decodes it."""
         snap = {'beta': getattr(self, 'beta', None), 'clip_epsilon': getattr(self, 'clip_epsilon', None),
-                'lr': self.actor_lr_scheduler.get_lr()[0]}       # (each mode defines only its own)
+                'lr': self.actor_lr_scheduler.get_lr()[0],       # (each mode defines only its own)
+                'n_sync': ws.n_sync}
         if not self.lazy_stats:
             return self._decode_stats(ws.scal.cpu(), snap)
         self._flush_stats()                        # the previous learn's, now that this one is queued
@@ -1531,10 +1553,14 @@ class PPOLearner(Learner):
         o = L.CTRL_WORDS
         Ep, Ev = self.epoch_policy, self.epoch_baseline
         ps = scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE).numpy(); o += (Ep + 1) * L.PS_STRIDE
+        o += snap['n_sync']
         vs = scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE).numpy(); o += Ev * L.VS_STRIDE
         ret_mom = scal[o + 3:o + 6].numpy()
         fin = scal[o + 8:o + 12].numpy()
         rf = scal[o + 12:o + 15].numpy()
+        if int(ctrl_i[L.C_SYNC_ERR]) != 0:
+            raise RuntimeError('the in-launch wait of a fused forward + backward epoch timed out in the last learn() '
+                               '(smx_epoch_fwdbwd_f32): a workgroup of the launch never published its loss sums')
         if int(ctrl_i[L.C_XCHG_ERR]) != 0:
             raise RuntimeError('a peer exchange timed out in the last learn(): error word 0x%x (0x100 | phase << 4 | peer) '
                                '-- a rank died or fell behind by more than the timeout' % (int(ctrl_i[L.C_XCHG_ERR]) & 0xffff))

@@ -264,6 +264,16 @@ class TorchCpuKernels(object):
             j['dz2T'].copy_(dz2.t())
             j['dz1T'].copy_(dz1.t())
 
+    def epoch_fwdbwd_supported(self, *nets):
+        return self.epoch_supported(*nets)
+
+    def epoch_fwdbwd(self, jobs, loss, ctrl, n_total, sync_word, kl_slots=None):
+        """the contract of smx_epoch_fwdbwd_f32: the two launches it replaces, back to back"""
+        self.epoch_forward(jobs, loss, ctrl, n_total)
+        self.epoch_backward(jobs, loss, ctrl, n_total)
+        if any(j.get('loss') == 'policy' for j in jobs):
+            sync_word += self.epoch_blocks(jobs[0]['x'].shape[0])
+
     def mlp3_wgrad_multi(self, jobs):
         for j in jobs:
             if j.get('stop') is not None and int(j['stop'][0]) != 0:

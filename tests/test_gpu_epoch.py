@@ -129,6 +129,91 @@ def test_epoch_forward_backward_wgrad(K, rows, D, H1, H2, A, mode):
         close(d[k], c[k], atol=1e-6, rtol=5e-5, msg=k)
 
 
+def _fb_pair(K, rows, D, H1, H2, A, mode, seed, kl_target=1e9, launches=1):
+    """the same problem twice on the device: forward + backward as two launches / as smx_epoch_fwdbwd_f32"""
+    out = []
+    for fb in (False, True):
+        t = build(rows, D, H1, H2, A, seed=seed, mode=mode, device='cuda')['d']
+        if kl_target is not None:
+            t['ctrl'][L.C_KL_TARGET] = kl_target
+        t['sync'] = torch.zeros(4, dtype=torch.int32, device='cuda')
+        t['slots'] = torch.zeros(4, 2 * ((rows + 15) // 16), dtype=torch.int32, device='cuda')
+        loss = dict(mode=mode, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
+                    adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=True,
+                    will_update=True, dlogvar=t['dlogvar'], dlogvar_sumsq=t['dlq'], stats=t['stats'],
+                    returns=t['returns'], v_dz3=t['v_dz3'], v_partials=t['v_partials'], v_will_update=True)
+        K.epoch_pack([(t['act'], t['pk_a']), (t['cri'], t['pk_c'])])
+        aj = dict(net=t['act'], packed=t['pk_a'], x=t['x'], h1T=t['h1aT'], h2T=t['h2aT'], act=L.SMX_ACT_TANH, loss='policy',
+                  dz3T=t['dz3aT'], dz2T=t['dz2aT'], dz1T=t['dz1aT'], xT=t['xT'], grads=t['grads_a'])
+        cj = dict(net=t['cri'], packed=t['pk_c'], x=t['x'], h1T=t['h1cT'], h2T=t['h2cT'], act=L.SMX_ACT_NONE,
+                  loss='value', dz3=t['v_dz3'], dz3T=t['v_dz3'], dz2T=t['dz2cT'], dz1T=t['dz1cT'], xT=t['xT'],
+                  grads=t['grads_c'])
+        for k in range(launches):
+            if fb:
+                K.epoch_fwdbwd([aj, cj], loss, t['ctrl'], rows, t['sync'][k:k + 1], t['slots'][k])
+            else:
+                K.epoch_forward([aj, cj], loss, t['ctrl'], rows)
+                K.epoch_backward([aj, cj], loss, t['ctrl'], rows)
+        K.mlp3_wgrad_multi([aj, cj])
+        torch.cuda.synchronize()
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize('mode', [L.SMX_PPO_ADAPT, L.SMX_PPO_CLIP])
+@pytest.mark.parametrize('rows,D,H1,H2,A', SHAPES)
+def test_epoch_fwdbwd_equals_forward_then_backward(K, rows, D, H1, H2, A, mode):
+    """smx_epoch_fwdbwd_f32 (one launch, batch means through the in-launch counter) against the two launches it
+    replaces, both on the device: the forward results and the loss sums bit for bit, the data gradients up to the
+    rounding of where c_kl is applied (one layer later), the weight gradients that follow within 2e-5."""
+    if not K.epoch_fwdbwd_supported(*[make_net(D, H1, H2, o, 1, 'cuda')[1] for o in (A, 1)]):
+        pytest.skip('shape outside smx_epoch_fwdbwd_supported')
+    # (no early exit here: in clip mode the fused launch forms the data gradients before workgroup 0 knows about it --
+    # the optimiser launch honours the flag -- where the separate backward launch returns early)
+    two, one = _fb_pair(K, rows, D, H1, H2, A, mode, seed=rows + D)
+    for k in ('h1aT', 'h2aT', 'h1cT', 'h2cT', 'partials', 'v_dz3', 'v_partials'):    # (g_surr / g_kl stay in LDS)
+        assert torch.equal(one[k], two[k]), k
+    close(one['stats'], two['stats'], atol=1e-6, rtol=2e-6, msg='stats')
+    close(one['dlogvar'], two['dlogvar'], atol=1e-7, rtol=2e-6, msg='dlogvar')
+    close(one['dlq'], two['dlq'], atol=1e-9, rtol=1e-5, msg='dlogvar sumsq')
+    assert torch.equal(one['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:], two['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:])
+    assert int(one['sync'][0]) == (rows + 15) // 16
+    for k in ('dz3aT', 'dz2aT', 'dz1aT', 'dz2cT', 'dz1cT'):
+        close(one[k], two[k], atol=1e-8, rtol=1e-5, msg=k)
+    for k in ('grads_a', 'grads_c'):
+        close(one[k], two[k], atol=1e-7, rtol=2e-5, msg=k)
+
+
+def test_epoch_fwdbwd_kl_cutoff_early_exit_and_repeats(K):
+    rows, D, H1, H2, A = 200, 24, 64, 48, 6
+    # (a) the KL cutoff active: c_kl = beta + 2 eta (KL - 2 kl_target) carries the batch KL through the counter
+    two, one = _fb_pair(K, rows, D, H1, H2, A, L.SMX_PPO_ADAPT, seed=11)
+    kl = float(two['stats'][L.PS_KL])
+    two, one = _fb_pair(K, rows, D, H1, H2, A, L.SMX_PPO_ADAPT, seed=11, kl_target=kl / 3.0)    # 2 kt < KL < 4 kt
+    assert int(one['ctrl'].view(torch.int32)[L.C_STOP]) == 0
+    # (c_kl is large here and the two shares cancel: the absolute bound scales with |c_kl| * |W3^T g_kl| ~ 1e-2)
+    for k in ('dz3aT', 'dz2aT', 'dz1aT'):
+        close(one[k], two[k], atol=3e-7, rtol=1e-5, msg=k)
+    assert float(one['dz3aT'].abs().sum()) > 0
+    # (b) the early exit: flag raised, counters untouched, no actor gradient leaves the launch in adapt mode
+    for mode in (L.SMX_PPO_ADAPT, L.SMX_PPO_CLIP):
+        two, one = _fb_pair(K, rows, D, H1, H2, A, mode, seed=12, kl_target=1e-7)
+        for t in (one, two):
+            ci = t['ctrl'].cpu().view(torch.int32)
+            assert int(ci[L.C_STOP]) == 1 and int(ci[L.C_EPOCHS_DONE]) == 0 and int(ci[L.C_STEP_ACTOR]) == 0
+            assert int(ci[L.C_STEP_CRITIC]) == 1
+        close(one['stats'], two['stats'], atol=1e-6, rtol=2e-6)
+        close(one['dz1cT'], two['dz1cT'], atol=1e-8, rtol=1e-5)
+        if mode == L.SMX_PPO_ADAPT:
+            assert float(one['dz1aT'].abs().sum()) == 0.0
+    # (c) three launches in a row on their own counter words give what three pairs of launches give
+    two, one = _fb_pair(K, rows, D, H1, H2, A, L.SMX_PPO_ADAPT, seed=13, launches=3)
+    assert one['sync'].cpu().tolist() == [(rows + 15) // 16] * 3 + [0]
+    assert torch.equal(one['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:], two['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:])
+    for k in ('dz2aT', 'dz1aT', 'dz1cT'):
+        close(one[k], two[k], atol=1e-8, rtol=1e-5, msg=k)
+
+
 def test_epoch_early_exit_and_final_pass(K):
     rows, D, H1, H2, A = 64, 16, 40, 24, 4
     # early exit: kl_target so small that KL > 4 kl_target -> flag raised, nothing updated
