@@ -454,23 +454,104 @@ def main():
                     help='epoch launch schedule (session_config.learner.epoch_schedule)')
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it (the shape of the driver's N = 1 command):
+    # launch the N ranks ourselves -- the same command the docstring names -- instead of refusing
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        diagnostic(args, 'WORLD_SIZE is %d but --gpus is %d: launch with torch.distributed.run --nproc-per-node %d '
+                         '(or plain `python bench.py --gpus %d`, which launches the ranks itself)'
+                   % (world, args.gpus, args.gpus, args.gpus), rank)
+        return 2
     # SMX_BENCH_BACKEND=gloo is the single-GPU rehearsal of the N > 1 path (tests/test_gpu_dist.py):
     # RCCL refuses two ranks on one device, gloo does not, and the ranks then share the GPU
     backend = os.environ.get('SMX_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    if ndev == 0 or (backend == 'nccl' and world > ndev):
+        diagnostic(args, 'this node shows %d GPU(s) to the process (HIP_VISIBLE_DEVICES=%r) but --gpus is %d; RCCL needs '
+                         'one device per rank (SMX_BENCH_BACKEND=gloo rehearses the N > 1 path on fewer devices)'
+                   % (ndev, os.environ.get('HIP_VISIBLE_DEVICES'), world), rank)
+        return 0
     if backend != 'nccl':
-        local_rank %= torch.cuda.device_count()
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
+        import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
+        # a bounded rendezvous / collective timeout: first contact with a node must end in a line, not in a hang
+        tmo = datetime.timedelta(seconds=float(os.environ.get('SMX_BENCH_PG_TIMEOUT_S', '180')))
+        try:
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+        except Exception as e:
+            diagnostic(args, 'init_process_group(%s) failed: %r' % (backend, e), rank)
+            return 0
+    try:
+        return run(args, world, rank, local_rank, backend)
+    except Exception as e:              # the line is the contract: say what stopped the run, then fail
+        import traceback
+        traceback.print_exc()
+        diagnostic(args, 'rank %d: %r' % (rank, e), 0)
+        return 1
+
+
+def _exchange_failure():
+    from surreal_amd.distributed.peer_exchange import PeerExchange
+    return PeerExchange.last_failure
+
+
+def diagnostic(args, why, rank=0):
+    """the ONE JSON line when no measurement could be made (value null + the reason)"""
+    if rank == 0:
+        print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'env-steps/s', 'n_gpus': args.gpus, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': args.scaling,
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'BASELINE configs[4]', 'parallelism': 'dp%d' % args.gpus},
+                          'error': why}), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N`: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same flags>` under a wall-clock budget, pass its JSON line through, and
+    print a diagnostic line of our own if it ends without one"""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if os.environ.get('SMX_BENCH_BACKEND', 'nccl') == 'nccl' and ndev < args.gpus:
+        diagnostic(args, 'this node shows %d GPU(s) (HIP_VISIBLE_DEVICES=%r) but --gpus is %d; RCCL needs one device per '
+                         'rank' % (ndev, os.environ.get('HIP_VISIBLE_DEVICES'), args.gpus))
+        return 0
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    budget = float(os.environ.get('SMX_BENCH_LAUNCH_BUDGET_S', '1500'))
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget, cwd=ROOT)
+        out, err, rc = r.stdout, r.stderr, r.returncode
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or '')
+        err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or '')
+        rc = 124
+        err += '\n[bench.py] the %d-rank run exceeded its wall-clock budget of %.0f s' % (args.gpus, budget)
+    sys.stderr.write(err[-8000:])
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    if lines:
+        print(lines[-1], flush=True)
+        return rc
+    diagnostic(args, 'the %d-rank launch ended (rc %d) without a result line: %s' % (args.gpus, rc, err.strip()[-600:]))
+    return rc or 1
+
+
+def run(args, world, rank, local_rank, backend):
+    import torch.distributed as dist
 
     def barrier():
         torch.cuda.synchronize()
@@ -567,6 +648,7 @@ def main():
                 'epoch_kernels': 'fused row-block' if getattr(ws, 'fused', False) else 'layered',
                 'collectives_per_step': getattr(learner, 'collectives_per_step', 0 if world == 1 else None),
                 'exchange': exchange_kind,
+                'exchange_fallback_reason': _exchange_failure() if world > 1 else None,
                 'epoch_all_reduce_us': collective_us, 'epoch_all_reduce_bytes': collective_bytes,
                 'epoch_all_reduce_us_process_group': pg_us,
                 'graph_segments': bool(world > 1 and learner.use_graph and getattr(learner._dist, 'exchange', None) is None),
@@ -632,7 +714,8 @@ def main():
         if getattr(learner, '_dist', None) is not None and learner._dist.exchange is not None:
             learner._dist.exchange.close()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -26,6 +26,8 @@ log = logging.getLogger('surreal_amd.peer_exchange')
 
 
 class PeerExchange(object):
+    last_failure = None        # why the most recent create() returned None (reported by bench.py / the self-test)
+
     def __init__(self, dist, capacity, timeout_s=2.0):
         """collective: every rank of `dist`'s default group constructs it with the same capacity
         (floats the largest exchange carries).  Raises SmxError / RuntimeError on failure."""
@@ -177,6 +179,7 @@ class PeerExchange(object):
             if ex is not None:
                 ex.close()
             log.warning('peer exchange unavailable on some rank (%s): using the process group', why or 'a peer failed')
+            cls.last_failure = 'set-up: %s' % (why or 'failed on another rank')
             return None
         try:
             good, msg = ex.self_check(rounds)
@@ -188,9 +191,11 @@ class PeerExchange(object):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok) < 1.0:
             log.warning('peer exchange self-check failed (%s): using the process group', msg)
+            cls.last_failure = 'self-check: %s' % (msg if not good else 'failed on another rank')
             ex.close()
             return None
         ex.check_message = msg
+        cls.last_failure = None
         return ex
 
     def close(self):
