@@ -230,7 +230,128 @@ def _time_learn(L, db, steps, warm=2):
     return (time.perf_counter() - t0) / steps
 
 
-def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5):
+# ---- pricing of a configuration: SURVEY.md 8(d)'s accounting, generalised over the policy ----------------
+CNN_FLOPS_PER_FRAME = 2.0 * (20 * 20 * 16 * (8 * 8 * 3) + 9 * 9 * 32 * (4 * 4 * 16) + 2592 * 256)   # builders.py:8-33 on 3x84x84
+
+
+def ppo_costs(Bs, Ns, Ds, As, rnn=False, pixel=None, hidden=HIDDEN, F=100, H=5, Ep=10, Ev=10):
+    """ALGORITHMIC flops and bytes of one learn(): the critic over all B (N + 1) steps once, the
+    policy epochs at 4 forward-equivalents each (forward + backward = 3, + the KL forward after the update,
+    ppo.py:553), the value epochs at 3, the reference policy once; with an LSTM / CNN stem every pass includes the
+    stem and the epochs run over B E rows (E = N - H + 1).  Bytes: what must be touched once -- observations
+    (uint8 frames stay uint8), rewards, dones, the first E steps' actions and behaviour pds, values, advantages, returns."""
+    E = Ns - H + 1 if rnn else 1
+    Din = Ds + (256 if pixel else 0)
+    stem = (2.0 * 4 * F * (Din + F) if rnn else 0.0) + (CNN_FLOPS_PER_FRAME if pixel else 0.0)     # per row-step
+    top = F if rnn else Din
+    Pa = 2.0 * (top * hidden[0] + hidden[0] * hidden[1] + hidden[1] * As)
+    Pc = 2.0 * (top * hidden[0] + hidden[0] * hidden[1] + hidden[1] * 1)
+    rows, steps_all = Bs * E, Bs * (Ns + 1)
+    flops = steps_all * (stem + Pc) + Ep * 4 * rows * (stem + Pa) + Ev * 3 * rows * (stem + Pc) + rows * (stem + Pa)
+    frame = (pixel[0] * pixel[1] * pixel[2]) if pixel else 0
+    bytes_ = steps_all * (4.0 * Ds + frame) + 2 * 4.0 * Bs * Ns + rows * 3 * As * 4.0 + 4.0 * steps_all + 2 * 4.0 * rows + \
+        (2 * 4.0 * Bs * F if rnn else 0.0)
+    return flops, bytes_, dict(stem_flops_per_row_step=stem, actor_flops_per_row=Pa, critic_flops_per_row=Pc,
+                               rows_per_epoch=rows, steps_all=steps_all)
+
+
+def kernel_table(fn):
+    """device time by kernel over ONE call of fn (torch.profiler / roctracer: every HIP kernel of the process, the
+    C-ABI's included, graph replays too): [(name, calls, total_us)], largest first"""
+    from torch.profiler import profile, ProfilerActivity
+    import warnings
+    torch.cuda.synchronize()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+    rows = [(e.key, int(e.count), float(e.device_time_total)) for e in prof.key_averages() if e.device_time_total > 0]
+    return sorted(rows, key=lambda r: -r[2])
+
+
+def _short(name):
+    n = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return n.split('(')[0][:64]
+
+
+def dominant_kernel(table, family_flops):
+    """the kernel family with the most device time and, where its algorithmic flops per learn are known
+    (family_flops: {name prefix: flops}), its fraction of the FP32 peak (MFMA and vector rate are both 157.3 TFLOP/s)"""
+    fam = {}
+    for name, calls, us in table:
+        k = _short(name)
+        k = k.split('<')[0]
+        c, t = fam.get(k, (0, 0.0))
+        fam[k] = (c + calls, t + us)
+    total = sum(t for _, t in fam.values())
+    k, (c, t) = max(fam.items(), key=lambda kv: kv[1][1])
+    out = {'name': k, 'launches_per_learn': c, 'avg_us': t / c, 'share_of_device_time': t / total,
+           'device_us_per_learn': total, 'timing': 'torch.profiler (roctracer) over one learn() of this run'}
+    for prefix, fl in family_flops.items():
+        if k.startswith(prefix):
+            out.update(algorithmic_flops_per_learn=fl, achieved_TFLOPs=fl / (t * 1e-6) / 1e12,
+                       frac=fl / (t * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+    out['top5'] = [{'name': kk, 'launches': cc, 'us': tt} for kk, (cc, tt) in
+                   sorted(fam.items(), key=lambda kv: -kv[1][1])[:5]]
+    return out
+
+
+def priced(dt, flops, bytes_, units, unit_name):
+    """whole-learn figures against both roofs"""
+    return {'algorithmic_flops_per_learn': flops, 'algorithmic_bytes_per_learn': bytes_,
+            'bound': 'mfma' if flops / max(bytes_, 1.0) > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9) else 'hbm',
+            'achieved_TFLOPs': flops / dt / 1e12, 'frac_of_fp32_peak': flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            'achieved_hbm_GBps': bytes_ / dt / 1e9, 'frac_of_hbm_peak': bytes_ / dt / 1e9 / PEAK_HBM_GBPS,
+            unit_name + '_per_s': units / dt}
+
+
+_CPU_THREADS = [None]      # the best thread count of the headline's sweep (cpu_baseline); else the physical cores, <= 32
+
+
+def _cpu_threads():
+    return _CPU_THREADS[0] or max(1, min(32, host_cpu()['physical_cores']))
+
+
+def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=12.0, sample_rows=None):
+    """the CPU restatement of the reference learner (oracle/ppo_oracle.py, kind "port") on this host for the same
+    configuration: one warm-up + timed learns inside the budget (at least one); sample_rows: a row subset of the batch
+    for configurations whose full learn takes minutes on a CPU (the rate is per env-step)"""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ppo_oracle
+    prev = torch.get_num_threads()
+    if sample_rows and sample_rows < Bs:
+        batch = slice_batch(batch, 0, sample_rows)
+        Bs = sample_rows
+    kw = dict(n_step=Ns, kl_target=1e9)
+    if rnn:
+        kw.update(if_rnn_policy=True, horizon=5)
+    best = None
+    # the headline's best thread count and 8 (small GEMMs get slower with more threads): the better of the two
+    for n in sorted({8, _cpu_threads()}):
+        torch.set_num_threads(n)
+        O = ppo_oracle.OraclePPOLearner(params, As, Bs, **kw)
+        t0 = time.time()
+        O.learn(copy.deepcopy(batch))
+        first = time.time() - t0
+        cold = first > budget_s / 4              # a learn that takes seconds: the first call is the sample
+        times = [first] if cold else []
+        while not cold and len(times) < 5 and (not times or sum(times) + first < budget_s / 2):
+            t1 = time.time()
+            O.learn(copy.deepcopy(batch))
+            times.append(time.time() - t1)
+        dt = sum(times) / len(times)
+        if best is None or dt < best[0]:
+            best = (dt, n, len(times), cold)
+    torch.set_num_threads(prev)
+    dt, n, k, cold = best
+    return {'value': Bs * Ns / dt, 'unit': 'env-steps/s', 'cores': n, 'kind': 'port', 's_per_learn': dt,
+            'sample': '%d timed learn(s) of %d x %d (%s), oracle/ppo_oracle.py, torch %s CPU, the better of 8 and %d threads%s' % (
+                k, Bs, Ns, 'full batch' if not sample_rows else 'the first %d sub-trajectories of the batch' % Bs,
+                torch.__version__, _cpu_threads(), ' (single call, no warm-up: one learn takes seconds)' if cold else '')}
+
+
+def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5, cpu=True, cpu_sample_rows=None):
     from surreal_amd.learner.ppo import PPOLearner
     lc = ppo_learner_config()
     lc.algo.n_step = Ns
@@ -239,15 +360,38 @@ def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5):
     lc.algo.consts.kl_target = 1e9
     lc.replay.batch_size = Bs
     L = PPOLearner(lc, ppo_env_config(Ds, As, pixel=pixel), ppo_session_config('/tmp/surreal_amd_bench2'))
-    batch = synthetic.make_ppo_batch(Bs, Ns, Ds, As, seed=1, rnn_hidden=lc.algo.rnn.rnn_hidden if rnn else 0,
-                                     pixel=pixel)
-    dt = _time_learn(L, L._preprocess_batch_ppo(copy.deepcopy(batch)), steps)
-    return {'ms_per_learn': dt * 1e3, 'env_steps_per_s': Bs * Ns / dt, 'B': Bs, 'n_step': Ns, 'obs_dim': Ds,
-            'action_dim': As, 'policy': ('cnn+' if pixel else '') + ('lstm100(H=5)+mlp' if rnn else 'mlp'),
-            'epochs': '10+10, KL early exit disabled'}
+    F = lc.algo.rnn.rnn_hidden
+    batch = synthetic.make_ppo_batch(Bs, Ns, Ds, As, seed=1, rnn_hidden=F if rnn else 0, pixel=pixel)
+    db = L._preprocess_batch_ppo(copy.deepcopy(batch))
+    dt = _time_learn(L, db, steps)
+    flops, bytes_, parts = ppo_costs(Bs, Ns, Ds, As, rnn=rnn, pixel=pixel, F=F)
+    out = {'ms_per_learn': dt * 1e3, 'env_steps_per_s': Bs * Ns / dt, 'B': Bs, 'n_step': Ns, 'obs_dim': Ds,
+           'action_dim': As, 'policy': ('cnn+' if pixel else '') + ('lstm100(H=5)+mlp' if rnn else 'mlp'),
+           'epochs': '10+10, KL early exit disabled', 'roofline': priced(dt, flops, bytes_, Bs * Ns, 'env_steps')}
+    try:
+        rows, steps_all = parts['rows_per_epoch'], parts['steps_all']
+        rec = 2.0 * 4 * F * F                               # the recurrent product of one row-step
+        fam = {'mlp3_rows16_kernel': steps_all * parts['critic_flops_per_row'],
+               'epoch_fb_kernel': 10 * 3 * rows * (parts['actor_flops_per_row'] + parts['critic_flops_per_row']) * (2.0 / 3.0),
+               'lstm_fwd': rec * (steps_all + 22 * rows), 'lstm_bwd': rec * 20 * rows,
+               'conv_u8_fwd': 2.0 * 20 * 20 * 16 * 192 * (steps_all + 22 * rows),
+               'conv_u8_wgrad': 2.0 * 20 * 20 * 16 * 192 * 20 * rows}
+        graph, L.use_graph = L.use_graph, False        # (kernels inside a hipGraph replay are not traced: one eager learn)
+        out['dominant_kernel'] = dominant_kernel(kernel_table(lambda: L.learn(db)), fam)
+        L.use_graph = graph
+    except Exception as e:
+        out['dominant_kernel'] = {'error': repr(e)}
+    if cpu:
+        try:
+            params = L.model.numpy_params()            # the same (randomly initialised) parameters on both sides
+            out['cpu_baseline'] = cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, sample_rows=cpu_sample_rows)
+            out['gpu_over_cpu'] = out['env_steps_per_s'] / out['cpu_baseline']['value']
+        except Exception as e:
+            out['cpu_baseline'] = {'error': repr(e)}
+    return out
 
 
-def secondary_ddpg(steps=200):
+def secondary_ddpg(steps=200, cpu=True):
     from surreal_amd.learner.ddpg import DDPGLearner
     from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
     from surreal_amd.replay import UniformReplay
@@ -279,8 +423,48 @@ def secondary_ddpg(steps=200):
         sample_and_learn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {'ms_per_iteration': dt * 1e3, 'samples_per_s': Bd / dt, 'batch': Bd, 'replay_rows': 1000000,
-            'what': 'uniform sample of 512 out of 1e6 device-resident rows + DDPGLearner.learn'}
+    # ALGORITHMIC work of one iteration (ddpg.py:244-352): target actor + target critic forward, critic forward +
+    # backward (3), actor forward, critic forward + its data gradient for the actor loss (2), actor backward (2);
+    # bytes: the sampled rows + parameters, gradients and both Adam moments read and written once
+    Pa = Dd * 300 + 300 * 200 + 200 * Ad
+    Pc = Dd * 400 + (400 + Ad) * 300 + 300
+    flops = 2.0 * Bd * (4 * Pa + 6 * Pc)
+    n_par = Pa + 300 + 200 + Ad + Pc + 400 + 300 + 1
+    bytes_ = 4.0 * Bd * (2 * Dd + Ad + 2) + 7 * 4.0 * n_par + 2 * 4.0 * n_par
+    out = {'ms_per_iteration': dt * 1e3, 'samples_per_s': Bd / dt, 'batch': Bd, 'replay_rows': 1000000,
+           'what': 'uniform sample of 512 out of 1e6 device-resident rows + DDPGLearner.learn',
+           'roofline': priced(dt, flops, bytes_, Bd, 'samples')}
+    out['roofline']['note'] = '~22 dependent launches of 512-row problems: launch-latency-bound, neither roof applies'
+    try:
+        graph, L.use_graph = getattr(L, 'use_graph', False), False
+        out['dominant_kernel'] = dominant_kernel(kernel_table(sample_and_learn), {'gemm': flops})
+        L.use_graph = graph
+    except Exception as e:
+        out['dominant_kernel'] = {'error': repr(e)}
+    if cpu:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+            import ddpg_oracle
+            n = _cpu_threads()
+            prev = torch.get_num_threads()
+            torch.set_num_threads(n)
+            O = ddpg_oracle.OracleDDPGLearner(ddpg_oracle.make_ddpg_params(Dd, Ad))
+            b = synthetic.make_ddpg_batch(Bd, Dd, Ad, seed=0)
+            for _ in range(5):
+                O.learn(copy.deepcopy(b))
+            t0, k = time.time(), 0
+            while k < 20 or (time.time() - t0 < 3.0 and k < 2000):
+                O.learn(copy.deepcopy(b))
+                k += 1
+            cdt = (time.time() - t0) / k
+            torch.set_num_threads(prev)
+            out['cpu_baseline'] = {'value': Bd / cdt, 'unit': 'samples/s', 'cores': n, 'kind': 'port', 's_per_iteration': cdt,
+                                   'sample': '%d iterations of oracle/ddpg_oracle.py learn() on a resident batch of 512 '
+                                             '(no replay sample on the CPU side), %d threads' % (k, n)}
+            out['gpu_over_cpu'] = out['samples_per_s'] / out['cpu_baseline']['value']
+        except Exception as e:
+            out['cpu_baseline'] = {'error': repr(e)}
+    return out
 
 
 def secondary_pipeline(actors, overlap=False):
@@ -410,6 +594,15 @@ def secondary_host_fed(iters=12):
     return out
 
 
+def _summary_key(key):
+    for tag, short in (('configs[0]', 'configs[0] PPO 2x25 LSTM'), ('64x128, MLP', 'configs[1] PPO 64x128 MLP'),
+                       ('64x128, LSTM', 'configs[1] PPO 64x128 LSTM'), ('PPO 1024x128', 'PPO 1024x128 LSTM'),
+                       ('configs[2]', 'configs[2] DDPG 512 of 1e6'), ('configs[3] PPO', 'configs[3] PPO 256x32 pixel CNN+LSTM')):
+        if tag in key:
+            return short
+    return key[:60]
+
+
 def secondaries():
     out = {}
     for key, fn in (
@@ -421,6 +614,8 @@ def secondaries():
             ('configs[3] on-device loop: 256 actors x 32 steps, 3x84x84 uint8 camera + 32-d state, CNN + LSTM policy',
              secondary_pixel_pipeline),
             ('host-fed learner: 1024 x 128 x 376 batches from host memory (pinned double-buffered ingest)', secondary_host_fed),
+            ('configs[0] PPO 2x25 D=17 A=6, LSTM policy (the shape of the reference test_ppo_gym --unit-test)',
+             lambda: secondary_ppo(2, 25, 17, 6, True, steps=10)),
             ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda: secondary_ppo(64, 128, 17, 6, False)),
             ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
              lambda: secondary_ppo(64, 128, 17, 6, True)),
@@ -428,7 +623,7 @@ def secondaries():
              lambda: secondary_ppo(1024, 128, 17, 6, True, steps=3)),
             ('configs[2] DDPG HalfCheetah shapes, uniform replay 1e6, batch 512', secondary_ddpg),
             ('configs[3] PPO 256 actors x 32 steps, 3x84x84 uint8 frames + 32-d state, CNN + LSTM policy',
-             lambda: secondary_ppo(256, 32, 32, 8, True, pixel=(3, 84, 84), steps=3))):
+             lambda: secondary_ppo(256, 32, 32, 8, True, pixel=(3, 84, 84), steps=3, cpu_sample_rows=32))):
         try:
             out[key] = fn()
         except Exception as e:       # a secondary must never take the headline line down
@@ -704,10 +899,29 @@ def run(args, world, rank, local_rank, backend):
                 out['cpu_baseline'] = cpu_baseline(args.mode, params, zstate, batch)
                 out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
                 out['gpu_over_cpu_single_thread'] = out['value'] / out['cpu_baseline']['single_thread']
+                _CPU_THREADS[0] = out['cpu_baseline']['cores']
             if not args.no_secondary:
                 del learner, dbatch
                 torch.cuda.empty_cache()
                 out['secondary'] = secondaries()
+                # the other BASELINE configurations at a glance (the full records are in `secondary`):
+                # rate | whole-learn fraction of the FP32 peak | dominant kernel (share, its own fraction) | GPU / CPU
+                summ = {}
+                for key, r in out['secondary'].items():
+                    if not isinstance(r, dict) or 'roofline' not in r:
+                        continue
+                    dk = r.get('dominant_kernel', {})
+                    cb = r.get('cpu_baseline', {})
+                    summ[_summary_key(key)] = {
+                        'rate': r.get('env_steps_per_s', r.get('samples_per_s')),
+                        'unit': 'env-steps/s' if 'env_steps_per_s' in r else 'samples/s',
+                        'ms': r.get('ms_per_learn', r.get('ms_per_iteration')),
+                        'frac_of_fp32_peak': r['roofline']['frac_of_fp32_peak'],
+                        'frac_of_hbm_peak': r['roofline']['frac_of_hbm_peak'],
+                        'dominant_kernel': dk.get('name'), 'dominant_share': dk.get('share_of_device_time'),
+                        'dominant_frac': dk.get('frac'),
+                        'cpu_baseline': cb.get('value'), 'cpu_cores': cb.get('cores'), 'gpu_over_cpu': r.get('gpu_over_cpu')}
+                out['secondary_summary'] = summ
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

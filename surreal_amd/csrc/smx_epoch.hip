@@ -393,9 +393,12 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     //   carries both jobs: those finish ~8 us ahead of the actor's); the optimiser launch that follows honours the flag.
     // All eight wavefronts stay: the four that do not run the loss execute its barriers.
     // =========================================================================================
-    __shared__ float S[8 + 2 * MAX_A];
-    __shared__ float s_kl;
-    __shared__ int wait_ok;
+    // (static LDS precedes the dynamic region unpadded: its size stays a multiple of 16 bytes, or every 16-byte LDS
+    // access of the kernel would sit off its natural alignment)
+    __shared__ __attribute__((aligned(16))) float S[8 + 2 * MAX_A + 8];
+    float& s_kl = S[8 + 2 * MAX_A];
+    int& wait_ok = *(int*)&S[8 + 2 * MAX_A + 1];
+    static_assert(sizeof(S) % 16 == 0, "static LDS is a multiple of 16 bytes");
     const PolArgs& p = G.pl;
     const bool policy = J.loss == SMX_EPOCH_LOSS_POLICY;
     const bool adapt = policy && p.mode == SMX_PPO_ADAPT;

@@ -177,6 +177,29 @@ def test_bench_two_ranks_share_one_gpu():
     assert all(np.isfinite(v) for v in out['final_stats'].values())
 
 
+def test_bench_launches_its_own_ranks_and_always_prints_a_line():
+    """`python bench.py --gpus 2` with no launcher around it: over gloo it starts its own two ranks and prints the
+    measurement line; over RCCL on a box with fewer devices than ranks it prints ONE diagnostic line (value null,
+    the reason) and exits cleanly -- first contact with a node never ends in an assert or a hang"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+    r = subprocess.run(cmd, env=dict(env, SMX_BENCH_BACKEND='gloo'), cwd=root, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['exchange'].startswith('peer buffers')
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=120)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+        out = json.loads(lines[0])
+        assert out['value'] is None and 'one device per rank' in out['error'] and out['n_gpus'] == 2
+
+
 # ---- PeerExchange by itself: two processes share the one GPU (the protocol, the bounded spins and graph capture are
 # exercised; NOT the cross-device cache behaviour -- both ranks sit behind one L2 -- which is why PeerExchange.create
 # self-checks against the process group on the real node before the learner uses it) --------------------------------

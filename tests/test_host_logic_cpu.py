@@ -181,3 +181,20 @@ def test_cnn_stem_host_logic_matches_aten_autograd(cpu_double, u8, C, H, W, feat
     for k, v in gp.views.items():
         scale = float(src[k].grad.abs().max())
         np.testing.assert_allclose(v.numpy() / scale, src[k].grad.numpy() / scale, rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_bench_without_devices_prints_one_diagnostic_line():
+    """bench.py --gpus 2 on a host that shows no GPU: one JSON line with value null and the reason, exit code 0"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['HIP_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out['value'] is None and out['n_gpus'] == 2 and 'GPU' in out['error']
