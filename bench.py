@@ -282,6 +282,10 @@ def dominant_kernel(table, family_flops):
     for name, calls, us in table:
         k = _short(name)
         k = k.split('<')[0]
+        if k.startswith('gemm'):
+            k = 'gemm kernels (gemm32 / gemm_rows / gemm_tile: every dense layer)'
+        elif k.startswith('lstm_fwd') or k.startswith('lstm_bwd'):
+            k = k[:8] + ' kernels'
         c, t = fam.get(k, (0, 0.0))
         fam[k] = (c + calls, t + us)
     total = sum(t for _, t in fam.values())
@@ -370,12 +374,20 @@ def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5, cpu=True, cpu_sample
            'epochs': '10+10, KL early exit disabled', 'roofline': priced(dt, flops, bytes_, Bs * Ns, 'env_steps')}
     try:
         rows, steps_all = parts['rows_per_epoch'], parts['steps_all']
-        rec = 2.0 * 4 * F * F                               # the recurrent product of one row-step
-        fam = {'mlp3_rows16_kernel': steps_all * parts['critic_flops_per_row'],
-               'epoch_fb_kernel': 10 * 3 * rows * (parts['actor_flops_per_row'] + parts['critic_flops_per_row']) * (2.0 / 3.0),
-               'lstm_fwd': rec * (steps_all + 22 * rows), 'lstm_bwd': rec * 20 * rows,
-               'conv_u8_fwd': 2.0 * 20 * 20 * 16 * 192 * (steps_all + 22 * rows),
-               'conv_u8_wgrad': 2.0 * 20 * 20 * 16 * 192 * 20 * rows}
+        rec = 2.0 * 4 * F * F if rnn else 0.0               # the recurrent product of one row-step
+        c1, c2 = (2.0 * 20 * 20 * 16 * 192, 2.0 * 9 * 9 * 32 * 256) if pixel else (0.0, 0.0)   # the two convolutions, per frame
+        n_fwd = steps_all + 22 * rows                       # row-steps through the stem forward: critic pass + ref + 11 + 10
+        H1, H2 = HIDDEN
+        fam = {'lstm_fwd': rec * n_fwd, 'lstm_bwd': rec * 20 * rows,
+               'conv_u8_fwd': c1 * n_fwd, 'conv_cl_fwd': c2 * n_fwd, 'conv_u8_wgrad': c1 * 20 * rows,
+               'conv_cl_wgrad': c2 * 20 * rows, 'conv_cl_dgrad': c2 * 20 * rows}
+        if not (rnn or pixel):
+            fam['mlp3_rows16_kernel'] = steps_all * parts['critic_flops_per_row']
+            fam['epoch_fb_kernel'] = 10.0 * rows * (parts['actor_flops_per_row'] + parts['critic_flops_per_row'] +
+                                                    2.0 * (2 * H1 * H2 + H2 * As + H2))
+            fam['gemm'] = 10.0 * rows * (parts['actor_flops_per_row'] + parts['critic_flops_per_row'])   # weight gradients
+        else:
+            fam['gemm'] = flops - sum(fam.values())         # every dense layer (stem input products, the MLPs, the CNN's Linear)
         graph, L.use_graph = L.use_graph, False        # (kernels inside a hipGraph replay are not traced: one eager learn)
         out['dominant_kernel'] = dominant_kernel(kernel_table(lambda: L.learn(db)), fam)
         L.use_graph = graph

@@ -614,6 +614,11 @@ int smx_gather_rows_f32(const float* table, int64_t capacity, int32_t width,
  * (random.randint(0, len-1) per draw in the reference, uniform_replay.py:44-45) */
 int smx_uniform_indices(int64_t* idx, int64_t n, int64_t len, uint64_t seed,
                         uint64_t offset, smx_stream_t stream);
+/* The generator behind it by itself -- Philox4x32-10 (Salmon et al., SC'11) on arbitrary counters and keys:
+ * ctr_key [n, 6] = {ctr0..3, key0, key1} -> out [n, 4].  The sampler's row i uses ctr = (lo32(offset + i),
+ * hi32(offset + i), 0, 0), key = (lo32(seed), hi32(seed)) and idx = mulhi64((out0 << 32) | out1, len).  Exists so that
+ * the device code can be checked against Random123's published known-answer vectors (tests/philox_ref.py). */
+int smx_philox4x32_10(const uint32_t* ctr_key, int64_t n, uint32_t* out, smx_stream_t stream);
 /* UniformReplay.sample (surreal/replay/uniform_replay.py:36-47) over a device-resident replay in ONE launch: the rows
  * idx[i] (or, idx == NULL, the rows smx_uniform_indices(len, seed, offset) would draw -- the same Philox counters) of up
  * to 8 field tables [capacity, row_bytes] -> dst [rows, row_bytes] each.  idx_out (nullable) receives the indices. */

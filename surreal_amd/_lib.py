@@ -242,6 +242,7 @@ _SIGS = {
     'smx_window_emit_bytes': (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'smx_ring_insert_f32': (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_int64, _P]),
     'smx_gather_rows_f32': (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, _P]),
+    'smx_philox4x32_10': (c_int32, [_P, c_int64, _P, _P]),
     'smx_uniform_indices': (c_int32, [_P, c_int64, c_int64, c_uint64, c_uint64, _P]),
     'smx_uniform_gather_multi': (c_int32, [POINTER(GatherJob), c_int32, c_int64, c_int64, _P, c_int64, c_uint64, c_uint64,
                                            _P, _P]),

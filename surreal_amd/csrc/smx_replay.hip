@@ -129,6 +129,21 @@ __global__ __launch_bounds__(256) void uniform_indices_kernel(int64_t* __restric
     idx[i] = (int64_t)__umul64hi(r64, len);
 }
 
+// the generator by itself, for arbitrary counters and keys: the known-answer self-test (Random123's kat_vectors)
+__global__ __launch_bounds__(256) void philox_kat_kernel(const uint32_t* __restrict__ ck, long n, uint32_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c[4] = {ck[6 * i], ck[6 * i + 1], ck[6 * i + 2], ck[6 * i + 3]};
+    uint32_t k0 = ck[6 * i + 4], k1 = ck[6 * i + 5];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[4 * i] = c[0]; out[4 * i + 1] = c[1]; out[4 * i + 2] = c[2]; out[4 * i + 3] = c[3];
+}
+
 __device__ __forceinline__ long philox_index(uint64_t ctr, uint64_t len, uint64_t seed) {
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -489,6 +504,14 @@ extern "C" int smx_gather_rows_f32(const float* table, int64_t capacity, int32_t
     SMX_REQUIRE(capacity > 0 && width > 0 && n > 0, SMX_E_SHAPE);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(row_blocks(n, width)), dim3(256), 0, smx_s(stream), table,
                        (long)capacity, width, idx, (long)n, dst, can_vec(table, dst, width));
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_philox4x32_10(const uint32_t* ctr_key, int64_t n, uint32_t* out, smx_stream_t stream) {
+    SMX_REQUIRE(ctr_key && out, SMX_E_NULL);
+    SMX_REQUIRE(n > 0, SMX_E_SHAPE);
+    hipLaunchKernelGGL(philox_kat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, smx_s(stream), ctr_key, (long)n, out);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

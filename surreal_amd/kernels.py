@@ -481,6 +481,10 @@ class HipKernels(object):
         L.call('smx_uniform_gather_multi', arr, len(tables), cap, rows, L.ptr(idx), int(length), int(seed), int(offset),
                L.ptr(idx_out), self._st())
 
+    def philox4x32_10(self, ctr_key, out):
+        """ctr_key [n, 6] int32 (bit patterns of uint32) -> out [n, 4] int32: the sampler's generator by itself"""
+        L.call('smx_philox4x32_10', L.ptr(ctr_key), ctr_key.shape[0], L.ptr(out), self._st())
+
     def uniform_indices(self, idx, length, seed, offset):
         L.call('smx_uniform_indices', L.ptr(idx), idx.numel(), int(length), int(seed), int(offset),
                self._st())

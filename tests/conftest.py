@@ -47,7 +47,8 @@ def pytest_sessionfinish(session, exitstatus):
         out = os.path.join(ROOT, 'gpurun_out')
         if os.path.isdir(out):
             import json
-            json.dump({k: {'path_vs_fp64': v[0], 'reference_vs_fp64': v[1], 'bound': v[2]} for k, v in arb.items()},
+            json.dump({k: {'path_vs_fp64': v[0], 'reference_vs_fp64': v[1], 'bound': v[2], 'share_of_bound': v[0] / v[2],
+                           'test': v[3] if len(v) > 3 else ''} for k, v in arb.items()},
                       open(os.path.join(out, 'fp64_arbiter_report.json'), 'w'), indent=0)
     rep = helpers.FINAL_PARAM_REPORT
     if not rep:

@@ -84,7 +84,9 @@ def assert_fp64_arbiter(rows, golden_rows, f64_rows, what, floor=LOOSE_RTOL):
             continue
         ours, ref = _max_rel(rows, f64_rows, key), _max_rel(golden_rows, f64_rows, key)
         bound = ARBITER_FACTOR * ref + floor
-        FP64_REPORT['%s %s' % (what, key)] = (ours, ref, bound)
+        cur = FP64_REPORT.get('%s %s' % (what, key))
+        if cur is None or ours / bound > cur[0] / cur[2]:      # several tests run the same case: the WORST one is reported
+            FP64_REPORT['%s %s' % (what, key)] = (ours, ref, bound, os.environ.get('PYTEST_CURRENT_TEST', ''))
         assert ours <= bound, '%s %s: %.3g from the float64 value, the reference is %.3g from it (bound %.3g)' % (
             what, key, ours, ref, bound)
 

@@ -658,6 +658,18 @@ def test_replay_kernels(K):
     assert float(counts.std()) < 3 * np.sqrt(65.5)
     K.uniform_indices(idx, 1000, 1234, 1 << 16)
     assert not torch.equal(idx.cpu(), a)
+    # ... and bit for bit the published generator: Random123's known-answer vectors through the device rounds, then
+    # the sampler's indices against the numpy statement of the same construction (tests/philox_ref.py)
+    import philox_ref as P
+    ck = torch.tensor([list(c) + list(k) for c, k, _ in P.KAT], dtype=torch.int64)
+    out = torch.zeros(len(P.KAT), 4, dtype=torch.int32).cuda()
+    K.philox4x32_10((ck - ((ck >> 31) << 32)).to(torch.int32).cuda(), out)       # (uint32 bit patterns as int32)
+    got = (out.cpu().to(torch.int64) & 0xFFFFFFFF).tolist()
+    assert got == [list(o) for _, _, o in P.KAT], [[hex(x) for x in r] for r in got]
+    for length, seed, offset in ((1000, 1234, 0), (1000000, 0x1234567890ABCDEF, (1 << 40) + 7), (3, 0, 0xFFFFFFFF)):
+        small = torch.empty(512, dtype=torch.int64).cuda()
+        K.uniform_indices(small, length, seed, offset)
+        assert small.cpu().tolist() == P.uniform_indices(512, length, seed, offset).tolist(), (length, seed, offset)
     # window emission: n_step/stride moving window (exp_sender_wrapper.py:209-228)
     src = torch.randn(6, 14, 10, generator=g)
     W = (14 - 5) // 3 + 1

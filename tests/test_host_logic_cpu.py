@@ -198,3 +198,13 @@ def test_bench_without_devices_prints_one_diagnostic_line():
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1000:] + r.stderr[-2000:]
     out = json.loads(lines[0])
     assert out['value'] is None and out['n_gpus'] == 2 and 'GPU' in out['error']
+
+
+def test_philox_restatement_meets_the_random123_known_answer_vectors():
+    """tests/philox_ref.py (the numpy statement of the replay sampler's generator) against Random123's published
+    philox4x32-10 vectors; the GPU tier holds the device code to the same vectors and to this restatement"""
+    import philox_ref as P
+    for ctr, key, want in P.KAT:
+        assert P.philox4x32_10(ctr, key) == want
+    idx = P.uniform_indices(4096, 1000, 1234, 0)
+    assert idx.min() >= 0 and idx.max() < 1000 and len(set(idx.tolist())) > 900
