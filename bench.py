@@ -597,6 +597,46 @@ def secondary_host_fed(iters=12):
         torch.cuda.empty_cache()
     except Exception as e:
         out['experience dicts from CPU agents, aggregated in place by the prefetch thread'] = {'error': repr(e)}
+    # the same with the aggregation spread over worker PROCESSES (the reference's prefetch_processes): every worker fills
+    # its rows of the one staging slot in place -- shared memory, host-registered for DMA (AggregationPool)
+    try:
+        import functools
+        from surreal_amd.distributed import SharedBatchStager, AggregationPool, PooledDataPrefetcher, ppo_aggregate_factory
+        ec = ppo_env_config(D, A)
+        cores = host_cpu()['physical_cores']
+        for W in sorted({min(8, cores), min(16, cores)}):
+            learner, _, _ = build_learner('adapt', torch.cuda.current_device())
+            learner.graph_input_sets = 2
+            example = slice_batch(batch, 0, B)
+            stager = SharedBatchStager(example, depth=2, device=learner.device)
+            pool = AggregationPool(stager, W, synthetic.SyntheticExperienceSource(B, N, D, A, seed0=100),
+                                   functools.partial(ppo_aggregate_factory, ec.obs_spec.to_dict(), ec.action_spec.to_dict()))
+            try:
+                pf = PooledDataPrefetcher(learner.session_config, B, pool)
+                pf.start()
+                for _ in range(4):
+                    learner.learn(pf.get())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    learner.learn(pf.get())
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 10
+                pf.stop()
+                out['experience dicts from CPU agents, aggregated in place by %d worker processes' % W] = {
+                    'ms_per_batch': dt * 1e3, 'env_steps_per_s': B * N / dt, 'workers': W,
+                    'slowest_worker_aggregate_ms': pool.aggregate_s * 1e3,
+                    'staging': 'POSIX shared memory, hipHostRegister-ed; workers write disjoint row ranges'}
+            finally:
+                pool.close()
+                del learner
+                torch.cuda.synchronize()
+                stager.close()
+                torch.cuda.empty_cache()
+    except Exception as e:
+        import traceback
+        out['experience dicts from CPU agents, aggregated in place by worker processes'] = {'error': repr(e),
+                                                                                           'trace': traceback.format_exc()[-800:]}
     out['batch_bytes'] = 4 * (B * N * D + B * D + B * N * A + 2 * B * N + B * N * 2 * A)
     out['pcie_roof'] = {'GBps': 63.0, 'env_steps_per_s': B * N / (out['batch_bytes'] / 63e9)}
     out['what'] = 'pinned double-buffered staging; H2D of batch k + 1 on a copy stream under learn(k); two captured graphs ' \

@@ -242,3 +242,256 @@ class LearnerDataPrefetcher(object):
         self._stop.set()
         if self._thread is not None:
             self._thread.join(2.0)
+
+
+# ======================================================================================================================
+# Several aggregating PROCESSES behind one staging slot (the reference's `prefetch_processes`,
+# surreal/distributed/data_fetcher.py:36-45, learner/base.py:102-110: N worker processes each pull a batch from the
+# replay and run `_prefetcher_preprocess` = the aggregator).
+#
+# What bounds a learner fed by remote CPU agents is not the GPU and not PCIe but the walk over the 131 072 per-step
+# Python objects of a 1024 x 128 batch: 27 ms per batch in ONE process (csrc/host/smx_host.c, GIL held for the walk) =
+# 4.7e6 env-steps/s, against 3.2e7 the PCIe link carries and 1.2e8 the learner ingests.  The walk cannot be threaded
+# (it IS the GIL), so it is spread over processes -- and instead of every worker building a whole batch and shipping
+# it to the learner (the reference: 226 MB per batch through a pipe), every worker fills ITS ROWS of the one staging
+# slot in place: the slot's host buffers live in POSIX shared memory, registered with the HIP runtime in the learner
+# process (hipHostRegister: DMA reads them like hipHostMalloc'ed memory), and the workers receive their experiences from
+# their own data source (a connection to the replay / collector of their own, as in the reference -- here a callable
+# built inside the worker by `source_factory`).  Per batch the learner process sends W small messages and receives W.
+# ======================================================================================================================
+import multiprocessing as _mp
+from multiprocessing import shared_memory as _shm
+
+
+def _tree_spec(example):
+    """[(path, shape, dtype str)] of a batch example: what a worker needs to rebuild numpy views over the shared blocks"""
+    spec = []
+    for path, leaf in _leaves(example):
+        if leaf is None:
+            continue
+        a = leaf.detach().cpu().numpy() if torch.is_tensor(leaf) else np.asarray(leaf)
+        spec.append((path, tuple(a.shape), 'uint8' if a.dtype == np.uint8 else 'float32'))
+    return spec
+
+
+def _views_over(buf, spec):
+    """{path: ndarray} over one shared block laid out leaf after leaf (64-byte aligned)"""
+    out, off = {}, 0
+    for path, shape, dt in spec:
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        out[path] = np.ndarray(shape, dtype=dt, buffer=buf, offset=off)
+        off += (n + 63) & ~63
+    return out
+
+
+def _block_bytes(spec):
+    return sum(((int(np.prod(s)) * np.dtype(d).itemsize) + 63) & ~63 for _, s, d in spec)
+
+
+class SharedBatchStager(PinnedBatchStager):
+    """PinnedBatchStager whose host buffers are POSIX shared-memory blocks (one per slot), host-registered for DMA in
+    this process and attachable by worker processes (`names`, `spec`)."""
+
+    def __init__(self, example, depth=2, device=None):
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.on_gpu = self.device.type == 'cuda'
+        if self.on_gpu and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.depth = depth
+        self.template = example
+        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.spec = _tree_spec(example)
+        nbytes = _block_bytes(self.spec)
+        self.blocks, self.names, self.slots, self.registered = [], [], [], []
+        for _ in range(depth):
+            blk = _shm.SharedMemory(create=True, size=max(nbytes, 64))
+            self.blocks.append(blk)
+            self.names.append(blk.name)
+            views = _views_over(blk.buf, self.spec)
+            host = {p: torch.from_numpy(v) for p, v in views.items()}
+            if self.on_gpu:
+                # DMA-able like hipHostMalloc'ed memory: the H2D copies below run asynchronously at the pinned rate
+                base = np.ndarray((nbytes,), dtype=np.uint8, buffer=blk.buf).ctypes.data
+                rc = torch.cuda.cudart().cudaHostRegister(base, nbytes, 0)
+                if int(rc) != 0:
+                    raise RuntimeError('hipHostRegister of a %d-byte shared block failed (%r)' % (nbytes, rc))
+                self.registered.append(base)
+            dev = {p: (torch.empty(h.shape, dtype=h.dtype, device=self.device) if self.on_gpu else h) for p, h in host.items()}
+            self.slots.append({'host': host, 'dev': dev, 'copied': None, 'consumed': None, 'state': 'free'})
+        self.bytes_per_batch = sum(t.numel() * t.element_size() for t in self.slots[0]['host'].values())
+        self._next = 0
+        self._cv = threading.Condition()
+
+    def close(self):
+        if self.on_gpu:
+            torch.cuda.synchronize()
+            for base in self.registered:
+                torch.cuda.cudart().cudaHostUnregister(base)
+        self.registered = []
+        for s in self.slots:
+            s['host'] = {}
+        self.slots = []
+        for blk in self.blocks:
+            try:
+                blk.close()
+                blk.unlink()
+            except Exception:
+                pass
+        self.blocks = []
+
+
+def _plain_structure(tree):
+    if isinstance(tree, dict):
+        return {k: _plain_structure(v) for k, v in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return [_plain_structure(v) for v in tree]
+    return None if tree is None else 0
+
+
+def ppo_aggregate_factory(obs_spec, action_spec):
+    """picklable aggregate_factory for AggregationPool: functools.partial(ppo_aggregate_factory, obs_spec, action_spec)"""
+    from surreal_amd.learner.aggregator import MultistepAggregatorWithInfo
+    return MultistepAggregatorWithInfo(obs_spec, action_spec).aggregate
+
+
+def _rows(tree, lo, hi):
+    """the [lo, hi) rows of every array of a batch-shaped tree of numpy views"""
+    if isinstance(tree, dict):
+        return type(tree)((k, _rows(v, lo, hi)) for k, v in tree.items())
+    if isinstance(tree, (list, tuple)):
+        return [_rows(v, lo, hi) for v in tree]
+    return None if tree is None else tree[lo:hi]
+
+
+def _aggregation_worker(index, conn, names, spec, template_spec, source_factory, aggregate_factory):
+    """worker process: attach to the slots' shared blocks, then serve (slot, lo, hi, seq) tasks -- pull hi - lo
+    experiences from this worker's own source and aggregate them straight into rows [lo, hi) of the slot"""
+    blocks = []
+    try:
+        import signal
+        signal.signal(signal.SIGINT, signal.SIG_IGN)
+        blocks = [_shm.SharedMemory(name=n) for n in names]
+        views = []
+        for blk in blocks:
+            flat = _views_over(blk.buf, spec)
+            views.append(_rebuild(template_spec, lambda p, leaf: None if leaf is None else flat[p]))
+        source = source_factory(index)
+        aggregate = aggregate_factory()
+        conn.send(('ready', index))
+        while True:
+            task = conn.recv()
+            if task is None:
+                break
+            slot, lo, hi, seq = task
+            t0 = time.time()
+            exps = source(hi - lo, seq, lo)
+            t1 = time.time()
+            aggregate(exps, out=_rows(views[slot], lo, hi))
+            conn.send(('done', index, t1 - t0, time.time() - t1))
+    except EOFError:
+        pass
+    except Exception as e:                  # surfaced by the pool's fill()
+        import traceback
+        try:
+            conn.send(('error', index, traceback.format_exc()))
+        except Exception:
+            pass
+        del e
+    finally:
+        views = None
+        for blk in blocks:
+            try:
+                blk.close()
+            except Exception:
+                pass
+
+
+class AggregationPool(object):
+    """`workers` aggregating processes behind a SharedBatchStager.
+
+    source_factory(worker_index) -> source(n, seq, row_lo) -> list of n experiences (runs INSIDE the worker: its own
+    connection to the replay / collector; must be picklable, i.e. a module-level callable or functools.partial of one)
+    aggregate_factory() -> aggregate(exp_list, out=views) (e.g. functools.partial(make_aggregator, obs_spec, action_spec))
+    """
+
+    def __init__(self, stager, workers, source_factory, aggregate_factory, start_method='spawn'):
+        self.stager = stager
+        self.workers = int(workers)
+        ctx = _mp.get_context(start_method)
+        # the template's STRUCTURE only (plain dicts / lists, None leaves kept): workers rebuild it over their views
+        tmpl = _plain_structure(stager.template)
+        self.conns, self.procs = [], []
+        for w in range(self.workers):
+            a, b = ctx.Pipe()
+            p = ctx.Process(target=_aggregation_worker, args=(w, b, stager.names, stager.spec, tmpl, source_factory,
+                                                              aggregate_factory), daemon=True)
+            p.start()
+            b.close()
+            self.conns.append(a)
+            self.procs.append(p)
+        for c in self.conns:
+            msg = self._recv(c, 120.0)
+            if msg[0] != 'ready':
+                raise RuntimeError('aggregation worker failed to start: %r' % (msg,))
+        self.seq = 0
+        self.source_s = self.aggregate_s = 0.0
+
+    @staticmethod
+    def _recv(conn, timeout):
+        if not conn.poll(timeout):
+            raise TimeoutError('aggregation worker did not answer within %.0f s' % timeout)
+        return conn.recv()
+
+    def fill(self, slot, batch_size, timeout=120.0):
+        """rows [0, batch_size) of `slot`, split evenly over the workers; returns when every worker is done"""
+        W = self.workers
+        cuts = [batch_size * w // W for w in range(W + 1)]
+        for w, c in enumerate(self.conns):
+            c.send((slot, cuts[w], cuts[w + 1], self.seq))
+        self.seq += 1
+        src = agg = 0.0
+        for c in self.conns:
+            msg = self._recv(c, timeout)
+            if msg[0] == 'error':
+                raise RuntimeError('aggregation worker %d failed:\n%s' % (msg[1], msg[2]))
+            src, agg = max(src, msg[2]), max(agg, msg[3])
+        self.source_s, self.aggregate_s = src, agg
+        return slot
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+            except Exception:
+                pass
+        for p in self.procs:
+            p.join(5.0)
+            if p.is_alive():
+                p.terminate()
+        self.conns, self.procs = [], []
+
+
+class PooledDataPrefetcher(LearnerDataPrefetcher):
+    """LearnerDataPrefetcher whose aggregation runs in `pool`'s worker processes: the prefetch thread only hands out
+    row ranges and submits the filled slot for its host-to-device copy"""
+
+    def __init__(self, session_config, batch_size, pool):
+        super().__init__(session_config, batch_size, stager=pool.stager)
+        self.pool = pool
+
+    def run(self):
+        try:
+            if self.stager.on_gpu:
+                torch.cuda.set_device(self.stager.device)
+            while not self._stop.is_set():
+                slot, _ = self.stager.begin_fill()
+                self.pool.fill(slot, self.batch_size)
+                data = ('slot', self.stager.submit(slot))
+                while not self._stop.is_set():
+                    try:
+                        self.preprocess_queue.put(data, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+        except Exception as e:
+            self.error = e

@@ -112,6 +112,10 @@ class Config(dict):
         try:
             return self[name]
         except KeyError:
+            if name.startswith('__') and name.endswith('__'):
+                # protocol look-ups (pickle's __getstate__ / __reduce_ex__, copy's __deepcopy__): not config keys --
+                # a Config travels to worker processes as the dict it is
+                raise AttributeError(name)
             raise ConfigError('config key "%s" missing.' % name)
 
     def update(self, other=None, **kw):

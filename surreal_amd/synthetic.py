@@ -169,3 +169,42 @@ def _ddpg_low_dim(rs, B, D, A):
         'rewards': rs.randn(B, 1).astype(np.float32),
         'dones': (rs.rand(B, 1) < 0.02).astype(np.float32),
     }
+
+
+def ppo_experiences(batch, lo=0, hi=None):
+    """rows [lo, hi) of a make_ppo_batch() batch as the per-step Python objects a collector hands over (SURVEY.md
+    Appendix B.1: lists of per-step observation dicts / action arrays / float rewards / bool dones / [pd] infos)"""
+    ob, obn = batch['obs']['low_dim']['flat_inputs'], batch['obs_next']['low_dim']['flat_inputs']
+    pi = batch['persistent_infos'][0]
+    N = ob.shape[1]
+    hi = ob.shape[0] if hi is None else hi
+    return [{'obs': [{'low_dim': {'flat_inputs': ob[b, s]}} for s in range(N)],
+             'obs_next': {'low_dim': {'flat_inputs': obn[b, 0]}},
+             'actions': [batch['actions'][b, s] for s in range(N)],
+             'rewards': [float(x) for x in batch['rewards'][b]], 'dones': [bool(x) for x in batch['dones'][b]],
+             'persistent_infos': [[pi[b, s]] for s in range(N)], 'onetime_infos': [], 'n_step': N}
+            for b in range(lo, hi)]
+
+
+class SyntheticExperienceSource(object):
+    """picklable source_factory for surreal_amd.distributed.AggregationPool: worker w serves source(n, seq, row_lo) ->
+    rows [row_lo, row_lo + n) of batch `seq % distinct` (seed0 + that), as per-step Python objects.  fresh=True rebuilds
+    the objects on every call from a pickled copy -- what a worker that has just deserialised a chunk from the collector
+    holds -- instead of handing out the same objects again."""
+
+    def __init__(self, B, N, D, A, seed0=100, distinct=1, fresh=False):
+        self.args = (B, N, D, A, seed0, distinct, fresh)
+
+    def __call__(self, worker_index):
+        import pickle
+        B, N, D, A, seed0, distinct, fresh = self.args
+        cache = {}
+
+        def source(n, seq, lo):
+            key = (seq % distinct, lo, n)
+            if key not in cache:
+                batch = make_ppo_batch(B, N, D, A, seed=seed0 + key[0])
+                exps = ppo_experiences(batch, lo, lo + n)
+                cache[key] = pickle.dumps(exps, protocol=4) if fresh else exps
+            return pickle.loads(cache[key]) if fresh else cache[key]
+        return source

@@ -183,3 +183,10 @@ def test_host_fed_learner_pinned_double_buffered_ingest():
     bit-identical to feeding the same batches synchronously"""
     import wire_cases
     wire_cases.check_host_fed_learner(expect_cuda=True)
+
+
+def test_host_fed_learner_aggregation_in_worker_processes():
+    """the host tier's aggregation spread over worker processes that fill disjoint row ranges of ONE shared,
+    host-registered staging slot (body: tests/wire_cases.py)"""
+    import wire_cases
+    wire_cases.check_pooled_host_fed_learner(expect_cuda=True)

@@ -679,3 +679,43 @@ def test_host_fed_learner_through_the_prefetcher(cpu_double):
     the staging slots, slot hand-over, same results as synchronous feeding"""
     import wire_cases
     wire_cases.check_host_fed_learner(expect_cuda=False)
+
+
+def test_aggregation_pool_fills_disjoint_row_ranges_of_one_shared_slot():
+    """three worker PROCESSES aggregate their row ranges of a batch in place, into shared-memory staging
+    (surreal_amd.distributed.AggregationPool; the reference's prefetch_processes, data_fetcher.py:36-45): the slot
+    equals the single-process aggregate of the same experiences, for two consecutive batches on two slots"""
+    import functools
+    from surreal_amd import synthetic
+    from surreal_amd.distributed import SharedBatchStager, AggregationPool, PooledDataPrefetcher, ppo_aggregate_factory
+    from surreal_amd.main.ppo_configs import ppo_env_config, ppo_session_config
+    from surreal_amd.learner.aggregator import MultistepAggregatorWithInfo
+    B, N, D, A = 13, 6, 5, 3
+    ec = ppo_env_config(D, A)
+    agg = MultistepAggregatorWithInfo(ec.obs_spec, ec.action_spec)
+    want = [agg.aggregate(synthetic.ppo_experiences(synthetic.make_ppo_batch(B, N, D, A, seed=40 + k))) for k in range(2)]
+    stager = SharedBatchStager(want[0], depth=2, device='cpu')
+    pool = AggregationPool(stager, 3, synthetic.SyntheticExperienceSource(B, N, D, A, seed0=40, distinct=2, fresh=True),
+                           functools.partial(ppo_aggregate_factory, dict(ec.obs_spec), dict(ec.action_spec)))
+    try:
+        pf = PooledDataPrefetcher(ppo_session_config('/tmp/smx_pool_test'), B, pool)
+        pf.start()
+        for k in range(4):
+            got = pf.get()
+            w = want[k % 2]
+            np.testing.assert_array_equal(got['obs']['low_dim']['flat_inputs'].numpy(), w['obs']['low_dim']['flat_inputs'])
+            np.testing.assert_array_equal(got['obs_next']['low_dim']['flat_inputs'].numpy(), w['obs_next']['low_dim']['flat_inputs'])
+            for name in ('actions', 'rewards', 'dones'):
+                np.testing.assert_array_equal(got[name].numpy(), np.asarray(w[name], dtype=np.float32))
+            np.testing.assert_array_equal(got['persistent_infos'][0].numpy(), w['persistent_infos'][0])
+        pf.stop()
+    finally:
+        pool.close()
+        stager.close()
+
+
+def test_pooled_host_fed_learner_equals_synchronous_feed(cpu_double):
+    """the learner fed by worker processes through the shared staging slot (host tier) -- same results as handing it
+    the batches synchronously"""
+    import wire_cases
+    wire_cases.check_pooled_host_fed_learner(expect_cuda=False, workers=2)

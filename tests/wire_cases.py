@@ -137,3 +137,60 @@ def check_host_fed_learner(expect_cuda):
             assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), 'learn %d: %s %r vs %r' % (i, k, a[k], b[k])
     assert torch.equal(fed.model.flat, plain.model.flat)
     pf.stop()
+
+
+def check_pooled_host_fed_learner(expect_cuda, workers=3):
+    """the aggregation in WORKER PROCESSES (surreal_amd.distributed.AggregationPool: the reference's prefetch_processes,
+    surreal/distributed/data_fetcher.py:36-45): every worker fills its rows of the shared staging slot in place, the
+    learner consumes the device twins -- and ends with exactly the statistics and parameters of a learner handed the
+    same batches synchronously"""
+    import functools
+    from surreal_amd.learner import PPOLearner
+    from surreal_amd.distributed import SharedBatchStager, AggregationPool, PooledDataPrefetcher, ppo_aggregate_factory
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    B, N, D, A, iters = 22, 6, 9, 3, 5
+    lc = ppo_learner_config()
+    lc.algo.n_step = N
+    lc.algo.rnn.if_rnn_policy = False
+    lc.replay.batch_size = B
+    lc.model.actor_fc_hidden_sizes = lc.model.critic_fc_hidden_sizes = [24, 16]
+    ec, sc = ppo_env_config(D, A), ppo_session_config('/tmp/surreal_amd_test_pooled')
+    params = synthetic.make_ppo_params(D, A, hidden=(24, 16), seed=3, final_scale=2.0, log_sig_spread=0.3)
+    zstate = synthetic.make_zfilter_state(D, seed=4)
+
+    def make():
+        learner = PPOLearner(lc, ec, sc)
+        for m in (learner.model, learner.ref_target_model):
+            m.load_params(params)
+            m.z_filter.load_state_dict(zstate)
+        return learner
+    plain, fed = make(), make()
+    batches = [synthetic.make_ppo_batch(B, N, D, A, seed=60 + k) for k in range(3)]
+    want = []
+    for i in range(iters):
+        b = plain.aggregator.aggregate(synthetic.ppo_experiences(batches[i % 3]))
+        want.append(dict(plain.learn(plain._preprocess_batch_ppo(b))))
+    example = fed.aggregator.aggregate(synthetic.ppo_experiences(batches[0]))
+    fed.graph_input_sets = 2
+    stager = SharedBatchStager(example, depth=2, device=fed.device)
+    pool = AggregationPool(stager, workers, synthetic.SyntheticExperienceSource(B, N, D, A, seed0=60, distinct=3, fresh=True),
+                           functools.partial(ppo_aggregate_factory, ec.obs_spec.to_dict(), ec.action_spec.to_dict()))
+    try:
+        pf = PooledDataPrefetcher(sc, B, pool)
+        pf.start()
+        got = []
+        for _ in range(iters):
+            batch = pf.get()
+            x = batch['obs']['low_dim']['flat_inputs']
+            assert torch.is_tensor(x) and x.is_cuda == expect_cuda
+            got.append(dict(fed.learn(batch)))
+        for i, (a, b) in enumerate(zip(got, want)):
+            for k in b:
+                assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), 'learn %d: %s %r vs %r' % (i, k, a[k], b[k])
+        assert torch.equal(fed.model.flat, plain.model.flat)
+        pf.stop()
+    finally:
+        pool.close()
+        if expect_cuda:
+            torch.cuda.synchronize()
+        stager.close()
