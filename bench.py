@@ -604,7 +604,7 @@ def secondary_host_fed(iters=12):
         from surreal_amd.distributed import SharedBatchStager, AggregationPool, PooledDataPrefetcher, ppo_aggregate_factory
         ec = ppo_env_config(D, A)
         cores = host_cpu()['physical_cores']
-        for W in sorted({min(8, cores), min(16, cores)}):
+        for W in sorted({min(8, cores), min(16, cores), min(32, max(1, cores // 2))}):
             learner, _, _ = build_learner('adapt', torch.cuda.current_device())
             learner.graph_input_sets = 2
             example = slice_batch(batch, 0, B)
@@ -617,6 +617,7 @@ def secondary_host_fed(iters=12):
                 for _ in range(4):
                     learner.learn(pf.get())
                 torch.cuda.synchronize()
+                pf.reset_stage_times()
                 t0 = time.perf_counter()
                 for _ in range(10):
                     learner.learn(pf.get())
@@ -626,6 +627,8 @@ def secondary_host_fed(iters=12):
                 out['experience dicts from CPU agents, aggregated in place by %d worker processes' % W] = {
                     'ms_per_batch': dt * 1e3, 'env_steps_per_s': B * N / dt, 'workers': W,
                     'slowest_worker_aggregate_ms': pool.aggregate_s * 1e3,
+                    'prefetch_thread_ms_per_batch': {k: v / max(pf.stage_s['batches'], 1) * 1e3
+                                                     for k, v in pf.stage_s.items() if k != 'batches'},
                     'staging': 'POSIX shared memory, hipHostRegister-ed; workers write disjoint row ranges'}
             finally:
                 pool.close()

@@ -263,6 +263,26 @@ import multiprocessing as _mp
 from multiprocessing import shared_memory as _shm
 
 
+def gpu_local_cpus(device):
+    """the CPUs of the NUMA node the GPU hangs off (sysfs), or None when that cannot be told: staging memory first
+    touched from there is what the GPU's DMA engines read without crossing the socket interconnect"""
+    try:
+        p = torch.cuda.get_device_properties(device)
+        bdf = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        import os
+        cpus &= os.sched_getaffinity(0)
+        return cpus or None
+    except Exception:
+        return None
+
+
 def _tree_spec(example):
     """[(path, shape, dtype str)] of a batch example: what a worker needs to rebuild numpy views over the shared blocks"""
     spec = []
@@ -303,8 +323,15 @@ class SharedBatchStager(PinnedBatchStager):
         self.spec = _tree_spec(example)
         nbytes = _block_bytes(self.spec)
         self.blocks, self.names, self.slots, self.registered = [], [], [], []
+        # first touch decides which NUMA node a page lives on: the blocks are touched HERE, from the GPU's node
+        import os
+        self.local_cpus = gpu_local_cpus(self.device) if self.on_gpu else None
+        prev_aff = os.sched_getaffinity(0) if self.local_cpus else None
+        if self.local_cpus:
+            os.sched_setaffinity(0, self.local_cpus)
         for _ in range(depth):
             blk = _shm.SharedMemory(create=True, size=max(nbytes, 64))
+            np.ndarray((blk.size,), dtype=np.uint8, buffer=blk.buf)[:] = 0
             self.blocks.append(blk)
             self.names.append(blk.name)
             views = _views_over(blk.buf, self.spec)
@@ -318,6 +345,8 @@ class SharedBatchStager(PinnedBatchStager):
                 self.registered.append(base)
             dev = {p: (torch.empty(h.shape, dtype=h.dtype, device=self.device) if self.on_gpu else h) for p, h in host.items()}
             self.slots.append({'host': host, 'dev': dev, 'copied': None, 'consumed': None, 'state': 'free'})
+        if prev_aff:
+            os.sched_setaffinity(0, prev_aff)
         self.bytes_per_batch = sum(t.numel() * t.element_size() for t in self.slots[0]['host'].values())
         self._next = 0
         self._cv = threading.Condition()
@@ -363,14 +392,31 @@ def _rows(tree, lo, hi):
     return None if tree is None else tree[lo:hi]
 
 
-def _aggregation_worker(index, conn, names, spec, template_spec, source_factory, aggregate_factory):
-    """worker process: attach to the slots' shared blocks, then serve (slot, lo, hi, seq) tasks -- pull hi - lo
-    experiences from this worker's own source and aggregate them straight into rows [lo, hi) of the slot"""
-    blocks = []
+_CTL_WORDS = 8          # control block (int64): [0] task sequence number, [1] slot, [2] batch size, [3] stop; then per worker:
+#                         done sequence number | error flag | seconds in source() (float64 bits) | seconds in aggregate()
+
+
+def _aggregation_worker(index, world, conn, names, ctl_name, spec, template_spec, source_factory, aggregate_factory,
+                        cpus=None):
+    """worker process: attach to the slots' shared blocks, then serve tasks posted in the shared control block -- pull
+    this worker's share of the batch from its own source and aggregate it straight into its rows of the slot.  Tasks
+    and completions travel as single stores to shared memory (a pipe message per worker and batch each way costs the
+    dispatching thread ~3 ms per batch at 32 workers -- as much as the aggregation itself); the pipe carries only
+    'ready' and tracebacks."""
+    blocks, ctl_blk = [], None
     try:
         import signal
         signal.signal(signal.SIGINT, signal.SIG_IGN)
+        if cpus:                             # next to the staging memory (and to the GPU): see SharedBatchStager
+            import os
+            try:
+                os.sched_setaffinity(0, cpus)
+            except OSError:
+                pass
         blocks = [_shm.SharedMemory(name=n) for n in names]
+        ctl_blk = _shm.SharedMemory(name=ctl_name)
+        ctl = np.ndarray((_CTL_WORDS + 4 * world,), dtype=np.int64, buffer=ctl_blk.buf)
+        secs = np.ndarray((_CTL_WORDS + 4 * world,), dtype=np.float64, buffer=ctl_blk.buf)
         views = []
         for blk in blocks:
             flat = _views_over(blk.buf, spec)
@@ -378,28 +424,38 @@ def _aggregation_worker(index, conn, names, spec, template_spec, source_factory,
         source = source_factory(index)
         aggregate = aggregate_factory()
         conn.send(('ready', index))
+        last, idle = 0, 0
         while True:
-            task = conn.recv()
-            if task is None:
+            seq = int(ctl[0])
+            if ctl[3]:
                 break
-            slot, lo, hi, seq = task
+            if seq == last:
+                idle += 1
+                time.sleep(0.00005 if idle < 2000 else 0.001)      # (an idle pool backs off to a millisecond)
+                continue
+            idle = 0
+            slot, bs = int(ctl[1]), int(ctl[2])
+            lo, hi = bs * index // world, bs * (index + 1) // world
             t0 = time.time()
-            exps = source(hi - lo, seq, lo)
+            exps = source(hi - lo, seq - 1, lo)
             t1 = time.time()
-            aggregate(exps, out=_rows(views[slot], lo, hi))
-            conn.send(('done', index, t1 - t0, time.time() - t1))
-    except EOFError:
-        pass
-    except Exception as e:                  # surfaced by the pool's fill()
+            if hi > lo:
+                aggregate(exps, out=_rows(views[slot], lo, hi))
+            secs[_CTL_WORDS + 2 * world + index] = t1 - t0
+            secs[_CTL_WORDS + 3 * world + index] = time.time() - t1
+            last = seq
+            ctl[_CTL_WORDS + index] = seq                          # (the completion: one store, after the rows are written)
+    except Exception:                       # surfaced by the pool's fill()
         import traceback
         try:
+            if ctl_blk is not None:
+                np.ndarray((_CTL_WORDS + 4 * world,), dtype=np.int64, buffer=ctl_blk.buf)[_CTL_WORDS + world + index] = 1
             conn.send(('error', index, traceback.format_exc()))
         except Exception:
             pass
-        del e
     finally:
-        views = None
-        for blk in blocks:
+        views = ctl = secs = None
+        for blk in blocks + ([ctl_blk] if ctl_blk is not None else []):
             try:
                 blk.close()
             except Exception:
@@ -411,64 +467,79 @@ class AggregationPool(object):
 
     source_factory(worker_index) -> source(n, seq, row_lo) -> list of n experiences (runs INSIDE the worker: its own
     connection to the replay / collector; must be picklable, i.e. a module-level callable or functools.partial of one)
-    aggregate_factory() -> aggregate(exp_list, out=views) (e.g. functools.partial(make_aggregator, obs_spec, action_spec))
+    aggregate_factory() -> aggregate(exp_list, out=views) (e.g. functools.partial(ppo_aggregate_factory, obs_spec, action_spec))
     """
 
     def __init__(self, stager, workers, source_factory, aggregate_factory, start_method='spawn'):
         self.stager = stager
-        self.workers = int(workers)
+        self.workers = W = int(workers)
         ctx = _mp.get_context(start_method)
         # the template's STRUCTURE only (plain dicts / lists, None leaves kept): workers rebuild it over their views
         tmpl = _plain_structure(stager.template)
+        self.ctl_blk = _shm.SharedMemory(create=True, size=8 * (_CTL_WORDS + 4 * W))
+        self.ctl = np.ndarray((_CTL_WORDS + 4 * W,), dtype=np.int64, buffer=self.ctl_blk.buf)
+        self.secs = np.ndarray((_CTL_WORDS + 4 * W,), dtype=np.float64, buffer=self.ctl_blk.buf)
+        self.ctl[:] = 0
         self.conns, self.procs = [], []
-        for w in range(self.workers):
+        for w in range(W):
             a, b = ctx.Pipe()
-            p = ctx.Process(target=_aggregation_worker, args=(w, b, stager.names, stager.spec, tmpl, source_factory,
-                                                              aggregate_factory), daemon=True)
+            p = ctx.Process(target=_aggregation_worker, args=(w, W, b, stager.names, self.ctl_blk.name, stager.spec, tmpl,
+                                                              source_factory, aggregate_factory,
+                                                              getattr(stager, 'local_cpus', None)), daemon=True)
             p.start()
             b.close()
             self.conns.append(a)
             self.procs.append(p)
         for c in self.conns:
-            msg = self._recv(c, 120.0)
+            if not c.poll(180.0):
+                raise TimeoutError('an aggregation worker did not come up within 180 s')
+            msg = c.recv()
             if msg[0] != 'ready':
-                raise RuntimeError('aggregation worker failed to start: %r' % (msg,))
+                raise RuntimeError('aggregation worker failed to start: %s' % (msg[-1],))
         self.seq = 0
         self.source_s = self.aggregate_s = 0.0
-
-    @staticmethod
-    def _recv(conn, timeout):
-        if not conn.poll(timeout):
-            raise TimeoutError('aggregation worker did not answer within %.0f s' % timeout)
-        return conn.recv()
 
     def fill(self, slot, batch_size, timeout=120.0):
         """rows [0, batch_size) of `slot`, split evenly over the workers; returns when every worker is done"""
         W = self.workers
-        cuts = [batch_size * w // W for w in range(W + 1)]
-        for w, c in enumerate(self.conns):
-            c.send((slot, cuts[w], cuts[w + 1], self.seq))
         self.seq += 1
-        src = agg = 0.0
-        for c in self.conns:
-            msg = self._recv(c, timeout)
-            if msg[0] == 'error':
-                raise RuntimeError('aggregation worker %d failed:\n%s' % (msg[1], msg[2]))
-            src, agg = max(src, msg[2]), max(agg, msg[3])
-        self.source_s, self.aggregate_s = src, agg
+        self.ctl[1], self.ctl[2] = slot, batch_size
+        self.ctl[0] = self.seq                                 # (posted last: the workers act on the sequence number)
+        done, err = self.ctl[_CTL_WORDS:_CTL_WORDS + W], self.ctl[_CTL_WORDS + W:_CTL_WORDS + 2 * W]
+        t0 = time.time()
+        while not (done == self.seq).all():
+            if err.any():
+                for c in self.conns:
+                    if c.poll(0.5):
+                        msg = c.recv()
+                        raise RuntimeError('aggregation worker %d failed:\n%s' % (msg[1], msg[2]))
+                raise RuntimeError('an aggregation worker failed')
+            if time.time() - t0 > timeout:
+                raise TimeoutError('aggregation workers %s did not finish within %.0f s' % (
+                    [int(w) for w in np.nonzero(done != self.seq)[0]], timeout))
+            time.sleep(0.00005)
+        self.source_s = float(self.secs[_CTL_WORDS + 2 * W:_CTL_WORDS + 3 * W].max())
+        self.aggregate_s = float(self.secs[_CTL_WORDS + 3 * W:_CTL_WORDS + 4 * W].max())
         return slot
 
     def close(self):
-        for c in self.conns:
-            try:
-                c.send(None)
-            except Exception:
-                pass
+        if getattr(self, 'ctl', None) is not None:
+            self.ctl[3] = 1
         for p in self.procs:
             p.join(5.0)
             if p.is_alive():
                 p.terminate()
+        for c in self.conns:
+            c.close()
         self.conns, self.procs = [], []
+        self.ctl = self.secs = None
+        if getattr(self, 'ctl_blk', None) is not None:
+            try:
+                self.ctl_blk.close()
+                self.ctl_blk.unlink()
+            except Exception:
+                pass
+            self.ctl_blk = None
 
 
 class PooledDataPrefetcher(LearnerDataPrefetcher):
@@ -479,19 +550,30 @@ class PooledDataPrefetcher(LearnerDataPrefetcher):
         super().__init__(session_config, batch_size, stager=pool.stager)
         self.pool = pool
 
+    def reset_stage_times(self):
+        self.stage_s = {'wait_slot': 0.0, 'fill': 0.0, 'submit': 0.0, 'hand_over': 0.0, 'batches': 0}
+
     def run(self):
         try:
             if self.stager.on_gpu:
                 torch.cuda.set_device(self.stager.device)
+            self.reset_stage_times()
             while not self._stop.is_set():
+                t0 = time.time()
                 slot, _ = self.stager.begin_fill()
+                t1 = time.time()
                 self.pool.fill(slot, self.batch_size)
+                t2 = time.time()
                 data = ('slot', self.stager.submit(slot))
+                t3 = time.time()
                 while not self._stop.is_set():
                     try:
                         self.preprocess_queue.put(data, timeout=0.05)
                         break
                     except queue.Full:
                         pass
+                st = self.stage_s
+                st['wait_slot'] += t1 - t0; st['fill'] += t2 - t1; st['submit'] += t3 - t2; st['hand_over'] += time.time() - t3
+                st['batches'] += 1
         except Exception as e:
             self.error = e
