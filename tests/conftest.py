@@ -50,6 +50,18 @@ def pytest_sessionfinish(session, exitstatus):
             json.dump({k: {'path_vs_fp64': v[0], 'reference_vs_fp64': v[1], 'bound': v[2], 'share_of_bound': v[0] / v[2],
                            'test': v[3] if len(v) > 3 else ''} for k, v in arb.items()},
                       open(os.path.join(out, 'fp64_arbiter_report.json'), 'w'), indent=0)
+    seeds = getattr(helpers, 'FP64_SEED_REPORT', {})
+    if seeds:
+        for k, v in seeds.items():
+            if 'hip' not in v:
+                continue
+            print('fp64 arbiter over %d seeds, %s: HIP worst %.3g (%.0f %% of its bound), median %.3g (%.0f %%); the reference '
+                  'worst %.3g, median %.3g' % (len(v['hip']), k, v['hip_max'], 100 * v['share_max'], v['hip_median'],
+                                               100 * v['share_median'], max(v['reference']), sorted(v['reference'])[len(v['reference']) // 2]))
+        out = os.path.join(ROOT, 'gpurun_out')
+        if os.path.isdir(out):
+            import json
+            json.dump(seeds, open(os.path.join(out, 'fp64_seed_report.json'), 'w'), indent=1)
     rep = helpers.FINAL_PARAM_REPORT
     if not rep:
         return

@@ -20,7 +20,10 @@ if os.environ.get('SMX_DIAG_CPU'):             # dry run of this script on the t
     from surreal_amd import kernels as KN
     from cpu_kernels import TorchCpuKernels
     KN.set_default_kernels(TorchCpuKernels(), 'cpu')
-g, case = H.load_golden(name)
+if name.startswith('seed'):             # a case of tests/golden/fp64_arbiter_seeds.json: python ... seed14
+    case = json.load(open(H.SEEDS_PATH))['seeds'][name[4:]]['case']
+else:
+    g, case = H.load_golden(name)
 case = copy.deepcopy(case)
 case['hyper'].update(epoch_policy=1, epoch_baseline=1, lr_actor=0.0, lr_critic=0.0)
 batch, params, zstate = H.case_inputs(case)

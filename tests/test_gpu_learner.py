@@ -213,3 +213,51 @@ def test_deferred_statistics_equal_the_synchronous_read():
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
     assert torch.equal(a[5], b[5])
     assert a[0][0] != a[0][1]                                                 # three different steps
+
+
+def test_fp64_arbiter_over_seeds_configs3():
+    """BASELINE configs[3] at full size on six seeds (the golden's and five more, tests/golden/fp64_arbiter_seeds.json,
+    each recorded from the REFERENCE'S OWN fp32 learner and from the float64 restatement).  On the extra seeds every
+    loss / KL may be no further from float64 than SEED_LOSS_FACTOR x the reference's own fp32 value is (+ 1e-5; the
+    reference does not reproduce itself to 1e-5 across two x86 hosts on this case -- tests/helpers.py -- while the
+    golden seed's direct 1e-5 comparison stays in test_learner_matches_reference_golden_graph); the gradient norms'
+    distances from float64 are held against the reference's over the same seeds as a distribution
+    (helpers.assert_fp64_seed_distribution)."""
+    doc = json.load(open(H.SEEDS_PATH))
+    g0, case0 = H.load_golden(doc['base'])
+    runs = [(case0, {'policy': json.loads(str(g0['policy_trace_json'])), 'value': json.loads(str(g0['value_trace_json']))},
+             H.FP64['golden'][doc['base']], True)]
+    for seed in sorted(doc['seeds'], key=int):
+        rec = doc['seeds'][seed]
+        runs.append((rec['case'], rec['reference_fp32'], rec['fp64'], False))
+    hip = {'grad_norm_actor': [], 'grad_norm_critic': []}
+    ref = {'grad_norm_actor': [], 'grad_norm_critic': []}
+    worst = {}
+    for case, ref32, f64, golden_seed in runs:
+        batch, params, zstate = H.case_inputs(case)
+        learner = H.make_learner(case, params, zstate)
+        learner.learn(copy.deepcopy(batch))
+        tr = learner.trace
+        assert len(tr['policy']) == len(ref32['policy']) and len(tr['value']) == len(ref32['value'])
+        for which in ('policy', 'value'):
+            for k in ('_surr_loss', '_kl_loss_adapt', '_val_loss', '_pol_kl'):
+                if k not in f64[which][0] or golden_seed:
+                    continue
+                # absolute distances (a surrogate loss sits near zero), the common 1e-5 abs + 1e-5 rel as the floor
+                theirs = max(abs(a[k] - b[k]) for a, b in zip(ref32[which], f64[which]))
+                for e, (a, b) in enumerate(zip(tr[which], f64[which])):
+                    ours, bound = abs(a[k] - b[k]), H.SEED_LOSS_FACTOR * theirs + H.ATOL + H.RTOL * abs(b[k])
+                    w = worst.get(k, (0, 0, 0, ''))
+                    if ours / bound > w[0]:
+                        worst[k] = (ours / bound, ours, theirs, '%s epoch %d' % (case['name'], e))
+                    assert ours <= bound, '%s %s epoch %d: %.3g from float64, the reference at most %.3g (bound %.3g)' % (
+                        case['name'], k, e, ours, theirs, bound)
+        for which, key in (('policy', 'grad_norm_actor'), ('value', 'grad_norm_critic')):
+            hip[key].append(H.seed_distances(tr[which], f64[which], key))
+            ref[key].append(H.seed_distances(ref32[which], f64[which], key))
+        del learner
+        torch.cuda.empty_cache()
+    H.assert_fp64_seed_distribution(hip, ref)
+    for k, (share, ours, theirs, name) in worst.items():
+        H.FP64_SEED_REPORT['loss ' + k] = {'worst_share_of_bound': share, 'hip_vs_fp64': ours, 'reference_vs_fp64': theirs,
+                                            'case': name}
