@@ -58,8 +58,10 @@ class DDPGLearner(Learner):
         # per GPU, ddpg_configs.py:89-93 / SURVEY.md 8(e)); gradients are averaged before each Adam step
         from surreal_amd.learner.ppo import _dist_info
         self._dist, self.world_size, self.rank = _dist_info()
-        self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu' \
-            and self.world_size == 1
+        # several ranks: the iteration is ONE hipGraph too when its exchanges run as kernels over IPC-mapped peer buffers
+        # (PeerExchange, set up and self-checked with the workspace); on the process group (RCCL) the launches stay eager
+        self.use_graph = bool(self.session_config.learner.get('use_hip_graph', True)) and self.device != 'cpu'
+        self.exchange_kind = None
         self._pending_stats = None
         self.lazy_stats = self.device != 'cpu' and bool(self.session_config.learner.get('lazy_stats', True))
         self.clip_actor_gradient = net.clip_actor_gradient
@@ -203,13 +205,38 @@ class DDPGLearner(Learner):
             ws.s_pix = ws.s_pix_next = None              # staged frames (allocated in their dtype)
         ws.graph = None
         self._rank_weight = 1.0
+        ws.xerr = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device != 'cpu' else None
         if self.world_size > 1:            # a rank's share of the global batch: the means are weighted sums
             mine = torch.tensor([B], dtype=torch.int64, device=self.device)
             every = torch.empty(self.world_size, dtype=torch.int64, device=self.device)
             self._dist.all_gather_into_tensor(every, mine)
             self._rank_weight = float(B) / float(sum(every.tolist()))
+            self._setup_peer_exchange(ws)
         self._ws = ws
         return ws
+
+    def _setup_peer_exchange(self, ws):
+        """several ranks on one node: the gradient / statistics all-reduces of an iteration (ddpg.py:244-400 run on
+        shards: SURVEY.md 8(e) "same pattern, 2 grad all-reduces per iteration") as kernels over IPC-mapped peer buffers
+        -- set up and SELF-CHECKED once, collectively; any failure leaves the process group in place and the launches
+        eager.  session_config.learner.peer_exchange = False keeps the process group."""
+        d = self._dist
+        d.err_word = ws.xerr
+        want = bool(self.session_config.learner.get('peer_exchange', True)) and self.device != 'cpu'
+        need = max(64, ws.grads_c.numel(), ws.grads_a.numel(),
+                   ws.grads_p.numel() if self.is_pixel_input else 0,
+                   ws.grads_c2.numel() if self.use_double_critic else 0)
+        if want and (d.exchange is None or d.exchange.capacity < need):
+            if d.exchange is not None:
+                d._d.barrier()
+                d.exchange.close()
+                d.exchange = None
+            from surreal_amd.distributed.peer_exchange import PeerExchange
+            d.exchange = PeerExchange.create(d._d, need, timeout_s=float(self.session_config.learner.get(
+                'peer_exchange_timeout_s', 5.0)))
+        self.exchange_kind = 'peer buffers (%s)' % d.exchange.check_message if d.exchange is not None else 'process group'
+        if d.exchange is None:
+            self.use_graph = False            # process-group collectives are not captured
 
     def _critic_backward(self, ws, x, B, model=None, dz3=None, xcat=None, h2c=None, gc=None):
         """gradients of a critic's parameters from dz3 (dLoss/dQ; default: the first critic's
@@ -486,8 +513,12 @@ class DDPGLearner(Learner):
             return self._decode_stats(ws.stats.cpu(), ws.stats2.cpu() if self.use_double_critic else None)
         self._flush_stats()
         if getattr(ws, 'stats_host', None) is None:
-            ws.stats_host = torch.empty(2, 8, pin_memory=True)
+            ws.stats_host = torch.empty(3, 8, pin_memory=True)
         ws.stats_host[0].copy_(ws.stats, non_blocking=True)
+        if ws.xerr is not None and self.world_size > 1:      # a peer exchange that timed out in this iteration
+            ws.stats_host[2, :1].view(torch.int32).copy_(ws.xerr, non_blocking=True)
+        else:
+            ws.stats_host[2].zero_()
         if self.use_double_critic:
             ws.stats_host[1].copy_(ws.stats2, non_blocking=True)
         ev = torch.cuda.Event()
@@ -501,6 +532,10 @@ class DDPGLearner(Learner):
         if pend is not None:
             ev, host, handle = pend
             ev.synchronize()
+            if int(host[2, :1].view(torch.int32)[0]) != 0:
+                raise RuntimeError('a peer exchange timed out in the last DDPG iteration: error word 0x%x (0x100 | phase << 4 '
+                                   '| peer) -- a rank died or fell behind by more than the timeout'
+                                   % (int(host[2, :1].view(torch.int32)[0]) & 0xffff))
             handle._value = self._decode_stats(host[0], host[1] if self.use_double_critic else None)
 
     def _decode_stats(self, st, st2):

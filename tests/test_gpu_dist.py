@@ -9,6 +9,7 @@ sub-trajectories and must reproduce the single reference learner's golden trace.
 import copy
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -148,6 +149,91 @@ def test_three_ranks_with_different_block_counts_hip(name):
     """37 sub-trajectories cut 5 | 20 | 12: 1, 2 and 1 sixteen-row loss blocks per rank (the loss-partial rows a
     rank does not own are cleared before every exchange)"""
     _run_ranks(name, 3, cuts=[0, 5, 25, 37])
+
+
+def _ddpg_worker(rank, world, port, name, q, overrides):
+    try:
+        import torch.distributed as dist
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+        from surreal_amd import synthetic
+        import ddpg_helpers as DH
+        g, case = DH.load(name)
+        B = case['B']
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        local = copy.deepcopy(case)
+        local['B'] = hi - lo
+        L = DH.make_learner(local)
+        for k, v in (overrides or {}).items():
+            L.session_config.learner[k] = v
+        assert L.world_size == world and str(L.device).startswith('cuda')
+        trace = []
+        for it in range(case['iters']):
+            b = synthetic.make_ddpg_batch(B, case['D'], case['A'], seed=10 + it)
+
+            def cut(x):
+                if isinstance(x, dict):
+                    return {k: cut(v) for k, v in x.items()}
+                return x[lo:hi]
+            trace.append(dict(L.learn(cut(b))))
+        q.put((rank, {'trace': trace, 'params': L.model.numpy_params(), 'target': L.model_target.numpy_params(),
+                      'exchange': L.exchange_kind, 'graph': L._ws.graph is not None}))
+        dist.barrier()
+        if L._dist.exchange is not None:
+            L._dist.exchange.close()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+
+
+@pytest.mark.parametrize('name,peer', [('cfg3_cheetah512', True), ('tiny_hard', True), ('cfg3_cheetah512', False)])
+def test_two_rank_hip_ddpg_equals_single_learner(name, peer):
+    """data-parallel DDPG on the HIP kernels (surreal/learner/ddpg.py:244-400 run on two shards of every batch): the
+    gradients and the reported means are all-reduced before each Adam step -- as kernels over the peer buffers INSIDE
+    the one captured graph of the iteration (peer=True), or eagerly on the process group (peer=False) -- and two ranks
+    reproduce the single reference learner's trace with bit-identical replicas"""
+    import json
+    import ddpg_helpers as DH
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddpg_worker, args=(r, world, port, name, q, None if peer else {'peer_exchange': False}))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=240)
+            res[r] = out
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    for r in range(world):
+        assert 'error' not in res[r], res[r].get('error')
+    g, case = DH.load(name)
+    ref = json.loads(str(g['trace_json']))
+    for r in range(world):
+        if peer:
+            assert res[r]['exchange'].startswith('peer buffers') and res[r]['graph'], (res[r]['exchange'], res[r]['graph'])
+        else:
+            assert res[r]['exchange'] == 'process group' and not res[r]['graph']
+        for it, want in enumerate(ref):
+            for k, v in want.items():
+                np.testing.assert_allclose(res[r]['trace'][it][k], v, atol=2e-5, rtol=2e-5,
+                                           err_msg='%s rank %d iteration %d %s' % (name, r, it, k))
+    for k in res[0]['params']:
+        np.testing.assert_array_equal(res[0]['params'][k], res[1]['params'][k])
+        np.testing.assert_array_equal(res[0]['target'][k], res[1]['target'][k])
+        if 'final.' + k in g:
+            assert np.mean(np.abs(res[0]['params'][k] - g['final.' + k]) > 2e-5) < 0.03, k
 
 
 def test_bench_two_ranks_share_one_gpu():
