@@ -868,7 +868,12 @@ int smx_flatten_order_f32(const float* in, int32_t O, int32_t C, int32_t P,
  * sampling, dynamics, recording and the z-filter use the expressions of smx_synth_act_env_step_f32.
  * eps [steps, n, A] standard normals (NULL: deterministic); zsum/zsumsq/zcount: the z-filter's running sums (NULL:
  * raw observations); rolls [n, rows_per_actor, .] (any may be NULL); state [n, D] is read at the start and left at
- * the state after the last step; t: the episode clock at the first step. */
+ * the state after the last step; t: the episode clock at the first step.
+ * obs_last [n, D] (nullable): where the observation AFTER row rows_per_actor - 1 goes.  With rows_per_actor = steps + 1
+ * (a rollout table) that observation is the table's last row and obs_last is not used; with rows_per_actor = steps the
+ * tables have exactly the replay's layout -- obs [n, n_step, D] + obs_next [n, 1, D] = obs_last -- and the rollout is
+ * recorded STRAIGHT INTO the FIFO's slots when stride == n_step (env/exp_sender_wrapper.py:209-228: a window then is
+ * the rollout; no window cut, no insert copy). */
 typedef struct smx_synth_rollout {
     const smx_mlp3_t* net;
     const float* packed;
@@ -888,6 +893,7 @@ typedef struct smx_synth_rollout {
     float* rew_roll;
     float* done_roll;
     float* pd_roll;
+    float* obs_last;
 } smx_synth_rollout_t;
 int32_t smx_synth_rollout_supported(int32_t D, int32_t H1, int32_t H2, int32_t A);
 int smx_synth_rollout_f32(const smx_synth_rollout_t* args, smx_stream_t stream);

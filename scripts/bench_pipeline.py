@@ -26,12 +26,13 @@ sys.path.insert(0, ROOT)
 
 
 def run_pipeline(actors=1024, steps=128, obs_dim=376, action_dim=17, iters=10, warmup=3, graph=True, fused_step=True,
-                 copies=False, cpu_double=False, learn_batch=1024, pixel=None, frame_stacks=1, rnn=False, overlap=False):
+                 copies=False, cpu_double=False, learn_batch=1024, pixel=None, frame_stacks=1, rnn=False, overlap=False,
+                 no_zero_copy=False):
     """-> the result dict main() prints (also called by bench.py for its `secondary` entry)"""
     args = argparse.Namespace(actors=actors, steps=steps, obs_dim=obs_dim, action_dim=action_dim, iters=iters,
                               warmup=warmup, graph=graph, fused_step=fused_step, copies=copies,
                               cpu_double=cpu_double, learn_batch=learn_batch, pixel=pixel, frame_stacks=frame_stacks,
-                              rnn=rnn, overlap=overlap)
+                              rnn=rnn, overlap=overlap, no_zero_copy=no_zero_copy)
     return _run(args)
 
 
@@ -53,6 +54,7 @@ def main():
                     help='camera frames (uint8) next to the low-dim state: the CNN-stem policy (configs[3]: 3 84 84)')
     ap.add_argument('--frame-stacks', type=int, default=1, help='frames the policy sees, stacked on the channel axis')
     ap.add_argument('--rnn', action='store_true', help='LSTM-stem policy (the reference default)')
+    ap.add_argument('--no-zero-copy', action='store_true', help='rollout -> window cut -> FIFO as separate launches')
     ap.add_argument('--overlap', action='store_true',
                     help='actors one rollout ahead of the learner: rollout k + 1 on a second stream while learn k runs '
                          '(how the reference runs: agents keep acting on the parameters they last fetched)')
@@ -83,6 +85,7 @@ def _run(args):
     cam = (args.frame_stacks * args.pixel[0], args.pixel[1], args.pixel[2]) if args.pixel else None   # what the policy sees
     ec, sc = ppo_env_config(D, A, pixel=cam), ppo_session_config()
     learner = PPOLearner(lc, ec, sc)
+    learner.graph_input_sets = 2 * max(1, n // LB)      # the FIFO hands out batches from two alternating row ranges
     agent = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')
     agent.attach_learner(learner)
     agent.fetch_parameter()
@@ -119,15 +122,31 @@ def _run(args):
 
     to_batch = venv.to_batch
     use_graph = bool(args.graph) and not stem        # (the stem path allocates per step: eager launches)
+    # stride == n_step: a window is the rollout -- the one-launch kernel records straight into the FIFO's slots
+    # (SyntheticVecEnv.rollout_into): no window cut, no insert copy, the learner pops views
+    zero_copy = bool(args.fused_step) and not args.copies and not stem and not args.no_zero_copy and venv.can_rollout_into(agent)
+
+    def rollout_to_fifo():
+        slots = replay.reserve_batch(n, venv.window_shapes(T))
+        if slots is None:
+            return False
+        venv.reset()
+        venv.rollout_into(agent, slots)
+        replay.commit_batch(n)
+        return True
 
     def iteration(times=None):
         t0 = time.perf_counter()
-        rollout()
+        direct = zero_copy and rollout_to_fifo()
+        if not direct:
+            rollout()
         if times is not None:
             sync()
         t1 = time.perf_counter()
-        slots = None if (args.copies or stem) else replay.reserve_batch(n, venv.window_shapes(T))
-        if slots is not None:                  # windows are cut straight into the FIFO table
+        slots = None if (args.copies or stem or direct) else replay.reserve_batch(n, venv.window_shapes(T))
+        if direct:
+            pass
+        elif slots is not None:                  # windows are cut straight into the FIFO table
             venv.emit_windows(T, T, out=slots)
             replay.commit_batch(n)
         else:
@@ -151,7 +170,7 @@ def _run(args):
             times.append((t1 - t0, t2 - t1, t3 - t0 - (t1 - t0) - (t2 - t1)))
 
     iteration()
-    if use_graph and not args.cpu_double:
+    if use_graph and not args.cpu_double and not zero_copy:
         import gc
         sync()
         venv.reset()
@@ -182,6 +201,22 @@ def _run(args):
 
         def iteration(times=None):                  # noqa: F811
             main_s = torch.cuda.current_stream()
+            if zero_copy:
+                # rollout k sits in the FIFO already; rollout k + 1 goes into the NEXT slots on the side stream while
+                # the learner pops and learns rollout k
+                side.wait_stream(main_s)
+                batches = [replay.sample_batch(LB, copy=False) for _ in range(n // LB)]
+                with torch.cuda.stream(side):
+                    ok = rollout_to_fifo()
+                    assert ok, 'the FIFO must hold two rollouts (memory_size >= 2 * actors)'
+                for b in batches:
+                    learner.learn(to_batch(b))
+                main_s.wait_stream(side)
+                agent.fetch_parameter()
+                if times is not None:
+                    sync()
+                    times.append((0.0, 0.0, 0.0))
+                return
             slots = None if (args.copies or stem) else replay.reserve_batch(n, venv.window_shapes(T))
             if slots is not None:
                 venv.emit_windows(T, T, out=slots)
@@ -198,7 +233,10 @@ def _run(args):
             if times is not None:
                 sync()
                 times.append((0.0, 0.0, 0.0))
-        rollout()                                   # rollout 0: the pipeline's fill
+        if zero_copy:
+            assert rollout_to_fifo()                # rollout 0: the pipeline's fill
+        else:
+            rollout()                               # rollout 0: the pipeline's fill
     for _ in range(args.warmup):
         iteration()
     sync()
@@ -216,6 +254,7 @@ def _run(args):
            'config': {'actors': n, 'steps_per_rollout': T, 'obs_dim': D, 'action_dim': A, 'learn_batch': LB,
                       'learns_per_rollout': n // LB, 'rollout_graph': graph is not None,
                       'fused_step': bool(args.fused_step), 'overlap': bool(args.overlap), 'rnn': bool(args.rnn),
+                      'rollout_into_fifo_slots': bool(zero_copy),
                       'pixel': list(args.pixel) if args.pixel else None, 'frame_stacks': args.frame_stacks},
            'stage_ms_synchronised': {'rollout': st[0] * 1e3, 'windows+fifo': st[1] * 1e3, 'learn': st[2] * 1e3},
            'rollout_env_steps_per_s': n * T / st[0] if st[0] > 0 else None}

@@ -129,7 +129,7 @@ class SynthRollout(Structure):
                 ('zsumsq', c_void_p), ('zcount', c_void_p), ('zeps', c_float), ('t', c_int32),
                 ('episode_len', c_int32), ('steps', c_int32), ('rows_per_actor', c_int32), ('slot', c_int32),
                 ('state', c_void_p), ('init_state', c_void_p), ('obs_roll', c_void_p), ('act_roll', c_void_p),
-                ('rew_roll', c_void_p), ('done_roll', c_void_p), ('pd_roll', c_void_p)]
+                ('rew_roll', c_void_p), ('done_roll', c_void_p), ('pd_roll', c_void_p), ('obs_last', c_void_p)]
 
 
 class Xchg(Structure):

@@ -45,7 +45,7 @@ struct RollArgs {
     float* state;                               // [n, D] in / out
     const float* init_state;
     int n, t0, episode_len, steps, R, slot0;    // R = rows per actor in the rollout tables
-    float *obs_roll, *act_roll, *rew_roll, *done_roll, *pd_roll;
+    float *obs_roll, *act_roll, *rew_roll, *done_roll, *pd_roll, *obs_last;
     int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_act, off_z, lds_floats;
 };
 
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
                         if (orow) {
                             orow[k] = s;
                             if (slot + 1 < R) orow[D + k] = sn;
+                            else if (G.obs_last) G.obs_last[a * D + k] = sn;     // (the replay's obs_next field)
                         }
                         if (i == 0) sn0 = sn;
                         const float next = done ? G.init_state[a * D + k] : sn;
@@ -311,7 +312,7 @@ extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t 
     G.state = a->state; G.init_state = a->init_state;
     G.n = a->n; G.t0 = a->t; G.episode_len = a->episode_len; G.steps = a->steps; G.R = a->rows_per_actor; G.slot0 = a->slot;
     G.obs_roll = a->obs_roll; G.act_roll = a->act_roll; G.rew_roll = a->rew_roll; G.done_roll = a->done_roll;
-    G.pd_roll = a->pd_roll;
+    G.pd_roll = a->pd_roll; G.obs_last = a->obs_last;
     int lds = carve(G);
     // one workgroup per CU: each keeps the four matrix pipes of a CU busy by itself
     if (lds < ROLL_EXCLUSIVE_LDS) lds = ROLL_EXCLUSIVE_LDS;

@@ -225,6 +225,36 @@ class SyntheticVecEnv(object):
             self.slot += 1
             self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
 
+    def can_rollout_into(self, agent):
+        """rollout_into() needs the one-launch kernel: a plain-MLP policy whose shapes it takes"""
+        return (self.persistent and self.pixel is None and not agent.rnn_config.if_rnn_policy and not agent.model.if_pixel
+                and self.K.synth_rollout_supported(agent.model.actor))
+
+    def rollout_into(self, agent, out, eps=None):
+        """A whole rollout recorded STRAIGHT INTO a replay's slots (Replay.reserve_batch(n, window_shapes(T)) ->
+        `out`: obs [n, T, D], obs_next [n, 1, D], actions [n, T, A], rewards / dones [n, T], pds [n, T, 2A]): with
+        stride == n_step == T the moving-window rule (exp_sender_wrapper.py:209-228) makes the one window of an actor
+        its rollout, so nothing is cut and nothing is copied -- the one-launch kernel writes the fields where the
+        learner will read them.  Starts at an episode boundary (reset() first), like start_rollout()."""
+        K, n = self.K, self.n
+        T = out['obs'].shape[1]
+        assert self.t == 0 and T <= self.episode_len and self.can_rollout_into(agent)
+        assert tuple(out['obs'].shape) == (n, T, self.D) and all(out[k].is_contiguous() for k in out)
+        deterministic = agent.agent_mode in ('eval_deterministic', 'eval_deterministic_local')
+        if eps is None and not deterministic:
+            eps = torch.randn(T, n, self.A, device=self.device)
+        actor = agent.model.actor
+        if getattr(self, '_pk', None) is None or self._pk.numel() != K.epoch_packed_numel(actor):
+            self._pk = torch.zeros(K.epoch_packed_numel(actor), device=self.device)
+        K.epoch_pack([(actor, self._pk)])
+        rolls = {'obs': out['obs'], 'actions': out['actions'], 'rewards': out['rewards'], 'dones': out['dones'],
+                 'pds': out['pds'], 'obs_last': out['obs_next']}
+        K.synth_rollout(actor, self._pk, L.SMX_ACT_TANH, self.state, self.init_state, agent.model.log_var.view(-1),
+                        agent.batch_noise(n).view(-1), None if deterministic else eps.contiguous(), self.t,
+                        self.episode_len, T, 0, rolls, agent.model.z_filter if agent.use_z_filter else None)
+        for _ in range(T):
+            self.t = 0 if self.t + 1 >= self.episode_len else self.t + 1
+
     def _rollout_stem(self, agent, eps):
         """policies with an LSTM and / or CNN stem: one batched act per step (PPOAgent.act_batch: the stem and the
         MLP for all actors at once) on the stacked observation, then the step launch; the LSTM state every actor

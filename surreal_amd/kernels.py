@@ -577,6 +577,7 @@ class HipKernels(object):
         p.state, p.init_state = L.ptr(state), L.ptr(init_state)
         p.obs_roll, p.act_roll = L.ptr(r.get('obs')), L.ptr(r.get('actions'))
         p.rew_roll, p.done_roll, p.pd_roll = L.ptr(r.get('rewards')), L.ptr(r.get('dones')), L.ptr(r.get('pds'))
+        p.obs_last = L.ptr(r.get('obs_last'))          # rows_per_actor == steps: the replay's layout (obs_next apart)
         L.call('smx_synth_rollout_f32', ctypes.byref(p), self._st())
 
     def synth_env_step(self, state, init_state, actions, t, episode_len, slot, obs_roll, act_roll,

@@ -73,6 +73,12 @@ class FIFOReplay(Replay):
         fields = {k: torch.empty((0,) + tuple(shp), dtype=dtypes.get(k, torch.float32)) for k, shp in shapes.items()}
         tables = self._ensure_tables(cap, fields)
         tail = (self._head + self._count) % cap
+        if tail + n > cap and self._count == 0 and n <= cap:
+            # an EMPTY ring whose next rows would wrap: start over at row 0 (nothing is stored, so nothing moves; views
+            # popped earlier than the most recent pop must no longer be in use -- a learner consumes a pop before the
+            # next one).  A producer / consumer pair that moves whole batches then alternates between two fixed row
+            # ranges: two address sets, two captured graphs, no staging copy.
+            self._head = tail = 0
         if n > cap - self._count or tail + n > cap:
             return None
         return {name: tables[name].rows(tail, n) for name in shapes}

@@ -1359,3 +1359,45 @@ def test_persistent_rollout_kernel(K, n, D, A, hidden, T, ep, use_z, det):
     assert float(one['pds'].abs().sum()) > 0 and float(one['obs'][:, T].abs().sum()) > 0
     if ep < T:
         assert float(one['dones'][:, :T].sum()) == n * (T // ep)
+
+
+@pytest.mark.parametrize('n,D,A,hidden,T', [(37, 11, 3, (24, 16), 9), (32, 376, 17, (300, 200), 6)])
+def test_rollout_recorded_straight_into_the_replay_slots(K, n, D, A, hidden, T):
+    """stride == n_step: a window IS the rollout (exp_sender_wrapper.py:209-228), so the one-launch rollout kernel
+    records straight into the FIFO's reserved slots (SyntheticVecEnv.rollout_into: tables without the extra row, the
+    observation after the last step into obs_next) -- bit for bit what rollout -> window cut -> insert leaves in the
+    replay, and what the learner pops as views"""
+    from surreal_amd.env import SyntheticVecEnv
+    from surreal_amd.replay import FIFOReplay
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    agent, _ = _rollout_setup(n, D, A, hidden, T, T, True, False, seed=21)
+    eps = torch.randn(T, n, A, generator=torch.Generator().manual_seed(5)).cuda()
+    lc = ppo_learner_config()
+    lc.algo.n_step = lc.algo.stride = T
+    lc.replay.batch_size, lc.replay.memory_size = n, 2 * n
+    ec, sc = ppo_env_config(D, A), ppo_session_config('/tmp/surreal_amd_test_rollout_into')
+
+    def three_launch_path():
+        venv = SyntheticVecEnv(n, D, A, episode_len=T, seeds=list(range(n)))
+        venv.start_rollout(T, info_width=2 * A)
+        venv.rollout(agent, eps=eps)
+        replay = FIFOReplay(lc, ec, sc)
+        replay.insert_batch(venv.emit_windows(T, T))
+        return replay.sample_batch(n), venv.state.clone(), venv.t
+
+    def zero_copy_path():
+        venv = SyntheticVecEnv(n, D, A, episode_len=T, seeds=list(range(n)))
+        venv.start_rollout(T, info_width=2 * A)            # (for window_shapes; its tables stay untouched)
+        assert venv.can_rollout_into(agent)
+        replay = FIFOReplay(lc, ec, sc)
+        slots = replay.reserve_batch(n, venv.window_shapes(T))
+        venv.rollout_into(agent, slots, eps=eps)
+        replay.commit_batch(n)
+        assert float(venv.rolls['obs'].abs().sum()) == 0.0
+        return replay.sample_batch(n, copy=False), venv.state.clone(), venv.t
+    (a, sa, ta), (b, sb, tb) = three_launch_path(), zero_copy_path()
+    torch.cuda.synchronize()
+    assert set(a) == set(b) and ta == tb and torch.equal(sa, sb)
+    for k in a:
+        assert torch.equal(a[k].reshape(b[k].shape), b[k]), k
+    assert float(b['obs_next'].abs().sum()) > 0 and float(b['pds'].abs().sum()) > 0
