@@ -20,9 +20,13 @@ RTOL = 1e-5
 # of cfg5_clip (2.9e-5 relative; the fp64 value is 3.7922557), because one ReLU pre-activation
 # that lands within fp32 rounding of zero flips its mask and with it that row's contribution
 # to the layer-1/2 gradients (measured with tests/diag/diag_inputs.py / diag_theta1.py; the HIP
-# path reproduces the GPU-box host value to 1.3e-7).  They get a 2e-4 relative bound.
+# path's fused schedule reproduces the GPU-box host value to 1.3e-7).  The size of ONE such flip
+# depends on the row it hits: 2.9e-5 there, 1.9e-4 on the same golden under the layered
+# (one-launch-per-layer) schedule, whose summation order flips a different unit
+# (gpurun_out/fp64_arbiter_report.json names the test).  The bound is two flips of the larger
+# measured size: 4e-4 relative (round 3 had 2e-4 = 1.07 x the larger one).
 LOOSE_KEYS = ('grad_norm_actor', 'grad_norm_critic')
-LOOSE_RTOL = 2e-4
+LOOSE_RTOL = 4e-4
 
 
 # ---- the fp64 arbiter (oracle/gen_golden_fp64.py -> tests/golden/fp64_arbiter.json) ------------------------------
