@@ -522,7 +522,7 @@ int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const str
  * terms are still in LDS.  The batch means the adapt loss needs (c_kl = beta + 2 eta max(0, KL - 2 kl_target),
  * ppo.py:272-276) travel INSIDE the launch: every actor workgroup stores its block's KL sum together with a "there"
  * bit as ONE 8-byte device-scope word (kl_slots[block]), multiplies both right-hand sides (g_surr / n, g_kl / n)
- * through the output layer meanwhile, then reads the slots of all blocks (bounded wait: 2 s, then ctrl->reserved[1]
+ * through the output layer meanwhile, then reads the slots of all blocks (bounded wait: 0.25 s, then ctrl->reserved[1]
  * is raised and the optimiser launch skips its step), adds them in a fixed order and continues with
  * dz2 = (W3^T g_surr + c_kl W3^T g_kl) * relu'(h2) -- the combination is formed one layer later than
  * smx_epoch_backward_f32 forms it (rounding differs in the last bit, the contract is the same).  Clip mode: no
@@ -533,7 +533,9 @@ int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const str
  * Jobs: SMX_EPOCH_LOSS_POLICY (at most one) and / or SMX_EPOCH_LOSS_VALUE, fields as for the two calls it
  * replaces.  sync_word: one int32 per launch; kl_slots: smx_epoch_blocks(rows of the policy job) 8-byte words per
  * launch; both zero on entry (the caller clears them once per learn).
- * smx_epoch_fwdbwd_supported: smx_epoch_supported and H2 <= 384 and the larger LDS carve-up fits. */
+ * smx_epoch_fwdbwd_supported: smx_epoch_supported and H2 <= 384 and the larger LDS carve-up fits.
+ * Adapt mode needs every actor workgroup of the launch resident at once (one per CU): a launch with more workgroups than
+ * the device has CUs runs as smx_epoch_forward_f32 + smx_epoch_backward_f32 (two launches, same results). */
 int32_t smx_epoch_fwdbwd_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
 int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
                          smx_ppo_ctrl_t* ctrl, int64_t n_total, int32_t* sync_word, uint64_t* kl_slots,

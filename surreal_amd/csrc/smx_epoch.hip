@@ -510,7 +510,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
             const long long t0 = (long long)wall_clock64();
             int okw = 1;
             while (__hip_atomic_load(G.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbp) {
-                if ((long long)wall_clock64() - t0 > 200000000LL) { okw = 0; break; }     // 2 s (100 MHz): a lost workgroup
+                if ((long long)wall_clock64() - t0 > 25000000LL) { okw = 0; break; }     // 0.25 s (100 MHz): a lost workgroup
                 __builtin_amdgcn_s_sleep(1);
             }
             wait_ok = okw;
@@ -529,7 +529,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
             for (int b = tid; b < nbp; b += 64) {
                 unsigned long long w;
                 while (((w = __hip_atomic_load(G.kl_slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0ull) {
-                    if ((long long)wall_clock64() - t0 > 200000000LL) { okw = 0; break; }    // 2 s (100 MHz): a lost workgroup
+                    if ((long long)wall_clock64() - t0 > 25000000LL) { okw = 0; break; }    // 0.25 s (100 MHz): a lost workgroup
                     __builtin_amdgcn_s_sleep(1);
                 }
                 t += __uint_as_float((unsigned)w);
@@ -1183,6 +1183,9 @@ extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs,
     return SMX_OK;
 }
 
+extern "C" int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
+                                      smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream);
+
 extern "C" int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, const smx_ppo_losses_t* loss,
                                     smx_ppo_ctrl_t* ctrl, int64_t n_total, int32_t* sync_word, uint64_t* kl_slots,
                                     smx_stream_t stream) {
@@ -1203,6 +1206,27 @@ extern "C" int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, 
             ++n_policy;
         }
     SMX_REQUIRE(n_policy <= 1, SMX_E_SHAPE);       // one counter, one set of partial rows
+    {
+        // Adapt mode: every actor workgroup waits for the KL sums of ALL actor workgroups, so all of them must be
+        // resident at once -- one per CU (the launch asks for more than half of a CU's LDS).  A launch with more
+        // workgroups than CUs (more than 16 x CUs rows) would wait for workgroups that cannot start:
+        // it runs as the two launches it would replace (same results, the batch means cross a launch boundary).
+        // Clip mode never waits inside the launch except in the grid's LAST workgroup, which is dispatched after
+        // every other one: safe at any size.
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 64;
+        }
+        const EJob& Lj0 = G.j[njobs - 1];
+        const int blocks0 = Lj0.blk_base + smx_epoch_blocks(Lj0.rows);
+        if (n_policy && loss->mode == SMX_PPO_ADAPT && blocks0 > n_cu) {
+            const int rc = smx_epoch_forward_f32(jobs, njobs, loss, ctrl, n_total, stream);
+            if (rc) return rc;
+            return smx_epoch_backward_f32(jobs, njobs, loss, ctrl, n_total, stream);
+        }
+    }
     G.sync = (int*)sync_word;
     G.kl_slots = (unsigned long long*)kl_slots;
     for (int k = 0; k < njobs; ++k)

@@ -160,8 +160,10 @@ def _fb_pair(K, rows, D, H1, H2, A, mode, seed, kl_target=1e9, launches=1):
     return out
 
 
+# (4500 rows: 282 + 282 workgroups, more than the device has CUs -- in adapt mode the launch cannot keep every actor
+# workgroup resident and runs as its two launches; in clip mode nothing waits and the one launch takes any size)
 @pytest.mark.parametrize('mode', [L.SMX_PPO_ADAPT, L.SMX_PPO_CLIP])
-@pytest.mark.parametrize('rows,D,H1,H2,A', SHAPES)
+@pytest.mark.parametrize('rows,D,H1,H2,A', SHAPES + [(4500, 20, 40, 24, 5)])
 def test_epoch_fwdbwd_equals_forward_then_backward(K, rows, D, H1, H2, A, mode):
     """smx_epoch_fwdbwd_f32 (one launch, batch means through the in-launch counter) against the two launches it
     replaces, both on the device: the forward results and the loss sums bit for bit, the data gradients up to the
@@ -173,11 +175,12 @@ def test_epoch_fwdbwd_equals_forward_then_backward(K, rows, D, H1, H2, A, mode):
     two, one = _fb_pair(K, rows, D, H1, H2, A, mode, seed=rows + D)
     for k in ('h1aT', 'h2aT', 'h1cT', 'h2cT', 'partials', 'v_dz3', 'v_partials'):    # (g_surr / g_kl stay in LDS)
         assert torch.equal(one[k], two[k]), k
+    many = 2 * ((rows + 15) // 16) > torch.cuda.get_device_properties(0).multi_processor_count
     close(one['stats'], two['stats'], atol=1e-6, rtol=2e-6, msg='stats')
     close(one['dlogvar'], two['dlogvar'], atol=1e-7, rtol=2e-6, msg='dlogvar')
     close(one['dlq'], two['dlq'], atol=1e-9, rtol=1e-5, msg='dlogvar sumsq')
     assert torch.equal(one['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:], two['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:])
-    assert int(one['sync'][0]) == (rows + 15) // 16
+    assert int(one['sync'][0]) == (0 if many and mode == L.SMX_PPO_ADAPT else (rows + 15) // 16)
     for k in ('dz3aT', 'dz2aT', 'dz1aT', 'dz2cT', 'dz1cT'):
         close(one[k], two[k], atol=1e-8, rtol=1e-5, msg=k)
     for k in ('grads_a', 'grads_c'):
