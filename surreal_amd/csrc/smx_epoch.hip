@@ -999,7 +999,7 @@ extern "C" int smx_epoch_prepare_f32(const smx_epoch_prep_t* a, smx_stream_t str
     SMX_REQUIRE(!a->ref_filter || (a->ref_sum && a->ref_sumsq && a->ref_count), SMX_E_NULL);
     SMX_REQUIRE(!a->xnext || (a->obs_next && a->ld_next >= a->D), SMX_E_SHAPE);
     SMX_REQUIRE(!a->ref_std || (a->ref_log_var && a->A > 0 && a->ld_ref >= a->A), SMX_E_SHAPE);
-    SMX_REQUIRE(a->n_zero >= 0 && a->n_zero <= 65536 && (a->n_zero == 0 || a->zero_words), SMX_E_SHAPE);
+    SMX_REQUIRE(a->n_zero >= 0 && a->n_zero <= (1 << 20) && (a->n_zero == 0 || a->zero_words), SMX_E_SHAPE);
     PrepArgs P;
     memset(&P, 0, sizeof(P));
     P.obs0 = a->obs0; P.ld_obs0 = (long)a->ld_obs0; P.rows = (long)a->rows; P.D = a->D;

@@ -14,6 +14,7 @@
 namespace {
 #include "smx_ppo_loss.inc.h"
 #include "smx_epoch_pack.inc.h"
+#include "smx_adam.inc.h"
 
 __global__ __launch_bounds__(256) void policy_loss_kernel(
     int mode, const float* __restrict__ g_mean, const float* __restrict__ log_var,
@@ -275,50 +276,11 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamGroups P,
     const float total = smx_block_sum(t, red);
     const float norm = sqrtf(total);
     const int which = G.which;
-    const float max_norm = which ? ctrl_v->critic_max_norm : ctrl_v->actor_max_norm;
-    float coef = 1.0f;
-    if (max_norm > 0.f) {
-        // clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1, always multiplied in
-        coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
-    }
     if (blk == 0 && threadIdx.x == 0 && G.grad_norm_out) *G.grad_norm_out = norm;
-
-    const double beta1 = 0.9, beta2 = 0.999;
-    const int step = which ? C.adam_step_critic : C.adam_step_actor;
-    const double lr = (double)(which ? C.lr_critic : C.lr_actor);
-    const float wd = which ? C.critic_weight_decay : C.actor_weight_decay;
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    const float neg_step_size = (float)(-(lr / bc1));
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2);
-    const float eps = 1e-8f;
-    auto step_one = [&](long i, float g, float p, float mi, float vi) {
-        g = g * coef;
-        if (wd != 0.f) g = g + wd * p;                         // grad.add(param, alpha=wd)
-        mi = mi + w1 * (g - mi);                               // exp_avg.lerp_(grad, 1 - beta1)
-        vi = vi * b2f + w2 * (g * g);                          // mul_(beta2).addcmul_(g, g, 1-beta2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        const float pn = p + (neg_step_size * mi) / denom;     // addcdiv_(exp_avg, denom, -step_size)
-        theta[i] = pn;
-        m[i] = mi;
-        v[i] = vi;
-        if (G.packed) {            // the same value into the forward / backward kernels' fragment-order copies
-            float* Pk = G.packed;
-            if (i >= G.oW1 && i < G.oW1 + (long)G.H1 * G.D) {
-                const int mm = (int)((i - G.oW1) / G.D), kk = (int)((i - G.oW1) - (long)mm * G.D);
-                Pk[pack_pos(G.D, mm, kk)] = pn;
-            } else if (i >= G.oW2 && i < G.oW2 + (long)G.H2 * G.H1) {
-                const int mm = (int)((i - G.oW2) / G.H1), kk = (int)((i - G.oW2) - (long)mm * G.H1);
-                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 1) + pack_pos(G.H1, mm, kk)] = pn;
-                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 3) + pack_pos(G.H2, kk, mm)] = pn;
-            } else if (i >= G.oW3 && i < G.oW3 + (long)G.OUT * G.H2) {
-                const int mm = (int)((i - G.oW3) / G.H2), kk = (int)((i - G.oW3) - (long)mm * G.H2);
-                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 2) + pack_pos(G.H2, mm, kk)] = pn;
-                Pk[4 * pack_off(G.D, G.H1, G.H2, G.OUT, 4) + pack_pos(G.OUT, kk, mm)] = pn;
-            }
-        }
-    };
+    const AdamCoef K = adam_coef(*ctrl_v, which, norm);
+    AdamPack Q;
+    Q.packed = G.packed; Q.oW1 = G.oW1; Q.oW2 = G.oW2; Q.oW3 = G.oW3; Q.D = G.D; Q.H1 = G.H1; Q.H2 = G.H2; Q.OUT = G.OUT;
+    auto step_one = [&](long i, float g, float p, float mi, float vi) { adam_step_one(K, Q, theta, m, v, i, g, p, mi, vi); };
     if (i0 < G.n) step_one(i0, g0, p0, m0, v0);
     if (i1 < G.n) step_one(i1, g1, p1, m1, v1);
     for (long i = i1 + stride; i < G.n; i += stride) step_one(i, grads[i], theta[i], m[i], v[i]);

@@ -330,7 +330,12 @@ class PPOLearner(Learner):
         # (+ per launch and row block of the fused forward + backward epochs: an 8-byte slot)
         n_slots = 0 if (self.if_rnn_policy or self.model.if_pixel or self.world_size > 1) else \
             2 * (max(Ep, Ev) + 1) * ((B + 15) // 16)
-        n_sync = self._sync_words() + n_slots
+        # (+ with learner.wgrad_adam -- weight gradients, clip-norm and Adam step in ONE launch, smx_mlp3_wgrad_adam_f32;
+        # measured equal to the two launches it replaces, DESIGN.md 3.2, so off by default -- an 8-byte slot per launch and
+        # 32 x 32 tile)
+        tiles_ac = K.mlp3_backward_partials(act) + K.mlp3_backward_partials(cri)
+        n_adam = 2 * max(Ep, Ev) * tiles_ac if n_slots and self.session_config.learner.get('wgrad_adam', False) else 0
+        n_sync = self._sync_words() + n_slots + n_adam
         n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + n_sync + Ev * L.VS_STRIDE + 12 + 4
         ws.scal = torch.zeros(n_scal, device=dev, dtype=torch.float32)
         o = 0
@@ -338,7 +343,9 @@ class PPOLearner(Learner):
         ws.ctrl_i = ws.ctrl_f.view(torch.int32)
         ws.pstats = ws.scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE); o += (Ep + 1) * L.PS_STRIDE
         ws.sync = ws.scal[o:o + n_sync].view(torch.int32); o += n_sync       # one word per epoch launch, zeroed per learn
-        ws.kl_slots = ws.sync[self._sync_words():].view(-1, 2 * ((B + 15) // 16)) if n_slots else None
+        ws.kl_slots = ws.sync[self._sync_words():self._sync_words() + n_slots].view(-1, 2 * ((B + 15) // 16)) \
+            if n_slots else None
+        ws.adam_slots = ws.sync[self._sync_words() + n_slots:].view(-1, 2 * tiles_ac) if n_adam else None
         ws.n_sync = n_sync
         ws.vstats = ws.scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE); o += Ev * L.VS_STRIDE
         ws.adv_mom = ws.scal[o:o + 3]; o += 3
@@ -923,6 +930,19 @@ class PPOLearner(Learner):
                 # forward + loss + data gradients of every job of the epoch in ONE launch (smx_epoch_fwdbwd_f32)
                 bj = ([aj] if pol_u else []) + ([cj] if val else [])
                 K.epoch_fwdbwd(bj, loss, ws.ctrl_f, n_total, ws.sync[e:e + 1], ws.kl_slots[e])
+                if ws.adam_slots is not None:
+                    # ... and the weight gradients, clip-norm and Adam step of both groups in a second one
+                    gs, pk = [], []
+                    if pol_u:
+                        gs.append((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq, ws.sumsq_a,
+                                   ws.np_a + 1, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1], 0))
+                        pk.append((m.actor, ws.pk_actor))
+                    if val:
+                        gs.append((m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq, ws.sumsq_c,
+                                   ws.np_c, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1], 1))
+                        pk.append((m.critic, ws.pk_critic))
+                    K.mlp3_wgrad_adam(bj, gs, ws.ctrl_f, ws.adam_slots[e], pack=pk)
+                    continue
                 K.mlp3_wgrad_multi(bj)
             else:
                 K.epoch_forward(([aj] if pol_f else []) + ([cj] if val else []), loss, ws.ctrl_f, n_total)

@@ -81,7 +81,11 @@ def test_learner_two_stream_schedule(name):
     ('cfg5_adapt', {'split_chains': True}),                      # actor / critic chains on two streams in the graph
     ('cfg5_clip', {'fused_epochs': False}),                      # the layered (one launch per layer) epoch schedule
     ('cfg2_adapt', {'fused_epochs': False, 'split_chains': True}),
-    ('cfg5_adapt_earlyexit', {'split_chains': True})])
+    ('cfg5_adapt_earlyexit', {'split_chains': True}),
+    ('cfg5_adapt', {'wgrad_adam': True}),                        # weight gradients + clip-norm + Adam in one launch
+    ('cfg5_adapt_earlyexit', {'wgrad_adam': True}),
+    ('tiny_adapt_cutoff2', {'wgrad_adam': True}),
+    ('cfg2_clip', {'wgrad_adam': True})])
 def test_learner_session_options_keep_the_numbers(name, opts):
     """every schedule option of the fused-epoch learner (session_config.learner.*) reproduces the same goldens"""
     check_case(name, *run_case(name, opts))
