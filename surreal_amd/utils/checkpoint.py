@@ -1,5 +1,7 @@
 """
-Checkpoints in the reference's on-disk format (surreal/utils/checkpoint.py:17-395):
+Checkpoints in the reference's on-disk format (surreal/utils/checkpoint.py:17-395) -- the FORMAT is the contract
+(a folder written by either side must restore on the other; tests/test_wire_formats.py holds a folder recorded
+from the reference):
 
     <folder>/<name>.<global_steps>.ckpt       pickle of OrderedDict(attr -> state_dict() | value)
     <folder>/<name>.best-<steps>.ckpt         copies of the best-scoring ones (keep_best > 0)
@@ -7,11 +9,16 @@ Checkpoints in the reference's on-disk format (surreal/utils/checkpoint.py:17-39
                                               keep_history, keep_best, history_ckpt_files (newest
                                               first), best_ckpt_files, best_scores, ckpt{file: info}
 
-An attribute is stored through ``state_dict()`` / restored through ``load_state_dict()`` when it has
-them (the reference tests ``isinstance(torch.nn.Module | Optimizer)``; the models here are not
-nn.Modules but keep the same two methods), anything else is pickled as is.  Tensors are moved to
-the host before pickling, so a checkpoint does not depend on the device it was written from.
+Three pieces: `_Layout` knows the file names, `_Manifest` is the yml (history rotation and the best-score ranking
+are list operations on it that return the files falling out), `Checkpoint` moves the tracked attributes between the
+object and the pickle and keeps the folder in step with the manifest.
+
+An attribute is stored through ``state_dict()`` / restored through ``load_state_dict()`` when it has them (the
+reference tests ``isinstance(torch.nn.Module | Optimizer)``; the models here are not nn.Modules but keep the same
+two methods), anything else is pickled as is.  Tensors are moved to the host before pickling, so a checkpoint does
+not depend on the device it was written from.
 """
+import bisect
 import collections
 import datetime
 import os
@@ -25,171 +32,197 @@ import yaml
 CHECKPOINT_VERSION = '0.0.1'       # surreal/utils/checkpoint.py:14
 
 
-def _to_host(obj):
-    if torch.is_tensor(obj):
-        return obj.detach().cpu()
-    if isinstance(obj, collections.OrderedDict):
-        return collections.OrderedDict((k, _to_host(v)) for k, v in obj.items())
-    if isinstance(obj, dict):
-        return {k: _to_host(v) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(_to_host(v) for v in obj)
-    return obj
+def _host_copy(tree):
+    """the same nested structure with every tensor on the host"""
+    if torch.is_tensor(tree):
+        return tree.detach().cpu()
+    if isinstance(tree, dict):           # OrderedDict stays an OrderedDict
+        return type(tree)((k, _host_copy(v)) for k, v in tree.items())
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_host_copy(v) for v in tree)
+    return tree
 
 
-def _stateful(obj):
-    return hasattr(obj, 'state_dict') and hasattr(obj, 'load_state_dict')
+def _has_state(obj):
+    return callable(getattr(obj, 'state_dict', None)) and callable(getattr(obj, 'load_state_dict', None))
 
 
-class _ScoreQueue(object):
-    """(score, file) pairs, best first, at most max_size (checkpoint.py:357-395)"""
+class _Layout(object):
+    """file names of one named checkpoint series inside a folder"""
 
-    def __init__(self, max_size):
-        self._queue = []
-        self.max_size = max_size
+    def __init__(self, folder, name):
+        self.folder, self.name = os.path.expanduser(folder), name
 
-    def set_queue(self, scores, filepaths):
-        self._queue = list(zip(scores, filepaths))
-        dropped = self._queue[self.max_size:]
-        del self._queue[self.max_size:]
-        return dropped
+    def file(self, suffix):
+        return '%s.%s.ckpt' % (self.name, suffix)
 
-    def add(self, score, filepath):
-        i = len(self._queue)
-        while i >= 1 and not self._queue[i - 1][0] > score:
-            i -= 1
-        self._queue.insert(i, (score, filepath))
-        if len(self._queue) > self.max_size:
-            return self._queue.pop()
-        return None
+    def best_file(self, suffix):
+        return self.file('best-%s' % (suffix,))
 
-    def get_scores_filepaths(self):
-        if not self._queue:
-            return [], []
-        scores, files = zip(*self._queue)
-        return list(scores), list(files)
+    def manifest(self):
+        return 'metadata.%s.yml' % (self.name,)
+
+    def at(self, fname, folder=None):
+        return os.path.join(folder or self.folder, fname)
+
+    def unlink(self, fname):
+        try:
+            os.remove(self.at(fname))
+        except FileNotFoundError:
+            pass
+
+
+class _Manifest(object):
+    """the yml as a dict (`.d`, what the reference calls metadata) plus the two retention rules"""
+
+    def __init__(self, d):
+        self.d = d
+
+    @classmethod
+    def fresh(cls, tracked_attrs, keep_history, keep_best):
+        if tracked_attrs is not None:
+            if not isinstance(tracked_attrs, (list, tuple)) or not all(isinstance(a, str) for a in tracked_attrs):
+                raise AssertionError('tracked_attrs must be a list of attribute name strings or None')
+            tracked_attrs = list(tracked_attrs)
+        assert keep_history >= 1 and keep_best >= 0
+        return cls(dict(version=CHECKPOINT_VERSION, save_counter=0, tracked_attrs=tracked_attrs,
+                        keep_history=keep_history, keep_best=keep_best, history_ckpt_files=[], best_ckpt_files=[],
+                        best_scores=[], ckpt={}))
+
+    @classmethod
+    def read(cls, path):
+        with open(path) as fp:
+            d = yaml.safe_load(fp)
+        if str(d.get('version')) != CHECKPOINT_VERSION:
+            raise ValueError('checkpoint version incompatible, please examine {} and make sure it is {}'
+                             .format(path, CHECKPOINT_VERSION))
+        return cls(d)
+
+    def write(self, path):
+        with open(path, 'w') as fp:
+            yaml.safe_dump(self.d, fp, default_flow_style=False)
+
+    def push_history(self, fname):
+        """fname becomes the newest history entry -> the files that fall off the end"""
+        files = [fname] + [f for f in self.d['history_ckpt_files'] if f != fname]
+        keep = self.d['keep_history']
+        self.d['history_ckpt_files'] = files[:keep]
+        return files[keep:]
+
+    def rank_best(self, score, fname):
+        """insert (score, fname) into the best list (descending scores; a tie goes IN FRONT of the entries already
+        there, checkpoint.py:357-395) -> (whether fname made it, the files that fall off)"""
+        scores, files = list(self.d['best_scores']), list(self.d['best_ckpt_files'])
+        keep = self.d['keep_best']
+        dropped = files[keep:]
+        del scores[keep:], files[keep:]
+        at = bisect.bisect_left([-s for s in scores], -score)
+        scores.insert(at, score)
+        files.insert(at, fname)
+        dropped += files[keep:]
+        del scores[keep:], files[keep:]
+        self.d['best_scores'], self.d['best_ckpt_files'] = scores, files
+        return fname in files, dropped
 
 
 class Checkpoint(object):
     def __init__(self, folder, name, *, tracked_obj, tracked_attrs=None, keep_history=1,
                  keep_best=1, mkdir=True):
-        self.folder = os.path.expanduser(folder)
+        self._layout = _Layout(folder, name)
         if mkdir:
-            os.makedirs(self.folder, exist_ok=True)
-        self.name = name
+            os.makedirs(self._layout.folder, exist_ok=True)
         self.tracked_obj = tracked_obj
         if os.path.exists(self.metadata_path()):
-            self._load_metadata()
+            self._manifest = _Manifest.read(self.metadata_path())
         else:
-            self._check_tracked_attrs(tracked_attrs)
-            assert keep_history >= 1 and keep_best >= 0
-            self.metadata = {
-                'version': CHECKPOINT_VERSION, 'save_counter': 0, 'history_ckpt_files': [],
-                'ckpt': {}, 'tracked_attrs': list(tracked_attrs) if tracked_attrs is not None else None,
-                'keep_history': keep_history, 'keep_best': keep_best, 'best_ckpt_files': [],
-                'best_scores': [],
-            }
+            self._manifest = _Manifest.fresh(tracked_attrs, keep_history, keep_best)
 
-    # ---- names ---------------------------------------------------------------------------------
+    # ---- what callers of the reference's class read --------------------------------------------------
+    @property
+    def folder(self):
+        return self._layout.folder
+
+    @property
+    def name(self):
+        return self._layout.name
+
+    @property
+    def metadata(self):
+        return self._manifest.d
+
     def metadata_name(self):
-        return 'metadata.{}.yml'.format(self.name)
+        return self._layout.manifest()
 
     def metadata_path(self):
-        return os.path.join(self.folder, self.metadata_name())
+        return self._layout.at(self._layout.manifest())
 
     def ckpt_name(self, suffix):
-        return '{}.{}.ckpt'.format(self.name, suffix)
+        return self._layout.file(suffix)
 
     def ckpt_path(self, suffix):
-        return os.path.join(self.folder, self.ckpt_name(suffix))
+        return self._layout.at(self._layout.file(suffix))
 
-    # ---- metadata ------------------------------------------------------------------------------
-    @staticmethod
-    def _check_tracked_attrs(tracked_attrs):
-        msg = 'tracked_attrs must be a list of attribute name strings or None'
-        if isinstance(tracked_attrs, (list, tuple)):
-            assert all(isinstance(a, str) for a in tracked_attrs), msg
-        else:
-            assert tracked_attrs is None, msg
-
-    def _load_metadata(self):
-        with open(self.metadata_path()) as fp:
-            self.metadata = yaml.safe_load(fp)
-        if str(self.metadata.get('version')) != CHECKPOINT_VERSION:
-            raise ValueError('checkpoint version incompatible, please examine {} and make sure it is {}'
-                             .format(self.metadata_path(), CHECKPOINT_VERSION))
-
-    def _save_metadata(self):
-        with open(self.metadata_path(), 'w') as fp:
-            yaml.safe_dump(self.metadata, fp, default_flow_style=False)
-
-    # ---- save ----------------------------------------------------------------------------------
-    def _save_ckpt(self, suffix):
+    # ---- object <-> pickle ---------------------------------------------------------------------------
+    def _snapshot(self):
         attrs = self.metadata['tracked_attrs']
         assert attrs is not None, 'tracked_attrs must not be None for save(). ' \
                                   'Did you forget to restore from an existing checkpoint?'
-        data = collections.OrderedDict()
-        for attr in attrs:
-            value = getattr(self.tracked_obj, attr)
-            data[attr] = _to_host(value.state_dict()) if _stateful(value) else _to_host(value)
-        with open(self.ckpt_path(suffix), 'wb') as fp:
-            pickle.dump(data, fp)
+        out = collections.OrderedDict()
+        for a in attrs:
+            v = getattr(self.tracked_obj, a)
+            out[a] = _host_copy(v.state_dict() if _has_state(v) else v)
+        return out
 
+    def _apply(self, data):
+        for a in self.metadata['tracked_attrs']:
+            v = getattr(self.tracked_obj, a)
+            if _has_state(v):
+                v.load_state_dict(data[a])
+            else:
+                setattr(self.tracked_obj, a, data[a])
+
+    # ---- save ----------------------------------------------------------------------------------------
     def save(self, score=None, global_steps=None, reload_metadata=False, **ckpt_info):
+        L = self._layout
         if reload_metadata:
-            self._load_metadata()
-        meta = self.metadata
-        meta['save_counter'] += 1
-        if global_steps is None:
-            global_steps = meta['save_counter']
-        suffix = global_steps
-        self._save_ckpt(suffix)
-        meta['global_steps'] = global_steps
-        meta['history_ckpt_files'] = [self.ckpt_name(suffix)] + \
-            [f for f in meta['history_ckpt_files'] if f != self.ckpt_name(suffix)]
-        for old in meta['history_ckpt_files'][meta['keep_history']:]:
-            path = os.path.join(self.folder, old)
-            if os.path.exists(path):
-                os.remove(path)
-        del meta['history_ckpt_files'][meta['keep_history']:]
-        entry = {'score': score, 'global_steps': global_steps, 'save_counter': meta['save_counter'],
-                 'time': time.time(), 'datetime': str(datetime.datetime.now())}
-        entry.update(ckpt_info)
-        meta['ckpt'][self.ckpt_name(suffix)] = entry
-        if meta['keep_best'] > 0:
+            self._manifest = _Manifest.read(self.metadata_path())
+        man, d = self._manifest, self._manifest.d
+        d['save_counter'] += 1
+        steps = d['save_counter'] if global_steps is None else global_steps
+        fname = L.file(steps)
+        with open(L.at(fname), 'wb') as fp:
+            pickle.dump(self._snapshot(), fp)
+        d['global_steps'] = steps
+        for old in man.push_history(fname):
+            L.unlink(old)
+        info = dict(score=score, global_steps=steps, save_counter=d['save_counter'], time=time.time(),
+                    datetime=str(datetime.datetime.now()), **ckpt_info)
+        d['ckpt'][fname] = info
+        if d['keep_best'] > 0:
             assert score is not None, 'score cannot be None if keep_best is enabled'
-            queue = _ScoreQueue(meta['keep_best'])
-            to_delete = queue.set_queue(meta['best_scores'], meta['best_ckpt_files'])
-            best_name = self.ckpt_name('best-{}'.format(suffix))
-            evicted = queue.add(score, best_name)
-            if evicted is None or evicted[1] != best_name:
-                shutil.copy(self.ckpt_path(suffix), os.path.join(self.folder, best_name))
-                meta['ckpt'][best_name] = dict(entry)
-            if evicted:
-                to_delete.append(evicted)
-            for _, fname in to_delete:
-                path = os.path.join(self.folder, fname)
-                if os.path.exists(path):
-                    os.remove(path)
-                meta['ckpt'].pop(fname, None)
-            meta['best_scores'], meta['best_ckpt_files'] = queue.get_scores_filepaths()
-        self._save_metadata()
+            best = L.best_file(steps)
+            kept, dropped = man.rank_best(score, best)
+            if kept:
+                shutil.copy(L.at(fname), L.at(best))
+                d['ckpt'][best] = dict(info)
+            for f in dropped:
+                L.unlink(f)
+                d['ckpt'].pop(f, None)
+        man.write(self.metadata_path())
 
-    # ---- restore -------------------------------------------------------------------------------
-    def _restore(self, ckpt_file, check_ckpt_exists, folder):
-        path = os.path.join(folder, ckpt_file)
+    # ---- restore -------------------------------------------------------------------------------------
+    def _manifest_of(self, folder):
+        """the manifest of this series in `folder` becomes the current one"""
+        self._manifest = _Manifest.read(self._layout.at(self._layout.manifest(), folder))
+
+    def _load_file(self, fname, folder, must_exist):
+        path = self._layout.at(fname, folder)
         if not os.path.exists(path):
-            if check_ckpt_exists:
+            if must_exist:
                 raise FileNotFoundError(path + ' missing.')
             return None
         with open(path, 'rb') as fp:
-            data = pickle.load(fp)
-        for attr in self.metadata['tracked_attrs']:
-            value = getattr(self.tracked_obj, attr)
-            if _stateful(value):
-                value.load_state_dict(data[attr])
-            else:
-                setattr(self.tracked_obj, attr, data[attr])
+            self._apply(pickle.load(fp))
         return path
 
     def restore(self, target, mode, reload_metadata=True, check_ckpt_exists=False,
@@ -198,36 +231,24 @@ class Checkpoint(object):
         assert mode in ('best', 'history')
         folder = os.path.expanduser(restore_folder) if restore_folder else self.folder
         if reload_metadata or restore_folder:
-            keep = self.folder
-            self.folder = folder
-            try:
-                self._load_metadata()
-            finally:
-                self.folder = keep
-        meta = self.metadata
+            self._manifest_of(folder)
         if isinstance(target, int):
             assert target >= 0, 'target int should start from 0 for the last or best'
-            files = meta['best_ckpt_files'] if mode == 'best' else meta['history_ckpt_files']
-            if target < len(files):
-                ckpt_file = files[target]
-            elif check_ckpt_exists:
-                raise FileNotFoundError('{} [{}] ckpt file missing'.format(mode.capitalize(), target))
-            else:
-                ckpt_file = '__DOES_NOT_EXIST__'
+            ranked = self.metadata['best_ckpt_files' if mode == 'best' else 'history_ckpt_files']
+            if target >= len(ranked):
+                if check_ckpt_exists:
+                    raise FileNotFoundError('{} [{}] ckpt file missing'.format(mode.capitalize(), target))
+                return None
+            fname = ranked[target]
         else:
             assert '.ckpt' not in str(target), 'use restore_full_name() instead'
-            ckpt_file = self.ckpt_name('best-{}'.format(target) if mode == 'best' else target)
-        return self._restore(ckpt_file, check_ckpt_exists, folder)
+            fname = self._layout.best_file(target) if mode == 'best' else self._layout.file(target)
+        return self._load_file(fname, folder, check_ckpt_exists)
 
     def restore_full_name(self, ckpt_file, check_ckpt_exists=True, restore_folder=None):
         folder = os.path.expanduser(restore_folder) if restore_folder else self.folder
-        keep = self.folder
-        self.folder = folder
-        try:
-            self._load_metadata()
-        finally:
-            self.folder = keep
-        return self._restore(ckpt_file, check_ckpt_exists, folder)
+        self._manifest_of(folder)
+        return self._load_file(ckpt_file, folder, check_ckpt_exists)
 
 
 class PeriodicCheckpoint(Checkpoint):
@@ -239,17 +260,16 @@ class PeriodicCheckpoint(Checkpoint):
         assert period >= 1
         self.period = period
         self.min_interval = min_interval
-        self._period_counter = 0
+        self._calls = 0
         self.last_update_time = time.time()
 
     def save(self, *args, **kwargs):
-        self._period_counter += 1
-        if self._period_counter % self.period == 0 and \
-                time.time() - self.last_update_time >= self.min_interval:
+        self._calls += 1
+        due = self._calls % self.period == 0 and time.time() - self.last_update_time >= self.min_interval
+        if due:
             super().save(*args, **kwargs)
             self.last_update_time = time.time()
-            return True
-        return False
+        return due
 
     def reset_period(self):
-        self._period_counter = 0
+        self._calls = 0
