@@ -3,6 +3,8 @@ finalize + data gradients; smx_mlp3_wgrad_multi_f32) through the C ABI against t
 the same contract (tests/cpu_kernels.py) on identical seeded inputs -- shapes of the benchmark
 (cfg 5), cfg 2, ragged row counts (partial last row block), widths that are not tile multiples, both
 PPO modes, the KL early exit and the forward-only final pass.  1e-5 abs + rel (fp32)."""
+import collections
+
 import numpy as np
 import pytest
 import torch
@@ -185,6 +187,97 @@ def test_epoch_fwdbwd_equals_forward_then_backward(K, rows, D, H1, H2, A, mode):
         close(one[k], two[k], atol=1e-8, rtol=1e-5, msg=k)
     for k in ('grads_a', 'grads_c'):
         close(one[k], two[k], atol=1e-7, rtol=2e-5, msg=k)
+
+
+@pytest.mark.parametrize('mode', ['adapt', 'clip'])
+@pytest.mark.parametrize('rows,D,H1,H2,A', [(1024, 376, 300, 200, 17), (100, 64, 332, 212, 32), (48, 12, 24, 16, 3)])
+def test_epoch_launches_against_the_reference_restatement_in_float64(K, rows, D, H1, H2, A, mode):
+    """An oracle the kernels share nothing with: the reference's losses as oracle/ppo_oracle.py restates them
+    (_adapt_loss / _clip_loss / _value_loss, surreal/learner/ppo.py:194-332) in float64 with torch autograd, against ONE
+    epoch of [smx_epoch_fwdbwd_f32 -> smx_mlp3_wgrad_multi_f32]: every gradient tensor of both networks and log_var, the
+    loss statistics, and the norms clip_grad_norm_ would see.  Tolerances: fp32 sums over <= 1024 rows against float64,
+    and hidden units whose pre-activation rounds to the other side of zero (a whole column of a weight gradient then
+    moves by one row's contribution): 2e-4 of the largest entry of the tensor."""
+    import ppo_oracle
+    t = build(rows, D, H1, H2, A, seed=rows + A, mode=mode, device='cuda')['d']
+    m = L.SMX_PPO_ADAPT if mode == 'adapt' else L.SMX_PPO_CLIP
+    na = t['act'].numel
+    ga = torch.zeros(na + A, device='cuda')
+    np_a = K.mlp3_backward_partials(t['act'])
+    sq_a, sq_c = torch.zeros(np_a + 1, device='cuda'), torch.zeros(K.mlp3_backward_partials(t['cri']), device='cuda')
+    t['ctrl'][L.C_KL_TARGET] = 0.015
+    sync = torch.zeros(4, dtype=torch.int32, device='cuda')
+    kl = torch.zeros(2 * ((rows + 15) // 16), dtype=torch.int32, device='cuda')
+    loss = dict(mode=m, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
+                adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=False,
+                will_update=True, dlogvar=ga[na:], dlogvar_sumsq=sq_a[np_a:], stats=t['stats'],
+                returns=t['returns'], v_dz3=t['v_dz3'], v_partials=t['v_partials'], v_will_update=True)
+    K.epoch_pack([(t['act'], t['pk_a']), (t['cri'], t['pk_c'])])
+    aj = dict(net=t['act'], packed=t['pk_a'], x=t['x'], h1T=t['h1aT'], h2T=t['h2aT'], act=L.SMX_ACT_TANH, loss='policy',
+              dz3T=t['dz3aT'], dz2T=t['dz2aT'], dz1T=t['dz1aT'], xT=t['xT'], grads=ga, sumsq=sq_a)
+    cj = dict(net=t['cri'], packed=t['pk_c'], x=t['x'], h1T=t['h1cT'], h2T=t['h2cT'], act=L.SMX_ACT_NONE, loss='value',
+              dz3=t['v_dz3'], dz3T=t['v_dz3'], dz2T=t['dz2cT'], dz1T=t['dz1cT'], xT=t['xT'], grads=t['grads_c'], sumsq=sq_c)
+    K.epoch_fwdbwd([aj, cj], loss, t['ctrl'], rows, sync[0:1], kl)
+    K.mlp3_wgrad_multi([aj, cj])
+    torch.cuda.synchronize()
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        params = collections.OrderedDict()
+        for nm, net in (('actor', t['act']), ('critic', t['cri'])):
+            for k in (1, 2, 3):
+                params['%s.fc%d.W' % (nm, k)] = net.views['W%d' % k].cpu().double().numpy()
+                params['%s.fc%d.b' % (nm, k)] = net.views['b%d' % k].cpu().double().numpy()
+        params['actor.log_var'] = t['log_var'].cpu().double().numpy().reshape(1, A)
+        O = ppo_oracle.OraclePPOLearner(params, A, rows, use_z_filter=False, ppo_mode=mode, kl_target=0.015)
+        d64 = lambda k: t[k].cpu().double()  # noqa: E731
+        obs = {'low_dim': {'s': d64('x')}}
+        if mode == 'adapt':
+            pl, st = O._adapt_loss(obs, d64('actions'), d64('adv'), d64('behave'), d64('ref'))
+        else:
+            pl, st = O._clip_loss(obs, d64('actions'), d64('adv'), d64('behave'))
+        pl.backward()
+        vl, vst = O._value_loss(obs, d64('returns').view(-1, 1))
+        vl.backward()
+        P = O.model.p
+        want_a = torch.cat([P['actor.fc%d.%s' % (k, w)].grad.reshape(-1) for k in (1, 2, 3) for w in ('W', 'b')] +
+                           [P['actor.log_var'].grad.reshape(-1)])
+        want_c = torch.cat([P['critic.fc%d.%s' % (k, w)].grad.reshape(-1) for k in (1, 2, 3) for w in ('W', 'b')])
+    finally:
+        torch.set_default_dtype(prev)
+    got_a, got_c = ga.cpu().double(), t['grads_c'].cpu().double()
+
+    bad = []
+
+    def near(got, want, what, who):
+        o = 0
+        for nm, n in what:
+            g, w = got[o:o + n], want[o:o + n]
+            tol = 2e-4 * float(w.abs().max()) + 1e-9
+            if not float((g - w).abs().max()) <= tol:
+                bad.append('%s %s: off by %.3g, tolerance %.3g (largest entry %.3g)' % (who, nm, float((g - w).abs().max()), tol,
+                                                                                   float(w.abs().max())))
+            o += n
+    sizes = lambda net, extra: [('W1', H1 * D), ('b1', H1), ('W2', H2 * H1), ('b2', H2), ('W3', net.OUT * H2),  # noqa: E731
+                                ('b3', net.OUT)] + extra
+    near(got_a, want_a, sizes(t['act'], [('log_var', A)]), 'actor')
+    near(got_c, want_c, sizes(t['cri'], []), 'critic')
+    assert not bad, (bad, st, t['stats'].cpu()[:4])
+    # what clip_grad_norm_ would see
+    assert abs(float(torch.sqrt(sq_a.double().sum())) - float(want_a.norm())) <= 2e-4 * float(want_a.norm())
+    assert abs(float(torch.sqrt(sq_c.double().sum())) - float(want_c.norm())) <= 2e-4 * float(want_c.norm())
+    # the epoch's statistics (mean-reduced sums of 1024 fp32 terms)
+    stats = t['stats'].cpu()
+    assert abs(float(stats[L.PS_SURR]) - st['_surr_loss']) <= 2e-5 * max(1.0, abs(st['_surr_loss']))
+    assert abs(float(stats[L.PS_ENTROPY]) - st['_entropy']) <= 2e-5 * max(1.0, abs(st['_entropy']))
+    if mode == 'adapt':
+        assert abs(float(stats[L.PS_KL]) - st['_pol_kl']) <= 2e-5 * max(1.0, abs(st['_pol_kl']))
+        assert abs(float(stats[L.PS_LOSS]) - st['_kl_loss_adapt']) <= 5e-5 * max(1.0, abs(st['_kl_loss_adapt']))
+    else:
+        assert abs(float(stats[L.PS_LOSS]) - st['_clip_surr_loss']) <= 2e-5 * max(1.0, abs(st['_clip_surr_loss']))
+    sq_err = float(t['v_partials'].cpu().double()[:, 5].sum())          # (word 5 of a block's row: its sum of squared errors)
+    assert abs(sq_err / rows - vst['_val_loss']) <= 2e-5 * max(1.0, vst['_val_loss'])
 
 
 def _wgrad_adam_side(K, rows, D, H1, H2, A, mode, seed, fused, steps=2, stop_at=None, only=None):
