@@ -70,9 +70,13 @@ if 'timing' in os.environ.get('SMX_LIB_PATH', ''):
     torch.cuda.synchronize()
     TT = tb.view(512, 32)[:128].cpu().double()
     base = TT[:, 0].min()
-    names = [(0, 1, 'prologue'), (1, 2, 'barrier'), (2, 3, 'layer 1'), (3, 4, 'layer 2'), (4, 5, 'layer 3'),
+    names = [(0, 12, 'job descriptor'), (12, 13, 'x + loss input loads issued'), (13, 14, 'hidden tiles cleared'),
+             (14, 15, 'x -> LDS (waits for x)'), (15, 1, 'loss inputs -> LDS'), (0, 1, 'prologue'), (1, 2, 'barrier'), (2, 3, 'layer 1'), (3, 4, 'layer 2'), (4, 5, 'layer 3'),
              (5, 6, 'loss + publish barrier'), (6, 7, 'rhs tiles + dz2 products'), (7, 8, 'wait + reduce sums'),
              (8, 9, 'dz2 epilogue + dz3T + barrier'), (9, 10, 'dz1'), (10, 11, 'scalars')]
+    for l, prev in ((0, 2), (1, 3), (2, 4)):
+        names += [(prev, 16 + 4 * l, 'layer %d: set-up, bias loads issued' % (l + 1)), (16 + 4 * l, 17 + 4 * l, 'layer %d: products' % (l + 1)),
+                  (17 + 4 * l, 18 + 4 * l, 'layer %d: epilogue' % (l + 1)), (18 + 4 * l, 3 + l, 'layer %d: barrier' % (l + 1))]
     for a, b, nm in names:
         d = TT[:, b] - TT[:, a]
         print('%-32s actor %7.0f (max %7.0f)   critic %7.0f (max %7.0f) cycles' % (

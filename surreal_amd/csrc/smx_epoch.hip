@@ -46,6 +46,7 @@ constexpr int TB = 3;             // the same, backward
 constexpr int MAX_EJOBS = 4;
 constexpr int XV = 7;             // 16-byte words of its x row a thread fetches up front (D <= 448; more: a loop)
 constexpr int LIN = 6;            // loss-input words a thread fetches up front: 16 rows x (5A + 1) <= 6 x 256
+constexpr int LINF = 3;           // the same in the 512-thread forward kernels
 constexpr int EXCLUSIVE_LDS = 84 * 1024;
 constexpr int LDZ = 68;           // row stride of the dz3 tile in LDS (backward: 64 zero-padded columns)
 constexpr int LDO = 36;           // row stride of the output tile in LDS (<= 32 outputs)
@@ -107,6 +108,16 @@ struct EArgs {
 };
 
 __device__ __forceinline__ EJob select_job(const EArgs& G, int bid) {
+    // one word of every 64-byte line of the job table, in the same batch of scalar loads as the block bases: the
+    // descriptor fetch below (its address depends on them) then finds its lines in the scalar cache instead of paying
+    // a second cold trip to the kernel-argument segment
+    {
+        const int* w = (const int*)&G.j[0];
+        int touch = 0;
+#pragma unroll
+        for (unsigned o = 0; o < sizeof(EJob) * MAX_EJOBS / 4; o += 16) touch |= w[o];
+        asm volatile("" :: "s"(touch));
+    }
     int pi = 0;
 #pragma unroll
     for (int k = 1; k < MAX_EJOBS; ++k) pi += (k < G.n && bid >= G.j[k].blk_base) ? 1 : 0;
@@ -181,6 +192,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fm = lane & 15, kq = lane >> 4;
+    TSTAMP(12);
 
     float* xs = sm;
     float* h1s = sm + G.off_h1;
@@ -207,34 +219,44 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     // loss inputs of the 16 rows -> LDS: policy [actions A | behave 2A | ref 2A | adv 1] per row
     const PolArgs& pa = G.pl;
     const int LW = 5 * pa.A + 1;
-    float lin[LIN];
+    float lin[LINF];
     float vret = 0.f;
-    // (one unconditional load per word from a selected, always valid address: no load under a lane mask)
-    auto loss_input = [&](int idx) -> float {
+    // (nothing touches a loaded word before it goes to LDS: a select right behind the load -- "0 for rows past the
+    // batch" -- makes hipcc wait for each word in turn; the row test is kept as a bit.  All eight waves fetch, three words
+    // each, and (row, column) of word tid + 512 i follows from that of word tid by addition: one integer division per
+    // thread, not one per word -- the address arithmetic was 3 k cycles of the actor workgroups' prologue)
+    unsigned lin_ok = 0u;
+    auto loss_word = [&](int n, int c, bool& ok) -> float {
         const int A = pa.A;
-        int n = idx / LW;
-        const int c = idx - n * LW;
-        const bool ok = n < nrows;
+        ok = n < nrows;
         n = ok ? n : 0;
         const long gr = row0 + n;
         const float* q = c < A ? pa.actions + gr * pa.ld_act + c
                        : c < 3 * A ? pa.behave + gr * pa.ld_beh + (c - A)
                        : c < 5 * A ? pa.ref + gr * pa.ld_ref + (c - 3 * A) : pa.adv + gr;
-        const float v = *q;
-        return ok ? v : 0.f;
+        return *q;
     };
-    if (lo && J.loss == SMX_EPOCH_LOSS_POLICY) {
+    if (J.loss == SMX_EPOCH_LOSS_POLICY) {
+        const int lq = FNTH / LW, lr = FNTH - lq * LW;
+        int n = tid / LW, c = tid - n * LW;
 #pragma unroll
-        for (int i = 0; i < LIN; ++i) {
-            const int idx = tid + NTH * i;
-            lin[i] = loss_input(idx < ER * LW ? idx : 0);
+        for (int i = 0; i < LINF; ++i) {
+            const bool in = tid + FNTH * i < ER * LW;
+            bool ok;
+            lin[i] = loss_word(in ? n : 0, in ? c : 0, ok);
+            lin_ok |= (ok && in) ? (1u << i) : 0u;
+            n += lq;
+            c += lr;
+            if (c >= LW) { c -= LW; ++n; }
         }
     } else if (lo && J.loss == SMX_EPOCH_LOSS_VALUE && tid < nrows) {
         vret = G.vl.returns[row0 + tid];
     }
+    TSTAMP(13);
     // ---- x tile -> LDS (rows past the batch and k >= D are zero), hidden tiles cleared -------
     for (int idx = tid; idx < (G.off_red - G.off_h1) >> 2; idx += FNTH)
         *(float4*)(h1s + 4 * idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+    TSTAMP(14);
     if (xvec && lo) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
@@ -251,14 +273,20 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
             xs[idx] = (j < J.D && n < nrows) ? J.x[(size_t)(row0 + n) * J.D + j] : 0.f;
         }
     }
+    TSTAMP(15);
     float* lin_s = sm + G.off_loss + loss_scratch_floats(pa.A);      // behind the loss body's own scratch
-    if (lo && J.loss == SMX_EPOCH_LOSS_POLICY) {
+    if (J.loss == SMX_EPOCH_LOSS_POLICY) {
 #pragma unroll
-        for (int i = 0; i < LIN; ++i) {
-            const int idx = tid + NTH * i;
-            if (idx < ER * LW) lin_s[idx] = lin[i];
+        for (int i = 0; i < LINF; ++i) {
+            const int idx = tid + FNTH * i;
+            if (idx < ER * LW) lin_s[idx] = ((lin_ok >> i) & 1u) ? lin[i] : 0.f;
         }
-        for (int idx = tid + NTH * LIN; idx < ER * LW; idx += NTH) lin_s[idx] = loss_input(idx);    // A > 19
+        for (int idx = tid + FNTH * LINF; idx < ER * LW; idx += FNTH) {                              // A > 19
+            const int n = idx / LW;
+            bool ok;
+            const float v = loss_word(n, idx - n * LW, ok);
+            lin_s[idx] = ok ? v : 0.f;
+        }
     }
     if (__builtin_amdgcn_readfirstlane(stopv) != 0) return;
     TSTAMP(1);

@@ -73,6 +73,36 @@ def test_zfilter(K):
         close(rs_d, rs, rtol=1e-5, atol=1e-3), close(rsq_d, rsq, rtol=1e-5, atol=1e-2), close(cnt_d, cnt)
 
 
+def test_zfilter_against_the_reference_restatement(K):
+    """statistics, forward (reciprocal: <= 1 ulp from the division) and update against oracle/ppo_oracle.py's ZFilter
+    (surreal/model/z_filter.py:40-79) in float64"""
+    import ppo_oracle
+    g = torch.Generator().manual_seed(21)
+    for D, rows in ((17, 64), (376, 1000), (5, 7)):
+        x = torch.randn(rows, D, generator=g) * 3 + 0.5
+        cnt = 1000.0 + 1e-5
+        rs = torch.randn(D, generator=g) * 100
+        rsq = rs * rs / cnt + (torch.rand(D, generator=g) * 4 + 0.5) * cnt       # a valid state: variance 0.5 .. 4.5
+        state = dict(running_sum=rs.numpy(), running_sumsq=rsq.numpy(), count=np.array([cnt], dtype=np.float32))
+        md, sd, od = torch.empty(D).cuda(), torch.empty(D).cuda(), torch.empty(rows, D).cuda()
+        rs_d, rsq_d, cnt_d = dev(rs.clone()), dev(rsq.clone()), dev(torch.tensor([cnt]))
+        K.zfilter_stats(rs_d, rsq_d, cnt_d, 1e-5, md, sd)
+        K.zfilter_forward(dev(x), md, sd, od)
+        K.zfilter_update(dev(x), rs_d, rsq_d, cnt_d, rows)
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            Z = ppo_oracle.ZFilter(D, state=state)
+            want = Z.forward(x.double())
+            Z.z_update(x.double())
+        finally:
+            torch.set_default_dtype(prev)
+        close(od.cpu().double(), want, atol=5e-6, rtol=1e-5, msg='z-filtered rows vs float64, D=%d' % D)
+        close(rs_d.cpu().double(), Z.running_sum, rtol=1e-5, atol=1e-3, msg='running_sum')
+        close(rsq_d.cpu().double(), Z.running_sumsq, rtol=1e-5, atol=1e-2, msg='running_sumsq')
+        close(cnt_d.cpu().double(), Z.count, rtol=1e-6, atol=0, msg='count')
+
+
 @pytest.mark.parametrize('B,N,H', [(8, 12, 12), (37, 19, 19), (1024, 128, 128), (5, 25, 5),
                                    (64, 128, 5), (3, 200, 1), (2, 1, 1)])
 def test_windowed_gae(K, B, N, H):
@@ -102,6 +132,36 @@ def test_windowed_gae(K, B, N, H):
               0.995 ** N, B, N, N, ad, rd)
         v0 = values.view(B, N + 1)[:, 0]
         close(ad.cpu(), rd.cpu() - v0, atol=2e-5, rtol=1e-5, msg='lambda=1 telescoping')
+
+
+@pytest.mark.parametrize('B,N,H,rnn', [(8, 12, 12, False), (1024, 128, 128, False), (37, 19, 19, False), (5, 25, 5, True),
+                                       (64, 128, 5, True), (3, 40, 1, True)])
+def test_windowed_gae_against_the_reference_restatement(K, B, N, H, rnn):
+    """the same launch against oracle/ppo_oracle.py's gae_from_values (surreal/learner/ppo.py:389-418, both the
+    whole-trajectory rule and the LSTM policy's sliding windows of `horizon` steps) evaluated in float64 -- an oracle that
+    shares no code with the kernel's CPU double"""
+    import ppo_oracle
+    g = torch.Generator().manual_seed(B * 7 + N)
+    values = torch.randn(B, N + 1, generator=g) * 3
+    rewards = torch.randn(B, N, generator=g)
+    dones = (torch.rand(B, N, generator=g) < 0.1).float()
+    idx = torch.tensor(range(N), dtype=torch.float32)
+    gpow, lpow = torch.pow(0.995, idx), torch.pow(0.97, idx)
+    E = N - H + 1
+    ad, rd = torch.empty(B * E).cuda(), torch.empty(B * E).cuda()
+    K.gae(dev(values.reshape(-1)), dev(rewards), dev(dones), dev(gpow), dev(lpow), 0.995, 0.995 ** H, B, N, H, ad, rd)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        O = ppo_oracle.OraclePPOLearner.__new__(ppo_oracle.OraclePPOLearner)     # the arithmetic only: no model
+        O.gamma, O.lam, O.n_step, O.horizon, O.if_rnn_policy, O.norm_adv, O.batch_size = 0.995, 0.97, N, H, rnn, False, B
+        masked = values.double().clone()
+        masked[:, 1:] *= 1 - dones.double()                  # ppo.py:386
+        adv, ret = O.gae_from_values(masked, rewards.double())
+    finally:
+        torch.set_default_dtype(prev)
+    close(ad.cpu().double(), adv.reshape(-1), atol=2e-5, rtol=2e-5, msg='advantages vs float64')
+    close(rd.cpu().double(), ret.reshape(-1), atol=2e-5, rtol=2e-5, msg='returns vs float64')
 
 
 def test_moments_and_normalize(K):
