@@ -45,3 +45,18 @@ static __device__ __forceinline__ double smx_wave_sum_d(double v) {
 }
 
 static inline hipStream_t smx_s(smx_stream_t s) { return (hipStream_t)s; }
+
+// compute units of the current device (what bounds the workgroups a launch with in-launch waits may have); 64 if the
+// runtime cannot say
+static inline int smx_cu_count() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            n_cu = n;
+        else
+            n_cu = 64;
+    }
+    return n_cu;
+}

@@ -108,16 +108,6 @@ struct EArgs {
 };
 
 __device__ __forceinline__ EJob select_job(const EArgs& G, int bid) {
-    // one word of every 64-byte line of the job table, in the same batch of scalar loads as the block bases: the
-    // descriptor fetch below (its address depends on them) then finds its lines in the scalar cache instead of paying
-    // a second cold trip to the kernel-argument segment
-    {
-        const int* w = (const int*)&G.j[0];
-        int touch = 0;
-#pragma unroll
-        for (unsigned o = 0; o < sizeof(EJob) * MAX_EJOBS / 4; o += 16) touch |= w[o];
-        asm volatile("" :: "s"(touch));
-    }
     int pi = 0;
 #pragma unroll
     for (int k = 1; k < MAX_EJOBS; ++k) pi += (k < G.n && bid >= G.j[k].blk_base) ? 1 : 0;
@@ -1241,12 +1231,7 @@ extern "C" int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, 
         // it runs as the two launches it would replace (same results, the batch means cross a launch boundary).
         // Clip mode never waits inside the launch except in the grid's LAST workgroup, which is dispatched after
         // every other one: safe at any size.
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 64;
-        }
+        const int n_cu = smx_cu_count();
         const EJob& Lj0 = G.j[njobs - 1];
         const int blocks0 = Lj0.blk_base + smx_epoch_blocks(Lj0.rows);
         if (n_policy && loss->mode == SMX_PPO_ADAPT && blocks0 > n_cu) {

@@ -1296,13 +1296,7 @@ extern "C" int smx_mlp3_wgrad_adam_f32(const smx_mlp3_job_t* jobs, int32_t njobs
     build_wgrads(G, jobs, njobs);
     for (int k = 0; k < G.n; ++k)
         if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 64;
-    }
+    const int n_cu = smx_cu_count();
     const GemmProb& Lp = G.p[G.n - 1];
     const int blocks = Lp.tile_base + Lp.tiles_m * Lp.tiles_n;
     bool fused = blocks <= 2 * n_cu;              // every workgroup resident at once: two per CU (__launch_bounds__, LDS)
