@@ -78,6 +78,9 @@ def build_learner(mode, device_index, B=B, split_chains=False, use_graph=True):
     sc = ppo_session_config('/tmp/surreal_amd_bench')
     sc.learner.split_chains = bool(split_chains)
     sc.learner.use_hip_graph = bool(use_graph)
+    for kv in filter(None, os.environ.get('SMX_BENCH_LEARNER_OPTS', '').split(',')):     # A/B runs: key=0|1[,key=...]
+        k, v = kv.split('=')
+        sc.learner[k] = bool(int(v))
     learner = PPOLearner(lc, ppo_env_config(D, A), sc)
     params = synthetic.make_ppo_params(D, A, hidden=HIDDEN, seed=1)
     zstate = synthetic.make_zfilter_state(D, seed=2)
