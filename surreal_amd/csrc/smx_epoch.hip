@@ -32,6 +32,7 @@
 // The weight gradients (sums over ALL rows) stay a GEMM launch (smx_gemm.hip), clip-norm + Adam
 // one more: 4 dependent launches per epoch instead of 9.
 #include "smx_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 // workgroup barrier for data exchanged through LDS: does NOT wait for the wave's global stores
@@ -56,7 +57,7 @@ static_assert(NTH == 256, "the shared loss code strides by 256 threads");
 // Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer) exist
 // only in a build with -DSMX_EPOCH_TIMING (scripts/bench_epoch.py); the product build has none.
 #ifdef SMX_EPOCH_TIMING
-#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)ts_blk * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
@@ -104,8 +105,20 @@ struct EArgs {
     const int* pol_stop;   // ... and that job's early-exit flag (its workgroups return at once when it is up)
     unsigned long long* kl_slots;   // ... [nb_pol]: a row block's KL sum | 1 << 32, zero on entry
     int fsplit;
+    int xsplit;        // forward kernels, two jobs of xsplit row blocks each: job 0 on XCDs 0-3, job 1 on XCDs 4-7 (0: as dispatched)
     long long* tbuf;   // SMX_EPOCH_TIMING builds: per-workgroup phase timestamps (else null)
 };
+
+// Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  With the actor's row blocks first and the
+// critic's behind them, every XCD ran eight of each and pulled BOTH networks' packed weights (rewritten by the optimiser
+// launch, so every epoch's first touch is a trip to the memory side) into its L2: 2.2 MB per XCD and launch where 1.1 would do.
+// Two jobs of equal size: job 0's row blocks on XCDs 0-3, job 1's on XCDs 4-7.
+__device__ __forceinline__ int xcd_job_order(const EArgs& G, int raw) {
+    const int nb = G.xsplit;
+    if (nb == 0) return raw;
+    const int xcd = raw & 7, slot = raw >> 3;
+    return (xcd >> 2) * nb + slot * 4 + (xcd & 3);
+}
 
 __device__ __forceinline__ EJob select_job(const EArgs& G, int bid) {
     int pi = 0;
@@ -172,10 +185,13 @@ __device__ __forceinline__ void fb_reduce_partials(const float* __restrict__ par
 template <bool FB>
 __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* __restrict__ ctrl) {
     extern __shared__ float sm[];
+    const int bid = xcd_job_order(G, (int)blockIdx.x);
+    const int ts_blk = bid;
+    (void)ts_blk;
     TSTAMP(0);
-    const EJob J = select_job(G, (int)blockIdx.x);
+    const EJob J = select_job(G, bid);
     const int stopv = J.stop ? __builtin_nontemporal_load(J.stop) : 0;
-    const int blk = blockIdx.x - J.blk_base;
+    const int blk = bid - J.blk_base;
     const long row0 = (long)blk * ER;
     int nrows = J.rows - (int)row0;
     if (nrows > ER) nrows = ER;
@@ -687,6 +703,8 @@ __global__ __launch_bounds__(FNTH) void epoch_fb_kernel(EArgs G, smx_ppo_ctrl_t*
 __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
     extern __shared__ float sm[];
     __shared__ float S[8 + 2 * MAX_A];
+    const int ts_blk = blockIdx.x;
+    (void)ts_blk;
     TSTAMP(0);
     const EJob J = select_job(G, (int)blockIdx.x);
     const int fs = G.fsplit;
@@ -1156,6 +1174,11 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
         G.pl.stats = a.stats;
         G.vl.returns = a.returns; G.vl.v_dz3 = a.v_dz3; G.vl.v_partials = a.v_partials;
         G.vl.will_update = a.v_will_update;
+    }
+    if (!backward && njobs == 2 && fsplit == 1) {         // two jobs of equal size on the two halves of the XCDs (xcd_job_order)
+        const int nb0 = smx_epoch_blocks(jobs[0].rows), nb1 = smx_epoch_blocks(jobs[1].rows);
+        static const bool off = getenv("SMX_EPOCH_NO_XSPLIT") != nullptr;     // A/B switch for measurements
+        if (nb0 == nb1 && (nb0 & 3) == 0 && !off) G.xsplit = nb0;
     }
     // LDS carve-up: [x tile | h1 tile | h2 tile | out tile | K-split partials | loss scratch]
     // (the K loops run over an even number of 32-wide chunks: rows are zero padded to 64 columns)
