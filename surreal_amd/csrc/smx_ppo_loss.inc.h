@@ -247,8 +247,14 @@ __device__ __forceinline__ void policy_loss_body(
 // batch sums S[0 .. 8 + 2A) of the block partial rows: staged through LDS with coalesced loads and
 // added in row order (the order, hence the result, is the same in every workgroup)
 constexpr int FIN_CH = 64;                                   // partial rows staged per pass
+// 256 threads.  Column c of the partial rows is summed by Q = 256 / stride threads, thread (q, c) taking the rows
+// q, q + Q, ... of every staged chunk; the Q chains of a column meet in the fixed order ((s0 + s1) + s2) + ... -- the same
+// bits on every run and in every workgroup.  (One chain per column was 7936 dependent additions at the LSTM policy's
+// 127 k rows: 197 us per launch, every workgroup of the finalize walking all of them.)
 __device__ __forceinline__ void reduce_row_partials(const float* __restrict__ partials, int nblk,
                                                     int stride, float* S, float* buf) {
+    const int Q = 256 / stride;                       // stride <= 8 + 2 * MAX_A = 72: at least 3 chains
+    const int q = (int)threadIdx.x / stride, c = (int)threadIdx.x - q * stride;
     float t = 0.f;
     for (int b0 = 0; b0 < nblk; b0 += FIN_CH) {
         const int nb = min(FIN_CH, nblk - b0);
@@ -265,11 +271,17 @@ __device__ __forceinline__ void reduce_row_partials(const float* __restrict__ pa
                 if (i0 + 256 * u < cnt) buf[i0 + 256 * u] = v[u];
         }
         SMX_LDS_BARRIER();
-        if ((int)threadIdx.x < stride)
-            for (int b = 0; b < nb; ++b) t += buf[b * stride + threadIdx.x];
+        if (q < Q)
+            for (int b = q; b < nb; b += Q) t += buf[b * stride + c];
         SMX_LDS_BARRIER();
     }
-    if ((int)threadIdx.x < stride) S[threadIdx.x] = t;
+    if (q < Q) buf[q * stride + c] = t;
+    SMX_LDS_BARRIER();
+    if ((int)threadIdx.x < stride) {
+        float s = buf[threadIdx.x];
+        for (int k = 1; k < Q; ++k) s += buf[k * stride + threadIdx.x];
+        S[threadIdx.x] = s;
+    }
     SMX_LDS_BARRIER();
 }
 
