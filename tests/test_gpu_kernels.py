@@ -413,6 +413,67 @@ def test_policy_loss_and_finalize(K, mode, rows, A, on_policy):
     assert ci_d.tolist() == ci_c.tolist()           # stop flag / step counters agree
 
 
+@pytest.mark.parametrize('mode', ['clip', 'adapt'])
+@pytest.mark.parametrize('rows,A,kl_target', [(37, 5, 1e-3), (1024, 17, 1e-3), (130, 17, 10.0), (7936, 6, 0.015)])
+def test_policy_loss_and_finalize_against_the_reference_restatement(K, mode, rows, A, kl_target):
+    """the layered loss launches (the stem policies' and the data-parallel path's: smx_ppo_policy_loss_f32 +
+    smx_ppo_loss_finalize_f32) against oracle/ppo_oracle.py's _clip_loss / _adapt_loss (surreal/learner/ppo.py:194-285)
+    in float64 with autograd through tanh: d loss / d z3 for every row, d loss / d log_var, and the statistics -- with the
+    KL cutoff term active (kl_target 1e-3 / 0.015) and not (10)"""
+    import ppo_oracle
+    g = torch.Generator().manual_seed(rows * 3 + A)
+    log_var = torch.full((A,), -1.0) + 0.1 * torch.randn(A, generator=g)
+    std = torch.exp(log_var)
+    z3 = 0.3 * torch.randn(rows, A, generator=g)
+    mean = torch.tanh(z3)
+    mb = mean + 0.05 * torch.randn(rows, A, generator=g)
+    actions = (mb + std * torch.randn(rows, A, generator=g)).clamp(-1, 1)
+    behave = torch.cat([mb, (std * 1.1).expand(rows, A)], 1).contiguous()
+    ref = torch.cat([mean + 0.02 * torch.randn(rows, A, generator=g), (std * 0.9).expand(rows, A)], 1).contiguous()
+    adv = torch.randn(rows, generator=g)
+    m = L.SMX_PPO_ADAPT if mode == 'adapt' else L.SMX_PPO_CLIP
+    ctrl = torch.zeros(L.CTRL_WORDS)
+    ctrl[L.C_BETA], ctrl[L.C_ETA], ctrl[L.C_CLIP_EPS], ctrl[L.C_KL_TARGET] = 1.0, 250.0, 0.2, kl_target
+    ctrl = ctrl.cuda()
+    nblk = K.loss_blocks(rows)
+    gs, gk, part = torch.empty(rows, A).cuda(), torch.empty(rows, A).cuda(), torch.zeros(nblk, 8 + 2 * A).cuda()
+    K.policy_loss(m, dev(mean), dev(log_var), dev(actions), dev(behave), dev(ref), dev(adv), ctrl, gs, gk, part)
+    dz3, dlv, dq, st = torch.empty(rows, A).cuda(), torch.empty(A).cuda(), torch.empty(1).cuda(), torch.zeros(L.PS_STRIDE).cuda()
+    K.policy_finalize(m, part, nblk, gs, gk, dev(log_var), rows, ctrl, False, True, dz3, dlv, dq, st)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        O = ppo_oracle.OraclePPOLearner.__new__(ppo_oracle.OraclePPOLearner)     # the losses only: a stand-in model
+        O.pd, O.cells, O.beta, O.eta, O.kl_target, O.clip_epsilon = ppo_oracle.DiagGauss(A), None, 1.0, 250.0, kl_target, 0.2
+        z = z3.double().clone().requires_grad_(True)
+        lv = log_var.double().clone().view(1, A).requires_grad_(True)
+
+        class Stand(object):
+            def forward_actor(self, obs, cells=None):        # builders.py:114-132 with the MLP's output given
+                mu = torch.tanh(z)
+                return torch.cat((mu, torch.exp(lv) * torch.ones(mu.size())), dim=1)
+        O.model = Stand()
+        if mode == 'adapt':
+            loss, stats = O._adapt_loss(None, actions.double(), adv.double(), behave.double(), ref.double())
+        else:
+            loss, stats = O._clip_loss(None, actions.double(), adv.double(), behave.double())
+        loss.backward()
+    finally:
+        torch.set_default_dtype(prev)
+    # gradients scale with the cutoff coefficient when it is active: tolerances relative to the largest entry
+    for got, want, nm in ((dz3, z.grad, 'd loss / d z3'), (dlv, lv.grad.view(-1), 'd loss / d log_var')):
+        tol = 2e-5 * float(want.abs().max()) + 1e-10
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= tol, (nm, err, tol)
+    s = st.cpu()
+    np.testing.assert_allclose(float(s[L.PS_SURR]), stats['_surr_loss'], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(float(s[L.PS_ENTROPY]), stats['_entropy'], rtol=2e-5)
+    np.testing.assert_allclose(float(s[L.PS_LOSS]), stats['_kl_loss_adapt' if mode == 'adapt' else '_clip_surr_loss'],
+                               rtol=5e-5, atol=2e-6)
+    if mode == 'adapt':
+        np.testing.assert_allclose(float(s[L.PS_KL]), stats['_pol_kl'], rtol=2e-5, atol=1e-7)
+
+
 def test_value_loss(K):
     g = torch.Generator().manual_seed(11)
     for rows in (8, 37, 1024, 1500):
