@@ -40,6 +40,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_T0 = time.time()            # the run's wall clock starts at import (--budget-s counts from here)
 
 from surreal_amd import synthetic  # noqa: E402
 from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config  # noqa: E402
@@ -186,6 +187,40 @@ def host_cpu():
             'logical_cpus': logical}
 
 
+def reference_learn_fn(params, zstate, batch, Bs, Ns, Ds, As, hyper, pixel=None):
+    """a callable that runs ONE learn of the REFERENCE'S OWN learner (surreal/learner/ppo.py `_preprocess_batch_ppo` +
+    `_optimize`) on `batch`, or None.  The code that runs is the reference's, byte-compiled from /root/reference by
+    oracle/make_ref.py into the git-ignored oracle/_ref/ (which ships with the tree snapshot), under the third-party
+    stand-ins of oracle/ref_shims.py -- cpu_baseline.kind "reference".  None where oracle/_ref was not built."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    try:
+        import ref_shims
+        if not ref_shims.reference_available():
+            return None
+        ref = ref_shims.import_reference()
+        import gen_golden as G
+        Lr = G.build_reference_learner(ref, params, zstate, Bs, Ns, Ds, As, dict(hyper, n_step=Ns), pixel=pixel)
+    except Exception as e:
+        sys.stderr.write('[bench.py] the reference learner could not be built: %r\n' % (e,))
+        return None
+
+    def learn():
+        bd = ref_shims.BeneDict(copy.deepcopy(batch))
+        bd = Lr._preprocess_batch_ppo(bd)
+        Lr._optimize(bd.obs, bd.actions, bd.rewards, bd.obs_next, bd.persistent_infos, bd.onetime_infos, bd.dones)
+    return learn
+
+
+def _timed_learns(fn, budget_s, at_least=2, at_most=10):
+    fn()                                    # warm-up
+    t0, times = time.time(), []
+    while len(times) < at_least or (time.time() - t0 < budget_s and len(times) < at_most):
+        t1 = time.time()
+        fn()
+        times.append(time.time() - t1)
+    return sum(times) / len(times), len(times)
+
+
 def cpu_baseline(mode, params, zstate, batch, budget_s=30.0):
     """the reference learner's CPU path (oracle restatement, same ATen ops) on this host, swept over
     torch.set_num_threads (n = physical cores AND n = 1; more threads than the GEMMs
@@ -197,12 +232,12 @@ def cpu_baseline(mode, params, zstate, batch, budget_s=30.0):
     counts = sorted({n for n in (1, 8, 16, 32, 64, cpu['physical_cores']) if 1 <= n <= cpu['logical_cpus']})
     O = ppo_oracle.OraclePPOLearner(params, A, B, zstate=zstate, n_step=N, ppo_mode=mode, kl_target=1e9)
     sweep = []
-    per = budget_s / len(counts)
+    per = budget_s / (len(counts) + 1)
     for n in counts:
         torch.set_num_threads(n)
         O.learn(copy.deepcopy(batch))        # warm-up at this thread count
         t0, k, times = time.time(), 0, []
-        while k < 3 or (time.time() - t0 < per and k < 20):      # at least three timed learns per thread count
+        while k < 2 or (time.time() - t0 < per and k < 20):      # at least two timed learns per thread count
             t1 = time.time()
             O.learn(copy.deepcopy(batch))
             times.append(time.time() - t1)
@@ -210,15 +245,24 @@ def cpu_baseline(mode, params, zstate, batch, budget_s=30.0):
         dt = (time.time() - t0) / k
         sweep.append({'threads': n, 's_per_learn': dt, 'env_steps_per_s': B * N / dt, 'learns': k,
                       's_per_learn_min': min(times), 's_per_learn_max': max(times)})
-    torch.set_num_threads(prev)
     best = max(sweep, key=lambda r: r['env_steps_per_s'])
     one = [r for r in sweep if r['threads'] == 1][0]
-    return {'value': best['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': best['threads'], 'kind': 'port',
-            'sample': 'learn() on the full 1024x128x376 batch (10+10 epochs, %s mode), torch %s CPU, one warm-up + '
-                      '>= 3 timed calls per thread count, best mean of the sweep (%.3f s per learn at %d threads)'
-                      % (mode, torch.__version__, best['s_per_learn'], best['threads']),
-            'single_thread': one['env_steps_per_s'], 'sweep': sweep, 'cpu_model': cpu['model'],
-            'physical_cores': cpu['physical_cores'], 'logical_cpus': cpu['logical_cpus']}
+    port = {'value': best['env_steps_per_s'], 'cores': best['threads'], 's_per_learn': best['s_per_learn']}
+    out = {'value': port['value'], 'unit': 'env-steps/s', 'cores': port['cores'], 'kind': 'port',
+           'sample': 'learn() on the full 1024x128x376 batch, 10+10 epochs, %s mode, torch %s CPU, 1 warm-up + >= 2 timed '
+                     'learns per thread count, best of the sweep' % (mode, torch.__version__),
+           'single_thread': one['env_steps_per_s'], 'sweep': sweep, 'cpu_model': cpu['model'],
+           'physical_cores': cpu['physical_cores'], 'logical_cpus': cpu['logical_cpus'], 'port': port}
+    # the reference's own code (oracle/_ref) at the port's best thread count: the baseline quoted is the FASTER of the two
+    fn = reference_learn_fn(params, zstate, batch, B, N, D, A, dict(ppo_mode=mode, kl_target=1e9))
+    if fn is not None:
+        torch.set_num_threads(best['threads'])
+        dt, k = _timed_learns(fn, per)
+        out['reference'] = {'value': B * N / dt, 'cores': best['threads'], 's_per_learn': dt, 'learns': k}
+        if out['reference']['value'] >= port['value']:
+            out.update(value=out['reference']['value'], kind='reference')
+    torch.set_num_threads(prev)
+    return out
 
 
 # ---- the other BASELINE configurations (N = 1 only; a few steps each) -----------------------------
@@ -313,6 +357,7 @@ def priced(dt, flops, bytes_, units, unit_name):
             unit_name + '_per_s': units / dt}
 
 
+_CPU_BUDGET = [12.0]        # seconds the next secondary's CPU leg may take (set by secondaries())
 _CPU_THREADS = [None]      # the best thread count of the headline's sweep (cpu_baseline); else the physical cores, <= 32
 
 
@@ -320,22 +365,26 @@ def _cpu_threads():
     return _CPU_THREADS[0] or max(1, min(32, host_cpu()['physical_cores']))
 
 
-def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=12.0, sample_rows=None):
+def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=None, sample_rows=None, mode='adapt'):
     """the CPU restatement of the reference learner (oracle/ppo_oracle.py, kind "port") on this host for the same
     configuration: one warm-up + timed learns inside the budget (at least one); sample_rows: a row subset of the batch
     for configurations whose full learn takes minutes on a CPU (the rate is per env-step)"""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import ppo_oracle
+    budget_s = _CPU_BUDGET[0] if budget_s is None else budget_s
     prev = torch.get_num_threads()
     if sample_rows and sample_rows < Bs:
         batch = slice_batch(batch, 0, sample_rows)
         Bs = sample_rows
-    kw = dict(n_step=Ns, kl_target=1e9)
+    kw = dict(n_step=Ns, kl_target=1e9, ppo_mode=mode)
     if rnn:
         kw.update(if_rnn_policy=True, horizon=5)
     best = None
+    t_start = time.time()
     # the headline's best thread count and 8 (small GEMMs get slower with more threads): the better of the two
     for n in sorted({8, _cpu_threads()}):
+        if best is not None and time.time() - t_start > budget_s / 2:      # the first thread count used the budget up
+            break
         torch.set_num_threads(n)
         O = ppo_oracle.OraclePPOLearner(params, As, Bs, **kw)
         t0 = time.time()
@@ -350,20 +399,41 @@ def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=12.0, sample_row
         dt = sum(times) / len(times)
         if best is None or dt < best[0]:
             best = (dt, n, len(times), cold)
-    torch.set_num_threads(prev)
     dt, n, k, cold = best
-    return {'value': Bs * Ns / dt, 'unit': 'env-steps/s', 'cores': n, 'kind': 'port', 's_per_learn': dt,
-            'sample': '%d timed learn(s) of %d x %d (%s), oracle/ppo_oracle.py, torch %s CPU, the better of 8 and %d threads%s' % (
-                k, Bs, Ns, 'full batch' if not sample_rows else 'the first %d sub-trajectories of the batch' % Bs,
-                torch.__version__, _cpu_threads(), ' (single call, no warm-up: one learn takes seconds)' if cold else '')}
+    out = {'value': Bs * Ns / dt, 'unit': 'env-steps/s', 'cores': n, 'kind': 'port', 's_per_learn': dt,
+           'sample': '%d timed learn(s) of %d x %d (%s), torch %s CPU, the better of 8 and %d threads%s' % (
+               k, Bs, Ns, 'full batch' if not sample_rows else 'the first %d sub-trajectories of the batch' % Bs,
+               torch.__version__, _cpu_threads(), ' (single call, no warm-up: one learn takes seconds)' if cold else '')}
+    out['port'] = {'value': out['value'], 'cores': n, 's_per_learn': dt}
+    # the reference's own code at the same thread count, when oracle/_ref is there and the budget allows one more leg:
+    # the baseline quoted is the faster of the two (the port is ~20 % slower than the reference on the LSTM policy)
+    if time.time() - t_start < budget_s:
+        fn = reference_learn_fn(params, None, batch, Bs, Ns, Ds, As, kw, pixel=pixel)
+        if fn is not None:
+            try:
+                torch.set_num_threads(n)
+                if cold:
+                    t1 = time.time()
+                    fn()
+                    rdt, rk = time.time() - t1, 1
+                else:
+                    rdt, rk = _timed_learns(fn, max(0.0, budget_s - (time.time() - t_start)) / 2, at_least=1, at_most=5)
+                out['reference'] = {'value': Bs * Ns / rdt, 'cores': n, 's_per_learn': rdt, 'learns': rk}
+                if out['reference']['value'] >= out['value']:
+                    out.update(value=out['reference']['value'], kind='reference', s_per_learn=rdt)
+            except Exception as e:
+                out['reference'] = {'error': repr(e)}
+    torch.set_num_threads(prev)
+    return out
 
 
-def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5, cpu=True, cpu_sample_rows=None):
+def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5, cpu=True, cpu_sample_rows=None, mode='adapt'):
     from surreal_amd.learner.ppo import PPOLearner
     lc = ppo_learner_config()
     lc.algo.n_step = Ns
     lc.algo.stride = Ns
     lc.algo.rnn.if_rnn_policy = rnn
+    lc.algo.ppo_mode = mode
     lc.algo.consts.kl_target = 1e9
     lc.replay.batch_size = Bs
     L = PPOLearner(lc, ppo_env_config(Ds, As, pixel=pixel), ppo_session_config('/tmp/surreal_amd_bench2'))
@@ -374,7 +444,7 @@ def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5, cpu=True, cpu_sample
     flops, bytes_, parts = ppo_costs(Bs, Ns, Ds, As, rnn=rnn, pixel=pixel, F=F)
     out = {'ms_per_learn': dt * 1e3, 'env_steps_per_s': Bs * Ns / dt, 'B': Bs, 'n_step': Ns, 'obs_dim': Ds,
            'action_dim': As, 'policy': ('cnn+' if pixel else '') + ('lstm100(H=5)+mlp' if rnn else 'mlp'),
-           'epochs': '10+10, KL early exit disabled', 'roofline': priced(dt, flops, bytes_, Bs * Ns, 'env_steps')}
+           'mode': mode, 'epochs': '10+10, KL early exit disabled', 'roofline': priced(dt, flops, bytes_, Bs * Ns, 'env_steps')}
     try:
         rows, steps_all = parts['rows_per_epoch'], parts['steps_all']
         rec = 2.0 * 4 * F * F if rnn else 0.0               # the recurrent product of one row-step
@@ -399,7 +469,7 @@ def secondary_ppo(Bs, Ns, Ds, As, rnn, pixel=None, steps=5, cpu=True, cpu_sample
     if cpu:
         try:
             params = L.model.numpy_params()            # the same (randomly initialised) parameters on both sides
-            out['cpu_baseline'] = cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, sample_rows=cpu_sample_rows)
+            out['cpu_baseline'] = cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, sample_rows=cpu_sample_rows, mode=mode)
             out['gpu_over_cpu'] = out['env_steps_per_s'] / out['cpu_baseline']['value']
         except Exception as e:
             out['cpu_baseline'] = {'error': repr(e)}
@@ -653,42 +723,185 @@ def secondary_host_fed(iters=12):
 
 
 def _summary_key(key):
-    for tag, short in (('configs[0]', 'configs[0] PPO 2x25 LSTM'), ('64x128, MLP', 'configs[1] PPO 64x128 MLP'),
-                       ('64x128, LSTM', 'configs[1] PPO 64x128 LSTM'), ('PPO 1024x128', 'PPO 1024x128 LSTM'),
-                       ('configs[2]', 'configs[2] DDPG 512 of 1e6'), ('configs[3] PPO', 'configs[3] PPO 256x32 pixel CNN+LSTM')):
+    for tag, short in (('configs[0]', 'cfg0 PPO 2x25 LSTM'), ('64x128, MLP', 'cfg1 PPO 64x128 MLP'),
+                       ('64x128, LSTM', 'cfg1 PPO 64x128 LSTM'), ('PPO 1024x128, D=17', 'PPO 1024x128 D17 LSTM'),
+                       ('configs[2]', 'cfg2 DDPG 512 of 1e6'), ('configs[3] PPO', 'cfg3 PPO 256x32 pixel CNN+LSTM'),
+                       ('configs[4] clip', 'cfg4 clip MLP'), ('configs[4] LSTM, adapt', 'cfg4 adapt LSTM'),
+                       ('configs[4] LSTM, clip', 'cfg4 clip LSTM'),
+                       ('configs[3] on-device', 'loop 256x32 pixel'), ('4096 actors', 'loop 4096x128'),
+                       ('one rollout ahead', 'loop 1024x128 overlapped'), ('on-device loop, 1024', 'loop 1024x128'),
+                       ('host-fed', 'host-fed')):
         if tag in key:
             return short
-    return key[:60]
+    return key[:40]
 
 
-def secondaries():
+def secondaries(which='core', deadline=None, cpu=True):
+    """the other BASELINE configurations, most important first.  `deadline` (time.time() value): an entry that would
+    start after it is skipped and says so; the CPU legs get what is left, split evenly over the entries still to run
+    (at least one timed learn each -- a CPU learn of the largest shapes runs on a row sample)."""
+    core = [
+        # BASELINE.md section 2's cfg-5 mode matrix: {clip, adapt} x {MLP, LSTM(100) H=5} at D=376, A=17 (adapt x MLP is the headline)
+        ('configs[4] clip mode, MLP policy: 1024x128x376, A=17',
+         lambda c: secondary_ppo(B, N, D, A, False, steps=5, cpu=c, mode='clip', cpu_sample_rows=256)),
+        ('configs[4] LSTM, adapt: 1024x128x376, A=17, LSTM(100) H=5 + MLP',
+         lambda c: secondary_ppo(B, N, D, A, True, steps=3, cpu=c, cpu_sample_rows=64)),
+        ('configs[4] LSTM, clip: 1024x128x376, A=17, LSTM(100) H=5 + MLP',
+         lambda c: secondary_ppo(B, N, D, A, True, steps=3, cpu=c, mode='clip', cpu_sample_rows=64)),
+        ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
+         lambda c: secondary_ppo(64, 128, 17, 6, True, cpu=c)),
+        ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda c: secondary_ppo(64, 128, 17, 6, False, cpu=c)),
+        ('configs[2] DDPG HalfCheetah shapes, uniform replay 1e6, batch 512', lambda c: secondary_ddpg(cpu=c)),
+        ('configs[3] PPO 256 actors x 32 steps, 3x84x84 uint8 frames + 32-d state, CNN + LSTM policy',
+         lambda c: secondary_ppo(256, 32, 32, 8, True, pixel=(3, 84, 84), steps=3, cpu=c, cpu_sample_rows=32)),
+        ('configs[0] PPO 2x25 D=17 A=6, LSTM policy (the shape of the reference test_ppo_gym --unit-test)',
+         lambda c: secondary_ppo(2, 25, 17, 6, True, steps=10, cpu=c)),
+        ('PPO 1024x128, D=17, A=6, LSTM policy (the reference default at the benchmark batch)',
+         lambda c: secondary_ppo(1024, 128, 17, 6, True, steps=3, cpu=c, cpu_sample_rows=128)),
+        ('on-device loop, 1024 actors x 128 steps (act + env step + windows + FIFO + learn)',
+         lambda c: secondary_pipeline(1024)),
+    ]
+    extra = [
+        ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout', lambda c: secondary_pipeline(4096)),
+        ('on-device loop, 1024 actors x 128 steps, actors one rollout ahead of the learner (two streams)',
+         lambda c: secondary_pipeline(1024, overlap=True)),
+        ('configs[3] on-device loop: 256 actors x 32 steps, 3x84x84 uint8 camera + 32-d state, CNN + LSTM policy',
+         lambda c: secondary_pixel_pipeline()),
+        ('host-fed learner: 1024 x 128 x 376 batches from host memory (pinned double-buffered ingest)',
+         lambda c: secondary_host_fed()),
+    ]
+    todo = core + (extra if which == 'all' else [])
     out = {}
-    for key, fn in (
-            ('on-device loop, 1024 actors x 128 steps (act + env step + windows + FIFO + learn)',
-             lambda: secondary_pipeline(1024)),
-            ('on-device loop, 4096 actors x 128 steps feeding 4 learns per rollout', lambda: secondary_pipeline(4096)),
-            ('on-device loop, 1024 actors x 128 steps, actors one rollout ahead of the learner (two streams)',
-             lambda: secondary_pipeline(1024, overlap=True)),
-            ('configs[3] on-device loop: 256 actors x 32 steps, 3x84x84 uint8 camera + 32-d state, CNN + LSTM policy',
-             secondary_pixel_pipeline),
-            ('host-fed learner: 1024 x 128 x 376 batches from host memory (pinned double-buffered ingest)', secondary_host_fed),
-            ('configs[0] PPO 2x25 D=17 A=6, LSTM policy (the shape of the reference test_ppo_gym --unit-test)',
-             lambda: secondary_ppo(2, 25, 17, 6, True, steps=10)),
-            ('configs[1] PPO HalfCheetah shapes 64x128, MLP policy', lambda: secondary_ppo(64, 128, 17, 6, False)),
-            ('configs[1] PPO HalfCheetah shapes 64x128, LSTM policy (reference default)',
-             lambda: secondary_ppo(64, 128, 17, 6, True)),
-            ('PPO 1024x128, D=17, A=6, LSTM policy (the reference default at the benchmark batch)',
-             lambda: secondary_ppo(1024, 128, 17, 6, True, steps=3)),
-            ('configs[2] DDPG HalfCheetah shapes, uniform replay 1e6, batch 512', secondary_ddpg),
-            ('configs[3] PPO 256 actors x 32 steps, 3x84x84 uint8 frames + 32-d state, CNN + LSTM policy',
-             lambda: secondary_ppo(256, 32, 32, 8, True, pixel=(3, 84, 84), steps=3, cpu_sample_rows=32))):
+    for i, (key, fn) in enumerate(todo):
+        now = time.time()
+        if deadline is not None and now > deadline:
+            out[key] = {'skipped': 'time budget (--budget-s) spent before this entry'}
+            continue
+        # the CPU leg's share of what is left: even split over the entries still to come, >= 1.5 s, <= 12 s
+        _CPU_BUDGET[0] = 12.0 if deadline is None else min(12.0, max(1.5, 0.6 * (deadline - now) / (len(todo) - i)))
         try:
-            out[key] = fn()
+            out[key] = fn(cpu)
         except Exception as e:       # a secondary must never take the headline line down
             out[key] = {'error': repr(e)}
+        if isinstance(out[key], dict):
+            out[key]['wall_s'] = time.time() - now
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
     return out
+
+
+# ---- the ONE stdout line: <= 4 KB (the driver keeps an 8 KB tail); everything else goes to --full-out -------------
+LINE_LIMIT = 4096
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the full-precision figures are in the --full-out record)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float('%.*g' % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def summary_row(r):
+    """<= 6 keys per secondary configuration: rate | ms | whole-learn fraction of its bounding roof | the dominant
+    kernel family's own fraction | the CPU baseline (value@cores, kind) | GPU / CPU"""
+    if not isinstance(r, dict):
+        return None
+    if 'error' in r or 'skipped' in r:
+        return {'error': str(r.get('error', r.get('skipped')))[:80]}
+    row = {'rate': r.get('env_steps_per_s', r.get('samples_per_s')), 'ms': r.get('ms_per_learn', r.get('ms_per_iteration'))}
+    if row['rate'] is None:          # an entry of sub-entries (the host-fed learner's producers): the best of them
+        subs = [v for v in r.values() if isinstance(v, dict) and 'env_steps_per_s' in v]
+        if subs:
+            best = max(subs, key=lambda v: v['env_steps_per_s'])
+            row = {'rate': best['env_steps_per_s'], 'ms': best.get('ms_per_batch')}
+    rf = r.get('roofline')
+    if isinstance(rf, dict):
+        row['frac_' + str(rf.get('bound', 'mfma'))] = rf.get('frac_of_fp32_peak') if rf.get('bound') == 'mfma' else rf.get('frac_of_hbm_peak')
+    dk = r.get('dominant_kernel')
+    if isinstance(dk, dict) and dk.get('frac') is not None:
+        row['dom_frac'] = dk['frac']
+    cb = r.get('cpu_baseline')
+    if isinstance(cb, dict) and cb.get('value') is not None:
+        row['cpu'] = '%.4g@%d %s' % (cb['value'], cb.get('cores', 0), cb.get('kind', 'port'))
+        row['x_cpu'] = r.get('gpu_over_cpu')
+    return {k: v for k, v in row.items() if v is not None}
+
+
+def compact_line(full, full_path=None):
+    """the driver-facing line from the full record: the contract's keys, `roofline`, `step_roofline`, `cpu_baseline`,
+    `secondary_summary`; shrunk further (summary first, then optional keys) if it would still exceed LINE_LIMIT"""
+    out = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling'))
+    for k in ('value', 'ms_per_step'):                 # null is meaningful here (diagnostic line)
+        out.setdefault(k, full.get(k))
+    out['vs_baseline'] = full.get('vs_baseline')
+    out.update(_pick(full, ('dtype', 'data', 'error')))
+    cfg = full.get('config', {})
+    out['config'] = _pick(cfg, ('workload', 'mode', 'B_per_gpu', 'n_step', 'obs_dim', 'action_dim', 'hidden', 'epochs', 'hip_graph',
+                                'parallelism', 'epoch_kernels', 'collectives_per_step', 'exchange', 'epoch_all_reduce_us',
+                                'epoch_all_reduce_bytes', 'graph_segments'))
+    if 'roofline' in full:
+        out['roofline'] = _pick(full['roofline'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                                   'mfma_busy_pct', 'kernel_ms', 'algorithmic_bytes_per_launch',
+                                                   'flops_per_launch', 'share_of_step'))
+        out['roofline'].setdefault('traffic', None)
+    if 'step_roofline' in full:
+        out['step_roofline'] = _pick(full['step_roofline'], ('mfma_frac', 'hbm_frac', 'algorithmic_flops_per_learn',
+                                                             'algorithmic_bytes_per_learn'))
+    if 'cpu_baseline' in full:
+        out['cpu_baseline'] = _pick(full['cpu_baseline'], ('value', 'unit', 'cores', 'kind', 'sample', 'single_thread', 'cpu_model',
+                                                           'physical_cores', 'port', 'reference'))
+        out.update(_pick(full, ('gpu_over_cpu', 'gpu_over_cpu_single_thread')))
+    if 'strong' in full:
+        out['strong'] = _pick(full['strong'], ('value', 'unit', 'ms_per_step', 'global_batch', 'B_per_gpu', 'hip_graph'))
+    if 'exchange_model' in full:
+        out['exchange_model'] = _pick(full['exchange_model'], ('exchange_ms_per_step', 'share_of_step', 'predicted_efficiency'))
+    if 'secondary' in full:
+        out['secondary_summary'] = {_summary_key(k): summary_row(r) for k, r in full['secondary'].items()
+                                    if summary_row(r) is not None}
+    out.update(_pick(full, ('bench_wall_s',)))
+    if full_path:
+        out['full_record'] = full_path
+    out = _r(out)
+    line = json.dumps(out)
+    # belt and braces: never hand the driver a line it cannot keep whole
+    for drop in ('exchange_model', 'strong', 'step_roofline'):
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out)
+    while len(line) > LINE_LIMIT and out.get('secondary_summary'):
+        out['secondary_summary'].popitem()
+        line = json.dumps(out)
+    if len(line) > LINE_LIMIT:
+        out['config'] = _pick(out['config'], ('workload', 'parallelism'))
+        out['config']['workload'] = out['config'].get('workload', '')[:120]
+        line = json.dumps(out)
+    return line
+
+
+def write_full(full, path):
+    """the complete record (every configuration's full entry) as a file; returns the path written, or None"""
+    if not path:
+        return None
+    try:
+        d = os.path.dirname(os.path.abspath(path))
+        os.makedirs(d, exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+    except OSError as e:
+        sys.stderr.write('[bench.py] could not write %s: %r\n' % (path, e))
+        return None
 
 
 def main():
@@ -703,6 +916,14 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: 1024 sub-trajectories per GPU (the headline); strong: 1024 in total')
     ap.add_argument('--no-secondary', action='store_true', help='skip the other BASELINE configurations')
+    ap.add_argument('--secondary', default='core', choices=['core', 'all'],
+                    help='core: the BASELINE configurations + the 1024-actor on-device loop (fits the default budget); '
+                         'all: also the 4096-actor / overlapped / pixel loops and the host-fed learner')
+    ap.add_argument('--budget-s', type=float, default=70.0,
+                    help='wall-clock budget of the whole run: CPU baselines shrink to what is left, secondaries that '
+                         'would start after it are skipped (and say so)')
+    ap.add_argument('--full-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_full.json'),
+                    help='the complete record (the stdout line is its <= 4 KB summary); "" to skip')
     ap.add_argument('--schedule', default='lockstep', choices=['lockstep', 'two_stream'],
                     help='epoch launch schedule (session_config.learner.epoch_schedule)')
     args = ap.parse_args()
@@ -762,11 +983,11 @@ def _exchange_failure():
 def diagnostic(args, why, rank=0):
     """the ONE JSON line when no measurement could be made (value null + the reason)"""
     if rank == 0:
-        print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'env-steps/s', 'n_gpus': args.gpus, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': args.scaling,
-                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                          'config': {'workload': 'BASELINE configs[4]', 'parallelism': 'dp%d' % args.gpus},
-                          'error': why}), flush=True)
+        print(compact_line({'metric': METRIC, 'value': None, 'unit': 'env-steps/s', 'n_gpus': args.gpus, 'steps': args.steps,
+                            'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': args.scaling,
+                            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                            'config': {'workload': 'BASELINE configs[4]', 'parallelism': 'dp%d' % args.gpus},
+                            'error': str(why)[-1500:]}), flush=True)
 
 
 def self_launch(args):
@@ -892,10 +1113,10 @@ def run(args, world, rank, local_rank, backend):
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[4]: PPO synthetic 1024 actors x 128 steps x 376-dim '
-                            'obs %s, A=17, MLP [300,200], z-filter, %s mode, 10 policy + 10 '
-                            'value epochs (KL early exit disabled), batch resident in HBM' % (
-                                'per GPU' if args.scaling == 'weak' else 'in total, split over the GPUs', args.mode),
+                'workload': 'BASELINE configs[4]: PPO synthetic 1024 actors x 128 steps x 376-dim obs %s, one learn() '
+                            'per step, batch resident in HBM' % (
+                                'per GPU' if args.scaling == 'weak' else 'in total, split over the GPUs'),
+                'mode': args.mode, 'hidden': list(HIDDEN), 'epochs': '10 policy + 10 value, KL early exit disabled',
                 'B_per_gpu': ws.key[0], 'n_step': N, 'obs_dim': D, 'action_dim': A,
                 'hip_graph': bool(learner.use_graph), 'parallelism': 'dp%d' % world,
                 'epoch_kernels': 'fused row-block' if getattr(ws, 'fused', False) else 'layered',
@@ -914,7 +1135,7 @@ def run(args, world, rank, local_rank, backend):
             traffic, tsrc = measured_traffic(rows)
             busy, bsrc = measured_mfma_util(rows)
             out['roofline'] = {
-                'kernel': 'mlp3_rows16_kernel<19,13,true> (z-filter + critic MLP over %d rows, smx_mlp3_rows16.hip)' % rows,
+                'kernel': 'mlp3_rows16_kernel<19,13,true> (z-filter + critic MLP, %d rows)' % rows,
                 'bound': 'mfma',
                 'achieved': flops / kt / 1e12,
                 'peak': PEAK_FP32_MFMA_TFLOPS,
@@ -954,33 +1175,16 @@ def run(args, world, rank, local_rank, backend):
             out['strong'] = strong
         if world == 1 and args.scaling == 'weak':
             if not args.no_cpu_baseline:
-                out['cpu_baseline'] = cpu_baseline(args.mode, params, zstate, batch)
+                out['cpu_baseline'] = cpu_baseline(args.mode, params, zstate, batch, budget_s=min(15.0, 0.25 * args.budget_s))
                 out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
                 out['gpu_over_cpu_single_thread'] = out['value'] / out['cpu_baseline']['single_thread']
                 _CPU_THREADS[0] = out['cpu_baseline']['cores']
             if not args.no_secondary:
                 del learner, dbatch
                 torch.cuda.empty_cache()
-                out['secondary'] = secondaries()
-                # the other BASELINE configurations at a glance (the full records are in `secondary`):
-                # rate | whole-learn fraction of the FP32 peak | dominant kernel (share, its own fraction) | GPU / CPU
-                summ = {}
-                for key, r in out['secondary'].items():
-                    if not isinstance(r, dict) or 'roofline' not in r:
-                        continue
-                    dk = r.get('dominant_kernel', {})
-                    cb = r.get('cpu_baseline', {})
-                    summ[_summary_key(key)] = {
-                        'rate': r.get('env_steps_per_s', r.get('samples_per_s')),
-                        'unit': 'env-steps/s' if 'env_steps_per_s' in r else 'samples/s',
-                        'ms': r.get('ms_per_learn', r.get('ms_per_iteration')),
-                        'frac_of_fp32_peak': r['roofline']['frac_of_fp32_peak'],
-                        'frac_of_hbm_peak': r['roofline']['frac_of_hbm_peak'],
-                        'dominant_kernel': dk.get('name'), 'dominant_share': dk.get('share_of_device_time'),
-                        'dominant_frac': dk.get('frac'),
-                        'cpu_baseline': cb.get('value'), 'cpu_cores': cb.get('cores'), 'gpu_over_cpu': r.get('gpu_over_cpu')}
-                out['secondary_summary'] = summ
-        print(json.dumps(out), flush=True)
+                out['secondary'] = secondaries(args.secondary, _T0 + args.budget_s, cpu=not args.no_cpu_baseline)
+        out['bench_wall_s'] = time.time() - _T0
+        print(compact_line(out, write_full(out, args.full_out)), flush=True)
     if world > 1:
         dist.barrier()
         if getattr(learner, '_dist', None) is not None and learner._dist.exchange is not None:

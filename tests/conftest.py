@@ -31,10 +31,20 @@ def cpu_double():
     KN.set_default_kernels(*prev)
 
 
+def _tier():
+    """'gpu' when the HIP path ran in this session (a device is visible), else 'cpu' (the kernel test double): the
+    report files carry it, so a CPU-tier run never overwrites the GPU box's evidence"""
+    try:
+        import torch
+        return 'gpu' if torch.cuda.is_available() else 'cpu'
+    except Exception:
+        return 'cpu'
+
+
 def pytest_sessionfinish(session, exitstatus):
     """how tight the final-parameter comparison was (helpers.assert_final_params): per golden case and tensor, the
     fraction of elements further than 1e-5 from the reference's and the largest difference -> one summary line, and
-    gpurun_out/final_params_report.json when that directory exists (the GPU box)"""
+    gpurun_out/final_params_report_<tier>.json (tier = gpu | cpu) when that directory exists (the GPU box)"""
     try:
         import helpers
     except Exception:
@@ -49,7 +59,7 @@ def pytest_sessionfinish(session, exitstatus):
             import json
             json.dump({k: {'path_vs_fp64': v[0], 'reference_vs_fp64': v[1], 'bound': v[2], 'share_of_bound': v[0] / v[2],
                            'test': v[3] if len(v) > 3 else ''} for k, v in arb.items()},
-                      open(os.path.join(out, 'fp64_arbiter_report.json'), 'w'), indent=0)
+                      open(os.path.join(out, 'fp64_arbiter_report_%s.json' % _tier()), 'w'), indent=0)
     seeds = getattr(helpers, 'FP64_SEED_REPORT', {})
     if seeds:
         for k, v in seeds.items():
@@ -61,7 +71,7 @@ def pytest_sessionfinish(session, exitstatus):
         out = os.path.join(ROOT, 'gpurun_out')
         if os.path.isdir(out):
             import json
-            json.dump(seeds, open(os.path.join(out, 'fp64_seed_report.json'), 'w'), indent=1)
+            json.dump(seeds, open(os.path.join(out, 'fp64_seed_report_%s.json' % _tier()), 'w'), indent=1)
     rep = helpers.FINAL_PARAM_REPORT
     if not rep:
         return
@@ -75,4 +85,4 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(out):
         json.dump({k: {'frac_off': v[0], 'max_diff': v[1], 'elements': v[2]} for k, v in rep.items()},
-                  open(os.path.join(out, 'final_params_report.json'), 'w'), indent=0)
+                  open(os.path.join(out, 'final_params_report_%s.json' % _tier()), 'w'), indent=0)

@@ -23,7 +23,7 @@ RTOL = 1e-5
 # path's fused schedule reproduces the GPU-box host value to 1.3e-7).  The size of ONE such flip
 # depends on the row it hits: 2.9e-5 there, 1.9e-4 on the same golden under the layered
 # (one-launch-per-layer) schedule, whose summation order flips a different unit
-# (gpurun_out/fp64_arbiter_report.json names the test).  The bound is two flips of the larger
+# (gpurun_out/fp64_arbiter_report_gpu.json names the test).  The bound is two flips of the larger
 # measured size: 4e-4 relative (round 3 had 2e-4 = 1.07 x the larger one).
 LOOSE_KEYS = ('grad_norm_actor', 'grad_norm_critic')
 LOOSE_RTOL = 4e-4
