@@ -540,6 +540,12 @@ int32_t smx_epoch_fwdbwd_supported(int32_t D, int32_t H1, int32_t H2, int32_t OU
 int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
                          smx_ppo_ctrl_t* ctrl, int64_t n_total, int32_t* sync_word, uint64_t* kl_slots,
                          smx_stream_t stream);
+/* A co-tenant for the launch above (diagnostics / tests; no reference counterpart): `blocks` workgroups, each holding
+ * one compute unit to itself (more than half of its LDS) for `microseconds` (<= 2 s) without doing work.  The in-launch
+ * wait of smx_epoch_fwdbwd_f32 is bounded at 0.25 s: a tenant that keeps its workgroups off the device for longer makes
+ * that learn fail loudly (ctrl->reserved[1]); a learner that may share the device uses the two-launch form
+ * (session_config.learner.exclusive_device = False). */
+int smx_device_occupy(int32_t blocks, int64_t microseconds, smx_stream_t stream);
 
 /* --- acting head (PPOAgent.act, ppo_agent.py:106-154; DiagGauss.sample/maxprob, ppo_net.py:74-91) ---
  * pd[r] = [mean[r, :], exp(log_var) * noise_scale[r]]   (builders.py:127; ppo_agent.py:139:

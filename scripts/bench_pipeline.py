@@ -84,6 +84,9 @@ def _run(args):
     lc.replay.batch_size, lc.replay.memory_size = LB, 2 * n
     cam = (args.frame_stacks * args.pixel[0], args.pixel[1], args.pixel[2]) if args.pixel else None   # what the policy sees
     ec, sc = ppo_env_config(D, A, pixel=cam), ppo_session_config()
+    # actors one rollout ahead: the rollout kernel of the side stream holds CUs while learn() runs -- the learner must
+    # not use the epoch launch that waits inside itself for all of its workgroups (learner/ppo.py: exclusive_device)
+    sc.learner.exclusive_device = not bool(args.overlap)
     learner = PPOLearner(lc, ec, sc)
     learner.graph_input_sets = 2 * max(1, n // LB)      # the FIFO hands out batches from two alternating row ranges
     agent = PPOAgent(lc, ec, sc, agent_id=0, agent_mode='training')

@@ -189,6 +189,7 @@ _SIGS = {
     'smx_epoch_backward_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P]),
     'smx_epoch_fwdbwd_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_fwdbwd_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P, _P, _P]),
+    'smx_device_occupy': (c_int32, [c_int32, c_int64, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_backward_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                         _P, _P]),

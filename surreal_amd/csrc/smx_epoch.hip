@@ -547,7 +547,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
                 if ((long long)wall_clock64() - t0 > 25000000LL) { okw = 0; break; }     // 0.25 s (100 MHz): a lost workgroup
                 __builtin_amdgcn_s_sleep(1);
             }
-            wait_ok = okw;
+            wait_ok = wait_ok & okw;
             if (!okw) atomicOr(&ctrl->reserved[1], 1);
         }
         __syncthreads();
@@ -572,7 +572,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
             okw = __all(okw);
             if (tid == 0) {
                 s_kl = t;
-                wait_ok = okw;
+                wait_ok = wait_ok & okw;         // (never un-flag an earlier timeout of this workgroup)
                 if (!okw) atomicOr(&ctrl->reserved[1], 1);
             }
         }
@@ -586,8 +586,8 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     };
     float c_kl = 0.f;
     bool stop_now = false;
+    if (tid == 0) wait_ok = 1;          // (thread 0 is the only writer; every wait of this workgroup ANDs into it)
     if (adapt) kl_coef(kl_total(), c_kl, stop_now);
-    else if (tid == 0) wait_ok = 1;
     // the partial ROW (all column sums: the finalizing workgroup's input) went out with device-scope stores during the
     // loss, several microseconds ago: wavefronts 0 and 1 make sure they have completed, then the counter moves
     if (policy && tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1313,6 +1313,37 @@ extern "C" int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs
         attr_set_b = true;
     }
     hipLaunchKernelGGL(epoch_bwd_kernel, dim3(blocks), dim3(NTH), lds, smx_s(stream), G, ctrl);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// smx_device_occupy: `blocks` workgroups that each hold a compute unit to themselves (more than half of its LDS) for
+// `microseconds`, doing nothing.  What a tenant of a shared device looks like to the launches above: the tests put it
+// on a second stream under the fused forward + backward epoch (tests/test_gpu_epoch.py) to show that the in-launch
+// wait rides out a co-resident kernel and that the learner falls back when it cannot.
+// ---------------------------------------------------------------------------------------------
+__global__ void occupy_kernel(long long ticks, int* sink) {
+    extern __shared__ float occ[];
+    const long long t0 = (long long)wall_clock64();
+    float acc = 0.f;
+    while ((long long)wall_clock64() - t0 < ticks) {
+        occ[threadIdx.x] = acc;
+        acc += occ[(threadIdx.x + 1) & 63];
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc == 12345.678f && sink) *sink = 1;      // (keeps the LDS traffic alive)
+}
+
+extern "C" int smx_device_occupy(int32_t blocks, int64_t microseconds, smx_stream_t stream) {
+    SMX_REQUIRE(blocks > 0 && blocks <= 4096 && microseconds >= 0 && microseconds <= 2000000, SMX_E_SHAPE);
+    static bool attr_set_o = false;
+    if (!attr_set_o) {
+        (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set_o = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), EXCLUSIVE_LDS, smx_s(stream), (long long)microseconds * 100LL,
+                       (int*)nullptr);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -266,6 +266,10 @@ class HipKernels(object):
         L.call('smx_epoch_fwdbwd_f32', self._epoch_jobs(jobs), len(jobs), self._epoch_loss(loss),
                L.ptr(ctrl), int(n_total), L.ptr(sync_word), L.ptr(kl_slots), self._st())
 
+    def device_occupy(self, blocks, microseconds):
+        """a co-tenant on the current stream: `blocks` workgroups that each hold one CU for `microseconds` (smx_device_occupy)"""
+        L.call('smx_device_occupy', int(blocks), int(microseconds), self._st())
+
     def mlp3_wgrad_multi(self, jobs):
         """the weight-gradient launch alone: dicts(net, x (for rows), grads, sumsq, xT, h1T, h2T, dz3T,
         dz2T, dz1T[, stop])"""

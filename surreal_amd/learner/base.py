@@ -179,6 +179,13 @@ class Learner(metaclass=AutoInitializeMeta):
         # the stager's device twins (fp32, uint8 for camera frames) are what preprocess() would make of the batch.
         # (Run there, a preprocess that moves the batch to the device -- DDPG's -- cost H->D->H->D, and its allocator /
         # synchronous copy calls came from the worker thread while the main thread may be capturing a hipGraph.)
+        # A subclass whose preprocess() does MORE than that move (scaling, reshapes, key renames -- the reference's
+        # documented per-algorithm hook, learner/base.py:102-110 `main_preprocess=self.preprocess`) still gets it:
+        # applied on the main thread to the device batch the stager hands out (fetch_batch), so both paths -- with
+        # and without prefetching -- deliver the same batches.  The hooks this package ships are marked
+        # `device_move_only` and skipped.
+        own = type(self).preprocess
+        self._prefetch_main_preprocess = None if getattr(own, 'device_move_only', False) else self.preprocess
         first = self._as_attr(self._prefetcher_preprocess(self._data_source()))
         device = getattr(self, 'device', 'cpu')
         stager = PinnedBatchStager(first, depth=depth, device=device)
@@ -202,6 +209,8 @@ class Learner(metaclass=AutoInitializeMeta):
         if getattr(self, '_prefetch_queue', None) is not None:
             t0 = time.time()
             data = self._prefetch_queue.get()
+            if getattr(self, '_prefetch_main_preprocess', None) is not None:
+                data = self._prefetch_main_preprocess(data)
             self.fetch_time_s = time.time() - t0
             return data
         if self._data_source is None:
@@ -219,7 +228,12 @@ class Learner(metaclass=AutoInitializeMeta):
             yield self.fetch_batch()
 
     def preprocess(self, batch):
+        """the per-algorithm hook on a fetched batch (reference: Learner.preprocess, learner/base.py:149-154).  With
+        prefetching on it receives the DEVICE-resident batch of the staging slot (leaves are torch tensors); an
+        override whose only job is the host-to-device move sets `preprocess.device_move_only = True` and is skipped
+        there (the stager has already done it)."""
         return batch
+    preprocess.device_move_only = True
 
     def _prefetcher_preprocess(self, batch):
         return batch

@@ -138,6 +138,7 @@ class DDPGLearner(Learner):
         for key in ('actions', 'rewards', 'dones'):
             batch[key] = self._to_dev(batch[key])
         return batch
+    preprocess.device_move_only = True       # (start_prefetching: the pinned stager does exactly this move)
 
     def _workspace(self, B, D):
         if self._ws is not None and self._ws.key == (B, D):

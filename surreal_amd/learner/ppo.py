@@ -462,7 +462,14 @@ class PPOLearner(Learner):
                     K.epoch_supported(act, cri))
         # ... and an updating epoch's forward + loss + data gradients as ONE launch (single rank; several ranks need the
         # all-reduce between them)
+        # In adapt mode every actor workgroup of that launch WAITS inside it for the KL sums of all the others, so all
+        # of them must be resident at once.  The C side checks the launch against the CU count; what it cannot see is
+        # who else is on the device: kernels of another stream (actors one rollout ahead of the learner) or of
+        # another process hold CUs for as long as they run, and the wait is bounded (0.25 s, then the learn fails
+        # loudly).  A learner that may share the device says so -- session_config.learner.exclusive_device = False
+        # (set it on shared GPUs) -- and runs the two-launch form: same results, one more launch per epoch.
         ws.fb = (ws.fused and self.world_size == 1 and bool(self.session_config.learner.get('fused_fwdbwd', True)) and
+                 bool(self.session_config.learner.get('exclusive_device', True)) and not getattr(self, '_fb_timed_out', False) and
                  n_slots > 0 and K.epoch_fwdbwd_supported(act, cri))
         vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
         ws.nblk_v = vblocks(rows)
@@ -1579,8 +1586,16 @@ class PPOLearner(Learner):
         fin = scal[o + 8:o + 12].numpy()
         rf = scal[o + 12:o + 15].numpy()
         if int(ctrl_i[L.C_SYNC_ERR]) != 0:
+            # the device is shared after all: from the next learn() on, the two-launch form (no in-launch wait).  The
+            # parameters hold the state after the last COMPLETE epoch of the failed learn (every later Adam step of it
+            # was skipped on the device); the caller decides whether to re-feed the batch.
+            self._fb_timed_out = True
+            self._ws = None
+            self._graphs = {}
             raise RuntimeError('the in-launch wait of a fused forward + backward epoch timed out in the last learn() '
-                               '(smx_epoch_fwdbwd_f32): a workgroup of the launch never published its loss sums')
+                               '(smx_epoch_fwdbwd_f32): a workgroup of the launch was not resident within 0.25 s -- the '
+                               'device is shared with other kernels.  This learner now runs the two-launch epochs '
+                               '(session_config.learner.exclusive_device = False selects them from the start)')
         if int(ctrl_i[L.C_XCHG_ERR]) != 0:
             raise RuntimeError('a peer exchange timed out in the last learn(): error word 0x%x (0x100 | phase << 4 | peer) '
                                '-- a rank died or fell behind by more than the timeout' % (int(ctrl_i[L.C_XCHG_ERR]) & 0xffff))

@@ -20,6 +20,7 @@ not depend on the device it was written from.
 """
 import bisect
 import collections
+import copy
 import datetime
 import os
 import pickle
@@ -36,8 +37,17 @@ def _host_copy(tree):
     """the same nested structure with every tensor on the host"""
     if torch.is_tensor(tree):
         return tree.detach().cpu()
-    if isinstance(tree, dict):           # OrderedDict stays an OrderedDict
-        return type(tree)((k, _host_copy(v)) for k, v in tree.items())
+    if isinstance(tree, dict):
+        # OrderedDict stays an OrderedDict; any other dict subclass keeps its type through a shallow copy + item
+        # assignment (a defaultdict's constructor wants its factory first, a Counter's would count the pairs)
+        if type(tree) in (dict, collections.OrderedDict):
+            return type(tree)((k, _host_copy(v)) for k, v in tree.items())
+        out = copy.copy(tree)
+        for k, v in tree.items():
+            out[k] = _host_copy(v)
+        return out
+    if isinstance(tree, tuple) and hasattr(tree, '_fields'):     # namedtuple: positional constructor
+        return type(tree)(*(_host_copy(v) for v in tree))
     if isinstance(tree, (list, tuple)):
         return type(tree)(_host_copy(v) for v in tree)
     return tree

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import helpers as H
+from surreal_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -265,3 +266,60 @@ def test_fp64_arbiter_over_seeds_configs3():
     for k, (share, ours, theirs, name) in worst.items():
         H.FP64_SEED_REPORT['loss ' + k] = {'worst_share_of_bound': share, 'hip_vs_fp64': ours, 'reference_vs_fp64': theirs,
                                             'case': name}
+
+
+# ---- the fused forward + backward epoch on a device it does not have to itself ---------
+def _learn_under_tenant(name, blocks, microseconds, session_overrides=None):
+    g, case = H.load_golden(name)
+    batch, params, zstate = H.case_inputs(case)
+    learner = H.make_learner(case, params, zstate, session_overrides=session_overrides)
+    db = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        learner.K.device_occupy(blocks, microseconds)
+    stats = learner.learn(db)
+    return g, case, learner, stats, db
+
+
+def test_fused_fwdbwd_rides_out_a_co_resident_kernel():
+    """cfg5 (1024 rows: 64 actor + 64 critic workgroups per epoch launch, every actor workgroup waiting inside the launch
+    for the KL sums of all the others) while a tenant on another stream holds 192 of the 256 CUs for 4 ms -- longer than the
+    whole learn.  The wait is a delay, not a failure: no sync error, results equal to the reference golden."""
+    g, case, learner, stats, _ = _learn_under_tenant('cfg5_adapt', 192, 4000)
+    assert learner._ws.fb, 'the fused forward + backward launch is the configuration under test'
+    torch.cuda.synchronize()
+    assert int(learner._ws.ctrl_i[L.C_SYNC_ERR].item()) == 0
+    check_case('cfg5_adapt', g, case, learner, stats)
+
+
+def test_shared_device_option_selects_the_two_launch_epochs():
+    """session_config.learner.exclusive_device = False: no in-launch wait anywhere (two launches per epoch), same goldens"""
+    g, case, learner, stats, _ = _learn_under_tenant('cfg5_adapt', 192, 4000, {'exclusive_device': False})
+    assert not learner._ws.fb
+    check_case('cfg5_adapt', g, case, learner, stats)
+
+
+def test_fused_fwdbwd_timeout_fails_loudly_and_falls_back():
+    """a tenant that keeps most CUs for longer than the wait's bound (0.25 s): the learn raises, the learner switches
+    itself to the two-launch epochs, and -- parameters reloaded -- the same batch then gives the golden results"""
+    name = 'cfg5_adapt'
+    g, case = H.load_golden(name)
+    batch, params, zstate = H.case_inputs(case)
+    learner = H.make_learner(case, params, zstate)
+    db = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        learner.K.device_occupy(224, 450000)          # 32 CUs left: 96 of the first epoch launch's 128 workgroups cannot start
+    with pytest.raises(RuntimeError, match='exclusive_device'):
+        stats = learner.learn(db)
+        dict(stats)                                   # (deferred statistics resolve here)
+        learner.learn(db)                             # ... at the latest when the next learn has been enqueued
+    torch.cuda.synchronize()
+    assert learner._fb_timed_out
+    fresh = H.make_learner(case, params, zstate)
+    fresh._fb_timed_out = True
+    stats = fresh.learn(copy.deepcopy(batch))
+    assert not fresh._ws.fb
+    check_case(name, g, case, fresh, stats)

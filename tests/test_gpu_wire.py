@@ -190,3 +190,8 @@ def test_host_fed_learner_aggregation_in_worker_processes():
     host-registered staging slot (body: tests/wire_cases.py)"""
     import wire_cases
     wire_cases.check_pooled_host_fed_learner(expect_cuda=True)
+
+
+def test_overriding_preprocess_sees_the_same_batches_with_and_without_prefetching():
+    import wire_cases
+    wire_cases.check_preprocess_override_same_batches(expect_cuda=True)

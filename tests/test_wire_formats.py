@@ -305,3 +305,23 @@ def test_reference_chunk_to_learn_equals_reference_batch_and_oracle(cpu_double):
     """f2 end to end on the host tier: reference chunk -> collector -> FIFO -> aggregator -> learn"""
     import wire_cases
     wire_cases.check_reference_chunk_to_learn(expect_cuda=False)
+
+
+def test_overriding_preprocess_sees_the_same_batches_with_and_without_prefetching(cpu_double):
+    import wire_cases
+    wire_cases.check_preprocess_override_same_batches(expect_cuda=False)
+
+
+def test_checkpoint_keeps_dict_subclasses_of_tracked_attributes(tmp_path):
+    """a tracked attribute that is a defaultdict / Counter: saved and restored with its type and items"""
+    import collections
+    t = Tracked()
+    t.visits = collections.defaultdict(list)
+    t.visits['a'].append(torch.ones(2))
+    t.counts = collections.Counter({'x': 3})
+    ck = Checkpoint(str(tmp_path), 'agent', tracked_obj=t, tracked_attrs=['visits', 'counts'], keep_history=1, keep_best=0)
+    ck.save(global_steps=1)
+    blob = pickle.load(open(ck.ckpt_path(1), 'rb'))
+    assert isinstance(blob['visits'], collections.defaultdict) and blob['visits'].default_factory is list
+    assert torch.equal(blob['visits']['a'][0], torch.ones(2))
+    assert isinstance(blob['counts'], collections.Counter) and blob['counts'] == collections.Counter({'x': 3})

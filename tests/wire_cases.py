@@ -139,6 +139,61 @@ def check_host_fed_learner(expect_cuda):
     pf.stop()
 
 
+def check_preprocess_override_same_batches(expect_cuda):
+    """a Learner subclass whose preprocess() does more than the device move (here: halves the rewards and adds a key)
+    sees the same batches with and without prefetching (reference: LearnerDataPrefetcher(main_preprocess=
+    self.preprocess), surreal/learner/base.py:102-110)"""
+    from surreal_amd.learner import PPOLearner
+    from surreal_amd.main.ppo_configs import ppo_learner_config, ppo_env_config, ppo_session_config
+    B, N, D, A = 6, 5, 7, 2
+    lc = ppo_learner_config()
+    lc.algo.n_step = N
+    lc.algo.rnn.if_rnn_policy = False
+    lc.replay.batch_size = B
+    lc.model.actor_fc_hidden_sizes = lc.model.critic_fc_hidden_sizes = [16, 8]
+    ec, sc = ppo_env_config(D, A), ppo_session_config('/tmp/surreal_amd_test_override')
+    calls = []
+
+    class Scaled(PPOLearner):
+        def preprocess(self, batch):
+            calls.append(type(batch['rewards']).__name__)
+            r = batch['rewards']
+            batch['rewards'] = (r if torch.is_tensor(r) else torch.as_tensor(np.asarray(r), dtype=torch.float32)) * 0.5
+            batch['scaled'] = True
+            return batch
+    batches = [synthetic.make_ppo_batch(B, N, D, A, seed=70 + k) for k in range(3)]
+
+    def make():
+        L = Scaled(lc, ec, sc)
+        it = iter([L.aggregator.aggregate(synthetic.ppo_experiences(b)) for b in batches])
+
+        def source():
+            try:
+                return next(it)
+            except StopIteration:
+                import time
+                time.sleep(3600)
+        L._prefetcher_preprocess = lambda data: data          # (the source already hands out aggregated batches)
+        L.set_data_source(source)
+        return L
+    plain, fed = make(), make()
+    want = [plain.fetch_batch() for _ in range(3)]
+    pf = fed.start_prefetching(depth=2)
+    assert fed._prefetch_main_preprocess is not None
+    for w in want:
+        got = fed.fetch_batch()
+        assert got['scaled'] is True and w['scaled'] is True
+        g, r = got['rewards'], w['rewards']
+        assert torch.is_tensor(g) and g.is_cuda == expect_cuda
+        np.testing.assert_array_equal(g.cpu().numpy().reshape(-1), np.asarray(r.cpu() if torch.is_tensor(r) else r).reshape(-1))
+        np.testing.assert_array_equal(got['obs']['low_dim']['flat_inputs'].cpu().numpy(),
+                                      np.asarray(w['obs']['low_dim']['flat_inputs']))
+    pf.stop()
+    # the hooks the package ships only move the batch: they are skipped under prefetching (the stager did the move)
+    base = PPOLearner(lc, ec, sc)
+    assert getattr(type(base).preprocess, 'device_move_only', False)
+
+
 def check_pooled_host_fed_learner(expect_cuda, workers=3):
     """the aggregation in WORKER PROCESSES (surreal_amd.distributed.AggregationPool: the reference's prefetch_processes,
     surreal/distributed/data_fetcher.py:36-45): every worker fills its rows of the shared staging slot in place, the
