@@ -106,7 +106,7 @@ def tol_for(key, atol, rtol, case=''):
 
 # goldens whose CPU re-run takes about a minute (8448 camera frames through the CNN stem 25 times): checked against
 # the oracle bit for bit when they were recorded (oracle/gen_golden.py), run by the GPU tier, skipped by the CPU tier
-BIG_CASES = ('cfg4_pixel_rnn_256x32',)
+BIG_CASES = ('cfg4_pixel_rnn_256x32', 'cfg5_rnn_adapt')
 
 
 def golden_cases(rnn=None, big=True):
@@ -122,6 +122,25 @@ def golden_cases(rnn=None, big=True):
         if rnn is None or rnn == has_stem:
             out.append(n)
     return out
+
+
+def assert_adv_ret(adv, ret, g, B, atol=ATOL, rtol=RTOL):
+    """advantages / returns tables (numpy, any shape with B leading rows) against the golden's.  The goldens of the big
+    LSTM cases hold every `sample_step`-th sub-trajectory plus float64 (sum, sum of squares) of the whole table
+    (oracle/gen_golden.py `sample_rows`): the sampled rows at the 1e-5 bar, the checksums at 1e-5 relative of the
+    table's own scale (sqrt(n * sumsq): the bound on |sum| and what an elementwise 1e-5 error can move it by)."""
+    for name, x in (('advantages', adv), ('returns', ret)):
+        want = g[name]
+        x = np.asarray(x).reshape(B, -1)
+        if 'sample_step' in g:
+            step = int(g['sample_step'])
+            np.testing.assert_allclose(x[::step].reshape(want.shape), want, atol=atol, rtol=rtol, err_msg=name)
+            s1, s2 = g[name + '_checksum']
+            scale = float(np.sqrt(x.size * s2))
+            assert abs(x.sum(dtype=np.float64) - s1) <= 1e-5 * scale + atol * x.size ** 0.5, (name, x.sum(dtype=np.float64), s1)
+            assert abs((x.astype(np.float64) ** 2).sum() - s2) <= 4e-5 * s2, (name, (x.astype(np.float64) ** 2).sum(), s2)
+        else:
+            np.testing.assert_allclose(x.reshape(want.shape), want, atol=atol, rtol=rtol, err_msg=name)
 
 
 def load_golden(name):

@@ -68,7 +68,7 @@ def _worker(rank, world, port, name, q, cuts=None):
 
 
 @pytest.mark.parametrize('name', ['tiny_clip', 'tiny_adapt_cutoff2', 'cfg2_adapt', 'tiny_rnn_clip', 'cfg1_rnn_adapt',
-                                  'tiny_pixel_clip', 'tiny_pixel_rnn_adapt', 'tiny_rnn2_adapt'])
+                                  'tiny_pixel_clip', 'tiny_pixel_rnn_adapt', 'tiny_rnn2_adapt', 'cfg2_rnn_clip'])
 def test_two_rank_learner_equals_single_learner(name):
     _ranks_equal_single_learner(name, 2)
 
@@ -109,10 +109,9 @@ def _ranks_equal_single_learner(name, world, cuts=None):
     for r in range(world):
         assert 'error' not in res[r], res[r].get('error')
     g, case = H.load_golden(name)
-    adv = np.concatenate([res[r]['adv'] for r in range(world)]).reshape(g['advantages'].shape)
-    ret = np.concatenate([res[r]['ret'] for r in range(world)]).reshape(g['returns'].shape)
-    np.testing.assert_allclose(adv, g['advantages'], atol=H.ATOL, rtol=H.RTOL)   # GLOBAL normalisation
-    np.testing.assert_allclose(ret, g['returns'], atol=H.ATOL, rtol=H.RTOL)
+    adv = np.concatenate([res[r]['adv'].reshape(-1) for r in range(world)])
+    ret = np.concatenate([res[r]['ret'].reshape(-1) for r in range(world)])
+    H.assert_adv_ret(adv, ret, g, case['shape']['B'])                             # GLOBAL normalisation
     for r in range(world):
         H.assert_trace_close(res[r]['trace'], g, what='%s rank %d' % (name, r))
         H.assert_stats_close(res[r]['stats'], g, what='%s rank %d' % (name, r))

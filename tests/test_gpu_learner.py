@@ -29,11 +29,8 @@ def run_case(name, session_overrides=None):
 
 def check_case(name, g, case, learner, stats):
     ws = learner._ws
-    np.testing.assert_allclose(ws.adv.cpu().numpy().reshape(g['advantages'].shape), g['advantages'],
-                               atol=H.ATOL, rtol=H.RTOL, err_msg='advantages')
-    np.testing.assert_allclose(ws.ret.cpu().numpy().reshape(g['returns'].shape), g['returns'],
-                               atol=H.ATOL, rtol=H.RTOL, err_msg='returns')
     B, N = case['shape']['B'], case['shape']['N']
+    H.assert_adv_ret(ws.adv.cpu().numpy(), ws.ret.cpu().numpy(), g, B)
     vr = learner.raw_values().cpu().numpy()
     np.testing.assert_allclose(vr[:g['values_raw'].shape[0]], g['values_raw'], atol=H.ATOL,
                                rtol=H.RTOL, err_msg='raw critic values')
