@@ -868,13 +868,13 @@ def compact_line(full, full_path=None):
     if 'secondary' in full:
         out['secondary_summary'] = {_summary_key(k): summary_row(r) for k, r in full['secondary'].items()
                                     if summary_row(r) is not None}
-    out.update(_pick(full, ('bench_wall_s',)))
+    out.update(_pick(full, ('final_stats', 'bench_wall_s')))
     if full_path:
         out['full_record'] = full_path
     out = _r(out)
     line = json.dumps(out)
     # belt and braces: never hand the driver a line it cannot keep whole
-    for drop in ('exchange_model', 'strong', 'step_roofline'):
+    for drop in ('final_stats', 'exchange_model', 'strong', 'step_roofline'):
         if len(line) <= LINE_LIMIT:
             break
         out.pop(drop, None)
