@@ -200,6 +200,18 @@ int smx_mlp3_backward_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_s
 int smx_mlp3_forward_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1,
                          float* h2, float* out, int32_t out_act,
                          const int32_t* stop_flag, smx_stream_t stream);
+/* The same over MANY rows (the MLPs on top of an LSTM / CNN stem: rows = B * E ~ 10^5 per epoch; the reference calls
+ * the same nn.Sequential, surreal/model/ppo_net.py:284-315): ONE launch of the fused 16-row kernel -- x read once,
+ * activations from the accumulators to h1 / h2 once and on to the next layer in registers -- behind a repack of the
+ * weights into `packed` (smx_mlp3_packed_bytes(D, H1, H2, OUT) bytes, 16-byte aligned; contents are scratch).
+ * out [rows, OUT] with row stride out_ld floats (0 = OUT).  Returns SMX_E_UNSUPPORTED outside the kernel's fast path
+ * (smx_mlp3_forward_rows_supported: D, H1, H2 multiples of 4, 64 < H1 <= 320, 64 < H2 <= 224, OUT <= 32; x, h1, h2
+ * 16-byte aligned) -- the caller then uses smx_mlp3_forward_f32.  Results equal the layered path's within fp32
+ * rounding (another summation order), not bit for bit. */
+int32_t smx_mlp3_forward_rows_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_mlp3_forward_rows_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1, float* h2,
+                              float* out, int32_t out_act, int32_t out_ld, float* packed, size_t packed_bytes,
+                              const int32_t* stop_flag, smx_stream_t stream);
 
 /* MLP backward from dz3 = dLoss/d(pre-activation of layer 3) [rows,OUT]:
  *   grads  flat [H1*D + H1 + H2*H1 + H2 + OUT*H2 + OUT] in (W1,b1,W2,b2,W3,b3) order

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('SMX_LIB_PATH') or os.path.join(_HERE, 'libsurreal_amd
 
 SMX_ACT_NONE, SMX_ACT_RELU, SMX_ACT_TANH = 0, 1, 2
 SMX_PPO_CLIP, SMX_PPO_ADAPT = 0, 1
+SMX_E_UNSUPPORTED = -3   # include/surreal_amd.h: shape outside what the kernel is built for
 # stats slots (include/surreal_amd.h)
 PS_SURR, PS_LOSS, PS_ENTROPY, PS_KL, PS_GRADNORM, PS_LB, PS_ISW, PS_REFBEH, PS_STRIDE = range(9)
 VS_LOSS, VS_EXPVAR, VS_GRADNORM = 0, 1, 2
@@ -190,6 +191,8 @@ _SIGS = {
     'smx_epoch_fwdbwd_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_fwdbwd_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P, _P, _P]),
     'smx_device_occupy': (c_int32, [c_int32, c_int64, _P]),
+    'smx_mlp3_forward_rows_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_mlp3_forward_rows_f32': (c_int32, [POINTER(Mlp3), _P, c_int64, _P, _P, _P, c_int32, c_int32, _P, c_size_t, _P, _P]),
     'smx_mlp3_backward_partials': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_mlp3_backward_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                         _P, _P]),

@@ -645,6 +645,9 @@ extern "C" int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_
     A.out_act = out_act;
     A.tbuf = g_fused_tbuf;
     A.exp = 0;
+    A.h1_out = A.h2_out = nullptr;
+    A.H1 = H1; A.H2 = H2; A.out_ld = OUT;
+    A.stop = nullptr;
     A.xvec = (D % 4 == 0) && (((uintptr_t)x_main & 15) == 0) &&
              (T1 == 0 || ((uintptr_t)x_tail & 15) == 0) &&
              (zmean == nullptr || ((((uintptr_t)zmean | (uintptr_t)zstd) & 15) == 0));
@@ -658,4 +661,44 @@ extern "C" int smx_mlp3_forward_fused_f32(const float* packed, int32_t D, int32_
         if (rc != SMX_E_UNSUPPORTED) return rc;
     }
     return launch_fused<10, 7>(A, smx_s(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// smx_mlp3_forward_rows_f32: smx_mlp3_forward_f32 (the forward pass that KEEPS h1 / h2 for the backward) over many
+// rows -- the MLPs on top of an LSTM / CNN stem, B*E ~ 10^5 rows per epoch (surreal/model/ppo_net.py:284-315 under
+// surreal/learner/ppo.py:227-353).  One launch of the 16-row fused kernel instead of three layer GEMMs: x is read
+// once, the activations go from the accumulators to memory once (and on, in registers, to the next layer).  The
+// weights are repacked into `packed` first (they change every epoch): one short launch.
+// SMX_E_UNSUPPORTED (the caller then uses the layered smx_mlp3_forward_f32) outside the fused kernel's fast path:
+// D % 4, H1 % 4, H2 % 4 == 0, 64 < H1 <= 320, 64 < H2 <= 224, OUT <= 32, 16-byte aligned x / h1 / h2.
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t smx_mlp3_forward_rows_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT) {
+    int nt1, nt2;
+    return D >= 4 && D % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0 && H1 > 64 && H2 > 64 && OUT >= 1 && OUT <= 32 &&
+           pick_variant(H1, H2, &nt1, &nt2) && nt1 > 2;
+}
+
+extern "C" int smx_mlp3_forward_rows_f32(const smx_mlp3_t* net, const float* x, int64_t rows, float* h1, float* h2,
+                                         float* out, int32_t out_act, int32_t out_ld, float* packed,
+                                         size_t packed_bytes, const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(net && x && h1 && h2 && out && packed, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0, SMX_E_SHAPE);
+    if (!smx_mlp3_forward_rows_supported(net->D, net->H1, net->H2, net->OUT)) return SMX_E_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)h1 | (uintptr_t)h2) & 15) != 0) return SMX_E_UNSUPPORTED;
+    int rc = smx_mlp3_pack_f32(net, packed, packed_bytes, stream);
+    if (rc) return rc;
+    FusedArgs A;
+    A.packed = packed;
+    A.x_main = x; A.x_tail = x;
+    A.zmean = nullptr; A.zstd = nullptr;
+    A.out = out;
+    A.total_rows = (long)rows;
+    A.T0 = 1; A.T1 = 0;
+    A.D = net->D; A.OUT = net->OUT; A.KC1 = (net->D + 31) / 32;
+    A.out_act = out_act;
+    A.tbuf = nullptr; A.exp = 0; A.xvec = 1;
+    A.h1_out = h1; A.h2_out = h2;
+    A.H1 = net->H1; A.H2 = net->H2; A.out_ld = out_ld > 0 ? out_ld : net->OUT;
+    A.stop = (const int*)stop_flag;
+    return smx_rows16_launch(A, net->H1, net->H2, smx_s(stream));
 }

@@ -17,6 +17,12 @@ struct FusedArgs {
     int T0, T1, D, OUT, KC1, out_act, xvec;
     long long* tbuf;   // SMX_FUSED_TIMING builds: per-workgroup phase timestamps (else null)
     int exp;           // SMX_FUSED_TIMING builds: experiment switches (SMX_FUSED_EXP)
+    // forward WITH the hidden activations kept for a backward pass (smx_mlp3_forward_rows_f32: the MLPs on top of an
+    // LSTM / CNN stem over B*E ~ 10^5 rows): h1 [rows, H1], h2 [rows, H2] row-major, or null
+    float* h1_out;
+    float* h2_out;
+    int H1, H2, out_ld;
+    const int* stop;   // device flag (may be null): non-zero turns the launch into a no-op
 };
 
 struct PackLayout {

@@ -73,13 +73,17 @@ __device__ __forceinline__ void stage_x16(float* dst, float4 v, const float4 zm,
 }
 
 // NT1 / NT2: 16-feature tiles of the two hidden layers (H1 <= 16 NT1, H2 <= 16 NT2)
-template <int NT1, int NT2, bool OUT1>
+// SAVE: the hidden activations h1 / h2 (after bias + ReLU) also go to memory, row-major, straight from the accumulators
+// (a lane holds 4 consecutive features of one row per tile: one 16-byte store; the four lane groups of a row fill a
+// 64-byte segment) -- the forward half of a training step over B*E ~ 10^5 rows (the MLPs on top of a stem)
+template <int NT1, int NT2, bool OUT1, bool SAVE>
 __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
     constexpr int P1 = (NT1 + 1) / 2, P2 = (NT2 + 1) / 2;      // 32-feature tiles of the packed layout
     constexpr int NW1 = (P1 * 32 + 63) / 64, NW2 = (P2 * 32 + 63) / 64;   // staging passes of 64 rows
     constexpr int WR = 64 * (NW1 > NW2 ? NW1 : NW2);
     static_assert(NW1 <= 5 && NW2 <= 4, "staging registers are written out for <= 5 / <= 4 passes");
     extern __shared__ float lds[];
+    if (SAVE && A.stop && *A.stop) return;
     TSTAMP(0);
     float* Wb0 = lds;
     float* Wb1 = Wb0 + WR * LDS16;
@@ -328,6 +332,16 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         acc1[t][2] = relu16(acc1[t][2] + bb.z);
         acc1[t][3] = relu16(acc1[t][3] + bb.w);
     }
+    if (SAVE && A.h1_out) {
+        const long r = row0 + wv * 16 + fm;
+        if (r < A.total_rows) {
+            float* dst = A.h1_out + r * (long)A.H1 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+                if (16 * t + 4 * g < A.H1)
+                    *reinterpret_cast<float4*>(dst + 16 * t) = make_float4(acc1[t][0], acc1[t][1], acc1[t][2], acc1[t][3]);
+        }
+    }
 
     // ======================= layer 2: acc2[u] = W2[tile u] . h1^T ==========================
     f32x4 acc2[NT2];
@@ -431,6 +445,16 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         acc2[u][2] = relu16(acc2[u][2] + bb.z);
         acc2[u][3] = relu16(acc2[u][3] + bb.w);
     }
+    if (SAVE && A.h2_out) {
+        const long r = row0 + wv * 16 + fm;
+        if (r < A.total_rows) {
+            float* dst = A.h2_out + r * (long)A.H2 + 4 * g;
+#pragma unroll
+            for (int u = 0; u < NT2; ++u)
+                if (16 * u + 4 * g < A.H2)
+                    *reinterpret_cast<float4*>(dst + 16 * u) = make_float4(acc2[u][0], acc2[u][1], acc2[u][2], acc2[u][3]);
+        }
+    }
 
     // ======================= layer 3 ========================================================
     const long myrow = row0 + wv * 16 + fm;
@@ -449,10 +473,10 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         v += __shfl_xor(v, 32, 64);
         v += b3v;
         if (A.out_act == SMX_ACT_TANH) v = tanhf(v);
-        if (g == 0 && myrow < A.total_rows) A.out[myrow] = v;
+        if (g == 0 && myrow < A.total_rows) A.out[SAVE ? myrow * A.out_ld : myrow] = v;
     } else {
-        // OUT <= 16 outputs: one more MFMA tile; all of W3 (P2 chunks of 32 rows) fits one staging buffer
-        f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // OUT <= 32 outputs: one or two more MFMA tiles; all of W3 (P2 chunks of 32 rows) fits one staging buffer
+        f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f}, acc3b = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             const float4* src = reinterpret_cast<const float4*>(W3p);
             for (int i = tid; i < P2 * 32 * 8; i += NTHR)
@@ -460,6 +484,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         }
         __syncthreads();
         const float* wrow = Wb0 + fm * LDS16 + 4 * g;
+        const bool two = A.OUT > 16;             // workgroup-uniform
 #pragma unroll
         for (int u = 0; u < NT2; ++u) {
             const float4 a = *reinterpret_cast<const float4*>(wrow + (u >> 1) * 32 * LDS16 + 16 * (u & 1));
@@ -468,15 +493,26 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
             acc3 = MFMA16(a.z, acc2[u][2], acc3);
             acc3 = MFMA16(a.w, acc2[u][3], acc3);
         }
-        if (myrow < A.total_rows) {
+        if (two) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 4 * g + r;
+            for (int u = 0; u < NT2; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(wrow + ((u >> 1) * 32 + 16) * LDS16 + 16 * (u & 1));
+                acc3b = MFMA16(a.x, acc2[u][0], acc3b);
+                acc3b = MFMA16(a.y, acc2[u][1], acc3b);
+                acc3b = MFMA16(a.z, acc2[u][2], acc3b);
+                acc3b = MFMA16(a.w, acc2[u][3], acc3b);
+            }
+        }
+        if (myrow < A.total_rows) {
+            const int ld = SAVE ? A.out_ld : A.OUT;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int o = (r < 4) ? 4 * g + r : 16 + 4 * g + (r - 4);
                 if (o < A.OUT) {
-                    float v = acc3[r] + w3s[o];
+                    float v = ((r < 4) ? acc3[r & 3] : acc3b[r & 3]) + w3s[o];
                     if (A.out_act == SMX_ACT_TANH) v = tanhf(v);
                     else if (A.out_act == SMX_ACT_RELU) v = relu16(v);
-                    A.out[myrow * A.OUT + o] = v;
+                    A.out[myrow * ld + o] = v;
                 }
             }
         }
@@ -486,7 +522,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
 #undef SMX_WST
 }
 
-template <int NT1, int NT2>
+template <int NT1, int NT2, bool SAVE>
 int launch16(const FusedArgs& A, hipStream_t st) {
     constexpr int P1 = (NT1 + 1) / 2, P2 = (NT2 + 1) / 2;
     constexpr int NW1 = (P1 * 32 + 63) / 64, NW2 = (P2 * 32 + 63) / 64;
@@ -494,7 +530,7 @@ int launch16(const FusedArgs& A, hipStream_t st) {
     const size_t lds = (size_t)(2 * WR * LDS16 + 2 * ROWS16 * LDS16 + P1 * 32 + 2 * P2 * 32 + 2 * A.KC1 * 32) * sizeof(float);
     if (lds > 160 * 1024) return SMX_E_UNSUPPORTED;     // very wide inputs: the 32-row kernel takes them
     const unsigned grid = (unsigned)((A.total_rows + ROWS16 - 1) / ROWS16);
-    void (*k)(FusedArgs) = (A.OUT == 1) ? mlp3_rows16_kernel<NT1, NT2, true> : mlp3_rows16_kernel<NT1, NT2, false>;
+    void (*k)(FusedArgs) = (A.OUT == 1) ? mlp3_rows16_kernel<NT1, NT2, true, SAVE> : mlp3_rows16_kernel<NT1, NT2, false, SAVE>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, st, A);
@@ -506,7 +542,13 @@ int launch16(const FusedArgs& A, hipStream_t st) {
 
 int smx_rows16_launch(const FusedArgs& A, int H1, int H2, hipStream_t st) {
     // the packed layout must be the 10 / 7 (x 32 features) one of smx_mlp3_pack_f32's large variant
-    if (!A.xvec || A.D < 4 || A.OUT > 16 || H1 <= 64 || H2 <= 64 || H1 > 320 || H2 > 224) return SMX_E_UNSUPPORTED;
-    if (H1 <= 304 && H2 <= 208) return launch16<19, 13>(A, st);
-    return launch16<20, 14>(A, st);
+    const bool save = A.h1_out || A.h2_out;
+    if (!A.xvec || A.D < 4 || A.OUT > 32 || H1 <= 64 || H2 <= 64 || H1 > 320 || H2 > 224) return SMX_E_UNSUPPORTED;
+    if (save) {
+        if ((H1 | H2) & 3) return SMX_E_UNSUPPORTED;
+        if (H1 <= 304 && H2 <= 208) return launch16<19, 13, true>(A, st);
+        return launch16<20, 14, true>(A, st);
+    }
+    if (H1 <= 304 && H2 <= 208) return launch16<19, 13, false>(A, st);
+    return launch16<20, 14, false>(A, st);
 }

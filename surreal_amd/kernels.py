@@ -94,8 +94,22 @@ class HipKernels(object):
                L.ptr(x_main), L.ptr(x_tail), G, T0, T1, L.ptr(zmean), L.ptr(zstd), L.ptr(out),
                act, self._st())
 
-    def mlp3_forward(self, net, x, h1, h2, out, act, stop=None):
+    # rows from which the fused many-row forward pays: below, its 128-row workgroups leave most of the 256 CUs idle and
+    # the layered GEMMs (32 x 32 / 64 x 64 tiles) win (7936 rows: 62 workgroups, measured equal)
+    FUSED_ROWS_MIN = 24576
+
+    def mlp3_forward(self, net, x, h1, h2, out, act, stop=None, pack=None):
+        """forward keeping h1 / h2.  pack: scratch of mlp3_packed_numel(net) floats -- with it, a pass over >=
+        FUSED_ROWS_MIN rows of a supported shape runs as ONE fused launch (smx_mlp3_forward_rows_f32)"""
         assert x.is_contiguous()
+        if pack is not None and x.shape[0] >= self.FUSED_ROWS_MIN and h1.is_contiguous() and h2.is_contiguous() and \
+                L.load().smx_mlp3_forward_rows_supported(net.D, net.H1, net.H2, net.OUT):
+            ld = 0 if out.dim() < 2 or out.stride(0) == out.shape[1] else out.stride(0)
+            rc = L.load().smx_mlp3_forward_rows_f32(ctypes.byref(net.desc), L.ptr(x), x.shape[0], L.ptr(h1), L.ptr(h2),
+                                                    L.ptr(out), act, ld, L.ptr(pack), pack.numel() * 4, L.ptr(stop), self._st())
+            if rc != L.SMX_E_UNSUPPORTED:
+                L.check(rc, 'smx_mlp3_forward_rows_f32')
+                return
         L.call('smx_mlp3_forward_f32', ctypes.byref(net.desc), L.ptr(x), x.shape[0], L.ptr(h1),
                L.ptr(h2), L.ptr(out), act, L.ptr(stop), self._st())
 

@@ -412,6 +412,12 @@ class PPOLearner(Learner):
             ws.h1G, ws.h2G = f(R1, cri.H1), f(R1, cri.H2)
             n_sk = max(K.mlp3_backward_ws_floats(n, rows) for n in (act, cri))
             ws.mlp_sk = f(n_sk) if n_sk else None          # split-K partials of the MLP weight gradients over B x T rows
+            # scratch for the packed weights of the fused many-row forward (K.mlp3_forward(pack=...): one launch instead
+            # of three layer GEMMs from FUSED_ROWS_MIN rows on; the shapes it does not take keep the layered path)
+            try:
+                ws.pack_stem = f(max(K.mlp3_packed_numel(n) for n in (act, cri)))
+            except Exception:
+                ws.pack_stem = None
             if rnn:
                 # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E)
                 # and for the critic pass (T = N + 1, ppo.py:376-386)
@@ -1223,7 +1229,7 @@ class PPOLearner(Learner):
         x = ws.xcat
         if rnn:
             x = self._lstm_forward_only(ws, m, ws.xcat, B, N + 1, ws.gatesG, ws.csG, ws.loG, ws.loG2)
-        K.mlp3_forward(m.critic, x, ws.h1G, ws.h2G, ws.vals.view(-1, 1), L.SMX_ACT_NONE)
+        K.mlp3_forward(m.critic, x, ws.h1G, ws.h2G, ws.vals.view(-1, 1), L.SMX_ACT_NONE, pack=ws.pack_stem)
         H = self.horizon if rnn else N
         K.gae(ws.vals, rewards, dones, ws.gpow, ws.lpow, self.gamma, self.gamma ** H, B, N, H,
               ws.adv, ws.ret)
@@ -1265,7 +1271,7 @@ class PPOLearner(Learner):
         A, W = self.action_dim, self.world_size
         mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
         x = self._stem_forward(ws, m, ws.xn, ws.stop)
-        K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
+        K.mlp3_forward(m.actor, x, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop, pack=ws.pack_stem)
         K.policy_loss(mode, ws.mean, m.log_var.view(-1), ws.act_it, ws.beh_it, ws.ref_pol, ws.adv,
                       ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
         part, nblk = ws.ppart, ws.nblk_p
@@ -1329,7 +1335,7 @@ class PPOLearner(Learner):
     def _stem_value_epoch(self, ws, e):
         K, m = self.K, self.model
         x = self._stem_forward(ws, m, ws.xn, None)
-        K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
+        K.mlp3_forward(m.critic, x, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None, pack=ws.pack_stem)
         n_total = ws.n_total
         # (several ranks: the moments only feed statistics -- gathered once after the last epoch)
         K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c,
@@ -1371,7 +1377,7 @@ class PPOLearner(Learner):
         if ref.if_rnn:
             x = self._lstm_forward_only(ws, ref, ws.xr, B, E, ws.gates, ws.cs, ws.lo,
                                         ws.upper[0].lo if ws.upper else None)
-        K.mlp3_forward(ref.actor, x, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None)
+        K.mlp3_forward(ref.actor, x, ws.h1r, ws.h2r, ws.ref_mean, L.SMX_ACT_TANH, None, pack=ws.pack_stem)
         ws.ref_pol[:, :A].copy_(ws.ref_mean)
         ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
 

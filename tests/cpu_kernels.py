@@ -100,7 +100,7 @@ class TorchCpuKernels(object):
         y = self._act(torch.nn.functional.linear(h, w['W3'], w['b3']), act)
         out.view(-1, net.OUT).copy_(y)
 
-    def mlp3_forward(self, net, x, h1, h2, out, act, stop=None):
+    def mlp3_forward(self, net, x, h1, h2, out, act, stop=None, pack=None):
         if stop is not None and int(stop[0]) != 0:
             return
         v = net.views

@@ -228,6 +228,48 @@ def test_mlp3_forward_backward(K, rows, D, H1, H2, OUT, act):
     assert float(od.min()) == 7.0
 
 
+@pytest.mark.parametrize('rows,D,H1,H2,OUT,act', [
+    (30000, 100, 300, 200, 6, L.SMX_ACT_TANH), (24576 + 77, 288, 300, 200, 8, L.SMX_ACT_TANH),
+    (126976, 100, 300, 200, 17, L.SMX_ACT_TANH), (25000, 100, 300, 200, 1, L.SMX_ACT_NONE),
+    (26000, 36, 320, 224, 32, L.SMX_ACT_NONE), (25001, 100, 128, 96, 3, L.SMX_ACT_TANH)])
+def test_mlp3_forward_fused_over_many_rows_keeps_activations(K, rows, D, H1, H2, OUT, act):
+    """K.mlp3_forward(pack=...) from FUSED_ROWS_MIN rows on: ONE launch of the 16-row fused kernel that also stores h1 / h2
+    (smx_mlp3_forward_rows_f32) against the layered launches (smx_mlp3_forward_f32) and the torch-CPU statement; the
+    stop flag; the strided output"""
+    nc, nd = make_net(D, H1, H2, OUT, rows + D, 'cuda')
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g)
+    xd = dev(x)
+    mk = lambda *s: torch.full(s, 9.0, device='cuda')  # noqa: E731
+    h1f, h2f, of = mk(rows, H1), mk(rows, H2), mk(rows, OUT)
+    h1l, h2l, ol = mk(rows, H1), mk(rows, H2), mk(rows, OUT)
+    pack = torch.empty(K.mlp3_packed_numel(nd), device='cuda')
+    assert rows >= K.FUSED_ROWS_MIN and K.lib.smx_mlp3_forward_rows_supported(D, H1, H2, OUT)
+    K.mlp3_forward(nd, xd, h1f, h2f, of, act, pack=pack)
+    K.mlp3_forward(nd, xd, h1l, h2l, ol, act)
+    close(h1f, h1l, msg='h1 vs layered'), close(h2f, h2l, msg='h2 vs layered'), close(of, ol, msg='out vs layered')
+    n = min(rows, 4096)                     # the CPU statement on a slice (first and last rows)
+    for sl in (slice(0, n), slice(rows - n, rows)):
+        h1c, h2c, oc = torch.empty(n, H1), torch.empty(n, H2), torch.empty(n, OUT)
+        C.mlp3_forward(nc, x[sl], h1c, h2c, oc, act)
+        close(h1f[sl], h1c, msg='h1'), close(h2f[sl], h2c, msg='h2'), close(of[sl], oc, msg='out')
+    # a second call after the weights moved (the pack is refreshed inside the call)
+    for v in nd.views.values():
+        v.mul_(0.5)
+    K.mlp3_forward(nd, xd, h1f, h2f, of, act, pack=pack)
+    K.mlp3_forward(nd, xd, h1l, h2l, ol, act)
+    close(of, ol, msg='out after a weight change'), close(h2f, h2l, msg='h2 after a weight change')
+    stop = torch.ones(1, dtype=torch.int32).cuda()
+    of.fill_(7.0)
+    K.mlp3_forward(nd, xd, h1f, h2f, of, act, stop, pack=pack)
+    assert float(of.min()) == 7.0 and float(of.max()) == 7.0
+    # output rows with a stride (a column block of a wider table)
+    wide = torch.full((rows, OUT + 3), 5.0, device='cuda')
+    K.mlp3_forward(nd, xd, h1f, h2f, wide[:, :OUT], act, pack=pack)
+    close(wide[:, :OUT], ol, msg='strided out')
+    assert float(wide[:, OUT:].min()) == 5.0 and float(wide[:, OUT:].max()) == 5.0
+
+
 @pytest.mark.parametrize('rows,D,H1,H2,OUT', [(7936, 100, 300, 200, 6), (2100, 17, 64, 40, 1), (40000, 132, 300, 200, 12),
                                               (900, 100, 300, 200, 6), (131072, 100, 300, 200, 17)])
 def test_mlp3_backward_splitk_over_many_rows(K, rows, D, H1, H2, OUT):
