@@ -8,6 +8,7 @@
 // fixed order (deterministic), and the epilogue (bias / ReLU / tanh / ReLU-mask / bias-gradient /
 // sum-of-squares for clip_grad_norm_) is fused.  Up to 6 problems are grouped into one launch.
 #include "smx_common.h"
+#include "smx_wgrad.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -1358,6 +1359,14 @@ extern "C" int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, cons
 // caller's workspace) and ONE segmented reduce forms the six gradients.  No sum-of-squares partials (the stem path takes
 // the norm of the whole parameter group afterwards).
 static int mlp3_splits(const smx_mlp3_t* n, int64_t rows) {
+    // the hidden layers' gradients on smx_wgrad.hip (one workgroup per CU holds a whole dW and walks ONE chunk of rows):
+    // as many chunks as CUs, chunks of >= 128 rows
+    int wm, wn;
+    if (rows >= SMX_WGRAD_ROWS_MIN && n->D % 4 == 0 && n->H1 % 4 == 0 && n->H2 % 4 == 0 &&
+        (smx_wgrad_rows_plan(n->H1, n->D, &wm, &wn) || smx_wgrad_rows_plan(n->H2, n->H1, &wm, &wn))) {
+        const long s = rows / 128;
+        return (int)(s > 256 ? 256 : s);
+    }
     const int t = ((n->H1 + 31) / 32) * ((n->D + 31) / 32) + ((n->H2 + 31) / 32) * ((n->H1 + 31) / 32) +
                   ((n->OUT + 31) / 32) * ((n->H2 + 31) / 32);
     long s = rows / 1024;
@@ -1411,8 +1420,15 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
     float* wsp = ws;
     // two launches: the layers wide enough for the 64 x 64 tile kernel, and the rest (the output layer: 1 - 17 rows of
     // dW3) on 32 x 32 tiles -- launch_batch() takes a batch to one kernel as a whole
+    // three launches at most: the wide layers straight from the row-major operands (smx_wgrad.hip: no LDS staging, 16 - 25
+    // MFMAs per two or four loads; SMX_WGRAD_TILED=1 keeps them on the tiled GEMM for A/B runs), layers wide enough for
+    // the 64 x 64 tile kernel but not for that one, and the rest (the output layer: 1 - 17 rows of dW3) on 32 x 32 tiles
+    // -- launch_batch() takes a batch to one kernel as a whole
+    static const bool tiled_only = getenv("SMX_WGRAD_TILED") != nullptr;
     GemmBatch Gw, Gr;
-    Gw.n = Gr.n = 0;
+    WgradBatch Gd;
+    Gw.n = Gr.n = Gd.n = 0;
+    Gd.stop = (const int*)stop_flag;
     RedSegs L;
     L.n = 6;
     int base_w = 0, base_r = 0, ebase = 0;
@@ -1421,16 +1437,23 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
         float* wpart = wsp;
         float* bpart = wsp + (size_t)S * M * N;
         wsp = bpart + (size_t)S * M;
-        const bool wide = M >= 48 && N >= 64 && M % 4 == 0 && N % 4 == 0;
-        GemmBatch& G = wide ? Gw : Gr;
-        int& base = wide ? base_w : base_r;
-        GemmProb& P = G.p[G.n++];
-        fill_prob(P, dz[l], M, 0, in[l], N, 0, nullptr, nullptr, wpart, N, M, N, R, SMX_ACT_NONE, bpart, nullptr, base,
-                  stop_flag);
-        P.splits = S;
-        P.k_chunk = k_chunk;
-        P.c_split = (long)M * N;
-        base += P.tiles_m * P.tiles_n * S;
+        if (!tiled_only && smx_wgrad_rows_eligible(dz[l], M, in[l], N, M, N, R)) {
+            WgradProb& P = Gd.p[Gd.n++];
+            P.A = dz[l]; P.B = in[l]; P.Cpart = wpart; P.bpart = bpart;
+            P.M = M; P.N = N; P.lda = M; P.ldb = N; P.rows = R;
+            P.splits = S; P.k_chunk = k_chunk;
+        } else {
+            const bool wide = M >= 48 && N >= 64 && M % 4 == 0 && N % 4 == 0;
+            GemmBatch& G = wide ? Gw : Gr;
+            int& base = wide ? base_w : base_r;
+            GemmProb& P = G.p[G.n++];
+            fill_prob(P, dz[l], M, 0, in[l], N, 0, nullptr, nullptr, wpart, N, M, N, R, SMX_ACT_NONE, bpart, nullptr, base,
+                      stop_flag);
+            P.splits = S;
+            P.k_chunk = k_chunk;
+            P.c_split = (long)M * N;
+            base += P.tiles_m * P.tiles_n * S;
+        }
         L.g[2 * l] = RedSeg{wpart, gdst, ebase, M * N};
         ebase += M * N;
         gdst += (size_t)M * N;
@@ -1439,6 +1462,10 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
         gdst += M;
     }
     L.total = ebase;
+    if (Gd.n) {
+        const int rc = smx_wgrad_rows_launch(Gd, smx_s(stream));
+        if (rc) return rc;
+    }
     for (GemmBatch* G : {&Gw, &Gr}) {
         if (!G->n) continue;
         const int rc = launch_batch(*G, smx_s(stream));

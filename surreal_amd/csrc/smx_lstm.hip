@@ -645,13 +645,17 @@ __device__ __forceinline__ float quad_xor2(float v) {       // lane ^ 2 inside t
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
 }
 
-template <int Q4>          // float4 words per k-quarter: H <= 16 Q4
+// RW batch rows per workgroup (rows RW b .. RW b + RW - 1) share the weights in registers: a step's latency chain
+// (LDS read -> FMAs -> quad reduce -> activation -> LDS write -> barrier, ~1700 cycles of which the FMAs are a quarter)
+// is walked once for RW rows.  One row per workgroup keeps 1024 rows in FOUR rounds of 256 workgroups at 0.18 of the
+// vector rate; RW = 4 is one round.  Every row's arithmetic is what RW = 1 does: results are bit-identical.
+template <int Q4, int RW>   // float4 words per k-quarter: H <= 16 Q4
 __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     if (a.stop && *a.stop) return;
-    __shared__ float4 hs4[2][4][Q4];           // h_{t-1} / h_t by k-quarter, zero padded
+    __shared__ float4 hs4[RW][2][4][Q4];       // h_{t-1} / h_t by k-quarter, zero padded
     const int H = a.H, G = 4 * H, T = a.T, QS = H >> 2;     // (H % 4 == 0)
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b0 = blockIdx.x * RW;
     const bool colv = tid < G;
     const int n = tid >> 2, kq = tid & 3;
     float4 w[4][Q4];
@@ -673,65 +677,90 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     const float bias = colv ? a.b_hh[col] : 0.f;
     const bool is_g = kq == 2;                 // the cell candidate: tanh; the other gates: sigmoid
     float* hs = reinterpret_cast<float*>(hs4);
-    for (int i = tid; i < 2 * 4 * 4 * Q4; i += NT) hs[i] = 0.f;
+    for (int i = tid; i < RW * 2 * 4 * 4 * Q4; i += NT) hs[i] = 0.f;
     __syncthreads();
     const int pos = colv ? (n / QS) * 4 * Q4 + (n % QS) : 0;       // unit n inside the quartered layout
-    if (colv && kq == 0 && a.h0) hs[pos] = a.h0[(size_t)b * H + n];
-    float creg = (colv && a.c0) ? a.c0[(size_t)b * H + n] : 0.f;
     // addressing: a UNIFORM row / step base (scalar registers) + a 32-bit lane offset, so that a step's loads and stores
     // carry no 64-bit vector address arithmetic (it was a fifth of the step's VALU instructions)
-    float* const grow = a.gates + (size_t)b * T * G;          // this row's gates [T][4H]
-    float* const orow = a.out + (size_t)b * T * H;
-    float* const crow = a.cs + (size_t)b * T * H;
-    float* const prow = a.hprev ? a.hprev + (size_t)b * T * H : nullptr;
+    bool rv[RW];                               // (uniform) the row exists
+    float creg[RW];
+    float* grow[RW];
+    float* orow[RW];
+    float* crow[RW];
+    float* prow[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        rv[r] = b0 + r < a.B;
+        const size_t br = rv[r] ? (size_t)(b0 + r) : (size_t)b0;         // (a missing row reads row b0: never stored)
+        if (colv && kq == 0 && a.h0) hs[r * 32 * Q4 + pos] = a.h0[br * H + n];
+        creg[r] = (colv && a.c0) ? a.c0[br * H + n] : 0.f;
+        grow[r] = a.gates + br * T * G;                                  // this row's gates [T][4H]
+        orow[r] = a.out + br * T * H;
+        crow[r] = a.cs + br * T * H;
+        prow[r] = a.hprev ? a.hprev + br * T * H : nullptr;
+    }
     const unsigned ucol = (unsigned)col, un = (unsigned)n;
     // the input half of the gates (smx_linear_f32 wrote it) is requested FOUR steps ahead: the [B, T, 4H] buffer does not
     // stay in L2 between the GEMM and this kernel, and a request made one step ahead -- as in lstm_fwdq_kernel -- makes
-    // every 0.9 us step wait for a memory round trip of about that length.  Four named registers rotated by unrolling.
-    float gx0 = colv ? grow[ucol] : 0.f;
-    float gx1 = (colv && 1 < T) ? (grow + G)[ucol] : 0.f;
-    float gx2 = (colv && 2 < T) ? (grow + 2 * G)[ucol] : 0.f;
-    float gx3 = (colv && 3 < T) ? (grow + 3 * G)[ucol] : 0.f;
+    // every 0.9 us step wait for a memory round trip of about that length.  Four named registers (per row) rotated by
+    // unrolling.
+    float gx0[RW], gx1[RW], gx2[RW], gx3[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        gx0[r] = colv ? grow[r][ucol] : 0.f;
+        gx1[r] = (colv && 1 < T) ? (grow[r] + G)[ucol] : 0.f;
+        gx2[r] = (colv && 2 < T) ? (grow[r] + 2 * G)[ucol] : 0.f;
+        gx3[r] = (colv && 3 < T) ? (grow[r] + 3 * G)[ucol] : 0.f;
+    }
     const bool odd = (kq & 1) != 0, hi = (kq & 2) != 0;
     __syncthreads();
 #define SMX_FWDK_STEP(GX, TT)                                                                                          \
     if ((TT) < T) {                                                                                                    \
         const int t = (TT);                                                                                            \
         const int p = t & 1;                                                                                           \
-        v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};                                        \
-        _Pragma("unroll") for (int q = 0; q < Q4; ++q) {                                                               \
-            const float4 hv = hs4[p][kq][q];                                                                           \
-            const v2f lo = {hv.x, hv.y}, up = {hv.z, hv.w};                                                            \
-            a0 = __builtin_elementwise_fma(lo, (v2f){w[0][q].x, w[0][q].y}, a0);                                       \
-            a1 = __builtin_elementwise_fma(lo, (v2f){w[1][q].x, w[1][q].y}, a1);                                       \
-            a2 = __builtin_elementwise_fma(lo, (v2f){w[2][q].x, w[2][q].y}, a2);                                       \
-            a3 = __builtin_elementwise_fma(lo, (v2f){w[3][q].x, w[3][q].y}, a3);                                       \
-            a0 = __builtin_elementwise_fma(up, (v2f){w[0][q].z, w[0][q].w}, a0);                                       \
-            a1 = __builtin_elementwise_fma(up, (v2f){w[1][q].z, w[1][q].w}, a1);                                       \
-            a2 = __builtin_elementwise_fma(up, (v2f){w[2][q].z, w[2][q].w}, a2);                                       \
-            a3 = __builtin_elementwise_fma(up, (v2f){w[3][q].z, w[3][q].w}, a3);                                       \
+        v2f a0[RW], a1[RW], a2[RW], a3[RW];                                                                            \
+        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                                               \
+            a0[r] = (v2f){0.f, 0.f}; a1[r] = (v2f){0.f, 0.f}; a2[r] = (v2f){0.f, 0.f}; a3[r] = (v2f){0.f, 0.f};       \
         }                                                                                                              \
-        const float p0 = a0.x + a0.y, p1 = a1.x + a1.y, p2 = a2.x + a2.y, p3 = a3.x + a3.y;                            \
-        /* reduce-scatter over the quad.  Step 1 (partner lane ^ 1): even lanes collect gates 0 and 2, odd lanes 1, 3 */ \
-        const float s_lo = (odd ? p1 : p0) + quad_xor1(odd ? p0 : p1);                                                 \
-        const float s_up = (odd ? p3 : p2) + quad_xor1(odd ? p2 : p3);                                                 \
-        /* step 2 (partner lane ^ 2): lanes 0, 1 keep gates 0, 1; lanes 2, 3 keep gates 2, 3 */                        \
-        const float tot = (hi ? s_up : s_lo) + quad_xor2(hi ? s_lo : s_up);                                            \
-        const float pre = GX + (tot + bias);                                                                           \
-        const float sg = fast_sigm(is_g ? 2.f * pre : pre);                                                          \
-        const float act = is_g ? 2.f * sg - 1.f : sg;            /* tanh for the cell candidate, sigmoid otherwise */   \
-        float* const gstep = grow + (size_t)t * G;                   /* uniform */                                      \
-        if (colv) gstep[ucol] = act;                                                                                   \
-        GX = (colv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                                                \
-        const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act); \
-        const float c = gf * creg + gi * gg;                                                                           \
-        const float h = go * fast_tanh(c);                                                                             \
-        creg = c;                                                                                                      \
-        if (colv && kq == 0) {                                                                                         \
-            (orow + (size_t)t * H)[un] = h;                                                                            \
-            (crow + (size_t)t * H)[un] = c;                                                                            \
-            if (prow) (prow + (size_t)t * H)[un] = hs[p * 16 * Q4 + pos];                                              \
-            hs[(1 - p) * 16 * Q4 + pos] = h;                                                                           \
+        _Pragma("unroll") for (int q = 0; q < Q4; ++q) {                                                               \
+            _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                                           \
+                const float4 hv = hs4[r][p][kq][q];                                                                    \
+                const v2f lo = {hv.x, hv.y}, up = {hv.z, hv.w};                                                        \
+                a0[r] = __builtin_elementwise_fma(lo, (v2f){w[0][q].x, w[0][q].y}, a0[r]);                             \
+                a1[r] = __builtin_elementwise_fma(lo, (v2f){w[1][q].x, w[1][q].y}, a1[r]);                             \
+                a2[r] = __builtin_elementwise_fma(lo, (v2f){w[2][q].x, w[2][q].y}, a2[r]);                             \
+                a3[r] = __builtin_elementwise_fma(lo, (v2f){w[3][q].x, w[3][q].y}, a3[r]);                             \
+                a0[r] = __builtin_elementwise_fma(up, (v2f){w[0][q].z, w[0][q].w}, a0[r]);                             \
+                a1[r] = __builtin_elementwise_fma(up, (v2f){w[1][q].z, w[1][q].w}, a1[r]);                             \
+                a2[r] = __builtin_elementwise_fma(up, (v2f){w[2][q].z, w[2][q].w}, a2[r]);                             \
+                a3[r] = __builtin_elementwise_fma(up, (v2f){w[3][q].z, w[3][q].w}, a3[r]);                             \
+            }                                                                                                          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                                               \
+            const float p0 = a0[r].x + a0[r].y, p1 = a1[r].x + a1[r].y, p2 = a2[r].x + a2[r].y, p3 = a3[r].x + a3[r].y; \
+            /* reduce-scatter over the quad.  Step 1 (partner lane ^ 1): even lanes collect gates 0 and 2, odd lanes 1, 3 */ \
+            const float s_lo = (odd ? p1 : p0) + quad_xor1(odd ? p0 : p1);                                             \
+            const float s_up = (odd ? p3 : p2) + quad_xor1(odd ? p2 : p3);                                             \
+            /* step 2 (partner lane ^ 2): lanes 0, 1 keep gates 0, 1; lanes 2, 3 keep gates 2, 3 */                    \
+            const float tot = (hi ? s_up : s_lo) + quad_xor2(hi ? s_lo : s_up);                                        \
+            const float pre = GX[r] + (tot + bias);                                                                    \
+            const float sg = fast_sigm(is_g ? 2.f * pre : pre);                                                      \
+            const float act = is_g ? 2.f * sg - 1.f : sg;        /* tanh for the cell candidate, sigmoid otherwise */   \
+            float* const gstep = grow[r] + (size_t)t * G;                /* uniform */                                  \
+            if (colv && rv[r]) gstep[ucol] = act;                                                                      \
+            GX[r] = (colv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                                         \
+            const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act); \
+            const float c = gf * creg[r] + gi * gg;                                                                    \
+            const float h = go * fast_tanh(c);                                                                         \
+            creg[r] = c;                                                                                               \
+            if (colv && kq == 0) {                                                                                     \
+                if (rv[r]) {                                                                                           \
+                    (orow[r] + (size_t)t * H)[un] = h;                                                                 \
+                    (crow[r] + (size_t)t * H)[un] = c;                                                                 \
+                    if (prow[r]) (prow[r] + (size_t)t * H)[un] = hs[(r * 2 + p) * 16 * Q4 + pos];                      \
+                }                                                                                                      \
+                hs[(r * 2 + 1 - p) * 16 * Q4 + pos] = h;                                                               \
+            }                                                                                                          \
         }                                                                                                              \
         LSTM_LDS_BARRIER();                                                                                            \
     }
@@ -743,8 +772,12 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     }
 #undef SMX_FWDK_STEP
     if (colv && kq == 0) {
-        if (a.hN) a.hN[(size_t)b * H + n] = hs[(T & 1) * 16 * Q4 + pos];
-        if (a.cN) a.cN[(size_t)b * H + n] = creg;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (rv[r]) {
+                if (a.hN) a.hN[(size_t)(b0 + r) * H + n] = hs[(r * 2 + (T & 1)) * 16 * Q4 + pos];
+                if (a.cN) a.cN[(size_t)(b0 + r) * H + n] = creg[r];
+            }
     }
 }
 
@@ -837,13 +870,14 @@ __device__ __forceinline__ float row_from_minus4(float v) {  // lane i <- lane i
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
 }
 
-template <int HH>          // float4 words per half gate block: H <= 8 HH
+// RW batch rows per workgroup share the weights in registers (see lstm_fwdk_kernel): bit-identical to RW = 1 per row.
+template <int HH, int RW>   // float4 words per half gate block: H <= 8 HH
 __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
     if (a.stop && *a.stop) return;
-    __shared__ float4 dg4[2][4][2 * HH];       // the step's dgates, gate block gb at dg4[p][gb] (zero padded)
+    __shared__ float4 dg4[RW][2][4][2 * HH];   // the step's dgates, gate block gb at dg4[r][p][gb] (zero padded)
     const int H = a.H, G = 4 * H, T = a.T;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b0 = blockIdx.x * RW;
     const bool colv = tid < G;
     const int n = colv ? tid >> 2 : 0, gb = tid & 3;                   // element-wise role: gate gb of unit n
     const int e = tid & 7, uA = 2 * (tid >> 3), kgb = e >> 1;          // product role: k-eighth e of units uA, uA + 1
@@ -862,71 +896,105 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
         wB[q] = vb;
     }
     float* dg = reinterpret_cast<float*>(dg4);
-    for (int idx = tid; idx < 2 * 4 * 8 * HH; idx += NT) dg[idx] = 0.f;
+    for (int idx = tid; idx < RW * 2 * 4 * 8 * HH; idx += NT) dg[idx] = 0.f;
     // addressing: uniform row / step bases + 32-bit lane offsets (no 64-bit vector address arithmetic inside the step)
-    const float* const grow = a.gates + (size_t)b * T * G;
-    float* const dgrow = a.dgates + (size_t)b * T * G;
-    const float* const crow = a.cs + (size_t)b * T * H;
-    const float* const drow = a.dout + (size_t)b * T * H;
-    const float* const c0row = a.c0 ? a.c0 + (size_t)b * H : nullptr;
+    bool rv[RW];
+    const float* grow[RW];
+    float* dgrow[RW];
+    const float* crow[RW];
+    const float* drow[RW];
+    const float* c0row[RW];
+    float dcreg[RW], dhr[RW], gmine[RW], c[RW], cp[RW], dout[RW];      // dhr: dh_rec[n] from the previous step's product
     const unsigned ug = (unsigned)(gb * H + n), un = (unsigned)n;
-    float dcreg = 0.f, dhr = 0.f;              // dhr: dh_rec[n] from the previous step's product
-    float gmine = 0.f, c = 0.f, cp = 0.f, dout = 0.f;
-    auto fetch = [&](int t, float& xg, float& xcp, float& xd) {
-        xg = (grow + (size_t)t * G)[ug];                                 // this lane's own gate of unit n
-        xcp = (t > 0) ? (crow + (size_t)(t - 1) * H)[un] : (c0row ? c0row[un] : 0.f);
-        xd = (drow + (size_t)t * H)[un];
-    };
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        rv[r] = b0 + r < a.B;
+        const size_t br = rv[r] ? (size_t)(b0 + r) : (size_t)b0;         // (a missing row reads row b0: never stored)
+        grow[r] = a.gates + br * T * G;
+        dgrow[r] = a.dgates + br * T * G;
+        crow[r] = a.cs + br * T * H;
+        drow[r] = a.dout + br * T * H;
+        c0row[r] = a.c0 ? a.c0 + br * H : nullptr;
+        dcreg[r] = 0.f; dhr[r] = 0.f; gmine[r] = 0.f; c[r] = 0.f; cp[r] = 0.f; dout[r] = 0.f;
+    }
+#define SMX_BWDK_FETCH(r, t, xg, xcp, xd)                                                                            \
+    do {                                                                                                             \
+        xg = (grow[r] + (size_t)(t) * G)[ug];                            /* this lane's own gate of unit n */          \
+        xcp = ((t) > 0) ? (crow[r] + (size_t)((t) - 1) * H)[un] : (c0row[r] ? c0row[r][un] : 0.f);                   \
+        xd = (drow[r] + (size_t)(t) * H)[un];                                                                        \
+    } while (0)
     if (colv) {
-        fetch(T - 1, gmine, cp, dout);
-        c = (crow + (size_t)(T - 1) * H)[un];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            SMX_BWDK_FETCH(r, T - 1, gmine[r], cp[r], dout[r]);
+            c[r] = (crow[r] + (size_t)(T - 1) * H)[un];
+        }
     }
     const bool upper = (tid & 4) != 0;         // the quad of unit uA + 1
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
         const int p = t & 1;
-        float ng = 0.f, ncp = 0.f, nd = 0.f;
-        if (colv && t > 0) fetch(t - 1, ng, ncp, nd);              // the next step's inputs: requested early
-        const float gi = quad_bcast<0>(gmine), gf = quad_bcast<1>(gmine), gg = quad_bcast<2>(gmine),
-                    go = quad_bcast<3>(gmine);
-        const float dh = dout + dhr;
-        const float tc = fast_tanh(c);             // (the forward pass formed h with the same function)
-        const float dc = dcreg + (dh * go) * (1.f - tc * tc);
-        const float dgi = (dc * gg) * (gi * (1.f - gi));
-        const float dgf = (dc * cp) * (gf * (1.f - gf));
-        const float dgg = (dc * gi) * (1.f - gg * gg);
-        const float dgo = (dh * tc) * (go * (1.f - go));
-        dcreg = dc * gf;
-        const float mine = gb == 0 ? dgi : (gb == 1 ? dgf : (gb == 2 ? dgg : dgo));
-        if (colv) {
-            (dgrow + (size_t)t * G)[ug] = mine;
-            dg[((p * 4 + gb) * 8 * HH) + n] = mine;
+        float ng[RW], ncp[RW], nd[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            ng[r] = 0.f; ncp[r] = 0.f; nd[r] = 0.f;
+            if (colv && t > 0) SMX_BWDK_FETCH(r, t - 1, ng[r], ncp[r], nd[r]);     // the next step's inputs: requested early
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float gi = quad_bcast<0>(gmine[r]), gf = quad_bcast<1>(gmine[r]), gg = quad_bcast<2>(gmine[r]),
+                        go = quad_bcast<3>(gmine[r]);
+            const float dh = dout[r] + dhr[r];
+            const float tc = fast_tanh(c[r]);          // (the forward pass formed h with the same function)
+            const float dc = dcreg[r] + (dh * go) * (1.f - tc * tc);
+            const float dgi = (dc * gg) * (gi * (1.f - gi));
+            const float dgf = (dc * cp[r]) * (gf * (1.f - gf));
+            const float dgg = (dc * gi) * (1.f - gg * gg);
+            const float dgo = (dh * tc) * (go * (1.f - go));
+            dcreg[r] = dc * gf;
+            const float mine = gb == 0 ? dgi : (gb == 1 ? dgf : (gb == 2 ? dgg : dgo));
+            if (colv) {
+                if (rv[r]) (dgrow[r] + (size_t)t * G)[ug] = mine;
+                dg[(((r * 2 + p) * 4 + gb) * 8 * HH) + n] = mine;
+            }
         }
         LSTM_LDS_BARRIER();
         if (t > 0) {                               // (every lane: lanes past 4 H hold zero weights)
-            v2f accA = {0.f, 0.f}, accB = {0.f, 0.f};
+            v2f accA[RW], accB[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) { accA[r] = (v2f){0.f, 0.f}; accB[r] = (v2f){0.f, 0.f}; }
 #pragma unroll
             for (int q = 0; q < HH; ++q) {
-                const float4 dv = dg4[p][kgb][q0 + q];
-                const v2f lo = {dv.x, dv.y}, up = {dv.z, dv.w};
-                accA = __builtin_elementwise_fma(lo, (v2f){wA[q].x, wA[q].y}, accA);
-                accB = __builtin_elementwise_fma(lo, (v2f){wB[q].x, wB[q].y}, accB);
-                accA = __builtin_elementwise_fma(up, (v2f){wA[q].z, wA[q].w}, accA);
-                accB = __builtin_elementwise_fma(up, (v2f){wB[q].z, wB[q].w}, accB);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const float4 dv = dg4[r][p][kgb][q0 + q];
+                    const v2f lo = {dv.x, dv.y}, up = {dv.z, dv.w};
+                    accA[r] = __builtin_elementwise_fma(lo, (v2f){wA[q].x, wA[q].y}, accA[r]);
+                    accB[r] = __builtin_elementwise_fma(lo, (v2f){wB[q].x, wB[q].y}, accB[r]);
+                    accA[r] = __builtin_elementwise_fma(up, (v2f){wA[q].z, wA[q].w}, accA[r]);
+                    accB[r] = __builtin_elementwise_fma(up, (v2f){wB[q].z, wB[q].w}, accB[r]);
+                }
             }
-            const float pA = accA.x + accA.y, pB = accB.x + accB.y;
-            // the two quads swap the partial of the unit the OTHER one owns
-            const float give = upper ? pA : pB;
-            // (both DPP moves run with every lane enabled: under a divergent branch a disabled source lane reads as 0)
-            const float from_lo = row_from_minus4(give), from_up = row_from_plus4(give);
-            const float got = upper ? from_lo : from_up;
-            const float s1 = (upper ? pB : pA) + got;
-            const float s2 = s1 + quad_xor1(s1);
-            dhr = s2 + quad_xor2(s2);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float pA = accA[r].x + accA[r].y, pB = accB[r].x + accB[r].y;
+                // the two quads swap the partial of the unit the OTHER one owns
+                const float give = upper ? pA : pB;
+                // (both DPP moves run with every lane enabled: under a divergent branch a disabled source lane reads as 0)
+                const float from_lo = row_from_minus4(give), from_up = row_from_plus4(give);
+                const float got = upper ? from_lo : from_up;
+                const float s1 = (upper ? pB : pA) + got;
+                const float s2 = s1 + quad_xor1(s1);
+                dhr[r] = s2 + quad_xor2(s2);
+            }
         }
-        c = cp;
-        gmine = ng; cp = ncp; dout = nd;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            c[r] = cp[r];
+            gmine[r] = ng[r]; cp[r] = ncp[r]; dout[r] = nd[r];
+        }
     }
+#undef SMX_BWDK_FETCH
 }
 
 constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
@@ -966,9 +1034,13 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;       // the LDS-exchange one-row kernels, for A/B runs
     static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;   // every lane reads all of h (the round-3 first form)
     if (!mfma4 && !v1 && !quad && H <= 112) {
-        hipLaunchKernelGGL((lstm_fwdk_kernel<7>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+        // rows per workgroup: as many as keep >= 256 workgroups (one per CU), at most 4
+        if (B >= 1024) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 4>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
+        else if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 128) {
-        hipLaunchKernelGGL((lstm_fwdk_kernel<8>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+        if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<8, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_fwdk_kernel<8, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 100) {
         hipLaunchKernelGGL((lstm_fwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 128) {
@@ -1017,9 +1089,12 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;
     static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;
     if (!mfma4 && !v1 && !quad && H <= 104) {
-        hipLaunchKernelGGL((lstm_bwdk_kernel<13>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+        if (B >= 1024) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 4>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
+        else if (B >= 512) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_bwdk_kernel<13, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 128) {
-        hipLaunchKernelGGL((lstm_bwdk_kernel<16>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+        if (B >= 512) hipLaunchKernelGGL((lstm_bwdk_kernel<16, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_bwdk_kernel<16, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 100) {
         hipLaunchKernelGGL((lstm_bwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 128) {

@@ -1,0 +1,28 @@
+// smx_wgrad.hip: split-K weight gradients over many rows straight from the row-major operands (no LDS staging).
+#pragma once
+#include "smx_common.h"
+
+constexpr int WGRAD_MAX_PROBS = 4;
+constexpr long SMX_WGRAD_ROWS_MIN = 32768;     // below: too few row chunks of a useful length for one workgroup per CU
+
+struct WgradProb {
+    const float* A;      // dZ [rows, >= M], row stride lda
+    const float* B;      // X  [rows, >= N], row stride ldb
+    float* Cpart;        // [splits][M][N] partial matrices (dense)
+    float* bpart;        // [splits][M] partial column sums of dZ, or null
+    int M, N, lda, ldb, rows;
+    int splits, k_chunk; // rows [s k_chunk, (s + 1) k_chunk) belong to split s; k_chunk % 32 == 0
+    int wm, wn;          // the workgroup's 8 wavefronts as wm x wn blocks of tiles (filled by smx_wgrad_rows_launch)
+    int wg_base;
+};
+struct WgradBatch {
+    WgradProb p[WGRAD_MAX_PROBS];
+    int n;
+    const int* stop;
+};
+
+__attribute__((visibility("hidden"))) bool smx_wgrad_rows_eligible(const float* A, int lda, const float* B, int ldb, int M, int N,
+                                                                 long rows);
+__attribute__((visibility("hidden"))) int smx_wgrad_rows_launch(WgradBatch& G, hipStream_t st);
+// shape-only part of the eligibility test (what sizes the split-K workspace)
+__attribute__((visibility("hidden"))) bool smx_wgrad_rows_plan(int M, int N, int* wm, int* wn);

@@ -912,7 +912,10 @@ def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
     (37, 9, 17, 100, False),     # ragged rows, zero initial state
     (64, 21, 17, 100, True),     # cfg2-sized batch
     (6, 7, 9, 108, True),        # 100 < H <= 112: the wider 4-row instantiation
-    (1024, 3, 17, 100, True),    # one workgroup per 4 rows: 256 workgroups
+    (1024, 3, 17, 100, True),    # four rows per workgroup (B >= 1024): 256 workgroups
+    (1027, 6, 17, 100, True),    # ... with a ragged last workgroup (3 of 4 rows)
+    (515, 7, 17, 100, False),    # two rows per workgroup (512 <= B < 1024), ragged
+    (513, 5, 9, 128, True),      # the H <= 128 instantiation, two rows per workgroup
     (3, 5, 9, 128, True),        # H > 112: 16-row kernels, W_hh fragments re-read every step
     (20, 6, 11, 256, True),
 ])

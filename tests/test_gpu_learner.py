@@ -305,14 +305,18 @@ def test_fused_fwdbwd_timeout_fails_loudly_and_falls_back():
     batch, params, zstate = H.case_inputs(case)
     learner = H.make_learner(case, params, zstate)
     db = learner._preprocess_batch_ppo(copy.deepcopy(batch))
+    learner.learn(db)                                 # the first learn() captures the graph (and would re-run a failed pass)
+    torch.cuda.synchronize()
+    for m in (learner.model, learner.ref_target_model):
+        m.load_params(params)
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     with torch.cuda.stream(side):
-        learner.K.device_occupy(224, 450000)          # 32 CUs left: 96 of the first epoch launch's 128 workgroups cannot start
+        # 4 CUs left per XCD: 16 of the epoch launch's 64 actor workgroups are resident and wait for the other 48
+        learner.K.device_occupy(224, 450000)
     with pytest.raises(RuntimeError, match='exclusive_device'):
         stats = learner.learn(db)
         dict(stats)                                   # (deferred statistics resolve here)
-        learner.learn(db)                             # ... at the latest when the next learn has been enqueued
     torch.cuda.synchronize()
     assert learner._fb_timed_out
     fresh = H.make_learner(case, params, zstate)
