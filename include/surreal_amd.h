@@ -231,6 +231,21 @@ int64_t smx_mlp3_backward_ws_floats(int32_t D, int32_t H1, int32_t H2, int32_t O
 int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
                                  const float* dz3, int64_t rows, float* dz2, float* dz1, float* grads, float* ws,
                                  int64_t ws_floats, const int32_t* stop_flag, smx_stream_t stream);
+/* ... with the three data-gradient products as ONE fused launch in front of the split-K weight gradients
+ * (csrc/smx_mlp3_bwd16.hip: a wavefront owns 16 rows from dz3 to dx, dz2 / dz1 go from the accumulators to memory once
+ * and on in registers; the weight gradients of the hidden layers run with the whole dW in one workgroup's registers,
+ * csrc/smx_wgrad.hip).  dx [rows, D] (may be NULL): the gradient with respect to the MLP's input -- what the layered
+ * path leaves to a separate smx_linear_f32(dz1, W1) call.  packedT: scratch of smx_mlp3_dgrad_rows_ws_floats() floats,
+ * 16-byte aligned.  Returns SMX_E_UNSUPPORTED -- nothing launched -- outside the fused kernel's shapes
+ * (smx_mlp3_dgrad_rows_supported: D <= 128, D / H1 / H2 multiples of 4, 64 < H1 <= 320, 64 < H2 <= 224, OUT <= 32),
+ * for unaligned operands, or when rows are too few for a split-K workspace: the caller then uses the call above.
+ * Same sums in another order: equal within fp32 rounding, not bit for bit. */
+int32_t smx_mlp3_dgrad_rows_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int64_t smx_mlp3_dgrad_rows_ws_floats(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
+int smx_mlp3_backward_rows_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
+                               const float* dz3, int64_t rows, float* dz2, float* dz1, float* dx, float* grads,
+                               float* ws, int64_t ws_floats, float* packedT, int64_t packedT_floats,
+                               const int32_t* stop_flag, smx_stream_t stream);
 
 /* --- windowed GAE / n-step returns (surreal/learner/ppo.py:387-418) ----------
  * values [B,N+1] RAW critic outputs -- or, when values_tail != NULL, values [B,N] for the N

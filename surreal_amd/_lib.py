@@ -198,6 +198,10 @@ _SIGS = {
                                         _P, _P]),
     'smx_mlp3_backward_ws_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int64]),
     'smx_mlp3_backward_splitk_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P]),
+    'smx_mlp3_dgrad_rows_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_mlp3_dgrad_rows_ws_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    'smx_mlp3_backward_rows_f32': (c_int32, [POINTER(Mlp3), _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, _P, c_int64,
+                                             _P, _P]),
     'smx_windowed_gae_returns_f32': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int32,
                                                c_int32, c_int32, _P, _P, _P]),
     'smx_windowed_gae_norm_f32': (c_int32, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int32, c_int32, c_int32, _P, _P, _P,

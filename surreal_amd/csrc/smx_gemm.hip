@@ -9,6 +9,7 @@
 // sum-of-squares for clip_grad_norm_) is fused.  Up to 6 problems are grouped into one launch.
 #include "smx_common.h"
 #include "smx_wgrad.h"
+#include "smx_mlp3_bwd16.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -1080,6 +1081,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 inline int pick_splits(int M, int N, int rows) {
+    int wm, wn;
+    if (rows >= SMX_WGRAD_ROWS_MIN && M % 4 == 0 && N % 4 == 0 && smx_wgrad_rows_plan(M, N, &wm, &wn)) {
+        const int s = rows / 128;           // smx_wgrad.hip: one workgroup per CU walks one chunk of >= 128 rows
+        return s > 256 ? 256 : s;
+    }
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
     int s = rows / 1024;                    // >= 8 super-blocks per wave and chunk
     const int cap = (2048 + tiles - 1) / tiles;     // ~8 workgroups per CU at most
@@ -1115,8 +1121,22 @@ extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const f
     G.p[0].c_split = (long)M * N;
     // every chunk must be non-empty
     while ((long)(G.p[0].splits - 1) * G.p[0].k_chunk >= rows) --G.p[0].splits;
-    const int rc = launch_batch(G, smx_s(stream));
-    if (rc) return rc;
+    static const bool tiled_only = getenv("SMX_WGRAD_TILED") != nullptr;
+    if (!tiled_only && smx_wgrad_rows_eligible(dZ, ldz, X, ldx, M, N, rows)) {
+        // the whole dW in one workgroup's registers, every operand row read once (smx_wgrad.hip)
+        WgradBatch Gd;
+        Gd.n = 1;
+        Gd.stop = nullptr;
+        WgradProb& P = Gd.p[0];
+        P.A = dZ; P.B = X; P.Cpart = part; P.bpart = dbpart;
+        P.M = M; P.N = N; P.lda = ldz; P.ldb = ldx; P.rows = rows;
+        P.splits = G.p[0].splits; P.k_chunk = G.p[0].k_chunk;
+        const int rc = smx_wgrad_rows_launch(Gd, smx_s(stream));
+        if (rc) return rc;
+    } else {
+        const int rc = launch_batch(G, smx_s(stream));
+        if (rc) return rc;
+    }
     const long total = (long)M * N + M;
     long blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -1388,29 +1408,11 @@ extern "C" int64_t smx_mlp3_backward_ws_floats(int32_t D, int32_t H1, int32_t H2
     return S > 1 ? (int64_t)S * mlp3_numel(&n) : 0;
 }
 
-extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
-                                            const float* dz3, int64_t rows, float* dz2, float* dz1, float* grads,
-                                            float* ws, int64_t ws_floats, const int32_t* stop_flag,
-                                            smx_stream_t stream) {
-    SMX_REQUIRE(net && x && h1 && h2 && dz3 && dz2 && dz1 && grads, SMX_E_NULL);
-    SMX_REQUIRE(rows > 0 && rows < (1 << 30), SMX_E_SHAPE);
-    int S = mlp3_splits(net, rows);
-    if (S <= 1 || !ws || ws_floats < (int64_t)S * mlp3_numel(net))
-        return smx_mlp3_backward_f32(net, x, h1, h2, dz3, rows, dz2, dz1, grads, nullptr, stop_flag, stream);
-    const int R = (int)rows, D = net->D, H1 = net->H1, H2 = net->H2, O = net->OUT;
-    // dz2 = (dz3 . W3) * relu'(h2), dz1 = (dz2 . W2) * relu'(h1): as smx_mlp3_backward_multi_f32
-    for (int stage = 0; stage < 2; ++stage) {
-        GemmBatch G;
-        G.n = 1;
-        if (stage == 0)
-            fill_prob(G.p[0], dz3, O, 1, net->W3, H2, 0, nullptr, h2, dz2, H2, R, H2, O, SMX_ACT_NONE, nullptr, nullptr, 0,
-                      stop_flag);
-        else
-            fill_prob(G.p[0], dz2, H2, 1, net->W2, H1, 0, nullptr, h1, dz1, H1, R, H1, H2, SMX_ACT_NONE, nullptr, nullptr,
-                      0, stop_flag);
-        const int rc = launch_batch(G, smx_s(stream));
-        if (rc) return rc;
-    }
+// the weight-gradient half of the many-row backward: split-K partials in the workspace + one segmented reduce
+static int mlp3_wgrads_splitk(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2, const float* dz3,
+                              const int R, const float* dz2, const float* dz1, float* grads, float* ws, int S,
+                              const int32_t* stop_flag, smx_stream_t stream) {
+    const int D = net->D, H1 = net->H1, H2 = net->H2, O = net->OUT;
     int k_chunk = ((R + S - 1) / S + 31) & ~31;
     while ((long)(S - 1) * k_chunk >= R) --S;                 // every chunk non-empty
     const float* dz[3] = {dz1, dz2, dz3};
@@ -1418,10 +1420,8 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
     const int Ms[3] = {H1, H2, O}, Ns[3] = {D, H1, H2};
     float* gdst = grads;
     float* wsp = ws;
-    // two launches: the layers wide enough for the 64 x 64 tile kernel, and the rest (the output layer: 1 - 17 rows of
-    // dW3) on 32 x 32 tiles -- launch_batch() takes a batch to one kernel as a whole
-    // three launches at most: the wide layers straight from the row-major operands (smx_wgrad.hip: no LDS staging, 16 - 25
-    // MFMAs per two or four loads; SMX_WGRAD_TILED=1 keeps them on the tiled GEMM for A/B runs), layers wide enough for
+    // three launches at most: the wide layers straight from the row-major operands (smx_wgrad.hip: the whole dW in one
+    // workgroup's registers; SMX_WGRAD_TILED=1 keeps them on the tiled GEMM for A/B runs), layers wide enough for
     // the 64 x 64 tile kernel but not for that one, and the rest (the output layer: 1 - 17 rows of dW3) on 32 x 32 tiles
     // -- launch_batch() takes a batch to one kernel as a whole
     static const bool tiled_only = getenv("SMX_WGRAD_TILED") != nullptr;
@@ -1476,3 +1476,50 @@ extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* 
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
+
+extern "C" int smx_mlp3_backward_splitk_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
+                                            const float* dz3, int64_t rows, float* dz2, float* dz1, float* grads,
+                                            float* ws, int64_t ws_floats, const int32_t* stop_flag,
+                                            smx_stream_t stream) {
+    SMX_REQUIRE(net && x && h1 && h2 && dz3 && dz2 && dz1 && grads, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && rows < (1 << 30), SMX_E_SHAPE);
+    int S = mlp3_splits(net, rows);
+    if (S <= 1 || !ws || ws_floats < (int64_t)S * mlp3_numel(net))
+        return smx_mlp3_backward_f32(net, x, h1, h2, dz3, rows, dz2, dz1, grads, nullptr, stop_flag, stream);
+    const int R = (int)rows, H1 = net->H1, H2 = net->H2, O = net->OUT;
+    // dz2 = (dz3 . W3) * relu'(h2), dz1 = (dz2 . W2) * relu'(h1): as smx_mlp3_backward_multi_f32
+    for (int stage = 0; stage < 2; ++stage) {
+        GemmBatch G;
+        G.n = 1;
+        if (stage == 0)
+            fill_prob(G.p[0], dz3, O, 1, net->W3, H2, 0, nullptr, h2, dz2, H2, R, H2, O, SMX_ACT_NONE, nullptr, nullptr, 0,
+                      stop_flag);
+        else
+            fill_prob(G.p[0], dz2, H2, 1, net->W2, H1, 0, nullptr, h1, dz1, H1, R, H1, H2, SMX_ACT_NONE, nullptr, nullptr,
+                      0, stop_flag);
+        const int rc = launch_batch(G, smx_s(stream));
+        if (rc) return rc;
+    }
+    return mlp3_wgrads_splitk(net, x, h1, h2, dz3, R, dz2, dz1, grads, ws, S, stop_flag, stream);
+}
+
+// The same with the data gradients as ONE fused launch (smx_mlp3_bwd16.hip: dz3 -> dz2 -> dz1 -> dx with the
+// intermediates handed on in registers) in front of the split-K weight gradients.  dx [rows, D] (may be NULL): the
+// gradient with respect to the MLP's input, which the layered path leaves to a separate smx_linear_f32 call.
+// packedT: scratch of smx_mlp3_dgrad_rows_ws_floats() floats for the transposed packed weights.
+// SMX_E_UNSUPPORTED (nothing launched) outside the fused kernel's shapes or without a split-K workspace: the caller
+// then uses smx_mlp3_backward_splitk_f32 + smx_linear_f32.
+extern "C" int smx_mlp3_backward_rows_f32(const smx_mlp3_t* net, const float* x, const float* h1, const float* h2,
+                                          const float* dz3, int64_t rows, float* dz2, float* dz1, float* dx, float* grads,
+                                          float* ws, int64_t ws_floats, float* packedT, int64_t packedT_floats,
+                                          const int32_t* stop_flag, smx_stream_t stream) {
+    SMX_REQUIRE(net && x && h1 && h2 && dz3 && dz2 && dz1 && grads && packedT, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && rows < (1 << 30), SMX_E_SHAPE);
+    const int S = mlp3_splits(net, rows);
+    if (S <= 1 || !ws || ws_floats < (int64_t)S * mlp3_numel(net)) return SMX_E_UNSUPPORTED;
+    const int rc = smx_mlp3_dgrad_rows_launch(net, h1, h2, dz3, rows, dz2, dz1, dx, packedT, packedT_floats, stop_flag,
+                                              smx_s(stream));
+    if (rc) return rc;
+    return mlp3_wgrads_splitk(net, x, h1, h2, dz3, (int)rows, dz2, dz1, grads, ws, S, stop_flag, stream);
+}
+

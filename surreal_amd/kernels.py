@@ -145,20 +145,35 @@ class HipKernels(object):
     def mlp3_backward_partials(self, net):
         return self.lib.smx_mlp3_backward_partials(net.D, net.H1, net.H2, net.OUT)
 
-    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None, ws=None):
+    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None, ws=None, packT=None, dx=None):
         """ws: optional split-K workspace (>= mlp3_backward_ws_floats(net, rows) floats) for many-row calls that do
-        not need the sum-of-squares partials: the weight gradients' rows are cut into chunks"""
+        not need the sum-of-squares partials: the weight gradients' rows are cut into chunks.
+        packT (scratch of mlp3_dgrad_rows_ws_floats(net) floats) [+ dx (rows, D): wanted gradient w.r.t. x]: from
+        FUSED_ROWS_MIN rows on the three data-gradient products run as ONE fused launch (smx_mlp3_backward_rows_f32).
+        -> True when dx was written (the caller then skips its own dz1 . W1 product)"""
+        if ws is not None and sumsq is None and packT is not None and x.shape[0] >= self.FUSED_ROWS_MIN and \
+                dz2.is_contiguous() and dz1.is_contiguous() and (dx is None or dx.is_contiguous()):
+            rc = L.load().smx_mlp3_backward_rows_f32(
+                ctypes.byref(net.desc), L.ptr(x), L.ptr(h1), L.ptr(h2), L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1),
+                L.ptr(dx), L.ptr(grads), L.ptr(ws), ws.numel(), L.ptr(packT), packT.numel(), L.ptr(stop), self._st())
+            if rc != L.SMX_E_UNSUPPORTED:
+                L.check(rc, 'smx_mlp3_backward_rows_f32')
+                return dx is not None
         if ws is not None and sumsq is None:
             L.call('smx_mlp3_backward_splitk_f32', ctypes.byref(net.desc), L.ptr(x), L.ptr(h1), L.ptr(h2),
                    L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1), L.ptr(grads), L.ptr(ws), ws.numel(),
                    L.ptr(stop), self._st())
-            return
+            return False
         L.call('smx_mlp3_backward_f32', ctypes.byref(net.desc), L.ptr(x), L.ptr(h1), L.ptr(h2),
                L.ptr(dz3), x.shape[0], L.ptr(dz2), L.ptr(dz1), L.ptr(grads), L.ptr(sumsq),
                L.ptr(stop), self._st())
 
     def mlp3_backward_ws_floats(self, net, rows):
         return int(self.lib.smx_mlp3_backward_ws_floats(net.D, net.H1, net.H2, net.OUT, int(rows)))
+
+    def mlp3_dgrad_rows_ws_floats(self, net):
+        """floats of the transposed-weights scratch of the fused many-row data gradients (0: shape not supported)"""
+        return int(self.lib.smx_mlp3_dgrad_rows_ws_floats(net.D, net.H1, net.H2, net.OUT))
 
     # ---- fused row-block epoch kernels (csrc/smx_epoch.hip) ------------------------------
     def epoch_supported(self, *nets):

@@ -418,6 +418,8 @@ class PPOLearner(Learner):
                 ws.pack_stem = f(max(K.mlp3_packed_numel(n) for n in (act, cri)))
             except Exception:
                 ws.pack_stem = None
+            n_pt = max(K.mlp3_dgrad_rows_ws_floats(n) for n in (act, cri))
+            ws.packT_stem = f(n_pt) if n_pt else None    # ... and of the fused many-row data gradients (K.mlp3_backward)
             if rnn:
                 # LSTM stem (ppo_net.py:143-152): sequence buffers for the epoch passes (T = E)
                 # and for the critic pass (T = N + 1, ppo.py:376-386)
@@ -1290,11 +1292,15 @@ class PPOLearner(Learner):
         B, E, D = ws.key[0], ws.E, ws.key[2]
         top = ws.upper[-1] if (m.if_rnn and ws.upper) else ws
         x = top.lo if m.if_rnn else ws.xn
-        K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop, ws=ws.mlp_sk)
+        # (from FUSED_ROWS_MIN rows on: the three data-gradient products, d loss / d (LSTM output) among them, as one fused
+        # launch -- kernels.mlp3_backward says whether it wrote dx)
+        have_dx = K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, g_mlp, None, stop, ws=ws.mlp_sk,
+                                  packT=ws.packT_stem, dx=top.dlo if m.if_rnn else None)
         if m.if_rnn:
             # d loss / d (LSTM output) = dz1 . W1, then BPTT (dgates overwrite the saved gates)
             F = m.rnn_hidden
-            K.linear(dz1, 1, net.views['W1'], 0, None, top.dlo, ws.rows, F, net.H1, stop=stop)
+            if not have_dx:
+                K.linear(dz1, 1, net.views['W1'], 0, None, top.dlo, ws.rows, F, net.H1, stop=stop)
             for layer in range(len(ws.upper), 0, -1):      # stacked layers, top down (rnn_layer > 1)
                 up = ws.upper[layer - 1]
                 below = ws.upper[layer - 2] if layer > 1 else ws

@@ -55,6 +55,9 @@ class TorchCpuKernels(object):
         cnt += float(count_rows)
 
     # ---- MLP ----------------------------------------------------------------------------
+    def mlp3_dgrad_rows_ws_floats(self, net):
+        return 0
+
     def mlp3_packed_numel(self, net):
         return net.numel          # opaque to the caller
 
@@ -137,9 +140,9 @@ class TorchCpuKernels(object):
     def mlp3_backward_ws_floats(self, net, rows):
         return 0
 
-    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None, ws=None):
+    def mlp3_backward(self, net, x, h1, h2, dz3, dz2, dz1, grads, sumsq, stop=None, ws=None, packT=None, dx=None):
         if stop is not None and int(stop[0]) != 0:
-            return
+            return False
         v = net.views
         dz2.copy_((dz3 @ v['W3']) * (h2 > 0))
         dz1.copy_((dz2 @ v['W2']) * (h1 > 0))

@@ -235,6 +235,7 @@ def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):
         np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg='%s stat %s' % (what, k))
 
 
+CHECKSUM_RTOL = {'cfg5_rnn_adapt': 1e-3}      # squared-sum checksums of the big stem cases (assert_final_params)
 FINAL_PARAM_REPORT = {}      # 'case tensor' -> (fraction of elements off by > atol, max diff, elements)
 
 
@@ -258,7 +259,12 @@ def assert_final_params(learner, g, case, atol=1e-5, what=''):
         # Adam steps on noise-floor gradients take them.  Measured: the oracle on the GPU box's host is off the golden
         # by up to 5.8e-4 on these checksums (cnn.conv2.b), the HIP path -- whose split-K weight / bias gradients sum
         # 3.4 M patch rows in another order -- by up to 3.5e-3 (cnn.fc.b); weights agree to 1e-4 or better on both)
-        np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=5e-3 if what in CASE_LOOSE_RTOL else 1e-4,
+        # (cfg5_rnn_adapt, 126 976 rows per epoch: the critic's bias vectors -- 200 / 300 elements of ~0.03 -- are where it
+        # shows.  One element taking one of its 10 Adam steps in the other direction (its gradient, a sum over 126 976
+        # rows in split-K order, sits at the fp32 noise floor; Adam turns it into +- lr) moves the squared sum by 5.7e-5
+        # relative.  Measured on two generations of the weight-gradient kernels: 2.3e-4 and 1.2e-4 on critic.fc2.b = 2 - 4
+        # of 2000 element-steps; every weight matrix within 1e-4.  Bound: 1e-3.)
+        np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=CHECKSUM_RTOL.get(what, 5e-3 if what in CASE_LOOSE_RTOL else 1e-4),
                                    err_msg=what + ' sumsq ' + k)
 
 

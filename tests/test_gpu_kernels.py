@@ -309,6 +309,57 @@ def test_mlp3_backward_splitk_over_many_rows(K, rows, D, H1, H2, OUT):
     assert float(g_split.min()) == 3.0 and float(g_split.max()) == 3.0
 
 
+@pytest.mark.parametrize('rows,D,H1,H2,OUT', [
+    (126976, 100, 300, 200, 6), (30000, 100, 300, 200, 17), (25000, 100, 300, 200, 1), (24576 + 5, 64, 128, 96, 3),
+    (25003, 128, 320, 224, 32), (40000, 36, 300, 200, 8)])
+def test_mlp3_backward_fused_data_gradients_over_many_rows(K, rows, D, H1, H2, OUT):
+    """K.mlp3_backward(ws=, packT=, dx=) from FUSED_ROWS_MIN rows on: dz3 -> dz2 -> dz1 -> dx as ONE launch
+    (smx_mlp3_backward_rows_f32) + the register-resident weight gradients, against the layered launches (+ the separate
+    dz1 . W1 product) and against a float64 statement of loss.backward(); the stop flag"""
+    _, nd = make_net(D, H1, H2, OUT, rows + D, 'cuda')
+    g = torch.Generator(device='cuda').manual_seed(rows)
+    x = torch.randn(rows, D, device='cuda', generator=g)
+    f = lambda *s: torch.empty(*s, device='cuda')  # noqa: E731
+    h1, h2, out = f(rows, H1), f(rows, H2), f(rows, OUT)
+    K.mlp3_forward(nd, x, h1, h2, out, L.SMX_ACT_NONE)
+    dz3 = torch.randn(rows, OUT, device='cuda', generator=g) / rows
+    n = nd.numel
+    ws = f(K.mlp3_backward_ws_floats(nd, rows))
+    npt = K.mlp3_dgrad_rows_ws_floats(nd)
+    assert npt > 0 and rows >= K.FUSED_ROWS_MIN
+    packT = f(npt)
+    gf, gl = torch.full((n,), float('nan'), device='cuda'), torch.zeros(n, device='cuda')
+    dz2f, dz1f, dxf = torch.full((rows, H2), 7.0, device='cuda'), torch.full((rows, H1), 7.0, device='cuda'), \
+        torch.full((rows, D), 7.0, device='cuda')
+    dz2l, dz1l, dxl = f(rows, H2), f(rows, H1), f(rows, D)
+    assert K.mlp3_backward(nd, x, h1, h2, dz3, dz2f, dz1f, gf, None, ws=ws, packT=packT, dx=dxf) is True
+    assert not K.mlp3_backward(nd, x, h1, h2, dz3, dz2l, dz1l, gl, None, ws=ws)
+    K.linear(dz1l, 1, nd.views['W1'], 0, None, dxl, rows, D, H1)
+    scale = lambda t: float(t.abs().max())  # noqa: E731
+    for got, ref, what in ((dz2f, dz2l, 'dz2'), (dz1f, dz1l, 'dz1'), (dxf, dxl, 'dx'), (gf, gl, 'grads')):
+        sc = scale(ref)
+        close(got / sc, ref / sc, atol=2e-6, rtol=2e-5, msg=what + ' vs layered')
+    v = nd.views
+    d3 = dz3.double()
+    d2 = (d3 @ v['W3'].double()) * (h2 > 0)
+    d1 = (d2 @ v['W2'].double()) * (h1 > 0)
+    dx64 = d1 @ v['W1'].double()
+    want = torch.cat([t.reshape(-1) for t in (d1.t() @ x.double(), d1.sum(0), d2.t() @ h1.double(), d2.sum(0),
+                                              d3.t() @ h2.double(), d3.sum(0))]).float()
+    close(gf, want, atol=2e-6, rtol=2e-5, msg='grads vs float64')
+    sc = scale(dx64)
+    close(dxf / sc, (dx64 / sc).float(), atol=2e-6, rtol=2e-5, msg='dx vs float64')
+    close(dz1f / scale(d1), (d1 / scale(d1)).float(), atol=2e-6, rtol=2e-5, msg='dz1 vs float64')
+    # without dx (a stem that needs no input gradient): same dz / grads, nothing else written
+    gf2 = torch.zeros(n, device='cuda')
+    assert K.mlp3_backward(nd, x, h1, h2, dz3, dz2f, dz1f, gf2, None, ws=ws, packT=packT) is False
+    assert torch.equal(gf2, gf)
+    stop = torch.ones(1, dtype=torch.int32, device='cuda')
+    gf.fill_(3.0); dxf.fill_(4.0)
+    K.mlp3_backward(nd, x, h1, h2, dz3, dz2f, dz1f, gf, None, stop, ws=ws, packT=packT, dx=dxf)
+    assert float(gf.min()) == 3.0 and float(gf.max()) == 3.0 and float(dxf.min()) == 4.0 and float(dxf.max()) == 4.0
+
+
 @pytest.mark.parametrize('G,T0,T1,D,H1,H2,OUT,z', [
     (8, 12, 1, 11, 24, 16, 1, True), (37, 19, 1, 29, 40, 24, 1, True),
     (5, 7, 0, 16, 64, 64, 6, False), (64, 128, 1, 17, 300, 200, 1, True),
