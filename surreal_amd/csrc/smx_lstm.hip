@@ -39,6 +39,11 @@ struct FwdArgs {
     float* cN;
     const int* stop;
     int B, T, H;
+    // lstm_fwdk_kernel<.., FOLD = true>: the input half of the gates formed INSIDE the recurrence (D <= 20)
+    const float* x;      // [B, T, D]
+    const float* W_ih;   // [4H, D]
+    const float* b_ih;   // [4H]
+    int D;
 };
 
 // ---- 16-row workgroups on 16x16x4 MFMA: the large-H variant (112 < H <= 384).  W_hh does not fit
@@ -649,7 +654,13 @@ __device__ __forceinline__ float quad_xor2(float v) {       // lane ^ 2 inside t
 // (LDS read -> FMAs -> quad reduce -> activation -> LDS write -> barrier, ~1700 cycles of which the FMAs are a quarter)
 // is walked once for RW rows.  One row per workgroup keeps 1024 rows in FOUR rounds of 256 workgroups at 0.18 of the
 // vector rate; RW = 4 is one round.  Every row's arithmetic is what RW = 1 does: results are bit-identical.
-template <int Q4, int RW>   // float4 words per k-quarter: H <= 16 Q4
+// FOLD (D <= 20, the low-dimensional observation in front of the first layer): the input half of the gates,
+// x_t . W_ih^T + b_ih, is formed inside the step -- 5 more weights per gate and lane in registers (the quad's four lanes
+// split the D inputs 5 / 5 / 5 / 5, zero padded), x_t staged in LDS one step ahead by 20 lanes per row from a four-step
+// register ring -- instead of being written by a GEMM launch over all B T rows and read back here: at 126 976 rows that
+// launch writes 203 MB for 1.7 GFLOP (210 us, profiles/r05_lstm_1024x128_kernel_stats_b.csv) and the recurrence reads
+// them again.  Same products, another summation order than igates + hgates (aten lstm_cell): within fp32 rounding.
+template <int Q4, int RW, bool FOLD>   // float4 words per k-quarter: H <= 16 Q4
 __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     if (a.stop && *a.stop) return;
     __shared__ float4 hs4[RW][2][4][Q4];       // h_{t-1} / h_t by k-quarter, zero padded
@@ -674,7 +685,25 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
             w[g][q] = v;
         }
     const int col = colv ? kq * H + n : 0;     // the gate column this lane activates: gate kq of unit n
-    const float bias = colv ? a.b_hh[col] : 0.f;
+    const float bias = colv ? (FOLD ? a.b_hh[col] + a.b_ih[col] : a.b_hh[col]) : 0.f;
+    // FOLD: W_ih[gate g of unit n][inputs 5 kq .. 5 kq + 4]
+    __shared__ float4 xs4[FOLD ? RW : 1][2][4][2];       // x_{t} / x_{t+1} by input quarter: 5 words + 3 zero pads
+    float wx[4][5];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            wx[g][j] = (FOLD && colv && 5 * kq + j < a.D) ? a.W_ih[(size_t)(g * H + n) * a.D + 5 * kq + j] : 0.f;
+    float* xsf = reinterpret_cast<float*>(xs4);
+    // staging role: lane tid < 20 RW carries input xj of row xr through the ring into LDS
+    const int xr = tid / 20, xj = tid - 20 * xr;
+    const bool xlane = FOLD && tid < 20 * RW && xj < a.D && b0 + xr < a.B;
+    const int xpos = (xj / 5) * 8 + (xj % 5);
+    const float* const xrow = FOLD ? a.x + (size_t)(b0 + (b0 + xr < a.B ? xr : 0)) * T * a.D + xj : nullptr;
+    float xg0 = 0.f, xg1 = 0.f, xg2 = 0.f, xg3 = 0.f;      // x_{t+1} .. x_{t+4} of this lane's (row, input)
+    if (FOLD) {
+        for (int i = tid; i < RW * 2 * 32; i += NT) xsf[i] = 0.f;
+    }
     const bool is_g = kq == 2;                 // the cell candidate: tanh; the other gates: sigmoid
     float* hs = reinterpret_cast<float*>(hs4);
     for (int i = tid; i < RW * 2 * 4 * 4 * Q4; i += NT) hs[i] = 0.f;
@@ -707,14 +736,24 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     float gx0[RW], gx1[RW], gx2[RW], gx3[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        gx0[r] = colv ? grow[r][ucol] : 0.f;
-        gx1[r] = (colv && 1 < T) ? (grow[r] + G)[ucol] : 0.f;
-        gx2[r] = (colv && 2 < T) ? (grow[r] + 2 * G)[ucol] : 0.f;
-        gx3[r] = (colv && 3 < T) ? (grow[r] + 3 * G)[ucol] : 0.f;
+        gx0[r] = (!FOLD && colv) ? grow[r][ucol] : 0.f;
+        gx1[r] = (!FOLD && colv && 1 < T) ? (grow[r] + G)[ucol] : 0.f;
+        gx2[r] = (!FOLD && colv && 2 < T) ? (grow[r] + 2 * G)[ucol] : 0.f;
+        gx3[r] = (!FOLD && colv && 3 < T) ? (grow[r] + 3 * G)[ucol] : 0.f;
+    }
+    if (FOLD) {
+        __syncthreads();                       // (the zero fill of xs4 above)
+        if (xlane) {
+            xsf[(xr * 2 + 0) * 32 + xpos] = xrow[0];
+            xg0 = (1 < T) ? xrow[(size_t)1 * a.D] : 0.f;
+            xg1 = (2 < T) ? xrow[(size_t)2 * a.D] : 0.f;
+            xg2 = (3 < T) ? xrow[(size_t)3 * a.D] : 0.f;
+            xg3 = (4 < T) ? xrow[(size_t)4 * a.D] : 0.f;
+        }
     }
     const bool odd = (kq & 1) != 0, hi = (kq & 2) != 0;
     __syncthreads();
-#define SMX_FWDK_STEP(GX, TT)                                                                                          \
+#define SMX_FWDK_STEP(GX, XG, TT)                                                                                        \
     if ((TT) < T) {                                                                                                    \
         const int t = (TT);                                                                                            \
         const int p = t & 1;                                                                                           \
@@ -736,6 +775,22 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
                 a3[r] = __builtin_elementwise_fma(up, (v2f){w[3][q].z, w[3][q].w}, a3[r]);                             \
             }                                                                                                          \
         }                                                                                                              \
+        if (FOLD) {                                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                                           \
+                const float4 xa = xs4[FOLD ? r : 0][p][kq][0], xb = xs4[FOLD ? r : 0][p][kq][1];                      \
+                const float xv[5] = {xa.x, xa.y, xa.z, xa.w, xb.x};                                                    \
+                _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                        \
+                    a0[r].x = __builtin_fmaf(xv[j], wx[0][j], a0[r].x);                                                \
+                    a1[r].x = __builtin_fmaf(xv[j], wx[1][j], a1[r].x);                                                \
+                    a2[r].x = __builtin_fmaf(xv[j], wx[2][j], a2[r].x);                                                \
+                    a3[r].x = __builtin_fmaf(xv[j], wx[3][j], a3[r].x);                                                \
+                }                                                                                                      \
+            }                                                                                                          \
+            if (xlane) {                        /* x_{t+1} into the other buffer; the ring moves on */                 \
+                xsf[(xr * 2 + 1 - p) * 32 + xpos] = XG;                                                                \
+                XG = (t + 5 < T) ? xrow[(size_t)(t + 5) * a.D] : 0.f;                                                  \
+            }                                                                                                          \
+        }                                                                                                              \
         _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                                               \
             const float p0 = a0[r].x + a0[r].y, p1 = a1[r].x + a1[r].y, p2 = a2[r].x + a2[r].y, p3 = a3[r].x + a3[r].y; \
             /* reduce-scatter over the quad.  Step 1 (partner lane ^ 1): even lanes collect gates 0 and 2, odd lanes 1, 3 */ \
@@ -748,7 +803,7 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
             const float act = is_g ? 2.f * sg - 1.f : sg;        /* tanh for the cell candidate, sigmoid otherwise */   \
             float* const gstep = grow[r] + (size_t)t * G;                /* uniform */                                  \
             if (colv && rv[r]) gstep[ucol] = act;                                                                      \
-            GX[r] = (colv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                                         \
+            GX[r] = (!FOLD && colv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                                \
             const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act); \
             const float c = gf * creg[r] + gi * gg;                                                                    \
             const float h = go * fast_tanh(c);                                                                         \
@@ -765,10 +820,10 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
         LSTM_LDS_BARRIER();                                                                                            \
     }
     for (int t0 = 0; t0 < T; t0 += 4) {
-        SMX_FWDK_STEP(gx0, t0)
-        SMX_FWDK_STEP(gx1, t0 + 1)
-        SMX_FWDK_STEP(gx2, t0 + 2)
-        SMX_FWDK_STEP(gx3, t0 + 3)
+        SMX_FWDK_STEP(gx0, xg0, t0)
+        SMX_FWDK_STEP(gx1, xg1, t0 + 1)
+        SMX_FWDK_STEP(gx2, xg2, t0 + 2)
+        SMX_FWDK_STEP(gx3, xg3, t0 + 3)
     }
 #undef SMX_FWDK_STEP
     if (colv && kq == 0) {
@@ -1020,27 +1075,37 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     const int H = net->H, D = net->D;
     SMX_REQUIRE(B > 0 && T > 0 && H > 0 && D > 0 && B * T * 4 * H < (1ll << 31), SMX_E_SHAPE);
     SMX_REQUIRE(H % 4 == 0 && H <= 16 * KG_MAX, SMX_E_UNSUPPORTED);
-    // input half of the gates for every (b, t) at once
-    int rc = smx_linear_f32(x, D, 1, net->W_ih, D, 1, net->b_ih, gates, 4 * H, (int32_t)(B * T),
-                            4 * H, D, SMX_ACT_NONE, nullptr, stop_flag, stream);
-    if (rc) return rc;
+    static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
+    static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;       // the LDS-exchange one-row kernels, for A/B runs
+    static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;   // every lane reads all of h (the round-3 first form)
+    static const bool nofold = getenv("SMX_LSTM_NOFOLD") != nullptr;
+    // D <= 20 on the default H <= 112 kernel: the input half of the gates is formed inside the recurrence (FOLD);
+    // else for every (b, t) at once by a GEMM launch in front of it
+    const bool fold = !nofold && !mfma4 && !v1 && !quad && H <= 112 && D <= 20;
+    if (!fold) {
+        int rc = smx_linear_f32(x, D, 1, net->W_ih, D, 1, net->b_ih, gates, 4 * H, (int32_t)(B * T),
+                                4 * H, D, SMX_ACT_NONE, nullptr, stop_flag, stream);
+        if (rc) return rc;
+    }
     FwdArgs a;
     a.W_hh = net->W_hh; a.b_hh = net->b_hh; a.h0 = h0; a.c0 = c0; a.gates = gates; a.out = out;
     a.cs = cs; a.hprev = hprev; a.hN = hN; a.cN = cN; a.stop = stop_flag;
     a.B = (int)B; a.T = T; a.H = H;
+    a.x = x; a.W_ih = net->W_ih; a.b_ih = net->b_ih; a.D = D;
     const int blocks = (int)((B + RB - 1) / RB);
     // H <= 128: one row per workgroup on the vector ALU (SMX_LSTM_MFMA4=1 keeps the 4-row MFMA kernels for A/B runs)
-    static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
-    static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;       // the LDS-exchange one-row kernels, for A/B runs
-    static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;   // every lane reads all of h (the round-3 first form)
-    if (!mfma4 && !v1 && !quad && H <= 112) {
+    if (fold) {
+        // (four rows per workgroup with the 20 extra weights: 256 registers and spills -- two it is)
+        if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2, true>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1, true>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && !quad && H <= 112) {
         // rows per workgroup: as many as keep >= 256 workgroups (one per CU), at most 4
-        if (B >= 1024) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 4>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
-        else if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
-        else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+        if (B >= 1024) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 4, false>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
+        else if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2, false>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1, false>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 128) {
-        if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<8, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
-        else hipLaunchKernelGGL((lstm_fwdk_kernel<8, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
+        if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<8, 2, false>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_fwdk_kernel<8, 1, false>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 100) {
         hipLaunchKernelGGL((lstm_fwdq_kernel<25>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && H <= 128) {
