@@ -266,15 +266,21 @@ def cpu_baseline(mode, params, zstate, batch, budget_s=30.0):
 
 
 # ---- the other BASELINE configurations (N = 1 only; a few steps each) -----------------------------
-def _time_learn(L, db, steps, warm=2):
+def _time_learn(L, db, steps, warm=2, repeats=3):
+    """seconds per learn() of a secondary configuration: `repeats` timed runs of `steps` learns each, the MEDIAN run (a
+    millisecond-scale learn timed once over five steps moved by 5 x between two bench runs of the same tree: one host
+    hiccup of 10 ms inside the window; the headline keeps the contract's single window of exactly K steps)"""
     for _ in range(warm):
         L.learn(db)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        L.learn(db)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    runs = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            L.learn(db)
+        torch.cuda.synchronize()
+        runs.append((time.perf_counter() - t0) / steps)
+    return sorted(runs)[len(runs) // 2]
 
 
 # ---- pricing of a configuration: SURVEY.md 8(d)'s accounting, generalised over the policy ----------------
