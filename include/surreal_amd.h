@@ -84,6 +84,13 @@ int smx_zfilter_forward_sums_f32(const float* x, int64_t ldx, int64_t rows, int3
 int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows, int32_t D,
                            float* running_sum, float* running_sumsq, float* count,
                            float count_rows, smx_stream_t stream);
+/* The same for MANY rows (the z-update of a policy on a stem runs over B * E ~ 10^5 observation rows): the rows are cut
+ * into chunks whose column sums go through ws (smx_zfilter_update_ws_floats(rows, D) floats; 0 = few rows) and are
+ * added in chunk order by a second launch.  With ws == NULL or too small this IS smx_zfilter_update_f32. */
+int64_t smx_zfilter_update_ws_floats(int64_t rows, int32_t D);
+int smx_zfilter_update_ws_f32(const float* x, int64_t ldx, int64_t rows, int32_t D, float* running_sum,
+                              float* running_sumsq, float* count, float count_rows, float* ws, int64_t ws_floats,
+                              smx_stream_t stream);
 
 /* Process-wide switch of smx_mlp3_forward_fused_f32's z-filter arithmetic.  0 (default): (x - m) * (1 / s), one rounding
  * more than surreal/model/z_filter.py:77 (<= 1 ulp of the filtered input); 1: the reference's division, on the
@@ -363,6 +370,12 @@ int smx_ppo_policy_loss_f32(int32_t mode, const float* mean, const float* log_va
  * dlogvar_sumsq (optional) receives sum(dlogvar^2), one more clip_grad_norm_ partial.
  * dz3_t (optional) receives the transposed copy dz3_t[a * ld_t + r] (see smx_mlp3_job_t).
  * No-op when ctrl->stop_flag is already set on entry. */
+/* Folds nblk partial rows (row stride = stride floats) to nout rows in front of smx_ppo_loss_finalize_f32: out[j] = the
+ * sum of rows [j R, (j + 1) R), R = ceil(nblk / nout), in a fixed order.  For the policies on a stem, whose B * E ~ 10^5
+ * rows leave thousands of partial rows that every workgroup of the finalize would walk.  No-op when ctrl (may be NULL)
+ * has its stop flag set. */
+int smx_ppo_partials_fold_f32(const float* row_partials, int32_t nblk, int32_t stride, float* out, int32_t nout,
+                              const smx_ppo_ctrl_t* ctrl, smx_stream_t stream);
 int smx_ppo_loss_finalize_f32(int32_t mode, const float* row_partials, int32_t nblk,
                               const float* g_surr, const float* g_kl, const float* log_var,
                               int64_t rows, int64_t n_total, int32_t A, smx_ppo_ctrl_t* ctrl,

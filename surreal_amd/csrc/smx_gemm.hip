@@ -1138,6 +1138,19 @@ extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const f
         if (rc) return rc;
     }
     const long total = (long)M * N + M;
+    if (ldw == N && G.p[0].splits > 32) {
+        // many chunks: 16 slices of the split index per element in parallel, combined in slice order (one thread per
+        // element walking 248 partials measured 67 us for a 400 x 100 gradient)
+        RedSegs L;
+        L.n = db ? 2 : 1;
+        L.g[0] = RedSeg{part, dW, 0, M * N};
+        L.g[1] = RedSeg{dbpart, db, M * N, M};
+        L.total = db ? (int)total : M * N;
+        hipLaunchKernelGGL(segmented_reduce_kernel, dim3((unsigned)((L.total + 15) / 16)), dim3(256), 0, smx_s(stream), L,
+                           G.p[0].splits, (const int*)nullptr);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SMX_OK : (int)e;
+    }
     long blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), part,

@@ -515,6 +515,80 @@ extern "C" int smx_zfilter_update_f32(const float* x, int64_t ldx, int64_t rows,
 }
 
 
+// The same over MANY rows (the stems' z-update over B * E ~ 10^5 observation rows): zupdate_kernel is ONE workgroup per 64
+// columns walking every row -- 0.99 ms at 126 976 x 17 (profiles/r05_lstm_1024x128_kernel_stats.csv).  Here the rows are cut
+// into `chunks` pieces, workgroup (chunk, column block) leaves its column sums in the caller's scratch and a second small
+// launch adds the chunks in order (deterministic) into the running sums.
+__global__ __launch_bounds__(1024) void zupdate_part_kernel(const float* __restrict__ x, long ldx, long rows, int D, int chunks,
+                                                            float* __restrict__ part) {
+    __shared__ float s1[16][64], s2[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + c;
+    const long per = (rows + chunks - 1) / chunks;
+    const long r0 = (long)blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (col < D) {
+        long r = r0 + g;
+        for (; r + 16 < r1; r += 32) {
+            const float v0 = x[r * ldx + col], v1 = x[(r + 16) * ldx + col];
+            a0 += v0; q0 += v0 * v0;
+            a1 += v1; q1 += v1 * v1;
+        }
+        if (r < r1) {
+            const float v = x[r * ldx + col];
+            a0 += v; q0 += v * v;
+        }
+    }
+    s1[g][c] = a0 + a1;
+    s2[g][c] = q0 + q1;
+    __syncthreads();
+    if (g == 0 && col < D) {
+        float ta = 0.f, tq = 0.f;
+        for (int k = 0; k < 16; ++k) { ta += s1[k][c]; tq += s2[k][c]; }
+        part[((size_t)blockIdx.x * 2 + 0) * D + col] = ta;
+        part[((size_t)blockIdx.x * 2 + 1) * D + col] = tq;
+    }
+}
+
+__global__ __launch_bounds__(256) void zupdate_merge_kernel(const float* __restrict__ part, int chunks, int D,
+                                                            float* __restrict__ rs, float* __restrict__ rsq,
+                                                            float* __restrict__ cnt, float count_rows) {
+    for (int col = blockIdx.x * 256 + threadIdx.x; col < D; col += gridDim.x * 256) {
+        float ta = 0.f, tq = 0.f;
+        for (int k = 0; k < chunks; ++k) {
+            ta += part[((size_t)k * 2 + 0) * D + col];
+            tq += part[((size_t)k * 2 + 1) * D + col];
+        }
+        rs[col] += ta;    // z_filter.py:55
+        rsq[col] += tq;   // z_filter.py:56
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0] += count_rows;  // z_filter.py:57
+}
+
+extern "C" int64_t smx_zfilter_update_ws_floats(int64_t rows, int32_t D) {
+    if (rows < 16384 || D <= 0) return 0;           // few rows: the one-launch form
+    const long chunks = rows / 512 < 256 ? rows / 512 : 256;
+    return 2 * chunks * (int64_t)D;
+}
+
+extern "C" int smx_zfilter_update_ws_f32(const float* x, int64_t ldx, int64_t rows, int32_t D, float* running_sum,
+                                         float* running_sumsq, float* count, float count_rows, float* ws, int64_t ws_floats,
+                                         smx_stream_t stream) {
+    const int64_t need = smx_zfilter_update_ws_floats(rows, D);
+    if (need == 0 || !ws || ws_floats < need)
+        return smx_zfilter_update_f32(x, ldx, rows, D, running_sum, running_sumsq, count, count_rows, stream);
+    SMX_REQUIRE(x && running_sum && running_sumsq && count, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && D > 0 && ldx >= D, SMX_E_SHAPE);
+    const int chunks = (int)(need / (2 * D));
+    hipLaunchKernelGGL(zupdate_part_kernel, dim3((unsigned)chunks, (unsigned)((D + 63) / 64)), dim3(1024), 0, smx_s(stream), x,
+                       (long)ldx, (long)rows, D, chunks, ws);
+    hipLaunchKernelGGL(zupdate_merge_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, smx_s(stream), ws, chunks, D,
+                       running_sum, running_sumsq, count, count_rows);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+
 // ---------------------------------------------------------------------------
 // What PPOLearner._optimize does after its epoch loops (ppo.py:565-584), in ONE launch instead of
 // four: the explained variance / value loss of every value epoch from their block moments, the

@@ -58,10 +58,19 @@ class HipKernels(object):
                L.ptr(actions), _row_stride(actions, A), L.ptr(pd),
                0 if pd is None else _row_stride(pd, 2 * A), self._st())
 
-    def zfilter_update(self, x_view, rs, rsq, cnt, count_rows):
+    def zfilter_update(self, x_view, rs, rsq, cnt, count_rows, ws=None):
+        """ws: optional scratch of zfilter_update_ws_floats(rows, D) floats -- many rows are then summed by many
+        workgroups (smx_zfilter_update_ws_f32)"""
         rows, D = x_view.shape
+        if ws is not None:
+            L.call('smx_zfilter_update_ws_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D, L.ptr(rs),
+                   L.ptr(rsq), L.ptr(cnt), float(count_rows), L.ptr(ws), ws.numel(), self._st())
+            return
         L.call('smx_zfilter_update_f32', L.ptr(x_view), _row_stride(x_view, D), rows, D, L.ptr(rs),
                L.ptr(rsq), L.ptr(cnt), float(count_rows), self._st())
+
+    def zfilter_update_ws_floats(self, rows, D):
+        return int(self.lib.smx_zfilter_update_ws_floats(int(rows), int(D)))
 
     # ---- MLP ----------------------------------------------------------------------------
     def mlp3_packed_numel(self, net):
@@ -365,6 +374,11 @@ class HipKernels(object):
                _row_stride(actions, A), L.ptr(behave), _row_stride(behave, 2 * A), L.ptr(ref),
                _row_stride(ref, 2 * A), L.ptr(adv), rows, A, L.ptr(ctrl), L.ptr(g_surr),
                L.ptr(g_kl), L.ptr(partials), self._st())
+
+    def partials_fold(self, partials, nblk, out, ctrl=None):
+        """out[j] = sum of the partial rows [j R, (j + 1) R), R = ceil(nblk / len(out)) (smx_ppo_partials_fold_f32)"""
+        L.call('smx_ppo_partials_fold_f32', L.ptr(partials), int(nblk), partials.stride(0), L.ptr(out), out.shape[0],
+               L.ptr(ctrl), self._st())
 
     def policy_finalize(self, mode, partials, nblk, g_surr, g_kl, log_var, n_total, ctrl,
                         check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None):

@@ -418,6 +418,8 @@ class PPOLearner(Learner):
                 ws.pack_stem = f(max(K.mlp3_packed_numel(n) for n in (act, cri)))
             except Exception:
                 ws.pack_stem = None
+            n_z = K.zfilter_update_ws_floats(rows, D)
+            ws.zscratch = f(n_z) if n_z else None          # the z-update's chunk sums over B * E rows (K.zfilter_update)
             n_pt = max(K.mlp3_dgrad_rows_ws_floats(n) for n in (act, cri))
             ws.packT_stem = f(n_pt) if n_pt else None    # ... and of the fused many-row data gradients (K.mlp3_backward)
             if rnn:
@@ -538,6 +540,7 @@ class PPOLearner(Learner):
         ws.grads_a, ws.grads_c = ws.grads_all[:n_a], ws.grads_all[n_a:]
         ws.ppart = f(ws.nblk_p, ws.pstride)
         ws.ppart_sum = f(1, ws.pstride)
+        ws.ppart_fold = f(64, ws.pstride)
         # partial rows a rank does not fill stay zero (count 0: skipped by the merge)
         ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
         ws.vpart_local = torch.zeros(ws.nblk_v, 8, device=dev)
@@ -1281,6 +1284,10 @@ class PPOLearner(Learner):
             torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
             self._dist.all_reduce(ws.ppart_sum)
             part, nblk = ws.ppart_sum, 1
+        elif nblk > 4 * ws.ppart_fold.shape[0]:
+            # thousands of partial rows (B * E ~ 10^5): folded to 64 first -- every workgroup of the finalize walks them all
+            K.partials_fold(ws.ppart, nblk, ws.ppart_fold, ws.ctrl_f)
+            part, nblk = ws.ppart_fold, ws.ppart_fold.shape[0]
         K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1), ws.n_total,
                           ws.ctrl_f, e > 0, e < self.epoch_policy, ws.dz3a,
                           ws.grads_a[m.actor.numel:m.actor.numel + A],
@@ -1406,14 +1413,14 @@ class PPOLearner(Learner):
         if self.use_z_filter:                   # model.z_update(obs_iter)  (ppo.py:578-579)
             if self.world_size > 1:
                 ws.zdelta.zero_()
-                K.zfilter_update(ws.low_it, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], B * E)
+                K.zfilter_update(ws.low_it, ws.zdelta[:D], ws.zdelta[D:2 * D], ws.zdelta[2 * D:], B * E, ws=ws.zscratch)
                 self._dist.all_reduce(ws.zdelta)
                 m.z_filter.running_sum += ws.zdelta[:D]
                 m.z_filter.running_sumsq += ws.zdelta[D:2 * D]
                 m.z_filter.count += ws.zdelta[2 * D:]
             else:
                 K.zfilter_update(ws.low_it, m.z_filter.running_sum, m.z_filter.running_sumsq,
-                                 m.z_filter.count, B * E)
+                                 m.z_filter.count, B * E, ws=ws.zscratch)
         self._enqueue_final_stats(ws)
 
     def _enqueue_final_stats(self, ws):

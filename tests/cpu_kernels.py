@@ -49,7 +49,10 @@ class TorchCpuKernels(object):
             pd[:, :A].copy_(mean)
             pd[:, A:].copy_(std)
 
-    def zfilter_update(self, x_view, rs, rsq, cnt, count_rows):
+    def zfilter_update_ws_floats(self, rows, D):
+        return 0
+
+    def zfilter_update(self, x_view, rs, rsq, cnt, count_rows, ws=None):
         rs += torch.sum(x_view, dim=0)
         rsq += torch.sum(x_view * x_view, dim=0)
         cnt += float(count_rows)
@@ -456,6 +459,14 @@ class TorchCpuKernels(object):
             partials[b, 5] = klb[sl].sum()
             partials[b, 8:8 + A] = gs[sl].sum(0)
             partials[b, 8 + A:8 + 2 * A] = gk[sl].sum(0)
+
+    def partials_fold(self, partials, nblk, out, ctrl=None):
+        if ctrl is not None and int(ctrl.view(torch.int32)[L.C_STOP]) != 0:
+            return
+        nout = out.shape[0]
+        R = (nblk + nout - 1) // nout
+        for j in range(nout):
+            out[j] = partials[j * R:min(nblk, (j + 1) * R)].sum(0)
 
     def policy_finalize(self, mode, partials, nblk, g_surr, g_kl, log_var, n_total, ctrl,
                         check_stop, will_update, dz3, dlogvar, dlogvar_sumsq, stats, dz3_t=None):

@@ -1618,3 +1618,41 @@ def test_rollout_recorded_straight_into_the_replay_slots(K, n, D, A, hidden, T):
     for k in a:
         assert torch.equal(a[k].reshape(b[k].shape), b[k]), k
     assert float(b['obs_next'].abs().sum()) > 0 and float(b['pds'].abs().sum()) > 0
+
+
+def test_partials_fold_and_many_row_zupdate(K):
+    """the two helpers of the many-row stem path: smx_ppo_partials_fold_f32 (thousands of loss partial rows -> 64) and
+    smx_zfilter_update_ws_f32 (column sums over 126 976 rows by many workgroups) against float64 sums / the one-launch form"""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for nblk, stride, nout in ((7936, 20, 64), (7936, 42, 64), (300, 20, 64), (65, 9, 64)):
+        part = torch.randn(nblk, stride, device='cuda', generator=g)
+        out = torch.full((nout, stride), float('nan'), device='cuda')
+        K.partials_fold(part, nblk, out)
+        R = (nblk + nout - 1) // nout
+        for j in (0, 1, nout // 2, nout - 1):
+            want = part[j * R:min(nblk, (j + 1) * R)].double().sum(0)
+            close(out[j], want.float(), atol=2e-5, rtol=1e-5, msg='fold row %d of %d x %d' % (j, nblk, stride))
+        close(out.double().sum(0).float(), part.double().sum(0).float(), atol=1e-4, rtol=1e-5)
+    ctrl = torch.zeros(64, dtype=torch.int32, device='cuda')
+    ctrl[L.C_STOP] = 1
+    out.fill_(3.0)
+    K.partials_fold(part, nblk, out, ctrl.view(torch.float32))
+    assert float(out.min()) == 3.0
+    for rows, D in ((126976, 17), (40000, 376), (16384, 5), (9000, 17)):
+        x = torch.randn(rows, D, device='cuda', generator=g) * 2 + 0.5
+        nws = K.zfilter_update_ws_floats(rows, D)
+        assert (nws > 0) == (rows >= 16384)
+        ws = torch.empty(max(nws, 1), device='cuda')
+        rs0, rq0, c0 = torch.randn(D, device='cuda', generator=g), torch.rand(D, device='cuda', generator=g) * 50, \
+            torch.tensor([1000.0], device='cuda')
+        rs1, rq1, c1 = rs0.clone(), rq0.clone(), c0.clone()
+        rs2, rq2, c2 = rs0.clone(), rq0.clone(), c0.clone()
+        K.zfilter_update(x, rs1, rq1, c1, rows, ws=ws)
+        K.zfilter_update(x, rs2, rq2, c2, rows)
+        want_s, want_q = rs0.double() + x.double().sum(0), rq0.double() + (x.double() ** 2).sum(0)
+        close(rs1, want_s.float(), atol=1e-2, rtol=2e-6, msg='sum %d x %d' % (rows, D))
+        close(rq1, want_q.float(), atol=1e-1, rtol=2e-6, msg='sumsq')
+        close(rs1, rs2, atol=1e-2, rtol=2e-6), close(rq1, rq2, atol=1e-1, rtol=2e-6)
+        assert float(c1) == float(c2) == 1000.0 + rows
+        if nws == 0:
+            assert torch.equal(rs1, rs2) and torch.equal(rq1, rq2)
