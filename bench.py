@@ -65,7 +65,7 @@ def algorithmic_costs(split_tail):
     return rows, flops, bytes_
 
 
-def build_learner(mode, device_index, B=B, split_chains=False, use_graph=True):
+def build_learner(mode, device_index, B=B, use_graph=True):
     from surreal_amd.learner.ppo import PPOLearner
     lc = ppo_learner_config()
     lc.model.actor_fc_hidden_sizes = list(HIDDEN)
@@ -77,7 +77,6 @@ def build_learner(mode, device_index, B=B, split_chains=False, use_graph=True):
     lc.algo.consts.kl_target = 1e9          # no data-dependent early exit: full 10 + 10 epochs
     lc.replay.batch_size = B
     sc = ppo_session_config('/tmp/surreal_amd_bench')
-    sc.learner.split_chains = bool(split_chains)
     sc.learner.use_hip_graph = bool(use_graph)
     for kv in filter(None, os.environ.get('SMX_BENCH_LEARNER_OPTS', '').split(',')):     # A/B runs: key=0|1[,key=...]
         k, v = kv.split('=')
@@ -918,7 +917,6 @@ def main():
     ap.add_argument('--mode', default='adapt', choices=['adapt', 'clip'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--split-chains', action='store_true', help='policy and value epochs on two streams')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: 1024 sub-trajectories per GPU (the headline); strong: 1024 in total')
     ap.add_argument('--no-secondary', action='store_true', help='skip the other BASELINE configurations')
@@ -930,8 +928,6 @@ def main():
                          'would start after it are skipped (and say so)')
     ap.add_argument('--full-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_full.json'),
                     help='the complete record (the stdout line is its <= 4 KB summary); "" to skip')
-    ap.add_argument('--schedule', default='lockstep', choices=['lockstep', 'two_stream'],
-                    help='epoch launch schedule (session_config.learner.epoch_schedule)')
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it (the shape of the driver's N = 1 command):
@@ -1041,9 +1037,7 @@ def run(args, world, rank, local_rank, backend):
 
     def timed_run(Bl, lo):
         """W warm-up steps, then exactly K steps between barriers + device syncs; max over ranks"""
-        learner, params, zstate = build_learner(args.mode, local_rank, B=Bl, split_chains=args.split_chains,
-                                                use_graph=not args.no_graph)
-        learner.epoch_schedule = args.schedule
+        learner, params, zstate = build_learner(args.mode, local_rank, B=Bl, use_graph=not args.no_graph)
         dbatch, batch = device_batch(learner, rank, B=Bl, lo=lo)
         for _ in range(args.warmup):
             learner.learn(dbatch)

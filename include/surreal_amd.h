@@ -644,20 +644,6 @@ int smx_clip_adam_step_group_f32(const smx_adam_group_t* group, int32_t which, c
                                  smx_stream_t stream);
 int smx_clip_adam_step_pair_f32(const smx_adam_group_t* actor, const smx_adam_group_t* critic,
                                 const smx_ppo_ctrl_t* ctrl, smx_stream_t stream);
-/* smx_mlp3_wgrad_multi_f32(jobs) followed by smx_clip_adam_step_group_f32(groups[j], which[j]) for every job, in ONE
- * launch: the workgroup that has formed a 32 x 32 tile of a weight gradient (and, in the first tile column, the bias
- * gradient) steps exactly those parameters, straight from its registers.  clip_grad_norm_ needs the whole group's norm:
- * every workgroup stores its tile's sum of squares with a "there" bit as ONE 8-byte device-scope word (slots[tile]) and
- * reads the slots of all tiles of its group (bounded wait: 0.25 s, then ctrl->reserved[1] is raised and nothing is
- * stepped), added in the optimiser launch's order -- parameters, moments, packed copies, gradients, partial sums and
- * the reported norm are bit-identical to the launches it replaces (tests/test_gpu_epoch.py).
- * groups[j]: the group of jobs[j] -- grads == jobs[j].grads (layout [W1 b1 W2 b2 W3 b3 | others], `others` (log_var)
- * already in the buffer), sumsq_partials == jobs[j].sumsq_partials with entries >= smx_mlp3_backward_partials(net)
- * written by an earlier launch.  slots: one 8-byte word per tile of the launch, zero on entry.
- * Needs every workgroup resident at once (tiles <= 2 per CU), K-contiguous 16-byte-aligned transposed operands and
- * rows < 2048; anything else runs as the launches it replaces. */
-int smx_mlp3_wgrad_adam_f32(const smx_mlp3_job_t* jobs, int32_t njobs, const smx_adam_group_t* groups,
-                            const int32_t* which, smx_ppo_ctrl_t* ctrl, uint64_t* slots, smx_stream_t stream);
 /* partials[b] = sum of squares of block b's slice of x; returns via *nblk_out the count
  * used (<= max_blocks). */
 int32_t smx_sumsq_blocks(int64_t n);

@@ -233,7 +233,6 @@ _SIGS = {
                                          c_int32, _P, _P]),
     'smx_clip_adam_step_group_f32': (c_int32, [POINTER(AdamGroup), c_int32, _P, _P]),
     'smx_clip_adam_step_pair_f32': (c_int32, [POINTER(AdamGroup), POINTER(AdamGroup), _P, _P]),
-    'smx_mlp3_wgrad_adam_f32': (c_int32, [POINTER(Mlp3Job), c_int32, POINTER(AdamGroup), POINTER(c_int32), _P, _P, _P]),
     'smx_sumsq_blocks': (c_int32, [c_int64]),
     'smx_sumsq_partials_f32': (c_int32, [_P, c_int64, _P, _P]),
     'smx_synth_act_env_step_head_f32': (c_int32, [POINTER(SynthActStep), _P, _P, _P, c_int64, c_int32, c_int32, _P]),

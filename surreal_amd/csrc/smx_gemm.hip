@@ -318,25 +318,8 @@ __device__ __forceinline__ void mainloop_co(const GemmProb& P, const KRange& R, 
 
 // ALL_VEC: every problem of the batch is mode (0, 0) -- the host picks this instantiation, which
 // fits 3 workgroups per CU (<= 168 VGPRs); the general one carries the scalar-load variants.
-// The optimiser step of a weight-gradient launch (gemm32_adam_kernel): job j of the launch is optimiser group j.
-struct AdamSide {
-    float* theta;                 // the group's parameters, exp_avg, exp_avg_sq: the layout of `grads`
-    float* m;
-    float* v;
-    const float* grads;           // base of the gradient buffer the job's C / dbias pointers lie in
-    long n, n_mlp;                // elements of the group; of them owned by the tiles (the rest: tile 0's workgroup)
-    unsigned long long* slots;    // [ntiles] {there, sum of squares}: zero on entry
-    const float* partials;        // [npart] plain partial sums: entries >= ntiles come from an earlier launch
-    int ntiles, npart, tile_base, which, honour_stop;
-    float* grad_norm_out;
-    AdamPack pack;
-};
-struct AdamTail {
-    AdamSide g[2];
-};
-
-template <bool ALL_VEC, bool ADAM>
-__device__ __forceinline__ void gemm32_body(const GemmBatch& G, const AdamTail* T, smx_ppo_ctrl_t* ctrl) {
+template <bool ALL_VEC>
+__device__ __forceinline__ void gemm32_body(const GemmBatch& G) {
     __shared__ float red[4][32 * 33];
     __shared__ float stage[ALL_VEC ? 4 * 2 * 32 * 36 : 4];      // wave-private operand tiles (coalesced path)
     __shared__ float dbr[8][32];
@@ -429,7 +412,6 @@ __device__ __forceinline__ void gemm32_body(const GemmBatch& G, const AdamTail* 
     __syncthreads();
 
     float ss = 0.f;
-    float gv0 = 0.f, gv1 = 0.f, gv2 = 0.f, gv3 = 0.f, gvb = 0.f;     // ADAM: this thread's gradient elements
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int n = n0 + oc0 + e;
@@ -444,10 +426,8 @@ __device__ __forceinline__ void gemm32_body(const GemmBatch& G, const AdamTail* 
             P.C[(size_t)sp * P.c_split + (size_t)m * P.ldc + n] = v;
             if (P.CT) P.CT[(size_t)n * P.ldct + m] = v;
             ss += v * v;
-            if (ADAM) { if (e == 0) gv0 = v; else if (e == 1) gv1 = v; else if (e == 2) gv2 = v; else gv3 = v; }
         }
     }
-    const bool has_b = P.dbias && tn == 0 && tid < 32 && m0 + tid < P.M;
     if (P.dbias && tn == 0 && tid < 32) {
         float d = 0.f;
 #pragma unroll
@@ -455,111 +435,17 @@ __device__ __forceinline__ void gemm32_body(const GemmBatch& G, const AdamTail* 
         if (m0 + tid < P.M) {
             P.dbias[(size_t)sp * P.M + m0 + tid] = d;
             ss += d * d;
-            gvb = d;
         }
     }
-    if (P.sumsq || ADAM) {
+    if (P.sumsq) {
         const float t = smx_block_sum(ss, sred);
-        if (tid == 0 && P.sumsq) P.sumsq[tile] = t;
-        if (ADAM) {
-            // ---- clip_grad_norm_ + Adam on this workgroup's own tile, straight from the registers ----------------
-            // The norm needs every tile of the group: each workgroup stores its sum of squares with a "there" bit as ONE
-            // 8-byte device-scope word, then reads the slots of all tiles (all workgroups of the launch are resident:
-            // the host checked tiles <= 2 per CU) and adds them in clip_adam_kernel's order -- the same bits everywhere.
-            const AdamSide S = T->g[pi / 3];
-            const smx_ppo_ctrl_t C = *ctrl;
-            if ((C.reserved[0] | C.reserved[1]) != 0) return;         // as clip_adam_kernel: no step after a failed wait
-            if (S.honour_stop && C.stop_flag) return;
-            const int jt = bid - S.tile_base;                          // tile of the job = index of its partial sum
-            if (tid == 0) {
-                __hip_atomic_store(S.slots + jt, (1ull << 32) | (unsigned long long)__float_as_uint(t), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            // this thread's parameters and moments are requested in front of the wait
-            const long ci = (long)(P.C - S.grads) + (long)m * P.ldc + n0 + oc0;
-            const bool in_m = m < P.M;
-            const bool ok0 = in_m && n0 + oc0 + 0 < P.N, ok1 = in_m && n0 + oc0 + 1 < P.N;
-            const bool ok2 = in_m && n0 + oc0 + 2 < P.N, ok3 = in_m && n0 + oc0 + 3 < P.N;
-            const long bi = has_b ? (long)(P.dbias - S.grads) + m0 + tid : 0;
-            const long c0 = ok0 ? ci : 0, c1 = ok1 ? ci + 1 : 0, c2 = ok2 ? ci + 2 : 0, c3 = ok3 ? ci + 3 : 0;
-            const float p0 = S.theta[c0], p1 = S.theta[c1], p2 = S.theta[c2], p3 = S.theta[c3], pbv = S.theta[bi];
-            const float q0 = S.m[c0], q1 = S.m[c1], q2 = S.m[c2], q3 = S.m[c3], qb = S.m[bi];
-            const float r0 = S.v[c0], r1 = S.v[c1], r2 = S.v[c2], r3 = S.v[c3], rb = S.v[bi];
-            AdamCoef K = adam_coef_pre(C, S.which);                    // (two pow(): under the wait)
-            float tsum = 0.f;
-            int okw = 1;
-            const long long t0 = (long long)wall_clock64();
-            for (int k = tid; k < S.npart; k += 256) {
-                float val;
-                if (k < S.ntiles) {
-                    unsigned long long w;
-                    while (((w = __hip_atomic_load(S.slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0ull) {
-                        if ((long long)wall_clock64() - t0 > 25000000LL) { okw = 0; break; }   // 0.25 s (100 MHz): a lost workgroup
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    val = __uint_as_float((unsigned)w);
-                } else {
-                    val = S.partials[k];
-                }
-                tsum += val;
-            }
-            if (!__syncthreads_and(okw)) {
-                if (tid == 0) __hip_atomic_store(&ctrl->reserved[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            const float total = smx_block_sum(tsum, sred);
-            const float norm = sqrtf(total);
-            if (jt == 0 && tid == 0 && S.grad_norm_out) *S.grad_norm_out = norm;
-            K.coef = clip_coef(C, S.which, norm);
-            // the tile knows its layer and (m, n): the packed copies' positions without clip_adam_kernel's index -> (row,
-            // column) divisions
-            const int layer = pi % 3;
-            float* Pk = S.pack.packed;
-            const int QD = S.pack.D, QH1 = S.pack.H1, QH2 = S.pack.H2, QO = S.pack.OUT;
-            float* Pa = nullptr;       // [M, K] block of this layer
-            float* Pt = nullptr;       // its transpose (layers 2, 3)
-            int Ka = 0, Kt = 0;
-            if (Pk) {
-                if (layer == 0) { Pa = Pk; Ka = QD; }
-                else if (layer == 1) { Pa = Pk + 4 * pack_off(QD, QH1, QH2, QO, 1); Ka = QH1; Pt = Pk + 4 * pack_off(QD, QH1, QH2, QO, 3); Kt = QH2; }
-                else { Pa = Pk + 4 * pack_off(QD, QH1, QH2, QO, 2); Ka = QH2; Pt = Pk + 4 * pack_off(QD, QH1, QH2, QO, 4); Kt = QO; }
-            }
-            auto step_w = [&](bool ok, long c, int e, float g, float p, float mi, float vi) {
-                if (!ok) return;
-                float pn;
-                adam_step_core(K, g, p, mi, vi, pn);
-                S.theta[c] = pn; S.m[c] = mi; S.v[c] = vi;
-                if (Pa) {
-                    const int n = n0 + oc0 + e;
-                    Pa[pack_pos(Ka, m, n)] = pn;
-                    if (Pt) Pt[pack_pos(Kt, n, m)] = pn;
-                }
-            };
-            step_w(ok0, c0, 0, gv0, p0, q0, r0);
-            step_w(ok1, c1, 1, gv1, p1, q1, r1);
-            step_w(ok2, c2, 2, gv2, p2, q2, r2);
-            step_w(ok3, c3, 3, gv3, p3, q3, r3);
-            if (has_b) {                                               // (biases have no packed copy)
-                float pn, mi = qb, vi = rb;
-                adam_step_core(K, gvb, pbv, mi, vi, pn);
-                S.theta[bi] = pn; S.m[bi] = mi; S.v[bi] = vi;
-            }
-            if (jt == 0)                                               // the group's elements outside the MLP (log_var)
-                for (long i = S.n_mlp + tid; i < S.n; i += 256)
-                    adam_step_one(K, S.pack, S.theta, S.m, S.v, i, S.grads[i], S.theta[i], S.m[i], S.v[i]);
-        }
+        if (tid == 0) P.sumsq[tile] = t;
     }
 }
 
 template <bool ALL_VEC>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(GemmBatch G) {
-    gemm32_body<ALL_VEC, false>(G, nullptr, nullptr);
-}
-
-// smx_mlp3_wgrad_adam_f32: the weight gradients of up to two MLPs, and the clip-norm + Adam step of their groups
-__global__ __launch_bounds__(256, 2) void gemm32_adam_kernel(GemmBatch G, AdamTail T, smx_ppo_ctrl_t* ctrl) {
-    gemm32_body<true, true>(G, &T, ctrl);
+    gemm32_body<ALL_VEC>(G);
 }
 
 // Many-row variant (M >= 2048: the stem passes over B*T or frames*pixels rows).  A workgroup owns a
@@ -1306,72 +1192,6 @@ extern "C" int smx_mlp3_wgrad_multi_f32(const smx_mlp3_job_t* jobs, int32_t njob
 }
 
 static int64_t mlp3_numel(const smx_mlp3_t* n);
-
-// smx_mlp3_wgrad_multi_f32 and the clip-norm + Adam step of the jobs' optimiser groups in ONE launch
-// (gemm32_adam_kernel): every workgroup steps the 32 x 32 tile of parameters whose gradient it has just formed.
-extern "C" int smx_mlp3_wgrad_adam_f32(const smx_mlp3_job_t* jobs, int32_t njobs, const smx_adam_group_t* groups,
-                                       const int32_t* which, smx_ppo_ctrl_t* ctrl, uint64_t* slots,
-                                       smx_stream_t stream) {
-    SMX_REQUIRE(jobs && groups && which && ctrl && slots, SMX_E_NULL);
-    SMX_REQUIRE(njobs >= 1 && njobs <= 2, SMX_E_SHAPE);
-    for (int j = 0; j < njobs; ++j) {
-        const smx_mlp3_job_t& J = jobs[j];
-        const smx_adam_group_t& A = groups[j];
-        SMX_REQUIRE(J.net && J.grads && J.xT && J.h1T && J.h2T && J.dz1T && J.dz2T && J.dz3T, SMX_E_NULL);
-        SMX_REQUIRE(A.theta && A.exp_avg && A.exp_avg_sq && A.sumsq_partials, SMX_E_NULL);
-        SMX_REQUIRE(J.rows > 0 && J.rows < (1 << 30), SMX_E_SHAPE);
-        SMX_REQUIRE(A.grads == J.grads && J.sumsq_partials == A.sumsq_partials, SMX_E_SHAPE);   // one buffer, two views
-        SMX_REQUIRE(which[j] == 0 || which[j] == 1, SMX_E_SHAPE);
-        SMX_REQUIRE(A.n >= mlp3_numel(J.net) && A.npart >= smx_mlp3_backward_partials(J.net->D, J.net->H1, J.net->H2, J.net->OUT),
-                    SMX_E_SHAPE);
-        SMX_REQUIRE(!A.packed == !A.pack_net, SMX_E_NULL);
-    }
-    GemmBatch G;
-    build_wgrads(G, jobs, njobs);
-    for (int k = 0; k < G.n; ++k)
-        if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
-    const int n_cu = smx_cu_count();
-    const GemmProb& Lp = G.p[G.n - 1];
-    const int blocks = Lp.tile_base + Lp.tiles_m * Lp.tiles_n;
-    bool fused = blocks <= 2 * n_cu;              // every workgroup resident at once: two per CU (__launch_bounds__, LDS)
-    for (int k = 0; k < G.n; ++k) fused = fused && G.p[k].a_mode == 0 && G.p[k].b_mode == 0 && G.p[k].K < 2048;
-    static const bool off = getenv("SMX_WGRAD_ADAM_OFF") != nullptr;     // A/B switch for measurements
-    if (!fused || off) {
-        // the two (three) launches it replaces: same results
-        int rc = launch_batch(G, smx_s(stream));
-        if (rc != SMX_OK) return rc;
-        if (njobs == 2 && which[0] == 0 && which[1] == 1)
-            return smx_clip_adam_step_pair_f32(&groups[0], &groups[1], ctrl, stream);
-        for (int j = 0; j < njobs && rc == SMX_OK; ++j)
-            rc = smx_clip_adam_step_group_f32(&groups[j], which[j], ctrl, stream);
-        return rc;
-    }
-    AdamTail T;
-    memset(&T, 0, sizeof(T));
-    for (int j = 0; j < njobs; ++j) {
-        const smx_adam_group_t& A = groups[j];
-        const smx_mlp3_t& N = *jobs[j].net;
-        AdamSide& S = T.g[j];
-        S.theta = A.theta; S.m = A.exp_avg; S.v = A.exp_avg_sq; S.grads = A.grads;
-        S.n = (long)A.n; S.n_mlp = (long)mlp3_numel(&N);
-        S.tile_base = G.p[3 * j].tile_base;
-        S.ntiles = smx_mlp3_backward_partials(N.D, N.H1, N.H2, N.OUT);
-        S.slots = (unsigned long long*)slots + S.tile_base;
-        S.partials = A.sumsq_partials; S.npart = A.npart;
-        S.which = which[j]; S.honour_stop = A.honour_stop; S.grad_norm_out = A.grad_norm_out;
-        S.pack.packed = nullptr;
-        if (A.packed) {
-            S.pack.packed = A.packed;
-            S.pack.oW1 = N.W1 - A.theta; S.pack.oW2 = N.W2 - A.theta; S.pack.oW3 = N.W3 - A.theta;
-            S.pack.D = N.D; S.pack.H1 = N.H1; S.pack.H2 = N.H2; S.pack.OUT = N.OUT;
-            SMX_REQUIRE(S.pack.oW1 >= 0 && S.pack.oW3 + (long)N.OUT * N.H2 <= A.n, SMX_E_SHAPE);
-        }
-    }
-    if (njobs == 1) T.g[1] = T.g[0];
-    hipLaunchKernelGGL(gemm32_adam_kernel, dim3(blocks), dim3(256), 0, smx_s(stream), G, T, ctrl);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SMX_OK : (int)e;
-}
 
 extern "C" int smx_mlp3_backward_f32(const smx_mlp3_t* net, const float* x, const float* h1,
                                      const float* h2, const float* dz3, int64_t rows, float* dz2,

@@ -488,20 +488,6 @@ class HipKernels(object):
         L.call('smx_clip_adam_step_pair_f32', ctypes.byref(gs[0]), ctypes.byref(gs[1]), L.ptr(ctrl),
                self._st())
 
-    def mlp3_wgrad_adam(self, jobs, groups, ctrl, slots, pack=None):
-        """mlp3_wgrad_multi(jobs) + the clip-norm / Adam step of each job's optimiser group in ONE launch
-        (smx_mlp3_wgrad_adam_f32).  groups[j] = (theta, grads, m, v, sumsq, npart, honour_stop, grad_norm_out, which) of
-        jobs[j]; pack[j] = (net, packed); slots: one zeroed 8-byte word per 32 x 32 tile of the launch"""
-        gs = (L.AdamGroup * len(groups))()
-        which = (ctypes.c_int32 * len(groups))()
-        for k, (theta, grads, m, v, sumsq, npart, honour_stop, gno, w) in enumerate(groups):
-            gs[k] = L.AdamGroup(L.ptr(theta), L.ptr(grads), L.ptr(m), L.ptr(v), theta.numel(), L.ptr(sumsq), npart,
-                                int(honour_stop), L.ptr(gno))
-            if pack is not None:
-                gs[k].pack_net, gs[k].packed = ctypes.pointer(pack[k][0].desc), L.ptr(pack[k][1])
-            which[k] = int(w)
-        L.call('smx_mlp3_wgrad_adam_f32', self._jobs(jobs), len(jobs), gs, which, L.ptr(ctrl), L.ptr(slots), self._st())
-
     def sumsq_blocks(self, n):
         return self.lib.smx_sumsq_blocks(n)
 

@@ -277,14 +277,12 @@ class PPOLearner(Learner):
         # collectives (_SegmentedGraph), unless session_config.learner.graph_segments is off
         self.use_graph = bool(lcfg.get('use_hip_graph', True)) and self.device != 'cpu' \
             and (self.world_size == 1 or bool(lcfg.get('graph_segments', True)))
-        self.overlap_value_epochs = bool(lcfg.get('overlap_value_epochs', True)) \
-            and self.device != 'cpu'
-        # 'lockstep': actor and critic epochs share launches; 'two_stream': separate chains.
-        # 'fused_epochs' (default where the shapes allow): a lock-step epoch is four launches of the
-        # row-block kernels (csrc/smx_epoch.hip) instead of nine layer launches
-        self.epoch_schedule = lcfg.get('epoch_schedule', 'lockstep')
+        # actor and critic epochs share launches (lock-step: the reference's two loops touch disjoint parameters).
+        # 'fused_epochs' (default where the shapes allow): an epoch is three launches of the row-block kernels
+        # (csrc/smx_epoch.hip) instead of nine layer launches.  (Rounds 2-4 also carried a two-stream schedule, the
+        # two chains on two streams inside the graph, and the weight gradients + Adam as one launch: each measured
+        # equal or slower, DESIGN.md 3.2, and was removed in round 5.)
         self.fused_epochs = bool(lcfg.get('fused_epochs', True))
-        self.split_chains = bool(lcfg.get('split_chains', False))
         self._ws = None
         self._graphs = {}
         self._ctrl_host = None
@@ -325,17 +323,15 @@ class PPOLearner(Learner):
         E = N - self.horizon + 1 if rnn else 1           # ppo.py:398-400, 521-537
         ws.E = E
         Ep, Ev = self.epoch_policy, self.epoch_baseline
-        # scalars block: ctrl | policy stats | value stats | moments
         # scalars block: ctrl | policy stats | in-launch counters of the fused forward + backward epochs | value stats | moments
         # (+ per launch and row block of the fused forward + backward epochs: an 8-byte slot)
         n_slots = 0 if (self.if_rnn_policy or self.model.if_pixel or self.world_size > 1) else \
             2 * (max(Ep, Ev) + 1) * ((B + 15) // 16)
-        # (+ with learner.wgrad_adam -- weight gradients, clip-norm and Adam step in ONE launch, smx_mlp3_wgrad_adam_f32;
-        # measured equal to the two launches it replaces, DESIGN.md 3.2, so off by default -- an 8-byte slot per launch and
-        # 32 x 32 tile)
-        tiles_ac = K.mlp3_backward_partials(act) + K.mlp3_backward_partials(cri)
-        n_adam = 2 * max(Ep, Ev) * tiles_ac if n_slots and self.session_config.learner.get('wgrad_adam', False) else 0
-        n_sync = self._sync_words() + n_slots + n_adam
+        if n_slots > (1 << 19):
+            # (the slots sit in the range epoch_prepare zeroes per learn, which the kernel bounds at 2^20 words: batches of
+            # more than ~380 k sub-trajectories run the two-launch epochs, which need none)
+            n_slots = 0
+        n_sync = self._sync_words() + n_slots
         n_scal = L.CTRL_WORDS + (Ep + 1) * L.PS_STRIDE + n_sync + Ev * L.VS_STRIDE + 12 + 4
         ws.scal = torch.zeros(n_scal, device=dev, dtype=torch.float32)
         o = 0
@@ -345,7 +341,6 @@ class PPOLearner(Learner):
         ws.sync = ws.scal[o:o + n_sync].view(torch.int32); o += n_sync       # one word per epoch launch, zeroed per learn
         ws.kl_slots = ws.sync[self._sync_words():self._sync_words() + n_slots].view(-1, 2 * ((B + 15) // 16)) \
             if n_slots else None
-        ws.adam_slots = ws.sync[self._sync_words() + n_slots:].view(-1, 2 * tiles_ac) if n_adam else None
         ws.n_sync = n_sync
         ws.vstats = ws.scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE); o += Ev * L.VS_STRIDE
         ws.adv_mom = ws.scal[o:o + 3]; o += 3
@@ -467,7 +462,7 @@ class PPOLearner(Learner):
         ws.nblk_p = K.loss_blocks(rows)
         # fused row-block epochs: plain MLP policy, shapes the kernels take; on several ranks the
         # paired-epoch schedule with one collective per epoch (epoch_policy == epoch_baseline)
-        ws.fused = (self.fused_epochs and self.epoch_schedule == 'lockstep' and not stem and
+        ws.fused = (self.fused_epochs and not stem and
                     (self.world_size == 1 or self.epoch_policy == self.epoch_baseline) and
                     K.epoch_supported(act, cri))
         # ... and an updating epoch's forward + loss + data gradients as ONE launch (single rank; several ranks need the
@@ -683,59 +678,6 @@ class PPOLearner(Learner):
                 K.moments_merge(ws.mom_parts, ws.adv_mom)
             K.adv_normalize(ws.adv, ws.adv_mom, 1e-4)
 
-    def _enqueue_policy_forward(self, ws, e, actions0, behave0):
-        """forward + loss + finalize for epoch slot e (ppo.py:209-225 / 266-285, 553-557)"""
-        K, m = self.K, self.model
-        mode = L.SMX_PPO_CLIP if self.ppo_mode == 'clip' else L.SMX_PPO_ADAPT
-        K.mlp3_forward(m.actor, ws.xn, ws.h1a, ws.h2a, ws.mean, L.SMX_ACT_TANH, ws.stop)
-        K.policy_loss(mode, ws.mean, m.log_var.view(-1), actions0, behave0, ws.ref_pol, ws.adv,
-                      ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
-        part, nblk = ws.ppart, ws.nblk_p
-        if self.world_size > 1:
-            torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
-            self._dist.all_reduce(ws.ppart_sum)
-            part, nblk = ws.ppart_sum, 1
-        A = self.action_dim
-        K.policy_finalize(mode, part, nblk, ws.g_surr, ws.g_kl, m.log_var.view(-1),
-                          ws.n_total, ws.ctrl_f, e > 0, e < self.epoch_policy,
-                          ws.dz3a, ws.grads_a[m.actor.numel:m.actor.numel + A],
-                          ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
-
-    def _enqueue_policy_update(self, ws, e):
-        """backward + clip_grad_norm_ + Adam (ppo.py:240-248 / 301-309)"""
-        K, m = self.K, self.model
-        K.mlp3_backward(m.actor, ws.xn, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a, ws.grads_a,
-                        ws.sumsq_a, ws.stop)
-        npart = ws.np_a + 1
-        if self.world_size > 1:
-            # the MLP gradients are per-rank sums over local rows (already scaled by 1/n_total);
-            # the log_var gradient was built from the all-reduced partials and is global already
-            self._dist.all_reduce(ws.grads_a[:m.actor.numel])
-            K.sumsq_partials(ws.grads_a, ws.sumsq_a)
-            npart = K.sumsq_blocks(ws.grads_a.numel())
-        K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
-                    ws.sumsq_a, npart, ws.ctrl_f, 0, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1])
-
-    def _enqueue_value_epoch(self, ws, e):
-        """forward + loss + backward + clip + Adam for the critic (ppo.py:323-353)"""
-        K, m = self.K, self.model
-        K.mlp3_forward(m.critic, ws.xn, ws.h1c, ws.h2c, ws.vpred.view(-1, 1), L.SMX_ACT_NONE, None)
-        n_total = ws.n_total
-        if self.world_size > 1:
-            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart_local, ws.ctrl_f, True)
-            self._dist.all_gather_into_tensor(ws.vpart[e].view(-1), ws.vpart_local.view(-1))
-        else:
-            K.value_loss(ws.vpred, ws.ret, n_total, ws.dz3c, ws.vpart[e], ws.ctrl_f, True)
-        K.mlp3_backward(m.critic, ws.xn, ws.h1c, ws.h2c, ws.dz3c.view(-1, 1), ws.dz2c, ws.dz1c,
-                        ws.grads_c, ws.sumsq_c, None)
-        npart = ws.np_c
-        if self.world_size > 1:
-            self._dist.all_reduce(ws.grads_c)
-            K.sumsq_partials(ws.grads_c, ws.sumsq_c)
-            npart = K.sumsq_blocks(ws.grads_c.numel())
-        K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
-                    ws.sumsq_c, npart, ws.ctrl_f, 1, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1])
-
     def _enqueue_lockstep_epochs(self, ws, actions0, behave0, first_extra=(), after_first=None):
         """Policy epoch e and value epoch e advance together: the reference runs the two loops
         one after the other (ppo.py:541-562) but they touch disjoint parameters, so the layer-l
@@ -912,35 +854,6 @@ class PPOLearner(Learner):
                                  ws.ctrl_f, pack=((m.actor, ws.pk_actor), (m.critic, ws.pk_critic)))
             return
 
-        if self.split_chains and self.device != 'cpu':
-            # The policy and the value epochs touch disjoint parameters (ppo.py:541-562) and each of
-            # their launches fills at most half of the chip: the two chains run on two streams, so a
-            # chain's launch gaps and latency-bound phases overlap with the other chain's kernels
-            main = torch.cuda.current_stream()
-            side = self._side_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                for e in range(Ev):
-                    loss = loss_args(e)
-                    K.epoch_forward([cj], loss, ws.ctrl_f, n_total)
-                    K.epoch_backward([cj], loss, ws.ctrl_f, n_total)
-                    K.mlp3_wgrad_multi([cj])
-                    K.clip_adam(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
-                                ws.sumsq_c, ws.np_c, ws.ctrl_f, 1, False,
-                                ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1], pack=(m.critic, ws.pk_critic))
-            for e in range(Ep + 1):
-                loss = loss_args(e)
-                K.epoch_forward([aj], loss, ws.ctrl_f, n_total)
-                K.epoch_backward([aj], loss, ws.ctrl_f, n_total)
-                if e < Ep:
-                    K.mlp3_wgrad_multi([aj])
-                    K.clip_adam(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
-                                ws.sumsq_a, ws.np_a + 1, ws.ctrl_f, 0, True,
-                                ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1], pack=(m.actor, ws.pk_actor))
-            main.wait_stream(side)
-            if not ws.merged_tail:
-                K.value_finalize(ws.vpart, Ev, ws.vpart.shape[1], ws.vstats, L.VS_STRIDE)
-            return
         for e in range(max(Ep + 1, Ev)):
             pol_f, pol_u, val = e <= Ep, e < Ep, e < Ev
             loss = loss_args(e)
@@ -948,19 +861,6 @@ class PPOLearner(Learner):
                 # forward + loss + data gradients of every job of the epoch in ONE launch (smx_epoch_fwdbwd_f32)
                 bj = ([aj] if pol_u else []) + ([cj] if val else [])
                 K.epoch_fwdbwd(bj, loss, ws.ctrl_f, n_total, ws.sync[e:e + 1], ws.kl_slots[e])
-                if ws.adam_slots is not None:
-                    # ... and the weight gradients, clip-norm and Adam step of both groups in a second one
-                    gs, pk = [], []
-                    if pol_u:
-                        gs.append((m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq, ws.sumsq_a,
-                                   ws.np_a + 1, True, ws.pstats[e, L.PS_GRADNORM:L.PS_GRADNORM + 1], 0))
-                        pk.append((m.actor, ws.pk_actor))
-                    if val:
-                        gs.append((m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq, ws.sumsq_c,
-                                   ws.np_c, False, ws.vstats[e, L.VS_GRADNORM:L.VS_GRADNORM + 1], 1))
-                        pk.append((m.critic, ws.pk_critic))
-                    K.mlp3_wgrad_adam(bj, gs, ws.ctrl_f, ws.adam_slots[e], pack=pk)
-                    continue
                 K.mlp3_wgrad_multi(bj)
             else:
                 K.epoch_forward(([aj] if pol_f else []) + ([cj] if val else []), loss, ws.ctrl_f, n_total)
@@ -1084,15 +984,10 @@ class PPOLearner(Learner):
         K, m, ref = self.K, self.model, self.ref_target_model
         B, N, D = obs.shape
         A = self.action_dim
-        lockstep = self.epoch_schedule == 'lockstep'
-        fused = lockstep and ws.fused
+        fused = ws.fused
         if not fused and not pre_zeroed:
             ws.zero_block.zero_()                # stop flag, epochs done, per-epoch policy statistics
-        tail = None
-        if lockstep:
-            tail = self._enqueue_critic_pass(ws, obs, obs_next, filter_tail=not fused)
-        else:
-            self._enqueue_gae(ws, obs, obs_next, rewards, dones)
+        tail = self._enqueue_critic_pass(ws, obs, obs_next, filter_tail=not fused)
 
         obs0 = obs[:, 0, :]                      # ppo.py:527-537 (views, no copies)
         actions0 = actions[:, 0, :]
@@ -1124,43 +1019,17 @@ class PPOLearner(Learner):
         if not fused:
             ws.xnT.copy_(ws.xn.t())
             ws.ref_pol[:, A:].copy_(torch.exp(ref.log_var).expand(ws.rows, A))
-        if not lockstep:
-            K.mlp3_forward_multi([ref_job])
-
-        def policy_epochs():
-            self._enqueue_policy_forward(ws, 0, actions0, behave0)
-            for e in range(self.epoch_policy):
-                self._enqueue_policy_update(ws, e)
-                self._enqueue_policy_forward(ws, e + 1, actions0, behave0)
-
-        def value_epochs():
-            for e in range(self.epoch_baseline):
-                self._enqueue_value_epoch(ws, e)
-            K.value_finalize(ws.vpart, self.epoch_baseline, ws.vpart.shape[1], ws.vstats,
-                             L.VS_STRIDE)
-
-        if lockstep and ws.fused:
+        if fused:
             self._enqueue_fused_epochs(ws, actions0, behave0, ref_job, tail,
                                        lambda: self._enqueue_gae_from_values(ws, obs, rewards, dones))
-        elif lockstep:
+        else:
             # the reference policy and the critic's obs_next rows ride in epoch 0's forward
             # launches (four independent networks, one launch per layer); GAE follows them
             self._enqueue_lockstep_epochs(
                 ws, actions0, behave0, first_extra=[ref_job] + ([tail] if tail is not None else []),
                 after_first=lambda: self._enqueue_gae_from_values(ws, obs, rewards, dones))
-        elif self.overlap_value_epochs and self.world_size == 1:
-            main = torch.cuda.current_stream()
-            side = self._side_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                value_epochs()
-            policy_epochs()
-            main.wait_stream(side)
-        else:
-            policy_epochs()
-            value_epochs()
 
-        if lockstep and ws.tail_deferred:
+        if ws.tail_deferred:
             self._enqueue_tail_exchange(ws, obs0, actions0, behave0)
             self._enqueue_final_stats(ws)
             return
@@ -1426,11 +1295,6 @@ class PPOLearner(Learner):
     def _enqueue_final_stats(self, ws):
         self.K.final_stats(self.model.log_var.view(-1),
                            self.model.z_filter if self.use_z_filter else None, ws.fin)
-
-    def _side_stream(self):
-        if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream()
-        return self._side
 
     # ======================================================================================
     # _optimize / learn  (ppo.py:487-613)

@@ -643,12 +643,6 @@ class TorchCpuKernels(object):
         if pack is not None:
             self.epoch_pack(list(pack))
 
-    def mlp3_wgrad_adam(self, jobs, groups, ctrl, slots, pack=None):
-        self.mlp3_wgrad_multi(jobs)
-        for k, (theta, grads, m, v, sumsq, npart, honour_stop, gno, which) in enumerate(groups):
-            self.clip_adam(theta, grads, m, v, sumsq, npart, ctrl, which, honour_stop, gno,
-                           pack=None if pack is None else pack[k])
-
     def sumsq_blocks(self, n):
         return max(1, min(256, (n + 4095) // 4096))
 

@@ -280,94 +280,6 @@ def test_epoch_launches_against_the_reference_restatement_in_float64(K, rows, D,
     assert abs(sq_err / rows - vst['_val_loss']) <= 2e-5 * max(1.0, vst['_val_loss'])
 
 
-def _wgrad_adam_side(K, rows, D, H1, H2, A, mode, seed, fused, steps=2, stop_at=None, only=None):
-    """`steps` epochs [forward + backward -> weight gradients -> clip-norm + Adam] on the device, the last two phases as
-    two launches (fused=False) or as smx_mlp3_wgrad_adam_f32"""
-    from surreal_amd.model.ppo_net import Mlp3Params
-    t = build(rows, D, H1, H2, A, seed=seed, mode=mode, device='cuda')['d']
-    na, nc = t['act'].numel, t['cri'].numel
-    th_a = torch.cat([torch.cat([v.reshape(-1) for v in t['act'].views.values()]), t['log_var']]).contiguous()
-    th_c = torch.cat([v.reshape(-1) for v in t['cri'].views.values()]).contiguous()
-    act, cri = Mlp3Params(th_a, 0, D, H1, H2, A), Mlp3Params(th_c, 0, D, H1, H2, 1)
-    log_var = th_a[na:]
-    g = torch.Generator().manual_seed(seed + 7)
-    z = lambda n: torch.zeros(n, device='cuda')  # noqa: E731
-    ga, gc = z(na + A), z(nc)
-    np_a, np_c = K.mlp3_backward_partials(act), K.mlp3_backward_partials(cri)
-    sq_a, sq_c = z(np_a + 1), z(np_c)
-    m_a, v_a = (0.01 * torch.randn(na + A, generator=g)).cuda(), (1e-4 * torch.rand(na + A, generator=g)).cuda()
-    m_c, v_c = (0.01 * torch.randn(nc, generator=g)).cuda(), (1e-4 * torch.rand(nc, generator=g)).cuda()
-    t['ctrl'][L.C_KL_TARGET] = 1e9 if stop_at is None else 0.015
-    t['ctrl'][L.C_ACTOR_MAX_NORM] = 0.05                 # the clip is active for the actor, not for the critic
-    t['ctrl'][L.C_ACTOR_WD], t['ctrl'][L.C_CRITIC_WD] = 0.0, 1e-3
-    ci = t['ctrl'].view(torch.int32)
-    ci[L.C_STEP_ACTOR], ci[L.C_STEP_CRITIC] = 3, 40
-    sync = torch.zeros(8, dtype=torch.int32, device='cuda')
-    kl = torch.zeros(8, 2 * ((rows + 15) // 16), dtype=torch.int32, device='cuda')
-    slots = torch.zeros(8, 2 * (np_a + np_c), dtype=torch.int32, device='cuda')
-    gn = z(4)
-    stats = torch.zeros(steps, L.PS_STRIDE, device='cuda')
-    K.epoch_pack([(act, t['pk_a']), (cri, t['pk_c'])])
-    aj = dict(net=act, packed=t['pk_a'], x=t['x'], h1T=t['h1aT'], h2T=t['h2aT'], act=L.SMX_ACT_TANH, loss='policy',
-              stop=ci[L.C_STOP:L.C_STOP + 1], dz3T=t['dz3aT'], dz2T=t['dz2aT'], dz1T=t['dz1aT'], xT=t['xT'], grads=ga, sumsq=sq_a)
-    cj = dict(net=cri, packed=t['pk_c'], x=t['x'], h1T=t['h1cT'], h2T=t['h2cT'], act=L.SMX_ACT_NONE, loss='value',
-              dz3=t['v_dz3'], dz3T=t['v_dz3'], dz2T=t['dz2cT'], dz1T=t['dz1cT'], xT=t['xT'], grads=gc, sumsq=sq_c)
-    jobs = [aj, cj] if only is None else [dict(a=aj, c=cj)[only]]
-    for e in range(steps):
-        loss = dict(mode=mode, rows=rows, log_var=log_var, actions=t['actions'], behave=t['behave'], ref=t['ref'],
-                    adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=e > 0,
-                    will_update=True, dlogvar=ga[na:], dlogvar_sumsq=sq_a[np_a:], stats=stats[e],
-                    returns=t['returns'], v_dz3=t['v_dz3'], v_partials=t['v_partials'], v_will_update=True)
-        K.epoch_fwdbwd(jobs, loss, t['ctrl'], rows, sync[e:e + 1], kl[e])
-        groups = dict(a=(th_a, ga, m_a, v_a, sq_a, np_a + 1, True, gn[0:1], 0), c=(th_c, gc, m_c, v_c, sq_c, np_c, False, gn[1:2], 1))
-        packs = dict(a=(act, t['pk_a']), c=(cri, t['pk_c']))
-        keys = ['a', 'c'] if only is None else [only]
-        if fused:
-            K.mlp3_wgrad_adam(jobs, [groups[k] for k in keys], t['ctrl'], slots[e], pack=[packs[k] for k in keys])
-        else:
-            K.mlp3_wgrad_multi(jobs)
-            for k in keys:
-                G = groups[k]
-                K.clip_adam(G[0], G[1], G[2], G[3], G[4], G[5], t['ctrl'], G[8], G[6], G[7], pack=packs[k])
-    torch.cuda.synchronize()
-    return dict(th_a=th_a, th_c=th_c, m_a=m_a, v_a=v_a, m_c=m_c, v_c=v_c, ga=ga, gc=gc, sq_a=sq_a, sq_c=sq_c, gn=gn,
-                pk_a=t['pk_a'], pk_c=t['pk_c'], ctrl=t['ctrl'], stats=stats, np=(np_a, np_c))
-
-
-@pytest.mark.parametrize('mode', [L.SMX_PPO_ADAPT, L.SMX_PPO_CLIP])
-@pytest.mark.parametrize('rows,D,H1,H2,A', [(1024, 376, 300, 200, 17), (64, 16, 300, 200, 6), (48, 12, 24, 16, 3), (100, 64, 332, 212, 32),
-                                            (37, 29, 40, 24, 5), (64, 1024, 384, 128, 4)])
-def test_wgrad_adam_equals_wgrad_then_clip_adam(K, rows, D, H1, H2, A, mode):
-    """smx_mlp3_wgrad_adam_f32 against the two launches it replaces, two epochs in a row: parameters, both moments, the
-    packed weight copies the next epoch's forward reads, gradients, partial sums of squares and reported norms -- the same
-    bits.  (37 rows: the transposed operands are not 16-byte aligned, the call runs as the launches it replaces; hidden
-    D = 1024, H1 = 384: 872 tiles, more than can be resident at once, likewise)"""
-    one = _wgrad_adam_side(K, rows, D, H1, H2, A, mode, seed=rows + H1, fused=True)
-    two = _wgrad_adam_side(K, rows, D, H1, H2, A, mode, seed=rows + H1, fused=False)
-    ci = one['ctrl'].view(torch.int32)
-    assert int(ci[L.C_SYNC_ERR]) == 0 and int(ci[L.C_STEP_ACTOR]) == 5 and int(ci[L.C_STEP_CRITIC]) == 42
-    assert float(two['gn'][0]) > 0.05 > 0                 # the actor's clip was active
-    for k in ('gn', 'sq_a', 'sq_c', 'ga', 'gc', 'th_a', 'th_c', 'm_a', 'v_a', 'm_c', 'v_c', 'pk_a', 'pk_c', 'stats'):
-        assert torch.equal(one[k], two[k]), (k, float((one[k] - two[k]).abs().max()))
-
-
-@pytest.mark.parametrize('only', ['a', 'c'])
-def test_wgrad_adam_single_group_and_early_exit(K, only):
-    """one group alone (unequal epoch counts), and the KL early exit: once the flag is up the actor's tiles neither form
-    gradients nor step, the critic's still do"""
-    for stop_at in (None, 1):
-        one = _wgrad_adam_side(K, 256, 48, 72, 40, 6, L.SMX_PPO_ADAPT, seed=11, fused=True, steps=3, stop_at=stop_at, only=only)
-        two = _wgrad_adam_side(K, 256, 48, 72, 40, 6, L.SMX_PPO_ADAPT, seed=11, fused=False, steps=3, stop_at=stop_at, only=only)
-        assert int(one['ctrl'].view(torch.int32)[L.C_SYNC_ERR]) == 0
-        for k in ('gn', 'th_a', 'th_c', 'm_a', 'v_a', 'm_c', 'v_c', 'pk_a', 'pk_c', 'stats'):
-            assert torch.equal(one[k], two[k]), (k, stop_at)
-    both1 = _wgrad_adam_side(K, 256, 48, 72, 40, 6, L.SMX_PPO_ADAPT, seed=11, fused=True, steps=3, stop_at=1)
-    both2 = _wgrad_adam_side(K, 256, 48, 72, 40, 6, L.SMX_PPO_ADAPT, seed=11, fused=False, steps=3, stop_at=1)
-    assert int(both2['ctrl'].view(torch.int32)[L.C_STOP]) != 0, 'the case does not reach the early exit'
-    for k in ('gn', 'th_a', 'th_c', 'm_a', 'v_a', 'm_c', 'v_c', 'pk_a', 'pk_c', 'stats'):
-        assert torch.equal(both1[k], both2[k]), k
-
-
 def test_epoch_fwdbwd_kl_cutoff_early_exit_and_repeats(K):
     rows, D, H1, H2, A = 200, 24, 64, 48, 6
     # (a) the KL cutoff active: c_kl = beta + 2 eta (KL - 2 kl_target) carries the batch KL through the counter

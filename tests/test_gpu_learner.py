@@ -65,27 +65,18 @@ def test_rnn_learner_matches_reference_golden_eager(name):
 
 @pytest.mark.parametrize('name', ['tiny_adapt_cutoff2', 'ragged_clip', 'cfg2_adapt', 'cfg5_adapt_earlyexit'])
 def test_learner_matches_reference_golden_eager(name):
-    """same numbers without graph capture and without stream overlap"""
-    check_case(name, *run_case(name, {'use_hip_graph': False, 'overlap_value_epochs': False}))
-
-
-@pytest.mark.parametrize('name', ['tiny_adapt_cutoff2', 'cfg2_clip'])
-def test_learner_two_stream_schedule(name):
-    """the alternative launch schedule (separate policy / value chains on two streams)"""
-    check_case(name, *run_case(name, {'epoch_schedule': 'two_stream'}))
+    """same numbers without graph capture"""
+    check_case(name, *run_case(name, {'use_hip_graph': False}))
 
 
 @pytest.mark.parametrize('name,opts', [
-    ('cfg5_adapt', {'split_chains': True}),                      # actor / critic chains on two streams in the graph
     ('cfg5_clip', {'fused_epochs': False}),                      # the layered (one launch per layer) epoch schedule
-    ('cfg2_adapt', {'fused_epochs': False, 'split_chains': True}),
-    ('cfg5_adapt_earlyexit', {'split_chains': True}),
-    ('cfg5_adapt', {'wgrad_adam': True}),                        # weight gradients + clip-norm + Adam in one launch
-    ('cfg5_adapt_earlyexit', {'wgrad_adam': True}),
-    ('tiny_adapt_cutoff2', {'wgrad_adam': True}),
-    ('cfg2_clip', {'wgrad_adam': True})])
+    ('cfg2_adapt', {'fused_epochs': False}),
+    ('cfg5_adapt', {'fused_fwdbwd': False}),                     # forward and backward of an epoch as two launches
+    ('cfg5_adapt_earlyexit', {'fused_fwdbwd': False}),
+    ('tiny_adapt_cutoff2', {'fused_epochs': False, 'use_hip_graph': False})])
 def test_learner_session_options_keep_the_numbers(name, opts):
-    """every schedule option of the fused-epoch learner (session_config.learner.*) reproduces the same goldens"""
+    """every schedule option the learner still carries (session_config.learner.*) reproduces the same goldens"""
     check_case(name, *run_case(name, opts))
 
 
