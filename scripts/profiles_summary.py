@@ -25,7 +25,7 @@ def mfma_summary(tag, mfma_dir):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(mfma_dir + '/bench_counter_collection.csv')):
         n = short(r['Kernel_Name'])
-        if 'fused' in n or 'rows16' in n or 'gemm' in n or 'lstm' in n or 'epoch' in n or 'adam' in n:
+        if any(t in n for t in ('fused', 'rows16', 'gemm', 'lstm', 'epoch', 'adam', 'bwd16', 'wgrad')):
             a[(n, int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
     res = {'note': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES '
                    'SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE (own pass), python bench.py --steps 3 --warmup 1 '

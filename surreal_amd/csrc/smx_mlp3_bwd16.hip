@@ -25,9 +25,30 @@ constexpr int NTHR = 512;
 // One product with the B operand in REGISTERS: out[t] (OT feature tiles) += W^T chunks . in (KT tiles of 16 k each).
 // Wp: packed [PK = ceil(KT / 2) chunks][PO * 32 feature rows][32 k].  Wb0 / Wb1: LDS staging, PO * 32 rows of LDW floats.
 // Every wavefront of the workgroup calls it (barriers inside).
+// the staging registers of one weight chunk (<= 5 passes of 64 rows): requested with first_chunk() BEFORE the epilogue of
+// the previous product (mask loads, stores) so that the chunk's L2 round trip is not exposed at the product's start
+struct Chunk { float4 v0, v1, v2, v3, v4; };
+
+template <int OT>
+__device__ __forceinline__ void first_chunk(Chunk& C, const float* __restrict__ Wp) {
+    constexpr int PO = (OT + 1) / 2;
+    constexpr int NW = (PO * 32 + 63) / 64;
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, sk8 = tid & 7;
+    const float4* src = reinterpret_cast<const float4*>(Wp);
+    C.v0 = C.v1 = C.v2 = C.v3 = C.v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define B16_OK(i) ((i) < NW && (srow + 64 * (i) < PO * 32 || (PO * 32) % 64 == 0))
+    if (B16_OK(0)) C.v0 = src[(srow + 0) * 8 + sk8];
+    if (B16_OK(1)) C.v1 = src[(srow + 64) * 8 + sk8];
+    if (B16_OK(2)) C.v2 = src[(srow + 128) * 8 + sk8];
+    if (B16_OK(3)) C.v3 = src[(srow + 192) * 8 + sk8];
+    if (B16_OK(4)) C.v4 = src[(srow + 256) * 8 + sk8];
+#undef B16_OK
+}
+
 template <int KT, int OT>
 __device__ __forceinline__ void product_from_registers(const f32x4 (&in)[KT], f32x4 (&out)[OT], const float* __restrict__ Wp,
-                                                       float* Wb0, float* Wb1) {
+                                                       float* Wb0, float* Wb1, const Chunk& first) {
     constexpr int PK = (KT + 1) / 2, PO = (OT + 1) / 2;
     constexpr int NW = (PO * 32 + 63) / 64;                // staging passes of 64 rows (512 threads x 16 bytes)
     static_assert(NW <= 5, "staging registers are written out for <= 5 passes");
@@ -35,8 +56,7 @@ __device__ __forceinline__ void product_from_registers(const f32x4 (&in)[KT], f3
     const int fm = lane & 15, g = lane >> 4;
     const int srow = tid >> 3, sk8 = tid & 7, sk4 = sk8 * 4;
     const int woff = fm * LDW + 4 * g;
-    float4 v0, v1, v2, v3, v4;
-    v0 = v1 = v2 = v3 = v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v0 = first.v0, v1 = first.v1, v2 = first.v2, v3 = first.v3, v4 = first.v4;
 #define B16_ROW_OK(i) ((i) < NW && (srow + 64 * (i) < PO * 32 || (PO * 32) % 64 == 0))
 #define B16_LD(c)                                                                                              \
     do {                                                                                                       \
@@ -57,7 +77,6 @@ __device__ __forceinline__ void product_from_registers(const f32x4 (&in)[KT], f3
     } while (0)
 #pragma unroll
     for (int t = 0; t < OT; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    B16_LD(0);
     __syncthreads();                    // (the previous product's last fragment reads of Wb0 are done)
     B16_ST(Wb0);
     if (PK > 1) B16_LD(1);
@@ -177,17 +196,30 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_bwd16_kernel(Bwd16Args A) {
             acc2[u] = c;
         }
     }
+    Chunk ck;
+#ifndef SMX_BWD16_NOHOIST               // (A/B switch, scripts/build_variant_lib.py)
+    first_chunk<NT1>(ck, A.pt2);        // (in flight under the mask loads and the dz2 stores)
+#endif
     mask_and_store<NT2>(acc2, A.h2, A.dz2, myrow, row_ok, A.H2, g);
+#ifdef SMX_BWD16_NOHOIST
+    first_chunk<NT1>(ck, A.pt2);
+#endif
 
     // ======================= dz1^T = W2^T . dz2^T ==============================================================
     f32x4 acc1[NT1];
-    product_from_registers<NT2, NT1>(acc2, acc1, A.pt2, Wb0, Wb1);
+    product_from_registers<NT2, NT1>(acc2, acc1, A.pt2, Wb0, Wb1, ck);
+#ifndef SMX_BWD16_NOHOIST
+    if (A.dx) first_chunk<NTD>(ck, A.pt1);
+#endif
     mask_and_store<NT1>(acc1, A.h1, A.dz1, myrow, row_ok, A.H1, g);
+#ifdef SMX_BWD16_NOHOIST
+    if (A.dx) first_chunk<NTD>(ck, A.pt1);
+#endif
 
     // ======================= dx^T = W1^T . dz1^T ================================================================
     if (A.dx) {
         f32x4 accx[NTD];
-        product_from_registers<NT1, NTD>(acc1, accx, A.pt1, Wb0, Wb1);
+        product_from_registers<NT1, NTD>(acc1, accx, A.pt1, Wb0, Wb1, ck);
         mask_and_store<NTD>(accx, nullptr, A.dx, myrow, row_ok, A.D, g);
     }
 }
