@@ -45,5 +45,10 @@ print('forward layered: %8.1f us  %6.1f TFLOP/s' % (t, fl / t / 1e6))
 t = timed(lambda: K.mlp3_forward(net, x, h1, h2, out, L.SMX_ACT_TANH, pack=pack))
 print('forward fused  : %8.1f us  %6.1f TFLOP/s' % (t, fl / t / 1e6))
 t = timed(lambda: K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, grads, None, ws=ws))
-print('backward (dgrad + split-K wgrad%s): %8.1f us  %6.1f TFLOP/s' % (
-    ', tiled' if os.environ.get('SMX_WGRAD_TILED') else '', t, (2 * fl - 2.0 * rows * D * H1) / t / 1e6))
+print('backward layered dgrad + split-K wgrad%s: %8.1f us  %6.1f TFLOP/s' % (
+    ' (tiled)' if os.environ.get('SMX_WGRAD_TILED') else '', t, (2 * fl - 2.0 * rows * D * H1) / t / 1e6))
+npt = K.mlp3_dgrad_rows_ws_floats(net)
+if npt:
+    packT, dx = f(npt), f(rows, D)
+    t = timed(lambda: K.mlp3_backward(net, x, h1, h2, dz3, dz2, dz1, grads, None, ws=ws, packT=packT, dx=dx))
+    print('backward fused dgrad (+ dx) + wgrad    : %8.1f us  %6.1f TFLOP/s' % (t, 2 * fl / t / 1e6))

@@ -967,8 +967,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 inline int pick_splits(int M, int N, int rows) {
-    int wm, wn;
-    if (rows >= SMX_WGRAD_ROWS_MIN && M % 4 == 0 && N % 4 == 0 && smx_wgrad_rows_plan(M, N, &wm, &wn)) {
+    int gw;
+    if (rows >= SMX_WGRAD_ROWS_MIN && M % 4 == 0 && N % 4 == 0 && smx_wgrad_rows_groups(M, N, &gw) > 0) {
         const int s = rows / 128;           // smx_wgrad.hip: one workgroup per CU walks one chunk of >= 128 rows
         return s > 256 ? 256 : s;
     }
@@ -1010,13 +1010,20 @@ extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const f
     static const bool tiled_only = getenv("SMX_WGRAD_TILED") != nullptr;
     if (!tiled_only && smx_wgrad_rows_eligible(dZ, ldz, X, ldx, M, N, rows)) {
         // the whole dW in one workgroup's registers, every operand row read once (smx_wgrad.hip)
+        // (a dW wider than one workgroup's registers -- the LSTM's dW_ih at 376 inputs: 400 x 376 -- goes as column groups,
+        // each a problem of the same launch that re-reads dZ)
         WgradBatch Gd;
-        Gd.n = 1;
+        int gw = N;
+        Gd.n = smx_wgrad_rows_groups(M, N, &gw);
         Gd.stop = nullptr;
-        WgradProb& P = Gd.p[0];
-        P.A = dZ; P.B = X; P.Cpart = part; P.bpart = dbpart;
-        P.M = M; P.N = N; P.lda = ldz; P.ldb = ldx; P.rows = rows;
-        P.splits = G.p[0].splits; P.k_chunk = G.p[0].k_chunk;
+        for (int gi = 0; gi < Gd.n; ++gi) {
+            WgradProb& P = Gd.p[gi];
+            const int c0 = gi * gw;
+            P.A = dZ; P.B = X + c0; P.Cpart = part + c0; P.bpart = gi == 0 ? dbpart : nullptr;
+            P.M = M; P.N = (N - c0 < gw) ? N - c0 : gw; P.lda = ldz; P.ldb = ldx; P.rows = rows;
+            P.ldc = N; P.c_split = (long)M * N; P.b_col0 = c0;
+            P.splits = G.p[0].splits; P.k_chunk = G.p[0].k_chunk;
+        }
         const int rc = smx_wgrad_rows_launch(Gd, smx_s(stream));
         if (rc) return rc;
     } else {
@@ -1270,10 +1277,12 @@ static int mlp3_wgrads_splitk(const smx_mlp3_t* net, const float* x, const float
         float* wpart = wsp;
         float* bpart = wsp + (size_t)S * M * N;
         wsp = bpart + (size_t)S * M;
-        if (!tiled_only && smx_wgrad_rows_eligible(dz[l], M, in[l], N, M, N, R)) {
+        int gw;
+        if (!tiled_only && smx_wgrad_rows_eligible(dz[l], M, in[l], N, M, N, R) && smx_wgrad_rows_groups(M, N, &gw) == 1) {
             WgradProb& P = Gd.p[Gd.n++];
             P.A = dz[l]; P.B = in[l]; P.Cpart = wpart; P.bpart = bpart;
             P.M = M; P.N = N; P.lda = M; P.ldb = N; P.rows = R;
+            P.ldc = N; P.c_split = (long)M * N; P.b_col0 = 0;
             P.splits = S; P.k_chunk = k_chunk;
         } else {
             const bool wide = M >= 48 && N >= 64 && M % 4 == 0 && N % 4 == 0;

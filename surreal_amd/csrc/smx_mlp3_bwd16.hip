@@ -110,6 +110,121 @@ __device__ __forceinline__ void product_from_registers(const f32x4 (&in)[KT], f3
 #undef B16_ROW_OK
 }
 
+// The same product on the forward kernel's schedule (smx_mlp3_rows16.hip, layer 2): the eight wavefronts leave every barrier
+// together, so "read all fragments, then all MFMAs" keeps them in lock-step -- LDS busy, matrix pipes idle, then the
+// reverse.  The output tiles are split in two halves; while the MFMAs of one half issue, the fragments of the next half are
+// on their way (in thirds, between the four k-step groups), the LDS stores of the next chunk sit between k-step groups too,
+// and the one barrier per chunk comes after the last fragment read of the current buffer, so the first fragments of the next
+// chunk are fetched under the chunk's last half-phase.  sched_barriers pin that order.
+template <int KT, int OT>
+__device__ __forceinline__ void product_interleaved(const f32x4 (&in)[KT], f32x4 (&out)[OT], const float* __restrict__ Wp,
+                                                    float* Wb0, float* Wb1, const Chunk& first) {
+    constexpr int PK = (KT + 1) / 2, PO = (OT + 1) / 2;
+    constexpr int NW = (PO * 32 + 63) / 64;
+    static_assert(NW <= 5, "staging registers are written out for <= 5 passes");
+    constexpr int UA = (OT + 1) / 2, UB = OT - UA;
+    constexpr int C1 = UA / 3, C2 = (2 * UA) / 3, D1 = UB / 3, D2 = (2 * UB) / 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int fm = lane & 15, g = lane >> 4;
+    const int srow = tid >> 3, sk8 = tid & 7, sk4 = sk8 * 4;
+    const int woff = fm * LDW + 4 * g;
+    float4 v0 = first.v0, v1 = first.v1, v2 = first.v2, v3 = first.v3, v4 = first.v4;
+    float4 ga[UA], gb[UB > 0 ? UB : 1];
+#define I16_OK(i) ((i) < NW && (srow + 64 * (i) < PO * 32 || (PO * 32) % 64 == 0))
+#define I16_LD(c)                                                                                              \
+    do {                                                                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(Wp + (size_t)(c) * PO * 1024);                   \
+        if (I16_OK(0)) v0 = src_[(srow + 0) * 8 + sk8];                                                        \
+        if (I16_OK(1)) v1 = src_[(srow + 64) * 8 + sk8];                                                       \
+        if (I16_OK(2)) v2 = src_[(srow + 128) * 8 + sk8];                                                      \
+        if (I16_OK(3)) v3 = src_[(srow + 192) * 8 + sk8];                                                      \
+        if (I16_OK(4)) v4 = src_[(srow + 256) * 8 + sk8];                                                      \
+    } while (0)
+#define I16_ST(dst, i, v) do { if (I16_OK(i)) *reinterpret_cast<float4*>((dst) + (srow + 64 * (i)) * LDW + sk4) = (v); } while (0)
+#define I16_RD_A(wrow, h, i0, i1)                                                 \
+    _Pragma("unroll") for (int u = (i0); u < (i1); ++u)                           \
+        ga[u] = *reinterpret_cast<const float4*>((wrow) + u * 16 * LDW + 16 * (h));
+#define I16_RD_B(wrow, h, i0, i1)                                                 \
+    _Pragma("unroll") for (int u = (i0); u < (i1); ++u)                           \
+        gb[u] = *reinterpret_cast<const float4*>((wrow) + (UA + u) * 16 * LDW + 16 * (h));
+#define I16_STEP_A(e, r)                                                          \
+    _Pragma("unroll") for (int u = 0; u < UA; ++u) out[u] = MFMA16(ga[u].e, bq[r], out[u]);
+#define I16_STEP_B(e, r)                                                          \
+    _Pragma("unroll") for (int u = 0; u < UB; ++u) out[UA + u] = MFMA16(gb[u].e, bq[r], out[UA + u]);
+#define I16_PIN __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int t = 0; t < OT; ++t) out[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                    // (the previous product's last fragment reads of Wb0 are done)
+    I16_ST(Wb0, 0, v0); I16_ST(Wb0, 1, v1); I16_ST(Wb0, 2, v2); I16_ST(Wb0, 3, v3); I16_ST(Wb0, 4, v4);
+    if (PK > 1) I16_LD(1);
+    __syncthreads();
+    I16_RD_A(Wb0 + woff, 0, 0, UA)
+#pragma unroll
+    for (int p = 0; p < PK; ++p) {
+        const float* Wc = (p & 1) ? Wb1 : Wb0;
+        float* Wn = (p & 1) ? Wb0 : Wb1;
+        const bool lastp = (p + 1 == PK);
+        const bool odd_tail = (2 * p + 1 >= KT);            // compile-time after unrolling: tile 2 p + 1 does not exist
+        I16_PIN;
+        {
+            const f32x4 bq = in[2 * p];
+            I16_STEP_A(x, 0) I16_PIN; I16_RD_B(Wc + woff, 0, 0, D1) I16_PIN;
+            I16_STEP_A(y, 1) I16_PIN; I16_RD_B(Wc + woff, 0, D1, D2) I16_PIN;
+            I16_STEP_A(z, 2) I16_PIN; I16_RD_B(Wc + woff, 0, D2, UB) I16_PIN;
+            I16_STEP_A(w, 3) I16_PIN;
+        }
+        {
+            const f32x4 bq = in[2 * p];
+            I16_STEP_B(x, 0) I16_PIN;
+            if (!odd_tail) { I16_RD_A(Wc + woff, 1, 0, C1) }
+            if (!lastp) { I16_ST(Wn, 0, v0); I16_ST(Wn, 1, v1); }
+            I16_PIN;
+            I16_STEP_B(y, 1) I16_PIN;
+            if (!odd_tail) { I16_RD_A(Wc + woff, 1, C1, C2) }
+            if (!lastp) { I16_ST(Wn, 2, v2); I16_ST(Wn, 3, v3); }
+            I16_PIN;
+            I16_STEP_B(z, 2) I16_PIN;
+            if (!odd_tail) { I16_RD_A(Wc + woff, 1, C2, UA) }
+            if (!lastp) { I16_ST(Wn, 4, v4); }
+            I16_PIN;
+            I16_STEP_B(w, 3) I16_PIN;
+        }
+        if (!odd_tail) {
+            const f32x4 bq = in[2 * p + 1 < KT ? 2 * p + 1 : 0];
+            I16_STEP_A(x, 0) I16_PIN; I16_RD_B(Wc + woff, 1, 0, D1) I16_PIN;
+            I16_STEP_A(y, 1) I16_PIN; I16_RD_B(Wc + woff, 1, D1, D2) I16_PIN;
+            I16_STEP_A(z, 2) I16_PIN; I16_RD_B(Wc + woff, 1, D2, UB) I16_PIN;
+            I16_STEP_A(w, 3) I16_PIN;
+        }
+        if (!lastp) __syncthreads();
+        if (!odd_tail) {
+            const f32x4 bq = in[2 * p + 1 < KT ? 2 * p + 1 : 0];
+            I16_STEP_B(x, 0) I16_PIN;
+            if (!lastp) { I16_RD_A(Wn + woff, 0, 0, C1) }
+            if (p + 2 < PK) I16_LD(p + 2);
+            I16_PIN;
+            I16_STEP_B(y, 1) I16_PIN;
+            if (!lastp) { I16_RD_A(Wn + woff, 0, C1, C2) }
+            I16_PIN;
+            I16_STEP_B(z, 2) I16_PIN;
+            if (!lastp) { I16_RD_A(Wn + woff, 0, C2, UA) }
+            I16_PIN;
+            I16_STEP_B(w, 3) I16_PIN;
+        } else if (!lastp) {
+            I16_RD_A(Wn + woff, 0, 0, UA)
+            if (p + 2 < PK) I16_LD(p + 2);
+        }
+    }
+#undef I16_OK
+#undef I16_LD
+#undef I16_ST
+#undef I16_RD_A
+#undef I16_RD_B
+#undef I16_STEP_A
+#undef I16_STEP_B
+#undef I16_PIN
+}
+
 // out[t][r] *= (act[row, 16 t + 4 g + r] > 0), then the tile goes to dst[row, 16 t + 4 g ..] (16-byte stores)
 template <int OT>
 __device__ __forceinline__ void mask_and_store(f32x4 (&acc)[OT], const float* __restrict__ act, float* __restrict__ dst,
@@ -207,7 +322,11 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_bwd16_kernel(Bwd16Args A) {
 
     // ======================= dz1^T = W2^T . dz2^T ==============================================================
     f32x4 acc1[NT1];
+#ifdef SMX_BWD16_SIMPLE                 // (A/B switch: the plain chunk loop)
     product_from_registers<NT2, NT1>(acc2, acc1, A.pt2, Wb0, Wb1, ck);
+#else
+    product_interleaved<NT2, NT1>(acc2, acc1, A.pt2, Wb0, Wb1, ck);
+#endif
 #ifndef SMX_BWD16_NOHOIST
     if (A.dx) first_chunk<NTD>(ck, A.pt1);
 #endif
@@ -219,7 +338,11 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_bwd16_kernel(Bwd16Args A) {
     // ======================= dx^T = W1^T . dz1^T ================================================================
     if (A.dx) {
         f32x4 accx[NTD];
+#ifdef SMX_BWD16_SIMPLE
         product_from_registers<NT1, NTD>(acc1, accx, A.pt1, Wb0, Wb1, ck);
+#else
+        product_interleaved<NT1, NTD>(acc1, accx, A.pt1, Wb0, Wb1, ck);
+#endif
         mask_and_store<NTD>(accx, nullptr, A.dx, myrow, row_ok, A.D, g);
     }
 }

@@ -74,7 +74,7 @@ __device__ __attribute__((noinline)) void wgrad_wave(const WgradProb& P, const i
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kq = lane >> 4;
     const rsrc_t rA = make_rsrc(P.A, (unsigned)P.rows * (unsigned)P.lda * 4u);
-    const rsrc_t rB = make_rsrc(P.B, (unsigned)P.rows * (unsigned)P.ldb * 4u);
+    const rsrc_t rB = make_rsrc(P.B, ((unsigned)P.rows * (unsigned)P.ldb - (unsigned)P.b_col0) * 4u);
     // byte offsets of this lane's words in row kq of a step; OOB when the lane's first column is past the matrix
     const unsigned a0 = (m0 + MA * i < P.M) ? ((unsigned)kq * P.lda + m0 + MA * i) * 4u : OOB;
     const unsigned a1 = (MB > 0 && m0 + 16 * MA + MB * i < P.M) ? ((unsigned)kq * P.lda + m0 + 16 * MA + MB * i) * 4u : OOB;
@@ -150,7 +150,7 @@ __device__ __attribute__((noinline)) void wgrad_wave(const WgradProb& P, const i
         for (int r = 0; r < 4; ++r) {
             const int m = (jm < MA) ? m0 + MA * (4 * kq + r) + jm : m0 + 16 * MA + MB * (4 * kq + r) + (jm - MA);
             if (m < P.M) {
-                float* row = C + (size_t)m * P.N;
+                float* row = C + (size_t)m * P.ldc;
                 const int c0 = n0 + NA * i, c1 = n0 + 16 * NA + NB * i;
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_rows_kernel(WgradBatch G) {
     cut((P.N + 15) >> 4, P.wn, wj, fn, cn);
     const int r_lo = s * P.k_chunk;
     const int r_hi = (r_lo + P.k_chunk < P.rows) ? r_lo + P.k_chunk : P.rows;
-    P.Cpart += (size_t)s * P.M * P.N;
+    P.Cpart += (size_t)s * P.c_split;
     if (P.bpart) P.bpart += (size_t)s * P.M;
     const bool bias = wj == 0 && P.bpart != nullptr;
     const int m0 = 16 * fm, n0 = 16 * fn;
@@ -237,11 +237,23 @@ bool smx_wgrad_rows_plan(int M, int N, int* wm, int* wn) {
     return true;
 }
 
-bool smx_wgrad_rows_eligible(const float* A, int lda, const float* B, int ldb, int M, int N, long rows) {
+int smx_wgrad_rows_groups(int M, int N, int* width) {
     int wm, wn;
+    if (smx_wgrad_rows_plan(M, N, &wm, &wn)) { *width = N; return 1; }
+    for (int g = 2; g <= WGRAD_MAX_PROBS; ++g) {
+        const int w = (((N + g - 1) / g) + 15) & ~15;          // whole 16-column tiles per group
+        const int last = N - (g - 1) * w;
+        if (last <= 0) continue;
+        if (smx_wgrad_rows_plan(M, w, &wm, &wn) && smx_wgrad_rows_plan(M, last, &wm, &wn)) { *width = w; return g; }
+    }
+    return 0;
+}
+
+bool smx_wgrad_rows_eligible(const float* A, int lda, const float* B, int ldb, int M, int N, long rows) {
+    int width;
     return rows >= SMX_WGRAD_ROWS_MIN && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
            ((((uintptr_t)A | (uintptr_t)B) & 15) == 0) && rows * (long)lda * 4 < (1l << 31) &&
-           rows * (long)ldb * 4 < (1l << 31) && smx_wgrad_rows_plan(M, N, &wm, &wn);
+           rows * (long)ldb * 4 < (1l << 31) && smx_wgrad_rows_groups(M, N, &width) > 0;
 }
 
 int smx_wgrad_rows_launch(WgradBatch& G, hipStream_t st) {

@@ -1160,7 +1160,10 @@ def test_clip_adam_pair_equals_two_launches(K):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('M,N,rows', [(400, 17, 7936), (400, 100, 31744), (16, 192, 102400), (33, 70, 5000), (8, 8, 900)])
+@pytest.mark.parametrize('M,N,rows', [(400, 17, 7936), (400, 100, 31744), (16, 192, 102400), (33, 70, 5000), (8, 8, 900),
+                                      (400, 100, 126976),     # the register-resident kernel (smx_wgrad.hip), one column group
+                                      (400, 376, 40000),      # ... three column groups (128 + 128 + 120)
+                                      (300, 288, 33000), (64, 48, 32768 + 7)])
 def test_linear_wgrad_splitk_matches_fp64(K, M, N, rows):
     """weight gradients over many rows (LSTM: B*T, CNN: B*E*pixels): split-K partial tiles added in
     a fixed order; compared with an fp64 reference (both the split and the plain kernel are fp32
