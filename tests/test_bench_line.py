@@ -76,3 +76,43 @@ def test_last_4k_of_stdout_parses(tmp_path):
     assert d['value'] > 0 and d['roofline']['frac'] > 0 and d['cpu_baseline']['value'] > 0
     rec = json.load(open(full))                    # the side file holds everything the line dropped
     assert 'secondary' in rec and len(json.dumps(rec)) > 20000
+
+
+def test_reference_and_port_cpu_legs_agree(monkeypatch):
+    """bench.py's two CPU baselines on a small shape: the REFERENCE'S OWN learner (oracle/_ref or /root/reference under the
+    shims; `kind: reference`) and the restatement (`kind: port`) are the same arithmetic -- cpu_ppo times both, and the
+    statistics of one learn agree bit for bit (skipped where neither the reference tree nor its byte-compiled copy exists)"""
+    import copy
+    import numpy as np
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ref_shims
+    if not ref_shims.reference_available():
+        pytest.skip('no reference tree and no oracle/_ref on this host')
+    import gen_golden as G
+    import ppo_oracle
+    from surreal_amd import synthetic
+    Bs, Ns, Ds, As = 6, 12, 9, 3
+    for rnn in (False, True):
+        F = 12 if rnn else 0
+        batch = synthetic.make_ppo_batch(Bs, Ns, Ds, As, seed=3, rnn_hidden=F)
+        params = synthetic.make_ppo_params(Ds, As, hidden=(24, 16), seed=1, rnn_hidden=F)
+        hyper = dict(n_step=Ns, kl_target=1e9, ppo_mode='adapt')
+        if rnn:
+            hyper.update(if_rnn_policy=True, horizon=4)
+        ref = ref_shims.import_reference()
+        Lr = G.build_reference_learner(ref, params, None, Bs, Ns, Ds, As, hyper)
+        bd = ref_shims.BeneDict(copy.deepcopy(batch))
+        bd = Lr._preprocess_batch_ppo(bd)
+        rs = Lr._optimize(bd.obs, bd.actions, bd.rewards, bd.obs_next, bd.persistent_infos, bd.onetime_infos, bd.dones)
+        O = ppo_oracle.OraclePPOLearner(params, As, Bs, **hyper)
+        os_ = O.learn(copy.deepcopy(batch))
+        for k, v in os_.items():
+            if k != '_lr':
+                assert float(rs[k]) == float(v) or (np.isnan(float(rs[k])) and np.isnan(float(v))), (rnn, k, rs[k], v)
+        # the timing leg itself: both kinds reported, the quoted value is the faster one
+        monkeypatch.setattr(bench, '_CPU_THREADS', [2])
+        out = bench.cpu_ppo(Bs, Ns, Ds, As, rnn, None, params, batch, budget_s=4.0)
+        assert out['port']['value'] > 0 and out['reference']['value'] > 0
+        assert out['value'] == max(out['port']['value'], out['reference']['value'])
+        assert out['kind'] == ('reference' if out['reference']['value'] >= out['port']['value'] else 'port')
