@@ -780,6 +780,20 @@ int smx_ddpg_critic_loss_f32(const float* q, const float* q_next_target, const f
 int smx_tanh_backward_f32(const float* da, const float* a, int64_t n, float* out,
                           smx_stream_t stream);
 int smx_fill_f32(float* x, int64_t n, float value, smx_stream_t stream);
+/* LayerNorm over the last dimension, forward and backward (DDPG use_layernorm = True: L.LayerNorm(1) behind every hidden
+ * ReLU of ActorNetworkX / CriticNetworkX, model_builders/builders.py:42-48, 65-75; taken as torch.nn.LayerNorm(F):
+ * biased variance, eps inside the root, elementwise affine -- torchx's source is not in the reference tree).
+ *   forward : y[r, :] = (x[r, :] - mean_r) * rstd_r * gamma + beta; mean / rstd [rows] saved for the backward (may be NULL)
+ *   backward: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; relu_mask != 0: dx *= (x > 0) (x is the output
+ *             of the ReLU in front of the LayerNorm: dx is then the gradient at that ReLU's input);
+ *             dgamma[j] = sum_r dy xhat, dbeta[j] = sum_r dy (overwritten; summed in a fixed order through ws,
+ *             smx_layernorm_backward_ws_floats(rows, F) floats).  F <= 1024. */
+int smx_layernorm_forward_f32(const float* x, int64_t ldx, int64_t rows, int32_t F, const float* gamma, const float* beta,
+                              float eps, float* y, int64_t ldy, float* mean, float* rstd, smx_stream_t stream);
+int64_t smx_layernorm_backward_ws_floats(int64_t rows, int32_t F);
+int smx_layernorm_backward_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                               const float* rstd, const float* gamma, int64_t rows, int32_t F, int32_t relu_mask, float* dx,
+                               int64_t lddx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, smx_stream_t stream);
 /* torch.optim.Adam step with optional clip_grad_value_ (Module.clip_grad_value, ddpg.py:309,332);
  * step = 1-based Adam step count; clip_value <= 0 disables clipping. */
 int smx_adam_step_f32(float* theta, const float* grads, float* exp_avg, float* exp_avg_sq,

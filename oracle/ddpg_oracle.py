@@ -1,7 +1,8 @@
 """
 TEST INFRASTRUCTURE ONLY.  CPU restatement (PyTorch fp32) of the reference's DDPG update
 (surreal/learner/ddpg.py:244-352, 403-428; surreal/model/ddpg_net.py:13-95;
-model_builders/builders.py:35-84 with use_layernorm=False), low-dimensional observations,
+model_builders/builders.py:35-84; use_layernorm when the parameters carry actor.ln* / critic.ln*: torchx's L.LayerNorm(1)
+taken as torch.nn.LayerNorm over the features, as oracle/ref_shims.py does), low-dimensional observations,
 single critic, no TD3 action regularisation (the reference defaults, ddpg_configs.py:16-98).
 oracle/gen_golden_ddpg.py pins it bit-for-bit against the reference's own DDPGLearner.
 
@@ -16,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def make_ddpg_params(D, A, actor_hidden=(300, 200), critic_hidden=(400, 300), seed=3):
+def make_ddpg_params(D, A, actor_hidden=(300, 200), critic_hidden=(400, 300), seed=3, layernorm=False):
     rs = np.random.RandomState(seed)
     p = collections.OrderedDict()
 
@@ -30,6 +31,11 @@ def make_ddpg_params(D, A, actor_hidden=(300, 200), critic_hidden=(400, 300), se
     lin('critic.fc1', critic_hidden[0], D)
     lin('critic.fc2', critic_hidden[1], critic_hidden[0] + A)
     lin('critic.fc3', 1, critic_hidden[1])
+    if layernorm:       # affine parameters away from their (1, 0) initial values, so that a test notices them
+        for net, hs in (('actor', actor_hidden), ('critic', critic_hidden)):
+            for i, h in enumerate(hs):
+                p['%s.ln%d.W' % (net, i + 1)] = (1.0 + 0.2 * rs.randn(h)).astype(np.float32)
+                p['%s.ln%d.b' % (net, i + 1)] = (0.1 * rs.randn(h)).astype(np.float32)
     return p
 
 
@@ -88,15 +94,20 @@ class OracleDDPGModel(object):
 
     def forward_actor(self, x):                       # builders.py:35-56
         p = self.p
-        h = torch.relu(F.linear(x, p['actor.fc1.W'], p['actor.fc1.b']))
-        h = torch.relu(F.linear(h, p['actor.fc2.W'], p['actor.fc2.b']))
+        h = self._ln('actor.ln1', torch.relu(F.linear(x, p['actor.fc1.W'], p['actor.fc1.b'])))
+        h = self._ln('actor.ln2', torch.relu(F.linear(h, p['actor.fc2.W'], p['actor.fc2.b'])))
         return torch.tanh(F.linear(h, p['actor.fc3.W'], p['actor.fc3.b']))
+
+    def _ln(self, name, h):                           # builders.py:42-48, 65-75 (use_layernorm)
+        if name + '.W' not in self.p:
+            return h
+        return F.layer_norm(h, (h.shape[1],), self.p[name + '.W'], self.p[name + '.b'], 1e-5)
 
     def forward_critic(self, x, a):                   # builders.py:58-84
         p = self.p
-        h = torch.relu(F.linear(x, p['critic.fc1.W'], p['critic.fc1.b']))
+        h = self._ln('critic.ln1', torch.relu(F.linear(x, p['critic.fc1.W'], p['critic.fc1.b'])))
         h = torch.cat((h, a), 1)
-        h = torch.relu(F.linear(h, p['critic.fc2.W'], p['critic.fc2.b']))
+        h = self._ln('critic.ln2', torch.relu(F.linear(h, p['critic.fc2.W'], p['critic.fc2.b'])))
         return F.linear(h, p['critic.fc3.W'], p['critic.fc3.b'])
 
     def load_from(self, other, tau=None):

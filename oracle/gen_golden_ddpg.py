@@ -27,6 +27,19 @@ def lin_layers(net_functional):
     return [l for l in net_functional.layers if hasattr(l, 'fc')]
 
 
+def ln_layers(net_functional):
+    """the L.LayerNorm(1) layers (ref_shims.LayerNorm: torch.nn.LayerNorm over the last dimension) in network order"""
+    return [l for l in net_functional.layers if hasattr(l, 'ln')]
+
+
+def _ln_sets(m):
+    out = []
+    if m.actor is not None:
+        out += [('actor.ln%d' % (i + 1), l) for i, l in enumerate(ln_layers(m.actor.model))]
+    out += [('critic.ln%d' % (i + 1), l) for i, l in enumerate(ln_layers(m.critic.model_obs) + ln_layers(m.critic.model_concat))]
+    return out
+
+
 def _perception_layers(m):
     ls = [l for l in m.perception.model.layers if hasattr(l, 'conv') or hasattr(l, 'fc')]
     return collections.OrderedDict(zip(('conv1', 'conv2', 'fc'), ls))
@@ -46,6 +59,9 @@ def inject(m, params):
         for i, l in enumerate(c):
             l.fc.weight.copy_(torch.tensor(params['critic.fc%d.W' % (i + 1)]))
             l.fc.bias.copy_(torch.tensor(params['critic.fc%d.b' % (i + 1)]))
+        for name, l in _ln_sets(m):
+            l.ln.weight.copy_(torch.tensor(params[name + '.W']))
+            l.ln.bias.copy_(torch.tensor(params[name + '.b']))
 
 
 def extract_perception(m):
@@ -66,6 +82,9 @@ def extract(m):
     for i, l in enumerate(lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)):
         out['critic.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
         out['critic.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    for name, l in _ln_sets(m):
+        out[name + '.W'] = l.ln.weight.detach().numpy().copy()
+        out[name + '.b'] = l.ln.bias.detach().numpy().copy()
     out.update(extract_perception(m))
     return out
 
@@ -102,7 +121,7 @@ def build_ref(params, D, A, ah, ch, hyper, params2=None, pixel=None, conv_hidden
     if pixel is not None:                                   # ddpg_net.py:37-44: the CNN perception
         obs_spec['pixel'] = collections.OrderedDict(camera0=list(pixel))
     obs_spec['low_dim'] = collections.OrderedDict(flat_inputs=[D])
-    mk = lambda **kw: DDPGModel(obs_spec=obs_spec, action_dim=A, use_layernorm=False,  # noqa: E731
+    mk = lambda **kw: DDPGModel(obs_spec=obs_spec, action_dim=A, use_layernorm=bool(hyper.get('layernorm', False)),  # noqa: E731
                                 actor_fc_hidden_sizes=list(ah), critic_fc_hidden_sizes=list(ch),
                                 conv_out_channels=[16, 32], conv_kernel_sizes=[8, 4], conv_strides=[4, 2],
                                 conv_hidden_dim=conv_hidden, **kw)
@@ -147,21 +166,32 @@ CASES = {
                                 hyper=dict(gamma=0.95, n_step=2, lr_actor=1e-3, lr_critic=1e-2, double_critic=True,
                                            action_reg=True, target_update_type='soft', target_update_interval=1,
                                            tau=0.1, clip_critic=True)),
+    # use_layernorm = True (reference default: off): a LayerNorm behind every hidden ReLU of both networks
+    'tiny_ln_hard': dict(B=16, D=5, A=2, ah=(24, 16), ch=(32, 24), iters=4,
+                         hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-3, lr_critic=1e-2, layernorm=True,
+                                    target_update_type='hard', target_update_interval=2)),
+    'ln_soft_clipcritic': dict(B=37, D=9, A=3, ah=(72, 40), ch=(80, 72), iters=3,
+                               hyper=dict(gamma=0.9, n_step=1, lr_actor=1e-3, lr_critic=1e-2, layernorm=True,
+                                          target_update_type='soft', target_update_interval=1,
+                                          tau=0.05, clip_critic=True)),
     'cfg3_cheetah512': dict(B=512, D=17, A=6, ah=(300, 200), ch=(400, 300), iters=3,
                             hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-4, lr_critic=1e-3,
                                        target_update_type='hard', target_update_interval=500)),
 }
 
 
-def main():
+def main(only=None):
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         hyper = dict(c['hyper'], B=c['B'])
         pixel = tuple(c['pixel']) if c.get('pixel') else None
         if pixel is not None:
             mkp = lambda seed: ddpg_oracle.make_ddpg_pixel_params(  # noqa: E731
                 c['D'], c['A'], pixel, c['conv_hidden'], c['ah'], c['ch'], seed=seed)
         else:
-            mkp = lambda seed: ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=seed)  # noqa: E731
+            mkp = lambda seed: ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=seed,  # noqa: E731
+                                                            layernorm=bool(hyper.get('layernorm', False)))
         params, params2 = mkp(3), mkp(4)
         Lr = build_ref(params, c['D'], c['A'], c['ah'], c['ch'], hyper, params2, pixel=pixel,
                        conv_hidden=c.get('conv_hidden', 200))
@@ -226,4 +256,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1:] or None)

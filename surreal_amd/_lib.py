@@ -191,6 +191,10 @@ _SIGS = {
     'smx_epoch_fwdbwd_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_fwdbwd_f32': (c_int32, [POINTER(EpochJob), c_int32, POINTER(PpoLosses), _P, c_int64, _P, _P, _P]),
     'smx_device_occupy': (c_int32, [c_int32, c_int64, _P]),
+    'smx_layernorm_forward_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_float, _P, c_int64, _P, _P, _P]),
+    'smx_layernorm_backward_ws_floats': (c_int64, [c_int64, c_int32]),
+    'smx_layernorm_backward_f32': (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P,
+                                             _P, c_int64, _P]),
     'smx_zfilter_update_ws_floats': (c_int64, [c_int64, c_int32]),
     'smx_zfilter_update_ws_f32': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_float, _P, c_int64, _P]),
     'smx_ppo_partials_fold_f32': (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P, _P]),

@@ -155,6 +155,124 @@ __global__ __launch_bounds__(1024) void ddpg_stats_kernel(
 
 inline unsigned nb(long n) { return (unsigned)((n + 255) / 256); }
 
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension (DDPG's use_layernorm = True: L.LayerNorm(1) behind every hidden ReLU of
+// ActorNetworkX / CriticNetworkX, surreal/model/model_builders/builders.py:42-48, 65-75; torchx's layer is taken as
+// torch.nn.LayerNorm(F): biased variance, eps inside the square root, elementwise affine -- its source is not in the
+// reference tree).  One wavefront per row, two passes over the row in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXC = 16;      // columns per lane: F <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, long rows, int F,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, float* __restrict__ y, long ldy,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + r * ldx;
+    float v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int j = lane + 64 * c;
+        v[c] = (j < F) ? xr[j] : 0.f;
+        s += v[c];
+    }
+    const float m = smx_wave_sum(s) / (float)F;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int j = lane + 64 * c;
+        const float d = (j < F) ? v[c] - m : 0.f;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(smx_wave_sum(q) / (float)F + eps);
+    float* yr = y + r * ldy;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int j = lane + 64 * c;
+        if (j < F) yr[j] = ((v[c] - m) * rs) * gamma[j] + beta[j];
+    }
+    if (lane == 0) {
+        if (mean) mean[r] = m;
+        if (rstd) rstd[r] = rs;
+    }
+}
+
+// dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma, xhat = (x - mean) rstd; optionally times (x > 0): x is the
+// output of the ReLU in front of the LayerNorm, so the product is the gradient at the ReLU's input.  Parameter gradients:
+// every block leaves the column sums of dy xhat and dy over ITS 16 rows in part[blk][2][F]; layernorm_pgrad_kernel adds
+// the blocks in order (deterministic).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                            long ldx, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            long rows, int F, int relu_mask, float* __restrict__ dx, long lddx,
+                                                            float* __restrict__ part) {
+    __shared__ float red[4][2][64 * LN_MAXC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float ag[LN_MAXC], ab[LN_MAXC];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) { ag[c] = 0.f; ab[c] = 0.f; }
+    for (int k = 0; k < 4; ++k) {
+        const long r = (long)blockIdx.x * 16 + 4 * k + wv;           // (wave-uniform)
+        if (r >= rows) break;
+        const float m = mean[r], rs = rstd[r];
+        const float* xr = x + r * ldx;
+        const float* dr = dy + r * lddy;
+        float xv[LN_MAXC], g[LN_MAXC], xh[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            const bool in = j < F;
+            xv[c] = in ? xr[j] : 0.f;
+            const float d = in ? dr[j] : 0.f;
+            xh[c] = in ? (xv[c] - m) * rs : 0.f;
+            g[c] = in ? d * gamma[j] : 0.f;
+            s1 += g[c];
+            s2 += g[c] * xh[c];
+            ag[c] += d * xh[c];
+            ab[c] += d;
+        }
+        const float m1 = smx_wave_sum(s1) / (float)F, m2 = smx_wave_sum(s2) / (float)F;
+        float* o = dx + r * lddx;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int j = lane + 64 * c;
+            if (j < F) {
+                float v = rs * ((g[c] - m1) - xh[c] * m2);
+                if (relu_mask) v = (xv[c] > 0.f) ? v : 0.f;
+                o[j] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        red[wv][0][lane + 64 * c] = ag[c];
+        red[wv][1][lane + 64 * c] = ab[c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < F; j += 256) {
+        part[((size_t)blockIdx.x * 2 + 0) * F + j] = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+        part[((size_t)blockIdx.x * 2 + 1) * F + j] = ((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_pgrad_kernel(const float* __restrict__ part, int nblk, int F,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < F; j += gridDim.x * 256) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < nblk; ++k) {
+            a += part[((size_t)k * 2 + 0) * F + j];
+            b += part[((size_t)k * 2 + 1) * F + j];
+        }
+        dgamma[j] = a;
+        dbeta[j] = b;
+    }
+}
+
 }  // namespace
 
 extern "C" int smx_ddpg_critic_loss_f32(const float* q, const float* q_next_target,
@@ -252,6 +370,39 @@ extern "C" int smx_ddpg_stats_f32(const float* q, const float* y, const float* r
     SMX_REQUIRE(rows > 0 && A > 0 && ld_act >= A, SMX_E_SHAPE);
     hipLaunchKernelGGL(ddpg_stats_kernel, dim3(1), dim3(1024), 0, smx_s(stream), q, y, rewards, actions,
                        ld_act, A, q_actor, (long)rows, stats);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_layernorm_forward_f32(const float* x, int64_t ldx, int64_t rows, int32_t F, const float* gamma,
+                                         const float* beta, float eps, float* y, int64_t ldy, float* mean, float* rstd,
+                                         smx_stream_t stream) {
+    SMX_REQUIRE(x && gamma && beta && y, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && F > 0 && ldx >= F && ldy >= F, SMX_E_SHAPE);
+    SMX_REQUIRE(F <= 64 * LN_MAXC, SMX_E_UNSUPPORTED);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, smx_s(stream), x, (long)ldx,
+                       (long)rows, F, gamma, beta, eps, y, (long)ldy, mean, rstd);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int64_t smx_layernorm_backward_ws_floats(int64_t rows, int32_t F) {
+    return rows > 0 && F > 0 ? 2 * ((rows + 15) / 16) * (int64_t)F : 0;
+}
+
+extern "C" int smx_layernorm_backward_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                          const float* rstd, const float* gamma, int64_t rows, int32_t F, int32_t relu_mask,
+                                          float* dx, int64_t lddx, float* dgamma, float* dbeta, float* ws, int64_t ws_floats,
+                                          smx_stream_t stream) {
+    SMX_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, SMX_E_NULL);
+    SMX_REQUIRE(rows > 0 && F > 0 && lddy >= F && ldx >= F && lddx >= F, SMX_E_SHAPE);
+    SMX_REQUIRE(F <= 64 * LN_MAXC, SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(ws_floats >= smx_layernorm_backward_ws_floats(rows, F), SMX_E_WORKSPACE);
+    const int nblk = (int)((rows + 15) / 16);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, smx_s(stream), dy, (long)lddy, x, (long)ldx, mean,
+                       rstd, gamma, (long)rows, F, relu_mask, dx, (long)lddx, ws);
+    hipLaunchKernelGGL(layernorm_pgrad_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, smx_s(stream), ws, nblk, F,
+                       dgamma, dbeta);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

@@ -304,6 +304,22 @@ class HipKernels(object):
         L.call('smx_epoch_fwdbwd_f32', self._epoch_jobs(jobs), len(jobs), self._epoch_loss(loss),
                L.ptr(ctrl), int(n_total), L.ptr(sync_word), L.ptr(kl_slots), self._st())
 
+    def layernorm_forward(self, x, gamma, beta, eps, y, mean=None, rstd=None):
+        """y = LayerNorm(x) over the last dimension (rows of x / y may be strided); mean / rstd [rows] for the backward"""
+        rows, F = x.shape
+        L.call('smx_layernorm_forward_f32', L.ptr(x), x.stride(0), rows, F, L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(y),
+               y.stride(0), L.ptr(mean), L.ptr(rstd), self._st())
+
+    def layernorm_backward_ws_floats(self, rows, F):
+        return int(self.lib.smx_layernorm_backward_ws_floats(int(rows), int(F)))
+
+    def layernorm_backward(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, relu_mask=False):
+        """dx (optionally times x > 0: x is a ReLU's output) and the affine parameters' gradients (overwritten)"""
+        rows, F = x.shape
+        L.call('smx_layernorm_backward_f32', L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(mean), L.ptr(rstd),
+               L.ptr(gamma), rows, F, int(bool(relu_mask)), L.ptr(dx), dx.stride(0), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws),
+               ws.numel(), self._st())
+
     def device_occupy(self, blocks, microseconds):
         """a co-tenant on the current stream: `blocks` workgroups that each hold one CU for `microseconds` (smx_device_occupy)"""
         L.call('smx_device_occupy', int(blocks), int(microseconds), self._st())

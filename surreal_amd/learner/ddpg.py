@@ -23,7 +23,8 @@ kernels) runs on camera0 / 255, its features go in front of the low-dim vector, 
 the critic loss (Adam with the critic's hyper-parameters) and follows the target updates; the actor
 update reuses the features formed before the critic step, as the reference does.
 
-Not built: LayerNorm (torchx's LayerNorm semantics are unpinned); it raises.
+use_layernorm (default off) is built for low-dimensional observations with one critic (_enqueue_iteration_ln); torchx's
+LayerNorm semantics are unpinned (its source is absent): taken as torch.nn.LayerNorm over the features.
 """
 import gc
 import types
@@ -204,6 +205,19 @@ class DDPGLearner(Learner):
                 ws.cnn_t2 = CnnStem.workspace(cnn, B, self.device, backward=False)
                 ws.grads_p2 = torch.zeros_like(m.perception_flat)
             ws.s_pix = ws.s_pix_next = None              # staged frames (allocated in their dtype)
+        if self.use_layernorm:
+            if self.use_double_critic or self.is_pixel_input:
+                raise NotImplementedError('use_layernorm=True is built for low-dimensional observations with one critic')
+            ws.ln, ws.ln_t = m.ln_workspace(B, self.device), self.model_target.ln_workspace(B, self.device)
+            ws.dn2, ws.dz1c = f(B, c2), f(B, c1)
+            ws.dn2a, ws.dn1a = f(B, a.H2), f(B, a.H1)
+            ws.ln_ws = f(max(self.K.layernorm_backward_ws_floats(B, k) for k in (c1, c2, a.H1, a.H2)))
+            ws.ln_scr = f(2 * max(c1, c2))
+            ws.ga = {}
+            o = 0
+            for name, v in list(m.actor.views.items()) + list(m.actor_ln.items()):
+                ws.ga[name] = ws.grads_a[o:o + v.numel()].view(v.shape)
+                o += v.numel()
         ws.graph = None
         self._rank_weight = 1.0
         ws.xerr = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device != 'cpu' else None
@@ -352,8 +366,71 @@ class DDPGLearner(Learner):
             return ((mt.ac_flat, m.ac_flat),)
         return ((mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat))
 
+    def _enqueue_iteration_ln(self, ws, x, xn, actions, rewards, done):
+        """one DDPG iteration (ddpg.py:244-352) with use_layernorm = True: every hidden ReLU is followed by a LayerNorm
+        (builders.py:42-48, 65-75), so the networks run layer by layer (smx_linear_f32 + smx_layernorm_*_f32) and the
+        LayerNorms' affine parameters are part of the two optimiser groups.  Low-dimensional observations, one critic."""
+        K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
+        B, D = x.shape
+        lw, lt = ws.ln, ws.ln_t
+        c, c1, c2, ld = m.critic, m.c1, m.c2, m.c1 + A
+        a, av, aln = m.actor, m.actor.views, m.actor_ln
+        gamma_n = pow(self.discount_factor, self.n_step)
+        # ---- target: y = r + gamma^n * Q'(s', mu'(s')) * (1 - done) ----
+        mt.actor_forward_ln(xn, lt, ws.act)
+        mt.critic_forward_ln(xn, ws.act, lt, ws.xcat_t, ws.q_next)
+        # ---- critic update ----
+        m.critic_forward_ln(x, actions, lw, ws.xcat, ws.q)
+        K.ddpg_critic_loss_step(ws.q, ws.q_next, rewards, done, gamma_n, ws.y, ws.dz3, ws.step)
+        gc, dz3 = ws.gc, ws.dz3.view(B, 1)
+        K.linear_wgrad(dz3, lw.c_n2, gc['W3'], gc['b3'], 1, c2, B, ldz=1)
+        K.linear(dz3, 1, c['W3'], 0, None, ws.dn2, B, c2, 1, lda=1, ldb=c2)                 # d/d(LN2 output)
+        K.layernorm_backward(ws.dn2, lw.c_a2, lw.cm2, lw.cr2, c['ln2.W'], ws.dz2, gc['ln2.W'], gc['ln2.b'], ws.ln_ws,
+                             relu_mask=True)
+        K.linear_wgrad(ws.dz2, ws.xcat, gc['W2'], gc['b2'], c2, c1 + A, B)
+        K.linear(ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1 + A, c2, ldb=ld, ldc=ld)        # d/d([LN1 output | action])
+        K.layernorm_backward(ws.dxcat[:, :c1], lw.c_a1, lw.cm1, lw.cr1, c['ln1.W'], ws.dz1c, gc['ln1.W'], gc['ln1.b'],
+                             ws.ln_ws, relu_mask=True)
+        K.linear_wgrad(ws.dz1c, x, gc['W1'], gc['b1'], c1, D, B)
+        self._average_over_ranks(ws.grads_c)
+        K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                        ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+        ws.q_policy.copy_(ws.q)
+        # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)) ----
+        m.actor_forward_ln(x, lw, ws.act)
+        m.critic_forward_ln(x, ws.act, lw, ws.xcat, ws.q_actor)
+        K.fill(ws.dz3, -1.0 / B)
+        K.linear(dz3, 1, c['W3'], 0, None, ws.dn2, B, c2, 1, lda=1, ldb=c2)
+        K.layernorm_backward(ws.dn2, lw.c_a2, lw.cm2, lw.cr2, c['ln2.W'], ws.dz2, ws.ln_scr[:c2], ws.ln_scr[c2:2 * c2],
+                             ws.ln_ws, relu_mask=True)                                        # (critic gradients discarded)
+        K.linear(ws.dz2, 1, c['W2'][:, c1:], 0, None, ws.dxcat[:, c1:], B, A, c2, ldb=ld, ldc=ld)   # d/d(action)
+        ws.dz3a.copy_(ws.dxcat[:, c1:])
+        K.tanh_backward(ws.dz3a, ws.act, ws.dz3a)
+        ga = ws.ga
+        K.linear_wgrad(ws.dz3a, lw.n2, ga['W3'], ga['b3'], A, a.H2, B)
+        K.linear(ws.dz3a, 1, av['W3'], 0, None, ws.dn2a, B, a.H2, A, ldb=a.H2)
+        K.layernorm_backward(ws.dn2a, lw.a2, lw.am2, lw.ar2, aln['ln2.W'], ws.dz2a, ga['ln2.W'], ga['ln2.b'], ws.ln_ws,
+                             relu_mask=True)
+        K.linear_wgrad(ws.dz2a, lw.n1, ga['W2'], ga['b2'], a.H2, a.H1, B)
+        K.linear(ws.dz2a, 1, av['W2'], 0, None, ws.dn1a, B, a.H1, a.H2, ldb=a.H1)
+        K.layernorm_backward(ws.dn1a, lw.a1, lw.am1, lw.ar1, aln['ln1.W'], ws.dz1a, ga['ln1.W'], ga['ln1.b'], ws.ln_ws,
+                             relu_mask=True)
+        K.linear_wgrad(ws.dz1a, x, ga['W1'], ga['b1'], a.H1, D, B)
+        self._average_over_ranks(ws.grads_a)
+        K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                        ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
+        K.ddpg_stats(ws.q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
+        self._average_over_ranks(ws.stats[:6])
+        for tgt, src in self._target_pairs(mt, m):
+            if self.target_update_type == 'soft':
+                K.soft_update(tgt, src, self.target_update_tau)
+            else:
+                K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
+
     def _enqueue_iteration(self, ws, x, xn, actions, rewards, done, pix=None, pix_next=None):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
+        if self.use_layernorm:
+            return self._enqueue_iteration_ln(ws, x, xn, actions, rewards, done)
         if self.level_schedule and not (self.is_pixel_input or self.use_double_critic or self.world_size > 1):
             return self._enqueue_iteration_levels(ws, x, xn, actions, rewards, done)
         K, m, mt, A = self.K, self.model, self.model_target, self.action_dim

@@ -1,13 +1,14 @@
 """
 DDPGModel on MI355X (surreal/model/ddpg_net.py:13-95; ActorNetworkX / CriticNetworkX,
-model_builders/builders.py:35-84), use_layernorm=False (the reference default, ddpg_configs.py:21;
-LayerNorm raises NotImplementedError).  With camera frames in the observation the "perception" CNN
+model_builders/builders.py:35-84).  use_layernorm=True (reference default: off, ddpg_configs.py:21) puts a LayerNorm over
+the features behind every hidden ReLU (builders.py:42-48, 65-75; torchx's L.LayerNorm(1) taken as torch.nn.LayerNorm(F) -- its
+source is not in the reference tree) -- low-dimensional observations only.  With camera frames in the observation the "perception" CNN
 (CNNStemNetwork, builders.py:8-33; ddpg_net.py:37-44, 67-78) runs on ``camera0 / 255`` and its
 features are concatenated IN FRONT of the low-dim vector; it trains with the critic
 (ddpg_net.py:57-61).
 
-  actor : Linear(D,h1)-ReLU-Linear(h1,h2)-ReLU-Linear(h2,A)-Tanh
-  critic: Linear(D,c1)-ReLU ; concat action ; Linear(c1+A,c2)-ReLU ; Linear(c2,1)
+  actor : Linear(D,h1)-ReLU[-LN]-Linear(h1,h2)-ReLU[-LN]-Linear(h2,A)-Tanh
+  critic: Linear(D,c1)-ReLU[-LN] ; concat action ; Linear(c1+A,c2)-ReLU[-LN] ; Linear(c2,1)
 
 One flat fp32 parameter buffer per network (actor / critic / perception).
 """
@@ -34,9 +35,9 @@ class DDPGModel(object):
                           conv_out_channels=conv_out_channels, conv_kernel_sizes=conv_kernel_sizes,
                           conv_strides=conv_strides, conv_hidden_dim=conv_hidden_dim,
                           critic_only=critic_only, device=device, kernels=self.K)
-        if use_layernorm:
-            raise NotImplementedError('use_layernorm=True is not built yet')
         self.is_pixel_input = 'pixel' in obs_spec
+        if use_layernorm and self.is_pixel_input:
+            raise NotImplementedError('use_layernorm=True with camera observations is not built')
         self.action_dim = A = action_dim
         self.use_layernorm = use_layernorm
         self.low_dim = int(obs_spec['low_dim']['flat_inputs'][0]) if 'low_dim' in obs_spec else 0
@@ -59,16 +60,26 @@ class DDPGModel(object):
         c1, c2 = ch
         sizes = [('W1', (c1, D)), ('b1', (c1,)), ('W2', (c2, c1 + A)), ('b2', (c2,)),
                  ('W3', (1, c2)), ('b3', (1,))]
+        if use_layernorm:            # the affine parameters of the two LayerNorms, behind the dense ones
+            sizes += [('ln1.W', (c1,)), ('ln1.b', (c1,)), ('ln2.W', (c2,)), ('ln2.b', (c2,))]
         n = sum(int(np.prod(s)) for _, s in sizes)
+        self.ln_eps = 1e-5           # torch.nn.LayerNorm's default
         self.actor_flat = self.ac_flat = None
         if not critic_only:
             # actor and critic parameters live in ONE buffer (each on a 256-byte boundary, the gap zero): the target
             # network's soft / hard update is then one launch over `ac_flat` instead of one per network
-            na = Mlp3Params.count(D, ah[0], ah[1], A)
+            n_mlp = Mlp3Params.count(D, ah[0], ah[1], A)
+            na = n_mlp + (2 * (ah[0] + ah[1]) if use_layernorm else 0)
             na_pad = (na + 63) // 64 * 64
             self.ac_flat = torch.zeros(na_pad + n, device=device)
             self.actor_flat = self.ac_flat[:na]
             self.actor = Mlp3Params(self.actor_flat, 0, D, ah[0], ah[1], A)
+            self.actor_ln = collections.OrderedDict()
+            if use_layernorm:
+                o = n_mlp
+                for name, k in (('ln1.W', ah[0]), ('ln1.b', ah[0]), ('ln2.W', ah[1]), ('ln2.b', ah[1])):
+                    self.actor_ln[name] = self.actor_flat[o:o + k]
+                    o += k
             self.critic_flat = self.ac_flat[na_pad:na_pad + n]
         else:
             self.actor = None
@@ -88,8 +99,15 @@ class DDPGModel(object):
         nets = [self.critic] + ([self.actor.views] if self.actor is not None else [])
         for views in nets:
             for name, v in views.items():
+                if name.startswith('ln'):
+                    continue
                 fan = views['W' + name[1]].shape[1]
                 v.uniform_(-1.0 / np.sqrt(fan), 1.0 / np.sqrt(fan))
+        if self.use_layernorm:           # torch.nn.LayerNorm: weight 1, bias 0
+            for views in [self.critic] + ([self.actor_ln] if self.actor is not None else []):
+                for name, v in views.items():
+                    if name.startswith('ln'):
+                        v.fill_(1.0 if name.endswith('.W') else 0.0)
 
     def named_parameters(self):
         out = collections.OrderedDict()
@@ -100,6 +118,12 @@ class DDPGModel(object):
         for i in (1, 2, 3):
             out['critic.fc%d.W' % i] = self.critic['W%d' % i]
             out['critic.fc%d.b' % i] = self.critic['b%d' % i]
+        if self.use_layernorm:
+            if self.actor is not None:
+                for k, v in self.actor_ln.items():
+                    out['actor.' + k] = v
+            for k in ('ln1.W', 'ln1.b', 'ln2.W', 'ln2.b'):
+                out['critic.' + k] = self.critic[k]
         if self.cnn is not None:
             for k, v in self.cnn.views.items():
                 out['cnn.' + k] = v
@@ -150,9 +174,50 @@ class DDPGModel(object):
         self.perception_into(frames, obs['low_dim']['flat_inputs'] if self.low_dim else None, cws, out)
         return out
 
+    # ---- the LayerNorm variant: layer by layer, the LayerNorm inputs and row statistics kept for a backward pass ----
+    def ln_workspace(self, rows, device=None):
+        """buffers of one actor and one critic pass with LayerNorm (activations in front of each LayerNorm, its outputs,
+        row means / reciprocal standard deviations)"""
+        import types
+        f = lambda *s: torch.empty(*s, device=device or self.device)  # noqa: E731
+        w = types.SimpleNamespace()
+        if self.actor is not None:
+            a = self.actor
+            w.a1, w.n1, w.a2, w.n2 = f(rows, a.H1), f(rows, a.H1), f(rows, a.H2), f(rows, a.H2)
+            w.am1, w.ar1, w.am2, w.ar2 = f(rows), f(rows), f(rows), f(rows)
+        w.c_a1, w.c_a2, w.c_n2 = f(rows, self.c1), f(rows, self.c2), f(rows, self.c2)
+        w.cm1, w.cr1, w.cm2, w.cr2 = f(rows), f(rows), f(rows), f(rows)
+        return w
+
+    def actor_forward_ln(self, x, w, out):
+        """out = tanh(fc3(LN(relu(fc2(LN(relu(fc1 x)))))))   (builders.py:35-56 with use_layernorm)"""
+        K, a, v, ln = self.K, self.actor, self.actor.views, self.actor_ln
+        rows, D = x.shape
+        K.linear(x, 1, v['W1'], 1, v['b1'], w.a1, rows, a.H1, D, act=1)
+        K.layernorm_forward(w.a1, ln['ln1.W'], ln['ln1.b'], self.ln_eps, w.n1, w.am1, w.ar1)
+        K.linear(w.n1, 1, v['W2'], 1, v['b2'], w.a2, rows, a.H2, a.H1, act=1)
+        K.layernorm_forward(w.a2, ln['ln2.W'], ln['ln2.b'], self.ln_eps, w.n2, w.am2, w.ar2)
+        K.linear(w.n2, 1, v['W3'], 1, v['b3'], out, rows, a.OUT, a.H2, act=2)
+
+    def critic_forward_ln(self, x, action, w, xcat, q):
+        """xcat [rows, c1 + A] receives LN(relu(fc1 x)) | action; q [rows]   (builders.py:58-84 with use_layernorm)"""
+        K, c = self.K, self.critic
+        rows, D = x.shape
+        A, c1, c2 = self.action_dim, self.c1, self.c2
+        K.linear(x, 1, c['W1'], 1, c['b1'], w.c_a1, rows, c1, D, act=1)
+        K.layernorm_forward(w.c_a1, c['ln1.W'], c['ln1.b'], self.ln_eps, xcat[:, :c1], w.cm1, w.cr1)
+        xcat[:, c1:].copy_(action)
+        K.linear(xcat, 1, c['W2'], 1, c['b2'], w.c_a2, rows, c2, c1 + A, act=1)
+        K.layernorm_forward(w.c_a2, c['ln2.W'], c['ln2.b'], self.ln_eps, w.c_n2, w.cm2, w.cr2)
+        K.linear(w.c_n2, 1, c['W3'], 1, c['b3'], q.view(rows, 1), rows, 1, c2, act=0)
+
     def forward_actor(self, x):
         a = self.actor
         rows = x.shape[0]
+        if self.use_layernorm:
+            out = torch.empty(rows, a.OUT, device=x.device)
+            self.actor_forward_ln(x.contiguous(), self.ln_workspace(rows, x.device), out)
+            return out
         h1 = torch.empty(rows, a.H1, device=x.device)
         h2 = torch.empty(rows, a.H2, device=x.device)
         out = torch.empty(rows, a.OUT, device=x.device)
@@ -171,6 +236,11 @@ class DDPGModel(object):
 
     def forward_critic(self, x, action):
         rows = x.shape[0]
+        if self.use_layernorm:
+            xcat = torch.empty(rows, self.c1 + self.action_dim, device=x.device)
+            q = torch.empty(rows, device=x.device)
+            self.critic_forward_ln(x.contiguous(), action, self.ln_workspace(rows, x.device), xcat, q)
+            return q.view(rows, 1)
         xcat = torch.empty(rows, self.c1 + self.action_dim, device=x.device)
         h2 = torch.empty(rows, self.c2, device=x.device)
         q = torch.empty(rows, device=x.device)

@@ -58,6 +58,29 @@ class TorchCpuKernels(object):
         cnt += float(count_rows)
 
     # ---- MLP ----------------------------------------------------------------------------
+    def layernorm_forward(self, x, gamma, beta, eps, y, mean=None, rstd=None):
+        m = x.mean(1, keepdim=True)
+        var = ((x - m) ** 2).mean(1, keepdim=True)
+        rs = 1.0 / torch.sqrt(var + eps)
+        y.copy_((x - m) * rs * gamma + beta)
+        if mean is not None:
+            mean.copy_(m.view(-1))
+        if rstd is not None:
+            rstd.copy_(rs.view(-1))
+
+    def layernorm_backward_ws_floats(self, rows, F):
+        return 1
+
+    def layernorm_backward(self, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, ws, relu_mask=False):
+        xh = (x - mean.view(-1, 1)) * rstd.view(-1, 1)
+        g = dy * gamma
+        v = rstd.view(-1, 1) * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+        if relu_mask:
+            v = v * (x > 0)
+        dgamma.copy_((dy * xh).sum(0))
+        dbeta.copy_(dy.sum(0))
+        dx.copy_(v)
+
     def mlp3_dgrad_rows_ws_floats(self, net):
         return 0
 

@@ -10,7 +10,7 @@ from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, 
 import ddpg_oracle
 
 DDPG_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'tiny_td3_hard', 'tiny_double_soft', 'tiny_pixel_hard',
-              'tiny_pixel_td3_soft', 'cfg3_cheetah512']
+              'tiny_pixel_td3_soft', 'cfg3_cheetah512', 'tiny_ln_hard', 'ln_soft_clipcritic']
 
 
 def load(name):
@@ -31,6 +31,7 @@ def make_learner(case):
                                      'interval': h['target_update_interval'], 'tau': h.get('tau', 1e-3)}
     lc.algo.network.use_double_critic = bool(h.get('double_critic', False))
     lc.algo.network.use_action_regularization = bool(h.get('action_reg', False))
+    lc.model.use_layernorm = bool(h.get('layernorm', False))
     lc.replay.batch_size = case['B']
     pixel = tuple(case['pixel']) if case.get('pixel') else None
     if pixel is not None:
@@ -41,7 +42,8 @@ def make_learner(case):
         if pixel is not None:
             return ddpg_oracle.make_ddpg_pixel_params(case['D'], case['A'], pixel, case['conv_hidden'],
                                                       tuple(case['ah']), tuple(case['ch']), seed=seed)
-        return ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=seed)
+        return ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=seed,
+                                            layernorm=bool(h.get('layernorm', False)))
     params = mkp(3)
     L.model.load_params(params)
     L.model_target.load_params(params)

@@ -21,7 +21,8 @@ def test_ddpg_oracle_matches_reference_golden(name):
         if pixel is not None:
             return ddpg_oracle.make_ddpg_pixel_params(c['D'], c['A'], pixel, c['conv_hidden'], tuple(c['ah']),
                                                       tuple(c['ch']), seed=seed)
-        return ddpg_oracle.make_ddpg_params(c['D'], c['A'], tuple(c['ah']), tuple(c['ch']), seed=seed)
+        return ddpg_oracle.make_ddpg_params(c['D'], c['A'], tuple(c['ah']), tuple(c['ch']), seed=seed,
+                                            layernorm=bool(h.get('layernorm', False)))
     params, params2 = mkp(3), mkp(4)
     O = ddpg_oracle.OracleDDPGLearner(
         params, gamma=h['gamma'], n_step=h['n_step'], lr_actor=h['lr_actor'], lr_critic=h['lr_critic'],
@@ -48,9 +49,15 @@ def test_ddpg_unsupported_switches_raise(cpu_double):
     from surreal_amd.learner.ddpg import DDPGLearner
     from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
     lc = ddpg_learner_config()
+    lc.model.use_layernorm = True                   # built for low-dimensional observations with one critic
+    lc.algo.network.use_double_critic = True
+    L = DDPGLearner(lc, ddpg_env_config(5, 2), ddpg_session_config())
+    with pytest.raises(NotImplementedError):
+        L.learn(synthetic.make_ddpg_batch(lc.replay.batch_size, 5, 2, seed=1))
+    lc = ddpg_learner_config()
     lc.model.use_layernorm = True
     with pytest.raises(NotImplementedError):
-        DDPGLearner(lc, ddpg_env_config(5, 2), ddpg_session_config())
+        DDPGLearner(lc, ddpg_env_config(5, 2, pixel=(2, 20, 24)), ddpg_session_config())
     lc = ddpg_learner_config()
     lc.algo.network.target_update = {'type': 'weird'}
     from surreal_amd.session import ConfigError

@@ -165,7 +165,7 @@ def _ddpg_worker(rank, world, port, name, q):
         q.put((rank, {'error': traceback.format_exc()}))
 
 
-@pytest.mark.parametrize('name', ['tiny_hard', 'tiny_double_soft'])
+@pytest.mark.parametrize('name', ['tiny_hard', 'tiny_double_soft', 'tiny_ln_hard'])
 def test_two_rank_ddpg_equals_single_learner(name):
     """data-parallel DDPG: each rank learns on half of every batch, gradients are averaged before
     each Adam step -> the single reference learner's trace, identical replicas"""

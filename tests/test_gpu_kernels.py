@@ -1659,3 +1659,38 @@ def test_partials_fold_and_many_row_zupdate(K):
         assert float(c1) == float(c2) == 1000.0 + rows
         if nws == 0:
             assert torch.equal(rs1, rs2) and torch.equal(rq1, rq2)
+
+
+@pytest.mark.parametrize('rows,F', [(512, 400), (37, 24), (16, 300), (5, 1000), (130, 72)])
+def test_layernorm_forward_backward_match_aten(K, rows, F):
+    """smx_layernorm_forward_f32 / _backward_f32 (DDPG use_layernorm) against torch.nn.functional.layer_norm + autograd on
+    the CPU, rows of x / y / dy strided (views into wider buffers), with and without the ReLU mask of the layer in front"""
+    g = torch.Generator().manual_seed(rows + F)
+    wide = torch.randn(rows, F + 3, generator=g)
+    x = torch.relu(wide[:, :F]).clone().requires_grad_(True)                  # the LayerNorm sits behind a ReLU
+    gamma = (1 + 0.2 * torch.randn(F, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(F, generator=g)).requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x, (F,), gamma, beta, 1e-5)
+    dy = torch.randn(rows, F, generator=g)
+    (y * dy).sum().backward()
+    xd = torch.zeros(rows, F + 3, device='cuda')
+    xd[:, :F] = x.detach().cuda()
+    yd = torch.full((rows, F + 5), 7.0, device='cuda')
+    mean, rstd = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    K.layernorm_forward(xd[:, :F], gamma.detach().cuda(), beta.detach().cuda(), 1e-5, yd[:, :F], mean, rstd)
+    close(yd[:, :F], y.detach(), msg='y')
+    assert float(yd[:, F:].min()) == 7.0
+    close(mean, x.detach().mean(1), msg='mean')
+    dyd = torch.zeros(rows, F + 2, device='cuda')
+    dyd[:, :F] = dy.cuda()
+    ws = torch.empty(K.layernorm_backward_ws_floats(rows, F), device='cuda')
+    for mask in (False, True):
+        dx, dg, db = torch.full((rows, F + 1), 3.0, device='cuda'), torch.empty(F, device='cuda'), torch.empty(F, device='cuda')
+        K.layernorm_backward(dyd[:, :F], xd[:, :F], mean, rstd, gamma.detach().cuda(), dx[:, :F], dg, db, ws, relu_mask=mask)
+        want = x.grad * (x.detach() > 0) if mask else x.grad
+        sc = float(want.abs().max())
+        close(dx[:, :F] / sc, want / sc, atol=2e-6, rtol=2e-5, msg='dx mask=%s' % mask)
+        assert float(dx[:, F:].min()) == 3.0
+        sg = float(gamma.grad.abs().max())
+        close(dg / sg, gamma.grad / sg, atol=2e-6, rtol=2e-5, msg='dgamma')
+        close(db / sg, beta.grad / sg, atol=2e-6, rtol=2e-5, msg='dbeta')
