@@ -189,6 +189,55 @@ def test_epoch_fwdbwd_equals_forward_then_backward(K, rows, D, H1, H2, A, mode):
         close(one[k], two[k], atol=1e-7, rtol=2e-5, msg=k)
 
 
+@pytest.mark.parametrize('mode', [L.SMX_PPO_ADAPT, L.SMX_PPO_CLIP])
+def test_epoch_fwdbwd_hand_off_under_uneven_load_many_times(K, mode):
+    """the in-launch publish / poll protocol of smx_epoch_fwdbwd_f32 (device-scope stores of the loss partial rows and the
+    KL slots, a counter, device-scope polls) exercised 3000 times at the benchmark shape while a second stream
+    keeps the device UNEVENLY busy (tenants of 40 ... 120 CUs for 20 ... 300 us, started at random points): every launch
+    must reproduce the statistics, the gradients' right-hand sides and the partial rows of the first one bit for bit, the
+    counter must count every actor workgroup, and no wait may time out"""
+    rows, D, H1, H2, A = 1024, 376, 300, 200, 17
+    t = build(rows, D, H1, H2, A, seed=99, mode=mode, device='cuda')['d']
+    t['ctrl'][L.C_KL_TARGET] = 1e9
+    nb = (rows + 15) // 16
+    loss = dict(mode=mode, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
+                adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=True,
+                will_update=True, dlogvar=t['dlogvar'], dlogvar_sumsq=t['dlq'], stats=t['stats'],
+                returns=t['returns'], v_dz3=t['v_dz3'], v_partials=t['v_partials'], v_will_update=True)
+    K.epoch_pack([(t['act'], t['pk_a']), (t['cri'], t['pk_c'])])
+    aj = dict(net=t['act'], packed=t['pk_a'], x=t['x'], h1T=t['h1aT'], h2T=t['h2aT'], act=L.SMX_ACT_TANH, loss='policy',
+              dz3T=t['dz3aT'], dz2T=t['dz2aT'], dz1T=t['dz1aT'], xT=t['xT'], grads=t['grads_a'])
+    cj = dict(net=t['cri'], packed=t['pk_c'], x=t['x'], h1T=t['h1cT'], h2T=t['h2cT'], act=L.SMX_ACT_NONE,
+              loss='value', dz3=t['v_dz3'], dz3T=t['v_dz3'], dz2T=t['dz2cT'], dz1T=t['dz1cT'], xT=t['xT'],
+              grads=t['grads_c'])
+    sync = torch.zeros(1, dtype=torch.int32, device='cuda')
+    slots = torch.zeros(2 * nb, dtype=torch.int32, device='cuda')
+    ctrl0 = t['ctrl'].clone()
+    keys = ('stats', 'dlogvar', 'partials', 'v_partials', 'dz3aT', 'dz2aT', 'dz1aT', 'dz2cT', 'dz1cT')
+    side = torch.cuda.Stream()
+    rs = np.random.RandomState(7)
+    first = None
+    for it in range(3000):
+        sync.zero_(); slots.zero_(); t['ctrl'].copy_(ctrl0)
+        for k in ('stats', 'dz1aT', 'dz1cT'):
+            t[k].fill_(123.0)             # (a stale result of the previous launch must not pass for a fresh one)
+        if rs.rand() < 0.7:
+            with torch.cuda.stream(side):
+                K.device_occupy(int(rs.randint(40, 121)), int(rs.randint(20, 301)))
+        K.epoch_fwdbwd([aj, cj], loss, t['ctrl'], rows, sync, slots)
+        if it % 50 == 0 or it < 5:                        # (a device sync every launch would remove the unevenness)
+            torch.cuda.synchronize()
+            assert int(t['ctrl'].view(torch.int32)[L.C_SYNC_ERR]) == 0, it
+            assert int(sync[0]) == nb, (it, int(sync[0]))
+            snap = {k: t[k].clone() for k in keys}
+            if first is None:
+                first = snap
+            for k in keys:
+                assert torch.equal(snap[k], first[k]), (it, k)
+    torch.cuda.synchronize()
+    assert int(t['ctrl'].view(torch.int32)[L.C_SYNC_ERR]) == 0
+
+
 @pytest.mark.parametrize('mode', ['adapt', 'clip'])
 @pytest.mark.parametrize('rows,D,H1,H2,A', [(1024, 376, 300, 200, 17), (100, 64, 332, 212, 32), (48, 12, 24, 16, 3)])
 def test_epoch_launches_against_the_reference_restatement_in_float64(K, rows, D, H1, H2, A, mode):
