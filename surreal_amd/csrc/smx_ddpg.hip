@@ -116,13 +116,15 @@ __global__ __launch_bounds__(1024) void ddpg_stats_kernel(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     float amax = 0.f;
+    int anan = 0;
     for (long r = threadIdx.x; r < rows; r += 1024) {
         const float d = q[r] - y[r];
         float nn = 0.f;
         for (int j = 0; j < A; ++j) {
             const float a = actions[r * ld_act + j];
             nn += a * a;
-            amax = (a == a) ? fmaxf(amax, fabsf(a)) : a;      // a NaN action must fail the check
+            if (a == a) amax = fmaxf(amax, fabsf(a));
+            else anan = 1;                                    // a NaN action must fail the check
         }
         acc[0] += (double)(-q_actor[r]);
         acc[1] += (double)(d * d);
@@ -142,14 +144,24 @@ __global__ __launch_bounds__(1024) void ddpg_stats_kernel(
             stats[k] = (float)(t / (double)rows);
         }
     }
-    // stats[6] = max |action| (the reference asserts |a| <= 1 with two host syncs, ddpg.py:262-263)
-    __shared__ float mx[1024];
-    mx[threadIdx.x] = amax;
+    // stats[6] = max |action| (the reference asserts |a| <= 1 with two host syncs, ddpg.py:262-263); NaN if any action
+    // is.  (Round 5: a wavefront-level reduction -- thread 0 walking 1024 LDS words took 18 of this launch's 22 us.)
+    int bad = anan;
+    float mxv = amax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mxv = fmaxf(mxv, __shfl_xor(mxv, off, 64));
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    __shared__ float mx[16];
+    __shared__ int nanw[16];
+    if (lane == 0) { mx[w] = mxv; nanw[w] = bad; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < 1024; ++i) t = (mx[i] == mx[i] && t == t) ? fmaxf(t, mx[i]) : NAN;
-        stats[6] = t;
+        int b = 0;
+        for (int i = 0; i < 16; ++i) { t = fmaxf(t, mx[i]); b |= nanw[i]; }
+        stats[6] = b ? NAN : t;
     }
 }
 
