@@ -121,6 +121,14 @@ __device__ __noinline__ void dense16(const Dense& Lr, long row0, int nrows, int 
     SMX_LDS_BARRIER();
 }
 
+// Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer, 32 slots per workgroup) exist
+// only in a build with -DSMX_DDPG_TIMING (scripts/bench_ddpg_rows.py); the product build has none.
+#ifdef SMX_DDPG_TIMING
+#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 struct RNet {                     // a network's biases (row-major parameter buffer) and packed weights
     const float *b1, *b2, *b3;
     PMat W1, W2, W3;
@@ -139,6 +147,7 @@ struct RArgs {
     int* step;
     // LDS carve-up (float offsets)
     int ldx, ldA, ldB, ldC, oX, oXn, oA, oB, oC, oO, oO2, oO3, oZ, oS, total;
+    long long* tbuf;              // SMX_DDPG_TIMING builds
 };
 
 __device__ __forceinline__ void zero_lds(int total) {
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     int nrows = G.rows - (int)row0;
     nrows = nrows > 16 ? 16 : nrows;
     const int A = G.A, c1 = G.c1, c2 = G.c2, ldc = c1 + A, R = G.rows;
+    TSTAMP(0);
     zero_lds(G.total);
     __syncthreads();
     stage_rows(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
@@ -186,13 +196,17 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     // ---- mu'(s') ----
     Dense L = mk(G.oXn, G.ldx, G.ta.W1, G.ta.b1, A_RELU, G.oA, G.ldA, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(1);
     L = mk(G.oA, G.ldA, G.ta.W2, G.ta.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(2);
     L = mk(G.oB, G.ldB, G.ta.W3, G.ta.b3, A_TANH, G.oO, LDO, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(3);
     // ---- Q'(s', mu'(s')): layer 1 into the first c1 columns of the concat tile, the action behind them ----
     L = mk(G.oXn, G.ldx, G.tc.W1, G.tc.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(4);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
         sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
@@ -200,11 +214,14 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     SMX_LDS_BARRIER();
     L = mk(G.oC, G.ldC, G.tc.W2, G.tc.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(5);
     L = mk(G.oB, G.ldB, G.tc.W3, G.tc.b3, A_NONE, G.oO2, LDO, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(6);
     // ---- Q(s, a) ----
     L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, G.xcat, ldc);
     dense16(L, row0, nrows, R);
+    TSTAMP(7);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
         const float v = (n < nrows) ? G.actions[(size_t)(row0 + n) * A + j] : 0.f;
@@ -214,8 +231,10 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     SMX_LDS_BARRIER();
     L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, G.h2c, c2);
     dense16(L, row0, nrows, R);
+    TSTAMP(8);
     L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, G.oO, LDO, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(9);
     // ---- y = r + gamma^n Q' (1 - done) (ddpg.py:279); dLoss/dQ of the mean squared error (ddpg.py:307-308) ----
     if (tid < 16) {
         const float qn = sm[G.oO2 + tid * LDO], q = sm[G.oO + tid * LDO];
@@ -245,13 +264,17 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     L = mk(G.oA, G.ldA, G.cW2Tlo, nullptr, A_MASK, -1, 0, G.dxcat, ldc);
     L.mask_off = G.oC; L.ldm = G.ldC;
     dense16(L, row0, nrows, R);
+    TSTAMP(10);
     // ---- mu(s), kept for the actor phase ----
     L = mk(G.oX, G.ldx, G.a.W1, G.a.b1, A_RELU, G.oA, G.ldA, G.h1a, G.H1);
     dense16(L, row0, nrows, R);
+    TSTAMP(11);
     L = mk(G.oA, G.ldA, G.a.W2, G.a.b2, A_RELU, G.oB, G.ldB, G.h2a, G.H2);
     dense16(L, row0, nrows, R);
+    TSTAMP(12);
     L = mk(G.oB, G.ldB, G.a.W3, G.a.b3, A_TANH, -1, 0, G.act, A);
     dense16(L, row0, nrows, R);
+    TSTAMP(13);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -264,6 +287,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     int nrows = G.rows - (int)row0;
     nrows = nrows > 16 ? 16 : nrows;
     const int A = G.A, c1 = G.c1, c2 = G.c2, R = G.rows;
+    TSTAMP(0);
     zero_lds(G.total);
     __syncthreads();
     stage_rows(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
@@ -271,6 +295,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     SMX_LDS_BARRIER();
     Dense L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(1);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
         sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
@@ -278,8 +303,10 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     SMX_LDS_BARRIER();
     L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(2);
     L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, -1, 0, G.q_actor, 1);
     dense16(L, row0, nrows, R);
+    TSTAMP(3);
     // the masks of the actor's backward pass (its own forward pass ran in the critic phase): h1a -> the concat tile, whose
     // layer-2 product is done; h2a follows once dz2 has read the critic's ReLU mask
     stage_rows(G.h1a, G.H1, G.H1, row0, nrows, G.oC, G.ldC);
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     // ---- d/d(action) = W2[:, c1:]^T dz2, through tanh ----
     L = mk(G.oA, G.ldA, G.cW2Thi, nullptr, A_NONE, G.oO2, LDO, nullptr, 0);
     dense16(L, row0, nrows, R);
+    TSTAMP(4);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
         const float a = sm[G.oO + n * LDO + j];
@@ -308,9 +336,11 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     L = mk(G.oZ, LDK, G.aW3T, nullptr, A_MASK, G.oA, G.ldA, G.dz2a, G.H2);
     L.mask_off = G.oB; L.ldm = G.ldB;
     dense16(L, row0, nrows, R);
+    TSTAMP(5);
     L = mk(G.oA, G.ldA, G.aW2T, nullptr, A_MASK, -1, 0, G.dz1a, G.H1);
     L.mask_off = G.oC; L.ldm = G.ldC;
     dense16(L, row0, nrows, R);
+    TSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -382,6 +412,8 @@ long block_base(const Dims& d, int b) {          // in 16-byte words
     }
     return o;
 }
+
+long long* g_tbuf = nullptr;
 
 int lds_floats(const Dims& d, RArgs* G) {
     const int ldx = r64(d.D) + 4;
@@ -456,6 +488,7 @@ int fill(RArgs& G, const smx_ddpg_rows_t* a) {
     G.q_actor = a->q_actor; G.dz3a = a->dz3a; G.dz2a = a->dz2a; G.dz1a = a->dz1a;
     G.step = a->step;
     lds_floats(d, &G);
+    G.tbuf = g_tbuf;
     return SMX_OK;
 }
 
@@ -464,6 +497,8 @@ int set_lds(const void* fn, int bytes) {
 }
 
 }  // namespace
+
+extern "C" void smx_ddpg_rows_debug_tbuf(void* p) { g_tbuf = (long long*)p; }
 
 extern "C" int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2) {
     Dims d;
