@@ -63,14 +63,17 @@ if os.environ.get('SMX_DDPG_TBUF'):
     ws = L._ws
     args = L._rows_args(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done)
     for which, names in (('critic', names_c), ('actor', names_a)):
-        tb = torch.zeros(nb, 32, dtype=torch.int64, device='cuda')
+        tb = torch.zeros(nb, 128, dtype=torch.int64, device='cuda')
         lib.smx_ddpg_rows_debug_tbuf(ctypes.c_void_p(tb.data_ptr()))
         L.K.ddpg_rows_pack(args)
         getattr(L.K, 'ddpg_rows_' + which)(args)
         torch.cuda.synchronize()
         lib.smx_ddpg_rows_debug_tbuf(None)
-        t = tb.cpu().numpy().astype(np.float64)[:, :len(names) + 1]
+        full = tb.cpu().numpy().astype(np.float64)
+        t = full[:, :len(names) + 1]
         d = np.diff(t, axis=1)
         print('%s launch, cycles per phase (median over %d workgroups; total %.0f):' % (which, nb, np.median(t[:, -1] - t[:, 0])))
-        for n, v in zip(names, np.median(d, axis=0)):
-            print('   %-14s %8.0f' % (n, v))
+        for k, (n, v) in enumerate(zip(names, np.median(d, axis=0))):
+            ds = np.median(np.diff(full[:, 16 + 5 * k:21 + 5 * k], axis=1), axis=0)
+            print('   %-14s %8.0f   inside the layer (wave 0): entry %.0f  K loop %.0f  epilogue %.0f  barrier %.0f'
+                  % (n, v, *ds))

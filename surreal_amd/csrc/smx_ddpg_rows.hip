@@ -51,22 +51,37 @@ struct Dense {
     int ldg;
 };
 
+#ifdef SMX_DDPG_TIMING
+#define DSTAMP(i) do { if (threadIdx.x == 0 && d_ts_l) d_ts_l[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DTS_PARAM , long long* d_ts_l
+#define DTS_ARG(ts) , (ts)
+#else
+#define DSTAMP(i) do { } while (0)
+#define DTS_PARAM
+#define DTS_ARG(ts)
+#endif
+
 // (noinline: a kernel calls this a dozen times; inlined, every call carries its own copies of the three loop bodies and
 // the workgroup -- which runs each instruction stream once -- spends its time fetching code, see smx_epoch_mma.inc.h)
-__device__ __noinline__ void dense16(const Dense& Lr, long row0, int nrows, int rows_total) {
+__device__ __noinline__ void dense16v(int in_off_, int ldi_, const float* Wp_, int M_, int K_, const float* bias_, int act_,
+                                      int mask_off_, int ldm_, int out_off_, int ldo_, float* g_, int ldg_, int row0_,
+                                      int nrows_, int rows_total_ DTS_PARAM) {
     extern __shared__ float sm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fm = lane & 15, kq = lane >> 4;
-    // the descriptor arrives through memory: its fields are workgroup-uniform, say so (scalar registers, scalar branches)
+    DSTAMP(0);
+    // the arguments arrive in vector registers (by value: through a descriptor in memory every call started with a scratch
+    // round trip); they are workgroup-uniform, say so (scalar registers, scalar branches)
 #define SMX_U(x) __builtin_amdgcn_readfirstlane(x)
-    const int in_off = SMX_U(Lr.in_off), ldi = SMX_U(Lr.ldi), M = SMX_U(Lr.W.M), K = SMX_U(Lr.W.K), act = SMX_U(Lr.act);
-    const int mask_off = SMX_U(Lr.mask_off), ldm = SMX_U(Lr.ldm), out_off = SMX_U(Lr.out_off), ldo = SMX_U(Lr.ldo);
-    const int ldg = SMX_U(Lr.ldg);
+    const int in_off = SMX_U(in_off_), ldi = SMX_U(ldi_), M = SMX_U(M_), K = SMX_U(K_), act = SMX_U(act_);
+    const int mask_off = SMX_U(mask_off_), ldm = SMX_U(ldm_), out_off = SMX_U(out_off_), ldo = SMX_U(ldo_);
+    const int ldg = SMX_U(ldg_), nrows = SMX_U(nrows_), rows_total = SMX_U(rows_total_);
+    const long row0 = (long)SMX_U(row0_);
 #undef SMX_U
-    const float* const Wp = Lr.W.P;
-    const float* const bias = Lr.bias;
-    float* const gout = Lr.g;
+    const float* const Wp = Wp_;
+    const float* const bias = bias_;
+    float* const gout = g_;
     const int tiles = (M + 15) >> 4, C2 = pack_chunks(K);
     const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
     const rsrc_t rb = make_rsrc(bias ? bias : Wp, bias ? (unsigned)M * 4u : 0u);
@@ -87,9 +102,11 @@ __device__ __noinline__ void dense16(const Dense& Lr, long row0, int nrows, int 
         f32x4 acc[TG];
 #pragma unroll
         for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        DSTAMP(1);
         if (nt > 2) fwd_tiles<3>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
         else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
         else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
+        DSTAMP(2);
         // lane (fm, kq) holds features f0 .. f0 + 3 of data row fm
 #pragma unroll
         for (int g = 0; g < DTG; ++g) {
@@ -118,16 +135,26 @@ __device__ __noinline__ void dense16(const Dense& Lr, long row0, int nrows, int 
             }
         }
     }
+    DSTAMP(3);
     SMX_LDS_BARRIER();
+    DSTAMP(4);
 }
 
-// Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer, 32 slots per workgroup) exist
-// only in a build with -DSMX_DDPG_TIMING (scripts/bench_ddpg_rows.py); the product build has none.
+// Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer, 128 slots per workgroup:
+// 0 .. 15 the launch's phases, 16 + 5 k .. the k-th dense layer's entry / K loop / epilogue / barrier) exist only in a build with -DSMX_DDPG_TIMING (scripts/bench_ddpg_rows.py); the product build has none.
 #ifdef SMX_DDPG_TIMING
-#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 32 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 128 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DTS(k) (G.tbuf ? G.tbuf + (size_t)blockIdx.x * 128 + 16 + 5 * (k) : nullptr)
 #else
+#define DTS(k) nullptr
 #define TSTAMP(i) do { } while (0)
 #endif
+
+__device__ __forceinline__ void dense16(const Dense& L, long row0, int nrows, int rows_total, long long* ts) {
+    (void)ts;
+    dense16v(L.in_off, L.ldi, L.W.P, L.W.M, L.W.K, L.bias, L.act, L.mask_off, L.ldm, L.out_off, L.ldo, L.g, L.ldg, (int)row0,
+             nrows, rows_total DTS_ARG(ts));
+}
 
 struct RNet {                     // a network's biases (row-major parameter buffer) and packed weights
     const float *b1, *b2, *b3;
@@ -195,17 +222,17 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
 
     // ---- mu'(s') ----
     Dense L = mk(G.oXn, G.ldx, G.ta.W1, G.ta.b1, A_RELU, G.oA, G.ldA, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(0));
     TSTAMP(1);
     L = mk(G.oA, G.ldA, G.ta.W2, G.ta.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(1));
     TSTAMP(2);
     L = mk(G.oB, G.ldB, G.ta.W3, G.ta.b3, A_TANH, G.oO, LDO, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(2));
     TSTAMP(3);
     // ---- Q'(s', mu'(s')): layer 1 into the first c1 columns of the concat tile, the action behind them ----
     L = mk(G.oXn, G.ldx, G.tc.W1, G.tc.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(3));
     TSTAMP(4);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
@@ -213,14 +240,14 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     }
     SMX_LDS_BARRIER();
     L = mk(G.oC, G.ldC, G.tc.W2, G.tc.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(4));
     TSTAMP(5);
     L = mk(G.oB, G.ldB, G.tc.W3, G.tc.b3, A_NONE, G.oO2, LDO, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(5));
     TSTAMP(6);
     // ---- Q(s, a) ----
     L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, G.xcat, ldc);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(6));
     TSTAMP(7);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
@@ -230,10 +257,10 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     }
     SMX_LDS_BARRIER();
     L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, G.h2c, c2);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(7));
     TSTAMP(8);
     L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, G.oO, LDO, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(8));
     TSTAMP(9);
     // ---- y = r + gamma^n Q' (1 - done) (ddpg.py:279); dLoss/dQ of the mean squared error (ddpg.py:307-308) ----
     if (tid < 16) {
@@ -263,17 +290,17 @@ __global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
     // ---- dz1 = (W2[:, :c1]^T dz2) relu'(h1) ----
     L = mk(G.oA, G.ldA, G.cW2Tlo, nullptr, A_MASK, -1, 0, G.dxcat, ldc);
     L.mask_off = G.oC; L.ldm = G.ldC;
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(9));
     TSTAMP(10);
     // ---- mu(s), kept for the actor phase ----
     L = mk(G.oX, G.ldx, G.a.W1, G.a.b1, A_RELU, G.oA, G.ldA, G.h1a, G.H1);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(10));
     TSTAMP(11);
     L = mk(G.oA, G.ldA, G.a.W2, G.a.b2, A_RELU, G.oB, G.ldB, G.h2a, G.H2);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(11));
     TSTAMP(12);
     L = mk(G.oB, G.ldB, G.a.W3, G.a.b3, A_TANH, -1, 0, G.act, A);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(12));
     TSTAMP(13);
 }
 
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     stage_rows(G.act, A, A, row0, nrows, G.oO, LDO);
     SMX_LDS_BARRIER();
     Dense L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(0));
     TSTAMP(1);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
@@ -302,10 +329,10 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     }
     SMX_LDS_BARRIER();
     L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(1));
     TSTAMP(2);
     L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, -1, 0, G.q_actor, 1);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(2));
     TSTAMP(3);
     // the masks of the actor's backward pass (its own forward pass ran in the critic phase): h1a -> the concat tile, whose
     // layer-2 product is done; h2a follows once dz2 has read the critic's ReLU mask
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     stage_rows(G.h2a, G.H2, G.H2, row0, nrows, G.oB, G.ldB);
     // ---- d/d(action) = W2[:, c1:]^T dz2, through tanh ----
     L = mk(G.oA, G.ldA, G.cW2Thi, nullptr, A_NONE, G.oO2, LDO, nullptr, 0);
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(3));
     TSTAMP(4);
     if (tid < 16 * A) {
         const int n = tid / A, j = tid - n * A;
@@ -335,11 +362,11 @@ __global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
     // ---- the actor's data gradients ----
     L = mk(G.oZ, LDK, G.aW3T, nullptr, A_MASK, G.oA, G.ldA, G.dz2a, G.H2);
     L.mask_off = G.oB; L.ldm = G.ldB;
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(4));
     TSTAMP(5);
     L = mk(G.oA, G.ldA, G.aW2T, nullptr, A_MASK, -1, 0, G.dz1a, G.H1);
     L.mask_off = G.oC; L.ldm = G.ldC;
-    dense16(L, row0, nrows, R);
+    dense16(L, row0, nrows, R, DTS(5));
     TSTAMP(6);
 }
 
