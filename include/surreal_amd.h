@@ -162,6 +162,15 @@ int64_t smx_linear_wgrad_ws_floats(int32_t M, int32_t N, int32_t rows);
 int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
                                 float* dW, int32_t ldw, float* db, int32_t M, int32_t N,
                                 int32_t rows, float* ws, int64_t ws_floats, smx_stream_t stream);
+/* TWO weight gradients from the same dZ [rows, M] (the LSTM's dW_ih = dgates^T . x and dW_hh = dgates^T . h_prev,
+ * ppo_net.py:143-152 under loss.backward()): dW1 [M, N1] = dZ^T . X1, dW2 [M, N2] = dZ^T . X2 (dense, row stride N),
+ * db1 / db2 [M] column sums (nullable).  One split-K launch for both when both run on the 32 x 32-tile kernel
+ * (ws >= smx_linear_wgrad_ws_floats(M, N1, rows) + ..(M, N2, rows) floats), otherwise exactly two
+ * smx_linear_wgrad_splitk_f32 calls; results are those of the two calls, bit for bit. */
+int smx_linear_wgrad_splitk_pair_f32(const float* dZ, int32_t ldz, int32_t M, int32_t rows, const float* X1,
+                                     int32_t ldx1, float* dW1, float* db1, int32_t N1, const float* X2,
+                                     int32_t ldx2, float* dW2, float* db2, int32_t N2, float* ws,
+                                     int64_t ws_floats, smx_stream_t stream);
 
 /* One MLP forward or backward "job" for the multi-network entry points below: PPO's actor and
  * critic are independent networks updated in lock-step epochs (ppo.py:541-562), so their

@@ -305,6 +305,8 @@ _SIGS = {
     'smx_linear_wgrad_ws_floats': (c_int64, [c_int32, c_int32, c_int32]),
     'smx_linear_wgrad_splitk_f32': (c_int32, [_P, c_int32, _P, c_int32, _P, c_int32, _P, c_int32,
                                               c_int32, c_int32, _P, c_int64, _P]),
+    'smx_linear_wgrad_splitk_pair_f32': (c_int32, [_P, c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P,
+                                                    c_int32, _P, _P, c_int32, _P, c_int64, _P]),
     'smx_im2col_f32': (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32,
                                  c_int32, c_int32, c_float, _P, _P]),
     'smx_col2im_f32': (c_int32, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

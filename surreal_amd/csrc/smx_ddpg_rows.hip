@@ -491,6 +491,13 @@ int fill(RArgs& G, const smx_ddpg_rows_t* a) {
     const Dims d = dims_of(*a);
     SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
     SMX_REQUIRE(a->rows > 0 && a->rows < (1 << 24), SMX_E_SHAPE);
+    {   // every row-major output is addressed through a buffer descriptor: 31-bit byte offsets
+        int widest = d.c1 + d.A;
+        widest = d.H1 > widest ? d.H1 : widest;
+        widest = d.c2 > widest ? d.c2 : widest;
+        widest = d.H2 > widest ? d.H2 : widest;
+        SMX_REQUIRE((int64_t)a->rows * widest * 4 < (1ll << 31), SMX_E_SHAPE);
+    }
     SMX_REQUIRE(((uintptr_t)a->packed & 15) == 0, SMX_E_ALIGN);
     const smx_ddpg_net_t* nets[4] = {&a->actor, &a->critic, &a->target_actor, &a->target_critic};
     for (int k = 0; k < 4; ++k)

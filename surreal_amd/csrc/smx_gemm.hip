@@ -777,6 +777,42 @@ inline bool launch_tiles(GemmBatch& G, hipStream_t st, int& rc) {
     return true;
 }
 
+// would launch_batch() hand this weight-gradient batch to the 64 x 64 tile kernel (below: `wide && wgs >= 512` and the
+// tile kernel's operand rules)?  Callers that MERGE batches ask first: a merge must not move a problem to another kernel
+// (another summation order).
+inline bool wgrad_batch_takes_tiles(const GemmBatch& G) {
+    static const bool off = getenv("SMX_GEMM_ROWS_ONLY") != nullptr;
+    if (off) return false;
+    bool wide = true;
+    long wgs = 0;
+    int am = -1, bm = -1;
+    for (int k = 0; k < G.n; ++k) {
+        const GemmProb& P = G.p[k];
+        wide = wide && P.K >= 2048 && P.M >= 48 && !P.sumsq;
+        wgs += (long)((P.M + 63) / 64) * ((P.N + 63) / 64) * P.splits;
+        int a, b;
+        if (!tile_mode_of(P.A, P.lda, P.a_kc, P.a_mode, a) || !tile_mode_of(P.B, P.ldb, P.b_kc, P.b_mode, b)) return false;
+        if (P.N < 64 || (P.splits > 1 ? P.k_chunk : P.K) < 32 || P.sumsq) return false;
+        if (k && (a != am || b != bm)) return false;
+        am = a; bm = b;
+    }
+    return wide && wgs >= 512;
+}
+// problems of `src` appended to `dst` (tile bases renumbered)
+inline void batch_append(GemmBatch& dst, const GemmBatch& src) {
+    int base = 0;
+    if (dst.n) {
+        const GemmProb& L = dst.p[dst.n - 1];
+        base = L.tile_base + L.tiles_m * L.tiles_n * L.splits;
+    }
+    for (int k = 0; k < src.n; ++k) {
+        GemmProb& P = dst.p[dst.n++];
+        P = src.p[k];
+        P.tile_base = base;
+        base += P.tiles_m * P.tiles_n * P.splits;
+    }
+}
+
 inline int launch_batch(GemmBatch& G, hipStream_t st) {
     for (int k = 0; k < G.n; ++k)
         if (!prob_ok(G.p[k])) return SMX_E_SHAPE;
@@ -980,6 +1016,30 @@ inline int pick_splits(int M, int N, int rows) {
     return s < 2 ? 1 : s;
 }
 
+// the second launch of a split-K weight gradient: the chunks' partial tiles added in chunk order
+inline int splitk_reduce_launch(float* part, float* dbpart, int splits, int M, int N, float* dW, int ldw, float* db,
+                                hipStream_t st) {
+    const long total = (long)M * N + M;
+    if (ldw == N && splits > 32) {
+        // many chunks: 16 slices of the split index per element in parallel, combined in slice order (one thread per
+        // element walking 248 partials measured 67 us for a 400 x 100 gradient)
+        RedSegs L;
+        L.n = db ? 2 : 1;
+        L.g[0] = RedSeg{part, dW, 0, M * N};
+        L.g[1] = RedSeg{dbpart, db, M * N, M};
+        L.total = db ? (int)total : M * N;
+        hipLaunchKernelGGL(segmented_reduce_kernel, dim3((unsigned)((L.total + 15) / 16)), dim3(256), 0, st, L, splits,
+                           (const int*)nullptr);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? SMX_OK : (int)e;
+    }
+    long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dbpart, splits, M, N, dW, ldw, db);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SMX_OK : (int)e;
+}
+
 }  // namespace
 
 extern "C" int64_t smx_linear_wgrad_ws_floats(int32_t M, int32_t N, int32_t rows) {
@@ -1030,26 +1090,55 @@ extern "C" int smx_linear_wgrad_splitk_f32(const float* dZ, int32_t ldz, const f
         const int rc = launch_batch(G, smx_s(stream));
         if (rc) return rc;
     }
-    const long total = (long)M * N + M;
-    if (ldw == N && G.p[0].splits > 32) {
-        // many chunks: 16 slices of the split index per element in parallel, combined in slice order (one thread per
-        // element walking 248 partials measured 67 us for a 400 x 100 gradient)
-        RedSegs L;
-        L.n = db ? 2 : 1;
-        L.g[0] = RedSeg{part, dW, 0, M * N};
-        L.g[1] = RedSeg{dbpart, db, M * N, M};
-        L.total = db ? (int)total : M * N;
-        hipLaunchKernelGGL(segmented_reduce_kernel, dim3((unsigned)((L.total + 15) / 16)), dim3(256), 0, smx_s(stream), L,
-                           G.p[0].splits, (const int*)nullptr);
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? SMX_OK : (int)e;
+    return splitk_reduce_launch(part, dbpart, G.p[0].splits, M, N, dW, ldw, db, smx_s(stream));
+}
+
+extern "C" int smx_linear_wgrad_splitk_pair_f32(const float* dZ, int32_t ldz, int32_t M, int32_t rows, const float* X1,
+                                                int32_t ldx1, float* dW1, float* db1, int32_t N1, const float* X2,
+                                                int32_t ldx2, float* dW2, float* db2, int32_t N2, float* ws,
+                                                int64_t ws_floats, smx_stream_t stream) {
+    SMX_REQUIRE(dZ && X1 && dW1 && X2 && dW2, SMX_E_NULL);
+    SMX_REQUIRE(M > 0 && N1 > 0 && N2 > 0 && rows > 0 && ldz >= M && ldx1 >= N1 && ldx2 >= N2, SMX_E_SHAPE);
+    const int S1 = pick_splits(M, N1, rows), S2 = pick_splits(M, N2, rows);
+    const int64_t need1 = S1 > 1 ? (int64_t)S1 * ((int64_t)M * N1 + M) : 0, need2 = S2 > 1 ? (int64_t)S2 * ((int64_t)M * N2 + M) : 0;
+    static const bool tiled_only = getenv("SMX_WGRAD_TILED") != nullptr;
+    static const bool no_pair = getenv("SMX_WGRAD_NO_PAIR") != nullptr;       // A/B switch
+    bool pair = !no_pair && S1 > 1 && S2 > 1 && ws && ws_floats >= need1 + need2;
+    pair = pair && (tiled_only || (!smx_wgrad_rows_eligible(dZ, ldz, X1, ldx1, M, N1, rows) &&
+                                   !smx_wgrad_rows_eligible(dZ, ldz, X2, ldx2, M, N2, rows)));
+    GemmBatch G, G1, G2;
+    float* part[2] = {ws, ws + need1};
+    if (pair) {
+        const float* X[2] = {X1, X2};
+        const int ldx[2] = {ldx1, ldx2}, N[2] = {N1, N2}, S[2] = {S1, S2};
+        G.n = 0;
+        int base = 0;
+        for (int k = 0; k < 2; ++k) {
+            GemmProb& P = G.p[G.n++];
+            fill_prob(P, dZ, ldz, 0, X[k], ldx[k], 0, nullptr, nullptr, part[k], N[k], M, N[k], rows, SMX_ACT_NONE,
+                      part[k] + (size_t)S[k] * M * N[k], nullptr, base);
+            P.splits = S[k];
+            P.k_chunk = ((rows + S[k] - 1) / S[k] + 31) & ~31;
+            P.c_split = (long)M * N[k];
+            while ((long)(P.splits - 1) * P.k_chunk >= rows) --P.splits;      // every chunk non-empty
+            base += P.tiles_m * P.tiles_n * P.splits;
+        }
+        G1.n = G2.n = 1;
+        G1.p[0] = G.p[0];
+        G2.p[0] = G.p[1]; G2.p[0].tile_base = 0;
+        // each problem must stay on the kernel it has alone (the 32 x 32 one)
+        pair = !wgrad_batch_takes_tiles(G1) && !wgrad_batch_takes_tiles(G2) && !wgrad_batch_takes_tiles(G);
     }
-    long blocks = (total + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, smx_s(stream), part,
-                       dbpart, G.p[0].splits, M, N, dW, ldw, db);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SMX_OK : (int)e;
+    if (!pair) {
+        const int rc = smx_linear_wgrad_splitk_f32(dZ, ldz, X1, ldx1, dW1, N1, db1, M, N1, rows, ws, ws_floats, stream);
+        if (rc) return rc;
+        return smx_linear_wgrad_splitk_f32(dZ, ldz, X2, ldx2, dW2, N2, db2, M, N2, rows, ws, ws_floats, stream);
+    }
+    int rc = launch_batch(G, smx_s(stream));
+    if (rc) return rc;
+    rc = splitk_reduce_launch(part[0], part[0] + (size_t)S1 * M * N1, G.p[0].splits, M, N1, dW1, N1, db1, smx_s(stream));
+    if (rc) return rc;
+    return splitk_reduce_launch(part[1], part[1] + (size_t)S2 * M * N2, G.p[1].splits, M, N2, dW2, N2, db2, smx_s(stream));
 }
 
 // ---------------------------------------------------------------------------
@@ -1307,6 +1396,12 @@ static int mlp3_wgrads_splitk(const smx_mlp3_t* net, const float* x, const float
     if (Gd.n) {
         const int rc = smx_wgrad_rows_launch(Gd, smx_s(stream));
         if (rc) return rc;
+    }
+    // both on the 32 x 32 kernel (the wide layers' batch below the tile kernel's break-even: B*E ~ 10^4 rows): ONE launch --
+    // the output layer's 12 us launch ran behind the hidden layers' instead of beside them
+    if (Gw.n && Gr.n && Gw.n + Gr.n <= MAX_PROBS && !wgrad_batch_takes_tiles(Gw)) {
+        batch_append(Gw, Gr);
+        Gr.n = 0;
     }
     for (GemmBatch* G : {&Gw, &Gr}) {
         if (!G->n) continue;

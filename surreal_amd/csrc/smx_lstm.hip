@@ -1193,17 +1193,16 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     float* gbih = gWhh + (size_t)4 * H * H;
     float* gbhh = gbih + 4 * H;
     const int32_t rows = (int32_t)(B * T);
-    int rc = smx_linear_wgrad_splitk_f32(dgates, 4 * H, x, D, gWih, D, gbih, 4 * H, D, rows, ws,
-                                         ws_floats, stream);
-    if (rc) return rc;
-    return smx_linear_wgrad_splitk_f32(dgates, 4 * H, hprev, H, gWhh, H, gbhh, 4 * H, H, rows, ws,
-                                       ws_floats, stream);
+    // both gradients read the same dgates: ONE split-K launch where both are on the 32 x 32 kernel (B*T ~ 10^4 rows; the
+    // call falls back to two launches by itself when one of them has a kernel of its own at these shapes)
+    return smx_linear_wgrad_splitk_pair_f32(dgates, 4 * H, 4 * H, rows, x, D, gWih, gbih, D, hprev, H, gWhh, gbhh, H, ws,
+                                            ws_floats, stream);
 }
 
 extern "C" int64_t smx_lstm_backward_ws_floats(int32_t D, int32_t H, int64_t B, int32_t T) {
     const int64_t a = smx_linear_wgrad_ws_floats(4 * H, D, (int32_t)(B * T));
     const int64_t b = smx_linear_wgrad_ws_floats(4 * H, H, (int32_t)(B * T));
-    return a > b ? a : b;
+    return a + b;             // (both partial sets at once: smx_linear_wgrad_splitk_pair_f32)
 }
 
 extern "C" int64_t smx_lstm_param_count(int32_t D, int32_t H) {

@@ -693,6 +693,14 @@ class HipKernels(object):
         L.call('smx_linear_wgrad_splitk_f32', L.ptr(dZ), ldz, L.ptr(X), ldx, L.ptr(dW), ldw, L.ptr(db),
                M, N, rows, L.ptr(ws), 0 if ws is None else ws.numel(), self._st())
 
+    def linear_wgrad_pair(self, dZ, X1, dW1, db1, X2, dW2, db2, rows, ws):
+        """dW1 = dZ^T . X1, dW2 = dZ^T . X2 (+ column sums of dZ) -- one split-K launch where both run on the 32 x 32 kernel;
+        ws >= linear_wgrad_ws_floats(M, N1, rows) + linear_wgrad_ws_floats(M, N2, rows) floats"""
+        M, N1, N2 = dW1.shape[0], dW1.shape[1], dW2.shape[1]
+        L.call('smx_linear_wgrad_splitk_pair_f32', L.ptr(dZ), dZ.stride(0), M, rows, L.ptr(X1), X1.stride(0), L.ptr(dW1),
+               L.ptr(db1), N1, L.ptr(X2), X2.stride(0), L.ptr(dW2), L.ptr(db2), N2, L.ptr(ws),
+               0 if ws is None else ws.numel(), self._st())
+
     def linear_wgrad_ws_floats(self, M, N, rows):
         return int(self.lib.smx_linear_wgrad_ws_floats(M, N, rows))
 

@@ -1185,6 +1185,35 @@ def test_linear_wgrad_splitk_matches_fp64(K, M, N, rows):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)          # deterministic
 
 
+@pytest.mark.parametrize('M,N1,N2,rows', [(400, 17, 100, 7936),       # the LSTM's dW_ih / dW_hh at 64 x 124 rows: ONE launch
+                                          (400, 376, 100, 7936), (400, 17, 100, 126976),     # ... a kernel of its own: two
+                                          (400, 17, 100, 900), (36, 5, 70, 4100)])
+def test_linear_wgrad_pair_is_the_two_single_calls_bit_for_bit(K, M, N1, N2, rows):
+    """smx_linear_wgrad_splitk_pair_f32: two weight gradients from the same dZ in one split-K launch where both run on the
+    32 x 32 kernel -- every tile is the same workgroup program on the same chunks, so the results are those of two
+    smx_linear_wgrad_splitk_f32 calls to the last bit (and it IS those two calls where a shape has another kernel)"""
+    g = torch.Generator().manual_seed(M + rows + N1)
+    dz = torch.randn(rows, M, generator=g).cuda()
+    x1, x2 = torch.randn(rows, N1, generator=g).cuda(), torch.randn(rows, N2, generator=g).cuda()
+    n1, n2 = K.linear_wgrad_ws_floats(M, N1, rows), K.linear_wgrad_ws_floats(M, N2, rows)
+    ws = torch.empty(max(n1 + n2, 1), device='cuda')
+    single = []
+    for x, N, n in ((x1, N1, n1), (x2, N2, n2)):
+        dW, db = torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda')
+        K.linear_wgrad(dz, x, dW, db, M, N, rows, ws=ws[:n] if n else None)
+        single += [dW, db]
+    for have_ws in (True, False):
+        out = [torch.full((M, N1), 7.0, device='cuda'), torch.full((M,), 7.0, device='cuda'),
+               torch.full((M, N2), 7.0, device='cuda'), torch.full((M,), 7.0, device='cuda')]
+        K.linear_wgrad_pair(dz, x1, out[0], out[1], x2, out[2], out[3], rows, ws if have_ws and n1 + n2 else None)
+        if have_ws:
+            for a, b in zip(out, single):
+                assert torch.equal(a, b)
+        else:                       # no workspace: the plain kernels (other summation order)
+            for a, b in zip(out, single):
+                close(a.cpu().double(), b.cpu().double(), atol=1e-4 * rows ** 0.5, rtol=1e-4, msg='pair without a workspace')
+
+
 @pytest.mark.parametrize('mode', [L.SMX_PPO_CLIP, L.SMX_PPO_ADAPT])
 @pytest.mark.parametrize('rows,A,world,kl_target', [(1024, 17, 8, 1e9), (100, 6, 2, 1e9), (100, 6, 2, 1e-4),
                                                      (5, 2, 1, 1e9)])
