@@ -13,7 +13,12 @@ def run(B, N, D, A, HID=100, horizon=5, steps=5):
     lc.algo.rnn.if_rnn_policy = True; lc.algo.rnn.rnn_hidden = HID; lc.algo.rnn.horizon = horizon
     lc.algo.consts.kl_target = 1e9
     lc.replay.batch_size = B
-    L = PPOLearner(lc, ppo_env_config(D, A), ppo_session_config('/tmp/x'))
+    sc = ppo_session_config('/tmp/x')
+    import os
+    for kv in filter(None, os.environ.get('SMX_BENCH_LEARNER_OPTS', '').split(',')):     # A/B runs: key=0|1[,key=...]
+        k, v = kv.split('=')
+        sc.learner[k] = bool(int(v))
+    L = PPOLearner(lc, ppo_env_config(D, A), sc)
     batch = synthetic.make_ppo_batch(B, N, D, A, seed=1, rnn_hidden=HID)
     db = L._preprocess_batch_ppo(copy.deepcopy(batch))
     for _ in range(2): L.learn(db)
