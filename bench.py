@@ -501,7 +501,7 @@ def secondary_ddpg(steps=200, cpu=True):
                         'dones': (torch.rand(n, device='cuda', generator=g) < 0.01).float()})
 
     def sample_and_learn():
-        f = R.sample_batch(Bd)
+        f = R.sample_batch(Bd, out=L.staging_fields(Bd))      # gathered where the captured iteration reads its batch
         return L.learn({'obs': {'low_dim': {'flat_inputs': f['obs']}},
                         'obs_next': {'low_dim': {'flat_inputs': f['obs_next']}}, 'actions': f['actions'],
                         'rewards': f['rewards'].view(Bd, 1), 'dones': f['dones'].view(Bd, 1)})
@@ -522,7 +522,7 @@ def secondary_ddpg(steps=200, cpu=True):
     n_par = Pa + 300 + 200 + Ad + Pc + 400 + 300 + 1
     bytes_ = 4.0 * Bd * (2 * Dd + Ad + 2) + 7 * 4.0 * n_par + 2 * 4.0 * n_par
     out = {'ms_per_iteration': dt * 1e3, 'samples_per_s': Bd / dt, 'batch': Bd, 'replay_rows': 1000000,
-           'what': 'uniform sample of 512 out of 1e6 device-resident rows + DDPGLearner.learn',
+           'what': 'uniform sample of 512 out of 1e6 device-resident rows (into the learner\'s staging buffers) + DDPGLearner.learn',
            'roofline': priced(dt, flops, bytes_, Bd, 'samples')}
     out['roofline']['note'] = '~22 dependent launches of 512-row problems: launch-latency-bound, neither roof applies'
     try:

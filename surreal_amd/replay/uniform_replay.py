@@ -66,9 +66,11 @@ class UniformReplay(Replay):
         self._draws += batch_size
         return idx
 
-    def sample_batch(self, batch_size, indices=None):
+    def sample_batch(self, batch_size, indices=None, out=None):
         """one launch for the whole sample (smx_uniform_gather_multi): every field's rows, the indices drawn where they
-        are used -- the same Philox counters as sample_indices(), so the two agree row for row"""
+        are used -- the same Philox counters as sample_indices(), so the two agree row for row.
+        out: {field: tensor} to gather INTO (contiguous, the field's dtype, batch_size rows) -- e.g. a learner's staging
+        buffers (DDPGLearner.staging_fields): the batch then needs no copy on its way into the captured iteration"""
         idx = None if indices is None else torch.as_tensor(indices, dtype=torch.int64).to(self._dev)
         self.cumulative_sampled_count += batch_size
         names = list(self._tables)
@@ -76,7 +78,15 @@ class UniformReplay(Replay):
             idx = self.sample_indices(batch_size) if idx is None else idx
             return {name: tab.gather(idx) for name, tab in self._tables.items()}
         tabs = [self._tables[k] for k in names]
-        outs = [torch.empty(batch_size, t.width, device=self._dev, dtype=t.dtype) for t in tabs]
+        outs = []
+        for k, t in zip(names, tabs):
+            o = None if out is None else out.get(k)
+            if o is None:
+                o = torch.empty(batch_size, t.width, device=self._dev, dtype=t.dtype)
+            else:
+                assert o.is_contiguous() and o.dtype == t.dtype and o.numel() == batch_size * t.width, k
+                o = o.view(batch_size, t.width)
+            outs.append(o)
         self._K.uniform_gather_multi([t.data for t in tabs], outs, self._dev_len, self.seed, self._draws, idx=idx)
         if idx is None:
             self._draws += batch_size

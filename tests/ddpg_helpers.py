@@ -91,3 +91,43 @@ def run_and_check(name, atol=1e-5, rtol=1e-5, opts=None):
             assert np.mean(np.abs(got2[k] - g['final2.' + k]) > 2e-5) < 0.03, k
             np.testing.assert_allclose(tgt2[k], g['target2.' + k], atol=2 * lr * case['iters'] + 1e-6, err_msg=k)
     return L
+
+
+def check_sampling_into_staging(device):
+    """replay.sample_batch(B, out=learner.staging_fields(B)): the sample lands where the captured iteration reads it, no
+    copies -- same rows (same Philox counters), same statistics and parameters, bit for bit, as sampling into fresh
+    tensors and letting learn() stage them"""
+    import torch
+    from surreal_amd.replay import UniformReplay
+    g, case = load('tiny_hard')
+    B, D, A = case['B'], case['D'], case['A']
+    learners = [make_learner(case), make_learner(case)]
+    lc = ddpg_learner_config()
+    lc.replay.batch_size = B
+    lc.replay.memory_size = 5000
+    gen = torch.Generator().manual_seed(3)
+    n = 3000
+    fields = {'obs': torch.randn(n, D, generator=gen), 'obs_next': torch.randn(n, D, generator=gen),
+              'actions': torch.rand(n, A, generator=gen) * 2 - 1, 'rewards': torch.randn(n, generator=gen),
+              'dones': (torch.rand(n, generator=gen) < 0.05).float()}
+    replays = []
+    for _ in range(2):
+        R = UniformReplay(lc, ddpg_env_config(D, A), ddpg_session_config())
+        R.insert_batch({k: v.to(device) for k, v in fields.items()})
+        replays.append(R)
+
+    def batch(f):
+        return {'obs': {'low_dim': {'flat_inputs': f['obs']}}, 'obs_next': {'low_dim': {'flat_inputs': f['obs_next']}},
+                'actions': f['actions'], 'rewards': f['rewards'].view(B, 1), 'dones': f['dones'].view(B, 1)}
+    for it in range(5):
+        f0 = replays[0].sample_batch(B)
+        st0 = dict(learners[0].learn(batch(f0)))
+        stage = learners[1].staging_fields(B)
+        f1 = replays[1].sample_batch(B, out=stage)
+        for k in stage:
+            assert f1[k].data_ptr() == stage[k].data_ptr(), k
+            assert torch.equal(f1[k].reshape(-1), f0[k].reshape(-1)), k
+        st1 = dict(learners[1].learn(batch(f1)))
+        assert st0 == st1, (it, st0, st1)
+    for a, b in ((learners[0].model, learners[1].model), (learners[0].model_target, learners[1].model_target)):
+        assert torch.equal(a.actor_flat, b.actor_flat) and torch.equal(a.critic_flat, b.critic_flat)

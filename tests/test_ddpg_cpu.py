@@ -54,6 +54,10 @@ def test_ddpg_learner_host_logic_row_schedule(name, cpu_double):
     assert getattr(L._ws, 'rows_args', None) is not None
 
 
+def test_replay_samples_straight_into_the_learners_staging_buffers(cpu_double):
+    DH.check_sampling_into_staging('cpu')
+
+
 def test_ddpg_unsupported_switches_raise(cpu_double):
     g, c = DH.load('tiny_hard')
     from surreal_amd.learner.ddpg import DDPGLearner

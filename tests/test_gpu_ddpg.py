@@ -122,3 +122,7 @@ def test_ddpg_stats_against_float64_and_its_nan_check():
             bad[i, j] = float('nan')
             K.ddpg_stats(q, y, r, bad, qa, st)
             assert np.isnan(float(st[6])), (rows, A, i, j)
+
+
+def test_replay_samples_straight_into_the_learners_staging_buffers():
+    DH.check_sampling_into_staging('cuda')
