@@ -39,7 +39,6 @@ from surreal_amd import kernels as KN
 from surreal_amd.learner.aggregator import MultistepAggregatorWithInfo
 from surreal_amd.learner.base import Learner, DeferredStats
 from surreal_amd.model.ppo_net import DiagGauss, PPOModel
-from surreal_amd.utils import AttrDict
 
 
 class LinearWithMinLR(object):
