@@ -1,0 +1,8 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+{
+python -m pytest tests/test_gpu_kernels.py -q -m gpu -x -k "lstm" 2>&1 | tail -12
+echo "== 1024 x 128 LSTM, matrix-pipe recurrences"; python scripts/bench_rnn_one.py 1024 128 17 6 2>&1 | tail -1
+echo "== vector recurrences"; SMX_LSTM_NO_MROWS=1 python scripts/bench_rnn_one.py 1024 128 17 6 2>&1 | tail -1
+echo "== cfg5 LSTM, matrix-pipe"; python scripts/bench_rnn_one.py 1024 128 376 17 2>&1 | tail -1
+echo "== vector"; SMX_LSTM_NO_MROWS=1 python scripts/bench_rnn_one.py 1024 128 376 17 2>&1 | tail -1
+} > gpurun_out/r05_mrows.log 2>&1

@@ -1052,6 +1052,262 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
 #undef SMX_BWDK_FETCH
 }
 
+// ===========================================================================================
+// Round 5: FOUR batch rows per workgroup on v_mfma_f32_4x4x1_16B (H <= 112), for B >= 1024 -- where every CU holds a
+// workgroup, the recurrence is throughput-, not latency-bound, and the vector kernels above spend 0.45 of a step issuing
+// multiply-adds (lstm_fwdk / lstm_bwdk at four rows: 2.7 - 2.9 us per step and CU).  One v_mfma_f32_4x4x1 is 16
+// independent 4 x 4 outer products: lane 4 b + i supplies row i of block b's A, lane 4 b + j column j of its B, and holds
+// column j of its 4 x 4 result.  Round 2's 4-row kernels (lstm_fwd4 / lstm_bwd4_kernel above, SMX_LSTM_MFMA4=1) used it with
+// gate columns in lane order; their results met in LDS, with two barriers and libm's expf / tanhf per step.  Here the
+// blocks are laid out so that NOTHING crosses wavefronts inside a step:
+//   forward   block b of wave w = hidden unit 16 w + b, its columns j = the unit's four gates (B = W_hh[j H + unit][k] in
+//             registers, A = h_{t-1}[i][k] from LDS, the same for every block).  A lane then holds gate j of its unit for
+//             the 4 rows, activates them (hardware exp2 / rcp), the quad exchanges gates by DPP, and lane j forms c_t, h_t
+//             of ROW j -- 16 units x 4 rows = the wave's 64 lanes.  h_t goes to the other LDS buffer: ONE barrier per step.
+//             FOLD (D <= 20): the input half of the gates is D more k-steps against x_t from LDS (W_ih in registers).
+//   backward  dh_rec = dgates . W_hh: block b = (gate block gb = b >> 2, column quad c = b & 3): A = dgates_t[i][gb H + k]
+//             from LDS, B = W_hh[gb H + k][16 w + 4 c + j]; the four gate blocks' partial sums of a column sit 16 lanes
+//             apart and meet by two cross-lane adds; lane (gb, c, j) then does the element-wise step of ROW gb of its
+//             column.  The step's inputs are requested one step ahead.  ONE barrier per step.
+// Four accumulators per lane (k mod 4) instead of one chain of 100 dependent MFMAs, added (x + y) + (z + w).
+// ===========================================================================================
+template <int KQ, bool FOLD>      // H <= 4 KQ <= 112
+__global__ __launch_bounds__(NT) void lstm_fwdm_kernel(FwdArgs a) {
+    if (a.stop && *a.stop) return;
+    constexpr int HS = KQ * 4 + 4;             // h row stride in LDS (columns >= H stay zero)
+    constexpr int XS = 24 + 4;                 // x row stride (D <= 20, zero padded)
+    __shared__ float hs[2][4][HS];
+    __shared__ float xs[2][4][XS];
+    const int H = a.H, G = 4 * H, T = a.T, D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 4;
+    const int g = lane & 3, unit = 16 * wv + (lane >> 2);
+    const bool uv = unit < H;
+    const bool wave_on = 16 * wv < H;          // (uniform) this wave has units
+    const int col = uv ? g * H + unit : 0;     // gate column of this lane
+    float4 wq[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+        wq[q] = (uv && 4 * q < H) ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + 4 * q)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 wi[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (FOLD && uv && 4 * q + j < D) v[j] = a.W_ih[(size_t)col * D + 4 * q + j];
+        wi[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const float bias = uv ? (FOLD ? a.b_hh[col] + a.b_ih[col] : a.b_hh[col]) : 0.f;
+    const bool is_g = g == 2;                  // the cell candidate: tanh; the other gates: sigmoid
+    // element-wise role: row g of this lane's unit
+    const bool inb = uv && row0 + g < a.B;
+    const size_t erow = (size_t)(inb ? row0 + g : row0);
+    float creg = (inb && a.c0) ? a.c0[erow * H + unit] : 0.f;
+    float* const orow = a.out + erow * T * H;
+    float* const crow = a.cs + erow * T * H;
+    float* const prow = a.hprev ? a.hprev + erow * T * H : nullptr;
+    for (int i = tid; i < 2 * 4 * HS; i += NT) (&hs[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * 4 * XS; i += NT) (&xs[0][0][0])[i] = 0.f;
+    __syncthreads();
+    if (inb && a.h0) hs[0][g][unit] = a.h0[erow * H + unit];
+    // the gates buffer of the four rows (rows past the batch read row0's: never stored)
+    bool rv[4];
+    float* grow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rv[r] = row0 + r < a.B;
+        grow[r] = a.gates + (size_t)(rv[r] ? row0 + r : row0) * T * G;
+    }
+    const unsigned ucol = (unsigned)col, un = (unsigned)unit;
+    // not FOLD: the input half (smx_linear_f32 wrote it), requested four steps ahead (see lstm_fwdk_kernel)
+    float gx0[4], gx1[4], gx2[4], gx3[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        gx0[r] = (!FOLD && uv) ? grow[r][ucol] : 0.f;
+        gx1[r] = (!FOLD && uv && 1 < T) ? (grow[r] + G)[ucol] : 0.f;
+        gx2[r] = (!FOLD && uv && 2 < T) ? (grow[r] + 2 * G)[ucol] : 0.f;
+        gx3[r] = (!FOLD && uv && 3 < T) ? (grow[r] + 3 * (size_t)G)[ucol] : 0.f;
+    }
+    // FOLD staging role: lane tid < 80 carries input xj of row xr through a four-step ring into LDS
+    const int xr = tid / 20, xj = tid - 20 * xr;
+    const bool xlane = FOLD && tid < 80 && xj < D && row0 + xr < a.B;
+    const float* const xrow = FOLD ? a.x + (size_t)(row0 + (xlane ? xr : 0)) * T * D + (xlane ? xj : 0) : nullptr;
+    float xg0 = 0.f, xg1 = 0.f, xg2 = 0.f, xg3 = 0.f;
+    if (xlane) {
+        xs[0][xr][xj] = xrow[0];
+        xg0 = (1 < T) ? xrow[(size_t)1 * D] : 0.f;
+        xg1 = (2 < T) ? xrow[(size_t)2 * D] : 0.f;
+        xg2 = (3 < T) ? xrow[(size_t)3 * D] : 0.f;
+        xg3 = (4 < T) ? xrow[(size_t)4 * D] : 0.f;
+    }
+    __syncthreads();
+#define SMX_FWDM_STEP(GX, XG, TT)                                                                                        \
+    if ((TT) < T) {                                                                                                    \
+        const int t = (TT);                                                                                            \
+        const int p = t & 1;                                                                                           \
+        float act[4] = {0.f, 0.f, 0.f, 0.f};                                                                           \
+        if (wave_on) {                                                                                                 \
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;                                                \
+            const float* hrow = &hs[p][g][0];                                                                          \
+            _Pragma("unroll") for (int q = 0; q < KQ; ++q) {                                                           \
+                const float4 hv = *reinterpret_cast<const float4*>(hrow + 4 * q);                                     \
+                ax = MFMA4(hv.x, wq[q].x, ax);                                                                         \
+                ay = MFMA4(hv.y, wq[q].y, ay);                                                                         \
+                az = MFMA4(hv.z, wq[q].z, az);                                                                         \
+                aw = MFMA4(hv.w, wq[q].w, aw);                                                                         \
+            }                                                                                                          \
+            if (FOLD) {                                                                                                \
+                const float* xrw = &xs[p][g][0];                                                                       \
+                _Pragma("unroll") for (int q = 0; q < 5; ++q) {                                                        \
+                    const float4 xv = *reinterpret_cast<const float4*>(xrw + 4 * q);                                  \
+                    ax = MFMA4(xv.x, wi[q].x, ax);                                                                     \
+                    ay = MFMA4(xv.y, wi[q].y, ay);                                                                     \
+                    az = MFMA4(xv.z, wi[q].z, az);                                                                     \
+                    aw = MFMA4(xv.w, wi[q].w, aw);                                                                     \
+                }                                                                                                      \
+            }                                                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
+                const float pre = GX[r] + (((ax[r] + ay[r]) + (az[r] + aw[r])) + bias);                                \
+                const float sg = fast_sigm(is_g ? 2.f * pre : pre);                                                  \
+                act[r] = is_g ? 2.f * sg - 1.f : sg;                                                                   \
+                float* const gstep = grow[r] + (size_t)t * G;                                                          \
+                if (uv && rv[r]) gstep[ucol] = act[r];                                                                 \
+                GX[r] = (!FOLD && uv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (xlane) {                            /* x_{t+1} into the other buffer; the ring moves on */                 \
+            xs[1 - p][xr][xj] = XG;                                                                                    \
+            XG = (t + 5 < T) ? xrow[(size_t)(t + 5) * D] : 0.f;                                                        \
+        }                                                                                                              \
+        /* the four gates of row g of this unit: lane j of the quad holds gate j of every row */                       \
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                \
+            const float vi = quad_bcast<0>(act[r]), vf = quad_bcast<1>(act[r]), vg = quad_bcast<2>(act[r]),            \
+                        vo = quad_bcast<3>(act[r]);                                                                    \
+            if (g == r) { gi = vi; gf = vf; gg = vg; go = vo; }                                                        \
+        }                                                                                                              \
+        const float c = gf * creg + gi * gg;                                                                           \
+        const float h = go * fast_tanh(c);                                                                             \
+        creg = c;                                                                                                      \
+        if (inb) {                                                                                                     \
+            (orow + (size_t)t * H)[un] = h;                                                                            \
+            (crow + (size_t)t * H)[un] = c;                                                                            \
+            if (prow) (prow + (size_t)t * H)[un] = hs[p][g][unit];                                                     \
+            hs[1 - p][g][unit] = h;                                                                                    \
+        }                                                                                                              \
+        LSTM_LDS_BARRIER();                                                                                            \
+    }
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        SMX_FWDM_STEP(gx0, xg0, t0)
+        SMX_FWDM_STEP(gx1, xg1, t0 + 1)
+        SMX_FWDM_STEP(gx2, xg2, t0 + 2)
+        SMX_FWDM_STEP(gx3, xg3, t0 + 3)
+    }
+#undef SMX_FWDM_STEP
+    if (inb) {
+        if (a.hN) a.hN[erow * H + unit] = hs[T & 1][g][unit];
+        if (a.cN) a.cN[erow * H + unit] = creg;
+    }
+}
+
+template <int KQ>                 // H <= 4 KQ <= 112
+__global__ __launch_bounds__(NT) void lstm_bwdm_kernel(BwdArgs a) {
+    if (a.stop && *a.stop) return;
+    constexpr int KB = KQ * 4;                 // a gate block's stride in the dgates tile (zero padded past H)
+    constexpr int DS = 4 * KB + 4;
+    __shared__ float dg[2][4][DS];             // the step's dgates: [row][gate block gb at gb KB]
+    const int H = a.H, G = 4 * H, T = a.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 4;
+    const int gb = lane >> 4, j = lane & 3;
+    const int n = 16 * wv + (lane & 15);       // hidden column of this lane: 16 w + 4 c + j
+    const bool nv = n < H;
+    const bool wave_on = 16 * wv < H;
+    float4 wq[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nv && 4 * q < H) {
+            const float* p = a.W_hh + ((size_t)gb * H + 4 * q) * H + n;
+            w.x = p[0]; w.y = p[H]; w.z = p[2 * (size_t)H]; w.w = p[3 * (size_t)H];
+        }
+        wq[q] = w;
+    }
+    for (int i = tid; i < 2 * 4 * DS; i += NT) (&dg[0][0][0])[i] = 0.f;
+    // element-wise role: row gb of column n
+    const bool inb = nv && row0 + gb < a.B;
+    const size_t erow = (size_t)(inb ? row0 + gb : row0);
+    const float* const grow = a.gates + erow * T * G;
+    float* const dgrow = a.dgates + erow * T * G;
+    const float* const crow = a.cs + erow * T * H;
+    const float* const drow = a.dout + erow * T * H;
+    const unsigned un = (unsigned)(nv ? n : 0);
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cp = 0.f, dout = 0.f, dcreg = 0.f, dhr = 0.f;
+#define SMX_BWDM_FETCH(t, xi, xf, xg, xo, xcp, xd)                                                                     \
+    do {                                                                                                             \
+        const float* gp_ = grow + (size_t)(t) * G;                                                                   \
+        xi = gp_[un]; xf = (gp_ + H)[un]; xg = (gp_ + 2 * H)[un]; xo = (gp_ + 3 * (size_t)H)[un];                    \
+        xcp = ((t) > 0) ? (crow + (size_t)((t) - 1) * H)[un] : (a.c0 ? a.c0[erow * H + un] : 0.f);                   \
+        xd = (drow + (size_t)(t) * H)[un];                                                                           \
+    } while (0)
+    if (inb) {
+        SMX_BWDM_FETCH(T - 1, gi, gf, gg, go, cp, dout);
+        c = (crow + (size_t)(T - 1) * H)[un];
+    }
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const int p = t & 1;
+        float ni = 0.f, nf = 0.f, ng = 0.f, no = 0.f, ncp = 0.f, nd = 0.f;
+        if (inb && t > 0) SMX_BWDM_FETCH(t - 1, ni, nf, ng, no, ncp, nd);          // the next step's inputs: requested early
+        {
+            const float dh = dout + dhr;
+            const float tc = fast_tanh(c);             // (the forward pass formed h with the same function)
+            const float dc = dcreg + (dh * go) * (1.f - tc * tc);
+            const float dgi = (dc * gg) * (gi * (1.f - gi));
+            const float dgf = (dc * cp) * (gf * (1.f - gf));
+            const float dgg = (dc * gi) * (1.f - gg * gg);
+            const float dgo = (dh * tc) * (go * (1.f - go));
+            dcreg = dc * gf;
+            if (inb) {
+                float* dp = dgrow + (size_t)t * G;
+                dp[un] = dgi; (dp + H)[un] = dgf; (dp + 2 * H)[un] = dgg; (dp + 3 * (size_t)H)[un] = dgo;
+                float* dl = &dg[p][gb][n];
+                dl[0] = dgi; dl[KB] = dgf; dl[2 * KB] = dgg; dl[3 * KB] = dgo;
+            }
+        }
+        LSTM_LDS_BARRIER();
+        if (t > 0 && wave_on) {
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;
+            const float* arow = &dg[p][j][gb * KB];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float4 dv = *reinterpret_cast<const float4*>(arow + 4 * q);
+                ax = MFMA4(dv.x, wq[q].x, ax);
+                ay = MFMA4(dv.y, wq[q].y, ay);
+                az = MFMA4(dv.z, wq[q].z, az);
+                aw = MFMA4(dv.w, wq[q].w, aw);
+            }
+            // the four gate blocks' partial sums of a column sit 16 lanes apart: (p + p^16) + (. ^32) -- the same two
+            // sums in every lane (a + b = b + a), so all four copies are bit-identical
+            float tot[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = (ax[r] + ay[r]) + (az[r] + aw[r]);
+                const float s2 = s + __shfl_xor(s, 16, 64);
+                tot[r] = s2 + __shfl_xor(s2, 32, 64);
+            }
+            dhr = gb == 0 ? tot[0] : (gb == 1 ? tot[1] : (gb == 2 ? tot[2] : tot[3]));
+        }
+        c = cp;
+        gi = ni; gf = nf; gg = ng; go = no; cp = ncp; dout = nd;
+    }
+#undef SMX_BWDM_FETCH
+}
+
 constexpr int KQ4 = 28;          // 4-row kernels: H <= 112
 
 inline size_t lds4_fwd(int kq) { return (size_t)RB4 * ((kq * 4 + 4) + (NWV * 64 + 4)) * sizeof(float); }
@@ -1094,7 +1350,18 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     a.x = x; a.W_ih = net->W_ih; a.b_ih = net->b_ih; a.D = D;
     const int blocks = (int)((B + RB - 1) / RB);
     // H <= 128: one row per workgroup on the vector ALU (SMX_LSTM_MFMA4=1 keeps the 4-row MFMA kernels for A/B runs)
-    if (fold) {
+    // B >= 1024 (a workgroup on every CU): four rows per workgroup on the matrix pipes (lstm_fwdm_kernel); SMX_LSTM_NO_MROWS=1
+    // keeps the vector kernels for A/B runs
+    static const bool no_mrows = getenv("SMX_LSTM_NO_MROWS") != nullptr;
+    static const long mrows_min = getenv("SMX_LSTM_MROWS_MIN") ? atol(getenv("SMX_LSTM_MROWS_MIN")) : 1024;   // (measurements)
+    const bool mrows = !no_mrows && !mfma4 && !v1 && !quad && H <= 112 && B >= mrows_min;
+    if (mrows) {
+        const dim3 grid((unsigned)((B + 3) / 4));
+        if (fold && H <= 100) hipLaunchKernelGGL((lstm_fwdm_kernel<25, true>), grid, dim3(NT), 0, smx_s(stream), a);
+        else if (fold) hipLaunchKernelGGL((lstm_fwdm_kernel<28, true>), grid, dim3(NT), 0, smx_s(stream), a);
+        else if (H <= 100) hipLaunchKernelGGL((lstm_fwdm_kernel<25, false>), grid, dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_fwdm_kernel<28, false>), grid, dim3(NT), 0, smx_s(stream), a);
+    } else if (fold) {
         // (four rows per workgroup with the 20 extra weights: 256 registers and spills -- two it is)
         if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2, true>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
         else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1, true>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
@@ -1153,7 +1420,13 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     static const bool mfma4 = getenv("SMX_LSTM_MFMA4") != nullptr;
     static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;
     static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;
-    if (!mfma4 && !v1 && !quad && H <= 104) {
+    static const bool no_mrows = getenv("SMX_LSTM_NO_MROWS") != nullptr;
+    static const long mrows_min = getenv("SMX_LSTM_MROWS_MIN") ? atol(getenv("SMX_LSTM_MROWS_MIN")) : 1024;
+    if (!no_mrows && !mfma4 && !v1 && !quad && H <= 112 && B >= mrows_min) {
+        const dim3 grid((unsigned)((B + 3) / 4));
+        if (H <= 100) hipLaunchKernelGGL((lstm_bwdm_kernel<25>), grid, dim3(NT), 0, smx_s(stream), a);
+        else hipLaunchKernelGGL((lstm_bwdm_kernel<28>), grid, dim3(NT), 0, smx_s(stream), a);
+    } else if (!mfma4 && !v1 && !quad && H <= 104) {
         if (B >= 1024) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 4>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
         else if (B >= 512) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
         else hipLaunchKernelGGL((lstm_bwdk_kernel<13, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
