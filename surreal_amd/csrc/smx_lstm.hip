@@ -6,10 +6,11 @@
 //   * the input half of the gates, x . W_ih^T + b_ih, has no time dependence: one GEMM over all
 //     B*T rows (smx_linear_f32) before the recurrent kernel;
 //   * per step the recurrent half h_{t-1} . W_hh^T with h_{t-1} read from LDS:
-//     H <= 128 (the reference default is 100): ONE row per workgroup on the vector ALU, thread = gate column with its
-//     W_hh row in REGISTERS for the whole sequence (lstm_fwd1 / lstm_bwd1_kernel; the 4-row v_mfma_f32_4x4x1 kernels
-//     it replaced remain behind SMX_LSTM_MFMA4=1); larger H: 16 rows on FP32 MFMA 16x16x4, W_hh fragments re-read
-//     from L2 every step;
+//     H <= 128 (the reference default is 100), B < 512: ONE row per workgroup on the vector ALU, a unit's four gates in a
+//     quad of lanes with their W_hh rows in REGISTERS for the whole sequence (lstm_fwdk / lstm_bwdk_kernel; the kernels
+//     they replaced remain behind SMX_LSTM_V1 / _QUAD / _MFMA4 for A/B runs); B >= 512 (H <= 112): FOUR rows per
+//     workgroup on v_mfma_f32_4x4x1 (lstm_fwdm / lstm_bwdm_kernel, round 5); larger H: 16 rows on FP32 MFMA 16x16x4, W_hh
+//     fragments re-read from L2 every step;
 //   * the cell update is elementwise on a fixed (row, unit) -> thread map; h_t goes back to LDS.
 // Backward is the mirror image (t = T-1 .. 0, dh_rec = dgates_t . W_hh on MFMA), followed by the
 // weight-gradient GEMMs over all B*T rows (split-K).
@@ -1350,10 +1351,11 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
     a.x = x; a.W_ih = net->W_ih; a.b_ih = net->b_ih; a.D = D;
     const int blocks = (int)((B + RB - 1) / RB);
     // H <= 128: one row per workgroup on the vector ALU (SMX_LSTM_MFMA4=1 keeps the 4-row MFMA kernels for A/B runs)
-    // B >= 1024 (a workgroup on every CU): four rows per workgroup on the matrix pipes (lstm_fwdm_kernel); SMX_LSTM_NO_MROWS=1
-    // keeps the vector kernels for A/B runs
+    // B >= 512: four rows per workgroup on the matrix pipes (lstm_fwdm_kernel; measured against the vector kernels at
+    // 128 steps: 23.2 vs 23.7 ms per learn at 512 sequences, 28.7 vs 38.3 at 768, 34.0 vs 39.2 at 1024 -- and 17.7 vs 13.8
+    // at 256, where one row per workgroup fills the chip).  SMX_LSTM_NO_MROWS=1 keeps the vector kernels for A/B runs
     static const bool no_mrows = getenv("SMX_LSTM_NO_MROWS") != nullptr;
-    static const long mrows_min = getenv("SMX_LSTM_MROWS_MIN") ? atol(getenv("SMX_LSTM_MROWS_MIN")) : 1024;   // (measurements)
+    static const long mrows_min = getenv("SMX_LSTM_MROWS_MIN") ? atol(getenv("SMX_LSTM_MROWS_MIN")) : 512;   // (measurements)
     const bool mrows = !no_mrows && !mfma4 && !v1 && !quad && H <= 112 && B >= mrows_min;
     if (mrows) {
         const dim3 grid((unsigned)((B + 3) / 4));
@@ -1366,9 +1368,8 @@ extern "C" int smx_lstm_forward_f32(const smx_lstm_t* net, const float* x, int64
         if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2, true>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
         else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1, true>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 112) {
-        // rows per workgroup: as many as keep >= 256 workgroups (one per CU), at most 4
-        if (B >= 1024) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 4, false>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
-        else if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2, false>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        // (B >= 512 reaches this only with SMX_LSTM_NO_MROWS: two rows per workgroup)
+        if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<7, 2, false>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
         else hipLaunchKernelGGL((lstm_fwdk_kernel<7, 1, false>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 128) {
         if (B >= 512) hipLaunchKernelGGL((lstm_fwdk_kernel<8, 2, false>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
@@ -1421,14 +1422,13 @@ extern "C" int smx_lstm_backward_f32(const smx_lstm_t* net, const float* x, int6
     static const bool v1 = getenv("SMX_LSTM_V1") != nullptr;
     static const bool quad = getenv("SMX_LSTM_QUAD") != nullptr;
     static const bool no_mrows = getenv("SMX_LSTM_NO_MROWS") != nullptr;
-    static const long mrows_min = getenv("SMX_LSTM_MROWS_MIN") ? atol(getenv("SMX_LSTM_MROWS_MIN")) : 1024;
+    static const long mrows_min = getenv("SMX_LSTM_MROWS_MIN") ? atol(getenv("SMX_LSTM_MROWS_MIN")) : 512;
     if (!no_mrows && !mfma4 && !v1 && !quad && H <= 112 && B >= mrows_min) {
         const dim3 grid((unsigned)((B + 3) / 4));
         if (H <= 100) hipLaunchKernelGGL((lstm_bwdm_kernel<25>), grid, dim3(NT), 0, smx_s(stream), a);
         else hipLaunchKernelGGL((lstm_bwdm_kernel<28>), grid, dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 104) {
-        if (B >= 1024) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 4>), dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, smx_s(stream), a);
-        else if (B >= 512) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
+        if (B >= 512) hipLaunchKernelGGL((lstm_bwdk_kernel<13, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);
         else hipLaunchKernelGGL((lstm_bwdk_kernel<13, 1>), dim3((unsigned)B), dim3(NT), 0, smx_s(stream), a);
     } else if (!mfma4 && !v1 && !quad && H <= 128) {
         if (B >= 512) hipLaunchKernelGGL((lstm_bwdk_kernel<16, 2>), dim3((unsigned)((B + 1) / 2)), dim3(NT), 0, smx_s(stream), a);

@@ -963,13 +963,13 @@ def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
     (37, 9, 17, 100, False),     # ragged rows, zero initial state
     (64, 21, 17, 100, True),     # cfg2-sized batch
     (6, 7, 9, 108, True),        # 100 < H <= 112: the wider 4-row instantiation
-    (1024, 3, 17, 100, True),    # four rows per workgroup (B >= 1024): 256 workgroups, v_mfma_f32_4x4x1 (lstm_fwdm / bwdm)
+    (1024, 3, 17, 100, True),    # B >= 512: four rows per workgroup on v_mfma_f32_4x4x1 (lstm_fwdm / bwdm): 256 workgroups
     (1027, 6, 17, 100, True),    # ... with a ragged last workgroup (3 of 4 rows)
-    (1026, 4, 9, 108, True),     # B >= 1024: four rows per workgroup on the matrix pipes, the 100 < H <= 112 instantiation
+    (1026, 4, 9, 108, True),     # ... the 100 < H <= 112 instantiation
     (1025, 3, 24, 100, False),   # ... with the input projection as a GEMM in front (D > 20)
     (1030, 5, 24, 112, True),    # ... both
-    (515, 7, 17, 100, False),    # two rows per workgroup (512 <= B < 1024), ragged
-    (513, 5, 9, 128, True),      # the H <= 128 instantiation, two rows per workgroup
+    (515, 7, 17, 100, False),    # ... ragged (3 of 4 rows in the last workgroup), zero initial state
+    (513, 5, 9, 128, True),      # 112 < H <= 128 at B >= 512: the vector kernels, two rows per workgroup
     (3, 5, 9, 128, True),        # H > 112: 16-row kernels, W_hh fragments re-read every step
     (20, 6, 11, 256, True),
 ])
