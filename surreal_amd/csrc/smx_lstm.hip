@@ -1072,6 +1072,40 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
 //             column.  The step's inputs are requested one step ahead.  ONE barrier per step.
 // Four accumulators per lane (k mod 4) instead of one chain of 100 dependent MFMAs, added (x + y) + (z + w).
 // ===========================================================================================
+// acc += A-row (LDS, 4 KQ floats) x the lane's weights, k mod 4 on four accumulators.  The operand words are requested a GROUP
+// ahead (five 16-byte words = 20 MFMAs = 160 cycles of matrix pipe, more than an LDS round trip with seven wavefronts
+// reading): left to itself hipcc keeps ONE word in flight (s_waitcnt lgkmcnt(1) behind every read) and the pipe waits for
+// LDS in every iteration -- MFMA busy 39 % in the first version of these kernels.
+template <int KQ>
+__device__ __forceinline__ void mrows_product(const float* __restrict__ row, const float4 (&w)[KQ], f32x4& ax, f32x4& ay,
+                                              f32x4& az, f32x4& aw) {
+    constexpr int GS = 5, NG = (KQ + GS - 1) / GS;
+    float4 c0, c1, c2, c3, c4, n0, n1, n2, n3, n4;
+    c0 = c1 = c2 = c3 = c4 = n0 = n1 = n2 = n3 = n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SMX_MR_LD(dst, q) do { if ((q) < KQ) dst = *reinterpret_cast<const float4*>(row + 4 * (q)); } while (0)
+#define SMX_MR_MM(src, q)                                                                    \
+    do {                                                                                     \
+        if ((q) < KQ) {                                                                      \
+            ax = MFMA4(src.x, w[(q) < KQ ? (q) : 0].x, ax);                                  \
+            ay = MFMA4(src.y, w[(q) < KQ ? (q) : 0].y, ay);                                  \
+            az = MFMA4(src.z, w[(q) < KQ ? (q) : 0].z, az);                                  \
+            aw = MFMA4(src.w, w[(q) < KQ ? (q) : 0].w, aw);                                  \
+        }                                                                                    \
+    } while (0)
+    SMX_MR_LD(c0, 0); SMX_MR_LD(c1, 1); SMX_MR_LD(c2, 2); SMX_MR_LD(c3, 3); SMX_MR_LD(c4, 4);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int qn = (gi + 1) * GS, qc = gi * GS;
+        __builtin_amdgcn_sched_barrier(0);
+        SMX_MR_LD(n0, qn); SMX_MR_LD(n1, qn + 1); SMX_MR_LD(n2, qn + 2); SMX_MR_LD(n3, qn + 3); SMX_MR_LD(n4, qn + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        SMX_MR_MM(c0, qc); SMX_MR_MM(c1, qc + 1); SMX_MR_MM(c2, qc + 2); SMX_MR_MM(c3, qc + 3); SMX_MR_MM(c4, qc + 4);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+    }
+#undef SMX_MR_LD
+#undef SMX_MR_MM
+}
+
 template <int KQ, bool FOLD>      // H <= 4 KQ <= 112
 __global__ __launch_bounds__(NT) void lstm_fwdm_kernel(FwdArgs a) {
     if (a.stop && *a.stop) return;
@@ -1087,21 +1121,28 @@ __global__ __launch_bounds__(NT) void lstm_fwdm_kernel(FwdArgs a) {
     const bool uv = unit < H;
     const bool wave_on = 16 * wv < H;          // (uniform) this wave has units
     const int col = uv ? g * H + unit : 0;     // gate column of this lane
+    // (all loads first, from addresses valid in every lane; what a lane must not see is zeroed afterwards -- a select right
+    // behind each load makes hipcc wait for them one by one)
     float4 wq[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q)
-        wq[q] = (uv && 4 * q < H) ? *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + 4 * q)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        wq[q] = *reinterpret_cast<const float4*>(a.W_hh + (size_t)col * H + (4 * q < H ? 4 * q : 0));
+    float wis[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) wis[k] = FOLD ? a.W_ih[(size_t)col * D + (k < D ? k : 0)] : 0.f;
+    const float bh = a.b_hh[col], bi = FOLD ? a.b_ih[col] : 0.f;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+        if (!(uv && 4 * q < H)) wq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 wi[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (FOLD && uv && 4 * q + j < D) v[j] = a.W_ih[(size_t)col * D + 4 * q + j];
+        for (int j = 0; j < 4; ++j) v[j] = (FOLD && uv && 4 * q + j < D) ? wis[4 * q + j] : 0.f;
         wi[q] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    const float bias = uv ? (FOLD ? a.b_hh[col] + a.b_ih[col] : a.b_hh[col]) : 0.f;
+    const float bias = uv ? bh + bi : 0.f;
     const bool is_g = g == 2;                  // the cell candidate: tanh; the other gates: sigmoid
     // element-wise role: row g of this lane's unit
     const bool inb = uv && row0 + g < a.B;
@@ -1125,63 +1166,69 @@ __global__ __launch_bounds__(NT) void lstm_fwdm_kernel(FwdArgs a) {
     const unsigned ucol = (unsigned)col, un = (unsigned)unit;
     // not FOLD: the input half (smx_linear_f32 wrote it), requested four steps ahead (see lstm_fwdk_kernel)
     float gx0[4], gx1[4], gx2[4], gx3[4];
+    // (every load of the ring is UNCONDITIONAL, from an address that is valid in every lane -- a lane without a unit reads
+    // column 0, a step past the sequence reads the last one -- and a value nobody needs is simply not used: a load under
+    // a lane mask is waited for at the end of the masked region, a select behind a load right there, and either puts a
+    // memory round trip into every step)
+    const int Tm = T - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        gx0[r] = (!FOLD && uv) ? grow[r][ucol] : 0.f;
-        gx1[r] = (!FOLD && uv && 1 < T) ? (grow[r] + G)[ucol] : 0.f;
-        gx2[r] = (!FOLD && uv && 2 < T) ? (grow[r] + 2 * G)[ucol] : 0.f;
-        gx3[r] = (!FOLD && uv && 3 < T) ? (grow[r] + 3 * (size_t)G)[ucol] : 0.f;
+        gx0[r] = gx1[r] = gx2[r] = gx3[r] = 0.f;
+        if (!FOLD) {
+            gx0[r] = grow[r][ucol];
+            gx1[r] = (grow[r] + (size_t)(1 < Tm ? 1 : Tm) * G)[ucol];
+            gx2[r] = (grow[r] + (size_t)(2 < Tm ? 2 : Tm) * G)[ucol];
+            gx3[r] = (grow[r] + (size_t)(3 < Tm ? 3 : Tm) * G)[ucol];
+        }
     }
     // FOLD staging role: lane tid < 80 carries input xj of row xr through a four-step ring into LDS
     const int xr = tid / 20, xj = tid - 20 * xr;
     const bool xlane = FOLD && tid < 80 && xj < D && row0 + xr < a.B;
+    const bool xwave = FOLD && wv < 2;         // (uniform) the waves that hold staging lanes
     const float* const xrow = FOLD ? a.x + (size_t)(row0 + (xlane ? xr : 0)) * T * D + (xlane ? xj : 0) : nullptr;
     float xg0 = 0.f, xg1 = 0.f, xg2 = 0.f, xg3 = 0.f;
-    if (xlane) {
-        xs[0][xr][xj] = xrow[0];
-        xg0 = (1 < T) ? xrow[(size_t)1 * D] : 0.f;
-        xg1 = (2 < T) ? xrow[(size_t)2 * D] : 0.f;
-        xg2 = (3 < T) ? xrow[(size_t)3 * D] : 0.f;
-        xg3 = (4 < T) ? xrow[(size_t)4 * D] : 0.f;
+    if (xwave) {
+        const float x0 = xrow[0];
+        xg0 = xrow[(size_t)(1 < Tm ? 1 : Tm) * D];
+        xg1 = xrow[(size_t)(2 < Tm ? 2 : Tm) * D];
+        xg2 = xrow[(size_t)(3 < Tm ? 3 : Tm) * D];
+        xg3 = xrow[(size_t)(4 < Tm ? 4 : Tm) * D];
+        if (xlane) xs[0][xr][xj] = x0;
     }
     __syncthreads();
+    // everything loaded so far is in its register HERE: redefined by an empty asm statement, or hipcc carries "may still be in
+    // flight" for these registers around the loop's back edge and drains the memory queue (s_waitcnt vmcnt(0): this step's
+    // stores and the ring's newest load) at their first use in the loop body
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) asm volatile("" : "+v"(wq[q].x), "+v"(wq[q].y), "+v"(wq[q].z), "+v"(wq[q].w));
+#pragma unroll
+    for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(wi[q].x), "+v"(wi[q].y), "+v"(wi[q].z), "+v"(wi[q].w));
+    asm volatile("" : "+v"(creg), "+v"(xg0), "+v"(xg1), "+v"(xg2), "+v"(xg3));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(gx0[r]), "+v"(gx1[r]), "+v"(gx2[r]), "+v"(gx3[r]));
 #define SMX_FWDM_STEP(GX, XG, TT)                                                                                        \
     if ((TT) < T) {                                                                                                    \
         const int t = (TT);                                                                                            \
         const int p = t & 1;                                                                                           \
         float act[4] = {0.f, 0.f, 0.f, 0.f};                                                                           \
+        /* x_{t+1} into the other buffer and the ring moves on -- at the TOP of the step: the wait for the ring's oldest load */ \
+        /* that hipcc puts here (vmcnt(0): it cannot count the divergent stores in between) then meets an empty queue */ \
+        if (xwave) {                                                                                                   \
+            if (xlane) xs[1 - p][xr][xj] = XG;                                                                         \
+            XG = xrow[(size_t)(t + 5 < Tm ? t + 5 : Tm) * D];                                                          \
+        }                                                                                                              \
         if (wave_on) {                                                                                                 \
             f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;                                                \
-            const float* hrow = &hs[p][g][0];                                                                          \
-            _Pragma("unroll") for (int q = 0; q < KQ; ++q) {                                                           \
-                const float4 hv = *reinterpret_cast<const float4*>(hrow + 4 * q);                                     \
-                ax = MFMA4(hv.x, wq[q].x, ax);                                                                         \
-                ay = MFMA4(hv.y, wq[q].y, ay);                                                                         \
-                az = MFMA4(hv.z, wq[q].z, az);                                                                         \
-                aw = MFMA4(hv.w, wq[q].w, aw);                                                                         \
-            }                                                                                                          \
-            if (FOLD) {                                                                                                \
-                const float* xrw = &xs[p][g][0];                                                                       \
-                _Pragma("unroll") for (int q = 0; q < 5; ++q) {                                                        \
-                    const float4 xv = *reinterpret_cast<const float4*>(xrw + 4 * q);                                  \
-                    ax = MFMA4(xv.x, wi[q].x, ax);                                                                     \
-                    ay = MFMA4(xv.y, wi[q].y, ay);                                                                     \
-                    az = MFMA4(xv.z, wi[q].z, az);                                                                     \
-                    aw = MFMA4(xv.w, wi[q].w, aw);                                                                     \
-                }                                                                                                      \
-            }                                                                                                          \
+            if (FOLD) mrows_product<5>(&xs[p][g][0], wi, ax, ay, az, aw);                                              \
+            mrows_product<KQ>(&hs[p][g][0], wq, ax, ay, az, aw);                                                       \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                            \
                 const float pre = GX[r] + (((ax[r] + ay[r]) + (az[r] + aw[r])) + bias);                                \
                 const float sg = fast_sigm(is_g ? 2.f * pre : pre);                                                  \
                 act[r] = is_g ? 2.f * sg - 1.f : sg;                                                                   \
                 float* const gstep = grow[r] + (size_t)t * G;                                                          \
                 if (uv && rv[r]) gstep[ucol] = act[r];                                                                 \
-                GX[r] = (!FOLD && uv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                              \
+                if (!FOLD) GX[r] = (grow[r] + (size_t)(t + 4 < Tm ? t + 4 : Tm) * G)[ucol];                            \
             }                                                                                                          \
-        }                                                                                                              \
-        if (xlane) {                            /* x_{t+1} into the other buffer; the ring moves on */                 \
-            xs[1 - p][xr][xj] = XG;                                                                                    \
-            XG = (t + 5 < T) ? xrow[(size_t)(t + 5) * D] : 0.f;                                                        \
         }                                                                                                              \
         /* the four gates of row g of this unit: lane j of the quad holds gate j of every row */                       \
         float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;                                                                  \
@@ -1230,14 +1277,13 @@ __global__ __launch_bounds__(NT) void lstm_bwdm_kernel(BwdArgs a) {
     const bool wave_on = 16 * wv < H;
     float4 wq[KQ];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nv && 4 * q < H) {
-            const float* p = a.W_hh + ((size_t)gb * H + 4 * q) * H + n;
-            w.x = p[0]; w.y = p[H]; w.z = p[2 * (size_t)H]; w.w = p[3 * (size_t)H];
-        }
-        wq[q] = w;
+    for (int q = 0; q < KQ; ++q) {             // (all loads first, from valid addresses; masked afterwards)
+        const float* p = a.W_hh + ((size_t)gb * H + (4 * q < H ? 4 * q : 0)) * H + (nv ? n : 0);
+        wq[q] = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
     }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+        if (!(nv && 4 * q < H)) wq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < 2 * 4 * DS; i += NT) (&dg[0][0][0])[i] = 0.f;
     // element-wise role: row gb of column n
     const bool inb = nv && row0 + gb < a.B;
@@ -1248,28 +1294,39 @@ __global__ __launch_bounds__(NT) void lstm_bwdm_kernel(BwdArgs a) {
     const float* const drow = a.dout + erow * T * H;
     const unsigned un = (unsigned)(nv ? n : 0);
     float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cp = 0.f, dout = 0.f, dcreg = 0.f, dhr = 0.f;
+    // the step's inputs are requested TWO steps ahead (they come from HBM: the forward pass wrote them a launch ago) and
+    // UNCONDITIONALLY, every lane from a valid address (see lstm_fwdm_kernel)
+    // (c_{-1}: the initial cell state, or -- without one -- any valid word: the use site takes 0 then)
+    const float* const c0row = a.c0 ? a.c0 + erow * H : crow;
 #define SMX_BWDM_FETCH(t, xi, xf, xg, xo, xcp, xd)                                                                     \
     do {                                                                                                             \
-        const float* gp_ = grow + (size_t)(t) * G;                                                                   \
+        const int tt_ = (t) > 0 ? (t) : 0;                                                                           \
+        const float* gp_ = grow + (size_t)tt_ * G;                                                                   \
         xi = gp_[un]; xf = (gp_ + H)[un]; xg = (gp_ + 2 * H)[un]; xo = (gp_ + 3 * (size_t)H)[un];                    \
-        xcp = ((t) > 0) ? (crow + (size_t)((t) - 1) * H)[un] : (a.c0 ? a.c0[erow * H + un] : 0.f);                   \
-        xd = (drow + (size_t)(t) * H)[un];                                                                           \
+        xcp = (tt_ > 0 ? crow + (size_t)(tt_ - 1) * H : c0row)[un];                                                  \
+        xd = (drow + (size_t)tt_ * H)[un];                                                                           \
     } while (0)
-    if (inb) {
-        SMX_BWDM_FETCH(T - 1, gi, gf, gg, go, cp, dout);
-        c = (crow + (size_t)(T - 1) * H)[un];
-    }
+    float mi = 0.f, mf = 0.f, mg = 0.f, mo = 0.f, mcp = 0.f, md = 0.f;       // step t - 1's inputs
+    SMX_BWDM_FETCH(T - 1, gi, gf, gg, go, cp, dout);
+    c = (crow + (size_t)(T - 1) * H)[un];
+    SMX_BWDM_FETCH(T - 2, mi, mf, mg, mo, mcp, md);
     __syncthreads();
+    // (loaded before the loop = in its register here: see lstm_fwdm_kernel)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) asm volatile("" : "+v"(wq[q].x), "+v"(wq[q].y), "+v"(wq[q].z), "+v"(wq[q].w));
+    asm volatile("" : "+v"(gi), "+v"(gf), "+v"(gg), "+v"(go), "+v"(cp), "+v"(dout), "+v"(c));
+    asm volatile("" : "+v"(mi), "+v"(mf), "+v"(mg), "+v"(mo), "+v"(mcp), "+v"(md));
     for (int t = T - 1; t >= 0; --t) {
         const int p = t & 1;
-        float ni = 0.f, nf = 0.f, ng = 0.f, no = 0.f, ncp = 0.f, nd = 0.f;
-        if (inb && t > 0) SMX_BWDM_FETCH(t - 1, ni, nf, ng, no, ncp, nd);          // the next step's inputs: requested early
+        float ni, nf, ng, no, ncp, nd;
+        SMX_BWDM_FETCH(t - 2, ni, nf, ng, no, ncp, nd);
         {
             const float dh = dout + dhr;
             const float tc = fast_tanh(c);             // (the forward pass formed h with the same function)
             const float dc = dcreg + (dh * go) * (1.f - tc * tc);
             const float dgi = (dc * gg) * (gi * (1.f - gi));
-            const float dgf = (dc * cp) * (gf * (1.f - gf));
+            const float cpu = (t > 0 || a.c0) ? cp : 0.f;      // c_{t-1}
+            const float dgf = (dc * cpu) * (gf * (1.f - gf));
             const float dgg = (dc * gi) * (1.f - gg * gg);
             const float dgo = (dh * tc) * (go * (1.f - go));
             dcreg = dc * gf;
@@ -1283,15 +1340,7 @@ __global__ __launch_bounds__(NT) void lstm_bwdm_kernel(BwdArgs a) {
         LSTM_LDS_BARRIER();
         if (t > 0 && wave_on) {
             f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;
-            const float* arow = &dg[p][j][gb * KB];
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                const float4 dv = *reinterpret_cast<const float4*>(arow + 4 * q);
-                ax = MFMA4(dv.x, wq[q].x, ax);
-                ay = MFMA4(dv.y, wq[q].y, ay);
-                az = MFMA4(dv.z, wq[q].z, az);
-                aw = MFMA4(dv.w, wq[q].w, aw);
-            }
+            mrows_product<KQ>(&dg[p][j][gb * KB], wq, ax, ay, az, aw);
             // the four gate blocks' partial sums of a column sit 16 lanes apart: (p + p^16) + (. ^32) -- the same two
             // sums in every lane (a + b = b + a), so all four copies are bit-identical
             float tot[4];
@@ -1304,7 +1353,8 @@ __global__ __launch_bounds__(NT) void lstm_bwdm_kernel(BwdArgs a) {
             dhr = gb == 0 ? tot[0] : (gb == 1 ? tot[1] : (gb == 2 ? tot[2] : tot[3]));
         }
         c = cp;
-        gi = ni; gf = nf; gg = ng; go = no; cp = ncp; dout = nd;
+        gi = mi; gf = mf; gg = mg; go = mo; cp = mcp; dout = md;
+        mi = ni; mf = nf; mg = ng; mo = no; mcp = ncp; md = nd;
     }
 #undef SMX_BWDM_FETCH
 }
