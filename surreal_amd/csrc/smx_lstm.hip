@@ -939,18 +939,18 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
     const int e = tid & 7, uA = 2 * (tid >> 3), kgb = e >> 1;          // product role: k-eighth e of units uA, uA + 1
     const int nq = H >> 2, half0 = (nq + 1) >> 1;                      // float4 words per gate block / in its first half
     const int q0 = (e & 1) ? half0 : 0, qn = (e & 1) ? nq - half0 : half0;
+    // (all loads first, from addresses valid in every lane, masked afterwards: a select or a lane mask right at a load makes
+    // hipcc wait for it there -- 13 dependent round trips in front of the first step)
     float4 wA[HH], wB[HH];
 #pragma unroll
     for (int q = 0; q < HH; ++q) {
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-        if (colv && q < qn) {
-            const float* p = a.W_hh + ((size_t)kgb * H + 4 * (q0 + q)) * H + uA;
-            va = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
-            vb = make_float4(p[1], p[H + 1], p[2 * (size_t)H + 1], p[3 * (size_t)H + 1]);
-        }
-        wA[q] = va;
-        wB[q] = vb;
+        const float* p = a.W_hh + ((size_t)kgb * H + 4 * (q0 + (q < qn ? q : 0))) * H + (colv ? uA : 0);
+        wA[q] = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
+        wB[q] = make_float4(p[1], p[H + 1], p[2 * (size_t)H + 1], p[3 * (size_t)H + 1]);
     }
+#pragma unroll
+    for (int q = 0; q < HH; ++q)
+        if (!(colv && q < qn)) { wA[q] = make_float4(0.f, 0.f, 0.f, 0.f); wB[q] = wA[q]; }
     float* dg = reinterpret_cast<float*>(dg4);
     for (int idx = tid; idx < RW * 2 * 4 * 8 * HH; idx += NT) dg[idx] = 0.f;
     // addressing: uniform row / step bases + 32-bit lane offsets (no 64-bit vector address arithmetic inside the step)
@@ -970,32 +970,38 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
         dgrow[r] = a.dgates + br * T * G;
         crow[r] = a.cs + br * T * H;
         drow[r] = a.dout + br * T * H;
-        c0row[r] = a.c0 ? a.c0 + br * H : nullptr;
+        c0row[r] = a.c0 ? a.c0 + br * H : crow[r];       // (no initial state: any valid word, the use site takes 0)
         dcreg[r] = 0.f; dhr[r] = 0.f; gmine[r] = 0.f; c[r] = 0.f; cp[r] = 0.f; dout[r] = 0.f;
     }
+    // The step's inputs are requested TWO steps ahead and UNCONDITIONALLY -- every lane from a valid address (a lane past the
+    // gate columns reads column 0, a step before the sequence reads step 0), a value nobody needs is simply not used.  Under
+    // `if (colv && t > 0)` the loads were waited for at the END OF THE MASKED REGION: a memory round trip inside every step
+    // (measured on the 4-row kernels below: 242 -> 185 us per launch).
 #define SMX_BWDK_FETCH(r, t, xg, xcp, xd)                                                                            \
     do {                                                                                                             \
-        xg = (grow[r] + (size_t)(t) * G)[ug];                            /* this lane's own gate of unit n */          \
-        xcp = ((t) > 0) ? (crow[r] + (size_t)((t) - 1) * H)[un] : (c0row[r] ? c0row[r][un] : 0.f);                   \
-        xd = (drow[r] + (size_t)(t) * H)[un];                                                                        \
+        const int tt_ = (t) > 0 ? (t) : 0;                                                                           \
+        xg = (grow[r] + (size_t)tt_ * G)[ug];                            /* this lane's own gate of unit n */          \
+        xcp = (tt_ > 0 ? crow[r] + (size_t)(tt_ - 1) * H : c0row[r])[un];                                            \
+        xd = (drow[r] + (size_t)tt_ * H)[un];                                                                        \
     } while (0)
-    if (colv) {
+    float mg[RW], mcp[RW], md[RW];             // step t - 1's inputs
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            SMX_BWDK_FETCH(r, T - 1, gmine[r], cp[r], dout[r]);
-            c[r] = (crow[r] + (size_t)(T - 1) * H)[un];
-        }
+    for (int r = 0; r < RW; ++r) {
+        SMX_BWDK_FETCH(r, T - 1, gmine[r], cp[r], dout[r]);
+        c[r] = (crow[r] + (size_t)(T - 1) * H)[un];
+        SMX_BWDK_FETCH(r, T - 2, mg[r], mcp[r], md[r]);
     }
     const bool upper = (tid & 4) != 0;         // the quad of unit uA + 1
+    const bool have_c0 = a.c0 != nullptr;
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RW; ++r)               // (loaded before the loop = in its register here: see lstm_fwdm_kernel)
+        asm volatile("" : "+v"(gmine[r]), "+v"(cp[r]), "+v"(dout[r]), "+v"(c[r]), "+v"(mg[r]), "+v"(mcp[r]), "+v"(md[r]));
     for (int t = T - 1; t >= 0; --t) {
         const int p = t & 1;
         float ng[RW], ncp[RW], nd[RW];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            ng[r] = 0.f; ncp[r] = 0.f; nd[r] = 0.f;
-            if (colv && t > 0) SMX_BWDK_FETCH(r, t - 1, ng[r], ncp[r], nd[r]);     // the next step's inputs: requested early
-        }
+        for (int r = 0; r < RW; ++r) SMX_BWDK_FETCH(r, t - 2, ng[r], ncp[r], nd[r]);
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const float gi = quad_bcast<0>(gmine[r]), gf = quad_bcast<1>(gmine[r]), gg = quad_bcast<2>(gmine[r]),
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
             const float tc = fast_tanh(c[r]);          // (the forward pass formed h with the same function)
             const float dc = dcreg[r] + (dh * go) * (1.f - tc * tc);
             const float dgi = (dc * gg) * (gi * (1.f - gi));
-            const float dgf = (dc * cp[r]) * (gf * (1.f - gf));
+            const float dgf = (dc * ((t > 0 || have_c0) ? cp[r] : 0.f)) * (gf * (1.f - gf));
             const float dgg = (dc * gi) * (1.f - gg * gg);
             const float dgo = (dh * tc) * (go * (1.f - go));
             dcreg[r] = dc * gf;
@@ -1047,7 +1053,8 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             c[r] = cp[r];
-            gmine[r] = ng[r]; cp[r] = ncp[r]; dout[r] = nd[r];
+            gmine[r] = mg[r]; cp[r] = mcp[r]; dout[r] = md[r];
+            mg[r] = ng[r]; mcp[r] = ncp[r]; md[r] = nd[r];
         }
     }
 #undef SMX_BWDK_FETCH
