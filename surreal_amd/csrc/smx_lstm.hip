@@ -699,8 +699,11 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     // staging role: lane tid < 20 RW carries input xj of row xr through the ring into LDS
     const int xr = tid / 20, xj = tid - 20 * xr;
     const bool xlane = FOLD && tid < 20 * RW && xj < a.D && b0 + xr < a.B;
+    const bool xwave = FOLD && tid < 128;      // (uniform per wavefront) the waves that hold staging lanes: 20 RW <= 80
     const int xpos = (xj / 5) * 8 + (xj % 5);
-    const float* const xrow = FOLD ? a.x + (size_t)(b0 + (b0 + xr < a.B ? xr : 0)) * T * a.D + xj : nullptr;
+    // (a lane without a staging role reads the workgroup's first word: its loads are unconditional, see SMX_FWDK_STEP)
+    const float* const xrow = FOLD ? a.x + (size_t)(b0 + (xlane ? xr : 0)) * T * a.D + (xlane ? xj : 0) : nullptr;
+    const int Tm = T - 1;
     float xg0 = 0.f, xg1 = 0.f, xg2 = 0.f, xg3 = 0.f;      // x_{t+1} .. x_{t+4} of this lane's (row, input)
     if (FOLD) {
         for (int i = tid; i < RW * 2 * 32; i += NT) xsf[i] = 0.f;
@@ -737,19 +740,23 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
     float gx0[RW], gx1[RW], gx2[RW], gx3[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        gx0[r] = (!FOLD && colv) ? grow[r][ucol] : 0.f;
-        gx1[r] = (!FOLD && colv && 1 < T) ? (grow[r] + G)[ucol] : 0.f;
-        gx2[r] = (!FOLD && colv && 2 < T) ? (grow[r] + 2 * G)[ucol] : 0.f;
-        gx3[r] = (!FOLD && colv && 3 < T) ? (grow[r] + 3 * G)[ucol] : 0.f;
+        gx0[r] = gx1[r] = gx2[r] = gx3[r] = 0.f;
+        if (!FOLD) {                           // (every lane, from valid addresses: ucol = 0 past the gate columns)
+            gx0[r] = grow[r][ucol];
+            gx1[r] = (grow[r] + (size_t)(1 < T - 1 ? 1 : T - 1) * G)[ucol];
+            gx2[r] = (grow[r] + (size_t)(2 < T - 1 ? 2 : T - 1) * G)[ucol];
+            gx3[r] = (grow[r] + (size_t)(3 < T - 1 ? 3 : T - 1) * G)[ucol];
+        }
     }
     if (FOLD) {
         __syncthreads();                       // (the zero fill of xs4 above)
-        if (xlane) {
-            xsf[(xr * 2 + 0) * 32 + xpos] = xrow[0];
-            xg0 = (1 < T) ? xrow[(size_t)1 * a.D] : 0.f;
-            xg1 = (2 < T) ? xrow[(size_t)2 * a.D] : 0.f;
-            xg2 = (3 < T) ? xrow[(size_t)3 * a.D] : 0.f;
-            xg3 = (4 < T) ? xrow[(size_t)4 * a.D] : 0.f;
+        if (xwave) {
+            const float x0 = xrow[0];
+            xg0 = xrow[(size_t)(1 < Tm ? 1 : Tm) * a.D];
+            xg1 = xrow[(size_t)(2 < Tm ? 2 : Tm) * a.D];
+            xg2 = xrow[(size_t)(3 < Tm ? 3 : Tm) * a.D];
+            xg3 = xrow[(size_t)(4 < Tm ? 4 : Tm) * a.D];
+            if (xlane) xsf[(xr * 2 + 0) * 32 + xpos] = x0;
         }
     }
     const bool odd = (kq & 1) != 0, hi = (kq & 2) != 0;
@@ -787,9 +794,11 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
                     a3[r].x = __builtin_fmaf(xv[j], wx[3][j], a3[r].x);                                                \
                 }                                                                                                      \
             }                                                                                                          \
-            if (xlane) {                        /* x_{t+1} into the other buffer; the ring moves on */                 \
-                xsf[(xr * 2 + 1 - p) * 32 + xpos] = XG;                                                                \
-                XG = (t + 5 < T) ? xrow[(size_t)(t + 5) * a.D] : 0.f;                                                  \
+            /* x_{t+1} into the other buffer; the ring moves on.  The load is UNCONDITIONAL inside a wave-uniform branch (under */ \
+            /* the lane mask it was waited for at the end of the masked region: a memory round trip in the step) */      \
+            if (xwave) {                                                                                               \
+                if (xlane) xsf[(xr * 2 + 1 - p) * 32 + xpos] = XG;                                                     \
+                XG = xrow[(size_t)(t + 5 < Tm ? t + 5 : Tm) * a.D];                                                    \
             }                                                                                                          \
         }                                                                                                              \
         _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                                               \
@@ -804,7 +813,7 @@ __global__ __launch_bounds__(NT) void lstm_fwdk_kernel(FwdArgs a) {
             const float act = is_g ? 2.f * sg - 1.f : sg;        /* tanh for the cell candidate, sigmoid otherwise */   \
             float* const gstep = grow[r] + (size_t)t * G;                /* uniform */                                  \
             if (colv && rv[r]) gstep[ucol] = act;                                                                      \
-            GX[r] = (!FOLD && colv && t + 4 < T) ? (gstep + 4 * (size_t)G)[ucol] : 0.f;                                \
+            if (!FOLD) GX[r] = (grow[r] + (size_t)(t + 4 < T - 1 ? t + 4 : T - 1) * G)[ucol];    /* (unconditional) */ \
             const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act); \
             const float c = gf * creg[r] + gi * gg;                                                                    \
             const float h = go * fast_tanh(c);                                                                         \
