@@ -967,6 +967,9 @@ def test_mlp3_multi_jobs_with_transposed_operands(K, rows, D):
     (1027, 6, 17, 100, True),    # ... with a ragged last workgroup (3 of 4 rows)
     (1026, 4, 9, 108, True),     # ... the 100 < H <= 112 instantiation
     (1025, 3, 24, 100, False),   # ... with the input projection as a GEMM in front (D > 20)
+    (1024, 1, 17, 100, True),    # ... a single step (1024 actors acting): every clamped prefetch index is 0
+    (600, 2, 17, 100, True),     # ... two steps
+    (40, 1, 17, 100, True), (40, 2, 17, 100, False),     # ... and the same on the vector kernels
     (1030, 5, 24, 112, True),    # ... both
     (515, 7, 17, 100, False),    # ... ragged (3 of 4 rows in the last workgroup), zero initial state
     (513, 5, 9, 128, True),      # 112 < H <= 128 at B >= 512: the vector kernels, two rows per workgroup
