@@ -26,11 +26,30 @@ __device__ __forceinline__ void gae_body(
         const float* v = values + (size_t)b * (values_tail ? N : N + 1);
         const float* r = rewards + (size_t)b * N;
         const float* d = dones + (size_t)b * N;
-        for (int t = lane; t <= N; t += 64) {
-            float x = (values_tail && t == N) ? values_tail[b] : v[t];
-            if (t >= 1) x = x * (1.0f - d[t - 1]);  // values[:, 1:] *= 1 - dones   (ppo.py:387)
-            Vm[t] = x;
-            if (t < N) R[t] = r[t];
+        // (four 64-step slices at a time: every load of a slice first, unconditionally and from an index valid in every
+        // lane, the conditions applied afterwards -- with `cond ? load : ...` per step hipcc waited for each load where it
+        // was issued: two dependent memory round trips per slice in front of a 16 us launch)
+        const float vt = values_tail ? values_tail[b] : 0.f;
+        const int vlast = values_tail ? N - 1 : N;
+        for (int t0 = 0; t0 <= N; t0 += 256) {
+            float xv[4], dv[4], rv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = t0 + lane + 64 * i;
+                xv[i] = v[t < vlast ? t : vlast];
+                dv[i] = d[t >= 1 ? (t - 1 < N ? t - 1 : N - 1) : 0];
+                rv[i] = r[t < N ? t : N - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = t0 + lane + 64 * i;
+                if (t <= N) {
+                    float x = (values_tail && t == N) ? vt : xv[i];
+                    if (t >= 1) x = x * (1.0f - dv[i]);  // values[:, 1:] *= 1 - dones   (ppo.py:387)
+                    Vm[t] = x;
+                    if (t < N) R[t] = rv[i];
+                }
+            }
         }
     }
     __syncthreads();
