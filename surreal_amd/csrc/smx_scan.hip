@@ -640,6 +640,20 @@ __global__ __launch_bounds__(1024) void learn_epilogue_kernel(EpilogueArgs P) {
             const float* x = P.x;
             const long ldx = P.ldx, rows = P.rows;
             long r = g;
+            // (sixteen loads in flight; the additions in the order of four passes of the loop below: bit-identical sums.
+            // With four in flight a thread's 64 rows were sixteen dependent round trips -- 10 of this launch's 12 us)
+            for (; r + 240 < rows; r += 256) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = x[(r + 16 * i) * ldx + col];
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    a0 += v[i]; q0 += v[i] * v[i];
+                    a1 += v[i + 1]; q1 += v[i + 1] * v[i + 1];
+                    a2 += v[i + 2]; q2 += v[i + 2] * v[i + 2];
+                    a3 += v[i + 3]; q3 += v[i + 3] * v[i + 3];
+                }
+            }
             for (; r + 48 < rows; r += 64) {
                 const float v0 = x[r * ldx + col], v1 = x[(r + 16) * ldx + col];
                 const float v2 = x[(r + 32) * ldx + col], v3 = x[(r + 48) * ldx + col];
