@@ -187,9 +187,12 @@ def host_cpu():
 
 def reference_learn_fn(params, zstate, batch, Bs, Ns, Ds, As, hyper, pixel=None):
     """a callable that runs ONE learn of the REFERENCE'S OWN learner (surreal/learner/ppo.py `_preprocess_batch_ppo` +
-    `_optimize`) on `batch`, or None.  The code that runs is the reference's, byte-compiled from /root/reference by
-    oracle/make_ref.py into the git-ignored oracle/_ref/ (which ships with the tree snapshot), under the third-party
-    stand-ins of oracle/ref_shims.py -- cpu_baseline.kind "reference".  None where oracle/_ref was not built."""
+    `_optimize`) on `batch`, or None.  Opt-in (SMX_BENCH_REFERENCE=1) and build-container only: the reference tree does
+    not travel to the GPU box in any form, so there this is always None and cpu_baseline.kind is "port" (the restatement,
+    which oracle/gen_golden.py asserts bit-identical to the reference and oracle/time_reference_vs_port.py times beside
+    it in the build container: profiles/r04_cpu_reference_vs_port.json)."""
+    if os.environ.get('SMX_BENCH_REFERENCE') != '1':
+        return None
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     try:
         import ref_shims
@@ -251,7 +254,7 @@ def cpu_baseline(mode, params, zstate, batch, budget_s=30.0):
                      'learns per thread count, best of the sweep' % (mode, torch.__version__),
            'single_thread': one['env_steps_per_s'], 'sweep': sweep, 'cpu_model': cpu['model'],
            'physical_cores': cpu['physical_cores'], 'logical_cpus': cpu['logical_cpus'], 'port': port}
-    # the reference's own code (oracle/_ref) at the port's best thread count: the baseline quoted is the FASTER of the two
+    # the reference's own code (build container, opt-in) at the port's best thread count: the baseline quoted is the FASTER of the two
     fn = reference_learn_fn(params, zstate, batch, B, N, D, A, dict(ppo_mode=mode, kl_target=1e9))
     if fn is not None:
         torch.set_num_threads(best['threads'])
@@ -409,7 +412,7 @@ def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=None, sample_row
                k, Bs, Ns, 'full batch' if not sample_rows else 'the first %d sub-trajectories of the batch' % Bs,
                torch.__version__, _cpu_threads(), ' (single call, no warm-up: one learn takes seconds)' if cold else '')}
     out['port'] = {'value': out['value'], 'cores': n, 's_per_learn': dt}
-    # the reference's own code at the same thread count, when oracle/_ref is there and the budget allows one more leg:
+    # the reference's own code at the same thread count (build container, opt-in) when the budget allows one more leg:
     # the baseline quoted is the faster of the two (the port is ~20 % slower than the reference on the LSTM policy)
     if time.time() - t_start < budget_s:
         fn = reference_learn_fn(params, None, batch, Bs, Ns, Ds, As, kw, pixel=pixel)

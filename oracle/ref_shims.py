@@ -30,11 +30,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-# The source tree in the build container; else oracle/_ref: the same modules byte-compiled from it by
-# oracle/make_ref.py (sourceless .pyc, git-ignored, ships to the GPU box with the tree snapshot).
-_BUILT_REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
-REFERENCE_ROOT = os.environ.get('SURREAL_REFERENCE_ROOT') or (
-    '/root/reference' if os.path.isdir('/root/reference/surreal') else _BUILT_REF)
+# The reference's source tree exists in the build container only.  It does not travel to the GPU box in any form
+# (no source, no bytecode): there `reference_available()` is False and every consumer falls back to the restatement.
+REFERENCE_ROOT = os.environ.get('SURREAL_REFERENCE_ROOT') or '/root/reference'
 
 
 def reference_available():

@@ -953,7 +953,8 @@ __global__ __launch_bounds__(NT) void lstm_bwdk_kernel(BwdArgs a) {
     float4 wA[HH], wB[HH];
 #pragma unroll
     for (int q = 0; q < HH; ++q) {
-        const float* p = a.W_hh + ((size_t)kgb * H + 4 * (q0 + (q < qn ? q : 0))) * H + (colv ? uA : 0);
+        // (qn == 0 -- H == 4, odd e -- has no word of its own: row 0 of the gate block, masked below, keeps the load in bounds)
+        const float* p = a.W_hh + ((size_t)kgb * H + 4 * (q < qn ? q0 + q : 0)) * H + (colv ? uA : 0);
         wA[q] = make_float4(p[0], p[H], p[2 * (size_t)H], p[3 * (size_t)H]);
         wB[q] = make_float4(p[1], p[H + 1], p[2 * (size_t)H + 1], p[3 * (size_t)H + 1]);
     }

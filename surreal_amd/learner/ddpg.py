@@ -620,7 +620,10 @@ class DDPGLearner(Learner):
         # (a batch sampled straight into staging_fields() is already where the captured iteration reads it)
         for dst, src in ((ws.s_obs, x), (ws.s_next, xn), (ws.s_act, actions.reshape(B, -1)), (ws.s_rew, rewards.reshape(-1)),
                          (ws.s_done, done.reshape(-1))):
-            if src.data_ptr() != dst.data_ptr():
+            # "already staged" means the SAME buffer, not merely the same address: a strided / reshaped view that starts at
+            # the staging buffer's address is copied like any other source
+            if not (src.data_ptr() == dst.data_ptr() and src.shape == dst.shape and src.stride() == dst.stride()
+                    and src.dtype == dst.dtype):
                 dst.copy_(src)
         frames = ()
         if self.is_pixel_input:

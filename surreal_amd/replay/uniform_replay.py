@@ -84,7 +84,8 @@ class UniformReplay(Replay):
             if o is None:
                 o = torch.empty(batch_size, t.width, device=self._dev, dtype=t.dtype)
             else:
-                assert o.is_contiguous() and o.dtype == t.dtype and o.numel() == batch_size * t.width, k
+                assert (o.is_contiguous() and o.dtype == t.dtype and o.numel() == batch_size * t.width
+                        and o.shape[0] == batch_size), k
                 o = o.view(batch_size, t.width)
             outs.append(o)
         self._K.uniform_gather_multi([t.data for t in tabs], outs, self._dev_len, self.seed, self._draws, idx=idx)

@@ -72,6 +72,22 @@ def pytest_sessionfinish(session, exitstatus):
         if os.path.isdir(out):
             import json
             json.dump(seeds, open(os.path.join(out, 'fp64_seed_report_%s.json' % _tier()), 'w'), indent=1)
+    try:
+        import ddpg_helpers
+        drep = ddpg_helpers.DDPG_PARAM_REPORT
+    except Exception:
+        drep = {}
+    if drep:
+        import json
+        tens = {k: v for k, v in drep.items() if isinstance(v, tuple)}
+        if tens:
+            w = max(tens.items(), key=lambda kv: kv[1][0] / kv[1][3])
+            print('\nDDPG parameters vs the reference: %d tensors, %d elements; closest to its bound: %s -- max diff %.2e '
+                  '(bound %.0e)' % (len(tens), sum(v[2] for v in tens.values()), w[0], w[1][0], w[1][3]))
+        out = os.path.join(ROOT, 'gpurun_out')
+        if os.path.isdir(out):
+            json.dump({k: (dict(max_diff=v[0], frac_off_1e5=v[1], elements=v[2], bound=v[3]) if isinstance(v, tuple) else v)
+                       for k, v in drep.items()}, open(os.path.join(out, 'ddpg_params_report_%s.json' % _tier()), 'w'), indent=0)
     rep = helpers.FINAL_PARAM_REPORT
     if not rep:
         return

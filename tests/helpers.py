@@ -106,7 +106,7 @@ def tol_for(key, atol, rtol, case=''):
 
 # goldens whose CPU re-run takes about a minute (8448 camera frames through the CNN stem 25 times): checked against
 # the oracle bit for bit when they were recorded (oracle/gen_golden.py), run by the GPU tier, skipped by the CPU tier
-BIG_CASES = ('cfg4_pixel_rnn_256x32', 'cfg5_rnn_adapt')
+BIG_CASES = ('cfg4_pixel_rnn_256x32', 'cfg5_rnn_adapt', 'cfg5_rnn_clip', 'b1024_d17_rnn_adapt')
 
 
 def golden_cases(rnn=None, big=True):
@@ -235,8 +235,12 @@ def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):
         np.testing.assert_allclose(stats[k], v, atol=at, rtol=rt, err_msg='%s stat %s' % (what, k))
 
 
-CHECKSUM_RTOL = {'cfg5_rnn_adapt': 1e-3}      # squared-sum checksums of the big stem cases (assert_final_params)
-FINAL_PARAM_REPORT = {}      # 'case tensor' -> (fraction of elements off by > atol, max diff, elements)
+CHECKSUM_RTOL = {'cfg5_rnn_adapt': 1e-3, 'cfg5_rnn_clip': 1e-3, 'b1024_d17_rnn_adapt': 1e-3}   # squared-sum checksums of the big stem cases
+# every-element bound on the final parameters where the common 1e-5 is not what the case can hold (measured; see
+# assert_final_params' notes and gpurun_out/final_params_report_gpu.json)
+FINAL_PARAM_ATOL = {}
+FINAL_PARAM_REPORT = {}      # 'case tensor' -> (fraction of elements off by > 1e-5, max diff, elements)
+MEASURE_ONLY = os.environ.get('SMX_MEASURE_ONLY') == '1'     # record the parameter distances, do not assert them
 
 
 def assert_final_params(learner, g, case, atol=1e-5, what=''):
@@ -245,16 +249,23 @@ def assert_final_params(learner, g, case, atol=1e-5, what=''):
     allowed epochs * 2 * lr on 2 % of the elements -- Adam's first steps move a weight by ~lr * sign(g), so an
     element whose gradient sat at the fp32 noise floor COULD differ by that much, but none does); squared-sum
     checksums for the big cases whose tensors are not stored.  tests/conftest.py prints the tightness summary."""
-    got = learner.model.numpy_params()
+    assert_final_params_dict(learner.model.numpy_params(), g, atol=atol, what=what)
+
+
+def assert_final_params_dict(got, g, atol=1e-5, what=''):
+    """`got`: {tensor name: numpy array} of the updated parameters (what `model.numpy_params()` returns)"""
     ck = json.loads(str(g['final_checksum_json']))
     for k, (s, sq) in ck.items():
         a = got[k].astype(np.float64)
         if 'final.' + k in g:
             ref = g['final.' + k]
             diff = np.abs(got[k] - ref)
-            FINAL_PARAM_REPORT['%s %s' % (what, k)] = (float(np.mean(diff > atol)), float(diff.max()), int(diff.size))
-            assert diff.max() <= atol, '%s %s: max diff %g, %.3f%% of elements off by > %g' % (
-                what, k, diff.max(), 100 * np.mean(diff > atol), atol)
+            bound = max(atol, FINAL_PARAM_ATOL.get(what.split(' ')[0], 0.0))
+            key = '%s %s' % (what, k)
+            if key not in FINAL_PARAM_REPORT or diff.max() > FINAL_PARAM_REPORT[key][1]:
+                FINAL_PARAM_REPORT[key] = (float(np.mean(diff > 1e-5)), float(diff.max()), int(diff.size))
+            assert MEASURE_ONLY or diff.max() <= bound, '%s %s: max diff %g, %.3f%% of elements off by > %g' % (
+                what, k, diff.max(), 100 * np.mean(diff > bound), bound)
         # (the full-size pixel case: parameters that start near zero -- the stem's biases -- end wherever ~20 sign-like
         # Adam steps on noise-floor gradients take them.  Measured: the oracle on the GPU box's host is off the golden
         # by up to 5.8e-4 on these checksums (cnn.conv2.b), the HIP path -- whose split-K weight / bias gradients sum
@@ -264,7 +275,7 @@ def assert_final_params(learner, g, case, atol=1e-5, what=''):
         # rows in split-K order, sits at the fp32 noise floor; Adam turns it into +- lr) moves the squared sum by 5.7e-5
         # relative.  Measured on two generations of the weight-gradient kernels: 2.3e-4 and 1.2e-4 on critic.fc2.b = 2 - 4
         # of 2000 element-steps; every weight matrix within 1e-4.  Bound: 1e-3.)
-        np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=CHECKSUM_RTOL.get(what, 5e-3 if what in CASE_LOOSE_RTOL else 1e-4),
+        np.testing.assert_allclose(np.sum(a ** 2), sq, rtol=CHECKSUM_RTOL.get(what.split(' ')[0], 5e-3 if what in CASE_LOOSE_RTOL else 1e-4),
                                    err_msg=what + ' sumsq ' + k)
 
 

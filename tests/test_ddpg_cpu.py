@@ -178,3 +178,7 @@ def test_frame_stack_preprocessor_joins_frame_lists(cpu_double):
     assert all(isinstance(o['pixel']['camera0'], list) for o in shared)
     with pytest.raises(AssertionError):
         FrameStackPreprocessor.preprocess_obs({'pixel': {'camera0': [np.zeros((2, 3))]}})
+
+
+def test_resume_across_the_hard_update_at_configs2_size(cpu_double):
+    DH.check_resume_across_hard_update()

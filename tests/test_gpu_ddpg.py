@@ -11,6 +11,11 @@ def test_ddpg_learner_matches_reference_golden(name):
     DH.run_and_check(name)
 
 
+def test_ddpg_resume_across_the_hard_update_at_configs2_size():
+    """ddpg.py:403-428 at interval 500 and batch 512, through the captured graph, at the 1e-5 bar (see the helper)"""
+    DH.check_resume_across_hard_update()
+
+
 ROWS_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'cfg3_cheetah512']     # low-dimensional, one critic, no LayerNorm
 
 
