@@ -20,7 +20,7 @@ timing = hasattr(K.lib, 'smx_rollout_debug_tbuf')
 for n in [int(a) for a in sys.argv[1:]] or [1024, 4096]:
     venv = SyntheticVecEnv(n, D, A, episode_len=T)
     eps = torch.randn(T, n, A, device='cuda')
-    tb = torch.zeros(((n + 15) // 16) * 16, dtype=torch.int64, device='cuda')
+    tb = torch.zeros(((n + 3) // 4) * 16, dtype=torch.int64, device="cuda")     # (one row of 16 stamps per workgroup; 4 actors each at most)
     if timing:
         K.lib.smx_rollout_debug_tbuf.argtypes = [ctypes.c_void_p]
         K.lib.smx_rollout_debug_tbuf(ctypes.c_void_p(tb.data_ptr()))

@@ -140,35 +140,6 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
 
 #define SMX_WLD(src, i) (src)[(srow + 64 * (i)) * 8 + sk8]
 #define SMX_WST(dst, i, v) *reinterpret_cast<float4*>((dst) + (srow + 64 * (i)) * LDS16 + sk4) = (v)
-#ifdef SMX_FUSED_GLDS
-    // EXPERIMENT (scripts/build_variant_lib.py glds smx_mlp3_rows16.hip -DSMX_FUSED_GLDS=1): layer 1's
-    // weight chunks go L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  The DMA's
-    // destination is lane-linear (base + 16 lane), so the image is UNPADDED rows of 32 floats and the bank spread comes from
-    // an XOR on the 16-byte column group, applied to the per-lane SOURCE address: group c of row r sits at c ^ ((r >> 1) & 7)
-    // -- conflict-free for the fragment reads under ds_read_b128's lane grouping (checked against the grouping table of
-    // MI355X_MICROARCH.md).  One instruction moves 8 rows; wavefront wv moves row groups wv, wv + 8, ...
-    const int g_drow = lane >> 3, g_dcg = lane & 7;
-    const int g_sw = (((wv & 1) << 2) | (g_drow >> 1)) & 7;                 // ((8 (wv + 8 k) + drow) >> 1) & 7 for every k
-    const int g_src = (8 * wv + g_drow) * 32 + ((g_dcg ^ g_sw) << 2);       // float offset inside a chunk, + 2048 k
-    const int g_fsw = (fm >> 1) & 7;
-    const int g_w0 = fm * 32 + ((g ^ g_fsw) << 2), g_w1 = fm * 32 + (((g ^ g_fsw) ^ 4) << 2);
-    // inline assembly, not __builtin_amdgcn_global_load_lds: hipcc orders every later ds_read behind the builtin with
-    // s_waitcnt vmcnt(0) (it cannot tell which LDS bytes the DMA writes), i.e. right behind the issue.  Hidden from its
-    // counter, the five loads only make its own vmcnt waits stricter (memory reads return in order); the waits the DMA
-    // itself needs are written out: SMX_GLDS_WAIT(n) with n = the loads issued after it.
-#define SMX_GLDS(dstbuf, chunk)                                                                                \
-    {                                                                                                          \
-        const unsigned lb_ = (unsigned)__builtin_amdgcn_readfirstlane(                                         \
-            (int)((unsigned)(size_t)(__attribute__((address_space(3))) float*)(dstbuf) + wv * 1024));          \
-        const float* gp_ = W1p + (size_t)(chunk) * P1 * 1024 + g_src;                                          \
-        _Pragma("unroll") for (int k_ = 0; k_ < (P1 * 32) / 64; ++k_)                                         \
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                  \
-                         :: "s"((unsigned)__builtin_amdgcn_readfirstlane((int)(lb_ + 8192 * k_))),            \
-                            "v"(gp_ + 2048 * k_) : "memory", "m0");                                           \
-    }
-#define SMX_GLDS_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-    static_assert((P1 * 32) % 64 == 0, "whole groups of 8 rows per wavefront");
-#endif
 
     // ======================= layer 1: acc1[t] = W1[tile t] . x^T ===========================
     f32x4 acc1[NT1];
@@ -182,26 +153,16 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         const float4 x1 = *reinterpret_cast<const float4*>(xp1 + kc);
         const float4 zm = ld16(rzm, (unsigned)kc * 4u);
         float4 zs = ld16(rzs, (unsigned)kc * 4u);
-#ifdef SMX_FUSED_GLDS
-        SMX_GLDS(Wb0, 0)
-        (void)wsrc;
-#else
         const float4 w0 = SMX_WLD(wsrc, 0), w1 = SMX_WLD(wsrc, 1), w2 = SMX_WLD(wsrc, 2), w3 = SMX_WLD(wsrc, 3);
         float4 w4 = w3;
         if (NW1 > 4) w4 = SMX_WLD(wsrc, 4);
-#endif
         const float4 rz = make_float4(1.0f / zs.x, 1.0f / zs.y, 1.0f / zs.z, 1.0f / zs.w);
         const bool kin = sk4 < A.D;
         stage_x16(Xb0 + srow * LDS16 + sk4, x0, zm, rz, hasz, xok0 && kin);
         stage_x16(Xb0 + (srow + 64) * LDS16 + sk4, x1, zm, rz, hasz, xok1 && kin);
-#ifndef SMX_FUSED_GLDS
         SMX_WST(Wb0, 0, w0); SMX_WST(Wb0, 1, w1); SMX_WST(Wb0, 2, w2); SMX_WST(Wb0, 3, w3);
         if (NW1 > 4) SMX_WST(Wb0, 4, w4);
-#endif
     }
-#ifdef SMX_FUSED_GLDS
-    SMX_GLDS_WAIT(0);
-#endif
     __syncthreads();
     TSTAMP(1);
 
@@ -223,15 +184,6 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
     constexpr int HA = (NT1 + 1) / 2, HB = NT1 - HA;     // tiles [0, HA) and [HA, NT1)
     constexpr int A1 = HA / 3, A2 = (2 * HA) / 3, B1 = HB / 3, B2 = (2 * HB) / 3;
     float4 fa[HA], fb[HB], bcur, bnxt;
-#ifdef SMX_FUSED_GLDS
-#define SMX_W1(buf) (buf)
-#define SMX_RD_A(wrow, h, i0, i1)                                                 \
-    _Pragma("unroll") for (int t = (i0); t < (i1); ++t)                           \
-        fa[t] = *reinterpret_cast<const float4*>((wrow) + t * 512 + ((h) ? g_w1 : g_w0));
-#define SMX_RD_B(wrow, h, i0, i1)                                                 \
-    _Pragma("unroll") for (int t = (i0); t < (i1); ++t)                           \
-        fb[t] = *reinterpret_cast<const float4*>((wrow) + (HA + t) * 512 + ((h) ? g_w1 : g_w0));
-#else
 #define SMX_W1(buf) ((buf) + woff)
 #define SMX_RD_A(wrow, h, i0, i1)                                                 \
     _Pragma("unroll") for (int t = (i0); t < (i1); ++t)                           \
@@ -239,7 +191,6 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
 #define SMX_RD_B(wrow, h, i0, i1)                                                 \
     _Pragma("unroll") for (int t = (i0); t < (i1); ++t)                           \
         fb[t] = *reinterpret_cast<const float4*>((wrow) + (HA + t) * 16 * LDS16 + 16 * (h));
-#endif
 #define SMX_STEP_A(e)                                                             \
     _Pragma("unroll") for (int t = 0; t < HA; ++t) acc1[t] = MFMA16(fa[t].e, bq.e, acc1[t]);
 #define SMX_STEP_B(e)                                                             \
@@ -258,14 +209,10 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         // pinned in the loop's issue order (w0 .. w4, x0, x1): s_waitcnt vmcnt counts back from the newest load,
         // and where the two paths into the loop disagree about the order hipcc waits for vmcnt(0) -- which made
         // every weight store wait for the x rows from HBM
-#ifndef SMX_FUSED_GLDS
         SMX_PIN; w0 = SMX_WLD(wsrc, 0); SMX_PIN; w1 = SMX_WLD(wsrc, 1); SMX_PIN; w2 = SMX_WLD(wsrc, 2); SMX_PIN;
         w3 = SMX_WLD(wsrc, 3); SMX_PIN;
         w4 = w3;
         if (NW1 > 4) w4 = SMX_WLD(wsrc, 4);
-#else
-        (void)wsrc; (void)w0; (void)w1; (void)w2; (void)w3; (void)w4;
-#endif
         SMX_PIN;
         x0 = *reinterpret_cast<const float4*>(xp0 + kc); SMX_PIN;
         x1 = *reinterpret_cast<const float4*>(xp1 + kc); SMX_PIN;
@@ -290,10 +237,6 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         const int kc2 = (32 * c2 + sk4 < A.D) ? 32 * c2 + sk4 : A.D - 4;     // unconditional, clamped loads
         SMX_PIN;
         TLOOP(0);
-#ifdef SMX_FUSED_GLDS
-        SMX_GLDS(Wn, cn)          // lands before this iteration's barrier (__syncthreads waits for vmcnt(0))
-        SMX_PIN;
-#endif
         // fragment thirds are issued in front of k-step groups x, y, z of the half-phase BEFORE the one that uses
         // them (two groups of slack at the least); the staging pieces follow groups x, y, z
         {   // ---- sub-chunk 0, first half ----
@@ -315,25 +258,17 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
             SMX_PIN;
             SMX_STEP_B(x) SMX_PIN;
             SMX_RD_A(SMX_W1(Wc), 1, A1, A2)
-#ifndef SMX_FUSED_GLDS
             if (!EXP(2)) { SMX_WST(Wn, 0, w0); SMX_WST(Wn, 1, w1); }
             if (!EXP(1)) { w0 = SMX_WLD(wsrc, 0); w1 = SMX_WLD(wsrc, 1); }
-#endif
             SMX_PIN;
             SMX_STEP_B(y) SMX_PIN;
             SMX_RD_A(SMX_W1(Wc), 1, A2, HA)
-#ifndef SMX_FUSED_GLDS
             if (!EXP(2)) { SMX_WST(Wn, 2, w2); SMX_WST(Wn, 3, w3); }
             if (!EXP(1)) { w2 = SMX_WLD(wsrc, 2); w3 = SMX_WLD(wsrc, 3); }
-#endif
             SMX_PIN;
             SMX_STEP_B(z) SMX_PIN;
-#ifndef SMX_FUSED_GLDS
             if (NW1 > 4 && !EXP(2)) SMX_WST(Wn, 4, w4);
             if (NW1 > 4 && !EXP(1)) w4 = SMX_WLD(wsrc, 4);
-#else
-            (void)wsrc;
-#endif
             SMX_PIN;
             SMX_STEP_B(w) SMX_PIN;
         }
@@ -364,9 +299,6 @@ __global__ __launch_bounds__(NTHR, 1) void mlp3_rows16_kernel(FusedArgs A) {
         }
         TLOOP(3);
         TLOOP(4);
-#ifdef SMX_FUSED_GLDS
-        SMX_GLDS_WAIT(2);         // everything but the two x loads issued behind the DMA
-#endif
         if (!EXP(8)) __syncthreads();
         TLOOP(5);
         {   // ---- sub-chunk 1, second half; first fragments of the next chunk ----

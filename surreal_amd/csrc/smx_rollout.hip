@@ -14,11 +14,13 @@
 // head + step), 384 launches for T = 128; here a step is the MFMA issue time of one CU for 16 rows (~12 us at
 // D = 376, [300, 200]) and the chip runs 256 such workgroups side by side (4096 actors cost what 1024 do).
 #include "smx_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
 #include "smx_epoch_pack.inc.h"
 #include "smx_epoch_mma.inc.h"
+#include "smx_rows4_mma.inc.h"
 
 // Phase timestamps exist only in a build with -DSMX_ROLLOUT_TIMING (scripts/bench_rollout.py); the product build has none.
 #ifdef SMX_ROLLOUT_TIMING
@@ -56,31 +58,38 @@ __device__ __forceinline__ float zclamp_r(float x, float m, float sd) {
 }
 
 constexpr int RNWV = 8;           // two wavefronts per SIMD: the K loops have no barrier inside, so one wave's loads
-constexpr int RNTH = 64 * RNWV;   // and epilogue hide under the other's MFMAs (a tile's arithmetic does not depend on
-                                  // which wave carries it: same bits as the four-wave epoch kernels)
-constexpr int RROWS = ER / RNWV;  // actor rows a wavefront steps in the environment phase
+constexpr int RNTH = 64 * RNWV;   // and epilogue hide under the other's MFMAs
 constexpr int RKV = 8;            // observation elements a lane owns per row (D <= 64 RKV)
-constexpr int RTG = 3;            // feature tiles a wave carries per pass (register budget of two waves per SIMD)
 
+// RG row groups of four actors per workgroup (round 6; smx_rows4_mma.inc.h).  1024 actors: RG = 1 -> 256 workgroups, one per
+// CU.  The host picks the smallest RG whose grid fits the chip once (more actors per workgroup = fewer passes over the
+// packed weights per actor; fewer = more CUs at work).
+template <int RG>
 __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
+    constexpr int RB = 4 * RG;                       // actors per workgroup
+    constexpr int WPR = RB < RNWV ? RNWV / RB : 1;   // wavefronts per actor row in the environment phase
+    constexpr int RPW = RB > RNWV ? RB / RNWV : 1;   // actor rows per wavefront
+    constexpr int KPL = RKV / WPR;                   // observation elements a lane owns per row
+    constexpr int NT = RG == 4 ? 1 : 3;              // feature tiles a wave carries per pass (register budget)
     extern __shared__ float sm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fm = lane & 15, kq = lane >> 4;
-    const long row0 = (long)blockIdx.x * ER;
+    const long row0 = (long)blockIdx.x * RB;
     int nrows = G.n - (int)row0;
-    if (nrows > ER) nrows = ER;
+    if (nrows > RB) nrows = RB;
     const int D = G.D, A = G.A, R = G.R;
     float* xs = sm;
     float* h1s = sm + G.off_h1;
     float* h2s = sm + G.off_h2;
     float* outs = sm + G.off_out;
-    float* s_act = sm + G.off_act;              // [16][RMAX_A] clipped actions
+    float* s_act = sm + G.off_act;              // [RB][RMAX_A] clipped actions
     const int ldx = G.ldx, ldh1 = G.ldh1, ldh2 = G.ldh2;
 
     // ---- once: clear the tiles; the z-filter's mean / std and k % A (an integer division per element and step
-    // otherwise) go to LDS tables; a lane owns elements k = lane + 64 i of the actor rows 2 wv and 2 wv + 1 and keeps
-    // their raw state in registers for the whole rollout
+    // otherwise) go to LDS tables; the environment phase's lanes keep the raw state of their elements in registers for
+    // the whole rollout: wave wv owns rows RPW wv .. (RB >= 8) or the part `part` of row wv / WPR (RB = 4), a lane the
+    // elements k = lane + 64 (part + WPR i)
     for (int i = tid; i < G.off_z; i += RNTH) sm[i] = 0.f;          // (incl. the action tile: its unused columns stay 0)
     float* zm = sm + G.off_z;                   // [D] z-filter mean | [D] std | [D] k % A (as int)
     float* zs = zm + D;
@@ -97,23 +106,24 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
         }
         zm[k] = m; zs[k] = sz;
     }
-    float st[RROWS][RKV];
+    const int erow0 = RPW * (wv / WPR), part = wv % WPR;
+    float st[RPW][KPL];
 #pragma unroll
-    for (int i = 0; i < RKV; ++i) {
-        const int k = lane + 64 * i;
+    for (int i = 0; i < KPL; ++i) {
+        const int k = lane + 64 * (part + WPR * i);
 #pragma unroll
-        for (int rr = 0; rr < RROWS; ++rr) {
-            const int r = RROWS * wv + rr;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = erow0 + rr;
             st[rr][i] = (k < D && r < nrows) ? G.state[(row0 + r) * D + k] : 0.f;
         }
     }
     SMX_LDS_BARRIER();
 #pragma unroll
-    for (int rr = 0; rr < RROWS; ++rr) {
-        const int r = RROWS * wv + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = erow0 + rr;
 #pragma unroll
-        for (int i = 0; i < RKV; ++i) {
-            const int k = lane + 64 * i;
+        for (int i = 0; i < KPL; ++i) {
+            const int k = lane + 64 * (part + WPR * i);
             if (k < D && r < nrows) xs[r * ldx + k] = G.zsum ? zclamp_r(st[rr][i], zm[k], zs[k]) : st[rr][i];
         }
     }
@@ -126,10 +136,10 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
         const int slot = G.slot0 + step;
         RSTAMP(0);
         // this step's normal draw of the lane's (row, action) pair, requested before the layers (consumed behind them)
-        const int hr = tid / A, hj = tid - hr * A;        // 16 x A <= 512 pairs
+        const int hr = tid / A, hj = tid - hr * A;        // RB x A <= 512 pairs
         float ev = 0.f;
         if (G.eps && hr < nrows) ev = G.eps[((size_t)step * G.n + row0 + hr) * A + hj];
-        // ---- the three layers: the loop of epoch_fwd_kernel without its global stores ---------------------
+        // ---- the three layers ------------------------------------------------------------------------------
 #pragma unroll 1
         for (int l = 0; l < 3; ++l) {
             const float* Wp = l == 0 ? G.P1 : (l == 1 ? G.P2 : G.P3);
@@ -145,36 +155,35 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
             const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
             const rsrc_t rbias = make_rsrc(bias, (unsigned)H * 4u);
 #pragma unroll 1
-            for (int tb = 0; tb < tiles; tb += RNWV * RTG) {
+            for (int tb = 0; tb < tiles; tb += RNWV * NT) {
                 const int t0 = tb + wv;
-                int nt = (tiles - t0 + RNWV - 1) / RNWV;
-                nt = nt < 0 ? 0 : (nt > RTG ? RTG : nt);
-                float bs[RTG][4];
+                if (t0 >= tiles) continue;                            // (wave-uniform)
+                float bs[NT];
 #pragma unroll
-                for (int g = 0; g < RTG; ++g) {
-                    const int f0 = 16 * (t0 + RNWV * g) + 4 * kq;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rbias, (g < nt) ? (unsigned)(f0 + r) * 4u : OOB);
+                for (int g = 0; g < NT; ++g) {
+                    const int f = 16 * (t0 + RNWV * g) + fm;
+                    bs[g] = ld4(rbias, (f < H) ? (unsigned)f * 4u : OOB);
                 }
-                f32x4 acc[TG];
+                f32x4 acc[NT][RG];
 #pragma unroll
-                for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (nt > 2) fwd_tiles<3>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
-                else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
-                else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                for (int g = 0; g < NT; ++g)
 #pragma unroll
-                for (int g = 0; g < RTG; ++g) {
-                    if (g < nt) {
-                        const int f0 = 16 * (t0 + RNWV * g) + 4 * kq;
-                        float v[4];
+                    for (int r = 0; r < RG; ++r) acc[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                fwd_tiles4<NT, RG>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                // the kq groups meet; lane (fm, kq) then keeps row kq of every group: bias, activation, one word to LDS
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float z = acc[g][r] + bs[g][r];
+                for (int g = 0; g < NT; ++g) {
+                    const int f = 16 * (t0 + RNWV * g) + fm;
+                    if (t0 + RNWV * g < tiles) {                      // (wave-uniform)
+#pragma unroll
+                        for (int r = 0; r < RG; ++r) {
+                            const f32x4 v = meet_kq(acc[g][r]);
+                            float z = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));
+                            z += bs[g];
                             if (l == 2) z = act_f(z, G.out_act);
                             else z = (z < 0.f) ? 0.f : z;
-                            v[r] = (f0 + r < H) ? z : 0.f;
+                            out_lds[(4 * r + kq) * ldo + f] = (f < H) ? z : 0.f;
                         }
-                        *(float4*)(out_lds + fm * ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -199,17 +208,17 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
         }
         SMX_LDS_BARRIER();
         RSTAMP(4);
-        // ---- environment step of the 16 actors (smx_synth_env_step_f32's expressions), recording, next x tile ---
+        // ---- environment step of the actors (smx_synth_env_step_f32's expressions), recording, next x tile ------
 #pragma unroll
-        for (int rr = 0; rr < RROWS; ++rr) {
-            const int r = RROWS * wv + rr;                 // wave-uniform
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = erow0 + rr;                      // wave-uniform
             if (r < nrows) {
                 const long a = row0 + r;
                 float* orow = G.obs_roll ? G.obs_roll + (a * R + slot) * D : nullptr;
                 float sn0 = 0.f;
 #pragma unroll
-                for (int i = 0; i < RKV; ++i) {
-                    const int k = lane + 64 * i;
+                for (int i = 0; i < KPL; ++i) {
+                    const int k = lane + 64 * (part + WPR * i);
                     if (k < D) {
                         const float ac = s_act[r * RMAX_A + kmod[k]];
                         const float s = st[rr][i];
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
                         xs[r * ldx + k] = G.zsum ? zclamp_r(next, zm[k], zs[k]) : next;
                     }
                 }
-                if (lane == 0) {                            // (k == 0 lives in lane 0, i == 0)
+                if (lane == 0 && part == 0) {               // (k == 0 lives in lane 0, i == 0 of the row's first wave)
                     // sum_j a_j^2 in fp64, j ascending (the order of smx_synth_env_step_f32).  All RMAX_A reads are
                     // issued up front (unused columns of the tile are zero and add +0.0): one LDS round trip, not A
                     float av[RMAX_A];
@@ -248,11 +257,11 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
     RWALL(14); RCYC(15);
     // ---- the states the actors are left in ---------------------------------------------------------------
 #pragma unroll
-    for (int rr = 0; rr < RROWS; ++rr) {
-        const int r = RROWS * wv + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = erow0 + rr;
 #pragma unroll
-        for (int i = 0; i < RKV; ++i) {
-            const int k = lane + 64 * i;
+        for (int i = 0; i < KPL; ++i) {
+            const int k = lane + 64 * (part + WPR * i);
             if (k < D && r < nrows) G.state[(row0 + r) * D + k] = st[rr][i];
         }
     }
@@ -260,15 +269,29 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
 
 inline int rr64(int v) { return (v + 63) & ~63; }
 
-int carve(RollArgs& G) {
-    G.ldx = rr64(G.D) + 4; G.ldh1 = rr64(G.H1) + 4; G.ldh2 = rr64(G.H2) + 4;
-    G.off_h1 = ER * G.ldx;
-    G.off_h2 = G.off_h1 + ER * G.ldh1;
-    G.off_out = G.off_h2 + ER * G.ldh2;
-    G.off_act = G.off_out + ER * RLDO;
-    G.off_z = G.off_act + ER * RMAX_A;
+// row strides = 16 mod 64 words: the rows of a group (a word's lanes: row l & 3, k offset 8 (l >> 4)) and the epilogue's
+// one-word stores (row kq, feature fm) fall on distinct banks of the 64.  A tile holds pack_chunks(K) * 32 + 8 columns at
+// least (the loop's last prefetch reads one chunk it does not use).
+int carve(RollArgs& G, int RB) {
+    G.ldx = rr64(G.D + 40) + 16; G.ldh1 = rr64(G.H1 + 40) + 16; G.ldh2 = rr64(G.H2 + 40) + 16;
+    G.off_h1 = RB * G.ldx;
+    G.off_h2 = G.off_h1 + RB * G.ldh1;
+    G.off_out = G.off_h2 + RB * G.ldh2;
+    G.off_act = G.off_out + RB * RLDO;
+    G.off_z = G.off_act + RB * RMAX_A;
     G.lds_floats = G.off_z + 3 * G.D;
     return G.lds_floats * (int)sizeof(float);
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
 }
 
 constexpr int ROLL_MAX_LDS = 150 * 1024;
@@ -287,7 +310,7 @@ extern "C" int32_t smx_synth_rollout_supported(int32_t D, int32_t H1, int32_t H2
     RollArgs G;
     memset(&G, 0, sizeof(G));
     G.D = D; G.H1 = H1; G.H2 = H2; G.A = A;
-    return carve(G) <= ROLL_MAX_LDS;
+    return carve(G, 16) <= ROLL_MAX_LDS;
 }
 
 extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t stream) {
@@ -313,16 +336,30 @@ extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t 
     G.n = a->n; G.t0 = a->t; G.episode_len = a->episode_len; G.steps = a->steps; G.R = a->rows_per_actor; G.slot0 = a->slot;
     G.obs_roll = a->obs_roll; G.act_roll = a->act_roll; G.rew_roll = a->rew_roll; G.done_roll = a->done_roll;
     G.pd_roll = a->pd_roll; G.obs_last = a->obs_last;
-    int lds = carve(G);
-    // one workgroup per CU: each keeps the four matrix pipes of a CU busy by itself
+    // the smallest row-group count whose grid fits the chip once (SMX_ROLLOUT_RG = 1 | 2 | 4 overrides: measurements)
+    int rg = 4;
+    for (int c = 1; c <= 4; c *= 2)
+        if ((a->n + 4 * c - 1) / (4 * c) <= device_cus()) { rg = c; break; }
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("SMX_ROLLOUT_RG");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2 || forced == 4) rg = forced;
+    int lds = carve(G, 4 * rg);
+    // one workgroup per CU: each streams the packed weights through the CU's four SIMDs by itself
     if (lds < ROLL_EXCLUSIVE_LDS) lds = ROLL_EXCLUSIVE_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)rollout_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)rollout_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)rollout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
         attr_set = true;
     }
-    const int blocks = (a->n + ER - 1) / ER;
-    hipLaunchKernelGGL(rollout_kernel, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
+    const int blocks = (a->n + 4 * rg - 1) / (4 * rg);
+    if (rg == 1) hipLaunchKernelGGL(rollout_kernel<1>, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
+    else if (rg == 2) hipLaunchKernelGGL(rollout_kernel<2>, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
+    else hipLaunchKernelGGL(rollout_kernel<4>, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
