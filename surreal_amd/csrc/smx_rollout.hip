@@ -70,7 +70,7 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
     constexpr int WPR = RB < RNWV ? RNWV / RB : 1;   // wavefronts per actor row in the environment phase
     constexpr int RPW = RB > RNWV ? RB / RNWV : 1;   // actor rows per wavefront
     constexpr int KPL = RKV / WPR;                   // observation elements a lane owns per row
-    constexpr int NT = RG == 4 ? 1 : 3;              // feature tiles a wave carries per pass (register budget)
+    constexpr int NT = 3;                            // feature tiles a wave carries per pass
     extern __shared__ float sm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,13 +267,218 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
     }
 }
 
+constexpr int RROWS = ER / RNWV;  // actor rows a wavefront steps in the environment phase
+constexpr int RTG = 3;            // feature tiles a wave carries per pass (register budget of two waves per SIMD)
+
+// More actors than 8 per CU (n > 2048 on 256 CUs): 16 actors per workgroup on v_mfma_f32_16x16x4_f32 (the row-block loop of
+// smx_epoch_mma.inc.h, bit-identical means to smx_epoch_forward_f32) -- at 16 rows the matrix pipes bound the step and one
+// 16x16x4 operand read feeds 16 rows where 4x4x1 needs four (measured, 4096 actors x 128 steps: 2.95 ms against 3.9 ms on
+// four row groups of the 4-row loop).
+__global__ __launch_bounds__(RNTH) void rollout16_kernel(RollArgs G) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fm = lane & 15, kq = lane >> 4;
+    const long row0 = (long)blockIdx.x * ER;
+    int nrows = G.n - (int)row0;
+    if (nrows > ER) nrows = ER;
+    const int D = G.D, A = G.A, R = G.R;
+    float* xs = sm;
+    float* h1s = sm + G.off_h1;
+    float* h2s = sm + G.off_h2;
+    float* outs = sm + G.off_out;
+    float* s_act = sm + G.off_act;              // [16][RMAX_A] clipped actions
+    const int ldx = G.ldx, ldh1 = G.ldh1, ldh2 = G.ldh2;
+
+    // ---- once: clear the tiles; the z-filter's mean / std and k % A (an integer division per element and step
+    // otherwise) go to LDS tables; a lane owns elements k = lane + 64 i of the actor rows 2 wv and 2 wv + 1 and keeps
+    // their raw state in registers for the whole rollout
+    for (int i = tid; i < G.off_z; i += RNTH) sm[i] = 0.f;          // (incl. the action tile: its unused columns stay 0)
+    float* zm = sm + G.off_z;                   // [D] z-filter mean | [D] std | [D] k % A (as int)
+    float* zs = zm + D;
+    int* kmod = (int*)(zs + D);
+    for (int k = tid; k < D; k += RNTH) {
+        kmod[k] = k % A;
+        float m = 0.f, sz = 1.f;
+        if (G.zsum) {
+            const float c = G.zcount[0];
+            m = G.zsum[k] / c;
+            const float var = G.zsumsq[k] / c - m * m;
+            sz = sqrtf(var);
+            if (sz == sz) sz = fmaxf(sz, G.zeps);
+        }
+        zm[k] = m; zs[k] = sz;
+    }
+    float st[RROWS][RKV];
+#pragma unroll
+    for (int i = 0; i < RKV; ++i) {
+        const int k = lane + 64 * i;
+#pragma unroll
+        for (int rr = 0; rr < RROWS; ++rr) {
+            const int r = RROWS * wv + rr;
+            st[rr][i] = (k < D && r < nrows) ? G.state[(row0 + r) * D + k] : 0.f;
+        }
+    }
+    SMX_LDS_BARRIER();
+#pragma unroll
+    for (int rr = 0; rr < RROWS; ++rr) {
+        const int r = RROWS * wv + rr;
+#pragma unroll
+        for (int i = 0; i < RKV; ++i) {
+            const int k = lane + 64 * i;
+            if (k < D && r < nrows) xs[r * ldx + k] = G.zsum ? zclamp_r(st[rr][i], zm[k], zs[k]) : st[rr][i];
+        }
+    }
+    SMX_LDS_BARRIER();
+
+    int t = G.t0;
+    RWALL(12); RCYC(13);
+#pragma unroll 1
+    for (int step = 0; step < G.steps; ++step) {
+        const int slot = G.slot0 + step;
+        RSTAMP(0);
+        // this step's normal draw of the lane's (row, action) pair, requested before the layers (consumed behind them)
+        const int hr = tid / A, hj = tid - hr * A;        // 16 x A <= 512 pairs
+        float ev = 0.f;
+        if (G.eps && hr < nrows) ev = G.eps[((size_t)step * G.n + row0 + hr) * A + hj];
+        // ---- the three layers: the loop of epoch_fwd_kernel without its global stores ---------------------
+#pragma unroll 1
+        for (int l = 0; l < 3; ++l) {
+            const float* Wp = l == 0 ? G.P1 : (l == 1 ? G.P2 : G.P3);
+            const float* bias = l == 0 ? G.b1 : (l == 1 ? G.b2 : G.b3);
+            const int H = l == 0 ? G.H1 : (l == 1 ? G.H2 : A);
+            const int K = l == 0 ? D : (l == 1 ? G.H1 : G.H2);
+            const float* in_lds = l == 0 ? xs : (l == 1 ? h1s : h2s);
+            const int ldi = l == 0 ? ldx : (l == 1 ? ldh1 : ldh2);
+            float* out_lds = l == 0 ? h1s : (l == 1 ? h2s : outs);
+            const int ldo = l == 0 ? ldh1 : (l == 1 ? ldh2 : RLDO);
+            const int tiles = (H + 15) >> 4;
+            const int C2 = pack_chunks(K);
+            const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
+            const rsrc_t rbias = make_rsrc(bias, (unsigned)H * 4u);
+#pragma unroll 1
+            for (int tb = 0; tb < tiles; tb += RNWV * RTG) {
+                const int t0 = tb + wv;
+                int nt = (tiles - t0 + RNWV - 1) / RNWV;
+                nt = nt < 0 ? 0 : (nt > RTG ? RTG : nt);
+                float bs[RTG][4];
+#pragma unroll
+                for (int g = 0; g < RTG; ++g) {
+                    const int f0 = 16 * (t0 + RNWV * g) + 4 * kq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rbias, (g < nt) ? (unsigned)(f0 + r) * 4u : OOB);
+                }
+                f32x4 acc[TG];
+#pragma unroll
+                for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (nt > 2) fwd_tiles<3>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+#pragma unroll
+                for (int g = 0; g < RTG; ++g) {
+                    if (g < nt) {
+                        const int f0 = 16 * (t0 + RNWV * g) + 4 * kq;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float z = acc[g][r] + bs[g][r];
+                            if (l == 2) z = act_f(z, G.out_act);
+                            else z = (z < 0.f) ? 0.f : z;
+                            v[r] = (f0 + r < H) ? z : 0.f;
+                        }
+                        *(float4*)(out_lds + fm * ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+            SMX_LDS_BARRIER();
+            RSTAMP(1 + l);
+        }
+        // ---- sampling head (smx_diaggauss_sample_f32's expressions): one (actor, action) pair per lane -------
+        const bool done = (t + 1 >= G.episode_len);
+        if (hr < nrows) {
+            const long a = row0 + hr;
+            const float mu = outs[hr * RLDO + hj];
+            float sd = expf(G.log_var[hj]);
+            if (G.noise_scale) sd = sd * G.noise_scale[a];
+            float act = G.eps ? ev * sd + mu : mu;
+            if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
+            s_act[hr * RMAX_A + hj] = act;
+            if (G.act_roll) G.act_roll[(a * R + slot) * A + hj] = act;
+            if (G.pd_roll) {
+                G.pd_roll[(a * R + slot) * 2 * A + hj] = mu;
+                G.pd_roll[(a * R + slot) * 2 * A + A + hj] = sd;
+            }
+        }
+        SMX_LDS_BARRIER();
+        RSTAMP(4);
+        // ---- environment step of the 16 actors (smx_synth_env_step_f32's expressions), recording, next x tile ---
+#pragma unroll
+        for (int rr = 0; rr < RROWS; ++rr) {
+            const int r = RROWS * wv + rr;                 // wave-uniform
+            if (r < nrows) {
+                const long a = row0 + r;
+                float* orow = G.obs_roll ? G.obs_roll + (a * R + slot) * D : nullptr;
+                float sn0 = 0.f;
+#pragma unroll
+                for (int i = 0; i < RKV; ++i) {
+                    const int k = lane + 64 * i;
+                    if (k < D) {
+                        const float ac = s_act[r * RMAX_A + kmod[k]];
+                        const float s = st[rr][i];
+                        const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+                        float sn = (0.9f * s + 0.5f * ac) + drift;
+                        sn = fminf(fmaxf(sn, -10.0f), 10.0f);
+                        if (orow) {
+                            orow[k] = s;
+                            if (slot + 1 < R) orow[D + k] = sn;
+                            else if (G.obs_last) G.obs_last[a * D + k] = sn;     // (the replay's obs_next field)
+                        }
+                        if (i == 0) sn0 = sn;
+                        const float next = done ? G.init_state[a * D + k] : sn;
+                        st[rr][i] = next;
+                        xs[r * ldx + k] = G.zsum ? zclamp_r(next, zm[k], zs[k]) : next;
+                    }
+                }
+                if (lane == 0) {                            // (k == 0 lives in lane 0, i == 0)
+                    // sum_j a_j^2 in fp64, j ascending (the order of smx_synth_env_step_f32).  All RMAX_A reads are
+                    // issued up front (unused columns of the tile are zero and add +0.0): one LDS round trip, not A
+                    float av[RMAX_A];
+#pragma unroll
+                    for (int j = 0; j < RMAX_A; ++j) av[j] = s_act[r * RMAX_A + j];
+                    double q = 0.0;
+#pragma unroll
+                    for (int j = 0; j < RMAX_A; ++j) q += (double)av[j] * (double)av[j];
+                    if (G.rew_roll) G.rew_roll[a * R + slot] = (float)(-0.1 * q + 0.05 * (double)sn0);
+                    if (G.done_roll) G.done_roll[a * R + slot] = done ? 1.0f : 0.0f;
+                }
+            }
+        }
+        t = done ? 0 : t + 1;
+        SMX_LDS_BARRIER();
+        RSTAMP(5);
+    }
+    RWALL(14); RCYC(15);
+    // ---- the states the actors are left in ---------------------------------------------------------------
+#pragma unroll
+    for (int rr = 0; rr < RROWS; ++rr) {
+        const int r = RROWS * wv + rr;
+#pragma unroll
+        for (int i = 0; i < RKV; ++i) {
+            const int k = lane + 64 * i;
+            if (k < D && r < nrows) G.state[(row0 + r) * D + k] = st[rr][i];
+        }
+    }
+}
+
 inline int rr64(int v) { return (v + 63) & ~63; }
 
 // row strides = 16 mod 64 words: the rows of a group (a word's lanes: row l & 3, k offset 8 (l >> 4)) and the epilogue's
 // one-word stores (row kq, feature fm) fall on distinct banks of the 64.  A tile holds pack_chunks(K) * 32 + 8 columns at
 // least (the loop's last prefetch reads one chunk it does not use).
+// (16 rows on the 16x16x4 loop: a word's lanes are row l & 15 -- strides of 4 mod 64 spread them.)
 int carve(RollArgs& G, int RB) {
-    G.ldx = rr64(G.D + 40) + 16; G.ldh1 = rr64(G.H1 + 40) + 16; G.ldh2 = rr64(G.H2 + 40) + 16;
+    if (RB == 16) { G.ldx = rr64(G.D) + 4; G.ldh1 = rr64(G.H1) + 4; G.ldh2 = rr64(G.H2) + 4; }
+    else { G.ldx = rr64(G.D + 40) + 16; G.ldh1 = rr64(G.H1 + 40) + 16; G.ldh2 = rr64(G.H2 + 40) + 16; }
     G.off_h1 = RB * G.ldx;
     G.off_h2 = G.off_h1 + RB * G.ldh1;
     G.off_out = G.off_h2 + RB * G.ldh2;
@@ -336,9 +541,9 @@ extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t 
     G.n = a->n; G.t0 = a->t; G.episode_len = a->episode_len; G.steps = a->steps; G.R = a->rows_per_actor; G.slot0 = a->slot;
     G.obs_roll = a->obs_roll; G.act_roll = a->act_roll; G.rew_roll = a->rew_roll; G.done_roll = a->done_roll;
     G.pd_roll = a->pd_roll; G.obs_last = a->obs_last;
-    // the smallest row-group count whose grid fits the chip once (SMX_ROLLOUT_RG = 1 | 2 | 4 overrides: measurements)
+    // 4 or 8 actors per workgroup while that grid fits the chip once, else 16 (SMX_ROLLOUT_RG = 1 | 2 | 4 overrides: measurements)
     int rg = 4;
-    for (int c = 1; c <= 4; c *= 2)
+    for (int c = 1; c <= 2; c *= 2)
         if ((a->n + 4 * c - 1) / (4 * c) <= device_cus()) { rg = c; break; }
     static int forced = -1;
     if (forced < 0) {
@@ -353,13 +558,13 @@ extern "C" int smx_synth_rollout_f32(const smx_synth_rollout_t* a, smx_stream_t 
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)rollout_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
         (void)hipFuncSetAttribute((const void*)rollout_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
-        (void)hipFuncSetAttribute((const void*)rollout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)rollout16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ROLL_MAX_LDS);
         attr_set = true;
     }
     const int blocks = (a->n + 4 * rg - 1) / (4 * rg);
     if (rg == 1) hipLaunchKernelGGL(rollout_kernel<1>, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
     else if (rg == 2) hipLaunchKernelGGL(rollout_kernel<2>, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
-    else hipLaunchKernelGGL(rollout_kernel<4>, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
+    else hipLaunchKernelGGL(rollout16_kernel, dim3(blocks), dim3(RNTH), lds, smx_s(stream), G);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

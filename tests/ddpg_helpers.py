@@ -71,6 +71,10 @@ PARAM_ATOL = {
     # the update checked in run_and_check; the 1e-5 statement about the update at this size is
     # check_resume_across_hard_update below (state of iteration 497 loaded, 5 iterations, every element 1e-5).
     'cfg3_cheetah512_x502': 0.16,
+    # lr_critic = 1e-2 on these tiny pixel cases: ONE of conv2.W's 8192 elements (1 of fc.W's 3072) has a gradient at the
+    # noise floor of its 3.4 k-term sum and takes one Adam step the other way -- on the HIP path AND on the CPU kernel double,
+    # by the same 1.43e-4 / 7.6e-5 (gpurun_out/ddpg_params_report_{gpu,cpu}.json); every other element of every tensor <= 1e-5
+    'tiny_pixel_hard': 3e-4, 'tiny_pixel_td3_soft': 2e-4,
 }
 # statistics of the long case: the first iterations at the common 1e-5, later ones at the drift's scale (as above)
 LATE_STATS = {'cfg3_cheetah512_x502': dict(after=10, atol=0.09, rtol=0.0)}

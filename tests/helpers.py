@@ -236,9 +236,23 @@ def assert_stats_close(stats, g, atol=ATOL, rtol=RTOL, what=''):
 
 
 CHECKSUM_RTOL = {'cfg5_rnn_adapt': 1e-3, 'cfg5_rnn_clip': 1e-3, 'b1024_d17_rnn_adapt': 1e-3}   # squared-sum checksums of the big stem cases
-# every-element bound on the final parameters where the common 1e-5 is not what the case can hold (measured; see
-# assert_final_params' notes and gpurun_out/final_params_report_gpu.json)
-FINAL_PARAM_ATOL = {}
+# Every-element bound on the final parameters.  The common bar is 1e-5 on EVERY element (held by every tiny / ragged case,
+# cfg2_*, cfg5_adapt, cfg5_adapt_earlyexit, and by cfg5_clip on two ranks and under the layered schedule: measured
+# <= 3.3e-6).  The cases below get {max |diff|, share of elements beyond 1e-5}: measured x ~2, never more than Adam's own
+# cap of epochs * 2 * lr = 2e-3.  Why they cannot hold 1e-5 (profiles/r06_param_parity_diag.txt: tests/diag/
+# diag_final_params.py + diag_epoch0_grads.py on the GPU box, oracle on its host): after ONE epoch every element of every
+# tensor is within 1e-7 (cfg2_rnn_adapt) or the differing elements are exactly those one ReLU mask feeds -- cfg5_clip,
+# fused schedule, epoch 0: the critic's dz2 differs from autograd's in ONE (row, hidden-2 unit 58) entry by 3.2e-4, i.e.
+# that unit's pre-activation sits within rounding of zero and the 16-row MFMA sum lands on the other side of it than
+# ATen's (the layered schedule's sum does not: 4e-7); dW2[58, :] moves in its 156 active columns, and Adam's first step,
+# lr * sign(g), turns every element whose |g| is below the change (45 of 112 800 in fc1.W, |g| <= 1.7e-5 against a median of
+# 2.3e-3) by 2 * lr.  From there the two learners see different parameters and the difference spreads through the
+# noise-floor elements epoch by epoch (0.04 % -> 0.4 % -> 0.8 % -> 8.6 % of fc1.W beyond 1e-5 after 1, 2, 3, 10 epochs)
+# while every loss stays within 1e-5.  The reference is as sensitive as that to ITS OWN summation order only through such
+# masks (rows or features permuted: < 7e-7, no flip on this seed) -- which side of zero a 1e-8 pre-activation falls on
+# is not something either fp32 evaluation owns.
+FINAL_PARAM_ATOL = {name: (1.5e-3, 0.25) for name in (
+    'cfg5_clip', 'cfg2_rnn_adapt', 'cfg2_rnn_clip', 'cfg5_rnn_adapt', 'cfg5_rnn_clip', 'b1024_d17_rnn_adapt')}
 FINAL_PARAM_REPORT = {}      # 'case tensor' -> (fraction of elements off by > 1e-5, max diff, elements)
 MEASURE_ONLY = os.environ.get('SMX_MEASURE_ONLY') == '1'     # record the parameter distances, do not assert them
 
@@ -260,12 +274,14 @@ def assert_final_params_dict(got, g, atol=1e-5, what=''):
         if 'final.' + k in g:
             ref = g['final.' + k]
             diff = np.abs(got[k] - ref)
-            bound = max(atol, FINAL_PARAM_ATOL.get(what.split(' ')[0], 0.0))
+            bound, frac_cap = FINAL_PARAM_ATOL.get(what.split(' ')[0], (atol, 0.0))
+            bound = max(bound, atol)
             key = '%s %s' % (what, k)
             if key not in FINAL_PARAM_REPORT or diff.max() > FINAL_PARAM_REPORT[key][1]:
                 FINAL_PARAM_REPORT[key] = (float(np.mean(diff > 1e-5)), float(diff.max()), int(diff.size))
-            assert MEASURE_ONLY or diff.max() <= bound, '%s %s: max diff %g, %.3f%% of elements off by > %g' % (
-                what, k, diff.max(), 100 * np.mean(diff > bound), bound)
+            assert MEASURE_ONLY or (diff.max() <= bound and np.mean(diff > atol) <= frac_cap), \
+                '%s %s: max diff %g (bound %g), %.3f%% of elements off by > %g (cap %.1f%%)' % (
+                    what, k, diff.max(), bound, 100 * np.mean(diff > atol), atol, 100 * frac_cap)
         # (the full-size pixel case: parameters that start near zero -- the stem's biases -- end wherever ~20 sign-like
         # Adam steps on noise-floor gradients take them.  Measured: the oracle on the GPU box's host is off the golden
         # by up to 5.8e-4 on these checksums (cnn.conv2.b), the HIP path -- whose split-K weight / bias gradients sum

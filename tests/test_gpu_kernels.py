@@ -1621,9 +1621,10 @@ def test_persistent_rollout_kernel(K, n, D, A, hidden, T, ep, use_z, det):
 
 
 @pytest.mark.parametrize('rg', [1, 2, 4])
-def test_persistent_rollout_kernel_row_group_counts_agree_bit_for_bit(K, rg):
-    """4, 8 and 16 actors per workgroup are the same arithmetic per actor (a row group is independent of its
-    neighbours in the workgroup): bit-identical recordings, incl. a partial last workgroup"""
+def test_persistent_rollout_kernel_row_group_counts_agree(K, rg):
+    """4 and 8 actors per workgroup are the same arithmetic per actor (a row group is independent of its neighbours in
+    the workgroup): bit-identical recordings, incl. a partial last workgroup.  16 actors per workgroup (what more than
+    2048 actors run on) is the 16x16x4 loop: equal to fp32 rounding of the layer sums."""
     import subprocess
     import sys
     # the row-group override is read once per process: one child per forced value, compared through a file
@@ -1646,6 +1647,8 @@ torch.save({k: v for k, v in out.items()}, sys.argv[1])
     for k in outs[0]:
         if k == 't':
             assert outs[0][k] == outs[1][k]
+        elif rg == 4:
+            np.testing.assert_allclose(outs[0][k].numpy(), outs[1][k].numpy(), rtol=2e-6, atol=2e-6, err_msg=k)
         else:
             assert torch.equal(outs[0][k], outs[1][k]), k
 
