@@ -380,7 +380,8 @@ def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=None, sample_row
     import ppo_oracle
     budget_s = _CPU_BUDGET[0] if budget_s is None else budget_s
     prev = torch.get_num_threads()
-    if sample_rows and sample_rows < Bs:
+    sampled = bool(sample_rows and sample_rows < Bs)
+    if sampled:
         batch = slice_batch(batch, 0, sample_rows)
         Bs = sample_rows
     kw = dict(n_step=Ns, kl_target=1e9, ppo_mode=mode)
@@ -409,8 +410,10 @@ def cpu_ppo(Bs, Ns, Ds, As, rnn, pixel, params, batch, budget_s=None, sample_row
     dt, n, k, cold = best
     out = {'value': Bs * Ns / dt, 'unit': 'env-steps/s', 'cores': n, 'kind': 'port', 's_per_learn': dt,
            'sample': '%d timed learn(s) of %d x %d (%s), torch %s CPU, the better of 8 and %d threads%s' % (
-               k, Bs, Ns, 'full batch' if not sample_rows else 'the first %d sub-trajectories of the batch' % Bs,
+               k, Bs, Ns, 'full batch' if not sampled else 'the first %d sub-trajectories of the batch' % Bs,
                torch.__version__, _cpu_threads(), ' (single call, no warm-up: one learn takes seconds)' if cold else '')}
+    if sampled:
+        out['sample_rows'] = Bs
     out['port'] = {'value': out['value'], 'cores': n, 's_per_learn': dt}
     # the reference's own code at the same thread count (build container, opt-in) when the budget allows one more leg:
     # the baseline quoted is the faster of the two (the port is ~20 % slower than the reference on the LSTM policy)
@@ -840,6 +843,8 @@ def summary_row(r):
     cb = r.get('cpu_baseline')
     if isinstance(cb, dict) and cb.get('value') is not None:
         row['cpu'] = '%.4g@%d %s' % (cb['value'], cb.get('cores', 0), cb.get('kind', 'port'))
+        if cb.get('sample_rows'):       # the CPU learn ran on a row sample of the batch: its rate is per env-step of the SAMPLE
+            row['cpu'] += ' extrapolated from %d rows' % cb['sample_rows']
         row['x_cpu'] = r.get('gpu_over_cpu')
     return {k: v for k, v in row.items() if v is not None}
 
@@ -854,11 +859,14 @@ def compact_line(full, full_path=None):
     out.update(_pick(full, ('dtype', 'data', 'error')))
     cfg = full.get('config', {})
     out['config'] = _pick(cfg, ('workload', 'mode', 'B_per_gpu', 'n_step', 'obs_dim', 'action_dim', 'hidden', 'epochs', 'hip_graph',
-                                'parallelism', 'epoch_kernels', 'collectives_per_step', 'exchange', 'epoch_all_reduce_us',
-                                'epoch_all_reduce_bytes', 'graph_segments'))
+                                'parallelism', 'epoch_kernels', 'collectives_per_step', 'exchange', 'exchange_fallback_reason',
+                                'rccl_ranks', 'epoch_all_reduce_us', 'epoch_all_reduce_bytes', 'graph_segments'))
+    if isinstance(out['config'].get('exchange_fallback_reason'), str):
+        out['config']['exchange_fallback_reason'] = out['config']['exchange_fallback_reason'][:160]
     if 'roofline' in full:
         out['roofline'] = _pick(full['roofline'], ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
-                                                   'mfma_busy_pct', 'kernel_ms', 'algorithmic_bytes_per_launch',
+                                                   'traffic_measured_in_run', 'mfma_busy_pct', 'mfma_busy_measured_in_run',
+                                                   'kernel_ms', 'algorithmic_bytes_per_launch',
                                                    'flops_per_launch', 'share_of_step'))
         out['roofline'].setdefault('traffic', None)
     if 'step_roofline' in full:
@@ -881,13 +889,17 @@ def compact_line(full, full_path=None):
     out = _r(out)
     line = json.dumps(out)
     # belt and braces: never hand the driver a line it cannot keep whole
-    for drop in ('final_stats', 'exchange_model', 'strong', 'step_roofline'):
+    # (the strong-scaling row and the exchange fields are what an N > 1 line exists for: they go last)
+    for drop in ('final_stats', 'exchange_model', 'step_roofline'):
         if len(line) <= LINE_LIMIT:
             break
         out.pop(drop, None)
         line = json.dumps(out)
     while len(line) > LINE_LIMIT and out.get('secondary_summary'):
         out['secondary_summary'].popitem()
+        line = json.dumps(out)
+    if len(line) > LINE_LIMIT:
+        out.pop('strong', None)
         line = json.dumps(out)
     if len(line) > LINE_LIMIT:
         out['config'] = _pick(out['config'], ('workload', 'parallelism'))
@@ -1124,6 +1136,7 @@ def run(args, world, rank, local_rank, backend):
                 'epoch_kernels': 'fused row-block' if getattr(ws, 'fused', False) else 'layered',
                 'collectives_per_step': getattr(learner, 'collectives_per_step', 0 if world == 1 else None),
                 'exchange': exchange_kind,
+                'rccl_ranks': world if world > 1 else None,      # ranks in the process group (backend nccl = RCCL; SMX_BENCH_BACKEND=gloo in rehearsals)
                 'exchange_fallback_reason': _exchange_failure() if world > 1 else None,
                 'epoch_all_reduce_us': collective_us, 'epoch_all_reduce_bytes': collective_bytes,
                 'epoch_all_reduce_us_process_group': pg_us,

@@ -48,7 +48,7 @@ struct RollArgs {
     const float* init_state;
     int n, t0, episode_len, steps, R, slot0;    // R = rows per actor in the rollout tables
     float *obs_roll, *act_roll, *rew_roll, *done_roll, *pd_roll, *obs_last;
-    int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_act, off_z, lds_floats;
+    int ldx, ldh1, ldh2, off_h1, off_h2, off_out, off_act, off_red3, off_z, lds_floats;
 };
 
 __device__ __forceinline__ float zclamp_r(float x, float m, float sd) {
@@ -129,19 +129,53 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
     }
     SMX_LDS_BARRIER();
 
+    // ---- the output layer (K = H2, <= 32 outputs) is a latency chain if two waves walk its chunks alone (measured: 5.0 k
+    // cycles of a 36 k-cycle step for 2 tiles x 8 chunks).  Its K is split over the EIGHT waves instead: wave w owns chunk w
+    // of both tiles, keeps those 4 KB of packed weights in registers for the whole rollout (no loads at all), and the
+    // eight partial sums of a (row, action) pair meet in the sampling head, added in wave order.  Shapes with more than 8
+    // chunks (H2 > 256) or more than 2 tiles take the generic loop.
+    const int tiles3 = (A + 15) >> 4, C3 = pack_chunks(G.H2);
+    const bool l3res = C3 <= RNWV && tiles3 <= 2;
+    float4 w3a[2], w3b[2];
+    {
+        const rsrc_t rw3 = make_rsrc(G.P3, (unsigned)tiles3 * (unsigned)C3 * 2048u);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const unsigned o = (l3res && g < tiles3 && wv < C3)
+                ? (((unsigned)g * (unsigned)C3 + (unsigned)wv) * 512u + (unsigned)lane * 4u) * 4u : OOB;
+            w3a[g] = ld16(rw3, o);
+            w3b[g] = ld16(rw3, o == OOB ? OOB : o + 1024u);
+        }
+    }
+    float* red3 = sm + G.off_red3;               // [RNWV][RB][32]: the waves' partial output sums
+    // the sampling head's per-pair constants (the same expressions, formed once instead of every step)
+    const int hr = tid / A, hj = tid - hr * A;            // RB x A <= 512 pairs
+    const float b3v = G.b3[hj];
+    float sd0 = expf(G.log_var[hj]);
+    if (G.noise_scale && hr < nrows) sd0 = sd0 * G.noise_scale[row0 + hr];
+    // the environment phase's per-element constants: the action column k % A and the drift term (an LDS round trip in front
+    // of the action read and an integer modulo per element and step otherwise)
+    int am[KPL];
+    float dr[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int k = lane + 64 * (part + WPR * i);
+        am[i] = k < D ? kmod[k] : 0;
+        dr[i] = 0.01f * (float)(((37 * k) % 17) - 8);
+    }
     int t = G.t0;
     RWALL(12); RCYC(13);
 #pragma unroll 1
     for (int step = 0; step < G.steps; ++step) {
         const int slot = G.slot0 + step;
+        const bool last_step = step + 1 == G.steps;
         RSTAMP(0);
         // this step's normal draw of the lane's (row, action) pair, requested before the layers (consumed behind them)
-        const int hr = tid / A, hj = tid - hr * A;        // RB x A <= 512 pairs
         float ev = 0.f;
         if (G.eps && hr < nrows) ev = G.eps[((size_t)step * G.n + row0 + hr) * A + hj];
         // ---- the three layers ------------------------------------------------------------------------------
 #pragma unroll 1
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < (l3res ? 2 : 3); ++l) {
             const float* Wp = l == 0 ? G.P1 : (l == 1 ? G.P2 : G.P3);
             const float* bias = l == 0 ? G.b1 : (l == 1 ? G.b2 : G.b3);
             const int H = l == 0 ? G.H1 : (l == 1 ? G.H2 : A);
@@ -190,20 +224,63 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
             SMX_LDS_BARRIER();
             RSTAMP(1 + l);
         }
+        if (l3res) {
+            // wave w: chunk w of the output layer against h2 (zero weights past the last chunk: a zero partial sum)
+            const float* bp = h2s + (lane & 3) * ldh2 + 8 * kq + 32 * (wv < C3 ? wv : 0);
+            f32x4 a3[2][RG];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) a3[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float4 x0[RG], x1[RG];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                x0[r] = *(const float4*)(bp + 4 * r * ldh2);
+                x1[r] = *(const float4*)(bp + 4 * r * ldh2 + 4);
+            }
+#define SMX_L3(X, W, E)                                                      \
+            _Pragma("unroll") for (int g = 0; g < 2; ++g)                    \
+                _Pragma("unroll") for (int r = 0; r < RG; ++r) a3[g][r] = MFMA4(X[r].E, W[g].E, a3[g][r]);
+            SMX_L3(x0, w3a, x) SMX_L3(x0, w3a, y) SMX_L3(x0, w3a, z) SMX_L3(x0, w3a, w)
+            SMX_L3(x1, w3b, x) SMX_L3(x1, w3b, y) SMX_L3(x1, w3b, z) SMX_L3(x1, w3b, w)
+#undef SMX_L3
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const f32x4 v = meet_kq(a3[g][r]);
+                    const float z = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));
+                    red3[(wv * RB + 4 * r + kq) * 32 + 16 * g + fm] = z;
+                }
+            SMX_LDS_BARRIER();
+            RSTAMP(3);
+        }
         // ---- sampling head (smx_diaggauss_sample_f32's expressions): one (actor, action) pair per lane -------
         const bool done = (t + 1 >= G.episode_len);
         if (hr < nrows) {
             const long a = row0 + hr;
-            const float mu = outs[hr * RLDO + hj];
-            float sd = expf(G.log_var[hj]);
-            if (G.noise_scale) sd = sd * G.noise_scale[a];
+            float mu;
+            if (l3res) {
+                float p8[RNWV];
+#pragma unroll
+                for (int w = 0; w < RNWV; ++w) p8[w] = red3[(w * RB + hr) * 32 + hj];
+                float z = p8[0];
+#pragma unroll
+                for (int w = 1; w < RNWV; ++w) z += p8[w];
+                mu = act_f(z + b3v, G.out_act);
+            } else {
+                mu = outs[hr * RLDO + hj];
+            }
+            const float sd = sd0;
             float act = G.eps ? ev * sd + mu : mu;
             if (act == act) act = fminf(fmaxf(act, -1.0f), 1.0f);
             s_act[hr * RMAX_A + hj] = act;
-            if (G.act_roll) G.act_roll[(a * R + slot) * A + hj] = act;
+            // (the rollout tables are written once and read by a later launch: streaming stores, so that 3 MB of them per
+            // step do not push the packed weights -- re-read by every workgroup every step -- out of the L2s)
+            if (G.act_roll) __builtin_nontemporal_store(act, &G.act_roll[(a * R + slot) * A + hj]);
             if (G.pd_roll) {
-                G.pd_roll[(a * R + slot) * 2 * A + hj] = mu;
-                G.pd_roll[(a * R + slot) * 2 * A + A + hj] = sd;
+                __builtin_nontemporal_store(mu, &G.pd_roll[(a * R + slot) * 2 * A + hj]);
+                __builtin_nontemporal_store(sd, &G.pd_roll[(a * R + slot) * 2 * A + A + hj]);
             }
         }
         SMX_LDS_BARRIER();
@@ -220,14 +297,17 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
                 for (int i = 0; i < KPL; ++i) {
                     const int k = lane + 64 * (part + WPR * i);
                     if (k < D) {
-                        const float ac = s_act[r * RMAX_A + kmod[k]];
+                        const float ac = s_act[r * RMAX_A + am[i]];
                         const float s = st[rr][i];
-                        const float drift = 0.01f * (float)(((37 * k) % 17) - 8);
+                        const float drift = dr[i];
                         float sn = (0.9f * s + 0.5f * ac) + drift;
                         sn = fminf(fmaxf(sn, -10.0f), 10.0f);
                         if (orow) {
-                            orow[k] = s;
-                            if (slot + 1 < R) orow[D + k] = sn;
+                            __builtin_nontemporal_store(s, &orow[k]);
+                            // the observation AFTER the step: row slot + 1 -- which the next step of this launch writes
+                            // itself (the same value, or the reset state when the episode ended here), so only the
+                            // launch's last step stores it
+                            if (slot + 1 < R) { if (last_step) __builtin_nontemporal_store(sn, &orow[D + k]); }
                             else if (G.obs_last) G.obs_last[a * D + k] = sn;     // (the replay's obs_next field)
                         }
                         if (i == 0) sn0 = sn;
@@ -245,8 +325,8 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
                     double q = 0.0;
 #pragma unroll
                     for (int j = 0; j < RMAX_A; ++j) q += (double)av[j] * (double)av[j];
-                    if (G.rew_roll) G.rew_roll[a * R + slot] = (float)(-0.1 * q + 0.05 * (double)sn0);
-                    if (G.done_roll) G.done_roll[a * R + slot] = done ? 1.0f : 0.0f;
+                    if (G.rew_roll) __builtin_nontemporal_store((float)(-0.1 * q + 0.05 * (double)sn0), &G.rew_roll[a * R + slot]);
+                    if (G.done_roll) __builtin_nontemporal_store(done ? 1.0f : 0.0f, &G.done_roll[a * R + slot]);
                 }
             }
         }
@@ -483,7 +563,8 @@ int carve(RollArgs& G, int RB) {
     G.off_h2 = G.off_h1 + RB * G.ldh1;
     G.off_out = G.off_h2 + RB * G.ldh2;
     G.off_act = G.off_out + RB * RLDO;
-    G.off_z = G.off_act + RB * RMAX_A;
+    G.off_red3 = G.off_act + RB * RMAX_A;
+    G.off_z = G.off_red3 + RNWV * RB * 32;
     G.lds_floats = G.off_z + 3 * G.D;
     return G.lds_floats * (int)sizeof(float);
 }

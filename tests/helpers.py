@@ -98,6 +98,7 @@ def assert_fp64_arbiter(rows, golden_rows, f64_rows, what, floor=LOOSE_RTOL):
 
 
 def tol_for(key, atol, rtol, case=''):
+    case = case.split(' ')[0]            # ('<case> rank 0', '<case> 2 ranks': the case's bounds)
     atol = max(atol, CASE_ATOL.get(case, {}).get(key, 0.0))
     if key in LOOSE_KEYS:
         return atol, max(rtol, CASE_LOOSE_RTOL.get(case, LOOSE_RTOL))

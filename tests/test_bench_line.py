@@ -51,6 +51,27 @@ def test_line_is_short_and_complete():
         assert len(row) <= 6, row
 
 
+def test_eight_gpu_line_carries_the_exchange_fields_and_both_scalings():
+    """what `bench.py --gpus 8` hands the driver: the process-group size, which exchange ran and why a
+    fallback happened, the weak AND the strong row -- all inside the 4 KB line, with every secondary row it can keep"""
+    import bench
+    full = _stub()
+    full.update(n_gpus=8, scaling='weak')
+    full['config'].update(parallelism='dp8', rccl_ranks=8, exchange='process group (RCCL)',
+                          exchange_fallback_reason='peer exchange self-check failed: ' + 'hipIpcOpenMemHandle ' * 20,
+                          collectives_per_step=25, epoch_all_reduce_us=41.0, epoch_all_reduce_bytes=1402000, graph_segments=True)
+    full['strong'] = {'value': 5.1e8, 'unit': 'env-steps/s', 'ms_per_step': 0.26, 'global_batch': 1024, 'B_per_gpu': 128,
+                      'hip_graph': True}
+    line = bench.compact_line(full, 'gpurun_out/bench_full.json')
+    d = json.loads(line)
+    assert len(line) < bench.LINE_LIMIT
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp8'
+    assert d['config']['rccl_ranks'] == 8 and d['config']['exchange'].startswith('process group')
+    assert d['config']['exchange_fallback_reason'].startswith('peer exchange self-check failed')
+    assert d['strong']['global_batch'] == 1024 and d['strong']['value'] > 0 and d['value'] > 0
+    assert 'traffic_measured_in_run' in d['roofline'] or 'traffic' in d['roofline']
+
+
 def test_diagnostic_line_is_short():
     import bench
     line = bench.compact_line({'metric': bench.METRIC, 'value': None, 'unit': 'env-steps/s', 'n_gpus': 8, 'steps': 20, 'warmup': 5,
