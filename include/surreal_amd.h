@@ -479,11 +479,8 @@ int smx_mlp3_wgrad_multi_f32(const smx_mlp3_job_t* jobs, int32_t njobs, smx_stre
 /* --- fused row-block epoch kernels -------------------------------------------------------------
  * One policy / value epoch of PPOLearner._optimize (surreal/learner/ppo.py:541-562; losses
  * :194-353; forward_actor / forward_critic surreal/model/ppo_net.py:253-315) on a few thousand
- * rows as FOUR dependent launches instead of nine: a workgroup owns a ROW BLOCK of one network -- 8 rows (jobs of up to
- * 1024 rows: two networks then fill the 256 CUs; FP32 MFMA 4x4x1, round 6) or 16 (larger jobs; FP32 MFMA 16x16x4);
- * smx_epoch_rows_per_block(rows) says which, smx_epoch_blocks(rows) how many blocks that makes -- the number of loss partial
- * rows, KL slots and value-moment rows the caller provides.  The jobs of one launch have the same block size.  It runs
- *   smx_epoch_forward_f32   layer 1 -> 2 -> 3 (activations through LDS) and the
+ * rows as FOUR dependent launches instead of nine: a workgroup owns 16 rows of one network and runs
+ *   smx_epoch_forward_f32   layer 1 -> 2 -> 3 (FP32 MFMA 16x16x4, activations through LDS) and the
  *                           job's loss on those rows: SMX_EPOCH_LOSS_POLICY = DiagGauss likelihoods /
  *                           KL / surrogate -> loss->g_surr, g_kl [rows, A] and the block partial
  *                           sums loss->row_partials [smx_epoch_blocks(rows), 8 + 2A];
@@ -563,7 +560,6 @@ typedef struct smx_epoch_prep {
 int smx_epoch_prepare_f32(const smx_epoch_prep_t* args, smx_stream_t stream);
 struct smx_ppo_losses;
 int32_t smx_epoch_blocks(int64_t rows);
-int32_t smx_epoch_rows_per_block(int64_t rows);
 int32_t smx_epoch_supported(int32_t D, int32_t H1, int32_t H2, int32_t OUT);
 int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs, const struct smx_ppo_losses* loss,
                           smx_ppo_ctrl_t* ctrl, int64_t n_total, smx_stream_t stream);

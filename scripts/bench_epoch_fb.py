@@ -15,7 +15,7 @@ t = TE.build(rows, D, H1, H2, A, seed=1, mode=mode, device='cuda')['d']
 t['ctrl'][L.C_KL_TARGET] = 1e9
 NS = 4096
 sync = torch.zeros(NS, dtype=torch.int32, device='cuda')
-slots = torch.zeros(NS, 2 * 64, dtype=torch.int32, device='cuda')
+slots = torch.zeros(NS, 2 * ((rows + 15) // 16), dtype=torch.int32, device="cuda")
 loss = dict(mode=mode, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
             adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=True,
             will_update=True, dlogvar=t['dlogvar'], dlogvar_sumsq=t['dlq'], stats=t['stats'],
@@ -68,7 +68,8 @@ if 'timing' in os.environ.get('SMX_LIB_PATH', ''):
     for _ in range(3):
         one()
     torch.cuda.synchronize()
-    TT = tb.view(512, 32)[:128].cpu().double()
+    NB = (rows + 15) // 16                     # row blocks per job (the launch: actor blocks, then critic blocks)
+    TT = tb.view(512, 32)[:2 * NB].cpu().double()
     base = TT[:, 0].min()
     names = [(0, 12, 'job descriptor'), (12, 13, 'x + loss input loads issued'), (13, 14, 'hidden tiles cleared'),
              (14, 15, 'x -> LDS (waits for x)'), (15, 1, 'loss inputs -> LDS'), (0, 1, 'prologue'), (1, 2, 'barrier'), (2, 3, 'layer 1'), (3, 4, 'layer 2'), (4, 5, 'layer 3'),
@@ -80,8 +81,8 @@ if 'timing' in os.environ.get('SMX_LIB_PATH', ''):
     for a, b, nm in names:
         d = TT[:, b] - TT[:, a]
         print('%-32s actor %7.0f (max %7.0f)   critic %7.0f (max %7.0f) cycles' % (
-            nm, d[:64].mean(), d[:64].max(), d[64:].mean(), d[64:].max()))
+            nm, d[:NB].mean(), d[:NB].max(), d[NB:].mean(), d[NB:].max()))
     tot = TT[:, 11] - TT[:, 0]
     print('in-kernel total: actor %.0f (max %.0f) critic %.0f ; last end - first start %.0f cycles; start spread %.0f' % (
-        tot[:64].mean(), tot[:64].max(), tot[64:].mean(), TT[:, 11].max() - base, TT[:, 0].max() - base))
+        tot[:NB].mean(), tot[:NB].max(), tot[NB:].mean(), TT[:, 11].max() - base, TT[:, 0].max() - base))
     lib.smx_epoch_debug_tbuf(None)

@@ -182,7 +182,6 @@ _SIGS = {
     'smx_mlp3_backward_multi_f32': (c_int32, [POINTER(Mlp3Job), c_int32, _P]),
     'smx_mlp3_wgrad_multi_f32': (c_int32, [POINTER(Mlp3Job), c_int32, _P]),
     'smx_epoch_blocks': (c_int32, [c_int64]),
-    'smx_epoch_rows_per_block': (c_int32, [c_int64]),
     'smx_epoch_supported': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_packed_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'smx_epoch_pack_f32': (c_int32, [POINTER(EpochPack), c_int32, _P]),

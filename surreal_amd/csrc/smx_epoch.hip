@@ -42,7 +42,6 @@ namespace {
 #include "smx_ppo_loss.inc.h"
 #include "smx_epoch_pack.inc.h"
 #include "smx_epoch_mma.inc.h"
-#include "smx_rows4_mma.inc.h"
 
 constexpr int TB = 3;             // the same, backward
 constexpr int MAX_EJOBS = 4;
@@ -105,7 +104,6 @@ struct EArgs {
     int nb_pol;        // ... row blocks of its policy job (0: none)
     const int* pol_stop;   // ... and that job's early-exit flag (its workgroups return at once when it is up)
     unsigned long long* kl_slots;   // ... [nb_pol]: a row block's KL sum | 1 << 32, zero on entry
-    int rb;            // rows a LOSS block holds: 8 (the 8-row forward-type kernels, round 6) or 16 -- smx_epoch_blocks(rows) of them
     int fsplit;
     int xsplit;        // forward kernels, two jobs of xsplit row blocks each: job 0 on XCDs 0-3, job 1 on XCDs 4-7 (0: as dispatched)
     long long* tbuf;   // SMX_EPOCH_TIMING builds: per-workgroup phase timestamps (else null)
@@ -184,16 +182,8 @@ __device__ __forceinline__ void fb_reduce_partials(const float* __restrict__ par
 
 // Forward of up to four jobs' row blocks (FB = false: epoch_fwd_kernel), or forward + loss + data gradients of the
 // same rows in ONE launch (FB = true: epoch_fb_kernel, see there).
-// RB: data rows per workgroup.  16: the v_mfma_f32_16x16x4 row-block loop (smx_epoch_mma.inc.h).  8 (round 6): two row groups
-// of four on v_mfma_f32_4x4x1 (smx_rows4_mma.inc.h) -- 1024 rows of two networks are then 256 workgroups, one per CU,
-// instead of 128 on half the chip; a workgroup with half the rows needs about three quarters of the time (it streams the
-// same packed weights).  The LDS tiles keep their 16-row layout (rows >= 8 are zero: the loss code and the right-hand-side
-// tiles see a partial block); loss partial rows, KL slots and value-moment rows are per 8-row block.  Per (row, feature)
-// the products are summed in the 4-row loop's order: equal to the 16-row kernels to fp32 rounding, not bit for bit.
-template <bool FB, int RB>
+template <bool FB>
 __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* __restrict__ ctrl) {
-    constexpr bool R8 = RB == 8;
-    constexpr int RG = 2;                                   // row groups of four in an 8-row block
     extern __shared__ float sm[];
     const int bid = xcd_job_order(G, (int)blockIdx.x);
     const int ts_blk = bid;
@@ -202,9 +192,9 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     const EJob J = select_job(G, bid);
     const int stopv = J.stop ? __builtin_nontemporal_load(J.stop) : 0;
     const int blk = bid - J.blk_base;
-    const long row0 = (long)blk * RB;
+    const long row0 = (long)blk * ER;
     int nrows = J.rows - (int)row0;
-    if (nrows > RB) nrows = RB;
+    if (nrows > ER) nrows = ER;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fm = lane & 15, kq = lane >> 4;
@@ -342,73 +332,12 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
             // buffer offsets, never branches: a load under a lane mask makes hipcc wait for it at the
             // end of the masked region, twenty times in a row
             float bs[FTG][4];
-            if constexpr (!R8) {
 #pragma unroll
             for (int g = 0; g < FTG; ++g) {
                 const int f0 = 16 * (t0 + FNWV * g) + 4 * kq;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rbias, (g < nt) ? (unsigned)(f0 + r) * 4u : OOB);
             }
-            }
-            if constexpr (R8) {
-                if (nt > 0) {                                            // wave-uniform
-                    // the epilogue's bias word of the lane's feature per tile
-                    float b8[FTG];
-#pragma unroll
-                    for (int g = 0; g < FTG; ++g) {
-                        const int f = 16 * (t0 + FNWV * g) + fm;
-                        b8[g] = ld4(rbias, (g < nt && f < H) ? (unsigned)f * 4u : OOB);
-                    }
-                    f32x4 a8[FTG][RG];
-#pragma unroll
-                    for (int g = 0; g < FTG; ++g)
-#pragma unroll
-                        for (int r = 0; r < RG; ++r) a8[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    TSTAMP(16 + 4 * l);
-                    fwd_tiles4<FTG, RG>(a8, rw, tiles, C2, in_lds, ldi, t0, FNWV, lane);
-                    TSTAMP(17 + 4 * l);
-                    // the kq groups meet: every lane of feature f then holds the four rows of each group.  LDS tile
-                    // [row][feature]: lane group kq writes row kq of both groups.  Hidden tiles to HBM as [feature][row]:
-                    // lane group rg writes the four consecutive rows of group rg; the output tile row-major: lane group
-                    // kq its row (consecutive features: coalesced).
-#pragma unroll
-                    for (int g = 0; g < FTG; ++g) {
-                        if (g < nt) {                                    // wave-uniform
-                            const int f = 16 * (t0 + FNWV * g) + fm;
-                            const bool fok = f < H;
-#pragma unroll
-                            for (int r = 0; r < RG; ++r) {
-                                const f32x4 s4 = meet_kq(a8[g][r]);
-                                float v[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    float z = s4[q] + b8[g];
-                                    if (g == 0 && l == 2) z = act_f(z, J.out_act);
-                                    else z = (z < 0.f) ? 0.f : z;
-                                    v[q] = fok ? z : 0.f;
-                                }
-                                const float mine = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));
-                                out_lds[(4 * r + kq) * ldo + f] = mine;
-                                if (l == 2) {
-                                    const int n = 4 * r + kq;
-                                    const bool ok = st_ok && n < nrows && fok;
-                                    __builtin_amdgcn_raw_buffer_store_b32(
-                                        __float_as_uint(mine), rst,
-                                        ok ? (unsigned)(row0 + n) * (unsigned)J.out_ld * 4u + (unsigned)f * 4u : OOB, 0, 0);
-                                } else {
-                                    const unsigned o = ((unsigned)f * (unsigned)J.ldT + (unsigned)(row0 + 4 * r)) * 4u;
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) {
-                                        const bool ok = st_ok && kq == r && 4 * r + q < nrows && fok;
-                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rst,
-                                                                              ok ? o + 4u * q : OOB, 0, 0);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            } else {
             f32x4 acc[TG];
 #pragma unroll
             for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -444,7 +373,6 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
                     }
                 }
             }
-            }       // (16-row products)
         }
         TSTAMP(18 + 4 * l);
         SMX_LDS_BARRIER();
@@ -459,7 +387,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
         // inputs staged in LDS: row stride LW, [actions | behave | ref | adv]
         policy_loss_body(blk, sm + G.off_loss, p.mode, outs, LDO, p.log_var, lin_s, LW, lin_s + p.A, LW,
                          lin_s + 3 * p.A, LW, lin_s + 5 * p.A, (long)J.rows, p.A, ctrl, p.g_surr, p.g_kl,
-                         p.row_partials, 1.0f, false, nullptr, nullptr, 0, row0, LW, nullptr, RB);
+                         p.row_partials, 1.0f, false, nullptr, nullptr, 0, row0, LW);
     } else if (J.loss == SMX_EPOCH_LOSS_VALUE && tid < 64) {
         // squared error of the 16 rows (ppo.py:323-332): dz3 and the block's mergeable moments of
         // d = ret - V and of ret (explained variance), as value_loss_body forms them per 256 rows
@@ -536,7 +464,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
         if (lo) {
             policy_loss_body<true>(blk, sm + G.off_loss, p.mode, outs, LDO, p.log_var, lin_s, LW, lin_s + p.A, LW,
                                    lin_s + 3 * p.A, LW, lin_s + 5 * p.A, (long)J.rows, p.A, ctrl, nullptr, nullptr,
-                                   p.row_partials, 1.0f, false, nullptr, nullptr, 0, row0, LW, G.kl_slots, RB);
+                                   p.row_partials, 1.0f, false, nullptr, nullptr, 0, row0, LW, G.kl_slots);
         } else {
 #pragma unroll
             for (int i = 0; i < POLICY_LOSS_BARRIERS; ++i) SMX_LDS_BARRIER();
@@ -582,40 +510,9 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     // ---- dz2 (before the mask) for both right-hand sides: every wave's tiles wv, wv + 8, ... (one chunk, K <= 32;
     // the weight fragments are shared by the two right-hand sides) ------------------------------------------
     f32x4 aS[FTG], aK[FTG];
-    f32x4 aS8[FTG][RG], aK8[FTG][RG];       // (8-row blocks: per row group; after the products, already met over kq)
 #pragma unroll
     for (int g = 0; g < FTG; ++g) { aS[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; aK[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    if constexpr (R8) {
-#pragma unroll
-        for (int g = 0; g < FTG; ++g)
-#pragma unroll
-            for (int r = 0; r < RG; ++r) { aS8[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f}; aK8[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        float4 s0[RG], s1[RG], k0[RG], k1[RG];
-#pragma unroll
-        for (int r = 0; r < RG; ++r) {
-            const float* bs = gss + (4 * r + (lane & 3)) * LDZ + 8 * kq;
-            s0[r] = *(const float4*)bs; s1[r] = *(const float4*)(bs + 4);
-            k0[r] = make_float4(0.f, 0.f, 0.f, 0.f); k1[r] = k0[r];
-            if (adapt) {
-                const float* bk = gks + (4 * r + (lane & 3)) * LDZ + 8 * kq;
-                k0[r] = *(const float4*)bk; k1[r] = *(const float4*)(bk + 4);
-            }
-        }
-#define SMX_DZ2(ACC, X, W, E)                                                \
-        _Pragma("unroll") for (int g = 0; g < FTG; ++g)                      \
-            _Pragma("unroll") for (int r = 0; r < RG; ++r) ACC[g][r] = MFMA4(X[r].E, W[g].E, ACC[g][r]);
-        SMX_DZ2(aS8, s0, wa, x) SMX_DZ2(aS8, s0, wa, y) SMX_DZ2(aS8, s0, wa, z) SMX_DZ2(aS8, s0, wa, w)
-        SMX_DZ2(aS8, s1, wb, x) SMX_DZ2(aS8, s1, wb, y) SMX_DZ2(aS8, s1, wb, z) SMX_DZ2(aS8, s1, wb, w)
-        if (adapt) {
-            SMX_DZ2(aK8, k0, wa, x) SMX_DZ2(aK8, k0, wa, y) SMX_DZ2(aK8, k0, wa, z) SMX_DZ2(aK8, k0, wa, w)
-            SMX_DZ2(aK8, k1, wb, x) SMX_DZ2(aK8, k1, wb, y) SMX_DZ2(aK8, k1, wb, z) SMX_DZ2(aK8, k1, wb, w)
-        }
-#undef SMX_DZ2
-#pragma unroll
-        for (int g = 0; g < FTG; ++g)
-#pragma unroll
-            for (int r = 0; r < RG; ++r) { aS8[g][r] = meet_kq(aS8[g][r]); aK8[g][r] = meet_kq(aK8[g][r]); }
-    } else {
+    {
         const float* bs = gss + (lane & 15) * LDZ + 8 * (lane >> 4);
         const float4 s0 = *(const float4*)bs, s1 = *(const float4*)(bs + 4);
         float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
@@ -699,33 +596,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
     TSTAMP(8);
     if (!stop_now) {
         // ---- dz2 = (W3^T dz3) * relu'(h2): LDS tile (dz1's B operand) + transposed copy (weight gradients) ----
-        if constexpr (R8) {
-            const rsrc_t rout = make_rsrc(J.dz2T, (unsigned)J.H2 * (unsigned)J.ldT * 4u);
-#pragma unroll
-            for (int g = 0; g < FTG; ++g) {
-                const int t = wv + FNWV * g;
-                if (t < tiles2) {                                   // wave-uniform
-                    const int f = 16 * t + fm;
-                    const bool fok = f < J.H2;
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        float v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float m = h2s[(4 * r + q) * ldh2 + f];
-                            v[q] = (m > 0.f) ? aS8[g][r][q] + c_kl * aK8[g][r][q] : 0.f;
-                        }
-                        dz2s[(4 * r + kq) * ldh2 + f] = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));
-                        const unsigned o = ((unsigned)f * (unsigned)J.ldT + (unsigned)(row0 + 4 * r)) * 4u;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool ok = kq == r && 4 * r + q < nrows && fok;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rout, ok ? o + 4u * q : OOB, 0, 0);
-                        }
-                    }
-                }
-            }
-        } else {
+        {
             const rsrc_t rout = make_rsrc(J.dz2T, (unsigned)J.H2 * (unsigned)J.ldT * 4u);
 #pragma unroll
             for (int g = 0; g < FTG; ++g) {
@@ -768,36 +639,6 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
                 const int t0 = tb + wv;
                 int nt = (tiles1 - t0 + FNWV - 1) / FNWV;
                 nt = nt < 0 ? 0 : (nt > FTG ? FTG : nt);
-                if constexpr (R8) {
-                    if (nt > 0) {                                       // wave-uniform
-                        f32x4 a8[FTG][RG];
-#pragma unroll
-                        for (int g = 0; g < FTG; ++g)
-#pragma unroll
-                            for (int r = 0; r < RG; ++r) a8[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        fwd_tiles4<FTG, RG>(a8, rw2, tiles1, C2h, dz2s, ldh2, t0, FNWV, lane);
-#pragma unroll
-                        for (int g = 0; g < FTG; ++g) {
-                            if (g < nt) {
-                                const int f = 16 * (t0 + FNWV * g) + fm;
-                                const bool fok = f < J.H1;
-#pragma unroll
-                                for (int r = 0; r < RG; ++r) {
-                                    const f32x4 s4 = meet_kq(a8[g][r]);
-                                    const unsigned o = ((unsigned)f * (unsigned)J.ldT + (unsigned)(row0 + 4 * r)) * 4u;
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) {
-                                        const float m = h1s[(4 * r + q) * ldh1 + f];
-                                        const float v = (m > 0.f) ? s4[q] : 0.f;
-                                        const bool ok = kq == r && 4 * r + q < nrows && fok;
-                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, ok ? o + 4u * q : OOB, 0, 0);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    continue;
-                }
                 f32x4 acc[TG];
 #pragma unroll
                 for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -841,10 +682,7 @@ __device__ __forceinline__ void epoch_fwd_body(const EArgs& G, smx_ppo_ctrl_t* _
 }
 
 __global__ __launch_bounds__(FNTH) void epoch_fwd_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
-    epoch_fwd_body<false, 16>(G, ctrl);
-}
-__global__ __launch_bounds__(FNTH) void epoch_fwd8_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
-    epoch_fwd_body<false, 8>(G, ctrl);
+    epoch_fwd_body<false>(G, ctrl);
 }
 
 // One launch per epoch for [forward + loss + data gradients] of the row blocks of both networks: what
@@ -852,10 +690,7 @@ __global__ __launch_bounds__(FNTH) void epoch_fwd8_kernel(EArgs G, smx_ppo_ctrl_
 // see the FB part of epoch_fwd_body).  The actor workgroups of a launch must be co-resident (<= one per CU,
 // dispatched before anything that could wait on them: they are); a wait is bounded all the same.
 __global__ __launch_bounds__(FNTH) void epoch_fb_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
-    epoch_fwd_body<true, 16>(G, ctrl);
-}
-__global__ __launch_bounds__(FNTH) void epoch_fb8_kernel(EArgs G, smx_ppo_ctrl_t* __restrict__ ctrl) {
-    epoch_fwd_body<true, 8>(G, ctrl);
+    epoch_fwd_body<true>(G, ctrl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -929,7 +764,7 @@ __global__ __launch_bounds__(NTH) void epoch_bwd_kernel(EArgs G, smx_ppo_ctrl_t*
     TSTAMP(1);
 
     if (policy) {
-        const int nblk = (J.rows + G.rb - 1) / G.rb;      // loss partial rows: per row block of the FORWARD launch
+        const int nblk = nb;
         reduce_row_partials(p.row_partials, nblk, 8 + 2 * A, S, sm + G.off_loss);   // ends with a barrier
         const float n = (float)G.n_total;
         float c_kl, loss;
@@ -1228,24 +1063,7 @@ extern "C" int smx_epoch_prepare_f32(const smx_epoch_prep_t* a, smx_stream_t str
 // SMX_EPOCH_TIMING builds only (not declared in include/surreal_amd.h): where the timestamps go
 extern "C" void smx_epoch_debug_tbuf(void* p) { g_tbuf = (long long*)p; }
 
-// Rows per LOSS block of the forward-type launches (smx_epoch_forward_f32, smx_epoch_fwdbwd_f32) for a job of `rows` rows: 8
-// up to 1024 rows (two networks = 256 workgroups: one per CU of an MI355X), 16 beyond (at 16 rows the matrix pipes bound a
-// workgroup and fewer passes over the packed weights win).  A function of the row count alone, so that the caller's buffers
-// (loss partial rows, KL slots, value-moment rows: smx_epoch_blocks(rows) of each) do not depend on what else is in a launch.
-// SMX_EPOCH_RB=16 restores 16-row blocks everywhere (measurements).
-constexpr int RB8_MAX_ROWS = 1024;
-static int epoch_rb(int64_t rows) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("SMX_EPOCH_RB");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced == 16) return ER;
-    return rows <= RB8_MAX_ROWS ? 8 : ER;
-}
-extern "C" int32_t smx_epoch_rows_per_block(int64_t rows) { return epoch_rb(rows); }
-extern "C" int32_t smx_epoch_blocks(int64_t rows) { const int rb = epoch_rb(rows); return (int32_t)((rows + rb - 1) / rb); }
-static int blocks16(int64_t rows) { return (int)((rows + ER - 1) / ER); }     // row blocks of the backward kernel's own grid
+extern "C" int32_t smx_epoch_blocks(int64_t rows) { return (int32_t)((rows + ER - 1) / ER); }
 
 // LDS bytes of a forward launch whose widest job is (D, H1, H2) with A-dimensional policy losses: the same
 // carve-up fill_args() makes ([x tile | h1 tile | h2 tile | out tile | K-split partials | loss scratch + inputs])
@@ -1324,10 +1142,7 @@ static int fill_args(EArgs& G, const smx_epoch_job_t* jobs, int32_t njobs, const
             J.P3T = s.packed + 4 * pack_off(n.D, n.H1, n.H2, n.OUT, 4);
         }
         J.blk_base = base;
-        base += (backward ? blocks16(s.rows) : smx_epoch_blocks(s.rows)) * fsplit;
-        // one row-block size per launch (every caller pairs jobs of equal row counts)
-        if (k == 0) G.rb = epoch_rb(s.rows);
-        SMX_REQUIRE(epoch_rb(s.rows) == G.rb, SMX_E_SHAPE);
+        base += smx_epoch_blocks(s.rows) * fsplit;
         if (s.loss == SMX_EPOCH_RHS_SURR || s.loss == SMX_EPOCH_RHS_KL) {
             SMX_REQUIRE(backward, SMX_E_UNSUPPORTED);
             SMX_REQUIRE(loss && loss->g_surr && loss->g_kl && s.dz3T, SMX_E_NULL);
@@ -1402,11 +1217,9 @@ extern "C" int smx_epoch_forward_f32(const smx_epoch_job_t* jobs, int32_t njobs,
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)epoch_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void*)epoch_fwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set = true;
     }
-    if (G.rb == 8) hipLaunchKernelGGL(epoch_fwd8_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
-    else hipLaunchKernelGGL(epoch_fwd_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
+    hipLaunchKernelGGL(epoch_fwd_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -1463,11 +1276,9 @@ extern "C" int smx_epoch_fwdbwd_f32(const smx_epoch_job_t* jobs, int32_t njobs, 
     static bool attr_set_fb = false;
     if (!attr_set_fb) {
         (void)hipFuncSetAttribute((const void*)epoch_fb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute((const void*)epoch_fb8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set_fb = true;
     }
-    if (G.rb == 8) hipLaunchKernelGGL(epoch_fb8_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
-    else hipLaunchKernelGGL(epoch_fb_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
+    hipLaunchKernelGGL(epoch_fb_kernel, dim3(blocks), dim3(FNTH), lds, smx_s(stream), G, ctrl);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -1491,7 +1302,7 @@ extern "C" int smx_epoch_backward_f32(const smx_epoch_job_t* jobs, int32_t njobs
             SMX_REQUIRE(!update || jobs[k].dz3T, SMX_E_NULL);
         }
     const EJob& Lj = G.j[njobs - 1];
-    int blocks = Lj.blk_base + blocks16(Lj.rows) * fs;
+    int blocks = Lj.blk_base + smx_epoch_blocks(Lj.rows) * fs;
     if (!update) {
         SMX_REQUIRE(njobs == 1, SMX_E_SHAPE);
         blocks = 1;

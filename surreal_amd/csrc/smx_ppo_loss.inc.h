@@ -61,9 +61,7 @@ __device__ __forceinline__ void policy_loss_body(
     const long in_row0 = 0 /* first row held by g_actions / g_behave / g_ref / adv (a staged block: row0) */,
     const int ld_adv = 1,
     unsigned long long* __restrict__ kl_slot = nullptr /* (COH) the block's KL sum | 1 << 32, ONE 8-byte device-scope
-    store as soon as it is known: value and "it is there" travel together (see epoch_fb_kernel) */,
-    const int rows_per_block = LOSS_ROWS_PER_BLOCK /* rows a block HOLDS (<= LOSS_ROWS_PER_BLOCK: the 8-row workgroups of the
-    fused epoch kernels); the scratch layout stays that of LOSS_ROWS_PER_BLOCK rows */) {
+    store as soon as it is known: value and "it is there" travel together (see epoch_fb_kernel) */) {
     const int R = LOSS_ROWS_PER_BLOCK;
     float* e_z2 = sm;              // ((a - mu)/sig)^2                    [R, A]
     float* e_zb2 = e_z2 + R * A;   // ((a - mb)/sb)^2
@@ -76,9 +74,9 @@ __device__ __forceinline__ void policy_loss_body(
     float* r_dll = e_gk + R * A;   // per-row d(loss_r)/d(ll)             [R]
     float* s_sig = r_dll + R;      // exp(log_var)  (builders.py:127)       [A]
     float* s_lsig = s_sig + MAX_A; // log(exp(log_var)): std0.log()  (ppo_net.py:40)
-    const long row0 = (long)blk * rows_per_block;
+    const long row0 = (long)blk * R;
     long nrows = rows - row0;
-    if (nrows > rows_per_block) nrows = rows_per_block;
+    if (nrows > R) nrows = R;
     const int tid = threadIdx.x;
     const int stride = 8 + 2 * A;
     float* P = partials + (size_t)blk * stride;

@@ -99,14 +99,21 @@ __device__ __forceinline__ void fwd_tiles4(f32x4 (&acc)[NT][RG], rsrc_t rw, int 
     }
 }
 
-// the four kq groups meet: afterwards every lane of a feature holds the full sums of its four rows
+// the four kq groups meet: afterwards every lane of a feature holds the full sums of its four rows.  Two register-file
+// swaps and two adds per value (v_permlane16_swap: odd 16-lane rows of one copy against even rows of the other ->
+// x0 + x1 | x2 + x3 in every row pair; v_permlane32_swap: the halves) -- as __shfl_xor (ds_bpermute, an LDS round trip
+// per hop) the 48 dependent pairs of a layer's epilogue cost more than the products they followed (measured in
+// epoch_fb8_kernel: layer 1's epilogue 7.3 k cycles against 4.4 k on 16-row blocks).
+__device__ __forceinline__ float meet_kq1(float x) {
+    unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    u = __float_as_uint(x);
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ f32x4 meet_kq(f32x4 v) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float x = v[r];
-        x += __shfl_xor(x, 16, 64);
-        x += __shfl_xor(x, 32, 64);
-        v[r] = x;
-    }
+    for (int r = 0; r < 4; ++r) v[r] = meet_kq1(v[r]);
     return v;
 }

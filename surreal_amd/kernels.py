@@ -193,11 +193,7 @@ class HipKernels(object):
                                                         max(n.H2 for n in nets), max(n.OUT for n in nets)))
 
     def epoch_blocks(self, rows):
-        """loss partial rows / KL slots / value-moment rows a fused forward-type launch forms for a job of `rows` rows"""
         return self.lib.smx_epoch_blocks(rows)
-
-    def epoch_rows_per_block(self, rows):
-        return self.lib.smx_epoch_rows_per_block(rows)
 
     def epoch_packed_numel(self, net):
         return self.lib.smx_epoch_packed_floats(net.D, net.H1, net.H2, net.OUT)

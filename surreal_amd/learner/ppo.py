@@ -325,7 +325,7 @@ class PPOLearner(Learner):
         # scalars block: ctrl | policy stats | in-launch counters of the fused forward + backward epochs | value stats | moments
         # (+ per launch and row block of the fused forward + backward epochs: an 8-byte slot)
         n_slots = 0 if (self.if_rnn_policy or self.model.if_pixel or self.world_size > 1) else \
-            2 * (max(Ep, Ev) + 1) * K.epoch_blocks(B)
+            2 * (max(Ep, Ev) + 1) * ((B + 15) // 16)
         if n_slots > (1 << 19):
             # (the slots sit in the range epoch_prepare zeroes per learn, which the kernel bounds at 2^20 words: batches of
             # more than ~380 k sub-trajectories run the two-launch epochs, which need none)
@@ -338,7 +338,7 @@ class PPOLearner(Learner):
         ws.ctrl_i = ws.ctrl_f.view(torch.int32)
         ws.pstats = ws.scal[o:o + (Ep + 1) * L.PS_STRIDE].view(Ep + 1, L.PS_STRIDE); o += (Ep + 1) * L.PS_STRIDE
         ws.sync = ws.scal[o:o + n_sync].view(torch.int32); o += n_sync       # one word per epoch launch, zeroed per learn
-        ws.kl_slots = ws.sync[self._sync_words():self._sync_words() + n_slots].view(-1, 2 * K.epoch_blocks(B)) \
+        ws.kl_slots = ws.sync[self._sync_words():self._sync_words() + n_slots].view(-1, 2 * ((B + 15) // 16)) \
             if n_slots else None
         ws.n_sync = n_sync
         ws.vstats = ws.scal[o:o + Ev * L.VS_STRIDE].view(Ev, L.VS_STRIDE); o += Ev * L.VS_STRIDE
@@ -458,6 +458,7 @@ class PPOLearner(Learner):
             ws.dz2cT, ws.dz1cT = ft(cri.H2), ft(cri.H1)
         # one buffer for both groups' gradients: a data-parallel lock-step epoch all-reduces it once
         n_a, n_c = self.model.actor_flat.numel(), self.model.critic_flat.numel()
+        ws.nblk_p = K.loss_blocks(rows)
         # fused row-block epochs: plain MLP policy, shapes the kernels take; on several ranks the
         # paired-epoch schedule with one collective per epoch (epoch_policy == epoch_baseline)
         ws.fused = (self.fused_epochs and not stem and
@@ -474,16 +475,13 @@ class PPOLearner(Learner):
         ws.fb = (ws.fused and self.world_size == 1 and bool(self.session_config.learner.get('fused_fwdbwd', True)) and
                  bool(self.session_config.learner.get('exclusive_device', True)) and not getattr(self, '_fb_timed_out', False) and
                  n_slots > 0 and K.epoch_fwdbwd_supported(act, cri))
-        # loss partial rows / value-loss moments per row block of the launches that form them: the fused kernels' 8 or 16 rows
-        # (smx_epoch_blocks), the layered loss launches' 16 / 256
-        pblocks = K.epoch_blocks if ws.fused else K.loss_blocks
-        vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks
-        ws.nblk_p = pblocks(rows)
+        vblocks = K.epoch_blocks if ws.fused else K.value_loss_blocks     # value-loss moments per 16 / 256 rows
         ws.nblk_v = vblocks(rows)
         # single rank: GAE + normalisation and the end-of-learn statistics are one launch each
         ws.merged_tail = ws.fused and self.world_size == 1
         ws.ticket = torch.zeros(2, dtype=torch.int32, device=dev)
         if ws.fused:
+            assert ws.nblk_p == K.epoch_blocks(rows)
             # the weights in the forward kernel's fragment order (model, critic, reference policy)
             ws.pk_actor = torch.zeros(K.epoch_packed_numel(act), device=dev)
             ws.pk_critic = torch.zeros(K.epoch_packed_numel(cri), device=dev)
@@ -500,7 +498,7 @@ class PPOLearner(Learner):
             every = every.view(-1, 2).tolist()
             ws.n_total, ws.B_total = sum(r for r, _ in every), sum(b for _, b in every)
             ws.nblk_v = max(vblocks(r) for r, _ in every)
-            nblk_p_all = max(pblocks(r) for r, _ in every)
+            nblk_p_all = max(K.loss_blocks(r) for r, _ in every)
         ws.dp_epoch = self.world_size > 1 and not stem
         ws.tail_deferred = ws.dp_epoch and self.epoch_policy >= self.epoch_baseline
         if ws.dp_epoch:

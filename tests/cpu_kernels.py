@@ -9,7 +9,6 @@ doubles as an executable statement of each kernel's contract for the GPU parity 
 It is never importable from the product package and the product never selects it.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -185,15 +184,8 @@ class TorchCpuKernels(object):
     def epoch_supported(self, *nets):
         return all(net.H1 % 4 == 0 and net.H2 % 4 == 0 and net.OUT <= 32 for net in nets)
 
-    def epoch_rows_per_block(self, rows):
-        # smx_epoch_rows_per_block: 8-row blocks up to 1024 rows, 16 beyond (SMX_EPOCH_RB=16: 16 everywhere)
-        if os.environ.get('SMX_EPOCH_RB') == '16':
-            return 16
-        return 8 if rows <= 1024 else 16
-
     def epoch_blocks(self, rows):
-        rb = self.epoch_rows_per_block(rows)
-        return (rows + rb - 1) // rb
+        return (rows + 15) // 16
 
     def epoch_packed_numel(self, net):
         return net.numel            # opaque to the caller
@@ -255,15 +247,14 @@ class TorchCpuKernels(object):
             if j.get('loss') == 'policy':
                 self.policy_loss(loss['mode'], out, loss['log_var'], loss['actions'], loss['behave'],
                                  loss['ref'], loss['adv'], ctrl, loss['g_surr'], loss['g_kl'],
-                                 loss['partials'], rows_per_block=self.epoch_rows_per_block(x.shape[0]))
+                                 loss['partials'])
             elif j.get('loss') == 'value':
                 vv, g = out.view(-1), loss['returns'].view(-1)
                 rows = vv.numel()
                 loss['v_dz3'].view(-1).copy_(2.0 * (vv - g) / float(n_total))
                 d = g - vv
-                rb = self.epoch_rows_per_block(rows)
                 for b in range(self.epoch_blocks(rows)):
-                    sl = slice(rb * b, min(rb * (b + 1), rows))
+                    sl = slice(16 * b, min(16 * (b + 1), rows))
                     db, gb = d[sl].double(), g[sl].double()
                     loss['v_partials'][b] = _f([db.numel(), db.mean(), ((db - db.mean()) ** 2).sum(), gb.mean(),
                                                 ((gb - gb.mean()) ** 2).sum(), (db ** 2).sum(), 0, 0])
@@ -440,7 +431,7 @@ class TorchCpuKernels(object):
         return (rows + self.LOSS_ROWS - 1) // self.LOSS_ROWS
 
     def policy_loss(self, mode, mean, log_var, actions, behave, ref, adv, ctrl, g_surr, g_kl,
-                    partials, rows_per_block=None):
+                    partials):
         ci = ctrl.view(torch.int32)
         if int(ci[L.C_STOP]) != 0:
             return
@@ -479,11 +470,10 @@ class TorchCpuKernels(object):
         gs = dll.view(-1, 1) * (z2 - 1.0)
         gk = 1.0 - (sr ** 2 + (mr - mean) ** 2) / sig ** 2
         isw = Ll / (Lb + 1e-4)
-        R = rows_per_block or self.LOSS_ROWS          # (the fused epoch launches: their own row-block size)
-        nblk = (rows + R - 1) // R
+        nblk = self.loss_blocks(rows)
         partials[:nblk].zero_()       # like the kernels: a launch rewrites the rows of ITS blocks, nothing else
         for b in range(nblk):
-            sl = slice(R * b, min(R * (b + 1), rows))
+            sl = slice(self.LOSS_ROWS * b, min(self.LOSS_ROWS * (b + 1), rows))
             partials[b, 0] = surr[sl].sum()
             partials[b, 1] = loss_r[sl].sum()
             partials[b, 2] = kl[sl].sum()

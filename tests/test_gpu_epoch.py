@@ -23,12 +23,6 @@ def K():
     return HipKernels()
 
 
-def _blocks(rows):
-    """row blocks of a fused forward-type launch over `rows` rows (8-row blocks up to 1024 rows, 16 beyond): the loss partial
-    rows, KL slots and value-moment rows it forms -- the CPU double states the same rule as smx_epoch_blocks"""
-    return C.epoch_blocks(rows)
-
-
 def ctrl_block(beta=1.0, eta=250.0, eps=0.2, kl_target=0.015):
     c = torch.zeros(L.CTRL_WORDS)
     c[L.C_LR_ACTOR], c[L.C_LR_CRITIC] = 1e-4, 1e-4
@@ -58,7 +52,7 @@ def build(rows, D, H1, H2, A, seed, mode, device):
     def side(dv, act, cri, Kx):
         f = lambda *s: torch.zeros(*s, device=dv)  # noqa: E731
         ft = lambda n: torch.zeros(n, ldT, device=dv)[:, :rows]  # noqa: E731
-        nblk = _blocks(rows)
+        nblk = (rows + 15) // 16
         t = dict(x=x.to(dv), log_var=log_var.to(dv), actions=actions.to(dv), behave=behave.to(dv), ref=ref.to(dv),
                  adv=adv.to(dv), returns=returns.to(dv), ctrl=ctrl_block().to(dv),
                  mean=f(rows, A), vpred=f(rows), g_surr=f(rows, A), g_kl=f(rows, A), partials=f(nblk, 8 + 2 * A),
@@ -145,7 +139,7 @@ def _fb_pair(K, rows, D, H1, H2, A, mode, seed, kl_target=1e9, launches=1):
         if kl_target is not None:
             t['ctrl'][L.C_KL_TARGET] = kl_target
         t['sync'] = torch.zeros(4, dtype=torch.int32, device='cuda')
-        t['slots'] = torch.zeros(4, 2 * (_blocks(rows)), dtype=torch.int32, device='cuda')
+        t['slots'] = torch.zeros(4, 2 * ((rows + 15) // 16), dtype=torch.int32, device='cuda')
         loss = dict(mode=mode, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
                     adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=True,
                     will_update=True, dlogvar=t['dlogvar'], dlogvar_sumsq=t['dlq'], stats=t['stats'],
@@ -183,12 +177,12 @@ def test_epoch_fwdbwd_equals_forward_then_backward(K, rows, D, H1, H2, A, mode):
     two, one = _fb_pair(K, rows, D, H1, H2, A, mode, seed=rows + D)
     for k in ('h1aT', 'h2aT', 'h1cT', 'h2cT', 'partials', 'v_dz3', 'v_partials'):    # (g_surr / g_kl stay in LDS)
         assert torch.equal(one[k], two[k]), k
-    many = 2 * (_blocks(rows)) > torch.cuda.get_device_properties(0).multi_processor_count
+    many = 2 * ((rows + 15) // 16) > torch.cuda.get_device_properties(0).multi_processor_count
     close(one['stats'], two['stats'], atol=1e-6, rtol=2e-6, msg='stats')
     close(one['dlogvar'], two['dlogvar'], atol=1e-7, rtol=2e-6, msg='dlogvar')
     close(one['dlq'], two['dlq'], atol=1e-9, rtol=1e-5, msg='dlogvar sumsq')
     assert torch.equal(one['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:], two['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:])
-    assert int(one['sync'][0]) == (0 if many and mode == L.SMX_PPO_ADAPT else _blocks(rows))
+    assert int(one['sync'][0]) == (0 if many and mode == L.SMX_PPO_ADAPT else (rows + 15) // 16)
     for k in ('dz3aT', 'dz2aT', 'dz1aT', 'dz2cT', 'dz1cT'):
         close(one[k], two[k], atol=1e-8, rtol=1e-5, msg=k)
     for k in ('grads_a', 'grads_c'):
@@ -205,7 +199,7 @@ def test_epoch_fwdbwd_hand_off_under_uneven_load_many_times(K, mode):
     rows, D, H1, H2, A = 1024, 376, 300, 200, 17
     t = build(rows, D, H1, H2, A, seed=99, mode=mode, device='cuda')['d']
     t['ctrl'][L.C_KL_TARGET] = 1e9
-    nb = _blocks(rows)
+    nb = (rows + 15) // 16
     loss = dict(mode=mode, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
                 adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=True,
                 will_update=True, dlogvar=t['dlogvar'], dlogvar_sumsq=t['dlq'], stats=t['stats'],
@@ -262,7 +256,7 @@ def test_epoch_launches_against_the_reference_restatement_in_float64(K, rows, D,
     sq_a, sq_c = torch.zeros(np_a + 1, device='cuda'), torch.zeros(K.mlp3_backward_partials(t['cri']), device='cuda')
     t['ctrl'][L.C_KL_TARGET] = 0.015
     sync = torch.zeros(4, dtype=torch.int32, device='cuda')
-    kl = torch.zeros(2 * (_blocks(rows)), dtype=torch.int32, device='cuda')
+    kl = torch.zeros(2 * ((rows + 15) // 16), dtype=torch.int32, device='cuda')
     loss = dict(mode=m, rows=rows, log_var=t['log_var'], actions=t['actions'], behave=t['behave'], ref=t['ref'],
                 adv=t['adv'], g_surr=t['g_surr'], g_kl=t['g_kl'], partials=t['partials'], check_stop=False,
                 will_update=True, dlogvar=ga[na:], dlogvar_sumsq=sq_a[np_a:], stats=t['stats'],
@@ -359,7 +353,7 @@ def test_epoch_fwdbwd_kl_cutoff_early_exit_and_repeats(K):
             assert float(one['dz1aT'].abs().sum()) == 0.0
     # (c) three launches in a row on their own counter words give what three pairs of launches give
     two, one = _fb_pair(K, rows, D, H1, H2, A, L.SMX_PPO_ADAPT, seed=13, launches=3)
-    assert one['sync'].cpu().tolist() == [_blocks(rows)] * 3 + [0]
+    assert one['sync'].cpu().tolist() == [(rows + 15) // 16] * 3 + [0]
     assert torch.equal(one['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:], two['ctrl'].view(torch.int32)[L.C_STEP_ACTOR:])
     for k in ('dz2aT', 'dz1aT', 'dz1cT'):
         close(one[k], two[k], atol=1e-8, rtol=1e-5, msg=k)
