@@ -2,8 +2,8 @@
 TEST INFRASTRUCTURE ONLY.  CPU restatement (PyTorch fp32) of the reference's DDPG update
 (surreal/learner/ddpg.py:244-352, 403-428; surreal/model/ddpg_net.py:13-95;
 model_builders/builders.py:35-84; use_layernorm when the parameters carry actor.ln* / critic.ln*: torchx's L.LayerNorm(1)
-taken as torch.nn.LayerNorm over the features, as oracle/ref_shims.py does), low-dimensional observations,
-single critic, no TD3 action regularisation (the reference defaults, ddpg_configs.py:16-98).
+taken as torch.nn.LayerNorm over the features, as oracle/ref_shims.py does), with every switch of ddpg.py: the TD3 double
+critic and action regularisation, camera observations (the perception CNN), LayerNorm -- alone and together.
 oracle/gen_golden_ddpg.py pins it bit-for-bit against the reference's own DDPGLearner.
 
 Canonical parameter names: actor.fc{1,2,3}.{W,b} (D->h1->h2->A, tanh);
@@ -40,12 +40,12 @@ def make_ddpg_params(D, A, actor_hidden=(300, 200), critic_hidden=(400, 300), se
 
 
 def make_ddpg_pixel_params(low_dim, A, pixel, conv_hidden, actor_hidden, critic_hidden, seed=3,
-                           channels=(16, 32), kernels=(8, 4), strides=(4, 2)):
+                           channels=(16, 32), kernels=(8, 4), strides=(4, 2), layernorm=False):
     """parameters of the pixel DDPGModel (ddpg_net.py:37-51): CNNStemNetwork perception (builders.py:8-33)
     whose features are concatenated IN FRONT of the low-dim vector (ddpg_net.py:67-78), then the
     MLPs over conv_hidden + low_dim inputs.  cnn.* names as in oracle/ppo_oracle.py."""
     C, H, W = pixel
-    p = make_ddpg_params(conv_hidden + low_dim, A, actor_hidden, critic_hidden, seed=seed)
+    p = make_ddpg_params(conv_hidden + low_dim, A, actor_hidden, critic_hidden, seed=seed, layernorm=layernorm)
     rs = np.random.RandomState(seed + 1000)
     h1, w1 = (H - kernels[0]) // strides[0] + 1, (W - kernels[0]) // strides[0] + 1
     h2, w2 = (h1 - kernels[1]) // strides[1] + 1, (w1 - kernels[1]) // strides[1] + 1

@@ -94,6 +94,10 @@ def extract_critic(m):
     for i, l in enumerate(lin_layers(m.critic.model_obs) + lin_layers(m.critic.model_concat)):
         out['critic.fc%d.W' % (i + 1)] = l.fc.weight.detach().numpy().copy()
         out['critic.fc%d.b' % (i + 1)] = l.fc.bias.detach().numpy().copy()
+    for name, l in _ln_sets(m):
+        if name.startswith('critic.'):
+            out[name + '.W'] = l.ln.weight.detach().numpy().copy()
+            out[name + '.b'] = l.ln.bias.detach().numpy().copy()
     out.update(extract_perception(m))
     return out
 
@@ -174,6 +178,19 @@ CASES = {
                                hyper=dict(gamma=0.9, n_step=1, lr_actor=1e-3, lr_critic=1e-2, layernorm=True,
                                           target_update_type='soft', target_update_interval=1,
                                           tau=0.05, clip_critic=True)),
+    # round 6: use_layernorm together with the other switches (builders.py:42-48, 65-74: the flag reaches every network,
+    # the second critic and the networks on top of the perception CNN included)
+    'tiny_ln_td3_soft': dict(B=21, D=7, A=3, ah=(24, 16), ch=(32, 24), iters=3,
+                             hyper=dict(gamma=0.95, n_step=2, lr_actor=1e-3, lr_critic=1e-2, layernorm=True,
+                                        double_critic=True, action_reg=True, target_update_type='soft',
+                                        target_update_interval=1, tau=0.1, clip_critic=True)),
+    'tiny_ln_pixel_hard': dict(B=12, D=4, A=2, ah=(24, 16), ch=(32, 24), iters=4, pixel=(2, 20, 24), conv_hidden=8,
+                               hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-3, lr_critic=1e-2, layernorm=True,
+                                          target_update_type='hard', target_update_interval=2)),
+    'tiny_ln_pixel_td3_soft': dict(B=10, D=3, A=2, ah=(24, 16), ch=(32, 24), iters=3, pixel=(3, 28, 36), conv_hidden=16,
+                                   hyper=dict(gamma=0.95, n_step=2, lr_actor=1e-3, lr_critic=1e-2, layernorm=True,
+                                              double_critic=True, action_reg=True, target_update_type='soft',
+                                              target_update_interval=1, tau=0.1, clip_critic=True)),
     'cfg3_cheetah512': dict(B=512, D=17, A=6, ah=(300, 200), ch=(400, 300), iters=3,
                             hyper=dict(gamma=0.99, n_step=3, lr_actor=1e-4, lr_critic=1e-3,
                                        target_update_type='hard', target_update_interval=500)),
@@ -194,7 +211,8 @@ def main(only=None):
         pixel = tuple(c['pixel']) if c.get('pixel') else None
         if pixel is not None:
             mkp = lambda seed: ddpg_oracle.make_ddpg_pixel_params(  # noqa: E731
-                c['D'], c['A'], pixel, c['conv_hidden'], c['ah'], c['ch'], seed=seed)
+                c['D'], c['A'], pixel, c['conv_hidden'], c['ah'], c['ch'], seed=seed,
+                layernorm=bool(hyper.get('layernorm', False)))
         else:
             mkp = lambda seed: ddpg_oracle.make_ddpg_params(c['D'], c['A'], c['ah'], c['ch'], seed=seed,  # noqa: E731
                                                             layernorm=bool(hyper.get('layernorm', False)))

@@ -23,8 +23,9 @@ kernels) runs on camera0 / 255, its features go in front of the low-dim vector, 
 the critic loss (Adam with the critic's hyper-parameters) and follows the target updates; the actor
 update reuses the features formed before the critic step, as the reference does.
 
-use_layernorm (default off) is built for low-dimensional observations with one critic (_enqueue_iteration_ln); torchx's
-LayerNorm semantics are unpinned (its source is absent): taken as torch.nn.LayerNorm over the features.
+use_layernorm (default off) runs layer by layer (_enqueue_iteration_ln), with every other switch (round 6: the double critic
+and camera observations too); torchx's LayerNorm semantics are unpinned (its source is absent): taken as
+torch.nn.LayerNorm over the features.
 """
 import gc
 import types
@@ -206,9 +207,10 @@ class DDPGLearner(Learner):
                 ws.grads_p2 = torch.zeros_like(m.perception_flat)
             ws.s_pix = ws.s_pix_next = None              # staged frames (allocated in their dtype)
         if self.use_layernorm:
-            if self.use_double_critic or self.is_pixel_input:
-                raise NotImplementedError('use_layernorm=True is built for low-dimensional observations with one critic')
             ws.ln, ws.ln_t = m.ln_workspace(B, self.device), self.model_target.ln_workspace(B, self.device)
+            if self.use_double_critic:
+                ws.ln2, ws.ln_t2 = self.model2.ln_workspace(B, self.device), self.model_target2.ln_workspace(B, self.device)
+                ws.xcat_t2 = f(B, c1 + A)
             ws.dn2, ws.dz1c = f(B, c2), f(B, c1)
             ws.dn2a, ws.dn1a = f(B, a.H2), f(B, a.H1)
             ws.ln_ws = f(max(self.K.layernorm_backward_ws_floats(B, k) for k in (c1, c2, a.H1, a.H2)))
@@ -370,12 +372,46 @@ class DDPGLearner(Learner):
             return ((mt.ac_flat, m.ac_flat),)
         return ((mt.actor_flat, m.actor_flat), (mt.critic_flat, m.critic_flat))
 
-    def _enqueue_iteration_ln(self, ws, x, xn, actions, rewards, done):
+    def _critic_backward_ln(self, ws, model, lw, x, xcat, dz3, gc):
+        """gradients of a LayerNorm critic's parameters from dz3 = dLoss/dQ [B] (builders.py:58-84 with use_layernorm,
+        backwards); leaves dLoss/d(layer-1 pre-LayerNorm output) in ws.dz1c (the perception CNN's way in)"""
+        K, A = self.K, self.action_dim
+        B, D = x.shape
+        c, c1, c2 = model.critic, model.c1, model.c2
+        ld = c1 + A
+        dz3 = dz3.view(B, 1)
+        K.linear_wgrad(dz3, lw.c_n2, gc['W3'], gc['b3'], 1, c2, B, ldz=1)
+        K.linear(dz3, 1, c['W3'], 0, None, ws.dn2, B, c2, 1, lda=1, ldb=c2)                 # d/d(LN2 output)
+        K.layernorm_backward(ws.dn2, lw.c_a2, lw.cm2, lw.cr2, c['ln2.W'], ws.dz2, gc['ln2.W'], gc['ln2.b'], ws.ln_ws,
+                             relu_mask=True)
+        K.linear_wgrad(ws.dz2, xcat, gc['W2'], gc['b2'], c2, c1 + A, B)
+        K.linear(ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1 + A, c2, ldb=ld, ldc=ld)        # d/d([LN1 output | action])
+        K.layernorm_backward(ws.dxcat[:, :c1], lw.c_a1, lw.cm1, lw.cr1, c['ln1.W'], ws.dz1c, gc['ln1.W'], gc['ln1.b'],
+                             ws.ln_ws, relu_mask=True)
+        K.linear_wgrad(ws.dz1c, x, gc['W1'], gc['b1'], c1, D, B)
+
+    def _perception_backward_ln(self, ws, model, xin, cnn_ws, grads_p):
+        """the critic loss through the perception CNN in front of a LayerNorm critic: d(layer-1 input) = dz1c . W1 under the
+        feature ReLU, then the stem's own backward (ws.dz1c still holds THIS critic's layer-1 gradient)"""
+        K = self.K
+        c1, Dx = model.c1, model.input_dim
+        K.linear(ws.dz1c, 1, model.critic['W1'], 0, None, ws.dxin, xin.shape[0], Dx, c1, relu_mask=xin, ldb=Dx)
+        model._cnn_stem.backward(model.cnn, xin.shape[0], cnn_ws, ws.dxin[:, :model.feat_dim], grads_p)
+
+    def _enqueue_iteration_ln(self, ws, x, xn, actions, rewards, done, pix=None, pix_next=None):
         """one DDPG iteration (ddpg.py:244-352) with use_layernorm = True: every hidden ReLU is followed by a LayerNorm
         (builders.py:42-48, 65-75), so the networks run layer by layer (smx_linear_f32 + smx_layernorm_*_f32) and the
-        LayerNorms' affine parameters are part of the two optimiser groups.  Low-dimensional observations, one critic."""
+        LayerNorms' affine parameters are part of the optimiser groups.  With the TD3 switches (a second LayerNorm critic
+        with its own target and optimiser, ddpg.py:119-147, 266-283, 312-319) and camera observations (the perception CNN
+        in front of both networks, trained by the critic loss, ddpg_net.py:37-88) as in the plain schedule."""
         K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
-        B, D = x.shape
+        B = x.shape[0]
+        low, low_next = x, xn
+        if self.is_pixel_input:
+            mt.perception_into(pix_next, low_next, ws.cnn_t, ws.xnf)
+            m.perception_into(pix, low, ws.cnn, ws.xf)
+            x, xn = ws.xf, ws.xnf
+        D = x.shape[1]
         lw, lt = ws.ln, ws.ln_t
         c, c1, c2, ld = m.critic, m.c1, m.c2, m.c1 + A
         a, av, aln = m.actor, m.actor.views, m.actor_ln
@@ -383,24 +419,58 @@ class DDPGLearner(Learner):
         # ---- target: y = r + gamma^n * Q'(s', mu'(s')) * (1 - done) ----
         mt.actor_forward_ln(xn, lt, ws.act)
         mt.critic_forward_ln(xn, ws.act, lt, ws.xcat_t, ws.q_next)
-        # ---- critic update ----
+        q_next = ws.q_next
+        if self.use_double_critic:           # y = min of the two targets; the noise reaches only the second (ddpg.py:266-283)
+            a2 = ws.act
+            if self.use_action_regularization:
+                torch.add(ws.act, ws.s_noise, out=ws.act_n)
+                ws.act_n.clamp_(-1.0, 1.0)
+                a2 = ws.act_n
+            xn2 = xn
+            if self.is_pixel_input:
+                self.model_target2.perception_into(pix_next, low_next, ws.cnn_t2, ws.xnf2)
+                xn2 = ws.xnf2
+            self.model_target2.critic_forward_ln(xn2, a2, ws.ln_t2, ws.xcat_t2, ws.q_next2)
+            torch.minimum(ws.q_next, ws.q_next2, out=ws.q_next2)
+            q_next = ws.q_next2
+        # ---- critic update(s) ----
         m.critic_forward_ln(x, actions, lw, ws.xcat, ws.q)
-        K.ddpg_critic_loss_step(ws.q, ws.q_next, rewards, done, gamma_n, ws.y, ws.dz3, ws.step)
-        gc, dz3 = ws.gc, ws.dz3.view(B, 1)
-        K.linear_wgrad(dz3, lw.c_n2, gc['W3'], gc['b3'], 1, c2, B, ldz=1)
-        K.linear(dz3, 1, c['W3'], 0, None, ws.dn2, B, c2, 1, lda=1, ldb=c2)                 # d/d(LN2 output)
-        K.layernorm_backward(ws.dn2, lw.c_a2, lw.cm2, lw.cr2, c['ln2.W'], ws.dz2, gc['ln2.W'], gc['ln2.b'], ws.ln_ws,
-                             relu_mask=True)
-        K.linear_wgrad(ws.dz2, ws.xcat, gc['W2'], gc['b2'], c2, c1 + A, B)
-        K.linear(ws.dz2, 1, c['W2'], 0, None, ws.dxcat, B, c1 + A, c2, ldb=ld, ldc=ld)        # d/d([LN1 output | action])
-        K.layernorm_backward(ws.dxcat[:, :c1], lw.c_a1, lw.cm1, lw.cr1, c['ln1.W'], ws.dz1c, gc['ln1.W'], gc['ln1.b'],
-                             ws.ln_ws, relu_mask=True)
-        K.linear_wgrad(ws.dz1c, x, gc['W1'], gc['b1'], c1, D, B)
+        x2 = x
+        if self.use_double_critic:
+            if self.is_pixel_input:
+                self.model2.perception_into(pix, low, ws.cnn2, ws.xf2)
+                x2 = ws.xf2
+            self.model2.critic_forward_ln(x2, actions, ws.ln2, ws.xcat2, ws.q2)
+        K.ddpg_critic_loss_step(ws.q, q_next, rewards, done, gamma_n, ws.y, ws.dz3, ws.step)
+        self._critic_backward_ln(ws, m, lw, x, ws.xcat, ws.dz3, ws.gc)
+        if self.is_pixel_input:
+            self._perception_backward_ln(ws, m, x, ws.cnn, ws.grads_p)
+            self._average_over_ranks(ws.grads_p)
         self._average_over_ranks(ws.grads_c)
         K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                         ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+        if self.is_pixel_input:
+            K.adam_step_dev(m.perception_flat, ws.grads_p, self.perc_exp_avg, self.perc_exp_avg_sq,
+                            ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
         ws.q_policy.copy_(ws.q)
-        # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)) ----
+        if self.use_double_critic:           # ddpg.py:312-319
+            m2 = self.model2
+            K.ddpg_critic_loss(ws.q2, q_next, rewards, done, gamma_n, ws.y2, ws.dz3_2)
+            self._critic_backward_ln(ws, m2, ws.ln2, x2, ws.xcat2, ws.dz3_2, ws.gc2)
+            if self.is_pixel_input:
+                self._perception_backward_ln(ws, m2, x2, ws.cnn2, ws.grads_p2)
+                self._average_over_ranks(ws.grads_p2)
+            self._average_over_ranks(ws.grads_c2)
+            K.adam_step_dev(m2.critic_flat, ws.grads_c2, self.critic2_exp_avg, self.critic2_exp_avg_sq,
+                            ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+            if self.is_pixel_input:
+                K.adam_step_dev(m2.perception_flat, ws.grads_p2, self.perc2_exp_avg, self.perc2_exp_avg_sq,
+                                ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+            K.ddpg_stats(ws.q2, ws.y2, rewards, actions, ws.q2, ws.stats2)    # (the SECOND critic's loss is what is reported)
+            self._average_over_ranks(ws.stats2[:6])
+        # ---- actor update through the UPDATED critic: loss = -mean Q(s, mu(s)); the features formed before the critic
+        # step are reused (ddpg.py:287, 326-327: perception.detach()) ----
+        dz3 = ws.dz3.view(B, 1)
         m.actor_forward_ln(x, lw, ws.act)
         m.critic_forward_ln(x, ws.act, lw, ws.xcat, ws.q_actor)
         K.fill(ws.dz3, -1.0 / B)
@@ -425,7 +495,14 @@ class DDPGLearner(Learner):
                         ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
         K.ddpg_stats(ws.q_policy, ws.y, rewards, actions, ws.q_actor, ws.stats)
         self._average_over_ranks(ws.stats[:6])
-        for tgt, src in self._target_pairs(mt, m):
+        pairs = list(self._target_pairs(mt, m))
+        if self.is_pixel_input:
+            pairs.append((mt.perception_flat, m.perception_flat))
+        if self.use_double_critic:
+            pairs.append((self.model_target2.critic_flat, self.model2.critic_flat))
+            if self.is_pixel_input:
+                pairs.append((self.model_target2.perception_flat, self.model2.perception_flat))
+        for tgt, src in pairs:
             if self.target_update_type == 'soft':
                 K.soft_update(tgt, src, self.target_update_tau)
             else:
@@ -434,7 +511,7 @@ class DDPGLearner(Learner):
     def _enqueue_iteration(self, ws, x, xn, actions, rewards, done, pix=None, pix_next=None):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
         if self.use_layernorm:
-            return self._enqueue_iteration_ln(ws, x, xn, actions, rewards, done)
+            return self._enqueue_iteration_ln(ws, x, xn, actions, rewards, done, pix, pix_next)
         if not (self.is_pixel_input or self.use_double_critic or self.world_size > 1):
             if self.level_schedule:
                 return self._enqueue_iteration_levels(ws, x, xn, actions, rewards, done)

@@ -36,8 +36,6 @@ class DDPGModel(object):
                           conv_strides=conv_strides, conv_hidden_dim=conv_hidden_dim,
                           critic_only=critic_only, device=device, kernels=self.K)
         self.is_pixel_input = 'pixel' in obs_spec
-        if use_layernorm and self.is_pixel_input:
-            raise NotImplementedError('use_layernorm=True with camera observations is not built')
         self.action_dim = A = action_dim
         self.use_layernorm = use_layernorm
         self.low_dim = int(obs_spec['low_dim']['flat_inputs'][0]) if 'low_dim' in obs_spec else 0

@@ -10,7 +10,8 @@ from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, 
 import ddpg_oracle
 
 DDPG_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'tiny_td3_hard', 'tiny_double_soft', 'tiny_pixel_hard',
-              'tiny_pixel_td3_soft', 'cfg3_cheetah512', 'tiny_ln_hard', 'ln_soft_clipcritic', 'cfg3_cheetah512_x502']
+              'tiny_pixel_td3_soft', 'cfg3_cheetah512', 'tiny_ln_hard', 'ln_soft_clipcritic', 'cfg3_cheetah512_x502',
+              'tiny_ln_td3_soft', 'tiny_ln_pixel_hard', 'tiny_ln_pixel_td3_soft']
 
 
 def load(name):
@@ -44,7 +45,8 @@ def make_learner(case, opts=None):
     def mkp(seed):
         if pixel is not None:
             return ddpg_oracle.make_ddpg_pixel_params(case['D'], case['A'], pixel, case['conv_hidden'],
-                                                      tuple(case['ah']), tuple(case['ch']), seed=seed)
+                                                      tuple(case['ah']), tuple(case['ch']), seed=seed,
+                                                      layernorm=bool(h.get('layernorm', False)))
         return ddpg_oracle.make_ddpg_params(case['D'], case['A'], tuple(case['ah']), tuple(case['ch']), seed=seed,
                                             layernorm=bool(h.get('layernorm', False)))
     params = mkp(3)

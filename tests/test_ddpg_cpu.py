@@ -20,7 +20,7 @@ def test_ddpg_oracle_matches_reference_golden(name):
     def mkp(seed):
         if pixel is not None:
             return ddpg_oracle.make_ddpg_pixel_params(c['D'], c['A'], pixel, c['conv_hidden'], tuple(c['ah']),
-                                                      tuple(c['ch']), seed=seed)
+                                                      tuple(c['ch']), seed=seed, layernorm=bool(h.get('layernorm', False)))
         return ddpg_oracle.make_ddpg_params(c['D'], c['A'], tuple(c['ah']), tuple(c['ch']), seed=seed,
                                             layernorm=bool(h.get('layernorm', False)))
     params, params2 = mkp(3), mkp(4)
