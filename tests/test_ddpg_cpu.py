@@ -48,20 +48,22 @@ def test_replay_samples_straight_into_the_learners_staging_buffers(cpu_double):
     DH.check_sampling_into_staging('cpu')
 
 
-def test_ddpg_unsupported_switches_raise(cpu_double):
-    g, c = DH.load('tiny_hard')
+def test_ddpg_every_switch_combination_constructs_and_learns(cpu_double):
+    """use_layernorm x double critic x camera observations (round 6: none refuses any more; the goldens tiny_ln_td3_soft,
+    tiny_ln_pixel_hard, tiny_ln_pixel_td3_soft pin the arithmetic); an unknown target-update type is a ConfigError"""
     from surreal_amd.learner.ddpg import DDPGLearner
     from surreal_amd.main.ddpg_configs import ddpg_learner_config, ddpg_env_config, ddpg_session_config
-    lc = ddpg_learner_config()
-    lc.model.use_layernorm = True                   # built for low-dimensional observations with one critic
-    lc.algo.network.use_double_critic = True
-    L = DDPGLearner(lc, ddpg_env_config(5, 2), ddpg_session_config())
-    with pytest.raises(NotImplementedError):
-        L.learn(synthetic.make_ddpg_batch(lc.replay.batch_size, 5, 2, seed=1))
-    lc = ddpg_learner_config()
-    lc.model.use_layernorm = True
-    with pytest.raises(NotImplementedError):
-        DDPGLearner(lc, ddpg_env_config(5, 2, pixel=(2, 20, 24)), ddpg_session_config())
+    for double, pixel in ((True, None), (False, (2, 20, 24)), (True, (2, 20, 24))):
+        lc = ddpg_learner_config()
+        lc.model.use_layernorm = True
+        lc.model.actor_fc_hidden_sizes, lc.model.critic_fc_hidden_sizes = [24, 16], [32, 24]
+        lc.algo.network.use_double_critic = double
+        lc.replay.batch_size = 8
+        if pixel:
+            lc.model.conv_spec.hidden_output_dim = 8
+        L = DDPGLearner(lc, ddpg_env_config(5, 2, pixel=pixel), ddpg_session_config())
+        st = dict(L.learn(synthetic.make_ddpg_batch(8, 5, 2, seed=1, pixel=pixel)))
+        assert np.isfinite(st['critic_loss']) and ('Q_policy2' in st) == double
     lc = ddpg_learner_config()
     lc.algo.network.target_update = {'type': 'weird'}
     from surreal_amd.session import ConfigError
