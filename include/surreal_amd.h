@@ -934,9 +934,11 @@ int smx_flatten_order_f32(const float* in, int32_t O, int32_t C, int32_t P,
 /* A whole device-resident rollout in ONE launch: `steps` iterations of [z-filter -> policy MLP -> DiagGauss sample ->
  * clip -> synthetic env step -> record] for all n actors (the per-step loop of surreal/agent/base.py:244-271 with
  * PPOAgent.act, surreal/agent/ppo_agent.py:106-154, and the recording of env/exp_sender_wrapper.py:153-264).  A
- * workgroup owns 16 actors for the whole rollout; the policy layers run on FP32 MFMA from `packed`
- * (smx_epoch_pack_f32 of `net`), with the operations of smx_epoch_forward_f32 in the same order (bit-identical means);
- * sampling, dynamics, recording and the z-filter use the expressions of smx_synth_act_env_step_f32.
+ * workgroup owns 4 actors for the whole rollout (8 from 1025 actors on, 16 beyond 2048: the smallest block whose grid fits
+ * the CUs once); the policy layers run on FP32 MFMA (v_mfma_f32_4x4x1; 16x16x4 for 16-actor blocks) from `packed`
+ * (smx_epoch_pack_f32 of `net`): the means equal smx_epoch_forward_f32's to fp32 rounding of the layer sums (another
+ * summation order), 4- and 8-actor blocks bit for bit each other's; sampling, dynamics, recording and the z-filter use the
+ * expressions of smx_synth_act_env_step_f32.
  * eps [steps, n, A] standard normals (NULL: deterministic); zsum/zsumsq/zcount: the z-filter's running sums (NULL:
  * raw observations); rolls [n, rows_per_actor, .] (any may be NULL); state [n, D] is read at the start and left at
  * the state after the last step; t: the episode clock at the first step.
