@@ -308,8 +308,10 @@ class DDPGLearner(Learner):
         H1, H2 = m.actor.H1, m.actor.H2
         R, T = L.SMX_ACT_RELU, L.SMX_ACT_TANH
         # 1: first layers of all four chains (none depends on another) -- and the batch's actions into the last A columns
-        # of the critic's concat buffer as a fifth problem of the launch, actions . I^T (exact: one product with 1, the rest
-        # with 0); as a strided torch copy in front it was a 9 us launch of its own
+        # of the critic's concat buffer as a fifth problem of the launch, actions . I^T (exact for FINITE actions: one product
+        # with 1, the rest with 0 -- the contract |a| <= 1 of ddpg.py:262-263, which the statistics launch checks on `actions`
+        # itself; an Inf would turn its row's other columns into NaN here, -0.0 becomes +0.0); as a strided torch copy in
+        # front it was a 9 us launch of its own
         if getattr(ws, 'eyeA', None) is None:
             ws.eyeA = torch.eye(A, device=self.device)
         K.linear_multi([('linear', xn, 1, ta['W1'], 1, ta['b1'], ws.h1a_t, B, H1, D, dict(act=R)),

@@ -62,6 +62,8 @@ class DDPGModel(object):
             sizes += [('ln1.W', (c1,)), ('ln1.b', (c1,)), ('ln2.W', (c2,)), ('ln2.b', (c2,))]
         n = sum(int(np.prod(s)) for _, s in sizes)
         self.ln_eps = 1e-5           # torch.nn.LayerNorm's default
+        if use_layernorm and max(list(actor_fc_hidden_sizes) + list(critic_fc_hidden_sizes)) > 1024:
+            raise NotImplementedError('use_layernorm: hidden sizes up to 1024 (smx_layernorm_*_f32 keep a row in one workgroup)')
         self.actor_flat = self.ac_flat = None
         if not critic_only:
             # actor and critic parameters live in ONE buffer (each on a 256-byte boundary, the gap zero): the target
@@ -173,6 +175,17 @@ class DDPGModel(object):
         return out
 
     # ---- the LayerNorm variant: layer by layer, the LayerNorm inputs and row statistics kept for a backward pass ----
+    def _ln_workspace_cached(self, rows, device):
+        """the per-step act path (forward_actor / forward_critic): one workspace per (rows, device), not ~14 allocations
+        per call"""
+        key = (int(rows), str(device))
+        cache = self.__dict__.setdefault('_ln_ws_cache', {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = self.ln_workspace(rows, device)
+        return cache[key]
+
     def ln_workspace(self, rows, device=None):
         """buffers of one actor and one critic pass with LayerNorm (activations in front of each LayerNorm, its outputs,
         row means / reciprocal standard deviations)"""
@@ -214,7 +227,7 @@ class DDPGModel(object):
         rows = x.shape[0]
         if self.use_layernorm:
             out = torch.empty(rows, a.OUT, device=x.device)
-            self.actor_forward_ln(x.contiguous(), self.ln_workspace(rows, x.device), out)
+            self.actor_forward_ln(x.contiguous(), self._ln_workspace_cached(rows, x.device), out)
             return out
         h1 = torch.empty(rows, a.H1, device=x.device)
         h2 = torch.empty(rows, a.H2, device=x.device)
@@ -237,7 +250,7 @@ class DDPGModel(object):
         if self.use_layernorm:
             xcat = torch.empty(rows, self.c1 + self.action_dim, device=x.device)
             q = torch.empty(rows, device=x.device)
-            self.critic_forward_ln(x.contiguous(), action, self.ln_workspace(rows, x.device), xcat, q)
+            self.critic_forward_ln(x.contiguous(), action, self._ln_workspace_cached(rows, x.device), xcat, q)
             return q.view(rows, 1)
         xcat = torch.empty(rows, self.c1 + self.action_dim, device=x.device)
         h2 = torch.empty(rows, self.c2, device=x.device)
