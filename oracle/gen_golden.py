@@ -272,6 +272,11 @@ _case('tiny_rnn_clip', S['tiny'], (24, 16),
 # (3, 84, 84) uint8 + robot state, A = 8; golden at 8 actors x 6 steps)
 _case('tiny_pixel_clip', dict(B=6, N=5, D=5, A=2), (24, 16), dict(ppo_mode='clip', kl_target=1e9),
       pixel=(3, 28, 36), cnn_feature_dim=16)
+# round 6 (VERDICT r05 "missing" 3): a hidden size that is not a multiple of 4 (ppo_net.py:144-149 takes any; the product pads
+# the stem inside its parameter layout)
+_case('tiny_rnn_h10_adapt', S['tiny'], (24, 16), dict(ppo_mode='adapt', if_rnn_policy=True, horizon=4), rnn_hidden=10)
+_case('tiny_rnn2_h6_clip', S['tiny'], (24, 16), dict(ppo_mode='clip', if_rnn_policy=True, horizon=3, kl_target=1e9),
+      rnn_hidden=6, rnn_layers=2)
 _case('tiny_rnn2_adapt', S['tiny'], (24, 16), dict(ppo_mode='adapt', if_rnn_policy=True, horizon=3),
       rnn_hidden=12, rnn_layers=2)
 _case('tiny_pixel_rnn_adapt', dict(B=5, N=6, D=4, A=2), (24, 16),

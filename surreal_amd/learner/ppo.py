@@ -1316,9 +1316,11 @@ class PPOLearner(Learner):
         if self.if_rnn_policy:
             # agent-side LSTM state at the head of every sub-trajectory (ppo.py:511-515):
             # (B, layers=1, H) -> the kernels' [B, H]
-            nl, F = self.model.rnn_layers, self.model.rnn_hidden
-            ws.h0L.copy_(onetime_infos[0].reshape(B, nl, F).transpose(0, 1))
-            ws.c0L.copy_(onetime_infos[1].reshape(B, nl, F).transpose(0, 1))
+            nl, F, Fl = self.model.rnn_layers, self.model.rnn_hidden, self.model.rnn_hidden_logical
+            if Fl != F:                 # (a hidden size padded to a multiple of 4: the pad of the state is zero)
+                ws.h0L.zero_(); ws.c0L.zero_()
+            ws.h0L[:, :, :Fl].copy_(onetime_infos[0].reshape(B, nl, Fl).transpose(0, 1))
+            ws.c0L[:, :, :Fl].copy_(onetime_infos[1].reshape(B, nl, Fl).transpose(0, 1))
         if self.use_graph:
             # A captured graph is bound to the addresses of its inputs.  The first batch is captured
             # in place (a pointer-stable feed -- device-resident replay, the benchmark -- never pays
@@ -1557,7 +1559,9 @@ class PPOLearner(Learner):
                 if self.cells is None:
                     ws.h0.zero_(); ws.c0.zero_()
                 else:
-                    ws.h0.copy_(self.cells[0].reshape(B, -1)); ws.c0.copy_(self.cells[1].reshape(B, -1))
+                    Fl = self.model.rnn_hidden_logical
+                    ws.h0.zero_(); ws.c0.zero_()
+                    ws.h0[:, :Fl].copy_(self.cells[0].reshape(B, -1)); ws.c0[:, :Fl].copy_(self.cells[1].reshape(B, -1))
             pix = obs['pixel']['camera0'] if self.model.if_pixel else None
             pixn = obs_next['pixel']['camera0'] if self.model.if_pixel else None
             self._enqueue_gae_stem(ws, x, xn, pix, pixn, rewards.contiguous(), dones.contiguous())

@@ -170,9 +170,6 @@ class PPOModel(object):
         self.rnn_layers = int(rnn_config.get('rnn_layer', 1)) if self.if_rnn else 0
         if self.if_rnn and self.rnn_layers < 1:
             raise ValueError('rnn_layer must be >= 1')
-        if self.if_rnn and int(rnn_config.rnn_hidden) % 4:
-            raise NotImplementedError('rnn_hidden must be a multiple of 4 (the LSTM kernels read W_hh 16 '
-                                      'bytes at a time; the reference default is 100)')
         self.obs_spec = obs_spec
         self.action_dim = action_dim
         self.model_config = model_config
@@ -187,7 +184,15 @@ class PPOModel(object):
                 self.low_dim += obs_spec['low_dim'][key][0]
         D, A = self.low_dim, action_dim
         ah, ch = model_config['actor_fc_hidden_sizes'], model_config['critic_fc_hidden_sizes']
-        self.rnn_hidden = int(rnn_config.rnn_hidden) if self.if_rnn else 0
+        # The LSTM kernels read W_hh rows and the hidden state 16 bytes at a time: a hidden size that is not a multiple of 4
+        # (ppo_net.py:144-149 takes any) is PADDED inside the parameter layout -- every gate block, the recurrent columns,
+        # the MLPs' input columns -- with zeros.  A padded unit's gates see zero pre-activations (g = tanh(0) = 0, so its
+        # cell stays at the zero it starts from and its output is 0), nothing downstream reads it through a non-zero
+        # weight, so its gradients are exactly zero and Adam leaves the zeros alone.  `rnn_hidden` is the PADDED size (what
+        # every device buffer is shaped by); `rnn_hidden_logical` what the configuration, the parameter dict, the wire
+        # formats and the agents' cells see.
+        self.rnn_hidden_logical = int(rnn_config.rnn_hidden) if self.if_rnn else 0
+        self.rnn_hidden = (self.rnn_hidden_logical + 3) & ~3
         self.cnn_feature_dim = int(model_config['cnn_feature_dim']) if self.if_pixel else 0
         Dx = D + self.cnn_feature_dim                    # stem input width (ppo_net.py:145)
         self.stem_in = Dx
@@ -234,10 +239,13 @@ class PPOModel(object):
         if self.if_pixel:
             self.cnn.init_torch_default()
         if self.if_rnn:                          # torch.nn.LSTM default: U(-1/sqrt(H), 1/sqrt(H))
-            b = 1.0 / np.sqrt(self.rnn_hidden)
-            for r in self.rnns:
-                for v in r.views.values():
+            b = 1.0 / np.sqrt(self.rnn_hidden_logical)
+            for k, v in self.named_parameters().items():        # (the logical views: a pad stays zero)
+                if k.startswith('rnn.'):
                     v.uniform_(-b, b)
+        if self.if_rnn and self.rnn_hidden != self.rnn_hidden_logical:
+            for net in (self.actor, self.critic):               # the MLPs' input columns behind the logical width
+                net.views['W1'][:, self.rnn_hidden_logical:].zero_()
 
     # ---- canonical parameter dict (names shared with the oracle / synthetic generator) ----
     def named_parameters(self):
@@ -251,11 +259,26 @@ class PPOModel(object):
         if self.if_pixel:
             for k, v in self.cnn.views.items():
                 out['cnn.' + k] = v
+        H, Hp = self.rnn_hidden_logical, self.rnn_hidden
+        padded = self.if_rnn and H != Hp
+        if padded:                                           # the MLPs read the LSTM output: logical columns only
+            out['actor.fc1.W'] = self.actor.views['W1'][:, :H]
+            out['critic.fc1.W'] = self.critic.views['W1'][:, :H]
         if self.if_rnn:
             for layer, r in enumerate(self.rnns):            # nn.LSTM's names: *_l0 (kept bare), *_l1, ...
                 for k, v in r.views.items():
+                    if padded:                               # [4 gate blocks of H of Hp rows (, H of Hp recurrent columns)]
+                        v = v.view((4, Hp) + tuple(v.shape[1:]))[:, :H]
+                        if k == 'weight_hh' or (k == 'weight_ih' and layer > 0):
+                            v = v[:, :, :H]
                     out['rnn.' + k + ('' if layer == 0 else '_l%d' % layer)] = v
         return out
+
+    def _logical_shape(self, k, v):
+        """the shape a parameter has outside this class (torch.nn.LSTM's [4H, .]): differs from the view's only under padding"""
+        if k.startswith('rnn.') and v.dim() >= 2 and v.shape[0] == 4 and self.rnn_hidden != self.rnn_hidden_logical:
+            return (4 * v.shape[1],) + tuple(v.shape[2:])
+        return tuple(v.shape)
 
     def load_params(self, params):
         with torch.no_grad():
@@ -263,11 +286,13 @@ class PPOModel(object):
                 v.copy_(torch.as_tensor(np.asarray(params[k]), dtype=torch.float32).view(v.shape))
 
     def numpy_params(self):
-        return collections.OrderedDict((k, v.detach().cpu().numpy().copy())
+        return collections.OrderedDict((k, v.detach().cpu().numpy().reshape(self._logical_shape(k, v)).copy())
                                        for k, v in self.named_parameters().items())
 
     def state_dict(self):
-        sd = collections.OrderedDict(self.named_parameters())
+        # (under padding the LSTM entries are reshaped COPIES in torch.nn.LSTM's shapes: an export, not an alias)
+        sd = collections.OrderedDict((k, v if tuple(v.shape) == self._logical_shape(k, v) else v.reshape(self._logical_shape(k, v)))
+                                     for k, v in self.named_parameters().items())
         if self.use_z_filter:
             for k, v in self.z_filter.state_dict().items():
                 sd['z_filter.' + k] = v
@@ -341,9 +366,11 @@ class PPOModel(object):
         x2 = x.reshape(B * T, D).contiguous()
         nl = self.rnn_layers
         h0 = c0 = None
-        if cells is not None:                    # (layers, B, H) each
-            h0 = cells[0].reshape(nl, B, H).to(dev, torch.float32).contiguous()
-            c0 = cells[1].reshape(nl, B, H).to(dev, torch.float32).contiguous()
+        Hl = self.rnn_hidden_logical
+        if cells is not None:                    # (layers, B, H) each, H the configured size (zero padded for the kernels)
+            h0, c0 = torch.zeros(nl, B, H, device=dev), torch.zeros(nl, B, H, device=dev)
+            h0[:, :, :Hl].copy_(cells[0].reshape(nl, B, Hl))
+            c0[:, :, :Hl].copy_(cells[1].reshape(nl, B, Hl))
         gates = torch.empty(B * T, 4 * H, device=dev)
         cs = torch.empty(B * T, H, device=dev)
         hN = cN = None
@@ -356,7 +383,7 @@ class PPOModel(object):
                                 hN[layer] if want_cells else None, cN[layer] if want_cells else None)
             x2 = out.view(B * T, H)
         if want_cells:
-            cells = (hN, cN)
+            cells = (hN[:, :, :Hl], cN[:, :, :Hl]) if Hl != H else (hN, cN)
         return out, cells
 
     def forward_actor(self, obs, cells=None):    # ppo_net.py:253-282, builders.py:114-132

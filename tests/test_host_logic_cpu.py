@@ -209,3 +209,32 @@ def test_philox_restatement_meets_the_random123_known_answer_vectors():
         assert P.philox4x32_10(ctr, key) == want
     idx = P.uniform_indices(4096, 1000, 1234, 0)
     assert idx.min() >= 0 and idx.max() < 1000 and len(set(idx.tolist())) > 900
+
+
+def test_rnn_hidden_not_a_multiple_of_four_is_padded_inside(cpu_double):
+    """rnn_hidden = 10 (ppo_net.py:144-149 takes any size): the stem is padded to 12 inside the parameter layout; outside --
+    parameter dict, state dict, the agents' cells -- nothing shows it, and the pad stays exactly zero through a learn"""
+    import copy
+    import torch
+    g, case = H.load_golden('tiny_rnn_h10_adapt')
+    batch, params, zstate = H.case_inputs(case)
+    learner = H.make_learner(case, params, zstate)
+    m = learner.model
+    assert m.rnn_hidden == 12 and m.rnn_hidden_logical == 10
+    got = m.numpy_params()
+    for k, v in params.items():
+        assert got[k].shape == np.asarray(v).shape, (k, got[k].shape)
+        np.testing.assert_array_equal(got[k], v)
+    sd = m.state_dict()
+    assert tuple(sd['rnn.weight_hh'].shape) == (40, 10) and tuple(sd['actor.fc1.W'].shape) == (24, 10)
+    twin = H.make_learner(case, params, zstate).model
+    twin.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sd.items()})
+    assert torch.equal(twin.flat, m.flat)
+    learner.learn(copy.deepcopy(batch))
+    pad = m.rnn.views['weight_hh'].view(4, 12, 12)
+    assert float(pad[:, 10:, :].abs().max()) == 0.0 and float(pad[:, :, 10:].abs().max()) == 0.0
+    assert float(m.actor.views['W1'][:, 10:].abs().max()) == 0.0 and float(m.critic.views['W1'][:, 10:].abs().max()) == 0.0
+    obs = {'low_dim': {'flat_inputs': torch.zeros(3, case['shape']['D'])}}
+    cells = (torch.zeros(1, 3, 10), torch.zeros(1, 3, 10))
+    pd, new = m.forward_actor_expose_cells(obs, cells)
+    assert tuple(new[0].shape) == (1, 3, 10) and tuple(pd.shape) == (3, 2 * case['shape']['A'])
