@@ -535,6 +535,18 @@ class PPOLearner(Learner):
         ws.ppart = f(ws.nblk_p, ws.pstride)
         ws.ppart_sum = f(1, ws.pstride)
         ws.ppart_fold = f(64, ws.pstride)
+        # Stem policies on several ranks, clip mode: ONE exchange per policy epoch.  Nothing in the clip gradient depends on
+        # the batch (dz3 = g_surr / n), so the loss sums travel WITH the gradient -- [actor group's gradient | loss sums] is
+        # one buffer, one all-reduce -- and the statistics, log_var's gradient and the KL early-exit flag are formed from
+        # the global sums behind it, in front of the optimiser launch that honours the flag (_stem_policy_update).  Adapt
+        # mode keeps two: its KL coefficient needs the global KL BEFORE the backward pass, and the two-right-hand-side
+        # form that avoids that would run the stem's backward twice.
+        ws.stem_one_exchange = bool(stem and self.world_size > 1 and self.ppo_mode == 'clip' and
+                                    self.session_config.learner.get('stem_one_exchange', True))
+        if ws.stem_one_exchange:
+            ws.ar_pol = torch.zeros(((n_a + 3) & ~3) + ws.pstride, device=dev)
+            ws.grads_a = ws.ar_pol[:n_a]
+            ws.ppart_sum = ws.ar_pol[(n_a + 3) & ~3:].view(1, ws.pstride)
         # partial rows a rank does not fill stay zero (count 0: skipped by the merge)
         ws.vpart = torch.zeros(Ev, self.world_size * ws.nblk_v, 8, device=dev)
         ws.vpart_local = torch.zeros(ws.nblk_v, 8, device=dev)
@@ -1148,6 +1160,12 @@ class PPOLearner(Learner):
         K.policy_loss(mode, ws.mean, m.log_var.view(-1), ws.act_it, ws.beh_it, ws.ref_pol, ws.adv,
                       ws.ctrl_f, ws.g_surr, ws.g_kl, ws.ppart)
         part, nblk = ws.ppart, ws.nblk_p
+        if W > 1 and ws.stem_one_exchange and e < self.epoch_policy:
+            # the loss sums ride on the gradient's all-reduce (_stem_policy_update finalises): here only what the backward
+            # pass needs, which in clip mode is local -- dz3 = g_surr * (1 / n), the finalize's own expression with c_kl = 0
+            torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
+            torch.mul(ws.g_surr, float(np.float32(1.0) / np.float32(ws.n_total)), out=ws.dz3a)
+            return
         if W > 1:
             torch.sum(ws.ppart, 0, keepdim=True, out=ws.ppart_sum)
             self._dist.all_reduce(ws.ppart_sum)
@@ -1202,7 +1220,18 @@ class PPOLearner(Learner):
         self._stem_backward(ws, m.actor, ws.h1a, ws.h2a, ws.dz3a, ws.dz2a, ws.dz1a,
                             ws.grads_a[:n_mlp], ws.grads_a[n0:n0 + m.n_cnn],
                             ws.grads_a[n0 + m.n_cnn:], ws.stop)
-        if self.world_size > 1:
+        if self.world_size > 1 and ws.stem_one_exchange:
+            # [gradient | loss sums] in one all-reduce; then the finalize on the GLOBAL sums: statistics, log_var's gradient
+            # (into its slot of the gradient, which the exchange left holding garbage: zero it first -- every rank the same),
+            # the early-exit flag and the step counter, once, in front of the optimiser launch
+            A = self.action_dim
+            mode = L.SMX_PPO_CLIP
+            ws.grads_a[n_mlp:n0].zero_()
+            self._dist.all_reduce(ws.ar_pol)
+            K.policy_finalize(mode, ws.ppart_sum, 1, ws.g_surr, ws.g_kl, m.log_var.view(-1), ws.n_total,
+                              ws.ctrl_f, e > 0, True, ws.dz3a, ws.grads_a[n_mlp:n_mlp + A],
+                              ws.sumsq_a[ws.np_a:ws.np_a + 1], ws.pstats[e])
+        elif self.world_size > 1:
             # ONE all-reduce for the MLP and the stem.  log_var's gradient (between them) was built from
             # all-reduced loss sums and is global already: exactly one copy may enter the sum
             if self.rank != 0:

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, q, cuts=None):
+def _worker(rank, world, port, name, q, cuts=None, overrides=None):
     try:
         import torch.distributed as dist
         os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -49,10 +49,10 @@ def _worker(rank, world, port, name, q, cuts=None):
         sb = shard(batch)
         case_local = copy.deepcopy(case)
         case_local['shape']['B'] = hi - lo
-        learner = H.make_learner(case_local, params, zstate)
+        learner = H.make_learner(case_local, params, zstate, session_overrides=overrides)
         assert learner.world_size == world
         stats = learner.learn(sb)
-        out = {'stats': stats, 'trace': learner.trace,
+        out = {'stats': stats, 'trace': learner.trace, 'collectives': getattr(learner, 'collectives_per_step', None),
                'adv': learner._ws.adv.numpy().copy(), 'ret': learner._ws.ret.numpy().copy(),
                'actor': learner.model.actor_flat.numpy().copy(),
                'critic': learner.model.critic_flat.numpy().copy(),
@@ -93,11 +93,23 @@ def test_three_ranks_with_different_block_counts(name):
     _ranks_equal_single_learner(name, 3, cuts=[0, 5, 25, 37])
 
 
-def _ranks_equal_single_learner(name, world, cuts=None):
+def test_stem_policy_in_clip_mode_exchanges_once_per_policy_epoch():
+    """an LSTM policy on two ranks, clip mode: the loss sums ride on the gradient's all-reduce (one exchange per policy epoch,
+    _stem_policy_update) -- epoch_policy fewer collectives per learn than the two-exchange form
+    (session_config.learner.stem_one_exchange = False), the same golden trace either way"""
+    one = _ranks_equal_single_learner('tiny_rnn_clip', 2)
+    two = _ranks_equal_single_learner('tiny_rnn_clip', 2, overrides={'stem_one_exchange': False})
+    g, case = H.load_golden('tiny_rnn_clip')
+    ep = case['hyper'].get('epoch_policy', 10)
+    assert one[0]['collectives'] is not None and two[0]['collectives'] - one[0]['collectives'] == ep, \
+        (one[0]['collectives'], two[0]['collectives'])
+
+
+def _ranks_equal_single_learner(name, world, cuts=None, overrides=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, cuts)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, cuts, overrides)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -126,6 +138,7 @@ def _ranks_equal_single_learner(name, world, cuts=None):
     if res[0]['z'] is not None:
         for k in ('running_sum', 'running_sumsq', 'count'):
             np.testing.assert_allclose(res[0]['z'][k], g['zfinal.' + k], rtol=1e-6)
+    return res
 
 
 def _ddpg_worker(rank, world, port, name, q):
