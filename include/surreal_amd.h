@@ -833,6 +833,42 @@ int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
                        const float* actions, int32_t ld_act, int32_t A, const float* q_actor,
                        int64_t rows, float* stats, smx_stream_t stream);
 
+/* --- one DDPG iteration on ROW BLOCKS (round 5; surreal/learner/ddpg.py:244-352, low-dimensional observations, one critic) ---
+ * The layer-by-layer schedule above is ~19 dependent launches of 512-row problems.  Batch rows are independent up to the
+ * weight gradients, so a workgroup carries 16 rows through whole chains (the MFMA row-block loop of the fused PPO epochs):
+ *   smx_ddpg_rows_critic_f32  mu'(s') -> Q'(s', mu'(s')) (target networks); Q(s, a); y = r + gamma^n Q' (1 - done) and
+ *                             dz3 = 2 (Q - y) / rows (ddpg.py:279, 307-308); *step += 1; the critic's data gradients
+ *                             dz2 [rows, c2] and dz1 (first c1 columns of dxcat); mu(s) for the actor phase (h1a, h2a, act)
+ *   smx_ddpg_rows_actor_f32   Q(s, mu(s)) through the critic as it is NOW (after its Adam step and a
+ *                             smx_ddpg_rows_pack_f32(SMX_DDPG_PACK_CRITIC)) -> q_actor; d(-mean Q)/d(action) through tanh
+ *                             -> dz3a; the actor's data gradients dz2a, dz1a (ddpg.py:326-331)
+ * The weight gradients (sums over all rows), Adam, the target update and the statistics stay the launches declared above,
+ * on the same row-major buffers.  Weights are read from a copy in MFMA fragment order (`packed`,
+ * smx_ddpg_rows_packed_floats floats, 16-byte aligned) which smx_ddpg_rows_pack_f32 refreshes from the row-major
+ * parameters: every network (SMX_DDPG_PACK_ALL) or the critic's blocks only.  xcat / dxcat have row stride c1 + A.
+ * H1, H2, c1, c2 multiples of 4, A <= 32: smx_ddpg_rows_supported; otherwise SMX_E_UNSUPPORTED. */
+typedef struct smx_ddpg_net {          /* nn.Linear layouts: W [out, in] row-major */
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+} smx_ddpg_net_t;
+typedef struct smx_ddpg_rows {
+    int64_t rows;
+    int32_t D, A, H1, H2, c1, c2;      /* actor D -> H1 -> H2 -> A (tanh); critic D -> c1, [c1 | A] -> c2 -> 1 */
+    smx_ddpg_net_t actor, critic, target_actor, target_critic;
+    float* packed;
+    const float *x, *x_next, *actions, *rewards, *dones;       /* [rows, D] x 2, [rows, A], [rows] x 2 */
+    float gamma_n;
+    float *xcat, *h2c, *q, *q_next, *y, *dz3, *dz2, *dxcat;    /* critic phase, out */
+    float *h1a, *h2a, *act;                                    /* critic phase out, actor phase in */
+    float *q_actor, *dz3a, *dz2a, *dz1a;                       /* actor phase, out */
+    int32_t* step;                                             /* device Adam step counter (may be NULL) */
+} smx_ddpg_rows_t;
+enum { SMX_DDPG_PACK_ALL = 0, SMX_DDPG_PACK_CRITIC = 1 };
+int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);
+int64_t smx_ddpg_rows_packed_floats(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);
+int smx_ddpg_rows_pack_f32(const smx_ddpg_rows_t* args, int32_t which, smx_stream_t stream);
+int smx_ddpg_rows_critic_f32(const smx_ddpg_rows_t* args, smx_stream_t stream);
+int smx_ddpg_rows_actor_f32(const smx_ddpg_rows_t* args, smx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LSTM stem (surreal/model/ppo_net.py:143-152: nn.LSTM(in, rnn_hidden, 1, batch_first=True) in
  * front of the actor / critic MLPs; forward at :277-279, :307-309, single step at :338-349).

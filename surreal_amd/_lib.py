@@ -118,6 +118,21 @@ class LinearJob(Structure):
                 ('K', c_int32), ('stop_flag', c_void_p)]
 
 
+class DdpgNet(Structure):
+    """smx_ddpg_net_t"""
+    _fields_ = [(n, c_void_p) for n in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')]
+
+
+class DdpgRows(Structure):
+    """smx_ddpg_rows_t"""
+    _fields_ = ([('rows', c_int64)] + [(n, c_int32) for n in ('D', 'A', 'H1', 'H2', 'c1', 'c2')] +
+                [(n, DdpgNet) for n in ('actor', 'critic', 'target_actor', 'target_critic')] +
+                [(n, c_void_p) for n in ('packed', 'x', 'x_next', 'actions', 'rewards', 'dones')] +
+                [('gamma_n', c_float)] +
+                [(n, c_void_p) for n in ('xcat', 'h2c', 'q', 'q_next', 'y', 'dz3', 'dz2', 'dxcat', 'h1a', 'h2a', 'act',
+                                         'q_actor', 'dz3a', 'dz2a', 'dz1a', 'step')])
+
+
 class GatherJob(Structure):
     """smx_gather_job_t"""
     _fields_ = [('table', c_void_p), ('dst', c_void_p), ('row_bytes', c_int64)]
@@ -275,6 +290,11 @@ _SIGS = {
     'smx_ddpg_critic_loss_step_f32': (c_int32, [_P, _P, _P, _P, c_float, c_int64, _P, _P, _P, _P]),
     'smx_adam_step_dev_f32': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, c_double, c_double, _P]),
     'smx_hard_update_every_f32': (c_int32, [_P, _P, c_int64, _P, c_int32, _P]),
+    'smx_ddpg_rows_supported': (c_int32, [c_int32] * 6),
+    'smx_ddpg_rows_packed_floats': (c_int64, [c_int32] * 6),
+    'smx_ddpg_rows_pack_f32': (c_int32, [_P, c_int32, _P]),
+    'smx_ddpg_rows_critic_f32': (c_int32, [_P, _P]),
+    'smx_ddpg_rows_actor_f32': (c_int32, [_P, _P]),
     'smx_ddpg_stats_f32': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int64, _P, _P]),
     'smx_lstm_param_count': (c_int64, [c_int32, c_int32]),
     'smx_lstm_forward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,

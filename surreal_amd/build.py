@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsurreal_amd.so')
 SOURCES = ['smx_scan.hip', 'smx_mlp3_fused.hip', 'smx_gemm.hip', 'smx_ppo.hip', 'smx_replay.hip',
            'smx_ddpg.hip', 'smx_lstm.hip', 'smx_conv.hip', 'smx_epoch.hip', 'smx_mlp3_rows16.hip', 'smx_xchg.hip',
-           'smx_rollout.hip', 'smx_wgrad.hip', 'smx_mlp3_bwd16.hip']
+           'smx_rollout.hip', 'smx_wgrad.hip', 'smx_mlp3_bwd16.hip', 'smx_ddpg_rows.hip']
 # -ffp-contract=off: the reference issues separate ATen mul/add ops; contraction into FMAs would
 # change roundings that the parity tests pin (the MFMA path is unaffected).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',

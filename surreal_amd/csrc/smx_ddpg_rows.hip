@@ -1,0 +1,936 @@
+// One DDPG iteration on ROW BLOCKS (surreal/learner/ddpg.py:244-352; low-dimensional observations, one critic):
+// the layer-by-layer schedule is ~19 dependent launches of 512-row problems, each a few microseconds of work behind a
+// launch boundary and an L2 first touch (0.21 ms per iteration, 70 % of it in 15 dense launches).  Batch rows are
+// independent up to the weight gradients, so here a workgroup owns 16 rows and carries them through whole chains, as the
+// fused PPO epoch kernels do (smx_epoch.hip; the same MFMA loop, smx_epoch_mma.inc.h, on the same packed weights):
+//
+//   ddpg_critic_rows_kernel   target actor -> target critic -> Q'(s', mu'(s'));  critic -> Q(s, a);  y and dLoss/dQ;
+//                             the critic's data gradients dz2, dz1;  the actor's forward pass for ITS update (it reads
+//                             only the actor's parameters, which the critic update does not touch)
+//   [weight gradients of the critic: smx_linear_multi_f32; Adam: smx_adam_step_dev_f32; the critic's packed copy]
+//   ddpg_actor_rows_kernel    Q(s, mu(s)) through the UPDATED critic; d(-mean Q)/d(action); tanh'; the actor's data
+//                             gradients dz2, dz1
+//   [weight gradients of the actor, Adam, target update, statistics]
+//
+// Activations and gradients that the weight-gradient launches read go to HBM row-major, exactly the buffers of the
+// layer-by-layer schedule.  Products are summed in the MFMA loop's order (32-wide K chunks, k ascending), not in
+// smx_linear_f32's: results agree with the layered schedule to fp32 rounding, not bit for bit.
+//
+// Round 6: up to 1024 rows a workgroup owns FOUR rows and runs the 4-row loop of smx_rows4_mma.inc.h
+// (v_mfma_f32_4x4x1, the same packed weights): configs[2]'s batch of 512 is 128 workgroups instead of 32.  The 16-row
+// blocks of round 5 were bound by the matrix pipes of 32 CUs (92 + 46 us for the two chains); 4-row blocks are bound by
+// what a CU pulls from L2 (every workgroup streams every weight once per layer), on four times as many CUs.  Past 1024
+// rows the 16-row blocks fill the chip and stream each weight a quarter as often: they stay for those.
+#include "smx_common.h"
+#include <string.h>
+
+#define SMX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+namespace {
+#include "smx_epoch_pack.inc.h"
+#include "smx_epoch_mma.inc.h"
+#include "smx_rows4_mma.inc.h"
+
+constexpr int DNWV = 8;           // wavefronts per workgroup: two per SIMD (one's loads hide under the other's MFMAs)
+constexpr int DNTH = 64 * DNWV;
+constexpr int DTG = 3;            // feature tiles a wave carries per pass
+constexpr int LDO = 36;           // row stride of an output tile (<= 32 outputs)
+constexpr int LDK = 68;           // row stride of a tile that is the K <= 32 input of a product (two zero-padded chunks)
+constexpr int LDK4 = 80;          // the same on 4-row blocks (strides = 16 mod 64: the 16 (row, kq) readers on distinct banks)
+constexpr int DTG4 = 4;           // feature tiles a wave carries per pass on 4-row blocks (8 x 4 = 32 tiles: 400 features in one pass)
+constexpr int MAX_LDS = 128 * 1024;
+enum { A_NONE = 0, A_RELU = 1, A_TANH = 2, A_MASK = 3 };
+
+__host__ __device__ inline int r64(int v) { return (v + 63) & ~63; }
+
+struct PMat {                     // a matrix in fragment order (smx_epoch_pack.inc.h): M features x K inputs
+    const float* P;
+    int M, K;
+};
+
+// one dense layer of a row block: out[16][M] = act(W . in + bias), tiles LDS -> LDS (and / or HBM, row-major)
+struct Dense {
+    int in_off, ldi;              // LDS input tile [16][ldi] (float offsets into the workgroup's dynamic LDS)
+    PMat W;
+    const float* bias;            // [M] or null
+    int act;                      // A_MASK: the result is zeroed where mask <= 0 (ReLU backward)
+    int mask_off, ldm;
+    int out_off, ldo;             // LDS output tile, < 0: none
+    float* g;                     // HBM output [rows][ldg] or null
+    int ldg;
+};
+
+#ifdef SMX_DDPG_TIMING
+#define DSTAMP(i) do { if (threadIdx.x == 0 && d_ts_l) d_ts_l[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DTS_PARAM , long long* d_ts_l
+#define DTS_ARG(ts) , (ts)
+#else
+#define DSTAMP(i) do { } while (0)
+#define DTS_PARAM
+#define DTS_ARG(ts)
+#endif
+
+// (noinline: a kernel calls this a dozen times; inlined, every call carries its own copies of the three loop bodies and
+// the workgroup -- which runs each instruction stream once -- spends its time fetching code, see smx_epoch_mma.inc.h)
+__device__ __noinline__ void dense16v(int in_off_, int ldi_, const float* Wp_, int M_, int K_, const float* bias_, int act_,
+                                      int mask_off_, int ldm_, int out_off_, int ldo_, float* g_, int ldg_, int row0_,
+                                      int nrows_, int rows_total_ DTS_PARAM) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fm = lane & 15, kq = lane >> 4;
+    DSTAMP(0);
+    // the arguments arrive in vector registers (by value: through a descriptor in memory every call started with a scratch
+    // round trip); they are workgroup-uniform, say so (scalar registers, scalar branches)
+#define SMX_U(x) __builtin_amdgcn_readfirstlane(x)
+    const int in_off = SMX_U(in_off_), ldi = SMX_U(ldi_), M = SMX_U(M_), K = SMX_U(K_), act = SMX_U(act_);
+    const int mask_off = SMX_U(mask_off_), ldm = SMX_U(ldm_), out_off = SMX_U(out_off_), ldo = SMX_U(ldo_);
+    const int ldg = SMX_U(ldg_), nrows = SMX_U(nrows_), rows_total = SMX_U(rows_total_);
+    const long row0 = (long)SMX_U(row0_);
+#undef SMX_U
+    const float* const Wp = Wp_;
+    const float* const bias = bias_;
+    float* const gout = g_;
+    const int tiles = (M + 15) >> 4, C2 = pack_chunks(K);
+    const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
+    const rsrc_t rb = make_rsrc(bias ? bias : Wp, bias ? (unsigned)M * 4u : 0u);
+    const rsrc_t rg = make_rsrc(gout ? gout : Wp, gout ? (unsigned)rows_total * (unsigned)ldg * 4u : 0u);
+    const float* in = sm + in_off;
+#pragma unroll 1
+    for (int tb = 0; tb < tiles; tb += DNWV * DTG) {
+        const int t0 = tb + wv;
+        int nt = (tiles - t0 + DNWV - 1) / DNWV;
+        nt = nt < 0 ? 0 : (nt > DTG ? DTG : nt);
+        float bs[DTG][4];
+#pragma unroll
+        for (int g = 0; g < DTG; ++g) {
+            const int f0 = 16 * (t0 + DNWV * g) + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rb, (g < nt && f0 + r < M) ? (unsigned)(f0 + r) * 4u : OOB);
+        }
+        f32x4 acc[TG];
+#pragma unroll
+        for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        DSTAMP(1);
+        if (nt > 2) fwd_tiles<3>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
+        else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
+        else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
+        DSTAMP(2);
+        // lane (fm, kq) holds features f0 .. f0 + 3 of data row fm
+#pragma unroll
+        for (int g = 0; g < DTG; ++g) {
+            if (g < nt) {                                            // wave-uniform
+                const int f0 = 16 * (t0 + DNWV * g) + 4 * kq;
+                float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (act == A_MASK) mk = *(const float4*)(sm + mask_off + fm * ldm + f0);
+                const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float z = acc[g][r] + bs[g][r];
+                    if (act == A_RELU) z = (z < 0.f) ? 0.f : z;
+                    else if (act == A_TANH) z = tanhf(z);
+                    else if (act == A_MASK) z = (mv[r] > 0.f) ? z : 0.f;
+                    v[r] = (f0 + r < M) ? z : 0.f;
+                }
+                if (out_off >= 0) *(float4*)(sm + out_off + fm * ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
+                const unsigned grow = (unsigned)(row0 + fm) * (unsigned)ldg * 4u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = fm < nrows && f0 + r < M;       // (no HBM output: every offset is out of range)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rg,
+                                                          ok ? grow + (unsigned)(f0 + r) * 4u : OOB, 0, 0);
+                }
+            }
+        }
+    }
+    DSTAMP(3);
+    SMX_LDS_BARRIER();
+    DSTAMP(4);
+}
+
+// Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer, 128 slots per workgroup:
+// 0 .. 15 the launch's phases, 16 + 5 k .. the k-th dense layer's entry / K loop / epilogue / barrier) exist only in a build with -DSMX_DDPG_TIMING (scripts/bench_ddpg_rows.py); the product build has none.
+#ifdef SMX_DDPG_TIMING
+#define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 128 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DTS(k) (G.tbuf ? G.tbuf + (size_t)blockIdx.x * 128 + 16 + 5 * (k) : nullptr)
+#else
+#define DTS(k) nullptr
+#define TSTAMP(i) do { } while (0)
+#endif
+
+template <int RB>
+__device__ __forceinline__ void dense_rb(const Dense& L, long row0, int nrows, int rows_total, long long* ts) {
+    (void)ts;
+    static_assert(RB == 16, "4-row blocks run the layer program of ddpg_rows4_kernel");
+    dense16v(L.in_off, L.ldi, L.W.P, L.W.M, L.W.K, L.bias, L.act, L.mask_off, L.ldm, L.out_off, L.ldo, L.g, L.ldg, (int)row0,
+             nrows, rows_total DTS_ARG(ts));
+}
+
+struct RNet {                     // a network's biases (row-major parameter buffer) and packed weights
+    const float *b1, *b2, *b3;
+    PMat W1, W2, W3;
+};
+
+struct RArgs {
+    int rows, D, A, H1, H2, c1, c2;
+    RNet a, c, ta, tc;
+    PMat cW2Tlo, cW2Thi, aW3T, aW2T;      // the transposed blocks of the backward products
+    const float* cW3;                     // the critic's output layer, row-major [c2]
+    const float *x, *xn, *actions, *rewards, *dones;
+    float gamma_n;
+    float *xcat, *h2c, *q, *q_next, *y, *dz3, *dz2, *dxcat;         // critic phase (xcat / dxcat: row stride c1 + A)
+    float *h1a, *h2a, *act;                                          // the actor's forward pass
+    float *q_actor, *dz3a, *dz2a, *dz1a;                             // actor phase
+    int* step;
+    // LDS carve-up (float offsets)
+    int ldx, ldA, ldB, ldC, oX, oXn, oA, oB, oC, oO, oO2, oO3, oZ, oS, oR, total;
+    long long* tbuf;              // SMX_DDPG_TIMING builds
+};
+
+__device__ __forceinline__ void zero_lds(int total) {
+    extern __shared__ float sm[];
+    for (int i = threadIdx.x; i < (total >> 2); i += DNTH) *(float4*)(sm + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// rows row0 .. row0 + RB - 1 of a row-major [rows][D] matrix -> an LDS tile (zero past the batch)
+template <int RB>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld_src, int cols, long row0, int nrows,
+                                           int off, int ld) {
+    extern __shared__ float sm[];
+    for (int idx = threadIdx.x; idx < RB * cols; idx += DNTH) {
+        const int n = idx / cols, j = idx - n * cols;
+        sm[off + n * ld + j] = (n < nrows) ? src[(size_t)(row0 + n) * ld_src + j] : 0.f;
+    }
+}
+
+__device__ __forceinline__ Dense mk(int in_off, int ldi, const PMat& W, const float* bias, int act, int out_off, int ldo,
+                                    float* g, int ldg) {
+    Dense L;
+    L.in_off = in_off; L.ldi = ldi; L.W = W; L.bias = bias; L.act = act; L.mask_off = 0; L.ldm = 0;
+    L.out_off = out_off; L.ldo = ldo; L.g = g; L.ldg = ldg;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// critic phase (ddpg.py:264-308 and the forward half of 326-329)
+// ---------------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    const long row0 = (long)blockIdx.x * RB;
+    int nrows = G.rows - (int)row0;
+    nrows = nrows > RB ? RB : nrows;
+    constexpr int LDKR = RB == 4 ? LDK4 : LDK;
+    const int A = G.A, c1 = G.c1, c2 = G.c2, ldc = c1 + A, R = G.rows;
+    TSTAMP(0);
+    zero_lds(G.total);
+    __syncthreads();
+    stage_rows<RB>(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
+    stage_rows<RB>(G.xn, G.D, G.D, row0, nrows, G.oXn, G.ldx);
+    // the loss inputs of the rows, requested here
+    float rew = 0.f, dn = 0.f;
+    if (tid < nrows) { rew = G.rewards[row0 + tid]; dn = G.dones[row0 + tid]; }
+    SMX_LDS_BARRIER();
+
+    // ---- mu'(s') ----
+    Dense L = mk(G.oXn, G.ldx, G.ta.W1, G.ta.b1, A_RELU, G.oA, G.ldA, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(0));
+    TSTAMP(1);
+    L = mk(G.oA, G.ldA, G.ta.W2, G.ta.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(1));
+    TSTAMP(2);
+    L = mk(G.oB, G.ldB, G.ta.W3, G.ta.b3, A_TANH, G.oO, LDO, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(2));
+    TSTAMP(3);
+    // ---- Q'(s', mu'(s')): layer 1 into the first c1 columns of the concat tile, the action behind them ----
+    L = mk(G.oXn, G.ldx, G.tc.W1, G.tc.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(3));
+    TSTAMP(4);
+    if (tid < RB * A) {
+        const int n = tid / A, j = tid - n * A;
+        sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
+    }
+    SMX_LDS_BARRIER();
+    L = mk(G.oC, G.ldC, G.tc.W2, G.tc.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(4));
+    TSTAMP(5);
+    L = mk(G.oB, G.ldB, G.tc.W3, G.tc.b3, A_NONE, G.oO2, LDO, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(5));
+    TSTAMP(6);
+    // ---- Q(s, a) ----
+    L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, G.xcat, ldc);
+    dense_rb<RB>(L, row0, nrows, R, DTS(6));
+    TSTAMP(7);
+    if (tid < RB * A) {
+        const int n = tid / A, j = tid - n * A;
+        const float v = (n < nrows) ? G.actions[(size_t)(row0 + n) * A + j] : 0.f;
+        sm[G.oC + n * G.ldC + c1 + j] = v;
+        if (n < nrows) G.xcat[(size_t)(row0 + n) * ldc + c1 + j] = v;
+    }
+    SMX_LDS_BARRIER();
+    L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, G.h2c, c2);
+    dense_rb<RB>(L, row0, nrows, R, DTS(7));
+    TSTAMP(8);
+    L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, G.oO, LDO, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(8));
+    TSTAMP(9);
+    // ---- y = r + gamma^n Q' (1 - done) (ddpg.py:279); dLoss/dQ of the mean squared error (ddpg.py:307-308) ----
+    if (tid < RB) {
+        const float qn = sm[G.oO2 + tid * LDO], q = sm[G.oO + tid * LDO];
+        const float t = (G.gamma_n * qn) * (1.0f - dn);
+        const float yy = rew + t;
+        const float d3 = (2.0f * (q - yy)) / (float)G.rows;
+        sm[G.oS + tid] = (tid < nrows) ? d3 : 0.f;
+        if (tid < nrows) {
+            G.q[row0 + tid] = q;
+            G.q_next[row0 + tid] = qn;
+            G.y[row0 + tid] = yy;
+            G.dz3[row0 + tid] = d3;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && G.step) *G.step += 1;      // this iteration's Adam step (both groups)
+    SMX_LDS_BARRIER();
+    // ---- dz2 = (dz3 W3) relu'(h2), a K = 1 product: elementwise ----
+    for (int idx = tid; idx < RB * c2; idx += DNTH) {
+        const int n = idx / c2, j = idx - n * c2;
+        float v = sm[G.oS + n] * G.cW3[j];
+        v = (sm[G.oB + n * G.ldB + j] > 0.f) ? v : 0.f;
+        sm[G.oA + n * G.ldA + j] = v;
+        if (n < nrows) G.dz2[(size_t)(row0 + n) * c2 + j] = v;
+    }
+    SMX_LDS_BARRIER();
+    // ---- dz1 = (W2[:, :c1]^T dz2) relu'(h1) ----
+    L = mk(G.oA, G.ldA, G.cW2Tlo, nullptr, A_MASK, -1, 0, G.dxcat, ldc);
+    L.mask_off = G.oC; L.ldm = G.ldC;
+    dense_rb<RB>(L, row0, nrows, R, DTS(9));
+    TSTAMP(10);
+    // ---- mu(s), kept for the actor phase ----
+    L = mk(G.oX, G.ldx, G.a.W1, G.a.b1, A_RELU, G.oA, G.ldA, G.h1a, G.H1);
+    dense_rb<RB>(L, row0, nrows, R, DTS(10));
+    TSTAMP(11);
+    L = mk(G.oA, G.ldA, G.a.W2, G.a.b2, A_RELU, G.oB, G.ldB, G.h2a, G.H2);
+    dense_rb<RB>(L, row0, nrows, R, DTS(11));
+    TSTAMP(12);
+    L = mk(G.oB, G.ldB, G.a.W3, G.a.b3, A_TANH, -1, 0, G.act, A);
+    dense_rb<RB>(L, row0, nrows, R, DTS(12));
+    TSTAMP(13);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// actor phase (ddpg.py:326-331): loss = -mean Q(s, mu(s)) through the updated critic
+// ---------------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    const long row0 = (long)blockIdx.x * RB;
+    int nrows = G.rows - (int)row0;
+    nrows = nrows > RB ? RB : nrows;
+    constexpr int LDKR = RB == 4 ? LDK4 : LDK;
+    const int A = G.A, c1 = G.c1, c2 = G.c2, R = G.rows;
+    TSTAMP(0);
+    zero_lds(G.total);
+    __syncthreads();
+    stage_rows<RB>(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
+    stage_rows<RB>(G.act, A, A, row0, nrows, G.oO, LDO);
+    SMX_LDS_BARRIER();
+    Dense L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(0));
+    TSTAMP(1);
+    if (tid < RB * A) {
+        const int n = tid / A, j = tid - n * A;
+        sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
+    }
+    SMX_LDS_BARRIER();
+    L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(1));
+    TSTAMP(2);
+    L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, -1, 0, G.q_actor, 1);
+    dense_rb<RB>(L, row0, nrows, R, DTS(2));
+    TSTAMP(3);
+    // the masks of the actor's backward pass (its own forward pass ran in the critic phase): h1a -> the concat tile, whose
+    // layer-2 product is done; h2a follows once dz2 has read the critic's ReLU mask
+    stage_rows<RB>(G.h1a, G.H1, G.H1, row0, nrows, G.oC, G.ldC);
+    // ---- d(-mean Q)/d(h2) = (-1/rows) W3 relu'(h2) ----
+    const float dq = -1.0f / (float)G.rows;
+    for (int idx = tid; idx < RB * c2; idx += DNTH) {
+        const int n = idx / c2, j = idx - n * c2;
+        float v = dq * G.cW3[j];
+        v = (n < nrows && sm[G.oB + n * G.ldB + j] > 0.f) ? v : 0.f;
+        sm[G.oA + n * G.ldA + j] = v;
+    }
+    SMX_LDS_BARRIER();
+    stage_rows<RB>(G.h2a, G.H2, G.H2, row0, nrows, G.oB, G.ldB);
+    // ---- d/d(action) = W2[:, c1:]^T dz2, through tanh ----
+    L = mk(G.oA, G.ldA, G.cW2Thi, nullptr, A_NONE, G.oO2, LDO, nullptr, 0);
+    dense_rb<RB>(L, row0, nrows, R, DTS(3));
+    TSTAMP(4);
+    if (tid < RB * A) {
+        const int n = tid / A, j = tid - n * A;
+        const float a = sm[G.oO + n * LDO + j];
+        const float v = sm[G.oO2 + n * LDO + j] * (1.0f - a * a);
+        sm[G.oZ + n * LDKR + j] = v;
+        if (n < nrows) G.dz3a[(size_t)(row0 + n) * A + j] = v;
+    }
+    SMX_LDS_BARRIER();
+    // ---- the actor's data gradients ----
+    L = mk(G.oZ, LDKR, G.aW3T, nullptr, A_MASK, G.oA, G.ldA, G.dz2a, G.H2);
+    L.mask_off = G.oB; L.ldm = G.ldB;
+    dense_rb<RB>(L, row0, nrows, R, DTS(4));
+    TSTAMP(5);
+    L = mk(G.oA, G.ldA, G.aW2T, nullptr, A_MASK, -1, 0, G.dz1a, G.H1);
+    L.mask_off = G.oC; L.ldm = G.ldC;
+    dense_rb<RB>(L, row0, nrows, R, DTS(5));
+    TSTAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 4-row blocks: the same two chains as a LAYER PROGRAM.  The 16-row kernels above call one noinline dense function a dozen
+// times; on 4-row blocks, where a layer's K loop is 2 - 9 k cycles, the calls were the larger half of the launch (phase
+// stamps: 3.3 k cycles per layer between return and the next entry -- callee-saved registers through scratch -- and 1.1 k
+// from entry to the first product).  Here the host writes the chain as a table of steps in the kernel arguments and the
+// kernel is ONE loop over it: the layer body exists once, inline, its operands arrive by scalar loads.  What sits between
+// two layers of a chain (the concat of the action, the Bellman target and dLoss/dQ, tanh') is the `post` of the step
+// before it.
+//
+//  * lane (fm, kq) keeps row kq of feature 16 t + fm: the kq groups meet by meet_rows (3 swaps, 3 adds)
+//  * layers of at most two feature tiles (the heads: 6 actions, 1 value; the action gradient) split K over the eight
+//    wavefronts instead of leaving 64 - 80 dependent products to one: a wave takes ceil(C2 / 8) chunks, the eight partial
+//    sums meet through LDS in wave order (k ascending inside a wave's chunks: a fixed order, not the full-K order)
+// ---------------------------------------------------------------------------------------------------------------
+enum { P_NONE = 0, P_TC_CAT, P_C_CAT, P_LOSS, P_A_CAT, P_A_DQ, P_A_TANH };
+constexpr int MAX_STEPS = 13;
+
+struct Step {
+    const float* W;               // packed weights
+    const float* bias;            // [M] or null
+    float* g;                     // HBM output [rows][ldg] or null
+    int M, K, in_off, ldi, act, mask_off, ldm, out_off, ldo, ldg, post;
+};
+struct Prog {
+    int n;
+    Step s[MAX_STEPS];
+};
+
+#ifdef SMX_DDPG_TIMING
+#define PSTAMP(k, i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 128 + 16 + 5 * (k) + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PSTAMP(k, i) do { } while (0)
+#endif
+
+template <int PHASE>
+__global__ __launch_bounds__(DNTH) void ddpg_rows4_kernel(RArgs G, Prog P) {
+    extern __shared__ float sm[];
+    constexpr int RB = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fm = lane & 15, kq = lane >> 4;
+    const long row0 = (long)blockIdx.x * RB;
+    int nrows = G.rows - (int)row0;
+    nrows = nrows > RB ? RB : nrows;
+    const int A = G.A, c1 = G.c1, c2 = G.c2, ldc = c1 + A;
+    TSTAMP(0);
+    zero_lds(G.total);
+    __syncthreads();
+    stage_rows<RB>(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
+    float rew = 0.f, dn = 0.f;
+    if (PHASE == 0) {
+        stage_rows<RB>(G.xn, G.D, G.D, row0, nrows, G.oXn, G.ldx);
+        if (tid < nrows) { rew = G.rewards[row0 + tid]; dn = G.dones[row0 + tid]; }
+    } else {
+        stage_rows<RB>(G.act, A, A, row0, nrows, G.oO, LDO);
+    }
+    SMX_LDS_BARRIER();
+
+#pragma unroll 1
+    for (int si = 0; si < P.n; ++si) {
+        const Step& S = P.s[si];
+        const int M = S.M, K = S.K, act = S.act, ldi = S.ldi, ldm = S.ldm, ldo = S.ldo, ldg = S.ldg;
+        const int mask_off = S.mask_off, out_off = S.out_off;
+        const int tiles = (M + 15) >> 4, C2 = pack_chunks(K);
+        const rsrc_t rw = make_rsrc(S.W, (unsigned)tiles * (unsigned)C2 * 2048u);
+        const rsrc_t rb = make_rsrc(S.bias ? S.bias : S.W, S.bias ? (unsigned)M * 4u : 0u);
+        const rsrc_t rg = make_rsrc(S.g ? S.g : S.W, S.g ? (unsigned)G.rows * (unsigned)ldg * 4u : 0u);
+        const float* in = sm + S.in_off;
+        PSTAMP(si, 0);
+        // row `r` of feature f is finished: bias, activation, the tile for the next layer, the row-major copy
+        auto finish = [&](float z, float bias_v, int f, int r) {
+            z += bias_v;
+            if (act == A_RELU) z = (z < 0.f) ? 0.f : z;
+            else if (act == A_TANH) z = tanhf(z);
+            else if (act == A_MASK) z = (sm[mask_off + r * ldm + f] > 0.f) ? z : 0.f;
+            const float v = (f < M) ? z : 0.f;
+            if (out_off >= 0) sm[out_off + r * ldo + f] = v;
+            const bool ok = r < nrows && f < M;                      // (no HBM output: every offset is out of range)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rg,
+                                                  ok ? ((unsigned)(row0 + r) * (unsigned)ldg + (unsigned)f) * 4u : OOB, 0, 0);
+        };
+        if (tiles <= 2) {
+            // ---- split K: wave w takes chunks [w per, w per + per) of both tiles ----
+            const int per = (C2 + DNWV - 1) / DNWV;
+            const int ca = wv * per;
+            int cb = ca + per;
+            cb = cb > C2 ? C2 : cb;
+            const int ft = 16 * (tid >> 6) + fm;                     // the (tile, row, feature) thread tid finishes
+            const float bfin = ld4(rb, (tid < 64 * tiles && ft < M) ? (unsigned)ft * 4u : OOB);
+            f32x4 a2[2][1];
+            a2[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            a2[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* bp = in + (lane & 3) * ldi + 8 * kq;
+            unsigned wo[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) wo[g] = (g < tiles) ? ((unsigned)g * (unsigned)C2 * 512u + (unsigned)lane * 4u) * 4u : OOB;
+#pragma unroll 1
+            for (int c = ca; c < cb; c += 2) {
+                const unsigned none[2] = {OOB, OOB};
+                WFrag4<2, 1> F0, F1;
+                ld_wfrag4<2, 1>(F0, rw, wo, bp, ldi, c);
+                if (c + 1 < cb) ld_wfrag4<2, 1>(F1, rw, wo, bp, ldi, c + 1);
+                else ld_wfrag4<2, 1>(F1, rw, none, bp, ldi, 0);
+                mma4_chunk<2, 1>(a2, F0);
+                mma4_chunk<2, 1>(a2, F1);
+            }
+            PSTAMP(si, 1);
+            float* red = sm + G.oR;                                  // [wave][tile][row][16]
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (g < tiles) red[((wv * 2 + g) * 4 + kq) * 16 + fm] = meet_rows(a2[g][0]);
+            SMX_LDS_BARRIER();
+            PSTAMP(si, 2);
+            if (tid < 64 * tiles) {
+                const int g = tid >> 6;
+                float z = red[(g * 4 + kq) * 16 + fm];
+#pragma unroll
+                for (int w = 1; w < DNWV; ++w) z += red[((w * 2 + g) * 4 + kq) * 16 + fm];
+                finish(z, bfin, ft, kq);
+            }
+        } else {
+#pragma unroll 1
+            for (int tb = 0; tb < tiles; tb += DNWV * DTG4) {
+                const int t0 = tb + wv;
+                int nt = (tiles - t0 + DNWV - 1) / DNWV;
+                nt = nt < 0 ? 0 : (nt > DTG4 ? DTG4 : nt);
+                float bs[DTG4];
+#pragma unroll
+                for (int g = 0; g < DTG4; ++g) {
+                    const int f = 16 * (t0 + DNWV * g) + fm;
+                    bs[g] = ld4(rb, (g < nt && f < M) ? (unsigned)f * 4u : OOB);
+                }
+                f32x4 acc[DTG4];
+#pragma unroll
+                for (int g = 0; g < DTG4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define SMX_RUN4(N)                                                                  \
+    {                                                                                \
+        f32x4 a[N][1];                                                               \
+        _Pragma("unroll") for (int g = 0; g < N; ++g) a[g][0] = acc[g];              \
+        fwd_tiles4<N, 1>(a, rw, tiles, C2, in, ldi, t0, DNWV, lane);                 \
+        _Pragma("unroll") for (int g = 0; g < N; ++g) acc[g] = a[g][0];              \
+    }
+                if (nt > 3) SMX_RUN4(4)
+                else if (nt > 2) SMX_RUN4(3)
+                else if (nt > 1) SMX_RUN4(2)
+                else if (nt > 0) SMX_RUN4(1)
+#undef SMX_RUN4
+                if (tb == 0) PSTAMP(si, 1);
+                float z[DTG4];
+#pragma unroll
+                for (int g = 0; g < DTG4; ++g) z[g] = meet_rows(acc[g]);
+#pragma unroll
+                for (int g = 0; g < DTG4; ++g)
+                    if (g < nt) finish(z[g], bs[g], 16 * (t0 + DNWV * g) + fm, kq);      // (wave-uniform)
+            }
+            PSTAMP(si, 2);
+        }
+        PSTAMP(si, 3);
+        SMX_LDS_BARRIER();
+        PSTAMP(si, 4);
+
+        // ---- what follows the layer in its chain ----
+        const int post = S.post;
+        if (PHASE == 0) {
+            if (post == P_TC_CAT) {            // [h1' | mu'(s')]: the action behind the first c1 columns of the concat tile
+                if (tid < RB * A) {
+                    const int n = tid / A, j = tid - n * A;
+                    sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
+                }
+                SMX_LDS_BARRIER();
+            } else if (post == P_C_CAT) {      // [h1 | a] and its row-major copy
+                if (tid < RB * A) {
+                    const int n = tid / A, j = tid - n * A;
+                    const float v = (n < nrows) ? G.actions[(size_t)(row0 + n) * A + j] : 0.f;
+                    sm[G.oC + n * G.ldC + c1 + j] = v;
+                    if (n < nrows) G.xcat[(size_t)(row0 + n) * ldc + c1 + j] = v;
+                }
+                SMX_LDS_BARRIER();
+            } else if (post == P_LOSS) {
+                // y = r + gamma^n Q' (1 - done) (ddpg.py:279); dLoss/dQ of the mean squared error (ddpg.py:307-308)
+                if (tid < RB) {
+                    const float qn = sm[G.oO2 + tid * LDO], q = sm[G.oO + tid * LDO];
+                    const float t = (G.gamma_n * qn) * (1.0f - dn);
+                    const float yy = rew + t;
+                    const float d3 = (2.0f * (q - yy)) / (float)G.rows;
+                    sm[G.oS + tid] = (tid < nrows) ? d3 : 0.f;
+                    if (tid < nrows) {
+                        G.q[row0 + tid] = q;
+                        G.q_next[row0 + tid] = qn;
+                        G.y[row0 + tid] = yy;
+                        G.dz3[row0 + tid] = d3;
+                    }
+                }
+                if (blockIdx.x == 0 && tid == 0 && G.step) *G.step += 1;      // this iteration's Adam step (both groups)
+                SMX_LDS_BARRIER();
+                // dz2 = (dz3 W3) relu'(h2), a K = 1 product: elementwise
+                for (int idx = tid; idx < RB * c2; idx += DNTH) {
+                    const int n = idx / c2, j = idx - n * c2;
+                    float v = sm[G.oS + n] * G.cW3[j];
+                    v = (sm[G.oB + n * G.ldB + j] > 0.f) ? v : 0.f;
+                    sm[G.oA + n * G.ldA + j] = v;
+                    if (n < nrows) G.dz2[(size_t)(row0 + n) * c2 + j] = v;
+                }
+                SMX_LDS_BARRIER();
+            }
+        } else {
+            if (post == P_A_CAT) {
+                if (tid < RB * A) {
+                    const int n = tid / A, j = tid - n * A;
+                    sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
+                }
+                SMX_LDS_BARRIER();
+            } else if (post == P_A_DQ) {
+                // the masks of the actor's backward pass (its forward pass ran in the critic phase): h1a -> the concat
+                // tile, whose layer-2 product is done; h2a follows once dz2 has read the critic's ReLU mask
+                stage_rows<RB>(G.h1a, G.H1, G.H1, row0, nrows, G.oC, G.ldC);
+                const float dq = -1.0f / (float)G.rows;            // d(-mean Q)/d(h2) = (-1/rows) W3 relu'(h2)
+                for (int idx = tid; idx < RB * c2; idx += DNTH) {
+                    const int n = idx / c2, j = idx - n * c2;
+                    float v = dq * G.cW3[j];
+                    v = (n < nrows && sm[G.oB + n * G.ldB + j] > 0.f) ? v : 0.f;
+                    sm[G.oA + n * G.ldA + j] = v;
+                }
+                SMX_LDS_BARRIER();
+                stage_rows<RB>(G.h2a, G.H2, G.H2, row0, nrows, G.oB, G.ldB);
+            } else if (post == P_A_TANH) {     // through tanh: the action gradient times 1 - a^2
+                if (tid < RB * A) {
+                    const int n = tid / A, j = tid - n * A;
+                    const float a = sm[G.oO + n * LDO + j];
+                    const float v = sm[G.oO2 + n * LDO + j] * (1.0f - a * a);
+                    sm[G.oZ + n * LDK4 + j] = v;
+                    if (n < nrows) G.dz3a[(size_t)(row0 + n) * A + j] = v;
+                }
+                SMX_LDS_BARRIER();
+            }
+        }
+        TSTAMP(si + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the packed copies: one thread per 16-byte word of [tile][chunk][half][lane][4]
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int N_MAT = 16;
+struct PItem {
+    const float* src;
+    int ld, M, K, tr;             // X[m][k] = tr ? src[k ld + m] : src[m ld + k]
+    long base;                    // first 16-byte word of the block in the packed buffer
+};
+struct PArgs {
+    PItem it[N_MAT];
+    float* packed;
+    int count;
+    long total;                   // words covered by the launch (items are contiguous from it[0].base)
+};
+
+__global__ __launch_bounds__(256) void ddpg_pack_kernel(PArgs P) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.total) return;
+    const long w0 = i + P.it[0].base;
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < N_MAT; ++k) pi += (k < P.count && w0 >= P.it[k].base) ? 1 : 0;
+    const PItem N = P.it[pi];
+    const long w = w0 - N.base;
+    const int C2 = pack_chunks(N.K);
+    const int lane = (int)(w & 63), half = (int)((w >> 6) & 1);
+    const long tc = w >> 7;
+    const int c = (int)(tc % C2), t = (int)(tc / C2);
+    const int m = 16 * t + (lane & 15), k = 32 * c + 8 * (lane >> 4) + 4 * half;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < N.M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (k + r < N.K) v[r] = N.tr ? N.src[(size_t)(k + r) * N.ld + m] : N.src[(size_t)m * N.ld + k + r];
+    }
+    *(float4*)(P.packed + 4 * w0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// block order of the packed buffer
+enum { B_AW1, B_AW2, B_AW3, B_AW3T, B_AW2T, B_CW1, B_CW2, B_CW3, B_CW2TLO, B_CW2THI, B_TAW1, B_TAW2, B_TAW3, B_TCW1,
+       B_TCW2, B_TCW3, B_COUNT };
+static_assert(B_COUNT == N_MAT, "one item per block");
+
+struct Dims { int D, A, H1, H2, c1, c2; };
+
+void block_shape(const Dims& d, int b, int& M, int& K) {
+    switch (b) {
+        case B_AW1: case B_TAW1: M = d.H1; K = d.D; break;
+        case B_AW2: case B_TAW2: M = d.H2; K = d.H1; break;
+        case B_AW3: case B_TAW3: M = d.A; K = d.H2; break;
+        case B_AW3T: M = d.H2; K = d.A; break;
+        case B_AW2T: M = d.H1; K = d.H2; break;
+        case B_CW1: case B_TCW1: M = d.c1; K = d.D; break;
+        case B_CW2: case B_TCW2: M = d.c2; K = d.c1 + d.A; break;
+        case B_CW3: case B_TCW3: M = 1; K = d.c2; break;
+        case B_CW2TLO: M = d.c1; K = d.c2; break;
+        default: M = d.A; K = d.c2; break;       // B_CW2THI
+    }
+}
+long block_base(const Dims& d, int b) {          // in 16-byte words
+    long o = 0;
+    for (int k = 0; k < b; ++k) {
+        int M, K;
+        block_shape(d, k, M, K);
+        o += pack_words(M, K);
+    }
+    return o;
+}
+
+long long* g_tbuf = nullptr;
+
+int rows_per_block(long rows) { return rows <= 1024 ? 4 : 16; }
+
+int lds_floats(const Dims& d, RArgs* G, int RB) {
+    const int pad = RB == 4 ? 16 : 4;
+    const int ldx = r64(d.D) + pad;
+    const int wa = d.H1 > d.c2 ? d.H1 : d.c2, wb = d.H2 > d.c2 ? d.H2 : d.c2;
+    const int wc = d.c1 + d.A > d.H1 ? d.c1 + d.A : d.H1;
+    const int ldA = r64(wa) + pad, ldB = r64(wb) + pad, ldC = r64(wc) + pad;
+    int o = 0;
+    const int oX = o; o += RB * ldx;
+    const int oXn = o; o += RB * ldx;
+    const int oA = o; o += RB * ldA;
+    const int oB = o; o += RB * ldB;
+    const int oC = o; o += RB * ldC;
+    const int oO = o; o += RB * LDO;
+    const int oO2 = o; o += RB * LDO;
+    const int oO3 = o; o += RB * LDO;
+    const int oZ = o; o += RB * (RB == 4 ? LDK4 : LDK);
+    const int oS = o; o += 16;
+    const int oR = o; o += (RB == 4) ? DNWV * 2 * 4 * 16 : 0;      // the split-K layers' partial sums
+    o += 128;                     // the K loop's prefetch reads up to two chunks past a tile's last row
+    if (G) {
+        G->ldx = ldx; G->ldA = ldA; G->ldB = ldB; G->ldC = ldC;
+        G->oX = oX; G->oXn = oXn; G->oA = oA; G->oB = oB; G->oC = oC; G->oO = oO; G->oO2 = oO2; G->oO3 = oO3;
+        G->oZ = oZ; G->oS = oS; G->oR = oR; G->total = o;
+    }
+    return o;
+}
+
+bool dims_ok(const Dims& d) {
+    return d.D > 0 && d.A > 0 && d.A <= 32 && d.H1 > 0 && d.H2 > 0 && d.c1 > 0 && d.c2 > 0 && d.D <= 2048 &&
+           d.H1 % 4 == 0 && d.H2 % 4 == 0 && d.c1 % 4 == 0 && d.c2 % 4 == 0 && d.H1 <= 1024 && d.H2 <= 1024 &&
+           d.c1 <= 1024 && d.c2 <= 1024 && lds_floats(d, nullptr, 16) * (int)sizeof(float) <= MAX_LDS;
+}
+
+Dims dims_of(const smx_ddpg_rows_t& a) {
+    Dims d;
+    d.D = a.D; d.A = a.A; d.H1 = a.H1; d.H2 = a.H2; d.c1 = a.c1; d.c2 = a.c2;
+    return d;
+}
+
+PMat pmat(const smx_ddpg_rows_t& a, const Dims& d, int b) {
+    PMat m;
+    block_shape(d, b, m.M, m.K);
+    m.P = a.packed + 4 * block_base(d, b);
+    return m;
+}
+
+int fill(RArgs& G, const smx_ddpg_rows_t* a) {
+    SMX_REQUIRE(a && a->packed, SMX_E_NULL);
+    const Dims d = dims_of(*a);
+    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(a->rows > 0 && a->rows < (1 << 24), SMX_E_SHAPE);
+    {   // every row-major output is addressed through a buffer descriptor: 31-bit byte offsets
+        int widest = d.c1 + d.A;
+        widest = d.H1 > widest ? d.H1 : widest;
+        widest = d.c2 > widest ? d.c2 : widest;
+        widest = d.H2 > widest ? d.H2 : widest;
+        SMX_REQUIRE((int64_t)a->rows * widest * 4 < (1ll << 31), SMX_E_SHAPE);
+    }
+    SMX_REQUIRE(((uintptr_t)a->packed & 15) == 0, SMX_E_ALIGN);
+    const smx_ddpg_net_t* nets[4] = {&a->actor, &a->critic, &a->target_actor, &a->target_critic};
+    for (int k = 0; k < 4; ++k)
+        SMX_REQUIRE(nets[k]->W1 && nets[k]->b1 && nets[k]->W2 && nets[k]->b2 && nets[k]->W3 && nets[k]->b3, SMX_E_NULL);
+    memset(&G, 0, sizeof(G));
+    G.rows = (int)a->rows; G.D = d.D; G.A = d.A; G.H1 = d.H1; G.H2 = d.H2; G.c1 = d.c1; G.c2 = d.c2;
+    RNet* rn[4] = {&G.a, &G.c, &G.ta, &G.tc};
+    const int w1[4] = {B_AW1, B_CW1, B_TAW1, B_TCW1};
+    for (int k = 0; k < 4; ++k) {
+        rn[k]->b1 = nets[k]->b1; rn[k]->b2 = nets[k]->b2; rn[k]->b3 = nets[k]->b3;
+        rn[k]->W1 = pmat(*a, d, w1[k]);
+        rn[k]->W2 = pmat(*a, d, w1[k] == B_AW1 ? B_AW2 : (w1[k] == B_CW1 ? B_CW2 : w1[k] + 1));
+        rn[k]->W3 = pmat(*a, d, w1[k] == B_AW1 ? B_AW3 : (w1[k] == B_CW1 ? B_CW3 : w1[k] + 2));
+    }
+    G.cW2Tlo = pmat(*a, d, B_CW2TLO); G.cW2Thi = pmat(*a, d, B_CW2THI);
+    G.aW3T = pmat(*a, d, B_AW3T); G.aW2T = pmat(*a, d, B_AW2T);
+    G.cW3 = a->critic.W3;
+    G.x = a->x; G.xn = a->x_next; G.actions = a->actions; G.rewards = a->rewards; G.dones = a->dones;
+    G.gamma_n = a->gamma_n;
+    G.xcat = a->xcat; G.h2c = a->h2c; G.q = a->q; G.q_next = a->q_next; G.y = a->y; G.dz3 = a->dz3; G.dz2 = a->dz2;
+    G.dxcat = a->dxcat; G.h1a = a->h1a; G.h2a = a->h2a; G.act = a->act;
+    G.q_actor = a->q_actor; G.dz3a = a->dz3a; G.dz2a = a->dz2a; G.dz1a = a->dz1a;
+    G.step = a->step;
+    lds_floats(d, &G, rows_per_block(a->rows));
+    G.tbuf = g_tbuf;
+    return SMX_OK;
+}
+
+Step step(int in_off, int ldi, const PMat& W, const float* bias, int act, int out_off, int ldo, float* g, int ldg, int post) {
+    Step S;
+    memset(&S, 0, sizeof(S));
+    S.W = W.P; S.bias = bias; S.g = g; S.M = W.M; S.K = W.K; S.in_off = in_off; S.ldi = ldi; S.act = act;
+    S.out_off = out_off; S.ldo = ldo; S.ldg = ldg; S.post = post;
+    return S;
+}
+
+// the chains of the two 16-row kernels above, step for step
+void critic_program(const RArgs& G, Prog& P) {
+    const int ldc = G.c1 + G.A;
+    int n = 0;
+    P.s[n++] = step(G.oXn, G.ldx, G.ta.W1, G.ta.b1, A_RELU, G.oA, G.ldA, nullptr, 0, P_NONE);         // mu'(s')
+    P.s[n++] = step(G.oA, G.ldA, G.ta.W2, G.ta.b2, A_RELU, G.oB, G.ldB, nullptr, 0, P_NONE);
+    P.s[n++] = step(G.oB, G.ldB, G.ta.W3, G.ta.b3, A_TANH, G.oO, LDO, nullptr, 0, P_NONE);
+    P.s[n++] = step(G.oXn, G.ldx, G.tc.W1, G.tc.b1, A_RELU, G.oC, G.ldC, nullptr, 0, P_TC_CAT);       // Q'(s', mu'(s'))
+    P.s[n++] = step(G.oC, G.ldC, G.tc.W2, G.tc.b2, A_RELU, G.oB, G.ldB, nullptr, 0, P_NONE);
+    P.s[n++] = step(G.oB, G.ldB, G.tc.W3, G.tc.b3, A_NONE, G.oO2, LDO, nullptr, 0, P_NONE);
+    P.s[n++] = step(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, G.xcat, ldc, P_C_CAT);          // Q(s, a)
+    P.s[n++] = step(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, G.h2c, G.c2, P_NONE);
+    P.s[n++] = step(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, G.oO, LDO, nullptr, 0, P_LOSS);              // -> y, dz3, dz2
+    P.s[n] = step(G.oA, G.ldA, G.cW2Tlo, nullptr, A_MASK, -1, 0, G.dxcat, ldc, P_NONE);               // dz1
+    P.s[n].mask_off = G.oC; P.s[n].ldm = G.ldC; ++n;
+    P.s[n++] = step(G.oX, G.ldx, G.a.W1, G.a.b1, A_RELU, G.oA, G.ldA, G.h1a, G.H1, P_NONE);           // mu(s), kept
+    P.s[n++] = step(G.oA, G.ldA, G.a.W2, G.a.b2, A_RELU, G.oB, G.ldB, G.h2a, G.H2, P_NONE);
+    P.s[n++] = step(G.oB, G.ldB, G.a.W3, G.a.b3, A_TANH, -1, 0, G.act, G.A, P_NONE);
+    P.n = n;
+}
+
+void actor_program(const RArgs& G, Prog& P) {
+    int n = 0;
+    P.s[n++] = step(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, nullptr, 0, P_A_CAT);           // Q(s, mu(s))
+    P.s[n++] = step(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, nullptr, 0, P_NONE);
+    P.s[n++] = step(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, -1, 0, G.q_actor, 1, P_A_DQ);                // -> masks, dz2
+    P.s[n++] = step(G.oA, G.ldA, G.cW2Thi, nullptr, A_NONE, G.oO2, LDO, nullptr, 0, P_A_TANH);        // d/d(action)
+    P.s[n] = step(G.oZ, LDK4, G.aW3T, nullptr, A_MASK, G.oA, G.ldA, G.dz2a, G.H2, P_NONE);            // the actor's dz2, dz1
+    P.s[n].mask_off = G.oB; P.s[n].ldm = G.ldB; ++n;
+    P.s[n] = step(G.oA, G.ldA, G.aW2T, nullptr, A_MASK, -1, 0, G.dz1a, G.H1, P_NONE);
+    P.s[n].mask_off = G.oC; P.s[n].ldm = G.ldC; ++n;
+    P.n = n;
+}
+static_assert(MAX_STEPS >= 13, "the critic chain has 13 layers");
+
+int set_lds(const void* fn, int bytes) {
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+extern "C" void smx_ddpg_rows_debug_tbuf(void* p) { g_tbuf = (long long*)p; }
+
+extern "C" int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2) {
+    Dims d;
+    d.D = D; d.A = A; d.H1 = H1; d.H2 = H2; d.c1 = c1; d.c2 = c2;
+    return dims_ok(d) ? 1 : 0;
+}
+
+extern "C" int64_t smx_ddpg_rows_packed_floats(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2) {
+    Dims d;
+    d.D = D; d.A = A; d.H1 = H1; d.H2 = H2; d.c1 = c1; d.c2 = c2;
+    return dims_ok(d) ? 4 * block_base(d, B_COUNT) : 0;
+}
+
+extern "C" int smx_ddpg_rows_pack_f32(const smx_ddpg_rows_t* a, int32_t which, smx_stream_t stream) {
+    SMX_REQUIRE(a && a->packed, SMX_E_NULL);
+    const Dims d = dims_of(*a);
+    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(which == SMX_DDPG_PACK_ALL || which == SMX_DDPG_PACK_CRITIC, SMX_E_SHAPE);
+    const int ldc = d.c1 + d.A;
+    const float* src[B_COUNT] = {a->actor.W1, a->actor.W2, a->actor.W3, a->actor.W3, a->actor.W2,
+                                 a->critic.W1, a->critic.W2, a->critic.W3, a->critic.W2, a->critic.W2 + d.c1,
+                                 a->target_actor.W1, a->target_actor.W2, a->target_actor.W3,
+                                 a->target_critic.W1, a->target_critic.W2, a->target_critic.W3};
+    const int ld[B_COUNT] = {d.D, d.H1, d.H2, d.H2, d.H1, d.D, ldc, d.c2, ldc, ldc, d.D, d.H1, d.H2, d.D, ldc, d.c2};
+    const int tr[B_COUNT] = {0, 0, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0};
+    const int b0 = which == SMX_DDPG_PACK_CRITIC ? B_CW1 : 0, b1 = which == SMX_DDPG_PACK_CRITIC ? B_CW2THI + 1 : B_COUNT;
+    PArgs P;
+    memset(&P, 0, sizeof(P));
+    P.packed = a->packed;
+    P.count = b1 - b0;
+    for (int b = b0; b < b1; ++b) {
+        SMX_REQUIRE(src[b], SMX_E_NULL);
+        PItem& it = P.it[b - b0];
+        it.src = src[b]; it.ld = ld[b]; it.tr = tr[b];
+        block_shape(d, b, it.M, it.K);
+        it.base = block_base(d, b);
+    }
+    P.total = block_base(d, b1) - block_base(d, b0);
+    hipLaunchKernelGGL(ddpg_pack_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, smx_s(stream), P);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ddpg_rows_critic_f32(const smx_ddpg_rows_t* a, smx_stream_t stream) {
+    RArgs G;
+    const int rc = fill(G, a);
+    if (rc) return rc;
+    SMX_REQUIRE(a->x && a->x_next && a->actions && a->rewards && a->dones, SMX_E_NULL);
+    SMX_REQUIRE(a->xcat && a->h2c && a->q && a->q_next && a->y && a->dz3 && a->dz2 && a->dxcat && a->h1a && a->h2a &&
+                    a->act, SMX_E_NULL);
+    const int bytes = G.total * (int)sizeof(float);
+    static int set[2] = {0, 0};
+    const int RB = rows_per_block(G.rows), v = RB == 4 ? 0 : 1;
+    const void* fn = RB == 4 ? (const void*)ddpg_rows4_kernel<0> : (const void*)ddpg_critic_rows_kernel<16>;
+    if (set[v] < bytes) {
+        const int e = set_lds(fn, bytes);
+        if (e) return e;
+        set[v] = bytes;
+    }
+    const dim3 grid((unsigned)((G.rows + RB - 1) / RB));
+    if (RB == 4) {
+        Prog P;
+        memset(&P, 0, sizeof(P));
+        critic_program(G, P);
+        hipLaunchKernelGGL(ddpg_rows4_kernel<0>, grid, dim3(DNTH), bytes, smx_s(stream), G, P);
+    } else {
+        hipLaunchKernelGGL(ddpg_critic_rows_kernel<16>, grid, dim3(DNTH), bytes, smx_s(stream), G);
+    }
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ddpg_rows_actor_f32(const smx_ddpg_rows_t* a, smx_stream_t stream) {
+    RArgs G;
+    const int rc = fill(G, a);
+    if (rc) return rc;
+    SMX_REQUIRE(a->x && a->h1a && a->h2a && a->act && a->q_actor && a->dz3a && a->dz2a && a->dz1a, SMX_E_NULL);
+    const int bytes = G.total * (int)sizeof(float);
+    static int set[2] = {0, 0};
+    const int RB = rows_per_block(G.rows), v = RB == 4 ? 0 : 1;
+    const void* fn = RB == 4 ? (const void*)ddpg_rows4_kernel<1> : (const void*)ddpg_actor_rows_kernel<16>;
+    if (set[v] < bytes) {
+        const int e = set_lds(fn, bytes);
+        if (e) return e;
+        set[v] = bytes;
+    }
+    const dim3 grid((unsigned)((G.rows + RB - 1) / RB));
+    if (RB == 4) {
+        Prog P;
+        memset(&P, 0, sizeof(P));
+        actor_program(G, P);
+        hipLaunchKernelGGL(ddpg_rows4_kernel<1>, grid, dim3(DNTH), bytes, smx_s(stream), G, P);
+    } else {
+        hipLaunchKernelGGL(ddpg_actor_rows_kernel<16>, grid, dim3(DNTH), bytes, smx_s(stream), G);
+    }
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}

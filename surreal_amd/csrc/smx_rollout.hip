@@ -211,8 +211,7 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
                     if (t0 + RNWV * g < tiles) {                      // (wave-uniform)
 #pragma unroll
                         for (int r = 0; r < RG; ++r) {
-                            const f32x4 v = meet_kq(acc[g][r]);
-                            float z = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));
+                            float z = meet_rows(acc[g][r]);
                             z += bs[g];
                             if (l == 2) z = act_f(z, G.out_act);
                             else z = (z < 0.f) ? 0.f : z;
@@ -248,8 +247,7 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
-                    const f32x4 v = meet_kq(a3[g][r]);
-                    const float z = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));
+                    const float z = meet_rows(a3[g][r]);
                     red3[(wv * RB + 4 * r + kq) * 32 + 16 * g + fm] = z;
                 }
             SMX_LDS_BARRIER();

@@ -117,3 +117,16 @@ __device__ __forceinline__ f32x4 meet_kq(f32x4 v) {
     for (int r = 0; r < 4; ++r) v[r] = meet_kq1(v[r]);
     return v;
 }
+
+// the same meeting when lane (fm, kq) only needs ROW kq of its feature (every epilogue: one word per lane): the swaps move
+// two registers at a time, so rows 0|1 and 2|3 travel together -- three swaps and three adds instead of eight and eight
+// and a four-way select.  Same additions in the same order as meet_kq ((kq0 + kq1) + (kq2 + kq3)): bit-identical.
+__device__ __forceinline__ float meet_rows(f32x4 v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+    // lane rows 0 | 1 | 2 | 3 now hold: row 0 over kq 0,1 | row 1 over kq 0,1 | row 0 over kq 2,3 | row 1 over kq 2,3 (a), rows 2, 3 (b)
+    const float u = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const float t = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(t), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}

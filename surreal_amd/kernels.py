@@ -745,6 +745,45 @@ class HipKernels(object):
                _row_stride(actions, A), A, L.ptr(q_actor), rows, L.ptr(stats), self._st())
 
 
+    # ---- one DDPG iteration on row blocks (smx_ddpg_rows.hip) -------------------------------------------
+    def ddpg_rows_supported(self, D, A, H1, H2, c1, c2):
+        return bool(self.lib.smx_ddpg_rows_supported(D, A, H1, H2, c1, c2))
+
+    def ddpg_rows_packed_floats(self, D, A, H1, H2, c1, c2):
+        return int(self.lib.smx_ddpg_rows_packed_floats(D, A, H1, H2, c1, c2))
+
+    def ddpg_rows_args(self, dims, nets, packed, io, gamma_n):
+        """the argument block of the three launches below.  dims = (D, A, H1, H2, c1, c2); nets: {'actor' | 'critic' |
+        'target_actor' | 'target_critic': {'W1', 'b1', ... 'b3'}} (views into the parameter buffers); packed: the
+        fragment-order weight copy (ddpg_rows_packed_floats floats); io: the tensors smx_ddpg_rows_t names
+        (include/surreal_amd.h).  Holds references to every tensor."""
+        a = L.DdpgRows()
+        a.D, a.A, a.H1, a.H2, a.c1, a.c2 = [int(v) for v in dims]
+        a.rows = int(io['x'].shape[0])
+        for name in ('actor', 'critic', 'target_actor', 'target_critic'):
+            n = getattr(a, name)
+            for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3'):
+                setattr(n, k, nets[name][k].data_ptr())
+        a.packed = packed.data_ptr()
+        a.gamma_n = float(gamma_n)
+        for k in ('x', 'x_next', 'actions', 'rewards', 'dones', 'xcat', 'h2c', 'q', 'q_next', 'y', 'dz3', 'dz2', 'dxcat',
+                  'h1a', 'h2a', 'act', 'q_actor', 'dz3a', 'dz2a', 'dz1a', 'step'):
+            t = io.get(k)
+            assert t is None or t.is_contiguous(), k
+            setattr(a, k, None if t is None else t.data_ptr())
+        a._refs = (nets, packed, io)
+        return a
+
+    def ddpg_rows_pack(self, args, critic_only=False):
+        L.call('smx_ddpg_rows_pack_f32', ctypes.byref(args), 1 if critic_only else 0, self._st())
+
+    def ddpg_rows_critic(self, args):
+        L.call('smx_ddpg_rows_critic_f32', ctypes.byref(args), self._st())
+
+    def ddpg_rows_actor(self, args):
+        L.call('smx_ddpg_rows_actor_f32', ctypes.byref(args), self._st())
+
+
     # ---- LSTM stem ----------------------------------------------------------------------------
     def lstm_forward(self, net, x, B, T, h0, c0, gates, out, cs, hprev=None, hN=None, cN=None,
                      stop=None):

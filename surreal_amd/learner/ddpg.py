@@ -108,6 +108,12 @@ class DDPGLearner(Learner):
         self._ws = None
         # independent layers of an iteration share launches (_enqueue_iteration_levels); off: one launch per layer
         self.level_schedule = bool(self.session_config.learner.get('ddpg_level_schedule', True))
+        # the iteration on row blocks (smx_ddpg_rows.hip): two chain launches instead of fifteen dense ones.  Unset: used
+        # for batches of up to 1024 rows per rank -- 4-row workgroups, measured 0.134 against 0.190 ms per iteration at
+        # batch 512; past that the 16-row blocks were never faster than the level schedule.  True / False
+        # force it on (where the shapes allow) / off.
+        rs = self.session_config.learner.get('ddpg_row_schedule', None)
+        self.row_schedule = None if rs is None else bool(rs)
 
     # ---- target update (ddpg.py:389-428) ----------------------------------------------------
     def _target_update_init(self):
@@ -366,6 +372,73 @@ class DDPGLearner(Learner):
             else:
                 K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
 
+    def _rows_dims(self, D):
+        """(D, A, H1, H2, c1, c2) when the row-block kernels take these shapes, else None"""
+        m = self.model
+        dims = (D, self.action_dim, m.actor.H1, m.actor.H2, m.c1, m.c2)
+        return dims if self.K.ddpg_rows_supported(*dims) else None
+
+    def _rows_args(self, ws, x, xn, actions, rewards, done):
+        if getattr(ws, 'rows_args', None) is not None and ws.rows_key == (x.data_ptr(), xn.data_ptr(), actions.data_ptr(),
+                                                                         rewards.data_ptr(), done.data_ptr()):
+            return ws.rows_args
+        K, m, mt = self.K, self.model, self.model_target
+        dims = self._rows_dims(x.shape[1])
+        ws.rows_packed = torch.zeros(K.ddpg_rows_packed_floats(*dims), device=self.device)
+        if not hasattr(ws, 'ga'):
+            ws.ga, o = {}, 0
+            for name, v in m.actor.views.items():
+                ws.ga[name] = ws.grads_a[o:o + v.numel()].view(v.shape)
+                o += v.numel()
+        nets = {'actor': m.actor.views, 'critic': m.critic, 'target_actor': mt.actor.views, 'target_critic': mt.critic}
+        io = dict(x=x, x_next=xn, actions=actions, rewards=rewards, dones=done, xcat=ws.xcat, h2c=ws.h2c, q=ws.q,
+                  q_next=ws.q_next, y=ws.y, dz3=ws.dz3, dz2=ws.dz2, dxcat=ws.dxcat, h1a=ws.h1a, h2a=ws.h2a, act=ws.act,
+                  q_actor=ws.q_actor, dz3a=ws.dz3a, dz2a=ws.dz2a, dz1a=ws.dz1a, step=ws.step)
+        ws.rows_args = K.ddpg_rows_args(dims, nets, ws.rows_packed, io, pow(self.discount_factor, self.n_step))
+        ws.rows_key = (x.data_ptr(), xn.data_ptr(), actions.data_ptr(), rewards.data_ptr(), done.data_ptr())
+        return ws.rows_args
+
+    def _enqueue_iteration_rows(self, ws, x, xn, actions, rewards, done):
+        """One DDPG iteration (ddpg.py:244-352; low-dimensional observations, one critic) on ROW BLOCKS: a
+        workgroup carries 4 batch rows (16 past 1024 rows) through whole chains -- target actor -> target critic -> y, critic -> loss ->
+        its data gradients, and the actor's forward pass in one launch; Q(s, mu(s)) through the updated critic -> the
+        actor's data gradients in a second (smx_ddpg_rows.hip).  Weight gradients (sums over all rows), Adam, the
+        target update and the statistics are the launches of the other schedules, on the same buffers: 10 launches where
+        the level schedule takes 22.  The MFMA loop sums a layer's products in another order than smx_linear_f32:
+        equal to the level schedule within fp32 rounding (tests/test_gpu_ddpg.py), not bit for bit."""
+        K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
+        B, D = x.shape
+        c1, c2, ld = m.c1, m.c2, m.c1 + A
+        H1, H2 = m.actor.H1, m.actor.H2
+        args = self._rows_args(ws, x, xn, actions, rewards, done)
+        gc, ga = ws.gc, ws.ga
+        # every network's weights in fragment order (the actor and both targets changed at the end of the last iteration;
+        # packed from the parameters each time, so nothing that writes them -- a checkpoint, a broadcast -- can leave
+        # the copy behind)
+        K.ddpg_rows_pack(args)
+        K.ddpg_rows_critic(args)
+        K.linear_multi([('wgrad', ws.dxcat, x, gc['W1'], gc['b1'], c1, D, B, dict(ldz=ld)),
+                        ('wgrad', ws.dz2, ws.xcat, gc['W2'], gc['b2'], c2, ld, B, {}),
+                        ('wgrad', ws.dz3.view(B, 1), ws.h2c, gc['W3'], gc['b3'], 1, c2, B, dict(ldz=1))])
+        self._average_over_ranks(ws.grads_c)
+        K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                        ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
+        K.ddpg_rows_pack(args, critic_only=True)
+        K.ddpg_rows_actor(args)
+        K.linear_multi([('wgrad', ws.dz1a, x, ga['W1'], ga['b1'], H1, D, B, {}),
+                        ('wgrad', ws.dz2a, ws.h1a, ga['W2'], ga['b2'], H2, H1, B, {}),
+                        ('wgrad', ws.dz3a, ws.h2a, ga['W3'], ga['b3'], A, H2, B, {})])
+        self._average_over_ranks(ws.grads_a)
+        K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                        ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
+        K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
+        self._average_over_ranks(ws.stats[:6])
+        for tgt, src in self._target_pairs(mt, m):
+            if self.target_update_type == 'soft':
+                K.soft_update(tgt, src, self.target_update_tau)
+            else:
+                K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
+
     @staticmethod
     def _target_pairs(mt, m):
         """(target, source) buffers of the target-network update (ddpg.py:344-352): actor + critic as the one buffer they
@@ -514,8 +587,11 @@ class DDPGLearner(Learner):
         """one DDPG iteration (ddpg.py:244-352) as a launch sequence without host round trips"""
         if self.use_layernorm:
             return self._enqueue_iteration_ln(ws, x, xn, actions, rewards, done, pix, pix_next)
-        if not (self.is_pixel_input or self.use_double_critic or self.world_size > 1):
-            if self.level_schedule:
+        if not (self.is_pixel_input or self.use_double_critic):
+            rows = self.row_schedule if self.row_schedule is not None else x.shape[0] <= 1024
+            if rows and self._rows_dims(x.shape[1]) is not None:
+                return self._enqueue_iteration_rows(ws, x, xn, actions, rewards, done)
+            if self.level_schedule and self.world_size == 1:
                 return self._enqueue_iteration_levels(ws, x, xn, actions, rewards, done)
         K, m, mt, A = self.K, self.model, self.model_target, self.action_dim
         B = x.shape[0]

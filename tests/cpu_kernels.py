@@ -968,6 +968,73 @@ class TorchCpuKernels(object):
         if int(step[0]) % interval == 0:
             target.copy_(source)
 
+    # ---- one DDPG iteration on row blocks: the CPU double works from the row-major parameters (the packed copy is what
+    # the HIP kernels read; a stale copy would go unnoticed here, so the double keeps its OWN snapshot, refreshed by
+    # ddpg_rows_pack exactly as the packed copy is)
+    def ddpg_rows_supported(self, D, A, H1, H2, c1, c2):
+        return all(v % 4 == 0 for v in (H1, H2, c1, c2)) and A <= 32
+
+    def ddpg_rows_packed_floats(self, D, A, H1, H2, c1, c2):
+        return 64
+
+    def ddpg_rows_args(self, dims, nets, packed, io, gamma_n):
+        import types
+        a = types.SimpleNamespace(dims=dims, nets=nets, packed=packed, io=io, gamma_n=float(gamma_n), snap={})
+        return a
+
+    def ddpg_rows_pack(self, args, critic_only=False):
+        for name in (('critic',) if critic_only else ('actor', 'critic', 'target_actor', 'target_critic')):
+            args.snap[name] = {k: v.clone() for k, v in args.nets[name].items()}
+
+    @staticmethod
+    def _rows_actor_fwd(n, x):
+        h1 = torch.relu(x @ n['W1'].t() + n['b1'])
+        h2 = torch.relu(h1 @ n['W2'].t() + n['b2'])
+        return h1, h2, torch.tanh(h2 @ n['W3'].t() + n['b3'])
+
+    @staticmethod
+    def _rows_critic_fwd(n, x, a):
+        xcat = torch.cat([torch.relu(x @ n['W1'].t() + n['b1']), a], 1)
+        h2 = torch.relu(xcat @ n['W2'].t() + n['b2'])
+        return xcat, h2, (h2 @ n['W3'].t() + n['b3']).view(-1)
+
+    def ddpg_rows_critic(self, args):
+        io, S = args.io, args.snap
+        D, A, H1, H2, c1, c2 = args.dims
+        x, xn = io['x'], io['x_next']
+        B = x.shape[0]
+        _, _, a_next = self._rows_actor_fwd(S['target_actor'], xn)
+        _, _, q_next = self._rows_critic_fwd(S['target_critic'], xn, a_next)
+        xcat, h2c, q = self._rows_critic_fwd(S['critic'], x, io['actions'])
+        y = io['rewards'].view(-1) + (args.gamma_n * q_next) * (1.0 - io['dones'].view(-1))
+        dz3 = 2.0 * (q - y) / B
+        io['xcat'].copy_(xcat); io['h2c'].copy_(h2c); io['q'].copy_(q); io['q_next'].copy_(q_next)
+        io['y'].copy_(y); io['dz3'].copy_(dz3)
+        if io.get('step') is not None:
+            io['step'] += 1
+        W2, W3 = S['critic']['W2'], S['critic']['W3']
+        dz2 = (dz3.view(B, 1) * W3.view(1, c2)) * (h2c > 0)
+        io['dz2'].copy_(dz2)
+        io['dxcat'][:, :c1].copy_((dz2 @ W2[:, :c1]) * (xcat[:, :c1] > 0))
+        h1a, h2a, act = self._rows_actor_fwd(S['actor'], x)
+        io['h1a'].copy_(h1a); io['h2a'].copy_(h2a); io['act'].copy_(act)
+
+    def ddpg_rows_actor(self, args):
+        io, S = args.io, args.snap
+        D, A, H1, H2, c1, c2 = args.dims
+        x = io['x']
+        B = x.shape[0]
+        xcat, h2c, q = self._rows_critic_fwd(S['critic'], x, io['act'])
+        io['q_actor'].copy_(q)
+        W2, W3 = S['critic']['W2'], S['critic']['W3']
+        dz2 = (torch.full((B, 1), -1.0 / B) * W3.view(1, c2)) * (h2c > 0)
+        da = dz2 @ W2[:, c1:]
+        dz3a = da * (1.0 - io['act'] * io['act'])
+        io['dz3a'].copy_(dz3a)
+        dz2a = (dz3a @ S['actor']['W3']) * (io['h2a'] > 0)
+        io['dz2a'].copy_(dz2a)
+        io['dz1a'].copy_((dz2a @ S['actor']['W2']) * (io['h1a'] > 0))
+
     def ddpg_stats(self, q, y, rewards, actions, q_actor, stats):
         stats[:6].copy_(_f([float(-q_actor.double().mean()), float(((q - y).double() ** 2).mean()),
                         float(actions.norm(2, 1).double().mean()), float(rewards.double().mean()),

@@ -44,6 +44,18 @@ def test_ddpg_learner_host_logic(name, cpu_double):
     DH.run_and_check(name)
 
 
+@pytest.mark.parametrize('name', ['tiny_hard', 'tiny_soft_clipcritic', 'cfg3_cheetah512'])
+def test_ddpg_learner_host_logic_both_schedules(name, cpu_double):
+    """the row-block schedule's host side (the default up to 1024 rows): which buffers the two chain launches and the
+    weight-gradient launches share, and WHEN the packed weight copy is refreshed -- the double works from a snapshot of
+    the parameters taken by ddpg_rows_pack, so a missing refresh (the critic's, between its Adam step and the actor
+    phase) fails the goldens here as it would on the device"""
+    L = DH.run_and_check(name)
+    assert getattr(L._ws, 'rows_args', None) is not None
+    L = DH.run_and_check(name, opts={'ddpg_row_schedule': False})          # the level schedule
+    assert getattr(L._ws, 'rows_args', None) is None
+
+
 def test_replay_samples_straight_into_the_learners_staging_buffers(cpu_double):
     DH.check_sampling_into_staging('cpu')
 

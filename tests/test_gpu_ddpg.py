@@ -16,6 +16,74 @@ def test_ddpg_resume_across_the_hard_update_at_configs2_size():
     DH.check_resume_across_hard_update()
 
 
+ROWS_CASES = ['tiny_hard', 'tiny_soft_clipcritic', 'cfg3_cheetah512']     # low-dimensional, one critic, no LayerNorm
+
+
+@pytest.mark.parametrize('name', ROWS_CASES)
+def test_ddpg_learner_matches_reference_golden_both_schedules(name):
+    """the reference goldens through the row-block launches (the default up to 1024 rows) and through the level schedule
+    (session_config.learner.ddpg_row_schedule = False)"""
+    L = DH.run_and_check(name)
+    assert getattr(L._ws, 'rows_args', None) is not None
+    L = DH.run_and_check(name, opts={'ddpg_row_schedule': False})
+    assert getattr(L._ws, 'rows_args', None) is None
+
+
+@pytest.mark.parametrize('name', ROWS_CASES)
+def test_row_schedule_agrees_with_the_level_schedule(name):
+    """smx_ddpg_rows.hip sums a layer's products in the MFMA loop's order, smx_linear_f32 in its own: after several
+    iterations parameters, targets and statistics agree within fp32 rounding of the level schedule's (measured: see the
+    assertion messages' bounds), not bit for bit"""
+    import copy
+    import numpy as np
+    import torch
+    from surreal_amd import synthetic
+    g, case = DH.load(name)
+    rows, levels = DH.make_learner(case, {'ddpg_row_schedule': True}), DH.make_learner(case, {'ddpg_row_schedule': False})
+    for it in range(4):
+        b = synthetic.make_ddpg_batch(case['B'], case['D'], case['A'], seed=10 + it)
+        sa, sb = dict(rows.learn(copy.deepcopy(b))), dict(levels.learn(copy.deepcopy(b)))
+        for k in sb:
+            np.testing.assert_allclose(sa[k], sb[k], rtol=2e-5, atol=2e-6, err_msg='%s iteration %d' % (k, it))
+    assert getattr(rows._ws, 'rows_args', None) is not None and getattr(levels._ws, 'rows_args', None) is None
+    lr = max(case['hyper']['lr_actor'], case['hyper']['lr_critic'])
+    for a, b in ((rows.model, levels.model), (rows.model_target, levels.model_target)):
+        for x, y in ((a.actor_flat, b.actor_flat), (a.critic_flat, b.critic_flat)):
+            d = (x - y).abs()
+            # (Adam's first steps move a weight by ~lr sign(g): an element whose gradient sits at the rounding noise
+            # floor may differ by that much, the rest agree to ~1e-7)
+            assert float(d.max()) <= 2 * lr * 4 + 1e-6, float(d.max())
+            assert float((d > 2e-6).float().mean()) < 0.02, float((d > 2e-6).float().mean())
+
+
+@pytest.mark.parametrize('name,B', [('tiny_hard', None), ('tiny_hard', 37), ('cfg3_cheetah512', None), ('cfg3_cheetah512', 1000), ('tiny_hard', 1030),
+                                    ('cfg3_cheetah512', 1100)])
+def test_row_block_launches_fill_the_level_schedules_buffers(name, B):
+    """one iteration, buffer by buffer: what the two row-block launches leave in the workspace (activations, Bellman
+    targets, data gradients of both networks) and the weight gradients formed from it, against the level schedule's --
+    also with batches that are not multiples of the row block (4 rows up to 1024 rows, 16 past that: both kernels)"""
+    import copy
+    import torch
+    from surreal_amd import synthetic
+    g, case = DH.load(name)
+    B = B or case['B']
+    rows, levels = DH.make_learner(case, {'ddpg_row_schedule': True}), DH.make_learner(case, {'ddpg_row_schedule': False})
+    b = synthetic.make_ddpg_batch(B, case['D'], case['A'], seed=77)
+    rows.learn(copy.deepcopy(b))
+    levels.learn(copy.deepcopy(b))
+    torch.cuda.synchronize()
+    wr, wl = rows._ws, levels._ws
+    c1 = rows.model.c1
+    pairs = [(k, getattr(wr, k), getattr(wl, k)) for k in ('xcat', 'h2c', 'q', 'q_next', 'y', 'dz3', 'h1a', 'h2a', 'act',
+                                                           'q_actor', 'dz3a', 'dz2a', 'dz1a', 'grads_c', 'grads_a')]
+    pairs.append(('dz1 (critic)', wr.dxcat[:, :c1], wl.dxcat[:, :c1]))
+    for k, x, y in pairs:
+        scale = float(y.abs().max()) + 1e-30
+        d = float((x - y).abs().max())
+        assert d <= 2e-6 * max(scale, 1.0) + 1e-5 * scale, '%s: max |diff| %g at scale %g' % (k, d, scale)
+    assert int(wr.step[0]) == int(wl.step[0])
+
+
 @pytest.mark.parametrize('name', ['tiny_hard', 'tiny_soft_clipcritic', 'cfg3_cheetah512'])
 def test_level_schedule_equals_layer_schedule_bit_for_bit(name):
     """the dependency-level schedule (independent layers of the four forward chains and a level's weight gradients
