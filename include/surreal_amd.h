@@ -869,6 +869,27 @@ int smx_ddpg_rows_pack_f32(const smx_ddpg_rows_t* args, int32_t which, smx_strea
 int smx_ddpg_rows_critic_f32(const smx_ddpg_rows_t* args, smx_stream_t stream);
 int smx_ddpg_rows_actor_f32(const smx_ddpg_rows_t* args, smx_stream_t stream);
 
+/* One optimiser group's step of the row schedule in ONE launch (round 6): Adam exactly as smx_adam_step_dev_f32
+ * (torch.optim.Adam after clip_grad_value_: ddpg.py:310-311, 332-333), then the group's target network -- soft
+ * (interval == 0: target = target (1 - tau) + theta tau) or hard every `interval` iterations of *step (ddpg.py:389-428),
+ * target == NULL: none -- and the fragment-order copies of both inside args->packed, element by element: no
+ * smx_ddpg_rows_pack_f32 is needed between iterations as long as nothing else writes the parameters.  theta / target are
+ * the group's parameter buffers ([n], holding the W1, W2, W3 that args names for the group at the same offsets). */
+typedef struct smx_ddpg_update {
+    float* theta;
+    const float* grads;
+    float *exp_avg, *exp_avg_sq;
+    float* target;
+    int64_t n;
+    const float* lr;                   /* device */
+    const int32_t* step;               /* device: Adam's step count of this iteration (also decides a hard update) */
+    float weight_decay, clip_value, tau;
+    int32_t interval;
+} smx_ddpg_update_t;
+enum { SMX_DDPG_GROUP_ACTOR = 0, SMX_DDPG_GROUP_CRITIC = 1 };
+int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* args, int32_t group, const smx_ddpg_update_t* update,
+                             smx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LSTM stem (surreal/model/ppo_net.py:143-152: nn.LSTM(in, rnn_hidden, 1, batch_first=True) in
  * front of the actor / critic MLPs; forward at :277-279, :307-309, single step at :338-349).

@@ -123,6 +123,13 @@ class DdpgNet(Structure):
     _fields_ = [(n, c_void_p) for n in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')]
 
 
+class DdpgUpdate(Structure):
+    """smx_ddpg_update_t"""
+    _fields_ = ([(n, c_void_p) for n in ('theta', 'grads', 'exp_avg', 'exp_avg_sq', 'target')] + [('n', c_int64)] +
+                [(n, c_void_p) for n in ('lr', 'step')] +
+                [(n, c_float) for n in ('weight_decay', 'clip_value', 'tau')] + [('interval', c_int32)])
+
+
 class DdpgRows(Structure):
     """smx_ddpg_rows_t"""
     _fields_ = ([('rows', c_int64)] + [(n, c_int32) for n in ('D', 'A', 'H1', 'H2', 'c1', 'c2')] +
@@ -295,6 +302,7 @@ _SIGS = {
     'smx_ddpg_rows_pack_f32': (c_int32, [_P, c_int32, _P]),
     'smx_ddpg_rows_critic_f32': (c_int32, [_P, _P]),
     'smx_ddpg_rows_actor_f32': (c_int32, [_P, _P]),
+    'smx_ddpg_rows_update_f32': (c_int32, [_P, c_int32, _P, _P]),
     'smx_ddpg_stats_f32': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int64, _P, _P]),
     'smx_lstm_param_count': (c_int64, [c_int32, c_int32]),
     'smx_lstm_forward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,

@@ -665,6 +665,89 @@ __global__ __launch_bounds__(256) void ddpg_pack_kernel(PArgs P) {
     *(float4*)(P.packed + 4 * w0) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// one optimiser group's step for the row schedule: Adam (smx_adam_step_dev_f32's expressions), the target update of the
+// group's target network (smx_soft_update_f32 / smx_hard_update_every_f32's) and BOTH fragment-order copies, element by
+// element in one launch -- the schedule's two pack launches and its target-update launch (12 + 4 us of a 135 us
+// iteration) disappear.  Nothing reads the target critic between the critic's Adam step and the end of the iteration
+// (the actor phase goes through the MODEL critic), so updating it here forms the same values as ddpg.py:344-352 does at
+// the end.
+// ---------------------------------------------------------------------------------------------------------------
+struct UMat {
+    long off;                     // first element of the matrix inside the group's buffer
+    int M, K;                     // [M, K] row-major
+    long base, base_tgt;          // packed blocks (float offsets): the model's copy, the target's
+    long base_t0, base_t1;        // transposed copies (< 0: none): columns < split -> t0, the rest -> t1
+    int split;
+};
+struct UArgs {
+    float* theta;
+    const float* grads;
+    float *m, *v, *target, *packed;
+    long n;
+    const float* lr;
+    const int* step;
+    float wd, clip_value, tau;
+    int interval;
+    UMat mat[3];
+};
+
+__global__ __launch_bounds__(256) void ddpg_rows_update_kernel(UArgs U) {
+    __shared__ float coef[2];
+    __shared__ int upd;
+    if (threadIdx.x == 0) {
+        const double beta1 = 0.9, beta2 = 0.999;
+        const int st = *U.step;
+        const double step = (double)st;
+        const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+        coef[0] = (float)(-((double)*U.lr / bc1));
+        coef[1] = (float)sqrt(bc2);
+        upd = U.interval > 0 ? (st % U.interval == 0) : 1;
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= U.n) return;
+    const float neg_step_size = coef[0], bc2_sqrt = coef[1];
+    const float w1 = (float)(1.0 - 0.9), b2f = (float)0.999, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
+    float g = U.grads[i];
+    if (U.clip_value > 0.f) g = fminf(fmaxf(g, -U.clip_value), U.clip_value);   // clip_grad_value_
+    const float p = U.theta[i];
+    if (U.wd != 0.f) g = g + U.wd * p;
+    float mi = U.m[i], vi = U.v[i];
+    mi = mi + w1 * (g - mi);
+    vi = vi * b2f + w2 * (g * g);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float pn = p + (neg_step_size * mi) / denom;
+    U.theta[i] = pn;
+    U.m[i] = mi;
+    U.v[i] = vi;
+    // the target network's element (torchx Module.soft_update: target * (1 - tau) + source * tau; a hard update copies)
+    bool tw = false;
+    float tn = 0.f;
+    if (U.target && upd) {
+        tn = (U.interval > 0 || U.tau >= 1.0f) ? pn : (U.target[i] * (1.0f - U.tau) + pn * U.tau);
+        U.target[i] = tn;
+        tw = true;
+    }
+    // the fragment-order copies
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const UMat& X = U.mat[j];
+        const long r = i - X.off;
+        if (r >= 0 && r < (long)X.M * X.K) {
+            const int mm = (int)(r / X.K), kk = (int)(r - (long)mm * X.K);
+            const long pos = pack_pos(X.K, mm, kk);
+            U.packed[X.base + pos] = pn;
+            if (tw) U.packed[X.base_tgt + pos] = tn;
+            if (kk < X.split) {
+                if (X.base_t0 >= 0) U.packed[X.base_t0 + pack_pos(X.M, kk, mm)] = pn;
+            } else if (X.base_t1 >= 0) {
+                U.packed[X.base_t1 + pack_pos(X.M, kk - X.split, mm)] = pn;
+            }
+        }
+    }
+}
+
 // block order of the packed buffer
 enum { B_AW1, B_AW2, B_AW3, B_AW3T, B_AW2T, B_CW1, B_CW2, B_CW3, B_CW2TLO, B_CW2THI, B_TAW1, B_TAW2, B_TAW3, B_TCW1,
        B_TCW2, B_TCW3, B_COUNT };
@@ -931,6 +1014,52 @@ extern "C" int smx_ddpg_rows_actor_f32(const smx_ddpg_rows_t* a, smx_stream_t st
     } else {
         hipLaunchKernelGGL(ddpg_actor_rows_kernel<16>, grid, dim3(DNTH), bytes, smx_s(stream), G);
     }
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* a, int32_t group, const smx_ddpg_update_t* u,
+                                        smx_stream_t stream) {
+    SMX_REQUIRE(a && a->packed && u, SMX_E_NULL);
+    SMX_REQUIRE(u->theta && u->grads && u->exp_avg && u->exp_avg_sq && u->lr && u->step, SMX_E_NULL);
+    SMX_REQUIRE(group == SMX_DDPG_GROUP_ACTOR || group == SMX_DDPG_GROUP_CRITIC, SMX_E_SHAPE);
+    SMX_REQUIRE(u->n > 0 && u->interval >= 0 && (u->target == nullptr || u->interval > 0 || u->tau > 0.f), SMX_E_SHAPE);
+    const Dims d = dims_of(*a);
+    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
+    const bool cr = group == SMX_DDPG_GROUP_CRITIC;
+    const smx_ddpg_net_t& net = cr ? a->critic : a->actor;
+    const smx_ddpg_net_t& tnet = cr ? a->target_critic : a->target_actor;
+    SMX_REQUIRE(net.W1 && net.W2 && net.W3, SMX_E_NULL);
+    UArgs U;
+    memset(&U, 0, sizeof(U));
+    U.theta = u->theta; U.grads = u->grads; U.m = u->exp_avg; U.v = u->exp_avg_sq; U.target = u->target;
+    U.packed = a->packed; U.n = u->n; U.lr = u->lr; U.step = u->step; U.wd = u->weight_decay;
+    U.clip_value = u->clip_value; U.tau = u->tau; U.interval = u->interval;
+    const float* W[3] = {net.W1, net.W2, net.W3};
+    const float* TW[3] = {tnet.W1, tnet.W2, tnet.W3};
+    const int blk[3] = {cr ? B_CW1 : B_AW1, cr ? B_CW2 : B_AW2, cr ? B_CW3 : B_AW3};
+    const int tblk[3] = {cr ? B_TCW1 : B_TAW1, cr ? B_TCW2 : B_TAW2, cr ? B_TCW3 : B_TAW3};
+    for (int j = 0; j < 3; ++j) {
+        UMat& X = U.mat[j];
+        block_shape(d, blk[j], X.M, X.K);
+        X.off = W[j] - u->theta;
+        // the matrices lie inside the group's buffer, the target's at the same offsets inside the target's
+        SMX_REQUIRE(X.off >= 0 && X.off + (long)X.M * X.K <= u->n, SMX_E_SHAPE);
+        if (u->target) SMX_REQUIRE(TW[j] && TW[j] - u->target == X.off, SMX_E_SHAPE);
+        X.base = 4 * block_base(d, blk[j]);
+        X.base_tgt = 4 * block_base(d, tblk[j]);
+        X.base_t0 = X.base_t1 = -1;
+        X.split = X.K;
+    }
+    if (cr) {
+        U.mat[1].base_t0 = 4 * block_base(d, B_CW2TLO);
+        U.mat[1].base_t1 = 4 * block_base(d, B_CW2THI);
+        U.mat[1].split = d.c1;
+    } else {
+        U.mat[1].base_t0 = 4 * block_base(d, B_AW2T);
+        U.mat[2].base_t0 = 4 * block_base(d, B_AW3T);
+    }
+    hipLaunchKernelGGL(ddpg_rows_update_kernel, dim3((unsigned)((u->n + 255) / 256)), dim3(256), 0, smx_s(stream), U);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

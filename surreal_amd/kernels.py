@@ -783,6 +783,20 @@ class HipKernels(object):
     def ddpg_rows_actor(self, args):
         L.call('smx_ddpg_rows_actor_f32', ctypes.byref(args), self._st())
 
+    def ddpg_rows_update(self, args, group, theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value,
+                         target=None, tau=0.0, interval=0):
+        """smx_ddpg_rows_update_f32: Adam on the group ('actor' | 'critic'), its target network's update (soft with tau,
+        or hard every `interval` iterations of *step; target None: none) and the fragment-order copies of both"""
+        u = L.DdpgUpdate()
+        u.theta, u.grads, u.exp_avg, u.exp_avg_sq = (t.data_ptr() for t in (theta, grads, exp_avg, exp_avg_sq))
+        u.target = None if target is None else target.data_ptr()
+        u.n = theta.numel()
+        assert grads.numel() == u.n and exp_avg.numel() == u.n and exp_avg_sq.numel() == u.n
+        assert target is None or target.numel() == u.n
+        u.lr, u.step = lr.data_ptr(), step.data_ptr()
+        u.weight_decay, u.clip_value, u.tau, u.interval = float(weight_decay or 0.0), float(clip_value or 0.0), float(tau), int(interval)
+        L.call('smx_ddpg_rows_update_f32', ctypes.byref(args), {'actor': 0, 'critic': 1}[group], ctypes.byref(u), self._st())
+
 
     # ---- LSTM stem ----------------------------------------------------------------------------
     def lstm_forward(self, net, x, B, T, h0, c0, gates, out, cs, hprev=None, hN=None, cN=None,

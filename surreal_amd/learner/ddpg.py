@@ -385,6 +385,7 @@ class DDPGLearner(Learner):
         K, m, mt = self.K, self.model, self.model_target
         dims = self._rows_dims(x.shape[1])
         ws.rows_packed = torch.zeros(K.ddpg_rows_packed_floats(*dims), device=self.device)
+        ws.rows_versions = None          # nothing packed yet
         if not hasattr(ws, 'ga'):
             ws.ga, o = {}, 0
             for name, v in m.actor.views.items():
@@ -412,32 +413,46 @@ class DDPGLearner(Learner):
         H1, H2 = m.actor.H1, m.actor.H2
         args = self._rows_args(ws, x, xn, actions, rewards, done)
         gc, ga = ws.gc, ws.ga
-        # every network's weights in fragment order (the actor and both targets changed at the end of the last iteration;
-        # packed from the parameters each time, so nothing that writes them -- a checkpoint, a broadcast -- can leave
-        # the copy behind)
-        K.ddpg_rows_pack(args)
+        # every network's weights in fragment order: the update launches below keep the copies current element by
+        # element; a full pack only when something ELSE wrote parameters since (construction, a checkpoint, a fetched
+        # state dict -- _rows_refresh, outside a captured graph)
+        if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+            self._rows_refresh(ws)
+        soft = self.target_update_type == 'soft'
+        tgt = dict(tau=self.target_update_tau if soft else 0.0, interval=0 if soft else self.target_update_interval)
         K.ddpg_rows_critic(args)
         K.linear_multi([('wgrad', ws.dxcat, x, gc['W1'], gc['b1'], c1, D, B, dict(ldz=ld)),
                         ('wgrad', ws.dz2, ws.xcat, gc['W2'], gc['b2'], c2, ld, B, {}),
                         ('wgrad', ws.dz3.view(B, 1), ws.h2c, gc['W3'], gc['b3'], 1, c2, B, dict(ldz=1))])
         self._average_over_ranks(ws.grads_c)
-        K.adam_step_dev(m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
-                        ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value)
-        K.ddpg_rows_pack(args, critic_only=True)
+        K.ddpg_rows_update(args, 'critic', m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
+                           ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value,
+                           target=mt.critic_flat, **tgt)
         K.ddpg_rows_actor(args)
         K.linear_multi([('wgrad', ws.dz1a, x, ga['W1'], ga['b1'], H1, D, B, {}),
                         ('wgrad', ws.dz2a, ws.h1a, ga['W2'], ga['b2'], H2, H1, B, {}),
                         ('wgrad', ws.dz3a, ws.h2a, ga['W3'], ga['b3'], A, H2, B, {})])
         self._average_over_ranks(ws.grads_a)
-        K.adam_step_dev(m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
-                        ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value)
+        K.ddpg_rows_update(args, 'actor', m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
+                           ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value,
+                           target=mt.actor_flat, **tgt)
         K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
         self._average_over_ranks(ws.stats[:6])
-        for tgt, src in self._target_pairs(mt, m):
-            if self.target_update_type == 'soft':
-                K.soft_update(tgt, src, self.target_update_tau)
-            else:
-                K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
+        ws.rows_versions = self._rows_versions()
+
+    def _rows_versions(self):
+        """torch's write counters of the four parameter buffers: the HIP launches do not move them (raw pointers), anything
+        that writes parameters through torch does"""
+        m, mt = self.model, self.model_target
+        return tuple(int(t._version) for t in (m.actor_flat, m.critic_flat, mt.actor_flat, mt.critic_flat))
+
+    def _rows_refresh(self, ws):
+        """the row schedule's fragment-order copies follow the parameters through ddpg_rows_update only: repack all of
+        them when the parameters were written from outside since the last iteration (or never packed)"""
+        args = getattr(ws, 'rows_args', None)
+        if args is not None and getattr(ws, 'rows_versions', None) != self._rows_versions():
+            self.K.ddpg_rows_pack(args)
+            ws.rows_versions = self._rows_versions()
 
     @staticmethod
     def _target_pairs(mt, m):
@@ -699,6 +714,7 @@ class DDPGLearner(Learner):
         ws = self._workspace(B, D)
         if ws.dev_step != self.critic_step:          # restored from a checkpoint
             ws.step.fill_(self.critic_step)
+            ws.rows_versions = None
         if ws.lr_host != (self.lr_actor, self.lr_critic):
             ws.lr_host = (self.lr_actor, self.lr_critic)
             ws.lr.copy_(torch.tensor(ws.lr_host, dtype=torch.float32))
@@ -737,7 +753,10 @@ class DDPGLearner(Learner):
             finally:
                 gc.enable()
         elif ws.graph is not None:
+            self._rows_refresh(ws)
             ws.graph.replay()
+            if getattr(ws, 'rows_args', None) is not None:
+                ws.rows_versions = self._rows_versions()
         else:
             self._enqueue_iteration(ws, ws.s_obs, ws.s_next, ws.s_act, ws.s_rew, ws.s_done, *frames)
         self.critic_step += 1

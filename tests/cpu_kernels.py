@@ -986,6 +986,19 @@ class TorchCpuKernels(object):
         for name in (('critic',) if critic_only else ('actor', 'critic', 'target_actor', 'target_critic')):
             args.snap[name] = {k: v.clone() for k, v in args.nets[name].items()}
 
+    def ddpg_rows_update(self, args, group, theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value,
+                         target=None, tau=0.0, interval=0):
+        """Adam + the group's target update + BOTH snapshots (the kernel keeps the packed copies of the group and of its
+        target current; nothing else is refreshed -- a schedule that relied on more would fail the goldens here)"""
+        self.adam_step_dev(theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value)
+        if target is not None:
+            if interval > 0:
+                self.hard_update_every(target, theta, step, interval)
+            else:
+                self.soft_update(target, theta, tau)
+        for name in ((group, 'target_' + group) if target is not None else (group,)):
+            args.snap[name] = {k: v.clone() for k, v in args.nets[name].items()}
+
     @staticmethod
     def _rows_actor_fwd(n, x):
         h1 = torch.relu(x @ n['W1'].t() + n['b1'])

@@ -83,7 +83,7 @@ STRUCTS = {               # C typedef -> ctypes mirror in surreal_amd/_lib.py
     'smx_ppo_losses_t': 'PpoLosses', 'smx_ppo_combine_t': 'PpoCombine', 'smx_synth_act_step_t': 'SynthActStep',
     'smx_epoch_job_t': 'EpochJob', 'smx_epoch_pack_t': 'EpochPack', 'smx_epoch_prep_t': 'EpochPrep', 'smx_learn_epilogue_t': 'LearnEpilogue',
     'smx_xchg_t': 'Xchg', 'smx_synth_rollout_t': 'SynthRollout', 'smx_linear_job_t': 'LinearJob',
-    'smx_gather_job_t': 'GatherJob', 'smx_ddpg_net_t': 'DdpgNet', 'smx_ddpg_rows_t': 'DdpgRows',
+    'smx_gather_job_t': 'GatherJob', 'smx_ddpg_net_t': 'DdpgNet', 'smx_ddpg_rows_t': 'DdpgRows', 'smx_ddpg_update_t': 'DdpgUpdate',
 }
 
 

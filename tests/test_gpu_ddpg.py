@@ -135,3 +135,50 @@ def test_ddpg_stats_against_float64_and_its_nan_check():
 
 def test_replay_samples_straight_into_the_learners_staging_buffers():
     DH.check_sampling_into_staging('cuda')
+
+
+@pytest.mark.parametrize('name', ['tiny_hard', 'tiny_soft_clipcritic', 'cfg3_cheetah512'])
+def test_update_launch_keeps_the_packed_copies_current(name):
+    """smx_ddpg_rows_update_f32 writes every updated weight (model and target) into the fragment-order copies: after
+    several iterations -- across a hard update where the case has one -- the packed buffer is, bit for bit, what a full
+    smx_ddpg_rows_pack_f32 of the parameters gives"""
+    import copy
+    import torch
+    from surreal_amd import synthetic
+    g, case = DH.load(name)
+    L = DH.make_learner(case, {'ddpg_row_schedule': True})
+    for it in range(max(5, case['hyper'].get('target_update_interval', 1) + 2) if case['hyper']['target_update_type'] == 'hard' and
+                    case['hyper']['target_update_interval'] <= 10 else 5):
+        L.learn(copy.deepcopy(synthetic.make_ddpg_batch(case['B'], case['D'], case['A'], seed=10 + it)))
+    torch.cuda.synchronize()
+    ws = L._ws
+    kept = ws.rows_packed.clone()
+    L.K.ddpg_rows_pack(ws.rows_args)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, ws.rows_packed)
+    assert float(kept.abs().sum()) > 0
+
+
+def test_parameters_written_from_outside_are_repacked():
+    """a state dict loaded between iterations (torch writes: the buffers' version counters move) reaches the row
+    kernels: the next iteration equals the level schedule's from the same parameters"""
+    import copy
+    import numpy as np
+    import torch
+    from surreal_amd import synthetic
+    g, case = DH.load('cfg3_cheetah512')
+    rows, levels = DH.make_learner(case, {'ddpg_row_schedule': True}), DH.make_learner(case, {'ddpg_row_schedule': False})
+    mk = lambda it: copy.deepcopy(synthetic.make_ddpg_batch(case['B'], case['D'], case['A'], seed=10 + it))  # noqa: E731
+    for it in range(3):
+        rows.learn(mk(it)); levels.learn(mk(it))
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for L in (rows, levels):
+        pass
+    newc = torch.randn(rows.model.critic_flat.shape, generator=gen, device='cuda') * 0.05
+    newa = torch.randn(rows.model.actor_flat.shape, generator=gen, device='cuda') * 0.05
+    for L in (rows, levels):
+        L.model.critic_flat.copy_(newc)
+        L.model_target.actor_flat.copy_(newa)
+    sa, sb = dict(rows.learn(mk(3))), dict(levels.learn(mk(3)))
+    for k in sb:
+        np.testing.assert_allclose(sa[k], sb[k], rtol=2e-5, atol=2e-6, err_msg=k)
