@@ -835,7 +835,9 @@ int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
 
 /* --- one DDPG iteration on ROW BLOCKS (round 5; surreal/learner/ddpg.py:244-352, low-dimensional observations, one critic) ---
  * The layer-by-layer schedule above is ~19 dependent launches of 512-row problems.  Batch rows are independent up to the
- * weight gradients, so a workgroup carries 16 rows through whole chains (the MFMA row-block loop of the fused PPO epochs):
+ * weight gradients, so a workgroup carries a block of rows through whole chains: 4 rows up to 1024 rows (round 6: the
+ * v_mfma_f32_4x4x1 loop of the rollout kernel, the chain as a table of layer steps in the kernel arguments), 16 rows beyond
+ * (the MFMA row-block loop of the fused PPO epochs):
  *   smx_ddpg_rows_critic_f32  mu'(s') -> Q'(s', mu'(s')) (target networks); Q(s, a); y = r + gamma^n Q' (1 - done) and
  *                             dz3 = 2 (Q - y) / rows (ddpg.py:279, 307-308); *step += 1; the critic's data gradients
  *                             dz2 [rows, c2] and dz1 (first c1 columns of dxcat); mu(s) for the actor phase (h1a, h2a, act)
