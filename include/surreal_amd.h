@@ -865,7 +865,9 @@ typedef struct smx_ddpg_rows {
     int32_t* step;                                             /* device Adam step counter (may be NULL) */
 } smx_ddpg_rows_t;
 enum { SMX_DDPG_PACK_ALL = 0, SMX_DDPG_PACK_CRITIC = 1 };
-int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);
+int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);   /* on 4-row blocks */
+/* ... for a batch of `rows`: past 1024 rows the 16-row blocks' tiles must fit the workgroup's LDS as well */
+int32_t smx_ddpg_rows_supported_at(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2, int64_t rows);
 int64_t smx_ddpg_rows_packed_floats(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);
 int smx_ddpg_rows_pack_f32(const smx_ddpg_rows_t* args, int32_t which, smx_stream_t stream);
 int smx_ddpg_rows_critic_f32(const smx_ddpg_rows_t* args, smx_stream_t stream);

@@ -298,6 +298,7 @@ _SIGS = {
     'smx_adam_step_dev_f32': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, c_double, c_double, _P]),
     'smx_hard_update_every_f32': (c_int32, [_P, _P, c_int64, _P, c_int32, _P]),
     'smx_ddpg_rows_supported': (c_int32, [c_int32] * 6),
+    'smx_ddpg_rows_supported_at': (c_int32, [c_int32] * 6 + [c_int64]),
     'smx_ddpg_rows_packed_floats': (c_int64, [c_int32] * 6),
     'smx_ddpg_rows_pack_f32': (c_int32, [_P, c_int32, _P]),
     'smx_ddpg_rows_critic_f32': (c_int32, [_P, _P]),

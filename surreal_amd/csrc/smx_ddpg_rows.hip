@@ -810,11 +810,12 @@ int lds_floats(const Dims& d, RArgs* G, int RB) {
     return o;
 }
 
-bool dims_ok(const Dims& d) {
+bool dims_ok(const Dims& d, int RB) {
     return d.D > 0 && d.A > 0 && d.A <= 32 && d.H1 > 0 && d.H2 > 0 && d.c1 > 0 && d.c2 > 0 && d.D <= 2048 &&
            d.H1 % 4 == 0 && d.H2 % 4 == 0 && d.c1 % 4 == 0 && d.c2 % 4 == 0 && d.H1 <= 1024 && d.H2 <= 1024 &&
-           d.c1 <= 1024 && d.c2 <= 1024 && lds_floats(d, nullptr, 16) * (int)sizeof(float) <= MAX_LDS;
+           d.c1 <= 1024 && d.c2 <= 1024 && lds_floats(d, nullptr, RB) * (int)sizeof(float) <= MAX_LDS;
 }
+bool dims_ok(const Dims& d) { return dims_ok(d, 4); }        // (the packed layout does not depend on the block size)
 
 Dims dims_of(const smx_ddpg_rows_t& a) {
     Dims d;
@@ -832,8 +833,8 @@ PMat pmat(const smx_ddpg_rows_t& a, const Dims& d, int b) {
 int fill(RArgs& G, const smx_ddpg_rows_t* a) {
     SMX_REQUIRE(a && a->packed, SMX_E_NULL);
     const Dims d = dims_of(*a);
-    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
     SMX_REQUIRE(a->rows > 0 && a->rows < (1 << 24), SMX_E_SHAPE);
+    SMX_REQUIRE(dims_ok(d, rows_per_block(a->rows)), SMX_E_UNSUPPORTED);
     {   // every row-major output is addressed through a buffer descriptor: 31-bit byte offsets
         int widest = d.c1 + d.A;
         widest = d.H1 > widest ? d.H1 : widest;
@@ -924,6 +925,13 @@ extern "C" int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int
     Dims d;
     d.D = D; d.A = A; d.H1 = H1; d.H2 = H2; d.c1 = c1; d.c2 = c2;
     return dims_ok(d) ? 1 : 0;
+}
+
+extern "C" int32_t smx_ddpg_rows_supported_at(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2,
+                                              int64_t rows) {
+    Dims d;
+    d.D = D; d.A = A; d.H1 = H1; d.H2 = H2; d.c1 = c1; d.c2 = c2;
+    return rows > 0 && rows < (1 << 24) && dims_ok(d, rows_per_block(rows)) ? 1 : 0;
 }
 
 extern "C" int64_t smx_ddpg_rows_packed_floats(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2) {

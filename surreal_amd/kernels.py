@@ -746,7 +746,9 @@ class HipKernels(object):
 
 
     # ---- one DDPG iteration on row blocks (smx_ddpg_rows.hip) -------------------------------------------
-    def ddpg_rows_supported(self, D, A, H1, H2, c1, c2):
+    def ddpg_rows_supported(self, D, A, H1, H2, c1, c2, rows=None):
+        if rows is not None:
+            return bool(self.lib.smx_ddpg_rows_supported_at(D, A, H1, H2, c1, c2, int(rows)))
         return bool(self.lib.smx_ddpg_rows_supported(D, A, H1, H2, c1, c2))
 
     def ddpg_rows_packed_floats(self, D, A, H1, H2, c1, c2):

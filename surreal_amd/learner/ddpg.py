@@ -372,18 +372,18 @@ class DDPGLearner(Learner):
             else:
                 K.hard_update_every(tgt, src, ws.step, self.target_update_interval)
 
-    def _rows_dims(self, D):
-        """(D, A, H1, H2, c1, c2) when the row-block kernels take these shapes, else None"""
+    def _rows_dims(self, D, rows=None):
+        """(D, A, H1, H2, c1, c2) when the row-block kernels take these shapes (for a batch of `rows`), else None"""
         m = self.model
         dims = (D, self.action_dim, m.actor.H1, m.actor.H2, m.c1, m.c2)
-        return dims if self.K.ddpg_rows_supported(*dims) else None
+        return dims if self.K.ddpg_rows_supported(*dims, rows=rows) else None
 
     def _rows_args(self, ws, x, xn, actions, rewards, done):
         if getattr(ws, 'rows_args', None) is not None and ws.rows_key == (x.data_ptr(), xn.data_ptr(), actions.data_ptr(),
                                                                          rewards.data_ptr(), done.data_ptr()):
             return ws.rows_args
         K, m, mt = self.K, self.model, self.model_target
-        dims = self._rows_dims(x.shape[1])
+        dims = self._rows_dims(x.shape[1], x.shape[0])
         ws.rows_packed = torch.zeros(K.ddpg_rows_packed_floats(*dims), device=self.device)
         ws.rows_versions = None          # nothing packed yet
         if not hasattr(ws, 'ga'):
@@ -604,7 +604,7 @@ class DDPGLearner(Learner):
             return self._enqueue_iteration_ln(ws, x, xn, actions, rewards, done, pix, pix_next)
         if not (self.is_pixel_input or self.use_double_critic):
             rows = self.row_schedule if self.row_schedule is not None else x.shape[0] <= 1024
-            if rows and self._rows_dims(x.shape[1]) is not None:
+            if rows and self._rows_dims(x.shape[1], x.shape[0]) is not None:
                 return self._enqueue_iteration_rows(ws, x, xn, actions, rewards, done)
             if self.level_schedule and self.world_size == 1:
                 return self._enqueue_iteration_levels(ws, x, xn, actions, rewards, done)

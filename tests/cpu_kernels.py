@@ -971,7 +971,7 @@ class TorchCpuKernels(object):
     # ---- one DDPG iteration on row blocks: the CPU double works from the row-major parameters (the packed copy is what
     # the HIP kernels read; a stale copy would go unnoticed here, so the double keeps its OWN snapshot, refreshed by
     # ddpg_rows_pack exactly as the packed copy is)
-    def ddpg_rows_supported(self, D, A, H1, H2, c1, c2):
+    def ddpg_rows_supported(self, D, A, H1, H2, c1, c2, rows=None):
         return all(v % 4 == 0 for v in (H1, H2, c1, c2)) and A <= 32
 
     def ddpg_rows_packed_floats(self, D, A, H1, H2, c1, c2):

@@ -182,3 +182,44 @@ def test_parameters_written_from_outside_are_repacked():
     sa, sb = dict(rows.learn(mk(3))), dict(levels.learn(mk(3)))
     for k in sb:
         np.testing.assert_allclose(sa[k], sb[k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('D,A,ah,ch,B', [
+    (1, 1, (4, 4), (4, 4), 5),                    # the smallest shapes the row kernels take
+    (50, 32, (1024, 64), (64, 1024), 130),        # two head tiles; K = 1024 split over the waves in two trips; 33 blocks
+    (300, 17, (300, 200), (400, 300), 1024),      # the largest batch on 4-row blocks
+    (2048, 3, (128, 36), (36, 128), 64),          # the widest observation
+    (17, 6, (304, 204), (404, 300), 515),         # tile counts off the multiples of eight, a ragged last block
+])
+def test_row_blocks_shape_sweep_against_the_level_schedule(D, A, ah, ch, B):
+    """shapes around the row kernels' branches (split-K heads, passes of 32 feature tiles, chunk counts 4 j and 4 j + 2,
+    ragged last blocks): one iteration's buffers against the level schedule's, as in
+    test_row_block_launches_fill_the_level_schedules_buffers"""
+    import copy
+    import torch
+    from surreal_amd import synthetic
+    g, case = DH.load('tiny_soft_clipcritic')
+    # (soft target update; the learning rates of configs[2] -- at the tiny cases' 1e-2 an Adam step of the critic on a
+    # noise-floor gradient moves the ACTOR phase of the same iteration by per cents: ReLU masks of Q(s, mu(s)) flip)
+    case = dict(case, D=D, A=A, ah=list(ah), ch=list(ch), B=B, hyper=dict(case['hyper'], lr_actor=1e-4, lr_critic=1e-3))
+    rows, levels = DH.make_learner(case, {'ddpg_row_schedule': True}), DH.make_learner(case, {'ddpg_row_schedule': False})
+    b = synthetic.make_ddpg_batch(B, D, A, seed=91)
+    rows.learn(copy.deepcopy(b))
+    levels.learn(copy.deepcopy(b))
+    torch.cuda.synchronize()
+    wr, wl = rows._ws, levels._ws
+    assert getattr(wr, 'rows_args', None) is not None and getattr(wl, 'rows_args', None) is None
+    c1 = rows.model.c1
+    pairs = [(k, getattr(wr, k), getattr(wl, k)) for k in ('xcat', 'h2c', 'q', 'q_next', 'y', 'dz3', 'h1a', 'h2a', 'act',
+                                                           'q_actor', 'dz3a', 'dz2a', 'dz1a', 'grads_c', 'grads_a')]
+    pairs.append(('dz1 (critic)', wr.dxcat[:, :c1], wl.dxcat[:, :c1]))
+    for k, x, y in pairs:
+        scale = float(y.abs().max()) + 1e-30
+        d = float((x - y).abs().max())
+        assert d <= 2e-6 * max(scale, 1.0) + 2e-5 * scale, '%s: max |diff| %g at scale %g' % (k, d, scale)
+    rows.learn(copy.deepcopy(synthetic.make_ddpg_batch(B, D, A, seed=92)))     # (the update launches' copies, twice)
+    torch.cuda.synchronize()
+    kept = wr.rows_packed.clone()
+    rows.K.ddpg_rows_pack(wr.rows_args)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, wr.rows_packed)
