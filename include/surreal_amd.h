@@ -893,6 +893,13 @@ typedef struct smx_ddpg_update {
 enum { SMX_DDPG_GROUP_ACTOR = 0, SMX_DDPG_GROUP_CRITIC = 1 };
 int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* args, int32_t group, const smx_ddpg_update_t* update,
                              smx_stream_t stream);
+/* The same step with the group's weight gradients formed in the SAME launch (one rank: nothing to exchange between them):
+ * dW = dz^T x and db = the column sums of dz over args->rows rows, from the buffers the chain launches wrote (critic:
+ * dxcat / dz2 / dz3 against x / xcat / h2c; actor: dz1a / dz2a / dz3a against x / h1a / h2a), written to update->grads
+ * (laid out like theta) and stepped while still in the accumulators.  update->n must be exactly the three layers'
+ * weights and biases. */
+int smx_ddpg_rows_wgrad_update_f32(const smx_ddpg_rows_t* args, int32_t group, const smx_ddpg_update_t* update,
+                                   smx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM stem (surreal/model/ppo_net.py:143-152: nn.LSTM(in, rnn_hidden, 1, batch_first=True) in

@@ -77,3 +77,21 @@ if os.environ.get('SMX_DDPG_TBUF'):
             ds = np.median(np.diff(full[:, 16 + 5 * k:21 + 5 * k], axis=1), axis=0)
             print('   %-14s %8.0f   inside the layer (wave 0): entry %.0f  K loop %.0f  epilogue %.0f  barrier %.0f'
                   % (n, v, *ds))
+
+if os.environ.get('SMX_DDPG_TBUF'):
+    # the fused weight-gradient + update launch (critic group), by phase
+    nbw = 160
+    tb = torch.zeros(nbw, 128, dtype=torch.int64, device='cuda')
+    lib.smx_ddpg_rows_debug_tbuf(ctypes.c_void_p(tb.data_ptr()))
+    soft = L.target_update_type == 'soft'
+    L.K.ddpg_rows_update(args, 'critic', L.model.critic_flat, ws.grads_c, L.critic_exp_avg, L.critic_exp_avg_sq, ws.lr[1:2], ws.step,
+                         L.critic_regularization, L.critic_gradient_clip_value, target=L.model_target.critic_flat,
+                         tau=L.target_update_tau if soft else 0.0, interval=0 if soft else L.target_update_interval, wgrad=True)
+    torch.cuda.synchronize()
+    lib.smx_ddpg_rows_debug_tbuf(None)
+    t = tb.cpu().numpy().astype(np.float64)
+    t = t[t[:, 0] > 0][:, :6]
+    d = np.diff(t, axis=1)
+    print('wgrad + update launch (critic), %d workgroups, cycles (median): loads issued %.0f  params requested + bias corrections %.0f  '
+          'products (waits for the loads) %.0f  meet + barrier %.0f  epilogue %.0f  total %.0f; first start -> last end %.0f'
+          % ((len(t),) + tuple(np.median(d, axis=0)) + (np.median(t[:, 5] - t[:, 0]), t[:, 5].max() - t[:, 0].min())))

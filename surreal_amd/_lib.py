@@ -304,6 +304,7 @@ _SIGS = {
     'smx_ddpg_rows_critic_f32': (c_int32, [_P, _P]),
     'smx_ddpg_rows_actor_f32': (c_int32, [_P, _P]),
     'smx_ddpg_rows_update_f32': (c_int32, [_P, c_int32, _P, _P]),
+    'smx_ddpg_rows_wgrad_update_f32': (c_int32, [_P, c_int32, _P, _P]),
     'smx_ddpg_stats_f32': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int64, _P, _P]),
     'smx_lstm_param_count': (c_int64, [c_int32, c_int32]),
     'smx_lstm_forward_f32': (c_int32, [POINTER(Lstm), _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P,

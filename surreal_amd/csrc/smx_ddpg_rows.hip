@@ -665,6 +665,19 @@ __global__ __launch_bounds__(256) void ddpg_pack_kernel(PArgs P) {
     *(float4*)(P.packed + 4 * w0) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// beta^n for Adam's bias corrections by repeated squaring: ~40 double multiplications instead of pow()'s several hundred
+// instructions -- the two powers were 3 us of ONE lane with the whole launch waiting behind it (phase stamps: 7 k cycles
+// at the barrier).  Within a few ulp of pow's double result; the coefficients are rounded to float afterwards.
+__device__ __forceinline__ double ipow(double b, int n) {
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= b;
+        b *= b;
+        n >>= 1;
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // one optimiser group's step for the row schedule: Adam (smx_adam_step_dev_f32's expressions), the target update of the
 // group's target network (smx_soft_update_f32 / smx_hard_update_every_f32's) and BOTH fragment-order copies, element by
@@ -683,6 +696,7 @@ struct UMat {
 struct UArgs {
     float* theta;
     const float* grads;
+    float* grads_out;             // the fused weight-gradient launch writes the gradient it steps with here
     float *m, *v, *target, *packed;
     long n;
     const float* lr;
@@ -696,10 +710,8 @@ __global__ __launch_bounds__(256) void ddpg_rows_update_kernel(UArgs U) {
     __shared__ float coef[2];
     __shared__ int upd;
     if (threadIdx.x == 0) {
-        const double beta1 = 0.9, beta2 = 0.999;
         const int st = *U.step;
-        const double step = (double)st;
-        const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+        const double bc1 = 1.0 - ipow(0.9, st), bc2 = 1.0 - ipow(0.999, st);
         coef[0] = (float)(-((double)*U.lr / bc1));
         coef[1] = (float)sqrt(bc2);
         upd = U.interval > 0 ? (st % U.interval == 0) : 1;
@@ -746,6 +758,212 @@ __global__ __launch_bounds__(256) void ddpg_rows_update_kernel(UArgs U) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The group's weight gradients AND its step in one launch (single rank): dW = dz^T x and db = column sums of dz over the
+// batch rows, then -- the gradient still in the accumulators -- the element's Adam step, target update and packed copies
+// as in ddpg_rows_update_kernel (value clipping is elementwise: no norm over the group is needed first, which is what keeps
+// PPO's clip-norm step a launch of its own).  Replaces smx_linear_multi_f32 (9 us at batch 512) + the update launch (6 us)
+// and the gap between them.
+//
+// A workgroup owns a 32 x 32 tile of one matrix: wave w forms ALL of it over the w-th eighth of the rows on
+// v_mfma_f32_16x16x4 (four quadrant accumulators; lane (i, g): a = dz[k + g][m0 + i], b = x[k + g][n0 + i], four rows
+// per instruction), the operands of its 64 rows requested at once; the eight partial tiles meet through LDS in row order
+// and every thread steps two elements.  Another summation order than smx_linear_wgrad_f32's: equal within fp32 rounding.
+// ---------------------------------------------------------------------------------------------------------------
+struct WMat {
+    const float* dz;              // [rows][M], row stride ldz
+    const float* x;               // [rows][N], row stride ldx
+    int ldz, ldx, tiles_n, tile0; // tile0: first workgroup of this matrix
+    long boff;                    // the bias [M] inside the group's buffer
+};
+struct WUArgs {
+    UArgs U;
+    WMat w[3];
+    int rows;
+    long long* tbuf;              // SMX_DDPG_TIMING builds
+};
+#ifdef SMX_DDPG_TIMING
+#define WSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 128 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
+
+#define MFMA16W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void ddpg_step_element(const UArgs& U, long i, float g, float p, float mi, float vi, float tg,
+                                                  float neg_step_size, float bc2_sqrt, int upd, float& pn, float& tn,
+                                                  bool& tw) {
+    const float w1 = (float)(1.0 - 0.9), b2f = (float)0.999, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
+    if (U.clip_value > 0.f) g = fminf(fmaxf(g, -U.clip_value), U.clip_value);
+    if (U.wd != 0.f) g = g + U.wd * p;
+    mi = mi + w1 * (g - mi);
+    vi = vi * b2f + w2 * (g * g);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pn = p + (neg_step_size * mi) / denom;
+    U.theta[i] = pn;
+    U.m[i] = mi;
+    U.v[i] = vi;
+    tw = false;
+    tn = 0.f;
+    if (U.target && upd) {
+        tn = (U.interval > 0 || U.tau >= 1.0f) ? pn : (tg * (1.0f - U.tau) + pn * U.tau);
+        U.target[i] = tn;
+        tw = true;
+    }
+}
+
+constexpr int WNW = 8;            // waves per tile: wave w takes the w-th eighth of the rows, the WHOLE 32 x 32 tile
+constexpr int WUB = 16;           // steps (of four rows) a wave requests at once: 64 rows, 64 loads in flight
+
+__global__ __launch_bounds__(64 * WNW) void ddpg_rows_wgrad_update_kernel(WUArgs G) {
+    __shared__ float red[WNW][4][64][4];            // every wave's four quadrant accumulators (32 KB)
+    __shared__ float redb[WNW][32];                 // ... and its column sums of dz
+    __shared__ float coef[2];
+    __shared__ int upd_s;
+    const UArgs& U = G.U;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    WSTAMP(0);
+    // consecutive workgroup ids land on the eight XCDs round-robin, each with its own L2: XCD x takes the x-th contiguous
+    // eighth of the tile list (tiles are row-major in M: a band of dz columns and all of x) instead of every eighth tile,
+    // or all eight L2s pull every operand across the fabric (as smx_gemm.hip's gemm32 does)
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x, qd = total >> 3, rem = total & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        bid = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + slot;
+    }
+    const int j = (bid >= G.w[2].tile0) ? 2 : (bid >= G.w[1].tile0) ? 1 : 0;
+    const WMat W = G.w[j];
+    const UMat X = U.mat[j];
+    const int tile = bid - W.tile0;
+    const int tm = tile / W.tiles_n, tn_ = tile - tm * W.tiles_n;
+    const int m0 = 32 * tm, n0 = 32 * tn_;
+    const int rows = G.rows;
+    const int qrows = ((rows + 4 * WNW - 1) / (4 * WNW)) << 2;      // rows per wave (a multiple of four)
+    const int k_lo = wv * qrows;
+    int k_hi = k_lo + qrows;
+    k_hi = k_hi < rows ? k_hi : rows;
+    // addressing: the lane's part (row g of a step, its column) is a vector offset formed ONCE, the step's rows a SCALAR
+    // offset -- no vector instruction between the loads.  The descriptors end at the wave's last row: the range check
+    // counts the scalar offset in, so a row past k_hi (or a column past the matrix: OOB) loads 0.
+    const rsrc_t rzk = make_rsrc(W.dz, (unsigned)(k_hi > 0 ? k_hi : 0) * (unsigned)W.ldz * 4u);
+    const rsrc_t rxk = make_rsrc(W.x, (unsigned)(k_hi > 0 ? k_hi : 0) * (unsigned)W.ldx * 4u);
+    const unsigned gz = (unsigned)g * (unsigned)W.ldz, gx = (unsigned)g * (unsigned)W.ldx;
+    const unsigned vz0 = (m0 + i < X.M) ? (gz + (unsigned)(m0 + i)) * 4u : OOB;
+    const unsigned vz1 = (m0 + 16 + i < X.M) ? (gz + (unsigned)(m0 + 16 + i)) * 4u : OOB;
+    const unsigned vx0 = (n0 + i < X.K) ? (gx + (unsigned)(n0 + i)) * 4u : OOB;
+    const unsigned vx1 = (n0 + 16 + i < X.K) ? (gx + (unsigned)(n0 + 16 + i)) * 4u : OOB;
+    const unsigned sz = 16u * (unsigned)W.ldz, sx = 16u * (unsigned)W.ldx;      // bytes per step of four rows
+#define SMX_LDW(R, v, k, sb) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(R, v, (unsigned)(k) / 4u * (sb), 0))
+    // Every wave forms the whole tile over ITS rows: a step is four loads (two halves of the dz columns, two of the x
+    // columns: each 64-byte segment is requested once per workgroup) for four products.  As quadrant waves over half the
+    // rows each segment was requested twice and the launch waited on its 4096 requests per workgroup (phase stamps: the
+    // last wave's operands arrived 17 k cycles in).
+    float a0[WUB], a1[WUB], b0[WUB], b1[WUB];
+#pragma unroll
+    for (int u = 0; u < WUB; ++u) {
+        a0[u] = SMX_LDW(rzk, vz0, k_lo + 4 * u, sz); a1[u] = SMX_LDW(rzk, vz1, k_lo + 4 * u, sz);
+        b0[u] = SMX_LDW(rxk, vx0, k_lo + 4 * u, sx); b1[u] = SMX_LDW(rxk, vx1, k_lo + 4 * u, sx);
+    }
+    WSTAMP(1);
+    // the two elements this THREAD steps once the waves' sums have met: (ml, nl) and (ml + 16, nl) of the tile, threads
+    // along n (coalesced); their parameters and moments are requested behind the operands
+    const int ml = tid >> 5, nl = tid & 31;
+    long ei[2];
+    float p2[2], m2[2], v2[2], t2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int m = m0 + ml + 16 * e, n = n0 + nl;
+        const bool ok = m < X.M && n < X.K;
+        ei[e] = ok ? X.off + (long)m * X.K + n : -1;
+        const long c = ok ? ei[e] : X.off;
+        p2[e] = U.theta[c]; m2[e] = U.m[c]; v2[e] = U.v[c];
+        t2[e] = U.target ? U.target[c] : 0.f;
+    }
+    // the bias of row m0 + tid (column tile 0, the first 32 threads)
+    const bool bok = tn_ == 0 && tid < 32 && m0 + tid < X.M;
+    const long bi = bok ? W.boff + m0 + tid : W.boff;
+    const float bp = U.theta[bi], bm = U.m[bi], bv = U.v[bi], bt = U.target ? U.target[bi] : 0.f;
+    if (tid == 64 * (WNW - 1)) {                    // Adam's bias corrections, while the loads are on their way
+        const int st = *U.step;
+        const double bc1 = 1.0 - ipow(0.9, st), bc2 = 1.0 - ipow(0.999, st);
+        coef[0] = (float)(-((double)*U.lr / bc1));
+        coef[1] = (float)sqrt(bc2);
+        upd_s = U.interval > 0 ? (st % U.interval == 0) : 1;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) acc[qq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float as0 = 0.f, as1 = 0.f;
+    WSTAMP(2);
+#pragma unroll 1
+    for (int k = k_lo; k < k_hi; k += 4 * WUB) {
+#pragma unroll
+        for (int u = 0; u < WUB; ++u) {
+            acc[0] = MFMA16W(a0[u], b0[u], acc[0]);
+            acc[1] = MFMA16W(a0[u], b1[u], acc[1]);
+            acc[2] = MFMA16W(a1[u], b0[u], acc[2]);
+            acc[3] = MFMA16W(a1[u], b1[u], acc[3]);
+            as0 += a0[u];
+            as1 += a1[u];
+        }
+        if (k + 4 * WUB < k_hi) {                   // (more than 512 rows: the next 64 of this wave's)
+#pragma unroll
+            for (int u = 0; u < WUB; ++u) {
+                a0[u] = SMX_LDW(rzk, vz0, k + 4 * (WUB + u), sz); a1[u] = SMX_LDW(rzk, vz1, k + 4 * (WUB + u), sz);
+                b0[u] = SMX_LDW(rxk, vx0, k + 4 * (WUB + u), sx); b1[u] = SMX_LDW(rxk, vx1, k + 4 * (WUB + u), sx);
+            }
+        }
+    }
+#undef SMX_LDW
+    WSTAMP(3);
+    // quadrant qq = 2 (m half) + (n half): lane (i, g) holds rows 16 (qq >> 1) + 4 g + r, column 16 (qq & 1) + i
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) *(f32x4*)&red[wv][qq][lane][0] = acc[qq];
+    as0 = meet_kq1(as0);                            // every lane of column i: the sum over this wave's rows
+    as1 = meet_kq1(as1);
+    if (g == 0) { redb[wv][i] = as0; redb[wv][16 + i] = as1; }
+    __syncthreads();
+    WSTAMP(4);
+    const float neg_step_size = coef[0], bc2_sqrt = coef[1];
+    const int upd = upd_s;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (ei[e] >= 0) {
+            const int mm = ml + 16 * e;                                       // (inside the tile)
+            const int qq = ((mm >> 4) << 1) | (nl >> 4), ln = 16 * ((mm & 15) >> 2) + (nl & 15), r = mm & 3;
+            float gsum = red[0][qq][ln][r];
+#pragma unroll
+            for (int w = 1; w < WNW; ++w) gsum += red[w][qq][ln][r];          // the waves' row ranges in order
+            U.grads_out[ei[e]] = gsum;
+            float pn, tn;
+            bool tw;
+            ddpg_step_element(U, ei[e], gsum, p2[e], m2[e], v2[e], t2[e], neg_step_size, bc2_sqrt, upd, pn, tn, tw);
+            const int gm = m0 + mm, kk = n0 + nl;
+            const long pos = pack_pos(X.K, gm, kk);
+            U.packed[X.base + pos] = pn;
+            if (tw) U.packed[X.base_tgt + pos] = tn;
+            if (kk < X.split) {
+                if (X.base_t0 >= 0) U.packed[X.base_t0 + pack_pos(X.M, kk, gm)] = pn;
+            } else if (X.base_t1 >= 0) {
+                U.packed[X.base_t1 + pack_pos(X.M, kk - X.split, gm)] = pn;
+            }
+        }
+    }
+    if (bok) {
+        float gb = redb[0][tid];
+#pragma unroll
+        for (int w = 1; w < WNW; ++w) gb += redb[w][tid];
+        U.grads_out[bi] = gb;
+        float pn, tn;
+        bool tw;
+        ddpg_step_element(U, bi, gb, bp, bm, bv, bt, neg_step_size, bc2_sqrt, upd, pn, tn, tw);
+    }
+    WSTAMP(5);
 }
 
 // block order of the packed buffer
@@ -1026,19 +1244,15 @@ extern "C" int smx_ddpg_rows_actor_f32(const smx_ddpg_rows_t* a, smx_stream_t st
     return SMX_OK;
 }
 
-extern "C" int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* a, int32_t group, const smx_ddpg_update_t* u,
-                                        smx_stream_t stream) {
-    SMX_REQUIRE(a && a->packed && u, SMX_E_NULL);
+namespace {
+int fill_update(UArgs& U, const smx_ddpg_rows_t* a, int32_t group, const smx_ddpg_update_t* u, const Dims& d) {
     SMX_REQUIRE(u->theta && u->grads && u->exp_avg && u->exp_avg_sq && u->lr && u->step, SMX_E_NULL);
     SMX_REQUIRE(group == SMX_DDPG_GROUP_ACTOR || group == SMX_DDPG_GROUP_CRITIC, SMX_E_SHAPE);
     SMX_REQUIRE(u->n > 0 && u->interval >= 0 && (u->target == nullptr || u->interval > 0 || u->tau > 0.f), SMX_E_SHAPE);
-    const Dims d = dims_of(*a);
-    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
     const bool cr = group == SMX_DDPG_GROUP_CRITIC;
     const smx_ddpg_net_t& net = cr ? a->critic : a->actor;
     const smx_ddpg_net_t& tnet = cr ? a->target_critic : a->target_actor;
     SMX_REQUIRE(net.W1 && net.W2 && net.W3, SMX_E_NULL);
-    UArgs U;
     memset(&U, 0, sizeof(U));
     U.theta = u->theta; U.grads = u->grads; U.m = u->exp_avg; U.v = u->exp_avg_sq; U.target = u->target;
     U.packed = a->packed; U.n = u->n; U.lr = u->lr; U.step = u->step; U.wd = u->weight_decay;
@@ -1067,7 +1281,68 @@ extern "C" int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* a, int32_t group,
         U.mat[1].base_t0 = 4 * block_base(d, B_AW2T);
         U.mat[2].base_t0 = 4 * block_base(d, B_AW3T);
     }
+    return SMX_OK;
+}
+}  // namespace
+
+extern "C" int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* a, int32_t group, const smx_ddpg_update_t* u,
+                                        smx_stream_t stream) {
+    SMX_REQUIRE(a && a->packed && u, SMX_E_NULL);
+    const Dims d = dims_of(*a);
+    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
+    UArgs U;
+    const int rc = fill_update(U, a, group, u, d);
+    if (rc) return rc;
     hipLaunchKernelGGL(ddpg_rows_update_kernel, dim3((unsigned)((u->n + 255) / 256)), dim3(256), 0, smx_s(stream), U);
+    SMX_LAUNCH_CHECK();
+    return SMX_OK;
+}
+
+extern "C" int smx_ddpg_rows_wgrad_update_f32(const smx_ddpg_rows_t* a, int32_t group, const smx_ddpg_update_t* u,
+                                              smx_stream_t stream) {
+    SMX_REQUIRE(a && a->packed && u, SMX_E_NULL);
+    const Dims d = dims_of(*a);
+    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(a->rows > 0 && a->rows < (1 << 24), SMX_E_SHAPE);
+    WUArgs G;
+    memset(&G, 0, sizeof(G));
+    const int rc = fill_update(G.U, a, group, u, d);
+    if (rc) return rc;
+    G.U.grads_out = const_cast<float*>(u->grads);
+    G.rows = (int)a->rows;
+    G.tbuf = g_tbuf;
+    const bool cr = group == SMX_DDPG_GROUP_CRITIC;
+    const smx_ddpg_net_t& net = cr ? a->critic : a->actor;
+    const smx_ddpg_net_t& tnet = cr ? a->target_critic : a->target_actor;
+    const int ldc = d.c1 + d.A;
+    // (gradient, input) of the three layers: the buffers the chain launches wrote
+    const float* dz[3] = {cr ? a->dxcat : a->dz1a, cr ? a->dz2 : a->dz2a, cr ? a->dz3 : a->dz3a};
+    const int ldz[3] = {cr ? ldc : d.H1, cr ? d.c2 : d.H2, cr ? 1 : d.A};
+    const float* x[3] = {a->x, cr ? a->xcat : a->h1a, cr ? a->h2c : a->h2a};
+    const int ldx[3] = {d.D, cr ? ldc : d.H1, cr ? d.c2 : d.H2};
+    const float* b[3] = {net.b1, net.b2, net.b3};
+    const float* tb[3] = {tnet.b1, tnet.b2, tnet.b3};
+    int tiles = 0;
+    for (int j = 0; j < 3; ++j) {
+        SMX_REQUIRE(dz[j] && x[j] && b[j], SMX_E_NULL);
+        WMat& W = G.w[j];
+        const UMat& X = G.U.mat[j];
+        W.dz = dz[j]; W.ldz = ldz[j]; W.x = x[j]; W.ldx = ldx[j];
+        W.boff = b[j] - u->theta;
+        SMX_REQUIRE(W.boff >= 0 && W.boff + X.M <= u->n, SMX_E_SHAPE);
+        if (u->target) SMX_REQUIRE(tb[j] && tb[j] - u->target == W.boff, SMX_E_SHAPE);
+        SMX_REQUIRE((int64_t)a->rows * (ldz[j] > ldx[j] ? ldz[j] : ldx[j]) * 4 < (1ll << 31), SMX_E_SHAPE);
+        W.tiles_n = (X.K + 31) / 32;
+        W.tile0 = tiles;
+        tiles += ((X.M + 31) / 32) * W.tiles_n;
+    }
+    // every element of the group's buffer is a weight or a bias of the three layers: nothing is left without its step
+    {
+        long covered = 0;
+        for (int j = 0; j < 3; ++j) covered += (long)G.U.mat[j].M * G.U.mat[j].K + G.U.mat[j].M;
+        SMX_REQUIRE(covered == u->n, SMX_E_SHAPE);
+    }
+    hipLaunchKernelGGL(ddpg_rows_wgrad_update_kernel, dim3((unsigned)tiles), dim3(64 * WNW), 0, smx_s(stream), G);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

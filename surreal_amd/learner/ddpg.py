@@ -114,6 +114,8 @@ class DDPGLearner(Learner):
         # force it on (where the shapes allow) / off.
         rs = self.session_config.learner.get('ddpg_row_schedule', None)
         self.row_schedule = None if rs is None else bool(rs)
+        # ... with a group's weight gradients formed in its update launch (one rank)
+        self.rows_fused_update = bool(self.session_config.learner.get('ddpg_rows_fused_update', True))
 
     # ---- target update (ddpg.py:389-428) ----------------------------------------------------
     def _target_update_init(self):
@@ -420,22 +422,27 @@ class DDPGLearner(Learner):
             self._rows_refresh(ws)
         soft = self.target_update_type == 'soft'
         tgt = dict(tau=self.target_update_tau if soft else 0.0, interval=0 if soft else self.target_update_interval)
+        # one rank: a group's weight gradients and its step are ONE launch (value clipping needs no norm over the group);
+        # several: the gradients are averaged over the ranks between them
+        fuse = self.world_size == 1 and self.rows_fused_update
         K.ddpg_rows_critic(args)
-        K.linear_multi([('wgrad', ws.dxcat, x, gc['W1'], gc['b1'], c1, D, B, dict(ldz=ld)),
-                        ('wgrad', ws.dz2, ws.xcat, gc['W2'], gc['b2'], c2, ld, B, {}),
-                        ('wgrad', ws.dz3.view(B, 1), ws.h2c, gc['W3'], gc['b3'], 1, c2, B, dict(ldz=1))])
-        self._average_over_ranks(ws.grads_c)
+        if not fuse:
+            K.linear_multi([('wgrad', ws.dxcat, x, gc['W1'], gc['b1'], c1, D, B, dict(ldz=ld)),
+                            ('wgrad', ws.dz2, ws.xcat, gc['W2'], gc['b2'], c2, ld, B, {}),
+                            ('wgrad', ws.dz3.view(B, 1), ws.h2c, gc['W3'], gc['b3'], 1, c2, B, dict(ldz=1))])
+            self._average_over_ranks(ws.grads_c)
         K.ddpg_rows_update(args, 'critic', m.critic_flat, ws.grads_c, self.critic_exp_avg, self.critic_exp_avg_sq,
                            ws.lr[1:2], ws.step, self.critic_regularization, self.critic_gradient_clip_value,
-                           target=mt.critic_flat, **tgt)
+                           target=mt.critic_flat, wgrad=fuse, **tgt)
         K.ddpg_rows_actor(args)
-        K.linear_multi([('wgrad', ws.dz1a, x, ga['W1'], ga['b1'], H1, D, B, {}),
-                        ('wgrad', ws.dz2a, ws.h1a, ga['W2'], ga['b2'], H2, H1, B, {}),
-                        ('wgrad', ws.dz3a, ws.h2a, ga['W3'], ga['b3'], A, H2, B, {})])
-        self._average_over_ranks(ws.grads_a)
+        if not fuse:
+            K.linear_multi([('wgrad', ws.dz1a, x, ga['W1'], ga['b1'], H1, D, B, {}),
+                            ('wgrad', ws.dz2a, ws.h1a, ga['W2'], ga['b2'], H2, H1, B, {}),
+                            ('wgrad', ws.dz3a, ws.h2a, ga['W3'], ga['b3'], A, H2, B, {})])
+            self._average_over_ranks(ws.grads_a)
         K.ddpg_rows_update(args, 'actor', m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                            ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value,
-                           target=mt.actor_flat, **tgt)
+                           target=mt.actor_flat, wgrad=fuse, **tgt)
         K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
         self._average_over_ranks(ws.stats[:6])
         ws.rows_versions = self._rows_versions()

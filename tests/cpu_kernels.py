@@ -987,9 +987,27 @@ class TorchCpuKernels(object):
             args.snap[name] = {k: v.clone() for k, v in args.nets[name].items()}
 
     def ddpg_rows_update(self, args, group, theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value,
-                         target=None, tau=0.0, interval=0):
+                         target=None, tau=0.0, interval=0, wgrad=False):
         """Adam + the group's target update + BOTH snapshots (the kernel keeps the packed copies of the group and of its
-        target current; nothing else is refreshed -- a schedule that relied on more would fail the goldens here)"""
+        target current; nothing else is refreshed -- a schedule that relied on more would fail the goldens here).
+        wgrad: the group's weight gradients first, from the buffers the chain launches wrote, into `grads` (laid out like
+        theta: W1, b1, W2, b2, W3, b3)"""
+        if wgrad:
+            io = args.io
+            D, A, H1, H2, c1, c2 = args.dims
+            x = io['x']
+            if group == 'critic':
+                pairs = [(io['dxcat'][:, :c1], x), (io['dz2'], io['xcat']), (io['dz3'].view(-1, 1), io['h2c'])]
+            else:
+                pairs = [(io['dz1a'], x), (io['dz2a'], io['h1a']), (io['dz3a'], io['h2a'])]
+            o = 0
+            for dz, xin in pairs:
+                M, N = dz.shape[1], xin.shape[1]
+                grads[o:o + M * N].copy_((dz.t() @ xin).reshape(-1))
+                o += M * N
+                grads[o:o + M].copy_(dz.sum(0))
+                o += M
+            assert o == grads.numel()
         self.adam_step_dev(theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value)
         if target is not None:
             if interval > 0:

@@ -27,6 +27,9 @@ def test_ddpg_learner_matches_reference_golden_both_schedules(name):
     assert getattr(L._ws, 'rows_args', None) is not None
     L = DH.run_and_check(name, opts={'ddpg_row_schedule': False})
     assert getattr(L._ws, 'rows_args', None) is None
+    # ... and with the weight gradients as their own launch in front of the update launch (what several ranks run)
+    L = DH.run_and_check(name, opts={'ddpg_rows_fused_update': False})
+    assert getattr(L._ws, 'rows_args', None) is not None
 
 
 @pytest.mark.parametrize('name', ROWS_CASES)
