@@ -835,17 +835,16 @@ int smx_ddpg_stats_f32(const float* q, const float* y, const float* rewards,
 
 /* --- one DDPG iteration on ROW BLOCKS (round 5; surreal/learner/ddpg.py:244-352, low-dimensional observations, one critic) ---
  * The layer-by-layer schedule above is ~19 dependent launches of 512-row problems.  Batch rows are independent up to the
- * weight gradients, so a workgroup carries a block of rows through whole chains: 4 rows up to 1024 rows (round 6: the
- * v_mfma_f32_4x4x1 loop of the rollout kernel, the chain as a table of layer steps in the kernel arguments), 16 rows beyond
- * (the MFMA row-block loop of the fused PPO epochs):
+ * weight gradients, so a workgroup carries FOUR rows through whole chains (round 6: the v_mfma_f32_4x4x1 loop of the
+ * rollout kernel, the chain as a table of layer steps in the kernel arguments; the learner uses it up to 1024 rows per rank):
  *   smx_ddpg_rows_critic_f32  mu'(s') -> Q'(s', mu'(s')) (target networks); Q(s, a); y = r + gamma^n Q' (1 - done) and
  *                             dz3 = 2 (Q - y) / rows (ddpg.py:279, 307-308); *step += 1; the critic's data gradients
  *                             dz2 [rows, c2] and dz1 (first c1 columns of dxcat); mu(s) for the actor phase (h1a, h2a, act)
- *   smx_ddpg_rows_actor_f32   Q(s, mu(s)) through the critic as it is NOW (after its Adam step and a
- *                             smx_ddpg_rows_pack_f32(SMX_DDPG_PACK_CRITIC)) -> q_actor; d(-mean Q)/d(action) through tanh
+ *   smx_ddpg_rows_actor_f32   Q(s, mu(s)) through the critic as it is NOW (after its step, which keeps the
+ *                             packed copy current) -> q_actor; d(-mean Q)/d(action) through tanh
  *                             -> dz3a; the actor's data gradients dz2a, dz1a (ddpg.py:326-331)
- * The weight gradients (sums over all rows), Adam, the target update and the statistics stay the launches declared above,
- * on the same row-major buffers.  Weights are read from a copy in MFMA fragment order (`packed`,
+ * The weight gradients (sums over all rows) and the optimiser step are smx_ddpg_rows_wgrad_update_f32 (one rank) or the
+ * launches declared above around smx_ddpg_rows_update_f32 (several), on the same row-major buffers.  Weights are read from a copy in MFMA fragment order (`packed`,
  * smx_ddpg_rows_packed_floats floats, 16-byte aligned) which smx_ddpg_rows_pack_f32 refreshes from the row-major
  * parameters: every network (SMX_DDPG_PACK_ALL) or the critic's blocks only.  xcat / dxcat have row stride c1 + A.
  * H1, H2, c1, c2 multiples of 4, A <= 32: smx_ddpg_rows_supported; otherwise SMX_E_UNSUPPORTED. */
@@ -866,7 +865,7 @@ typedef struct smx_ddpg_rows {
 } smx_ddpg_rows_t;
 enum { SMX_DDPG_PACK_ALL = 0, SMX_DDPG_PACK_CRITIC = 1 };
 int32_t smx_ddpg_rows_supported(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);   /* on 4-row blocks */
-/* ... for a batch of `rows`: past 1024 rows the 16-row blocks' tiles must fit the workgroup's LDS as well */
+/* ... for a batch of `rows` (the same answer for every row count since the 16-row kernels of round 5 are gone) */
 int32_t smx_ddpg_rows_supported_at(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2, int64_t rows);
 int64_t smx_ddpg_rows_packed_floats(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2);
 int smx_ddpg_rows_pack_f32(const smx_ddpg_rows_t* args, int32_t which, smx_stream_t stream);

@@ -56,7 +56,7 @@ if os.environ.get('SMX_DDPG_TBUF'):
     b = dev_batch(0)
     for _ in range(3):
         L.learn(copy.copy(b))
-    nb = (B + 3) // 4 if B <= 1024 else (B + 15) // 16
+    nb = (B + 3) // 4
     names_c = ['prologue+ta.L1', 'ta.L2', 'ta.L3', 'tc.L1', 'tc.L2', 'tc.L3', 'c.L1', 'c.L2', 'c.L3', 'loss+dz2+dz1', 'a.L1',
                'a.L2', 'a.L3']
     names_a = ['prologue+c.L1', 'c.L2', 'c.L3', 'dz2+W2Thi', 'tanh+aW3T', 'aW2T']

@@ -1,26 +1,26 @@
 // One DDPG iteration on ROW BLOCKS (surreal/learner/ddpg.py:244-352; low-dimensional observations, one critic):
 // the layer-by-layer schedule is ~19 dependent launches of 512-row problems, each a few microseconds of work behind a
-// launch boundary and an L2 first touch (0.21 ms per iteration, 70 % of it in 15 dense launches).  Batch rows are
-// independent up to the weight gradients, so here a workgroup owns 16 rows and carries them through whole chains, as the
-// fused PPO epoch kernels do (smx_epoch.hip; the same MFMA loop, smx_epoch_mma.inc.h, on the same packed weights):
+// launch boundary and an L2 first touch (0.19 ms per iteration, 70 % of it in 15 dense launches).  Batch rows are
+// independent up to the weight gradients, so here a workgroup owns FOUR rows and carries them through whole chains on the
+// 4-row loop of the rollout kernel (smx_rows4_mma.inc.h: v_mfma_f32_4x4x1, weights in the fragment order of
+// smx_epoch_pack.inc.h) -- configs[2]'s batch of 512 is 128 workgroups:
 //
-//   ddpg_critic_rows_kernel   target actor -> target critic -> Q'(s', mu'(s'));  critic -> Q(s, a);  y and dLoss/dQ;
+//   ddpg_rows4_kernel<0>      target actor -> target critic -> Q'(s', mu'(s'));  critic -> Q(s, a);  y and dLoss/dQ;
 //                             the critic's data gradients dz2, dz1;  the actor's forward pass for ITS update (it reads
 //                             only the actor's parameters, which the critic update does not touch)
-//   [weight gradients of the critic: smx_linear_multi_f32; Adam: smx_adam_step_dev_f32; the critic's packed copy]
-//   ddpg_actor_rows_kernel    Q(s, mu(s)) through the UPDATED critic; d(-mean Q)/d(action); tanh'; the actor's data
+//   ddpg_rows_wgrad_update    the critic's weight gradients, Adam, its target network's update, the packed copies
+//   ddpg_rows4_kernel<1>      Q(s, mu(s)) through the UPDATED critic; d(-mean Q)/d(action); tanh'; the actor's data
 //                             gradients dz2, dz1
-//   [weight gradients of the actor, Adam, target update, statistics]
+//   ddpg_rows_wgrad_update    the same for the actor;  [statistics: smx_ddpg_stats_f32]
 //
 // Activations and gradients that the weight-gradient launches read go to HBM row-major, exactly the buffers of the
-// layer-by-layer schedule.  Products are summed in the MFMA loop's order (32-wide K chunks, k ascending), not in
-// smx_linear_f32's: results agree with the layered schedule to fp32 rounding, not bit for bit.
+// layer-by-layer schedule.  Products are summed in the MFMA loop's order (32-wide K chunks, k ascending per lane group),
+// not in smx_linear_f32's: results agree with the layered schedule to fp32 rounding, not bit for bit.
 //
-// Round 6: up to 1024 rows a workgroup owns FOUR rows and runs the 4-row loop of smx_rows4_mma.inc.h
-// (v_mfma_f32_4x4x1, the same packed weights): configs[2]'s batch of 512 is 128 workgroups instead of 32.  The 16-row
-// blocks of round 5 were bound by the matrix pipes of 32 CUs (92 + 46 us for the two chains); 4-row blocks are bound by
-// what a CU pulls from L2 (every workgroup streams every weight once per layer), on four times as many CUs.  Past 1024
-// rows the 16-row blocks fill the chip and stream each weight a quarter as often: they stay for those.
+// History: round 5 built this on 16-row blocks and one noinline dense function (32 workgroups bound by the matrix pipes of
+// 32 CUs, 92 + 46 us for the two chains against the 145 us of the launches they replaced: slower, off by default); round 6
+// moved it to 4-row blocks (bound by what a CU pulls from L2 -- every workgroup streams every weight once per layer -- on
+// four times as many CUs: 42 + 22 us) and removed the 16-row kernels: they were never faster than the level schedule.
 #include "smx_common.h"
 #include <string.h>
 
@@ -33,11 +33,10 @@ namespace {
 
 constexpr int DNWV = 8;           // wavefronts per workgroup: two per SIMD (one's loads hide under the other's MFMAs)
 constexpr int DNTH = 64 * DNWV;
-constexpr int DTG = 3;            // feature tiles a wave carries per pass
+constexpr int RBLK = 4;           // batch rows per workgroup
 constexpr int LDO = 36;           // row stride of an output tile (<= 32 outputs)
-constexpr int LDK = 68;           // row stride of a tile that is the K <= 32 input of a product (two zero-padded chunks)
-constexpr int LDK4 = 80;          // the same on 4-row blocks (strides = 16 mod 64: the 16 (row, kq) readers on distinct banks)
-constexpr int DTG4 = 4;           // feature tiles a wave carries per pass on 4-row blocks (8 x 4 = 32 tiles: 400 features in one pass)
+constexpr int LDK4 = 80;          // row stride of a tile that is the K <= 32 input of a product (two zero-padded chunks; strides = 16 mod 64: the 16 (row, kq) readers on distinct banks)
+constexpr int DTG4 = 4;           // feature tiles a wave carries per pass (8 x 4 = 32 tiles: 400 features in one pass)
 constexpr int MAX_LDS = 128 * 1024;
 enum { A_NONE = 0, A_RELU = 1, A_TANH = 2, A_MASK = 3 };
 
@@ -48,124 +47,14 @@ struct PMat {                     // a matrix in fragment order (smx_epoch_pack.
     int M, K;
 };
 
-// one dense layer of a row block: out[16][M] = act(W . in + bias), tiles LDS -> LDS (and / or HBM, row-major)
-struct Dense {
-    int in_off, ldi;              // LDS input tile [16][ldi] (float offsets into the workgroup's dynamic LDS)
-    PMat W;
-    const float* bias;            // [M] or null
-    int act;                      // A_MASK: the result is zeroed where mask <= 0 (ReLU backward)
-    int mask_off, ldm;
-    int out_off, ldo;             // LDS output tile, < 0: none
-    float* g;                     // HBM output [rows][ldg] or null
-    int ldg;
-};
-
-#ifdef SMX_DDPG_TIMING
-#define DSTAMP(i) do { if (threadIdx.x == 0 && d_ts_l) d_ts_l[(i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#define DTS_PARAM , long long* d_ts_l
-#define DTS_ARG(ts) , (ts)
-#else
-#define DSTAMP(i) do { } while (0)
-#define DTS_PARAM
-#define DTS_ARG(ts)
-#endif
-
-// (noinline: a kernel calls this a dozen times; inlined, every call carries its own copies of the three loop bodies and
-// the workgroup -- which runs each instruction stream once -- spends its time fetching code, see smx_epoch_mma.inc.h)
-__device__ __noinline__ void dense16v(int in_off_, int ldi_, const float* Wp_, int M_, int K_, const float* bias_, int act_,
-                                      int mask_off_, int ldm_, int out_off_, int ldo_, float* g_, int ldg_, int row0_,
-                                      int nrows_, int rows_total_ DTS_PARAM) {
-    extern __shared__ float sm[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fm = lane & 15, kq = lane >> 4;
-    DSTAMP(0);
-    // the arguments arrive in vector registers (by value: through a descriptor in memory every call started with a scratch
-    // round trip); they are workgroup-uniform, say so (scalar registers, scalar branches)
-#define SMX_U(x) __builtin_amdgcn_readfirstlane(x)
-    const int in_off = SMX_U(in_off_), ldi = SMX_U(ldi_), M = SMX_U(M_), K = SMX_U(K_), act = SMX_U(act_);
-    const int mask_off = SMX_U(mask_off_), ldm = SMX_U(ldm_), out_off = SMX_U(out_off_), ldo = SMX_U(ldo_);
-    const int ldg = SMX_U(ldg_), nrows = SMX_U(nrows_), rows_total = SMX_U(rows_total_);
-    const long row0 = (long)SMX_U(row0_);
-#undef SMX_U
-    const float* const Wp = Wp_;
-    const float* const bias = bias_;
-    float* const gout = g_;
-    const int tiles = (M + 15) >> 4, C2 = pack_chunks(K);
-    const rsrc_t rw = make_rsrc(Wp, (unsigned)tiles * (unsigned)C2 * 2048u);
-    const rsrc_t rb = make_rsrc(bias ? bias : Wp, bias ? (unsigned)M * 4u : 0u);
-    const rsrc_t rg = make_rsrc(gout ? gout : Wp, gout ? (unsigned)rows_total * (unsigned)ldg * 4u : 0u);
-    const float* in = sm + in_off;
-#pragma unroll 1
-    for (int tb = 0; tb < tiles; tb += DNWV * DTG) {
-        const int t0 = tb + wv;
-        int nt = (tiles - t0 + DNWV - 1) / DNWV;
-        nt = nt < 0 ? 0 : (nt > DTG ? DTG : nt);
-        float bs[DTG][4];
-#pragma unroll
-        for (int g = 0; g < DTG; ++g) {
-            const int f0 = 16 * (t0 + DNWV * g) + 4 * kq;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bs[g][r] = ld4(rb, (g < nt && f0 + r < M) ? (unsigned)(f0 + r) * 4u : OOB);
-        }
-        f32x4 acc[TG];
-#pragma unroll
-        for (int g = 0; g < TG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        DSTAMP(1);
-        if (nt > 2) fwd_tiles<3>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
-        else if (nt > 1) fwd_tiles<2>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
-        else if (nt > 0) fwd_tiles<1>(acc, rw, tiles, C2, in, ldi, t0, DNWV, lane);
-        DSTAMP(2);
-        // lane (fm, kq) holds features f0 .. f0 + 3 of data row fm
-#pragma unroll
-        for (int g = 0; g < DTG; ++g) {
-            if (g < nt) {                                            // wave-uniform
-                const int f0 = 16 * (t0 + DNWV * g) + 4 * kq;
-                float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (act == A_MASK) mk = *(const float4*)(sm + mask_off + fm * ldm + f0);
-                const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float z = acc[g][r] + bs[g][r];
-                    if (act == A_RELU) z = (z < 0.f) ? 0.f : z;
-                    else if (act == A_TANH) z = tanhf(z);
-                    else if (act == A_MASK) z = (mv[r] > 0.f) ? z : 0.f;
-                    v[r] = (f0 + r < M) ? z : 0.f;
-                }
-                if (out_off >= 0) *(float4*)(sm + out_off + fm * ldo + f0) = make_float4(v[0], v[1], v[2], v[3]);
-                const unsigned grow = (unsigned)(row0 + fm) * (unsigned)ldg * 4u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = fm < nrows && f0 + r < M;       // (no HBM output: every offset is out of range)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rg,
-                                                          ok ? grow + (unsigned)(f0 + r) * 4u : OOB, 0, 0);
-                }
-            }
-        }
-    }
-    DSTAMP(3);
-    SMX_LDS_BARRIER();
-    DSTAMP(4);
-}
-
 // Phase timestamps (cycle counter of thread 0 of every workgroup into a caller-supplied buffer, 128 slots per workgroup:
-// 0 .. 15 the launch's phases, 16 + 5 k .. the k-th dense layer's entry / K loop / epilogue / barrier) exist only in a build with -DSMX_DDPG_TIMING (scripts/bench_ddpg_rows.py); the product build has none.
+// 0 .. 15 the launch's phases, 16 + 5 k .. the k-th layer's entry / K loop / epilogue / barrier) exist only in a build with
+// -DSMX_DDPG_TIMING (scripts/bench_ddpg_rows.py); the product build has none.
 #ifdef SMX_DDPG_TIMING
 #define TSTAMP(i) do { if (G.tbuf && threadIdx.x == 0) G.tbuf[(size_t)blockIdx.x * 128 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#define DTS(k) (G.tbuf ? G.tbuf + (size_t)blockIdx.x * 128 + 16 + 5 * (k) : nullptr)
 #else
-#define DTS(k) nullptr
 #define TSTAMP(i) do { } while (0)
 #endif
-
-template <int RB>
-__device__ __forceinline__ void dense_rb(const Dense& L, long row0, int nrows, int rows_total, long long* ts) {
-    (void)ts;
-    static_assert(RB == 16, "4-row blocks run the layer program of ddpg_rows4_kernel");
-    dense16v(L.in_off, L.ldi, L.W.P, L.W.M, L.W.K, L.bias, L.act, L.mask_off, L.ldm, L.out_off, L.ldo, L.g, L.ldg, (int)row0,
-             nrows, rows_total DTS_ARG(ts));
-}
 
 struct RNet {                     // a network's biases (row-major parameter buffer) and packed weights
     const float *b1, *b2, *b3;
@@ -193,204 +82,21 @@ __device__ __forceinline__ void zero_lds(int total) {
     for (int i = threadIdx.x; i < (total >> 2); i += DNTH) *(float4*)(sm + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// rows row0 .. row0 + RB - 1 of a row-major [rows][D] matrix -> an LDS tile (zero past the batch)
-template <int RB>
+// rows row0 .. row0 + 3 of a row-major [rows][D] matrix -> an LDS tile (zero past the batch)
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld_src, int cols, long row0, int nrows,
                                            int off, int ld) {
     extern __shared__ float sm[];
-    for (int idx = threadIdx.x; idx < RB * cols; idx += DNTH) {
+    for (int idx = threadIdx.x; idx < RBLK * cols; idx += DNTH) {
         const int n = idx / cols, j = idx - n * cols;
         sm[off + n * ld + j] = (n < nrows) ? src[(size_t)(row0 + n) * ld_src + j] : 0.f;
     }
 }
 
-__device__ __forceinline__ Dense mk(int in_off, int ldi, const PMat& W, const float* bias, int act, int out_off, int ldo,
-                                    float* g, int ldg) {
-    Dense L;
-    L.in_off = in_off; L.ldi = ldi; L.W = W; L.bias = bias; L.act = act; L.mask_off = 0; L.ldm = 0;
-    L.out_off = out_off; L.ldo = ldo; L.g = g; L.ldg = ldg;
-    return L;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// critic phase (ddpg.py:264-308 and the forward half of 326-329)
-// ---------------------------------------------------------------------------------------------------------------
-template <int RB>
-__global__ __launch_bounds__(DNTH) void ddpg_critic_rows_kernel(RArgs G) {
-    extern __shared__ float sm[];
-    const int tid = threadIdx.x;
-    const long row0 = (long)blockIdx.x * RB;
-    int nrows = G.rows - (int)row0;
-    nrows = nrows > RB ? RB : nrows;
-    constexpr int LDKR = RB == 4 ? LDK4 : LDK;
-    const int A = G.A, c1 = G.c1, c2 = G.c2, ldc = c1 + A, R = G.rows;
-    TSTAMP(0);
-    zero_lds(G.total);
-    __syncthreads();
-    stage_rows<RB>(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
-    stage_rows<RB>(G.xn, G.D, G.D, row0, nrows, G.oXn, G.ldx);
-    // the loss inputs of the rows, requested here
-    float rew = 0.f, dn = 0.f;
-    if (tid < nrows) { rew = G.rewards[row0 + tid]; dn = G.dones[row0 + tid]; }
-    SMX_LDS_BARRIER();
-
-    // ---- mu'(s') ----
-    Dense L = mk(G.oXn, G.ldx, G.ta.W1, G.ta.b1, A_RELU, G.oA, G.ldA, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(0));
-    TSTAMP(1);
-    L = mk(G.oA, G.ldA, G.ta.W2, G.ta.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(1));
-    TSTAMP(2);
-    L = mk(G.oB, G.ldB, G.ta.W3, G.ta.b3, A_TANH, G.oO, LDO, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(2));
-    TSTAMP(3);
-    // ---- Q'(s', mu'(s')): layer 1 into the first c1 columns of the concat tile, the action behind them ----
-    L = mk(G.oXn, G.ldx, G.tc.W1, G.tc.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(3));
-    TSTAMP(4);
-    if (tid < RB * A) {
-        const int n = tid / A, j = tid - n * A;
-        sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
-    }
-    SMX_LDS_BARRIER();
-    L = mk(G.oC, G.ldC, G.tc.W2, G.tc.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(4));
-    TSTAMP(5);
-    L = mk(G.oB, G.ldB, G.tc.W3, G.tc.b3, A_NONE, G.oO2, LDO, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(5));
-    TSTAMP(6);
-    // ---- Q(s, a) ----
-    L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, G.xcat, ldc);
-    dense_rb<RB>(L, row0, nrows, R, DTS(6));
-    TSTAMP(7);
-    if (tid < RB * A) {
-        const int n = tid / A, j = tid - n * A;
-        const float v = (n < nrows) ? G.actions[(size_t)(row0 + n) * A + j] : 0.f;
-        sm[G.oC + n * G.ldC + c1 + j] = v;
-        if (n < nrows) G.xcat[(size_t)(row0 + n) * ldc + c1 + j] = v;
-    }
-    SMX_LDS_BARRIER();
-    L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, G.h2c, c2);
-    dense_rb<RB>(L, row0, nrows, R, DTS(7));
-    TSTAMP(8);
-    L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, G.oO, LDO, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(8));
-    TSTAMP(9);
-    // ---- y = r + gamma^n Q' (1 - done) (ddpg.py:279); dLoss/dQ of the mean squared error (ddpg.py:307-308) ----
-    if (tid < RB) {
-        const float qn = sm[G.oO2 + tid * LDO], q = sm[G.oO + tid * LDO];
-        const float t = (G.gamma_n * qn) * (1.0f - dn);
-        const float yy = rew + t;
-        const float d3 = (2.0f * (q - yy)) / (float)G.rows;
-        sm[G.oS + tid] = (tid < nrows) ? d3 : 0.f;
-        if (tid < nrows) {
-            G.q[row0 + tid] = q;
-            G.q_next[row0 + tid] = qn;
-            G.y[row0 + tid] = yy;
-            G.dz3[row0 + tid] = d3;
-        }
-    }
-    if (blockIdx.x == 0 && tid == 0 && G.step) *G.step += 1;      // this iteration's Adam step (both groups)
-    SMX_LDS_BARRIER();
-    // ---- dz2 = (dz3 W3) relu'(h2), a K = 1 product: elementwise ----
-    for (int idx = tid; idx < RB * c2; idx += DNTH) {
-        const int n = idx / c2, j = idx - n * c2;
-        float v = sm[G.oS + n] * G.cW3[j];
-        v = (sm[G.oB + n * G.ldB + j] > 0.f) ? v : 0.f;
-        sm[G.oA + n * G.ldA + j] = v;
-        if (n < nrows) G.dz2[(size_t)(row0 + n) * c2 + j] = v;
-    }
-    SMX_LDS_BARRIER();
-    // ---- dz1 = (W2[:, :c1]^T dz2) relu'(h1) ----
-    L = mk(G.oA, G.ldA, G.cW2Tlo, nullptr, A_MASK, -1, 0, G.dxcat, ldc);
-    L.mask_off = G.oC; L.ldm = G.ldC;
-    dense_rb<RB>(L, row0, nrows, R, DTS(9));
-    TSTAMP(10);
-    // ---- mu(s), kept for the actor phase ----
-    L = mk(G.oX, G.ldx, G.a.W1, G.a.b1, A_RELU, G.oA, G.ldA, G.h1a, G.H1);
-    dense_rb<RB>(L, row0, nrows, R, DTS(10));
-    TSTAMP(11);
-    L = mk(G.oA, G.ldA, G.a.W2, G.a.b2, A_RELU, G.oB, G.ldB, G.h2a, G.H2);
-    dense_rb<RB>(L, row0, nrows, R, DTS(11));
-    TSTAMP(12);
-    L = mk(G.oB, G.ldB, G.a.W3, G.a.b3, A_TANH, -1, 0, G.act, A);
-    dense_rb<RB>(L, row0, nrows, R, DTS(12));
-    TSTAMP(13);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// actor phase (ddpg.py:326-331): loss = -mean Q(s, mu(s)) through the updated critic
-// ---------------------------------------------------------------------------------------------------------------
-template <int RB>
-__global__ __launch_bounds__(DNTH) void ddpg_actor_rows_kernel(RArgs G) {
-    extern __shared__ float sm[];
-    const int tid = threadIdx.x;
-    const long row0 = (long)blockIdx.x * RB;
-    int nrows = G.rows - (int)row0;
-    nrows = nrows > RB ? RB : nrows;
-    constexpr int LDKR = RB == 4 ? LDK4 : LDK;
-    const int A = G.A, c1 = G.c1, c2 = G.c2, R = G.rows;
-    TSTAMP(0);
-    zero_lds(G.total);
-    __syncthreads();
-    stage_rows<RB>(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
-    stage_rows<RB>(G.act, A, A, row0, nrows, G.oO, LDO);
-    SMX_LDS_BARRIER();
-    Dense L = mk(G.oX, G.ldx, G.c.W1, G.c.b1, A_RELU, G.oC, G.ldC, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(0));
-    TSTAMP(1);
-    if (tid < RB * A) {
-        const int n = tid / A, j = tid - n * A;
-        sm[G.oC + n * G.ldC + c1 + j] = sm[G.oO + n * LDO + j];
-    }
-    SMX_LDS_BARRIER();
-    L = mk(G.oC, G.ldC, G.c.W2, G.c.b2, A_RELU, G.oB, G.ldB, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(1));
-    TSTAMP(2);
-    L = mk(G.oB, G.ldB, G.c.W3, G.c.b3, A_NONE, -1, 0, G.q_actor, 1);
-    dense_rb<RB>(L, row0, nrows, R, DTS(2));
-    TSTAMP(3);
-    // the masks of the actor's backward pass (its own forward pass ran in the critic phase): h1a -> the concat tile, whose
-    // layer-2 product is done; h2a follows once dz2 has read the critic's ReLU mask
-    stage_rows<RB>(G.h1a, G.H1, G.H1, row0, nrows, G.oC, G.ldC);
-    // ---- d(-mean Q)/d(h2) = (-1/rows) W3 relu'(h2) ----
-    const float dq = -1.0f / (float)G.rows;
-    for (int idx = tid; idx < RB * c2; idx += DNTH) {
-        const int n = idx / c2, j = idx - n * c2;
-        float v = dq * G.cW3[j];
-        v = (n < nrows && sm[G.oB + n * G.ldB + j] > 0.f) ? v : 0.f;
-        sm[G.oA + n * G.ldA + j] = v;
-    }
-    SMX_LDS_BARRIER();
-    stage_rows<RB>(G.h2a, G.H2, G.H2, row0, nrows, G.oB, G.ldB);
-    // ---- d/d(action) = W2[:, c1:]^T dz2, through tanh ----
-    L = mk(G.oA, G.ldA, G.cW2Thi, nullptr, A_NONE, G.oO2, LDO, nullptr, 0);
-    dense_rb<RB>(L, row0, nrows, R, DTS(3));
-    TSTAMP(4);
-    if (tid < RB * A) {
-        const int n = tid / A, j = tid - n * A;
-        const float a = sm[G.oO + n * LDO + j];
-        const float v = sm[G.oO2 + n * LDO + j] * (1.0f - a * a);
-        sm[G.oZ + n * LDKR + j] = v;
-        if (n < nrows) G.dz3a[(size_t)(row0 + n) * A + j] = v;
-    }
-    SMX_LDS_BARRIER();
-    // ---- the actor's data gradients ----
-    L = mk(G.oZ, LDKR, G.aW3T, nullptr, A_MASK, G.oA, G.ldA, G.dz2a, G.H2);
-    L.mask_off = G.oB; L.ldm = G.ldB;
-    dense_rb<RB>(L, row0, nrows, R, DTS(4));
-    TSTAMP(5);
-    L = mk(G.oA, G.ldA, G.aW2T, nullptr, A_MASK, -1, 0, G.dz1a, G.H1);
-    L.mask_off = G.oC; L.ldm = G.ldC;
-    dense_rb<RB>(L, row0, nrows, R, DTS(5));
-    TSTAMP(6);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 4-row blocks: the same two chains as a LAYER PROGRAM.  The 16-row kernels above call one noinline dense function a dozen
-// times; on 4-row blocks, where a layer's K loop is 2 - 9 k cycles, the calls were the larger half of the launch (phase
-// stamps: 3.3 k cycles per layer between return and the next entry -- callee-saved registers through scratch -- and 1.1 k
-// from entry to the first product).  Here the host writes the chain as a table of steps in the kernel arguments and the
+// The two chains as a LAYER PROGRAM.  With one noinline dense function called a dozen times (round 5's structure) the
+// calls were the larger half of a launch whose K loops are 2 - 9 k cycles (phase stamps: 3.3 k cycles per layer between
+// return and the next entry -- callee-saved registers through scratch -- and 1.1 k from entry to the first product).
+// Here the host writes the chain as a table of steps in the kernel arguments and the
 // kernel is ONE loop over it: the layer body exists once, inline, its operands arrive by scalar loads.  What sits between
 // two layers of a chain (the concat of the action, the Bellman target and dLoss/dQ, tanh') is the `post` of the step
 // before it.
@@ -423,7 +129,7 @@ struct Prog {
 template <int PHASE>
 __global__ __launch_bounds__(DNTH) void ddpg_rows4_kernel(RArgs G, Prog P) {
     extern __shared__ float sm[];
-    constexpr int RB = 4;
+    constexpr int RB = RBLK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fm = lane & 15, kq = lane >> 4;
@@ -434,13 +140,13 @@ __global__ __launch_bounds__(DNTH) void ddpg_rows4_kernel(RArgs G, Prog P) {
     TSTAMP(0);
     zero_lds(G.total);
     __syncthreads();
-    stage_rows<RB>(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
+    stage_rows(G.x, G.D, G.D, row0, nrows, G.oX, G.ldx);
     float rew = 0.f, dn = 0.f;
     if (PHASE == 0) {
-        stage_rows<RB>(G.xn, G.D, G.D, row0, nrows, G.oXn, G.ldx);
+        stage_rows(G.xn, G.D, G.D, row0, nrows, G.oXn, G.ldx);
         if (tid < nrows) { rew = G.rewards[row0 + tid]; dn = G.dones[row0 + tid]; }
     } else {
-        stage_rows<RB>(G.act, A, A, row0, nrows, G.oO, LDO);
+        stage_rows(G.act, A, A, row0, nrows, G.oO, LDO);
     }
     SMX_LDS_BARRIER();
 
@@ -601,7 +307,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_rows4_kernel(RArgs G, Prog P) {
             } else if (post == P_A_DQ) {
                 // the masks of the actor's backward pass (its forward pass ran in the critic phase): h1a -> the concat
                 // tile, whose layer-2 product is done; h2a follows once dz2 has read the critic's ReLU mask
-                stage_rows<RB>(G.h1a, G.H1, G.H1, row0, nrows, G.oC, G.ldC);
+                stage_rows(G.h1a, G.H1, G.H1, row0, nrows, G.oC, G.ldC);
                 const float dq = -1.0f / (float)G.rows;            // d(-mean Q)/d(h2) = (-1/rows) W3 relu'(h2)
                 for (int idx = tid; idx < RB * c2; idx += DNTH) {
                     const int n = idx / c2, j = idx - n * c2;
@@ -610,7 +316,7 @@ __global__ __launch_bounds__(DNTH) void ddpg_rows4_kernel(RArgs G, Prog P) {
                     sm[G.oA + n * G.ldA + j] = v;
                 }
                 SMX_LDS_BARRIER();
-                stage_rows<RB>(G.h2a, G.H2, G.H2, row0, nrows, G.oB, G.ldB);
+                stage_rows(G.h2a, G.H2, G.H2, row0, nrows, G.oB, G.ldB);
             } else if (post == P_A_TANH) {     // through tanh: the action gradient times 1 - a^2
                 if (tid < RB * A) {
                     const int n = tid / A, j = tid - n * A;
@@ -999,10 +705,9 @@ long block_base(const Dims& d, int b) {          // in 16-byte words
 
 long long* g_tbuf = nullptr;
 
-int rows_per_block(long rows) { return rows <= 1024 ? 4 : 16; }
-
-int lds_floats(const Dims& d, RArgs* G, int RB) {
-    const int pad = RB == 4 ? 16 : 4;
+int lds_floats(const Dims& d, RArgs* G) {
+    constexpr int RB = RBLK;
+    const int pad = 16;             // row strides = 16 mod 64: the 16 (row, kq) readers of the 4-row loop on distinct banks
     const int ldx = r64(d.D) + pad;
     const int wa = d.H1 > d.c2 ? d.H1 : d.c2, wb = d.H2 > d.c2 ? d.H2 : d.c2;
     const int wc = d.c1 + d.A > d.H1 ? d.c1 + d.A : d.H1;
@@ -1016,9 +721,9 @@ int lds_floats(const Dims& d, RArgs* G, int RB) {
     const int oO = o; o += RB * LDO;
     const int oO2 = o; o += RB * LDO;
     const int oO3 = o; o += RB * LDO;
-    const int oZ = o; o += RB * (RB == 4 ? LDK4 : LDK);
+    const int oZ = o; o += RB * LDK4;
     const int oS = o; o += 16;
-    const int oR = o; o += (RB == 4) ? DNWV * 2 * 4 * 16 : 0;      // the split-K layers' partial sums
+    const int oR = o; o += DNWV * 2 * 4 * 16;      // the split-K layers' partial sums
     o += 128;                     // the K loop's prefetch reads up to two chunks past a tile's last row
     if (G) {
         G->ldx = ldx; G->ldA = ldA; G->ldB = ldB; G->ldC = ldC;
@@ -1028,12 +733,11 @@ int lds_floats(const Dims& d, RArgs* G, int RB) {
     return o;
 }
 
-bool dims_ok(const Dims& d, int RB) {
+bool dims_ok(const Dims& d) {
     return d.D > 0 && d.A > 0 && d.A <= 32 && d.H1 > 0 && d.H2 > 0 && d.c1 > 0 && d.c2 > 0 && d.D <= 2048 &&
            d.H1 % 4 == 0 && d.H2 % 4 == 0 && d.c1 % 4 == 0 && d.c2 % 4 == 0 && d.H1 <= 1024 && d.H2 <= 1024 &&
-           d.c1 <= 1024 && d.c2 <= 1024 && lds_floats(d, nullptr, RB) * (int)sizeof(float) <= MAX_LDS;
+           d.c1 <= 1024 && d.c2 <= 1024 && lds_floats(d, nullptr) * (int)sizeof(float) <= MAX_LDS;
 }
-bool dims_ok(const Dims& d) { return dims_ok(d, 4); }        // (the packed layout does not depend on the block size)
 
 Dims dims_of(const smx_ddpg_rows_t& a) {
     Dims d;
@@ -1052,7 +756,7 @@ int fill(RArgs& G, const smx_ddpg_rows_t* a) {
     SMX_REQUIRE(a && a->packed, SMX_E_NULL);
     const Dims d = dims_of(*a);
     SMX_REQUIRE(a->rows > 0 && a->rows < (1 << 24), SMX_E_SHAPE);
-    SMX_REQUIRE(dims_ok(d, rows_per_block(a->rows)), SMX_E_UNSUPPORTED);
+    SMX_REQUIRE(dims_ok(d), SMX_E_UNSUPPORTED);
     {   // every row-major output is addressed through a buffer descriptor: 31-bit byte offsets
         int widest = d.c1 + d.A;
         widest = d.H1 > widest ? d.H1 : widest;
@@ -1083,7 +787,7 @@ int fill(RArgs& G, const smx_ddpg_rows_t* a) {
     G.dxcat = a->dxcat; G.h1a = a->h1a; G.h2a = a->h2a; G.act = a->act;
     G.q_actor = a->q_actor; G.dz3a = a->dz3a; G.dz2a = a->dz2a; G.dz1a = a->dz1a;
     G.step = a->step;
-    lds_floats(d, &G, rows_per_block(a->rows));
+    lds_floats(d, &G);
     G.tbuf = g_tbuf;
     return SMX_OK;
 }
@@ -1096,7 +800,7 @@ Step step(int in_off, int ldi, const PMat& W, const float* bias, int act, int ou
     return S;
 }
 
-// the chains of the two 16-row kernels above, step for step
+// the two chains, step for step
 void critic_program(const RArgs& G, Prog& P) {
     const int ldc = G.c1 + G.A;
     int n = 0;
@@ -1149,7 +853,7 @@ extern "C" int32_t smx_ddpg_rows_supported_at(int32_t D, int32_t A, int32_t H1, 
                                               int64_t rows) {
     Dims d;
     d.D = D; d.A = A; d.H1 = H1; d.H2 = H2; d.c1 = c1; d.c2 = c2;
-    return rows > 0 && rows < (1 << 24) && dims_ok(d, rows_per_block(rows)) ? 1 : 0;
+    return rows > 0 && rows < (1 << 24) && dims_ok(d) ? 1 : 0;
 }
 
 extern "C" int64_t smx_ddpg_rows_packed_floats(int32_t D, int32_t A, int32_t H1, int32_t H2, int32_t c1, int32_t c2) {
@@ -1196,23 +900,16 @@ extern "C" int smx_ddpg_rows_critic_f32(const smx_ddpg_rows_t* a, smx_stream_t s
     SMX_REQUIRE(a->xcat && a->h2c && a->q && a->q_next && a->y && a->dz3 && a->dz2 && a->dxcat && a->h1a && a->h2a &&
                     a->act, SMX_E_NULL);
     const int bytes = G.total * (int)sizeof(float);
-    static int set[2] = {0, 0};
-    const int RB = rows_per_block(G.rows), v = RB == 4 ? 0 : 1;
-    const void* fn = RB == 4 ? (const void*)ddpg_rows4_kernel<0> : (const void*)ddpg_critic_rows_kernel<16>;
-    if (set[v] < bytes) {
-        const int e = set_lds(fn, bytes);
+    static int set = 0;
+    if (set < bytes) {
+        const int e = set_lds((const void*)ddpg_rows4_kernel<0>, bytes);
         if (e) return e;
-        set[v] = bytes;
+        set = bytes;
     }
-    const dim3 grid((unsigned)((G.rows + RB - 1) / RB));
-    if (RB == 4) {
-        Prog P;
-        memset(&P, 0, sizeof(P));
-        critic_program(G, P);
-        hipLaunchKernelGGL(ddpg_rows4_kernel<0>, grid, dim3(DNTH), bytes, smx_s(stream), G, P);
-    } else {
-        hipLaunchKernelGGL(ddpg_critic_rows_kernel<16>, grid, dim3(DNTH), bytes, smx_s(stream), G);
-    }
+    Prog P;
+    memset(&P, 0, sizeof(P));
+    critic_program(G, P);
+    hipLaunchKernelGGL(ddpg_rows4_kernel<0>, dim3((unsigned)((G.rows + RBLK - 1) / RBLK)), dim3(DNTH), bytes, smx_s(stream), G, P);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }
@@ -1223,23 +920,16 @@ extern "C" int smx_ddpg_rows_actor_f32(const smx_ddpg_rows_t* a, smx_stream_t st
     if (rc) return rc;
     SMX_REQUIRE(a->x && a->h1a && a->h2a && a->act && a->q_actor && a->dz3a && a->dz2a && a->dz1a, SMX_E_NULL);
     const int bytes = G.total * (int)sizeof(float);
-    static int set[2] = {0, 0};
-    const int RB = rows_per_block(G.rows), v = RB == 4 ? 0 : 1;
-    const void* fn = RB == 4 ? (const void*)ddpg_rows4_kernel<1> : (const void*)ddpg_actor_rows_kernel<16>;
-    if (set[v] < bytes) {
-        const int e = set_lds(fn, bytes);
+    static int set = 0;
+    if (set < bytes) {
+        const int e = set_lds((const void*)ddpg_rows4_kernel<1>, bytes);
         if (e) return e;
-        set[v] = bytes;
+        set = bytes;
     }
-    const dim3 grid((unsigned)((G.rows + RB - 1) / RB));
-    if (RB == 4) {
-        Prog P;
-        memset(&P, 0, sizeof(P));
-        actor_program(G, P);
-        hipLaunchKernelGGL(ddpg_rows4_kernel<1>, grid, dim3(DNTH), bytes, smx_s(stream), G, P);
-    } else {
-        hipLaunchKernelGGL(ddpg_actor_rows_kernel<16>, grid, dim3(DNTH), bytes, smx_s(stream), G);
-    }
+    Prog P;
+    memset(&P, 0, sizeof(P));
+    actor_program(G, P);
+    hipLaunchKernelGGL(ddpg_rows4_kernel<1>, dim3((unsigned)((G.rows + RBLK - 1) / RBLK)), dim3(DNTH), bytes, smx_s(stream), G, P);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

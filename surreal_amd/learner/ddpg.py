@@ -110,7 +110,7 @@ class DDPGLearner(Learner):
         self.level_schedule = bool(self.session_config.learner.get('ddpg_level_schedule', True))
         # the iteration on row blocks (smx_ddpg_rows.hip): two chain launches instead of fifteen dense ones.  Unset: used
         # for batches of up to 1024 rows per rank -- 4-row workgroups, measured 0.134 against 0.190 ms per iteration at
-        # batch 512; past that the 16-row blocks were never faster than the level schedule.  True / False
+        # batch 512; past that more rounds of 4-row workgroups stream the weights again and the level schedule is used.  True / False
         # force it on (where the shapes allow) / off.
         rs = self.session_config.learner.get('ddpg_row_schedule', None)
         self.row_schedule = None if rs is None else bool(rs)
@@ -403,7 +403,7 @@ class DDPGLearner(Learner):
 
     def _enqueue_iteration_rows(self, ws, x, xn, actions, rewards, done):
         """One DDPG iteration (ddpg.py:244-352; low-dimensional observations, one critic) on ROW BLOCKS: a
-        workgroup carries 4 batch rows (16 past 1024 rows) through whole chains -- target actor -> target critic -> y, critic -> loss ->
+        workgroup carries 4 batch rows through whole chains -- target actor -> target critic -> y, critic -> loss ->
         its data gradients, and the actor's forward pass in one launch; Q(s, mu(s)) through the updated critic -> the
         actor's data gradients in a second (smx_ddpg_rows.hip).  Weight gradients (sums over all rows), Adam, the
         target update and the statistics are the launches of the other schedules, on the same buffers: 10 launches where

@@ -64,7 +64,7 @@ def test_row_schedule_agrees_with_the_level_schedule(name):
 def test_row_block_launches_fill_the_level_schedules_buffers(name, B):
     """one iteration, buffer by buffer: what the two row-block launches leave in the workspace (activations, Bellman
     targets, data gradients of both networks) and the weight gradients formed from it, against the level schedule's --
-    also with batches that are not multiples of the row block (4 rows up to 1024 rows, 16 past that: both kernels)"""
+    also with batches that are not multiples of the row block (4 rows; past 1024 rows -- where the learner would pick the level schedule by itself -- several rounds of workgroups)"""
     import copy
     import torch
     from surreal_amd import synthetic
