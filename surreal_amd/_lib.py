@@ -127,7 +127,7 @@ class DdpgUpdate(Structure):
     """smx_ddpg_update_t"""
     _fields_ = ([(n, c_void_p) for n in ('theta', 'grads', 'exp_avg', 'exp_avg_sq', 'target')] + [('n', c_int64)] +
                 [(n, c_void_p) for n in ('lr', 'step')] +
-                [(n, c_float) for n in ('weight_decay', 'clip_value', 'tau')] + [('interval', c_int32)])
+                [(n, c_float) for n in ('weight_decay', 'clip_value', 'tau')] + [('interval', c_int32), ('stats', c_void_p)])
 
 
 class DdpgRows(Structure):

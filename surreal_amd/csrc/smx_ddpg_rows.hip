@@ -30,6 +30,7 @@ namespace {
 #include "smx_epoch_pack.inc.h"
 #include "smx_epoch_mma.inc.h"
 #include "smx_rows4_mma.inc.h"
+#include "smx_ddpg_stats.inc.h"
 
 constexpr int DNWV = 8;           // wavefronts per workgroup: two per SIMD (one's loads hide under the other's MFMAs)
 constexpr int DNTH = 64 * DNWV;
@@ -488,6 +489,10 @@ struct WUArgs {
     UArgs U;
     WMat w[3];
     int rows;
+    // optional: the iteration's statistics as one more workgroup of this launch (the last one of the iteration)
+    float* stats;
+    const float *s_q, *s_y, *s_rewards, *s_actions, *s_q_actor;
+    int s_A, tiles;
     long long* tbuf;              // SMX_DDPG_TIMING builds
 };
 #ifdef SMX_DDPG_TIMING
@@ -532,13 +537,17 @@ __global__ __launch_bounds__(64 * WNW) void ddpg_rows_wgrad_update_kernel(WUArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
+    if ((int)blockIdx.x == G.tiles) {               // the workgroup behind the last tile: the statistics
+        ddpg_stats_block<64 * WNW>(G.s_q, G.s_y, G.s_rewards, G.s_actions, G.s_A, G.s_A, G.s_q_actor, (long)G.rows, G.stats);
+        return;
+    }
     WSTAMP(0);
     // consecutive workgroup ids land on the eight XCDs round-robin, each with its own L2: XCD x takes the x-th contiguous
     // eighth of the tile list (tiles are row-major in M: a band of dz columns and all of x) instead of every eighth tile,
     // or all eight L2s pull every operand across the fabric (as smx_gemm.hip's gemm32 does)
     int bid = blockIdx.x;
     {
-        const int total = gridDim.x, qd = total >> 3, rem = total & 7;
+        const int total = G.tiles, qd = total >> 3, rem = total & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         bid = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + slot;
     }
@@ -1032,7 +1041,14 @@ extern "C" int smx_ddpg_rows_wgrad_update_f32(const smx_ddpg_rows_t* a, int32_t 
         for (int j = 0; j < 3; ++j) covered += (long)G.U.mat[j].M * G.U.mat[j].K + G.U.mat[j].M;
         SMX_REQUIRE(covered == u->n, SMX_E_SHAPE);
     }
-    hipLaunchKernelGGL(ddpg_rows_wgrad_update_kernel, dim3((unsigned)tiles), dim3(64 * WNW), 0, smx_s(stream), G);
+    G.tiles = tiles;
+    if (u->stats) {
+        SMX_REQUIRE(a->q && a->y && a->rewards && a->actions && a->q_actor, SMX_E_NULL);
+        G.stats = u->stats; G.s_q = a->q; G.s_y = a->y; G.s_rewards = a->rewards; G.s_actions = a->actions;
+        G.s_q_actor = a->q_actor; G.s_A = d.A;
+    }
+    hipLaunchKernelGGL(ddpg_rows_wgrad_update_kernel, dim3((unsigned)(tiles + (u->stats ? 1 : 0))), dim3(64 * WNW), 0,
+                       smx_s(stream), G);
     SMX_LAUNCH_CHECK();
     return SMX_OK;
 }

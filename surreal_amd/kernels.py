@@ -786,7 +786,7 @@ class HipKernels(object):
         L.call('smx_ddpg_rows_actor_f32', ctypes.byref(args), self._st())
 
     def ddpg_rows_update(self, args, group, theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value,
-                         target=None, tau=0.0, interval=0, wgrad=False):
+                         target=None, tau=0.0, interval=0, wgrad=False, stats=None):
         """smx_ddpg_rows_update_f32 (wgrad: smx_ddpg_rows_wgrad_update_f32, which forms the gradients first): Adam on the group ('actor' | 'critic'), its target network's update (soft with tau,
         or hard every `interval` iterations of *step; target None: none) and the fragment-order copies of both"""
         u = L.DdpgUpdate()
@@ -796,6 +796,8 @@ class HipKernels(object):
         assert grads.numel() == u.n and exp_avg.numel() == u.n and exp_avg_sq.numel() == u.n
         assert target is None or target.numel() == u.n
         u.lr, u.step = lr.data_ptr(), step.data_ptr()
+        assert stats is None or wgrad
+        u.stats = None if stats is None else stats.data_ptr()
         u.weight_decay, u.clip_value, u.tau, u.interval = float(weight_decay or 0.0), float(clip_value or 0.0), float(tau), int(interval)
         L.call('smx_ddpg_rows_wgrad_update_f32' if wgrad else 'smx_ddpg_rows_update_f32', ctypes.byref(args),
                {'actor': 0, 'critic': 1}[group], ctypes.byref(u), self._st())

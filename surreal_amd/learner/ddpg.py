@@ -442,9 +442,10 @@ class DDPGLearner(Learner):
             self._average_over_ranks(ws.grads_a)
         K.ddpg_rows_update(args, 'actor', m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                            ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value,
-                           target=mt.actor_flat, wgrad=fuse, **tgt)
-        K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
-        self._average_over_ranks(ws.stats[:6])
+                           target=mt.actor_flat, wgrad=fuse, stats=ws.stats if fuse else None, **tgt)
+        if not fuse:                 # (fused: the statistics are one more workgroup of the actor's launch)
+            K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
+            self._average_over_ranks(ws.stats[:6])
         ws.rows_versions = self._rows_versions()
 
     def _rows_versions(self):
