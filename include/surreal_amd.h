@@ -890,6 +890,8 @@ typedef struct smx_ddpg_update {
     int32_t interval;
     float* stats;                      /* smx_ddpg_rows_wgrad_update_f32 only, may be NULL: [7] as smx_ddpg_stats_f32 writes them,
                                           from args' q, y, rewards, actions, q_actor -- one more workgroup of the launch */
+    float* stats_host;                 /* with stats, may be NULL: device-accessible HOST memory [2][8]; the same seven words also
+                                          go to slot (*step & 1) -- the caller reads them after the launch without a copy */
 } smx_ddpg_update_t;
 enum { SMX_DDPG_GROUP_ACTOR = 0, SMX_DDPG_GROUP_CRITIC = 1 };
 int smx_ddpg_rows_update_f32(const smx_ddpg_rows_t* args, int32_t group, const smx_ddpg_update_t* update,

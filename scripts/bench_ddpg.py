@@ -19,6 +19,14 @@ torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
 for i in range(n): st = L.learn(batches[i % 8])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print('DDPG learn (batch resident): %.3f ms/iter  %.3g samples/s  critic_loss %.4f' % (dt * 1e3, B / dt, st['critic_loss']))
+# how much of that is the HOST: the same loop's enqueue time alone (the clock stops before the device is waited for), and the
+# device's own time per iteration from events around the loop
+torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for i in range(n): st = L.learn(batches[i % 8])
+e1.record(); th = (time.perf_counter() - t0) / n
+torch.cuda.synchronize()
+print('   host enqueue time per learn(): %.3f ms; device time per iteration (events): %.3f ms' % (th * 1e3, e0.elapsed_time(e1) / n))
 # ---- with the uniform replay in the loop: 1e6 SSAR rows resident in HBM, sample 512 + learn ----
 from surreal_amd.replay import UniformReplay
 lc.replay.memory_size = 1000000

@@ -127,7 +127,7 @@ class DdpgUpdate(Structure):
     """smx_ddpg_update_t"""
     _fields_ = ([(n, c_void_p) for n in ('theta', 'grads', 'exp_avg', 'exp_avg_sq', 'target')] + [('n', c_int64)] +
                 [(n, c_void_p) for n in ('lr', 'step')] +
-                [(n, c_float) for n in ('weight_decay', 'clip_value', 'tau')] + [('interval', c_int32), ('stats', c_void_p)])
+                [(n, c_float) for n in ('weight_decay', 'clip_value', 'tau')] + [('interval', c_int32), ('stats', c_void_p), ('stats_host', c_void_p)])
 
 
 class DdpgRows(Structure):
@@ -384,8 +384,19 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = None
+
+
 def current_stream():
+    """the HIP stream torch's launches would go to now (torch.cuda.stream() contexts included).  Through the raw-handle
+    call: torch.cuda.current_stream() builds a Stream object through four layers of device-index look-ups, 9 us per launch
+    -- a tenth of a DDPG iteration"""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', False)
+    if _raw_stream:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

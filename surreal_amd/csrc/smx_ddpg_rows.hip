@@ -491,6 +491,7 @@ struct WUArgs {
     int rows;
     // optional: the iteration's statistics as one more workgroup of this launch (the last one of the iteration)
     float* stats;
+    float* stats_host;            // host-mapped mirror, two slots of 8 floats: slot *step & 1
     const float *s_q, *s_y, *s_rewards, *s_actions, *s_q_actor;
     int s_A, tiles;
     long long* tbuf;              // SMX_DDPG_TIMING builds
@@ -538,7 +539,9 @@ __global__ __launch_bounds__(64 * WNW) void ddpg_rows_wgrad_update_kernel(WUArgs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     if ((int)blockIdx.x == G.tiles) {               // the workgroup behind the last tile: the statistics
-        ddpg_stats_block<64 * WNW>(G.s_q, G.s_y, G.s_rewards, G.s_actions, G.s_A, G.s_A, G.s_q_actor, (long)G.rows, G.stats);
+        float* mirror = G.stats_host ? G.stats_host + 8 * (*G.U.step & 1) : nullptr;
+        ddpg_stats_block<64 * WNW>(G.s_q, G.s_y, G.s_rewards, G.s_actions, G.s_A, G.s_A, G.s_q_actor, (long)G.rows, G.stats,
+                                   mirror);
         return;
     }
     WSTAMP(0);
@@ -1046,6 +1049,7 @@ extern "C" int smx_ddpg_rows_wgrad_update_f32(const smx_ddpg_rows_t* a, int32_t 
         SMX_REQUIRE(a->q && a->y && a->rewards && a->actions && a->q_actor, SMX_E_NULL);
         G.stats = u->stats; G.s_q = a->q; G.s_y = a->y; G.s_rewards = a->rewards; G.s_actions = a->actions;
         G.s_q_actor = a->q_actor; G.s_A = d.A;
+        G.stats_host = u->stats_host;
     }
     hipLaunchKernelGGL(ddpg_rows_wgrad_update_kernel, dim3((unsigned)(tiles + (u->stats ? 1 : 0))), dim3(64 * WNW), 0,
                        smx_s(stream), G);

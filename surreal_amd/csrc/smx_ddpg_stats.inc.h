@@ -5,13 +5,14 @@
 //   (per thread over its rows, over the wavefront, over the wavefronts in order -- the thread count only moves additions
 //   between those three levels: differences at double rounding, far below the float the mean is stored as);
 //   stats[6] = max |action| (the reference asserts |a| <= 1 with two host syncs, ddpg.py:262-263); NaN if any action is.
+//   mirror: a second destination for the same seven words (host-mapped memory: the learner reads them without a copy launch).
 #pragma once
 
 template <int NT>
 __device__ __forceinline__ void ddpg_stats_block(const float* __restrict__ q, const float* __restrict__ y,
                                                  const float* __restrict__ rewards, const float* __restrict__ actions,
                                                  int ld_act, int A, const float* __restrict__ q_actor, long rows,
-                                                 float* __restrict__ stats) {
+                                                 float* __restrict__ stats, float* __restrict__ mirror = nullptr) {
     constexpr int NW = NT / 64;
     __shared__ double red[NW];
     __shared__ float mx[NW];
@@ -45,6 +46,7 @@ __device__ __forceinline__ void ddpg_stats_block(const float* __restrict__ q, co
             double t = 0.0;
             for (int i = 0; i < NW; ++i) t += red[i];
             stats[k] = (float)(t / (double)rows);
+            if (mirror) mirror[k] = stats[k];
         }
     }
     // (round 5: a wavefront-level reduction -- thread 0 walking 1024 LDS words took 18 of the launch's 22 us)
@@ -62,5 +64,6 @@ __device__ __forceinline__ void ddpg_stats_block(const float* __restrict__ q, co
         int b = 0;
         for (int i = 0; i < NW; ++i) { t = fmaxf(t, mx[i]); b |= nanw[i]; }
         stats[6] = b ? NAN : t;
+        if (mirror) mirror[6] = stats[6];
     }
 }

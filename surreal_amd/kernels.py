@@ -786,7 +786,7 @@ class HipKernels(object):
         L.call('smx_ddpg_rows_actor_f32', ctypes.byref(args), self._st())
 
     def ddpg_rows_update(self, args, group, theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value,
-                         target=None, tau=0.0, interval=0, wgrad=False, stats=None):
+                         target=None, tau=0.0, interval=0, wgrad=False, stats=None, stats_host=None):
         """smx_ddpg_rows_update_f32 (wgrad: smx_ddpg_rows_wgrad_update_f32, which forms the gradients first): Adam on the group ('actor' | 'critic'), its target network's update (soft with tau,
         or hard every `interval` iterations of *step; target None: none) and the fragment-order copies of both"""
         u = L.DdpgUpdate()
@@ -798,6 +798,8 @@ class HipKernels(object):
         u.lr, u.step = lr.data_ptr(), step.data_ptr()
         assert stats is None or wgrad
         u.stats = None if stats is None else stats.data_ptr()
+        assert stats_host is None or (stats is not None and stats_host.is_pinned() and stats_host.numel() >= 16)
+        u.stats_host = None if stats_host is None else stats_host.data_ptr()
         u.weight_decay, u.clip_value, u.tau, u.interval = float(weight_decay or 0.0), float(clip_value or 0.0), float(tau), int(interval)
         L.call('smx_ddpg_rows_wgrad_update_f32' if wgrad else 'smx_ddpg_rows_update_f32', ctypes.byref(args),
                {'actor': 0, 'critic': 1}[group], ctypes.byref(u), self._st())

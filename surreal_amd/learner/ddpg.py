@@ -388,6 +388,8 @@ class DDPGLearner(Learner):
         dims = self._rows_dims(x.shape[1], x.shape[0])
         ws.rows_packed = torch.zeros(K.ddpg_rows_packed_floats(*dims), device=self.device)
         ws.rows_versions = None          # nothing packed yet
+        if getattr(ws, 'stats_slots', None) is None:
+            ws.stats_slots = torch.zeros(2, 8, pin_memory=torch.cuda.is_available())
         if not hasattr(ws, 'ga'):
             ws.ga, o = {}, 0
             for name, v in m.actor.views.items():
@@ -442,7 +444,9 @@ class DDPGLearner(Learner):
             self._average_over_ranks(ws.grads_a)
         K.ddpg_rows_update(args, 'actor', m.actor_flat, ws.grads_a, self.actor_exp_avg, self.actor_exp_avg_sq,
                            ws.lr[0:1], ws.step, self.actor_regularization, self.actor_gradient_clip_value,
-                           target=mt.actor_flat, wgrad=fuse, stats=ws.stats if fuse else None, **tgt)
+                           target=mt.actor_flat, wgrad=fuse, stats=ws.stats if fuse else None,
+                           stats_host=ws.stats_slots if fuse and self.lazy_stats else None, **tgt)
+        ws.stats_zero_copy = bool(fuse and self.lazy_stats)
         if not fuse:                 # (fused: the statistics are one more workgroup of the actor's launch)
             K.ddpg_stats(ws.q, ws.y, rewards, actions, ws.q_actor, ws.stats)
             self._average_over_ranks(ws.stats[:6])
@@ -791,29 +795,42 @@ class DDPGLearner(Learner):
         self._flush_stats()
         if getattr(ws, 'stats_host', None) is None:
             ws.stats_host = torch.empty(3, 8, pin_memory=True)
-        ws.stats_host[0].copy_(ws.stats, non_blocking=True)
+        if getattr(ws, 'stats_zero_copy', False):
+            # the row schedule's last launch wrote the statistics into host-mapped memory itself (slot = the iteration's
+            # Adam step & 1: the slot of the iteration before is still being read): no copy launch
+            host0 = ws.stats_slots[self.critic_step & 1]
+        else:
+            ws.stats_host[0].copy_(ws.stats, non_blocking=True)
+            host0 = ws.stats_host[0]
         if ws.xerr is not None and self.world_size > 1:      # a peer exchange that timed out in this iteration
             ws.stats_host[2, :1].view(torch.int32).copy_(ws.xerr, non_blocking=True)
         else:
             ws.stats_host[2].zero_()
         if self.use_double_critic:
             ws.stats_host[1].copy_(ws.stats2, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # (two events in turn, recorded on a Stream object cached per raw handle: Event() + record() through
+        # torch.cuda.current_stream() were 15 us of host time per iteration)
+        raw = L.current_stream().value
+        if getattr(ws, 'ev_raw', -1) != raw:
+            ws.ev_raw, ws.ev_stream = raw, torch.cuda.current_stream()
+            ws.ev_pair, ws.ev_turn = (torch.cuda.Event(), torch.cuda.Event()), 0
+        ev = ws.ev_pair[ws.ev_turn]
+        ws.ev_turn ^= 1
+        ev.record(ws.ev_stream)
         handle = DeferredStats(self._flush_stats)
-        self._pending_stats = (ev, ws.stats_host, handle)
+        self._pending_stats = (ev, ws.stats_host, handle, host0)
         return handle
 
     def _flush_stats(self):
         pend, self._pending_stats = self._pending_stats, None
         if pend is not None:
-            ev, host, handle = pend
+            ev, host, handle, host0 = pend
             ev.synchronize()
             if int(host[2, :1].view(torch.int32)[0]) != 0:
                 raise RuntimeError('a peer exchange timed out in the last DDPG iteration: error word 0x%x (0x100 | phase << 4 '
                                    '| peer) -- a rank died or fell behind by more than the timeout'
                                    % (int(host[2, :1].view(torch.int32)[0]) & 0xffff))
-            handle._value = self._decode_stats(host[0], host[1] if self.use_double_critic else None)
+            handle._value = self._decode_stats(host0, host[1] if self.use_double_critic else None)
 
     def _decode_stats(self, st, st2):
         st = st.numpy()

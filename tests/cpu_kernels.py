@@ -987,7 +987,7 @@ class TorchCpuKernels(object):
             args.snap[name] = {k: v.clone() for k, v in args.nets[name].items()}
 
     def ddpg_rows_update(self, args, group, theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value,
-                         target=None, tau=0.0, interval=0, wgrad=False, stats=None):
+                         target=None, tau=0.0, interval=0, wgrad=False, stats=None, stats_host=None):
         """Adam + the group's target update + BOTH snapshots (the kernel keeps the packed copies of the group and of its
         target current; nothing else is refreshed -- a schedule that relied on more would fail the goldens here).
         wgrad: the group's weight gradients first, from the buffers the chain launches wrote, into `grads` (laid out like
@@ -1011,6 +1011,8 @@ class TorchCpuKernels(object):
         if stats is not None:       # (independent of the step: read from the chain launches' buffers)
             io = args.io
             self.ddpg_stats(io['q'], io['y'], io['rewards'], io['actions'], io['q_actor'], stats)
+            if stats_host is not None:
+                stats_host.view(2, 8)[int(step[0]) & 1, :7].copy_(stats[:7])
         self.adam_step_dev(theta, grads, exp_avg, exp_avg_sq, lr, step, weight_decay, clip_value)
         if target is not None:
             if interval > 0:
