@@ -203,7 +203,7 @@ __global__ __launch_bounds__(RNTH) void rollout_kernel(RollArgs G) {
                 for (int g = 0; g < NT; ++g)
 #pragma unroll
                     for (int r = 0; r < RG; ++r) acc[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                fwd_tiles4<NT, RG>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
+                fwd_tiles4<NT, RG, true>(acc, rw, tiles, C2, in_lds, ldi, t0, RNWV, lane);
                 // the kq groups meet; lane (fm, kq) then keeps row kq of every group: bias, activation, one word to LDS
 #pragma unroll
                 for (int g = 0; g < NT; ++g) {

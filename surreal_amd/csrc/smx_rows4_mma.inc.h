@@ -57,7 +57,7 @@ __device__ __forceinline__ void mma4_chunk(f32x4 (&acc)[NT][RG], const WFrag4<NT
 // tiles t0, t0 + tstep, ... (NT of them; tiles >= `tiles` are out-of-range operands) over the C2 (even) K chunks; the data
 // rows at in_lds[row * ldi + k].  Four register stages as in fwd_tiles (smx_epoch_mma.inc.h); loads past the last chunk are
 // past the buffer (zeros) on the weight side and read LDS words that exist (the caller's tiles are padded to C2 chunks + 2).
-template <int NT, int RG>
+template <int NT, int RG, bool SHALLOW = false>
 __device__ __forceinline__ void fwd_tiles4(f32x4 (&acc)[NT][RG], rsrc_t rw, int tiles, int C2, const float* in_lds,
                                            int ldi, int t0, int tstep, int lane) {
     unsigned wo[NT];
@@ -68,6 +68,26 @@ __device__ __forceinline__ void fwd_tiles4(f32x4 (&acc)[NT][RG], rsrc_t rw, int 
     }
     const float* bp = in_lds + (lane & 3) * ldi + 8 * (lane >> 4);
     auto cl = [&](int c) { return c < C2 ? c : C2 - 1; };      // (the LDS side of a prefetch past the end: a valid chunk)
+    // SHALLOW: ONE chunk in flight behind the one being multiplied (two register stages) instead of two (four).  Which is
+    // faster depends on how many workgroups share the L2s: with all 256 CUs streaming (the rollout kernel) the shallow queue
+    // wins by 3 % (1.59 -> 1.55 ms at 1024 actors; THREE in flight: 1.63), with 128 (the DDPG chains) the deeper one by 5 %.
+    if (SHALLOW) {
+        WFrag4<NT, RG> P0, P1;
+        ld_wfrag4<NT, RG>(P0, rw, wo, bp, ldi, 0);
+        int c = 0;
+#pragma unroll 1
+        for (; c + 2 <= C2; c += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            ld_wfrag4<NT, RG>(P1, rw, wo, bp, ldi, c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4_chunk<NT, RG>(acc, P0);
+            __builtin_amdgcn_sched_barrier(0);
+            ld_wfrag4<NT, RG>(P0, rw, wo, bp, ldi, cl(c + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            mma4_chunk<NT, RG>(acc, P1);
+        }
+        return;
+    }
     WFrag4<NT, RG> P0, P1, Q0, Q1;
     ld_wfrag4<NT, RG>(P0, rw, wo, bp, ldi, 0);
     __builtin_amdgcn_sched_barrier(0);
